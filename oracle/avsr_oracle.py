@@ -1,0 +1,731 @@
+"""CPU oracle for the AVSR seq2seq hot path -- TEST INFRASTRUCTURE ONLY.
+
+**Parity unpinned.**  This file is a CPU restatement (torch-CPU tensors, autograd for
+BPTT) of the TensorFlow-1.13.1 semantics that the reference's hot path selects.  The
+reference (georgesterpu/avsr-tf1) is pure Python driving `tensorflow==1.13.1`; it cannot
+be imported here (no TensorFlow), has no tests and no golden vectors (SURVEY.md section 0,
+F1-F3).  The *wiring* below follows the reference files line by line (cited per
+function); the *arithmetic* follows the published TF r1.13 algorithms
+(`rnn_cell_impl.LSTMCell/GRUCell`, `rnn.dynamic_rnn`,
+`contrib.seq2seq.{LuongAttention,BahdanauAttention,AttentionWrapper,BasicDecoder,
+GreedyEmbeddingHelper,TrainingHelper,dynamic_decode,sequence_loss}`, `layers.batch_normalization`,
+`train.AdamOptimizer`, `clip_by_global_norm`) as summarised in SURVEY.md Appendix A.
+Nothing here has been checked against a running TensorFlow.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import
+this module.  The product (`avsr_tf1_amd`) never does.
+
+Weight naming / layout ("TF layout"): every kernel is `[in, out]` exactly as TF stores it
+(`LSTMCell.kernel [in+H, 4H]`, gate blocks ordered i, j, f, o).  The HIP engine uses a
+different internal layout; `avsr_tf1_amd.params` converts.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+Tensor = torch.Tensor
+
+LUONG_TYPES = ("luong", "scaled_luong")
+BAHDANAU_TYPES = ("bahdanau", "normed_bahdanau")
+
+
+# ----------------------------------------------------------------------------------------
+# configuration (mirrors the hparams the hot path reads: avsr/avsr.py:150-198)
+# ----------------------------------------------------------------------------------------
+@dataclass
+class OracleConfig:
+    architecture: str = "unimodal"            # unimodal | bimodal | av_align   (seq2seq.py:47,55,96,114)
+    encoder_type: str = "unidirectional"      # unidirectional | bidirectional (encoder.py:67,90)
+    cell_type: str = "lstm"                   # lstm | gru                       (cells.py:13,24)
+    video_units: Optional[Tuple[int, ...]] = None   # encoder_units_per_layer[0]; None = no video stream
+    audio_units: Optional[Tuple[int, ...]] = (256, 256, 256)  # encoder_units_per_layer[1]
+    decoder_units: Tuple[int, ...] = (256,)
+    attention_type: Tuple[Tuple[str, ...], Tuple[str, ...]] = (("scaled_luong",), ("scaled_luong",))
+    enable_attention: bool = True
+    embedding_size: int = 128
+    vocab_size: int = 31                      # len(unit_dict) - 1 (decoder_unimodal.py:49)
+    go_id: int = 30
+    eos_id: int = 29
+    video_feat: int = 128
+    audio_feat: int = 80
+    batch_normalisation: bool = True          # avsr.py:36
+    regress_aus: bool = False                 # encoder.py:34, :173
+    au_loss_weight: float = 10.0              # seq2seq.py:189
+    recurrent_l2: Optional[float] = 1e-4      # avsr.py:44
+    clip_gradients: bool = True
+    max_gradient_norm: float = 1.0
+    learning_rate: float = 1e-3
+    warmup_steps: int = 750                   # seq2seq.py:275
+    max_label_length: int = 150               # avsr.py:157
+    # stochastic train-time features (off for parity fixtures; SURVEY section 7 "hard parts")
+    use_dropout: bool = False
+    video_dropout: Tuple[float, float, float] = (0.9, 0.9, 0.9)   # keep probs (in, state, out)
+    audio_dropout: Tuple[float, float, float] = (0.9, 0.9, 0.9)
+    decoder_dropout: Tuple[float, float, float] = (0.9, 0.9, 0.9)
+    sampling_probability: float = 0.0
+
+    def streams(self) -> List[str]:
+        s = []
+        if self.video_units is not None:
+            s.append("video")
+        if self.audio_units is not None:
+            s.append("audio")
+        return s
+
+    def directions(self) -> List[str]:
+        return ["fw", "bw"] if self.encoder_type == "bidirectional" else ["fw"]
+
+    def memory_depth(self, stream: str) -> int:
+        units = self.video_units if stream == "video" else self.audio_units
+        mult = 2 if self.encoder_type == "bidirectional" else 1
+        return units[-1] * mult
+
+    def decoder_memories(self) -> List[Tuple[str, str]]:
+        """[(stream, attention_type)] in AttentionWrapper order.
+
+        bimodal: video mechanisms first, then audio (decoder_bimodal.py:184-223).
+        unimodal / av_align: audio if present else video, types = attention_type[1]
+        (seq2seq.py:96-112, decoder_unimodal.py:322)."""
+        if not self.enable_attention:
+            return []
+        if self.architecture == "bimodal":
+            out = []
+            if self.video_units is not None:
+                out += [("video", t) for t in self.attention_type[0]]
+            if self.audio_units is not None:
+                out += [("audio", t) for t in self.attention_type[1]]
+            return out
+        stream = "audio" if self.audio_units is not None else "video"
+        return [(stream, t) for t in self.attention_type[1]]
+
+    def output_attention(self) -> bool:
+        """output_attention flag = that of the LAST mechanism created
+        (attention.py:108-117; decoder_bimodal.py:396-441 side effect)."""
+        mems = self.decoder_memories()
+        if not mems:
+            return False
+        return mems[-1][1] in LUONG_TYPES
+
+    def validate(self):
+        if self.architecture not in ("unimodal", "bimodal", "av_align"):
+            raise Exception("Unknown architecture")                       # seq2seq.py:66
+        if self.encoder_type not in ("unidirectional", "bidirectional"):
+            raise Exception("Allowed encoder types: `unidirectional`, `bidirectional`")  # encoder.py:146
+        if self.cell_type not in ("lstm", "gru"):
+            raise Exception("cell type not supported: {}".format(self.cell_type))  # cells.py:44
+        for types in self.attention_type:
+            for t in types:
+                if t not in LUONG_TYPES + BAHDANAU_TYPES:
+                    raise Exception("unknown attention mechanism")        # attention.py:86
+        if self.architecture == "bimodal" and self.cell_type != "lstm":
+            raise ValueError("bimodal decoder requires LSTM state tuples")  # decoder_bimodal.py:130-142
+        if self.architecture == "av_align":
+            if self.encoder_type != "unidirectional":
+                raise ValueError("AttentiveEncoder implements only unidirectional")  # encoder.py:229
+            if self.video_units is None or self.audio_units is None:
+                raise ValueError("av_align needs both streams")
+        if len(self.decoder_units) != 1:
+            raise NotImplementedError("multi-layer decoders are out of scope this round")
+
+
+# ----------------------------------------------------------------------------------------
+# initialisers
+# ----------------------------------------------------------------------------------------
+def _variance_scaling(rng: np.random.Generator, shape) -> np.ndarray:
+    """tf.variance_scaling_initializer(): scale 1, fan_in, truncated normal (cells.py:17)."""
+    fan_in = shape[0] if len(shape) > 1 else shape[0]
+    std = math.sqrt(1.0 / max(1.0, fan_in)) / 0.87962566103423978
+    x = rng.standard_normal(size=shape)
+    bad = np.abs(x) > 2.0
+    while bad.any():
+        x[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(x) > 2.0
+    return (x * std).astype(np.float32)
+
+
+def _glorot_uniform(rng: np.random.Generator, shape) -> np.ndarray:
+    fan_in, fan_out = (shape[0], shape[1]) if len(shape) == 2 else (shape[0], shape[0])
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def _cell_params(rng, cfg: OracleConfig, prefix: str, in_dim: int, units: int, P: Dict[str, np.ndarray]):
+    if cfg.cell_type == "lstm":
+        P[prefix + "/kernel"] = _variance_scaling(rng, (in_dim + units, 4 * units))
+        P[prefix + "/bias"] = np.zeros((4 * units,), np.float32)
+    else:  # gru: kernel AND bias use variance scaling (cells.py:26-27)
+        P[prefix + "/gates_kernel"] = _variance_scaling(rng, (in_dim + units, 2 * units))
+        P[prefix + "/gates_bias"] = _variance_scaling(rng, (2 * units,))
+        P[prefix + "/cand_kernel"] = _variance_scaling(rng, (in_dim + units, units))
+        P[prefix + "/cand_bias"] = _variance_scaling(rng, (units,))
+
+
+def _attention_params(rng, prefix: str, att_type: str, depth: int, units: int, P):
+    P[prefix + "/memory_kernel"] = _glorot_uniform(rng, (depth, units))       # memory_layer, no bias
+    if att_type == "scaled_luong":
+        P[prefix + "/g"] = np.ones((1,), np.float32)                          # attention_g init 1.0
+    if att_type in BAHDANAU_TYPES:
+        P[prefix + "/query_kernel"] = _glorot_uniform(rng, (units, units))    # query_layer, no bias
+        P[prefix + "/v"] = _glorot_uniform(rng, (units, 1)).reshape(units)    # attention_v
+        if att_type == "normed_bahdanau":
+            P[prefix + "/g"] = np.full((1,), math.sqrt(1.0 / units), np.float32)
+            P[prefix + "/b"] = np.zeros((units,), np.float32)
+    P[prefix + "/layer_kernel"] = _glorot_uniform(rng, (units + depth, units))  # attention_layer, no bias
+
+
+def init_params(cfg: OracleConfig, seed: int = 2001) -> Dict[str, np.ndarray]:
+    """All trainable variables + BN moving stats, TF layout, reference initialisers."""
+    cfg.validate()
+    rng = np.random.default_rng(seed)
+    P: Dict[str, np.ndarray] = {}
+    dec_units = cfg.decoder_units[0]
+    for stream in cfg.streams():
+        feat = cfg.video_feat if stream == "video" else cfg.audio_feat
+        units = cfg.video_units if stream == "video" else cfg.audio_units
+        if cfg.batch_normalisation:
+            P[f"{stream}/bn/gamma"] = np.ones((feat,), np.float32)
+            P[f"{stream}/bn/beta"] = np.zeros((feat,), np.float32)
+            P[f"{stream}/bn/moving_mean"] = np.zeros((feat,), np.float32)
+            P[f"{stream}/bn/moving_variance"] = np.ones((feat,), np.float32)
+        attentive = cfg.architecture == "av_align" and stream == "audio"
+        for d in cfg.directions():
+            in_dim = feat
+            for l, u in enumerate(units):
+                extra = units[-1] if (attentive and l == len(units) - 1) else 0   # + attention feedback
+                _cell_params(rng, cfg, f"{stream}/enc/{d}/l{l}", in_dim + extra, u, P)
+                in_dim = u
+        if attentive:
+            _attention_params(rng, "audio/enc/att0", cfg.attention_type[0][0],
+                              cfg.memory_depth("video"), units[-1], P)
+        if cfg.encoder_type == "bidirectional":
+            # final-state projection of the LAST layer (encoder.py:124-141); lower layers'
+            # projections exist in the reference graph but never reach a 1-layer decoder.
+            if cfg.cell_type == "lstm":
+                P[f"{stream}/enc/proj_c"] = _glorot_uniform(rng, (2 * units[-1], dec_units))
+                P[f"{stream}/enc/proj_h"] = _glorot_uniform(rng, (2 * units[-1], dec_units))
+            else:
+                P[f"{stream}/enc/proj"] = _glorot_uniform(rng, (2 * units[-1], dec_units))
+        if stream == "video" and cfg.regress_aus:
+            P["video/au/kernel"] = _glorot_uniform(rng, (cfg.memory_depth("video"), 2))
+            P["video/au/bias"] = np.zeros((2,), np.float32)
+    # decoder
+    V, E = cfg.vocab_size, cfg.embedding_size
+    lim = 1.732 / V
+    P["dec/embedding"] = rng.uniform(-lim, lim, size=(V, E)).astype(np.float32)
+    mems = cfg.decoder_memories()
+    att_total = dec_units * len(mems)
+    _cell_params(rng, cfg, "dec/l0", E + att_total, dec_units, P)
+    for i, (stream, t) in enumerate(mems):
+        _attention_params(rng, f"dec/att{i}", t, cfg.memory_depth(stream), dec_units, P)
+    out_dim = att_total if cfg.output_attention() else dec_units
+    P["dec/out/kernel"] = _glorot_uniform(rng, (out_dim, V))
+    P["dec/out/bias"] = np.zeros((V,), np.float32)
+    if cfg.architecture == "bimodal":
+        P["dec/state_proj"] = _glorot_uniform(rng, (2 * dec_units, dec_units))  # decoder_bimodal.py:482
+    return P
+
+
+NON_TRAINABLE = ("moving_mean", "moving_variance")
+
+
+def trainable_names(P: Dict[str, np.ndarray]) -> List[str]:
+    return [k for k in P if not k.endswith(NON_TRAINABLE)]
+
+
+def l2_names(P, cfg: OracleConfig) -> List[str]:
+    """seq2seq.py:283-290: trainable vars whose name contains 'lstm_'/'gru_' and not 'bias'.
+    In TF those are exactly the RNN cell kernels (encoders and decoder)."""
+    out = []
+    for k in trainable_names(P):
+        if "bias" in k:
+            continue
+        if k.endswith("/kernel") and ("/enc/fw/" in k or "/enc/bw/" in k or k.startswith("dec/l")):
+            out.append(k)
+        if k.endswith(("/gates_kernel", "/cand_kernel")):
+            out.append(k)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# batches (io_utils.BatchedData: io_utils.py:8-18)
+# ----------------------------------------------------------------------------------------
+@dataclass
+class Batch:
+    audio: Optional[np.ndarray] = None          # [B, T_a, F_a] float32
+    audio_len: Optional[np.ndarray] = None      # [B] int32
+    video: Optional[np.ndarray] = None          # [B, T_v, F_v]
+    video_len: Optional[np.ndarray] = None
+    aus: Optional[np.ndarray] = None            # [B, T_v, 2]
+    labels: Optional[np.ndarray] = None         # [B, L] int32, EOS appended, 0 padded
+    labels_len: Optional[np.ndarray] = None     # [B] int32 (includes EOS)
+
+
+def synthetic_batch(cfg: OracleConfig, B: int, T_a: int = 500, T_v: int = 75, L: int = 40,
+                    ragged: bool = False, seed: int = 1000) -> Batch:
+    """SURVEY section 8(d) synthetic inputs (fixed seeds)."""
+    b = Batch()
+    r = lambda k: np.random.default_rng(seed + k)
+    if cfg.audio_units is not None:
+        b.audio = r(1).standard_normal((B, T_a, cfg.audio_feat)).astype(np.float32)
+        b.audio_len = (r(2).integers(T_a // 2, T_a + 1, size=B) if ragged else np.full(B, T_a)).astype(np.int32)
+        b.audio *= (np.arange(T_a)[None, :, None] < b.audio_len[:, None, None])   # padded_batch zero pads
+    if cfg.video_units is not None:
+        b.video = r(3).standard_normal((B, T_v, cfg.video_feat)).astype(np.float32)
+        b.video_len = (r(4).integers((T_v + 1) // 2, T_v + 1, size=B) if ragged else np.full(B, T_v)).astype(np.int32)
+        b.video *= (np.arange(T_v)[None, :, None] < b.video_len[:, None, None])
+        b.aus = r(5).uniform(0.0, 3.0, size=(B, T_v, 2)).astype(np.float32)
+    lab = r(6).integers(1, cfg.eos_id, size=(B, L)).astype(np.int32)
+    ll = (r(7).integers(max(1, L // 2), L + 1, size=B) if ragged else np.full(B, L)).astype(np.int32)
+    if ragged:
+        ll[0] = L                       # padded_batch pads to the batch max, so max == L
+    for i in range(B):
+        lab[i, ll[i] - 1] = cfg.eos_id
+        lab[i, ll[i]:] = 0
+    b.labels, b.labels_len = lab, ll
+    return b
+
+
+# ----------------------------------------------------------------------------------------
+# stateless counter RNG shared bit-for-bit with the HIP kernels (dropout / scheduled sampling)
+# ----------------------------------------------------------------------------------------
+def hash_u32(seed: int, stream: int, idx: np.ndarray) -> np.ndarray:
+    """lowbias32 mix of (idx ^ key); identical integer arithmetic in csrc/common.h."""
+    with np.errstate(over="ignore"):
+        key = np.uint32((seed * 0x9E3779B9 + stream * 0x85EBCA6B) & 0xFFFFFFFF)
+        x = idx.astype(np.uint32) ^ key
+        x ^= x >> np.uint32(16)
+        x = x * np.uint32(0x7FEB352D)
+        x ^= x >> np.uint32(15)
+        x = x * np.uint32(0x846CA68B)
+        x ^= x >> np.uint32(16)
+    return x
+
+
+def uniform01(seed: int, stream: int, idx: np.ndarray) -> np.ndarray:
+    return (hash_u32(seed, stream, idx) >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+# ----------------------------------------------------------------------------------------
+# cells
+# ----------------------------------------------------------------------------------------
+def lstm_cell(x: Tensor, c: Tensor, h: Tensor, W: Tensor, b: Tensor):
+    """tf LSTMCell(use_peepholes=False, cell_clip=1.0, forget_bias=1.0) -- cells.py:14-18."""
+    z = torch.cat([x, h], dim=-1) @ W + b
+    i, j, f, o = z.chunk(4, dim=-1)
+    c_new = torch.sigmoid(f + 1.0) * c + torch.sigmoid(i) * torch.tanh(j)
+    c_new = torch.clamp(c_new, -1.0, 1.0)
+    h_new = torch.sigmoid(o) * torch.tanh(c_new)
+    return c_new, h_new
+
+
+def gru_cell(x: Tensor, h: Tensor, Wg: Tensor, bg: Tensor, Wc: Tensor, bc: Tensor):
+    """tf GRUCell -- cells.py:25-29."""
+    ru = torch.sigmoid(torch.cat([x, h], dim=-1) @ Wg + bg)
+    r, u = ru.chunk(2, dim=-1)
+    cand = torch.tanh(torch.cat([x, r * h], dim=-1) @ Wc + bc)
+    return u * h + (1.0 - u) * cand
+
+
+class _Cell:
+    """One RNN layer's weights + step function; state is (c, h) for LSTM, (h,) for GRU."""
+
+    def __init__(self, P: Dict[str, Tensor], prefix: str, cell_type: str, units: int):
+        self.t, self.units = cell_type, units
+        if cell_type == "lstm":
+            self.W, self.b = P[prefix + "/kernel"], P[prefix + "/bias"]
+        else:
+            self.Wg, self.bg = P[prefix + "/gates_kernel"], P[prefix + "/gates_bias"]
+            self.Wc, self.bc = P[prefix + "/cand_kernel"], P[prefix + "/cand_bias"]
+
+    def zero_state(self, B, dtype):
+        z = torch.zeros(B, self.units, dtype=dtype)
+        return (z, z) if self.t == "lstm" else (z,)
+
+    def __call__(self, x, state):
+        if self.t == "lstm":
+            c, h = lstm_cell(x, state[0], state[1], self.W, self.b)
+            return h, (c, h)
+        h = gru_cell(x, state[0], self.Wg, self.bg, self.Wc, self.bc)
+        return h, (h,)
+
+
+def _select(mask: Tensor, new, old):
+    return tuple(torch.where(mask, n, o) for n, o in zip(new, old))
+
+
+# ----------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------
+class _Mechanism:
+    """contrib.seq2seq Luong/Bahdanau attention over one memory (attention.py:25-72)."""
+
+    def __init__(self, P, prefix: str, att_type: str, memory: Tensor, memory_len: Tensor):
+        B, T, D = memory.shape
+        self.type = att_type
+        mask = (torch.arange(T)[None, :] < memory_len[:, None])
+        self.mask = mask
+        self.values = memory * mask[:, :, None].to(memory.dtype)          # _prepare_memory
+        self.keys = self.values @ P[prefix + "/memory_kernel"]            # memory_layer, once per batch
+        self.layer = P[prefix + "/layer_kernel"]
+        self.g = P.get(prefix + "/g")
+        if att_type in BAHDANAU_TYPES:
+            self.Wq, self.v = P[prefix + "/query_kernel"], P[prefix + "/v"]
+            self.b = P.get(prefix + "/b")
+
+    def __call__(self, query: Tensor):
+        if self.type in LUONG_TYPES:
+            score = torch.einsum("bth,bh->bt", self.keys, query)
+            if self.type == "scaled_luong":
+                score = score * self.g
+        else:
+            pq = query @ self.Wq
+            if self.type == "normed_bahdanau":
+                v = self.g * self.v / torch.sqrt(torch.sum(self.v * self.v))
+                score = torch.sum(v * torch.tanh(self.keys + pq[:, None, :] + self.b), dim=-1)
+            else:
+                score = torch.sum(self.v * torch.tanh(self.keys + pq[:, None, :]), dim=-1)
+        score = torch.where(self.mask, score, torch.full_like(score, -float("inf")))
+        align = torch.softmax(score, dim=-1)
+        ctx = torch.einsum("bt,btd->bd", align, self.values)
+        return align, ctx
+
+
+def attention_wrapper_step(cell: _Cell, mechs: List[_Mechanism], output_attention: bool,
+                           x: Tensor, cell_state, attention: Tensor):
+    """contrib.seq2seq.AttentionWrapper.call (attention.py:173-181; decoder_bimodal.py:241-248)."""
+    cell_out, new_state = cell(torch.cat([x, attention], dim=-1), cell_state)
+    atts, aligns = [], []
+    for m in mechs:
+        al, ctx = m(cell_out)
+        atts.append(torch.cat([cell_out, ctx], dim=-1) @ m.layer)
+        aligns.append(al)
+    new_att = torch.cat(atts, dim=-1)
+    out = new_att if output_attention else cell_out
+    return out, new_state, new_att, aligns
+
+
+# ----------------------------------------------------------------------------------------
+# encoders
+# ----------------------------------------------------------------------------------------
+def batch_norm(x: Tensor, P, prefix: str, training: bool, updates: Optional[dict]):
+    """tf.layers.batch_normalization(axis=-1, fused=True), momentum .99 eps 1e-3 (encoder.py:44-50).
+    Statistics over B*T rows INCLUDING zero padding."""
+    eps = 1e-3
+    if training:
+        flat = x.reshape(-1, x.shape[-1])
+        mean = flat.mean(dim=0)
+        var = ((flat - mean) ** 2).mean(dim=0)
+        if updates is not None:
+            n = flat.shape[0]
+            unbiased = var.detach() * (n / max(1, n - 1))       # fused kernel feeds Bessel-corrected var to the moving average
+            updates[prefix + "/moving_mean"] = 0.99 * P[prefix + "/moving_mean"] + 0.01 * mean.detach()
+            updates[prefix + "/moving_variance"] = 0.99 * P[prefix + "/moving_variance"] + 0.01 * unbiased
+    else:
+        mean, var = P[prefix + "/moving_mean"], P[prefix + "/moving_variance"]
+    return (x - mean) * torch.rsqrt(var + eps) * P[prefix + "/gamma"] + P[prefix + "/beta"]
+
+
+def _reverse_sequence(x: Tensor, lens: Tensor) -> Tensor:
+    B, T = x.shape[0], x.shape[1]
+    t = torch.arange(T)[None, :]
+    idx = torch.where(t < lens[:, None], lens[:, None] - 1 - t, t)
+    return torch.gather(x, 1, idx[:, :, None].expand_as(x))
+
+
+def dynamic_rnn(step_fn, zero_state, x: Tensor, lens: Tensor):
+    """tf.nn.dynamic_rnn with sequence_length: zero output / state copy-through past len.
+    step_fn(x_t, state) -> (out_t, state)."""
+    B, T = x.shape[0], x.shape[1]
+    state = zero_state
+    outs = []
+    for t in range(T):
+        o, ns = step_fn(x[:, t], state)
+        valid = (t < lens)[:, None]
+        outs.append(torch.where(valid, o, torch.zeros_like(o)))
+        state = _map_state(lambda n, s: torch.where(valid, n, s), ns, state)
+    return torch.stack(outs, dim=1), state
+
+
+def _map_state(fn, new, old):
+    """Apply fn(new_leaf, old_leaf) over a nested tuple of tensors."""
+    if isinstance(new, Tensor):
+        return fn(new, old)
+    return tuple(_map_state(fn, n, o) for n, o in zip(new, old))
+
+
+def _stack_step(cells: List[_Cell]):
+    def step(x, states):
+        new_states = []
+        for c, s in zip(cells, states):
+            x, ns = c(x, s)
+            new_states.append(ns)
+        return x, tuple(new_states)
+    return step
+
+
+@dataclass
+class EncoderOut:
+    outputs: Tensor            # [B, T, D]
+    final_state: tuple         # last layer's state: (c, h) or (h,)
+    alignments: Optional[Tensor] = None
+
+
+def encode_stream(P, cfg: OracleConfig, stream: str, x: Tensor, lens: Tensor, training: bool,
+                  bn_updates: Optional[dict], attended: Optional[Tuple[Tensor, Tensor]] = None) -> EncoderOut:
+    """Seq2SeqEncoder / AttentiveEncoder (encoder.py:14-196, :199-335)."""
+    units = cfg.video_units if stream == "video" else cfg.audio_units
+    B, dtype = x.shape[0], x.dtype
+    if cfg.batch_normalisation:
+        x = batch_norm(x, P, f"{stream}/bn", training, bn_updates)
+    if attended is not None:                                   # av_align: top layer attention-wrapped
+        cells = [_Cell(P, f"{stream}/enc/fw/l{l}", cfg.cell_type, u) for l, u in enumerate(units)]
+        mech = _Mechanism(P, "audio/enc/att0", cfg.attention_type[0][0], attended[0], attended[1])
+        out_att = cfg.attention_type[0][0] in LUONG_TYPES
+        aligns = []
+
+        def step(x_t, state):
+            lower, (top_state, att) = state
+            new_lower = []
+            for c, s in zip(cells[:-1], lower):
+                x_t, ns = c(x_t, s)
+                new_lower.append(ns)
+            out, ns, new_att, al = attention_wrapper_step(cells[-1], [mech], out_att, x_t, top_state, att)
+            aligns.append(al[0])
+            return out, (tuple(new_lower), (ns, new_att))
+
+        zero = (tuple(c.zero_state(B, dtype) for c in cells[:-1]),
+                (cells[-1].zero_state(B, dtype), torch.zeros(B, units[-1], dtype=dtype)))
+        outs, st = dynamic_rnn(step, zero, x, lens)
+        return EncoderOut(outs, st[1][0], torch.stack(aligns, dim=1))
+    if cfg.encoder_type == "unidirectional":
+        cells = [_Cell(P, f"{stream}/enc/fw/l{l}", cfg.cell_type, u) for l, u in enumerate(units)]
+        outs, st = dynamic_rnn(_stack_step(cells), tuple(c.zero_state(B, dtype) for c in cells), x, lens)
+        return EncoderOut(outs, st[-1])
+    # bidirectional: two independent stacks, concat at the top only (encoder.py:92-121)
+    fw = [_Cell(P, f"{stream}/enc/fw/l{l}", cfg.cell_type, u) for l, u in enumerate(units)]
+    bw = [_Cell(P, f"{stream}/enc/bw/l{l}", cfg.cell_type, u) for l, u in enumerate(units)]
+    o_fw, s_fw = dynamic_rnn(_stack_step(fw), tuple(c.zero_state(B, dtype) for c in fw), x, lens)
+    o_bw, s_bw = dynamic_rnn(_stack_step(bw), tuple(c.zero_state(B, dtype) for c in bw),
+                             _reverse_sequence(x, lens), lens)
+    o_bw = _reverse_sequence(o_bw, lens)
+    outs = torch.cat([o_fw, o_bw], dim=-1)
+    if cfg.cell_type == "lstm":
+        c = torch.cat([s_fw[-1][0], s_bw[-1][0]], dim=-1) @ P[f"{stream}/enc/proj_c"]
+        h = torch.cat([s_fw[-1][1], s_bw[-1][1]], dim=-1) @ P[f"{stream}/enc/proj_h"]
+        return EncoderOut(outs, (c, h))
+    h = torch.cat([s_fw[-1][0], s_bw[-1][0]], dim=-1) @ P[f"{stream}/enc/proj"]
+    return EncoderOut(outs, (h,))
+
+
+def au_loss(P, enc: EncoderOut, aus: Tensor, lens: Tensor) -> Tensor:
+    """encoder.py:173-189: Dense(2, sigmoid) vs clip(aus,0,3)/3, tf.losses.mean_squared_error with
+    weights = sequence mask tiled to [B,T,2] (reduction SUM_BY_NONZERO_WEIGHTS)."""
+    pred = torch.sigmoid(enc.outputs @ P["video/au/kernel"] + P["video/au/bias"])
+    tgt = torch.clamp(aus, 0.0, 3.0) / 3.0
+    T = pred.shape[1]
+    w = (torch.arange(T)[None, :] < lens[:, None]).to(pred.dtype)[:, :, None].expand_as(pred)
+    num = torch.sum(w * (pred - tgt) ** 2)
+    den = torch.sum(w)
+    return num / den if float(den) > 0 else num * 0.0
+
+
+# ----------------------------------------------------------------------------------------
+# the model: encoders + decoder (seq2seq.py:30-126)
+# ----------------------------------------------------------------------------------------
+class _Model:
+    def __init__(self, P: Dict[str, Tensor], cfg: OracleConfig, batch: Batch, training: bool, dtype):
+        self.P, self.cfg, self.training = P, cfg, training
+        self.bn_updates: dict = {}
+        tt = lambda a: None if a is None else torch.as_tensor(np.asarray(a), dtype=dtype)
+        ti = lambda a: None if a is None else torch.as_tensor(np.asarray(a), dtype=torch.int64)
+        self.enc: Dict[str, EncoderOut] = {}
+        self.lens: Dict[str, Tensor] = {}
+        self.aux_loss = None
+        if cfg.video_units is not None:
+            self.lens["video"] = ti(batch.video_len)
+            self.enc["video"] = encode_stream(P, cfg, "video", tt(batch.video), self.lens["video"],
+                                              training, self.bn_updates)
+            if cfg.regress_aus and training:
+                self.aux_loss = au_loss(P, self.enc["video"], tt(batch.aus), self.lens["video"])
+        if cfg.audio_units is not None:
+            self.lens["audio"] = ti(batch.audio_len)
+            attended = None
+            if cfg.architecture == "av_align":
+                attended = (self.enc["video"].outputs, self.lens["video"])
+            self.enc["audio"] = encode_stream(P, cfg, "audio", tt(batch.audio), self.lens["audio"],
+                                              training, self.bn_updates, attended)
+        self.B = (batch.audio if batch.audio is not None else batch.video).shape[0]
+        self.dtype = dtype
+        self._init_decoder()
+
+    def _init_decoder(self):
+        P, cfg = self.P, self.cfg
+        self.cell = _Cell(P, "dec/l0", cfg.cell_type, cfg.decoder_units[0])
+        self.mechs = [
+            _Mechanism(P, f"dec/att{i}", t, self.enc[s].outputs, self.lens[s])
+            for i, (s, t) in enumerate(cfg.decoder_memories())
+        ]
+        self.out_att = cfg.output_attention()
+        if cfg.architecture == "bimodal":
+            # _project_lstm_state_tuple: ONE shared Dense on concat c and on concat h (decoder_bimodal.py:480-490)
+            H = cfg.decoder_units[0]
+            z = torch.zeros(self.B, H, dtype=self.dtype)
+            vs = self.enc["video"].final_state if "video" in self.enc else (z, z)
+            as_ = self.enc["audio"].final_state if "audio" in self.enc else (z, z)
+            c = torch.cat([vs[0], as_[0]], dim=-1) @ P["dec/state_proj"]
+            h = torch.cat([vs[1], as_[1]], dim=-1) @ P["dec/state_proj"]
+            self.init_state = (c, h)
+        else:
+            s = "audio" if "audio" in self.enc else "video"
+            self.init_state = self.enc[s].final_state             # decoder_unimodal.py:144-145
+        self.att_dim = cfg.decoder_units[0] * len(self.mechs)
+
+    def step(self, x, state, att):
+        if self.mechs:
+            return attention_wrapper_step(self.cell, self.mechs, self.out_att, x, state, att)
+        out, ns = self.cell(x, state)
+        return out, ns, att, []
+
+    def logits(self, out):
+        return out @ self.P["dec/out/kernel"] + self.P["dec/out/bias"]
+
+
+def forward_train(P: Dict[str, Tensor], cfg: OracleConfig, batch: Batch, dtype=torch.float64):
+    """Train-graph forward (teacher forcing, sampling off): returns logits [B,L,V], loss pieces, model."""
+    m = _Model(P, cfg, batch, True, dtype)
+    labels = torch.as_tensor(batch.labels, dtype=torch.int64)
+    ll = torch.as_tensor(batch.labels_len, dtype=torch.int64)
+    B, L = labels.shape
+    go = torch.full((B, 1), cfg.go_id, dtype=torch.int64)
+    inputs = P["dec/embedding"][torch.cat([go, labels], dim=1)]            # decoder_unimodal.py:66-68,:170
+    state, att = m.init_state, torch.zeros(B, m.att_dim, dtype=dtype)
+    steps = int(ll.max())
+    logits = []
+    for t in range(steps):
+        out, ns, natt, _ = m.step(inputs[:, t], state, att)
+        lg = m.logits(out)
+        fin = (t >= ll)[:, None]            # TrainingHelper: finished once t >= sequence_length
+        logits.append(torch.where(fin, torch.zeros_like(lg), lg))          # impute_finished
+        state = _map_state(lambda n, s: torch.where(fin, s, n), ns, state)
+        att = torch.where(fin, att, natt)
+    logits = torch.stack(logits, dim=1)
+    if steps < L:
+        logits = torch.cat([logits, torch.zeros(B, L - steps, logits.shape[-1], dtype=dtype)], dim=1)
+    return logits, m
+
+
+def loss_fn(P, cfg: OracleConfig, batch: Batch, logits: Tensor, m: _Model):
+    """seq2seq.py:142-190: masked sequence CE + L2 on RNN kernels + au_loss_weight * AU loss."""
+    labels = torch.as_tensor(batch.labels, dtype=torch.int64)
+    ll = torch.as_tensor(batch.labels_len, dtype=torch.int64)
+    w = (torch.arange(labels.shape[1])[None, :] < ll[:, None]).to(logits.dtype)
+    ce = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1),
+                                           reduction="none").reshape(labels.shape)
+    seq = torch.sum(ce * w) / (torch.sum(w) + 1e-12)
+    total = seq
+    if cfg.recurrent_l2 is not None:
+        for k in l2_names(P, cfg):
+            total = total + cfg.recurrent_l2 * 0.5 * torch.sum(P[k] ** 2)
+    if cfg.regress_aus and m.aux_loss is not None:
+        total = total + cfg.au_loss_weight * m.aux_loss
+    return total, seq
+
+
+def to_torch(P_np: Dict[str, np.ndarray], dtype=torch.float64, requires_grad=False) -> Dict[str, Tensor]:
+    out = {}
+    for k, v in P_np.items():
+        t = torch.tensor(np.asarray(v), dtype=dtype)
+        if requires_grad and not k.endswith(NON_TRAINABLE):
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def lr_at(cfg: OracleConfig, step: int) -> float:
+    """seq2seq.py:259-280 (constant lr, linear warm-up)."""
+    lr = cfg.learning_rate
+    if cfg.warmup_steps:
+        lr *= min(1.0, (step + 1) / float(cfg.warmup_steps))
+    return lr
+
+
+def train_step(P_np: Dict[str, np.ndarray], opt: Optional[dict], cfg: OracleConfig, batch: Batch,
+               dtype=torch.float64):
+    """One full train step: fwd, BPTT, global-norm clip, Adam, BN moving stats.
+    Returns dict(loss, seq_loss, global_norm, grads, params, opt, logits)."""
+    P = to_torch(P_np, dtype, requires_grad=True)
+    logits, m = forward_train(P, cfg, batch, dtype)
+    loss, seq = loss_fn(P, cfg, batch, logits, m)
+    names = trainable_names(P)
+    grads = torch.autograd.grad(loss, [P[k] for k in names], allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(P[k])) for k, g in zip(names, grads)}
+    gnorm = torch.sqrt(sum(torch.sum(g * g) for g in grads.values()))
+    scale = 1.0
+    if cfg.clip_gradients:
+        scale = cfg.max_gradient_norm / max(float(gnorm), cfg.max_gradient_norm)
+    if opt is None:
+        opt = {"step": 0, "m": {k: np.zeros_like(P_np[k], dtype=np.float64) for k in names},
+               "v": {k: np.zeros_like(P_np[k], dtype=np.float64) for k in names}}
+    step = opt["step"]
+    lr = lr_at(cfg, step)
+    t = step + 1
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    newP = {k: np.array(v, copy=True) for k, v in P_np.items()}
+    new_opt = {"step": t, "m": {}, "v": {}}
+    for k in names:
+        g = grads[k].detach().numpy().astype(np.float64) * scale
+        mm = b1 * opt["m"][k] + (1 - b1) * g
+        vv = b2 * opt["v"][k] + (1 - b2) * g * g
+        new_opt["m"][k], new_opt["v"][k] = mm, vv
+        newP[k] = (P_np[k].astype(np.float64) - lr_t * mm / (np.sqrt(vv) + eps)).astype(P_np[k].dtype)
+    for k, v in m.bn_updates.items():
+        newP[k] = v.detach().numpy().astype(P_np[k].dtype)
+    return {"loss": float(loss.detach()), "seq_loss": float(seq.detach()), "global_norm": float(gnorm.detach()),
+            "grads": {k: g.detach().numpy() for k, g in grads.items()}, "params": newP, "opt": new_opt,
+            "logits": logits.detach().numpy()}
+
+
+@torch.no_grad()
+def greedy_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Batch, max_steps: Optional[int] = None,
+                  dtype=torch.float64, return_logits: bool = False):
+    """Eval graph: BN moving stats, GreedyEmbeddingHelper, dynamic_decode(impute_finished=True)
+    (decoder_unimodal.py:176-217; decoder_bimodal.py:279-323).  Returns int32 [B, T_out]."""
+    P = to_torch(P_np, dtype)
+    m = _Model(P, cfg, batch, False, dtype)
+    B = m.B
+    max_steps = cfg.max_label_length if max_steps is None else max_steps
+    tok = torch.full((B,), cfg.go_id, dtype=torch.int64)
+    state, att = m.init_state, torch.zeros(B, m.att_dim, dtype=dtype)
+    finished = torch.zeros(B, dtype=torch.bool)
+    ids, lgs = [], []
+    for t in range(max_steps):
+        out, ns, natt, _ = m.step(P["dec/embedding"][tok], state, att)
+        lg = m.logits(out)
+        sample = torch.argmax(lg, dim=-1)
+        f = finished[:, None]
+        ids.append(torch.where(finished, torch.zeros_like(sample), sample))
+        lgs.append(torch.where(f, torch.zeros_like(lg), lg))
+        state = _map_state(lambda n, s: torch.where(f, s, n), ns, state)
+        att = torch.where(f, att, natt)
+        tok = sample
+        finished = finished | (sample == cfg.eos_id)
+        if bool(finished.all()):
+            break
+    ids = torch.stack(ids, dim=1).to(torch.int32).numpy()
+    if return_logits:
+        return ids, torch.stack(lgs, dim=1).numpy()
+    return ids
+
+
+@torch.no_grad()
+def encoder_outputs(P_np, cfg: OracleConfig, batch: Batch, training: bool, dtype=torch.float64):
+    """Convenience for kernel-level parity tests: encoder memories + final states."""
+    P = to_torch(P_np, dtype)
+    m = _Model(P, cfg, batch, training, dtype)
+    return {s: (e.outputs.numpy(), tuple(x.numpy() for x in e.final_state)) for s, e in m.enc.items()}
