@@ -1,0 +1,6 @@
+"""avsr_tf1_amd -- MI355X (gfx950) engine for the AVSR seq2seq hot path of georgesterpu/avsr-tf1.
+
+Python host code mirroring the reference's surface (avsr/__init__.py:1-3), hand-written HIP kernels
+behind the C ABI in include/avsr_hip.h.  See DESIGN.md / INTEGRATION.md.
+"""
+__version__ = "0.1.0"

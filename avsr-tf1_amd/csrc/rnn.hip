@@ -1,0 +1,160 @@
+// Host-side wavefront scheduler for the masked multi-layer RNN (encoder stacks).
+//
+// tf.nn.dynamic_rnn runs layer-by-layer inside one while_loop iteration, T iterations in sequence
+// (encoder.py:80, :110).  Cell (layer l, time t) only needs (l-1, t) and (l, t-1), so all cells on
+// an anti-diagonal are independent: launch s runs cell (l, t = s - l) of every stack at once.  That
+// cuts the sequential chain from n_layers*T launches to T + n_layers - 1, and lets the video and
+// audio encoders and both directions of a bidirectional stack share launches.  The backward pass
+// (BPTT) runs the mirrored wavefront.
+#include "step.h"
+#include "avsr_hip.h"
+
+extern "C" int avsr_step_launch_raw(const void* launch, void* stream);
+
+namespace avsr {
+
+static inline float* hbuf(const avsr_rnn_layer& l, int B, int parity) { return l.state + (long)parity * B * l.units; }
+static inline float* cbuf(const avsr_rnn_layer& l, int B, int parity) { return l.state + (long)(2 + parity) * B * l.units; }
+// dstate: dG rolling [2][B][4H] | dc [2][B][H] | dh_carry [2][B][H]
+static inline float* dgroll(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)parity * B * 4 * l.units; }
+static inline float* dcbuf(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)(8 + parity) * B * l.units; }
+static inline float* dhcarry(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)(10 + parity) * B * l.units; }
+
+}  // namespace avsr
+
+extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
+  using namespace avsr;
+  if (!st || n <= 0 || n > AVSR_MAX_STACKS) return AVSR_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int nsteps = 0, ntask_max = 0;
+  for (int i = 0; i < n; ++i) {
+    const avsr_rnn_stack& S = st[i];
+    if (S.cell != 0) return AVSR_ERR_UNSUPPORTED;
+    if (S.n_layers <= 0 || S.n_layers > AVSR_MAX_LAYERS || S.B <= 0 || S.T <= 0) return AVSR_ERR_ARG;
+    for (int l = 0; l < S.n_layers; ++l) {
+      const avsr_rnn_layer& Ly = S.layer[l];
+      if (Ly.units % 4 || Ly.in_dim % 4 || !Ly.wt || !Ly.gates || !Ly.cs || !Ly.state) return AVSR_ERR_ARG;
+      if (Ly.hoisted && l != 0) return AVSR_ERR_ARG;
+      // zero initial state: h parity 0, c parity 0
+      if (hipMemsetAsync(hbuf(Ly, S.B, 0), 0, sizeof(float) * S.B * Ly.units, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (hipMemsetAsync(cbuf(Ly, S.B, 0), 0, sizeof(float) * S.B * Ly.units, s) != hipSuccess) return AVSR_ERR_HIP;
+    }
+    nsteps = nsteps > S.T + S.n_layers - 1 ? nsteps : S.T + S.n_layers - 1;
+    ntask_max += S.n_layers;
+  }
+  if (ntask_max > STEP_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
+
+  static thread_local StepLaunch L;
+  for (int step = 0; step < nsteps; ++step) {
+    L.ntask = 0;
+    for (int i = 0; i < n; ++i) {
+      const avsr_rnn_stack& S = st[i];
+      for (int l = 0; l < S.n_layers; ++l) {
+        const int t = step - l;
+        if (t < 0 || t >= S.T) continue;
+        const avsr_rnn_layer& Ly = S.layer[l];
+        StepTask& tk = L.task[L.ntask++];
+        tk = StepTask{};
+        const int H = Ly.units, in = Ly.in_dim;
+        tk.nsrc = 0;
+        if (!Ly.hoisted) {
+          if (l == 0) return AVSR_ERR_UNSUPPORTED;  // layer 0 input projection must be hoisted (avsr_gemm)
+          const avsr_rnn_layer& Lo = S.layer[l - 1];
+          StepSrc& x = tk.src[tk.nsrc++];
+          x.a = hbuf(Lo, S.B, (t + 1) & 1); x.sb = Lo.units; x.K = in; x.w = Ly.wt; x.ldw = in + H; x.kind = SRC_PLAIN;
+        }
+        StepSrc& h = tk.src[tk.nsrc++];
+        h.a = hbuf(Ly, S.B, t & 1); h.sb = H; h.K = H; h.w = Ly.wt + in; h.ldw = in + H; h.kind = SRC_PLAIN;
+        tk.B = S.B; tk.N = 4 * H; tk.mode = EP_LSTM_FWD;
+        tk.t = t; tk.T = S.T; tk.reverse = S.reverse; tk.len = S.len; tk.bias = Ly.bias;
+        tk.p0 = Ly.gates; tk.p1 = Ly.cs;
+        tk.p2 = Ly.out ? Ly.out + Ly.ld_out /* slot 1 = time 0 */ + Ly.out_col : nullptr;
+        tk.s0 = (long)(S.T + 2) * Ly.ld_out; tk.s1 = Ly.ld_out; tk.s2 = Ly.hoisted ? 1 : 0;
+        tk.p3 = cbuf(Ly, S.B, t & 1); tk.p4 = hbuf(Ly, S.B, t & 1);
+        tk.p5 = cbuf(Ly, S.B, (t + 1) & 1); tk.p6 = hbuf(Ly, S.B, (t + 1) & 1);
+      }
+    }
+    if (L.ntask == 0) continue;
+    int rc = avsr_step_launch_raw(&L, stream);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < n; ++i) {
+    const avsr_rnn_stack& S = st[i];
+    for (int l = 0; l < S.n_layers; ++l) {
+      const avsr_rnn_layer& Ly = S.layer[l];
+      const size_t bytes = sizeof(float) * S.B * Ly.units;
+      if (Ly.h_final && hipMemcpyAsync(Ly.h_final, hbuf(Ly, S.B, S.T & 1), bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return AVSR_ERR_HIP;
+      if (Ly.c_final && hipMemcpyAsync(Ly.c_final, cbuf(Ly, S.B, S.T & 1), bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return AVSR_ERR_HIP;
+    }
+  }
+  return AVSR_OK;
+}
+
+extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
+  using namespace avsr;
+  if (!st || n <= 0 || n > AVSR_MAX_STACKS) return AVSR_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int nsteps = 0, ntask_max = 0;
+  for (int i = 0; i < n; ++i) {
+    const avsr_rnn_stack& S = st[i];
+    if (S.cell != 0) return AVSR_ERR_UNSUPPORTED;
+    if (S.n_layers <= 0 || S.n_layers > AVSR_MAX_LAYERS) return AVSR_ERR_ARG;
+    for (int l = 0; l < S.n_layers; ++l) {
+      const avsr_rnn_layer& Ly = S.layer[l];
+      if (!Ly.w || !Ly.dgates || !Ly.dstate || !Ly.gates || !Ly.cs) return AVSR_ERR_ARG;
+      const size_t bh = sizeof(float) * S.B * Ly.units;
+      // rolling dG (both parities), dc / dh_carry at parity T&1 = gradient of the final state
+      if (hipMemsetAsync(Ly.dstate, 0, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (l == S.n_layers - 1) {
+        if (S.dc_final && hipMemcpyAsync(dcbuf(Ly, S.B, S.T & 1), S.dc_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
+          return AVSR_ERR_HIP;
+        if (S.dh_final && hipMemcpyAsync(dhcarry(Ly, S.B, S.T & 1), S.dh_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
+          return AVSR_ERR_HIP;
+      }
+    }
+    nsteps = nsteps > S.T + S.n_layers - 1 ? nsteps : S.T + S.n_layers - 1;
+    ntask_max += S.n_layers;
+  }
+  if (ntask_max > STEP_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
+
+  static thread_local StepLaunch L;
+  for (int step = 0; step < nsteps; ++step) {
+    L.ntask = 0;
+    for (int i = 0; i < n; ++i) {
+      const avsr_rnn_stack& S = st[i];
+      const int nl = S.n_layers;
+      for (int l = nl - 1; l >= 0; --l) {
+        const int t = S.T - 1 - (step - (nl - 1 - l));
+        if (t < 0 || t >= S.T) continue;
+        const avsr_rnn_layer& Ly = S.layer[l];
+        StepTask& tk = L.task[L.ntask++];
+        tk = StepTask{};
+        const int H = Ly.units, in = Ly.in_dim;
+        // dh[b,u] = dG_{t+1}(own) . Wh[u,:]  +  dG_t(upper layer) . Wx_upper[u,:]
+        StepSrc& a = tk.src[0];
+        a.a = dgroll(Ly, S.B, (t + 1) & 1); a.sb = 4 * H; a.K = 4 * H; a.w = Ly.w + (long)in * 4 * H; a.ldw = 4 * H; a.kind = SRC_PLAIN;
+        tk.nsrc = 1;
+        if (l + 1 < nl) {
+          const avsr_rnn_layer& Up = S.layer[l + 1];
+          StepSrc& u = tk.src[tk.nsrc++];
+          u.a = dgroll(Up, S.B, t & 1); u.sb = 4 * Up.units; u.K = 4 * Up.units; u.w = Up.w; u.ldw = 4 * Up.units; u.kind = SRC_PLAIN;
+        }
+        tk.B = S.B; tk.N = H; tk.mode = EP_LSTM_BWD;
+        tk.t = t; tk.T = S.T; tk.reverse = S.reverse; tk.len = S.len; tk.bias = nullptr;
+        tk.p0 = Ly.gates; tk.p1 = Ly.cs; tk.p2 = Ly.dgates; tk.p3 = dgroll(Ly, S.B, t & 1);
+        tk.p4 = dcbuf(Ly, S.B, (t + 1) & 1); tk.p5 = dcbuf(Ly, S.B, t & 1);
+        tk.p6 = dhcarry(Ly, S.B, (t + 1) & 1); tk.p7 = dhcarry(Ly, S.B, t & 1);
+        if (Ly.dout) {
+          tk.p8 = const_cast<float*>(Ly.dout) + Ly.ld_dout + Ly.dout_col;  // slot 1 = time 0
+          tk.s0 = (long)(S.T + 2) * Ly.ld_dout; tk.s1 = Ly.ld_dout;
+        }
+      }
+    }
+    if (L.ntask == 0) continue;
+    int rc = avsr_step_launch_raw(&L, stream);
+    if (rc) return rc;
+  }
+  return AVSR_OK;
+}
