@@ -1,0 +1,313 @@
+// Attention score / masked softmax / context kernels (forward and per-step backward).
+//
+// Restates contrib.seq2seq.{Luong,Bahdanau}Attention.__call__ + _compute_attention as selected by
+// avsr/attention.py:25-72 and avsr/decoder_bimodal.py:383-445:
+//   Luong     score[b,t] = g * sum_h keys[b,t,h] * q[b,h]              (g only for scaled_luong)
+//   Bahdanau  score[b,t] = sum_h v[h] * tanh(keys[b,t,h] + pq[b,h] (+ b[h]))
+//   alpha = softmax_t(score masked to -inf past len[b]);  ctx[b,:] = sum_t alpha[b,t] * values[b,t,:]
+//
+// This is the HBM-bound part of the decoder step: every step streams keys [B,T,H] and values
+// [B,T,D] once.  One launch covers every mechanism of the AttentionWrapper (video + audio memory).
+// Work item = (mechanism, utterance b, chunk of <= 128 time steps): flash-decoding style partials
+// (chunk max m, chunk sum l, un-normalised partial context) so that >= 2 workgroups per CU stream
+// concurrently; the consumer (the attention-layer step kernel, step.hip SRC_SOFTMAX) merges the
+// partials while it loads its A operand, so no extra launch sits in the sequential chain.
+//
+// Access pattern: 16 lanes cooperate on one memory row (each lane 16-byte loads at 64-byte stride
+// groups -> 256 contiguous bytes per row per instruction, 16 rows in flight per workgroup pass);
+// the context phase assigns one float4 column per thread and walks rows, fully coalesced.
+// Rows past len[b] are never loaded.
+#include "attn.h"
+
+namespace avsr {
+
+__device__ __forceinline__ void locate(const AttnLaunch& L, int& m, int& b, int& c) {
+  int blk = blockIdx.x;
+  m = 0;
+#pragma unroll
+  for (int i = 1; i < AVSR_MAX_MECH; ++i)
+    if (i < L.nmech && blk >= L.blk_off[i]) m = i;
+  blk -= L.blk_off[m];
+  c = blk % L.m[m].nchunk;
+  b = blk / L.m[m].nchunk;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnLaunch L) {
+  __shared__ float sc[ATTN_MAX_CHUNK];
+  __shared__ float red[4];
+  __shared__ __attribute__((aligned(16))) float cpart[1024];
+  int mi, b, c;
+  locate(L, mi, b, c);
+  const AttnMechDev& M = L.m[mi];
+  const int tid = threadIdx.x;
+  const int len = min(M.len ? M.len[b] : M.T, M.T);
+  const int t0 = c * M.chunk;
+  const int n = max(0, min(M.chunk, len - t0));  // valid rows in this chunk
+  const int H = M.H, D = M.D;
+  const float* keys = M.keys + (long)b * M.T * H;
+  const float* q = M.query + (long)b * M.query_sb;
+
+  // ---- phase 1: scores for rows t0 .. t0+n-1 (16 lanes per row) ----
+  const int s16 = tid & 15, rg = tid >> 4;
+  for (int r = rg; r < n; r += 16) {
+    const float* krow = keys + (long)(t0 + r) * H;
+    float acc = 0.f;
+    if (M.type <= ATT_SCALED_LUONG) {
+      for (int k = 4 * s16; k < H; k += 64) {
+        const f32x4 kv = ld4(krow + k), qv = ld4(q + k);
+        acc += kv[0] * qv[0] + kv[1] * qv[1] + kv[2] * qv[2] + kv[3] * qv[3];
+      }
+    } else {
+      for (int k = 4 * s16; k < H; k += 64) {
+        f32x4 kv = ld4(krow + k) + ld4(q + k);
+        if (M.bq) kv += ld4(M.bq + k);
+        const f32x4 vv = ld4(M.v + k);
+        acc += vv[0] * tanhf(kv[0]) + vv[1] * tanhf(kv[1]) + vv[2] * tanhf(kv[2]) + vv[3] * tanhf(kv[3]);
+      }
+    }
+    acc = group16_sum(acc);
+    if (s16 == 0) {
+      M.scores[(long)b * M.scores_sb + t0 + r] = acc;
+      sc[r] = (M.type == ATT_SCALED_LUONG) ? acc * M.g[0] : acc;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: chunk max / exp / sum ----
+  float mloc = -INFINITY;
+  for (int r = tid; r < n; r += 256) mloc = fmaxf(mloc, sc[r]);
+  const float mx = block_max_256(mloc, red);
+  float lloc = 0.f;
+  for (int r = tid; r < n; r += 256) {
+    const float p = expf(sc[r] - mx);
+    sc[r] = p;
+    lloc += p;
+  }
+  const float lsum = block_sum_256(lloc, red);  // (contains the barrier that publishes sc[])
+  if (tid == 0) {
+    M.pm[(long)c * L.B + b] = (n > 0) ? mx : -INFINITY;
+    M.pl[(long)c * L.B + b] = lsum;
+  }
+
+  // ---- phase 3: partial context = sum_r p_r * values[t0+r, :] ----
+  const int cols = D >> 2;                 // float4 columns
+  const float* vals = M.values + (long)b * M.values_sb;
+  float* pout = M.pctx + ((long)c * L.B + b) * D;
+  for (int cb = 0; cb < cols; cb += 256) {
+    const int ccols = min(256, cols - cb);
+    const int G = 256 / ccols;             // row groups
+    const int col = tid % ccols, grp = tid / ccols;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (grp < G) {
+      const float* vp = vals + 4 * (cb + col);
+      for (int r = grp; r < n; r += G) acc += sc[r] * ld4(vp + (long)(t0 + r) * M.values_st);
+    }
+    if (G == 1) {
+      if (grp < G) st4(pout + 4 * (cb + col), acc);
+    } else {
+      __syncthreads();
+      if (grp < G) st4(&cpart[4 * (grp * ccols + col)], acc);
+      __syncthreads();
+      if (tid < ccols) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int g2 = 0; g2 < G; ++g2) s += ld4(&cpart[4 * (g2 * ccols + tid)]);
+        st4(pout + 4 * (cb + tid), s);
+      }
+    }
+  }
+}
+
+// Per-step backward.  Inputs: d ctx [B,D] (gradient of this step's context), the forward context,
+// the saved raw scores and softmax partial statistics of this step.  Outputs: d score [B,T] (wrt the
+// softmax input) and per-chunk partial gradients of the query.
+//   d alpha_t = values_t . dctx ;  d s_t = alpha_t * (d alpha_t - ctx . dctx)       [sum_j alpha_j dalpha_j = ctx.dctx]
+//   Luong:    d q      += g * d s_t * keys_t
+//   Bahdanau: d pq[h]  += d s_t * v[h] * (1 - tanh^2(keys_t[h] + pq[h] + b[h]))
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnLaunch L) {
+  __shared__ float ds[ATTN_MAX_CHUNK];
+  __shared__ float red[4];
+  __shared__ __attribute__((aligned(16))) float cpart[1024];
+  int mi, b, c;
+  locate(L, mi, b, c);
+  const AttnMechDev& M = L.m[mi];
+  const int tid = threadIdx.x;
+  const int len = min(M.len ? M.len[b] : M.T, M.T);
+  const int t0 = c * M.chunk;
+  const int n = max(0, min(M.chunk, len - t0));
+  const int H = M.H, D = M.D;
+
+  // global softmax statistics of this row from the forward partials
+  float Mx = -INFINITY;
+  for (int j = 0; j < M.nchunk; ++j) Mx = fmaxf(Mx, M.pm[(long)j * L.B + b]);
+  float Ls = 0.f;
+  for (int j = 0; j < M.nchunk; ++j) {
+    const float pmj = M.pm[(long)j * L.B + b];
+    if (pmj != -INFINITY) Ls += expf(pmj - Mx) * M.pl[(long)j * L.B + b];
+  }
+  const float invL = Ls > 0.f ? 1.f / Ls : 0.f;
+
+  const float* dctx = M.dctx + (long)b * M.dctx_sb;
+  const float* ctx = M.ctx + (long)b * M.ctx_sb;
+  float cdl = 0.f;
+  for (int k = tid; k < D; k += 256) cdl += ctx[k] * dctx[k];
+  const float cd = block_sum_256(cdl, red);
+
+  const float gscale = (M.type == ATT_SCALED_LUONG) ? M.g[0] : 1.f;
+  const float* vals = M.values + (long)b * M.values_sb;
+  const int s16 = tid & 15, rg = tid >> 4;
+  for (int r = rg; r < n; r += 16) {
+    const float* vrow = vals + (long)(t0 + r) * M.values_st;
+    float acc = 0.f;
+    for (int k = 4 * s16; k < D; k += 64) {
+      const f32x4 a = ld4(vrow + k), d4 = ld4(dctx + k);
+      acc += a[0] * d4[0] + a[1] * d4[1] + a[2] * d4[2] + a[3] * d4[3];
+    }
+    acc = group16_sum(acc);
+    if (s16 == 0) {
+      const float raw = M.scores[(long)b * M.scores_sb + t0 + r];
+      const float alpha = expf(raw * gscale - Mx) * invL;
+      const float d = alpha * (acc - cd);
+      ds[r] = d;
+      M.dscores[(long)b * M.dscores_sb + t0 + r] = d;
+    }
+  }
+  // zero d score for the masked tail of this chunk (keeps the post-loop GEMMs exact)
+  for (int r = n + tid; r < M.chunk && t0 + r < M.T; r += 256) M.dscores[(long)b * M.dscores_sb + t0 + r] = 0.f;
+  __syncthreads();
+
+  // partial d query over this chunk
+  const int cols = H >> 2;
+  const float* keys = M.keys + (long)b * M.T * H;
+  const float* q = M.query + (long)b * M.query_sb;
+  float* pout = M.pdq + ((long)c * L.B + b) * H;
+  for (int cb = 0; cb < cols; cb += 256) {
+    const int ccols = min(256, cols - cb);
+    const int G = 256 / ccols;
+    const int col = tid % ccols, grp = tid / ccols;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (grp < G) {
+      const int k = 4 * (cb + col);
+      if (M.type <= ATT_SCALED_LUONG) {
+        for (int r = grp; r < n; r += G) acc += (ds[r] * gscale) * ld4(keys + (long)(t0 + r) * H + k);
+      } else {
+        f32x4 pq = ld4(q + k);
+        if (M.bq) pq += ld4(M.bq + k);
+        const f32x4 vv = ld4(M.v + k);
+        for (int r = grp; r < n; r += G) {
+          const f32x4 kv = ld4(keys + (long)(t0 + r) * H + k) + pq;
+          f32x4 th;
+          th[0] = tanhf(kv[0]); th[1] = tanhf(kv[1]); th[2] = tanhf(kv[2]); th[3] = tanhf(kv[3]);
+          acc += ds[r] * (vv * (1.f - th * th));
+        }
+      }
+    }
+    if (G == 1) {
+      if (grp < G) st4(pout + 4 * (cb + col), acc);
+    } else {
+      __syncthreads();
+      if (grp < G) st4(&cpart[4 * (grp * ccols + col)], acc);
+      __syncthreads();
+      if (tid < ccols) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int g2 = 0; g2 < G; ++g2) s += ld4(&cpart[4 * (g2 * ccols + tid)]);
+        st4(pout + 4 * (cb + tid), s);
+      }
+    }
+  }
+}
+
+// In-place: scores[b,l,:] (raw) -> alpha[b,l,:]; also rowdot[b*L+l] = sum_t dscores*raw (for d g).
+// One workgroup per (b, l) row.
+__global__ __launch_bounds__(256) void attn_alpha_rows_kernel(float* scores, const float* dscores, const int* len,
+                                                              const int* steplen, const float* g, float* rowdot,
+                                                              int B, int Lsteps, int T) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const int b = row / Lsteps, l = row % Lsteps;
+  const int n = min(len ? len[b] : T, T);
+  float* s = scores + (long)row * T;
+  const float* d = dscores + (long)row * T;
+  const bool step_valid = steplen ? (l < steplen[b]) : true;
+  const float gs = g ? g[0] : 1.f;
+  float mx = -INFINITY, dot = 0.f;
+  for (int t = threadIdx.x; t < n; t += 256) {
+    mx = fmaxf(mx, s[t] * gs);
+    dot += d[t] * s[t];
+  }
+  mx = block_max_256(mx, red);
+  dot = block_sum_256(dot, red);
+  float sum = 0.f;
+  for (int t = threadIdx.x; t < n; t += 256) sum += expf(s[t] * gs - mx);
+  sum = block_sum_256(sum, red);
+  const float inv = (sum > 0.f && step_valid) ? 1.f / sum : 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) s[t] = (t < n) ? expf(s[t] * gs - mx) * inv : 0.f;
+  if (threadIdx.x == 0 && rowdot) rowdot[row] = step_valid ? dot : 0.f;
+}
+
+// Bahdanau post-loop: d keys[b,t,h] (+)= sum_l ds[b,l,t] * v[h] * (1 - tanh^2(keys + pq[b,l,h] + bq[h]))
+//                     d v partial[blk][h] = sum_{t in blk, l} ds[b,l,t] * tanh(...)
+// grid = (ceil(T/16), B); block = H threads rounded up (<= 1024)
+__global__ void bahdanau_dkeys_kernel(const float* keys, const float* pq, long pq_sb, long pq_sl, const float* dscores,
+                                      const float* v, const float* bq, const int* len, float* dkeys, float* dv_part,
+                                      int B, int Lsteps, int T, int H) {
+  const int b = blockIdx.y, tb = blockIdx.x * 16;
+  const int n = min(len ? len[b] : T, T);
+  for (int h = threadIdx.x; h < H; h += blockDim.x) {
+    const float vh = v[h], bh = bq ? bq[h] : 0.f;
+    float dvacc = 0.f;
+    for (int t = tb; t < min(tb + 16, T); ++t) {
+      float acc = 0.f;
+      if (t < n) {
+        const float k = keys[((long)b * T + t) * H + h] + bh;
+        for (int l = 0; l < Lsteps; ++l) {
+          const float d = dscores[((long)b * Lsteps + l) * T + t];
+          if (d != 0.f) {
+            const float th = tanhf(k + pq[(long)b * pq_sb + (long)l * pq_sl + h]);
+            acc += d * (1.f - th * th);
+            dvacc += d * th;
+          }
+        }
+      }
+      dkeys[((long)b * T + t) * H + h] = acc * vh;
+    }
+    dv_part[((long)blockIdx.y * gridDim.x + blockIdx.x) * H + h] = dvacc;
+  }
+}
+
+}  // namespace avsr
+
+extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stream) {
+  using namespace avsr;
+  const AttnLaunch* L = (const AttnLaunch*)launch;
+  if (!L || L->nmech <= 0 || L->nmech > AVSR_MAX_MECH) return AVSR_ERR_ARG;
+  const int nblk = L->blk_off[L->nmech];
+  if (nblk <= 0) return AVSR_ERR_ARG;
+  if (backward) hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *L);
+  else hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *L);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_attn_alpha_rows(float* scores, const float* dscores, const int32_t* len, const int32_t* steplen,
+                                    const float* g, float* rowdot, int32_t B, int32_t L, int32_t T, void* stream) {
+  using namespace avsr;
+  if (!scores || !dscores || B <= 0 || L <= 0 || T <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(attn_alpha_rows_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, scores, dscores, len,
+                     steplen, g, rowdot, B, L, T);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_bahdanau_dkeys(const float* keys, const float* pq, int64_t pq_sb, int64_t pq_sl,
+                                   const float* dscores, const float* v, const float* bq, const int32_t* len,
+                                   float* dkeys, float* dv_part, int32_t B, int32_t L, int32_t T, int32_t H,
+                                   void* stream) {
+  using namespace avsr;
+  if (!keys || !pq || !dscores || !v || !dkeys || !dv_part) return AVSR_ERR_ARG;
+  int threads = ((H + 63) / 64) * 64;
+  if (threads > 1024) threads = 1024;
+  hipLaunchKernelGGL(bahdanau_dkeys_kernel, dim3((T + 15) / 16, B), dim3(threads), 0, (hipStream_t)stream, keys, pq,
+                     (long)pq_sb, (long)pq_sl, dscores, v, bq, len, dkeys, dv_part, B, L, T, H);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}

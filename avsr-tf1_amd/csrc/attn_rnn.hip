@@ -1,0 +1,350 @@
+// Host-side scheduler for the attention-wrapped LSTM sequence (decoder train / greedy, AV-Align
+// top encoder layer) -- see avsr_hip.h for the contract and the reference call sites.
+//
+// Forward chain per step:  [LSTM step] -> [Bahdanau query layer]* -> [attention partials] ->
+//                          [attention layer (merges partials)] -> ([logits] -> [sample])^greedy
+// Backward chain per step: [d attention] -> [d context] -> [attention backward] -> [partial sums]
+//                          -> [LSTM backward]
+// Every box is one launch covering all mechanisms; weight/keys gradients are deferred to post-loop
+// GEMMs over all L steps (done by the caller with avsr_gemm).
+#include "step.h"
+#include "attn.h"
+
+extern "C" int avsr_step_launch_raw(const void* launch, void* stream);
+extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stream);
+
+namespace avsr {
+
+struct SlabJob {
+  float* dst; long dst_sb;
+  const float* add; long add_sb;
+  const float* src[AVSR_MAX_MECH]; int nslab[AVSR_MAX_MECH];
+  int nsrc, W;
+};
+struct SlabLaunch { int njob, B; SlabJob job[AVSR_MAX_MECH + 1]; };
+
+// dst[b, k] = add[b, k] + sum_sets sum_c src[c][b][k]
+__global__ void slab_sum_kernel(const SlabLaunch L) {
+  const SlabJob& J = L.job[blockIdx.y];
+  const long total = (long)L.B * J.W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / J.W), k = (int)(i % J.W);
+    float s = J.add ? J.add[(long)b * J.add_sb + k] : 0.f;
+    for (int j = 0; j < J.nsrc; ++j)
+      for (int c = 0; c < J.nslab[j]; ++c) s += J.src[j][((long)c * L.B + b) * J.W + k];
+    J.dst[(long)b * J.dst_sb + k] = s;
+  }
+}
+
+// GreedyEmbeddingHelper.sample/next_inputs + dynamic_decode finished bookkeeping (one block).
+__global__ void greedy_sample_kernel(const float* logits, long logits_sb, int V, int32_t* ids, long ids_sb, int32_t* tok,
+                                     int32_t* steplen, int32_t* n_unfinished, int B, int l, int eos) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int local = 0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    int id = 0;
+    if (l < steplen[b]) {
+      const float* lg = logits + (long)b * logits_sb;
+      float best = lg[0];
+      for (int v = 1; v < V; ++v)
+        if (lg[v] > best) { best = lg[v]; id = v; }   // first maximum (tf.argmax)
+      tok[b] = id;
+      if (id == eos) steplen[b] = l + 1; else local += 1;
+    }
+    ids[(long)b * ids_sb] = id;
+  }
+  atomicAdd(&cnt, local);
+  __syncthreads();
+  if (threadIdx.x == 0) n_unfinished[0] = cnt;
+}
+
+static inline float* hbuf(const avsr_attn_rnn& d, int p) { return d.state + (long)p * d.B * d.H; }
+static inline float* cbuf(const avsr_attn_rnn& d, int p) { return d.state + (long)(2 + p) * d.B * d.H; }
+static inline float* dgroll(const avsr_attn_rnn& d, int p) { return d.dstate + (long)p * d.B * 4 * d.H; }
+static inline float* dcbuf(const avsr_attn_rnn& d, int p) { return d.dstate + (long)(8 + p) * d.B * d.H; }
+static inline float* dhcarry(const avsr_attn_rnn& d, int p) { return d.dstate + (long)(10 + p) * d.B * d.H; }
+static inline int nchunk(const avsr_attn_mech& m) { return (m.T + m.chunk - 1) / m.chunk; }
+static inline bool is_bahdanau(const avsr_attn_mech& m) { return m.type >= ATT_BAHDANAU; }
+
+static int validate(const avsr_attn_rnn* d) {
+  if (!d || d->B <= 0 || d->L <= 0 || d->H <= 0 || d->H % 4 || d->E % 4 || d->n_mech < 0 || d->n_mech > AVSR_MAX_MECH)
+    return AVSR_ERR_ARG;
+  if (!d->wt || !d->gates || !d->cs || !d->cell_out || !d->state || !d->steplen) return AVSR_ERR_ARG;
+  if (d->n_mech > 0 && !d->att) return AVSR_ERR_ARG;
+  for (int m = 0; m < d->n_mech; ++m) {
+    const avsr_attn_mech& M = d->mech[m];
+    if (M.T <= 0 || M.D % 4 || M.chunk <= 0 || M.chunk > ATTN_MAX_CHUNK || nchunk(M) > STEP_MAX_SLAB) return AVSR_ERR_ARG;
+    if (M.D > 1024 || d->H > 1024) return AVSR_ERR_UNSUPPORTED;
+    if (!M.keys || !M.values || !M.watt_t || !M.scores || !M.ctx || !M.pstat || !M.pctx) return AVSR_ERR_ARG;
+    if (M.type < 0 || M.type > ATT_NORMED_BAHDANAU) return AVSR_ERR_UNSUPPORTED;
+    if (M.type == ATT_SCALED_LUONG && !M.g) return AVSR_ERR_ARG;
+    if (is_bahdanau(M) && (!M.v || !M.wq_t || !M.pq)) return AVSR_ERR_ARG;
+  }
+  return AVSR_OK;
+}
+
+static void fill_attn_launch(const avsr_attn_rnn& d, int l, AttnLaunch& AL) {
+  const int B = d.B, H = d.H, L = d.L;
+  AL = AttnLaunch{};
+  AL.nmech = d.n_mech; AL.B = B;
+  int off = 0;
+  for (int m = 0; m < d.n_mech; ++m) {
+    const avsr_attn_mech& M = d.mech[m];
+    AttnMechDev& X = AL.m[m];
+    const int nc = nchunk(M);
+    AL.blk_off[m] = off;
+    off += B * nc;
+    X.keys = M.keys; X.values = M.values; X.values_sb = M.values_sb; X.values_st = M.values_st; X.len = M.len;
+    if (is_bahdanau(M)) { X.query = M.pq + (long)l * H; X.query_sb = (long)L * H; }
+    else { X.query = d.cell_out + (long)(l + 1) * H; X.query_sb = (long)(L + 1) * H; }
+    X.g = M.g; X.v = M.v; X.bq = M.bq;
+    X.scores = M.scores + (long)l * M.T; X.scores_sb = (long)L * M.T;
+    X.pm = M.pstat + (long)(2 * l) * nc * B; X.pl = M.pstat + (long)(2 * l + 1) * nc * B;
+    X.pctx = M.pctx;
+    X.T = M.T; X.D = M.D; X.H = H; X.type = M.type; X.nchunk = nc; X.chunk = M.chunk;
+    if (M.dctx) { X.dctx = M.dctx + (long)l * M.D; X.dctx_sb = (long)L * M.D; }
+    X.ctx = M.ctx + (long)l * M.D; X.ctx_sb = (long)L * M.D;
+    if (M.dscores) { X.dscores = M.dscores + (long)l * M.T; X.dscores_sb = (long)L * M.T; }
+    X.pdq = M.pdq;
+  }
+  AL.blk_off[d.n_mech] = off;
+}
+
+}  // namespace avsr
+
+extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32_t l_end, void* stream) {
+  using namespace avsr;
+  int rc = validate(dp);
+  if (rc) return rc;
+  const avsr_attn_rnn& d = *dp;
+  hipStream_t s = (hipStream_t)stream;
+  const int B = d.B, H = d.H, L = d.L, E = d.E, A = d.n_mech * H, KW = E + A + H;
+  if (l_begin < 0 || l_end > L || l_begin > l_end) return AVSR_ERR_ARG;
+  if (d.mode == 1 && (!d.embedding || !d.wout_t || !d.logits || !d.ids || !d.tok || !d.n_unfinished)) return AVSR_ERR_ARG;
+  const size_t bh = sizeof(float) * B * H;
+
+  if (l_begin == 0) {
+    // initial state -> ping-pong parity 0, cell_out slot 0 = h0, attention slot 0 = 0
+    if (d.h0) { if (hipMemcpyAsync(hbuf(d, 0), d.h0, bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP; }
+    else if (hipMemsetAsync(hbuf(d, 0), 0, bh, s) != hipSuccess) return AVSR_ERR_HIP;
+    if (d.c0) { if (hipMemcpyAsync(cbuf(d, 0), d.c0, bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP; }
+    else if (hipMemsetAsync(cbuf(d, 0), 0, bh, s) != hipSuccess) return AVSR_ERR_HIP;
+    if (hipMemcpy2DAsync(d.cell_out, sizeof(float) * (L + 1) * H, hbuf(d, 0), sizeof(float) * H, sizeof(float) * H, B,
+                         hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+    if (A > 0 && hipMemset2DAsync(d.att, sizeof(float) * (L + 1) * A, 0, sizeof(float) * A, B, s) != hipSuccess)
+      return AVSR_ERR_HIP;
+  }
+
+  static thread_local StepLaunch SL;
+  static thread_local AttnLaunch AL;
+  for (int l = l_begin; l < l_end; ++l) {
+    // ---- K1: LSTM step -------------------------------------------------------------------
+    SL.ntask = 1;
+    {
+      StepTask& tk = SL.task[0];
+      tk = StepTask{};
+      if (d.mode == 1) {
+        StepSrc& x = tk.src[tk.nsrc++];
+        x.a = d.embedding; x.sb = E; x.K = E; x.w = d.wt; x.ldw = KW; x.kind = SRC_PLAIN;
+        tk.gather = d.tok;
+      }
+      if (A > 0) {
+        StepSrc& a = tk.src[tk.nsrc++];
+        a.a = d.att + (long)l * A; a.sb = (long)(L + 1) * A; a.K = A; a.w = d.wt + E; a.ldw = KW; a.kind = SRC_PLAIN;
+      }
+      StepSrc& h = tk.src[tk.nsrc++];
+      h.a = hbuf(d, l & 1); h.sb = H; h.K = H; h.w = d.wt + E + A; h.ldw = KW; h.kind = SRC_PLAIN;
+      tk.B = B; tk.N = 4 * H; tk.mode = EP_LSTM_FWD; tk.t = l; tk.T = L; tk.reverse = 0;
+      tk.len = d.steplen; tk.bias = d.bias;
+      tk.p0 = d.gates; tk.p1 = d.cs; tk.p2 = d.cell_out + H; tk.s0 = (long)(L + 1) * H; tk.s1 = H;
+      tk.s2 = (d.mode == 0) ? 1 : 0;
+      tk.p3 = cbuf(d, l & 1); tk.p4 = hbuf(d, l & 1); tk.p5 = cbuf(d, (l + 1) & 1); tk.p6 = hbuf(d, (l + 1) & 1);
+    }
+    if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+
+    if (d.n_mech > 0) {
+      // ---- Kq: Bahdanau processed query  pq = cell_out . Wq ---------------------------------
+      SL.ntask = 0;
+      for (int m = 0; m < d.n_mech; ++m) {
+        const avsr_attn_mech& M = d.mech[m];
+        if (!is_bahdanau(M)) continue;
+        StepTask& tk = SL.task[SL.ntask++];
+        tk = StepTask{};
+        StepSrc& x = tk.src[tk.nsrc++];
+        x.a = d.cell_out + (long)(l + 1) * H; x.sb = (long)(L + 1) * H; x.K = H; x.w = M.wq_t; x.ldw = H; x.kind = SRC_PLAIN;
+        tk.B = B; tk.N = H; tk.mode = EP_LINEAR; tk.t = l; tk.T = L;
+        tk.p0 = M.pq + (long)l * H; tk.s0 = (long)L * H;
+      }
+      if (SL.ntask && (rc = avsr_step_launch_raw(&SL, stream))) return rc;
+
+      // ---- K2: attention partials ---------------------------------------------------------
+      fill_attn_launch(d, l, AL);
+      if ((rc = avsr_attn_launch_raw(&AL, 0, stream))) return rc;
+
+      // ---- K3: attention layer  att_m = [cell_out, ctx_m] . W_att,m --------------------------
+      SL.ntask = 0;
+      for (int m = 0; m < d.n_mech; ++m) {
+        const avsr_attn_mech& M = d.mech[m];
+        const int nc = nchunk(M);
+        StepTask& tk = SL.task[SL.ntask++];
+        tk = StepTask{};
+        StepSrc& x = tk.src[tk.nsrc++];
+        x.a = d.cell_out + (long)(l + 1) * H; x.sb = (long)(L + 1) * H; x.K = H; x.w = M.watt_t; x.ldw = H + M.D; x.kind = SRC_PLAIN;
+        StepSrc& c = tk.src[tk.nsrc++];
+        c.a = M.pctx; c.sb = M.D; c.K = M.D; c.w = M.watt_t + H; c.ldw = H + M.D; c.kind = SRC_SOFTMAX;
+        tk.pm = M.pstat + (long)(2 * l) * nc * B; tk.pl = M.pstat + (long)(2 * l + 1) * nc * B;
+        tk.nslab = nc; tk.slab_stride = (long)B * M.D;
+        tk.ctx_save = M.ctx + (long)l * M.D; tk.ctx_sb = (long)L * M.D;
+        tk.B = B; tk.N = H; tk.mode = EP_LINEAR; tk.t = l; tk.T = L; tk.len = d.steplen;
+        tk.p0 = d.att + (long)(l + 1) * A + (long)m * H; tk.s0 = (long)(L + 1) * A;
+      }
+      if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+    }
+
+    if (d.mode == 1) {
+      // ---- K4/K5: output layer + greedy sample ---------------------------------------------
+      const bool oa = d.output_attention && A > 0;
+      const int O = oa ? A : H;
+      SL.ntask = 1;
+      StepTask& tk = SL.task[0];
+      tk = StepTask{};
+      StepSrc& x = tk.src[tk.nsrc++];
+      if (oa) { x.a = d.att + (long)(l + 1) * A; x.sb = (long)(L + 1) * A; }
+      else { x.a = d.cell_out + (long)(l + 1) * H; x.sb = (long)(L + 1) * H; }
+      x.K = O; x.w = d.wout_t; x.ldw = O; x.kind = SRC_PLAIN;
+      tk.B = B; tk.N = d.V; tk.mode = EP_LINEAR; tk.t = l; tk.T = L; tk.len = d.steplen; tk.bias = d.bout;
+      tk.p0 = d.logits + (long)l * d.V; tk.s0 = (long)L * d.V;
+      if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+      hipLaunchKernelGGL(greedy_sample_kernel, dim3(1), dim3(256), 0, s, d.logits + (long)l * d.V, (long)L * d.V, d.V,
+                         d.ids + l, (long)L, d.tok, d.steplen, d.n_unfinished, B, l, d.eos_id);
+      AVSR_CHECK_LAUNCH();
+    }
+  }
+  if (l_end == L) {
+    if (d.h_final && hipMemcpyAsync(d.h_final, hbuf(d, L & 1), bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+    if (d.c_final && hipMemcpyAsync(d.c_final, cbuf(d, L & 1), bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+  }
+  return AVSR_OK;
+}
+
+extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
+  using namespace avsr;
+  int rc = validate(dp);
+  if (rc) return rc;
+  const avsr_attn_rnn& d = *dp;
+  hipStream_t s = (hipStream_t)stream;
+  const int B = d.B, H = d.H, L = d.L, E = d.E, A = d.n_mech * H;
+  if (!d.w || !d.dgates || !d.dstate) return AVSR_ERR_ARG;
+  if (A > 0 && !d.datt) return AVSR_ERR_ARG;
+  int n_bah = 0, n_luong = 0;
+  for (int m = 0; m < d.n_mech; ++m) {
+    const avsr_attn_mech& M = d.mech[m];
+    if (!M.watt || !M.dscores || !M.dctx || !M.pdq) return AVSR_ERR_ARG;
+    if (is_bahdanau(M)) { if (!M.wq || !M.dpq) return AVSR_ERR_ARG; ++n_bah; } else ++n_luong;
+  }
+  if (1 + d.n_mech + n_bah > STEP_MAX_SRC) return AVSR_ERR_UNSUPPORTED;
+  const bool use_dq = (n_luong > 0) || d.dcell_ext;
+  if (use_dq && !d.dq) return AVSR_ERR_ARG;
+  const size_t bh = sizeof(float) * B * H;
+  if (hipMemsetAsync(d.dstate, 0, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
+  if (d.dc_final && hipMemcpyAsync(dcbuf(d, L & 1), d.dc_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+  if (d.dh_final && hipMemcpyAsync(dhcarry(d, L & 1), d.dh_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+
+  static thread_local StepLaunch SL;
+  static thread_local AttnLaunch AL;
+  static thread_local SlabLaunch BL;
+  for (int l = L - 1; l >= 0; --l) {
+    if (A > 0) {
+      // ---- KB3: d attention_l = datt_ext[l] + dG_{l+1} . Wx_att^T ----------------------------
+      SL.ntask = 1;
+      {
+        StepTask& tk = SL.task[0];
+        tk = StepTask{};
+        StepSrc& x = tk.src[tk.nsrc++];
+        x.a = dgroll(d, (l + 1) & 1); x.sb = 4 * H; x.K = 4 * H; x.w = d.w + (long)E * 4 * H; x.ldw = 4 * H; x.kind = SRC_PLAIN;
+        tk.B = B; tk.N = A; tk.mode = EP_LINEAR; tk.t = l; tk.T = L;
+        if (d.datt_ext) { tk.p1 = const_cast<float*>(d.datt_ext) + (long)l * A; tk.s1 = (long)L * A; }
+        tk.p0 = d.datt + (long)l * A; tk.s0 = (long)L * A;
+      }
+      if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+      // ---- KB4: d ctx_m = d att_m . W_att,m[H:, :]^T ----------------------------------------
+      SL.ntask = 0;
+      for (int m = 0; m < d.n_mech; ++m) {
+        const avsr_attn_mech& M = d.mech[m];
+        StepTask& tk = SL.task[SL.ntask++];
+        tk = StepTask{};
+        StepSrc& x = tk.src[tk.nsrc++];
+        x.a = d.datt + (long)l * A + (long)m * H; x.sb = (long)L * A; x.K = H; x.w = M.watt + (long)H * H; x.ldw = H; x.kind = SRC_PLAIN;
+        tk.B = B; tk.N = M.D; tk.mode = EP_LINEAR; tk.t = l; tk.T = L;
+        tk.p0 = M.dctx + (long)l * M.D; tk.s0 = (long)L * M.D;
+      }
+      if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+      // ---- KB5: attention backward -----------------------------------------------------------
+      fill_attn_launch(d, l, AL);
+      if ((rc = avsr_attn_launch_raw(&AL, 1, stream))) return rc;
+    }
+    // ---- KB5b: reduce the per-chunk query gradients --------------------------------------------
+    BL = SlabLaunch{};
+    BL.B = B;
+    if (use_dq) {
+      SlabJob& J = BL.job[BL.njob++];
+      J.dst = d.dq + (long)l * H; J.dst_sb = (long)L * H; J.W = H;
+      if (d.dcell_ext) { J.add = d.dcell_ext + (long)l * H; J.add_sb = (long)L * H; }
+      for (int m = 0; m < d.n_mech; ++m)
+        if (!is_bahdanau(d.mech[m])) { J.src[J.nsrc] = d.mech[m].pdq; J.nslab[J.nsrc] = nchunk(d.mech[m]); ++J.nsrc; }
+    }
+    for (int m = 0; m < d.n_mech; ++m) {
+      const avsr_attn_mech& M = d.mech[m];
+      if (!is_bahdanau(M)) continue;
+      SlabJob& J = BL.job[BL.njob++];
+      J.dst = M.dpq + (long)l * H; J.dst_sb = (long)L * H; J.W = H;
+      J.src[0] = M.pdq; J.nslab[0] = nchunk(M); J.nsrc = 1;
+    }
+    if (BL.njob) {
+      int gx = (B * H + 255) / 256;
+      if (gx > 64) gx = 64;
+      hipLaunchKernelGGL(slab_sum_kernel, dim3(gx, BL.njob), dim3(256), 0, s, BL);
+      AVSR_CHECK_LAUNCH();
+    }
+    // ---- KB2: LSTM backward ----------------------------------------------------------------------
+    SL.ntask = 1;
+    {
+      StepTask& tk = SL.task[0];
+      tk = StepTask{};
+      StepSrc& a = tk.src[tk.nsrc++];
+      a.a = dgroll(d, (l + 1) & 1); a.sb = 4 * H; a.K = 4 * H; a.w = d.w + (long)(E + A) * 4 * H; a.ldw = 4 * H; a.kind = SRC_PLAIN;
+      for (int m = 0; m < d.n_mech; ++m) {
+        const avsr_attn_mech& M = d.mech[m];
+        StepSrc& x = tk.src[tk.nsrc++];
+        x.a = d.datt + (long)l * A + (long)m * H; x.sb = (long)L * A; x.K = H; x.w = M.watt; x.ldw = H; x.kind = SRC_PLAIN;
+        if (is_bahdanau(M)) {
+          StepSrc& q = tk.src[tk.nsrc++];
+          q.a = M.dpq + (long)l * H; q.sb = (long)L * H; q.K = H; q.w = M.wq; q.ldw = H; q.kind = SRC_PLAIN;
+        }
+      }
+      tk.B = B; tk.N = H; tk.mode = EP_LSTM_BWD; tk.t = l; tk.T = L; tk.reverse = 0; tk.len = d.steplen;
+      tk.bias = d.c0;
+      tk.p0 = d.gates; tk.p1 = d.cs; tk.p2 = d.dgates; tk.p3 = dgroll(d, l & 1);
+      tk.p4 = dcbuf(d, (l + 1) & 1); tk.p5 = dcbuf(d, l & 1);
+      tk.p6 = dhcarry(d, (l + 1) & 1); tk.p7 = dhcarry(d, l & 1);
+      if (use_dq) { tk.p8 = d.dq; tk.s0 = (long)L * H; tk.s1 = H; }
+    }
+    if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+  }
+  // gradient wrt the initial state
+  if (d.dh0) {
+    SL.ntask = 1;
+    StepTask& tk = SL.task[0];
+    tk = StepTask{};
+    StepSrc& a = tk.src[tk.nsrc++];
+    a.a = dgroll(d, 0); a.sb = 4 * H; a.K = 4 * H; a.w = d.w + (long)(E + A) * 4 * H; a.ldw = 4 * H; a.kind = SRC_PLAIN;
+    tk.B = B; tk.N = H; tk.mode = EP_LINEAR; tk.t = 0; tk.T = L;
+    tk.p1 = dhcarry(d, 0); tk.s1 = H;
+    tk.p0 = d.dh0; tk.s0 = H;
+    if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+  }
+  if (d.dc0 && hipMemcpyAsync(d.dc0, dcbuf(d, 0), bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+  return AVSR_OK;
+}

@@ -1,0 +1,497 @@
+// Memory-bound helper kernels of the train step: weight transposes, batch-norm, column reductions,
+// embedding lookup / gradient, masked sequence cross-entropy, AU regression loss, L2 + global-norm
+// clip + Adam.  All are single-pass, 16-byte vectorised where the layout allows, and deterministic
+// (two-stage reductions, no float atomics).
+#include "common.h"
+#include "avsr_hip.h"
+
+namespace avsr {
+
+// ---------------------------------------------------------------------------------------------
+// batched 2-D transposes (derived "Wt" operands of the step kernels), up to 16 jobs per launch
+struct TJob { const float* src; float* dst; int rows, cols; };
+struct TLaunch { int njob; TJob job[AVSR_MAX_TRANSPOSE]; };
+
+__global__ void transpose_kernel(const TLaunch L) {
+  __shared__ float tile[32][33];
+  const TJob& J = L.job[blockIdx.z];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int tiles_c = (J.cols + 31) / 32, tiles_r = (J.rows + 31) / 32;
+  for (int tIdx = blockIdx.x; tIdx < tiles_c * tiles_r; tIdx += gridDim.x) {
+    const int r0 = (tIdx / tiles_c) * 32, c0 = (tIdx % tiles_c) * 32;
+    for (int j = ty; j < 32; j += 8) {
+      const int r = r0 + j, c = c0 + tx;
+      tile[j][tx] = (r < J.rows && c < J.cols) ? J.src[(long)r * J.cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+      const int c = c0 + j, r = r0 + tx;
+      if (r < J.rows && c < J.cols) J.dst[(long)c * J.rows + r] = tile[tx][j];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// column reduction: out[f] = alpha * sum_r a[r][f] * (b ? b[r][f] : 1) + beta * out[f]
+// two-level row addressing on a and b (same convention as avsr_gemm)
+__device__ __forceinline__ long rowoff(int r, long ld, int T, long ldo) {
+  return T ? (long)(r / T) * ldo + (long)(r % T) * ld : (long)r * ld;
+}
+
+__global__ void colsum_partial_kernel(const float* a, long lda, int Ta, long ldoa, const float* b, long ldb, int Tb,
+                                      long ldob, float* part, int rows, int F, int rows_per_blk) {
+  const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const float x = a[rowoff(r, lda, Ta, ldoa) + f];
+      s += b ? x * b[rowoff(r, ldb, Tb, ldob) + f] : x;
+    }
+    part[(long)blockIdx.x * F + f] = s;
+  }
+}
+
+__global__ void colsum_final_kernel(const float* part, int nblk, float* out, int F, float alpha, float beta) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += (double)part[(long)i * F + f];
+  const float v = alpha * (float)s;
+  out[f] = beta != 0.f ? v + beta * out[f] : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch norm over rows (tf.layers.batch_normalization axis=-1, encoder.py:44-50): statistics over ALL
+// B*T rows including zero padding.  Stage 1: partial sums.  Stage 2: partial centred squares.  Stage 3:
+// normalise (+ moving-average update and saved mean / inv-std by block 0).
+__global__ void bn_partial_sum_kernel(const float* x, float* part, int rows, int F, int rows_per_blk) {
+  const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += x[(long)r * F + f];
+    part[(long)blockIdx.x * F + f] = s;
+  }
+}
+
+__global__ void bn_partial_sq_kernel(const float* x, const float* psum, int nblk, float* part, int rows, int F,
+                                     int rows_per_blk) {
+  const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    double m = 0.0;
+    for (int i = 0; i < nblk; ++i) m += (double)psum[(long)i * F + f];
+    const float mean = (float)(m / rows);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const float d = x[(long)r * F + f] - mean;
+      s += d * d;
+    }
+    part[(long)blockIdx.x * F + f] = s;
+  }
+}
+
+__global__ void bn_apply_kernel(const float* x, const float* psum, const float* psq, int nblk, const float* gamma,
+                                const float* beta, float* mov_mean, float* mov_var, float* save_mean,
+                                float* save_invstd, float* y, int rows, int F, int rows_per_blk, int training,
+                                float eps, float momentum) {
+  const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float mean, var;
+    if (training) {
+      double m = 0.0, q = 0.0;
+      for (int i = 0; i < nblk; ++i) { m += (double)psum[(long)i * F + f]; q += (double)psq[(long)i * F + f]; }
+      mean = (float)(m / rows);
+      var = (float)(q / rows);
+    } else {
+      mean = mov_mean[f];
+      var = mov_var[f];
+    }
+    const float invstd = rsqrtf(var + eps);
+    const float g = gamma[f] * invstd, bta = beta[f];
+    for (int r = r0; r < r1; ++r) y[(long)r * F + f] = (x[(long)r * F + f] - mean) * g + bta;
+    if (blockIdx.x == 0) {
+      if (save_mean) { save_mean[f] = mean; save_invstd[f] = invstd; }
+      if (training && mov_mean) {
+        const float unbiased = var * ((float)rows / (float)max(1, rows - 1));   // fused BN feeds Bessel-corrected var
+        mov_mean[f] = momentum * mov_mean[f] + (1.f - momentum) * mean;
+        mov_var[f] = momentum * mov_var[f] + (1.f - momentum) * unbiased;
+      }
+    }
+  }
+}
+
+// xhat[r][f] = (x - mean) * invstd  (for d gamma = sum dy * xhat)
+__global__ void bn_xhat_kernel(const float* x, const float* mean, const float* invstd, float* xhat, long n, int F) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int f = (int)(i % F);
+    xhat[i] = (x[i] - mean[f]) * invstd[f];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// embedding lookup of the GO-prefixed label sequence (decoder_unimodal.py:66-68, :170)
+__global__ void embed_labels_kernel(const float* emb, const int32_t* labels, int go, float* out, int B, int L, int E) {
+  const int row = blockIdx.x;  // b * L + l
+  const int b = row / L, l = row % L;
+  const int tok = (l == 0) ? go : labels[(long)b * L + l - 1];
+  for (int e = threadIdx.x; e < E; e += blockDim.x) out[(long)row * E + e] = emb[(long)tok * E + e];
+}
+
+// d emb[v, :] = sum over rows whose input token == v (deterministic: one block per vocabulary row)
+__global__ void embed_grad_kernel(const float* dx, const int32_t* labels, int go, float* demb, int B, int L, int E, int V) {
+  const int v = blockIdx.x;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float s = 0.f;
+    for (int row = 0; row < B * L; ++row) {
+      const int b = row / L, l = row % L;
+      const int tok = (l == 0) ? go : labels[(long)b * L + l - 1];
+      if (tok == v) s += dx[(long)row * E + e];
+    }
+    demb[(long)v * E + e] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// seq2seq.sequence_loss (seq2seq.py:165-171): masked sparse softmax CE averaged over sum(mask)+1e-12
+__global__ void seqlen_sum_kernel(const int32_t* len, int B, int L, float* denom) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) s += (float)min(max(len[b], 0), L);
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) denom[0] = s;
+}
+
+__global__ void seq_loss_kernel(const float* logits, const int32_t* labels, const int32_t* len, const float* denom,
+                                float* row_loss, float* dlogits, int B, int L, int V) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= B * L) return;
+  const int b = row / L, l = row % L;
+  const float* lg = logits + (long)row * V;
+  float* dl = dlogits ? dlogits + (long)row * V : nullptr;
+  const bool valid = l < len[b];
+  if (!valid) {
+    row_loss[row] = 0.f;
+    if (dl) for (int v = 0; v < V; ++v) dl[v] = 0.f;
+    return;
+  }
+  const float inv = 1.f / (denom[0] + 1e-12f);
+  float mx = lg[0];
+  for (int v = 1; v < V; ++v) mx = fmaxf(mx, lg[v]);
+  float s = 0.f;
+  for (int v = 0; v < V; ++v) s += expf(lg[v] - mx);
+  const float lse = mx + logf(s);
+  const int y = labels[row];
+  row_loss[row] = (lse - lg[y]) * inv;
+  if (dl) for (int v = 0; v < V; ++v) dl[v] = (expf(lg[v] - lse) - (v == y ? 1.f : 0.f)) * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// AU regression loss (encoder.py:173-189): pred = sigmoid(z), target = clip(aus,0,3)/3,
+// loss = sum_w (pred - tgt)^2 / sum_w  over valid frames x 2 units;  dz = weight * 2 (pred-tgt) pred (1-pred) / sum_w
+__global__ void au_loss_kernel(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz,
+                               int B, int T, float weight) {
+  __shared__ float red[4];
+  float cnt = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) cnt += 2.f * (float)min(max(len[b], 0), T);
+  cnt = block_sum_256(cnt, red);
+  const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+  for (int row = blockIdx.x * 256 + threadIdx.x; row < B * T; row += gridDim.x * 256) {
+    const int b = row / T, t = row % T;
+    float l = 0.f;
+    for (int k = 0; k < 2; ++k) {
+      float d = 0.f;
+      if (t < len[b]) {
+        const float p = sigmoidf_(z[(long)row * 2 + k]);
+        const float tg = fminf(fmaxf(aus[(long)row * 2 + k], 0.f), 3.f) / 3.f;
+        l += (p - tg) * (p - tg) * inv;
+        d = weight * 2.f * (p - tg) * p * (1.f - p) * inv;
+      }
+      if (dz) dz[(long)row * 2 + k] = d;
+    }
+    row_loss[row] = l * weight;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// normed Bahdanau score vector: vn = g * v / |v|   and its backward
+__global__ void normed_v_kernel(const float* v, const float* g, float* vn, int H) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int h = threadIdx.x; h < H; h += 256) s += v[h] * v[h];
+  s = block_sum_256(s, red);
+  const float sc = g[0] * rsqrtf(s);
+  for (int h = threadIdx.x; h < H; h += 256) vn[h] = v[h] * sc;
+}
+__global__ void normed_v_bwd_kernel(const float* v, const float* g, const float* dvn, float* dv, float* dg, int H) {
+  __shared__ float red[4];
+  float s = 0.f, d = 0.f;
+  for (int h = threadIdx.x; h < H; h += 256) { s += v[h] * v[h]; d += v[h] * dvn[h]; }
+  s = block_sum_256(s, red);
+  d = block_sum_256(d, red);
+  const float nrm = sqrtf(s);
+  for (int h = threadIdx.x; h < H; h += 256) dv[h] = g[0] / nrm * (dvn[h] - d * v[h] / s);
+  if (threadIdx.x == 0) dg[0] = d / nrm;
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimiser (seq2seq.py:175-178, :195-199, :245-246, :259-280)
+// 1) L2: g += l2 * w on the RNN kernels, reg partial = 0.5 * l2 * sum w^2
+// 2) partial sums of g^2  ->  global norm
+// 3) Adam with clip-by-global-norm folded in; step counter and lr warm-up live on the device
+struct Seg { long off, n; };
+struct SegLaunch { int nseg; Seg seg[AVSR_MAX_SEGMENTS]; };
+
+__global__ void l2_grad_kernel(const SegLaunch S, const float* w, float* g, float l2, float* part) {
+  __shared__ float red[4];
+  const Seg sg = S.seg[blockIdx.y];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < sg.n; i += (long)gridDim.x * 256) {
+    const float x = w[sg.off + i];
+    g[sg.off + i] += l2 * x;
+    s += x * x;
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = 0.5f * l2 * s;
+}
+
+__global__ void sumsq_partial_kernel(const float* g, long n, float* part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// out[0] = scale * (sqrt ? sqrt(sum part) : sum part) [+ out[0] if accumulate]
+__global__ void reduce_scalar_kernel(const float* part, int n, float* out, int do_sqrt, int accumulate, float scale) {
+  __shared__ double dred[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)part[i];
+  dred[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) dred[threadIdx.x] += dred[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double v = dred[0];
+    if (do_sqrt) v = sqrt(v);
+    v *= scale;
+    out[0] = accumulate ? out[0] + (float)v : (float)v;
+  }
+}
+
+// hyper: [0] step (as float-exact int32 via reinterpret), see avsr_adam_step
+__global__ void adam_kernel(float* p, float* g, float* m, float* v, long n, const float* gnorm, int32_t* step,
+                            float lr, int warmup, float clip, float b1, float b2, float eps, float grad_scale) {
+  const int t = step[0] + 1;
+  float lr_now = lr;
+  if (warmup > 0) lr_now *= fminf(1.0f, (float)t / (float)warmup);   // min(1, (global_step + 1) / warmup)
+  const double c1 = 1.0 - exp((double)t * log((double)b1));
+  const double c2 = 1.0 - exp((double)t * log((double)b2));
+  const float lr_t = (float)((double)lr_now * sqrt(c2) / c1);
+  float scale = grad_scale;
+  if (clip > 0.f) scale *= clip / fmaxf(gnorm[0], clip);   // gnorm is the norm of the already-scaled gradient   // tf.clip_by_global_norm
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+__global__ void step_inc_kernel(int32_t* step) { step[0] += 1; }
+
+static inline int blocks_for(long n, int per = 256, int cap = 2048) {
+  long b = (n + per - 1) / per;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace avsr
+
+using namespace avsr;
+#define S_(x) ((hipStream_t)(x))
+
+extern "C" int avsr_transpose(const avsr_transpose_job* jobs, int32_t n, void* stream) {
+  if (!jobs || n <= 0) return AVSR_ERR_ARG;
+  for (int i0 = 0; i0 < n; i0 += AVSR_MAX_TRANSPOSE) {
+    TLaunch L;
+    L.njob = (n - i0) < AVSR_MAX_TRANSPOSE ? (n - i0) : AVSR_MAX_TRANSPOSE;
+    int maxtiles = 1;
+    for (int i = 0; i < L.njob; ++i) {
+      const avsr_transpose_job& j = jobs[i0 + i];
+      if (!j.src || !j.dst || j.rows <= 0 || j.cols <= 0) return AVSR_ERR_ARG;
+      L.job[i] = TJob{j.src, j.dst, j.rows, j.cols};
+      const int tiles = ((j.rows + 31) / 32) * ((j.cols + 31) / 32);
+      if (tiles > maxtiles) maxtiles = tiles;
+    }
+    if (maxtiles > 1024) maxtiles = 1024;
+    hipLaunchKernelGGL(transpose_kernel, dim3(maxtiles, 1, L.njob), dim3(256), 0, S_(stream), L);
+    AVSR_CHECK_LAUNCH();
+  }
+  return AVSR_OK;
+}
+
+extern "C" int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, int32_t F, float alpha, float beta,
+                           float* out, float* scratch, int64_t scratch_floats, void* stream) {
+  if (!a || !a->ptr || !out || !scratch || rows <= 0 || F <= 0) return AVSR_ERR_ARG;
+  int rpb = 128;
+  int nblk = (rows + rpb - 1) / rpb;
+  if ((long)nblk * F > scratch_floats) {
+    nblk = (int)(scratch_floats / F);
+    if (nblk < 1) return AVSR_ERR_ARG;
+    rpb = (rows + nblk - 1) / nblk;
+    nblk = (rows + rpb - 1) / rpb;
+  }
+  const int th = F >= 256 ? 256 : ((F + 63) / 64) * 64;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(th), 0, S_(stream), a->ptr, (long)a->ld, a->T, (long)a->ldo,
+                     b ? b->ptr : nullptr, b ? (long)b->ld : 0, b ? b->T : 0, b ? (long)b->ldo : 0, scratch, rows, F, rpb);
+  AVSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 255) / 256), dim3(256), 0, S_(stream), scratch, nblk, out, F, alpha, beta);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_batchnorm_fwd(const float* x, float* y, int32_t rows, int32_t F, const float* gamma,
+                                  const float* beta, float* moving_mean, float* moving_var, float* save_mean,
+                                  float* save_invstd, int32_t training, float* scratch, int64_t scratch_floats,
+                                  void* stream) {
+  if (!x || !y || !gamma || !beta || rows <= 0 || F <= 0 || !scratch) return AVSR_ERR_ARG;
+  int rpb = 64;
+  int nblk = (rows + rpb - 1) / rpb;
+  if ((long)2 * nblk * F > scratch_floats) {
+    nblk = (int)(scratch_floats / (2 * F));
+    if (nblk < 1) return AVSR_ERR_ARG;
+    rpb = (rows + nblk - 1) / nblk;
+    nblk = (rows + rpb - 1) / rpb;
+  }
+  float* psum = scratch;
+  float* psq = scratch + (long)nblk * F;
+  const int th = F >= 256 ? 256 : ((F + 63) / 64) * 64;
+  if (training) {
+    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(nblk), dim3(th), 0, S_(stream), x, psum, rows, F, rpb);
+    AVSR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_partial_sq_kernel, dim3(nblk), dim3(th), 0, S_(stream), x, psum, nblk, psq, rows, F, rpb);
+    AVSR_CHECK_LAUNCH();
+  } else if (!moving_mean || !moving_var) {
+    return AVSR_ERR_ARG;
+  }
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk), dim3(th), 0, S_(stream), x, psum, psq, nblk, gamma, beta, moving_mean,
+                     moving_var, save_mean, save_invstd, y, rows, F, rpb, training, 1e-3f, 0.99f);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_batchnorm_xhat(const float* x, const float* mean, const float* invstd, float* xhat, int32_t rows,
+                                   int32_t F, void* stream) {
+  if (!x || !mean || !invstd || !xhat) return AVSR_ERR_ARG;
+  const long n = (long)rows * F;
+  hipLaunchKernelGGL(bn_xhat_kernel, dim3(blocks_for(n)), dim3(256), 0, S_(stream), x, mean, invstd, xhat, n, F);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_embed_labels(const float* emb, const int32_t* labels, int32_t go_id, float* out, int32_t B,
+                                 int32_t L, int32_t E, void* stream) {
+  if (!emb || !labels || !out) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(embed_labels_kernel, dim3(B * L), dim3(E >= 256 ? 256 : ((E + 63) / 64) * 64), 0, S_(stream), emb,
+                     labels, go_id, out, B, L, E);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_embed_grad(const float* dx, const int32_t* labels, int32_t go_id, float* demb, int32_t B, int32_t L,
+                               int32_t E, int32_t V, void* stream) {
+  if (!dx || !labels || !demb) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(embed_grad_kernel, dim3(V), dim3(E >= 256 ? 256 : ((E + 63) / 64) * 64), 0, S_(stream), dx, labels,
+                     go_id, demb, B, L, E, V);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_seq_loss(const float* logits, const int32_t* labels, const int32_t* labels_len, float* denom,
+                             int32_t compute_denom, float* row_loss, float* dlogits, int32_t B, int32_t L, int32_t V,
+                             void* stream) {
+  if (!logits || !labels || !labels_len || !denom || !row_loss) return AVSR_ERR_ARG;
+  if (compute_denom) {
+    hipLaunchKernelGGL(seqlen_sum_kernel, dim3(1), dim3(256), 0, S_(stream), labels_len, B, L, denom);
+    AVSR_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(seq_loss_kernel, dim3((B * L + 127) / 128), dim3(128), 0, S_(stream), logits, labels, labels_len,
+                     denom, row_loss, dlogits, B, L, V);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_au_loss(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz, int32_t B,
+                            int32_t T, float weight, void* stream) {
+  if (!z || !aus || !len || !row_loss) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(au_loss_kernel, dim3(blocks_for((long)B * T, 256, 256)), dim3(256), 0, S_(stream), z, aus, len,
+                     row_loss, dz, B, T, weight);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_normed_v(const float* v, const float* g, float* vn, int32_t H, void* stream) {
+  if (!v || !g || !vn) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(normed_v_kernel, dim3(1), dim3(256), 0, S_(stream), v, g, vn, H);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+extern "C" int avsr_normed_v_bwd(const float* v, const float* g, const float* dvn, float* dv, float* dg, int32_t H,
+                                 void* stream) {
+  if (!v || !g || !dvn || !dv || !dg) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(normed_v_bwd_kernel, dim3(1), dim3(256), 0, S_(stream), v, g, dvn, dv, dg, H);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_reduce_scalar(const float* part, int32_t n, float* out, int32_t do_sqrt, int32_t accumulate,
+                                  float scale, void* stream) {
+  if (!part || !out || n <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, S_(stream), part, n, out, do_sqrt, accumulate, scale);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_l2_regularise(const int64_t* seg_off, const int64_t* seg_n, int32_t nseg, const float* params,
+                                  float* grads, float l2, float* loss_accum, float* scratch, void* stream) {
+  if (nseg <= 0) return AVSR_OK;
+  if (!seg_off || !seg_n || !params || !grads || !scratch || nseg > AVSR_MAX_SEGMENTS) return AVSR_ERR_ARG;
+  SegLaunch S;
+  S.nseg = nseg;
+  for (int i = 0; i < nseg; ++i) S.seg[i] = Seg{(long)seg_off[i], (long)seg_n[i]};
+  const int gx = 64;
+  hipLaunchKernelGGL(l2_grad_kernel, dim3(gx, nseg), dim3(256), 0, S_(stream), S, params, grads, l2, scratch);
+  AVSR_CHECK_LAUNCH();
+  if (loss_accum) {
+    hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, S_(stream), scratch, gx * nseg, loss_accum, 0, 1, 1.0f);
+    AVSR_CHECK_LAUNCH();
+  }
+  return AVSR_OK;
+}
+
+extern "C" int avsr_global_norm(const float* grads, int64_t n, float grad_scale, float* norm_out, float* scratch,
+                                void* stream) {
+  if (!grads || !norm_out || !scratch || n <= 0) return AVSR_ERR_ARG;
+  const int gx = blocks_for(n, 1024, 1024);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(gx), dim3(256), 0, S_(stream), grads, (long)n, scratch);
+  AVSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, S_(stream), scratch, gx, norm_out, 1, 0, grad_scale);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_adam_step(float* params, float* grads, float* m, float* v, int64_t n, const float* global_norm,
+                              int32_t* step, float lr, int32_t warmup_steps, float clip_norm, float grad_scale,
+                              void* stream) {
+  if (!params || !grads || !m || !v || !step || n <= 0) return AVSR_ERR_ARG;
+  if (clip_norm > 0.f && !global_norm) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 1024, 2048)), dim3(256), 0, S_(stream), params, grads, m, v, (long)n,
+                     global_norm, step, lr, warmup_steps, clip_norm, 0.9f, 0.999f, 1e-8f, grad_scale);
+  AVSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, S_(stream), step);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}

@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void step_kernel(const StepLaunch L) {
       // p0 out (row stride s0), p1 add (row stride s1)
       if (tk.bias) z += tk.bias[n];
       if (tk.p1) z += tk.p1[(long)b * tk.s1 + n];
-      tk.p0[(long)b * tk.s0 + n] = apply_act(z, tk.act);
+      z = apply_act(z, tk.act);
+      if (tk.len && t >= tk.len[b]) z = 0.f;   // dynamic_rnn / impute_finished: zero output past the valid length
+      tk.p0[(long)b * tk.s0 + n] = z;
       return;
     }
     // ---- EP_LSTM_BWD: n = unit.  p0 gates, p1 cs, p2 dgates record, p3 dG rolling out [B,4H],

@@ -33,6 +33,9 @@ extern "C" {
 #define AVSR_MAX_LAYERS 4
 #define AVSR_MAX_MECH 4
 #define AVSR_MAX_STACKS 4
+#define AVSR_HAVE_ATTN 1
+#define AVSR_MAX_TRANSPOSE 16
+#define AVSR_MAX_SEGMENTS 32
 
 int avsr_abi_version(void);
 
@@ -119,6 +122,165 @@ typedef struct avsr_rnn_stack {
 
 int avsr_rnn_fwd(const avsr_rnn_stack* stacks, int32_t n_stacks, void* stream);
 int avsr_rnn_bwd(const avsr_rnn_stack* stacks, int32_t n_stacks, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Attention-wrapped LSTM over a sequence.  Replaces
+ *   seq2seq.dynamic_decode(BasicDecoder(AttentionWrapper(LSTMCell, [mechanisms]), helper, Dense(V)))
+ * for the unimodal and bimodal decoders (avsr/decoder_unimodal.py:299-352 train, :176-217 greedy;
+ * avsr/decoder_bimodal.py:227-277, :279-326) and tf.nn.dynamic_rnn over the AttentionWrapper'd top
+ * audio layer of AV-Align (avsr/encoder.py:265-290).
+ *
+ * Per step l (AttentionWrapper.call):  x' = [x_l, attention_{l-1}] -> LSTM -> cell_out;
+ * for each mechanism m: alpha_m = softmax(score_m(cell_out)), ctx_m = alpha_m . values_m,
+ * att_m = [cell_out, ctx_m] . W_att,m;  attention_l = concat_m att_m.
+ * Steps with l >= steplen[b] are frozen (state copy-through, zero outputs).
+ *
+ * mode 0 (train / encoder): x_l . Wx is hoisted by the caller into `gates` (avsr_gemm).
+ * mode 1 (greedy):          x_l = embedding[tok[b]]; after each step logits = out . Wout + bout,
+ *                           ids[b,l] = argmax (0 once finished), steplen[b] is set when EOS is emitted
+ *                           (GreedyEmbeddingHelper + impute_finished).  The caller initialises
+ *                           steplen[b] = L and tok[b] = GO, and may run steps in slices [l0, l1).
+ *
+ * Buffers (A = n_mech * H):
+ *   gates [B][L][H][4], cs [B][L][H], cell_out [B][L+1][H] (slot l+1 = step l; slot 0 = h0, written
+ *   by the op), att [B][L+1][A] (slot l+1 = attention after step l; slot 0 zero, written by the op),
+ *   state scratch 4*B*H.
+ *   per mechanism: scores [B][L][T] raw scores (Luong: un-scaled), ctx [B][L][D], pq [B][L][H]
+ *   (Bahdanau), pstat [L][2][nchunk][B], pctx scratch [nchunk][B][D], with nchunk = ceil(T / chunk).
+ * Backward adds: dgates [B][L][H][4], dstate scratch 12*B*H, datt [B][L][A], dq [B][L][H];
+ *   per mechanism dscores [B][L][T], dctx [B][L][D], dpq [B][L][H] (Bahdanau), pdq scratch
+ *   [nchunk][B][H].  Inputs datt_ext [B][L][A] / dcell_ext [B][L][H]: gradient of the loss wrt the
+ *   emitted attention / cell output of every step (from the output layer, or from the consumer of the
+ *   encoder memory); either may be NULL.  Outputs dh0, dc0 [B][H].
+ */
+typedef struct avsr_attn_mech {
+  int32_t type;                 /* 0 luong, 1 scaled_luong, 2 bahdanau, 3 normed_bahdanau */
+  int32_t T, D, chunk;
+  const int32_t* len;           /* [B] memory lengths */
+  const float* keys;            /* [B][T][H] */
+  const float* values;          /* row (b,t) at values + b*values_sb + t*values_st */
+  int64_t values_sb, values_st;
+  const float* g;               /* scalar: scaled_luong */
+  const float* v;               /* [H] Bahdanau (normed: g*v/|v|) */
+  const float* bq;              /* [H] normed_bahdanau bias */
+  const float* wq_t;            /* [H][H]   query_layer^T */
+  const float* wq;              /* [H][H]   query_layer */
+  const float* watt_t;          /* [H][H+D] attention_layer^T */
+  const float* watt;            /* [H+D][H] attention_layer */
+  float* scores;
+  float* ctx;
+  float* pq;
+  float* pstat;
+  float* pctx;
+  float* dscores;
+  float* dctx;
+  float* dpq;
+  float* pdq;
+} avsr_attn_mech;
+
+typedef struct avsr_attn_rnn {
+  int32_t B, L, H, E, n_mech, output_attention, V, mode;
+  int32_t go_id, eos_id;
+  int32_t* steplen;             /* [B] valid steps (labels_len / audio len); greedy: updated in place */
+  const float* wt;              /* [4H][E + A + H] */
+  const float* w;               /* [E + A + H][4H] */
+  const float* bias;            /* [H][4] */
+  float* gates;
+  float* cs;
+  float* cell_out;
+  float* att;
+  const float* h0;
+  const float* c0;
+  float* state;
+  float* h_final;
+  float* c_final;
+  avsr_attn_mech mech[AVSR_MAX_MECH];
+  /* greedy */
+  const float* embedding;       /* [V][E] */
+  const float* wout_t;          /* [V][O], O = A if output_attention else H */
+  const float* bout;            /* [V] */
+  float* logits;                /* [B][L][V] (greedy: per-step logits, zero once finished) */
+  int32_t* ids;                 /* [B][L] */
+  int32_t* tok;                 /* [B] */
+  int32_t* n_unfinished;        /* [1] device counter, recomputed after every greedy step */
+  /* backward */
+  float* dgates;
+  float* dstate;
+  float* datt;
+  float* dq;
+  const float* datt_ext;
+  const float* dcell_ext;
+  float* dh0;
+  float* dc0;
+  const float* dh_final;        /* [B][H] gradient wrt the final cell state (AV-Align: from the decoder init) */
+  const float* dc_final;
+} avsr_attn_rnn;
+
+int avsr_attn_rnn_fwd(const avsr_attn_rnn* d, int32_t l_begin, int32_t l_end, void* stream);
+int avsr_attn_rnn_bwd(const avsr_attn_rnn* d, void* stream);
+
+/* Post-loop helpers of the attention backward (see csrc/attention.hip). */
+int avsr_attn_alpha_rows(float* scores, const float* dscores, const int32_t* len, const int32_t* steplen,
+                         const float* g, float* rowdot, int32_t B, int32_t L, int32_t T, void* stream);
+int avsr_bahdanau_dkeys(const float* keys, const float* pq, int64_t pq_sb, int64_t pq_sl, const float* dscores,
+                        const float* v, const float* bq, const int32_t* len, float* dkeys, float* dv_part,
+                        int32_t B, int32_t L, int32_t T, int32_t H, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Memory-bound helpers (csrc/elementwise.hip).  scratch buffers are caller-provided device floats. */
+typedef struct avsr_transpose_job {
+  const float* src;             /* [rows][cols] */
+  float* dst;                   /* [cols][rows] */
+  int32_t rows, cols;
+} avsr_transpose_job;
+/* jobs is a HOST array (copied into kernel arguments). */
+int avsr_transpose(const avsr_transpose_job* jobs, int32_t n, void* stream);
+
+/* out[f] = alpha * sum_r a[r][f] * (b ? b[r][f] : 1) + beta*out[f]   (bias / BN gradients); scratch >= 2*F floats */
+int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, int32_t F, float alpha, float beta, float* out,
+                float* scratch, int64_t scratch_floats, void* stream);
+
+/* tf.layers.batch_normalization(axis=-1, momentum=.99, eps=1e-3) over `rows` = B*T rows incl. padding
+ * (avsr/encoder.py:44-50).  training=1: batch statistics + moving-average update; 0: moving statistics. */
+int avsr_batchnorm_fwd(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta,
+                       float* moving_mean, float* moving_var, float* save_mean, float* save_invstd, int32_t training,
+                       float* scratch, int64_t scratch_floats, void* stream);
+int avsr_batchnorm_xhat(const float* x, const float* mean, const float* invstd, float* xhat, int32_t rows, int32_t F,
+                        void* stream);
+
+/* embedding_lookup(labels_padded_GO) (avsr/decoder_unimodal.py:66-68, :170) and its gradient. */
+int avsr_embed_labels(const float* emb, const int32_t* labels, int32_t go_id, float* out, int32_t B, int32_t L,
+                      int32_t E, void* stream);
+int avsr_embed_grad(const float* dx, const int32_t* labels, int32_t go_id, float* demb, int32_t B, int32_t L, int32_t E,
+                    int32_t V, void* stream);
+
+/* seq2seq.sequence_loss (avsr/seq2seq.py:165-171): row_loss[b*L+l] = CE * mask / (sum(mask) + 1e-12) and
+ * d loss / d logits.  denom[0] = sum(mask) is computed when compute_denom=1 (single GPU) or supplied
+ * (data parallel: all-reduced by the caller). */
+int avsr_seq_loss(const float* logits, const int32_t* labels, const int32_t* labels_len, float* denom,
+                  int32_t compute_denom, float* row_loss, float* dlogits, int32_t B, int32_t L, int32_t V, void* stream);
+
+/* AU regression loss (avsr/encoder.py:173-189); z = pre-sigmoid Dense(2) outputs [B][T][2]. */
+int avsr_au_loss(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz, int32_t B, int32_t T,
+                 float weight, void* stream);
+
+int avsr_normed_v(const float* v, const float* g, float* vn, int32_t H, void* stream);
+int avsr_normed_v_bwd(const float* v, const float* g, const float* dvn, float* dv, float* dg, int32_t H, void* stream);
+
+/* out[0] (+)= scale * (do_sqrt ? sqrt(sum part) : sum part) */
+int avsr_reduce_scalar(const float* part, int32_t n, float* out, int32_t do_sqrt, int32_t accumulate, float scale,
+                       void* stream);
+
+/* l2_regularizer on the RNN kernels (avsr/seq2seq.py:175-178): grads += l2*w; loss_accum += 0.5*l2*sum w^2.
+ * seg_off/seg_n are HOST arrays of flat-buffer segments; scratch >= 64*nseg floats. */
+int avsr_l2_regularise(const int64_t* seg_off, const int64_t* seg_n, int32_t nseg, const float* params, float* grads,
+                       float l2, float* loss_accum, float* scratch, void* stream);
+/* norm_out[0] = grad_scale * ||grads||_2 ; scratch >= 1024 floats */
+int avsr_global_norm(const float* grads, int64_t n, float grad_scale, float* norm_out, float* scratch, void* stream);
+/* tf.clip_by_global_norm + tf.train.AdamOptimizer(eps=1e-8) + linear warm-up (avsr/seq2seq.py:195-199, :245-246,
+ * :275-280).  step[0] (device int32) is read as global_step and incremented. clip_norm <= 0 disables clipping. */
+int avsr_adam_step(float* params, float* grads, float* m, float* v, int64_t n, const float* global_norm, int32_t* step,
+                   float lr, int32_t warmup_steps, float clip_norm, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

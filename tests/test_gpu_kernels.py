@@ -51,7 +51,8 @@ def test_gemm_splitk_and_two_level_rows():
     # C with two-level rows: Y[b, t+1, :] = G[b,t,:] @ W
     W = rng.standard_normal((N, F)).astype(np.float32)
     y = torch.zeros(Bn, T + 2, F, device="cuda")
-    ops.gemm(ops.mat(g, N), ops.mat(dev(W), F), ops.mat(y, F, T=T, ldo=(T + 2) * F, offset=F), Bn * T, F, N)
+    w = dev(W)
+    ops.gemm(ops.mat(g, N), ops.mat(w, F), ops.mat(y, F, T=T, ldo=(T + 2) * F, offset=F), Bn * T, F, N)
     torch.cuda.synchronize()
     yr = np.zeros((Bn, T + 2, F))
     yr[:, 1:T + 1] = G.astype(np.float64) @ W.astype(np.float64)
@@ -65,7 +66,8 @@ def test_gemm_batched():
     A = rng.standard_normal((nb, K, M)).astype(np.float32)
     B = rng.standard_normal((nb, K, N)).astype(np.float32)
     c = torch.zeros(nb, M, N, device="cuda")
-    ops.gemm(ops.mat(dev(A), M), ops.mat(dev(B), N), ops.mat(c, N), M, N, K, trans_a=1, batch=nb,
+    a, b = dev(A), dev(B)          # keep alive: ops.mat only captures the raw device pointer
+    ops.gemm(ops.mat(a, M), ops.mat(b, N), ops.mat(c, N), M, N, K, trans_a=1, batch=nb,
              strides=(K * M, K * N, M * N))
     torch.cuda.synchronize()
     ref = np.einsum("bkm,bkn->bmn", A.astype(np.float64), B.astype(np.float64))
