@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
                 ("trans_a", C.c_int32), ("trans_b", C.c_int32),
                 ("alpha", C.c_float), ("beta", C.c_float), ("batch", C.c_int32),
                 ("stride_a", C.c_int64), ("stride_b", C.c_int64), ("stride_c", C.c_int64),
+                ("alpha_dev", C.c_void_p),
                 ("splitk", C.c_int32), ("pad_", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
 
@@ -53,7 +54,45 @@ class RnnStack(C.Structure):
                 ("layer", RnnLayer * MAX_LAYERS)]
 
 
-_STRUCTS = {"avsr_mat": Mat, "avsr_gemm_desc": GemmDesc, "avsr_rnn_layer": RnnLayer, "avsr_rnn_stack": RnnStack}
+class AttnMech(C.Structure):
+    _fields_ = [("type", C.c_int32), ("T", C.c_int32), ("D", C.c_int32), ("chunk", C.c_int32),
+                ("len", C.c_void_p), ("keys", C.c_void_p), ("values", C.c_void_p),
+                ("values_sb", C.c_int64), ("values_st", C.c_int64),
+                ("g", C.c_void_p), ("v", C.c_void_p), ("bq", C.c_void_p),
+                ("wq_t", C.c_void_p), ("wq", C.c_void_p), ("watt_t", C.c_void_p), ("watt", C.c_void_p),
+                ("scores", C.c_void_p), ("ctx", C.c_void_p), ("pq", C.c_void_p), ("pstat", C.c_void_p),
+                ("pctx", C.c_void_p), ("dscores", C.c_void_p), ("dctx", C.c_void_p), ("dpq", C.c_void_p),
+                ("pdq", C.c_void_p)]
+
+
+class AttnRnn(C.Structure):
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("E", C.c_int32),
+                ("n_mech", C.c_int32), ("output_attention", C.c_int32), ("V", C.c_int32), ("mode", C.c_int32),
+                ("go_id", C.c_int32), ("eos_id", C.c_int32),
+                ("steplen", C.c_void_p), ("wt", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+                ("gates", C.c_void_p), ("cs", C.c_void_p), ("cell_out", C.c_void_p), ("att", C.c_void_p),
+                ("h0", C.c_void_p), ("c0", C.c_void_p), ("state", C.c_void_p),
+                ("h_final", C.c_void_p), ("c_final", C.c_void_p),
+                ("mech", AttnMech * MAX_MECH),
+                ("embedding", C.c_void_p), ("wout_t", C.c_void_p), ("bout", C.c_void_p),
+                ("logits", C.c_void_p), ("ids", C.c_void_p), ("tok", C.c_void_p), ("n_unfinished", C.c_void_p),
+                ("dgates", C.c_void_p), ("dstate", C.c_void_p), ("datt", C.c_void_p), ("dq", C.c_void_p),
+                ("datt_ext", C.c_void_p), ("dcell_ext", C.c_void_p), ("dh0", C.c_void_p), ("dc0", C.c_void_p),
+                ("dh_final", C.c_void_p), ("dc_final", C.c_void_p)]
+
+
+class TransposeJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
+_STRUCTS = {"avsr_mat": Mat, "avsr_gemm_desc": GemmDesc, "avsr_rnn_layer": RnnLayer, "avsr_rnn_stack": RnnStack,
+            "avsr_attn_mech": AttnMech, "avsr_attn_rnn": AttnRnn, "avsr_transpose_job": TransposeJob}
+
+EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_attn_rnn_fwd",
+           "avsr_attn_rnn_bwd", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_colsum",
+           "avsr_batchnorm_fwd", "avsr_batchnorm_xhat", "avsr_embed_labels", "avsr_embed_grad", "avsr_seq_loss",
+           "avsr_au_loss", "avsr_normed_v", "avsr_normed_v_bwd", "avsr_reduce_scalar", "avsr_l2_regularise",
+           "avsr_global_norm", "avsr_adam_step"]
 
 _lib = None
 
@@ -78,6 +117,37 @@ def load():
     lib.avsr_abi_version.restype = C.c_int
     lib.avsr_sizeof.restype = C.c_int64
     lib.avsr_sizeof.argtypes = [C.c_char_p]
+    for sym in EXPORTS:
+        if not hasattr(lib, sym):
+            raise AvsrError("libavsr_hip.so does not export %s" % sym)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    sigs = {
+        "avsr_gemm": [C.POINTER(GemmDesc), vp],
+        "avsr_rnn_fwd": [C.POINTER(RnnStack), i32, vp],
+        "avsr_rnn_bwd": [C.POINTER(RnnStack), i32, vp],
+        "avsr_attn_rnn_fwd": [C.POINTER(AttnRnn), i32, i32, vp],
+        "avsr_attn_rnn_bwd": [C.POINTER(AttnRnn), vp],
+        "avsr_attn_alpha_rows": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+        "avsr_bahdanau_dkeys": [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+        "avsr_transpose": [C.POINTER(TransposeJob), i32, vp],
+        "avsr_colsum": [C.POINTER(Mat), C.POINTER(Mat), i32, i32, f32, f32, vp, vp, i64, vp],
+        "avsr_batchnorm_fwd": [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp],
+        "avsr_batchnorm_xhat": [vp, vp, vp, vp, i32, i32, vp],
+        "avsr_embed_labels": [vp, vp, i32, vp, i32, i32, i32, vp],
+        "avsr_embed_grad": [vp, vp, i32, vp, i32, i32, i32, i32, vp],
+        "avsr_seq_loss": [vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp],
+        "avsr_au_loss": [vp, vp, vp, vp, vp, i32, i32, f32, vp],
+        "avsr_normed_v": [vp, vp, vp, i32, vp],
+        "avsr_normed_v_bwd": [vp, vp, vp, vp, vp, i32, vp],
+        "avsr_reduce_scalar": [vp, i32, vp, i32, i32, f32, vp],
+        "avsr_l2_regularise": [C.POINTER(i64), C.POINTER(i64), i32, vp, vp, f32, vp, vp, vp],
+        "avsr_global_norm": [vp, i64, f32, vp, vp, vp],
+        "avsr_adam_step": [vp, vp, vp, vp, i64, vp, vp, f32, i32, f32, f32, vp],
+    }
+    for name, at in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = at
+        fn.restype = C.c_int
     for name, st in _STRUCTS.items():
         n = lib.avsr_sizeof(name.encode())
         if n != C.sizeof(st):

@@ -1,0 +1,105 @@
+"""Hyper-parameters the hot path reads (mirror of the HParams bag, avsr/avsr.py:150-198)."""
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+LUONG_TYPES = ("luong", "scaled_luong")
+BAHDANAU_TYPES = ("bahdanau", "normed_bahdanau")
+ATT_CODE = {"luong": 0, "scaled_luong": 1, "bahdanau": 2, "normed_bahdanau": 3}
+
+
+@dataclass
+class ModelConfig:
+    architecture: str = "unimodal"
+    encoder_type: str = "unidirectional"
+    cell_type: str = "lstm"
+    video_units: Optional[Tuple[int, ...]] = None      # encoder_units_per_layer[0]; None = no video stream
+    audio_units: Optional[Tuple[int, ...]] = (256, 256, 256)
+    decoder_units: Tuple[int, ...] = (256,)
+    attention_type: Tuple[Tuple[str, ...], Tuple[str, ...]] = (("scaled_luong",), ("scaled_luong",))
+    enable_attention: bool = True
+    embedding_size: int = 128
+    vocab_size: int = 31
+    go_id: int = 30
+    eos_id: int = 29
+    video_feat: int = 128
+    audio_feat: int = 80
+    batch_normalisation: bool = True
+    regress_aus: bool = False
+    au_loss_weight: float = 10.0
+    recurrent_l2: Optional[float] = 1e-4
+    clip_gradients: bool = True
+    max_gradient_norm: float = 1.0
+    learning_rate: float = 1e-3
+    warmup_steps: int = 750
+    max_label_length: int = 150
+    use_dropout: bool = False
+    sampling_probability: float = 0.0
+
+    # -- same helpers/validation rules as the reference wiring (error types as in the reference) --
+    def streams(self) -> List[str]:
+        s = []
+        if self.video_units is not None:
+            s.append("video")
+        if self.audio_units is not None:
+            s.append("audio")
+        return s
+
+    def directions(self) -> List[str]:
+        return ["fw", "bw"] if self.encoder_type == "bidirectional" else ["fw"]
+
+    def units(self, stream):
+        return self.video_units if stream == "video" else self.audio_units
+
+    def feat(self, stream):
+        return self.video_feat if stream == "video" else self.audio_feat
+
+    def memory_depth(self, stream: str) -> int:
+        return self.units(stream)[-1] * (2 if self.encoder_type == "bidirectional" else 1)
+
+    def decoder_memories(self) -> List[Tuple[str, str]]:
+        """[(stream, attention_type)] in AttentionWrapper order (decoder_bimodal.py:184-223: video first)."""
+        if not self.enable_attention:
+            return []
+        if self.architecture == "bimodal":
+            out = []
+            if self.video_units is not None:
+                out += [("video", t) for t in self.attention_type[0]]
+            if self.audio_units is not None:
+                out += [("audio", t) for t in self.attention_type[1]]
+            return out
+        stream = "audio" if self.audio_units is not None else "video"
+        return [(stream, t) for t in self.attention_type[1]]
+
+    def output_attention(self) -> bool:
+        mems = self.decoder_memories()
+        return bool(mems) and mems[-1][1] in LUONG_TYPES
+
+    def validate(self):
+        if self.architecture not in ("unimodal", "bimodal", "av_align"):
+            raise Exception("Unknown architecture")                                   # seq2seq.py:66
+        if self.encoder_type not in ("unidirectional", "bidirectional"):
+            raise Exception("Allowed encoder types: `unidirectional`, `bidirectional`")  # encoder.py:146
+        if self.cell_type == "gru":
+            raise NotImplementedError("GRU cells are not built in the HIP engine yet (LSTM only this round)")
+        if self.cell_type != "lstm":
+            raise Exception("cell type not supported: {}".format(self.cell_type))      # cells.py:44
+        for types in self.attention_type:
+            for t in types:
+                if t not in ATT_CODE:
+                    raise Exception("unknown attention mechanism")                    # attention.py:86
+        if self.architecture == "av_align":
+            if self.encoder_type != "unidirectional":
+                raise ValueError("AttentiveEncoder implements only `unidirectional` (encoder.py:229)")
+            if self.video_units is None or self.audio_units is None:
+                raise ValueError("av_align needs both a video and an audio stream")
+        if len(self.decoder_units) != 1:
+            raise NotImplementedError("multi-layer decoders are not built yet")
+        if not self.streams():
+            raise Exception("labels are None")                                         # seq2seq.py:94
+        dims = [self.embedding_size, self.decoder_units[0]]
+        for s in self.streams():
+            dims += list(self.units(s)) + [self.feat(s)]
+        if any(d % 4 for d in dims):
+            raise ValueError("feature / unit / embedding sizes must be multiples of 4 for the HIP engine")
+        if self.use_dropout or self.sampling_probability > 0:
+            raise NotImplementedError("dropout / scheduled sampling kernels are not built yet")

@@ -38,6 +38,7 @@ struct GemmArgs {
   MatView A, B;
   float* C; long ldc; int Tc; long ldoc;
   const float* bias;
+  const float* alpha_dev;
   int M, N, K;
   int ta, tb;           // ta: A stored [K][M]; tb: B stored [N][K]
   float alpha, beta;
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 
   // epilogue: C/D layout of mfma 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const bool split = g.splitk > 1;
+  const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         } else {
           float* c = g.C + (long)bz * g.sC +
                      (g.Tc ? (long)(row / g.Tc) * g.ldoc + (long)(row % g.Tc) * g.ldc : (long)row * g.ldc) + col;
-          float v = g.alpha * acc[i][j][r];
+          float v = alpha * acc[i][j][r];
           if (g.beta != 0.f) v += g.beta * *c;
           if (g.bias) v += g.bias[col];
           *c = v;
@@ -200,7 +202,7 @@ __global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
     for (int z = 0; z < g.splitk; ++z) s += g.ws[((long)(bz * g.splitk + z) * g.M + row) * g.N + col];
     float* c = g.C + (long)bz * g.sC +
                (g.Tc ? (long)(row / g.Tc) * g.ldoc + (long)(row % g.Tc) * g.ldc : (long)row * g.ldc) + col;
-    float v = g.alpha * s;
+    float v = (g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha) * s;
     if (g.beta != 0.f) v += g.beta * *c;
     if (g.bias) v += g.bias[col];
     *c = v;
@@ -222,6 +224,7 @@ extern "C" int avsr_gemm(const avsr_gemm_desc* d, void* stream) {
   g.B = MatView{d->B.ptr, d->B.ld, d->B.T, d->B.ldo};
   g.C = d->C.ptr; g.ldc = d->C.ld; g.Tc = d->C.T; g.ldoc = d->C.ldo;
   g.bias = d->bias;
+  g.alpha_dev = d->alpha_dev;
   g.M = d->M; g.N = d->N; g.K = d->K;
   g.ta = d->trans_a; g.tb = d->trans_b;
   g.alpha = d->alpha; g.beta = d->beta;

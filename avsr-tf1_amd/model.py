@@ -1,0 +1,779 @@
+"""Host-side model: the wiring of avsr/seq2seq.py `Seq2SeqModel` (encoders -> AV-Align / dual attention ->
+decoder -> loss -> BPTT -> clip -> Adam) expressed as a sequence of C-ABI calls into libavsr_hip.so.
+
+All arithmetic runs in hand-written HIP kernels (csrc/); this file only owns buffers (torch tensors
+as containers) and the order of calls.  There is no CPU fallback: without the library / a GPU every
+entry point raises.
+
+Reference call sites mirrored here:
+  encoders            avsr/seq2seq.py:30-68  -> avsr/encoder.py:37-55 (BN), :67-143 (uni/bi RNN), :173-189 (AU loss)
+  AV-Align            avsr/encoder.py:224-294
+  decoder init state  avsr/decoder_unimodal.py:126-157, avsr/decoder_bimodal.py:125-166, :480-490
+  decoder train       avsr/decoder_unimodal.py:299-352, avsr/decoder_bimodal.py:227-277
+  greedy decode       avsr/decoder_unimodal.py:176-217, avsr/decoder_bimodal.py:279-326
+  loss / optimiser    avsr/seq2seq.py:135-257, :259-280
+"""
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops, params as PR
+from ._lib import AttnRnn, RnnStack
+from .config import ATT_CODE, BAHDANAU_TYPES, LUONG_TYPES, ModelConfig
+
+
+@dataclass
+class Batch:
+    """Device-side BatchedData (avsr/io_utils.py:8-18).  float32 [B,T,F] inputs, int32 lengths/labels."""
+    audio: Optional[torch.Tensor] = None
+    audio_len: Optional[torch.Tensor] = None
+    video: Optional[torch.Tensor] = None
+    video_len: Optional[torch.Tensor] = None
+    aus: Optional[torch.Tensor] = None
+    labels: Optional[torch.Tensor] = None
+    labels_len: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def from_numpy(b, device="cuda"):
+        def f(a, dt):
+            return None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(device).contiguous()
+        return Batch(f(getattr(b, "audio", None), torch.float32), f(getattr(b, "audio_len", None), torch.int32),
+                     f(getattr(b, "video", None), torch.float32), f(getattr(b, "video_len", None), torch.int32),
+                     f(getattr(b, "aus", None), torch.float32), f(getattr(b, "labels", None), torch.int32),
+                     f(getattr(b, "labels_len", None), torch.int32))
+
+
+class Ref:
+    """A named slice of a flat device buffer."""
+
+    def __init__(self, t, off, shape):
+        self.t, self.off, self.shape = t, int(off), tuple(shape)
+        self.n = int(np.prod(shape))
+
+    def mat(self, ld=None, row0=0, col0=0):
+        ld = self.shape[-1] if ld is None else ld
+        return ops.mat(self.t, ld, offset=self.off + row0 * ld + col0)
+
+    def view(self):
+        return self.t[self.off:self.off + self.n].view(*self.shape)
+
+
+class SeqBuf:
+    """[B, lead + T + trail, D] sequence buffer; time t lives in slot lead + t; guard slots stay zero."""
+
+    def __init__(self, B, T, D, lead, trail, device):
+        self.B, self.T, self.D, self.lead = B, T, D, lead
+        self.slots = lead + T + trail
+        self.t = torch.zeros(B, self.slots, D, device=device)
+        self.sb, self.st = self.slots * D, D
+
+    def off(self, dt=0, col=0):
+        return (self.lead + dt) * self.D + col
+
+    def mat(self, dt=0, col=0):
+        return ops.mat(self.t, self.D, T=self.T, ldo=self.sb, offset=self.off(dt, col))
+
+
+def _splitk(M, N, K):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    sk = max(1, min(32, 512 // max(1, tiles), K // 256))
+    return sk
+
+
+class Seq2SeqModel:
+    def __init__(self, cfg: ModelConfig, device="cuda", seed=0, weights: Optional[Dict[str, np.ndarray]] = None):
+        cfg.validate()
+        if not torch.cuda.is_available():
+            raise RuntimeError("avsr_tf1_amd needs an MI355X GPU: the HIP engine has no CPU fallback")
+        from . import _lib
+        _lib.load()
+        self.cfg, self.dev = cfg, torch.device(device)
+        self.inv = PR.inventory(cfg)
+        # ---- flat parameter storage (engine layout) ------------------------------------------------
+        self._train_off, self._stat_off = OrderedDict(), OrderedDict()
+        nt = ns = 0
+        for name, (shape, kind, _init) in self.inv.items():
+            n = (int(np.prod(shape)) + 3) // 4 * 4      # keep every tensor 16-byte aligned
+            if name.endswith(PR.NON_TRAINABLE):
+                self._stat_off[name] = ns
+                ns += n
+            else:
+                self._train_off[name] = nt
+                nt += n
+        z = lambda n, dt=torch.float32: torch.zeros(max(n, 4), dtype=dt, device=self.dev)
+        self.params, self.grads, self.adam_m, self.adam_v = z(nt), z(nt), z(nt), z(nt)
+        self.stats = z(ns)
+        self.n_train = nt
+        self.step = z(1, torch.int32)
+        self.P = {n: Ref(self.params, o, self._eshape(n)) for n, o in self._train_off.items()}
+        self.G = {n: Ref(self.grads, o, self._eshape(n)) for n, o in self._train_off.items()}
+        self.S = {n: Ref(self.stats, o, self.inv[n][0]) for n, o in self._stat_off.items()}
+        self.l2_segments = [(self._train_off[n], int(np.prod(self.inv[n][0]))) for n in self._train_off if PR.is_l2(n)]
+        # ---- derived transposed operands -----------------------------------------------------------
+        self._tjobs, self.Tr = [], {}
+        tn = 0
+        for name in self._train_off:
+            if name.endswith(("/kernel", "/query_kernel", "/layer_kernel")) and not name.startswith(("video/au", "audio/au")):
+                if name.endswith("memory_kernel"):
+                    continue
+                r, c = self._eshape(name)
+                self._tjobs.append((name, tn, r, c))
+                tn += (r * c + 3) // 4 * 4
+        self.derived = z(tn)
+        for name, off, r, c in self._tjobs:
+            self.Tr[name] = Ref(self.derived, off, (c, r))
+        self._ws_cache = {}
+        self.load_tf_weights(weights if weights is not None else PR.initialise(cfg, seed))
+        self.scratch = z(1 << 22)
+        self.gemm_ws = None
+        self.loss = z(1)
+        self.gnorm = z(1)
+        self.denom = z(1)
+
+    # ------------------------------------------------------------------------------------------------
+    def _eshape(self, name):
+        return self.inv[name][0]
+
+    def load_tf_weights(self, W: Dict[str, np.ndarray]):
+        """Import a {name: array} dict in TF layout (same names as oracle / export_tf_weights)."""
+        for name, (shape, kind, _i) in self.inv.items():
+            a = np.asarray(W[name], dtype=np.float32).reshape(shape)
+            e = torch.from_numpy(PR.to_engine(kind, a).reshape(-1)).to(self.dev)
+            ref = self.S[name] if name in self.S else self.P[name]
+            ref.t[ref.off:ref.off + e.numel()].copy_(e)
+        self._refresh_derived()
+
+    def export_tf_weights(self, which="params") -> Dict[str, np.ndarray]:
+        src = {"params": self.params, "grads": self.grads, "adam_m": self.adam_m, "adam_v": self.adam_v}[which]
+        host = src.detach().cpu().numpy()
+        out = OrderedDict()
+        for name, (shape, kind, _i) in self.inv.items():
+            n = int(np.prod(shape))
+            if name in self._stat_off:
+                if which == "params":
+                    o = self._stat_off[name]
+                    out[name] = self.stats[o:o + n].cpu().numpy().reshape(shape).copy()
+                continue
+            o = self._train_off[name]
+            out[name] = PR.from_engine(kind, host[o:o + n].reshape(shape))
+        return out
+
+    def _refresh_derived(self):
+        jobs = [(self.params, self._train_off[n], self.derived, off, r, c) for n, off, r, c in self._tjobs]
+        if jobs:
+            ops.transpose(jobs)
+
+    # ------------------------------------------------------------------------------------------------
+    # workspace
+    def _get_ws(self, B, Ta, Tv, L, greedy):
+        key = (B, Ta, Tv, L, greedy)
+        if key in self._ws_cache:
+            return self._ws_cache[key]
+        cfg, dev = self.cfg, self.dev
+        z = lambda *s: torch.zeros(*s, device=dev)
+        ws = {"enc": {}}
+        ndir = len(cfg.directions())
+        for s in cfg.streams():
+            T = Ta if s == "audio" else Tv
+            F, units = cfg.feat(s), cfg.units(s)
+            attentive = cfg.architecture == "av_align" and s == "audio"
+            nplain = len(units) - 1 if attentive else len(units)
+            E = {"T": T, "F": F, "units": units, "nplain": nplain, "attentive": attentive}
+            E["xn"], E["dxn"], E["xhat"] = z(B * T, F), z(B * T, F), z(B * T, F)
+            E["mean"], E["invstd"] = z(F), z(F)
+            Dm = units[-1] * ndir
+            if not attentive:
+                E["mem"] = SeqBuf(B, T, Dm, 1, 1, dev)
+                E["dmem"] = SeqBuf(B, T, Dm, 1, 1, dev)
+            E["layers"] = {}
+            for di, d in enumerate(cfg.directions()):
+                for l in range(nplain):
+                    u = units[l]
+                    Ld = {"gates": z(B, T, u, 4), "cs": z(B, T, u), "state": z(4 * B * u), "dgates": z(B, T, u, 4),
+                          "dstate": z(12 * B * u), "hf": z(B, u), "cf": z(B, u), "dhf": z(B, u), "dcf": z(B, u)}
+                    top = (l == len(units) - 1)
+                    if top:
+                        Ld["out"], Ld["col"], Ld["dout"] = E["mem"], di * u, E["dmem"]
+                    else:
+                        Ld["out"], Ld["col"] = SeqBuf(B, T, u, 1, 1, dev), 0
+                        Ld["dout"] = SeqBuf(B, T, u, 1, 1, dev) if (attentive and l == nplain - 1) else None
+                    E["layers"][(d, l)] = Ld
+            H = cfg.decoder_units[0]
+            E["c_dec"], E["h_dec"], E["dc_dec"], E["dh_dec"] = z(B, H), z(B, H), z(B, H), z(B, H)
+            if s == "video" and cfg.regress_aus:
+                E["au_z"], E["au_dz"], E["au_row"] = z(B * T, 2), z(B * T, 2), z(B * T)
+            ws["enc"][s] = E
+        if cfg.architecture == "av_align":
+            A = ws["enc"]["audio"]
+            u = cfg.audio_units[-1]
+            in_w = cfg.audio_units[-2] if len(cfg.audio_units) > 1 else cfg.audio_feat
+            A["blk"] = self._make_block(ws, B, Ta, u, in_w, [("video", cfg.attention_type[0][0])], "audio/enc/fw/l%d" % (len(cfg.audio_units) - 1),
+                                        ["audio/enc/att0"], Tv=Tv, Ta=Ta, greedy=False)
+        Ldec = L
+        ws["dec"] = self._make_block(ws, B, Ldec, cfg.decoder_units[0], cfg.embedding_size, cfg.decoder_memories(), "dec/l0",
+                                     ["dec/att%d" % i for i in range(len(cfg.decoder_memories()))], Tv=Tv, Ta=Ta, greedy=greedy)
+        D = ws["dec"]
+        V = cfg.vocab_size
+        D["xemb"], D["dxemb"] = z(B * Ldec, cfg.embedding_size), z(B * Ldec, cfg.embedding_size)
+        D["logits"], D["dlogits"], D["row_loss"] = z(B, Ldec, V), z(B, Ldec, V), z(B * Ldec)
+        D["ids"] = torch.zeros(B, Ldec, dtype=torch.int32, device=dev)
+        D["tok"] = torch.zeros(B, dtype=torch.int32, device=dev)
+        D["nunf"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        D["steplen"] = torch.zeros(B, dtype=torch.int32, device=dev)
+        ws["B"], ws["L"] = B, L
+        self._ws_cache[key] = ws
+        return ws
+
+    def _make_block(self, ws, B, L, H, E, mems, cell_prefix, att_prefixes, Tv, Ta, greedy):
+        cfg, dev = self.cfg, self.dev
+        z = lambda *s: torch.zeros(*s, device=dev)
+        A = H * len(mems)
+        blk = {"B": B, "L": L, "H": H, "E": E, "A": A, "cell": cell_prefix, "mems": []}
+        blk.update(gates=z(B, L, H, 4), cs=z(B, L, H), cell_out=SeqBuf(B, L, H, 1, 0, dev), state=z(4 * B * H),
+                   dgates=z(B, L, H, 4), dstate=z(12 * B * H), dq=z(B, L, H), dh0=z(B, H), dc0=z(B, H),
+                   hf=z(B, H), cf=z(B, H), dcell_ext=z(B, L, H))
+        if A:
+            blk.update(att=SeqBuf(B, L, A, 1, 0, dev), datt=z(B, L, A), datt_ext=z(B, L, A))
+        for (stream, att_type), pre in zip(mems, att_prefixes):
+            T = Ta if stream == "audio" else Tv
+            D = cfg.memory_depth(stream)
+            chunk = 64 if T > 64 else max(16, (T + 1) // 2)
+            while (T + chunk - 1) // chunk > 16:
+                chunk *= 2
+            nc = (T + chunk - 1) // chunk
+            m = {"stream": stream, "type": att_type, "prefix": pre, "T": T, "D": D, "chunk": chunk, "nc": nc}
+            m.update(keys=z(B, T, H), dkeys=z(B, T, H), scores=z(B, L, T), dscores=z(B, L, T), ctx=z(B, L, D), dctx=z(B, L, D),
+                     pstat=z(L, 2, nc, B), pctx=z(nc, B, D), pdq=z(nc, B, H), rowdot=z(B * L))
+            if att_type in BAHDANAU_TYPES:
+                m.update(pq=z(B, L, H), dpq=z(B, L, H), vn=z(H), dvn=z(H), dv_part=z(((T + 15) // 16) * B, H))
+            blk["mems"].append(m)
+        return blk
+
+    # ------------------------------------------------------------------------------------------------
+    # encoders
+    def _rnn_stack(self, ws, s, d, B, len_t, backward=False):
+        cfg = self.cfg
+        E = ws["enc"][s]
+        st = RnnStack()
+        st.B, st.T, st.reverse, st.n_layers, st.cell = B, E["T"], int(d == "bw"), E["nplain"], 0
+        st.len = ops.fptr(len_t)
+        i = E["F"]
+        for l in range(E["nplain"]):
+            u = E["units"][l]
+            Ld = E["layers"][(d, l)]
+            name = f"{s}/enc/{d}/l{l}/kernel"
+            Ly = st.layer[l]
+            Ly.units, Ly.in_dim, Ly.hoisted, Ly.out_col = u, i, int(l == 0), Ld["col"]
+            Ly.wt = ops.fptr(self.derived, self.Tr[name].off)
+            Ly.w = ops.fptr(self.params, self.P[name].off)
+            Ly.bias = ops.fptr(self.params, self.P[f"{s}/enc/{d}/l{l}/bias"].off)
+            Ly.gates, Ly.cs = ops.fptr(Ld["gates"]), ops.fptr(Ld["cs"])
+            Ly.out, Ly.ld_out = ops.fptr(Ld["out"].t), Ld["out"].D
+            Ly.state, Ly.h_final, Ly.c_final = ops.fptr(Ld["state"]), ops.fptr(Ld["hf"]), ops.fptr(Ld["cf"])
+            Ly.dgates, Ly.dstate = ops.fptr(Ld["dgates"]), ops.fptr(Ld["dstate"])
+            if backward and Ld["dout"] is not None:
+                Ly.dout, Ly.ld_dout, Ly.dout_col = ops.fptr(Ld["dout"].t), Ld["dout"].D, Ld["col"]
+            i = u
+        if backward and not E["attentive"]:
+            top = E["layers"][(d, E["nplain"] - 1)]
+            st.dh_final, st.dc_final = ops.fptr(top["dhf"]), ops.fptr(top["dcf"])
+        return st
+
+    def _encode(self, ws, batch: Batch, training: bool):
+        cfg, B = self.cfg, ws["B"]
+        stacks = []
+        for s in cfg.streams():
+            E = ws["enc"][s]
+            T, F = E["T"], E["F"]
+            x = batch.video if s == "video" else batch.audio
+            len_t = batch.video_len if s == "video" else batch.audio_len
+            assert x.shape == (B, T, F) and x.is_contiguous() and x.dtype == torch.float32
+            E["x"], E["len"] = x, len_t
+            if cfg.batch_normalisation:
+                ops.batchnorm_fwd(x, E["xn"], B * T, F, self._pp(f"{s}/bn/gamma"), self._pp(f"{s}/bn/beta"),
+                                  self._sp(f"{s}/bn/moving_mean"), self._sp(f"{s}/bn/moving_variance"),
+                                  E["mean"], E["invstd"], training, self.scratch)
+                E["xin"] = E["xn"]
+            else:
+                E["xin"] = x
+            if E["nplain"] == 0:
+                continue
+            for d in cfg.directions():
+                u0 = E["units"][0]
+                W0 = self.P[f"{s}/enc/{d}/l0/kernel"]
+                ops.gemm(ops.mat(E["xin"], F), W0.mat(4 * u0), ops.mat(E["layers"][(d, 0)]["gates"], 4 * u0), B * T, 4 * u0, F)
+                stacks.append(self._rnn_stack(ws, s, d, B, len_t))
+        self._run_stacks(stacks, ops.rnn_fwd)
+        for s in cfg.streams():
+            E = ws["enc"][s]
+            if E["attentive"]:
+                self._av_align_forward(ws, batch, training)
+                continue
+            self._final_state_fwd(ws, s)
+            if s == "video" and cfg.regress_aus and training:
+                Wau = self.P["video/au/kernel"]
+                ops.gemm(E["mem"].mat(), Wau.mat(2), ops.mat(E["au_z"], 2), B * E["T"], 2, E["mem"].D, bias=self._pp("video/au/bias"))
+                ops.au_loss(E["au_z"], batch.aus, E["len"], E["au_row"], E["au_dz"], B, E["T"], cfg.au_loss_weight)
+
+    @staticmethod
+    def _run_stacks(stacks, fn):
+        if not stacks:
+            return
+        if sum(s.n_layers for s in stacks) <= 8 and len(stacks) <= 4:
+            fn(stacks)
+            return
+        for s in stacks:
+            fn([s])
+
+    def _pp(self, name):
+        r = self.P[name]
+        return r.t[r.off:r.off + r.n]
+
+    def _gp(self, name):
+        r = self.G[name]
+        return r.t[r.off:r.off + r.n]
+
+    def _sp(self, name):
+        r = self.S[name]
+        return r.t[r.off:r.off + r.n]
+
+    def _final_state_fwd(self, ws, s):
+        """uni: last layer's (c, h) (decoder_unimodal.py:144-145); bi: Dense on concat fw|bw (encoder.py:133-138)."""
+        cfg, B = self.cfg, ws["B"]
+        E = ws["enc"][s]
+        top = len(E["units"]) - 1
+        u, H = E["units"][-1], cfg.decoder_units[0]
+        if cfg.encoder_type == "unidirectional":
+            Lt = E["layers"][("fw", top)]
+            E["c_fin"], E["h_fin"] = Lt["cf"], Lt["hf"]
+            return
+        for nm, key, dst in (("proj_c", "cf", "c_dec"), ("proj_h", "hf", "h_dec")):
+            Pm = self.P[f"{s}/enc/{nm}"]
+            for di, d in enumerate(cfg.directions()):
+                ops.gemm(ops.mat(E["layers"][(d, top)][key], u), Pm.mat(H, row0=di * u), ops.mat(E[dst], H), B, H, u,
+                         beta=0.0 if di == 0 else 1.0)
+        E["c_fin"], E["h_fin"] = E["c_dec"], E["h_dec"]
+
+    def _final_state_bwd(self, ws, s, dc, dh):
+        """dc, dh: [B, Hdec] gradient wrt the stream's final (c, h) handed to the decoder."""
+        cfg, B = self.cfg, ws["B"]
+        E = ws["enc"][s]
+        top = len(E["units"]) - 1
+        u, H = E["units"][-1], cfg.decoder_units[0]
+        if E["attentive"]:
+            E["blk"]["dcf_in"], E["blk"]["dhf_in"] = dc, dh
+            return
+        if cfg.encoder_type == "unidirectional":
+            Lt = E["layers"][("fw", top)]
+            Lt["dcf"].copy_(dc)
+            Lt["dhf"].copy_(dh)
+            return
+        for nm, key, dkey, g in (("proj_c", "cf", "dcf", dc), ("proj_h", "hf", "dhf", dh)):
+            Pm, Gm = self.P[f"{s}/enc/{nm}"], self.G[f"{s}/enc/{nm}"]
+            for di, d in enumerate(cfg.directions()):
+                Lt = E["layers"][(d, top)]
+                ops.gemm(ops.mat(g, H), Pm.mat(H, row0=di * u), ops.mat(Lt[dkey], u), B, u, H, trans_b=1)
+                ops.gemm(ops.mat(Lt[key], u), ops.mat(g, H), Gm.mat(H, row0=di * u), u, H, B, trans_a=1, beta=1.0)
+
+    def _encode_backward(self, ws, batch: Batch):
+        cfg, B = self.cfg, ws["B"]
+        self._ensure_gemm_ws()
+        # AU loss gradient into the video memory
+        if "video" in ws["enc"] and cfg.regress_aus:
+            E = ws["enc"]["video"]
+            T, D = E["T"], E["mem"].D
+            ops.gemm(ops.mat(E["au_dz"], 2), self.P["video/au/kernel"].mat(2), E["dmem"].mat(), B * T, D, 2, trans_b=1, beta=1.0)
+            ops.gemm(E["mem"].mat(), ops.mat(E["au_dz"], 2), self.G["video/au/kernel"].mat(2), D, 2, B * T, trans_a=1, beta=1.0)
+            ops.colsum(ops.mat(E["au_dz"], 2), B * T, 2, self.grads, self.scratch, beta=1.0, out_offset=self.G["video/au/bias"].off)
+        if cfg.architecture == "av_align":
+            self._av_align_backward(ws, batch)       # needs the complete gradient of the audio memory; fills video dmem
+        stacks = []
+        for s in cfg.streams():
+            E = ws["enc"][s]
+            if E["nplain"] == 0:
+                continue
+            for d in cfg.directions():
+                stacks.append(self._rnn_stack(ws, s, d, B, E["len"], backward=True))
+        self._run_stacks(stacks, ops.rnn_bwd)
+        for s in cfg.streams():
+            E = ws["enc"][s]
+            T, F = E["T"], E["F"]
+            first = True
+            for d in cfg.directions():
+                i = F
+                for l in range(E["nplain"]):
+                    u = E["units"][l]
+                    Ld = E["layers"][(d, l)]
+                    Gk = self.G[f"{s}/enc/{d}/l{l}/kernel"]
+                    dg = ops.mat(Ld["dgates"], 4 * u)
+                    a_x = ops.mat(E["xin"], F) if l == 0 else E["layers"][(d, l - 1)]["out"].mat(0, E["layers"][(d, l - 1)]["col"])
+                    self._gemm_tn(a_x, dg, Gk.mat(4 * u), i, 4 * u, B * T)
+                    a_h = Ld["out"].mat(1 if d == "bw" else -1, Ld["col"])
+                    self._gemm_tn(a_h, dg, Gk.mat(4 * u, row0=i), u, 4 * u, B * T)
+                    ops.colsum(dg, B * T, 4 * u, self.grads, self.scratch, beta=1.0, out_offset=self.G[f"{s}/enc/{d}/l{l}/bias"].off)
+                    i = u
+                if E["nplain"] > 0 and cfg.batch_normalisation:
+                    u0 = E["units"][0]
+                    W0 = self.P[f"{s}/enc/{d}/l0/kernel"]
+                    ops.gemm(ops.mat(E["layers"][(d, 0)]["dgates"], 4 * u0), W0.mat(4 * u0), ops.mat(E["dxn"], F), B * T, F, 4 * u0,
+                             trans_b=1, beta=0.0 if first else 1.0)
+                    first = False
+            if cfg.batch_normalisation:
+                # (a 1-layer attentive encoder wrote dxn in _av_align_backward)
+                ops.batchnorm_xhat(E["x"], E["mean"], E["invstd"], E["xhat"], B * T, F)
+                ops.colsum(ops.mat(E["dxn"], F), B * T, F, self.grads, self.scratch, b=ops.mat(E["xhat"], F), beta=1.0,
+                           out_offset=self.G[f"{s}/bn/gamma"].off)
+                ops.colsum(ops.mat(E["dxn"], F), B * T, F, self.grads, self.scratch, beta=1.0, out_offset=self.G[f"{s}/bn/beta"].off)
+
+    def _ensure_gemm_ws(self):
+        if self.gemm_ws is None:
+            self.gemm_ws = torch.empty(48 << 20, device=self.dev)
+
+    def _gemm_tn(self, A, Bm, Cm, M, N, K, beta=1.0):
+        """C (+)= A^T B with K = number of (b,t) rows: split-K so the small M x N output still fills the chip."""
+        sk = _splitk(M, N, K)
+        while sk > 1 and sk * M * N > self.gemm_ws.numel():
+            sk //= 2
+        ops.gemm(A, Bm, Cm, M, N, K, trans_a=1, beta=beta, splitk=sk, workspace=self.gemm_ws)
+
+    # ------------------------------------------------------------------------------------------------
+    # attention-wrapped LSTM block (decoder, AV-Align top layer)
+    def _mem_desc(self, ws, stream):
+        """(values SeqBuf-like view, grad view, len) of a stream's encoder memory as seen by attention."""
+        E = ws["enc"][stream]
+        if not E["attentive"]:
+            return dict(t=E["mem"].t, off=E["mem"].off(), sb=E["mem"].sb, st=E["mem"].st, vmat=E["mem"].mat(),
+                        gt=E["dmem"].t, goff=E["dmem"].off(), gsb=E["dmem"].sb, gmat=E["dmem"].mat(), len=E["len"])
+        blk = E["blk"]
+        if blk["mems"][0]["type"] in LUONG_TYPES:     # encoder output = attention vector (output_attention=True)
+            buf, g = blk["att"], blk["datt_ext"]
+        else:
+            buf, g = blk["cell_out"], blk["dcell_ext"]
+        D = buf.D
+        return dict(t=buf.t, off=buf.off(), sb=buf.sb, st=buf.st, vmat=buf.mat(), gt=g, goff=0, gsb=buf.T * D,
+                    gmat=ops.mat(g, D), len=E["len"])
+
+    def _block_desc(self, ws, blk, steplen, mode, h0, c0, with_bwd):
+        cfg = self.cfg
+        B, L, H, E, A = blk["B"], blk["L"], blk["H"], blk["E"], blk["A"]
+        d = AttnRnn()
+        d.B, d.L, d.H, d.E, d.n_mech, d.V, d.mode = B, L, H, E, len(blk["mems"]), cfg.vocab_size, mode
+        d.go_id, d.eos_id = cfg.go_id, cfg.eos_id
+        d.steplen = ops.fptr(steplen)
+        kname = blk["cell"] + "/kernel"
+        d.wt, d.w = ops.fptr(self.derived, self.Tr[kname].off), ops.fptr(self.params, self.P[kname].off)
+        d.bias = ops.fptr(self.params, self.P[blk["cell"] + "/bias"].off)
+        d.gates, d.cs, d.cell_out = ops.fptr(blk["gates"]), ops.fptr(blk["cs"]), ops.fptr(blk["cell_out"].t)
+        d.att = ops.fptr(blk["att"].t) if A else None
+        d.h0, d.c0, d.state = ops.fptr(h0), ops.fptr(c0), ops.fptr(blk["state"])
+        d.h_final, d.c_final = ops.fptr(blk["hf"]), ops.fptr(blk["cf"])
+        for i, m in enumerate(blk["mems"]):
+            md = self._mem_desc(ws, m["stream"])
+            M = d.mech[i]
+            pre = m["prefix"]
+            M.type, M.T, M.D, M.chunk = ATT_CODE[m["type"]], m["T"], m["D"], m["chunk"]
+            M.len, M.keys = ops.fptr(md["len"]), ops.fptr(m["keys"])
+            M.values, M.values_sb, M.values_st = ops.fptr(md["t"], md["off"]), md["sb"], md["st"]
+            if m["type"] == "scaled_luong":
+                M.g = ops.fptr(self.params, self.P[pre + "/g"].off)
+            if m["type"] in BAHDANAU_TYPES:
+                if m["type"] == "normed_bahdanau":
+                    M.v, M.bq = ops.fptr(m["vn"]), ops.fptr(self.params, self.P[pre + "/b"].off)
+                else:
+                    M.v = ops.fptr(self.params, self.P[pre + "/v"].off)
+                M.wq_t = ops.fptr(self.derived, self.Tr[pre + "/query_kernel"].off)
+                M.wq = ops.fptr(self.params, self.P[pre + "/query_kernel"].off)
+                M.pq, M.dpq = ops.fptr(m["pq"]), ops.fptr(m["dpq"])
+            M.watt_t = ops.fptr(self.derived, self.Tr[pre + "/layer_kernel"].off)
+            M.watt = ops.fptr(self.params, self.P[pre + "/layer_kernel"].off)
+            M.scores, M.ctx, M.pstat, M.pctx = ops.fptr(m["scores"]), ops.fptr(m["ctx"]), ops.fptr(m["pstat"]), ops.fptr(m["pctx"])
+            if with_bwd:
+                M.dscores, M.dctx, M.pdq = ops.fptr(m["dscores"]), ops.fptr(m["dctx"]), ops.fptr(m["pdq"])
+        if with_bwd:
+            d.dgates, d.dstate, d.dq = ops.fptr(blk["dgates"]), ops.fptr(blk["dstate"]), ops.fptr(blk["dq"])
+            d.datt = ops.fptr(blk["datt"]) if A else None
+            d.dh0, d.dc0 = ops.fptr(blk["dh0"]), ops.fptr(blk["dc0"])
+        return d
+
+    def _block_prepare(self, ws, blk):
+        """Per-batch attention memory preparation: keys = values . W_mem (attention.py memory_layer)."""
+        B, H = blk["B"], blk["H"]
+        for m in blk["mems"]:
+            md = self._mem_desc(ws, m["stream"])
+            pre = m["prefix"]
+            ops.gemm(md["vmat"], self.P[pre + "/memory_kernel"].mat(H), ops.mat(m["keys"], H), B * m["T"], H, m["D"])
+            if m["type"] == "normed_bahdanau":
+                ops.normed_v(self._pp(pre + "/v"), self._pp(pre + "/g"), m["vn"], H)
+
+    def _block_backward(self, ws, blk, desc, xin_mat, dxin_mat, dxin_beta, out_att):
+        """attention-RNN BPTT + every deferred (post-loop) gradient GEMM of the block.
+        xin_mat: Mat over the [B*L, E] hoisted inputs; dxin_mat: where d(inputs) goes (or None)."""
+        cfg = self.cfg
+        B, L, H, E, A = blk["B"], blk["L"], blk["H"], blk["E"], blk["A"]
+        self._ensure_gemm_ws()
+        ops.attn_rnn_bwd(desc)
+        rows = B * L
+        co = blk["cell_out"]
+        for i, m in enumerate(blk["mems"]):
+            pre, T, D = m["prefix"], m["T"], m["D"]
+            md = self._mem_desc(ws, m["stream"])
+            datt_m = ops.mat(blk["datt"], A, offset=i * H)
+            Gl = self.G[pre + "/layer_kernel"]
+            self._gemm_tn(co.mat(0), datt_m, Gl.mat(H), H, H, rows)                 # rows 0..H: cell_out part
+            self._gemm_tn(ops.mat(m["ctx"], D), datt_m, Gl.mat(H, row0=H), D, H, rows)   # rows H..H+D: context part
+            luong = m["type"] in LUONG_TYPES
+            g_t = self._pp(pre + "/g") if m["type"] == "scaled_luong" else None
+            # scores -> alpha (in place); rowdot = sum_t ds * raw  (d g for scaled_luong)
+            ops.attn_alpha_rows(m["scores"], m["dscores"], md["len"], desc_steplen(desc), g_t if luong else None, m["rowdot"], B, L, T)
+            if m["type"] == "scaled_luong":
+                ops.reduce_scalar(m["rowdot"], rows, self.grads, accumulate=True, out_offset=self.G[pre + "/g"].off)
+            # d values[b,t,:] += sum_l alpha[b,l,t] * dctx[b,l,:]        (batched over b)
+            ops.gemm(ops.mat(m["scores"], T), ops.mat(m["dctx"], D), ops.mat(md["gt"], md["st"], offset=md["goff"]), T, D, L,
+                     trans_a=1, beta=1.0, batch=B, strides=(L * T, L * D, md["gsb"]))
+            if luong:
+                # d keys[b,t,:] = g * sum_l ds[b,l,t] * cell_out[b,l,:]
+                ops.gemm(ops.mat(m["dscores"], T), ops.mat(co.t, H, offset=co.off(0)), ops.mat(m["dkeys"], H), T, H, L,
+                         trans_a=1, batch=B, strides=(L * T, co.sb, T * H), alpha_dev=g_t)
+            else:
+                v_t = m["vn"] if m["type"] == "normed_bahdanau" else self._pp(pre + "/v")
+                bq = self._pp(pre + "/b") if m["type"] == "normed_bahdanau" else None
+                ops.bahdanau_dkeys(m["keys"], m["pq"], L * H, H, m["dscores"], v_t, bq, md["len"], m["dkeys"], m["dv_part"], B, L, T, H)
+                nblk = m["dv_part"].shape[0]
+                if m["type"] == "normed_bahdanau":
+                    ops.colsum(ops.mat(m["dv_part"], H), nblk, H, m["dvn"], self.scratch)
+                    ops.normed_v_bwd(self._pp(pre + "/v"), self._pp(pre + "/g"), m["dvn"], self._gp(pre + "/v"), self._gp(pre + "/g"), H)
+                    ops.colsum(ops.mat(m["dpq"], H), rows, H, self.grads, self.scratch, beta=1.0, out_offset=self.G[pre + "/b"].off)
+                else:
+                    ops.colsum(ops.mat(m["dv_part"], H), nblk, H, self.grads, self.scratch, beta=1.0, out_offset=self.G[pre + "/v"].off)
+                self._gemm_tn(co.mat(0), ops.mat(m["dpq"], H), self.G[pre + "/query_kernel"].mat(H), H, H, rows)
+            # memory_layer: d values += d keys . W_mem^T ; d W_mem = values^T . d keys
+            Wm, Gm = self.P[pre + "/memory_kernel"], self.G[pre + "/memory_kernel"]
+            ops.gemm(ops.mat(m["dkeys"], H), Wm.mat(H), md["gmat"], B * T, D, H, trans_b=1, beta=1.0)
+            self._gemm_tn(md["vmat"], ops.mat(m["dkeys"], H), Gm.mat(H), D, H, B * T)
+        # cell kernel: rows [0:E] inputs, [E:E+A] previous attention, [E+A:] previous h
+        Gk = self.G[blk["cell"] + "/kernel"]
+        dg = ops.mat(blk["dgates"], 4 * H)
+        self._gemm_tn(xin_mat, dg, Gk.mat(4 * H), E, 4 * H, rows)
+        if A:
+            self._gemm_tn(blk["att"].mat(-1), dg, Gk.mat(4 * H, row0=E), A, 4 * H, rows)
+        self._gemm_tn(co.mat(-1), dg, Gk.mat(4 * H, row0=E + A), H, 4 * H, rows)
+        ops.colsum(dg, rows, 4 * H, self.grads, self.scratch, beta=1.0, out_offset=self.G[blk["cell"] + "/bias"].off)
+        if dxin_mat is not None:
+            ops.gemm(dg, self.P[blk["cell"] + "/kernel"].mat(4 * H), dxin_mat, rows, E, 4 * H, trans_b=1, beta=dxin_beta)
+
+    # ------------------------------------------------------------------------------------------------
+    # AV-Align: attention-wrapped top audio layer over the video memory (encoder.py:265-290)
+    def _av_align_forward(self, ws, batch, training):
+        cfg, B = self.cfg, ws["B"]
+        E = ws["enc"]["audio"]
+        blk = E["blk"]
+        T, H, Ein = E["T"], blk["H"], blk["E"]
+        kname = blk["cell"] + "/kernel"
+        xin = self._av_xin(E)
+        ops.gemm(xin, self.P[kname].mat(4 * H), ops.mat(blk["gates"], 4 * H), B * T, 4 * H, Ein)
+        self._block_prepare(ws, blk)
+        blk["desc"] = self._block_desc(ws, blk, E["len"], 0, None, None, with_bwd=training)
+        ops.attn_rnn_fwd(blk["desc"], 0, T)
+        E["c_fin"], E["h_fin"] = blk["cf"], blk["hf"]
+
+    def _av_xin(self, E):
+        if E["nplain"] == 0:
+            return ops.mat(E["xin"], E["F"])
+        Ld = E["layers"][("fw", E["nplain"] - 1)]
+        return Ld["out"].mat(0)
+
+    def _av_align_backward(self, ws, batch):
+        cfg, B = self.cfg, ws["B"]
+        E = ws["enc"]["audio"]
+        blk = E["blk"]
+        d = blk["desc"]
+        luong = blk["mems"][0]["type"] in LUONG_TYPES
+        d.datt_ext = ops.fptr(blk["datt_ext"]) if luong else None
+        d.dcell_ext = None if luong else ops.fptr(blk["dcell_ext"])
+        d.dh_final, d.dc_final = ops.fptr(blk["dhf_in"]), ops.fptr(blk["dcf_in"])
+        if E["nplain"] == 0:
+            dxin, beta = ops.mat(E["dxn"], E["F"]), 0.0
+        else:
+            Ld = E["layers"][("fw", E["nplain"] - 1)]
+            dxin, beta = Ld["dout"].mat(0), 0.0
+        self._block_backward(ws, blk, d, self._av_xin(E), dxin, beta, luong)
+
+    # ------------------------------------------------------------------------------------------------
+    # decoder
+    def _decoder_init_state(self, ws):
+        """unimodal / av_align: encoder final (c,h) used directly; bimodal: ONE shared Dense on concat c and on
+        concat h (decoder_bimodal.py:480-490); a missing stream contributes zeros (:129-142)."""
+        cfg, B = self.cfg, ws["B"]
+        D = ws["dec"]
+        H = cfg.decoder_units[0]
+        if cfg.architecture != "bimodal":
+            s = "audio" if "audio" in ws["enc"] else "video"
+            E = ws["enc"][s]
+            D["h0"], D["c0"] = E["h_fin"], E["c_fin"]
+            return
+        if "c0buf" not in D:
+            D["c0buf"], D["h0buf"] = torch.zeros(B, H, device=self.dev), torch.zeros(B, H, device=self.dev)
+        SP = self.P["dec/state_proj"]
+        for key, dst in (("c_fin", "c0buf"), ("h_fin", "h0buf")):
+            first = True
+            for si, s in enumerate(("video", "audio")):
+                if s not in ws["enc"]:
+                    continue
+                ops.gemm(ops.mat(ws["enc"][s][key], H), SP.mat(H, row0=si * H), ops.mat(D[dst], H), B, H, H, beta=0.0 if first else 1.0)
+                first = False
+        D["h0"], D["c0"] = D["h0buf"], D["c0buf"]
+
+    def _decoder_init_state_bwd(self, ws):
+        cfg, B = self.cfg, ws["B"]
+        D = ws["dec"]
+        H = cfg.decoder_units[0]
+        if cfg.architecture != "bimodal":
+            s = "audio" if "audio" in ws["enc"] else "video"
+            self._final_state_bwd(ws, s, D["dc0"], D["dh0"])
+            return
+        SP, GSP = self.P["dec/state_proj"], self.G["dec/state_proj"]
+        for si, s in enumerate(("video", "audio")):
+            if s not in ws["enc"]:
+                continue
+            E = ws["enc"][s]
+            for key, g, dst in (("c_fin", D["dc0"], "dc_dec"), ("h_fin", D["dh0"], "dh_dec")):
+                ops.gemm(ops.mat(g, H), SP.mat(H, row0=si * H), ops.mat(E[dst], H), B, H, H, trans_b=1)
+                ops.gemm(ops.mat(E[key], H), ops.mat(g, H), GSP.mat(H, row0=si * H), H, H, B, trans_a=1, beta=1.0)
+            self._final_state_bwd(ws, s, E["dc_dec"], E["dh_dec"])
+
+    def _out_vec(self, D):
+        """what the output Dense consumes: attention (Luong family) or the cell output (Bahdanau family)."""
+        if self.cfg.output_attention():
+            return D["att"].mat(0), D["A"]
+        return D["cell_out"].mat(0), D["H"]
+
+    # ------------------------------------------------------------------------------------------------
+    # public API
+    def forward_train(self, batch: Batch, compute_denom=True):
+        """Train-graph forward: encoders, teacher-forced decoder, logits, loss (stays on device)."""
+        cfg = self.cfg
+        B, L = batch.labels.shape
+        Ta = batch.audio.shape[1] if batch.audio is not None else 0
+        Tv = batch.video.shape[1] if batch.video is not None else 0
+        ws = self._get_ws(B, Ta, Tv, L, False)
+        self._cur = (ws, batch)
+        self._refresh_derived()
+        self._encode(ws, batch, True)
+        D = ws["dec"]
+        H, E, V = D["H"], D["E"], cfg.vocab_size
+        self._decoder_init_state(ws)
+        ops.embed_labels(self._pp("dec/embedding"), batch.labels, cfg.go_id, D["xemb"], B, L, E)
+        ops.gemm(ops.mat(D["xemb"], E), self.P["dec/l0/kernel"].mat(4 * H), ops.mat(D["gates"], 4 * H), B * L, 4 * H, E)
+        self._block_prepare(ws, D)
+        D["desc"] = self._block_desc(ws, D, batch.labels_len, 0, D["h0"], D["c0"], with_bwd=True)
+        ops.attn_rnn_fwd(D["desc"], 0, L)
+        ov, O = self._out_vec(D)
+        ops.gemm(ov, self.P["dec/out/kernel"].mat(V), ops.mat(D["logits"], V), B * L, V, O, bias=self._pp("dec/out/bias"))
+        ops.seq_loss(D["logits"], batch.labels, batch.labels_len, self.denom, compute_denom, D["row_loss"], D["dlogits"], B, L, V)
+        ops.reduce_scalar(D["row_loss"], B * L, self.loss)
+        if cfg.regress_aus and "video" in ws["enc"]:
+            Ev = ws["enc"]["video"]
+            ops.reduce_scalar(Ev["au_row"], B * Ev["T"], self.loss, accumulate=True)
+        return D["logits"]
+
+    def backward(self):
+        """BPTT through decoder and encoders; leaves the full gradient in self.grads (engine layout)."""
+        cfg = self.cfg
+        ws, batch = self._cur
+        B, L = ws["B"], ws["L"]
+        D = ws["dec"]
+        H, E, A, V = D["H"], D["E"], D["A"], cfg.vocab_size
+        self._ensure_gemm_ws()
+        self.grads.zero_()
+        for s in cfg.streams():
+            Es = ws["enc"][s]
+            if "dmem" in Es:
+                Es["dmem"].t.zero_()
+        if cfg.architecture == "av_align":
+            ws["enc"]["audio"]["blk"]["datt_ext"].zero_()
+            ws["enc"]["audio"]["blk"]["dcell_ext"].zero_()
+        # output layer
+        ov, O = self._out_vec(D)
+        dl = ops.mat(D["dlogits"], V)
+        self._gemm_tn(ov, dl, self.G["dec/out/kernel"].mat(V), O, V, B * L)
+        ops.colsum(dl, B * L, V, self.grads, self.scratch, beta=1.0, out_offset=self.G["dec/out/bias"].off)
+        oa = cfg.output_attention()
+        dext = D["datt_ext"] if oa else D["dcell_ext"]
+        ops.gemm(dl, self.P["dec/out/kernel"].mat(V), ops.mat(dext, O), B * L, O, V, trans_b=1)
+        d = D["desc"]
+        d.datt_ext = ops.fptr(dext) if oa else None
+        d.dcell_ext = None if oa else ops.fptr(dext)
+        self._block_backward(ws, D, d, ops.mat(D["xemb"], E), ops.mat(D["dxemb"], E), 0.0, oa)
+        ops.embed_grad(D["dxemb"], batch.labels, cfg.go_id, self._gp("dec/embedding"), B, L, E, V)
+        self._decoder_init_state_bwd(ws)
+        self._encode_backward(ws, batch)
+
+    def apply_update(self):
+        """L2 on the RNN kernels, global-norm clip, Adam, LR warm-up (seq2seq.py:175-178, :195-199, :245-257)."""
+        cfg = self.cfg
+        if cfg.recurrent_l2 is not None:
+            ops.l2_regularise(self.l2_segments, self.params, self.grads, cfg.recurrent_l2, self.loss, self.scratch)
+        ops.global_norm(self.grads, self.n_train, self.gnorm, self.scratch)
+        ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.n_train, self.gnorm, self.step,
+                      cfg.learning_rate, cfg.warmup_steps, cfg.max_gradient_norm if cfg.clip_gradients else 0.0)
+
+    def train_step(self, batch: Batch):
+        """One `session.run([train_op, batch_loss, global_norm])` (avsr/avsr.py:265-271); returns device scalars."""
+        self.forward_train(batch)
+        self.backward()
+        self.apply_update()
+        return self.loss, self.gnorm
+
+    def greedy_decode(self, batch: Batch, max_steps: Optional[int] = None, check_every: int = 8):
+        """Eval graph with GreedyEmbeddingHelper (decoder_unimodal.py:176-217): int32 ids [B, T_out], zeros after EOS."""
+        cfg = self.cfg
+        B = (batch.audio if batch.audio is not None else batch.video).shape[0]
+        L = cfg.max_label_length if max_steps is None else max_steps
+        Ta = batch.audio.shape[1] if batch.audio is not None else 0
+        Tv = batch.video.shape[1] if batch.video is not None else 0
+        ws = self._get_ws(B, Ta, Tv, L, True)
+        self._refresh_derived()
+        self._encode(ws, batch, False)
+        D = ws["dec"]
+        self._decoder_init_state(ws)
+        self._block_prepare(ws, D)
+        D["steplen"].fill_(L)
+        D["tok"].fill_(cfg.go_id)
+        D["ids"].zero_()
+        d = self._block_desc(ws, D, D["steplen"], 1, D["h0"], D["c0"], with_bwd=False)
+        d.output_attention = int(cfg.output_attention())
+        d.embedding = ops.fptr(self.params, self.P["dec/embedding"].off)
+        d.wout_t = ops.fptr(self.derived, self.Tr["dec/out/kernel"].off)
+        d.bout = ops.fptr(self.params, self.P["dec/out/bias"].off)
+        d.logits, d.ids, d.tok, d.n_unfinished = ops.fptr(D["logits"]), ops.fptr(D["ids"]), ops.fptr(D["tok"]), ops.fptr(D["nunf"])
+        l = 0
+        while l < L:
+            l1 = min(L, l + check_every)
+            ops.attn_rnn_fwd(d, l, l1)
+            l = l1
+            if int(D["nunf"].item()) == 0:      # all utterances emitted EOS
+                break
+        t_out = min(int(D["steplen"].max().item()), l)   # dynamic_decode stops once every utterance has finished
+        self._last_greedy = (ws, t_out)
+        return D["ids"][:, :t_out].contiguous()
+
+
+def desc_steplen(desc):
+    return _PtrView(desc.steplen)
+
+
+class _PtrView:
+    """Wraps a raw device address so it can be passed where ops.fptr() expects a tensor."""
+
+    def __init__(self, addr):
+        self.addr = addr
+        self.is_cuda = True
+
+    def data_ptr(self):
+        return self.addr
+
+    def element_size(self):
+        return 4

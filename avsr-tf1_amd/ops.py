@@ -4,23 +4,32 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import GemmDesc, Mat, RnnLayer, RnnStack, check, ptr, stream_ptr
+from ._lib import (AttnMech, AttnRnn, GemmDesc, Mat, RnnLayer, RnnStack, TransposeJob, check, stream_ptr)
 
 
 def fptr(t, offset=0):
-    """Device address of element `offset` of a float32 tensor."""
+    """Device address of element `offset` of a tensor (None -> NULL)."""
     if t is None:
         return None
-    assert t.dtype == torch.float32 and t.is_cuda
-    return t.data_ptr() + 4 * int(offset)
+    assert t.is_cuda, "HIP engine buffers must live on the GPU"
+    return t.data_ptr() + t.element_size() * int(offset)
 
 
 def mat(t, ld, T=0, ldo=0, offset=0):
+    assert t.dtype == torch.float32
     return Mat(fptr(t, offset), int(ld), int(T), 0, int(ldo))
 
 
+def _L():
+    return _lib.load()
+
+
+def _s():
+    return stream_ptr()
+
+
 def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None,
-         batch=1, strides=(0, 0, 0), splitk=1, workspace=None):
+         batch=1, strides=(0, 0, 0), splitk=1, workspace=None, alpha_dev=None):
     """C = alpha*op(A)*op(B) + beta*C + bias.  A, B, Cm are `Mat` views (see `mat`)."""
     d = GemmDesc()
     d.A, d.B, d.C = A, B, Cm
@@ -30,20 +39,113 @@ def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, b
     d.alpha, d.beta = float(alpha), float(beta)
     d.batch = int(batch)
     d.stride_a, d.stride_b, d.stride_c = [int(s) for s in strides]
+    d.alpha_dev = fptr(alpha_dev)
     d.splitk = int(splitk)
     if splitk > 1:
         need = batch * splitk * M * N
         assert workspace is not None and workspace.numel() >= need, "split-K workspace too small"
         d.workspace = fptr(workspace)
         d.workspace_floats = workspace.numel()
-    check(_lib.load().avsr_gemm(C.byref(d), C.c_void_p(stream_ptr())), "avsr_gemm")
+    check(_L().avsr_gemm(C.byref(d), _s()), "avsr_gemm")
 
 
 def rnn_fwd(stacks):
     arr = (RnnStack * len(stacks))(*stacks)
-    check(_lib.load().avsr_rnn_fwd(arr, C.c_int32(len(stacks)), C.c_void_p(stream_ptr())), "avsr_rnn_fwd")
+    check(_L().avsr_rnn_fwd(arr, len(stacks), _s()), "avsr_rnn_fwd")
 
 
 def rnn_bwd(stacks):
     arr = (RnnStack * len(stacks))(*stacks)
-    check(_lib.load().avsr_rnn_bwd(arr, C.c_int32(len(stacks)), C.c_void_p(stream_ptr())), "avsr_rnn_bwd")
+    check(_L().avsr_rnn_bwd(arr, len(stacks), _s()), "avsr_rnn_bwd")
+
+
+def attn_rnn_fwd(desc, l_begin, l_end):
+    check(_L().avsr_attn_rnn_fwd(C.byref(desc), int(l_begin), int(l_end), _s()), "avsr_attn_rnn_fwd")
+
+
+def attn_rnn_bwd(desc):
+    check(_L().avsr_attn_rnn_bwd(C.byref(desc), _s()), "avsr_attn_rnn_bwd")
+
+
+def attn_alpha_rows(scores, dscores, mem_len, steplen, g, rowdot, B, L, T):
+    check(_L().avsr_attn_alpha_rows(fptr(scores), fptr(dscores), fptr(mem_len), fptr(steplen), fptr(g), fptr(rowdot),
+                                    B, L, T, _s()), "avsr_attn_alpha_rows")
+
+
+def bahdanau_dkeys(keys, pq, pq_sb, pq_sl, dscores, v, bq, mem_len, dkeys, dv_part, B, L, T, H):
+    check(_L().avsr_bahdanau_dkeys(fptr(keys), fptr(pq), pq_sb, pq_sl, fptr(dscores), fptr(v), fptr(bq),
+                                   fptr(mem_len), fptr(dkeys), fptr(dv_part), B, L, T, H, _s()), "avsr_bahdanau_dkeys")
+
+
+def transpose(jobs):
+    """jobs: list of (src_tensor, src_off, dst_tensor, dst_off, rows, cols)."""
+    arr = (TransposeJob * len(jobs))()
+    for i, (s, so, d, do, r, c) in enumerate(jobs):
+        arr[i] = TransposeJob(fptr(s, so), fptr(d, do), int(r), int(c))
+    check(_L().avsr_transpose(arr, len(jobs), _s()), "avsr_transpose")
+
+
+def colsum(a, rows, F, out, scratch, b=None, alpha=1.0, beta=0.0, out_offset=0):
+    check(_L().avsr_colsum(C.byref(a), C.byref(b) if b is not None else None, rows, F, alpha, beta,
+                           fptr(out, out_offset), fptr(scratch), scratch.numel(), _s()), "avsr_colsum")
+
+
+def batchnorm_fwd(x, y, rows, F, gamma, beta, mov_mean, mov_var, save_mean, save_invstd, training, scratch):
+    check(_L().avsr_batchnorm_fwd(fptr(x), fptr(y), rows, F, fptr(gamma), fptr(beta), fptr(mov_mean), fptr(mov_var),
+                                  fptr(save_mean), fptr(save_invstd), int(training), fptr(scratch), scratch.numel(),
+                                  _s()), "avsr_batchnorm_fwd")
+
+
+def batchnorm_xhat(x, mean, invstd, xhat, rows, F):
+    check(_L().avsr_batchnorm_xhat(fptr(x), fptr(mean), fptr(invstd), fptr(xhat), rows, F, _s()), "avsr_batchnorm_xhat")
+
+
+def embed_labels(emb, labels, go_id, out, B, L, E):
+    check(_L().avsr_embed_labels(fptr(emb), fptr(labels), go_id, fptr(out), B, L, E, _s()), "avsr_embed_labels")
+
+
+def embed_grad(dx, labels, go_id, demb, B, L, E, V):
+    check(_L().avsr_embed_grad(fptr(dx), fptr(labels), go_id, fptr(demb), B, L, E, V, _s()), "avsr_embed_grad")
+
+
+def seq_loss(logits, labels, labels_len, denom, compute_denom, row_loss, dlogits, B, L, V):
+    check(_L().avsr_seq_loss(fptr(logits), fptr(labels), fptr(labels_len), fptr(denom), int(compute_denom),
+                             fptr(row_loss), fptr(dlogits), B, L, V, _s()), "avsr_seq_loss")
+
+
+def au_loss(z, aus, lens, row_loss, dz, B, T, weight):
+    check(_L().avsr_au_loss(fptr(z), fptr(aus), fptr(lens), fptr(row_loss), fptr(dz), B, T, float(weight), _s()),
+          "avsr_au_loss")
+
+
+def normed_v(v, g, vn, H):
+    check(_L().avsr_normed_v(fptr(v), fptr(g), fptr(vn), H, _s()), "avsr_normed_v")
+
+
+def normed_v_bwd(v, g, dvn, dv, dg, H):
+    check(_L().avsr_normed_v_bwd(fptr(v), fptr(g), fptr(dvn), fptr(dv), fptr(dg), H, _s()), "avsr_normed_v_bwd")
+
+
+def reduce_scalar(part, n, out, do_sqrt=False, accumulate=False, scale=1.0, out_offset=0):
+    check(_L().avsr_reduce_scalar(fptr(part), n, fptr(out, out_offset), int(do_sqrt), int(accumulate), float(scale),
+                                  _s()), "avsr_reduce_scalar")
+
+
+def l2_regularise(segments, params, grads, l2, loss_accum, scratch):
+    n = len(segments)
+    if n == 0:
+        return
+    off = (C.c_int64 * n)(*[int(o) for o, _ in segments])
+    cnt = (C.c_int64 * n)(*[int(c) for _, c in segments])
+    check(_L().avsr_l2_regularise(off, cnt, n, fptr(params), fptr(grads), float(l2), fptr(loss_accum), fptr(scratch),
+                                  _s()), "avsr_l2_regularise")
+
+
+def global_norm(grads, n, norm_out, scratch, grad_scale=1.0):
+    check(_L().avsr_global_norm(fptr(grads), n, float(grad_scale), fptr(norm_out), fptr(scratch), _s()),
+          "avsr_global_norm")
+
+
+def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, grad_scale=1.0):
+    check(_L().avsr_adam_step(fptr(params), fptr(grads), fptr(m), fptr(v), n, fptr(gnorm), fptr(step), float(lr),
+                              int(warmup_steps), float(clip_norm), float(grad_scale), _s()), "avsr_adam_step")

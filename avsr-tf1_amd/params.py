@@ -1,8 +1,17 @@
-"""TF-layout <-> engine-layout weight conversion (numpy, host side).
+"""Parameter inventory, initialisers and TF-layout <-> engine-layout conversion (host side, numpy).
 
-TF stores `LSTMCell.kernel` as [in+H, 4H] with gate blocks i, j, f, o (rnn_cell_impl.py); the
-engine interleaves gates per unit (column u*4+g) so a 16-column MFMA tile holds 4 whole units."""
+Variable set and shapes follow the reference graph (cells.py:14-18, encoder.py:124-141/:174-176,
+attention.py:26-72 mechanisms + AttentionWrapper attention_layer, decoder_unimodal.py:80-91/:112,
+decoder_bimodal.py:482).  TF stores `LSTMCell.kernel` as [in+H, 4H] with gate blocks i, j, f, o;
+the engine interleaves gates per unit (column u*4+g) so a 16-column MFMA tile holds 4 whole units."""
+import math
+from collections import OrderedDict
+
 import numpy as np
+
+from .config import BAHDANAU_TYPES, ModelConfig
+
+NON_TRAINABLE = ("moving_mean", "moving_variance")
 
 
 def lstm_kernel_to_engine(W):
@@ -25,3 +34,116 @@ def lstm_bias_to_engine(b):
 def lstm_bias_from_engine(b):
     H = b.shape[0] // 4
     return np.ascontiguousarray(b.reshape(H, 4).T.reshape(4 * H))
+
+
+def to_engine(kind, a):
+    if kind == "lstm_kernel":
+        return lstm_kernel_to_engine(a)
+    if kind == "lstm_bias":
+        return lstm_bias_to_engine(a)
+    return np.ascontiguousarray(a)
+
+
+def from_engine(kind, a):
+    if kind == "lstm_kernel":
+        return lstm_kernel_from_engine(a)
+    if kind == "lstm_bias":
+        return lstm_bias_from_engine(a)
+    return np.ascontiguousarray(a)
+
+
+def inventory(cfg: ModelConfig):
+    """OrderedDict name -> (tf_shape, kind, init) for every variable of the model, in a fixed order.
+    kind: lstm_kernel | lstm_bias | plain;  init: vs (variance scaling) | glorot | zeros | ones | emb | const:x"""
+    inv = OrderedDict()
+    dec = cfg.decoder_units[0]
+    for stream in cfg.streams():
+        feat, units = cfg.feat(stream), cfg.units(stream)
+        if cfg.batch_normalisation:
+            inv[f"{stream}/bn/gamma"] = ((feat,), "plain", "ones")
+            inv[f"{stream}/bn/beta"] = ((feat,), "plain", "zeros")
+            inv[f"{stream}/bn/moving_mean"] = ((feat,), "plain", "zeros")
+            inv[f"{stream}/bn/moving_variance"] = ((feat,), "plain", "ones")
+        attentive = cfg.architecture == "av_align" and stream == "audio"
+        for d in cfg.directions():
+            i = feat
+            for l, u in enumerate(units):
+                extra = units[-1] if (attentive and l == len(units) - 1) else 0
+                inv[f"{stream}/enc/{d}/l{l}/kernel"] = ((i + extra + u, 4 * u), "lstm_kernel", "vs")
+                inv[f"{stream}/enc/{d}/l{l}/bias"] = ((4 * u,), "lstm_bias", "zeros")
+                i = u
+        if attentive:
+            _attention(inv, "audio/enc/att0", cfg.attention_type[0][0], cfg.memory_depth("video"), units[-1])
+        if cfg.encoder_type == "bidirectional":
+            inv[f"{stream}/enc/proj_c"] = ((2 * units[-1], dec), "plain", "glorot")
+            inv[f"{stream}/enc/proj_h"] = ((2 * units[-1], dec), "plain", "glorot")
+        if stream == "video" and cfg.regress_aus:
+            inv["video/au/kernel"] = ((cfg.memory_depth("video"), 2), "plain", "glorot")
+            inv["video/au/bias"] = ((2,), "plain", "zeros")
+    V, E = cfg.vocab_size, cfg.embedding_size
+    inv["dec/embedding"] = ((V, E), "plain", "emb")
+    mems = cfg.decoder_memories()
+    A = dec * len(mems)
+    inv["dec/l0/kernel"] = ((E + A + dec, 4 * dec), "lstm_kernel", "vs")
+    inv["dec/l0/bias"] = ((4 * dec,), "lstm_bias", "zeros")
+    for i, (stream, t) in enumerate(mems):
+        _attention(inv, f"dec/att{i}", t, cfg.memory_depth(stream), dec)
+    O = A if cfg.output_attention() else dec
+    inv["dec/out/kernel"] = ((O, V), "plain", "glorot")
+    inv["dec/out/bias"] = ((V,), "plain", "zeros")
+    if cfg.architecture == "bimodal":
+        inv["dec/state_proj"] = ((2 * dec, dec), "plain", "glorot")
+    return inv
+
+
+def _attention(inv, prefix, att_type, depth, units):
+    inv[prefix + "/memory_kernel"] = ((depth, units), "plain", "glorot")
+    if att_type == "scaled_luong":
+        inv[prefix + "/g"] = ((1,), "plain", "const:1.0")
+    if att_type in BAHDANAU_TYPES:
+        inv[prefix + "/query_kernel"] = ((units, units), "plain", "glorot")
+        inv[prefix + "/v"] = ((units,), "plain", "glorot_vec")
+        if att_type == "normed_bahdanau":
+            inv[prefix + "/g"] = ((1,), "plain", "const:%r" % math.sqrt(1.0 / units))
+            inv[prefix + "/b"] = ((units,), "plain", "zeros")
+    inv[prefix + "/layer_kernel"] = ((units + depth, units), "plain", "glorot")
+
+
+def is_l2(name):
+    """seq2seq.py:283-290: variables whose name contains 'lstm_' and not 'bias' = the RNN cell kernels."""
+    return name.endswith("/kernel") and ("/enc/fw/" in name or "/enc/bw/" in name or name.startswith("dec/l"))
+
+
+def initialise(cfg: ModelConfig, seed=0):
+    """Reference initialisers (TF layout): variance-scaling truncated normal for LSTM kernels (cells.py:17),
+    glorot-uniform Dense kernels, zero biases, uniform +-1.732/V embedding (decoder_unimodal.py:80-83)."""
+    rng = np.random.default_rng(seed)
+    out = OrderedDict()
+    for name, (shape, _kind, init) in inventory(cfg).items():
+        if init == "vs":
+            std = math.sqrt(1.0 / shape[0]) / 0.87962566103423978
+            x = rng.standard_normal(shape)
+            bad = np.abs(x) > 2.0
+            while bad.any():
+                x[bad] = rng.standard_normal(int(bad.sum()))
+                bad = np.abs(x) > 2.0
+            a = x * std
+        elif init == "glorot":
+            lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+            a = rng.uniform(-lim, lim, shape)
+        elif init == "glorot_vec":
+            lim = math.sqrt(6.0 / (shape[0] + 1))
+            a = rng.uniform(-lim, lim, shape)
+        elif init == "emb":
+            lim = 1.732 / shape[0]
+            a = rng.uniform(-lim, lim, shape)
+        elif init == "ones":
+            a = np.ones(shape)
+        elif init == "zeros":
+            a = np.zeros(shape)
+        elif init.startswith("const:"):
+            a = np.full(shape, float(init[6:]))
+        else:
+            raise ValueError(init)
+        out[name] = a.astype(np.float32)
+    return out

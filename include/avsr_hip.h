@@ -64,6 +64,7 @@ typedef struct avsr_gemm_desc {
   float alpha, beta;
   int32_t batch;
   int64_t stride_a, stride_b, stride_c;
+  const float* alpha_dev;       /* optional device scalar multiplied into alpha (learned attention scale g) */
   int32_t splitk;
   int32_t pad_;
   float* workspace;

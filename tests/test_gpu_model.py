@@ -1,0 +1,122 @@
+"""Model-level parity: full train step (fwd, BPTT, clip, Adam) and greedy decode through the C ABI vs the
+CPU oracle.  "vs CPU restatement of TF-1.13.1 semantics; TF parity unpinned" (SURVEY.md 8c).
+
+Tolerances: logits / loss / global norm 1e-4 absolute (north_star), gradients 2e-4 of the tensor's max
+magnitude, greedy ids bit-exact."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "c1_audio_uni_luong": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
+                               attention_type=(("scaled_luong",), ("scaled_luong",))),
+    "audio_uni3_luong": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32, 32),
+                             attention_type=(("luong",), ("luong",))),
+    "c2_audio_bi_bahdanau": dict(architecture="unimodal", encoder_type="bidirectional", video_units=None, audio_units=(32, 32),
+                                 attention_type=(("bahdanau",), ("bahdanau",))),
+    "c3_video_bi_normed": dict(architecture="unimodal", encoder_type="bidirectional", video_units=(32, 32), audio_units=None,
+                               attention_type=(("normed_bahdanau",), ("normed_bahdanau",)), regress_aus=True),
+    "c4_bimodal_uni": dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
+                           attention_type=(("scaled_luong",), ("scaled_luong",)), regress_aus=True),
+    "bimodal_bi_mixed": dict(architecture="bimodal", encoder_type="bidirectional", video_units=(16,), audio_units=(16, 16),
+                             decoder_units=(32,), attention_type=(("normed_bahdanau",), ("bahdanau",))),
+    "c5_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
+                        attention_type=(("scaled_luong",), ("scaled_luong",)), regress_aus=True),
+    "av_align_1layer_bahdanau": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32,), audio_units=(32,),
+                                     attention_type=(("bahdanau",), ("luong",))),
+    "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
+                          batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
+}
+
+
+def make(case, B=5, Ta=21, Tv=9, L=7, ragged=True, **over):
+    from avsr_tf1_amd.config import ModelConfig
+    from oracle import avsr_oracle as O
+    kw = dict(decoder_units=(32,), embedding_size=16, video_feat=12, audio_feat=20)
+    kw.update(CASES[case])
+    kw.update(over)
+    ocfg = O.OracleConfig(**kw)
+    mcfg = ModelConfig(**{f.name: getattr(ocfg, f.name) for f in dataclasses.fields(ModelConfig) if hasattr(ocfg, f.name)})
+    W = O.init_params(ocfg, seed=2001)
+    # non-trivial biases / BN parameters so that every term is exercised
+    rng = np.random.default_rng(7)
+    for k in W:
+        if k.endswith(("bias", "/b", "beta")):
+            W[k] = (rng.standard_normal(W[k].shape) * 0.1).astype(np.float32)
+        if k.endswith("gamma"):
+            W[k] = (1.0 + rng.standard_normal(W[k].shape) * 0.1).astype(np.float32)
+        if k.endswith("/g"):
+            W[k] = (W[k] * 1.3).astype(np.float32)
+    batch = O.synthetic_batch(ocfg, B=B, T_a=Ta, T_v=Tv, L=L, ragged=ragged)
+    return O, ocfg, mcfg, W, batch
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_train_step_parity(case):
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    O, ocfg, mcfg, W, batch = make(case)
+    ref = O.train_step(W, None, ocfg, batch)
+    model = Seq2SeqModel(mcfg, weights=W)
+    dbatch = Batch.from_numpy(batch)
+    logits = model.forward_train(dbatch)
+    torch.cuda.synchronize()
+    lg = logits.cpu().numpy()
+    assert np.isfinite(lg).all()
+    assert np.abs(lg - ref["logits"]).max() < 1e-4, np.abs(lg - ref["logits"]).max()
+    model.backward()
+    model.apply_update()
+    torch.cuda.synchronize()
+    assert abs(float(model.loss.item()) - ref["loss"]) < 1e-4, (float(model.loss.item()), ref["loss"])
+    assert abs(float(model.gnorm.item()) - ref["global_norm"]) < 1e-4 * max(1.0, ref["global_norm"])
+    grads = model.export_tf_weights("grads")
+    for k, g in ref["grads"].items():
+        scale = max(1e-3, np.abs(g).max())
+        err = np.abs(grads[k] - g).max()
+        assert err < 2e-4 * scale + 1e-6, (k, err, scale)
+    newp = model.export_tf_weights("params")
+    for k, v in ref["params"].items():
+        err = np.abs(newp[k] - v).max()
+        assert err < 2e-5, (k, err)     # one Adam step moves each weight by <= lr_t ~ 4e-5 at step 1 of warm-up
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_greedy_decode_parity(case):
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    O, ocfg, mcfg, W, batch = make(case)
+    # a few training steps of the oracle make EOS reachable for some utterances; decode must agree exactly
+    ids_ref, lg_ref = O.greedy_decode(W, ocfg, batch, max_steps=12, return_logits=True)
+    model = Seq2SeqModel(mcfg, weights=W)
+    ids = model.greedy_decode(Batch.from_numpy(batch), max_steps=12).cpu().numpy()
+    assert ids.shape == ids_ref.shape, (ids.shape, ids_ref.shape)
+    assert (ids == ids_ref).all()
+    ws, t_out = model._last_greedy
+    lg = ws["dec"]["logits"][:, :t_out].cpu().numpy()
+    assert np.abs(lg - lg_ref).max() < 1e-4
+
+
+def test_second_step_and_eos_path():
+    """Two consecutive train steps (Adam state, BN moving averages) and a decode where EOS fires early."""
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    O, ocfg, mcfg, W, batch = make("c4_bimodal_uni")
+    r1 = O.train_step(W, None, ocfg, batch)
+    r2 = O.train_step(r1["params"], r1["opt"], ocfg, batch)
+    model = Seq2SeqModel(mcfg, weights=W)
+    db = Batch.from_numpy(batch)
+    model.train_step(db)
+    loss2, gn2 = model.train_step(db)
+    torch.cuda.synchronize()
+    assert abs(float(loss2.item()) - r2["loss"]) < 1e-4
+    newp = model.export_tf_weights("params")
+    for k, v in r2["params"].items():
+        assert np.abs(newp[k] - v).max() < 5e-5, k
+    # force EOS: bias the output layer towards EOS so every utterance finishes at step 0 or 1
+    W2 = {k: v.copy() for k, v in r2["params"].items()}
+    W2["dec/out/bias"][ocfg.eos_id] += 3.0
+    ids_ref = O.greedy_decode(W2, ocfg, batch, max_steps=10)
+    m2 = Seq2SeqModel(mcfg, weights=W2)
+    ids = m2.greedy_decode(db, max_steps=10).cpu().numpy()
+    assert ids.shape == ids_ref.shape and (ids == ids_ref).all()
