@@ -161,16 +161,17 @@ __global__ void seqlen_sum_kernel(const int32_t* len, int B, int L, float* denom
   if (threadIdx.x == 0) denom[0] = s;
 }
 
-__global__ void seq_loss_kernel(const float* logits, const int32_t* labels, const int32_t* len, const float* denom,
+__global__ void seq_loss_kernel(float* logits, const int32_t* labels, const int32_t* len, const float* denom,
                                 float* row_loss, float* dlogits, int B, int L, int V) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= B * L) return;
   const int b = row / L, l = row % L;
-  const float* lg = logits + (long)row * V;
+  float* lg = logits + (long)row * V;
   float* dl = dlogits ? dlogits + (long)row * V : nullptr;
   const bool valid = l < len[b];
   if (!valid) {
     row_loss[row] = 0.f;
+    for (int v = 0; v < V; ++v) lg[v] = 0.f;       // dynamic_decode(impute_finished=True): zero outputs once finished
     if (dl) for (int v = 0; v < V; ++v) dl[v] = 0.f;
     return;
   }
@@ -410,7 +411,7 @@ extern "C" int avsr_embed_grad(const float* dx, const int32_t* labels, int32_t g
   return AVSR_OK;
 }
 
-extern "C" int avsr_seq_loss(const float* logits, const int32_t* labels, const int32_t* labels_len, float* denom,
+extern "C" int avsr_seq_loss(float* logits, const int32_t* labels, const int32_t* labels_len, float* denom,
                              int32_t compute_denom, float* row_loss, float* dlogits, int32_t B, int32_t L, int32_t V,
                              void* stream) {
   if (!logits || !labels || !labels_len || !denom || !row_loss) return AVSR_ERR_ARG;

@@ -107,7 +107,7 @@ class Seq2SeqModel:
         self.params, self.grads, self.adam_m, self.adam_v = z(nt), z(nt), z(nt), z(nt)
         self.stats = z(ns)
         self.n_train = nt
-        self.step = z(1, torch.int32)
+        self.step = z(1, torch.int32)[:1]
         self.P = {n: Ref(self.params, o, self._eshape(n)) for n, o in self._train_off.items()}
         self.G = {n: Ref(self.grads, o, self._eshape(n)) for n, o in self._train_off.items()}
         self.S = {n: Ref(self.stats, o, self.inv[n][0]) for n, o in self._stat_off.items()}
@@ -129,9 +129,9 @@ class Seq2SeqModel:
         self.load_tf_weights(weights if weights is not None else PR.initialise(cfg, seed))
         self.scratch = z(1 << 22)
         self.gemm_ws = None
-        self.loss = z(1)
-        self.gnorm = z(1)
-        self.denom = z(1)
+        self.loss = z(1)[:1]
+        self.gnorm = z(1)[:1]
+        self.denom = z(1)[:1]
 
     # ------------------------------------------------------------------------------------------------
     def _eshape(self, name):

@@ -257,8 +257,9 @@ int avsr_embed_grad(const float* dx, const int32_t* labels, int32_t go_id, float
 
 /* seq2seq.sequence_loss (avsr/seq2seq.py:165-171): row_loss[b*L+l] = CE * mask / (sum(mask) + 1e-12) and
  * d loss / d logits.  denom[0] = sum(mask) is computed when compute_denom=1 (single GPU) or supplied
- * (data parallel: all-reduced by the caller). */
-int avsr_seq_loss(const float* logits, const int32_t* labels, const int32_t* labels_len, float* denom,
+ * (data parallel: all-reduced by the caller).  Logit rows of finished steps are zeroed in place
+ * (dynamic_decode impute_finished=True, avsr/decoder_unimodal.py:344-350). */
+int avsr_seq_loss(float* logits, const int32_t* labels, const int32_t* labels_len, float* denom,
                   int32_t compute_denom, float* row_loss, float* dlogits, int32_t B, int32_t L, int32_t V, void* stream);
 
 /* AU regression loss (avsr/encoder.py:173-189); z = pre-sigmoid Dense(2) outputs [B][T][2]. */
