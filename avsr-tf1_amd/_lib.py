@@ -92,7 +92,7 @@ EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr
            "avsr_attn_rnn_bwd", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_colsum",
            "avsr_batchnorm_fwd", "avsr_batchnorm_xhat", "avsr_embed_labels", "avsr_embed_grad", "avsr_seq_loss",
            "avsr_au_loss", "avsr_normed_v", "avsr_normed_v_bwd", "avsr_reduce_scalar", "avsr_l2_regularise",
-           "avsr_global_norm", "avsr_adam_step"]
+           "avsr_global_norm", "avsr_adam_step", "avsr_prof_begin", "avsr_prof_end"]
 
 _lib = None
 
@@ -143,6 +143,8 @@ def load():
         "avsr_l2_regularise": [C.POINTER(i64), C.POINTER(i64), i32, vp, vp, f32, vp, vp, vp],
         "avsr_global_norm": [vp, i64, f32, vp, vp, vp],
         "avsr_adam_step": [vp, vp, vp, vp, i64, vp, vp, f32, i32, f32, f32, vp],
+        "avsr_prof_begin": [i32],
+        "avsr_prof_end": [C.POINTER(i32), C.POINTER(f32)],
     }
     for name, at in sigs.items():
         fn = getattr(lib, name)

@@ -18,6 +18,7 @@
 // the context phase assigns one float4 column per thread and walks rows, fully coalesced.
 // Rows past len[b] are never loaded.
 #include "attn.h"
+#include "prof.h"
 
 namespace avsr {
 
@@ -282,6 +283,7 @@ extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stre
   if (!L || L->nmech <= 0 || L->nmech > AVSR_MAX_MECH) return AVSR_ERR_ARG;
   const int nblk = L->blk_off[L->nmech];
   if (nblk <= 0) return AVSR_ERR_ARG;
+  ProfScope ps(backward ? PROF_ATTN_BWD : PROF_ATTN_FWD, (hipStream_t)stream);
   if (backward) hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *L);
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *L);
   AVSR_CHECK_LAUNCH();

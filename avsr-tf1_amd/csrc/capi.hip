@@ -14,3 +14,53 @@ extern "C" int64_t avsr_sizeof(const char* name) {
 #undef SZ
   return -1;
 }
+
+// ---- per-kernel event profiler ---------------------------------------------------------------------
+#include <vector>
+#include "prof.h"
+namespace avsr {
+bool g_prof_enabled = false;
+static std::vector<hipEvent_t> g_ev;      // pairs: [2i] start, [2i+1] stop
+static std::vector<int> g_kind;
+static size_t g_used = 0;
+void prof_record(int kind, hipStream_t s, bool begin) {
+  if (begin) {
+    if (g_used >= g_kind.size()) { g_prof_enabled = false; return; }
+    g_kind[g_used] = kind;
+    hipEventRecord(g_ev[2 * g_used], s);
+  } else {
+    hipEventRecord(g_ev[2 * g_used + 1], s);
+    ++g_used;
+  }
+}
+}  // namespace avsr
+
+extern "C" int avsr_prof_begin(int32_t max_launches) {
+  using namespace avsr;
+  if (max_launches <= 0) return AVSR_ERR_ARG;
+  while (g_ev.size() < (size_t)2 * max_launches) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return AVSR_ERR_HIP;
+    g_ev.push_back(e);
+  }
+  g_kind.assign(max_launches, 0);
+  g_used = 0;
+  g_prof_enabled = true;
+  return AVSR_OK;
+}
+
+// out_count[k], out_ms[k] for k < AVSR_PROF_NKIND (gemm, lstm_fwd step, lstm_bwd step, dense step, attn fwd, attn bwd)
+extern "C" int avsr_prof_end(int32_t* out_count, float* out_ms) {
+  using namespace avsr;
+  g_prof_enabled = false;
+  if (!out_count || !out_ms) return AVSR_ERR_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return AVSR_ERR_HIP;
+  for (int k = 0; k < PROF_NKIND; ++k) { out_count[k] = 0; out_ms[k] = 0.f; }
+  for (size_t i = 0; i < g_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_ev[2 * i], g_ev[2 * i + 1]) != hipSuccess) return AVSR_ERR_HIP;
+    out_count[g_kind[i]] += 1;
+    out_ms[g_kind[i]] += ms;
+  }
+  return AVSR_OK;
+}

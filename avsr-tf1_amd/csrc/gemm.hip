@@ -19,6 +19,7 @@
 // tall-skinny dW GEMMs (K = B*T rows, tiny M x N).
 #include "common.h"
 #include "avsr_hip.h"
+#include "prof.h"
 
 namespace avsr {
 
@@ -241,6 +242,7 @@ extern "C" int avsr_gemm(const avsr_gemm_desc* d, void* stream) {
   const bool vb = vec_ok(&d->B, g.tb != 0, g.N, g.K);
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * splitk);
   hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(PROF_GEMM, s);
   if (va && vb) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, g);
   else if (va) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, g);
   else if (vb) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, g);

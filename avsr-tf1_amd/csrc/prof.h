@@ -1,0 +1,16 @@
+// Optional per-launch HIP-event timing of the engine's kernels (used by bench.py for the roofline
+// numbers).  Disabled by default: a ProfScope is then two predictable branches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace avsr {
+enum ProfKind { PROF_GEMM = 0, PROF_STEP_LSTM_FWD, PROF_STEP_LSTM_BWD, PROF_STEP_LINEAR, PROF_ATTN_FWD, PROF_ATTN_BWD,
+                PROF_NKIND };
+void prof_record(int kind, hipStream_t s, bool begin);
+extern bool g_prof_enabled;
+struct ProfScope {
+  int kind; hipStream_t s;
+  ProfScope(int k, hipStream_t st) : kind(k), s(st) { if (g_prof_enabled) prof_record(kind, s, true); }
+  ~ProfScope() { if (g_prof_enabled) prof_record(kind, s, false); }
+};
+}  // namespace avsr

@@ -15,6 +15,7 @@
 // LSTM weights are stored gate-interleaved (column = 4*unit + {i,j,f,o}), so a 16-column tile is 4
 // complete units and the epilogue needs no cross-workgroup exchange.
 #include "step.h"
+#include "prof.h"
 
 namespace avsr {
 
@@ -114,6 +115,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void step_kernel(const StepLaunch L) {
   __shared__ __attribute__((aligned(16))) float red[4][16][16];
   const StepTask& tk = L.task[blockIdx.z];
@@ -128,12 +130,12 @@ __global__ __launch_bounds__(256) void step_kernel(const StepLaunch L) {
   __syncthreads();
 
   const int t = tk.t;
-  if (tk.mode == EP_LINEAR || tk.mode == EP_LSTM_BWD) {
+  if constexpr (MODE == EP_LINEAR || MODE == EP_LSTM_BWD) {
     const int r = tid >> 4, cidx = tid & 15;
     const int b = row0 + r, n = col0 + cidx;
     if (b >= tk.B || n >= tk.N) return;
     float z = red[0][r][cidx] + red[1][r][cidx] + red[2][r][cidx] + red[3][r][cidx];
-    if (tk.mode == EP_LINEAR) {
+    if constexpr (MODE == EP_LINEAR) {
       // p0 out (row stride s0), p1 add (row stride s1)
       if (tk.bias) z += tk.bias[n];
       if (tk.p1) z += tk.p1[(long)b * tk.s1 + n];
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void step_kernel(const StepLaunch L) {
     return;
   }
 
-  if (tk.mode == EP_LSTM_FWD) {
+  if constexpr (MODE == EP_LSTM_FWD) {
     // p0 gates/zpre [B,T,H,4], p1 cs [B,T,H], p2 seq_out (s0 batch stride, s1 time stride),
     // p3 c_in, p4 h_in, p5 c_out, p6 h_out; s2 = has_zpre
     if (tid >= 64) return;
@@ -240,7 +242,22 @@ extern "C" int avsr_step_launch_raw(const void* launch, void* stream) {
     if (L->task[i].B > maxB) maxB = L->task[i].B;
   }
   dim3 grid((maxN + 15) / 16, (maxB + 15) / 16, L->ntask);
-  hipLaunchKernelGGL(step_kernel, grid, dim3(256), 0, (hipStream_t)stream, *L);
+  const int mode = L->task[0].mode;
+  for (int i = 1; i < L->ntask; ++i)
+    if (L->task[i].mode != mode) return AVSR_ERR_ARG;   // one epilogue kind per launch
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == EP_LSTM_FWD) {
+    ProfScope ps(PROF_STEP_LSTM_FWD, s);
+    hipLaunchKernelGGL(step_kernel<EP_LSTM_FWD>, grid, dim3(256), 0, s, *L);
+  } else if (mode == EP_LSTM_BWD) {
+    ProfScope ps(PROF_STEP_LSTM_BWD, s);
+    hipLaunchKernelGGL(step_kernel<EP_LSTM_BWD>, grid, dim3(256), 0, s, *L);
+  } else if (mode == EP_LINEAR) {
+    ProfScope ps(PROF_STEP_LINEAR, s);
+    hipLaunchKernelGGL(step_kernel<EP_LINEAR>, grid, dim3(256), 0, s, *L);
+  } else {
+    return AVSR_ERR_UNSUPPORTED;
+  }
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

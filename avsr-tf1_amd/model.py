@@ -126,6 +126,7 @@ class Seq2SeqModel:
         for name, off, r, c in self._tjobs:
             self.Tr[name] = Ref(self.derived, off, (c, r))
         self._ws_cache = {}
+        self.au_scale = 1.0          # data parallel: 1 / world_size (AU term averaged over ranks)
         self.load_tf_weights(weights if weights is not None else PR.initialise(cfg, seed))
         self.scratch = z(1 << 22)
         self.gemm_ws = None
@@ -316,7 +317,7 @@ class Seq2SeqModel:
             if s == "video" and cfg.regress_aus and training:
                 Wau = self.P["video/au/kernel"]
                 ops.gemm(E["mem"].mat(), Wau.mat(2), ops.mat(E["au_z"], 2), B * E["T"], 2, E["mem"].D, bias=self._pp("video/au/bias"))
-                ops.au_loss(E["au_z"], batch.aus, E["len"], E["au_row"], E["au_dz"], B, E["T"], cfg.au_loss_weight)
+                ops.au_loss(E["au_z"], batch.aus, E["len"], E["au_row"], E["au_dz"], B, E["T"], cfg.au_loss_weight * self.au_scale)
 
     @staticmethod
     def _run_stacks(stacks, fn):

@@ -149,3 +149,18 @@ def global_norm(grads, n, norm_out, scratch, grad_scale=1.0):
 def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, grad_scale=1.0):
     check(_L().avsr_adam_step(fptr(params), fptr(grads), fptr(m), fptr(v), n, fptr(gnorm), fptr(step), float(lr),
                               int(warmup_steps), float(clip_norm), float(grad_scale), _s()), "avsr_adam_step")
+
+
+PROF_KINDS = ("gemm", "step_lstm_fwd", "step_lstm_bwd", "step_dense", "attn_fwd", "attn_bwd")
+
+
+def prof_begin(max_launches=65536):
+    check(_L().avsr_prof_begin(int(max_launches)), "avsr_prof_begin")
+
+
+def prof_end():
+    """{kind: (launch count, total ms)} since prof_begin (synchronises the device)."""
+    cnt = (C.c_int32 * len(PROF_KINDS))()
+    ms = (C.c_float * len(PROF_KINDS))()
+    check(_L().avsr_prof_end(cnt, ms), "avsr_prof_end")
+    return {k: (int(cnt[i]), float(ms[i])) for i, k in enumerate(PROF_KINDS)}

@@ -1,0 +1,99 @@
+"""Data-parallel training by utterance + hipGraph replay of the train step.
+
+The reference is single-device (`num_gpus` is deprecated and ignored, avsr/avsr.py:67,:127).  This is
+the MI355X-native addition SURVEY.md 8(e) describes: one process per GPU, each rank runs the whole
+hot path on its shard of the utterances, and the only collectives are
+  (1) a scalar all-reduce of sum(mask) so every rank normalises the sequence loss by the GLOBAL token
+      count (seq2seq.py:165-171), before the backward pass;
+  (2) ONE all-reduce (sum) of the flat fp32 gradient buffer (RCCL over xGMI) between BPTT and the
+      clip/Adam update, so global-norm clipping and Adam see identical gradients on every rank.
+Encoder-input batch-norm statistics stay per rank (no sync-BN) and the AU regression term is averaged
+over ranks; both are noted in DESIGN.md.
+
+Launch overhead: a train step is ~1.3k dependent kernel launches; they are captured once per batch
+shape into a hipGraph (torch.cuda.CUDAGraph is only the capture/replay plumbing -- every node is one
+of our kernels or a memset/memcpy) and replayed.
+"""
+import torch
+
+
+class DataParallelTrainer:
+    def __init__(self, model, dist=None, use_graph=True):
+        self.model, self.dist = model, dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.use_graph = use_graph
+        self.mode = "eager"
+        self._graphs = {}
+        self._static = {}
+        model.au_scale = 1.0 / self.world
+
+    # -- helpers ----------------------------------------------------------------------------------
+    @staticmethod
+    def _key(batch):
+        return tuple((None if t is None else tuple(t.shape)) for t in
+                     (batch.audio, batch.video, batch.labels))
+
+    def _stage(self, key, batch):
+        """Copy the batch into the static buffers the captured graph reads."""
+        st = self._static.get(key)
+        if st is None:
+            st = type(batch)(*[None if t is None else t.clone() for t in
+                               (batch.audio, batch.audio_len, batch.video, batch.video_len, batch.aus, batch.labels,
+                                batch.labels_len)])
+            self._static[key] = st
+            return st
+        for name in ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len"):
+            src, dst = getattr(batch, name), getattr(st, name)
+            if src is not None and src.data_ptr() != dst.data_ptr():
+                dst.copy_(src)
+        return st
+
+    def _fwd_bwd(self, batch):
+        self.model.forward_train(batch, compute_denom=(self.world == 1))
+        self.model.backward()
+
+    def _capture(self, fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
+
+    # -- one training step ---------------------------------------------------------------------------
+    def train_step(self, batch):
+        m, dist = self.model, self.dist
+        key = self._key(batch)
+        if self.world > 1:
+            # global loss normaliser: sum over ALL ranks of min(labels_len, L)
+            L = batch.labels.shape[1]
+            m.denom.copy_(batch.labels_len.clamp(0, L).sum().to(torch.float32).reshape(1))
+            dist.all_reduce(m.denom)
+        if not self.use_graph:
+            self._fwd_bwd(batch)
+            if self.world > 1:
+                dist.all_reduce(m.grads)
+            m.apply_update()
+            return m.loss, m.gnorm
+        st = self._stage(key, batch)
+        gr = self._graphs.get(key)
+        if gr is None:
+            # one eager step allocates every workspace; then capture
+            self._fwd_bwd(st)
+            if self.world > 1:
+                dist.all_reduce(m.grads)
+            m.apply_update()
+            torch.cuda.synchronize()
+            try:
+                ga = self._capture(lambda: self._fwd_bwd(st))
+                gb = self._capture(m.apply_update)
+                self._graphs[key] = gr = (ga, gb)
+                self.mode = "hipgraph"
+            except Exception as e:  # capture unsupported: stay eager (still the HIP engine, just host-launched)
+                self.use_graph = False
+                self.mode = "eager (graph capture failed: %s)" % type(e).__name__
+            return m.loss, m.gnorm
+        ga, gb = gr
+        ga.replay()
+        if self.world > 1:
+            dist.all_reduce(m.grads)
+        gb.replay()
+        return m.loss, m.gnorm

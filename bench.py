@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py -- utterances/sec of one full AVSR train step (fwd + BPTT + clip + Adam) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c2|c3|c5] [--no-graph]
+
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL): utterances are
+sharded across ranks (weak scaling: B utterances PER GPU), the only collective on the data path is the
+gradient all-reduce (+ a scalar all-reduce of the loss normaliser).
+
+Prints ONE JSON line (rank 0).  `value` = utterances processed by all ranks / max-over-ranks wall time,
+inputs resident in HBM.  `roofline` = the dominant kernel of the step (by summed time, measured here with
+HIP events around every launch in a separate eager pass); `cpu_baseline` = the CPU oracle restatement
+(torch-CPU fp32, "port") on a bounded sample of the same workload -- a reported baseline, not a target.
+The reference publishes no number for this metric, so `vs_baseline` is null.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[3]: AV dual-attention WLAS, reference defaults (uni encoders, scaled_luong), B=64
+    "c4": dict(desc="AV dual-attention (bimodal) video 1x256 + audio 3x256 uni-LSTM, scaled_luong, B=64 T_a=500x80 T_v=75x128(features) L=40",
+               B=64, cfg=dict(architecture="bimodal", encoder_type="unidirectional", video_units=(256,), audio_units=(256, 256, 256),
+                              attention_type=(("scaled_luong",), ("scaled_luong",)), regress_aus=True)),
+    # configs[1]: audio-only LAS 3 x bi-LSTM-256 + Bahdanau decoder
+    "c2": dict(desc="audio-only LAS 3x bi-LSTM-256 + LSTM-256 Bahdanau decoder, B=64 T_a=500x80 L=40",
+               B=64, cfg=dict(architecture="unimodal", encoder_type="bidirectional", video_units=None, audio_units=(256, 256, 256),
+                              attention_type=(("bahdanau",), ("bahdanau",)))),
+    # configs[2]: visual-only 2 x bi-LSTM-256 (lip CNN bypassed: video_processing='features')
+    "c3": dict(desc="visual-only 2x bi-LSTM-256 on 128-d lip features (CNN front-end not built), B=64 T_v=75 L=40",
+               B=64, cfg=dict(architecture="unimodal", encoder_type="bidirectional", video_units=(256, 256), audio_units=None,
+                              attention_type=(("scaled_luong",), ("scaled_luong",)), regress_aus=True)),
+    # configs[4]: AV-Align (uni encoders -- the reference implements AV-Align for unidirectional only), B=128
+    "c5": dict(desc="AV-Align video 1x256 + audio 3x256 (top layer attends video), scaled_luong, B=128 T_a=500 T_v=75 L=40",
+               B=128, cfg=dict(architecture="av_align", encoder_type="unidirectional", video_units=(256,), audio_units=(256, 256, 256),
+                               attention_type=(("scaled_luong",), ("scaled_luong",)), regress_aus=True)),
+}
+TA, TV, LDEC, FA, FV = 500, 75, 40, 80, 128
+
+
+def synth(cfg, B, rank):
+    """SURVEY 8(d) synthetic inputs, fixed seeds (offset per rank so shards differ)."""
+    r = lambda k: np.random.default_rng(1000 + k + 100 * rank)
+    d = {}
+    if cfg.audio_units is not None:
+        d["audio"] = r(1).standard_normal((B, TA, FA)).astype(np.float32)
+        d["audio_len"] = np.full(B, TA, np.int32)
+    if cfg.video_units is not None:
+        d["video"] = r(3).standard_normal((B, TV, FV)).astype(np.float32)
+        d["video_len"] = np.full(B, TV, np.int32)
+        d["aus"] = r(5).uniform(0, 3, (B, TV, 2)).astype(np.float32)
+    lab = r(6).integers(1, 29, (B, LDEC)).astype(np.int32)
+    lab[:, -1] = 29
+    d["labels"], d["labels_len"] = lab, np.full(B, LDEC, np.int32)
+    return d
+
+
+class NS:
+    def __init__(self, d):
+        self.__dict__.update(d)
+
+
+def work_model(cfg, B):
+    """Algorithmic FLOPs / bytes per launch class for the roofline (fp32)."""
+    H = cfg.decoder_units[0]
+    mems = cfg.decoder_memories()
+    attn_bytes = sum(4 * B * (TA if s == "audio" else TV) * (H + cfg.memory_depth(s)) for s, _ in mems)
+    A = H * len(mems)
+    # forward LSTM step launches: encoder wavefront (x part of layer 0 is hoisted) + decoder cell (embedding hoisted)
+    fl_f = n_f = 0
+    fl_b = n_b = 0
+    nsteps = 0
+    for s in cfg.streams():
+        T = TA if s == "audio" else TV
+        units = cfg.units(s)
+        attentive = cfg.architecture == "av_align" and s == "audio"
+        nplain = len(units) - 1 if attentive else len(units)
+        nsteps = max(nsteps, T + nplain - 1)
+        for _d in cfg.directions():
+            for l in range(nplain):
+                u = units[l]
+                kin = 0 if l == 0 else units[l - 1]
+                fl_f += T * 2 * B * (kin + u) * 4 * u
+                up = units[l + 1] if l + 1 < nplain else 0
+                fl_b += T * 2 * B * (4 * u + 4 * up) * u
+        if attentive:
+            u = units[-1]
+            fl_f += T * 2 * B * (u + u) * 4 * u
+            fl_b += T * 2 * B * (4 * u + u) * u
+            n_f += T
+            n_b += T
+    n_f += nsteps + LDEC
+    n_b += nsteps + LDEC
+    fl_f += LDEC * 2 * B * (A + H) * 4 * H
+    fl_b += LDEC * 2 * B * (4 * H + A) * H
+    return dict(attn_bytes=attn_bytes, lstm_fwd_flops=fl_f / max(1, n_f), lstm_bwd_flops=fl_b / max(1, n_b))
+
+
+def cpu_baseline(wl, sample_B=8, steps=2):
+    """The CPU oracle (torch-CPU fp32 restatement, all host threads) on a bounded sample: sample_B utterances at
+    full T_a/T_v/L.  'TF-1.13.1 CPU number unavailable' -- see BASELINE.md section 2."""
+    from oracle import avsr_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    ocfg = O.OracleConfig(**wl["cfg"])
+    P = O.init_params(ocfg, seed=2001)
+    b = O.synthetic_batch(ocfg, B=sample_B, T_a=TA, T_v=TV, L=LDEC)
+    O.train_step(P, None, ocfg, b, dtype=torch.float32)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.train_step(P, None, ocfg, b, dtype=torch.float32)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(sample_B / dt, 3), "unit": "utterances/sec", "cores": ncores, "kind": "port",
+            "sample": "oracle/avsr_oracle.py train_step (torch-CPU fp32, autograd BPTT), %d utterances at full T_a=%d T_v=%d L=%d, "
+                      "mean of %d steps after 1 warm-up; TF-1.13.1 reference cannot run here" % (sample_B, TA, TV, LDEC, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: the workload's B)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from avsr_tf1_amd import ops
+    from avsr_tf1_amd.config import ModelConfig
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    from avsr_tf1_amd.parallel import DataParallelTrainer
+
+    wl = WORKLOADS[args.workload]
+    B = args.batch or wl["B"]
+    cfg = ModelConfig(audio_feat=FA, video_feat=FV, **wl["cfg"])
+    model = Seq2SeqModel(cfg, seed=2001)
+    trainer = DataParallelTrainer(model, dist, use_graph=not args.no_graph)
+    batch = Batch.from_numpy(NS(synth(cfg, B, rank)))
+
+    for _ in range(max(1, args.warmup)):
+        trainer.train_step(batch)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step(batch)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(model.loss.item())
+
+    out = {
+        "metric": "utterances/sec (train step) at B=64 T_a=500 T_v=75",
+        "value": round(B * world * args.steps / dt, 2), "unit": "utterances/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload + ": " + wl["desc"], "utterances_per_gpu": B, "global_batch": B * world,
+                   "T_a": TA, "F_a": FA, "T_v": TV, "F_v": FV, "T_dec": LDEC, "parallelism": "dp%d" % world,
+                   "launch": trainer.mode, "dropout": False, "scheduled_sampling": False,
+                   "parity": "vs CPU restatement of TF-1.13.1 semantics; TF parity unpinned"},
+        "final_loss": round(loss, 5),
+    }
+
+    if rank == 0 and not args.no_profile:
+        # per-kernel timing: one eager step with a HIP-event pair around every engine launch
+        ops.prof_begin(1 << 16)
+        model.train_step(batch)
+        prof = ops.prof_end()
+        wm = work_model(cfg, B)
+        kinds = {}
+        for k, (cnt, ms) in prof.items():
+            if cnt:
+                kinds[k] = {"launches": cnt, "total_ms": round(ms, 3), "avg_us": round(1e3 * ms / cnt, 3)}
+        out["kernel_time_eager_events"] = kinds
+        dom = max((k for k in kinds if k != "gemm" or True), key=lambda k: kinds[k]["total_ms"])
+        HBM_PEAK, MFMA_PEAK = 8000.0, 157.3
+
+        def roof(kind):
+            us = kinds[kind]["avg_us"]
+            if kind in ("attn_fwd", "attn_bwd"):
+                ach = wm["attn_bytes"] / (us * 1e-6) / 1e9
+                return {"kernel": kind, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": wm["attn_bytes"], "avg_launch_us": us}
+            fl = {"step_lstm_fwd": wm["lstm_fwd_flops"], "step_lstm_bwd": wm["lstm_bwd_flops"]}.get(kind)
+            if fl is None:
+                return {"kernel": kind, "bound": "mfma", "achieved": None, "peak": MFMA_PEAK, "unit": "TFLOP/s", "frac": None,
+                        "traffic": None, "avg_launch_us": us}
+            ach = fl / (us * 1e-6) / 1e12
+            return {"kernel": kind, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK, 4), "traffic": None, "algorithmic_flops_per_launch": int(fl), "avg_launch_us": us}
+
+        out["roofline"] = roof(dom)
+        if "attn_fwd" in kinds:
+            out["roofline_attention_step"] = roof("attn_fwd")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        except Exception as e:  # the oracle is optional test infrastructure
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

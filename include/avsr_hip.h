@@ -284,6 +284,14 @@ int avsr_global_norm(const float* grads, int64_t n, float grad_scale, float* nor
 int avsr_adam_step(float* params, float* grads, float* m, float* v, int64_t n, const float* global_norm, int32_t* step,
                    float lr, int32_t warmup_steps, float clip_norm, float grad_scale, void* stream);
 
+/* Optional per-launch HIP-event timing of the engine's own kernels (bench.py roofline figures).  Between
+ * begin and end every gemm / step / attention launch is bracketed by an event pair on its stream; end
+ * synchronises the device and returns per-kind launch counts and summed milliseconds.
+ * kinds: 0 gemm, 1 LSTM-forward step, 2 LSTM-backward step, 3 dense step, 4 attention fwd, 5 attention bwd. */
+#define AVSR_PROF_NKIND 6
+int avsr_prof_begin(int32_t max_launches);
+int avsr_prof_end(int32_t* out_count, float* out_ms);
+
 #ifdef __cplusplus
 }
 #endif
