@@ -52,13 +52,23 @@ __global__ void colsum_partial_kernel(const float* a, long lda, int Ta, long ldo
   }
 }
 
+// one block per 32 columns: 8 row-groups x 32 columns of threads walk the partials, then an LDS tree
 __global__ void colsum_final_kernel(const float* part, int nblk, float* out, int F, float alpha, float beta) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= F) return;
+  __shared__ double red[8][32];
+  const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int f = blockIdx.x * 32 + fl;
   double s = 0.0;
-  for (int i = 0; i < nblk; ++i) s += (double)part[(long)i * F + f];
-  const float v = alpha * (float)s;
-  out[f] = beta != 0.f ? v + beta * out[f] : v;
+  if (f < F)
+    for (int i = g; i < nblk; i += 8) s += (double)part[(long)i * F + f];
+  red[g][fl] = s;
+  __syncthreads();
+  if (g == 0 && f < F) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += red[j][fl];
+    const float v = alpha * (float)t;
+    out[f] = beta != 0.f ? v + beta * out[f] : v;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -137,18 +147,30 @@ __global__ void embed_labels_kernel(const float* emb, const int32_t* labels, int
   for (int e = threadIdx.x; e < E; e += blockDim.x) out[(long)row * E + e] = emb[(long)tok * E + e];
 }
 
-// d emb[v, :] = sum over rows whose input token == v (deterministic: one block per vocabulary row)
+// d emb[v, :] = sum over rows whose input token == v.  One block per vocabulary row; the token ids of a
+// tile of rows are staged in LDS (broadcast reads), every thread owns embedding columns and walks the
+// tile in row order (deterministic summation order).
 __global__ void embed_grad_kernel(const float* dx, const int32_t* labels, int go, float* demb, int B, int L, int E, int V) {
+  __shared__ int toks[1024];
   const int v = blockIdx.x;
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
-    float s = 0.f;
-    for (int row = 0; row < B * L; ++row) {
-      const int b = row / L, l = row % L;
-      const int tok = (l == 0) ? go : labels[(long)b * L + l - 1];
-      if (tok == v) s += dx[(long)row * E + e];
+  const int rows = B * L;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};      // E <= 4 * blockDim.x
+  for (int base = 0; base < rows; base += 1024) {
+    const int n = min(1024, rows - base);
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      const int row = base + j, b = row / L, l = row % L;
+      toks[j] = (l == 0) ? go : labels[(long)b * L + l - 1];
     }
-    demb[(long)v * E + e] = s;
+    __syncthreads();
+    for (int e = threadIdx.x, slot = 0; e < E && slot < 4; e += blockDim.x, ++slot) {
+      float a = acc[slot];
+      for (int j = 0; j < n; ++j)
+        if (toks[j] == v) a += dx[(long)(base + j) * E + e];
+      acc[slot] = a;
+    }
   }
+  for (int e = threadIdx.x, slot = 0; e < E && slot < 4; e += blockDim.x, ++slot) demb[(long)v * E + e] = acc[slot];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -337,7 +359,7 @@ extern "C" int avsr_transpose(const avsr_transpose_job* jobs, int32_t n, void* s
 extern "C" int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, int32_t F, float alpha, float beta,
                            float* out, float* scratch, int64_t scratch_floats, void* stream) {
   if (!a || !a->ptr || !out || !scratch || rows <= 0 || F <= 0) return AVSR_ERR_ARG;
-  int rpb = 128;
+  int rpb = 32;
   int nblk = (rows + rpb - 1) / rpb;
   if ((long)nblk * F > scratch_floats) {
     nblk = (int)(scratch_floats / F);
@@ -349,7 +371,7 @@ extern "C" int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, i
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(th), 0, S_(stream), a->ptr, (long)a->ld, a->T, (long)a->ldo,
                      b ? b->ptr : nullptr, b ? (long)b->ld : 0, b ? b->T : 0, b ? (long)b->ldo : 0, scratch, rows, F, rpb);
   AVSR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 255) / 256), dim3(256), 0, S_(stream), scratch, nblk, out, F, alpha, beta);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(256), 0, S_(stream), scratch, nblk, out, F, alpha, beta);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

@@ -19,214 +19,310 @@
 
 namespace avsr {
 
-struct TileCtx {
-  int row0, col0;
-};
+static int g_step_geo = -1;   // development override of the workgroup geometry (tools/step_probe.hip)
 
 // ---- the shared MFMA core: returns this wave's partial 16x16 tile -------------------------------
-__device__ __forceinline__ f32x4 mm16_partial(const StepTask& tk, int row0, int col0, bool save_ctx) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// The concatenated K range (all sources) is cut into 16-wide chunks; wave w of NW owns the CONTIGUOUS
+// chunk range [w*NC/NW, (w+1)*NC/NW) so every 128-byte line of an operand row is fetched by one wave.
+// Loads are issued in batches of UN chunks (2*UN 16-byte loads per lane in flight) before the MFMAs
+// that consume them; four independent accumulators keep the matrix pipe at its 32-cycle issue rate.
+
+template <int KP, int UN, int RM>
+__device__ __forceinline__ void mm16_partial(const StepTask& tk, int row0, int col0, int kp, bool save_ctx, f32x4 (&out)[RM]) {
+  const int lane = threadIdx.x & 63;
   const int i = lane & 15, q = lane >> 4;
-  const int arow = row0 + i;
   const int wcol = col0 + i;
-  const bool arow_ok = arow < tk.B;
   const bool wcol_ok = wcol < tk.N;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[RM][4];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[r][e] = zero4;
+  int NC = 0;
+  for (int s = 0; s < tk.nsrc; ++s) NC += (tk.src[s].K + 15) >> 4;
+  const int g0 = (kp * NC) / KP, g1 = ((kp + 1) * NC) / KP;       // this wave's global chunk range
   int cbase = 0;
   for (int s = 0; s < tk.nsrc; ++s) {
     const StepSrc& S = tk.src[s];
     const int nch = (S.K + 15) >> 4;
-    const float* wp = S.w + (long)wcol * S.ldw;
-    int c = (wave - cbase) & 3;  // first chunk of this source owned by this wave
+    const int c0 = max(g0 - cbase, 0), c1 = min(g1 - cbase, nch);  // local chunk range of this source
+    cbase += nch;
+    if (c0 >= c1) continue;
+    const float* wp = S.w + (long)wcol * S.ldw + (q << 2);
     if (S.kind == SRC_PLAIN) {
-      long rb = arow;
-      if (s == 0 && tk.gather && arow_ok) rb = tk.gather[arow];
-      const float* ap = S.a + rb * S.sb;
-#pragma unroll 4
-      for (; c < nch; c += 4) {
-        const int k = (c << 4) + (q << 2);
-        f32x4 av = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
-        if (k < S.K) {
-          if (arow_ok) av = ld4(ap + k);
-          if (wcol_ok) wv = ld4(wp + k);
+      const float* ap[RM];
+      bool aok[RM];
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        const int arow = row0 + 16 * r + i;
+        aok[r] = arow < tk.B;
+        long rb = arow;
+        if (s == 0 && tk.gather && aok[r]) rb = tk.gather[arow];
+        ap[r] = S.a + rb * S.sb + (q << 2);
+      }
+      for (int c = c0; c < c1; c += UN) {
+        f32x4 av[RM][UN], wv[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+          const int k = (c + j) << 4;
+          const bool in = (c + j < c1) && (k + (q << 2) < S.K);
+#ifdef PROBE_NO_LOAD
+          wv[j] = zero4 + (float)lane;
+#pragma unroll
+          for (int r = 0; r < RM; ++r) av[r][j] = zero4 + (float)k;
+#else
+          wv[j] = (in && wcol_ok) ? ld4(wp + k) : zero4;
+#pragma unroll
+          for (int r = 0; r < RM; ++r) av[r][j] = (in && aok[r]) ? ld4(ap[r] + k) : zero4;
+#endif
         }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], wv[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], wv[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], wv[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], wv[3], acc1, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+          if (c + j < c1) {
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[r][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][j][e], wv[j][e], acc[r][e], 0, 0, 0);
+            }
+          }
+        }
       }
     } else {
       // A row = sum_j wgt_j * slab_j[row]  (attention context from per-chunk softmax partials, or a plain sum)
-      float wgt[STEP_MAX_SLAB];
       const int ns = tk.nslab;
-      if (S.kind == SRC_SOFTMAX) {
-        float M = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < STEP_MAX_SLAB; ++j) {
-          wgt[j] = -INFINITY;
-          if (j < ns && arow_ok) wgt[j] = tk.pm[(long)j * tk.B + arow];
-          M = fmaxf(M, wgt[j]);
-        }
-        float L = 0.f;
+      for (int r = 0; r < RM; ++r) {
+        const int arow = row0 + 16 * r + i;
+        const bool arow_ok = arow < tk.B;
+        float wgt[STEP_MAX_SLAB];
+        if (S.kind == SRC_SOFTMAX) {
+          float M = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < STEP_MAX_SLAB; ++j) {
-          const float e = (wgt[j] == -INFINITY) ? 0.f : expf(wgt[j] - M);
-          if (j < ns && arow_ok) L += e * tk.pl[(long)j * tk.B + arow];
-          wgt[j] = e;
-        }
-        const float inv = L > 0.f ? 1.0f / L : 0.f;
-#pragma unroll
-        for (int j = 0; j < STEP_MAX_SLAB; ++j) wgt[j] *= inv;
-      } else {
-#pragma unroll
-        for (int j = 0; j < STEP_MAX_SLAB; ++j) wgt[j] = 1.0f;
-      }
-      const float* ap = S.a + (long)arow * S.sb;
-      for (; c < nch; c += 4) {
-        const int k = (c << 4) + (q << 2);
-        f32x4 av = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
-        if (k < S.K) {
-          if (arow_ok) {
-#pragma unroll
-            for (int j = 0; j < STEP_MAX_SLAB; ++j) {
-              if (j < ns) {
-                const f32x4 p = ld4(ap + (long)j * tk.slab_stride + k);
-                av += wgt[j] * p;
-              }
-            }
-            if (save_ctx && tk.ctx_save) st4(tk.ctx_save + (long)arow * tk.ctx_sb + k, av);
+          for (int j = 0; j < STEP_MAX_SLAB; ++j) {
+            wgt[j] = -INFINITY;
+            if (j < ns && arow_ok) wgt[j] = tk.pm[(long)j * tk.B + arow];
+            M = fmaxf(M, wgt[j]);
           }
-          if (wcol_ok) wv = ld4(wp + k);
+          float Ls = 0.f;
+#pragma unroll
+          for (int j = 0; j < STEP_MAX_SLAB; ++j) {
+            const float e = (wgt[j] == -INFINITY) ? 0.f : expf(wgt[j] - M);
+            if (j < ns && arow_ok) Ls += e * tk.pl[(long)j * tk.B + arow];
+            wgt[j] = e;
+          }
+          const float inv = Ls > 0.f ? 1.0f / Ls : 0.f;
+#pragma unroll
+          for (int j = 0; j < STEP_MAX_SLAB; ++j) wgt[j] *= inv;
+        } else {
+#pragma unroll
+          for (int j = 0; j < STEP_MAX_SLAB; ++j) wgt[j] = 1.0f;
         }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], wv[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], wv[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], wv[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], wv[3], acc1, 0, 0, 0);
+        const float* ap = S.a + (long)arow * S.sb + (q << 2);
+        for (int c = c0; c < c1; ++c) {
+          const int k = c << 4;
+          f32x4 av = zero4, wv = zero4;
+          if (k + (q << 2) < S.K) {
+            if (arow_ok) {
+#pragma unroll
+              for (int j = 0; j < STEP_MAX_SLAB; ++j) {
+                if (j < ns) av += wgt[j] * ld4(ap + (long)j * tk.slab_stride + k);
+              }
+              if (save_ctx && tk.ctx_save) st4(tk.ctx_save + (long)arow * tk.ctx_sb + k + (q << 2), av);
+            }
+            if (wcol_ok) wv = ld4(wp + k);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[r][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wv[e], acc[r][e], 0, 0, 0);
+        }
       }
     }
-    cbase += nch;
   }
-  return acc0 + acc1;
+#pragma unroll
+  for (int r = 0; r < RM; ++r) out[r] = (acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]);
 }
 
+// fast activations: v_exp_f32 / v_rcp_f32 based (|err| ~1e-7 absolute, far inside the 1e-4 parity budget)
+__device__ __forceinline__ float fsigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == 1) return tanhf(v);
-  if (act == 2) return sigmoidf_(v);
+  if (act == 1) return ftanh(v);
+  if (act == 2) return fsigmoid(v);
   return v;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void step_kernel(const StepLaunch L) {
-  __shared__ __attribute__((aligned(16))) float red[4][16][16];
+// Workgroup = TM x TN output tiles of 16x16.  A wave owns the TM row tiles of ONE column tile for its
+// K-part, so each weight fragment it loads feeds TM MFMAs (weights are the larger operand); the K range
+// is split over KP waves and reduced through LDS.  NW = TN * KP waves.
+template <int MODE, int TM, int TN, int KP>
+__global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) {
+  constexpr int NTILE = TM * TN;
+  __shared__ __attribute__((aligned(16))) float red[KP][NTILE][16][16];
   const StepTask& tk = L.task[blockIdx.z];
-  const int col0 = blockIdx.x * 16, row0 = blockIdx.y * 16;
-  if (col0 >= tk.N || row0 >= tk.B) return;
+  if ((int)blockIdx.x * TN * 16 >= tk.N || (int)blockIdx.y * TM * 16 >= tk.B) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = wave % TN, kp = wave / TN;
+#ifdef PROBE_EMPTY
+  if (tk.B < 0) tk.p5[tid] = 1.f;
+  return;
+#endif
+  const int t = tk.t;
 
-  const f32x4 acc = mm16_partial(tk, row0, col0, blockIdx.x == 0);
+  // ---- epilogue operands are fetched BEFORE the matmul so their latency hides behind it ------------
+  // LSTM fwd: one thread per (row, unit): tile e_tile, 64 threads each.  LINEAR / LSTM bwd: one per (row, col).
+  constexpr int EPT = (MODE == EP_LSTM_FWD) ? 64 : 256;
+  constexpr int NTHR = TN * KP * 64;
+  static_assert(NTILE * EPT <= NTHR || true, "");
+  // when the workgroup has fewer threads than epilogue items, threads loop (EPI_IT passes)
+  constexpr int EPI_IT = (NTILE * EPT + NTHR - 1) / NTHR;
+  static_assert(EPI_IT == 1, "geometry must give every epilogue item its own thread");
+  const bool epi = tid < NTILE * EPT;
+  const int e_tile = tid / EPT, e_l = tid % EPT;
+  const int e_mt = e_tile / TN, e_nt = e_tile % TN;
+  const int e_row0 = ((int)blockIdx.y * TM + e_mt) * 16, e_col0 = ((int)blockIdx.x * TN + e_nt) * 16;
+  bool e_ok = false, valid = false;
+  int b = 0, n = 0, len = 0, tau = 0;
+  float pre0 = 0.f, pre1 = 0.f, pre2 = 0.f, pre3 = 0.f;
+  f32x4 pre4a = {0.f, 0.f, 0.f, 0.f}, pre4b = {0.f, 0.f, 0.f, 0.f};
+  if (epi) {
+    if constexpr (MODE == EP_LSTM_FWD) {
+      b = e_row0 + (e_l >> 2);
+      n = (e_col0 >> 2) + (e_l & 3);                 // unit index
+      e_ok = b < tk.B && e_col0 < tk.N;
+      if (e_ok) {
+        const int H = tk.N >> 2;
+        len = tk.len ? tk.len[b] : tk.T;
+        valid = t < len;
+        tau = tk.reverse ? len - 1 - t : t;
+        pre0 = tk.p3[(long)b * H + n];               // c_prev
+        pre1 = tk.p4[(long)b * H + n];               // h_prev
+        if (valid) {
+          if (tk.bias) pre4a = ld4(tk.bias + n * 4);
+          if (tk.s2) pre4b = ld4(tk.p0 + (((long)b * tk.T + tau) * H + n) * 4);
+        }
+      }
+    } else if constexpr (MODE == EP_LSTM_BWD) {
+      b = e_row0 + (e_l >> 4);
+      n = e_col0 + (e_l & 15);
+      e_ok = b < tk.B && n < tk.N;
+      if (e_ok) {
+        const int H = tk.N;
+        len = tk.len ? tk.len[b] : tk.T;
+        valid = t < len;
+        tau = tk.reverse ? len - 1 - t : t;
+        const long bh = (long)b * H + n;
+        pre0 = tk.p4[bh];                            // dc_in
+        pre1 = tk.p6 ? tk.p6[bh] : 0.f;              // dh carry
+        if (valid) {
+          const long bt = (long)b * tk.T + tau;
+          pre4a = ld4(tk.p0 + (bt * H + n) * 4);     // gates i, j, f, o
+          pre2 = tk.p1[bt * H + n];                  // c
+          if (t == 0) pre3 = tk.bias ? tk.bias[bh] : 0.f;
+          else pre3 = tk.p1[(bt + (tk.reverse ? 1 : -1)) * H + n];   // c_prev
+          if (tk.p8) pre1 += tk.p8[(long)b * tk.s0 + (long)tau * tk.s1 + n];
+        }
+      }
+    } else {
+      b = e_row0 + (e_l >> 4);
+      n = e_col0 + (e_l & 15);
+      e_ok = b < tk.B && n < tk.N;
+      if (e_ok) {
+        if (tk.bias) pre0 = tk.bias[n];
+        if (tk.p1) pre0 += tk.p1[(long)b * tk.s1 + n];
+        valid = !(tk.len && t >= tk.len[b]);
+      }
+    }
+  }
+
+  const int row0 = (int)blockIdx.y * TM * 16, col0 = ((int)blockIdx.x * TN + nt) * 16;
+  constexpr int UN = (TM >= 4) ? 2 : (TM == 2 ? 4 : 8);
+  f32x4 acc[TM];
+  mm16_partial<KP, UN, TM>(tk, row0, col0, kp, blockIdx.x == 0 && nt == 0, acc);
   // C/D layout of mfma 16x16: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[kp][m * TN + nt][(lane >> 4) * 4 + r][lane & 15] = acc[m][r];
   __syncthreads();
+#ifdef PROBE_NO_EPI
+  if (tid < 256 && row0 + (tid >> 4) < tk.B) tk.p5[(long)(row0 + (tid >> 4)) * 16 + (tid & 15)] = red[0][0][tid >> 4][tid & 15] + red[KP - 1][NTILE - 1][tid >> 4][tid & 15];
+  return;
+#endif
+  if (!epi || !e_ok) return;
 
-  const int t = tk.t;
-  if constexpr (MODE == EP_LINEAR || MODE == EP_LSTM_BWD) {
-    const int r = tid >> 4, cidx = tid & 15;
-    const int b = row0 + r, n = col0 + cidx;
-    if (b >= tk.B || n >= tk.N) return;
-    float z = red[0][r][cidx] + red[1][r][cidx] + red[2][r][cidx] + red[3][r][cidx];
-    if constexpr (MODE == EP_LINEAR) {
-      // p0 out (row stride s0), p1 add (row stride s1)
-      if (tk.bias) z += tk.bias[n];
-      if (tk.p1) z += tk.p1[(long)b * tk.s1 + n];
-      z = apply_act(z, tk.act);
-      if (tk.len && t >= tk.len[b]) z = 0.f;   // dynamic_rnn / impute_finished: zero output past the valid length
-      tk.p0[(long)b * tk.s0 + n] = z;
-      return;
-    }
-    // ---- EP_LSTM_BWD: n = unit.  p0 gates, p1 cs, p2 dgates record, p3 dG rolling out [B,4H],
-    //      p4 dc_in, p5 dc_out, p6 dh_carry_in, p7 dh_carry_out, p8 dout (s0 batch stride, s1 time stride),
-    //      bias = c_init [B,H] (state before step 0; null = zeros)
+  if constexpr (MODE == EP_LINEAR) {
+    // p0 out (row stride s0), p1 add (row stride s1)
+    float z = pre0;
+#pragma unroll
+    for (int w = 0; w < KP; ++w) z += red[w][e_tile][e_l >> 4][e_l & 15];
+    z = apply_act(z, tk.act);
+    if (!valid) z = 0.f;                     // dynamic_rnn / impute_finished: zero output past the valid length
+    tk.p0[(long)b * tk.s0 + n] = z;
+  } else if constexpr (MODE == EP_LSTM_BWD) {
+    // n = unit.  p0 gates, p1 cs, p2 dgates record, p3 dG rolling out [B,4H], p4 dc_in, p5 dc_out,
+    // p6 dh_carry_in, p7 dh_carry_out, p8 dout (s0 batch stride, s1 time stride), bias = c_init [B,H]
     const int H = tk.N;
-    const int len = tk.len ? tk.len[b] : tk.T;
-    const bool valid = t < len;
     const long bh = (long)b * H + n;
-    const float dc_in = tk.p4[bh];
-    const float carry = tk.p6 ? tk.p6[bh] : 0.f;
     f32x4 dg = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
-      const int tau = tk.reverse ? len - 1 - t : t;
-      const long bt = (long)b * tk.T + tau;
-      float dh = z + carry;
-      if (tk.p8) dh += tk.p8[(long)b * tk.s0 + (long)tau * tk.s1 + n];
-      const f32x4 g = ld4(tk.p0 + (bt * H + n) * 4);  // i, j, f, o (activated)
-      const float c = tk.p1[bt * H + n];
-      float cprev;
-      if (t == 0) cprev = tk.bias ? tk.bias[bh] : 0.f;
-      else cprev = tk.p1[(bt + (tk.reverse ? 1 : -1)) * H + n];
-      const float tc = tanhf(c);
-      float dc = dh * g[3] * (1.f - tc * tc) + dc_in;
-      if (!(fabsf(c) < 1.0f)) dc = 0.f;            // cell_clip=1.0: no gradient through a clipped cell
+      float dh = pre1;                       // carry + external d out
+#pragma unroll
+      for (int w = 0; w < KP; ++w) dh += red[w][e_tile][e_l >> 4][e_l & 15];
+      const f32x4 g = pre4a;
+      const float c = pre2, cprev = pre3;
+      const float tc = ftanh(c);
+      float dc = dh * g[3] * (1.f - tc * tc) + pre0;
+      if (!(fabsf(c) < 1.0f)) dc = 0.f;      // cell_clip=1.0: no gradient through a clipped cell
       dg[3] = dh * tc * g[3] * (1.f - g[3]);
       dg[0] = dc * g[1] * g[0] * (1.f - g[0]);
       dg[1] = dc * g[0] * (1.f - g[1] * g[1]);
       dg[2] = dc * cprev * g[2] * (1.f - g[2]);
       tk.p5[bh] = dc * g[2];
       if (tk.p7) tk.p7[bh] = 0.f;
-      st4(tk.p2 + (bt * H + n) * 4, dg);
+      st4(tk.p2 + (((long)b * tk.T + tau) * H + n) * 4, dg);
     } else {
-      tk.p5[bh] = dc_in;
-      if (tk.p7) tk.p7[bh] = carry;
+      tk.p5[bh] = pre0;
+      if (tk.p7) tk.p7[bh] = pre1;
       if (t < tk.T) st4(tk.p2 + (((long)b * tk.T + t) * H + n) * 4, dg);  // padding position t: zero record
     }
     st4(tk.p3 + bh * 4, dg);
-    return;
-  }
-
-  if constexpr (MODE == EP_LSTM_FWD) {
-    // p0 gates/zpre [B,T,H,4], p1 cs [B,T,H], p2 seq_out (s0 batch stride, s1 time stride),
+  } else {
+    // EP_LSTM_FWD: p0 gates/zpre [B,T,H,4], p1 cs [B,T,H], p2 seq_out (s0 batch stride, s1 time stride),
     // p3 c_in, p4 h_in, p5 c_out, p6 h_out; s2 = has_zpre
-    if (tid >= 64) return;
-    const int r = tid >> 2, ul = tid & 3;
-    const int b = row0 + r;
-    if (b >= tk.B) return;
     const int H = tk.N >> 2;
-    const int u = (col0 >> 2) + ul;
-    const int len = tk.len ? tk.len[b] : tk.T;
-    const bool valid = t < len;
-    const long bh = (long)b * H + u;
-    const float cprev = tk.p3[bh], hprev = tk.p4[bh];
+    const long bh = (long)b * H + n;
+    const float cprev = pre0, hprev = pre1;
     if (valid) {
-      const int tau = tk.reverse ? len - 1 - t : t;
       const long bt = (long)b * tk.T + tau;
-      f32x4 z;
+      f32x4 z = pre4a + pre4b;
+      const int r = e_l >> 2, ul = e_l & 3;
 #pragma unroll
       for (int gi = 0; gi < 4; ++gi) {
-        const int cc = ul * 4 + gi;
-        z[gi] = red[0][r][cc] + red[1][r][cc] + red[2][r][cc] + red[3][r][cc];
+        float zz = 0.f;
+#pragma unroll
+        for (int w = 0; w < KP; ++w) zz += red[w][e_tile][r][ul * 4 + gi];
+        z[gi] += zz;
       }
-      if (tk.bias) z += ld4(tk.bias + u * 4);
-      float* gp = tk.p0 + (bt * H + u) * 4;
-      if (tk.s2) z += ld4(gp);
       f32x4 g;
-      g[0] = sigmoidf_(z[0]);
-      g[1] = tanhf(z[1]);
-      g[2] = sigmoidf_(z[2] + 1.0f);   // forget_bias = 1.0
-      g[3] = sigmoidf_(z[3]);
+      g[0] = fsigmoid(z[0]);
+      g[1] = ftanh(z[1]);
+      g[2] = fsigmoid(z[2] + 1.0f);          // forget_bias = 1.0
+      g[3] = fsigmoid(z[3]);
       float c = g[2] * cprev + g[0] * g[1];
-      c = fminf(1.0f, fmaxf(-1.0f, c));  // cell_clip = 1.0 (cells.py:16)
-      const float h = g[3] * tanhf(c);
-      st4(gp, g);
-      tk.p1[bt * H + u] = c;
-      if (tk.p2) tk.p2[(long)b * tk.s0 + (long)tau * tk.s1 + u] = h;
+      c = fminf(1.0f, fmaxf(-1.0f, c));      // cell_clip = 1.0 (cells.py:16)
+      const float h = g[3] * ftanh(c);
+      st4(tk.p0 + (bt * H + n) * 4, g);
+      tk.p1[bt * H + n] = c;
+      if (tk.p2) tk.p2[(long)b * tk.s0 + (long)tau * tk.s1 + n] = h;
       tk.p5[bh] = c;
       tk.p6[bh] = h;
     } else {
       tk.p5[bh] = cprev;
       tk.p6[bh] = hprev;
-      if (tk.p2 && t < tk.T) tk.p2[(long)b * tk.s0 + (long)t * tk.s1 + u] = 0.f;  // zero output past len
+      if (tk.p2 && t < tk.T) tk.p2[(long)b * tk.s0 + (long)t * tk.s1 + n] = 0.f;  // zero output past len
     }
-    return;
   }
 }
 
@@ -241,23 +337,40 @@ extern "C" int avsr_step_launch_raw(const void* launch, void* stream) {
     if (L->task[i].N > maxN) maxN = L->task[i].N;
     if (L->task[i].B > maxB) maxB = L->task[i].B;
   }
-  dim3 grid((maxN + 15) / 16, (maxB + 15) / 16, L->ntask);
   const int mode = L->task[0].mode;
-  for (int i = 1; i < L->ntask; ++i)
+  int ksum = 0;
+  for (int i = 0; i < L->ntask; ++i) {
     if (L->task[i].mode != mode) return AVSR_ERR_ARG;   // one epilogue kind per launch
-  hipStream_t s = (hipStream_t)stream;
-  if (mode == EP_LSTM_FWD) {
-    ProfScope ps(PROF_STEP_LSTM_FWD, s);
-    hipLaunchKernelGGL(step_kernel<EP_LSTM_FWD>, grid, dim3(256), 0, s, *L);
-  } else if (mode == EP_LSTM_BWD) {
-    ProfScope ps(PROF_STEP_LSTM_BWD, s);
-    hipLaunchKernelGGL(step_kernel<EP_LSTM_BWD>, grid, dim3(256), 0, s, *L);
-  } else if (mode == EP_LINEAR) {
-    ProfScope ps(PROF_STEP_LINEAR, s);
-    hipLaunchKernelGGL(step_kernel<EP_LINEAR>, grid, dim3(256), 0, s, *L);
-  } else {
-    return AVSR_ERR_UNSUPPORTED;
+    int k = 0;
+    for (int j = 0; j < L->task[i].nsrc; ++j) k += L->task[i].src[j].K;
+    if (k > ksum) ksum = k;
   }
+  hipStream_t s = (hipStream_t)stream;
+  // geometry (TM, TN, KP): probe sweep on MI355X (tools/step_probe.hip, B=64 H=256 3-task wavefront):
+  //   fwd (K<=768): (1,1,4) 8.1 us  vs (1,1,8) 11.0, (2,1,8) 10.1, 2x2-tile variants 11-15 us
+  //   bwd (K>=1024): (1,1,8) 10.6 us vs (1,1,4) 12.1-13.6, (2,1,8) 15.5, (1,1,16) 12.2 us
+  // i.e. many small workgroups win; sharing operands inside a workgroup costs more latency than it saves.
+  int geo = (ksum >= 1024) ? 1 : 0;
+  if (g_step_geo >= 0) geo = g_step_geo;
+#define LAUNCH_(M, K_)                                                                                         \
+  {                                                                                                            \
+    ProfScope ps(K_, s);                                                                                       \
+    switch (geo) {                                                                                             \
+      case 0: hipLaunchKernelGGL((step_kernel<M, 1, 1, 4>), GRID(1, 1), dim3(256), 0, s, *L); break;           \
+      case 1: hipLaunchKernelGGL((step_kernel<M, 1, 1, 8>), GRID(1, 1), dim3(512), 0, s, *L); break;           \
+      case 2: hipLaunchKernelGGL((step_kernel<M, 2, 1, 8>), GRID(2, 1), dim3(512), 0, s, *L); break;           \
+      default: return AVSR_ERR_ARG;                                                                            \
+    }                                                                                                          \
+  }
+#define GRID(tm, tn) dim3((maxN + 16 * (tn) - 1) / (16 * (tn)), (maxB + 16 * (tm) - 1) / (16 * (tm)), L->ntask)
+  if (mode == EP_LSTM_FWD) LAUNCH_(EP_LSTM_FWD, PROF_STEP_LSTM_FWD)
+  else if (mode == EP_LSTM_BWD) LAUNCH_(EP_LSTM_BWD, PROF_STEP_LSTM_BWD)
+  else if (mode == EP_LINEAR) LAUNCH_(EP_LINEAR, PROF_STEP_LINEAR)
+  else return AVSR_ERR_UNSUPPORTED;
+#undef LAUNCH_
+#undef GRID
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
+
+extern "C" void avsr_step_set_geometry(int geo) { avsr::g_step_geo = geo; }
