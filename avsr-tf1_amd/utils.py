@@ -1,0 +1,61 @@
+"""Error-rate metrics and prediction files (same behaviour as avsr/utils.py:4-57 of the reference; own code).
+
+`compute_wer(predictions, ground_truth, split_words)` returns (mean error rate, per-file dict): per file the
+Levenshtein distance between the symbol sequences (EOS / END / MASK stripped) divided by the ground-truth
+length; with split_words the symbols are joined and split on whitespace first.  Pinned against the real
+reference functions by tests/golden/reference_cer_wer.json."""
+from os import path
+
+_EXTRA = ("EOS", "END", "MASK")
+
+
+def _strip_extra_chars(seq):
+    return [s for s in seq if s not in _EXTRA]
+
+
+def levenshtein(ground_truth, prediction):
+    """Edit distance (unit costs) with a single rolling row over the shorter sequence."""
+    a, b = list(ground_truth), list(prediction)
+    if len(a) > len(b):
+        a, b = b, a
+    row = list(range(len(a) + 1))
+    for i, cb in enumerate(b, start=1):
+        diag, row[0] = row[0], i
+        for j, ca in enumerate(a, start=1):
+            cost = diag + (ca != cb)
+            diag = row[j]
+            row[j] = min(row[j] + 1, row[j - 1] + 1, cost)
+    return row[len(a)]
+
+
+def compute_wer(predictions_dict, ground_truth_dict, split_words=False):
+    total, per_file = 0.0, {}
+    for fname, pred in predictions_dict.items():
+        hyp = _strip_extra_chars(pred)
+        ref = _strip_extra_chars(ground_truth_dict[fname])
+        if split_words:
+            hyp, ref = "".join(hyp).split(), "".join(ref).split()
+        err = levenshtein(ref, hyp) / float(len(ref))
+        per_file[fname] = err
+        total += err
+    return total / (float(len(predictions_dict)) or 1), per_file
+
+
+def write_sequences_to_labelfile(sequence_dict, fname, original_dict, error_dict, sep=""):
+    """`<file> <prediction> [<truth>] [<error>]` per line (avsr/utils.py:49-57)."""
+    with open(fname, "w") as f:
+        for key, seq in sequence_dict.items():
+            hyp = sep.join(_strip_extra_chars(seq))
+            ref = sep.join(_strip_extra_chars(original_dict[key]))
+            f.write("%s %s [%s] [%.3f]\n" % (key, hyp, ref, error_dict[key]))
+
+
+def get_files(file_list, dataset_dir, remove_sa=True, shuffle_sentences=False):
+    with open(file_list, "r") as f:
+        names = [path.join(dataset_dir, line.split()[0]) for line in f.read().splitlines()]
+    if remove_sa:
+        names = [n for n in names if "/sa" not in n]
+    if shuffle_sentences:
+        from random import shuffle
+        shuffle(names)
+    return names

@@ -104,11 +104,13 @@ def work_model(cfg, B):
     return dict(attn_bytes=attn_bytes, lstm_fwd_flops=fl_f / max(1, n_f), lstm_bwd_flops=fl_b / max(1, n_b))
 
 
-def cpu_baseline(wl, sample_B=8, steps=2):
+def cpu_baseline(wl, sample_B=8, steps=3):
     """The CPU oracle (torch-CPU fp32 restatement, all host threads) on a bounded sample: sample_B utterances at
     full T_a/T_v/L.  'TF-1.13.1 CPU number unavailable' -- see BASELINE.md section 2."""
     from oracle import avsr_oracle as O
-    ncores = os.cpu_count() or 1
+    # the recurrent chain is thousands of tiny [B,H]x[H,4H] matmuls: past ~16 threads torch-CPU only adds
+    # synchronisation cost (256 hardware threads on the GPU node made a step take minutes), so cap it
+    ncores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(ncores)
     ocfg = O.OracleConfig(**wl["cfg"])
     P = O.init_params(ocfg, seed=2001)

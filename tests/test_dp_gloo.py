@@ -1,0 +1,110 @@
+"""Data-parallel algebra on CPU: world_size 2, gloo.  The HIP model is replaced by an oracle-backed stand-in that
+exposes the same attributes DataParallelTrainer drives (denom / grads / loss / forward_train / backward /
+apply_update), so the test exercises exactly the collective logic that runs on RCCL:
+  sharded utterances + all-reduced loss normaliser + summed gradients  ==  one process on the whole batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from avsr_tf1_amd.model import Batch
+from avsr_tf1_amd.parallel import DataParallelTrainer
+from oracle import avsr_oracle as O
+
+
+def _cfg():
+    return O.OracleConfig(architecture="bimodal", video_units=(8,), audio_units=(8, 8), decoder_units=(8,), embedding_size=4,
+                          video_feat=4, audio_feat=8, batch_normalisation=False, regress_aus=False)
+
+
+class OracleBackedModel:
+    def __init__(self, cfg, W):
+        self.cfg, self.W, self.opt = cfg, {k: v.copy() for k, v in W.items()}, None
+        self.names = O.trainable_names(W)
+        self.sizes = [W[k].size for k in self.names]
+        self.grads = torch.zeros(sum(self.sizes), dtype=torch.float64)
+        self.denom, self.loss, self.gnorm = torch.zeros(1), torch.zeros(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64)
+        self.au_scale = 1.0
+
+    def forward_train(self, batch, compute_denom=True):
+        nb = O.Batch(**{k: (None if getattr(batch, k) is None else getattr(batch, k).numpy())
+                        for k in ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len")})
+        self._P = O.to_torch(self.W, torch.float64, requires_grad=True)
+        logits, _m = O.forward_train(self._P, self.cfg, nb)
+        labels = torch.as_tensor(nb.labels, dtype=torch.int64)
+        ll = torch.as_tensor(nb.labels_len, dtype=torch.int64)
+        w = (torch.arange(labels.shape[1])[None, :] < ll[:, None]).to(torch.float64)
+        if compute_denom:
+            self.denom.copy_(w.sum().to(torch.float32).reshape(1))
+        ce = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1), reduction="none").reshape(labels.shape)
+        self._loss = torch.sum(ce * w) / (self.denom.to(torch.float64)[0] + 1e-12)
+        self.loss.copy_(self._loss.detach().reshape(1))
+
+    def backward(self):
+        gs = torch.autograd.grad(self._loss, [self._P[k] for k in self.names], allow_unused=True)
+        flat = [(g if g is not None else torch.zeros_like(self._P[k])).reshape(-1) for g, k in zip(gs, self.names)]
+        self.grads.copy_(torch.cat(flat))
+
+    def apply_update(self):
+        cfg = self.cfg
+        g = dict(zip(self.names, torch.split(self.grads.clone(), self.sizes)))
+        for k in O.l2_names(self.W, cfg):
+            g[k] = g[k] + cfg.recurrent_l2 * torch.tensor(self.W[k], dtype=torch.float64).reshape(-1)
+        gn = torch.sqrt(sum(torch.sum(x * x) for x in g.values()))
+        self.gnorm.copy_(gn.reshape(1))
+        scale = cfg.max_gradient_norm / max(float(gn), cfg.max_gradient_norm)
+        if self.opt is None:
+            self.opt = {"step": 0, "m": {k: np.zeros(self.W[k].size) for k in self.names}, "v": {k: np.zeros(self.W[k].size) for k in self.names}}
+        t = self.opt["step"] + 1
+        lr_t = O.lr_at(cfg, self.opt["step"]) * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        for k in self.names:
+            gi = g[k].numpy() * scale
+            self.opt["m"][k] = 0.9 * self.opt["m"][k] + 0.1 * gi
+            self.opt["v"][k] = 0.999 * self.opt["v"][k] + 0.001 * gi * gi
+            upd = lr_t * self.opt["m"][k] / (np.sqrt(self.opt["v"][k]) + 1e-8)
+            self.W[k] = (self.W[k].astype(np.float64) - upd.reshape(self.W[k].shape)).astype(np.float32)
+        self.opt["step"] = t
+
+
+def _shard(b, lo, hi):
+    def f(a, dt):
+        return None if a is None else torch.as_tensor(np.ascontiguousarray(a[lo:hi]), dtype=dt)
+    return Batch(f(b.audio, torch.float32), f(b.audio_len, torch.int32), f(b.video, torch.float32), f(b.video_len, torch.int32),
+                 f(b.aus, torch.float32), f(b.labels, torch.int32), f(b.labels_len, torch.int32))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    cfg = _cfg()
+    W = O.init_params(cfg, seed=9)
+    full = O.synthetic_batch(cfg, B=4, T_a=7, T_v=4, L=5, ragged=True)
+    per = 4 // world
+    model = OracleBackedModel(cfg, W)
+    trainer = DataParallelTrainer(model, dist, use_graph=False)
+    for _ in range(2):
+        trainer.train_step(_shard(full, rank * per, (rank + 1) * per))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), gnorm=model.gnorm.numpy(), **model.W)
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_equals_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    cfg = _cfg()
+    W = O.init_params(cfg, seed=9)
+    full = O.synthetic_batch(cfg, B=4, T_a=7, T_v=4, L=5, ragged=True)
+    a = O.train_step(W, None, cfg, full)
+    b = O.train_step(a["params"], a["opt"], cfg, full)
+    assert abs(float(r0["gnorm"][0]) - b["global_norm"]) < 1e-9
+    for k in O.trainable_names(W):
+        assert np.array_equal(r0[k], r1[k]), k                  # replicas stay bit-identical
+        assert np.abs(r0[k] - b["params"][k]).max() < 1e-6, k   # and equal the single-process step on the whole batch

@@ -1,0 +1,130 @@
+"""CPU tests of the oracle itself (no GPU): golden regression, gradient checks, independent cross-checks and
+the structural invariants SURVEY.md 8(c) lists.  The oracle is test infrastructure -- "parity unpinned"."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import avsr_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_fixture(path):
+    z = np.load(path)
+    cfg = O.OracleConfig(**{k: (tuple(tuple(x) if isinstance(x, list) else x for x in v) if isinstance(v, list) else v)
+                            for k, v in json.loads(str(z["cfg_json"])).items()})
+    W = {k[2:]: z[k] for k in z.files if k.startswith("w:")}
+    b = O.Batch(**{k[3:]: z[k] for k in z.files if k.startswith("in:")})
+    out = {k[4:]: z[k] for k in z.files if k.startswith("out:")}
+    return cfg, W, b, out
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "oracle_restatement_*.npz"))))
+def test_oracle_matches_committed_fixture(path):
+    cfg, W, b, out = load_fixture(path)
+    r = O.train_step(W, None, cfg, b)
+    assert abs(r["loss"] - float(out["loss"])) < 1e-9
+    assert abs(r["global_norm"] - float(out["global_norm"])) < 1e-9
+    assert np.abs(r["logits"] - out["logits"]).max() < 1e-6
+    assert (O.greedy_decode(W, cfg, b, max_steps=8) == out["greedy_ids"]).all()
+
+
+def test_lstm_cell_against_torch_lstmcell():
+    """TF gate order i,j,f,o with forget_bias 1.0 == torch's i,f,g,o after permutation (independent implementation)."""
+    rng = np.random.default_rng(0)
+    B, I, H = 5, 7, 6
+    W = rng.standard_normal((I + H, 4 * H)) * 0.4
+    b = rng.standard_normal(4 * H) * 0.2
+    x, c, h = rng.standard_normal((B, I)), rng.standard_normal((B, H)) * 0.3, rng.standard_normal((B, H)) * 0.3
+    c2, h2 = O.lstm_cell(*[torch.tensor(a) for a in (x, c, h, W, b)])
+    cell = torch.nn.LSTMCell(I, H).double()
+    i_, j_, f_, o_ = [W[:, k * H:(k + 1) * H] for k in range(4)]
+    bi, bj, bf, bo = [b[k * H:(k + 1) * H] for k in range(4)]
+    Wt = np.concatenate([i_, f_, j_, o_], axis=1)            # torch order i, f, g, o
+    bt = np.concatenate([bi, bf + 1.0, bj, bo])
+    with torch.no_grad():
+        cell.weight_ih.copy_(torch.tensor(Wt[:I].T)); cell.weight_hh.copy_(torch.tensor(Wt[I:].T))
+        cell.bias_ih.copy_(torch.tensor(bt)); cell.bias_hh.zero_()
+        ht, ct = cell(torch.tensor(x), (torch.tensor(h), torch.tensor(c)))
+    ct_clip = torch.clamp(ct, -1, 1)
+    assert np.abs(c2.numpy() - ct_clip.numpy()).max() < 1e-12
+    unclipped = (ct.abs() < 1).numpy()
+    assert np.abs((h2 - ht).numpy()[unclipped]).max() < 1e-12
+
+
+def _small(arch="bimodal", **kw):
+    base = dict(architecture=arch, video_units=(8,), audio_units=(8, 8), decoder_units=(8,), embedding_size=4,
+                video_feat=4, audio_feat=8, regress_aus=True)
+    if arch == "unimodal":
+        base["video_units"], base["regress_aus"] = None, False
+    base.update(kw)
+    cfg = O.OracleConfig(**base)
+    return cfg, O.init_params(cfg, seed=5), O.synthetic_batch(cfg, B=3, T_a=7, T_v=4, L=4, ragged=True)
+
+
+@pytest.mark.parametrize("arch,att", [("bimodal", "scaled_luong"), ("av_align", "scaled_luong"), ("unimodal", "normed_bahdanau")])
+def test_gradients_by_finite_differences(arch, att):
+    cfg, W, b = _small(arch, attention_type=((att,), (att,)))
+    r = O.train_step(W, None, cfg, b)
+
+    def loss_of(Wn):
+        P = O.to_torch(Wn)
+        logits, m = O.forward_train(P, cfg, b)
+        return float(O.loss_fn(P, cfg, b, logits, m)[0])
+
+    rng = np.random.default_rng(1)
+    names = [k for k in O.trainable_names(W)]
+    for k in [names[i] for i in rng.choice(len(names), size=min(8, len(names)), replace=False)]:
+        idx = tuple(int(rng.integers(0, s)) for s in W[k].shape)
+        eps = 1e-5
+        Wp = {n: v.astype(np.float64).copy() for n, v in W.items()}
+        Wm = {n: v.astype(np.float64).copy() for n, v in W.items()}
+        Wp[k][idx] += eps
+        Wm[k][idx] -= eps
+        fd = (loss_of(Wp) - loss_of(Wm)) / (2 * eps)
+        an = float(r["grads"][k][idx])
+        assert abs(fd - an) < 1e-6 + 1e-4 * abs(an), (k, idx, fd, an)
+
+
+def test_masking_invariants():
+    cfg, W, b = _small("bimodal")
+    outs = O.encoder_outputs(W, cfg, b, training=False)
+    for s, lens in (("video", b.video_len), ("audio", b.audio_len)):
+        mem, (c, h) = outs[s]
+        for i, n in enumerate(lens):
+            assert np.all(mem[i, n:] == 0.0)                    # zero outputs past sequence_length
+            assert np.allclose(mem[i, n - 1], h[i])             # state carried = output at last valid step
+    P = O.to_torch(W)
+    m = O._Model(P, cfg, b, False, torch.float64)
+    for mech in m.mechs:
+        al, _ = mech(torch.zeros(3, cfg.decoder_units[0], dtype=torch.float64))
+        assert np.allclose(al.sum(-1).numpy(), 1.0)
+        assert np.all(al.numpy()[~mech.mask.numpy()] == 0.0)    # exactly zero past the memory length
+
+
+def test_greedy_zero_after_eos_and_stops():
+    cfg, W, b = _small("unimodal")
+    W = {k: v.copy() for k, v in W.items()}
+    W["dec/out/bias"][cfg.eos_id] += 2.5                         # EOS soon, but not necessarily at step 0
+    ids = O.greedy_decode(W, cfg, b, max_steps=20)
+    assert ids.shape[1] < 20
+    for row in ids:
+        pos = np.where(row == cfg.eos_id)[0]
+        if len(pos):
+            assert np.all(row[pos[0] + 1:] == 0)
+    assert (ids[:, -1] == cfg.eos_id).any()                      # the loop ended when the LAST utterance emitted EOS
+
+
+def test_adam_and_warmup_formula():
+    cfg, W, b = _small("unimodal", warmup_steps=3)
+    assert abs(O.lr_at(cfg, 0) - cfg.learning_rate / 3) < 1e-12 and O.lr_at(cfg, 5) == cfg.learning_rate
+    r = O.train_step(W, None, cfg, b)
+    k = "dec/out/bias"
+    g = r["grads"][k] * min(1.0, cfg.max_gradient_norm / r["global_norm"])
+    m, v = 0.1 * g, 0.001 * g * g
+    lr_t = O.lr_at(cfg, 0) * np.sqrt(1 - 0.999) / (1 - 0.9)
+    assert np.abs(r["params"][k] - (W[k] - lr_t * m / (np.sqrt(v) + 1e-8))).max() < 1e-7
