@@ -44,13 +44,16 @@ class RnnLayer(C.Structure):
                 ("gates", C.c_void_p), ("cs", C.c_void_p), ("out", C.c_void_p), ("ld_out", C.c_int64),
                 ("state", C.c_void_p), ("h_final", C.c_void_p), ("c_final", C.c_void_p),
                 ("dgates", C.c_void_p), ("dstate", C.c_void_p), ("dout", C.c_void_p), ("ld_dout", C.c_int64),
-                ("dout_col", C.c_int32), ("pad_", C.c_int32)]
+                ("dout_col", C.c_int32), ("pad_", C.c_int32), ("hs_seq", C.c_void_p), ("xt_seq", C.c_void_p)]
 
 
 class RnnStack(C.Structure):
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("reverse", C.c_int32), ("n_layers", C.c_int32),
                 ("cell", C.c_int32), ("pad_", C.c_int32),
                 ("len", C.c_void_p), ("dh_final", C.c_void_p), ("dc_final", C.c_void_p),
+                ("seed", C.c_void_p), ("keep_in", C.c_float), ("keep_state", C.c_float), ("keep_out", C.c_float),
+                ("consumer_keep", C.c_float), ("cell_id_base", C.c_int32), ("consumer_stream", C.c_int32),
+                ("consumer_width", C.c_int32), ("pad2_", C.c_int32),
                 ("layer", RnnLayer * MAX_LAYERS)]
 
 
@@ -78,7 +81,10 @@ class AttnRnn(C.Structure):
                 ("logits", C.c_void_p), ("ids", C.c_void_p), ("tok", C.c_void_p), ("n_unfinished", C.c_void_p),
                 ("dgates", C.c_void_p), ("dstate", C.c_void_p), ("datt", C.c_void_p), ("dq", C.c_void_p),
                 ("datt_ext", C.c_void_p), ("dcell_ext", C.c_void_p), ("dh0", C.c_void_p), ("dc0", C.c_void_p),
-                ("dh_final", C.c_void_p), ("dc_final", C.c_void_p)]
+                ("dh_final", C.c_void_p), ("dc_final", C.c_void_p),
+                ("seed", C.c_void_p), ("keep_in", C.c_float), ("keep_state", C.c_float), ("keep_out", C.c_float),
+                ("sampling_prob", C.c_float), ("cell_id", C.c_int32), ("pad3_", C.c_int32),
+                ("hs_seq", C.c_void_p), ("attd", C.c_void_p), ("xs", C.c_void_p), ("labels", C.c_void_p), ("fed", C.c_void_p)]
 
 
 class TransposeJob(C.Structure):
@@ -90,7 +96,7 @@ _STRUCTS = {"avsr_mat": Mat, "avsr_gemm_desc": GemmDesc, "avsr_rnn_layer": RnnLa
 
 EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_attn_rnn_fwd",
            "avsr_attn_rnn_bwd", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_colsum",
-           "avsr_batchnorm_fwd", "avsr_batchnorm_xhat", "avsr_embed_labels", "avsr_embed_grad", "avsr_seq_loss",
+           "avsr_batchnorm_fwd", "avsr_batchnorm_xhat", "avsr_embed_labels", "avsr_embed_grad", "avsr_dropout_rows", "avsr_seq_loss",
            "avsr_au_loss", "avsr_normed_v", "avsr_normed_v_bwd", "avsr_reduce_scalar", "avsr_l2_regularise",
            "avsr_global_norm", "avsr_adam_step", "avsr_prof_begin", "avsr_prof_end"]
 
@@ -133,8 +139,9 @@ def load():
         "avsr_colsum": [C.POINTER(Mat), C.POINTER(Mat), i32, i32, f32, f32, vp, vp, i64, vp],
         "avsr_batchnorm_fwd": [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp],
         "avsr_batchnorm_xhat": [vp, vp, vp, vp, i32, i32, vp],
-        "avsr_embed_labels": [vp, vp, i32, vp, i32, i32, i32, vp],
-        "avsr_embed_grad": [vp, vp, i32, vp, i32, i32, i32, i32, vp],
+        "avsr_embed_labels": [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp],
+        "avsr_embed_grad": [vp, vp, vp, i32, i32, i32, i32, vp],
+        "avsr_dropout_rows": [C.POINTER(Mat), C.POINTER(Mat), i32, i32, vp, i32, f32, i32, i32, i32, vp],
         "avsr_seq_loss": [vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp],
         "avsr_au_loss": [vp, vp, vp, vp, vp, i32, i32, f32, vp],
         "avsr_normed_v": [vp, vp, vp, i32, vp],

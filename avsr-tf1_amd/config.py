@@ -5,6 +5,12 @@ from typing import List, Optional, Tuple
 LUONG_TYPES = ("luong", "scaled_luong")
 BAHDANAU_TYPES = ("bahdanau", "normed_bahdanau")
 ATT_CODE = {"luong": 0, "scaled_luong": 1, "bahdanau": 2, "normed_bahdanau": 3}
+CELL_ID_DECODER = 40
+
+
+def encoder_cell_id(stream, direction, layer):
+    """RNG stream family of a DropoutWrapper'd encoder cell (stream = cell_id*4 + {0 input, 1 state, 2 output})."""
+    return 1 + ((0 if stream == "video" else 1) * 2 + (0 if direction == "fw" else 1)) * 8 + layer
 
 
 @dataclass
@@ -33,6 +39,9 @@ class ModelConfig:
     warmup_steps: int = 750
     max_label_length: int = 150
     use_dropout: bool = False
+    video_dropout: Tuple[float, float, float] = (0.9, 0.9, 0.9)     # keep probabilities (input, state, output), avsr.py:52-54
+    audio_dropout: Tuple[float, float, float] = (0.9, 0.9, 0.9)
+    decoder_dropout: Tuple[float, float, float] = (0.9, 0.9, 0.9)
     sampling_probability: float = 0.0
 
     # -- same helpers/validation rules as the reference wiring (error types as in the reference) --
@@ -101,5 +110,3 @@ class ModelConfig:
             dims += list(self.units(s)) + [self.feat(s)]
         if any(d % 4 for d in dims):
             raise ValueError("feature / unit / embedding sizes must be multiples of 4 for the HIP engine")
-        if self.use_dropout or self.sampling_probability > 0:
-            raise NotImplementedError("dropout / scheduled sampling kernels are not built yet")

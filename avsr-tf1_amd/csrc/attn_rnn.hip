@@ -60,6 +60,47 @@ __global__ void greedy_sample_kernel(const float* logits, long logits_sb, int V,
   if (threadIdx.x == 0) n_unfinished[0] = cnt;
 }
 
+// ScheduledEmbeddingTrainingHelper.sample/next_inputs (contrib/seq2seq/python/ops/helper.py): per utterance draw
+// select ~ Bernoulli(p); where selected feed the embedding of a categorical sample of this step's logits, else the
+// ground-truth token.  One block per utterance; the draw is an fp32 inverse CDF in index order (oracle: categorical_f32).
+__global__ void sched_sample_kernel(const float* logits, long logits_sb, int V, const int32_t* labels, int32_t* fed, float* xs,
+                                    const float* emb, int B, int L, int E, int l, const int32_t* seed, float prob,
+                                    float keep_in, uint32_t r_in, int in_W) {
+  __shared__ int tok_s;
+  const int b = blockIdx.x;
+  if (l + 1 >= L) return;
+  if (threadIdx.x == 0) {
+    const uint32_t sd = (uint32_t)seed[0];
+    const uint32_t idx = (uint32_t)(b * L + l);
+    int tok = labels[(long)b * L + l];
+    if (prob > 0.f && uniform01(sd, 1000u, idx) < prob) {
+      const float* lg = logits + (long)b * logits_sb;
+      float mx = lg[0];
+      for (int v = 1; v < V; ++v) mx = fmaxf(mx, lg[v]);
+      float tot = 0.f;
+      for (int v = 0; v < V; ++v) tot += expf(lg[v] - mx);
+      const float target = uniform01(sd, 1001u, idx) * tot;
+      float run = 0.f;
+      tok = V - 1;
+      for (int v = 0; v < V; ++v) {
+        run += expf(lg[v] - mx);
+        if (run > target) { tok = v; break; }
+      }
+    }
+    fed[(long)b * L + l + 1] = tok;
+    tok_s = tok;
+  }
+  __syncthreads();
+  const int tok = tok_s;
+  const bool on = keep_in < 1.0f;
+  const uint32_t sd = (uint32_t)seed[0];
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float v = emb[(long)tok * E + e];
+    if (on) v = uniform01(sd, r_in, (uint32_t)(((long)b * L + l + 1) * in_W + e)) < keep_in ? v / keep_in : 0.f;
+    xs[((long)b * L + l + 1) * E + e] = v;
+  }
+}
+
 static inline float* hbuf(const avsr_attn_rnn& d, int p) { return d.state + (long)p * d.B * d.H; }
 static inline float* cbuf(const avsr_attn_rnn& d, int p) { return d.state + (long)(2 + p) * d.B * d.H; }
 static inline float* dgroll(const avsr_attn_rnn& d, int p) { return d.dstate + (long)p * d.B * 4 * d.H; }
@@ -123,6 +164,10 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
   const int B = d.B, H = d.H, L = d.L, E = d.E, A = d.n_mech * H, KW = E + A + H;
   if (l_begin < 0 || l_end > L || l_begin > l_end) return AVSR_ERR_ARG;
   if (d.mode == 1 && (!d.embedding || !d.wout_t || !d.logits || !d.ids || !d.tok || !d.n_unfinished)) return AVSR_ERR_ARG;
+  if (d.mode == 2 && (!d.embedding || !d.wout_t || !d.logits || !d.xs || !d.labels || !d.fed || !d.seed)) return AVSR_ERR_ARG;
+  const bool drop = d.seed && d.mode != 1 && (d.keep_in < 1.f || d.keep_state < 1.f || d.keep_out < 1.f);
+  if (drop && (!d.hs_seq || (A > 0 && !d.attd))) return AVSR_ERR_ARG;
+  const uint32_t cid4 = (uint32_t)d.cell_id * 4;
   const size_t bh = sizeof(float) * B * H;
 
   if (l_begin == 0) {
@@ -135,6 +180,12 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
                          hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
     if (A > 0 && hipMemset2DAsync(d.att, sizeof(float) * (L + 1) * A, 0, sizeof(float) * A, B, s) != hipSuccess)
       return AVSR_ERR_HIP;
+    if (drop) {
+      if (hipMemcpy2DAsync(d.hs_seq, sizeof(float) * (L + 1) * H, hbuf(d, 0), sizeof(float) * H, sizeof(float) * H, B,
+                           hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (A > 0 && hipMemset2DAsync(d.attd, sizeof(float) * (L + 1) * A, 0, sizeof(float) * A, B, s) != hipSuccess)
+        return AVSR_ERR_HIP;
+    }
   }
 
   static thread_local StepLaunch SL;
@@ -149,10 +200,13 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
         StepSrc& x = tk.src[tk.nsrc++];
         x.a = d.embedding; x.sb = E; x.K = E; x.w = d.wt; x.ldw = KW; x.kind = SRC_PLAIN;
         tk.gather = d.tok;
+      } else if (d.mode == 2) {
+        StepSrc& x = tk.src[tk.nsrc++];
+        x.a = d.xs + (long)l * E; x.sb = (long)L * E; x.K = E; x.w = d.wt; x.ldw = KW; x.kind = SRC_PLAIN;
       }
       if (A > 0) {
         StepSrc& a = tk.src[tk.nsrc++];
-        a.a = d.att + (long)l * A; a.sb = (long)(L + 1) * A; a.K = A; a.w = d.wt + E; a.ldw = KW; a.kind = SRC_PLAIN;
+        a.a = (drop ? d.attd : d.att) + (long)l * A; a.sb = (long)(L + 1) * A; a.K = A; a.w = d.wt + E; a.ldw = KW; a.kind = SRC_PLAIN;
       }
       StepSrc& h = tk.src[tk.nsrc++];
       h.a = hbuf(d, l & 1); h.sb = H; h.K = H; h.w = d.wt + E + A; h.ldw = KW; h.kind = SRC_PLAIN;
@@ -161,6 +215,11 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
       tk.p0 = d.gates; tk.p1 = d.cs; tk.p2 = d.cell_out + H; tk.s0 = (long)(L + 1) * H; tk.s1 = H;
       tk.s2 = (d.mode == 0) ? 1 : 0;
       tk.p3 = cbuf(d, l & 1); tk.p4 = hbuf(d, l & 1); tk.p5 = cbuf(d, (l + 1) & 1); tk.p6 = hbuf(d, (l + 1) & 1);
+      if (drop) {
+        tk.seed = d.seed; tk.k_st = d.keep_state; tk.k_out = d.keep_out; tk.k_in = 1.0f;
+        tk.r_st = cid4 + 1; tk.r_out = cid4 + 2;
+        tk.p9 = d.hs_seq + H; tk.s4 = (long)(L + 1) * H; tk.s5 = H;
+      }
     }
     if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
 
@@ -199,12 +258,16 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
         tk.ctx_save = M.ctx + (long)l * M.D; tk.ctx_sb = (long)L * M.D;
         tk.B = B; tk.N = H; tk.mode = EP_LINEAR; tk.t = l; tk.T = L; tk.len = d.steplen;
         tk.p0 = d.att + (long)(l + 1) * A + (long)m * H; tk.s0 = (long)(L + 1) * A;
+        if (drop) {   // pre-dropped copy = the attention half of step l+1's cell input (mask index of time l+1)
+          tk.seed = d.seed; tk.k_in = d.keep_in; tk.r_in = cid4; tk.in_W = E + A; tk.in_coff = (E + A) + E + m * H;
+          tk.p9 = d.attd + (long)(l + 1) * A + (long)m * H; tk.s4 = (long)(L + 1) * A;
+        }
       }
       if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
     }
 
-    if (d.mode == 1) {
-      // ---- K4/K5: output layer + greedy sample ---------------------------------------------
+    if (d.mode == 1 || d.mode == 2) {
+      // ---- K4/K5: output layer + greedy / scheduled sample -----------------------------------
       const bool oa = d.output_attention && A > 0;
       const int O = oa ? A : H;
       SL.ntask = 1;
@@ -217,8 +280,13 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
       tk.B = B; tk.N = d.V; tk.mode = EP_LINEAR; tk.t = l; tk.T = L; tk.len = d.steplen; tk.bias = d.bout;
       tk.p0 = d.logits + (long)l * d.V; tk.s0 = (long)L * d.V;
       if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
-      hipLaunchKernelGGL(greedy_sample_kernel, dim3(1), dim3(256), 0, s, d.logits + (long)l * d.V, (long)L * d.V, d.V,
-                         d.ids + l, (long)L, d.tok, d.steplen, d.n_unfinished, B, l, d.eos_id);
+      if (d.mode == 1) {
+        hipLaunchKernelGGL(greedy_sample_kernel, dim3(1), dim3(256), 0, s, d.logits + (long)l * d.V, (long)L * d.V, d.V,
+                           d.ids + l, (long)L, d.tok, d.steplen, d.n_unfinished, B, l, d.eos_id);
+      } else {
+        hipLaunchKernelGGL(sched_sample_kernel, dim3(B), dim3(64), 0, s, d.logits + (long)l * d.V, (long)L * d.V, d.V, d.labels,
+                           d.fed, d.xs, d.embedding, B, L, E, l, d.seed, d.sampling_prob, drop ? d.keep_in : 1.0f, cid4, E + A);
+      }
       AVSR_CHECK_LAUNCH();
     }
   }
@@ -245,6 +313,8 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
     if (is_bahdanau(M)) { if (!M.wq || !M.dpq) return AVSR_ERR_ARG; ++n_bah; } else ++n_luong;
   }
   if (1 + d.n_mech + n_bah > STEP_MAX_SRC) return AVSR_ERR_UNSUPPORTED;
+  const bool drop = d.seed && (d.keep_in < 1.f || d.keep_state < 1.f || d.keep_out < 1.f);
+  const uint32_t cid4 = (uint32_t)d.cell_id * 4;
   const bool use_dq = (n_luong > 0) || d.dcell_ext;
   if (use_dq && !d.dq) return AVSR_ERR_ARG;
   const size_t bh = sizeof(float) * B * H;
@@ -267,6 +337,9 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
         tk.B = B; tk.N = A; tk.mode = EP_LINEAR; tk.t = l; tk.T = L;
         if (d.datt_ext) { tk.p1 = const_cast<float*>(d.datt_ext) + (long)l * A; tk.s1 = (long)L * A; }
         tk.p0 = d.datt + (long)l * A; tk.s0 = (long)L * A;
+        if (drop) {   // the product is the gradient of step l+1's DROPPED attention input
+          tk.act = 8; tk.seed = d.seed; tk.k_in = d.keep_in; tk.r_in = cid4; tk.in_W = E + A; tk.in_coff = (E + A) + E;
+        }
       }
       if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
       // ---- KB4: d ctx_m = d att_m . W_att,m[H:, :]^T ----------------------------------------
@@ -330,6 +403,10 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
       tk.p4 = dcbuf(d, (l + 1) & 1); tk.p5 = dcbuf(d, l & 1);
       tk.p6 = dhcarry(d, (l + 1) & 1); tk.p7 = dhcarry(d, l & 1);
       if (use_dq) { tk.p8 = d.dq; tk.s0 = (long)L * H; tk.s1 = H; }
+      if (drop) {
+        tk.seed = d.seed; tk.k_st = d.keep_state; tk.k_out = d.keep_out; tk.k_in = 1.0f;
+        tk.r_st = cid4 + 1; tk.r_out = cid4 + 2;
+      }
     }
     if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
   }

@@ -140,17 +140,35 @@ __global__ void bn_xhat_kernel(const float* x, const float* mean, const float* i
 
 // ---------------------------------------------------------------------------------------------
 // embedding lookup of the GO-prefixed label sequence (decoder_unimodal.py:66-68, :170)
-__global__ void embed_labels_kernel(const float* emb, const int32_t* labels, int go, float* out, int B, int L, int E) {
-  const int row = blockIdx.x;  // b * L + l
-  const int b = row / L, l = row % L;
+__global__ void embed_labels_kernel(const float* emb, const int32_t* labels, int go, float* out, int32_t* fed, int B, int L,
+                                    int E, int nsteps) {
+  const int b = blockIdx.x / nsteps, l = blockIdx.x % nsteps;
   const int tok = (l == 0) ? go : labels[(long)b * L + l - 1];
-  for (int e = threadIdx.x; e < E; e += blockDim.x) out[(long)row * E + e] = emb[(long)tok * E + e];
+  if (fed && threadIdx.x == 0) fed[(long)b * L + l] = tok;
+  for (int e = threadIdx.x; e < E; e += blockDim.x) out[((long)b * L + l) * E + e] = emb[(long)tok * E + e];
+}
+
+// inverted dropout over a row-structured matrix (two-level row addressing like avsr_gemm)
+__global__ void dropout_rows_kernel(const float* x, long ldx, int Tx, long ldox, float* y, long ldy, int Ty, long ldoy,
+                                    int rows, int cols, const int32_t* seed, uint32_t stream, float keep, int idx_w,
+                                    int idx_coff, int accumulate) {
+  const long total = (long)rows * cols;
+  const bool on = seed && keep < 1.0f;
+  const uint32_t sd = on ? (uint32_t)seed[0] : 0u;
+  const float inv = 1.0f / keep;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    float v = x[rowoff(r, ldx, Tx, ldox) + c];
+    if (on) v = uniform01(sd, stream, (uint32_t)((long)r * idx_w + idx_coff + c)) < keep ? v * inv : 0.f;
+    float* d = y + rowoff(r, ldy, Ty, ldoy) + c;
+    *d = accumulate ? *d + v : v;
+  }
 }
 
 // d emb[v, :] = sum over rows whose input token == v.  One block per vocabulary row; the token ids of a
 // tile of rows are staged in LDS (broadcast reads), every thread owns embedding columns and walks the
 // tile in row order (deterministic summation order).
-__global__ void embed_grad_kernel(const float* dx, const int32_t* labels, int go, float* demb, int B, int L, int E, int V) {
+__global__ void embed_grad_kernel(const float* dx, const int32_t* fed, float* demb, int B, int L, int E, int V) {
   __shared__ int toks[1024];
   const int v = blockIdx.x;
   const int rows = B * L;
@@ -158,10 +176,7 @@ __global__ void embed_grad_kernel(const float* dx, const int32_t* labels, int go
   for (int base = 0; base < rows; base += 1024) {
     const int n = min(1024, rows - base);
     __syncthreads();
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
-      const int row = base + j, b = row / L, l = row % L;
-      toks[j] = (l == 0) ? go : labels[(long)b * L + l - 1];
-    }
+    for (int j = threadIdx.x; j < n; j += blockDim.x) toks[j] = fed[base + j];
     __syncthreads();
     for (int e = threadIdx.x, slot = 0; e < E && slot < 4; e += blockDim.x, ++slot) {
       float a = acc[slot];
@@ -415,20 +430,31 @@ extern "C" int avsr_batchnorm_xhat(const float* x, const float* mean, const floa
   return AVSR_OK;
 }
 
-extern "C" int avsr_embed_labels(const float* emb, const int32_t* labels, int32_t go_id, float* out, int32_t B,
-                                 int32_t L, int32_t E, void* stream) {
-  if (!emb || !labels || !out) return AVSR_ERR_ARG;
-  hipLaunchKernelGGL(embed_labels_kernel, dim3(B * L), dim3(E >= 256 ? 256 : ((E + 63) / 64) * 64), 0, S_(stream), emb,
-                     labels, go_id, out, B, L, E);
+extern "C" int avsr_embed_labels(const float* emb, const int32_t* labels, int32_t go_id, float* out, int32_t* fed,
+                                 int32_t B, int32_t L, int32_t E, int32_t n_steps, void* stream) {
+  if (!emb || !labels || !out || n_steps <= 0 || n_steps > L) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(embed_labels_kernel, dim3(B * n_steps), dim3(E >= 256 ? 256 : ((E + 63) / 64) * 64), 0, S_(stream),
+                     emb, labels, go_id, out, fed, B, L, E, n_steps);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
 
-extern "C" int avsr_embed_grad(const float* dx, const int32_t* labels, int32_t go_id, float* demb, int32_t B, int32_t L,
-                               int32_t E, int32_t V, void* stream) {
-  if (!dx || !labels || !demb) return AVSR_ERR_ARG;
-  hipLaunchKernelGGL(embed_grad_kernel, dim3(V), dim3(E >= 256 ? 256 : ((E + 63) / 64) * 64), 0, S_(stream), dx, labels,
-                     go_id, demb, B, L, E, V);
+extern "C" int avsr_embed_grad(const float* dx, const int32_t* fed, float* demb, int32_t B, int32_t L, int32_t E,
+                               int32_t V, void* stream) {
+  if (!dx || !fed || !demb || E > 1024) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(embed_grad_kernel, dim3(V), dim3(E >= 256 ? 256 : ((E + 63) / 64) * 64), 0, S_(stream), dx, fed, demb,
+                     B, L, E, V);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_dropout_rows(const avsr_mat* x, const avsr_mat* y, int32_t rows, int32_t cols, const int32_t* seed,
+                                 int32_t stream_id, float keep, int32_t idx_width, int32_t idx_coff, int32_t accumulate,
+                                 void* stream) {
+  if (!x || !y || !x->ptr || !y->ptr || rows <= 0 || cols <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(dropout_rows_kernel, dim3(blocks_for((long)rows * cols)), dim3(256), 0, S_(stream), x->ptr, (long)x->ld,
+                     x->T, (long)x->ldo, y->ptr, (long)y->ld, y->T, (long)y->ldo, rows, cols, seed, (uint32_t)stream_id, keep,
+                     idx_width, idx_coff, accumulate);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

@@ -15,6 +15,20 @@ namespace avsr {
 
 static inline float* hbuf(const avsr_rnn_layer& l, int B, int parity) { return l.state + (long)parity * B * l.units; }
 static inline float* cbuf(const avsr_rnn_layer& l, int B, int parity) { return l.state + (long)(2 + parity) * B * l.units; }
+// dropout only: the layer's output as its consumer sees it (output mask x consumer's input mask), ping-pong
+static inline float* xbuf(const avsr_rnn_layer& l, int B, int parity) { return l.state + (long)(4 + parity) * B * l.units; }
+static inline void set_cell_dropout(StepTask& tk, const avsr_rnn_stack& S, int l) {
+  if (!S.seed) return;
+  const uint32_t cid = (uint32_t)(S.cell_id_base + l);
+  tk.seed = S.seed;
+  tk.k_st = S.keep_state; tk.k_out = S.keep_out; tk.k_in = 1.0f;
+  tk.r_st = cid * 4 + 1; tk.r_out = cid * 4 + 2;
+  if (l + 1 < S.n_layers) {            // consumer = next layer of the stack: mask over its [units_l] wide input
+    tk.k_in = S.keep_in; tk.r_in = (cid + 1) * 4; tk.in_W = S.layer[l].units; tk.in_coff = 0;
+  } else if (S.consumer_width > 0) {   // consumer = attention-wrapped layer above the stack (AV-Align)
+    tk.k_in = S.consumer_keep; tk.r_in = (uint32_t)S.consumer_stream; tk.in_W = S.consumer_width; tk.in_coff = 0;
+  }
+}
 // dstate: dG rolling [2][B][4H] | dc [2][B][H] | dh_carry [2][B][H]
 static inline float* dgroll(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)parity * B * 4 * l.units; }
 static inline float* dcbuf(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)(8 + parity) * B * l.units; }
@@ -61,7 +75,7 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
           if (l == 0) return AVSR_ERR_UNSUPPORTED;  // layer 0 input projection must be hoisted (avsr_gemm)
           const avsr_rnn_layer& Lo = S.layer[l - 1];
           StepSrc& x = tk.src[tk.nsrc++];
-          x.a = hbuf(Lo, S.B, (t + 1) & 1); x.sb = Lo.units; x.K = in; x.w = Ly.wt; x.ldw = in + H; x.kind = SRC_PLAIN;
+          x.a = S.seed ? xbuf(Lo, S.B, (t + 1) & 1) : hbuf(Lo, S.B, (t + 1) & 1); x.sb = Lo.units; x.K = in; x.w = Ly.wt; x.ldw = in + H; x.kind = SRC_PLAIN;
         }
         StepSrc& h = tk.src[tk.nsrc++];
         h.a = hbuf(Ly, S.B, t & 1); h.sb = H; h.K = H; h.w = Ly.wt + in; h.ldw = in + H; h.kind = SRC_PLAIN;
@@ -72,6 +86,13 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
         tk.s0 = (long)(S.T + 2) * Ly.ld_out; tk.s1 = Ly.ld_out; tk.s2 = Ly.hoisted ? 1 : 0;
         tk.p3 = cbuf(Ly, S.B, t & 1); tk.p4 = hbuf(Ly, S.B, t & 1);
         tk.p5 = cbuf(Ly, S.B, (t + 1) & 1); tk.p6 = hbuf(Ly, S.B, (t + 1) & 1);
+        if (S.seed) {
+          set_cell_dropout(tk, S, l);
+          tk.s4 = (long)(S.T + 2) * H; tk.s5 = H;
+          if (Ly.hs_seq) tk.p9 = Ly.hs_seq + H;                       // slot 1 = time 0
+          if (l + 1 < S.n_layers) tk.p10 = xbuf(Ly, S.B, (t + 1) & 1);
+          if (Ly.xt_seq) tk.p11 = Ly.xt_seq + H;
+        }
       }
     }
     if (L.ntask == 0) continue;
@@ -149,6 +170,10 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
         if (Ly.dout) {
           tk.p8 = const_cast<float*>(Ly.dout) + Ly.ld_dout + Ly.dout_col;  // slot 1 = time 0
           tk.s0 = (long)(S.T + 2) * Ly.ld_dout; tk.s1 = Ly.ld_dout;
+        }
+        if (S.seed) {
+          set_cell_dropout(tk, S, l);
+          if (l + 1 >= nl) tk.k_in = 1.0f;   // no upper layer inside the stack: external d out is already wrt the output
         }
       }
     }

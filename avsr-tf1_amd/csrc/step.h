@@ -45,7 +45,15 @@ struct StepTask {
   float* ctx_save; long ctx_sb;      // optional: combined slab source written back (by column-tile 0)
   // epilogue I/O (meaning per mode; see step.hip)
   float* p0; float* p1; float* p2; float* p3; float* p4; float* p5; float* p6; float* p7; float* p8;
-  long s0, s1, s2, s3;
+  float* p9; float* p10; float* p11;   // dropout-time extra outputs: state-dropped h sequence / second dense output,
+                                       // consumer-input (x~) rolling buffer, x~ sequence
+  long s0, s1, s2, s3, s4, s5;
+  // DropoutWrapper (cells.py:46-54): stateless masks keyed by (*seed, stream, index); seed == null -> off
+  const int32_t* seed;
+  float k_st, k_out, k_in;             // keep prob: own state h, own output, the consumer's input mask
+  uint32_t r_st, r_out, r_in;          // RNG stream ids
+  int in_W, in_coff;                   // input-mask index = (b*T + tau) * in_W + in_coff + column
+  int pad1;
 };
 
 struct StepLaunch {

@@ -27,7 +27,7 @@ static int g_step_geo = -1;   // development override of the workgroup geometry 
 // Loads are issued in batches of UN chunks (2*UN 16-byte loads per lane in flight) before the MFMAs
 // that consume them; four independent accumulators keep the matrix pipe at its 32-cycle issue rate.
 
-template <int KP, int UN, int RM>
+template <int KP, int UN, int RM, bool GROUPS>
 __device__ __forceinline__ void mm16_partial(const StepTask& tk, int row0, int col0, int kp, bool save_ctx, f32x4 (&out)[RM]) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, q = lane >> 4;
@@ -41,7 +41,14 @@ __device__ __forceinline__ void mm16_partial(const StepTask& tk, int row0, int c
     for (int e = 0; e < 4; ++e) acc[r][e] = zero4;
   int NC = 0;
   for (int s = 0; s < tk.nsrc; ++s) NC += (tk.src[s].K + 15) >> 4;
-  const int g0 = (kp * NC) / KP, g1 = ((kp + 1) * NC) / KP;       // this wave's global chunk range
+  int g0 = (kp * NC) / KP, g1 = ((kp + 1) * NC) / KP;             // this wave's global chunk range
+  if (GROUPS && tk.nsrc > 1) {
+    // LSTM backward: source 0 (recurrent path, masked by the STATE dropout) is reduced by the lower half of the
+    // waves, every other source (gradient of the cell OUTPUT) by the upper half, so the epilogue can mask them apart
+    const int n0 = (tk.src[0].K + 15) >> 4, h = KP / 2;
+    if (kp < h) { g0 = (kp * n0) / h; g1 = ((kp + 1) * n0) / h; }
+    else { g0 = n0 + ((kp - h) * (NC - n0)) / h; g1 = n0 + ((kp - h + 1) * (NC - n0)) / h; }
+  }
   int cbase = 0;
   for (int s = 0; s < tk.nsrc; ++s) {
     const StepSrc& S = tk.src[s];
@@ -147,9 +154,15 @@ __device__ __forceinline__ void mm16_partial(const StepTask& tk, int row0, int c
 __device__ __forceinline__ float fsigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float ftanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
+// inverted-dropout factor of element idx: 1/keep if kept, 0 if dropped, 1 if dropout is off
+__device__ __forceinline__ float drop_scale(const int32_t* seed, uint32_t stream, uint32_t idx, float keep) {
+  if (!seed || keep >= 1.0f) return 1.0f;
+  return uniform01((uint32_t)seed[0], stream, idx) < keep ? 1.0f / keep : 0.0f;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == 1) return ftanh(v);
-  if (act == 2) return fsigmoid(v);
+  if ((act & 3) == 1) return ftanh(v);
+  if ((act & 3) == 2) return fsigmoid(v);
   return v;
 }
 
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
   const int e_row0 = ((int)blockIdx.y * TM + e_mt) * 16, e_col0 = ((int)blockIdx.x * TN + e_nt) * 16;
   bool e_ok = false, valid = false;
   int b = 0, n = 0, len = 0, tau = 0;
-  float pre0 = 0.f, pre1 = 0.f, pre2 = 0.f, pre3 = 0.f;
+  float pre0 = 0.f, pre1 = 0.f, pre2 = 0.f, pre3 = 0.f, pre2b = 0.f;
   f32x4 pre4a = {0.f, 0.f, 0.f, 0.f}, pre4b = {0.f, 0.f, 0.f, 0.f};
   if (epi) {
     if constexpr (MODE == EP_LSTM_FWD) {
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
           pre2 = tk.p1[bt * H + n];                  // c
           if (t == 0) pre3 = tk.bias ? tk.bias[bh] : 0.f;
           else pre3 = tk.p1[(bt + (tk.reverse ? 1 : -1)) * H + n];   // c_prev
-          if (tk.p8) pre1 += tk.p8[(long)b * tk.s0 + (long)tau * tk.s1 + n];
+          if (tk.p8) pre2b = tk.p8[(long)b * tk.s0 + (long)tau * tk.s1 + n];   // external d out
         }
       }
     } else {
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
   const int row0 = (int)blockIdx.y * TM * 16, col0 = ((int)blockIdx.x * TN + nt) * 16;
   constexpr int UN = (TM >= 4) ? 2 : (TM == 2 ? 4 : 8);
   f32x4 acc[TM];
-  mm16_partial<KP, UN, TM>(tk, row0, col0, kp, blockIdx.x == 0 && nt == 0, acc);
+  mm16_partial<KP, UN, TM, MODE == EP_LSTM_BWD>(tk, row0, col0, kp, blockIdx.x == 0 && nt == 0, acc);
   // C/D layout of mfma 16x16: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
   for (int m = 0; m < TM; ++m)
@@ -254,12 +267,15 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
 
   if constexpr (MODE == EP_LINEAR) {
     // p0 out (row stride s0), p1 add (row stride s1)
-    float z = pre0;
+    float z = 0.f;
 #pragma unroll
     for (int w = 0; w < KP; ++w) z += red[w][e_tile][e_l >> 4][e_l & 15];
-    z = apply_act(z, tk.act);
+    const uint32_t midx = (uint32_t)(((long)b * tk.T + t) * tk.in_W + tk.in_coff + n);
+    if (tk.act & 8) z *= drop_scale(tk.seed, tk.r_in, midx, tk.k_in);   // gradient through an input-dropout mask
+    z = apply_act(z + pre0, tk.act);
     if (!valid) z = 0.f;                     // dynamic_rnn / impute_finished: zero output past the valid length
     tk.p0[(long)b * tk.s0 + n] = z;
+    if (tk.p9) tk.p9[(long)b * tk.s4 + n] = z * drop_scale(tk.seed, tk.r_in, midx, tk.k_in);   // pre-dropped copy for the consumer
   } else if constexpr (MODE == EP_LSTM_BWD) {
     // n = unit.  p0 gates, p1 cs, p2 dgates record, p3 dG rolling out [B,4H], p4 dc_in, p5 dc_out,
     // p6 dh_carry_in, p7 dh_carry_out, p8 dout (s0 batch stride, s1 time stride), bias = c_init [B,H]
@@ -267,9 +283,22 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
     const long bh = (long)b * H + n;
     f32x4 dg = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
-      float dh = pre1;                       // carry + external d out
+      // zA: recurrent path (gradient of the state h), zB: gradient of the emitted output from upper layer / attention
+      float zA = 0.f, zB = 0.f;
+      if (tk.nsrc > 1) {
 #pragma unroll
-      for (int w = 0; w < KP; ++w) dh += red[w][e_tile][e_l >> 4][e_l & 15];
+        for (int w = 0; w < KP / 2; ++w) zA += red[w][e_tile][e_l >> 4][e_l & 15];
+#pragma unroll
+        for (int w = KP / 2; w < KP; ++w) zB += red[w][e_tile][e_l >> 4][e_l & 15];
+      } else {
+#pragma unroll
+        for (int w = 0; w < KP; ++w) zA += red[w][e_tile][e_l >> 4][e_l & 15];
+      }
+      const uint32_t oidx = (uint32_t)(((long)b * tk.T + tau) * H + n);
+      const uint32_t iidx = (uint32_t)(((long)b * tk.T + tau) * tk.in_W + tk.in_coff + n);
+      const float dout = pre2b + zB * drop_scale(tk.seed, tk.r_in, iidx, tk.k_in);
+      const float dh = dout * drop_scale(tk.seed, tk.r_out, oidx, tk.k_out) +
+                       (zA + pre1) * drop_scale(tk.seed, tk.r_st, oidx, tk.k_st);
       const f32x4 g = pre4a;
       const float c = pre2, cprev = pre3;
       const float tc = ftanh(c);
@@ -315,13 +344,27 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
       const float h = g[3] * ftanh(c);
       st4(tk.p0 + (bt * H + n) * 4, g);
       tk.p1[bt * H + n] = c;
-      if (tk.p2) tk.p2[(long)b * tk.s0 + (long)tau * tk.s1 + n] = h;
+      // DropoutWrapper: emitted output and recurrent h carry independent masks; c is never dropped
+      const uint32_t oidx = (uint32_t)(bt * H + n);
+      const float ho = h * drop_scale(tk.seed, tk.r_out, oidx, tk.k_out);
+      const float hs = h * drop_scale(tk.seed, tk.r_st, oidx, tk.k_st);
+      if (tk.p2) tk.p2[(long)b * tk.s0 + (long)tau * tk.s1 + n] = ho;
       tk.p5[bh] = c;
-      tk.p6[bh] = h;
+      tk.p6[bh] = hs;
+      if (tk.p9) tk.p9[(long)b * tk.s4 + (long)tau * tk.s5 + n] = hs;          // state-dropped h sequence (dWh operand)
+      if (tk.p10 || tk.p11) {                                                   // consumer's (input-dropped) view of the output
+        const float xn = ho * drop_scale(tk.seed, tk.r_in, (uint32_t)(bt * tk.in_W + tk.in_coff + n), tk.k_in);
+        if (tk.p10) tk.p10[bh] = xn;
+        if (tk.p11) tk.p11[(long)b * tk.s4 + (long)tau * tk.s5 + n] = xn;
+      }
     } else {
       tk.p5[bh] = cprev;
       tk.p6[bh] = hprev;
-      if (tk.p2 && t < tk.T) tk.p2[(long)b * tk.s0 + (long)t * tk.s1 + n] = 0.f;  // zero output past len
+      if (t < tk.T) {                                                            // zero output past len
+        if (tk.p2) tk.p2[(long)b * tk.s0 + (long)t * tk.s1 + n] = 0.f;
+        if (tk.p9) tk.p9[(long)b * tk.s4 + (long)t * tk.s5 + n] = 0.f;
+        if (tk.p11) tk.p11[(long)b * tk.s4 + (long)t * tk.s5 + n] = 0.f;
+      }
     }
   }
 }

@@ -22,7 +22,7 @@ import torch
 
 from . import ops, params as PR
 from ._lib import AttnRnn, RnnStack
-from .config import ATT_CODE, BAHDANAU_TYPES, LUONG_TYPES, ModelConfig
+from .config import ATT_CODE, BAHDANAU_TYPES, CELL_ID_DECODER, LUONG_TYPES, ModelConfig, encoder_cell_id
 
 
 @dataclass
@@ -126,6 +126,7 @@ class Seq2SeqModel:
         for name, off, r, c in self._tjobs:
             self.Tr[name] = Ref(self.derived, off, (c, r))
         self._ws_cache = {}
+        self._dropping = False
         self.au_scale = 1.0          # data parallel: 1 / world_size (AU term averaged over ranks)
         self.load_tf_weights(weights if weights is not None else PR.initialise(cfg, seed))
         self.scratch = z(1 << 22)
@@ -184,6 +185,9 @@ class Seq2SeqModel:
             nplain = len(units) - 1 if attentive else len(units)
             E = {"T": T, "F": F, "units": units, "nplain": nplain, "attentive": attentive}
             E["xn"], E["dxn"], E["xhat"] = z(B * T, F), z(B * T, F), z(B * T, F)
+            if cfg.use_dropout:
+                E["xd"] = {d: z(B * T, F) for d in cfg.directions()}     # layer-0 input after each direction's input mask
+                E["dx_tmp"] = z(B * T, F)
             E["mean"], E["invstd"] = z(F), z(F)
             Dm = units[-1] * ndir
             if not attentive:
@@ -193,7 +197,7 @@ class Seq2SeqModel:
             for di, d in enumerate(cfg.directions()):
                 for l in range(nplain):
                     u = units[l]
-                    Ld = {"gates": z(B, T, u, 4), "cs": z(B, T, u), "state": z(4 * B * u), "dgates": z(B, T, u, 4),
+                    Ld = {"gates": z(B, T, u, 4), "cs": z(B, T, u), "state": z(6 * B * u), "dgates": z(B, T, u, 4),
                           "dstate": z(12 * B * u), "hf": z(B, u), "cf": z(B, u), "dhf": z(B, u), "dcf": z(B, u)}
                     top = (l == len(units) - 1)
                     if top:
@@ -201,6 +205,10 @@ class Seq2SeqModel:
                     else:
                         Ld["out"], Ld["col"] = SeqBuf(B, T, u, 1, 1, dev), 0
                         Ld["dout"] = SeqBuf(B, T, u, 1, 1, dev) if (attentive and l == nplain - 1) else None
+                    if cfg.use_dropout:
+                        Ld["hs_seq"] = SeqBuf(B, T, u, 1, 1, dev)
+                        if not top or attentive:
+                            Ld["xt_seq"] = SeqBuf(B, T, u, 1, 1, dev)
                     E["layers"][(d, l)] = Ld
             H = cfg.decoder_units[0]
             E["c_dec"], E["h_dec"], E["dc_dec"], E["dh_dec"] = z(B, H), z(B, H), z(B, H), z(B, H)
@@ -220,6 +228,7 @@ class Seq2SeqModel:
         V = cfg.vocab_size
         D["xemb"], D["dxemb"] = z(B * Ldec, cfg.embedding_size), z(B * Ldec, cfg.embedding_size)
         D["logits"], D["dlogits"], D["row_loss"] = z(B, Ldec, V), z(B, Ldec, V), z(B * Ldec)
+        D["fed"] = torch.zeros(B, Ldec, dtype=torch.int32, device=dev)
         D["ids"] = torch.zeros(B, Ldec, dtype=torch.int32, device=dev)
         D["tok"] = torch.zeros(B, dtype=torch.int32, device=dev)
         D["nunf"] = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -233,6 +242,14 @@ class Seq2SeqModel:
         z = lambda *s: torch.zeros(*s, device=dev)
         A = H * len(mems)
         blk = {"B": B, "L": L, "H": H, "E": E, "A": A, "cell": cell_prefix, "mems": []}
+        if cell_prefix.startswith("dec/"):
+            blk["cell_id"], blk["keep"] = CELL_ID_DECODER, cfg.decoder_dropout
+        else:
+            blk["cell_id"], blk["keep"] = encoder_cell_id("audio", "fw", len(cfg.audio_units) - 1), cfg.audio_dropout
+        if cfg.use_dropout:
+            blk["hs_seq"] = SeqBuf(B, L, H, 1, 0, dev)
+            if A:
+                blk["attd"] = SeqBuf(B, L, A, 1, 0, dev)
         blk.update(gates=z(B, L, H, 4), cs=z(B, L, H), cell_out=SeqBuf(B, L, H, 1, 0, dev), state=z(4 * B * H),
                    dgates=z(B, L, H, 4), dstate=z(12 * B * H), dq=z(B, L, H), dh0=z(B, H), dc0=z(B, H),
                    hf=z(B, H), cf=z(B, H), dcell_ext=z(B, L, H))
@@ -255,12 +272,32 @@ class Seq2SeqModel:
 
     # ------------------------------------------------------------------------------------------------
     # encoders
+    def _keeps(self, s):
+        return self.cfg.video_dropout if s == "video" else self.cfg.audio_dropout
+
+    def _sdrop(self, s):
+        """DropoutWrapper active for this stream's encoder cells in the current pass?"""
+        return self._dropping and min(self._keeps(s)) < 1.0
+
+    def _bdrop(self, blk):
+        return self._dropping and min(blk["keep"]) < 1.0
+
     def _rnn_stack(self, ws, s, d, B, len_t, backward=False):
         cfg = self.cfg
         E = ws["enc"][s]
         st = RnnStack()
         st.B, st.T, st.reverse, st.n_layers, st.cell = B, E["T"], int(d == "bw"), E["nplain"], 0
         st.len = ops.fptr(len_t)
+        drop = self._sdrop(s)
+        if drop:
+            k = self._keeps(s)
+            st.seed = ops.fptr(self.step)
+            st.keep_in, st.keep_state, st.keep_out = k
+            st.cell_id_base = encoder_cell_id(s, d, 0)
+            if E["attentive"]:                   # the attention-wrapped top layer consumes this stack through xt_seq
+                st.consumer_keep = k[0]
+                st.consumer_stream = encoder_cell_id(s, d, E["nplain"]) * 4
+                st.consumer_width = E["units"][-2] + E["units"][-1]
         i = E["F"]
         for l in range(E["nplain"]):
             u = E["units"][l]
@@ -275,6 +312,10 @@ class Seq2SeqModel:
             Ly.out, Ly.ld_out = ops.fptr(Ld["out"].t), Ld["out"].D
             Ly.state, Ly.h_final, Ly.c_final = ops.fptr(Ld["state"]), ops.fptr(Ld["hf"]), ops.fptr(Ld["cf"])
             Ly.dgates, Ly.dstate = ops.fptr(Ld["dgates"]), ops.fptr(Ld["dstate"])
+            if drop:
+                Ly.hs_seq = ops.fptr(Ld["hs_seq"].t)
+                if "xt_seq" in Ld:
+                    Ly.xt_seq = ops.fptr(Ld["xt_seq"].t)
             if backward and Ld["dout"] is not None:
                 Ly.dout, Ly.ld_dout, Ly.dout_col = ops.fptr(Ld["dout"].t), Ld["dout"].D, Ld["col"]
             i = u
@@ -285,6 +326,7 @@ class Seq2SeqModel:
 
     def _encode(self, ws, batch: Batch, training: bool):
         cfg, B = self.cfg, ws["B"]
+        self._dropping = bool(cfg.use_dropout and training)       # cells.py:46: DropoutWrapper only in the train graph
         stacks = []
         for s in cfg.streams():
             E = ws["enc"][s]
@@ -305,7 +347,12 @@ class Seq2SeqModel:
             for d in cfg.directions():
                 u0 = E["units"][0]
                 W0 = self.P[f"{s}/enc/{d}/l0/kernel"]
-                ops.gemm(ops.mat(E["xin"], F), W0.mat(4 * u0), ops.mat(E["layers"][(d, 0)]["gates"], 4 * u0), B * T, 4 * u0, F)
+                xin = E["xin"]
+                if self._sdrop(s):               # DropoutWrapper input mask of the layer-0 cell of this direction
+                    xin = E["xd"][d]
+                    ops.dropout_rows(ops.mat(E["xin"], F), ops.mat(xin, F), B * T, F, self.step, encoder_cell_id(s, d, 0) * 4,
+                                     self._keeps(s)[0], F)
+                ops.gemm(ops.mat(xin, F), W0.mat(4 * u0), ops.mat(E["layers"][(d, 0)]["gates"], 4 * u0), B * T, 4 * u0, F)
                 stacks.append(self._rnn_stack(ws, s, d, B, len_t))
         self._run_stacks(stacks, ops.rnn_fwd)
         for s in cfg.streams():
@@ -410,17 +457,30 @@ class Seq2SeqModel:
                     Ld = E["layers"][(d, l)]
                     Gk = self.G[f"{s}/enc/{d}/l{l}/kernel"]
                     dg = ops.mat(Ld["dgates"], 4 * u)
-                    a_x = ops.mat(E["xin"], F) if l == 0 else E["layers"][(d, l - 1)]["out"].mat(0, E["layers"][(d, l - 1)]["col"])
+                    drop = self._sdrop(s)
+                    if l == 0:
+                        a_x = ops.mat(E["xd"][d] if drop else E["xin"], F)
+                    elif drop:
+                        a_x = E["layers"][(d, l - 1)]["xt_seq"].mat(0)
+                    else:
+                        a_x = E["layers"][(d, l - 1)]["out"].mat(0, E["layers"][(d, l - 1)]["col"])
                     self._gemm_tn(a_x, dg, Gk.mat(4 * u), i, 4 * u, B * T)
-                    a_h = Ld["out"].mat(1 if d == "bw" else -1, Ld["col"])
+                    sh = 1 if d == "bw" else -1
+                    a_h = Ld["hs_seq"].mat(sh) if drop else Ld["out"].mat(sh, Ld["col"])
                     self._gemm_tn(a_h, dg, Gk.mat(4 * u, row0=i), u, 4 * u, B * T)
                     ops.colsum(dg, B * T, 4 * u, self.grads, self.scratch, beta=1.0, out_offset=self.G[f"{s}/enc/{d}/l{l}/bias"].off)
                     i = u
                 if E["nplain"] > 0 and cfg.batch_normalisation:
                     u0 = E["units"][0]
                     W0 = self.P[f"{s}/enc/{d}/l0/kernel"]
-                    ops.gemm(ops.mat(E["layers"][(d, 0)]["dgates"], 4 * u0), W0.mat(4 * u0), ops.mat(E["dxn"], F), B * T, F, 4 * u0,
-                             trans_b=1, beta=0.0 if first else 1.0)
+                    if self._sdrop(s):
+                        ops.gemm(ops.mat(E["layers"][(d, 0)]["dgates"], 4 * u0), W0.mat(4 * u0), ops.mat(E["dx_tmp"], F), B * T, F,
+                                 4 * u0, trans_b=1)
+                        ops.dropout_rows(ops.mat(E["dx_tmp"], F), ops.mat(E["dxn"], F), B * T, F, self.step,
+                                         encoder_cell_id(s, d, 0) * 4, self._keeps(s)[0], F, accumulate=not first)
+                    else:
+                        ops.gemm(ops.mat(E["layers"][(d, 0)]["dgates"], 4 * u0), W0.mat(4 * u0), ops.mat(E["dxn"], F), B * T, F, 4 * u0,
+                                 trans_b=1, beta=0.0 if first else 1.0)
                     first = False
             if cfg.batch_normalisation:
                 # (a 1-layer attentive encoder wrote dxn in _av_align_backward)
@@ -493,6 +553,13 @@ class Seq2SeqModel:
             M.scores, M.ctx, M.pstat, M.pctx = ops.fptr(m["scores"]), ops.fptr(m["ctx"]), ops.fptr(m["pstat"]), ops.fptr(m["pctx"])
             if with_bwd:
                 M.dscores, M.dctx, M.pdq = ops.fptr(m["dscores"]), ops.fptr(m["dctx"]), ops.fptr(m["pdq"])
+        if self._bdrop(blk) and mode != 1:
+            keep = blk["keep"]
+            d.seed = ops.fptr(self.step)
+            d.keep_in, d.keep_state, d.keep_out = keep
+            d.cell_id = blk["cell_id"]
+            d.hs_seq = ops.fptr(blk["hs_seq"].t)
+            d.attd = ops.fptr(blk["attd"].t) if A else None
         if with_bwd:
             d.dgates, d.dstate, d.dq = ops.fptr(blk["dgates"]), ops.fptr(blk["dstate"]), ops.fptr(blk["dq"])
             d.datt = ops.fptr(blk["datt"]) if A else None
@@ -557,10 +624,11 @@ class Seq2SeqModel:
         # cell kernel: rows [0:E] inputs, [E:E+A] previous attention, [E+A:] previous h
         Gk = self.G[blk["cell"] + "/kernel"]
         dg = ops.mat(blk["dgates"], 4 * H)
+        drop = self._bdrop(blk)
         self._gemm_tn(xin_mat, dg, Gk.mat(4 * H), E, 4 * H, rows)
         if A:
-            self._gemm_tn(blk["att"].mat(-1), dg, Gk.mat(4 * H, row0=E), A, 4 * H, rows)
-        self._gemm_tn(co.mat(-1), dg, Gk.mat(4 * H, row0=E + A), H, 4 * H, rows)
+            self._gemm_tn((blk["attd"] if drop else blk["att"]).mat(-1), dg, Gk.mat(4 * H, row0=E), A, 4 * H, rows)
+        self._gemm_tn((blk["hs_seq"] if drop else co).mat(-1), dg, Gk.mat(4 * H, row0=E + A), H, 4 * H, rows)
         ops.colsum(dg, rows, 4 * H, self.grads, self.scratch, beta=1.0, out_offset=self.G[blk["cell"] + "/bias"].off)
         if dxin_mat is not None:
             ops.gemm(dg, self.P[blk["cell"] + "/kernel"].mat(4 * H), dxin_mat, rows, E, 4 * H, trans_b=1, beta=dxin_beta)
@@ -573,6 +641,9 @@ class Seq2SeqModel:
         blk = E["blk"]
         T, H, Ein = E["T"], blk["H"], blk["E"]
         kname = blk["cell"] + "/kernel"
+        if self._sdrop("audio") and E["nplain"] == 0:
+            ops.dropout_rows(ops.mat(E["xin"], E["F"]), ops.mat(E["xd"]["fw"], E["F"]), B * T, E["F"], self.step, blk["cell_id"] * 4,
+                             blk["keep"][0], Ein + blk["A"])
         xin = self._av_xin(E)
         ops.gemm(xin, self.P[kname].mat(4 * H), ops.mat(blk["gates"], 4 * H), B * T, 4 * H, Ein)
         self._block_prepare(ws, blk)
@@ -581,10 +652,11 @@ class Seq2SeqModel:
         E["c_fin"], E["h_fin"] = blk["cf"], blk["hf"]
 
     def _av_xin(self, E):
+        """Hoisted input of the attention-wrapped layer (already carrying that cell's input mask under dropout)."""
         if E["nplain"] == 0:
-            return ops.mat(E["xin"], E["F"])
+            return ops.mat(E["xd"]["fw"] if self._sdrop("audio") else E["xin"], E["F"])
         Ld = E["layers"][("fw", E["nplain"] - 1)]
-        return Ld["out"].mat(0)
+        return (Ld["xt_seq"] if self._sdrop("audio") else Ld["out"]).mat(0)
 
     def _av_align_backward(self, ws, batch):
         cfg, B = self.cfg, ws["B"]
@@ -596,11 +668,17 @@ class Seq2SeqModel:
         d.dcell_ext = None if luong else ops.fptr(blk["dcell_ext"])
         d.dh_final, d.dc_final = ops.fptr(blk["dhf_in"]), ops.fptr(blk["dcf_in"])
         if E["nplain"] == 0:
-            dxin, beta = ops.mat(E["dxn"], E["F"]), 0.0
+            dxin, beta = ops.mat(E["dx_tmp"] if self._sdrop("audio") else E["dxn"], E["F"]), 0.0
         else:
             Ld = E["layers"][("fw", E["nplain"] - 1)]
             dxin, beta = Ld["dout"].mat(0), 0.0
         self._block_backward(ws, blk, d, self._av_xin(E), dxin, beta, luong)
+        if self._sdrop("audio"):                 # gradient of the DROPPED input -> gradient of the layer below's output
+            keep, W = blk["keep"][0], blk["E"] + blk["A"]
+            if E["nplain"] == 0:
+                ops.dropout_rows(dxin, ops.mat(E["dxn"], E["F"]), B * E["T"], E["F"], self.step, blk["cell_id"] * 4, keep, W)
+            else:
+                ops.dropout_rows(dxin, dxin, B * E["T"], blk["E"], self.step, blk["cell_id"] * 4, keep, W)
 
     # ------------------------------------------------------------------------------------------------
     # decoder
@@ -666,13 +744,37 @@ class Seq2SeqModel:
         D = ws["dec"]
         H, E, V = D["H"], D["E"], cfg.vocab_size
         self._decoder_init_state(ws)
-        ops.embed_labels(self._pp("dec/embedding"), batch.labels, cfg.go_id, D["xemb"], B, L, E)
-        ops.gemm(ops.mat(D["xemb"], E), self.P["dec/l0/kernel"].mat(4 * H), ops.mat(D["gates"], 4 * H), B * L, 4 * H, E)
+        sampling = cfg.sampling_probability > 0
+        A = D["A"]
+        drop_in = self._dropping and cfg.decoder_dropout[0] < 1.0
+        xm = ops.mat(D["xemb"], E)
+        # decoder inputs = embedding of the GO-prefixed labels (all steps when teacher forcing, only step 0 when sampling)
+        ops.embed_labels(self._pp("dec/embedding"), batch.labels, cfg.go_id, D["xemb"], D["fed"], B, L, E, 1 if sampling else L)
+        if drop_in:
+            if sampling:     # only row (b, 0): address rows with stride L*E, mask index (b*L + 0)*(E+A) + e
+                ops.dropout_rows(ops.mat(D["xemb"], L * E), ops.mat(D["xemb"], L * E), B, E, self.step, CELL_ID_DECODER * 4,
+                                 cfg.decoder_dropout[0], L * (E + A))
+            else:
+                ops.dropout_rows(xm, xm, B * L, E, self.step, CELL_ID_DECODER * 4, cfg.decoder_dropout[0], E + A)
+        if not sampling:
+            ops.gemm(xm, self.P["dec/l0/kernel"].mat(4 * H), ops.mat(D["gates"], 4 * H), B * L, 4 * H, E)
         self._block_prepare(ws, D)
-        D["desc"] = self._block_desc(ws, D, batch.labels_len, 0, D["h0"], D["c0"], with_bwd=True)
-        ops.attn_rnn_fwd(D["desc"], 0, L)
-        ov, O = self._out_vec(D)
-        ops.gemm(ov, self.P["dec/out/kernel"].mat(V), ops.mat(D["logits"], V), B * L, V, O, bias=self._pp("dec/out/bias"))
+        D["desc"] = d = self._block_desc(ws, D, batch.labels_len, 2 if sampling else 0, D["h0"], D["c0"], with_bwd=True)
+        if sampling:
+            d.output_attention = int(cfg.output_attention())
+            d.seed = ops.fptr(self.step)
+            d.sampling_prob = cfg.sampling_probability
+            if not self._bdrop(D):
+                d.keep_in = d.keep_state = d.keep_out = 1.0
+                d.cell_id = CELL_ID_DECODER
+            d.embedding = ops.fptr(self.params, self.P["dec/embedding"].off)
+            d.wout_t = ops.fptr(self.derived, self.Tr["dec/out/kernel"].off)
+            d.bout = ops.fptr(self.params, self.P["dec/out/bias"].off)
+            d.logits, d.xs, d.labels, d.fed = ops.fptr(D["logits"]), ops.fptr(D["xemb"]), ops.fptr(batch.labels), ops.fptr(D["fed"])
+        ops.attn_rnn_fwd(d, 0, L)
+        if not sampling:
+            ov, O = self._out_vec(D)
+            ops.gemm(ov, self.P["dec/out/kernel"].mat(V), ops.mat(D["logits"], V), B * L, V, O, bias=self._pp("dec/out/bias"))
         ops.seq_loss(D["logits"], batch.labels, batch.labels_len, self.denom, compute_denom, D["row_loss"], D["dlogits"], B, L, V)
         ops.reduce_scalar(D["row_loss"], B * L, self.loss)
         if cfg.regress_aus and "video" in ws["enc"]:
@@ -708,7 +810,10 @@ class Seq2SeqModel:
         d.datt_ext = ops.fptr(dext) if oa else None
         d.dcell_ext = None if oa else ops.fptr(dext)
         self._block_backward(ws, D, d, ops.mat(D["xemb"], E), ops.mat(D["dxemb"], E), 0.0, oa)
-        ops.embed_grad(D["dxemb"], batch.labels, cfg.go_id, self._gp("dec/embedding"), B, L, E, V)
+        if self._dropping and cfg.decoder_dropout[0] < 1.0:
+            dm = ops.mat(D["dxemb"], E)
+            ops.dropout_rows(dm, dm, B * L, E, self.step, CELL_ID_DECODER * 4, cfg.decoder_dropout[0], E + A)
+        ops.embed_grad(D["dxemb"], D["fed"], self._gp("dec/embedding"), B, L, E, V)
         self._decoder_init_state_bwd(ws)
         self._encode_backward(ws, batch)
 

@@ -100,12 +100,19 @@ def batchnorm_xhat(x, mean, invstd, xhat, rows, F):
     check(_L().avsr_batchnorm_xhat(fptr(x), fptr(mean), fptr(invstd), fptr(xhat), rows, F, _s()), "avsr_batchnorm_xhat")
 
 
-def embed_labels(emb, labels, go_id, out, B, L, E):
-    check(_L().avsr_embed_labels(fptr(emb), fptr(labels), go_id, fptr(out), B, L, E, _s()), "avsr_embed_labels")
+def embed_labels(emb, labels, go_id, out, fed, B, L, E, n_steps=None):
+    check(_L().avsr_embed_labels(fptr(emb), fptr(labels), go_id, fptr(out), fptr(fed), B, L, E, L if n_steps is None else n_steps,
+                                 _s()), "avsr_embed_labels")
 
 
-def embed_grad(dx, labels, go_id, demb, B, L, E, V):
-    check(_L().avsr_embed_grad(fptr(dx), fptr(labels), go_id, fptr(demb), B, L, E, V, _s()), "avsr_embed_grad")
+def embed_grad(dx, fed, demb, B, L, E, V):
+    check(_L().avsr_embed_grad(fptr(dx), fptr(fed), fptr(demb), B, L, E, V, _s()), "avsr_embed_grad")
+
+
+def dropout_rows(x, y, rows, cols, seed, stream_id, keep, idx_width, idx_coff=0, accumulate=False):
+    """y (+)= x * mask / keep; x, y are Mat views; mask index = r*idx_width + idx_coff + c."""
+    check(_L().avsr_dropout_rows(C.byref(x), C.byref(y), rows, cols, fptr(seed), int(stream_id), float(keep), int(idx_width),
+                                 int(idx_coff), int(accumulate), _s()), "avsr_dropout_rows")
 
 
 def seq_loss(logits, labels, labels_len, denom, compute_denom, row_loss, dlogits, B, L, V):

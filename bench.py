@@ -104,7 +104,7 @@ def work_model(cfg, B):
     return dict(attn_bytes=attn_bytes, lstm_fwd_flops=fl_f / max(1, n_f), lstm_bwd_flops=fl_b / max(1, n_b))
 
 
-def cpu_baseline(wl, sample_B=8, steps=3):
+def cpu_baseline(wl, stoch, sample_B=8, steps=3):
     """The CPU oracle (torch-CPU fp32 restatement, all host threads) on a bounded sample: sample_B utterances at
     full T_a/T_v/L.  'TF-1.13.1 CPU number unavailable' -- see BASELINE.md section 2."""
     from oracle import avsr_oracle as O
@@ -112,7 +112,7 @@ def cpu_baseline(wl, sample_B=8, steps=3):
     # synchronisation cost (256 hardware threads on the GPU node made a step take minutes), so cap it
     ncores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(ncores)
-    ocfg = O.OracleConfig(**wl["cfg"])
+    ocfg = O.OracleConfig(**wl["cfg"], **stoch)
     P = O.init_params(ocfg, seed=2001)
     b = O.synthetic_batch(ocfg, B=sample_B, T_a=TA, T_v=TV, L=LDEC)
     O.train_step(P, None, ocfg, b, dtype=torch.float32)          # warm-up
@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: the workload's B)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-dropout", action="store_true", help="disable DropoutWrapper + scheduled sampling (reference defaults are ON)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -156,7 +157,8 @@ def main():
 
     wl = WORKLOADS[args.workload]
     B = args.batch or wl["B"]
-    cfg = ModelConfig(audio_feat=FA, video_feat=FV, **wl["cfg"])
+    stoch = {} if args.no_dropout else dict(use_dropout=True, sampling_probability=0.1)   # avsr/avsr.py:51-56 defaults
+    cfg = ModelConfig(audio_feat=FA, video_feat=FV, **wl["cfg"], **stoch)
     model = Seq2SeqModel(cfg, seed=2001)
     trainer = DataParallelTrainer(model, dist, use_graph=not args.no_graph)
     batch = Batch.from_numpy(NS(synth(cfg, B, rank)))
@@ -189,7 +191,8 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload + ": " + wl["desc"], "utterances_per_gpu": B, "global_batch": B * world,
                    "T_a": TA, "F_a": FA, "T_v": TV, "F_v": FV, "T_dec": LDEC, "parallelism": "dp%d" % world,
-                   "launch": trainer.mode, "dropout": False, "scheduled_sampling": False,
+                   "launch": trainer.mode, "dropout": bool(cfg.use_dropout), "dropout_keep": list(cfg.decoder_dropout) if cfg.use_dropout else None,
+                   "scheduled_sampling": cfg.sampling_probability,
                    "parity": "vs CPU restatement of TF-1.13.1 semantics; TF parity unpinned"},
         "final_loss": round(loss, 5),
     }
@@ -233,7 +236,7 @@ def main():
             out["roofline_attention_step"] = roof("attn_fwd")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(wl)
+            out["cpu_baseline"] = cpu_baseline(wl, stoch)
         except Exception as e:  # the oracle is optional test infrastructure
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:

@@ -110,6 +110,9 @@ typedef struct avsr_rnn_layer {
   const float* dout;
   int64_t ld_dout;
   int32_t dout_col, pad_;
+  /* DropoutWrapper buffers (NULL when dropout is off): both [B][T+2][units], slot s = time s-1 */
+  float* hs_seq;                /* state-dropped h (what the next time step consumed): dWh operand */
+  float* xt_seq;                /* output as seen by the consumer above (output mask x its input mask): dWx operand */
 } avsr_rnn_layer;
 
 typedef struct avsr_rnn_stack {
@@ -118,6 +121,14 @@ typedef struct avsr_rnn_stack {
   const int32_t* len;
   const float* dh_final;          /* [B][H_top] gradient wrt the top layer's final h (may be NULL) */
   const float* dc_final;
+  /* tf.contrib.rnn.DropoutWrapper(input/state/output keep prob, variational_recurrent=False) (avsr/cells.py:46-54).
+   * Masks are stateless: bit = hash(*seed, stream, index) (csrc/common.h hash_u32), stream = cell_id*4 + {0 in,1 state,2 out},
+   * cell_id = cell_id_base + layer, index = (b*T + t)*width + column.  seed == NULL disables dropout.  With dropout on,
+   * `state` scratch must hold 6*B*H floats per layer.  consumer_*: input mask of whatever reads the TOP layer's output
+   * through xt_seq (AV-Align attentive layer); consumer_width 0 = none. */
+  const int32_t* seed;
+  float keep_in, keep_state, keep_out, consumer_keep;
+  int32_t cell_id_base, consumer_stream, consumer_width, pad2_;
   avsr_rnn_layer layer[AVSR_MAX_LAYERS];
 } avsr_rnn_stack;
 
@@ -215,6 +226,19 @@ typedef struct avsr_attn_rnn {
   float* dc0;
   const float* dh_final;        /* [B][H] gradient wrt the final cell state (AV-Align: from the decoder init) */
   const float* dc_final;
+  /* DropoutWrapper on the wrapped cell (train only; seed NULL = off), stream = cell_id*4 + kind, input width E + A */
+  const int32_t* seed;
+  float keep_in, keep_state, keep_out, sampling_prob;
+  int32_t cell_id, pad3_;
+  float* hs_seq;                /* [B][L+1][H] state-dropped h, slot 0 = h0 (dropout only) */
+  float* attd;                  /* [B][L+1][A] input-dropped attention fed to the next step, slot 0 = 0 (dropout only) */
+  /* mode 2 = train with scheduled sampling (ScheduledEmbeddingTrainingHelper, avsr/decoder_unimodal.py:304-309):
+   * x_l = xs[b][l][:] (caller fills slot 0 = dropout(emb[GO])); after step l the op computes logits[b][l][:], draws
+   * select ~ Bernoulli(sampling_prob) and a categorical sample with the stateless RNG (streams 1000 / 1001, index b*L+l)
+   * and writes fed[b][l+1] = select ? sample : labels[b][l], xs[b][l+1][:] = dropout(emb[fed[b][l+1]]). */
+  float* xs;                    /* [B][L][E] */
+  const int32_t* labels;        /* [B][L] */
+  int32_t* fed;                 /* [B][L] tokens actually fed (fed[b][0] = GO set by the caller) */
 } avsr_attn_rnn;
 
 int avsr_attn_rnn_fwd(const avsr_attn_rnn* d, int32_t l_begin, int32_t l_end, void* stream);
@@ -249,11 +273,19 @@ int avsr_batchnorm_fwd(const float* x, float* y, int32_t rows, int32_t F, const 
 int avsr_batchnorm_xhat(const float* x, const float* mean, const float* invstd, float* xhat, int32_t rows, int32_t F,
                         void* stream);
 
-/* embedding_lookup(labels_padded_GO) (avsr/decoder_unimodal.py:66-68, :170) and its gradient. */
-int avsr_embed_labels(const float* emb, const int32_t* labels, int32_t go_id, float* out, int32_t B, int32_t L,
-                      int32_t E, void* stream);
-int avsr_embed_grad(const float* dx, const int32_t* labels, int32_t go_id, float* demb, int32_t B, int32_t L, int32_t E,
-                    int32_t V, void* stream);
+/* embedding_lookup(labels_padded_GO) (avsr/decoder_unimodal.py:66-68, :170): fed[b][l] = l ? labels[b][l-1] : GO,
+ * out[b][l][:] = emb[fed[b][l]] for l < n_steps (n_steps = L: all; 1: only the GO column).  Gradient: demb[v][:] = sum of
+ * dx rows whose fed token is v. */
+int avsr_embed_labels(const float* emb, const int32_t* labels, int32_t go_id, float* out, int32_t* fed, int32_t B,
+                      int32_t L, int32_t E, int32_t n_steps, void* stream);
+int avsr_embed_grad(const float* dx, const int32_t* fed, float* demb, int32_t B, int32_t L, int32_t E, int32_t V,
+                    void* stream);
+
+/* y[r][c] = (accumulate ? y[r][c] : 0) + x[r][c] * mask(r, c) / keep for r < rows, c < cols;
+ * mask index = r * idx_width + idx_coff + c (r = b*T + t), stream as in avsr_rnn_stack.  Used for input dropout of
+ * hoisted operands and for the matching gradients.  seed NULL or keep >= 1 copies. */
+int avsr_dropout_rows(const avsr_mat* x, const avsr_mat* y, int32_t rows, int32_t cols, const int32_t* seed,
+                      int32_t stream_id, float keep, int32_t idx_width, int32_t idx_coff, int32_t accumulate, void* stream);
 
 /* seq2seq.sequence_loss (avsr/seq2seq.py:165-171): row_loss[b*L+l] = CE * mask / (sum(mask) + 1e-12) and
  * d loss / d logits.  denom[0] = sum(mask) is computed when compute_denom=1 (single GPU) or supplied

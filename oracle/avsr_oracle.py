@@ -331,27 +331,69 @@ def gru_cell(x: Tensor, h: Tensor, Wg: Tensor, bg: Tensor, Wc: Tensor, bc: Tenso
     return u * h + (1.0 - u) * cand
 
 
+# stream ids of the stateless RNG (shared with the HIP engine): cell id * 4 + kind
+DROP_IN, DROP_STATE, DROP_OUT = 0, 1, 2
+CELL_ID_DECODER = 40
+STREAM_SS_SELECT, STREAM_SS_SAMPLE = 1000, 1001
+
+
+def encoder_cell_id(stream: str, direction: str, layer: int) -> int:
+    return 1 + ((0 if stream == "video" else 1) * 2 + (0 if direction == "fw" else 1)) * 8 + layer
+
+
 class _Cell:
-    """One RNN layer's weights + step function; state is (c, h) for LSTM, (h,) for GRU."""
+    """One RNN layer's weights + step function; state is (c, h) for LSTM, (h,) for GRU.
+    With `drop` set it behaves like tf.contrib.rnn.DropoutWrapper(cell, input/state/output keep prob,
+    variational_recurrent=False) (cells.py:46-54): fresh masks every step, h-state dropped, c-state not."""
 
     def __init__(self, P: Dict[str, Tensor], prefix: str, cell_type: str, units: int):
         self.t, self.units = cell_type, units
+        self.drop = None
         if cell_type == "lstm":
             self.W, self.b = P[prefix + "/kernel"], P[prefix + "/bias"]
         else:
             self.Wg, self.bg = P[prefix + "/gates_kernel"], P[prefix + "/gates_bias"]
             self.Wc, self.bc = P[prefix + "/cand_kernel"], P[prefix + "/cand_bias"]
 
+    def set_dropout(self, keep, cid, T, seed, lens=None, reverse=False):
+        self.drop = dict(keep=tuple(float(k) for k in keep), cid=cid, T=T, seed=seed, lens=lens, reverse=reverse)
+
     def zero_state(self, B, dtype):
         z = torch.zeros(B, self.units, dtype=dtype)
         return (z, z) if self.t == "lstm" else (z,)
 
-    def __call__(self, x, state):
+    def _mask(self, kind, width, t, B, dtype):
+        d = self.drop
+        keep = d["keep"][kind]
+        if keep >= 1.0:
+            return None
+        if d["reverse"]:
+            tau = torch.clamp(d["lens"] - 1 - t, min=0)
+        else:
+            tau = torch.full((B,), t, dtype=torch.int64)
+        idx = ((torch.arange(B) * d["T"] + tau)[:, None] * width + torch.arange(width)[None, :]).numpy().astype(np.uint32)
+        u = uniform01(d["seed"], d["cid"] * 4 + kind, idx)
+        return torch.tensor((u < np.float32(keep)).astype(np.float64) / keep, dtype=dtype)
+
+    def __call__(self, x, state, t=0):
+        if self.drop is not None:
+            m = self._mask(DROP_IN, x.shape[1], t, x.shape[0], x.dtype)
+            if m is not None:
+                x = x * m
         if self.t == "lstm":
             c, h = lstm_cell(x, state[0], state[1], self.W, self.b)
-            return h, (c, h)
-        h = gru_cell(x, state[0], self.Wg, self.bg, self.Wc, self.bc)
-        return h, (h,)
+            out, ns = h, (c, h)
+        else:
+            h = gru_cell(x, state[0], self.Wg, self.bg, self.Wc, self.bc)
+            out, ns = h, (h,)
+        if self.drop is not None:
+            ms = self._mask(DROP_STATE, self.units, t, x.shape[0], x.dtype)
+            mo = self._mask(DROP_OUT, self.units, t, x.shape[0], x.dtype)
+            if ms is not None:
+                ns = ns[:-1] + (ns[-1] * ms,)
+            if mo is not None:
+                out = out * mo
+        return out, ns
 
 
 def _select(mask: Tensor, new, old):
@@ -396,9 +438,9 @@ class _Mechanism:
 
 
 def attention_wrapper_step(cell: _Cell, mechs: List[_Mechanism], output_attention: bool,
-                           x: Tensor, cell_state, attention: Tensor):
+                           x: Tensor, cell_state, attention: Tensor, t: int = 0):
     """contrib.seq2seq.AttentionWrapper.call (attention.py:173-181; decoder_bimodal.py:241-248)."""
-    cell_out, new_state = cell(torch.cat([x, attention], dim=-1), cell_state)
+    cell_out, new_state = cell(torch.cat([x, attention], dim=-1), cell_state, t)
     atts, aligns = [], []
     for m in mechs:
         al, ctx = m(cell_out)
@@ -439,12 +481,12 @@ def _reverse_sequence(x: Tensor, lens: Tensor) -> Tensor:
 
 def dynamic_rnn(step_fn, zero_state, x: Tensor, lens: Tensor):
     """tf.nn.dynamic_rnn with sequence_length: zero output / state copy-through past len.
-    step_fn(x_t, state) -> (out_t, state)."""
+    step_fn(x_t, state, t) -> (out_t, state)."""
     B, T = x.shape[0], x.shape[1]
     state = zero_state
     outs = []
     for t in range(T):
-        o, ns = step_fn(x[:, t], state)
+        o, ns = step_fn(x[:, t], state, t)
         valid = (t < lens)[:, None]
         outs.append(torch.where(valid, o, torch.zeros_like(o)))
         state = _map_state(lambda n, s: torch.where(valid, n, s), ns, state)
@@ -459,10 +501,10 @@ def _map_state(fn, new, old):
 
 
 def _stack_step(cells: List[_Cell]):
-    def step(x, states):
+    def step(x, states, t=0):
         new_states = []
         for c, s in zip(cells, states):
-            x, ns = c(x, s)
+            x, ns = c(x, s, t)
             new_states.append(ns)
         return x, tuple(new_states)
     return step
@@ -475,26 +517,36 @@ class EncoderOut:
     alignments: Optional[Tensor] = None
 
 
+def _make_cells(P, cfg: OracleConfig, stream: str, direction: str, units, training: bool, seed: int, T: int, lens: Tensor):
+    cells = [_Cell(P, f"{stream}/enc/{direction}/l{l}", cfg.cell_type, u) for l, u in enumerate(units)]
+    if cfg.use_dropout and training:                                  # cells.py:46: only in the train graph
+        keep = cfg.video_dropout if stream == "video" else cfg.audio_dropout
+        for l, c in enumerate(cells):
+            c.set_dropout(keep, encoder_cell_id(stream, direction, l), T, seed, lens, direction == "bw")
+    return cells
+
+
 def encode_stream(P, cfg: OracleConfig, stream: str, x: Tensor, lens: Tensor, training: bool,
-                  bn_updates: Optional[dict], attended: Optional[Tuple[Tensor, Tensor]] = None) -> EncoderOut:
+                  bn_updates: Optional[dict], attended: Optional[Tuple[Tensor, Tensor]] = None, seed: int = 0) -> EncoderOut:
     """Seq2SeqEncoder / AttentiveEncoder (encoder.py:14-196, :199-335)."""
     units = cfg.video_units if stream == "video" else cfg.audio_units
     B, dtype = x.shape[0], x.dtype
+    T = x.shape[1]
     if cfg.batch_normalisation:
         x = batch_norm(x, P, f"{stream}/bn", training, bn_updates)
     if attended is not None:                                   # av_align: top layer attention-wrapped
-        cells = [_Cell(P, f"{stream}/enc/fw/l{l}", cfg.cell_type, u) for l, u in enumerate(units)]
+        cells = _make_cells(P, cfg, stream, "fw", units, training, seed, T, lens)
         mech = _Mechanism(P, "audio/enc/att0", cfg.attention_type[0][0], attended[0], attended[1])
         out_att = cfg.attention_type[0][0] in LUONG_TYPES
         aligns = []
 
-        def step(x_t, state):
+        def step(x_t, state, t=0):
             lower, (top_state, att) = state
             new_lower = []
             for c, s in zip(cells[:-1], lower):
-                x_t, ns = c(x_t, s)
+                x_t, ns = c(x_t, s, t)
                 new_lower.append(ns)
-            out, ns, new_att, al = attention_wrapper_step(cells[-1], [mech], out_att, x_t, top_state, att)
+            out, ns, new_att, al = attention_wrapper_step(cells[-1], [mech], out_att, x_t, top_state, att, t)
             aligns.append(al[0])
             return out, (tuple(new_lower), (ns, new_att))
 
@@ -503,12 +555,12 @@ def encode_stream(P, cfg: OracleConfig, stream: str, x: Tensor, lens: Tensor, tr
         outs, st = dynamic_rnn(step, zero, x, lens)
         return EncoderOut(outs, st[1][0], torch.stack(aligns, dim=1))
     if cfg.encoder_type == "unidirectional":
-        cells = [_Cell(P, f"{stream}/enc/fw/l{l}", cfg.cell_type, u) for l, u in enumerate(units)]
+        cells = _make_cells(P, cfg, stream, "fw", units, training, seed, T, lens)
         outs, st = dynamic_rnn(_stack_step(cells), tuple(c.zero_state(B, dtype) for c in cells), x, lens)
         return EncoderOut(outs, st[-1])
     # bidirectional: two independent stacks, concat at the top only (encoder.py:92-121)
-    fw = [_Cell(P, f"{stream}/enc/fw/l{l}", cfg.cell_type, u) for l, u in enumerate(units)]
-    bw = [_Cell(P, f"{stream}/enc/bw/l{l}", cfg.cell_type, u) for l, u in enumerate(units)]
+    fw = _make_cells(P, cfg, stream, "fw", units, training, seed, T, lens)
+    bw = _make_cells(P, cfg, stream, "bw", units, training, seed, T, lens)
     o_fw, s_fw = dynamic_rnn(_stack_step(fw), tuple(c.zero_state(B, dtype) for c in fw), x, lens)
     o_bw, s_bw = dynamic_rnn(_stack_step(bw), tuple(c.zero_state(B, dtype) for c in bw),
                              _reverse_sequence(x, lens), lens)
@@ -538,8 +590,8 @@ def au_loss(P, enc: EncoderOut, aus: Tensor, lens: Tensor) -> Tensor:
 # the model: encoders + decoder (seq2seq.py:30-126)
 # ----------------------------------------------------------------------------------------
 class _Model:
-    def __init__(self, P: Dict[str, Tensor], cfg: OracleConfig, batch: Batch, training: bool, dtype):
-        self.P, self.cfg, self.training = P, cfg, training
+    def __init__(self, P: Dict[str, Tensor], cfg: OracleConfig, batch: Batch, training: bool, dtype, seed: int = 0):
+        self.P, self.cfg, self.training, self.seed = P, cfg, training, seed
         self.bn_updates: dict = {}
         tt = lambda a: None if a is None else torch.as_tensor(np.asarray(a), dtype=dtype)
         ti = lambda a: None if a is None else torch.as_tensor(np.asarray(a), dtype=torch.int64)
@@ -549,7 +601,7 @@ class _Model:
         if cfg.video_units is not None:
             self.lens["video"] = ti(batch.video_len)
             self.enc["video"] = encode_stream(P, cfg, "video", tt(batch.video), self.lens["video"],
-                                              training, self.bn_updates)
+                                              training, self.bn_updates, seed=seed)
             if cfg.regress_aus and training:
                 self.aux_loss = au_loss(P, self.enc["video"], tt(batch.aus), self.lens["video"])
         if cfg.audio_units is not None:
@@ -558,7 +610,7 @@ class _Model:
             if cfg.architecture == "av_align":
                 attended = (self.enc["video"].outputs, self.lens["video"])
             self.enc["audio"] = encode_stream(P, cfg, "audio", tt(batch.audio), self.lens["audio"],
-                                              training, self.bn_updates, attended)
+                                              training, self.bn_updates, attended, seed=seed)
         self.B = (batch.audio if batch.audio is not None else batch.video).shape[0]
         self.dtype = dtype
         self._init_decoder()
@@ -585,30 +637,59 @@ class _Model:
             self.init_state = self.enc[s].final_state             # decoder_unimodal.py:144-145
         self.att_dim = cfg.decoder_units[0] * len(self.mechs)
 
-    def step(self, x, state, att):
+    def step(self, x, state, att, t=0):
         if self.mechs:
-            return attention_wrapper_step(self.cell, self.mechs, self.out_att, x, state, att)
-        out, ns = self.cell(x, state)
+            return attention_wrapper_step(self.cell, self.mechs, self.out_att, x, state, att, t)
+        out, ns = self.cell(x, state, t)
         return out, ns, att, []
 
     def logits(self, out):
         return out @ self.P["dec/out/kernel"] + self.P["dec/out/bias"]
 
 
-def forward_train(P: Dict[str, Tensor], cfg: OracleConfig, batch: Batch, dtype=torch.float64):
-    """Train-graph forward (teacher forcing, sampling off): returns logits [B,L,V], loss pieces, model."""
-    m = _Model(P, cfg, batch, True, dtype)
+def categorical_f32(logits_row: np.ndarray, u: np.float32) -> int:
+    """Inverse-CDF draw exactly as the sampling kernel does it (fp32, sequential order)."""
+    lg = logits_row.astype(np.float32)
+    mx = lg.max()
+    p = np.exp(lg - mx, dtype=np.float32)
+    tot = np.float32(0.0)
+    for v in p:
+        tot = np.float32(tot + v)
+    target = np.float32(u * tot)
+    run = np.float32(0.0)
+    for i, v in enumerate(p):
+        run = np.float32(run + v)
+        if run > target:
+            return i
+    return len(p) - 1
+
+
+def forward_train(P: Dict[str, Tensor], cfg: OracleConfig, batch: Batch, dtype=torch.float64, seed: int = 0):
+    """Train-graph forward: teacher forcing with optional scheduled sampling (ScheduledEmbeddingTrainingHelper,
+    decoder_unimodal.py:304-309) and DropoutWrapper'd cells; `seed` = global step keys the stateless RNG.
+    Returns logits [B,L,V] and the model."""
+    m = _Model(P, cfg, batch, True, dtype, seed)
     labels = torch.as_tensor(batch.labels, dtype=torch.int64)
     ll = torch.as_tensor(batch.labels_len, dtype=torch.int64)
     B, L = labels.shape
+    if cfg.use_dropout:
+        m.cell.set_dropout(cfg.decoder_dropout, CELL_ID_DECODER, L, seed)
     go = torch.full((B, 1), cfg.go_id, dtype=torch.int64)
-    inputs = P["dec/embedding"][torch.cat([go, labels], dim=1)]            # decoder_unimodal.py:66-68,:170
+    fed = torch.cat([go, labels], dim=1)[:, :L].numpy().copy()           # decoder_unimodal.py:66-68: tokens fed at step t
     state, att = m.init_state, torch.zeros(B, m.att_dim, dtype=dtype)
     steps = int(ll.max())
     logits = []
     for t in range(steps):
-        out, ns, natt, _ = m.step(inputs[:, t], state, att)
+        out, ns, natt, _ = m.step(P["dec/embedding"][torch.as_tensor(fed[:, t].copy())], state, att, t)
         lg = m.logits(out)
+        if cfg.sampling_probability > 0 and t + 1 < L:
+            idx = (np.arange(B) * L + t).astype(np.uint32)
+            sel = uniform01(seed, STREAM_SS_SELECT, idx) < np.float32(cfg.sampling_probability)
+            us = uniform01(seed, STREAM_SS_SAMPLE, idx)
+            lgn = lg.detach().numpy()
+            for b in range(B):
+                if sel[b]:
+                    fed[b, t + 1] = categorical_f32(lgn[b], us[b])      # a draw, not argmax; no gradient through it
         fin = (t >= ll)[:, None]            # TrainingHelper: finished once t >= sequence_length
         logits.append(torch.where(fin, torch.zeros_like(lg), lg))          # impute_finished
         state = _map_state(lambda n, s: torch.where(fin, s, n), ns, state)
@@ -616,6 +697,7 @@ def forward_train(P: Dict[str, Tensor], cfg: OracleConfig, batch: Batch, dtype=t
     logits = torch.stack(logits, dim=1)
     if steps < L:
         logits = torch.cat([logits, torch.zeros(B, L - steps, logits.shape[-1], dtype=dtype)], dim=1)
+    m.fed_tokens = fed
     return logits, m
 
 
@@ -659,7 +741,7 @@ def train_step(P_np: Dict[str, np.ndarray], opt: Optional[dict], cfg: OracleConf
     """One full train step: fwd, BPTT, global-norm clip, Adam, BN moving stats.
     Returns dict(loss, seq_loss, global_norm, grads, params, opt, logits)."""
     P = to_torch(P_np, dtype, requires_grad=True)
-    logits, m = forward_train(P, cfg, batch, dtype)
+    logits, m = forward_train(P, cfg, batch, dtype, seed=(opt["step"] if opt else 0))
     loss, seq = loss_fn(P, cfg, batch, logits, m)
     names = trainable_names(P)
     grads = torch.autograd.grad(loss, [P[k] for k in names], allow_unused=True)
@@ -688,7 +770,7 @@ def train_step(P_np: Dict[str, np.ndarray], opt: Optional[dict], cfg: OracleConf
         newP[k] = v.detach().numpy().astype(P_np[k].dtype)
     return {"loss": float(loss.detach()), "seq_loss": float(seq.detach()), "global_norm": float(gnorm.detach()),
             "grads": {k: g.detach().numpy() for k, g in grads.items()}, "params": newP, "opt": new_opt,
-            "logits": logits.detach().numpy()}
+            "logits": logits.detach().numpy(), "fed_tokens": m.fed_tokens}
 
 
 @torch.no_grad()

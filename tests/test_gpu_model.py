@@ -120,3 +120,50 @@ def test_second_step_and_eos_path():
     m2 = Seq2SeqModel(mcfg, weights=W2)
     ids = m2.greedy_decode(db, max_steps=10).cpu().numpy()
     assert ids.shape == ids_ref.shape and (ids == ids_ref).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# train-time stochastic wrappers: DropoutWrapper (cells.py:46-54) and scheduled sampling (decoder_*.py).  The masks and
+# draws come from the stateless hash RNG shared bit-for-bit by the oracle and the kernels, so parity stays exact.
+STOCH = [
+    ("c1_audio_uni_luong", dict(use_dropout=True)),
+    ("audio_uni3_luong", dict(use_dropout=True, sampling_probability=0.3)),
+    ("c2_audio_bi_bahdanau", dict(use_dropout=True, sampling_probability=0.3)),
+    ("c4_bimodal_uni", dict(use_dropout=True, sampling_probability=0.25)),
+    ("bimodal_bi_mixed", dict(use_dropout=True, audio_dropout=(0.8, 0.9, 0.7), video_dropout=(1.0, 0.9, 0.9), decoder_dropout=(0.9, 0.8, 1.0))),
+    ("c5_av_align", dict(use_dropout=True, sampling_probability=0.3)),
+    ("av_align_1layer_bahdanau", dict(use_dropout=True)),
+    ("c4_bimodal_uni", dict(sampling_probability=0.5)),
+]
+
+
+@pytest.mark.parametrize("case,over", STOCH)
+def test_train_step_parity_with_dropout_and_sampling(case, over):
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    O, ocfg, mcfg, W, batch = make(case, **over)
+    r1 = O.train_step(W, None, ocfg, batch)
+    r2 = O.train_step(r1["params"], r1["opt"], ocfg, batch)          # second step: new seed -> new masks
+    model = Seq2SeqModel(mcfg, weights=W)
+    db = Batch.from_numpy(batch)
+    logits = model.forward_train(db)
+    torch.cuda.synchronize()
+    ws = model._cur[0]
+    # tokens fed to VALID steps must agree exactly (draws for already-finished rows feed frozen steps: don't-care)
+    consumed = np.arange(batch.labels.shape[1])[None, :] < batch.labels_len[:, None]
+    assert (ws["dec"]["fed"].cpu().numpy()[consumed] == r1["fed_tokens"][consumed]).all()
+    assert np.abs(logits.cpu().numpy() - r1["logits"]).max() < 1e-4
+    model.backward()
+    model.apply_update()
+    torch.cuda.synchronize()
+    assert abs(float(model.loss.item()) - r1["loss"]) < 1e-4
+    assert abs(float(model.gnorm.item()) - r1["global_norm"]) < 1e-4 * max(1.0, r1["global_norm"])
+    grads = model.export_tf_weights("grads")
+    for k, g in r1["grads"].items():
+        scale = max(1e-3, np.abs(g).max())
+        assert np.abs(grads[k] - g).max() < 2e-4 * scale + 1e-6, k
+    loss2, _ = model.train_step(db)
+    torch.cuda.synchronize()
+    assert abs(float(loss2.item()) - r2["loss"]) < 2e-4
+    # eval graph: no dropout
+    ids_ref = O.greedy_decode(r2["params"], ocfg, batch, max_steps=8)
+    assert (model.greedy_decode(db, max_steps=8).cpu().numpy() == ids_ref).all()
