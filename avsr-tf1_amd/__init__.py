@@ -4,3 +4,14 @@ Python host code mirroring the reference's surface (avsr/__init__.py:1-3), hand-
 behind the C ABI in include/avsr_hip.h.  See DESIGN.md / INTEGRATION.md.
 """
 __version__ = "0.1.0"
+
+
+def __getattr__(name):
+    """Lazy exports of the reference's public surface (avsr/__init__.py:1-3): AVSR, run_experiment."""
+    if name == "AVSR":
+        from .avsr import AVSR
+        return AVSR
+    if name == "run_experiment":
+        from .experiment import run_experiment
+        return run_experiment
+    raise AttributeError(name)

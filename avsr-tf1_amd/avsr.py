@@ -1,0 +1,255 @@
+"""`AVSR` -- the reference's top-level class (avsr/avsr.py:20-753) on the MI355X engine.
+
+Same constructor keywords and defaults (avsr/avsr.py:21-75), same `train(logfile, num_epochs,
+try_restore_latest_checkpoint)` / `evaluate(checkpoint_path, epoch)` behaviour and side-effect files:
+`logs/<logfile>` (average loss per epoch, error rates every 10th epoch), `checkpoints/<name>/checkpoint.ckp-<epoch>`
+(own .npz format: TF-layout weights + Adam slots + step; epoch parsed from the file name on resume, :233-249),
+`predictions/<name>/predicted_epoch_<N>.mlf`.  TensorFlow graphs/sessions/summaries do not exist here.
+
+Not built yet (raise / warn explicitly): lip-CNN front-ends (`video_processing='resnet_cnn'|...`), `'wav'` audio
+(non-functional in the reference too), beam search (greedy is used with a warning), GRU cells.
+"""
+import glob
+import os
+import time
+import warnings
+from os import makedirs, path
+
+import numpy as np
+import torch
+
+from .config import ModelConfig
+from .io_utils import (_get_input_shape_from_record, create_unit_dict, make_iterator_from_one_record,
+                       make_iterator_from_two_records)
+from .model import Batch, Seq2SeqModel
+from .parallel import DataParallelTrainer
+from .utils import compute_wer, write_sequences_to_labelfile
+
+
+class AVSR(object):
+    def __init__(self,
+                 unit,
+                 unit_file=None,
+                 video_processing=None,
+                 video_train_record=None,
+                 video_test_record=None,
+                 audio_processing=None,
+                 audio_train_record=None,
+                 audio_test_record=None,
+                 labels_train_record=None,
+                 labels_test_record=None,
+                 batch_size=(64, 64),
+                 cnn_filters=(8, 16, 32, 64),
+                 cnn_dense_units=128,
+                 regress_aus=False,
+                 batch_normalisation=True,
+                 instance_normalisation=False,
+                 input_dense_layers=(0,),
+                 architecture='unimodal',
+                 encoder_type='unidirectional',
+                 highway_encoder=False,
+                 residual_encoder=False,
+                 cell_type='lstm',
+                 recurrent_l2_regularisation=0.0001,
+                 weight_decay=0.0001,
+                 encoder_units_per_layer=((256, ), (256, 256, 256)),
+                 decoder_units_per_layer=(256,),
+                 encoder_weight_sharing=False,
+                 enable_attention=True,
+                 attention_type=(('scaled_luong',)*1, ('scaled_luong',)*1),
+                 use_dropout=True,
+                 audio_encoder_dropout_probability=(0.9, 0.9, 0.9),
+                 video_encoder_dropout_probability=(0.9, 0.9, 0.9),
+                 decoder_dropout_probability=(0.9, 0.9, 0.9),
+                 embedding_size=128,
+                 sampling_probability_outputs=0.1,
+                 label_smoothing=0.0,
+                 decoding_algorithm='beam_search',
+                 beam_width=10,
+                 max_sentence_length=None,
+                 optimiser='Adam',
+                 learning_rate=0.001,
+                 lr_decay=None,
+                 loss_fun=None,
+                 clip_gradients=True,
+                 max_gradient_norm=1.0,
+                 num_gpus=1,
+                 write_attention_alignment=False,
+                 write_beam_search_graphs=False,
+                 write_estimated_modality_lags=False,
+                 precision='float32',
+                 profiling=False,
+                 required_grahps=('train', 'eval'),
+                 **kwargs):
+        self._unit = unit
+        self._unit_dict = create_unit_dict(unit_file=unit_file)
+        self._video_processing, self._audio_processing = video_processing, audio_processing
+        self._records = {
+            'train': (video_train_record, audio_train_record, labels_train_record),
+            'evaluate': (video_test_record, audio_test_record, labels_test_record)}
+        self._batch_size = batch_size
+        self._max_sentence_length = max_sentence_length
+        self._required_graphs = required_grahps
+
+        for name, val, ok in (("instance_normalisation", instance_normalisation, False), ("highway_encoder", highway_encoder, False),
+                              ("residual_encoder", residual_encoder, False), ("encoder_weight_sharing", encoder_weight_sharing, False),
+                              ("loss_fun", loss_fun, None), ("lr_decay", lr_decay, None), ("precision", precision, 'float32'),
+                              ("optimiser", optimiser, 'Adam')):
+            if val != ok:
+                raise NotImplementedError("%s=%r is a non-default option of the reference that the HIP engine does not build" % (name, val))
+        if tuple(input_dense_layers) != (0,) or label_smoothing != 0.0:
+            raise NotImplementedError("input_dense_layers / label_smoothing are not built")
+        if video_processing is not None and video_processing != 'features':
+            raise NotImplementedError("video_processing=%r: the lip-CNN front-end is not built yet; feed 128-d features" % video_processing)
+        if audio_processing is not None and audio_processing != 'features':
+            raise NotImplementedError("audio_processing=%r (the reference's 'wav' path is non-functional as well)" % audio_processing)
+        if decoding_algorithm == 'beam_search':
+            warnings.warn("beam search is not built yet: evaluating with greedy decoding")
+        elif decoding_algorithm != 'greedy':
+            raise Exception('The only supported algorithms are `greedy` and `beam_search`')     # decoder_unimodal.py:124
+
+        reverse = {v: k for k, v in self._unit_dict.items()}
+        feats = {}
+        for idx, (proc, key) in enumerate(((video_processing, 'video'), (audio_processing, 'audio'))):
+            rec = self._records['train'][idx] or self._records['evaluate'][idx]
+            if proc is not None:
+                shape, _ = _get_input_shape_from_record(rec)
+                if len(shape) != 1:
+                    raise NotImplementedError("raw video records need the lip-CNN front-end")
+                feats[key] = shape[0]
+        self._cfg = ModelConfig(
+            architecture=architecture, encoder_type=encoder_type, cell_type=cell_type,
+            video_units=tuple(encoder_units_per_layer[0]) if video_processing is not None else None,
+            audio_units=tuple(encoder_units_per_layer[1]) if audio_processing is not None else None,
+            decoder_units=tuple(decoder_units_per_layer), attention_type=tuple(tuple(t) for t in attention_type),
+            enable_attention=enable_attention, embedding_size=embedding_size,
+            vocab_size=len(self._unit_dict) - 1, go_id=reverse['GO'], eos_id=reverse['EOS'],
+            video_feat=feats.get('video', 128), audio_feat=feats.get('audio', 80),
+            batch_normalisation=batch_normalisation, regress_aus=regress_aus,
+            au_loss_weight=kwargs.get('au_loss_weight', 10.0),
+            recurrent_l2=recurrent_l2_regularisation, clip_gradients=clip_gradients, max_gradient_norm=max_gradient_norm,
+            learning_rate=learning_rate, warmup_steps=kwargs.get('warmup_steps', 750),
+            max_label_length={'viseme': 150, 'phoneme': 150, 'character': 150}[unit],
+            use_dropout=use_dropout, video_dropout=tuple(video_encoder_dropout_probability),
+            audio_dropout=tuple(audio_encoder_dropout_probability), decoder_dropout=tuple(decoder_dropout_probability),
+            sampling_probability=sampling_probability_outputs)
+        self._model = Seq2SeqModel(self._cfg, seed=kwargs.get('seed', 0))
+        self._trainer = DataParallelTrainer(self._model, None, use_graph=False)   # bucketed batches: shapes vary per step
+
+    # ------------------------------------------------------------------------------------------------
+    def _iterator(self, mode):
+        vrec, arec, lrec = self._records[mode]
+        bs = self._batch_size[0 if mode == 'train' else 1]
+        shuffle = mode == 'train'
+        if self._video_processing is not None and self._audio_processing is not None:
+            return make_iterator_from_two_records(vrec, arec, lrec, bs, self._unit_dict, shuffle=shuffle, bucket_width=45)
+        rec = vrec if self._video_processing is not None else arec
+        return make_iterator_from_one_record(rec, lrec, self._unit_dict, bs, shuffle=shuffle, bucket_width=45,
+                                             max_sentence_length=self._max_sentence_length if self._audio_processing is not None else None)
+
+    def _to_batch(self, bd):
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda()
+        b = Batch(labels=t(bd.labels, torch.int32), labels_len=t(bd.labels_length, torch.int32))
+        if isinstance(bd.inputs, tuple):
+            b.video, b.audio = t(bd.inputs[0], torch.float32), t(bd.inputs[1], torch.float32)
+            b.video_len, b.audio_len = t(bd.inputs_length[0], torch.int32), t(bd.inputs_length[1], torch.int32)
+            names = bd.inputs_filenames[0]
+        elif self._video_processing is not None:
+            b.video, b.video_len, names = t(bd.inputs, torch.float32), t(bd.inputs_length, torch.int32), bd.inputs_filenames
+        else:
+            b.audio, b.audio_len, names = t(bd.inputs, torch.float32), t(bd.inputs_length, torch.int32), bd.inputs_filenames
+        if 'aus' in bd.payload:
+            b.aus = t(bd.payload['aus'], torch.float32)
+        elif self._cfg.regress_aus and b.video is not None:
+            raise ValueError("regress_aus=True needs Action Units in the video record")
+        return b, names
+
+    # ------------------------------------------------------------------------------------------------
+    def save(self, checkpoint_path):
+        m = self._model
+        blob = {"step": np.array(int(m.step.item()), np.int64)}
+        for which in ("params", "adam_m", "adam_v"):
+            for k, v in m.export_tf_weights(which).items():
+                blob[which + ":" + k] = v
+        makedirs(path.dirname(checkpoint_path), exist_ok=True)
+        np.savez(checkpoint_path + ".npz", **blob)
+        return checkpoint_path
+
+    def restore(self, checkpoint_path):
+        z = np.load(checkpoint_path if checkpoint_path.endswith(".npz") else checkpoint_path + ".npz")
+        m = self._model
+        m.load_tf_weights({k[7:]: z[k] for k in z.files if k.startswith("params:")})
+        for which, buf in (("adam_m", m.adam_m), ("adam_v", m.adam_v)):
+            W = {k[len(which) + 1:]: z[k] for k in z.files if k.startswith(which + ":")}
+            if W:
+                m.load_flat(buf, W)
+        m.step.fill_(int(z["step"]))
+
+    @staticmethod
+    def latest_checkpoint(checkpoint_dir):
+        files = glob.glob(path.join(checkpoint_dir, "checkpoint.ckp-*.npz"))
+        if not files:
+            return None
+        best = max(files, key=lambda f: int(f[:-4].split('-')[-1]))
+        return best[:-4]
+
+    # ------------------------------------------------------------------------------------------------
+    def train(self, logfile, num_epochs=400, try_restore_latest_checkpoint=False):
+        checkpoint_dir = path.join('checkpoints', path.split(logfile)[-1])
+        checkpoint_path = path.join(checkpoint_dir, 'checkpoint.ckp')
+        makedirs(checkpoint_dir, exist_ok=True)
+        if path.dirname(logfile):
+            makedirs(path.dirname(logfile), exist_ok=True)
+        last_epoch = 0
+        if try_restore_latest_checkpoint is True:
+            try:
+                latest_ckp = self.latest_checkpoint(checkpoint_dir)
+                last_epoch = int(latest_ckp.split('-')[-1])
+                self.restore(latest_ckp)
+                print('Restoring checkpoint from epoch {}\n'.format(last_epoch))
+            except Exception:
+                print('Could not restore from checkpoint, training from scratch!\n')
+        f = open(logfile, 'a')
+        for current_epoch in range(1, num_epochs):            # num_epochs - 1 epochs actually run (avsr.py:253)
+            epoch = last_epoch + current_epoch
+            sum_loss, batches = 0.0, 0
+            start = time.time()
+            for bd in self._iterator('train'):                # end of data = StopIteration (reference: OutOfRangeError)
+                batch, _names = self._to_batch(bd)
+                loss, gnorm = self._trainer.train_step(batch)
+                batch_loss, global_norm = float(loss.item()), float(gnorm.item())
+                sum_loss += batch_loss
+                print('batch: {}, batch loss: {:.2f}, gradient norm: {:.2f}'.format(batches, batch_loss, global_norm))
+                batches += 1
+            print('epoch time: {}'.format(time.time() - start))
+            f.write('Average batch_loss as epoch {} is {}\n'.format(epoch, sum_loss / max(1, batches)))
+            f.flush()
+            if epoch % 10 == 0:
+                save_path = self.save(checkpoint_path + '-{}'.format(epoch))
+                error_rate = self.evaluate(save_path, epoch)
+                for (k, v) in error_rate.items():
+                    f.write(k + ': {:.4f}% '.format(v * 100))
+                f.write('\n')
+                f.flush()
+        f.close()
+
+    def evaluate(self, checkpoint_path, epoch=None, alignments_outdir='./alignments/tmp/', beam_graphs_outdir='./beam_graphs/tmp/'):
+        self.restore(checkpoint_path)                         # the path argument is honoured, as in avsr.py:328-331
+        predictions_dict, labels_dict = {}, {}
+        for bd in self._iterator('evaluate'):
+            batch, names = self._to_batch(bd)
+            ids = self._model.greedy_decode(batch, max_steps=self._cfg.max_label_length).cpu().numpy()
+            for idx in range(len(names)):
+                file = names[idx].decode('utf-8')
+                predictions_dict[file] = [self._unit_dict[int(s)] for s in ids[idx]]
+                labels_dict[file] = [self._unit_dict[int(s)] for s in bd.labels[idx]]
+        uer, uer_dict = compute_wer(predictions_dict, labels_dict)
+        error_rate = {self._unit: uer}
+        if self._unit == 'character':
+            wer, _wer_dict = compute_wer(predictions_dict, labels_dict, split_words=True)
+            error_rate['word'] = wer
+        outdir = path.join('predictions', path.split(path.split(checkpoint_path)[0])[-1])
+        makedirs(outdir, exist_ok=True)
+        write_sequences_to_labelfile(predictions_dict, path.join(outdir, 'predicted_epoch_{}.mlf'.format(epoch)), labels_dict,
+                                     uer_dict, sep=' ' if self._unit == 'phoneme' else '')
+        return error_rate

@@ -1,0 +1,381 @@
+"""TF-free input pipeline with the behaviour of avsr/io_utils.py (tf.data over TFRecord SequenceExamples).
+
+On-disk schema = what avsr/dataset_writer.py writes (:290-311 labels, :439-459 features, :461-498 video):
+  data record   context {input_length:int64, input_size:int64 | width,height,channels:int64, filename:bytes}
+                feature_lists {inputs: one float list per time step [, aus: float[2] per step]}
+  label record  context {unit:bytes, labels_length:int64, filename:bytes}, feature_lists {labels: one int64 per step}
+TFRecord framing (tensorflow/core/lib/io/record_writer.cc): u64 length | masked crc32c(length) | payload |
+masked crc32c(payload).  The protobuf wire format is decoded by hand (no dependency on tensorflow or protobuf).
+
+Pipeline semantics mirrored from the reference: zip data and label records by position (io_utils.py:99, :189-194),
+append EOS and add 1 to labels_length (:81-85), optional max_sentence_length filter (:102-103), shuffle with a
+5000-element buffer (:105-106), bucket by input_length // bucket_width with windows of batch_size
+(group_by_window, :133-143), zero padded batches with a ragged final batch (:113-127).
+No reference .tfrecord exists to test against, so byte compatibility is checked against the protobuf wire format
+produced by the official `protobuf` runtime in tests/test_io.py (and CRC32C against its published test vector).
+"""
+import collections
+import random
+import struct
+
+import numpy as np
+
+
+class BatchedData(collections.namedtuple("BatchedData", ("iterator_initializer", "inputs", "inputs_length", "inputs_filenames",
+                                                          "labels", "labels_length", "labels_filenames", "payload"))):
+    """Same fields as avsr/io_utils.py:8-18; here `inputs` etc. are numpy arrays of ONE batch."""
+
+
+# ------------------------------------------------------------------------------------------------
+# crc32c + TFRecord framing
+def _make_crc_table():
+    tbl = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        tbl.append(c)
+    return tbl
+
+
+_CRC_TABLE = _make_crc_table()
+
+
+def crc32c(data: bytes) -> int:
+    c = 0xFFFFFFFF
+    for b in data:
+        c = _CRC_TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _masked_crc(data: bytes) -> int:
+    c = crc32c(data)
+    return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def read_tfrecord(path, verify_crc=False):
+    """Yield the serialized payload of every record of a TFRecord file."""
+    with open(path, "rb") as f:
+        while True:
+            head = f.read(12)
+            if not head:
+                return
+            if len(head) < 12:
+                raise IOError("truncated TFRecord header in %s" % path)
+            (length,), (lcrc,) = struct.unpack("<Q", head[:8]), struct.unpack("<I", head[8:])
+            if verify_crc and _masked_crc(head[:8]) != lcrc:
+                raise IOError("corrupt TFRecord length crc in %s" % path)
+            data = f.read(length)
+            tail = f.read(4)
+            if len(data) < length or len(tail) < 4:
+                raise IOError("truncated TFRecord payload in %s" % path)
+            if verify_crc and _masked_crc(data) != struct.unpack("<I", tail)[0]:
+                raise IOError("corrupt TFRecord payload crc in %s" % path)
+            yield data
+
+
+class TFRecordFileWriter:
+    def __init__(self, path):
+        self._f = open(path, "wb")
+
+    def write(self, payload: bytes):
+        head = struct.pack("<Q", len(payload))
+        self._f.write(head + struct.pack("<I", _masked_crc(head)) + payload + struct.pack("<I", _masked_crc(payload)))
+
+    def close(self):
+        self._f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# protobuf wire format (tensorflow/core/example/{example,feature}.proto)
+def _varint(buf, i):
+    r, s = 0, 0
+    while True:
+        b = buf[i]
+        i += 1
+        r |= (b & 0x7F) << s
+        if b < 0x80:
+            return r, i
+        s += 7
+
+
+def _enc_varint(v):
+    out = bytearray()
+    v &= (1 << 64) - 1
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _fields(buf):
+    """Iterate (field_number, wire_type, value) of one message; length-delimited values are memoryview slices."""
+    i, n = 0, len(buf)
+    while i < n:
+        key, i = _varint(buf, i)
+        fn, wt = key >> 3, key & 7
+        if wt == 0:
+            v, i = _varint(buf, i)
+        elif wt == 2:
+            ln, i = _varint(buf, i)
+            v = buf[i:i + ln]
+            i += ln
+        elif wt == 5:
+            v = buf[i:i + 4]
+            i += 4
+        elif wt == 1:
+            v = buf[i:i + 8]
+            i += 8
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % wt)
+        yield fn, wt, v
+
+
+def _parse_feature(buf):
+    """Feature -> ('bytes', [bytes]) | ('float', np.float32[]) | ('int64', np.int64[])."""
+    for fn, _wt, v in _fields(buf):
+        if fn == 1:
+            return "bytes", [bytes(x) for f2, _w, x in _fields(v) if f2 == 1]
+        if fn == 2:
+            parts = []
+            for f2, w2, x in _fields(v):
+                if f2 == 1:
+                    parts.append(np.frombuffer(x, dtype="<f4"))          # packed (wt 2) or single fixed32 (wt 5)
+            return "float", (np.concatenate(parts) if len(parts) != 1 else parts[0]) if parts else np.zeros(0, np.float32)
+        if fn == 3:
+            vals = []
+            for f2, w2, x in _fields(v):
+                if f2 != 1:
+                    continue
+                if w2 == 0:
+                    vals.append(x)
+                else:
+                    j, xb = 0, bytes(x)
+                    while j < len(xb):
+                        val, j = _varint(xb, j)
+                        vals.append(val)
+            arr = np.array(vals, dtype=np.uint64).astype(np.int64)
+            return "int64", arr
+    return "none", None
+
+
+def parse_sequence_example(payload: bytes):
+    """-> (context: {name: value-list}, feature_lists: {name: [value per step]})."""
+    buf = memoryview(payload)
+    context, flists = {}, {}
+    for fn, _wt, v in _fields(buf):
+        if fn == 1:                                   # Features context
+            for f2, _w, entry in _fields(v):
+                if f2 != 1:
+                    continue
+                key, feat = None, None
+                for f3, _w3, x in _fields(entry):
+                    if f3 == 1:
+                        key = bytes(x).decode("utf-8")
+                    elif f3 == 2:
+                        feat = _parse_feature(x)
+                context[key] = feat[1] if feat else None
+        elif fn == 2:                                 # FeatureLists
+            for f2, _w, entry in _fields(v):
+                if f2 != 1:
+                    continue
+                key, steps = None, []
+                for f3, _w3, x in _fields(entry):
+                    if f3 == 1:
+                        key = bytes(x).decode("utf-8")
+                    elif f3 == 2:                     # FeatureList { repeated Feature feature = 1; }
+                        steps = [_parse_feature(fx)[1] for f4, _w4, fx in _fields(x) if f4 == 1]
+                flists[key] = steps
+    return context, flists
+
+
+def _ld(fn, payload):
+    return _enc_varint((fn << 3) | 2) + _enc_varint(len(payload)) + payload
+
+
+def _enc_feature(value):
+    if isinstance(value, (bytes, str)):
+        b = value.encode("utf-8") if isinstance(value, str) else value
+        return _ld(1, _ld(1, b))
+    arr = np.asarray(value)
+    if arr.dtype.kind == "f":
+        return _ld(2, _ld(1, arr.astype("<f4").tobytes()))
+    return _ld(3, _ld(1, b"".join(_enc_varint(int(x)) for x in arr.reshape(-1))))
+
+
+def make_sequence_example(context: dict, feature_lists: dict) -> bytes:
+    """Serialize with the same field layout tf.train.SequenceExample produces (packed repeated scalars)."""
+    ctx = b"".join(_ld(1, _ld(1, k.encode("utf-8")) + _ld(2, _enc_feature(v))) for k, v in context.items())
+    fls = b""
+    for k, steps in feature_lists.items():
+        fl = b"".join(_ld(1, _enc_feature(s)) for s in steps)
+        fls += _ld(1, _ld(1, k.encode("utf-8")) + _ld(2, fl))
+    return _ld(1, ctx) + _ld(2, fls)
+
+
+def make_feature_example(sentence_id, inputs):
+    """avsr/dataset_writer.py:439-459"""
+    inputs = np.asarray(inputs, np.float32)
+    return make_sequence_example({"input_length": [len(inputs)], "input_size": [inputs.shape[-1]], "filename": sentence_id},
+                                 {"inputs": list(inputs)})
+
+
+def make_video_example(sentence_id, frames, aus=None):
+    """avsr/dataset_writer.py:461-498 (frames [T,H,W[,C]])"""
+    frames = np.asarray(frames, np.float32)
+    h, w = frames.shape[1], frames.shape[2]
+    c = frames.shape[3] if frames.ndim == 4 else 1
+    fl = {"inputs": [f.reshape(-1) for f in frames]}
+    if aus is not None:
+        fl["aus"] = [np.asarray(a, np.float32).reshape(-1) for a in aus]
+    return make_sequence_example({"input_length": [len(frames)], "width": [w], "height": [h], "channels": [c], "filename": sentence_id}, fl)
+
+
+def make_label_example(label_id, labels, unit):
+    """avsr/dataset_writer.py:290-311"""
+    return make_sequence_example({"unit": unit, "labels_length": [len(labels)], "filename": label_id},
+                                 {"labels": [np.asarray([int(l)], np.int64) for l in labels]})
+
+
+# ------------------------------------------------------------------------------------------------
+def create_unit_dict(unit_file):
+    """id -> symbol: MASK=0, END=-1, symbols 1..N, EOS=N+1, GO=N+2 (avsr/io_utils.py:354-370)."""
+    unit_dict = {"MASK": 0, "END": -1}
+    with open(unit_file, "r") as f:
+        unit_list = f.read().splitlines()
+    idx = 0
+    for idx, sub in enumerate(unit_list):
+        unit_dict[sub] = idx + 1
+    unit_dict["EOS"] = idx + 2
+    unit_dict["GO"] = idx + 3
+    return {v: k for k, v in unit_dict.items()}
+
+
+def _get_input_shape_from_record(record):
+    """avsr/io_utils.py:309-345: feature-vector stream vs raw video stream, optional Action Units."""
+    ctx, fl = parse_sequence_example(next(read_tfrecord(record)))
+    content = {}
+    if "input_size" in ctx:
+        shape, content["stream"] = [int(ctx["input_size"][0])], "feature"
+    else:
+        ch = int(ctx["channels"][0]) if "channels" in ctx else 1
+        shape, content["stream"] = [int(ctx["width"][0]), int(ctx["height"][0]), ch], "video"
+    if fl.get("aus"):
+        content["aus"] = True
+    return shape, content
+
+
+def _parse_input(payload, input_shape):
+    ctx, fl = parse_sequence_example(payload)
+    T = int(ctx["input_length"][0])
+    x = np.stack(fl["inputs"]).astype(np.float32).reshape([T] + list(input_shape)) if T else np.zeros([0] + list(input_shape), np.float32)
+    aus = np.stack(fl["aus"]).astype(np.float32).reshape(T, 2) if fl.get("aus") else None
+    return x, aus, T, ctx["filename"][0]
+
+
+def _parse_labels(payload, eos_id):
+    ctx, fl = parse_sequence_example(payload)
+    lab = np.array([int(s[0]) for s in fl["labels"]] + [eos_id], dtype=np.int32)      # io_utils.py:81-83
+    return lab, int(ctx["labels_length"][0]) + 1, ctx["filename"][0]
+
+
+def _pad_stack(arrs):
+    T = max(a.shape[0] for a in arrs)
+    out = np.zeros((len(arrs), T) + arrs[0].shape[1:], arrs[0].dtype)
+    for i, a in enumerate(arrs):
+        out[i, :a.shape[0]] = a
+    return out
+
+
+class _Pipeline:
+    """shuffle(5000) -> bucket(group_by_window) -> padded_batch over zipped (data streams..., labels)."""
+
+    def __init__(self, data_records, label_record, unit_dict, batch_size, shuffle, bucket_width, max_sentence_length, seed=None):
+        self.data_records, self.label_record = data_records, label_record
+        self.eos = {v: k for k, v in unit_dict.items()}["EOS"]
+        self.shapes = [_get_input_shape_from_record(r) for r in data_records]
+        self.batch_size, self.shuffle, self.bucket_width, self.max_len = batch_size, shuffle, bucket_width, max_sentence_length
+        self.rng = random.Random(seed)
+
+    def _examples(self):
+        its = [read_tfrecord(r) for r in self.data_records] + [read_tfrecord(self.label_record)]
+        for recs in zip(*its):
+            streams = [_parse_input(p, shp[0]) for p, shp in zip(recs[:-1], self.shapes)]
+            lab = _parse_labels(recs[-1], self.eos)
+            if self.max_len is not None and not lab[1] < self.max_len:
+                continue
+            yield streams, lab
+
+    def _shuffled(self):
+        if not self.shuffle:
+            yield from self._examples()
+            return
+        buf = []
+        for ex in self._examples():
+            buf.append(ex)
+            if len(buf) >= 5000:
+                yield buf.pop(self.rng.randrange(len(buf)))
+        self.rng.shuffle(buf)
+        yield from buf
+
+    def _batch(self, exs):
+        streams = list(zip(*[e[0] for e in exs]))
+        inputs = [_pad_stack([s[0] for s in st]) for st in streams]
+        lens = [np.array([s[2] for s in st], np.int32) for st in streams]
+        names = [[s[3] for s in st] for st in streams]
+        payload = {}
+        for st in streams:
+            if st[0][1] is not None:
+                payload["aus"] = _pad_stack([s[1] for s in st])
+        labels = _pad_stack([e[1][0] for e in exs])
+        llen = np.array([e[1][1] for e in exs], np.int32)
+        lnames = [e[1][2] for e in exs]
+        one = len(inputs) == 1
+        return BatchedData(None, inputs[0] if one else tuple(inputs), lens[0] if one else tuple(lens),
+                           names[0] if one else tuple(names), labels, llen, lnames, payload)
+
+    def __iter__(self):
+        if self.bucket_width == -1:
+            cur = []
+            for ex in self._shuffled():
+                cur.append(ex)
+                if len(cur) == self.batch_size:
+                    yield self._batch(cur)
+                    cur = []
+            if cur:
+                yield self._batch(cur)
+            return
+        windows = collections.OrderedDict()
+        for ex in self._shuffled():
+            key = ex[0][0][2] // self.bucket_width             # first stream's input_length (video for AV)
+            w = windows.setdefault(key, [])
+            w.append(ex)
+            if len(w) == self.batch_size:
+                yield self._batch(w)
+                del windows[key]
+        for w in windows.values():                              # group_by_window flushes partial windows at the end
+            yield self._batch(w)
+
+
+def make_iterator_from_one_record(data_record, label_record, unit_dict, batch_size, shuffle=False, reverse_input=False,
+                                  bucket_width=-1, num_cores=4, max_sentence_length=None, seed=None):
+    """Iterable of BatchedData (avsr/io_utils.py:88-165).  reverse_input is always False in the reference's callers."""
+    if reverse_input:
+        raise NotImplementedError("reverse_input is never enabled by the reference (avsr/avsr.py:646, :658, :671)")
+    return _Pipeline([data_record], label_record, unit_dict, batch_size, shuffle, bucket_width, max_sentence_length, seed)
+
+
+def make_iterator_from_two_records(video_record, audio_record, label_record, batch_size, unit_dict, shuffle=False,
+                                   reverse_input=False, bucket_width=-1, num_cores=4, seed=None):
+    """Iterable of BatchedData with (video, audio) tuples (avsr/io_utils.py:168-259); buckets on the VIDEO length."""
+    return _Pipeline([video_record, audio_record], label_record, unit_dict, batch_size, shuffle, bucket_width, None, seed)

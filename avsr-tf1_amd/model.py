@@ -125,7 +125,8 @@ class Seq2SeqModel:
         self.derived = z(tn)
         for name, off, r, c in self._tjobs:
             self.Tr[name] = Ref(self.derived, off, (c, r))
-        self._ws_cache = {}
+        self._ws_cache = OrderedDict()
+        self.max_cached_shapes = 8
         self._dropping = False
         self.au_scale = 1.0          # data parallel: 1 / world_size (AU term averaged over ranks)
         self.load_tf_weights(weights if weights is not None else PR.initialise(cfg, seed))
@@ -147,6 +148,14 @@ class Seq2SeqModel:
             ref = self.S[name] if name in self.S else self.P[name]
             ref.t[ref.off:ref.off + e.numel()].copy_(e)
         self._refresh_derived()
+
+    def load_flat(self, buf, W: Dict[str, np.ndarray]):
+        """Fill an optimiser-slot buffer (same layout as params) from a TF-layout dict."""
+        for name, (shape, kind, _i) in self.inv.items():
+            if name in self._train_off and name in W:
+                e = torch.from_numpy(PR.to_engine(kind, np.asarray(W[name], np.float32).reshape(shape)).reshape(-1)).to(self.dev)
+                o = self._train_off[name]
+                buf[o:o + e.numel()].copy_(e)
 
     def export_tf_weights(self, which="params") -> Dict[str, np.ndarray]:
         src = {"params": self.params, "grads": self.grads, "adam_m": self.adam_m, "adam_v": self.adam_v}[which]
@@ -173,7 +182,10 @@ class Seq2SeqModel:
     def _get_ws(self, B, Ta, Tv, L, greedy):
         key = (B, Ta, Tv, L, greedy)
         if key in self._ws_cache:
+            self._ws_cache[key] = self._ws_cache.pop(key)          # most recently used last
             return self._ws_cache[key]
+        while len(self._ws_cache) >= self.max_cached_shapes:       # bucketed training visits many shapes
+            self._ws_cache.pop(next(iter(self._ws_cache)))
         cfg, dev = self.cfg, self.dev
         z = lambda *s: torch.zeros(*s, device=dev)
         ws = {"enc": {}}
@@ -434,7 +446,7 @@ class Seq2SeqModel:
             E = ws["enc"]["video"]
             T, D = E["T"], E["mem"].D
             ops.gemm(ops.mat(E["au_dz"], 2), self.P["video/au/kernel"].mat(2), E["dmem"].mat(), B * T, D, 2, trans_b=1, beta=1.0)
-            ops.gemm(E["mem"].mat(), ops.mat(E["au_dz"], 2), self.G["video/au/kernel"].mat(2), D, 2, B * T, trans_a=1, beta=1.0)
+            self._gemm_tn(E["mem"].mat(), ops.mat(E["au_dz"], 2), self.G["video/au/kernel"].mat(2), D, 2, B * T)
             ops.colsum(ops.mat(E["au_dz"], 2), B * T, 2, self.grads, self.scratch, beta=1.0, out_offset=self.G["video/au/bias"].off)
         if cfg.architecture == "av_align":
             self._av_align_backward(ws, batch)       # needs the complete gradient of the audio memory; fills video dmem

@@ -6,6 +6,7 @@
 import os as _os
 
 __path__ = [_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "avsr-tf1_amd")]
+__package__ = __name__           # make the module a package so relative imports inside __init__ work
 __file__ = _os.path.join(__path__[0], "__init__.py")
 with open(__file__) as _f:
     exec(compile(_f.read(), __file__, "exec"))
