@@ -215,13 +215,28 @@ def main():
         out["kernel_time_events"] = kinds
         dom = max((k for k in kinds if k != "gemm" or True), key=lambda k: kinds[k]["total_ms"])
         HBM_PEAK, MFMA_PEAK = 8000.0, 157.3
+        # HBM traffic per launch from the committed PMC passes (profiles/r01_c4_pmc.json: FETCH_SIZE / WRITE_SIZE collected in
+        # separate rocprofv3 runs of this same workload, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); null
+        # for workloads / kernels that were not profiled.
+        pmc = {}
+        try:
+            if args.workload == "c4":
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c4_pmc.json")))["kernels"]
+        except Exception:
+            pmc = {}
+        pmc_name = {"attn_fwd": "avsr::attn_fwd_kernel", "attn_bwd": "avsr::attn_bwd_kernel",
+                    "step_lstm_fwd": "avsr::step_kernel<1, 1, 1, 4>", "step_lstm_bwd": "avsr::step_kernel<2, 1, 1, 8>"}
+
+        def traffic(kind):
+            k = pmc.get(pmc_name.get(kind, ""))
+            return k["hbm_bytes_per_dispatch_corrected"] if k else None
 
         def roof(kind):
             us = kinds[kind]["avg_us"]
             if kind in ("attn_fwd", "attn_bwd"):
                 ach = wm["attn_bytes"] / (us * 1e-6) / 1e9
                 return {"kernel": kind, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK, 4), "traffic": None,
+                        "frac": round(ach / HBM_PEAK, 4), "traffic": traffic(kind),
                         "algorithmic_bytes_per_launch": wm["attn_bytes"], "avg_launch_us": us}
             fl = {"step_lstm_fwd": wm["lstm_fwd_flops"], "step_lstm_bwd": wm["lstm_bwd_flops"]}.get(kind)
             if fl is None:
@@ -229,7 +244,7 @@ def main():
                         "traffic": None, "avg_launch_us": us}
             ach = fl / (us * 1e-6) / 1e12
             return {"kernel": kind, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK, 4), "traffic": None, "algorithmic_flops_per_launch": int(fl), "avg_launch_us": us}
+                    "frac": round(ach / MFMA_PEAK, 4), "traffic": traffic(kind), "algorithmic_flops_per_launch": int(fl), "avg_launch_us": us}
 
         out["roofline"] = roof(dom)
         if "attn_fwd" in kinds:
