@@ -44,7 +44,8 @@ class RnnLayer(C.Structure):
                 ("gates", C.c_void_p), ("cs", C.c_void_p), ("out", C.c_void_p), ("ld_out", C.c_int64),
                 ("state", C.c_void_p), ("h_final", C.c_void_p), ("c_final", C.c_void_p),
                 ("dgates", C.c_void_p), ("dstate", C.c_void_p), ("dout", C.c_void_p), ("ld_dout", C.c_int64),
-                ("dout_col", C.c_int32), ("pad_", C.c_int32), ("hs_seq", C.c_void_p), ("xt_seq", C.c_void_p)]
+                ("dout_col", C.c_int32), ("pad_", C.c_int32), ("hs_seq", C.c_void_p), ("xt_seq", C.c_void_p),
+                ("wt2", C.c_void_p), ("w2", C.c_void_p), ("bias2", C.c_void_p), ("rh_seq", C.c_void_p), ("dgates2", C.c_void_p)]
 
 
 class RnnStack(C.Structure):
@@ -84,7 +85,9 @@ class AttnRnn(C.Structure):
                 ("dh_final", C.c_void_p), ("dc_final", C.c_void_p),
                 ("seed", C.c_void_p), ("keep_in", C.c_float), ("keep_state", C.c_float), ("keep_out", C.c_float),
                 ("sampling_prob", C.c_float), ("cell_id", C.c_int32), ("pad3_", C.c_int32),
-                ("hs_seq", C.c_void_p), ("attd", C.c_void_p), ("xs", C.c_void_p), ("labels", C.c_void_p), ("fed", C.c_void_p)]
+                ("hs_seq", C.c_void_p), ("attd", C.c_void_p), ("xs", C.c_void_p), ("labels", C.c_void_p), ("fed", C.c_void_p),
+                ("cell", C.c_int32), ("pad4_", C.c_int32), ("wt2", C.c_void_p), ("w2", C.c_void_p), ("bias2", C.c_void_p),
+                ("rh_seq", C.c_void_p), ("dgates2", C.c_void_p)]
 
 
 class TransposeJob(C.Structure):

@@ -88,14 +88,14 @@ class ModelConfig:
             raise Exception("Unknown architecture")                                   # seq2seq.py:66
         if self.encoder_type not in ("unidirectional", "bidirectional"):
             raise Exception("Allowed encoder types: `unidirectional`, `bidirectional`")  # encoder.py:146
-        if self.cell_type == "gru":
-            raise NotImplementedError("GRU cells are not built in the HIP engine yet (LSTM only this round)")
-        if self.cell_type != "lstm":
+        if self.cell_type not in ("lstm", "gru"):
             raise Exception("cell type not supported: {}".format(self.cell_type))      # cells.py:44
         for types in self.attention_type:
             for t in types:
                 if t not in ATT_CODE:
                     raise Exception("unknown attention mechanism")                    # attention.py:86
+        if self.architecture == "bimodal" and self.cell_type != "lstm":
+            raise ValueError("the bimodal decoder needs LSTM state tuples (decoder_bimodal.py:130-142, :484-485)")
         if self.architecture == "av_align":
             if self.encoder_type != "unidirectional":
                 raise ValueError("AttentiveEncoder implements only `unidirectional` (encoder.py:229)")

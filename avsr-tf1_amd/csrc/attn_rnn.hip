@@ -165,6 +165,8 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
   if (l_begin < 0 || l_end > L || l_begin > l_end) return AVSR_ERR_ARG;
   if (d.mode == 1 && (!d.embedding || !d.wout_t || !d.logits || !d.ids || !d.tok || !d.n_unfinished)) return AVSR_ERR_ARG;
   if (d.mode == 2 && (!d.embedding || !d.wout_t || !d.logits || !d.xs || !d.labels || !d.fed || !d.seed)) return AVSR_ERR_ARG;
+  const bool gru = d.cell == 1;
+  if (gru && (!d.wt2 || !d.rh_seq)) return AVSR_ERR_ARG;
   const bool drop = d.seed && d.mode != 1 && (d.keep_in < 1.f || d.keep_state < 1.f || d.keep_out < 1.f);
   if (drop && (!d.hs_seq || (A > 0 && !d.attd))) return AVSR_ERR_ARG;
   const uint32_t cid4 = (uint32_t)d.cell_id * 4;
@@ -192,36 +194,45 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
   static thread_local AttnLaunch AL;
   for (int l = l_begin; l < l_end; ++l) {
     // ---- K1: LSTM step -------------------------------------------------------------------
-    SL.ntask = 1;
-    {
+    for (int phase = 0; phase < (gru ? 2 : 1); ++phase) {
+      SL.ntask = 1;
       StepTask& tk = SL.task[0];
       tk = StepTask{};
+      const float* wt = (gru && phase == 1) ? d.wt2 : d.wt;
       if (d.mode == 1) {
         StepSrc& x = tk.src[tk.nsrc++];
-        x.a = d.embedding; x.sb = E; x.K = E; x.w = d.wt; x.ldw = KW; x.kind = SRC_PLAIN;
+        x.a = d.embedding; x.sb = E; x.K = E; x.w = wt; x.ldw = KW; x.kind = SRC_PLAIN;
         tk.gather = d.tok;
       } else if (d.mode == 2) {
         StepSrc& x = tk.src[tk.nsrc++];
-        x.a = d.xs + (long)l * E; x.sb = (long)L * E; x.K = E; x.w = d.wt; x.ldw = KW; x.kind = SRC_PLAIN;
+        x.a = d.xs + (long)l * E; x.sb = (long)L * E; x.K = E; x.w = wt; x.ldw = KW; x.kind = SRC_PLAIN;
       }
       if (A > 0) {
         StepSrc& a = tk.src[tk.nsrc++];
-        a.a = (drop ? d.attd : d.att) + (long)l * A; a.sb = (long)(L + 1) * A; a.K = A; a.w = d.wt + E; a.ldw = KW; a.kind = SRC_PLAIN;
+        a.a = (drop ? d.attd : d.att) + (long)l * A; a.sb = (long)(L + 1) * A; a.K = A; a.w = wt + E; a.ldw = KW; a.kind = SRC_PLAIN;
       }
       StepSrc& h = tk.src[tk.nsrc++];
-      h.a = hbuf(d, l & 1); h.sb = H; h.K = H; h.w = d.wt + E + A; h.ldw = KW; h.kind = SRC_PLAIN;
-      tk.B = B; tk.N = 4 * H; tk.mode = EP_LSTM_FWD; tk.t = l; tk.T = L; tk.reverse = 0;
-      tk.len = d.steplen; tk.bias = d.bias;
-      tk.p0 = d.gates; tk.p1 = d.cs; tk.p2 = d.cell_out + H; tk.s0 = (long)(L + 1) * H; tk.s1 = H;
+      h.a = (gru && phase == 1) ? hbuf(d, 2) /* r*h */ : hbuf(d, l & 1); h.sb = H; h.K = H; h.w = wt + E + A; h.ldw = KW; h.kind = SRC_PLAIN;
+      tk.B = B; tk.t = l; tk.T = L; tk.reverse = 0; tk.len = d.steplen;
       tk.s2 = (d.mode == 0) ? 1 : 0;
-      tk.p3 = cbuf(d, l & 1); tk.p4 = hbuf(d, l & 1); tk.p5 = cbuf(d, (l + 1) & 1); tk.p6 = hbuf(d, (l + 1) & 1);
-      if (drop) {
-        tk.seed = d.seed; tk.k_st = d.keep_state; tk.k_out = d.keep_out; tk.k_in = 1.0f;
-        tk.r_st = cid4 + 1; tk.r_out = cid4 + 2;
-        tk.p9 = d.hs_seq + H; tk.s4 = (long)(L + 1) * H; tk.s5 = H;
+      tk.p4 = hbuf(d, l & 1);
+      if (gru && phase == 0) {
+        tk.N = 2 * H; tk.mode = EP_GRU_GATES; tk.bias = d.bias;
+        tk.p0 = d.gates; tk.p1 = hbuf(d, 2); tk.p2 = d.rh_seq;
+      } else {
+        if (gru) { tk.N = H; tk.mode = EP_GRU_CAND; tk.bias = d.bias2; tk.p0 = d.cs; tk.p1 = d.gates; }
+        else { tk.N = 4 * H; tk.mode = EP_LSTM_FWD; tk.bias = d.bias; tk.p0 = d.gates; tk.p1 = d.cs;
+               tk.p3 = cbuf(d, l & 1); tk.p5 = cbuf(d, (l + 1) & 1); }
+        tk.p2 = d.cell_out + H; tk.s0 = (long)(L + 1) * H; tk.s1 = H;
+        tk.p6 = hbuf(d, (l + 1) & 1);
+        if (drop) {
+          tk.seed = d.seed; tk.k_st = d.keep_state; tk.k_out = d.keep_out; tk.k_in = 1.0f;
+          tk.r_st = cid4 + 1; tk.r_out = cid4 + 2;
+          tk.p9 = d.hs_seq + H; tk.s4 = (long)(L + 1) * H; tk.s5 = H;
+        }
       }
+      if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
     }
-    if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
 
     if (d.n_mech > 0) {
       // ---- Kq: Bahdanau processed query  pq = cell_out . Wq ---------------------------------
@@ -292,7 +303,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
   }
   if (l_end == L) {
     if (d.h_final && hipMemcpyAsync(d.h_final, hbuf(d, L & 1), bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
-    if (d.c_final && hipMemcpyAsync(d.c_final, cbuf(d, L & 1), bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+    if (!gru && d.c_final && hipMemcpyAsync(d.c_final, cbuf(d, L & 1), bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
   }
   return AVSR_OK;
 }
@@ -315,12 +326,21 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
   if (1 + d.n_mech + n_bah > STEP_MAX_SRC) return AVSR_ERR_UNSUPPORTED;
   const bool drop = d.seed && (d.keep_in < 1.f || d.keep_state < 1.f || d.keep_out < 1.f);
   const uint32_t cid4 = (uint32_t)d.cell_id * 4;
+  const bool gru = d.cell == 1;
+  if (gru && (!d.w2 || !d.dgates2)) return AVSR_ERR_ARG;
+  const int G = gru ? 2 : 4;      // gate pre-activations per unit
+  // GRU dstate: dGg rolling [2][B][2H] | d(cand pre-act) rolling [2][B][H] | carry [2][B][H] | tmp du | tmp dh*u
+  auto g_dgg = [&](int p) { return d.dstate + (long)p * B * 2 * H; };
+  auto g_dpc = [&](int p) { return d.dstate + (long)(4 + p) * B * H; };
+  auto g_carry = [&](int p) { return d.dstate + (long)(6 + p) * B * H; };
+  auto g_tmp = [&](int w) { return d.dstate + (long)(8 + w) * B * H; };
   const bool use_dq = (n_luong > 0) || d.dcell_ext;
   if (use_dq && !d.dq) return AVSR_ERR_ARG;
   const size_t bh = sizeof(float) * B * H;
   if (hipMemsetAsync(d.dstate, 0, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
-  if (d.dc_final && hipMemcpyAsync(dcbuf(d, L & 1), d.dc_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
-  if (d.dh_final && hipMemcpyAsync(dhcarry(d, L & 1), d.dh_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+  if (!gru && d.dc_final && hipMemcpyAsync(dcbuf(d, L & 1), d.dc_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+  if (d.dh_final && hipMemcpyAsync(gru ? g_carry(L & 1) : dhcarry(d, L & 1), d.dh_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return AVSR_ERR_HIP;
 
   static thread_local StepLaunch SL;
   static thread_local AttnLaunch AL;
@@ -333,7 +353,11 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
         StepTask& tk = SL.task[0];
         tk = StepTask{};
         StepSrc& x = tk.src[tk.nsrc++];
-        x.a = dgroll(d, (l + 1) & 1); x.sb = 4 * H; x.K = 4 * H; x.w = d.w + (long)E * 4 * H; x.ldw = 4 * H; x.kind = SRC_PLAIN;
+        x.a = gru ? g_dgg((l + 1) & 1) : dgroll(d, (l + 1) & 1); x.sb = G * H; x.K = G * H; x.w = d.w + (long)E * G * H; x.ldw = G * H; x.kind = SRC_PLAIN;
+        if (gru) {
+          StepSrc& x2 = tk.src[tk.nsrc++];
+          x2.a = g_dpc((l + 1) & 1); x2.sb = H; x2.K = H; x2.w = d.w2 + (long)E * H; x2.ldw = H; x2.kind = SRC_PLAIN;
+        }
         tk.B = B; tk.N = A; tk.mode = EP_LINEAR; tk.t = l; tk.T = L;
         if (d.datt_ext) { tk.p1 = const_cast<float*>(d.datt_ext) + (long)l * A; tk.s1 = (long)L * A; }
         tk.p0 = d.datt + (long)l * A; tk.s0 = (long)L * A;
@@ -387,7 +411,7 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
       StepTask& tk = SL.task[0];
       tk = StepTask{};
       StepSrc& a = tk.src[tk.nsrc++];
-      a.a = dgroll(d, (l + 1) & 1); a.sb = 4 * H; a.K = 4 * H; a.w = d.w + (long)(E + A) * 4 * H; a.ldw = 4 * H; a.kind = SRC_PLAIN;
+      a.a = gru ? g_dgg((l + 1) & 1) : dgroll(d, (l + 1) & 1); a.sb = G * H; a.K = G * H; a.w = d.w + (long)(E + A) * G * H; a.ldw = G * H; a.kind = SRC_PLAIN;
       for (int m = 0; m < d.n_mech; ++m) {
         const avsr_attn_mech& M = d.mech[m];
         StepSrc& x = tk.src[tk.nsrc++];
@@ -397,11 +421,19 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
           q.a = M.dpq + (long)l * H; q.sb = (long)L * H; q.K = H; q.w = M.wq; q.ldw = H; q.kind = SRC_PLAIN;
         }
       }
-      tk.B = B; tk.N = H; tk.mode = EP_LSTM_BWD; tk.t = l; tk.T = L; tk.reverse = 0; tk.len = d.steplen;
-      tk.bias = d.c0;
-      tk.p0 = d.gates; tk.p1 = d.cs; tk.p2 = d.dgates; tk.p3 = dgroll(d, l & 1);
-      tk.p4 = dcbuf(d, (l + 1) & 1); tk.p5 = dcbuf(d, l & 1);
-      tk.p6 = dhcarry(d, (l + 1) & 1); tk.p7 = dhcarry(d, l & 1);
+      tk.B = B; tk.N = H; tk.t = l; tk.T = L; tk.reverse = 0; tk.len = d.steplen;
+      if (gru) {
+        tk.mode = EP_GRU_BWD_CAND;
+        tk.p0 = d.gates; tk.p1 = d.cs;
+        tk.p2 = drop ? d.hs_seq : d.cell_out; tk.s2 = (long)(L + 1) * H; tk.s3 = H;     // slot l = h consumed by step l
+        tk.p4 = g_carry((l + 1) & 1); tk.p5 = g_dpc(l & 1); tk.p3 = d.dgates2; tk.p6 = g_tmp(0); tk.p7 = g_tmp(1);
+      } else {
+        tk.mode = EP_LSTM_BWD;
+        tk.bias = d.c0;
+        tk.p0 = d.gates; tk.p1 = d.cs; tk.p2 = d.dgates; tk.p3 = dgroll(d, l & 1);
+        tk.p4 = dcbuf(d, (l + 1) & 1); tk.p5 = dcbuf(d, l & 1);
+        tk.p6 = dhcarry(d, (l + 1) & 1); tk.p7 = dhcarry(d, l & 1);
+      }
       if (use_dq) { tk.p8 = d.dq; tk.s0 = (long)L * H; tk.s1 = H; }
       if (drop) {
         tk.seed = d.seed; tk.k_st = d.keep_state; tk.k_out = d.keep_out; tk.k_in = 1.0f;
@@ -409,6 +441,17 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
       }
     }
     if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+    if (gru) {   // second phase: through r*h and the gate pre-activations
+      SL.ntask = 1;
+      StepTask& tk = SL.task[0];
+      tk = StepTask{};
+      StepSrc& a = tk.src[tk.nsrc++];
+      a.a = g_dpc(l & 1); a.sb = H; a.K = H; a.w = d.w2 + (long)(E + A) * H; a.ldw = H; a.kind = SRC_PLAIN;
+      tk.B = B; tk.N = H; tk.mode = EP_GRU_BWD_GATES; tk.t = l; tk.T = L; tk.reverse = 0; tk.len = d.steplen;
+      tk.p0 = d.gates; tk.p2 = drop ? d.hs_seq : d.cell_out; tk.s2 = (long)(L + 1) * H; tk.s3 = H;
+      tk.p6 = g_tmp(0); tk.p7 = g_tmp(1); tk.p5 = g_carry(l & 1); tk.p3 = d.dgates; tk.p1 = g_dgg(l & 1);
+      if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+    }
   }
   // gradient wrt the initial state
   if (d.dh0) {
@@ -416,12 +459,12 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
     StepTask& tk = SL.task[0];
     tk = StepTask{};
     StepSrc& a = tk.src[tk.nsrc++];
-    a.a = dgroll(d, 0); a.sb = 4 * H; a.K = 4 * H; a.w = d.w + (long)(E + A) * 4 * H; a.ldw = 4 * H; a.kind = SRC_PLAIN;
+    a.a = gru ? g_dgg(0) : dgroll(d, 0); a.sb = G * H; a.K = G * H; a.w = d.w + (long)(E + A) * G * H; a.ldw = G * H; a.kind = SRC_PLAIN;
     tk.B = B; tk.N = H; tk.mode = EP_LINEAR; tk.t = 0; tk.T = L;
-    tk.p1 = dhcarry(d, 0); tk.s1 = H;
+    tk.p1 = gru ? g_carry(0) : dhcarry(d, 0); tk.s1 = H;
     tk.p0 = d.dh0; tk.s0 = H;
     if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
   }
-  if (d.dc0 && hipMemcpyAsync(d.dc0, dcbuf(d, 0), bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+  if (!gru && d.dc0 && hipMemcpyAsync(d.dc0, dcbuf(d, 0), bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
   return AVSR_OK;
 }

@@ -33,6 +33,11 @@ static inline void set_cell_dropout(StepTask& tk, const avsr_rnn_stack& S, int l
 static inline float* dgroll(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)parity * B * 4 * l.units; }
 static inline float* dcbuf(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)(8 + parity) * B * l.units; }
 static inline float* dhcarry(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)(10 + parity) * B * l.units; }
+// GRU dstate: d(gate pre-act) rolling [2][B][2H] | d(cand pre-act) rolling [2][B][H] | carry [2][B][H] | tmp du | tmp dh*u
+static inline float* g_dgg(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)parity * B * 2 * l.units; }
+static inline float* g_dpc(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)(4 + parity) * B * l.units; }
+static inline float* g_carry(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)(6 + parity) * B * l.units; }
+static inline float* g_tmp(const avsr_rnn_layer& l, int B, int which) { return l.dstate + (long)(8 + which) * B * l.units; }
 
 }  // namespace avsr
 
@@ -43,7 +48,8 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
   int nsteps = 0, ntask_max = 0;
   for (int i = 0; i < n; ++i) {
     const avsr_rnn_stack& S = st[i];
-    if (S.cell != 0) return AVSR_ERR_UNSUPPORTED;
+    if (S.cell != 0 && S.cell != 1) return AVSR_ERR_UNSUPPORTED;
+    if (S.cell != st[0].cell) return AVSR_ERR_ARG;            // one cell kind per call
     if (S.n_layers <= 0 || S.n_layers > AVSR_MAX_LAYERS || S.B <= 0 || S.T <= 0) return AVSR_ERR_ARG;
     for (int l = 0; l < S.n_layers; ++l) {
       const avsr_rnn_layer& Ly = S.layer[l];
@@ -59,7 +65,9 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
   if (ntask_max > STEP_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
 
   static thread_local StepLaunch L;
+  const bool gru = st[0].cell == 1;
   for (int step = 0; step < nsteps; ++step) {
+   for (int phase = 0; phase < (gru ? 2 : 1); ++phase) {
     L.ntask = 0;
     for (int i = 0; i < n; ++i) {
       const avsr_rnn_stack& S = st[i];
@@ -71,6 +79,38 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
         tk = StepTask{};
         const int H = Ly.units, in = Ly.in_dim;
         tk.nsrc = 0;
+        if (gru) {
+          if (!Ly.wt2 || !Ly.rh_seq) return AVSR_ERR_ARG;
+          const float* wt = phase == 0 ? Ly.wt : Ly.wt2;
+          if (!Ly.hoisted) {
+            if (l == 0) return AVSR_ERR_UNSUPPORTED;
+            const avsr_rnn_layer& Lo = S.layer[l - 1];
+            StepSrc& x = tk.src[tk.nsrc++];
+            x.a = S.seed ? xbuf(Lo, S.B, (t + 1) & 1) : hbuf(Lo, S.B, (t + 1) & 1); x.sb = Lo.units; x.K = in; x.w = wt; x.ldw = in + H; x.kind = SRC_PLAIN;
+          }
+          StepSrc& h = tk.src[tk.nsrc++];
+          h.a = phase == 0 ? hbuf(Ly, S.B, t & 1) : hbuf(Ly, S.B, 2) /* r*h */; h.sb = H; h.K = H; h.w = wt + in; h.ldw = in + H; h.kind = SRC_PLAIN;
+          tk.B = S.B; tk.t = t; tk.T = S.T; tk.reverse = S.reverse; tk.len = S.len; tk.s2 = Ly.hoisted ? 1 : 0;
+          tk.p4 = hbuf(Ly, S.B, t & 1);
+          if (phase == 0) {
+            tk.N = 2 * H; tk.mode = EP_GRU_GATES; tk.bias = Ly.bias;
+            tk.p0 = Ly.gates; tk.p1 = hbuf(Ly, S.B, 2); tk.p2 = Ly.rh_seq;
+          } else {
+            tk.N = H; tk.mode = EP_GRU_CAND; tk.bias = Ly.bias2;
+            tk.p0 = Ly.cs; tk.p1 = Ly.gates;
+            tk.p2 = Ly.out ? Ly.out + Ly.ld_out + Ly.out_col : nullptr;
+            tk.s0 = (long)(S.T + 2) * Ly.ld_out; tk.s1 = Ly.ld_out;
+            tk.p6 = hbuf(Ly, S.B, (t + 1) & 1);
+            if (S.seed) {
+              set_cell_dropout(tk, S, l);
+              tk.s4 = (long)(S.T + 2) * H; tk.s5 = H;
+              if (Ly.hs_seq) tk.p9 = Ly.hs_seq + H;
+              if (l + 1 < S.n_layers) tk.p10 = xbuf(Ly, S.B, (t + 1) & 1);
+              if (Ly.xt_seq) tk.p11 = Ly.xt_seq + H;
+            }
+          }
+          continue;
+        }
         if (!Ly.hoisted) {
           if (l == 0) return AVSR_ERR_UNSUPPORTED;  // layer 0 input projection must be hoisted (avsr_gemm)
           const avsr_rnn_layer& Lo = S.layer[l - 1];
@@ -98,6 +138,7 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
     if (L.ntask == 0) continue;
     int rc = avsr_step_launch_raw(&L, stream);
     if (rc) return rc;
+   }
   }
   for (int i = 0; i < n; ++i) {
     const avsr_rnn_stack& S = st[i];
@@ -106,7 +147,7 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
       const size_t bytes = sizeof(float) * S.B * Ly.units;
       if (Ly.h_final && hipMemcpyAsync(Ly.h_final, hbuf(Ly, S.B, S.T & 1), bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return AVSR_ERR_HIP;
-      if (Ly.c_final && hipMemcpyAsync(Ly.c_final, cbuf(Ly, S.B, S.T & 1), bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      if (!gru && Ly.c_final && hipMemcpyAsync(Ly.c_final, cbuf(Ly, S.B, S.T & 1), bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return AVSR_ERR_HIP;
     }
   }
@@ -120,7 +161,7 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
   int nsteps = 0, ntask_max = 0;
   for (int i = 0; i < n; ++i) {
     const avsr_rnn_stack& S = st[i];
-    if (S.cell != 0) return AVSR_ERR_UNSUPPORTED;
+    if ((S.cell != 0 && S.cell != 1) || S.cell != st[0].cell) return AVSR_ERR_UNSUPPORTED;
     if (S.n_layers <= 0 || S.n_layers > AVSR_MAX_LAYERS) return AVSR_ERR_ARG;
     for (int l = 0; l < S.n_layers; ++l) {
       const avsr_rnn_layer& Ly = S.layer[l];
@@ -129,10 +170,15 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
       // rolling dG (both parities), dc / dh_carry at parity T&1 = gradient of the final state
       if (hipMemsetAsync(Ly.dstate, 0, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
       if (l == S.n_layers - 1) {
-        if (S.dc_final && hipMemcpyAsync(dcbuf(Ly, S.B, S.T & 1), S.dc_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
-          return AVSR_ERR_HIP;
-        if (S.dh_final && hipMemcpyAsync(dhcarry(Ly, S.B, S.T & 1), S.dh_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
-          return AVSR_ERR_HIP;
+        if (S.cell == 1) {
+          if (S.dh_final && hipMemcpyAsync(g_carry(Ly, S.B, S.T & 1), S.dh_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return AVSR_ERR_HIP;
+        } else {
+          if (S.dc_final && hipMemcpyAsync(dcbuf(Ly, S.B, S.T & 1), S.dc_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return AVSR_ERR_HIP;
+          if (S.dh_final && hipMemcpyAsync(dhcarry(Ly, S.B, S.T & 1), S.dh_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return AVSR_ERR_HIP;
+        }
       }
     }
     nsteps = nsteps > S.T + S.n_layers - 1 ? nsteps : S.T + S.n_layers - 1;
@@ -141,7 +187,9 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
   if (ntask_max > STEP_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
 
   static thread_local StepLaunch L;
+  const bool gru = st[0].cell == 1;
   for (int step = 0; step < nsteps; ++step) {
+   for (int phase = 0; phase < (gru ? 2 : 1); ++phase) {
     L.ntask = 0;
     for (int i = 0; i < n; ++i) {
       const avsr_rnn_stack& S = st[i];
@@ -153,6 +201,44 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
         StepTask& tk = L.task[L.ntask++];
         tk = StepTask{};
         const int H = Ly.units, in = Ly.in_dim;
+        if (gru) {
+          if (!Ly.w2 || !Ly.dgates2) return AVSR_ERR_ARG;
+          // h(t-1) as the cell consumed it: the state-dropped sequence under dropout, else the output sequence
+          const float* hseq = S.seed ? Ly.hs_seq : Ly.out + Ly.out_col;
+          const long hld = S.seed ? H : Ly.ld_out;
+          tk.B = S.B; tk.N = H; tk.t = t; tk.T = S.T; tk.reverse = S.reverse; tk.len = S.len;
+          tk.p0 = Ly.gates;
+          tk.p2 = const_cast<float*>(hseq) + (S.reverse ? 2 * hld : 0); tk.s2 = (long)(S.T + 2) * hld; tk.s3 = hld;
+          tk.p6 = g_tmp(Ly, S.B, 0); tk.p7 = g_tmp(Ly, S.B, 1);
+          if (phase == 0) {
+            tk.mode = EP_GRU_BWD_CAND;
+            StepSrc& a = tk.src[tk.nsrc++];
+            a.a = g_dgg(Ly, S.B, (t + 1) & 1); a.sb = 2 * H; a.K = 2 * H; a.w = Ly.w + (long)in * 2 * H; a.ldw = 2 * H; a.kind = SRC_PLAIN;
+            if (l + 1 < nl) {
+              const avsr_rnn_layer& Up = S.layer[l + 1];
+              StepSrc& u1 = tk.src[tk.nsrc++];
+              u1.a = g_dgg(Up, S.B, t & 1); u1.sb = 2 * Up.units; u1.K = 2 * Up.units; u1.w = Up.w; u1.ldw = 2 * Up.units; u1.kind = SRC_PLAIN;
+              StepSrc& u2 = tk.src[tk.nsrc++];
+              u2.a = g_dpc(Up, S.B, t & 1); u2.sb = Up.units; u2.K = Up.units; u2.w = Up.w2; u2.ldw = Up.units; u2.kind = SRC_PLAIN;
+            }
+            tk.p1 = Ly.cs; tk.p4 = g_carry(Ly, S.B, (t + 1) & 1);
+            tk.p5 = g_dpc(Ly, S.B, t & 1); tk.p3 = Ly.dgates2;
+            if (Ly.dout) {
+              tk.p8 = const_cast<float*>(Ly.dout) + Ly.ld_dout + Ly.dout_col;
+              tk.s0 = (long)(S.T + 2) * Ly.ld_dout; tk.s1 = Ly.ld_dout;
+            }
+            if (S.seed) {
+              set_cell_dropout(tk, S, l);
+              if (l + 1 >= nl) tk.k_in = 1.0f;
+            }
+          } else {
+            tk.mode = EP_GRU_BWD_GATES;
+            StepSrc& a = tk.src[tk.nsrc++];
+            a.a = g_dpc(Ly, S.B, t & 1); a.sb = H; a.K = H; a.w = Ly.w2 + (long)in * H; a.ldw = H; a.kind = SRC_PLAIN;
+            tk.p5 = g_carry(Ly, S.B, t & 1); tk.p3 = Ly.dgates; tk.p1 = g_dgg(Ly, S.B, t & 1);
+          }
+          continue;
+        }
         // dh[b,u] = dG_{t+1}(own) . Wh[u,:]  +  dG_t(upper layer) . Wx_upper[u,:]
         StepSrc& a = tk.src[0];
         a.a = dgroll(Ly, S.B, (t + 1) & 1); a.sb = 4 * H; a.K = 4 * H; a.w = Ly.w + (long)in * 4 * H; a.ldw = 4 * H; a.kind = SRC_PLAIN;
@@ -180,6 +266,7 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
     if (L.ntask == 0) continue;
     int rc = avsr_step_launch_raw(&L, stream);
     if (rc) return rc;
+   }
   }
   return AVSR_OK;
 }

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
           if (tk.p8) pre2b = tk.p8[(long)b * tk.s0 + (long)tau * tk.s1 + n];   // external d out
         }
       }
-    } else {
+    } else if constexpr (MODE == EP_LINEAR) {
       b = e_row0 + (e_l >> 4);
       n = e_col0 + (e_l & 15);
       e_ok = b < tk.B && n < tk.N;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
   const int row0 = (int)blockIdx.y * TM * 16, col0 = ((int)blockIdx.x * TN + nt) * 16;
   constexpr int UN = (TM >= 4) ? 2 : (TM == 2 ? 4 : 8);
   f32x4 acc[TM];
-  mm16_partial<KP, UN, TM, MODE == EP_LSTM_BWD>(tk, row0, col0, kp, blockIdx.x == 0 && nt == 0, acc);
+  mm16_partial<KP, UN, TM, MODE == EP_LSTM_BWD || MODE == EP_GRU_BWD_CAND>(tk, row0, col0, kp, blockIdx.x == 0 && nt == 0, acc);
   // C/D layout of mfma 16x16: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
   for (int m = 0; m < TM; ++m)
@@ -263,6 +263,125 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
   if (tid < 256 && row0 + (tid >> 4) < tk.B) tk.p5[(long)(row0 + (tid >> 4)) * 16 + (tid & 15)] = red[0][0][tid >> 4][tid & 15] + red[KP - 1][NTILE - 1][tid >> 4][tid & 15];
   return;
 #endif
+  if constexpr (MODE >= EP_GRU_GATES) {
+    // ===================== GRU (rnn_cell_impl.GRUCell, cells.py:25-29) =====================
+    //   [r,u] = sigmoid([x,h] Wg + bg);  c~ = tanh([x, r*h] Wc + bc);  h' = u*h + (1-u)*c~
+    // Two launches per time step forward (gates, candidate) and backward (candidate path, gate path); gate columns are
+    // unit-interleaved (col = 2*unit + {0:r, 1:u}).  Records: gates [B,T,H,2], c~ [B,T,H], r*h [B,T,H].
+    constexpr int GEPT = (MODE == EP_GRU_GATES) ? 128 : 256;
+    if (tid >= NTILE * GEPT) return;
+    const int gt = tid / GEPT, gl = tid % GEPT;
+    const int g_row0 = ((int)blockIdx.y * TM + gt / TN) * 16, g_col0 = ((int)blockIdx.x * TN + gt % TN) * 16;
+    if constexpr (MODE == EP_GRU_GATES) {
+      // p0 gates record (+ hoisted x.Wg if s2), p4 h_in, p1 r*h out [B,H], p2 r*h record [B,T,H]
+      const int r = gl >> 3, ul = gl & 7;
+      const int bb = g_row0 + r, H = tk.N >> 1, u = (g_col0 >> 1) + ul;
+      if (bb >= tk.B || u >= H) return;
+      const int ln = tk.len ? tk.len[bb] : tk.T;
+      if (!(t < ln)) return;
+      const int ta = tk.reverse ? ln - 1 - t : t;
+      const long bt = (long)bb * tk.T + ta;
+      float zr = 0.f, zu = 0.f;
+#pragma unroll
+      for (int w = 0; w < KP; ++w) { zr += red[w][gt][r][2 * ul]; zu += red[w][gt][r][2 * ul + 1]; }
+      if (tk.bias) { zr += tk.bias[2 * u]; zu += tk.bias[2 * u + 1]; }
+      float* gp = tk.p0 + (bt * H + u) * 2;
+      if (tk.s2) { zr += gp[0]; zu += gp[1]; }
+      const float rr = fsigmoid(zr), uu = fsigmoid(zu);
+      gp[0] = rr; gp[1] = uu;
+      const float rh = rr * tk.p4[(long)bb * H + u];
+      tk.p1[(long)bb * H + u] = rh;
+      if (tk.p2) tk.p2[bt * H + u] = rh;
+      return;
+    }
+    const int bb = g_row0 + (gl >> 4), nn = g_col0 + (gl & 15), H = tk.N;
+    if (bb >= tk.B || nn >= H) return;
+    const int ln = tk.len ? tk.len[bb] : tk.T;
+    const bool ok = t < ln;
+    const int ta = tk.reverse ? ln - 1 - t : t;
+    const long bt = (long)bb * tk.T + ta, bh = (long)bb * H + nn;
+    float z = 0.f, zB = 0.f;
+    if (MODE == EP_GRU_BWD_CAND && tk.nsrc > 1) {
+#pragma unroll
+      for (int w = 0; w < KP / 2; ++w) z += red[w][gt][gl >> 4][gl & 15];
+#pragma unroll
+      for (int w = KP / 2; w < KP; ++w) zB += red[w][gt][gl >> 4][gl & 15];
+    } else {
+#pragma unroll
+      for (int w = 0; w < KP; ++w) z += red[w][gt][gl >> 4][gl & 15];
+    }
+    if constexpr (MODE == EP_GRU_CAND) {
+      // p0 c~ record (+ hoisted x.Wc if s2), p1 gates record, p2 seq_out (s0,s1), p4 h_in, p6 h_out, p9/p10/p11 as LSTM fwd
+      const float hprev = tk.p4[bh];
+      if (ok) {
+        if (tk.bias) z += tk.bias[nn];
+        if (tk.s2) z += tk.p0[bt * H + nn];
+        const float cand = ftanh(z), uu = tk.p1[(bt * H + nn) * 2 + 1];
+        const float h = uu * hprev + (1.f - uu) * cand;
+        tk.p0[bt * H + nn] = cand;
+        const uint32_t oidx = (uint32_t)(bt * H + nn);
+        const float ho = h * drop_scale(tk.seed, tk.r_out, oidx, tk.k_out);
+        const float hs = h * drop_scale(tk.seed, tk.r_st, oidx, tk.k_st);
+        if (tk.p2) tk.p2[(long)bb * tk.s0 + (long)ta * tk.s1 + nn] = ho;
+        tk.p6[bh] = hs;
+        if (tk.p9) tk.p9[(long)bb * tk.s4 + (long)ta * tk.s5 + nn] = hs;
+        if (tk.p10 || tk.p11) {
+          const float xn = ho * drop_scale(tk.seed, tk.r_in, (uint32_t)(bt * tk.in_W + tk.in_coff + nn), tk.k_in);
+          if (tk.p10) tk.p10[bh] = xn;
+          if (tk.p11) tk.p11[(long)bb * tk.s4 + (long)ta * tk.s5 + nn] = xn;
+        }
+      } else {
+        tk.p6[bh] = hprev;
+        if (t < tk.T) {
+          if (tk.p2) tk.p2[(long)bb * tk.s0 + (long)t * tk.s1 + nn] = 0.f;
+          if (tk.p9) tk.p9[(long)bb * tk.s4 + (long)t * tk.s5 + nn] = 0.f;
+          if (tk.p11) tk.p11[(long)bb * tk.s4 + (long)t * tk.s5 + nn] = 0.f;
+        }
+      }
+    } else if constexpr (MODE == EP_GRU_BWD_CAND) {
+      // z = d(state h) from the gate path of step t+1 (source 0) [+ zB = d(output) from the layer above]
+      // p0 gates rec, p1 c~ rec, p2 h_prev sequence (s2 batch stride, s3 time stride; index tau), p4 carry_in, p8 d out (s0,s1),
+      // p5 d(c~ pre-act) rolling out [B,H], p3 d(c~ pre-act) record, p6 tmp d(u pre-act) [B,H], p7 tmp dh*u [B,H]
+      const float carry = tk.p4[bh];
+      if (ok) {
+        const uint32_t oidx = (uint32_t)(bt * H + nn);
+        float dout = zB * drop_scale(tk.seed, tk.r_in, (uint32_t)(bt * tk.in_W + tk.in_coff + nn), tk.k_in);
+        if (tk.p8) dout += tk.p8[(long)bb * tk.s0 + (long)ta * tk.s1 + nn];
+        const float dh = dout * drop_scale(tk.seed, tk.r_out, oidx, tk.k_out) + (z + carry) * drop_scale(tk.seed, tk.r_st, oidx, tk.k_st);
+        const float uu = tk.p0[(bt * H + nn) * 2 + 1], cand = tk.p1[bt * H + nn];
+        const float hprev = tk.p2[(long)bb * tk.s2 + (long)ta * tk.s3 + nn];
+        const float dpc = dh * (1.f - uu) * (1.f - cand * cand);
+        tk.p5[bh] = dpc;
+        tk.p3[bt * H + nn] = dpc;
+        tk.p6[bh] = dh * (hprev - cand) * uu * (1.f - uu);
+        tk.p7[bh] = dh * uu;
+      } else {
+        tk.p5[bh] = 0.f;
+        if (t < tk.T) tk.p3[((long)bb * tk.T + t) * H + nn] = 0.f;
+        tk.p6[bh] = 0.f;
+        tk.p7[bh] = carry;
+      }
+    } else {
+      // EP_GRU_BWD_GATES: z = d(r*h) = d(c~ pre-act) . Wc_h^T.  p0 gates rec, p2 h_prev sequence (s2,s3), p6 tmp d(u pre-act),
+      // p7 tmp dh*u, p5 carry_out [B,H], p3 d(gate pre-act) record [B,T,H,2], p1 d(gate pre-act) rolling out [B,2H]
+      float dr = 0.f, du = 0.f;
+      const float dhdir = tk.p7[bh];
+      if (ok) {
+        const float rr = tk.p0[(bt * H + nn) * 2];
+        const float hprev = tk.p2[(long)bb * tk.s2 + (long)ta * tk.s3 + nn];
+        dr = z * hprev * rr * (1.f - rr);
+        du = tk.p6[bh];
+        tk.p5[bh] = dhdir + z * rr;
+        float* rec = tk.p3 + (bt * H + nn) * 2;
+        rec[0] = dr; rec[1] = du;
+      } else {
+        tk.p5[bh] = dhdir;
+        if (t < tk.T) { float* rec = tk.p3 + (((long)bb * tk.T + t) * H + nn) * 2; rec[0] = 0.f; rec[1] = 0.f; }
+      }
+      tk.p1[bh * 2] = dr; tk.p1[bh * 2 + 1] = du;
+    }
+    return;
+  }
   if (!epi || !e_ok) return;
 
   if constexpr (MODE == EP_LINEAR) {
@@ -401,7 +520,6 @@ extern "C" int avsr_step_launch_raw(const void* launch, void* stream) {
     switch (geo) {                                                                                             \
       case 0: hipLaunchKernelGGL((step_kernel<M, 1, 1, 4>), GRID(1, 1), dim3(256), 0, s, *L); break;           \
       case 1: hipLaunchKernelGGL((step_kernel<M, 1, 1, 8>), GRID(1, 1), dim3(512), 0, s, *L); break;           \
-      case 2: hipLaunchKernelGGL((step_kernel<M, 2, 1, 8>), GRID(2, 1), dim3(512), 0, s, *L); break;           \
       default: return AVSR_ERR_ARG;                                                                            \
     }                                                                                                          \
   }
@@ -409,6 +527,10 @@ extern "C" int avsr_step_launch_raw(const void* launch, void* stream) {
   if (mode == EP_LSTM_FWD) LAUNCH_(EP_LSTM_FWD, PROF_STEP_LSTM_FWD)
   else if (mode == EP_LSTM_BWD) LAUNCH_(EP_LSTM_BWD, PROF_STEP_LSTM_BWD)
   else if (mode == EP_LINEAR) LAUNCH_(EP_LINEAR, PROF_STEP_LINEAR)
+  else if (mode == EP_GRU_GATES) LAUNCH_(EP_GRU_GATES, PROF_STEP_LSTM_FWD)
+  else if (mode == EP_GRU_CAND) LAUNCH_(EP_GRU_CAND, PROF_STEP_LSTM_FWD)
+  else if (mode == EP_GRU_BWD_CAND) LAUNCH_(EP_GRU_BWD_CAND, PROF_STEP_LSTM_BWD)
+  else if (mode == EP_GRU_BWD_GATES) LAUNCH_(EP_GRU_BWD_GATES, PROF_STEP_LSTM_BWD)
   else return AVSR_ERR_UNSUPPORTED;
 #undef LAUNCH_
 #undef GRID

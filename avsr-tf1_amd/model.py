@@ -91,6 +91,8 @@ class Seq2SeqModel:
         from . import _lib
         _lib.load()
         self.cfg, self.dev = cfg, torch.device(device)
+        self.gru = cfg.cell_type == "gru"
+        self.G = 2 if self.gru else 4                       # gate pre-activations per unit of the main cell kernel
         self.inv = PR.inventory(cfg)
         # ---- flat parameter storage (engine layout) ------------------------------------------------
         self._train_off, self._stat_off = OrderedDict(), OrderedDict()
@@ -109,14 +111,14 @@ class Seq2SeqModel:
         self.n_train = nt
         self.step = z(1, torch.int32)[:1]
         self.P = {n: Ref(self.params, o, self._eshape(n)) for n, o in self._train_off.items()}
-        self.G = {n: Ref(self.grads, o, self._eshape(n)) for n, o in self._train_off.items()}
+        self.Gr = {n: Ref(self.grads, o, self._eshape(n)) for n, o in self._train_off.items()}
         self.S = {n: Ref(self.stats, o, self.inv[n][0]) for n, o in self._stat_off.items()}
         self.l2_segments = [(self._train_off[n], int(np.prod(self.inv[n][0]))) for n in self._train_off if PR.is_l2(n)]
         # ---- derived transposed operands -----------------------------------------------------------
         self._tjobs, self.Tr = [], {}
         tn = 0
         for name in self._train_off:
-            if name.endswith(("/kernel", "/query_kernel", "/layer_kernel")) and not name.startswith(("video/au", "audio/au")):
+            if name.endswith(("/kernel", "/query_kernel", "/layer_kernel", "/gates_kernel", "/cand_kernel")) and not name.startswith(("video/au", "audio/au")):
                 if name.endswith("memory_kernel"):
                     continue
                 r, c = self._eshape(name)
@@ -217,6 +219,8 @@ class Seq2SeqModel:
                     else:
                         Ld["out"], Ld["col"] = SeqBuf(B, T, u, 1, 1, dev), 0
                         Ld["dout"] = SeqBuf(B, T, u, 1, 1, dev) if (attentive and l == nplain - 1) else None
+                    if self.gru:
+                        Ld["rh"], Ld["dpc"] = z(B, T, u), z(B, T, u)
                     if cfg.use_dropout:
                         Ld["hs_seq"] = SeqBuf(B, T, u, 1, 1, dev)
                         if not top or attentive:
@@ -258,6 +262,8 @@ class Seq2SeqModel:
             blk["cell_id"], blk["keep"] = CELL_ID_DECODER, cfg.decoder_dropout
         else:
             blk["cell_id"], blk["keep"] = encoder_cell_id("audio", "fw", len(cfg.audio_units) - 1), cfg.audio_dropout
+        if self.gru:
+            blk["rh"], blk["dpc"] = z(B, L, H), z(B, L, H)
         if cfg.use_dropout:
             blk["hs_seq"] = SeqBuf(B, L, H, 1, 0, dev)
             if A:
@@ -284,6 +290,10 @@ class Seq2SeqModel:
 
     # ------------------------------------------------------------------------------------------------
     # encoders
+    def _kn(self, prefix):
+        """(main kernel, main bias) parameter names of a cell: LSTM kernel / GRU gate kernel."""
+        return (prefix + "/gates_kernel", prefix + "/gates_bias") if self.gru else (prefix + "/kernel", prefix + "/bias")
+
     def _keeps(self, s):
         return self.cfg.video_dropout if s == "video" else self.cfg.audio_dropout
 
@@ -298,7 +308,7 @@ class Seq2SeqModel:
         cfg = self.cfg
         E = ws["enc"][s]
         st = RnnStack()
-        st.B, st.T, st.reverse, st.n_layers, st.cell = B, E["T"], int(d == "bw"), E["nplain"], 0
+        st.B, st.T, st.reverse, st.n_layers, st.cell = B, E["T"], int(d == "bw"), E["nplain"], int(self.gru)
         st.len = ops.fptr(len_t)
         drop = self._sdrop(s)
         if drop:
@@ -314,12 +324,17 @@ class Seq2SeqModel:
         for l in range(E["nplain"]):
             u = E["units"][l]
             Ld = E["layers"][(d, l)]
-            name = f"{s}/enc/{d}/l{l}/kernel"
+            name, bname = self._kn(f"{s}/enc/{d}/l{l}")
             Ly = st.layer[l]
             Ly.units, Ly.in_dim, Ly.hoisted, Ly.out_col = u, i, int(l == 0), Ld["col"]
             Ly.wt = ops.fptr(self.derived, self.Tr[name].off)
             Ly.w = ops.fptr(self.params, self.P[name].off)
-            Ly.bias = ops.fptr(self.params, self.P[f"{s}/enc/{d}/l{l}/bias"].off)
+            Ly.bias = ops.fptr(self.params, self.P[bname].off)
+            if self.gru:
+                cn = f"{s}/enc/{d}/l{l}/cand_kernel"
+                Ly.wt2, Ly.w2 = ops.fptr(self.derived, self.Tr[cn].off), ops.fptr(self.params, self.P[cn].off)
+                Ly.bias2 = ops.fptr(self.params, self.P[f"{s}/enc/{d}/l{l}/cand_bias"].off)
+                Ly.rh_seq, Ly.dgates2 = ops.fptr(Ld["rh"]), ops.fptr(Ld["dpc"])
             Ly.gates, Ly.cs = ops.fptr(Ld["gates"]), ops.fptr(Ld["cs"])
             Ly.out, Ly.ld_out = ops.fptr(Ld["out"].t), Ld["out"].D
             Ly.state, Ly.h_final, Ly.c_final = ops.fptr(Ld["state"]), ops.fptr(Ld["hf"]), ops.fptr(Ld["cf"])
@@ -333,7 +348,7 @@ class Seq2SeqModel:
             i = u
         if backward and not E["attentive"]:
             top = E["layers"][(d, E["nplain"] - 1)]
-            st.dh_final, st.dc_final = ops.fptr(top["dhf"]), ops.fptr(top["dcf"])
+            st.dh_final, st.dc_final = ops.fptr(top["dhf"]), (None if self.gru else ops.fptr(top["dcf"]))
         return st
 
     def _encode(self, ws, batch: Batch, training: bool):
@@ -358,13 +373,16 @@ class Seq2SeqModel:
                 continue
             for d in cfg.directions():
                 u0 = E["units"][0]
-                W0 = self.P[f"{s}/enc/{d}/l0/kernel"]
+                W0 = self.P[self._kn(f"{s}/enc/{d}/l0")[0]]
                 xin = E["xin"]
                 if self._sdrop(s):               # DropoutWrapper input mask of the layer-0 cell of this direction
                     xin = E["xd"][d]
                     ops.dropout_rows(ops.mat(E["xin"], F), ops.mat(xin, F), B * T, F, self.step, encoder_cell_id(s, d, 0) * 4,
                                      self._keeps(s)[0], F)
-                ops.gemm(ops.mat(xin, F), W0.mat(4 * u0), ops.mat(E["layers"][(d, 0)]["gates"], 4 * u0), B * T, 4 * u0, F)
+                G = self.G
+                ops.gemm(ops.mat(xin, F), W0.mat(G * u0), ops.mat(E["layers"][(d, 0)]["gates"], G * u0), B * T, G * u0, F)
+                if self.gru:                     # candidate kernel's input part, hoisted into the c~ record
+                    ops.gemm(ops.mat(xin, F), self.P[f"{s}/enc/{d}/l0/cand_kernel"].mat(u0), ops.mat(E["layers"][(d, 0)]["cs"], u0), B * T, u0, F)
                 stacks.append(self._rnn_stack(ws, s, d, B, len_t))
         self._run_stacks(stacks, ops.rnn_fwd)
         for s in cfg.streams():
@@ -393,7 +411,7 @@ class Seq2SeqModel:
         return r.t[r.off:r.off + r.n]
 
     def _gp(self, name):
-        r = self.G[name]
+        r = self.Gr[name]
         return r.t[r.off:r.off + r.n]
 
     def _sp(self, name):
@@ -408,14 +426,14 @@ class Seq2SeqModel:
         u, H = E["units"][-1], cfg.decoder_units[0]
         if cfg.encoder_type == "unidirectional":
             Lt = E["layers"][("fw", top)]
-            E["c_fin"], E["h_fin"] = Lt["cf"], Lt["hf"]
+            E["c_fin"], E["h_fin"] = (None if self.gru else Lt["cf"]), Lt["hf"]
             return
-        for nm, key, dst in (("proj_c", "cf", "c_dec"), ("proj_h", "hf", "h_dec")):
+        for nm, key, dst in ((("proj", "hf", "h_dec"),) if self.gru else (("proj_c", "cf", "c_dec"), ("proj_h", "hf", "h_dec"))):
             Pm = self.P[f"{s}/enc/{nm}"]
             for di, d in enumerate(cfg.directions()):
                 ops.gemm(ops.mat(E["layers"][(d, top)][key], u), Pm.mat(H, row0=di * u), ops.mat(E[dst], H), B, H, u,
                          beta=0.0 if di == 0 else 1.0)
-        E["c_fin"], E["h_fin"] = E["c_dec"], E["h_dec"]
+        E["c_fin"], E["h_fin"] = (None if self.gru else E["c_dec"]), E["h_dec"]
 
     def _final_state_bwd(self, ws, s, dc, dh):
         """dc, dh: [B, Hdec] gradient wrt the stream's final (c, h) handed to the decoder."""
@@ -428,11 +446,12 @@ class Seq2SeqModel:
             return
         if cfg.encoder_type == "unidirectional":
             Lt = E["layers"][("fw", top)]
-            Lt["dcf"].copy_(dc)
+            if not self.gru:
+                Lt["dcf"].copy_(dc)
             Lt["dhf"].copy_(dh)
             return
-        for nm, key, dkey, g in (("proj_c", "cf", "dcf", dc), ("proj_h", "hf", "dhf", dh)):
-            Pm, Gm = self.P[f"{s}/enc/{nm}"], self.G[f"{s}/enc/{nm}"]
+        for nm, key, dkey, g in ((("proj", "hf", "dhf", dh),) if self.gru else (("proj_c", "cf", "dcf", dc), ("proj_h", "hf", "dhf", dh))):
+            Pm, Gm = self.P[f"{s}/enc/{nm}"], self.Gr[f"{s}/enc/{nm}"]
             for di, d in enumerate(cfg.directions()):
                 Lt = E["layers"][(d, top)]
                 ops.gemm(ops.mat(g, H), Pm.mat(H, row0=di * u), ops.mat(Lt[dkey], u), B, u, H, trans_b=1)
@@ -446,8 +465,8 @@ class Seq2SeqModel:
             E = ws["enc"]["video"]
             T, D = E["T"], E["mem"].D
             ops.gemm(ops.mat(E["au_dz"], 2), self.P["video/au/kernel"].mat(2), E["dmem"].mat(), B * T, D, 2, trans_b=1, beta=1.0)
-            self._gemm_tn(E["mem"].mat(), ops.mat(E["au_dz"], 2), self.G["video/au/kernel"].mat(2), D, 2, B * T)
-            ops.colsum(ops.mat(E["au_dz"], 2), B * T, 2, self.grads, self.scratch, beta=1.0, out_offset=self.G["video/au/bias"].off)
+            self._gemm_tn(E["mem"].mat(), ops.mat(E["au_dz"], 2), self.Gr["video/au/kernel"].mat(2), D, 2, B * T)
+            ops.colsum(ops.mat(E["au_dz"], 2), B * T, 2, self.grads, self.scratch, beta=1.0, out_offset=self.Gr["video/au/bias"].off)
         if cfg.architecture == "av_align":
             self._av_align_backward(ws, batch)       # needs the complete gradient of the audio memory; fills video dmem
         stacks = []
@@ -467,8 +486,10 @@ class Seq2SeqModel:
                 for l in range(E["nplain"]):
                     u = E["units"][l]
                     Ld = E["layers"][(d, l)]
-                    Gk = self.G[f"{s}/enc/{d}/l{l}/kernel"]
-                    dg = ops.mat(Ld["dgates"], 4 * u)
+                    kname, bname = self._kn(f"{s}/enc/{d}/l{l}")
+                    Gk = self.Gr[kname]
+                    G = self.G
+                    dg = ops.mat(Ld["dgates"], G * u)
                     drop = self._sdrop(s)
                     if l == 0:
                         a_x = ops.mat(E["xd"][d] if drop else E["xin"], F)
@@ -476,30 +497,38 @@ class Seq2SeqModel:
                         a_x = E["layers"][(d, l - 1)]["xt_seq"].mat(0)
                     else:
                         a_x = E["layers"][(d, l - 1)]["out"].mat(0, E["layers"][(d, l - 1)]["col"])
-                    self._gemm_tn(a_x, dg, Gk.mat(4 * u), i, 4 * u, B * T)
+                    self._gemm_tn(a_x, dg, Gk.mat(G * u), i, G * u, B * T)
                     sh = 1 if d == "bw" else -1
                     a_h = Ld["hs_seq"].mat(sh) if drop else Ld["out"].mat(sh, Ld["col"])
-                    self._gemm_tn(a_h, dg, Gk.mat(4 * u, row0=i), u, 4 * u, B * T)
-                    ops.colsum(dg, B * T, 4 * u, self.grads, self.scratch, beta=1.0, out_offset=self.G[f"{s}/enc/{d}/l{l}/bias"].off)
+                    self._gemm_tn(a_h, dg, Gk.mat(G * u, row0=i), u, G * u, B * T)
+                    ops.colsum(dg, B * T, G * u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
+                    if self.gru:                 # candidate kernel: inputs [x ; r*h]
+                        Gc = self.Gr[f"{s}/enc/{d}/l{l}/cand_kernel"]
+                        dpc = ops.mat(Ld["dpc"], u)
+                        self._gemm_tn(a_x, dpc, Gc.mat(u), i, u, B * T)
+                        self._gemm_tn(ops.mat(Ld["rh"], u), dpc, Gc.mat(u, row0=i), u, u, B * T)
+                        ops.colsum(dpc, B * T, u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/enc/{d}/l{l}/cand_bias"].off)
                     i = u
                 if E["nplain"] > 0 and cfg.batch_normalisation:
-                    u0 = E["units"][0]
-                    W0 = self.P[f"{s}/enc/{d}/l0/kernel"]
+                    u0, G = E["units"][0], self.G
+                    W0 = self.P[self._kn(f"{s}/enc/{d}/l0")[0]]
+                    L0 = E["layers"][(d, 0)]
+                    tgt = E["dx_tmp"] if self._sdrop(s) else E["dxn"]
+                    beta0 = 0.0 if (self._sdrop(s) or first) else 1.0
+                    ops.gemm(ops.mat(L0["dgates"], G * u0), W0.mat(G * u0), ops.mat(tgt, F), B * T, F, G * u0, trans_b=1, beta=beta0)
+                    if self.gru:
+                        ops.gemm(ops.mat(L0["dpc"], u0), self.P[f"{s}/enc/{d}/l0/cand_kernel"].mat(u0), ops.mat(tgt, F), B * T, F, u0,
+                                 trans_b=1, beta=1.0)
                     if self._sdrop(s):
-                        ops.gemm(ops.mat(E["layers"][(d, 0)]["dgates"], 4 * u0), W0.mat(4 * u0), ops.mat(E["dx_tmp"], F), B * T, F,
-                                 4 * u0, trans_b=1)
                         ops.dropout_rows(ops.mat(E["dx_tmp"], F), ops.mat(E["dxn"], F), B * T, F, self.step,
                                          encoder_cell_id(s, d, 0) * 4, self._keeps(s)[0], F, accumulate=not first)
-                    else:
-                        ops.gemm(ops.mat(E["layers"][(d, 0)]["dgates"], 4 * u0), W0.mat(4 * u0), ops.mat(E["dxn"], F), B * T, F, 4 * u0,
-                                 trans_b=1, beta=0.0 if first else 1.0)
                     first = False
             if cfg.batch_normalisation:
                 # (a 1-layer attentive encoder wrote dxn in _av_align_backward)
                 ops.batchnorm_xhat(E["x"], E["mean"], E["invstd"], E["xhat"], B * T, F)
                 ops.colsum(ops.mat(E["dxn"], F), B * T, F, self.grads, self.scratch, b=ops.mat(E["xhat"], F), beta=1.0,
-                           out_offset=self.G[f"{s}/bn/gamma"].off)
-                ops.colsum(ops.mat(E["dxn"], F), B * T, F, self.grads, self.scratch, beta=1.0, out_offset=self.G[f"{s}/bn/beta"].off)
+                           out_offset=self.Gr[f"{s}/bn/gamma"].off)
+                ops.colsum(ops.mat(E["dxn"], F), B * T, F, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/bn/beta"].off)
 
     def _ensure_gemm_ws(self):
         if self.gemm_ws is None:
@@ -536,9 +565,15 @@ class Seq2SeqModel:
         d.B, d.L, d.H, d.E, d.n_mech, d.V, d.mode = B, L, H, E, len(blk["mems"]), cfg.vocab_size, mode
         d.go_id, d.eos_id = cfg.go_id, cfg.eos_id
         d.steplen = ops.fptr(steplen)
-        kname = blk["cell"] + "/kernel"
+        kname, bname = self._kn(blk["cell"])
         d.wt, d.w = ops.fptr(self.derived, self.Tr[kname].off), ops.fptr(self.params, self.P[kname].off)
-        d.bias = ops.fptr(self.params, self.P[blk["cell"] + "/bias"].off)
+        d.bias = ops.fptr(self.params, self.P[bname].off)
+        if self.gru:
+            cn = blk["cell"] + "/cand_kernel"
+            d.cell = 1
+            d.wt2, d.w2 = ops.fptr(self.derived, self.Tr[cn].off), ops.fptr(self.params, self.P[cn].off)
+            d.bias2 = ops.fptr(self.params, self.P[blk["cell"] + "/cand_bias"].off)
+            d.rh_seq, d.dgates2 = ops.fptr(blk["rh"]), ops.fptr(blk["dpc"])
         d.gates, d.cs, d.cell_out = ops.fptr(blk["gates"]), ops.fptr(blk["cs"]), ops.fptr(blk["cell_out"].t)
         d.att = ops.fptr(blk["att"].t) if A else None
         d.h0, d.c0, d.state = ops.fptr(h0), ops.fptr(c0), ops.fptr(blk["state"])
@@ -601,7 +636,7 @@ class Seq2SeqModel:
             pre, T, D = m["prefix"], m["T"], m["D"]
             md = self._mem_desc(ws, m["stream"])
             datt_m = ops.mat(blk["datt"], A, offset=i * H)
-            Gl = self.G[pre + "/layer_kernel"]
+            Gl = self.Gr[pre + "/layer_kernel"]
             self._gemm_tn(co.mat(0), datt_m, Gl.mat(H), H, H, rows)                 # rows 0..H: cell_out part
             self._gemm_tn(ops.mat(m["ctx"], D), datt_m, Gl.mat(H, row0=H), D, H, rows)   # rows H..H+D: context part
             luong = m["type"] in LUONG_TYPES
@@ -609,7 +644,7 @@ class Seq2SeqModel:
             # scores -> alpha (in place); rowdot = sum_t ds * raw  (d g for scaled_luong)
             ops.attn_alpha_rows(m["scores"], m["dscores"], md["len"], desc_steplen(desc), g_t if luong else None, m["rowdot"], B, L, T)
             if m["type"] == "scaled_luong":
-                ops.reduce_scalar(m["rowdot"], rows, self.grads, accumulate=True, out_offset=self.G[pre + "/g"].off)
+                ops.reduce_scalar(m["rowdot"], rows, self.grads, accumulate=True, out_offset=self.Gr[pre + "/g"].off)
             # d values[b,t,:] += sum_l alpha[b,l,t] * dctx[b,l,:]        (batched over b)
             ops.gemm(ops.mat(m["scores"], T), ops.mat(m["dctx"], D), ops.mat(md["gt"], md["st"], offset=md["goff"]), T, D, L,
                      trans_a=1, beta=1.0, batch=B, strides=(L * T, L * D, md["gsb"]))
@@ -625,25 +660,38 @@ class Seq2SeqModel:
                 if m["type"] == "normed_bahdanau":
                     ops.colsum(ops.mat(m["dv_part"], H), nblk, H, m["dvn"], self.scratch)
                     ops.normed_v_bwd(self._pp(pre + "/v"), self._pp(pre + "/g"), m["dvn"], self._gp(pre + "/v"), self._gp(pre + "/g"), H)
-                    ops.colsum(ops.mat(m["dpq"], H), rows, H, self.grads, self.scratch, beta=1.0, out_offset=self.G[pre + "/b"].off)
+                    ops.colsum(ops.mat(m["dpq"], H), rows, H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[pre + "/b"].off)
                 else:
-                    ops.colsum(ops.mat(m["dv_part"], H), nblk, H, self.grads, self.scratch, beta=1.0, out_offset=self.G[pre + "/v"].off)
-                self._gemm_tn(co.mat(0), ops.mat(m["dpq"], H), self.G[pre + "/query_kernel"].mat(H), H, H, rows)
+                    ops.colsum(ops.mat(m["dv_part"], H), nblk, H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[pre + "/v"].off)
+                self._gemm_tn(co.mat(0), ops.mat(m["dpq"], H), self.Gr[pre + "/query_kernel"].mat(H), H, H, rows)
             # memory_layer: d values += d keys . W_mem^T ; d W_mem = values^T . d keys
-            Wm, Gm = self.P[pre + "/memory_kernel"], self.G[pre + "/memory_kernel"]
+            Wm, Gm = self.P[pre + "/memory_kernel"], self.Gr[pre + "/memory_kernel"]
             ops.gemm(ops.mat(m["dkeys"], H), Wm.mat(H), md["gmat"], B * T, D, H, trans_b=1, beta=1.0)
             self._gemm_tn(md["vmat"], ops.mat(m["dkeys"], H), Gm.mat(H), D, H, B * T)
         # cell kernel: rows [0:E] inputs, [E:E+A] previous attention, [E+A:] previous h
-        Gk = self.G[blk["cell"] + "/kernel"]
-        dg = ops.mat(blk["dgates"], 4 * H)
+        kname, bname = self._kn(blk["cell"])
+        Gk, G = self.Gr[kname], self.G
+        dg = ops.mat(blk["dgates"], G * H)
         drop = self._bdrop(blk)
-        self._gemm_tn(xin_mat, dg, Gk.mat(4 * H), E, 4 * H, rows)
+        a_att = (blk["attd"] if drop else blk["att"]).mat(-1) if A else None
+        a_h = (blk["hs_seq"] if drop else co).mat(-1)
+        self._gemm_tn(xin_mat, dg, Gk.mat(G * H), E, G * H, rows)
         if A:
-            self._gemm_tn((blk["attd"] if drop else blk["att"]).mat(-1), dg, Gk.mat(4 * H, row0=E), A, 4 * H, rows)
-        self._gemm_tn((blk["hs_seq"] if drop else co).mat(-1), dg, Gk.mat(4 * H, row0=E + A), H, 4 * H, rows)
-        ops.colsum(dg, rows, 4 * H, self.grads, self.scratch, beta=1.0, out_offset=self.G[blk["cell"] + "/bias"].off)
+            self._gemm_tn(a_att, dg, Gk.mat(G * H, row0=E), A, G * H, rows)
+        self._gemm_tn(a_h, dg, Gk.mat(G * H, row0=E + A), H, G * H, rows)
+        ops.colsum(dg, rows, G * H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
         if dxin_mat is not None:
-            ops.gemm(dg, self.P[blk["cell"] + "/kernel"].mat(4 * H), dxin_mat, rows, E, 4 * H, trans_b=1, beta=dxin_beta)
+            ops.gemm(dg, self.P[kname].mat(G * H), dxin_mat, rows, E, G * H, trans_b=1, beta=dxin_beta)
+        if self.gru:                             # candidate kernel: inputs [x ; attention ; r*h]
+            cn = blk["cell"] + "/cand_kernel"
+            Gc, dpc = self.Gr[cn], ops.mat(blk["dpc"], H)
+            self._gemm_tn(xin_mat, dpc, Gc.mat(H), E, H, rows)
+            if A:
+                self._gemm_tn(a_att, dpc, Gc.mat(H, row0=E), A, H, rows)
+            self._gemm_tn(ops.mat(blk["rh"], H), dpc, Gc.mat(H, row0=E + A), H, H, rows)
+            ops.colsum(dpc, rows, H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[blk["cell"] + "/cand_bias"].off)
+            if dxin_mat is not None:
+                ops.gemm(dpc, self.P[cn].mat(H), dxin_mat, rows, E, H, trans_b=1, beta=1.0)
 
     # ------------------------------------------------------------------------------------------------
     # AV-Align: attention-wrapped top audio layer over the video memory (encoder.py:265-290)
@@ -652,16 +700,18 @@ class Seq2SeqModel:
         E = ws["enc"]["audio"]
         blk = E["blk"]
         T, H, Ein = E["T"], blk["H"], blk["E"]
-        kname = blk["cell"] + "/kernel"
+        kname = self._kn(blk["cell"])[0]
         if self._sdrop("audio") and E["nplain"] == 0:
             ops.dropout_rows(ops.mat(E["xin"], E["F"]), ops.mat(E["xd"]["fw"], E["F"]), B * T, E["F"], self.step, blk["cell_id"] * 4,
                              blk["keep"][0], Ein + blk["A"])
         xin = self._av_xin(E)
-        ops.gemm(xin, self.P[kname].mat(4 * H), ops.mat(blk["gates"], 4 * H), B * T, 4 * H, Ein)
+        ops.gemm(xin, self.P[kname].mat(self.G * H), ops.mat(blk["gates"], self.G * H), B * T, self.G * H, Ein)
+        if self.gru:
+            ops.gemm(xin, self.P[blk["cell"] + "/cand_kernel"].mat(H), ops.mat(blk["cs"], H), B * T, H, Ein)
         self._block_prepare(ws, blk)
         blk["desc"] = self._block_desc(ws, blk, E["len"], 0, None, None, with_bwd=training)
         ops.attn_rnn_fwd(blk["desc"], 0, T)
-        E["c_fin"], E["h_fin"] = blk["cf"], blk["hf"]
+        E["c_fin"], E["h_fin"] = (None if self.gru else blk["cf"]), blk["hf"]
 
     def _av_xin(self, E):
         """Hoisted input of the attention-wrapped layer (already carrying that cell's input mask under dropout)."""
@@ -703,7 +753,7 @@ class Seq2SeqModel:
         if cfg.architecture != "bimodal":
             s = "audio" if "audio" in ws["enc"] else "video"
             E = ws["enc"][s]
-            D["h0"], D["c0"] = E["h_fin"], E["c_fin"]
+            D["h0"], D["c0"] = E["h_fin"], E["c_fin"]        # GRU: c_fin is None (state = h only)
             return
         if "c0buf" not in D:
             D["c0buf"], D["h0buf"] = torch.zeros(B, H, device=self.dev), torch.zeros(B, H, device=self.dev)
@@ -725,7 +775,7 @@ class Seq2SeqModel:
             s = "audio" if "audio" in ws["enc"] else "video"
             self._final_state_bwd(ws, s, D["dc0"], D["dh0"])
             return
-        SP, GSP = self.P["dec/state_proj"], self.G["dec/state_proj"]
+        SP, GSP = self.P["dec/state_proj"], self.Gr["dec/state_proj"]
         for si, s in enumerate(("video", "audio")):
             if s not in ws["enc"]:
                 continue
@@ -769,7 +819,9 @@ class Seq2SeqModel:
             else:
                 ops.dropout_rows(xm, xm, B * L, E, self.step, CELL_ID_DECODER * 4, cfg.decoder_dropout[0], E + A)
         if not sampling:
-            ops.gemm(xm, self.P["dec/l0/kernel"].mat(4 * H), ops.mat(D["gates"], 4 * H), B * L, 4 * H, E)
+            ops.gemm(xm, self.P[self._kn("dec/l0")[0]].mat(self.G * H), ops.mat(D["gates"], self.G * H), B * L, self.G * H, E)
+            if self.gru:
+                ops.gemm(xm, self.P["dec/l0/cand_kernel"].mat(H), ops.mat(D["cs"], H), B * L, H, E)
         self._block_prepare(ws, D)
         D["desc"] = d = self._block_desc(ws, D, batch.labels_len, 2 if sampling else 0, D["h0"], D["c0"], with_bwd=True)
         if sampling:
@@ -813,8 +865,8 @@ class Seq2SeqModel:
         # output layer
         ov, O = self._out_vec(D)
         dl = ops.mat(D["dlogits"], V)
-        self._gemm_tn(ov, dl, self.G["dec/out/kernel"].mat(V), O, V, B * L)
-        ops.colsum(dl, B * L, V, self.grads, self.scratch, beta=1.0, out_offset=self.G["dec/out/bias"].off)
+        self._gemm_tn(ov, dl, self.Gr["dec/out/kernel"].mat(V), O, V, B * L)
+        ops.colsum(dl, B * L, V, self.grads, self.scratch, beta=1.0, out_offset=self.Gr["dec/out/bias"].off)
         oa = cfg.output_attention()
         dext = D["datt_ext"] if oa else D["dcell_ext"]
         ops.gemm(dl, self.P["dec/out/kernel"].mat(V), ops.mat(dext, O), B * L, O, V, trans_b=1)

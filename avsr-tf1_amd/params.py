@@ -36,19 +36,30 @@ def lstm_bias_from_engine(b):
     return np.ascontiguousarray(b.reshape(H, 4).T.reshape(4 * H))
 
 
+def _interleave(a, G):
+    """columns g*H + u -> u*G + g (last axis)"""
+    H = a.shape[-1] // G
+    return np.ascontiguousarray(a.reshape(a.shape[:-1] + (G, H)).swapaxes(-1, -2).reshape(a.shape))
+
+
+def _deinterleave(a, G):
+    H = a.shape[-1] // G
+    return np.ascontiguousarray(a.reshape(a.shape[:-1] + (H, G)).swapaxes(-1, -2).reshape(a.shape))
+
+
 def to_engine(kind, a):
-    if kind == "lstm_kernel":
-        return lstm_kernel_to_engine(a)
-    if kind == "lstm_bias":
-        return lstm_bias_to_engine(a)
+    if kind in ("lstm_kernel", "lstm_bias"):
+        return _interleave(a, 4)
+    if kind in ("gru_gates_kernel", "gru_gates_bias"):      # GRUCell gate kernel: blocks r, u -> per unit (r, u)
+        return _interleave(a, 2)
     return np.ascontiguousarray(a)
 
 
 def from_engine(kind, a):
-    if kind == "lstm_kernel":
-        return lstm_kernel_from_engine(a)
-    if kind == "lstm_bias":
-        return lstm_bias_from_engine(a)
+    if kind in ("lstm_kernel", "lstm_bias"):
+        return _deinterleave(a, 4)
+    if kind in ("gru_gates_kernel", "gru_gates_bias"):
+        return _deinterleave(a, 2)
     return np.ascontiguousarray(a)
 
 
@@ -69,14 +80,16 @@ def inventory(cfg: ModelConfig):
             i = feat
             for l, u in enumerate(units):
                 extra = units[-1] if (attentive and l == len(units) - 1) else 0
-                inv[f"{stream}/enc/{d}/l{l}/kernel"] = ((i + extra + u, 4 * u), "lstm_kernel", "vs")
-                inv[f"{stream}/enc/{d}/l{l}/bias"] = ((4 * u,), "lstm_bias", "zeros")
+                _cell(inv, cfg, f"{stream}/enc/{d}/l{l}", i + extra, u)
                 i = u
         if attentive:
             _attention(inv, "audio/enc/att0", cfg.attention_type[0][0], cfg.memory_depth("video"), units[-1])
         if cfg.encoder_type == "bidirectional":
-            inv[f"{stream}/enc/proj_c"] = ((2 * units[-1], dec), "plain", "glorot")
-            inv[f"{stream}/enc/proj_h"] = ((2 * units[-1], dec), "plain", "glorot")
+            if cfg.cell_type == "gru":                        # encoder.py:128-131
+                inv[f"{stream}/enc/proj"] = ((2 * units[-1], dec), "plain", "glorot")
+            else:                                             # encoder.py:132-138
+                inv[f"{stream}/enc/proj_c"] = ((2 * units[-1], dec), "plain", "glorot")
+                inv[f"{stream}/enc/proj_h"] = ((2 * units[-1], dec), "plain", "glorot")
         if stream == "video" and cfg.regress_aus:
             inv["video/au/kernel"] = ((cfg.memory_depth("video"), 2), "plain", "glorot")
             inv["video/au/bias"] = ((2,), "plain", "zeros")
@@ -84,8 +97,7 @@ def inventory(cfg: ModelConfig):
     inv["dec/embedding"] = ((V, E), "plain", "emb")
     mems = cfg.decoder_memories()
     A = dec * len(mems)
-    inv["dec/l0/kernel"] = ((E + A + dec, 4 * dec), "lstm_kernel", "vs")
-    inv["dec/l0/bias"] = ((4 * dec,), "lstm_bias", "zeros")
+    _cell(inv, cfg, "dec/l0", E + A, dec)
     for i, (stream, t) in enumerate(mems):
         _attention(inv, f"dec/att{i}", t, cfg.memory_depth(stream), dec)
     O = A if cfg.output_attention() else dec
@@ -94,6 +106,17 @@ def inventory(cfg: ModelConfig):
     if cfg.architecture == "bimodal":
         inv["dec/state_proj"] = ((2 * dec, dec), "plain", "glorot")
     return inv
+
+
+def _cell(inv, cfg, prefix, in_dim, u):
+    if cfg.cell_type == "lstm":                               # cells.py:14-18
+        inv[prefix + "/kernel"] = ((in_dim + u, 4 * u), "lstm_kernel", "vs")
+        inv[prefix + "/bias"] = ((4 * u,), "lstm_bias", "zeros")
+    else:                                                     # cells.py:25-29: kernel AND bias variance-scaling initialised
+        inv[prefix + "/gates_kernel"] = ((in_dim + u, 2 * u), "gru_gates_kernel", "vs")
+        inv[prefix + "/gates_bias"] = ((2 * u,), "gru_gates_bias", "vs")
+        inv[prefix + "/cand_kernel"] = ((in_dim + u, u), "plain", "vs")
+        inv[prefix + "/cand_bias"] = ((u,), "plain", "vs")
 
 
 def _attention(inv, prefix, att_type, depth, units):
@@ -111,7 +134,8 @@ def _attention(inv, prefix, att_type, depth, units):
 
 def is_l2(name):
     """seq2seq.py:283-290: variables whose name contains 'lstm_' and not 'bias' = the RNN cell kernels."""
-    return name.endswith("/kernel") and ("/enc/fw/" in name or "/enc/bw/" in name or name.startswith("dec/l"))
+    return name.endswith(("/kernel", "/gates_kernel", "/cand_kernel")) and \
+        ("/enc/fw/" in name or "/enc/bw/" in name or name.startswith("dec/l"))
 
 
 def initialise(cfg: ModelConfig, seed=0):

@@ -113,11 +113,20 @@ typedef struct avsr_rnn_layer {
   /* DropoutWrapper buffers (NULL when dropout is off): both [B][T+2][units], slot s = time s-1 */
   float* hs_seq;                /* state-dropped h (what the next time step consumed): dWh operand */
   float* xt_seq;                /* output as seen by the consumer above (output mask x its input mask): dWx operand */
+  /* GRU (stack.cell == 1; rnn_cell_impl.GRUCell, avsr/cells.py:25-29).  wt/w/bias = gate kernel [in+H][2H] with unit-
+   * interleaved columns (2*unit + {0:r,1:u}) and its transpose; wt2/w2/bias2 = candidate kernel [in+H][H].
+   * `gates` holds [B][T][H][2] (hoisted x.Wg_x on entry), `cs` the candidate record [B][T][H] (hoisted x.Wc_x on entry),
+   * rh_seq [B][T][H] = r*h (dWc operand); backward: dgates [B][T][H][2], dgates2 [B][T][H]. */
+  const float* wt2;
+  const float* w2;
+  const float* bias2;
+  float* rh_seq;
+  float* dgates2;
 } avsr_rnn_layer;
 
 typedef struct avsr_rnn_stack {
   int32_t B, T, reverse, n_layers;
-  int32_t cell, pad_;             /* 0 = LSTM */
+  int32_t cell, pad_;             /* 0 = LSTM, 1 = GRU */
   const int32_t* len;
   const float* dh_final;          /* [B][H_top] gradient wrt the top layer's final h (may be NULL) */
   const float* dc_final;
@@ -239,6 +248,13 @@ typedef struct avsr_attn_rnn {
   float* xs;                    /* [B][L][E] */
   const int32_t* labels;        /* [B][L] */
   int32_t* fed;                 /* [B][L] tokens actually fed (fed[b][0] = GO set by the caller) */
+  /* GRU cell (cell == 1): same conventions as avsr_rnn_layer; gates [B][L][H][2], cs = candidate record [B][L][H] */
+  int32_t cell, pad4_;
+  const float* wt2;
+  const float* w2;
+  const float* bias2;
+  float* rh_seq;
+  float* dgates2;
 } avsr_attn_rnn;
 
 int avsr_attn_rnn_fwd(const avsr_attn_rnn* d, int32_t l_begin, int32_t l_end, void* stream);

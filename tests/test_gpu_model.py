@@ -28,6 +28,12 @@ CASES = {
                         attention_type=(("scaled_luong",), ("scaled_luong",)), regress_aus=True),
     "av_align_1layer_bahdanau": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32,), audio_units=(32,),
                                      attention_type=(("bahdanau",), ("luong",))),
+    "gru_audio_uni": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32),
+                          cell_type="gru", attention_type=(("scaled_luong",), ("scaled_luong",))),
+    "gru_video_bi_bahdanau": dict(architecture="unimodal", encoder_type="bidirectional", video_units=(32, 32), audio_units=None,
+                                  cell_type="gru", attention_type=(("bahdanau",), ("bahdanau",)), regress_aus=True),
+    "gru_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
+                         cell_type="gru", attention_type=(("scaled_luong",), ("normed_bahdanau",))),
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
@@ -134,6 +140,9 @@ STOCH = [
     ("c5_av_align", dict(use_dropout=True, sampling_probability=0.3)),
     ("av_align_1layer_bahdanau", dict(use_dropout=True)),
     ("c4_bimodal_uni", dict(sampling_probability=0.5)),
+    ("gru_audio_uni", dict(use_dropout=True, sampling_probability=0.3)),
+    ("gru_video_bi_bahdanau", dict(use_dropout=True)),
+    ("gru_av_align", dict(use_dropout=True, sampling_probability=0.3)),
 ]
 
 

@@ -63,6 +63,9 @@ CONFIGS = [
     dict(architecture="bimodal", encoder_type="bidirectional", video_units=(8,), audio_units=(8,), attention_type=(("bahdanau",), ("luong",))),
     dict(architecture="av_align", video_units=(8,), audio_units=(8, 8)),
     dict(architecture="av_align", video_units=(8,), audio_units=(8,), attention_type=(("bahdanau",), ("scaled_luong",))),
+    dict(architecture="unimodal", video_units=None, audio_units=(8, 8), cell_type="gru"),
+    dict(architecture="unimodal", encoder_type="bidirectional", video_units=None, audio_units=(8,), cell_type="gru"),
+    dict(architecture="av_align", video_units=(8,), audio_units=(8, 8), cell_type="gru"),
 ]
 
 
@@ -100,8 +103,9 @@ def test_config_validation_errors_follow_the_reference():
         ModelConfig(attention_type=(("luong",), ("dot",))).validate()
     with pytest.raises(ValueError):
         ModelConfig(architecture="av_align", encoder_type="bidirectional", video_units=(8,)).validate()
-    with pytest.raises(NotImplementedError):
-        ModelConfig(cell_type="gru").validate()
+    with pytest.raises(ValueError):
+        ModelConfig(architecture="bimodal", video_units=(256,), cell_type="gru").validate()   # decoder_bimodal.py:130-142
+    ModelConfig(cell_type="gru").validate()
     ModelConfig(architecture="bimodal", video_units=(256,)).validate()
 
 
