@@ -87,7 +87,10 @@ class AttnRnn(C.Structure):
                 ("sampling_prob", C.c_float), ("cell_id", C.c_int32), ("pad3_", C.c_int32),
                 ("hs_seq", C.c_void_p), ("attd", C.c_void_p), ("xs", C.c_void_p), ("labels", C.c_void_p), ("fed", C.c_void_p),
                 ("cell", C.c_int32), ("pad4_", C.c_int32), ("wt2", C.c_void_p), ("w2", C.c_void_p), ("bias2", C.c_void_p),
-                ("rh_seq", C.c_void_p), ("dgates2", C.c_void_p)]
+                ("rh_seq", C.c_void_p), ("dgates2", C.c_void_p),
+                ("beam_width", C.c_int32), ("pad5_", C.c_int32), ("length_penalty", C.c_float), ("pad6_", C.c_float),
+                ("beam_logp", C.c_void_p), ("beam_fin", C.c_void_p), ("beam_len", C.c_void_p), ("step_ids", C.c_void_p),
+                ("parent_ids", C.c_void_p), ("parent_rows", C.c_void_p)]
 
 
 class TransposeJob(C.Structure):
@@ -98,7 +101,7 @@ _STRUCTS = {"avsr_mat": Mat, "avsr_gemm_desc": GemmDesc, "avsr_rnn_layer": RnnLa
             "avsr_attn_mech": AttnMech, "avsr_attn_rnn": AttnRnn, "avsr_transpose_job": TransposeJob}
 
 EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_attn_rnn_fwd",
-           "avsr_attn_rnn_bwd", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_colsum",
+           "avsr_attn_rnn_bwd", "avsr_beam_gather_tree", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_colsum",
            "avsr_batchnorm_fwd", "avsr_batchnorm_xhat", "avsr_embed_labels", "avsr_embed_grad", "avsr_dropout_rows", "avsr_seq_loss",
            "avsr_au_loss", "avsr_normed_v", "avsr_normed_v_bwd", "avsr_reduce_scalar", "avsr_l2_regularise",
            "avsr_global_norm", "avsr_adam_step", "avsr_prof_begin", "avsr_prof_end"]
@@ -136,6 +139,7 @@ def load():
         "avsr_rnn_bwd": [C.POINTER(RnnStack), i32, vp],
         "avsr_attn_rnn_fwd": [C.POINTER(AttnRnn), i32, i32, vp],
         "avsr_attn_rnn_bwd": [C.POINTER(AttnRnn), vp],
+        "avsr_beam_gather_tree": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "avsr_attn_alpha_rows": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
         "avsr_bahdanau_dkeys": [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "avsr_transpose": [C.POINTER(TransposeJob), i32, vp],

@@ -6,13 +6,12 @@ try_restore_latest_checkpoint)` / `evaluate(checkpoint_path, epoch)` behaviour a
 (own .npz format: TF-layout weights + Adam slots + step; epoch parsed from the file name on resume, :233-249),
 `predictions/<name>/predicted_epoch_<N>.mlf`.  TensorFlow graphs/sessions/summaries do not exist here.
 
-Not built yet (raise / warn explicitly): lip-CNN front-ends (`video_processing='resnet_cnn'|...`), `'wav'` audio
-(non-functional in the reference too), beam search (greedy is used with a warning), GRU cells.
+Not built yet (raise explicitly): lip-CNN front-ends (`video_processing='resnet_cnn'|...`), `'wav'` audio
+(non-functional in the reference too), non-default cell types / losses / optimisers.
 """
 import glob
 import os
 import time
-import warnings
 from os import makedirs, path
 
 import numpy as np
@@ -103,10 +102,9 @@ class AVSR(object):
             raise NotImplementedError("video_processing=%r: the lip-CNN front-end is not built yet; feed 128-d features" % video_processing)
         if audio_processing is not None and audio_processing != 'features':
             raise NotImplementedError("audio_processing=%r (the reference's 'wav' path is non-functional as well)" % audio_processing)
-        if decoding_algorithm == 'beam_search':
-            warnings.warn("beam search is not built yet: evaluating with greedy decoding")
-        elif decoding_algorithm != 'greedy':
+        if decoding_algorithm not in ('greedy', 'beam_search'):
             raise Exception('The only supported algorithms are `greedy` and `beam_search`')     # decoder_unimodal.py:124
+        self._decoding_algorithm, self._beam_width = decoding_algorithm, beam_width
 
         reverse = {v: k for k, v in self._unit_dict.items()}
         feats = {}
@@ -238,7 +236,11 @@ class AVSR(object):
         predictions_dict, labels_dict = {}, {}
         for bd in self._iterator('evaluate'):
             batch, names = self._to_batch(bd)
-            ids = self._model.greedy_decode(batch, max_steps=self._cfg.max_label_length).cpu().numpy()
+            if self._decoding_algorithm == 'beam_search':     # avsr.py:58-59 default: width 10, first beam returned
+                ids = self._model.beam_search_decode(batch, beam_width=self._beam_width, max_steps=self._cfg.max_label_length)
+            else:
+                ids = self._model.greedy_decode(batch, max_steps=self._cfg.max_label_length)
+            ids = ids.cpu().numpy()
             for idx in range(len(names)):
                 file = names[idx].decode('utf-8')
                 predictions_dict[file] = [self._unit_dict[int(s)] for s in ids[idx]]

@@ -101,6 +101,86 @@ __global__ void sched_sample_kernel(const float* logits, long logits_sb, int V, 
   }
 }
 
+// One BeamSearchDecoder step for one utterance (block): see avsr_hip.h mode 3 and oracle.beam_search_decode.
+__global__ void beam_step_kernel(const float* logits, long logits_sb, int V, int K, int l, int eos, float w,
+                                 const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
+                                 float* logp_out, int32_t* fin_out, int32_t* len_out, int32_t* tok, int32_t* parent_rows,
+                                 int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished) {
+  extern __shared__ float sm[];          // scores [K*V] | totals [K*V]
+  float* score = sm;
+  float* total = sm + K * V;
+  const int b = blockIdx.x;
+  const float FMIN = -3.4028234663852886e38f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const int r = b * K + k;
+    const float* lg = logits + (long)r * logits_sb;
+    float mx = lg[0];
+    for (int v = 1; v < V; ++v) mx = fmaxf(mx, lg[v]);
+    float s = 0.f;
+    for (int v = 0; v < V; ++v) s += expf(lg[v] - mx);
+    const float lse = mx + logf(s);
+    const bool fin = fin_in[r] != 0;
+    const float prev = logp_in[r];
+    const int ln = len_in[r];
+    for (int v = 0; v < V; ++v) {
+      const float sl = fin ? (v == eos ? 0.f : FMIN) : lg[v] - lse;
+      const float tot = prev + sl;
+      const int nl = ln + ((fin || v == eos) ? 0 : 1);
+      total[k * V + v] = tot;
+      score[k * V + v] = tot / powf((5.0f + (float)nl) / 6.0f, w);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int alive = 0;
+    for (int j = 0; j < K; ++j) {                      // top-K by repeated arg-max, first index wins ties (tf.nn.top_k)
+      int best = -1;
+      float bs = 0.f;
+      for (int i = 0; i < K * V; ++i) {
+        const float sc = score[i];
+        if (sc != sc) continue;                         // NaN marks an already selected candidate
+        if (best < 0 || sc > bs) { best = i; bs = sc; }
+      }
+      score[best] = __builtin_nanf("");
+      const int word = best % V, parent = best / V, r = b * K + j, pr = b * K + parent;
+      const bool pf = fin_in[pr] != 0;
+      logp_out[r] = total[best];
+      fin_out[r] = (pf || word == eos) ? 1 : 0;
+      len_out[r] = len_in[pr] + (pf ? 0 : 1);
+      tok[r] = word;
+      parent_rows[r] = pr;
+      step_ids[r] = word;
+      parent_ids[r] = parent;
+      if (!fin_out[r]) ++alive;
+    }
+    if (alive) atomicAdd(n_unfinished, alive);
+  }
+}
+
+__global__ void beam_gather_tree_kernel(const int32_t* step_ids, const int32_t* parent_ids, const int32_t* beam_len, int32_t* out,
+                                        int nutt, int K, int T, int eos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nutt * K) return;
+  const int b = i / K, k = i % K, R = nutt * K;
+  int ml = 0;
+  for (int j = 0; j < K; ++j) ml = max(ml, beam_len[b * K + j]);
+  ml = min(ml, T);
+  int32_t* o = out + (long)b * T * K + k;              // out[b][t][k]
+  for (int t = 0; t < T; ++t) o[(long)t * K] = eos;
+  if (ml <= 0) return;
+  int parent = parent_ids[(long)(ml - 1) * R + b * K + k];
+  o[(long)(ml - 1) * K] = step_ids[(long)(ml - 1) * R + b * K + k];
+  for (int level = ml - 2; level >= 0; --level) {
+    o[(long)level * K] = step_ids[(long)level * R + b * K + parent];
+    parent = parent_ids[(long)level * R + b * K + parent];
+  }
+  bool seen = false;
+  for (int t = 0; t < ml; ++t) {
+    if (seen) o[(long)t * K] = eos;
+    else if (o[(long)t * K] == eos) seen = true;
+  }
+}
+
 static inline float* hbuf(const avsr_attn_rnn& d, int p) { return d.state + (long)p * d.B * d.H; }
 static inline float* cbuf(const avsr_attn_rnn& d, int p) { return d.state + (long)(2 + p) * d.B * d.H; }
 static inline float* dgroll(const avsr_attn_rnn& d, int p) { return d.dstate + (long)p * d.B * 4 * d.H; }
@@ -165,6 +245,10 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
   if (l_begin < 0 || l_end > L || l_begin > l_end) return AVSR_ERR_ARG;
   if (d.mode == 1 && (!d.embedding || !d.wout_t || !d.logits || !d.ids || !d.tok || !d.n_unfinished)) return AVSR_ERR_ARG;
   if (d.mode == 2 && (!d.embedding || !d.wout_t || !d.logits || !d.xs || !d.labels || !d.fed || !d.seed)) return AVSR_ERR_ARG;
+  if (d.mode == 3 && (!d.embedding || !d.wout_t || !d.logits || !d.tok || !d.n_unfinished || d.beam_width <= 0 || B % d.beam_width ||
+                      !d.beam_logp || !d.beam_fin || !d.beam_len || !d.step_ids || !d.parent_ids || !d.parent_rows)) return AVSR_ERR_ARG;
+  if (d.mode == 3 && (size_t)2 * d.beam_width * d.V * sizeof(float) > 60000) return AVSR_ERR_UNSUPPORTED;
+  const bool feed = (d.mode == 1 || d.mode == 3);      // inputs come from the embedding of the previous prediction
   const bool gru = d.cell == 1;
   if (gru && (!d.wt2 || !d.rh_seq)) return AVSR_ERR_ARG;
   const bool drop = d.seed && d.mode != 1 && (d.keep_in < 1.f || d.keep_state < 1.f || d.keep_out < 1.f);
@@ -199,10 +283,11 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
       StepTask& tk = SL.task[0];
       tk = StepTask{};
       const float* wt = (gru && phase == 1) ? d.wt2 : d.wt;
-      if (d.mode == 1) {
+      if (feed) {
         StepSrc& x = tk.src[tk.nsrc++];
         x.a = d.embedding; x.sb = E; x.K = E; x.w = wt; x.ldw = KW; x.kind = SRC_PLAIN;
         tk.gather = d.tok;
+        if (d.mode == 3) tk.gather2 = d.parent_rows;
       } else if (d.mode == 2) {
         StepSrc& x = tk.src[tk.nsrc++];
         x.a = d.xs + (long)l * E; x.sb = (long)L * E; x.K = E; x.w = wt; x.ldw = KW; x.kind = SRC_PLAIN;
@@ -277,8 +362,8 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
       if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
     }
 
-    if (d.mode == 1 || d.mode == 2) {
-      // ---- K4/K5: output layer + greedy / scheduled sample -----------------------------------
+    if (d.mode >= 1) {
+      // ---- K4/K5: output layer + greedy / scheduled sample / beam step ------------------------
       const bool oa = d.output_attention && A > 0;
       const int O = oa ? A : H;
       SL.ntask = 1;
@@ -288,12 +373,20 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
       if (oa) { x.a = d.att + (long)(l + 1) * A; x.sb = (long)(L + 1) * A; }
       else { x.a = d.cell_out + (long)(l + 1) * H; x.sb = (long)(L + 1) * H; }
       x.K = O; x.w = d.wout_t; x.ldw = O; x.kind = SRC_PLAIN;
-      tk.B = B; tk.N = d.V; tk.mode = EP_LINEAR; tk.t = l; tk.T = L; tk.len = d.steplen; tk.bias = d.bout;
+      tk.B = B; tk.N = d.V; tk.mode = EP_LINEAR; tk.t = l; tk.T = L; tk.len = (d.mode == 3) ? nullptr : d.steplen; tk.bias = d.bout;
       tk.p0 = d.logits + (long)l * d.V; tk.s0 = (long)L * d.V;
       if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
       if (d.mode == 1) {
         hipLaunchKernelGGL(greedy_sample_kernel, dim3(1), dim3(256), 0, s, d.logits + (long)l * d.V, (long)L * d.V, d.V,
                            d.ids + l, (long)L, d.tok, d.steplen, d.n_unfinished, B, l, d.eos_id);
+      } else if (d.mode == 3) {
+        const int K = d.beam_width, pin = l & 1, pout = (l + 1) & 1;
+        if (hipMemsetAsync(d.n_unfinished + l, 0, sizeof(int32_t), s) != hipSuccess) return AVSR_ERR_HIP;   // per-step count [L]
+        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(64), 2 * K * d.V * sizeof(float), s, d.logits + (long)l * d.V,
+                           (long)L * d.V, d.V, K, l, d.eos_id, d.length_penalty, d.beam_logp + (long)pin * B, d.beam_fin + (long)pin * B,
+                           d.beam_len + (long)pin * B, d.beam_logp + (long)pout * B, d.beam_fin + (long)pout * B,
+                           d.beam_len + (long)pout * B, d.tok, d.parent_rows, d.step_ids + (long)l * B, d.parent_ids + (long)l * B,
+                           d.n_unfinished + l);
       } else {
         hipLaunchKernelGGL(sched_sample_kernel, dim3(B), dim3(64), 0, s, d.logits + (long)l * d.V, (long)L * d.V, d.V, d.labels,
                            d.fed, d.xs, d.embedding, B, L, E, l, d.seed, d.sampling_prob, drop ? d.keep_in : 1.0f, cid4, E + A);
@@ -466,5 +559,16 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
     if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
   }
   if (!gru && d.dc0 && hipMemcpyAsync(d.dc0, dcbuf(d, 0), bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+  return AVSR_OK;
+}
+
+extern "C" int avsr_beam_gather_tree(const int32_t* step_ids, const int32_t* parent_ids, const int32_t* beam_len, int32_t* out,
+                                     int32_t n_utt, int32_t beam_width, int32_t T, int32_t eos_id, void* stream) {
+  using namespace avsr;
+  if (!step_ids || !parent_ids || !beam_len || !out || n_utt <= 0 || beam_width <= 0 || T <= 0) return AVSR_ERR_ARG;
+  const int n = n_utt * beam_width;
+  hipLaunchKernelGGL(beam_gather_tree_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, step_ids, parent_ids, beam_len, out,
+                     n_utt, beam_width, T, eos_id);
+  AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

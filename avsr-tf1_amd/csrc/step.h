@@ -39,6 +39,7 @@ struct StepTask {
   const int* len;                  // [B] valid lengths (null = all valid)
   const float* bias;               // [N]
   const int* gather;               // row gather for src[0] (embedding lookup)
+  const int* gather2;              // row gather for every other source and for the previous-state reads (beam search parents)
   // softmax-partial / slab combine (applies to the src whose kind != SRC_PLAIN)
   const float* pm; const float* pl;  // [nslab][B] chunk max / chunk sum
   long slab_stride; int nslab; int pad0;

@@ -65,7 +65,10 @@ __device__ __forceinline__ void mm16_partial(const StepTask& tk, int row0, int c
         const int arow = row0 + 16 * r + i;
         aok[r] = arow < tk.B;
         long rb = arow;
-        if (s == 0 && tk.gather && aok[r]) rb = tk.gather[arow];
+        if (aok[r]) {
+          if (s == 0 && tk.gather) rb = tk.gather[arow];
+          else if (tk.gather2) rb = tk.gather2[arow];
+        }
         ap[r] = S.a + rb * S.sb + (q << 2);
       }
       for (int c = c0; c < c1; c += UN) {
@@ -209,8 +212,9 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
         len = tk.len ? tk.len[b] : tk.T;
         valid = t < len;
         tau = tk.reverse ? len - 1 - t : t;
-        pre0 = tk.p3[(long)b * H + n];               // c_prev
-        pre1 = tk.p4[(long)b * H + n];               // h_prev
+        const long gb = tk.gather2 ? tk.gather2[b] : b;   // beam search: previous state lives in the parent's row
+        pre0 = tk.p3[gb * H + n];                    // c_prev
+        pre1 = tk.p4[gb * H + n];                    // h_prev
         if (valid) {
           if (tk.bias) pre4a = ld4(tk.bias + n * 4);
           if (tk.s2) pre4b = ld4(tk.p0 + (((long)b * tk.T + tau) * H + n) * 4);
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
       if (tk.s2) { zr += gp[0]; zu += gp[1]; }
       const float rr = fsigmoid(zr), uu = fsigmoid(zu);
       gp[0] = rr; gp[1] = uu;
-      const float rh = rr * tk.p4[(long)bb * H + u];
+      const float rh = rr * tk.p4[(long)(tk.gather2 ? tk.gather2[bb] : bb) * H + u];
       tk.p1[(long)bb * H + u] = rh;
       if (tk.p2) tk.p2[bt * H + u] = rh;
       return;
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
     }
     if constexpr (MODE == EP_GRU_CAND) {
       // p0 c~ record (+ hoisted x.Wc if s2), p1 gates record, p2 seq_out (s0,s1), p4 h_in, p6 h_out, p9/p10/p11 as LSTM fwd
-      const float hprev = tk.p4[bh];
+      const float hprev = tk.p4[(long)(tk.gather2 ? tk.gather2[bb] : bb) * H + nn];
       if (ok) {
         if (tk.bias) z += tk.bias[nn];
         if (tk.s2) z += tk.p0[bt * H + nn];

@@ -897,6 +897,77 @@ class Seq2SeqModel:
         self.apply_update()
         return self.loss, self.gnorm
 
+    def beam_search_decode(self, batch: Batch, beam_width: int = 10, length_penalty_weight: Optional[float] = None,
+                           max_steps: Optional[int] = None, check_every: int = 8, return_all: bool = False):
+        """Eval graph with BeamSearchDecoder (decoder_unimodal.py:222-271, decoder_bimodal.py:328-381): ids of beam 0,
+        int32 [B, T_out]; positions after the first EOS hold EOS (gather_tree).  length_penalty_weight defaults to the
+        reference's 0.6 (unimodal / av_align) or 0.5 (bimodal)."""
+        cfg, K = self.cfg, int(beam_width)
+        B = (batch.audio if batch.audio is not None else batch.video).shape[0]
+        L = cfg.max_label_length if max_steps is None else max_steps
+        w = length_penalty_weight if length_penalty_weight is not None else (0.5 if cfg.architecture == "bimodal" else 0.6)
+        Ta = batch.audio.shape[1] if batch.audio is not None else 0
+        Tv = batch.video.shape[1] if batch.video is not None else 0
+        ws = self._get_ws(B, Ta, Tv, 1, True)                  # encoders at batch B (decoder block of this ws is unused)
+        self._refresh_derived()
+        self._encode(ws, batch, False)
+        # tile_batch: memories, lengths and final states repeated K times; the decoder block runs on B*K rows
+        wsb = {"enc": {}, "B": B * K, "L": L}
+        for s in cfg.streams():
+            E = ws["enc"][s]
+            md = self._mem_desc(ws, s)
+            src = E["mem"] if not E["attentive"] else (E["blk"]["att"] if E["blk"]["mems"][0]["type"] in LUONG_TYPES else E["blk"]["cell_out"])
+            Eb = {"attentive": False, "mem": _Tiled(src.t, src.lead, src.T, src.D, K), "dmem": None,
+                  "len": md["len"].repeat_interleave(K).contiguous(), "T": E["T"], "units": E["units"],
+                  "h_fin": E["h_fin"].repeat_interleave(K, dim=0).contiguous(),
+                  "c_fin": None if E["c_fin"] is None else E["c_fin"].repeat_interleave(K, dim=0).contiguous()}
+            Eb["dmem"] = Eb["mem"]
+            H = cfg.decoder_units[0]
+            Eb["c_dec"], Eb["h_dec"] = torch.zeros(B * K, H, device=self.dev), torch.zeros(B * K, H, device=self.dev)
+            wsb["enc"][s] = Eb
+        mems = cfg.decoder_memories()
+        D = self._make_block(wsb, B * K, L, cfg.decoder_units[0], cfg.embedding_size, mems, "dec/l0",
+                             ["dec/att%d" % i for i in range(len(mems))], Tv=Tv, Ta=Ta, greedy=True)
+        wsb["dec"] = D
+        R, V, dev = B * K, cfg.vocab_size, self.dev
+        D["logits"] = torch.zeros(R, L, V, device=dev)
+        D["tok"] = torch.full((R,), cfg.go_id, dtype=torch.int32, device=dev)
+        D["nunf"] = torch.ones(L, dtype=torch.int32, device=dev)
+        D["steplen"] = torch.full((R,), L, dtype=torch.int32, device=dev)
+        logp = torch.full((2, B, K), float("-inf"), device=dev)
+        logp[0, :, 0] = 0.0
+        fin, ln = torch.zeros(2, R, dtype=torch.int32, device=dev), torch.zeros(2, R, dtype=torch.int32, device=dev)
+        sid, pid = torch.zeros(L, R, dtype=torch.int32, device=dev), torch.zeros(L, R, dtype=torch.int32, device=dev)
+        prow = torch.arange(R, dtype=torch.int32, device=dev)
+        self._decoder_init_state(wsb)
+        self._block_prepare(wsb, D)
+        d = self._block_desc(wsb, D, D["steplen"], 3, D["h0"], D["c0"], with_bwd=False)
+        d.output_attention = int(cfg.output_attention())
+        d.embedding = ops.fptr(self.params, self.P["dec/embedding"].off)
+        d.wout_t = ops.fptr(self.derived, self.Tr["dec/out/kernel"].off)
+        d.bout = ops.fptr(self.params, self.P["dec/out/bias"].off)
+        d.logits, d.tok, d.n_unfinished = ops.fptr(D["logits"]), ops.fptr(D["tok"]), ops.fptr(D["nunf"])
+        d.beam_width, d.length_penalty = K, float(w)
+        d.beam_logp, d.beam_fin, d.beam_len = ops.fptr(logp), ops.fptr(fin), ops.fptr(ln)
+        d.step_ids, d.parent_ids, d.parent_rows = ops.fptr(sid), ops.fptr(pid), ops.fptr(prow)
+        l = 0
+        while l < L:
+            l1 = min(L, l + check_every)
+            ops.attn_rnn_fwd(d, l, l1)
+            l = l1
+            if int(D["nunf"][l - 1].item()) == 0:
+                break
+        # dynamic_decode stops right after the first step at which every beam is finished
+        hist = D["nunf"][:l].cpu().numpy()
+        done = np.nonzero(hist == 0)[0]
+        T = int(done[0]) + 1 if len(done) else l
+        out = torch.zeros(B, T, K, dtype=torch.int32, device=dev)
+        ops.beam_gather_tree(sid, pid, ln[T & 1], out, B, K, T, cfg.eos_id)     # lengths after step T-1 live at parity T&1
+        self._last_beam = (D, T)
+        if return_all:
+            return out
+        return out[:, :, 0].contiguous()
+
     def greedy_decode(self, batch: Batch, max_steps: Optional[int] = None, check_every: int = 8):
         """Eval graph with GreedyEmbeddingHelper (decoder_unimodal.py:176-217): int32 ids [B, T_out], zeros after EOS."""
         cfg = self.cfg
@@ -929,6 +1000,22 @@ class Seq2SeqModel:
         t_out = min(int(D["steplen"].max().item()), l)   # dynamic_decode stops once every utterance has finished
         self._last_greedy = (ws, t_out)
         return D["ids"][:, :t_out].contiguous()
+
+
+class _Tiled:
+    """tile_batch view of a [B, slots, D] sequence buffer for beam search (each utterance repeated beam_width times)."""
+
+    def __init__(self, t, lead, T, D, K):
+        self.t = t.repeat_interleave(K, dim=0).contiguous()
+        self.T, self.D, self.lead = T, D, lead
+        self.slots = t.shape[1]
+        self.sb, self.st = self.slots * D, D
+
+    def off(self, dt=0, col=0):
+        return (self.lead + dt) * self.D + col
+
+    def mat(self, dt=0, col=0):
+        return ops.mat(self.t, self.D, T=self.T, ldo=self.sb, offset=self.off(dt, col))
 
 
 def desc_steplen(desc):

@@ -67,6 +67,11 @@ def attn_rnn_bwd(desc):
     check(_L().avsr_attn_rnn_bwd(C.byref(desc), _s()), "avsr_attn_rnn_bwd")
 
 
+def beam_gather_tree(step_ids, parent_ids, beam_len, out, n_utt, beam_width, T, eos_id):
+    check(_L().avsr_beam_gather_tree(fptr(step_ids), fptr(parent_ids), fptr(beam_len), fptr(out), n_utt, beam_width, T, eos_id, _s()),
+          "avsr_beam_gather_tree")
+
+
 def attn_alpha_rows(scores, dscores, mem_len, steplen, g, rowdot, B, L, T):
     check(_L().avsr_attn_alpha_rows(fptr(scores), fptr(dscores), fptr(mem_len), fptr(steplen), fptr(g), fptr(rowdot),
                                     B, L, T, _s()), "avsr_attn_alpha_rows")

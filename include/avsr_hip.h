@@ -255,10 +255,29 @@ typedef struct avsr_attn_rnn {
   const float* bias2;
   float* rh_seq;
   float* dgates2;
+  /* mode 3 = beam search (contrib.seq2seq.BeamSearchDecoder, avsr/decoder_unimodal.py:248-271, avsr/decoder_bimodal.py:358-381):
+   * the B rows are beam_width consecutive hypotheses per utterance over tile_batch'ed memories.  After every step the op
+   * scores log_softmax(logits) + beam log-prob with the length penalty ((5+len)/6)^w, keeps the top beam_width of the
+   * beam_width*V continuations per utterance (ties -> lower index), and records step_ids / parent_ids [L][B].  The next
+   * step reads its previous state through parent_rows (no state copies).  Caller initialises tok = GO, parent_rows = identity,
+   * beam_logp[0] = {0, -inf, ...} per utterance, beam_fin = beam_len = 0, steplen = L.  In this mode n_unfinished is an
+   * [L] array: entry l = number of unfinished beams after step l (dynamic_decode stops at the first 0). */
+  int32_t beam_width, pad5_;
+  float length_penalty;
+  float pad6_;
+  float* beam_logp;             /* [2][B] ping-pong */
+  int32_t* beam_fin;            /* [2][B] */
+  int32_t* beam_len;            /* [2][B] */
+  int32_t* step_ids;            /* [L][B] */
+  int32_t* parent_ids;          /* [L][B] */
+  int32_t* parent_rows;         /* [B] */
 } avsr_attn_rnn;
 
 int avsr_attn_rnn_fwd(const avsr_attn_rnn* d, int32_t l_begin, int32_t l_end, void* stream);
 int avsr_attn_rnn_bwd(const avsr_attn_rnn* d, void* stream);
+/* gather_tree over the recorded beam steps: out[b][t][k] for t < T (ids after the first EOS and past the longest beam = EOS) */
+int avsr_beam_gather_tree(const int32_t* step_ids, const int32_t* parent_ids, const int32_t* beam_len, int32_t* out,
+                          int32_t n_utt, int32_t beam_width, int32_t T, int32_t eos_id, void* stream);
 
 /* Post-loop helpers of the attention backward (see csrc/attention.hip). */
 int avsr_attn_alpha_rows(float* scores, const float* dscores, const int32_t* len, const int32_t* steplen,

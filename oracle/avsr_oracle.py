@@ -811,3 +811,91 @@ def encoder_outputs(P_np, cfg: OracleConfig, batch: Batch, training: bool, dtype
     P = to_torch(P_np, dtype)
     m = _Model(P, cfg, batch, training, dtype)
     return {s: (e.outputs.numpy(), tuple(x.numpy() for x in e.final_state)) for s, e in m.enc.items()}
+
+
+# ----------------------------------------------------------------------------------------
+# beam search (contrib.seq2seq.BeamSearchDecoder as configured by decoder_unimodal.py:248-271 /
+# decoder_bimodal.py:358-381).  Restated from the published r1.13 algorithm (beam_search_decoder.py:
+# _beam_search_step, _get_scores / _length_penalty, _mask_probs, finalize -> gather_tree); SURVEY A12 rates
+# the recall of its details "low confidence" -- parity unpinned like everything else here.
+# ----------------------------------------------------------------------------------------
+def gather_tree(step_ids: np.ndarray, parent_ids: np.ndarray, max_len: np.ndarray, end_token: int) -> np.ndarray:
+    """step_ids / parent_ids [T, B, K] -> beams [T, B, K] (gather_tree op semantics)."""
+    T, B, K = step_ids.shape
+    out = np.full((T, B, K), end_token, dtype=np.int32)
+    for b in range(B):
+        ml = min(int(max_len[b]), T)
+        if ml <= 0:
+            continue
+        for k in range(K):
+            parent = parent_ids[ml - 1, b, k]
+            out[ml - 1, b, k] = step_ids[ml - 1, b, k]
+            for level in range(ml - 2, -1, -1):
+                out[level, b, k] = step_ids[level, b, parent]
+                parent = parent_ids[level, b, parent]
+            seen = False
+            for level in range(ml):
+                if seen:
+                    out[level, b, k] = end_token
+                elif out[level, b, k] == end_token:
+                    seen = True
+    return out
+
+
+@torch.no_grad()
+def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Batch, beam_width: int = 10,
+                       length_penalty_weight: Optional[float] = None, max_steps: Optional[int] = None, dtype=torch.float64,
+                       return_all: bool = False):
+    """Returns predicted ids of beam 0, int32 [B, T_out] (`outputs.predicted_ids[:, :, 0]`, decoder_unimodal.py:269).
+    length_penalty_weight defaults to the reference's 0.6 (unimodal / av_align) or 0.5 (bimodal)."""
+    P = to_torch(P_np, dtype)
+    m = _Model(P, cfg, batch, False, dtype)
+    B, K, V, eos = m.B, beam_width, cfg.vocab_size, cfg.eos_id
+    w = length_penalty_weight if length_penalty_weight is not None else (0.5 if cfg.architecture == "bimodal" else 0.6)
+    max_steps = cfg.max_label_length if max_steps is None else max_steps
+    tile = lambda t: t.repeat_interleave(K, dim=0)                       # seq2seq.tile_batch
+    for mech in m.mechs:
+        mech.values, mech.keys, mech.mask = tile(mech.values), tile(mech.keys), tile(mech.mask)
+    state = tuple(tile(s) for s in m.init_state)
+    att = torch.zeros(B * K, m.att_dim, dtype=dtype)
+    tok = torch.full((B * K,), cfg.go_id, dtype=torch.int64)
+    logp = torch.full((B, K), -float("inf"), dtype=dtype)
+    logp[:, 0] = 0.0
+    finished = torch.zeros(B, K, dtype=torch.bool)
+    lengths = torch.zeros(B, K, dtype=torch.int64)
+    FMIN = torch.finfo(torch.float32).min
+    step_ids, parent_ids = [], []
+    for t in range(max_steps):
+        out, state, att, _ = m.step(P["dec/embedding"][tok], state, att, t)
+        step_lp = torch.log_softmax(m.logits(out), dim=-1).reshape(B, K, V)
+        fin_row = torch.full((V,), FMIN, dtype=dtype)
+        fin_row[eos] = 0.0
+        step_lp = torch.where(finished[:, :, None], fin_row[None, None, :], step_lp)     # _mask_probs
+        total = logp[:, :, None] + step_lp
+        add = torch.ones(V, dtype=torch.int64)
+        add[eos] = 0
+        new_len = lengths[:, :, None] + add[None, None, :] * (~finished)[:, :, None].to(torch.int64)
+        penalty = ((5.0 + new_len.to(dtype)) / 6.0) ** w
+        scores = (total / penalty).reshape(B, K * V)
+        # tf.nn.top_k: descending, ties -> lower index first
+        order = torch.argsort(scores, dim=1, descending=True, stable=True)[:, :K]
+        word = order % V
+        parent = order // V
+        logp = torch.gather(total.reshape(B, K * V), 1, order)
+        prev_fin = torch.gather(finished, 1, parent)
+        lengths = torch.gather(lengths, 1, parent) + (~prev_fin).to(torch.int64)
+        finished = prev_fin | (word == eos)
+        rows = (torch.arange(B)[:, None] * K + parent).reshape(-1)
+        state = tuple(s[rows] for s in state)
+        att = att[rows]
+        tok = word.reshape(-1)
+        step_ids.append(word.numpy().astype(np.int32))
+        parent_ids.append(parent.numpy().astype(np.int32))
+        if bool(finished.all()):
+            break
+    sid, pid = np.stack(step_ids), np.stack(parent_ids)
+    beams = gather_tree(sid, pid, lengths.max(dim=1).values.numpy(), eos)               # [T, B, K]
+    ids = np.ascontiguousarray(beams.transpose(1, 0, 2))                                 # [B, T, K]
+    if return_all:
+        return ids, logp.numpy(), lengths.numpy()
+    return ids[:, :, 0]

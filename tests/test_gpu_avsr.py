@@ -63,6 +63,6 @@ def test_run_experiment_bimodal(tmp_path, monkeypatch):
                         unit="character", unit_list_file=unit_file, iterations=((2, 1),), learning_rates=((0.01, 0.001),),
                         logfile="exp_av", architecture="bimodal", video_processing="features", audio_processing="features",
                         batch_size=(4, 4), encoder_units_per_layer=((32,), (32, 32)), decoder_units_per_layer=(32,), embedding_size=16,
-                        decoding_algorithm="greedy")
+                        decoding_algorithm="beam_search", beam_width=4)
     log = open("logs/exp_av").read()
     assert log.count("Average batch_loss") == 3 and "=====" in log

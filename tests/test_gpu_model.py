@@ -176,3 +176,25 @@ def test_train_step_parity_with_dropout_and_sampling(case, over):
     # eval graph: no dropout
     ids_ref = O.greedy_decode(r2["params"], ocfg, batch, max_steps=8)
     assert (model.greedy_decode(db, max_steps=8).cpu().numpy() == ids_ref).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# beam search (the reference's default decoding_algorithm, avsr.py:58): engine vs the oracle restatement
+@pytest.mark.parametrize("case", ["c1_audio_uni_luong", "c2_audio_bi_bahdanau", "c4_bimodal_uni", "c5_av_align", "gru_audio_uni"])
+@pytest.mark.parametrize("K", [1, 4])
+def test_beam_search_parity(case, K):
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    O, ocfg, mcfg, W, batch = make(case)
+    r = O.train_step(W, None, ocfg, batch)                     # move off the all-uniform initial distribution
+    W2 = {k: v.copy() for k, v in r["params"].items()}
+    W2["dec/out/bias"][ocfg.eos_id] += 1.2                     # EOS reachable within a few steps, not immediately
+    ref = O.beam_search_decode(W2, ocfg, batch, beam_width=K, max_steps=14, return_all=True)[0]
+    model = Seq2SeqModel(mcfg, weights=W2)
+    out = model.beam_search_decode(Batch.from_numpy(batch), beam_width=K, max_steps=14, check_every=3, return_all=True).cpu().numpy()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert (out == ref).all()
+    if K == 1:                                                  # width-1 beam search == greedy up to the EOS padding convention
+        g = O.greedy_decode(W2, ocfg, batch, max_steps=14)
+        T = min(g.shape[1], ref.shape[1])
+        gg = np.where(np.cumsum(g[:, :T] == ocfg.eos_id, axis=1) - (g[:, :T] == ocfg.eos_id) > 0, ocfg.eos_id, g[:, :T])
+        assert (gg == ref[:, :T, 0]).all()
