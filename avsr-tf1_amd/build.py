@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libavsr_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "step.hip", "rnn.hip", "attention.hip", "attn_rnn.hip", "elementwise.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "step.hip", "rnn.hip", "rnn_persist.hip", "attention.hip", "attn_rnn.hip", "elementwise.hip"]
 
 
 def _hipcc():
@@ -36,6 +36,7 @@ def build(force=False, verbose=False):
         o = s[:-4] + ".o"
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
                "-Wno-pass-failed", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", s, "-o", o]
+        cmd[1:1] = os.environ.get("AVSR_HIPCC_FLAGS", "").split()     # e.g. -DPERSIST_TIMING for the probes
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(o)
     for cmd, p in procs:

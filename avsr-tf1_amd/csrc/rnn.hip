@@ -10,6 +10,7 @@
 #include "avsr_hip.h"
 
 extern "C" int avsr_step_launch_raw(const void* launch, void* stream);
+int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream);
 
 namespace avsr {
 
@@ -45,6 +46,10 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
   using namespace avsr;
   if (!st || n <= 0 || n > AVSR_MAX_STACKS) return AVSR_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
+  {
+    const int rc = avsr_rnn_fwd_persistent(st, n, stream);   // one launch for the whole sequence when it fits
+    if (rc != AVSR_ERR_UNSUPPORTED) return rc;
+  }
   int nsteps = 0, ntask_max = 0;
   for (int i = 0; i < n; ++i) {
     const avsr_rnn_stack& S = st[i];

@@ -1,0 +1,379 @@
+// Persistent wavefront kernel for the masked multi-layer LSTM forward pass (opt-in fast path of avsr_rnn_fwd).
+//
+// Why: with one launch per wavefront step every step pays a dependent-launch boundary (~1.6 us), a cold-L2
+// re-read of the step's weight slice (~10 MB of fabric traffic per launch), kernel-argument setup and an
+// epilogue round trip -- ~8-10 us per step for <2 us of MFMA work (tools/step_probe.hip).  Here ONE launch
+// covers the whole sequence: every workgroup owns 16 batch rows x 8 units of one (stack, layer) cell for all
+// T steps, keeps its weight fragments in registers and its (c, h) state in registers, and the per-step
+// all-to-all (each workgroup needs the full previous h of its 16 rows, and the layer below's output) goes
+// through the sequence buffers themselves: producers store h with write-through (sc1) stores and bump a
+// per-(row-tile, time) arrival counter; consumers poll that ONE counter (relaxed, agent scope), then read the
+// rows with sc1 loads (MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility":
+// {sc1 stores + drained vmcnt + relaxed agent flag} / {relaxed poll + sc1 loads}; no dispatch-order or
+// placement assumption).  Because the exchange buffers are the time-indexed records (never a ring), a fast
+// layer can run ahead of a slow one without any overwrite hazard.
+//
+// Every spin is bounded: on timeout the workgroup raises *err and stops waiting, so a scheduling surprise
+// yields a flagged wrong result instead of a hang.  Requirements (else the caller uses the launch path):
+// LSTM, units % 8 == 0, (in + H) <= 512 per layer, total workgroups <= 512 (2 per CU: co-residency with margin).
+#include "step.h"
+#include "avsr_hip.h"
+#include "prof.h"
+
+#define P_MAX_TASKS 8
+#define P_MAXC 8
+#define P_HDR 256          // sync words reserved ahead of the counters: [0] sticky error flag, [16..] debug timing
+
+namespace avsr {
+
+struct PTask {
+  const float* wt; const float* bias; const int* len;
+  float* gates; float* cs;
+  float* out; long out_sb, out_st;          // emitted output of position tau: out + b*out_sb + tau*out_st
+  float* hs_w; long hs_sb, hs_st;           // state-dropped h of position tau (dropout only; else the output doubles as state)
+  const float* hs_r; long hsr_sb, hsr_st;   // index tau -> h consumed by the step at position tau (previous step's state)
+  const float* x_r; long x_sb, x_st;        // lower layer's output as this layer consumes it, position tau (null: hoisted)
+  float* xt_w; long xt_sb, xt_st;           // this layer's output as ITS consumer sees it (dropout only)
+  float* h_final; float* c_final;
+  int* done; const int* done_lower;         // arrival counters [nrt][T]
+  int B, T, H, in, hoisted, reverse, nct, nct_lower, wg_begin, nrt;
+  const int32_t* seed; float k_st, k_out, k_in; uint32_t r_st, r_out, r_in; int in_W, in_coff;
+};
+struct PLaunch { int ntask; int* err; PTask task[P_MAX_TASKS]; };
+
+__device__ __forceinline__ f32x4 ld4_sc1(const float* p) {
+  // 16-byte load that bypasses this CU's L1 (the line may have been rewritten by another CU since we last read it)
+  typedef unsigned long long u64;
+  const u64 a = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u64 b = __hip_atomic_load(reinterpret_cast<const u64*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  f32x4 v;
+  v[0] = __builtin_bit_cast(float, (unsigned)(a & 0xffffffffu)); v[1] = __builtin_bit_cast(float, (unsigned)(a >> 32));
+  v[2] = __builtin_bit_cast(float, (unsigned)(b & 0xffffffffu)); v[3] = __builtin_bit_cast(float, (unsigned)(b >> 32));
+  return v;
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// bounded wait for *ctr >= target; false (and *err = 1) on timeout or if another workgroup already failed
+__device__ __forceinline__ bool wait_ge(const int* ctr, int target, int* err) {
+  for (int spins = 0; spins < (1 << 21); ++spins) {
+    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+
+__device__ __forceinline__ float p_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float p_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+__device__ __forceinline__ float p_drop(const int32_t* seed, uint32_t stream, uint32_t idx, float keep) {
+  if (!seed || keep >= 1.0f) return 1.0f;
+  return uniform01((uint32_t)seed[0], stream, idx) < keep ? 1.0f / keep : 0.0f;
+}
+
+// bounded wait for (*c0 >= n0 && *c1 >= n1): both counters are fetched in the same round trip
+__device__ __forceinline__ bool wait_ge2(const int* c0, int n0, const int* c1, int n1, int* err) {
+  for (int spins = 0; spins < (1 << 21); ++spins) {
+    const int a = c0 ? __hip_atomic_load(c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n0;
+    const int b = c1 ? __hip_atomic_load(c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n1;
+    if (a >= n0 && b >= n1) return true;
+    if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+
+#define P_XC 4      // 16-wide K chunks per wave of the input part   (in  <= 256)
+#define P_HC 4      // 16-wide K chunks per wave of the recurrent part (H <= 256)
+
+__global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(const PLaunch L) {
+  __shared__ __attribute__((aligned(16))) float red[4][2][16][16];
+  int ti = 0;
+#pragma unroll
+  for (int i = 1; i < P_MAX_TASKS; ++i)
+    if (i < L.ntask && (int)blockIdx.x >= L.task[i].wg_begin) ti = i;
+  ti = __builtin_amdgcn_readfirstlane(ti);       // uniform: task fields come through scalar loads
+  const PTask& tk = L.task[ti];
+  const int local = blockIdx.x - tk.wg_begin;
+  const int rt = local / tk.nct, ct = local % tk.nct;
+  const int row0 = rt * 16, col0 = ct * 32, unit0 = ct * 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int H = tk.H, T = tk.T;
+  const int hoisted = tk.hoisted, reverse = tk.reverse;
+  const int Kx = hoisted ? 0 : tk.in;
+  // K split: every wave takes a quarter of the input chunks AND a quarter of the recurrent chunks, so the
+  // recurrent part -- the only one on the step-to-step critical path -- is spread over all four SIMDs
+  const int ncx = (Kx + 15) >> 4, nchh = (H + 15) >> 4;
+  const int xg0 = (wave * ncx) / 4, nxw = ((wave + 1) * ncx) / 4 - xg0;      // <= P_XC (host-checked)
+  const int hg0 = (wave * nchh) / 4, nhw = ((wave + 1) * nchh) / 4 - hg0;    // <= P_HC
+  const long ldw = tk.in + H;
+
+  // ---- weights of this workgroup's 32 gate columns: registers for the whole sequence ----
+  f32x4 wx[P_XC][2], wh[P_HC][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = col0 + nt * 16 + i;
+#pragma unroll
+    for (int c = 0; c < P_XC; ++c) {
+      const int k = (xg0 + c) * 16 + 4 * q;
+      wx[c][nt] = (c < nxw && col < 4 * H && k < Kx) ? ld4(tk.wt + (long)col * ldw + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < P_HC; ++c) {
+      const int k = (hg0 + c) * 16 + 4 * q;
+      wh[c][nt] = (c < nhw && col < 4 * H && k < H) ? ld4(tk.wt + (long)col * ldw + tk.in + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  // ---- per-thread epilogue ownership: thread e (< 128) owns (row er, unit eu) for all steps ----
+  const int er = tid >> 3, eu = tid & 7;
+  const int b = row0 + er, u = unit0 + eu;
+  const bool eok = tid < 128 && b < tk.B && u < H;
+  const int len_b = eok ? (tk.len ? tk.len[b] : T) : 0;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (eok && tk.bias) bias4 = ld4(tk.bias + u * 4);
+  float c_state = 0.f, h_state = 0.f;
+
+  // A-operand row of this lane; 32-bit element offsets from uniform bases (host checks spans < 2^31 elements)
+  const int ab = row0 + i;
+  const bool aok = ab < tk.B;
+  const int len_a = aok ? (tk.len ? tk.len[ab] : T) : 0;
+  const int xrow = (int)(ab * tk.x_sb) + 4 * q, hrow = (int)(ab * tk.hsr_sb) + 4 * q;
+  const int x_st = (int)tk.x_st, h_st = (int)tk.hsr_st;
+  const float* const x_r = tk.x_r; const float* const hs_r = tk.hs_r;
+  const int nct = tk.nct, nct_lower = tk.nct_lower;
+  int* const done_mine = tk.done + (long)rt * T;
+  const int* const done_low = hoisted ? nullptr : tk.done_lower + (long)rt * T;
+  const int rec_b = b * T * H + u;                       // gates record: *4, cs record: *1
+  const int out_b = (int)(b * tk.out_sb) + u, hsw_b = (int)(b * tk.hs_sb) + u, xtw_b = (int)(b * tk.xt_sb) + u;
+  const int out_st = (int)tk.out_st, hs_st = (int)tk.hs_st, xt_st = (int)tk.xt_st;
+  float* const gates_p = tk.gates; float* const cs_p = tk.cs; float* const out_p = tk.out;
+  float* const hsw_p = tk.hs_w; float* const xtw_p = tk.xt_w;
+  const int32_t* const seed = tk.seed;
+  const float k_st = tk.k_st, k_out = tk.k_out, k_in = tk.k_in;
+  const uint32_t r_st = tk.r_st, r_out = tk.r_out, r_in = tk.r_in;
+  const int in_W = tk.in_W, in_coff = tk.in_coff;
+
+  // input-part operands run one step ahead of the recurrence: x(t+1) is fetched during step t
+  f32x4 xcur[P_XC];
+#pragma unroll
+  for (int c = 0; c < P_XC; ++c) xcur[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_x = [&](int t, f32x4* dst) {
+    const bool v = aok && t < len_a;
+    const int xo = xrow + (reverse ? len_a - 1 - t : t) * x_st;
+#pragma unroll
+    for (int c = 0; c < P_XC; ++c) {
+      const int k = (xg0 + c) * 16;
+      dst[c] = (c < nxw && v && k + 4 * q < Kx) ? ld4_sc1(x_r + (xo + k)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if (done_low) {
+    if (tid == 0) wait_ge2(done_low, nct_lower, nullptr, 0, L.err);
+    __syncthreads();
+    load_x(0, xcur);
+  }
+
+  f32x4 znext = {0.f, 0.f, 0.f, 0.f};
+  if (eok && hoisted && 0 < len_b) znext = ld4(gates_p + (long)(rec_b + (reverse ? len_b - 1 : 0) * H) * 4);
+#ifdef PERSIST_TIMING
+  long tm[6] = {0, 0, 0, 0, 0, 0};
+#define TICK(k) { const long now_ = __builtin_amdgcn_s_memtime(); tm[k] += now_ - last_; last_ = now_; }
+#else
+#define TICK(k)
+#endif
+  for (int t = 0; t < T; ++t) {
+#ifdef PERSIST_TIMING
+    long last_ = __builtin_amdgcn_s_memtime();
+#endif
+    const f32x4 zpre = znext;
+    // ---- dependencies: previous step of this layer (all column tiles of my row tile); layer below one step ahead ----
+    if (tid == 0) {
+      const int tl = t + 1 < T ? t + 1 : T - 1;
+      wait_ge2(t > 0 ? done_mine + (t - 1) : nullptr, nct, done_low ? done_low + tl : nullptr, nct_lower, L.err);
+    }
+    __syncthreads();
+    TICK(0)
+
+    // ---- recurrent operand rows (sc1: produced by other CUs during this launch), next step's input rows ----
+    const bool avalid = aok && t < len_a;
+    const int ho_ = hrow + (reverse ? len_a - 1 - t : t) * h_st;
+    f32x4 hv[P_HC];
+#pragma unroll
+    for (int c = 0; c < P_HC; ++c) {
+      const int k = (hg0 + c) * 16;
+      hv[c] = (c < nhw && avalid && t > 0 && k + 4 * q < H) ? ld4_sc1(hs_r + (ho_ + k)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) acc[nt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // input part first: its operands arrived a step ago, so these MFMAs run under the loads just issued
+#pragma unroll
+    for (int c = 0; c < P_XC; ++c)
+      if (c < nxw) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[nt][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xcur[c][e], wx[c][nt][e], acc[nt][e & 1], 0, 0, 0);
+      }
+    if (done_low && t + 1 < T) load_x(t + 1, xcur);      // refill in place: consumed a step from now
+    // hoisted x.Wx of the NEXT step (written before this launch, cold in HBM).  Issued last: vmcnt retires in
+    // order, so a slow load must be younger than the recurrent operands or it would stall their wait.
+#ifndef PROBE_NOZ
+    if (eok && hoisted && t + 1 < len_b) znext = ld4(gates_p + (long)(rec_b + (reverse ? len_b - 2 - t : t + 1) * H) * 4);
+#endif
+    asm volatile("" ::: "memory");
+#ifdef PERSIST_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TICK(1)
+#endif
+#pragma unroll
+    for (int c = 0; c < P_HC; ++c)
+      if (c < nhw) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[nt][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[c][e], wh[c][nt][e], acc[nt][e & 1], 0, 0, 0);
+      }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const f32x4 s4 = acc[nt][0] + acc[nt][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][nt][(lane >> 4) * 4 + r][lane & 15] = s4[r];
+    }
+    __syncthreads();
+    TICK(2)
+
+    // ---- gates, cell clip, length masking, dropout; records + exchanged outputs ----
+    if (eok) {
+      const bool valid = t < len_b;
+      if (valid) {
+        const int tau = reverse ? len_b - 1 - t : t;
+        const long bt = (long)b * T + tau;
+        f32x4 z = bias4 + zpre;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cc = eu * 4 + g;
+          z[g] += red[0][cc >> 4][er][cc & 15] + red[1][cc >> 4][er][cc & 15] + red[2][cc >> 4][er][cc & 15] + red[3][cc >> 4][er][cc & 15];
+        }
+        f32x4 g4;
+        g4[0] = p_sigmoid(z[0]); g4[1] = p_tanh(z[1]); g4[2] = p_sigmoid(z[2] + 1.0f); g4[3] = p_sigmoid(z[3]);
+        float c = g4[2] * c_state + g4[0] * g4[1];
+        c = fminf(1.0f, fmaxf(-1.0f, c));
+        const float h = g4[3] * p_tanh(c);
+        const uint32_t oidx = (uint32_t)(bt * H + u);
+        const float ho = h * p_drop(seed, r_out, oidx, k_out);
+        const float hs = h * p_drop(seed, r_st, oidx, k_st);
+        st_sc1(out_p + (out_b + tau * out_st), ho);                 // exchanged values first, records after
+        if (hsw_p) st_sc1(hsw_p + (hsw_b + tau * hs_st), hs);
+        if (xtw_p) st_sc1(xtw_p + (xtw_b + tau * xt_st), ho * p_drop(seed, r_in, (uint32_t)(bt * in_W + in_coff + u), k_in));
+#ifndef PROBE_NOREC
+        st4(gates_p + (long)(rec_b + tau * H) * 4, g4);
+        cs_p[rec_b + tau * H] = c;
+#endif
+        c_state = c;
+        h_state = hs;
+      } else {                     // past the utterance: zero output at padding position t, state carried in registers
+        st_sc1(out_p + (out_b + t * out_st), 0.f);
+        if (hsw_p) st_sc1(hsw_p + (hsw_b + t * hs_st), 0.f);
+        if (xtw_p) st_sc1(xtw_p + (xtw_b + t * xt_st), 0.f);
+      }
+    }
+    TICK(3)
+    // ---- publish: every storing wave drains its write-through stores, then ONE arrival per workgroup ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    TICK(4)
+    if (tid == 0) __hip_atomic_fetch_add(done_mine + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    TICK(5)
+  }
+#ifdef PERSIST_TIMING
+  if (tid == 0 && local == 0)
+    for (int k = 0; k < 6; ++k) L.err[16 + ti * 8 + k] = (int)(tm[k] / T);
+#endif
+  if (eok) {
+    if (tk.h_final) tk.h_final[(long)b * H + u] = h_state;
+    if (tk.c_final) tk.c_final[(long)b * H + u] = c_state;
+  }
+}
+
+static int32_t* g_sync = nullptr;
+static int64_t g_sync_ints = 0;
+
+}  // namespace avsr
+
+// sync: int32 device scratch [ints] owned by the caller: word 0 = sticky error flag (zero it when installing),
+// words 1.. = arrival counters (zeroed by every persistent call).  NULL disables the persistent path.
+extern "C" int avsr_rnn_set_persistent(int32_t* sync, int64_t ints) {
+  avsr::g_sync = sync; avsr::g_sync_ints = sync ? ints : 0;
+  return AVSR_OK;
+}
+
+// Returns AVSR_ERR_UNSUPPORTED when the persistent path is disabled or the configuration does not fit it
+// (avsr_rnn_fwd then uses one launch per wavefront step).
+int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream) {
+  using namespace avsr;
+  int32_t* sync = g_sync; const int64_t sync_ints = g_sync_ints;
+  if (!sync) return AVSR_ERR_UNSUPPORTED;
+  static thread_local PLaunch L;
+  L = PLaunch{};
+  int wg = 0;
+  long ctr = P_HDR;
+  for (int i = 0; i < n; ++i) {
+    const avsr_rnn_stack& S = st[i];
+    if (S.cell != 0) return AVSR_ERR_UNSUPPORTED;
+    const int nrt = (S.B + 15) / 16;
+    for (int l = 0; l < S.n_layers; ++l) {
+      const avsr_rnn_layer& Ly = S.layer[l];
+      if (L.ntask >= P_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
+      const int H = Ly.units, in = Ly.in_dim;
+      if ((long)S.B * (S.T + 2) * (Ly.ld_out > 4 * H ? Ly.ld_out : 4 * H) >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
+      if (H % 8 || !Ly.out || H > 64 * P_HC || (!Ly.hoisted && in > 64 * P_XC) || in % 4) return AVSR_ERR_UNSUPPORTED;
+      if (!Ly.hoisted && l == 0) return AVSR_ERR_UNSUPPORTED;
+      if (S.seed && !Ly.hs_seq) return AVSR_ERR_UNSUPPORTED;
+      PTask& tk = L.task[L.ntask++];
+      tk.wt = Ly.wt; tk.bias = Ly.bias; tk.len = S.len;
+      tk.gates = Ly.gates; tk.cs = Ly.cs;
+      tk.out = Ly.out + Ly.ld_out + Ly.out_col; tk.out_sb = (long)(S.T + 2) * Ly.ld_out; tk.out_st = Ly.ld_out;
+      const float* hseq; long hld;
+      if (S.seed) { tk.hs_w = Ly.hs_seq + H; tk.hs_sb = (long)(S.T + 2) * H; tk.hs_st = H; hseq = Ly.hs_seq; hld = H; }
+      else { hseq = Ly.out + Ly.out_col; hld = Ly.ld_out; }
+      tk.hs_r = hseq + (S.reverse ? 2 * hld : 0); tk.hsr_sb = (long)(S.T + 2) * hld; tk.hsr_st = hld;
+      if (!Ly.hoisted) {
+        const avsr_rnn_layer& Lo = S.layer[l - 1];
+        if (S.seed) { if (!Lo.xt_seq) return AVSR_ERR_UNSUPPORTED; tk.x_r = Lo.xt_seq + Lo.units; tk.x_sb = (long)(S.T + 2) * Lo.units; tk.x_st = Lo.units; }
+        else { tk.x_r = Lo.out + Lo.ld_out + Lo.out_col; tk.x_sb = (long)(S.T + 2) * Lo.ld_out; tk.x_st = Lo.ld_out; }
+      }
+      if (S.seed && Ly.xt_seq) { tk.xt_w = Ly.xt_seq + H; tk.xt_sb = (long)(S.T + 2) * H; tk.xt_st = H; }
+      tk.h_final = Ly.h_final; tk.c_final = Ly.c_final;
+      tk.B = S.B; tk.T = S.T; tk.H = H; tk.in = in; tk.hoisted = Ly.hoisted; tk.reverse = S.reverse;
+      tk.nct = H / 8; tk.nrt = nrt; tk.wg_begin = wg;
+      wg += nrt * tk.nct;
+      tk.done = sync + ctr;
+      ctr += (long)nrt * S.T;
+      if (!Ly.hoisted) { tk.done_lower = L.task[L.ntask - 2].done; tk.nct_lower = L.task[L.ntask - 2].nct; }
+      if (S.seed) {
+        const uint32_t cid = (uint32_t)(S.cell_id_base + l);
+        tk.seed = S.seed; tk.k_st = S.keep_state; tk.k_out = S.keep_out; tk.k_in = 1.0f;
+        tk.r_st = cid * 4 + 1; tk.r_out = cid * 4 + 2;
+        if (l + 1 < S.n_layers) { tk.k_in = S.keep_in; tk.r_in = (cid + 1) * 4; tk.in_W = H; tk.in_coff = 0; }
+        else if (S.consumer_width > 0) { tk.k_in = S.consumer_keep; tk.r_in = (uint32_t)S.consumer_stream; tk.in_W = S.consumer_width; tk.in_coff = 0; }
+      }
+    }
+  }
+  if (wg > 512 || ctr > sync_ints) return AVSR_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (ctr - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
+  L.err = sync;
+  {
+    ProfScope ps(PROF_STEP_LSTM_FWD, s);
+    hipLaunchKernelGGL(rnn_persist_fwd_kernel, dim3(wg), dim3(256), 0, s, L);
+  }
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}

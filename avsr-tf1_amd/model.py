@@ -17,6 +17,8 @@ from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -92,6 +94,9 @@ class Seq2SeqModel:
         _lib.load()
         self.cfg, self.dev = cfg, torch.device(device)
         self.gru = cfg.cell_type == "gru"
+        # one-launch persistent encoder forward (csrc/rnn_persist.hip); process-wide engine switch
+        self.persistent_rnn = os.environ.get("AVSR_PERSISTENT_RNN", "0") == "1"
+        ops.rnn_set_persistent(self.persistent_rnn, device=device)
         self.G = 2 if self.gru else 4                       # gate pre-activations per unit of the main cell kernel
         self.inv = PR.inventory(cfg)
         # ---- flat parameter storage (engine layout) ------------------------------------------------

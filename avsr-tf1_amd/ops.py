@@ -176,3 +176,23 @@ def prof_end():
     ms = (C.c_float * len(PROF_KINDS))()
     check(_L().avsr_prof_end(cnt, ms), "avsr_prof_end")
     return {k: (int(cnt[i]), float(ms[i])) for i, k in enumerate(PROF_KINDS)}
+
+
+_persist_sync = None
+
+
+def rnn_set_persistent(on, device="cuda", ints=1 << 20):
+    """Enable / disable the one-launch persistent execution of avsr_rnn_fwd (see include/avsr_hip.h)."""
+    global _persist_sync
+    if on:
+        if _persist_sync is None:
+            _persist_sync = torch.zeros(ints, dtype=torch.int32, device=device)
+        _persist_sync[:1].zero_()
+        check(_L().avsr_rnn_set_persistent(_persist_sync.data_ptr(), ints), "avsr_rnn_set_persistent")
+    else:
+        check(_L().avsr_rnn_set_persistent(None, 0), "avsr_rnn_set_persistent")
+
+
+def rnn_persistent_error():
+    """Sticky flag: a device-side bounded wait of the persistent kernel expired (results of that call are invalid)."""
+    return bool(_persist_sync is not None and int(_persist_sync[:1].item()) != 0)

@@ -144,6 +144,14 @@ typedef struct avsr_rnn_stack {
 int avsr_rnn_fwd(const avsr_rnn_stack* stacks, int32_t n_stacks, void* stream);
 int avsr_rnn_bwd(const avsr_rnn_stack* stacks, int32_t n_stacks, void* stream);
 
+/* Opt-in persistent execution of avsr_rnn_fwd (LSTM stacks): ONE launch runs the whole layer/time wavefront,
+ * weights and (c, h) state stay in registers, steps are ordered by device-side arrival counters instead of
+ * launch boundaries.  `sync` = caller-owned int32 device scratch of `ints` words: word 0 is a sticky error flag
+ * (a bounded wait expired; zero it before installing, read it back to check), the rest are counters
+ * (needs 1 + sum over layers of ceil(B/16)*T).  NULL disables.  Configurations that do not fit (GRU,
+ * units %% 8, in+units > 512, > 512 workgroups) silently use the per-step launches.  Same results either way. */
+int avsr_rnn_set_persistent(int32_t* sync, int64_t ints);
+
 /* ---------------------------------------------------------------------------------------------
  * Attention-wrapped LSTM over a sequence.  Replaces
  *   seq2seq.dynamic_decode(BasicDecoder(AttentionWrapper(LSTMCell, [mechanisms]), helper, Dense(V)))

@@ -97,9 +97,10 @@ def _oracle_stack(x, lens, Ws, bs, reverse, R_out, R_h, R_c):
             [P[f"s/l{l}/bias"].grad.numpy() for l in range(len(Ws))])
 
 
+@pytest.mark.parametrize("persistent", [0, 1])
 @pytest.mark.parametrize("reverse", [0, 1])
 @pytest.mark.parametrize("units", [(32,), (32, 48, 32)])
-def test_rnn_stack_fwd_bwd(units, reverse):
+def test_rnn_stack_fwd_bwd(units, reverse, persistent):
     from avsr_tf1_amd import ops, params as PR
     from avsr_tf1_amd._lib import RnnLayer, RnnStack
     rng = np.random.default_rng(11 + reverse + len(units))
@@ -155,8 +156,13 @@ def test_rnn_stack_fwd_bwd(units, reverse):
     top.dout, top.ld_dout, top.dout_col = dout.data_ptr(), Htop, 0
     st.dh_final, st.dc_final = dhf.data_ptr(), dcf.data_ptr()
 
-    ops.rnn_fwd([st])
-    torch.cuda.synchronize()
+    ops.rnn_set_persistent(bool(persistent))      # one persistent launch vs one launch per wavefront step
+    try:
+        ops.rnn_fwd([st])
+        torch.cuda.synchronize()
+        assert not ops.rnn_persistent_error()
+    finally:
+        ops.rnn_set_persistent(False)
     out = bufs[-1]["out"][:, 1:T + 1].cpu().numpy()
     assert np.abs(out - o_out).max() < 2e-5
     assert np.abs(bufs[-1]["hf"].cpu().numpy() - o_h).max() < 2e-5

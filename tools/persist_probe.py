@@ -1,0 +1,20 @@
+"""Phase timing of the persistent encoder kernel (build with AVSR_HIPCC_FLAGS=-DPERSIST_TIMING).
+Prints, per (stack, layer) task, the mean shader-clock ticks per step that workgroup 0 of the task spent in:
+wait | operand loads | mfma+lds | epilogue issue | store drain | arrival atomic."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["AVSR_PERSISTENT_RNN"] = "1"
+sys.argv = [sys.argv[0], "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-graph"] + sys.argv[1:]
+import bench  # noqa: E402
+
+bench.main()
+from avsr_tf1_amd import ops  # noqa: E402
+
+h = ops._persist_sync[:256].cpu().numpy()
+print("err", h[0])
+for ti in range(8):
+    r = h[16 + ti * 8:16 + ti * 8 + 6]
+    if r.any():
+        print("task", ti, "ticks/step: wait %d loads %d mfma %d epi %d drain %d atomic %d  total %d" % (*r, r.sum()))
