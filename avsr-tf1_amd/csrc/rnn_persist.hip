@@ -36,10 +36,10 @@ struct PTask {
   float* xt_w; long xt_sb, xt_st;           // this layer's output as ITS consumer sees it (dropout only)
   float* h_final; float* c_final;
   int* done; const int* done_lower;         // arrival counters [nrt][T]
-  int B, T, H, in, hoisted, reverse, nct, nct_lower, wg_begin, nrt;
+  int B, T, H, in, hoisted, reverse, nct, nct_lower, wg_begin, nrt, uw;
   const int32_t* seed; float k_st, k_out, k_in; uint32_t r_st, r_out, r_in; int in_W, in_coff;
 };
-struct PLaunch { int ntask; int* err; PTask task[P_MAX_TASKS]; };
+struct PLaunch { int ntask, wpx, ngroups; int* err; int* claim; PTask task[P_MAX_TASKS]; };
 
 __device__ __forceinline__ f32x4 ld4_sc1(const float* p) {
   // 16-byte load that bypasses this CU's L1 (the line may have been rewritten by another CU since we last read it)
@@ -84,6 +84,11 @@ __device__ __forceinline__ bool wait_ge2(const int* c0, int n0, const int* c1, i
   return false;
 }
 
+#ifdef PERSIST_TIMING
+#define TICK(k) { const long now_ = __builtin_amdgcn_s_memtime(); tm[k] += now_ - last_; last_ = now_; }
+#else
+#define TICK(k)
+#endif
 #define P_XC 4      // 16-wide K chunks per wave of the input part   (in  <= 256)
 #define P_HC 4      // 16-wide K chunks per wave of the recurrent part (H <= 256)
 
@@ -179,9 +184,6 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(const PLaunch L) {
   if (eok && hoisted && 0 < len_b) znext = ld4(gates_p + (long)(rec_b + (reverse ? len_b - 1 : 0) * H) * 4);
 #ifdef PERSIST_TIMING
   long tm[6] = {0, 0, 0, 0, 0, 0};
-#define TICK(k) { const long now_ = __builtin_amdgcn_s_memtime(); tm[k] += now_ - last_; last_ = now_; }
-#else
-#define TICK(k)
 #endif
   for (int t = 0; t < T; ++t) {
 #ifdef PERSIST_TIMING
@@ -302,7 +304,263 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(const PLaunch L) {
   }
 }
 
+
+// ======================================================================================================
+// XCD-local variant.  Batch rows are independent, so the batch is cut into groups of 8 rows and every group
+// is bound to ONE XCD: all (stack, layer, column-tile) workgroups of a group share that XCD's L2, the only
+// coherence point they need.  Hand-off inside an XCD (tools/xcd_probe.hip: 0.44 us per hop against 1.0-1.1 us
+// for the agent-scope forms): plain stores (the line stays in the L2) -> s_waitcnt -> per-workgroup progress
+// word; consumers poll the progress words of their row group with ONE coalesced L1-bypassing load and read the
+// rows with 16-byte sc1 (L1-bypass, L2-served) loads.
+// Placement is never assumed: a workgroup READS its XCC_ID and claims a slot of that XCD's group from a
+// per-XCD counter, so every member of a group is physically on the group's XCD whatever the dispatcher did.
+// Only liveness depends on the dispatcher handing each XCD its share of the grid; every wait is bounded and a
+// miss raises the sticky error word (the host then switches the path off).
+// ======================================================================================================
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf; }   // HW_REG_XCC_ID[3:0]
+__device__ __forceinline__ f32x4 ldx_sc1(__amdgpu_buffer_rsrc_t r, int elem_off) {
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(r, elem_off * 4, 0, 16);                      // aux 16 = sc1
+  return __builtin_bit_cast(f32x4, v);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rnn_persist_fwd_xcd_kernel(const PLaunch L) {
+  __shared__ __attribute__((aligned(16))) float red[4][4][8][16];
+  __shared__ int s_slot;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = __builtin_amdgcn_readfirstlane(xcc_id());
+  if (tid == 0) s_slot = __hip_atomic_fetch_add(L.claim + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int slot = __builtin_amdgcn_readfirstlane(s_slot);
+  if (g >= L.ngroups || slot >= L.wpx) return;
+  int ti = 0;
+#pragma unroll
+  for (int i = 1; i < P_MAX_TASKS; ++i)
+    if (i < L.ntask && slot >= L.task[i].wg_begin) ti = i;
+  ti = __builtin_amdgcn_readfirstlane(ti);
+  const PTask& tk = L.task[ti];
+  const int ct = slot - tk.wg_begin;
+  const int UW = tk.uw, uw_shift = UW == 16 ? 4 : 3;
+  const int row0 = g * 8, col0 = ct * UW * 4, unit0 = ct * UW;
+  const int i = lane & 15, q = lane >> 4;
+  const int H = tk.H, T = tk.T;
+  const int hoisted = tk.hoisted, reverse = tk.reverse;
+  const bool wide = hoisted && UW == 16;          // recurrent-only layer: the input-part registers hold two more column tiles
+  const int Kx = hoisted ? 0 : tk.in;
+  const int ncx = (Kx + 15) >> 4, nchh = (H + 15) >> 4;
+  const int xg0 = (wave * ncx) / 4, nxw = ((wave + 1) * ncx) / 4 - xg0;
+  const int hg0 = (wave * nchh) / 4, nhw = ((wave + 1) * nchh) / 4 - hg0;
+  const long ldw = tk.in + H;
+
+  f32x4 wa[P_XC][2], wb[P_HC][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = col0 + nt * 16 + i;
+#pragma unroll
+    for (int c = 0; c < P_HC; ++c) {
+      const int k = (hg0 + c) * 16 + 4 * q;
+      wb[c][nt] = (c < nhw && col < 4 * H && k < H) ? ld4(tk.wt + (long)col * ldw + tk.in + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < P_XC; ++c) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (wide) {
+        const int k = (hg0 + c) * 16 + 4 * q, col2 = col + 32;
+        if (c < nhw && col2 < 4 * H && k < H) v = ld4(tk.wt + (long)col2 * ldw + tk.in + k);
+      } else {
+        const int k = (xg0 + c) * 16 + 4 * q;
+        if (c < nxw && col < 4 * H && k < Kx) v = ld4(tk.wt + (long)col * ldw + k);
+      }
+      wa[c][nt] = v;
+    }
+  }
+
+  // epilogue ownership: thread e (< 8 * UW) owns (row er, unit eu) for all steps
+  const int er = tid >> uw_shift, eu = tid & (UW - 1);
+  const int b = row0 + er, u = unit0 + eu;
+  const bool eok = tid < 8 * UW && b < tk.B && u < H;
+  const int len_b = eok ? (tk.len ? tk.len[b] : T) : 0;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (eok && tk.bias) bias4 = ld4(tk.bias + u * 4);
+  float c_state = 0.f, h_state = 0.f;
+
+  const int ab = row0 + i;
+  const bool aok = i < 8 && ab < tk.B;
+  const int len_a = aok ? (tk.len ? tk.len[ab] : T) : 0;
+  const int xrow = (int)(ab * tk.x_sb) + 4 * q, hrow = (int)(ab * tk.hsr_sb) + 4 * q;
+  const int x_st = (int)tk.x_st, h_st = (int)tk.hsr_st;
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)tk.x_r, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc((void*)tk.hs_r, 0, 0xffffffff, 0x00020000);
+  const bool has_low = !hoisted;
+  // progress words: 32 per (task, group); wave 0 polls own (lanes 0-31) and lower (lanes 32-63) in one load
+  int* const my_flag = tk.done + g * 32 + ct;
+  const int* poll_ptr = nullptr;
+  if (wave == 0) {
+    if (lane < 32) { if (lane < tk.nct) poll_ptr = tk.done + g * 32 + lane; }
+    else if (has_low && lane - 32 < tk.nct_lower) poll_ptr = tk.done_lower + g * 32 + (lane - 32);
+  }
+  const int rec_b = b * T * H + u;
+  const int out_b = (int)(b * tk.out_sb) + u, hsw_b = (int)(b * tk.hs_sb) + u, xtw_b = (int)(b * tk.xt_sb) + u;
+  const int out_st = (int)tk.out_st, hs_st = (int)tk.hs_st, xt_st = (int)tk.xt_st;
+  float* const gates_p = tk.gates; float* const cs_p = tk.cs; float* const out_p = tk.out;
+  float* const hsw_p = tk.hs_w; float* const xtw_p = tk.xt_w;
+  const int32_t* const seed = tk.seed;
+  const float k_st = tk.k_st, k_out = tk.k_out, k_in = tk.k_in;
+  const uint32_t r_st = tk.r_st, r_out = tk.r_out, r_in = tk.r_in;
+  const int in_W = tk.in_W, in_coff = tk.in_coff;
+
+  // wave 0: wait until own progress >= need_own and lower progress >= need_low (bounded)
+  auto wait_progress = [&](int need_own, int need_low) {
+    if (wave != 0) return;
+    const int need = lane < 32 ? need_own : need_low;
+    for (int spins = 0; spins < (1 << 21); ++spins) {
+      const int v = poll_ptr ? __hip_atomic_load(poll_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+      if (__all(v >= need)) return;
+      if ((spins & 1023) == 1023 && __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
+    if (lane == 0) __hip_atomic_store(L.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  f32x4 xcur[P_XC];
+#pragma unroll
+  for (int c = 0; c < P_XC; ++c) xcur[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_x = [&](int t, f32x4* dst) {
+    const bool v = aok && t < len_a;
+    const int xo = xrow + (reverse ? len_a - 1 - t : t) * x_st;
+#pragma unroll
+    for (int c = 0; c < P_XC; ++c) {
+      const int k = (xg0 + c) * 16;
+      dst[c] = (c < nxw && v && k + 4 * q < Kx) ? ldx_sc1(x_rs, xo + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if (has_low) {
+    wait_progress(0, 1);
+    __syncthreads();
+    load_x(0, xcur);
+  }
+  f32x4 znext = {0.f, 0.f, 0.f, 0.f};
+  if (eok && hoisted && 0 < len_b) znext = ld4(gates_p + (long)(rec_b + (reverse ? len_b - 1 : 0) * H) * 4);
+#ifdef PERSIST_TIMING
+  long tm[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  for (int t = 0; t < T; ++t) {
+#ifdef PERSIST_TIMING
+    long last_ = __builtin_amdgcn_s_memtime();
+#endif
+    const f32x4 zpre = znext;
+    // dependencies: step t-1 of this layer (all column tiles of my rows); the layer below one step ahead
+    wait_progress(t, t + 2 < T ? t + 2 : T);
+    __syncthreads();
+    TICK(0)
+    const bool avalid = aok && t < len_a;
+    const int ho_ = hrow + (reverse ? len_a - 1 - t : t) * h_st;
+    f32x4 hv[P_HC];
+#pragma unroll
+    for (int c = 0; c < P_HC; ++c) {
+      const int k = (hg0 + c) * 16;
+      hv[c] = (c < nhw && avalid && t > 0 && k + 4 * q < H) ? ldx_sc1(h_rs, ho_ + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!hoisted) {
+      // input part first: its operands arrived a step ago, so these MFMAs run under the loads just issued
+#pragma unroll
+      for (int c = 0; c < P_XC; ++c)
+        if (c < nxw) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xcur[c][e], wa[c][nt][e], acc[nt], 0, 0, 0);
+        }
+      if (t + 1 < T) load_x(t + 1, xcur);      // refill in place: consumed a step from now
+    }
+    // hoisted x.Wx of the NEXT step (cold in HBM).  Issued last: vmcnt retires in order, so a slow load must be
+    // younger than the recurrent operands or it would stall their wait.
+    if (eok && hoisted && t + 1 < len_b) znext = ld4(gates_p + (long)(rec_b + (reverse ? len_b - 2 - t : t + 1) * H) * 4);
+    asm volatile("" ::: "memory");
+#ifdef PERSIST_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TICK(1)
+#endif
+#pragma unroll
+    for (int c = 0; c < P_HC; ++c)
+      if (c < nhw) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[c][e], wb[c][nt][e], acc[nt], 0, 0, 0);
+        if (wide) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[2 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[c][e], wa[c][nt][e], acc[2 + nt], 0, 0, 0);
+        }
+      }
+    if (q < 2) {                                 // C rows (lane>>4)*4 + r: only rows 0-7 carry batch rows
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][nt][q * 4 + r][i] = acc[nt][r];
+    }
+    __syncthreads();
+    TICK(2)
+    if (eok) {
+      const bool valid = t < len_b;
+      if (valid) {
+        const int tau = reverse ? len_b - 1 - t : t;
+        const long bt = (long)b * T + tau;
+        f32x4 z = bias4 + zpre;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+          const int cc = eu * 4 + gi;
+          z[gi] += (red[0][cc >> 4][er][cc & 15] + red[1][cc >> 4][er][cc & 15]) + (red[2][cc >> 4][er][cc & 15] + red[3][cc >> 4][er][cc & 15]);
+        }
+        f32x4 g4;
+        g4[0] = p_sigmoid(z[0]); g4[1] = p_tanh(z[1]); g4[2] = p_sigmoid(z[2] + 1.0f); g4[3] = p_sigmoid(z[3]);
+        float c = g4[2] * c_state + g4[0] * g4[1];
+        c = fminf(1.0f, fmaxf(-1.0f, c));
+        const float h = g4[3] * p_tanh(c);
+        const uint32_t oidx = (uint32_t)(bt * H + u);
+        const float ho = h * p_drop(seed, r_out, oidx, k_out);
+        const float hs = h * p_drop(seed, r_st, oidx, k_st);
+        out_p[out_b + tau * out_st] = ho;                              // exchanged values first, records after
+        if (hsw_p) hsw_p[hsw_b + tau * hs_st] = hs;
+        if (xtw_p) xtw_p[xtw_b + tau * xt_st] = ho * p_drop(seed, r_in, (uint32_t)(bt * in_W + in_coff + u), k_in);
+        st4(gates_p + (long)(rec_b + tau * H) * 4, g4);
+        cs_p[rec_b + tau * H] = c;
+        c_state = c;
+        h_state = hs;
+      } else {                     // past the utterance: zero output at padding position t, state carried in registers
+        out_p[out_b + t * out_st] = 0.f;
+        if (hsw_p) hsw_p[hsw_b + t * hs_st] = 0.f;
+        if (xtw_p) xtw_p[xtw_b + t * xt_st] = 0.f;
+      }
+    }
+    TICK(3)
+    // publish: stores drained into the XCD's L2, then this workgroup's progress word
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    TICK(4)
+    if (tid == 0) __hip_atomic_store(my_flag, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    TICK(5)
+  }
+#ifdef PERSIST_TIMING
+  if (tid == 0 && ct == 0 && g == 0)
+    for (int k = 0; k < 6; ++k) L.err[16 + ti * 8 + k] = (int)(tm[k] / T);
+#endif
+  if (eok) {
+    if (tk.h_final) tk.h_final[(long)b * H + u] = h_state;
+    if (tk.c_final) tk.c_final[(long)b * H + u] = c_state;
+  }
+}
+
 static int32_t* g_sync = nullptr;
+static int g_persist_mode = 3;      // bit 0: agent-scope kernel allowed, bit 1: XCD-local kernel allowed
+
 static int64_t g_sync_ints = 0;
 
 }  // namespace avsr
@@ -314,25 +572,24 @@ extern "C" int avsr_rnn_set_persistent(int32_t* sync, int64_t ints) {
   return AVSR_OK;
 }
 
-// Returns AVSR_ERR_UNSUPPORTED when the persistent path is disabled or the configuration does not fit it
-// (avsr_rnn_fwd then uses one launch per wavefront step).
-int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream) {
-  using namespace avsr;
-  int32_t* sync = g_sync; const int64_t sync_ints = g_sync_ints;
-  if (!sync) return AVSR_ERR_UNSUPPORTED;
-  static thread_local PLaunch L;
+namespace avsr {
+
+// Fill the task table for one persistent launch.  local = XCD-local variant (8-row groups, progress words),
+// else the agent-scope variant (16-row tiles, arrival counters).  Returns AVSR_ERR_UNSUPPORTED if it does not fit.
+static int build_tasks(const avsr_rnn_stack* st, int n, bool local, int32_t* sync, int64_t sync_ints, PLaunch& L, int* wg_out, long* words_out) {
   L = PLaunch{};
   int wg = 0;
-  long ctr = P_HDR;
+  long ctr = P_HDR + 8;                 // [P_HDR, P_HDR+8): per-XCD slot claim counters
   for (int i = 0; i < n; ++i) {
     const avsr_rnn_stack& S = st[i];
-    if (S.cell != 0) return AVSR_ERR_UNSUPPORTED;
-    const int nrt = (S.B + 15) / 16;
+    if (S.cell != 0 || S.B != st[0].B) return AVSR_ERR_UNSUPPORTED;
+    const int nrt = local ? (S.B + 7) / 8 : (S.B + 15) / 16;
+    if (local && nrt > 8) return AVSR_ERR_UNSUPPORTED;
     for (int l = 0; l < S.n_layers; ++l) {
       const avsr_rnn_layer& Ly = S.layer[l];
       if (L.ntask >= P_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
       const int H = Ly.units, in = Ly.in_dim;
-      if ((long)S.B * (S.T + 2) * (Ly.ld_out > 4 * H ? Ly.ld_out : 4 * H) >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
+      if ((long)S.B * (S.T + 2) * (Ly.ld_out > 4 * H ? Ly.ld_out : 4 * H) >= (1L << 30)) return AVSR_ERR_UNSUPPORTED;
       if (H % 8 || !Ly.out || H > 64 * P_HC || (!Ly.hoisted && in > 64 * P_XC) || in % 4) return AVSR_ERR_UNSUPPORTED;
       if (!Ly.hoisted && l == 0) return AVSR_ERR_UNSUPPORTED;
       if (S.seed && !Ly.hs_seq) return AVSR_ERR_UNSUPPORTED;
@@ -352,10 +609,12 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream) {
       if (S.seed && Ly.xt_seq) { tk.xt_w = Ly.xt_seq + H; tk.xt_sb = (long)(S.T + 2) * H; tk.xt_st = H; }
       tk.h_final = Ly.h_final; tk.c_final = Ly.c_final;
       tk.B = S.B; tk.T = S.T; tk.H = H; tk.in = in; tk.hoisted = Ly.hoisted; tk.reverse = S.reverse;
-      tk.nct = H / 8; tk.nrt = nrt; tk.wg_begin = wg;
-      wg += nrt * tk.nct;
+      tk.uw = (local && Ly.hoisted && H % 16 == 0) ? 16 : 8;
+      tk.nct = H / tk.uw; tk.nrt = nrt; tk.wg_begin = wg;
+      if (tk.nct > 32) return AVSR_ERR_UNSUPPORTED;
+      wg += local ? tk.nct : nrt * tk.nct;
       tk.done = sync + ctr;
-      ctr += (long)nrt * S.T;
+      ctr += local ? 8 * 32 : (long)nrt * S.T;
       if (!Ly.hoisted) { tk.done_lower = L.task[L.ntask - 2].done; tk.nct_lower = L.task[L.ntask - 2].nct; }
       if (S.seed) {
         const uint32_t cid = (uint32_t)(S.cell_id_base + l);
@@ -366,14 +625,45 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream) {
       }
     }
   }
-  if (wg > 512 || ctr > sync_ints) return AVSR_ERR_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (ctr - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
-  L.err = sync;
-  {
-    ProfScope ps(PROF_STEP_LSTM_FWD, s);
-    hipLaunchKernelGGL(rnn_persist_fwd_kernel, dim3(wg), dim3(256), 0, s, L);
-  }
-  AVSR_CHECK_LAUNCH();
+  // co-residency: every workgroup of the launch must be resident at once (they wait on each other).
+  // agent-scope kernel: <= 2 per CU chip-wide; XCD-local kernel: <= 3 per CU of one XCD (its VGPR budget admits 3).
+  if (ctr > sync_ints) return AVSR_ERR_UNSUPPORTED;
+  if (local ? wg > 96 : wg > 512) return AVSR_ERR_UNSUPPORTED;
+  L.err = sync; L.claim = sync + P_HDR; L.wpx = wg; L.ngroups = (st[0].B + 7) / 8;
+  *wg_out = wg; *words_out = ctr;
   return AVSR_OK;
+}
+
+}  // namespace avsr
+
+extern "C" int avsr_rnn_set_persistent_mode(int mode) { avsr::g_persist_mode = mode; return AVSR_OK; }
+
+// Returns AVSR_ERR_UNSUPPORTED when the persistent path is disabled or the configuration does not fit it
+// (avsr_rnn_fwd then uses one launch per wavefront step).
+int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream) {
+  using namespace avsr;
+  int32_t* sync = g_sync; const int64_t sync_ints = g_sync_ints;
+  if (!sync) return AVSR_ERR_UNSUPPORTED;
+  static thread_local PLaunch L;
+  hipStream_t s = (hipStream_t)stream;
+  int wg = 0; long words = 0;
+  if ((g_persist_mode & 2) && build_tasks(st, n, true, sync, sync_ints, L, &wg, &words) == AVSR_OK) {
+    if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
+    {
+      ProfScope ps(PROF_STEP_LSTM_FWD, s);
+      hipLaunchKernelGGL(rnn_persist_fwd_xcd_kernel, dim3(8 * wg), dim3(256), 0, s, L);
+    }
+    AVSR_CHECK_LAUNCH();
+    return AVSR_OK;
+  }
+  if ((g_persist_mode & 1) && build_tasks(st, n, false, sync, sync_ints, L, &wg, &words) == AVSR_OK) {
+    if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
+    {
+      ProfScope ps(PROF_STEP_LSTM_FWD, s);
+      hipLaunchKernelGGL(rnn_persist_fwd_kernel, dim3(wg), dim3(256), 0, s, L);
+    }
+    AVSR_CHECK_LAUNCH();
+    return AVSR_OK;
+  }
+  return AVSR_ERR_UNSUPPORTED;
 }

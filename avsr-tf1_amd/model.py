@@ -95,8 +95,9 @@ class Seq2SeqModel:
         self.cfg, self.dev = cfg, torch.device(device)
         self.gru = cfg.cell_type == "gru"
         # one-launch persistent encoder forward (csrc/rnn_persist.hip); process-wide engine switch
-        self.persistent_rnn = os.environ.get("AVSR_PERSISTENT_RNN", "0") == "1"
-        ops.rnn_set_persistent(self.persistent_rnn, device=device)
+        pm = int(os.environ.get("AVSR_PERSISTENT_RNN", "0"))      # 0 off | 1 agent-scope only | 2 XCD-local only | 3 both
+        self.persistent_rnn = pm != 0
+        ops.rnn_set_persistent(self.persistent_rnn, device=device, mode=pm or 3)
         self.G = 2 if self.gru else 4                       # gate pre-activations per unit of the main cell kernel
         self.inv = PR.inventory(cfg)
         # ---- flat parameter storage (engine layout) ------------------------------------------------

@@ -181,9 +181,11 @@ def prof_end():
 _persist_sync = None
 
 
-def rnn_set_persistent(on, device="cuda", ints=1 << 20):
-    """Enable / disable the one-launch persistent execution of avsr_rnn_fwd (see include/avsr_hip.h)."""
+def rnn_set_persistent(on, device="cuda", ints=1 << 20, mode=3):
+    """Enable / disable the one-launch persistent execution of avsr_rnn_fwd (see include/avsr_hip.h).
+    mode: bit 0 agent-scope kernel, bit 1 XCD-local kernel (tried first)."""
     global _persist_sync
+    check(_L().avsr_rnn_set_persistent_mode(int(mode)), "avsr_rnn_set_persistent_mode")
     if on:
         if _persist_sync is None:
             _persist_sync = torch.zeros(ints, dtype=torch.int32, device=device)

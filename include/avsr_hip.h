@@ -151,6 +151,9 @@ int avsr_rnn_bwd(const avsr_rnn_stack* stacks, int32_t n_stacks, void* stream);
  * (needs 1 + sum over layers of ceil(B/16)*T).  NULL disables.  Configurations that do not fit (GRU,
  * units %% 8, in+units > 512, > 512 workgroups) silently use the per-step launches.  Same results either way. */
 int avsr_rnn_set_persistent(int32_t* sync, int64_t ints);
+/* Which persistent kernels may be used: bit 0 = agent-scope (any placement, 16-row tiles), bit 1 = XCD-local
+ * (8-row groups bound to the XCD their workgroups actually run on; tried first).  Default 3. */
+int avsr_rnn_set_persistent_mode(int mode);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention-wrapped LSTM over a sequence.  Replaces

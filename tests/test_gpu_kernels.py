@@ -97,7 +97,7 @@ def _oracle_stack(x, lens, Ws, bs, reverse, R_out, R_h, R_c):
             [P[f"s/l{l}/bias"].grad.numpy() for l in range(len(Ws))])
 
 
-@pytest.mark.parametrize("persistent", [0, 1])
+@pytest.mark.parametrize("persistent", [0, 1, 2])
 @pytest.mark.parametrize("reverse", [0, 1])
 @pytest.mark.parametrize("units", [(32,), (32, 48, 32)])
 def test_rnn_stack_fwd_bwd(units, reverse, persistent):
@@ -156,7 +156,8 @@ def test_rnn_stack_fwd_bwd(units, reverse, persistent):
     top.dout, top.ld_dout, top.dout_col = dout.data_ptr(), Htop, 0
     st.dh_final, st.dc_final = dhf.data_ptr(), dcf.data_ptr()
 
-    ops.rnn_set_persistent(bool(persistent))      # one persistent launch vs one launch per wavefront step
+    # one launch per wavefront step | persistent agent-scope kernel | persistent XCD-local kernel
+    ops.rnn_set_persistent(bool(persistent), mode=max(persistent, 1))
     try:
         ops.rnn_fwd([st])
         torch.cuda.synchronize()

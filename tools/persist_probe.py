@@ -5,7 +5,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["AVSR_PERSISTENT_RNN"] = "1"
+os.environ.setdefault("AVSR_PERSISTENT_RNN", "3")
 sys.argv = [sys.argv[0], "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-graph"] + sys.argv[1:]
 import bench  # noqa: E402
 
