@@ -1,0 +1,60 @@
+// Device helpers shared by the persistent RNN kernels (rnn_persist.hip forward, rnn_persist_bwd.hip backward).
+#pragma once
+#include "common.h"
+
+#define P_HDR 256          // sync words reserved ahead of the counters: [0] sticky error flag, [16..] debug timing
+
+namespace avsr {
+
+extern int32_t* g_sync;
+extern int64_t g_sync_ints;
+extern int g_persist_mode;
+
+__device__ __forceinline__ f32x4 ld4_sc1(const float* p) {
+  // 16-byte load that bypasses this CU's L1 (the line may have been rewritten by another CU since we last read it)
+  typedef unsigned long long u64;
+  const u64 a = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const u64 b = __hip_atomic_load(reinterpret_cast<const u64*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  f32x4 v;
+  v[0] = __builtin_bit_cast(float, (unsigned)(a & 0xffffffffu)); v[1] = __builtin_bit_cast(float, (unsigned)(a >> 32));
+  v[2] = __builtin_bit_cast(float, (unsigned)(b & 0xffffffffu)); v[3] = __builtin_bit_cast(float, (unsigned)(b >> 32));
+  return v;
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// bounded wait for *ctr >= target; false (and *err = 1) on timeout or if another workgroup already failed
+__device__ __forceinline__ bool wait_ge(const int* ctr, int target, int* err) {
+  for (int spins = 0; spins < (1 << 21); ++spins) {
+    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+
+__device__ __forceinline__ float p_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float p_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+__device__ __forceinline__ float p_drop(const int32_t* seed, uint32_t stream, uint32_t idx, float keep) {
+  if (!seed || keep >= 1.0f) return 1.0f;
+  return uniform01((uint32_t)seed[0], stream, idx) < keep ? 1.0f / keep : 0.0f;
+}
+
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf; }   // HW_REG_XCC_ID[3:0]
+__device__ __forceinline__ f32x4 ldx_sc1(__amdgpu_buffer_rsrc_t r, int elem_off) {
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(r, elem_off * 4, 0, 16);                      // aux 16 = sc1
+  return __builtin_bit_cast(f32x4, v);
+}
+
+
+// 16-byte write-through store (one fabric write; four scalar sc1 stores cost ~6x per byte)
+__device__ __forceinline__ void stx_sc1(__amdgpu_buffer_rsrc_t r, int elem_off, f32x4 v) {
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r, elem_off * 4, 0, 16);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xffffffff, 0x00020000);
+}
+
+}  // namespace avsr

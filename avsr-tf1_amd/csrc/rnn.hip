@@ -10,7 +10,20 @@
 #include "avsr_hip.h"
 
 extern "C" int avsr_step_launch_raw(const void* launch, void* stream);
-int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream);
+int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
+int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
+
+// Persistent execution: all stacks in one launch when they fit together, else one launch per stack when every
+// stack fits on its own (checked first: nothing runs unless everything can), else AVSR_ERR_UNSUPPORTED.
+static int run_persistent(int (*fn)(const avsr_rnn_stack*, int32_t, void*, int), const avsr_rnn_stack* st, int32_t n, void* stream) {
+  int rc = fn(st, n, stream, 0);
+  if (rc != AVSR_ERR_UNSUPPORTED || n == 1) return rc;
+  for (int i = 0; i < n; ++i)
+    if ((rc = fn(st + i, 1, stream, 1)) != AVSR_OK) return rc;
+  for (int i = 0; i < n; ++i)
+    if ((rc = fn(st + i, 1, stream, 0)) != AVSR_OK) return rc;
+  return AVSR_OK;
+}
 
 namespace avsr {
 
@@ -47,7 +60,7 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
   if (!st || n <= 0 || n > AVSR_MAX_STACKS) return AVSR_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   {
-    const int rc = avsr_rnn_fwd_persistent(st, n, stream);   // one launch for the whole sequence when it fits
+    const int rc = run_persistent(avsr_rnn_fwd_persistent, st, n, stream);   // one launch for the whole sequence when it fits
     if (rc != AVSR_ERR_UNSUPPORTED) return rc;
   }
   int nsteps = 0, ntask_max = 0;
@@ -190,6 +203,10 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
     ntask_max += S.n_layers;
   }
   if (ntask_max > STEP_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
+  {
+    const int rc = run_persistent(avsr_rnn_bwd_persistent, st, n, stream);   // one launch for the whole BPTT when it fits
+    if (rc != AVSR_ERR_UNSUPPORTED) return rc;
+  }
 
   static thread_local StepLaunch L;
   const bool gru = st[0].cell == 1;

@@ -19,10 +19,10 @@
 #include "step.h"
 #include "avsr_hip.h"
 #include "prof.h"
+#include "persist.h"
 
 #define P_MAX_TASKS 8
 #define P_MAXC 8
-#define P_HDR 256          // sync words reserved ahead of the counters: [0] sticky error flag, [16..] debug timing
 
 namespace avsr {
 
@@ -40,36 +40,6 @@ struct PTask {
   const int32_t* seed; float k_st, k_out, k_in; uint32_t r_st, r_out, r_in; int in_W, in_coff;
 };
 struct PLaunch { int ntask, wpx, ngroups; int* err; int* claim; PTask task[P_MAX_TASKS]; };
-
-__device__ __forceinline__ f32x4 ld4_sc1(const float* p) {
-  // 16-byte load that bypasses this CU's L1 (the line may have been rewritten by another CU since we last read it)
-  typedef unsigned long long u64;
-  const u64 a = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const u64 b = __hip_atomic_load(reinterpret_cast<const u64*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  f32x4 v;
-  v[0] = __builtin_bit_cast(float, (unsigned)(a & 0xffffffffu)); v[1] = __builtin_bit_cast(float, (unsigned)(a >> 32));
-  v[2] = __builtin_bit_cast(float, (unsigned)(b & 0xffffffffu)); v[3] = __builtin_bit_cast(float, (unsigned)(b >> 32));
-  return v;
-}
-__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// bounded wait for *ctr >= target; false (and *err = 1) on timeout or if another workgroup already failed
-__device__ __forceinline__ bool wait_ge(const int* ctr, int target, int* err) {
-  for (int spins = 0; spins < (1 << 21); ++spins) {
-    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-    if ((spins & 1023) == 1023 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-    __builtin_amdgcn_s_sleep(2);
-  }
-  __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return false;
-}
-
-__device__ __forceinline__ float p_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float p_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
-__device__ __forceinline__ float p_drop(const int32_t* seed, uint32_t stream, uint32_t idx, float keep) {
-  if (!seed || keep >= 1.0f) return 1.0f;
-  return uniform01((uint32_t)seed[0], stream, idx) < keep ? 1.0f / keep : 0.0f;
-}
 
 // bounded wait for (*c0 >= n0 && *c1 >= n1): both counters are fetched in the same round trip
 __device__ __forceinline__ bool wait_ge2(const int* c0, int n0, const int* c1, int n1, int* err) {
@@ -317,13 +287,6 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(const PLaunch L) {
 // Only liveness depends on the dispatcher handing each XCD its share of the grid; every wait is bounded and a
 // miss raises the sticky error word (the host then switches the path off).
 // ======================================================================================================
-__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf; }   // HW_REG_XCC_ID[3:0]
-__device__ __forceinline__ f32x4 ldx_sc1(__amdgpu_buffer_rsrc_t r, int elem_off) {
-  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-  const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(r, elem_off * 4, 0, 16);                      // aux 16 = sc1
-  return __builtin_bit_cast(f32x4, v);
-}
-
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rnn_persist_fwd_xcd_kernel(const PLaunch L) {
   __shared__ __attribute__((aligned(16))) float red[4][4][8][16];
   __shared__ int s_slot;
@@ -558,10 +521,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
-static int32_t* g_sync = nullptr;
-static int g_persist_mode = 3;      // bit 0: agent-scope kernel allowed, bit 1: XCD-local kernel allowed
+int32_t* g_sync = nullptr;
+int g_persist_mode = 3;      // bit 0: agent-scope kernel allowed, bit 1: XCD-local kernel allowed
 
-static int64_t g_sync_ints = 0;
+int64_t g_sync_ints = 0;
 
 }  // namespace avsr
 
@@ -640,7 +603,7 @@ extern "C" int avsr_rnn_set_persistent_mode(int mode) { avsr::g_persist_mode = m
 
 // Returns AVSR_ERR_UNSUPPORTED when the persistent path is disabled or the configuration does not fit it
 // (avsr_rnn_fwd then uses one launch per wavefront step).
-int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream) {
+int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry) {
   using namespace avsr;
   int32_t* sync = g_sync; const int64_t sync_ints = g_sync_ints;
   if (!sync) return AVSR_ERR_UNSUPPORTED;
@@ -648,6 +611,7 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int wg = 0; long words = 0;
   if ((g_persist_mode & 2) && build_tasks(st, n, true, sync, sync_ints, L, &wg, &words) == AVSR_OK) {
+    if (dry) return AVSR_OK;
     if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
       ProfScope ps(PROF_STEP_LSTM_FWD, s);
@@ -657,6 +621,7 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream) {
     return AVSR_OK;
   }
   if ((g_persist_mode & 1) && build_tasks(st, n, false, sync, sync_ints, L, &wg, &words) == AVSR_OK) {
+    if (dry) return AVSR_OK;
     if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
       ProfScope ps(PROF_STEP_LSTM_FWD, s);

@@ -1,0 +1,362 @@
+// Persistent BPTT of the masked multi-layer LSTM stacks (fast path of avsr_rnn_bwd; same results as the
+// one-launch-per-step wavefront in rnn.hip, which stays as the fallback).
+//
+// Layout.  Batch rows are independent, so the batch is cut into groups of 16 rows (one full MFMA row tile) and
+// every group owns a PAIR of XCDs (group r -> XCDs 2r, 2r+1).  The (stack, layer) cells of a group are divided
+// between the two XCDs of its pair so that each cell's own recurrence -- the step-to-step critical path -- stays
+// inside one XCD's L2, and only layer-to-layer edges may cross (the layer above runs ahead of the layer below in
+// BPTT, so a crossing edge is off the critical path).  A workgroup = 512 threads = 16 rows x 16 units (32 for a
+// top-of-stack cell) with its slice of Wh^T (and of the upper layer's Wx^T) resident in registers for the whole
+// sequence; its dc / dh carries live in registers too.
+//
+// Hand-off forms (MI355X_MICROARCH.md "inter-workgroup visibility"; tools/xcd_probe.hip):
+//   same XCD : plain stores (line stays in that L2) -> s_waitcnt vmcnt(0) -> barrier -> progress word;
+//              reader: one coalesced L1-bypassing poll of the progress words -> 16-byte sc1 loads (L2-served).
+//   crossing : 16-byte sc1 stores -> s_waitcnt vmcnt(0) -> barrier -> agent-scope arrival counter;
+//              reader: agent-scope poll of the counter -> 16-byte sc1 loads.
+// Placement is never assumed: a workgroup reads HW_REG_XCC_ID and claims a slot of the XCD it actually runs on.
+// Only liveness depends on every XCD receiving its share of the grid; every wait is bounded and a miss raises
+// the sticky error word (avsr_rnn_set_persistent documents it).
+#include "step.h"
+#include "avsr_hip.h"
+#include "prof.h"
+#include "persist.h"
+
+#define B_MAX_TASKS 8
+#define B_CH 8            // 16-wide K chunks per wave per operand part (4H / 16 / 8 waves, H <= 256)
+
+namespace avsr {
+
+struct BTask {
+  const float* w_own; const float* w_up; long ldw_own, ldw_up;
+  const int* len;
+  const float* gates; const float* cs;
+  float* dgates; float* ring; const float* up_dgates;
+  const float* dout; long dout_sb, dout_st;
+  const float* dh_final; const float* dc_final;
+  int* prog; const int* prog_up;
+  int* ctr; const int* ctr_up;
+  int B, T, H, H_up, reverse, nct, nct_up, slot_begin, half, ntile, up_remote;
+  const int32_t* seed; float k_st, k_out, k_in; uint32_t r_st, r_out, r_in; int in_W, in_coff;
+};
+struct BLaunch { int ntask, ngroups, wpx0, wpx1; int* err; int* claim; BTask task[B_MAX_TASKS]; };
+
+__global__ __launch_bounds__(512) void rnn_persist_bwd_kernel(const BLaunch L) {
+  __shared__ __attribute__((aligned(16))) float red[8][2][16][16];
+  __shared__ int s_slot;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int xcc = __builtin_amdgcn_readfirstlane(xcc_id());
+  if (tid == 0) s_slot = __hip_atomic_fetch_add(L.claim + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int slot = __builtin_amdgcn_readfirstlane(s_slot);
+  const int g = xcc >> 1, half = xcc & 1;
+  if (g >= L.ngroups || slot >= (half ? L.wpx1 : L.wpx0)) return;
+  int ti = -1;
+#pragma unroll
+  for (int i = 0; i < B_MAX_TASKS; ++i)
+    if (i < L.ntask && L.task[i].half == half && slot >= L.task[i].slot_begin) ti = i;    // same-half tasks: ascending slot_begin
+  ti = __builtin_amdgcn_readfirstlane(ti);
+  const BTask& tk = L.task[ti];
+  const int ct = slot - tk.slot_begin;
+  const int H = tk.H, T = tk.T, reverse = tk.reverse;
+  const int NT = tk.ntile;
+  const bool top = tk.w_up == nullptr;           // no upper layer inside the stack
+  const int unit0 = ct * 16 * NT, row0 = g * 16;
+  const int i = lane & 15, q = lane >> 4;
+  const int K_own = 4 * H, K_up = 4 * tk.H_up;
+  const int nco = K_own >> 4, ncu = top ? 0 : K_up >> 4;
+  const int oc0 = (wave * nco) / 8, n_own = ((wave + 1) * nco) / 8 - oc0;      // <= B_CH (host-checked)
+  const int uc0 = (wave * ncu) / 8, n_up = ((wave + 1) * ncu) / 8 - uc0;
+
+  // ---- weight slices: registers for the whole sequence ----
+  // w1: Wh^T rows of column tile 0.  w2: top cell -> column tile 1 of Wh^T;  else -> the upper layer's Wx^T rows.
+  f32x4 w1[B_CH], w2[B_CH];
+  {
+    const int u1 = unit0 + i, u2 = unit0 + 16 + i;
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c) {
+      const int k = (oc0 + c) * 16 + 4 * q;
+      w1[c] = (c < n_own && u1 < H) ? ld4(tk.w_own + (long)u1 * tk.ldw_own + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (top) {
+        if (NT == 2 && c < n_own && u2 < H) v = ld4(tk.w_own + (long)u2 * tk.ldw_own + k);
+      } else if (c < n_up && u1 < H) {
+        v = ld4(tk.w_up + (long)u1 * tk.ldw_up + (uc0 + c) * 16 + 4 * q);
+      }
+      w2[c] = v;
+    }
+  }
+
+  // ---- epilogue ownership: one thread per (row, unit) for all steps ----
+  const int tile = tid >> 8, er = (tid & 255) >> 4, eu = tid & 15;
+  const int b = row0 + er, u = unit0 + tile * 16 + eu;
+  const bool eok = tile < NT && b < tk.B && u < H;
+  const int len_b = eok ? (tk.len ? tk.len[b] : T) : 0;
+  float dc_carry = (eok && tk.dc_final) ? tk.dc_final[(long)b * H + u] : 0.f;
+  float dh_carry = (eok && tk.dh_final) ? tk.dh_final[(long)b * H + u] : 0.f;
+  const int rec_b = b * T * H + u;
+  const float* const gates_p = tk.gates; const float* const cs_p = tk.cs;
+  float* const dgates_p = tk.dgates;
+  const __amdgpu_buffer_rsrc_t dgates_rs = make_rsrc(tk.dgates);
+  float* const ring_p = tk.ring;
+  const float* const dout_p = tk.dout;
+  const int dout_b = (int)(b * tk.dout_sb) + u, dout_st = (int)tk.dout_st;
+  const int32_t* const seed = tk.seed;
+  const float k_st = tk.k_st, k_out = tk.k_out, k_in = tk.k_in;
+  const uint32_t r_st = tk.r_st, r_out = tk.r_out, r_in = tk.r_in;
+  const int in_W = tk.in_W, in_coff = tk.in_coff;
+  const bool publish_remote = tk.ctr != nullptr;
+
+  // ---- A-operand row of this lane ----
+  const int ab = row0 + i;
+  const bool aok = ab < tk.B;
+  const int len_a = aok ? (tk.len ? tk.len[ab] : T) : 0;
+  const __amdgpu_buffer_rsrc_t ring_rs = make_rsrc(tk.ring);
+  const __amdgpu_buffer_rsrc_t up_rs = make_rsrc(tk.up_dgates);
+  const int ring_row = ab * K_own + oc0 * 16 + 4 * q;
+  const int ring_par = tk.B * K_own;
+  const int up_row = ab * T * K_up + uc0 * 16 + 4 * q;
+
+  // ---- progress polling (wave 0): lanes 0-31 own progress words, lanes 32-63 the upper layer ----
+  int* const my_prog = tk.prog + g * 32 + ct;
+  int* const my_ctr = publish_remote ? tk.ctr + (long)g * T : nullptr;
+  const int up_remote = tk.up_remote, nct_up = tk.nct_up;
+  const int* poll_own = nullptr; const int* poll_up = nullptr;
+  if (wave == 0) {
+    if (lane < 32) { if (lane < tk.nct) poll_own = tk.prog + g * 32 + lane; }
+    else if (!top) {
+      if (up_remote) { if (lane == 32) poll_up = tk.ctr_up + (long)g * T; }
+      else if (lane - 32 < nct_up) poll_up = tk.prog_up + g * 32 + (lane - 32);
+    }
+  }
+  // own: steps completed >= need_own.  upper: step index t_up completed (local: progress >= T - t_up; crossing: counter[t_up] >= nct_up)
+  auto wait_progress = [&](int need_own, int t_up) {
+    if (wave != 0) return;
+    const int* p = lane < 32 ? poll_own : (poll_up ? (up_remote ? poll_up + t_up : poll_up) : nullptr);
+    const int need = lane < 32 ? need_own : (up_remote ? nct_up : T - t_up);
+    for (int spins = 0; spins < (1 << 21); ++spins) {
+      const int v = p ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+      if (__all(v >= need)) return;
+      if ((spins & 1023) == 1023 && __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
+    if (lane == 0) __hip_atomic_store(L.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  // upper-layer operands (d gates of the layer above at the same step) run one step ahead of the recurrence
+  f32x4 a_up[B_CH];
+#pragma unroll
+  for (int c = 0; c < B_CH; ++c) a_up[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_up = [&](int t) {
+    const bool v = aok && t < len_a;
+    const int o = up_row + (reverse ? len_a - 1 - t : t) * K_up;
+#pragma unroll
+    for (int c = 0; c < B_CH; ++c)
+      a_up[c] = (c < n_up && v) ? ldx_sc1(up_rs, o + c * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // epilogue operands of the next step (records written by the forward pass: cold in HBM) are fetched a step ahead
+  f32x4 n_g = {0.f, 0.f, 0.f, 0.f};
+  float n_c = 0.f, n_cp = 0.f, n_do = 0.f;
+  auto load_rec = [&](int t) {
+    if (eok && t >= 0 && t < len_b) {
+      const int tau = reverse ? len_b - 1 - t : t;
+      const int o = rec_b + tau * H;
+      n_g = ld4(gates_p + (long)o * 4);
+      n_c = cs_p[o];
+      n_cp = t == 0 ? 0.f : cs_p[o + (reverse ? H : -H)];
+      n_do = dout_p ? dout_p[dout_b + tau * dout_st] : 0.f;
+    }
+  };
+  if (!top) {
+    wait_progress(0, T - 1);
+    __syncthreads();
+    load_up(T - 1);
+  }
+  load_rec(T - 1);
+
+  for (int t = T - 1; t >= 0; --t) {
+    const f32x4 g4 = n_g;
+    const float c = n_c, cprev = n_cp, dout_ext = n_do;
+    // dependencies: step t+1 of this cell (every column tile of my rows); the cell above one step ahead (t-1)
+    wait_progress(T - 1 - t, t > 0 ? t - 1 : 0);
+    __syncthreads();
+    // ---- recurrent operand: d gates of step t+1 from the two-slot ring (zero-filled by the host for t = T-1) ----
+    f32x4 a_own[B_CH];
+    {
+      const int o = ring_row + ((t + 1) & 1) * ring_par;
+#pragma unroll
+      for (int cc = 0; cc < B_CH; ++cc)
+        a_own[cc] = (cc < n_own && aok) ? ldx_sc1(ring_rs, o + cc * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (!top) {
+      // upper-layer part first: its operands arrived a step ago, so these MFMAs run under the loads just issued
+#pragma unroll
+      for (int cc = 0; cc < B_CH; ++cc)
+        if (cc < n_up) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_up[cc][e], w2[cc][e], acc1, 0, 0, 0);
+        }
+      if (t > 0) load_up(t - 1);               // refill in place: consumed a step from now
+    }
+    load_rec(t - 1);                           // issued last: vmcnt retires in order (see rnn_persist.hip)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int cc = 0; cc < B_CH; ++cc)
+      if (cc < n_own) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_own[cc][e], w1[cc][e], acc0, 0, 0, 0);
+        if (top && NT == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_own[cc][e], w2[cc][e], acc1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { red[wave][0][q * 4 + r][i] = acc0[r]; red[wave][1][q * 4 + r][i] = acc1[r]; }
+    __syncthreads();
+
+    // ---- LSTM cell backward (same arithmetic as EP_LSTM_BWD in step.hip) ----
+    if (eok) {
+      f32x4 dg = {0.f, 0.f, 0.f, 0.f};
+      const bool valid = t < len_b;
+      int tau = t;
+      if (valid) {
+        tau = reverse ? len_b - 1 - t : t;
+        float zA = 0.f, zB = 0.f;
+        const int ka = top ? tile : 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) zA += red[w][ka][er][eu];
+        if (!top) {
+#pragma unroll
+          for (int w = 0; w < 8; ++w) zB += red[w][1][er][eu];
+        }
+        const long bt = (long)b * T + tau;
+        const uint32_t oidx = (uint32_t)(bt * H + u);
+        const uint32_t iidx = (uint32_t)(bt * in_W + in_coff + u);
+        const float dout = dout_ext + zB * p_drop(seed, r_in, iidx, k_in);
+        const float dh = dout * p_drop(seed, r_out, oidx, k_out) + (zA + dh_carry) * p_drop(seed, r_st, oidx, k_st);
+        const float tc = p_tanh(c);
+        float dc = dh * g4[3] * (1.f - tc * tc) + dc_carry;
+        if (!(fabsf(c) < 1.0f)) dc = 0.f;      // cell_clip = 1.0: no gradient through a clipped cell
+        dg[3] = dh * tc * g4[3] * (1.f - g4[3]);
+        dg[0] = dc * g4[1] * g4[0] * (1.f - g4[0]);
+        dg[1] = dc * g4[0] * (1.f - g4[1] * g4[1]);
+        dg[2] = dc * cprev * g4[2] * (1.f - g4[2]);
+        dc_carry = dc * g4[2];
+        dh_carry = 0.f;
+      }
+      // ring first (the recurrence reads it), then the record (zero at padding position t past the utterance)
+      st4(ring_p + (long)(t & 1) * ring_par + (long)b * K_own + u * 4, dg);
+      const int ro = (rec_b + tau * H) * 4;
+      if (publish_remote) stx_sc1(dgates_rs, ro, dg);
+      else st4(dgates_p + ro, dg);
+    }
+    // ---- publish ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(my_prog, T - t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (my_ctr) __hip_atomic_fetch_add(my_ctr + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// Choose the XCD half of every cell: all assignments are enumerated (<= 2^8); feasible ones keep each half within
+// `cap` workgroups; the winner has the fewest crossing layer edges, then the smallest larger half.
+static bool assign_halves(const int* cost, const int* upper, int n, int cap, int* half_out) {
+  int best = -1, best_cross = 1 << 30, best_load = 1 << 30;
+  for (int m = 0; m < (1 << n); ++m) {
+    int load[2] = {0, 0}, cross = 0;
+    for (int i = 0; i < n; ++i) {
+      load[(m >> i) & 1] += cost[i];
+      if (upper[i] >= 0 && (((m >> i) ^ (m >> upper[i])) & 1)) ++cross;
+    }
+    if (load[0] > cap || load[1] > cap) continue;
+    const int mx = load[0] > load[1] ? load[0] : load[1];
+    if (cross < best_cross || (cross == best_cross && mx < best_load)) { best = m; best_cross = cross; best_load = mx; }
+  }
+  if (best < 0) return false;
+  for (int i = 0; i < n; ++i) half_out[i] = (best >> i) & 1;
+  return true;
+}
+
+}  // namespace avsr
+
+// Returns AVSR_ERR_UNSUPPORTED when the persistent path is disabled or the configuration does not fit it
+// (avsr_rnn_bwd then uses one launch per wavefront step).  The caller has already zeroed every layer's dstate
+// (ring slots) and nothing else of the launch path's setup is needed: the final-state gradients are read here.
+int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry) {
+  using namespace avsr;
+  int32_t* sync = g_sync; const int64_t sync_ints = g_sync_ints;
+  if (!sync || !(g_persist_mode & 2)) return AVSR_ERR_UNSUPPORTED;
+  static thread_local BLaunch L;
+  L = BLaunch{};
+  int cost[B_MAX_TASKS], upper[B_MAX_TASKS], half[B_MAX_TASKS];
+  const int B = st[0].B;
+  const int ngroups = (B + 15) / 16;
+  if (ngroups > 4) return AVSR_ERR_UNSUPPORTED;
+  for (int i = 0; i < n; ++i) {
+    const avsr_rnn_stack& S = st[i];
+    if (S.cell != 0 || S.B != B) return AVSR_ERR_UNSUPPORTED;
+    const int first = L.ntask;
+    for (int l = 0; l < S.n_layers; ++l) {
+      const avsr_rnn_layer& Ly = S.layer[l];
+      if (L.ntask >= B_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
+      const int H = Ly.units, in = Ly.in_dim;
+      const bool top = l + 1 >= S.n_layers;
+      if (H % 16 || H > 32 * B_CH || (long)S.B * S.T * H * 4 >= (1L << 30)) return AVSR_ERR_UNSUPPORTED;
+      if (!top && (S.layer[l + 1].units % 16 || S.layer[l + 1].units > 32 * B_CH || S.layer[l + 1].in_dim != H)) return AVSR_ERR_UNSUPPORTED;
+      if (Ly.dout && (long)S.B * (S.T + 2) * Ly.ld_dout >= (1L << 30)) return AVSR_ERR_UNSUPPORTED;
+      const int t_i = L.ntask++;
+      BTask& tk = L.task[t_i];
+      tk.w_own = Ly.w + (long)in * 4 * H; tk.ldw_own = 4 * H;
+      if (!top) { const avsr_rnn_layer& Up = S.layer[l + 1]; tk.w_up = Up.w; tk.ldw_up = 4 * Up.units; tk.H_up = Up.units; tk.up_dgates = Up.dgates; }
+      tk.len = S.len; tk.gates = Ly.gates; tk.cs = Ly.cs; tk.dgates = Ly.dgates; tk.ring = Ly.dstate;
+      if (Ly.dout) { tk.dout = Ly.dout + Ly.ld_dout + Ly.dout_col; tk.dout_sb = (long)(S.T + 2) * Ly.ld_dout; tk.dout_st = Ly.ld_dout; }
+      if (top) { tk.dh_final = S.dh_final; tk.dc_final = S.dc_final; }
+      tk.B = S.B; tk.T = S.T; tk.H = H; tk.reverse = S.reverse;
+      tk.ntile = (top && H % 32 == 0) ? 2 : 1;
+      tk.nct = H / (16 * tk.ntile);
+      if (tk.nct > 32) return AVSR_ERR_UNSUPPORTED;
+      cost[t_i] = tk.nct; upper[t_i] = top ? -1 : t_i + 1;
+      if (S.seed) {
+        const uint32_t cid = (uint32_t)(S.cell_id_base + l);
+        tk.seed = S.seed; tk.k_st = S.keep_state; tk.k_out = S.keep_out; tk.k_in = 1.0f;
+        tk.r_st = cid * 4 + 1; tk.r_out = cid * 4 + 2;
+        if (!top) { tk.k_in = S.keep_in; tk.r_in = (cid + 1) * 4; tk.in_W = H; tk.in_coff = 0; }
+      }
+    }
+    (void)first;
+  }
+  // one 512-thread workgroup per CU (its register budget admits no second one): <= 32 per XCD, keep a margin
+  if (!assign_halves(cost, upper, L.ntask, 28, half)) return AVSR_ERR_UNSUPPORTED;
+  long words = P_HDR + 8;
+  int slots[2] = {0, 0};
+  for (int i = 0; i < L.ntask; ++i) {
+    BTask& tk = L.task[i];
+    tk.half = half[i]; tk.slot_begin = slots[half[i]]; slots[half[i]] += tk.nct;
+    tk.prog = sync + words; words += 4 * 32;
+  }
+  for (int i = 0; i < L.ntask; ++i) {
+    BTask& tk = L.task[i];
+    if (upper[i] < 0) continue;
+    BTask& up = L.task[upper[i]];
+    tk.prog_up = up.prog; tk.nct_up = up.nct;
+    if (up.half != tk.half) {               // crossing edge: the upper cell publishes through memory
+      tk.up_remote = 1;
+      if (!up.ctr) { up.ctr = sync + words; words += (long)ngroups * up.T; }
+      tk.ctr_up = up.ctr;
+    }
+  }
+  if (words > sync_ints) return AVSR_ERR_UNSUPPORTED;
+  if (dry) return AVSR_OK;
+  L.err = sync; L.claim = sync + P_HDR; L.ngroups = ngroups; L.wpx0 = slots[0]; L.wpx1 = slots[1];
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
+  const int wpx = slots[0] > slots[1] ? slots[0] : slots[1];
+  {
+    ProfScope ps(PROF_STEP_LSTM_BWD, s);
+    hipLaunchKernelGGL(rnn_persist_bwd_kernel, dim3(8 * wpx), dim3(512), 0, s, L);
+  }
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}

@@ -95,7 +95,7 @@ class Seq2SeqModel:
         self.cfg, self.dev = cfg, torch.device(device)
         self.gru = cfg.cell_type == "gru"
         # one-launch persistent encoder forward (csrc/rnn_persist.hip); process-wide engine switch
-        pm = int(os.environ.get("AVSR_PERSISTENT_RNN", "0"))      # 0 off | 1 agent-scope only | 2 XCD-local only | 3 both
+        pm = int(os.environ.get("AVSR_PERSISTENT_RNN", "3"))      # 0 off | 1 agent-scope fwd | 2 XCD-local fwd+bwd | 3 both (default)
         self.persistent_rnn = pm != 0
         ops.rnn_set_persistent(self.persistent_rnn, device=device, mode=pm or 3)
         self.G = 2 if self.gru else 4                       # gate pre-activations per unit of the main cell kernel
@@ -401,6 +401,19 @@ class Seq2SeqModel:
                 Wau = self.P["video/au/kernel"]
                 ops.gemm(E["mem"].mat(), Wau.mat(2), ops.mat(E["au_z"], 2), B * E["T"], 2, E["mem"].D, bias=self._pp("video/au/bias"))
                 ops.au_loss(E["au_z"], batch.aus, E["len"], E["au_row"], E["au_dz"], B, E["T"], cfg.au_loss_weight * self.au_scale)
+
+    def check_persistent(self, disable=True):
+        """Synchronise and read the persistent kernels' sticky error word (a bounded device-side wait expired: some
+        workgroups were not co-resident).  Returns True if the last results are invalid; the persistent path is then
+        switched off so that the caller can simply redo the pass through the per-step launches."""
+        if not self.persistent_rnn or not ops.rnn_persistent_error():
+            return False
+        if disable:
+            import warnings
+            warnings.warn("avsr_tf1_amd: persistent RNN kernel timed out; falling back to per-step launches")
+            self.persistent_rnn = False
+            ops.rnn_set_persistent(False)
+        return True
 
     @staticmethod
     def _run_stacks(stacks, fn):
@@ -971,7 +984,9 @@ class Seq2SeqModel:
         ops.beam_gather_tree(sid, pid, ln[T & 1], out, B, K, T, cfg.eos_id)     # lengths after step T-1 live at parity T&1
         self._last_beam = (D, T)
         if return_all:
+            self.check_persistent()
             return out
+        self.check_persistent()
         return out[:, :, 0].contiguous()
 
     def greedy_decode(self, batch: Batch, max_steps: Optional[int] = None, check_every: int = 8):
@@ -1005,6 +1020,7 @@ class Seq2SeqModel:
                 break
         t_out = min(int(D["steplen"].max().item()), l)   # dynamic_decode stops once every utterance has finished
         self._last_greedy = (ws, t_out)
+        self.check_persistent()
         return D["ids"][:, :t_out].contiguous()
 
 

@@ -24,6 +24,7 @@ class DataParallelTrainer:
         self.use_graph = use_graph
         self.mode = "eager"
         self._graphs = {}
+        self._checked = False
         self._static = {}
         model.au_scale = 1.0 / self.world
 
@@ -52,6 +53,10 @@ class DataParallelTrainer:
         self.model.forward_train(batch, compute_denom=(self.world == 1))
         self.model.backward()
 
+    def _persistent_failed(self):
+        chk = getattr(self.model, "check_persistent", None)
+        return bool(chk and chk())
+
     def _capture(self, fn):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -69,6 +74,10 @@ class DataParallelTrainer:
             dist.all_reduce(m.denom)
         if not self.use_graph:
             self._fwd_bwd(batch)
+            if not self._checked:                      # first step: make sure the persistent kernels were co-resident
+                self._checked = True
+                if self._persistent_failed():
+                    self._fwd_bwd(batch)
             if self.world > 1:
                 dist.all_reduce(m.grads)
             m.apply_update()
@@ -78,6 +87,8 @@ class DataParallelTrainer:
         if gr is None:
             # one eager step allocates every workspace; then capture
             self._fwd_bwd(st)
+            if self._persistent_failed():              # persistent kernels not co-resident: redo through the launch path
+                self._fwd_bwd(st)
             if self.world > 1:
                 dist.all_reduce(m.grads)
             m.apply_update()

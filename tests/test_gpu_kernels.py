@@ -170,8 +170,13 @@ def test_rnn_stack_fwd_bwd(units, reverse, persistent):
     assert np.abs(bufs[-1]["cf"].cpu().numpy() - o_c).max() < 2e-5
     assert float(bufs[-1]["out"][:, 0].abs().max()) == 0.0 and float(bufs[-1]["out"][:, T + 1].abs().max()) == 0.0
 
-    ops.rnn_bwd([st])
-    torch.cuda.synchronize()
+    ops.rnn_set_persistent(bool(persistent), mode=max(persistent, 1))
+    try:
+        ops.rnn_bwd([st])
+        torch.cuda.synchronize()
+        assert not ops.rnn_persistent_error()
+    finally:
+        ops.rnn_set_persistent(False)
     for l, u in enumerate(units):
         dg = bufs[l]["dgates"]
         i = ins[l]

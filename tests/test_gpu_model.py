@@ -179,6 +179,46 @@ def test_train_step_parity_with_dropout_and_sampling(case, over):
 
 
 # ------------------------------------------------------------------------------------------------
+# full-width encoders (BASELINE configs[3] widths, short sequences): at 256 units and 64 utterances the persistent
+# kernels run with all four 16-row groups, both XCDs of every pair and a crossing layer edge; the same case through
+# the per-step launches (mode 0) keeps that path covered at width.  Both are checked against the oracle.
+FULL_WIDTH = [
+    ("c4_bimodal_uni", dict(video_units=(256,), audio_units=(256, 256, 256), decoder_units=(256,), embedding_size=128,
+                            video_feat=128, audio_feat=80, use_dropout=True, sampling_probability=0.1)),
+    ("c2_audio_bi_bahdanau", dict(audio_units=(256, 256, 256), decoder_units=(256,), embedding_size=128, audio_feat=80)),
+    ("c5_av_align", dict(video_units=(256,), audio_units=(256, 256), decoder_units=(256,), embedding_size=128,
+                         video_feat=128, audio_feat=80, use_dropout=True)),
+]
+
+
+@pytest.mark.parametrize("mode", ["0", "3"])
+@pytest.mark.parametrize("case,over", FULL_WIDTH)
+def test_full_width_train_step(case, over, mode, monkeypatch):
+    from avsr_tf1_amd import ops
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    monkeypatch.setenv("AVSR_PERSISTENT_RNN", mode)
+    O, ocfg, mcfg, W, batch = make(case, B=64, Ta=26, Tv=9, L=5, **over)
+    ref = O.train_step(W, None, ocfg, batch)
+    try:
+        model = Seq2SeqModel(mcfg, weights=W)
+        db = Batch.from_numpy(batch)
+        logits = model.forward_train(db)
+        model.backward()
+        model.apply_update()
+        torch.cuda.synchronize()
+        assert not ops.rnn_persistent_error()
+    finally:
+        ops.rnn_set_persistent(False)
+    assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
+    assert abs(float(model.loss.item()) - ref["loss"]) < 1e-4
+    assert abs(float(model.gnorm.item()) - ref["global_norm"]) < 1e-4 * max(1.0, ref["global_norm"])
+    grads = model.export_tf_weights("grads")
+    for k, g in ref["grads"].items():
+        scale = max(1e-3, np.abs(g).max())
+        assert np.abs(grads[k] - g).max() < 2e-4 * scale + 1e-6, k
+
+
+# ------------------------------------------------------------------------------------------------
 # beam search (the reference's default decoding_algorithm, avsr.py:58): engine vs the oracle restatement
 @pytest.mark.parametrize("case", ["c1_audio_uni_luong", "c2_audio_bi_bahdanau", "c4_bimodal_uni", "c5_av_align", "gru_audio_uni"])
 @pytest.mark.parametrize("K", [1, 4])
