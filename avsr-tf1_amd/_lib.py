@@ -160,7 +160,7 @@ def load():
         "avsr_global_norm": [vp, i64, f32, vp, vp, vp],
         "avsr_adam_step": [vp, vp, vp, vp, i64, vp, vp, f32, i32, f32, f32, vp],
         "avsr_prof_begin": [i32],
-        "avsr_prof_end": [C.POINTER(i32), C.POINTER(f32)],
+        "avsr_prof_end": [C.POINTER(i32), C.POINTER(f32), C.POINTER(C.c_double)],
     }
     for name, at in sigs.items():
         fn = getattr(lib, name)

@@ -242,7 +242,7 @@ extern "C" int avsr_gemm(const avsr_gemm_desc* d, void* stream) {
   const bool vb = vec_ok(&d->B, g.tb != 0, g.N, g.K);
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * splitk);
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(PROF_GEMM, s);
+  ProfScope ps(PROF_GEMM, s, 2.0 * g.M * g.N * g.K * g.batch);
   if (va && vb) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, g);
   else if (va) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, g);
   else if (vb) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, g);

@@ -35,9 +35,11 @@ __device__ __forceinline__ bool wait_ge(const int* ctr, int target, int* err) {
 
 __device__ __forceinline__ float p_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float p_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
-__device__ __forceinline__ float p_drop(const int32_t* seed, uint32_t stream, uint32_t idx, float keep) {
-  if (!seed || keep >= 1.0f) return 1.0f;
-  return uniform01((uint32_t)seed[0], stream, idx) < keep ? 1.0f / keep : 0.0f;
+// DropoutWrapper mask scale.  The seed VALUE is read once per kernel: a load inside the step loop would put an
+// s_waitcnt vmcnt(0) -- and with it every operand prefetched for the next step -- on the critical path.
+__device__ __forceinline__ float p_drop(bool on, uint32_t seedv, uint32_t stream, uint32_t idx, float keep) {
+  if (!on || keep >= 1.0f) return 1.0f;
+  return uniform01(seedv, stream, idx) < keep ? 1.0f / keep : 0.0f;
 }
 
 __device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf; }   // HW_REG_XCC_ID[3:0]
@@ -48,13 +50,35 @@ __device__ __forceinline__ f32x4 ldx_sc1(__amdgpu_buffer_rsrc_t r, int elem_off)
 }
 
 
+// Workgroup barrier that does NOT drain the vector-memory queue.  __syncthreads() carries a workgroup-scope fence, which
+// the compiler lowers to s_waitcnt vmcnt(0) before s_barrier: every operand prefetched for the NEXT step would be waited
+// for on the critical path of THIS step.  The persistent kernels only need LDS ordering (and plain arrival) at their
+// in-step barriers; the publish barrier drains stores explicitly.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // 16-byte write-through store (one fabric write; four scalar sc1 stores cost ~6x per byte)
 __device__ __forceinline__ void stx_sc1(__amdgpu_buffer_rsrc_t r, int elem_off, f32x4 v) {
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r, elem_off * 4, 0, 16);
 }
+// Raw buffer resource of 2 GiB: byte offsets < 2^31 are in range, P_OOB (2^31) is out of range, so an operand a lane
+// must not fetch is "loaded" with offset P_OOB: the hardware returns 0 without touching memory and the load stays
+// unconditional.  (Loads inside divergent branches make the compiler give up counting vmcnt and wait for everything.)
+#define P_OOB ((int)0x80000000)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xffffffff, 0x00020000);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x80000000u, 0x00020000);
+}
+// byte-offset forms
+__device__ __forceinline__ f32x4 ldb_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f32x4, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
+__device__ __forceinline__ f32x4 ldb4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f32x4, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float ldb1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
 
 }  // namespace avsr

@@ -5,12 +5,13 @@
 
 namespace avsr {
 enum ProfKind { PROF_GEMM = 0, PROF_STEP_LSTM_FWD, PROF_STEP_LSTM_BWD, PROF_STEP_LINEAR, PROF_ATTN_FWD, PROF_ATTN_BWD,
-                PROF_NKIND };
-void prof_record(int kind, hipStream_t s, bool begin);
+                PROF_RNN_PERSIST_FWD, PROF_RNN_PERSIST_BWD, PROF_NKIND };
+void prof_record(int kind, hipStream_t s, bool begin, double work = 0.0);
 extern bool g_prof_enabled;
 struct ProfScope {
   int kind; hipStream_t s;
-  ProfScope(int k, hipStream_t st) : kind(k), s(st) { if (g_prof_enabled) prof_record(kind, s, true); }
+  // work = algorithmic FLOPs of the launch where the caller knows them (GEMM, persistent RNN kernels)
+  ProfScope(int k, hipStream_t st, double work = 0.0) : kind(k), s(st) { if (g_prof_enabled) prof_record(kind, s, true, work); }
   ~ProfScope() { if (g_prof_enabled) prof_record(kind, s, false); }
 };
 }  // namespace avsr

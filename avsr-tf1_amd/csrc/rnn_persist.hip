@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(const PLaunch L) {
   const int out_st = (int)tk.out_st, hs_st = (int)tk.hs_st, xt_st = (int)tk.xt_st;
   float* const gates_p = tk.gates; float* const cs_p = tk.cs; float* const out_p = tk.out;
   float* const hsw_p = tk.hs_w; float* const xtw_p = tk.xt_w;
-  const int32_t* const seed = tk.seed;
+  const bool drop_on = tk.seed != nullptr;
+  const uint32_t seedv = drop_on ? (uint32_t)tk.seed[0] : 0u;
   const float k_st = tk.k_st, k_out = tk.k_out, k_in = tk.k_in;
   const uint32_t r_st = tk.r_st, r_out = tk.r_out, r_in = tk.r_in;
   const int in_W = tk.in_W, in_coff = tk.in_coff;
@@ -159,13 +160,14 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(const PLaunch L) {
 #ifdef PERSIST_TIMING
     long last_ = __builtin_amdgcn_s_memtime();
 #endif
-    const f32x4 zpre = znext;
+    f32x4 zpre = znext;                          // prefetched during the previous step; handed over here (see rnn_persist_bwd.hip)
+    asm volatile("" : "+v"(zpre));
     // ---- dependencies: previous step of this layer (all column tiles of my row tile); layer below one step ahead ----
     if (tid == 0) {
       const int tl = t + 1 < T ? t + 1 : T - 1;
       wait_ge2(t > 0 ? done_mine + (t - 1) : nullptr, nct, done_low ? done_low + tl : nullptr, nct_lower, L.err);
     }
-    __syncthreads();
+    lds_barrier();
     TICK(0)
 
     // ---- recurrent operand rows (sc1: produced by other CUs during this launch), next step's input rows ----
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(const PLaunch L) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave][nt][(lane >> 4) * 4 + r][lane & 15] = s4[r];
     }
-    __syncthreads();
+    lds_barrier();
     TICK(2)
 
     // ---- gates, cell clip, length masking, dropout; records + exchanged outputs ----
@@ -239,11 +241,11 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(const PLaunch L) {
         c = fminf(1.0f, fmaxf(-1.0f, c));
         const float h = g4[3] * p_tanh(c);
         const uint32_t oidx = (uint32_t)(bt * H + u);
-        const float ho = h * p_drop(seed, r_out, oidx, k_out);
-        const float hs = h * p_drop(seed, r_st, oidx, k_st);
+        const float ho = h * p_drop(drop_on, seedv, r_out, oidx, k_out);
+        const float hs = h * p_drop(drop_on, seedv, r_st, oidx, k_st);
         st_sc1(out_p + (out_b + tau * out_st), ho);                 // exchanged values first, records after
         if (hsw_p) st_sc1(hsw_p + (hsw_b + tau * hs_st), hs);
-        if (xtw_p) st_sc1(xtw_p + (xtw_b + tau * xt_st), ho * p_drop(seed, r_in, (uint32_t)(bt * in_W + in_coff + u), k_in));
+        if (xtw_p) st_sc1(xtw_p + (xtw_b + tau * xt_st), ho * p_drop(drop_on, seedv, r_in, (uint32_t)(bt * in_W + in_coff + u), k_in));
 #ifndef PROBE_NOREC
         st4(gates_p + (long)(rec_b + tau * H) * 4, g4);
         cs_p[rec_b + tau * H] = c;
@@ -367,7 +369,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int out_st = (int)tk.out_st, hs_st = (int)tk.hs_st, xt_st = (int)tk.xt_st;
   float* const gates_p = tk.gates; float* const cs_p = tk.cs; float* const out_p = tk.out;
   float* const hsw_p = tk.hs_w; float* const xtw_p = tk.xt_w;
-  const int32_t* const seed = tk.seed;
+  const bool drop_on = tk.seed != nullptr;
+  const uint32_t seedv = drop_on ? (uint32_t)tk.seed[0] : 0u;
   const float k_st = tk.k_st, k_out = tk.k_out, k_in = tk.k_in;
   const uint32_t r_st = tk.r_st, r_out = tk.r_out, r_in = tk.r_in;
   const int in_W = tk.in_W, in_coff = tk.in_coff;
@@ -410,10 +413,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #ifdef PERSIST_TIMING
     long last_ = __builtin_amdgcn_s_memtime();
 #endif
-    const f32x4 zpre = znext;
+    f32x4 zpre = znext;                          // prefetched during the previous step; handed over here (see rnn_persist_bwd.hip)
+    asm volatile("" : "+v"(zpre));
     // dependencies: step t-1 of this layer (all column tiles of my rows); the layer below one step ahead
     wait_progress(t, t + 2 < T ? t + 2 : T);
-    __syncthreads();
+    lds_barrier();
     TICK(0)
     const bool avalid = aok && t < len_a;
     const int ho_ = hrow + (reverse ? len_a - 1 - t : t) * h_st;
@@ -423,6 +427,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const int k = (hg0 + c) * 16;
       hv[c] = (c < nhw && avalid && t > 0 && k + 4 * q < H) ? ldx_sc1(h_rs, ho_ + k) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#ifdef PERSIST_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // timing build only: isolate the recurrent-operand latency
+    TICK(1)
+#endif
     f32x4 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -443,10 +451,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // younger than the recurrent operands or it would stall their wait.
     if (eok && hoisted && t + 1 < len_b) znext = ld4(gates_p + (long)(rec_b + (reverse ? len_b - 2 - t : t + 1) * H) * 4);
     asm volatile("" ::: "memory");
-#ifdef PERSIST_TIMING
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TICK(1)
-#endif
 #pragma unroll
     for (int c = 0; c < P_HC; ++c)
       if (c < nhw) {
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][nt][q * 4 + r][i] = acc[nt][r];
     }
-    __syncthreads();
+    lds_barrier();
     TICK(2)
     if (eok) {
       const bool valid = t < len_b;
@@ -488,11 +492,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         c = fminf(1.0f, fmaxf(-1.0f, c));
         const float h = g4[3] * p_tanh(c);
         const uint32_t oidx = (uint32_t)(bt * H + u);
-        const float ho = h * p_drop(seed, r_out, oidx, k_out);
-        const float hs = h * p_drop(seed, r_st, oidx, k_st);
+        const float ho = h * p_drop(drop_on, seedv, r_out, oidx, k_out);
+        const float hs = h * p_drop(drop_on, seedv, r_st, oidx, k_st);
         out_p[out_b + tau * out_st] = ho;                              // exchanged values first, records after
         if (hsw_p) hsw_p[hsw_b + tau * hs_st] = hs;
-        if (xtw_p) xtw_p[xtw_b + tau * xt_st] = ho * p_drop(seed, r_in, (uint32_t)(bt * in_W + in_coff + u), k_in);
+        if (xtw_p) xtw_p[xtw_b + tau * xt_st] = ho * p_drop(drop_on, seedv, r_in, (uint32_t)(bt * in_W + in_coff + u), k_in);
         st4(gates_p + (long)(rec_b + tau * H) * 4, g4);
         cs_p[rec_b + tau * H] = c;
         c_state = c;
@@ -539,8 +543,10 @@ namespace avsr {
 
 // Fill the task table for one persistent launch.  local = XCD-local variant (8-row groups, progress words),
 // else the agent-scope variant (16-row tiles, arrival counters).  Returns AVSR_ERR_UNSUPPORTED if it does not fit.
+static double g_fwd_flops = 0.0;      // algorithmic FLOPs of the launch being built (event profiler)
 static int build_tasks(const avsr_rnn_stack* st, int n, bool local, int32_t* sync, int64_t sync_ints, PLaunch& L, int* wg_out, long* words_out) {
   L = PLaunch{};
+  g_fwd_flops = 0.0;
   int wg = 0;
   long ctr = P_HDR + 8;                 // [P_HDR, P_HDR+8): per-XCD slot claim counters
   for (int i = 0; i < n; ++i) {
@@ -572,6 +578,7 @@ static int build_tasks(const avsr_rnn_stack* st, int n, bool local, int32_t* syn
       if (S.seed && Ly.xt_seq) { tk.xt_w = Ly.xt_seq + H; tk.xt_sb = (long)(S.T + 2) * H; tk.xt_st = H; }
       tk.h_final = Ly.h_final; tk.c_final = Ly.c_final;
       tk.B = S.B; tk.T = S.T; tk.H = H; tk.in = in; tk.hoisted = Ly.hoisted; tk.reverse = S.reverse;
+      g_fwd_flops += 2.0 * S.B * S.T * ((Ly.hoisted ? 0 : in) + H) * 4.0 * H;
       tk.uw = (local && Ly.hoisted && H % 16 == 0) ? 16 : 8;
       tk.nct = H / tk.uw; tk.nrt = nrt; tk.wg_begin = wg;
       if (tk.nct > 32) return AVSR_ERR_UNSUPPORTED;
@@ -614,7 +621,7 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
     if (dry) return AVSR_OK;
     if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
-      ProfScope ps(PROF_STEP_LSTM_FWD, s);
+      ProfScope ps(PROF_RNN_PERSIST_FWD, s, g_fwd_flops);
       hipLaunchKernelGGL(rnn_persist_fwd_xcd_kernel, dim3(8 * wg), dim3(256), 0, s, L);
     }
     AVSR_CHECK_LAUNCH();
@@ -624,7 +631,7 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
     if (dry) return AVSR_OK;
     if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
-      ProfScope ps(PROF_STEP_LSTM_FWD, s);
+      ProfScope ps(PROF_RNN_PERSIST_FWD, s, g_fwd_flops);
       hipLaunchKernelGGL(rnn_persist_fwd_kernel, dim3(wg), dim3(256), 0, s, L);
     }
     AVSR_CHECK_LAUNCH();

@@ -64,26 +64,35 @@ __global__ __launch_bounds__(512) void rnn_persist_bwd_kernel(const BLaunch L) {
   const int unit0 = ct * 16 * NT, row0 = g * 16;
   const int i = lane & 15, q = lane >> 4;
   const int K_own = 4 * H, K_up = 4 * tk.H_up;
+  // ---- K split.  Every wave runs two runs of <= 8 chunks (16 K each): operand part A with weights wA into acc0,
+  // part B with wB into acc1.
+  //   cell with a layer above : A = own d gates (ring), chunks split over the 8 waves; B = upper layer's d gates
+  //                             (prefetched a step ahead), chunks split over the 8 waves; both for column tile 0
+  //   top cell, 2 column tiles: wave w serves tile w>>2 with the K quarter w&3: A = first half of the quarter, B = second
+  //   top cell, 1 column tile : A = own d gates split over the 8 waves; B unused
+  const bool two = top && NT == 2;
   const int nco = K_own >> 4, ncu = top ? 0 : K_up >> 4;
-  const int oc0 = (wave * nco) / 8, n_own = ((wave + 1) * nco) / 8 - oc0;      // <= B_CH (host-checked)
-  const int uc0 = (wave * ncu) / 8, n_up = ((wave + 1) * ncu) / 8 - uc0;
+  int a0, nA, b0, nB;                        // first chunk / chunk count of parts A and B (chunk = 16 K)
+  if (two) {
+    const int kq = wave & 3, q0 = (kq * nco) / 4, q1 = ((kq + 1) * nco) / 4, qm = q0 + (q1 - q0 + 1) / 2;
+    a0 = q0; nA = qm - q0; b0 = qm; nB = q1 - qm;
+  } else {
+    a0 = (wave * nco) / 8; nA = ((wave + 1) * nco) / 8 - a0;
+    b0 = (wave * ncu) / 8; nB = ((wave + 1) * ncu) / 8 - b0;
+  }
+  const int wtile = two ? wave >> 2 : 0;     // column tile this wave multiplies
 
   // ---- weight slices: registers for the whole sequence ----
-  // w1: Wh^T rows of column tile 0.  w2: top cell -> column tile 1 of Wh^T;  else -> the upper layer's Wx^T rows.
-  f32x4 w1[B_CH], w2[B_CH];
+  f32x4 wA[B_CH], wB[B_CH];
   {
-    const int u1 = unit0 + i, u2 = unit0 + 16 + i;
+    const int uu = unit0 + wtile * 16 + i;
 #pragma unroll
     for (int c = 0; c < B_CH; ++c) {
-      const int k = (oc0 + c) * 16 + 4 * q;
-      w1[c] = (c < n_own && u1 < H) ? ld4(tk.w_own + (long)u1 * tk.ldw_own + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      wA[c] = (c < nA && uu < H) ? ld4(tk.w_own + (long)uu * tk.ldw_own + (a0 + c) * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (top) {
-        if (NT == 2 && c < n_own && u2 < H) v = ld4(tk.w_own + (long)u2 * tk.ldw_own + k);
-      } else if (c < n_up && u1 < H) {
-        v = ld4(tk.w_up + (long)u1 * tk.ldw_up + (uc0 + c) * 16 + 4 * q);
-      }
-      w2[c] = v;
+      if (c < nB && uu < H) v = top ? ld4(tk.w_own + (long)uu * tk.ldw_own + (b0 + c) * 16 + 4 * q)
+                                    : ld4(tk.w_up + (long)uu * tk.ldw_up + (b0 + c) * 16 + 4 * q);
+      wB[c] = v;
     }
   }
 
@@ -95,27 +104,29 @@ __global__ __launch_bounds__(512) void rnn_persist_bwd_kernel(const BLaunch L) {
   float dc_carry = (eok && tk.dc_final) ? tk.dc_final[(long)b * H + u] : 0.f;
   float dh_carry = (eok && tk.dh_final) ? tk.dh_final[(long)b * H + u] : 0.f;
   const int rec_b = b * T * H + u;
-  const float* const gates_p = tk.gates; const float* const cs_p = tk.cs;
+  const __amdgpu_buffer_rsrc_t gates_rs = make_rsrc(tk.gates), cs_rs = make_rsrc(tk.cs), dout_rs = make_rsrc(tk.dout);
+  const bool has_dout = tk.dout != nullptr;
   float* const dgates_p = tk.dgates;
   const __amdgpu_buffer_rsrc_t dgates_rs = make_rsrc(tk.dgates);
   float* const ring_p = tk.ring;
-  const float* const dout_p = tk.dout;
   const int dout_b = (int)(b * tk.dout_sb) + u, dout_st = (int)tk.dout_st;
-  const int32_t* const seed = tk.seed;
+  const bool drop_on = tk.seed != nullptr;
+  const uint32_t seedv = drop_on ? (uint32_t)tk.seed[0] : 0u;
   const float k_st = tk.k_st, k_out = tk.k_out, k_in = tk.k_in;
   const uint32_t r_st = tk.r_st, r_out = tk.r_out, r_in = tk.r_in;
   const int in_W = tk.in_W, in_coff = tk.in_coff;
   const bool publish_remote = tk.ctr != nullptr;
 
-  // ---- A-operand row of this lane ----
+  // ---- A-operand row of this lane (byte offsets; P_OOB = "reads as zero") ----
   const int ab = row0 + i;
   const bool aok = ab < tk.B;
   const int len_a = aok ? (tk.len ? tk.len[ab] : T) : 0;
   const __amdgpu_buffer_rsrc_t ring_rs = make_rsrc(tk.ring);
   const __amdgpu_buffer_rsrc_t up_rs = make_rsrc(tk.up_dgates);
-  const int ring_row = ab * K_own + oc0 * 16 + 4 * q;
-  const int ring_par = tk.B * K_own;
-  const int up_row = ab * T * K_up + uc0 * 16 + 4 * q;
+  const int ring_par = tk.B * K_own * 4;                                   // bytes between the two ring slots
+  const int ringA = aok ? (ab * K_own + a0 * 16 + 4 * q) * 4 : P_OOB;
+  const int ringB = aok ? (ab * K_own + b0 * 16 + 4 * q) * 4 : P_OOB;     // top cell with two tiles only
+  const int up_row = (ab * T * K_up + b0 * 16 + 4 * q) * 4;
 
   // ---- progress polling (wave 0): lanes 0-31 own progress words, lanes 32-63 the upper layer ----
   int* const my_prog = tk.prog + g * 32 + ct;
@@ -142,29 +153,26 @@ __global__ __launch_bounds__(512) void rnn_persist_bwd_kernel(const BLaunch L) {
     if (lane == 0) __hip_atomic_store(L.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
-  // upper-layer operands (d gates of the layer above at the same step) run one step ahead of the recurrence
-  f32x4 a_up[B_CH];
+  // part-B operands of a cell with a layer above (d gates of that layer at the same step) run one step ahead
+  f32x4 aB[B_CH];
 #pragma unroll
-  for (int c = 0; c < B_CH; ++c) a_up[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < B_CH; ++c) aB[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto load_up = [&](int t) {
-    const bool v = aok && t < len_a;
-    const int o = up_row + (reverse ? len_a - 1 - t : t) * K_up;
+    const int o = (aok && t >= 0 && t < len_a) ? up_row + (reverse ? len_a - 1 - t : t) * (K_up * 4) : P_OOB;
 #pragma unroll
-    for (int c = 0; c < B_CH; ++c)
-      a_up[c] = (c < n_up && v) ? ldx_sc1(up_rs, o + c * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < B_CH; ++c) aB[c] = ldb_sc1(up_rs, c < nB ? o + c * 64 : P_OOB);
   };
   // epilogue operands of the next step (records written by the forward pass: cold in HBM) are fetched a step ahead
   f32x4 n_g = {0.f, 0.f, 0.f, 0.f};
   float n_c = 0.f, n_cp = 0.f, n_do = 0.f;
   auto load_rec = [&](int t) {
-    if (eok && t >= 0 && t < len_b) {
-      const int tau = reverse ? len_b - 1 - t : t;
-      const int o = rec_b + tau * H;
-      n_g = ld4(gates_p + (long)o * 4);
-      n_c = cs_p[o];
-      n_cp = t == 0 ? 0.f : cs_p[o + (reverse ? H : -H)];
-      n_do = dout_p ? dout_p[dout_b + tau * dout_st] : 0.f;
-    }
+    const bool v = eok && t >= 0 && t < len_b;
+    const int tau = reverse ? len_b - 1 - t : t;
+    const int o = v ? (rec_b + tau * H) * 4 : P_OOB;
+    n_g = ldb4(gates_rs, v ? o * 4 : P_OOB);
+    n_c = ldb1(cs_rs, o);
+    n_cp = ldb1(cs_rs, (v && t > 0) ? o + (reverse ? H : -H) * 4 : P_OOB);
+    n_do = ldb1(dout_rs, (v && has_dout) ? (dout_b + tau * dout_st) * 4 : P_OOB);
   };
   if (!top) {
     wait_progress(0, T - 1);
@@ -172,47 +180,67 @@ __global__ __launch_bounds__(512) void rnn_persist_bwd_kernel(const BLaunch L) {
     load_up(T - 1);
   }
   load_rec(T - 1);
+#ifdef PERSIST_TIMING
+  long tm[6] = {0, 0, 0, 0, 0, 0};
+#define BTICK(k) { const long now_ = __builtin_amdgcn_s_memtime(); tm[k] += now_ - last_; last_ = now_; }
+#else
+#define BTICK(k)
+#endif
 
   for (int t = T - 1; t >= 0; --t) {
-    const f32x4 g4 = n_g;
-    const float c = n_c, cprev = n_cp, dout_ext = n_do;
+#ifdef PERSIST_TIMING
+    long last_ = __builtin_amdgcn_s_memtime();
+#endif
+    // hand the records prefetched during the previous step over HERE (pinned by the empty asm): left to the compiler the
+    // copy sinks to just before the next prefetch, behind loads issued in between, and its wait serialises them
+    f32x4 g4 = n_g;
+    float c = n_c, cprev = n_cp, dout_ext = n_do;
+    asm volatile("" : "+v"(g4), "+v"(c), "+v"(cprev), "+v"(dout_ext));
     // dependencies: step t+1 of this cell (every column tile of my rows); the cell above one step ahead (t-1)
     wait_progress(T - 1 - t, t > 0 ? t - 1 : 0);
-    __syncthreads();
+    lds_barrier();
+    BTICK(0)
     // ---- recurrent operand: d gates of step t+1 from the two-slot ring (zero-filled by the host for t = T-1) ----
-    f32x4 a_own[B_CH];
+    f32x4 aA[B_CH];
     {
-      const int o = ring_row + ((t + 1) & 1) * ring_par;
+      const int par = ((t + 1) & 1) * ring_par;
+      const int oA = aok ? ringA + par : P_OOB, oB = aok ? ringB + par : P_OOB;
 #pragma unroll
-      for (int cc = 0; cc < B_CH; ++cc)
-        a_own[cc] = (cc < n_own && aok) ? ldx_sc1(ring_rs, o + cc * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int cc = 0; cc < B_CH; ++cc) aA[cc] = ldb_sc1(ring_rs, cc < nA ? oA + cc * 64 : P_OOB);
+      if (two) {
+#pragma unroll
+        for (int cc = 0; cc < B_CH; ++cc) aB[cc] = ldb_sc1(ring_rs, cc < nB ? oB + cc * 64 : P_OOB);
+      }
     }
+#ifdef PERSIST_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // timing build only: isolate the recurrent-operand latency
+    BTICK(1)
+#endif
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    if (!top) {
-      // upper-layer part first: its operands arrived a step ago, so these MFMAs run under the loads just issued
+    if (!two) {
+      // part B (upper layer, or nothing): operands arrived a step ago, so these MFMAs run under the loads just issued
 #pragma unroll
       for (int cc = 0; cc < B_CH; ++cc)
-        if (cc < n_up) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_up[cc][e], w2[cc][e], acc1, 0, 0, 0);
-        }
-      if (t > 0) load_up(t - 1);               // refill in place: consumed a step from now
+        for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[cc][e], wB[cc][e], acc1, 0, 0, 0);
+      load_up(t - 1);                          // refill in place: consumed a step from now
     }
     load_rec(t - 1);                           // issued last: vmcnt retires in order (see rnn_persist.hip)
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int cc = 0; cc < B_CH; ++cc)
-      if (cc < n_own) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_own[cc][e], w1[cc][e], acc0, 0, 0, 0);
-        if (top && NT == 2) {
+      for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aA[cc][e], wA[cc][e], acc0, 0, 0, 0);
+    if (two) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_own[cc][e], w2[cc][e], acc1, 0, 0, 0);
-        }
-      }
+      for (int cc = 0; cc < B_CH; ++cc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[cc][e], wB[cc][e], acc1, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { red[wave][0][q * 4 + r][i] = acc0[r]; red[wave][1][q * 4 + r][i] = acc1[r]; }
-    __syncthreads();
+    lds_barrier();
+    BTICK(2)
 
     // ---- LSTM cell backward (same arithmetic as EP_LSTM_BWD in step.hip) ----
     if (eok) {
@@ -222,18 +250,18 @@ __global__ __launch_bounds__(512) void rnn_persist_bwd_kernel(const BLaunch L) {
       if (valid) {
         tau = reverse ? len_b - 1 - t : t;
         float zA = 0.f, zB = 0.f;
-        const int ka = top ? tile : 0;
+        if (two) {                               // the four waves of my column tile, both halves of their K quarter
 #pragma unroll
-        for (int w = 0; w < 8; ++w) zA += red[w][ka][er][eu];
-        if (!top) {
+          for (int w = 0; w < 4; ++w) zA += red[tile * 4 + w][0][er][eu] + red[tile * 4 + w][1][er][eu];
+        } else {
 #pragma unroll
-          for (int w = 0; w < 8; ++w) zB += red[w][1][er][eu];
+          for (int w = 0; w < 8; ++w) { zA += red[w][0][er][eu]; zB += red[w][1][er][eu]; }
         }
         const long bt = (long)b * T + tau;
         const uint32_t oidx = (uint32_t)(bt * H + u);
         const uint32_t iidx = (uint32_t)(bt * in_W + in_coff + u);
-        const float dout = dout_ext + zB * p_drop(seed, r_in, iidx, k_in);
-        const float dh = dout * p_drop(seed, r_out, oidx, k_out) + (zA + dh_carry) * p_drop(seed, r_st, oidx, k_st);
+        const float dout = dout_ext + zB * p_drop(drop_on, seedv, r_in, iidx, k_in);
+        const float dh = dout * p_drop(drop_on, seedv, r_out, oidx, k_out) + (zA + dh_carry) * p_drop(drop_on, seedv, r_st, oidx, k_st);
         const float tc = p_tanh(c);
         float dc = dh * g4[3] * (1.f - tc * tc) + dc_carry;
         if (!(fabsf(c) < 1.0f)) dc = 0.f;      // cell_clip = 1.0: no gradient through a clipped cell
@@ -245,19 +273,26 @@ __global__ __launch_bounds__(512) void rnn_persist_bwd_kernel(const BLaunch L) {
         dh_carry = 0.f;
       }
       // ring first (the recurrence reads it), then the record (zero at padding position t past the utterance)
-      st4(ring_p + (long)(t & 1) * ring_par + (long)b * K_own + u * 4, dg);
+      st4(ring_p + (long)(t & 1) * (ring_par >> 2) + (long)b * K_own + u * 4, dg);
       const int ro = (rec_b + tau * H) * 4;
       if (publish_remote) stx_sc1(dgates_rs, ro, dg);
       else st4(dgates_p + ro, dg);
     }
+    BTICK(3)
     // ---- publish ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    BTICK(4)
     if (tid == 0) {
       __hip_atomic_store(my_prog, T - t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (my_ctr) __hip_atomic_fetch_add(my_ctr + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    BTICK(5)
   }
+#ifdef PERSIST_TIMING
+  if (tid == 0 && ct == 0 && g == 0)
+    for (int k = 0; k < 6; ++k) L.err[80 + ti * 8 + k] = (int)(tm[k] / T);
+#endif
 }
 
 // Choose the XCD half of every cell: all assignments are enumerated (<= 2^8); feasible ones keep each half within
@@ -290,6 +325,7 @@ int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
   if (!sync || !(g_persist_mode & 2)) return AVSR_ERR_UNSUPPORTED;
   static thread_local BLaunch L;
   L = BLaunch{};
+  double flops = 0.0;
   int cost[B_MAX_TASKS], upper[B_MAX_TASKS], half[B_MAX_TASKS];
   const int B = st[0].B;
   const int ngroups = (B + 15) / 16;
@@ -303,9 +339,9 @@ int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
       if (L.ntask >= B_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
       const int H = Ly.units, in = Ly.in_dim;
       const bool top = l + 1 >= S.n_layers;
-      if (H % 16 || H > 32 * B_CH || (long)S.B * S.T * H * 4 >= (1L << 30)) return AVSR_ERR_UNSUPPORTED;
+      if (H % 16 || H > 32 * B_CH || (long)S.B * S.T * H * 4 >= (1L << 29)) return AVSR_ERR_UNSUPPORTED;
       if (!top && (S.layer[l + 1].units % 16 || S.layer[l + 1].units > 32 * B_CH || S.layer[l + 1].in_dim != H)) return AVSR_ERR_UNSUPPORTED;
-      if (Ly.dout && (long)S.B * (S.T + 2) * Ly.ld_dout >= (1L << 30)) return AVSR_ERR_UNSUPPORTED;
+      if (Ly.dout && (long)S.B * (S.T + 2) * Ly.ld_dout >= (1L << 29)) return AVSR_ERR_UNSUPPORTED;
       const int t_i = L.ntask++;
       BTask& tk = L.task[t_i];
       tk.w_own = Ly.w + (long)in * 4 * H; tk.ldw_own = 4 * H;
@@ -314,6 +350,7 @@ int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
       if (Ly.dout) { tk.dout = Ly.dout + Ly.ld_dout + Ly.dout_col; tk.dout_sb = (long)(S.T + 2) * Ly.ld_dout; tk.dout_st = Ly.ld_dout; }
       if (top) { tk.dh_final = S.dh_final; tk.dc_final = S.dc_final; }
       tk.B = S.B; tk.T = S.T; tk.H = H; tk.reverse = S.reverse;
+      flops += 2.0 * S.B * S.T * (4.0 * H + (top ? 0.0 : 4.0 * S.layer[l + 1].units)) * H;
       tk.ntile = (top && H % 32 == 0) ? 2 : 1;
       tk.nct = H / (16 * tk.ntile);
       if (tk.nct > 32) return AVSR_ERR_UNSUPPORTED;
@@ -354,7 +391,7 @@ int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
   if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
   const int wpx = slots[0] > slots[1] ? slots[0] : slots[1];
   {
-    ProfScope ps(PROF_STEP_LSTM_BWD, s);
+    ProfScope ps(PROF_RNN_PERSIST_BWD, s, flops);
     hipLaunchKernelGGL(rnn_persist_bwd_kernel, dim3(8 * wpx), dim3(512), 0, s, L);
   }
   AVSR_CHECK_LAUNCH();

@@ -505,11 +505,13 @@ extern "C" int avsr_step_launch_raw(const void* launch, void* stream) {
   }
   const int mode = L->task[0].mode;
   int ksum = 0;
+  double flops = 0.0;                                    // algorithmic FLOPs of this launch (event profiler)
   for (int i = 0; i < L->ntask; ++i) {
     if (L->task[i].mode != mode) return AVSR_ERR_ARG;   // one epilogue kind per launch
     int k = 0;
     for (int j = 0; j < L->task[i].nsrc; ++j) k += L->task[i].src[j].K;
     if (k > ksum) ksum = k;
+    flops += 2.0 * L->task[i].B * L->task[i].N * k;
   }
   hipStream_t s = (hipStream_t)stream;
   // geometry (TM, TN, KP): probe sweep on MI355X (tools/step_probe.hip, B=64 H=256 3-task wavefront):
@@ -520,7 +522,7 @@ extern "C" int avsr_step_launch_raw(const void* launch, void* stream) {
   if (g_step_geo >= 0) geo = g_step_geo;
 #define LAUNCH_(M, K_)                                                                                         \
   {                                                                                                            \
-    ProfScope ps(K_, s);                                                                                       \
+    ProfScope ps(K_, s, flops);                                                                                    \
     switch (geo) {                                                                                             \
       case 0: hipLaunchKernelGGL((step_kernel<M, 1, 1, 4>), GRID(1, 1), dim3(256), 0, s, *L); break;           \
       case 1: hipLaunchKernelGGL((step_kernel<M, 1, 1, 8>), GRID(1, 1), dim3(512), 0, s, *L); break;           \

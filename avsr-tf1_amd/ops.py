@@ -163,7 +163,7 @@ def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, 
                               int(warmup_steps), float(clip_norm), float(grad_scale), _s()), "avsr_adam_step")
 
 
-PROF_KINDS = ("gemm", "step_lstm_fwd", "step_lstm_bwd", "step_dense", "attn_fwd", "attn_bwd")
+PROF_KINDS = ("gemm", "step_lstm_fwd", "step_lstm_bwd", "step_dense", "attn_fwd", "attn_bwd", "rnn_persist_fwd", "rnn_persist_bwd")
 
 
 def prof_begin(max_launches=65536):
@@ -171,11 +171,12 @@ def prof_begin(max_launches=65536):
 
 
 def prof_end():
-    """{kind: (launch count, total ms)} since prof_begin (synchronises the device)."""
+    """{kind: (launch count, total ms, algorithmic FLOPs or 0)} since prof_begin (synchronises the device)."""
     cnt = (C.c_int32 * len(PROF_KINDS))()
     ms = (C.c_float * len(PROF_KINDS))()
-    check(_L().avsr_prof_end(cnt, ms), "avsr_prof_end")
-    return {k: (int(cnt[i]), float(ms[i])) for i, k in enumerate(PROF_KINDS)}
+    fl = (C.c_double * len(PROF_KINDS))()
+    check(_L().avsr_prof_end(cnt, ms, fl), "avsr_prof_end")
+    return {k: (int(cnt[i]), float(ms[i]), float(fl[i])) for i, k in enumerate(PROF_KINDS)}
 
 
 _persist_sync = None

@@ -209,11 +209,13 @@ def main():
         prof = ops.prof_end()
         wm = work_model(cfg, B)
         kinds = {}
-        for k, (cnt, ms) in prof.items():
+        for k, (cnt, ms, fl) in prof.items():
             if cnt:
                 kinds[k] = {"launches": cnt, "total_ms": round(ms, 3), "avg_us": round(1e3 * ms / cnt, 3)}
+                if fl:
+                    kinds[k]["algorithmic_gflop"] = round(fl / 1e9, 3)
         out["kernel_time_events"] = kinds
-        dom = max((k for k in kinds if k != "gemm" or True), key=lambda k: kinds[k]["total_ms"])
+        dom = max(kinds, key=lambda k: kinds[k]["total_ms"])
         HBM_PEAK, MFMA_PEAK = 8000.0, 157.3
         # HBM traffic per launch from the committed PMC passes (profiles/r01_c4_pmc.json: FETCH_SIZE / WRITE_SIZE collected in
         # separate rocprofv3 runs of this same workload, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); null
@@ -225,7 +227,8 @@ def main():
         except Exception:
             pmc = {}
         pmc_name = {"attn_fwd": "avsr::attn_fwd_kernel", "attn_bwd": "avsr::attn_bwd_kernel",
-                    "step_lstm_fwd": "avsr::step_kernel<1, 1, 1, 4>", "step_lstm_bwd": "avsr::step_kernel<2, 1, 1, 8>"}
+                    "step_lstm_fwd": "avsr::step_kernel<1, 1, 1, 4>", "step_lstm_bwd": "avsr::step_kernel<2, 1, 1, 8>",
+                    "rnn_persist_fwd": "avsr::rnn_persist_fwd_xcd_kernel", "rnn_persist_bwd": "avsr::rnn_persist_bwd_kernel"}
 
         def traffic(kind):
             k = pmc.get(pmc_name.get(kind, ""))
@@ -238,8 +241,9 @@ def main():
                 return {"kernel": kind, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK, 4), "traffic": traffic(kind),
                         "algorithmic_bytes_per_launch": wm["attn_bytes"], "avg_launch_us": us}
-            fl = {"step_lstm_fwd": wm["lstm_fwd_flops"], "step_lstm_bwd": wm["lstm_bwd_flops"]}.get(kind)
-            if fl is None:
+            # fp32 MFMA work: algorithmic FLOPs summed by the launchers (2*M*N*K of every GEMM / step task / persistent sequence)
+            fl = prof[kind][2] / max(1, prof[kind][0])
+            if not fl:
                 return {"kernel": kind, "bound": "mfma", "achieved": None, "peak": MFMA_PEAK, "unit": "TFLOP/s", "frac": None,
                         "traffic": None, "avg_launch_us": us}
             ach = fl / (us * 1e-6) / 1e12
@@ -247,8 +251,7 @@ def main():
                     "frac": round(ach / MFMA_PEAK, 4), "traffic": traffic(kind), "algorithmic_flops_per_launch": int(fl), "avg_launch_us": us}
 
         out["roofline"] = roof(dom)
-        if "attn_fwd" in kinds:
-            out["roofline_attention_step"] = roof("attn_fwd")
+        out["roofline_other"] = [roof(k) for k in kinds if k != dom and k != "step_dense"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(wl, stoch)

@@ -365,10 +365,12 @@ int avsr_adam_step(float* params, float* grads, float* m, float* v, int64_t n, c
 /* Optional per-launch HIP-event timing of the engine's own kernels (bench.py roofline figures).  Between
  * begin and end every gemm / step / attention launch is bracketed by an event pair on its stream; end
  * synchronises the device and returns per-kind launch counts and summed milliseconds.
- * kinds: 0 gemm, 1 LSTM-forward step, 2 LSTM-backward step, 3 dense step, 4 attention fwd, 5 attention bwd. */
-#define AVSR_PROF_NKIND 6
+ * kinds: 0 gemm, 1 LSTM-forward step, 2 LSTM-backward step, 3 dense step, 4 attention fwd, 5 attention bwd,
+ * 6 persistent RNN forward, 7 persistent RNN backward.  out_flops (may be NULL): algorithmic FLOPs summed per kind
+ * where the launcher knows them (gemm, persistent RNN kernels), else 0. */
+#define AVSR_PROF_NKIND 8
 int avsr_prof_begin(int32_t max_launches);
-int avsr_prof_end(int32_t* out_count, float* out_ms);
+int avsr_prof_end(int32_t* out_count, float* out_ms, double* out_flops);
 
 #ifdef __cplusplus
 }

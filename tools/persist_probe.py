@@ -14,7 +14,8 @@ from avsr_tf1_amd import ops  # noqa: E402
 
 h = ops._persist_sync[:256].cpu().numpy()
 print("err", h[0])
-for ti in range(8):
-    r = h[16 + ti * 8:16 + ti * 8 + 6]
-    if r.any():
-        print("task", ti, "ticks/step: wait %d loads %d mfma %d epi %d drain %d atomic %d  total %d" % (*r, r.sum()))
+for name, base in (("fwd", 16), ("bwd", 80)):
+    for ti in range(8):
+        r = h[base + ti * 8:base + ti * 8 + 6]
+        if r.any():
+            print(name, "task", ti, "ticks/step: wait %d loads %d mfma %d epi %d drain %d publish %d  total %d" % (*r, r.sum()))
