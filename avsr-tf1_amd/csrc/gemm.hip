@@ -49,52 +49,81 @@ struct GemmArgs {
   int batch;
 };
 
-// Load one operand tile into registers.  The LDS image is k-major: T[k][mn], k in [0,16), mn in [0,128).
-// kcontig: stored rows are indexed by mn and k is the contiguous dim (A with ta=0, B with tb=1).
-// else   : stored rows are indexed by k and mn is the contiguous dim (A with ta=1, B with tb=0).
-template <bool VEC>
-__device__ __forceinline__ void load_tile(const MatView& S, bool kcontig, int mn0, int k0, int MN, int K,
-                                          int kend, f32x4 (&r)[2]) {
-  const int tid = threadIdx.x;
+// Operand loader.  One thread fetches two 16-byte pieces of each operand per K tile into registers; the LDS image is
+// k-major: T[k][mn], k in [0,16), mn in [0,128).
+//   KC (k contiguous in memory: A with ta=0, B with tb=1): piece p = row mn0 + (tid&127), k = k0 + 4*((tid>>7) + 2p)
+//   else (mn contiguous: A with ta=1, B with tb=0)       : piece p = row k0 + (tid>>5) + 8p, mn = mn0 + 4*(tid&31)
+// Loads are raw buffer loads with an out-of-range offset for pieces outside the matrix / K slice (the hardware
+// returns 0): no branch around any load, so the compiler keeps exact vmcnt counts and all pieces of a tile -- and of
+// the next tiles -- are in flight together.  (The first version branched per piece; the compiler then waited for
+// each load before issuing the next: four serial ~0.5 us round trips per K tile.)  The two-level row address
+// (r / T, r % T) is computed once and advanced incrementally.
+#define G_OOB ((int)0x80000000)
+template <bool KC, bool VEC>
+struct OperandLoader {
+  __amdgpu_buffer_rsrc_t rs;
+  int off[2];        // KC: byte offset of (row, k = this thread's k phase) ; else: byte offset of this thread's mn within a row
+  int q[2], r[2];    // !KC: two-level position of the k row of piece p
+  bool ok;           // KC: row inside the matrix; else: mn inside the matrix
+  int ldb, ldob, T;  // strides in bytes
+  int tail;          // !VEC: number of valid elements handling
+  int MN, mn;
+
+  __device__ __forceinline__ void init(const MatView& S, int mn0, int k0, int MN_) {
+    const int tid = threadIdx.x;
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.p), 0, 0x80000000u, 0x00020000);
+    ldb = (int)S.ld * 4; ldob = (int)S.ldo * 4; T = S.T; MN = MN_;
+    if (KC) {
+      mn = mn0 + (tid & 127);
+      ok = mn < MN;
+      const int ro = T ? (mn / T) * ldob + (mn % T) * ldb : mn * ldb;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (kcontig) {
-      const int mn = mn0 + (tid & 127);
-      const int k = k0 + 4 * ((tid >> 7) + 2 * p);
-      if (mn < MN) {
-        const float* src = S.row(mn) + k;
-        if (VEC) {
-          if (k < kend) v = ld4(src);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (k + e < kend) v[e] = src[e];
-        }
-      }
+      for (int p = 0; p < 2; ++p) off[p] = ro + (k0 + 4 * ((tid >> 7) + 2 * p)) * 4;
     } else {
-      const int k = k0 + (tid >> 5) + 8 * p;
-      const int mn = mn0 + 4 * (tid & 31);
-      if (k < kend) {
-        const float* src = S.row(k) + mn;
-        if (VEC) {
-          if (mn < MN) v = ld4(src);
-        } else {
+      mn = mn0 + 4 * (tid & 31);
+      ok = mn < MN;
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (mn + e < MN) v[e] = src[e];
+      for (int p = 0; p < 2; ++p) {
+        const int k = k0 + (tid >> 5) + 8 * p;
+        q[p] = T ? k / T : 0; r[p] = T ? k % T : k;
+        off[p] = mn * 4;
+      }
+    }
+  }
+  // fetch the pieces of the K tile starting at k0 (k0 only feeds the bounds test) and advance to the next tile
+  __device__ __forceinline__ void load(int k0, int kend, f32x4 (&out)[2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      int o, k;
+      if (KC) { k = k0 + 4 * ((tid >> 7) + 2 * p); o = off[p]; off[p] += BK * 4; }
+      else {
+        k = k0 + (tid >> 5) + 8 * p;
+        o = (T ? q[p] * ldob + r[p] * ldb : r[p] * ldb) + off[p];
+        r[p] += BK;
+        if (T) { while (r[p] >= T) { r[p] -= T; ++q[p]; } }
+      }
+      const bool in = ok && k < kend;
+      typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+      if (VEC) {
+        out[p] = __builtin_bit_cast(f32x4, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(rs, in ? o : G_OOB, 0, 0));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ine = in && (KC ? k + e < kend : mn + e < MN);
+          out[p][e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, ine ? o + 4 * e : G_OOB, 0, 0));
         }
       }
     }
-    r[p] = v;
   }
-}
+};
 
-__device__ __forceinline__ void store_tile(float* T, bool kcontig, const f32x4 (&r)[2]) {
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* T, const f32x4 (&r)[2]) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    if (kcontig) {
+    if (KC) {
       const int mn = tid & 127;
       const int k = 4 * ((tid >> 7) + 2 * p);
 #pragma unroll
@@ -107,8 +136,8 @@ __device__ __forceinline__ void store_tile(float* T, bool kcontig, const f32x4 (
   }
 }
 
-template <bool VECA, bool VECB>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+template <bool AKC, bool BKC, bool VECA, bool VECB>
+__global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][BK * BM];  // [buf][A|B][k][mn]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -120,7 +149,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kbeg = sz * g.kper;
   const int kend = min(g.K, kbeg + g.kper);
-  const bool akc = (g.ta == 0), bkc = (g.tb != 0);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -130,20 +158,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[2], rb[2];
-  load_tile<VECA>(A, akc, m0, kbeg, g.M, g.K, kend, ra);
-  load_tile<VECB>(B, bkc, n0, kbeg, g.N, g.K, kend, rb);
-  store_tile(lds[0][0], akc, ra);
-  store_tile(lds[0][1], bkc, rb);
+  // Software pipeline, prefetch distance 2: while tile i is multiplied out of LDS, tile i+1 sits in registers (it is
+  // written to the other LDS buffer after the MFMAs) and tile i+2 is in flight from L2/HBM.  With distance 1 the LDS
+  // write waited ~1 us of load latency behind every 0.85 us of MFMAs (one workgroup ran at 2 us per K tile).
+  f32x4 ra[2][2], rb[2][2];
+  OperandLoader<AKC, VECA> la;
+  OperandLoader<BKC, VECB> lb;
+  la.init(A, m0, kbeg, g.M);
+  lb.init(B, n0, kbeg, g.N);
+  la.load(kbeg, kend, ra[0]);
+  lb.load(kbeg, kend, rb[0]);
+  la.load(kbeg + BK, kend, ra[1]);
+  lb.load(kbeg + BK, kend, rb[1]);
+  store_tile<AKC>(lds[0][0], ra[0]);
+  store_tile<BKC>(lds[0][1], rb[0]);
   __syncthreads();
 
-  int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = (k0 + BK) < kend;
-    if (more) {
-      load_tile<VECA>(A, akc, m0, k0 + BK, g.M, g.K, kend, ra);
-      load_tile<VECB>(B, bkc, n0, k0 + BK, g.N, g.K, kend, rb);
-    }
+  auto ktile = [&](int k0, int buf, f32x4 (&ra_next)[2], f32x4 (&rb_next)[2], f32x4 (&ra_free)[2], f32x4 (&rb_free)[2]) {
+    // ra_free held tile k0 (already in LDS): refill it with tile k0 + 2*BK; ra_next holds tile k0 + BK
+    la.load(k0 + 2 * BK, kend, ra_free);       // past the slice: every piece is out of range, nothing is fetched
+    lb.load(k0 + 2 * BK, kend, rb_free);
     const float* As = lds[buf][0];
     const float* Bs = lds[buf][1];
 #pragma unroll
@@ -158,12 +192,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-    if (more) {
-      store_tile(lds[buf ^ 1][0], akc, ra);
-      store_tile(lds[buf ^ 1][1], bkc, rb);
-    }
-    __syncthreads();
-    buf ^= 1;
+    store_tile<AKC>(lds[buf ^ 1][0], ra_next);
+    store_tile<BKC>(lds[buf ^ 1][1], rb_next);
+    // LDS-only barrier: __syncthreads() also drains vmcnt, i.e. it would wait for the tiles still in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+    ktile(k0, 0, ra[1], rb[1], ra[0], rb[0]);
+    if (k0 + BK < kend) ktile(k0 + BK, 1, ra[0], rb[0], ra[1], rb[1]);
   }
 
   // epilogue: C/D layout of mfma 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -243,10 +279,18 @@ extern "C" int avsr_gemm(const avsr_gemm_desc* d, void* stream) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * splitk);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(PROF_GEMM, s, 2.0 * g.M * g.N * g.K * g.batch);
-  if (va && vb) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, g);
-  else if (va) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, g);
-  else if (vb) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, g);
+  if ((long)d->A.ld * 4 >= (1L << 31) || (long)d->B.ld * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
+#define GEMM_GO(AK, BK_) \
+  { if (va && vb) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, true, true>), grid, dim3(256), 0, s, g); \
+    else if (va) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, true, false>), grid, dim3(256), 0, s, g); \
+    else if (vb) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, false, true>), grid, dim3(256), 0, s, g); \
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, false, false>), grid, dim3(256), 0, s, g); }
+  const bool akc = g.ta == 0, bkc = g.tb != 0;
+  if (akc && bkc) GEMM_GO(true, true)
+  else if (akc) GEMM_GO(true, false)
+  else if (bkc) GEMM_GO(false, true)
+  else GEMM_GO(false, false)
+#undef GEMM_GO
   AVSR_CHECK_LAUNCH();
   if (splitk > 1) {
     const long total = (long)g.batch * g.M * g.N;

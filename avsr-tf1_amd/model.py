@@ -80,9 +80,7 @@ class SeqBuf:
 
 
 def _splitk(M, N, K):
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    sk = max(1, min(32, 512 // max(1, tiles), K // 256))
-    return sk
+    return ops.auto_splitk(M, N, K)
 
 
 class Seq2SeqModel:
@@ -140,6 +138,7 @@ class Seq2SeqModel:
         self.load_tf_weights(weights if weights is not None else PR.initialise(cfg, seed))
         self.scratch = z(1 << 22)
         self.gemm_ws = None
+        self._ensure_gemm_ws()               # split-K scratch, also used by forward GEMMs with few output tiles
         self.loss = z(1)[:1]
         self.gnorm = z(1)[:1]
         self.denom = z(1)[:1]
@@ -552,6 +551,7 @@ class Seq2SeqModel:
     def _ensure_gemm_ws(self):
         if self.gemm_ws is None:
             self.gemm_ws = torch.empty(48 << 20, device=self.dev)
+        ops.set_gemm_workspace(self.gemm_ws)
 
     def _gemm_tn(self, A, Bm, Cm, M, N, K, beta=1.0):
         """C (+)= A^T B with K = number of (b,t) rows: split-K so the small M x N output still fills the chip."""

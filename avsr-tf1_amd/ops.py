@@ -28,9 +28,30 @@ def _s():
     return stream_ptr()
 
 
+_gemm_ws = None
+
+
+def set_gemm_workspace(t):
+    """Register the split-K scratch (float32 device tensor) that `gemm(..., splitk=None)` may use."""
+    global _gemm_ws
+    _gemm_ws = t
+
+
+def auto_splitk(M, N, K, batch=1):
+    """Split-K factor for a GEMM whose M x N tile grid alone cannot fill the chip (tools/gemm_bench.py on MI355X):
+    one 128x128 workgroup walks K at ~1.5 us per 16-deep tile, so few-tile GEMMs are latency-bound unless K is cut.
+    Aim at ~768 workgroups, keep >= 64 of K per slice, never split when the grid already has >= 128 tiles."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128) * max(1, batch)
+    if tiles >= 128:
+        return 1
+    sk = min(768 // tiles, K // 64, 64)
+    return sk if sk >= 2 else 1
+
+
 def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None,
-         batch=1, strides=(0, 0, 0), splitk=1, workspace=None, alpha_dev=None):
-    """C = alpha*op(A)*op(B) + beta*C + bias.  A, B, Cm are `Mat` views (see `mat`)."""
+         batch=1, strides=(0, 0, 0), splitk=None, workspace=None, alpha_dev=None):
+    """C = alpha*op(A)*op(B) + beta*C + bias.  A, B, Cm are `Mat` views (see `mat`).
+    splitk=None picks the factor (auto_splitk) when a workspace is available, else 1."""
     d = GemmDesc()
     d.A, d.B, d.C = A, B, Cm
     d.bias = fptr(bias)
@@ -40,6 +61,11 @@ def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, b
     d.batch = int(batch)
     d.stride_a, d.stride_b, d.stride_c = [int(s) for s in strides]
     d.alpha_dev = fptr(alpha_dev)
+    if splitk is None:
+        workspace = workspace if workspace is not None else _gemm_ws
+        splitk = auto_splitk(M, N, K, batch) if workspace is not None else 1
+        while splitk > 1 and batch * splitk * M * N > workspace.numel():
+            splitk //= 2
     d.splitk = int(splitk)
     if splitk > 1:
         need = batch * splitk * M * N
