@@ -16,6 +16,7 @@
 // complete units and the epilogue needs no cross-workgroup exchange.
 #include "step.h"
 #include "prof.h"
+#include "persist.h"
 
 namespace avsr {
 
@@ -100,26 +101,36 @@ __device__ __forceinline__ void mm16_partial(const StepTask& tk, int row0, int c
         }
       }
     } else {
-      // A row = sum_j wgt_j * slab_j[row]  (attention context from per-chunk softmax partials, or a plain sum)
+      // A row = sum_j wgt_j * slab_j[row]  (attention context from per-chunk softmax partials, or a plain sum).
+      // Every load is an unconditional raw buffer load (out-of-range offset = reads 0) so that the statistics and all
+      // slabs of a chunk are in flight together; guarded loads compiled to one branch + full vmcnt wait per load.
       const int ns = tk.nslab;
+      const __amdgpu_buffer_rsrc_t pm_rs = make_rsrc(tk.pm), pl_rs = make_rsrc(tk.pl), a_rs = make_rsrc(S.a), w_rs = make_rsrc(S.w);
+      const int w_off = wcol_ok ? (int)(((long)wcol * S.ldw + (q << 2)) * 4) : P_OOB;
 #pragma unroll
       for (int r = 0; r < RM; ++r) {
         const int arow = row0 + 16 * r + i;
         const bool arow_ok = arow < tk.B;
         float wgt[STEP_MAX_SLAB];
         if (S.kind == SRC_SOFTMAX) {
+          float pmv[STEP_MAX_SLAB], plv[STEP_MAX_SLAB];
+#pragma unroll
+          for (int j = 0; j < STEP_MAX_SLAB; ++j) {
+            const int o = (j < ns && arow_ok) ? (j * tk.B + arow) * 4 : P_OOB;
+            pmv[j] = ldb1(pm_rs, o);
+            plv[j] = ldb1(pl_rs, o);
+          }
           float M = -INFINITY;
 #pragma unroll
           for (int j = 0; j < STEP_MAX_SLAB; ++j) {
-            wgt[j] = -INFINITY;
-            if (j < ns && arow_ok) wgt[j] = tk.pm[(long)j * tk.B + arow];
+            wgt[j] = (j < ns && arow_ok) ? pmv[j] : -INFINITY;
             M = fmaxf(M, wgt[j]);
           }
           float Ls = 0.f;
 #pragma unroll
           for (int j = 0; j < STEP_MAX_SLAB; ++j) {
             const float e = (wgt[j] == -INFINITY) ? 0.f : expf(wgt[j] - M);
-            if (j < ns && arow_ok) Ls += e * tk.pl[(long)j * tk.B + arow];
+            Ls += e * plv[j];                  // plv is 0 for slabs that do not exist
             wgt[j] = e;
           }
           const float inv = Ls > 0.f ? 1.0f / Ls : 0.f;
@@ -129,20 +140,20 @@ __device__ __forceinline__ void mm16_partial(const StepTask& tk, int row0, int c
 #pragma unroll
           for (int j = 0; j < STEP_MAX_SLAB; ++j) wgt[j] = 1.0f;
         }
-        const float* ap = S.a + (long)arow * S.sb + (q << 2);
+        const int a_off = (int)(((long)arow * S.sb + (q << 2)) * 4);
+        const int slab_b = (int)(tk.slab_stride * 4);
         for (int c = c0; c < c1; ++c) {
           const int k = c << 4;
-          f32x4 av = zero4, wv = zero4;
-          if (k + (q << 2) < S.K) {
-            if (arow_ok) {
+          const bool kin = k + (q << 2) < S.K;
+          f32x4 sv[STEP_MAX_SLAB];
 #pragma unroll
-              for (int j = 0; j < STEP_MAX_SLAB; ++j) {
-                if (j < ns) av += wgt[j] * ld4(ap + (long)j * tk.slab_stride + k);
-              }
-              if (save_ctx && tk.ctx_save) st4(tk.ctx_save + (long)arow * tk.ctx_sb + k + (q << 2), av);
-            }
-            if (wcol_ok) wv = ld4(wp + k);
-          }
+          for (int j = 0; j < STEP_MAX_SLAB; ++j)
+            sv[j] = ldb4(a_rs, (kin && arow_ok && j < ns) ? a_off + j * slab_b + k * 4 : P_OOB);
+          const f32x4 wv = ldb4(w_rs, kin ? w_off + k * 4 : P_OOB);
+          f32x4 av = zero4;
+#pragma unroll
+          for (int j = 0; j < STEP_MAX_SLAB; ++j) av += wgt[j] * sv[j];
+          if (kin && arow_ok && save_ctx && tk.ctx_save) st4(tk.ctx_save + (long)arow * tk.ctx_sb + k + (q << 2), av);
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[r][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wv[e], acc[r][e], 0, 0, 0);
         }
