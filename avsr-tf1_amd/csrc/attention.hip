@@ -19,6 +19,7 @@
 // Rows past len[b] are never loaded.
 #include "attn.h"
 #include "prof.h"
+#include "persist.h"
 
 namespace avsr {
 
@@ -31,6 +32,61 @@ __device__ __forceinline__ void locate(const AttnLaunch& L, int& m, int& b, int&
   blk -= L.blk_off[m];
   c = blk % L.m[m].nchunk;
   b = blk / L.m[m].nchunk;
+}
+
+
+// ---- streaming helpers (Luong paths).  The memory rows are the HBM stream of the decoder step, and only ~1.25
+// workgroups per CU run, so each thread must keep many 16-byte loads in flight: rows are fetched in unconditional
+// batches through raw buffer loads (out-of-range offset = reads 0 for rows past the chunk), never one row per loop trip.
+
+// 16 lanes per row: dot(row[r], vec) for the rows r = rg + 16*u of a chunk (u < 8); vec fragments v4[j] at k = 4*s16 + 64*j.
+template <class Emit>
+__device__ __forceinline__ void rows_dot16(__amdgpu_buffer_rsrc_t rs, int base_b, int row_stride_b, int W, int n,
+                                           const f32x4 (&v4)[4], Emit&& emit) {
+  const int s16 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+#pragma unroll
+  for (int u0 = 0; u0 < 8; u0 += 4) {
+    if (rg + 16 * u0 >= n) break;                       // uniform per 16-lane group; later rows are out of the chunk too
+    f32x4 x[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = rg + 16 * (u0 + u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * s16 + 64 * j;
+        x[u][j] = ldb4(rs, (r < n && k < W) ? base_b + r * row_stride_b + k * 4 : P_OOB);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc += x[u][j][0] * v4[j][0] + x[u][j][1] * v4[j][1] + x[u][j][2] * v4[j][2] + x[u][j][3] * v4[j][3];
+      acc = group16_sum(acc);
+      const int r = rg + 16 * (u0 + u);
+      if (r < n) emit(r, acc);
+    }
+  }
+}
+
+// one float4 column per thread: sum_r w[r] * row[r][col] over the rows r = grp + G*u of the chunk, 8 rows in flight
+__device__ __forceinline__ f32x4 rows_wsum(__amdgpu_buffer_rsrc_t rs, int base_b, int row_stride_b, int col4, int grp, int G,
+                                           int n, const float* w, float scale) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int r0 = grp; r0 < n; r0 += 8 * G) {
+    f32x4 x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = r0 + u * G;
+      x[u] = ldb4(rs, r < n ? base_b + r * row_stride_b + col4 * 16 : P_OOB);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = r0 + u * G;
+      acc += ((r < n) ? w[r] * scale : 0.f) * x[u];
+    }
+  }
+  return acc;
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnLaunch L) {
@@ -50,6 +106,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnLaunch L) {
 
   // ---- phase 1: scores for rows t0 .. t0+n-1 (16 lanes per row) ----
   const int s16 = tid & 15, rg = tid >> 4;
+  const bool fast = M.type <= ATT_SCALED_LUONG && H <= 256 && (long)M.T * H * 4 < (1L << 31) && (long)M.T * M.values_st * 4 < (1L << 31);
+  if (fast) {
+    f32x4 q4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 4 * s16 + 64 * j;
+      q4[j] = k < H ? ld4(q + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float gsc = (M.type == ATT_SCALED_LUONG) ? M.g[0] : 1.f;
+    float* srow = M.scores + (long)b * M.scores_sb + t0;
+    rows_dot16(make_rsrc(keys), t0 * H * 4, H * 4, H, n, q4, [&](int r, float acc) {
+      if (s16 == 0) { srow[r] = acc; sc[r] = acc * gsc; }
+    });
+  } else
   for (int r = rg; r < n; r += 16) {
     const float* krow = keys + (long)(t0 + r) * H;
     float acc = 0.f;
@@ -100,8 +170,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnLaunch L) {
     const int col = tid % ccols, grp = tid / ccols;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (grp < G) {
-      const float* vp = vals + 4 * (cb + col);
-      for (int r = grp; r < n; r += G) acc += sc[r] * ld4(vp + (long)(t0 + r) * M.values_st);
+      if (fast) {
+        acc = rows_wsum(make_rsrc(vals), t0 * (int)M.values_st * 4, (int)M.values_st * 4, cb + col, grp, G, n, sc, 1.0f);
+      } else {
+        const float* vp = vals + 4 * (cb + col);
+        for (int r = grp; r < n; r += G) acc += sc[r] * ld4(vp + (long)(t0 + r) * M.values_st);
+      }
     }
     if (G == 1) {
       if (grp < G) st4(pout + 4 * (cb + col), acc);
@@ -156,6 +230,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnLaunch L) {
   const float gscale = (M.type == ATT_SCALED_LUONG) ? M.g[0] : 1.f;
   const float* vals = M.values + (long)b * M.values_sb;
   const int s16 = tid & 15, rg = tid >> 4;
+  const bool fast = M.type <= ATT_SCALED_LUONG && D <= 256 && (long)M.T * H * 4 < (1L << 31) && (long)M.T * M.values_st * 4 < (1L << 31);
+  if (fast) {
+    f32x4 d4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 4 * s16 + 64 * j;
+      d4[j] = k < D ? ld4(dctx + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* raws = M.scores + (long)b * M.scores_sb + t0;
+    float* dsr = M.dscores + (long)b * M.dscores_sb + t0;
+    rows_dot16(make_rsrc(vals), t0 * (int)M.values_st * 4, (int)M.values_st * 4, D, n, d4, [&](int r, float acc) {
+      if (s16 == 0) {
+        const float alpha = expf(raws[r] * gscale - Mx) * invL;
+        const float d = alpha * (acc - cd);
+        ds[r] = d;
+        dsr[r] = d;
+      }
+    });
+  } else
   for (int r = rg; r < n; r += 16) {
     const float* vrow = vals + (long)(t0 + r) * M.values_st;
     float acc = 0.f;
@@ -188,7 +281,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnLaunch L) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (grp < G) {
       const int k = 4 * (cb + col);
-      if (M.type <= ATT_SCALED_LUONG) {
+      if (fast) {
+        acc = rows_wsum(make_rsrc(keys), t0 * H * 4, H * 4, cb + col, grp, G, n, ds, gscale);
+      } else if (M.type <= ATT_SCALED_LUONG) {
         for (int r = grp; r < n; r += G) acc += (ds[r] * gscale) * ld4(keys + (long)(t0 + r) * H + k);
       } else {
         f32x4 pq = ld4(q + k);
