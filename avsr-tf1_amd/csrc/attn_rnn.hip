@@ -67,14 +67,22 @@ __global__ void sched_sample_kernel(const float* logits, long logits_sb, int V, 
                                     const float* emb, int B, int L, int E, int l, const int32_t* seed, float prob,
                                     float keep_in, uint32_t r_in, int in_W) {
   __shared__ int tok_s;
-  const int b = blockIdx.x;
+  extern __shared__ float lg_s[];          // this utterance's logits: fetched by all lanes together with the seed and the
+  const int b = blockIdx.x;                // label, so the serial inverse-CDF below runs out of LDS (one memory round trip)
   if (l + 1 >= L) return;
+  const uint32_t sd0 = (uint32_t)seed[0];
+  const int label = labels[(long)b * L + l];
+  {
+    const float* lg = logits + (long)b * logits_sb;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) lg_s[v] = lg[v];
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t sd = (uint32_t)seed[0];
+    const uint32_t sd = sd0;
     const uint32_t idx = (uint32_t)(b * L + l);
-    int tok = labels[(long)b * L + l];
+    int tok = label;
     if (prob > 0.f && uniform01(sd, 1000u, idx) < prob) {
-      const float* lg = logits + (long)b * logits_sb;
+      const float* lg = lg_s;
       float mx = lg[0];
       for (int v = 1; v < V; ++v) mx = fmaxf(mx, lg[v]);
       float tot = 0.f;
@@ -93,7 +101,7 @@ __global__ void sched_sample_kernel(const float* logits, long logits_sb, int V, 
   __syncthreads();
   const int tok = tok_s;
   const bool on = keep_in < 1.0f;
-  const uint32_t sd = (uint32_t)seed[0];
+  const uint32_t sd = sd0;
   for (int e = threadIdx.x; e < E; e += blockDim.x) {
     float v = emb[(long)tok * E + e];
     if (on) v = uniform01(sd, r_in, (uint32_t)(((long)b * L + l + 1) * in_W + e)) < keep_in ? v / keep_in : 0.f;
@@ -388,7 +396,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
                            d.beam_len + (long)pout * B, d.tok, d.parent_rows, d.step_ids + (long)l * B, d.parent_ids + (long)l * B,
                            d.n_unfinished + l);
       } else {
-        hipLaunchKernelGGL(sched_sample_kernel, dim3(B), dim3(64), 0, s, d.logits + (long)l * d.V, (long)L * d.V, d.V, d.labels,
+        hipLaunchKernelGGL(sched_sample_kernel, dim3(B), dim3(128), sizeof(float) * d.V, s, d.logits + (long)l * d.V, (long)L * d.V, d.V, d.labels,
                            d.fed, d.xs, d.embedding, B, L, E, l, d.seed, d.sampling_prob, drop ? d.keep_in : 1.0f, cid4, E + A);
       }
       AVSR_CHECK_LAUNCH();
