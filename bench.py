@@ -217,17 +217,18 @@ def main():
         out["kernel_time_events"] = kinds
         dom = max(kinds, key=lambda k: kinds[k]["total_ms"])
         HBM_PEAK, MFMA_PEAK = 8000.0, 157.3
-        # HBM traffic per launch from the committed PMC passes (profiles/r01_c4_pmc.json: FETCH_SIZE / WRITE_SIZE collected in
+        # HBM traffic per launch from the committed PMC passes (profiles/r01_c4_pmc_v3.json: FETCH_SIZE / WRITE_SIZE collected in
         # separate rocprofv3 runs of this same workload, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); null
         # for workloads / kernels that were not profiled.
         pmc = {}
         try:
             if args.workload == "c4":
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c4_pmc.json")))["kernels"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c4_pmc_v3.json")))["kernels"]
         except Exception:
             pmc = {}
         pmc_name = {"attn_fwd": "avsr::attn_fwd_kernel", "attn_bwd": "avsr::attn_bwd_kernel",
                     "step_lstm_fwd": "avsr::step_kernel<1, 1, 1, 4>", "step_lstm_bwd": "avsr::step_kernel<2, 1, 1, 8>",
+                    "step_dense": "avsr::step_kernel<0, 1, 1, 4>",
                     "rnn_persist_fwd": "avsr::rnn_persist_fwd_xcd_kernel", "rnn_persist_bwd": "avsr::rnn_persist_bwd_kernel"}
 
         def traffic(kind):
