@@ -39,7 +39,7 @@ struct PTask {
   int B, T, H, in, hoisted, reverse, nct, nct_lower, wg_begin, nrt, uw;
   const int32_t* seed; float k_st, k_out, k_in; uint32_t r_st, r_out, r_in; int in_W, in_coff;
 };
-struct PLaunch { int ntask, wpx, ngroups; int* err; int* claim; PTask task[P_MAX_TASKS]; };
+struct PLaunch { int ntask, wpx, ngroups, b0; int* err; int* claim; PTask task[P_MAX_TASKS]; };   // b0: first batch row of this launch
 
 // bounded wait for (*c0 >= n0 && *c1 >= n1): both counters are fetched in the same round trip
 __device__ __forceinline__ bool wait_ge2(const int* c0, int n0, const int* c1, int n1, int* err) {
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const PTask& tk = L.task[ti];
   const int ct = slot - tk.wg_begin;
   const int UW = tk.uw, uw_shift = UW == 16 ? 4 : 3;
-  const int row0 = g * 8, col0 = ct * UW * 4, unit0 = ct * UW;
+  const int row0 = L.b0 + g * 8, col0 = ct * UW * 4, unit0 = ct * UW;
   const int i = lane & 15, q = lane >> 4;
   const int H = tk.H, T = tk.T;
   const int hoisted = tk.hoisted, reverse = tk.reverse;
@@ -553,7 +553,6 @@ static int build_tasks(const avsr_rnn_stack* st, int n, bool local, int32_t* syn
     const avsr_rnn_stack& S = st[i];
     if (S.cell != 0 || S.B != st[0].B) return AVSR_ERR_UNSUPPORTED;
     const int nrt = local ? (S.B + 7) / 8 : (S.B + 15) / 16;
-    if (local && nrt > 8) return AVSR_ERR_UNSUPPORTED;
     for (int l = 0; l < S.n_layers; ++l) {
       const avsr_rnn_layer& Ly = S.layer[l];
       if (L.ntask >= P_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
@@ -599,7 +598,7 @@ static int build_tasks(const avsr_rnn_stack* st, int n, bool local, int32_t* syn
   // agent-scope kernel: <= 2 per CU chip-wide; XCD-local kernel: <= 3 per CU of one XCD (its VGPR budget admits 3).
   if (ctr > sync_ints) return AVSR_ERR_UNSUPPORTED;
   if (local ? wg > 96 : wg > 512) return AVSR_ERR_UNSUPPORTED;
-  L.err = sync; L.claim = sync + P_HDR; L.wpx = wg; L.ngroups = (st[0].B + 7) / 8;
+  L.err = sync; L.claim = sync + P_HDR; L.wpx = wg; L.ngroups = 0; L.b0 = 0;
   *wg_out = wg; *words_out = ctr;
   return AVSR_OK;
 }
@@ -619,12 +618,17 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
   int wg = 0; long words = 0;
   if ((g_persist_mode & 2) && build_tasks(st, n, true, sync, sync_ints, L, &wg, &words) == AVSR_OK) {
     if (dry) return AVSR_OK;
-    if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
-    {
-      ProfScope ps(PROF_RNN_PERSIST_FWD, s, g_fwd_flops);
-      hipLaunchKernelGGL(rnn_persist_fwd_xcd_kernel, dim3(8 * wg), dim3(256), 0, s, L);
+    // 8 XCDs x 8 rows per launch; a larger batch runs as consecutive launches over 64-row slices (rows are independent)
+    const int B = st[0].B;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+      L.b0 = b0; L.ngroups = ((B - b0 < 64 ? B - b0 : 64) + 7) / 8;
+      if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
+      {
+        ProfScope ps(PROF_RNN_PERSIST_FWD, s, g_fwd_flops * (L.ngroups * 8 < B - b0 ? L.ngroups * 8 : B - b0) / B);
+        hipLaunchKernelGGL(rnn_persist_fwd_xcd_kernel, dim3(8 * wg), dim3(256), 0, s, L);
+      }
+      AVSR_CHECK_LAUNCH();
     }
-    AVSR_CHECK_LAUNCH();
     return AVSR_OK;
   }
   if ((g_persist_mode & 1) && build_tasks(st, n, false, sync, sync_ints, L, &wg, &words) == AVSR_OK) {

@@ -39,7 +39,7 @@ struct BTask {
   int B, T, H, H_up, reverse, nct, nct_up, slot_begin, half, ntile, up_remote;
   const int32_t* seed; float k_st, k_out, k_in; uint32_t r_st, r_out, r_in; int in_W, in_coff;
 };
-struct BLaunch { int ntask, ngroups, wpx0, wpx1; int* err; int* claim; BTask task[B_MAX_TASKS]; };
+struct BLaunch { int ntask, ngroups, wpx0, wpx1, b0; int* err; int* claim; BTask task[B_MAX_TASKS]; };   // b0: first batch row of this launch
 
 __global__ __launch_bounds__(512) void rnn_persist_bwd_kernel(const BLaunch L) {
   __shared__ __attribute__((aligned(16))) float red[8][2][16][16];
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512) void rnn_persist_bwd_kernel(const BLaunch L) {
   const int H = tk.H, T = tk.T, reverse = tk.reverse;
   const int NT = tk.ntile;
   const bool top = tk.w_up == nullptr;           // no upper layer inside the stack
-  const int unit0 = ct * 16 * NT, row0 = g * 16;
+  const int unit0 = ct * 16 * NT, row0 = L.b0 + g * 16;
   const int i = lane & 15, q = lane >> 4;
   const int K_own = 4 * H, K_up = 4 * tk.H_up;
   // ---- K split.  Every wave runs two runs of <= 8 chunks (16 K each): operand part A with weights wA into acc0,
@@ -319,6 +319,10 @@ static bool assign_halves(const int* cost, const int* upper, int n, int cap, int
 // Returns AVSR_ERR_UNSUPPORTED when the persistent path is disabled or the configuration does not fit it
 // (avsr_rnn_bwd then uses one launch per wavefront step).  The caller has already zeroed every layer's dstate
 // (ring slots) and nothing else of the launch path's setup is needed: the final-state gradients are read here.
+#include <cstdio>
+#include <cstdlib>
+// AVSR_PERSIST_DEBUG=1 prints which precondition sent a call back to the per-step launches
+#define UNSUP(code) do { if (getenv("AVSR_PERSIST_DEBUG")) fprintf(stderr, "[avsr] persistent BPTT not used: reason %d (rnn_persist_bwd.hip)\n", code); return AVSR_ERR_UNSUPPORTED; } while (0)
 int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry) {
   using namespace avsr;
   int32_t* sync = g_sync; const int64_t sync_ints = g_sync_ints;
@@ -328,20 +332,19 @@ int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
   double flops = 0.0;
   int cost[B_MAX_TASKS], upper[B_MAX_TASKS], half[B_MAX_TASKS];
   const int B = st[0].B;
-  const int ngroups = (B + 15) / 16;
-  if (ngroups > 4) return AVSR_ERR_UNSUPPORTED;
+  const int ngroups = B < 64 ? (B + 15) / 16 : 4;      // per launch: 4 XCD pairs x 16 rows; larger batches run as 64-row slices
   for (int i = 0; i < n; ++i) {
     const avsr_rnn_stack& S = st[i];
-    if (S.cell != 0 || S.B != B) return AVSR_ERR_UNSUPPORTED;
+    if (S.cell != 0 || S.B != B) UNSUP(3);
     const int first = L.ntask;
     for (int l = 0; l < S.n_layers; ++l) {
       const avsr_rnn_layer& Ly = S.layer[l];
-      if (L.ntask >= B_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
+      if (L.ntask >= B_MAX_TASKS) UNSUP(4);
       const int H = Ly.units, in = Ly.in_dim;
       const bool top = l + 1 >= S.n_layers;
-      if (H % 16 || H > 32 * B_CH || (long)S.B * S.T * H * 4 >= (1L << 29)) return AVSR_ERR_UNSUPPORTED;
-      if (!top && (S.layer[l + 1].units % 16 || S.layer[l + 1].units > 32 * B_CH || S.layer[l + 1].in_dim != H)) return AVSR_ERR_UNSUPPORTED;
-      if (Ly.dout && (long)S.B * (S.T + 2) * Ly.ld_dout >= (1L << 29)) return AVSR_ERR_UNSUPPORTED;
+      if (H % 16 || H > 32 * B_CH || (long)S.B * S.T * H * 4 >= (1L << 29)) UNSUP(5);
+      if (!top && (S.layer[l + 1].units % 16 || S.layer[l + 1].units > 32 * B_CH || S.layer[l + 1].in_dim != H)) UNSUP(6);
+      if (Ly.dout && (long)S.B * (S.T + 2) * Ly.ld_dout >= (1L << 29)) UNSUP(7);
       const int t_i = L.ntask++;
       BTask& tk = L.task[t_i];
       tk.w_own = Ly.w + (long)in * 4 * H; tk.ldw_own = 4 * H;
@@ -353,7 +356,7 @@ int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
       flops += 2.0 * S.B * S.T * (4.0 * H + (top ? 0.0 : 4.0 * S.layer[l + 1].units)) * H;
       tk.ntile = (top && H % 32 == 0) ? 2 : 1;
       tk.nct = H / (16 * tk.ntile);
-      if (tk.nct > 32) return AVSR_ERR_UNSUPPORTED;
+      if (tk.nct > 32) UNSUP(8);
       cost[t_i] = tk.nct; upper[t_i] = top ? -1 : t_i + 1;
       if (S.seed) {
         const uint32_t cid = (uint32_t)(S.cell_id_base + l);
@@ -365,7 +368,7 @@ int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
     (void)first;
   }
   // one 512-thread workgroup per CU (its register budget admits no second one): <= 32 per XCD, keep a margin
-  if (!assign_halves(cost, upper, L.ntask, 28, half)) return AVSR_ERR_UNSUPPORTED;
+  if (!assign_halves(cost, upper, L.ntask, 28, half)) UNSUP(9);
   long words = P_HDR + 8;
   int slots[2] = {0, 0};
   for (int i = 0; i < L.ntask; ++i) {
@@ -384,16 +387,20 @@ int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
       tk.ctr_up = up.ctr;
     }
   }
-  if (words > sync_ints) return AVSR_ERR_UNSUPPORTED;
+  if (words > sync_ints) UNSUP(10);
   if (dry) return AVSR_OK;
-  L.err = sync; L.claim = sync + P_HDR; L.ngroups = ngroups; L.wpx0 = slots[0]; L.wpx1 = slots[1];
+  L.err = sync; L.claim = sync + P_HDR; L.wpx0 = slots[0]; L.wpx1 = slots[1];
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
   const int wpx = slots[0] > slots[1] ? slots[0] : slots[1];
-  {
-    ProfScope ps(PROF_RNN_PERSIST_BWD, s, flops);
-    hipLaunchKernelGGL(rnn_persist_bwd_kernel, dim3(8 * wpx), dim3(512), 0, s, L);
+  for (int b0 = 0; b0 < B; b0 += 64) {                 // rows are independent: consecutive launches over 64-row slices
+    const int rows = B - b0 < 64 ? B - b0 : 64;
+    L.b0 = b0; L.ngroups = (rows + 15) / 16;
+    if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
+    {
+      ProfScope ps(PROF_RNN_PERSIST_BWD, s, flops * rows / B);
+      hipLaunchKernelGGL(rnn_persist_bwd_kernel, dim3(8 * wpx), dim3(512), 0, s, L);
+    }
+    AVSR_CHECK_LAUNCH();
   }
-  AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

@@ -97,14 +97,15 @@ def _oracle_stack(x, lens, Ws, bs, reverse, R_out, R_h, R_c):
             [P[f"s/l{l}/bias"].grad.numpy() for l in range(len(Ws))])
 
 
+@pytest.mark.parametrize("B", [19, 70])      # 70: more than one 64-row slice of the persistent kernels
 @pytest.mark.parametrize("persistent", [0, 1, 2])
 @pytest.mark.parametrize("reverse", [0, 1])
 @pytest.mark.parametrize("units", [(32,), (32, 48, 32)])
-def test_rnn_stack_fwd_bwd(units, reverse, persistent):
+def test_rnn_stack_fwd_bwd(units, reverse, persistent, B):
     from avsr_tf1_amd import ops, params as PR
     from avsr_tf1_amd._lib import RnnLayer, RnnStack
     rng = np.random.default_rng(11 + reverse + len(units))
-    B, T, F = 19, 23, 20
+    T, F = 23, 20
     lens = rng.integers(T // 2, T + 1, size=B).astype(np.int32)
     lens[0] = T
     lens[1] = 1
