@@ -100,7 +100,7 @@ class TransposeJob(C.Structure):
 _STRUCTS = {"avsr_mat": Mat, "avsr_gemm_desc": GemmDesc, "avsr_rnn_layer": RnnLayer, "avsr_rnn_stack": RnnStack,
             "avsr_attn_mech": AttnMech, "avsr_attn_rnn": AttnRnn, "avsr_transpose_job": TransposeJob}
 
-EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_rnn_set_persistent", "avsr_rnn_set_persistent_mode", "avsr_attn_rnn_fwd",
+EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_rnn_set_persistent", "avsr_rnn_set_persistent_mode", "avsr_rnn_set_persistent_scratch", "avsr_attn_rnn_fwd",
            "avsr_attn_rnn_bwd", "avsr_beam_gather_tree", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_colsum",
            "avsr_batchnorm_fwd", "avsr_batchnorm_xhat", "avsr_embed_labels", "avsr_embed_grad", "avsr_dropout_rows", "avsr_seq_loss",
            "avsr_au_loss", "avsr_normed_v", "avsr_normed_v_bwd", "avsr_reduce_scalar", "avsr_l2_regularise",
@@ -139,6 +139,7 @@ def load():
         "avsr_rnn_bwd": [C.POINTER(RnnStack), i32, vp],
         "avsr_rnn_set_persistent": [vp, i64],
         "avsr_rnn_set_persistent_mode": [i32],
+        "avsr_rnn_set_persistent_scratch": [vp, i64],
         "avsr_attn_rnn_fwd": [C.POINTER(AttnRnn), i32, i32, vp],
         "avsr_attn_rnn_bwd": [C.POINTER(AttnRnn), vp],
         "avsr_beam_gather_tree": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
@@ -149,7 +150,7 @@ def load():
         "avsr_batchnorm_fwd": [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp],
         "avsr_batchnorm_xhat": [vp, vp, vp, vp, i32, i32, vp],
         "avsr_embed_labels": [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp],
-        "avsr_embed_grad": [vp, vp, vp, i32, i32, i32, i32, vp],
+        "avsr_embed_grad": [vp, vp, vp, i32, i32, i32, i32, vp, i64, vp],
         "avsr_dropout_rows": [C.POINTER(Mat), C.POINTER(Mat), i32, i32, vp, i32, f32, i32, i32, i32, vp],
         "avsr_seq_loss": [vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp],
         "avsr_au_loss": [vp, vp, vp, vp, vp, i32, i32, f32, vp],

@@ -52,20 +52,27 @@ __global__ void colsum_partial_kernel(const float* a, long lda, int Ta, long ldo
   }
 }
 
-// one block per 32 columns: 8 row-groups x 32 columns of threads walk the partials, then an LDS tree
-__global__ void colsum_final_kernel(const float* part, int nblk, float* out, int F, float alpha, float beta) {
-  __shared__ double red[8][32];
+// one block per 32 columns: 32 row-groups x 32 columns of threads walk the partials (4 loads in flight), then an LDS tree
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* part, int nblk, float* out, int F, float alpha, float beta) {
+  __shared__ double red[32][33];
   const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int f = blockIdx.x * 32 + fl;
   double s = 0.0;
-  if (f < F)
-    for (int i = g; i < nblk; i += 8) s += (double)part[(long)i * F + f];
+  if (f < F) {
+    int i = g;
+    for (; i + 96 < nblk; i += 128) {
+      const float a0 = part[(long)i * F + f], a1 = part[(long)(i + 32) * F + f];
+      const float a2 = part[(long)(i + 64) * F + f], a3 = part[(long)(i + 96) * F + f];
+      s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    }
+    for (; i < nblk; i += 32) s += (double)part[(long)i * F + f];
+  }
   red[g][fl] = s;
   __syncthreads();
   if (g == 0 && f < F) {
     double t = 0.0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t += red[j][fl];
+    for (int j = 0; j < 32; ++j) t += red[j][fl];
     const float v = alpha * (float)t;
     out[f] = beta != 0.f ? v + beta * out[f] : v;
   }
@@ -75,58 +82,95 @@ __global__ void colsum_final_kernel(const float* part, int nblk, float* out, int
 // batch norm over rows (tf.layers.batch_normalization axis=-1, encoder.py:44-50): statistics over ALL
 // B*T rows including zero padding.  Stage 1: partial sums.  Stage 2: partial centred squares.  Stage 3:
 // normalise (+ moving-average update and saved mean / inv-std by block 0).
+// Thread layout of the row-walking BN kernels: G = 256 / F row sub-groups of F columns (F < 256), so narrow feature
+// vectors (80 audio / 128 video) still use the whole block; partials are per (block, sub-group).
 __global__ void bn_partial_sum_kernel(const float* x, float* part, int rows, int F, int rows_per_blk) {
+  const int G = F < 256 ? 256 / F : 1;
   const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-  for (int f = threadIdx.x; f < F; f += blockDim.x) {
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += x[(long)r * F + f];
-    part[(long)blockIdx.x * F + f] = s;
+  for (int idx = threadIdx.x; idx < G * F; idx += blockDim.x) {     // G > 1: a single pass (G*F <= 256)
+    const int f = idx % F, g = idx / F;
+    float s0 = 0.f, s1 = 0.f;
+    int r = r0 + g;
+    for (; r + G < r1; r += 2 * G) { s0 += x[(long)r * F + f]; s1 += x[(long)(r + G) * F + f]; }
+    if (r < r1) s0 += x[(long)r * F + f];
+    part[((long)blockIdx.x * G + g) * F + f] = s0 + s1;
   }
 }
 
-__global__ void bn_partial_sq_kernel(const float* x, const float* psum, int nblk, float* part, int rows, int F,
-                                     int rows_per_blk) {
-  const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-  for (int f = threadIdx.x; f < F; f += blockDim.x) {
-    double m = 0.0;
-    for (int i = 0; i < nblk; ++i) m += (double)psum[(long)i * F + f];
-    const float mean = (float)(m / rows);
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) {
-      const float d = x[(long)r * F + f] - mean;
-      s += d * d;
-    }
-    part[(long)blockIdx.x * F + f] = s;
+// mean[f] = sum of partials / rows   (one launch, one block per 32 columns; npart = nblk * G)
+__global__ __launch_bounds__(1024) void bn_mean_kernel(const float* part, int npart, float* mean, int rows, int F) {
+  __shared__ double red[32][33];
+  const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int f = blockIdx.x * 32 + fl;
+  double s = 0.0;
+  if (f < F)
+    for (int i = g; i < npart; i += 32) s += (double)part[(long)i * F + f];
+  red[g][fl] = s;
+  __syncthreads();
+  if (g == 0 && f < F) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) t += red[j][fl];
+    mean[f] = (float)(t / rows);
   }
 }
 
-__global__ void bn_apply_kernel(const float* x, const float* psum, const float* psq, int nblk, const float* gamma,
-                                const float* beta, float* mov_mean, float* mov_var, float* save_mean,
-                                float* save_invstd, float* y, int rows, int F, int rows_per_blk, int training,
-                                float eps, float momentum) {
+__global__ void bn_partial_sq_kernel(const float* x, const float* mean_v, float* part, int rows, int F, int rows_per_blk) {
+  const int G = F < 256 ? 256 / F : 1;
   const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-  for (int f = threadIdx.x; f < F; f += blockDim.x) {
-    float mean, var;
-    if (training) {
-      double m = 0.0, q = 0.0;
-      for (int i = 0; i < nblk; ++i) { m += (double)psum[(long)i * F + f]; q += (double)psq[(long)i * F + f]; }
-      mean = (float)(m / rows);
-      var = (float)(q / rows);
-    } else {
-      mean = mov_mean[f];
-      var = mov_var[f];
+  for (int idx = threadIdx.x; idx < G * F; idx += blockDim.x) {
+    const int f = idx % F, g = idx / F;
+    const float mean = mean_v[f];
+    float s0 = 0.f, s1 = 0.f;
+    int r = r0 + g;
+    for (; r + G < r1; r += 2 * G) {
+      const float d0 = x[(long)r * F + f] - mean, d1 = x[(long)(r + G) * F + f] - mean;
+      s0 += d0 * d0; s1 += d1 * d1;
     }
-    const float invstd = rsqrtf(var + eps);
-    const float g = gamma[f] * invstd, bta = beta[f];
-    for (int r = r0; r < r1; ++r) y[(long)r * F + f] = (x[(long)r * F + f] - mean) * g + bta;
-    if (blockIdx.x == 0) {
-      if (save_mean) { save_mean[f] = mean; save_invstd[f] = invstd; }
-      if (training && mov_mean) {
-        const float unbiased = var * ((float)rows / (float)max(1, rows - 1));   // fused BN feeds Bessel-corrected var
-        mov_mean[f] = momentum * mov_mean[f] + (1.f - momentum) * mean;
-        mov_var[f] = momentum * mov_var[f] + (1.f - momentum) * unbiased;
-      }
+    if (r < r1) { const float d0 = x[(long)r * F + f] - mean; s0 += d0 * d0; }
+    part[((long)blockIdx.x * G + g) * F + f] = s0 + s1;
+  }
+}
+
+// var from the centred-square partials, inverse std, moving-average update (one launch, one block per 32 columns)
+__global__ __launch_bounds__(1024) void bn_var_kernel(const float* part, int npart, const float* mean_v, float* invstd_v, float* mov_mean,
+                                                      float* mov_var, int rows, int F, float eps, float momentum) {
+  __shared__ double red[32][33];
+  const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int f = blockIdx.x * 32 + fl;
+  double s = 0.0;
+  if (f < F)
+    for (int i = g; i < npart; i += 32) s += (double)part[(long)i * F + f];
+  red[g][fl] = s;
+  __syncthreads();
+  if (g == 0 && f < F) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) t += red[j][fl];
+    const float var = (float)(t / rows), mean = mean_v[f];
+    invstd_v[f] = rsqrtf(var + eps);
+    if (mov_mean) {
+      const float unbiased = var * ((float)rows / (float)max(1, rows - 1));   // fused BN feeds Bessel-corrected var
+      mov_mean[f] = momentum * mov_mean[f] + (1.f - momentum) * mean;
+      mov_var[f] = momentum * mov_var[f] + (1.f - momentum) * unbiased;
     }
+  }
+}
+
+// y = (x - mean) * invstd * gamma + beta, flat over rows * F (F % 4 == 0: one float4 per thread-iteration)
+__global__ void bn_apply_kernel(const float* x, const float* mean_v, const float* invstd_v, const float* mov_mean, const float* mov_var,
+                                const float* gamma, const float* beta, float* y, long n4, int F, int training, float eps) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int f = (int)((i * 4) % F);
+    const f32x4 xv = ld4(x + i * 4);
+    f32x4 yv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float mean = training ? mean_v[f + e] : mov_mean[f + e];
+      const float istd = training ? invstd_v[f + e] : rsqrtf(mov_var[f + e] + eps);
+      yv[e] = (xv[e] - mean) * (gamma[f + e] * istd) + beta[f + e];
+    }
+    st4(y + i * 4, yv);
   }
 }
 
@@ -165,27 +209,28 @@ __global__ void dropout_rows_kernel(const float* x, long ldx, int Tx, long ldox,
   }
 }
 
-// d emb[v, :] = sum over rows whose input token == v.  One block per vocabulary row; the token ids of a
-// tile of rows are staged in LDS (broadcast reads), every thread owns embedding columns and walks the
-// tile in row order (deterministic summation order).
-__global__ void embed_grad_kernel(const float* dx, const int32_t* fed, float* demb, int B, int L, int E, int V) {
-  __shared__ int toks[1024];
-  const int v = blockIdx.x;
-  const int rows = B * L;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};      // E <= 4 * blockDim.x
-  for (int base = 0; base < rows; base += 1024) {
-    const int n = min(1024, rows - base);
-    __syncthreads();
-    for (int j = threadIdx.x; j < n; j += blockDim.x) toks[j] = fed[base + j];
-    __syncthreads();
-    for (int e = threadIdx.x, slot = 0; e < E && slot < 4; e += blockDim.x, ++slot) {
-      float a = acc[slot];
-      for (int j = 0; j < n; ++j)
-        if (toks[j] == v) a += dx[(long)(base + j) * E + e];
-      acc[slot] = a;
+// d emb[v, :] = sum over rows whose input token == v.  Block (v, chunk of 256 rows): the token ids of the chunk are
+// staged in LDS, every thread owns embedding columns and walks the chunk in row order with UNCONDITIONAL loads (the
+// select is on the value, so 8 rows are in flight); per-chunk partials [nchunk][V*E] are then summed in chunk order
+// by colsum_final_kernel (deterministic summation order).
+#define EG_ROWS 256
+__global__ void embed_grad_partial_kernel(const float* dx, const int32_t* fed, float* part, int rows, int E, int V) {
+  __shared__ int toks[EG_ROWS];
+  const int v = blockIdx.x, base = blockIdx.y * EG_ROWS;
+  const int n = min(EG_ROWS, rows - base);
+  for (int j = threadIdx.x; j < EG_ROWS; j += blockDim.x) toks[j] = j < n ? fed[base + j] : -1;
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    float a = 0.f;
+    for (int j = 0; j < n; j += 8) {
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) x[k] = dx[(long)(base + min(j + k, n - 1)) * E + e];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a += (j + k < n && toks[j + k] == v) ? x[k] : 0.f;
     }
+    part[((long)blockIdx.y * V + v) * E + e] = a;
   }
-  for (int e = threadIdx.x, slot = 0; e < E && slot < 4; e += blockDim.x, ++slot) demb[(long)v * E + e] = acc[slot];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -386,7 +431,7 @@ extern "C" int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, i
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(th), 0, S_(stream), a->ptr, (long)a->ld, a->T, (long)a->ldo,
                      b ? b->ptr : nullptr, b ? (long)b->ld : 0, b ? b->T : 0, b ? (long)b->ldo : 0, scratch, rows, F, rpb);
   AVSR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(256), 0, S_(stream), scratch, nblk, out, F, alpha, beta);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), scratch, nblk, out, F, alpha, beta);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
@@ -396,27 +441,38 @@ extern "C" int avsr_batchnorm_fwd(const float* x, float* y, int32_t rows, int32_
                                   float* save_invstd, int32_t training, float* scratch, int64_t scratch_floats,
                                   void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0 || F <= 0 || !scratch) return AVSR_ERR_ARG;
+  if (F % 4) return AVSR_ERR_ARG;
+  const int G = F < 256 ? 256 / F : 1;
   int rpb = 64;
   int nblk = (rows + rpb - 1) / rpb;
-  if ((long)2 * nblk * F > scratch_floats) {
-    nblk = (int)(scratch_floats / (2 * F));
+  if ((long)nblk * G * F + 2 * F > scratch_floats) {
+    nblk = (int)((scratch_floats - 2 * F) / ((long)G * F));
     if (nblk < 1) return AVSR_ERR_ARG;
     rpb = (rows + nblk - 1) / nblk;
     nblk = (rows + rpb - 1) / rpb;
   }
-  float* psum = scratch;
-  float* psq = scratch + (long)nblk * F;
-  const int th = F >= 256 ? 256 : ((F + 63) / 64) * 64;
+  // scratch: partials [nblk*G][F] | mean [F] | invstd [F]  (mean / invstd go to save_mean / save_invstd when given)
+  float* part = scratch;
+  float* mean_v = save_mean ? save_mean : scratch + (long)nblk * G * F;
+  float* invstd_v = save_invstd ? save_invstd : scratch + (long)nblk * G * F + F;
   if (training) {
-    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(nblk), dim3(th), 0, S_(stream), x, psum, rows, F, rpb);
+    hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, part, rows, F, rpb);
     AVSR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_partial_sq_kernel, dim3(nblk), dim3(th), 0, S_(stream), x, psum, nblk, psq, rows, F, rpb);
+    hipLaunchKernelGGL(bn_mean_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, nblk * G, mean_v, rows, F);
+    AVSR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_partial_sq_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, mean_v, part, rows, F, rpb);
+    AVSR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_var_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, nblk * G, mean_v, invstd_v, moving_mean,
+                       moving_var, rows, F, 1e-3f, 0.99f);
     AVSR_CHECK_LAUNCH();
   } else if (!moving_mean || !moving_var) {
     return AVSR_ERR_ARG;
   }
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk), dim3(th), 0, S_(stream), x, psum, psq, nblk, gamma, beta, moving_mean,
-                     moving_var, save_mean, save_invstd, y, rows, F, rpb, training, 1e-3f, 0.99f);
+  const long n4 = (long)rows * F / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, S_(stream), x, mean_v, invstd_v, moving_mean, moving_var, gamma, beta, y,
+                     n4, F, training, 1e-3f);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
@@ -440,10 +496,15 @@ extern "C" int avsr_embed_labels(const float* emb, const int32_t* labels, int32_
 }
 
 extern "C" int avsr_embed_grad(const float* dx, const int32_t* fed, float* demb, int32_t B, int32_t L, int32_t E,
-                               int32_t V, void* stream) {
-  if (!dx || !fed || !demb || E > 1024) return AVSR_ERR_ARG;
-  hipLaunchKernelGGL(embed_grad_kernel, dim3(V), dim3(E >= 256 ? 256 : ((E + 63) / 64) * 64), 0, S_(stream), dx, fed, demb,
-                     B, L, E, V);
+                               int32_t V, float* scratch, int64_t scratch_floats, void* stream) {
+  if (!dx || !fed || !demb || !scratch || B <= 0 || L <= 0 || E <= 0 || V <= 0) return AVSR_ERR_ARG;
+  const int rows = B * L;
+  const int nchunk = (rows + EG_ROWS - 1) / EG_ROWS;
+  if ((long)nchunk * V * E > scratch_floats || nchunk > 65535) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(embed_grad_partial_kernel, dim3(V, nchunk), dim3(E >= 256 ? 256 : ((E + 63) / 64) * 64), 0, S_(stream), dx, fed,
+                     scratch, rows, E, V);
+  AVSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((V * E + 31) / 32), dim3(1024), 0, S_(stream), scratch, nchunk, demb, V * E, 1.0f, 0.0f);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

@@ -235,8 +235,16 @@ __global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
     const int col = (int)(i % g.N);
     const int row = (int)((i / g.N) % g.M);
     const int bz = (int)(i / ((long)g.M * g.N));
+    // slices summed in index order (deterministic), four loads in flight
+    const float* w = g.ws + ((long)bz * g.splitk * g.M + row) * g.N + col;
+    const long zs = (long)g.M * g.N;
     float s = 0.f;
-    for (int z = 0; z < g.splitk; ++z) s += g.ws[((long)(bz * g.splitk + z) * g.M + row) * g.N + col];
+    int z = 0;
+    for (; z + 4 <= g.splitk; z += 4) {
+      const float a0 = w[z * zs], a1 = w[(z + 1) * zs], a2 = w[(z + 2) * zs], a3 = w[(z + 3) * zs];
+      s = (((s + a0) + a1) + a2) + a3;
+    }
+    for (; z < g.splitk; ++z) s += w[z * zs];
     float* c = g.C + (long)bz * g.sC +
                (g.Tc ? (long)(row / g.Tc) * g.ldoc + (long)(row % g.Tc) * g.ldc : (long)row * g.ldc) + col;
     float v = (g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha) * s;

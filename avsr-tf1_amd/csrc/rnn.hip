@@ -12,6 +12,7 @@
 extern "C" int avsr_step_launch_raw(const void* launch, void* stream);
 int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
 int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
+int avsr_rnn_bwd_persistent_split(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
 
 // Persistent execution: all stacks in one launch when they fit together, else one launch per stack when every
 // stack fits on its own (checked first: nothing runs unless everything can), else AVSR_ERR_UNSUPPORTED.
@@ -204,7 +205,9 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
   }
   if (ntask_max > STEP_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
   {
-    const int rc = run_persistent(avsr_rnn_bwd_persistent, st, n, stream);   // one launch for the whole BPTT when it fits
+    int rc = run_persistent(avsr_rnn_bwd_persistent_split, st, n, stream);   // one launch for the whole BPTT when it fits:
+    if (rc != AVSR_ERR_UNSUPPORTED) return rc;                                // split form first, then the fused form
+    rc = run_persistent(avsr_rnn_bwd_persistent, st, n, stream);
     if (rc != AVSR_ERR_UNSUPPORTED) return rc;
   }
 

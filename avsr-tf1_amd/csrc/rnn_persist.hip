@@ -382,6 +382,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int spins = 0; spins < (1 << 21); ++spins) {
       const int v = poll_ptr ? __hip_atomic_load(poll_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
       if (__all(v >= need)) return;
+#ifdef POLL_SLEEP
+      __builtin_amdgcn_s_sleep(POLL_SLEEP);
+#endif
       if ((spins & 1023) == 1023 && __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     }
     if (lane == 0) __hip_atomic_store(L.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 int32_t* g_sync = nullptr;
-int g_persist_mode = 3;      // bit 0: agent-scope kernel allowed, bit 1: XCD-local kernel allowed
+int g_persist_mode = 3;      // bit 0: agent-scope forward, bit 1: XCD-local forward + fused BPTT, bit 2: split BPTT (opt-in)
 
 int64_t g_sync_ints = 0;
 

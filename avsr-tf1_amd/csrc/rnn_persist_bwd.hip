@@ -148,6 +148,9 @@ __global__ __launch_bounds__(512) void rnn_persist_bwd_kernel(const BLaunch L) {
     for (int spins = 0; spins < (1 << 21); ++spins) {
       const int v = p ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
       if (__all(v >= need)) return;
+#ifdef POLL_SLEEP
+      __builtin_amdgcn_s_sleep(POLL_SLEEP);
+#endif
       if ((spins & 1023) == 1023 && __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     }
     if (lane == 0) __hip_atomic_store(L.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -93,7 +93,9 @@ class Seq2SeqModel:
         self.cfg, self.dev = cfg, torch.device(device)
         self.gru = cfg.cell_type == "gru"
         # one-launch persistent encoder forward (csrc/rnn_persist.hip); process-wide engine switch
-        pm = int(os.environ.get("AVSR_PERSISTENT_RNN", "3"))      # 0 off | 1 agent-scope fwd | 2 XCD-local fwd+bwd | 3 both (default)
+        # bits: 1 agent-scope forward | 2 XCD-local forward + fused BPTT | 4 split BPTT (measured slower on c4: 3.0 vs 2.7 ms,
+        # kept selectable); 0 = per-step launches only
+        pm = int(os.environ.get("AVSR_PERSISTENT_RNN", "3"))
         self.persistent_rnn = pm != 0
         ops.rnn_set_persistent(self.persistent_rnn, device=device, mode=pm or 3)
         self.G = 2 if self.gru else 4                       # gate pre-activations per unit of the main cell kernel
@@ -896,7 +898,7 @@ class Seq2SeqModel:
         if self._dropping and cfg.decoder_dropout[0] < 1.0:
             dm = ops.mat(D["dxemb"], E)
             ops.dropout_rows(dm, dm, B * L, E, self.step, CELL_ID_DECODER * 4, cfg.decoder_dropout[0], E + A)
-        ops.embed_grad(D["dxemb"], D["fed"], self._gp("dec/embedding"), B, L, E, V)
+        ops.embed_grad(D["dxemb"], D["fed"], self._gp("dec/embedding"), B, L, E, V, self.scratch)
         self._decoder_init_state_bwd(ws)
         self._encode_backward(ws, batch)
 

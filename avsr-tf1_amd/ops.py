@@ -136,8 +136,8 @@ def embed_labels(emb, labels, go_id, out, fed, B, L, E, n_steps=None):
                                  _s()), "avsr_embed_labels")
 
 
-def embed_grad(dx, fed, demb, B, L, E, V):
-    check(_L().avsr_embed_grad(fptr(dx), fptr(fed), fptr(demb), B, L, E, V, _s()), "avsr_embed_grad")
+def embed_grad(dx, fed, demb, B, L, E, V, scratch):
+    check(_L().avsr_embed_grad(fptr(dx), fptr(fed), fptr(demb), B, L, E, V, fptr(scratch), scratch.numel(), _s()), "avsr_embed_grad")
 
 
 def dropout_rows(x, y, rows, cols, seed, stream_id, keep, idx_width, idx_coff=0, accumulate=False):
@@ -206,16 +206,21 @@ def prof_end():
 
 
 _persist_sync = None
+_persist_scratch = None
 
 
-def rnn_set_persistent(on, device="cuda", ints=1 << 20, mode=3):
-    """Enable / disable the one-launch persistent execution of avsr_rnn_fwd (see include/avsr_hip.h).
-    mode: bit 0 agent-scope kernel, bit 1 XCD-local kernel (tried first)."""
-    global _persist_sync
+def rnn_set_persistent(on, device="cuda", ints=1 << 20, mode=3, scratch_floats=64 << 20):
+    """Enable / disable the one-launch persistent execution of avsr_rnn_fwd / avsr_rnn_bwd (see include/avsr_hip.h).
+    mode: bit 0 agent-scope forward, bit 1 XCD-local forward + fused BPTT, bit 2 split BPTT (uses a float scratch)."""
+    global _persist_sync, _persist_scratch
     check(_L().avsr_rnn_set_persistent_mode(int(mode)), "avsr_rnn_set_persistent_mode")
     if on:
         if _persist_sync is None:
             _persist_sync = torch.zeros(ints, dtype=torch.int32, device=device)
+        if (mode & 4) and _persist_scratch is None:
+            _persist_scratch = torch.zeros(scratch_floats, dtype=torch.float32, device=device)
+        if _persist_scratch is not None:
+            check(_L().avsr_rnn_set_persistent_scratch(_persist_scratch.data_ptr(), _persist_scratch.numel()), "avsr_rnn_set_persistent_scratch")
         _persist_sync[:1].zero_()
         check(_L().avsr_rnn_set_persistent(_persist_sync.data_ptr(), ints), "avsr_rnn_set_persistent")
     else:

@@ -152,8 +152,12 @@ int avsr_rnn_bwd(const avsr_rnn_stack* stacks, int32_t n_stacks, void* stream);
  * units %% 8, in+units > 512, > 512 workgroups) silently use the per-step launches.  Same results either way. */
 int avsr_rnn_set_persistent(int32_t* sync, int64_t ints);
 /* Which persistent kernels may be used: bit 0 = agent-scope (any placement, 16-row tiles), bit 1 = XCD-local
- * (8-row groups bound to the XCD their workgroups actually run on; tried first).  Default 3. */
+ * (8-row groups bound to the XCD their workgroups actually run on; tried first) and the fused persistent BPTT,
+ * bit 2 = split persistent BPTT (needs avsr_rnn_set_persistent_scratch; opt-in).  Default 3. */
 int avsr_rnn_set_persistent_mode(int mode);
+/* Float device scratch for the split persistent BPTT (bit 2 of the mode): one [B,T,units] operand per encoder cell that has a
+ * layer above it.  NULL / too small: that form is skipped (the fused form or the per-step launches run instead). */
+int avsr_rnn_set_persistent_scratch(float* scratch, int64_t floats);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention-wrapped LSTM over a sequence.  Replaces
@@ -321,11 +325,11 @@ int avsr_batchnorm_xhat(const float* x, const float* mean, const float* invstd, 
 
 /* embedding_lookup(labels_padded_GO) (avsr/decoder_unimodal.py:66-68, :170): fed[b][l] = l ? labels[b][l-1] : GO,
  * out[b][l][:] = emb[fed[b][l]] for l < n_steps (n_steps = L: all; 1: only the GO column).  Gradient: demb[v][:] = sum of
- * dx rows whose fed token is v. */
+ * dx rows whose fed token is v (deterministic order; scratch >= ceil(B*L/256) * V * E floats). */
 int avsr_embed_labels(const float* emb, const int32_t* labels, int32_t go_id, float* out, int32_t* fed, int32_t B,
                       int32_t L, int32_t E, int32_t n_steps, void* stream);
 int avsr_embed_grad(const float* dx, const int32_t* fed, float* demb, int32_t B, int32_t L, int32_t E, int32_t V,
-                    void* stream);
+                    float* scratch, int64_t scratch_floats, void* stream);
 
 /* y[r][c] = (accumulate ? y[r][c] : 0) + x[r][c] * mask(r, c) / keep for r < rows, c < cols;
  * mask index = r * idx_width + idx_coff + c (r = b*T + t), stream as in avsr_rnn_stack.  Used for input dropout of
