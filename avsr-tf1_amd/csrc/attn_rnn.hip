@@ -486,7 +486,9 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
     // ---- KB5b: reduce the per-chunk query gradients --------------------------------------------
     BL = SlabLaunch{};
     BL.B = B;
-    if (use_dq) {
+    // LSTM with only Luong mechanisms (<= 2): the cell-backward epilogue sums the partials itself (no launch here)
+    const bool fold_dq = use_dq && !gru && n_bah == 0 && n_luong <= 2;
+    if (use_dq && !fold_dq) {
       SlabJob& J = BL.job[BL.njob++];
       J.dst = d.dq + (long)l * H; J.dst_sb = (long)L * H; J.W = H;
       if (d.dcell_ext) { J.add = d.dcell_ext + (long)l * H; J.add_sb = (long)L * H; }
@@ -535,7 +537,16 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
         tk.p4 = dcbuf(d, (l + 1) & 1); tk.p5 = dcbuf(d, l & 1);
         tk.p6 = dhcarry(d, (l + 1) & 1); tk.p7 = dhcarry(d, l & 1);
       }
-      if (use_dq) { tk.p8 = d.dq; tk.s0 = (long)L * H; tk.s1 = H; }
+      if (fold_dq) {
+        if (d.dcell_ext) { tk.p8 = const_cast<float*>(d.dcell_ext); tk.s0 = (long)L * H; tk.s1 = H; }
+        int k = 0;
+        for (int m = 0; m < d.n_mech; ++m) {
+          if (is_bahdanau(d.mech[m])) continue;
+          if (k == 0) { tk.pm = d.mech[m].pdq; tk.nslab = nchunk(d.mech[m]); }
+          else { tk.pl = d.mech[m].pdq; tk.pad0 = nchunk(d.mech[m]); }
+          ++k;
+        }
+      } else if (use_dq) { tk.p8 = d.dq; tk.s0 = (long)L * H; tk.s1 = H; }
       if (drop) {
         tk.seed = d.seed; tk.k_st = d.keep_state; tk.k_out = d.keep_out; tk.k_in = 1.0f;
         tk.r_st = cid4 + 1; tk.r_out = cid4 + 2;

@@ -197,9 +197,7 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(const PLaunch L) {
     if (done_low && t + 1 < T) load_x(t + 1, xcur);      // refill in place: consumed a step from now
     // hoisted x.Wx of the NEXT step (written before this launch, cold in HBM).  Issued last: vmcnt retires in
     // order, so a slow load must be younger than the recurrent operands or it would stall their wait.
-#ifndef PROBE_NOZ
     if (eok && hoisted && t + 1 < len_b) znext = ld4(gates_p + (long)(rec_b + (reverse ? len_b - 2 - t : t + 1) * H) * 4);
-#endif
     asm volatile("" ::: "memory");
 #ifdef PERSIST_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -246,10 +244,8 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(const PLaunch L) {
         st_sc1(out_p + (out_b + tau * out_st), ho);                 // exchanged values first, records after
         if (hsw_p) st_sc1(hsw_p + (hsw_b + tau * hs_st), hs);
         if (xtw_p) st_sc1(xtw_p + (xtw_b + tau * xt_st), ho * p_drop(drop_on, seedv, r_in, (uint32_t)(bt * in_W + in_coff + u), k_in));
-#ifndef PROBE_NOREC
         st4(gates_p + (long)(rec_b + tau * H) * 4, g4);
         cs_p[rec_b + tau * H] = c;
-#endif
         c_state = c;
         h_state = hs;
       } else {                     // past the utterance: zero output at padding position t, state carried in registers

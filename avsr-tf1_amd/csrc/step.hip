@@ -250,6 +250,23 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
           if (t == 0) pre3 = tk.bias ? tk.bias[bh] : 0.f;
           else pre3 = tk.p1[(bt + (tk.reverse ? 1 : -1)) * H + n];   // c_prev
           if (tk.p8) pre2b = tk.p8[(long)b * tk.s0 + (long)tau * tk.s1 + n];   // external d out
+          // + per-chunk partial gradients of the attention query (attention backward emits one partial per memory chunk):
+          // summed here, in chunk order, instead of by a reduction launch in the decoder's sequential chain.
+          // pm / nslab = first partial set [nslab][B][H], pl / pad0 = second set; unconditional loads (out of range = 0).
+          if (tk.pm) {
+            const __amdgpu_buffer_rsrc_t r0 = make_rsrc(tk.pm), r1 = make_rsrc(tk.pl);
+            const int o = (b * H + n) * 4, cs = tk.B * H * 4;
+            float v0[STEP_MAX_SLAB], v1[STEP_MAX_SLAB];
+#pragma unroll
+            for (int c = 0; c < STEP_MAX_SLAB; ++c) {
+              v0[c] = ldb1(r0, c < tk.nslab ? o + c * cs : P_OOB);
+              v1[c] = ldb1(r1, (tk.pl && c < tk.pad0) ? o + c * cs : P_OOB);
+            }
+#pragma unroll
+            for (int c = 0; c < STEP_MAX_SLAB; ++c) pre2b += v0[c];
+#pragma unroll
+            for (int c = 0; c < STEP_MAX_SLAB; ++c) pre2b += v1[c];
+          }
         }
       }
     } else if constexpr (MODE == EP_LINEAR) {
