@@ -109,6 +109,78 @@ __global__ void sched_sample_kernel(const float* logits, long logits_sb, int V, 
   }
 }
 
+
+// Output layer + ScheduledEmbeddingTrainingHelper step fused into ONE launch of the decoder's sequential chain (it replaces a
+// dense step launch + sched_sample_kernel): block = utterance b.
+//   logits[b, :] = x[b, :] . Wout + bout   (zero past the utterance's step length, as dynamic_decode's impute_finished)
+//   then the draw of sched_sample_kernel above and the (input-dropped) embedding of the token fed to step l+1.
+// Thread (vc = tid & 31, ks = tid >> 5): column v0 + vc, K slice ks of 8 (16-byte loads, Wout^T rows are K-contiguous).
+__global__ __launch_bounds__(256) void logits_sample_kernel(const float* x, long x_sb, int O, const float* wout_t, const float* bout,
+                                                            float* logits, long logits_sb, int V, const int32_t* steplen,
+                                                            const int32_t* labels, int32_t* fed, float* xs, const float* emb, int B, int L,
+                                                            int E, int l, const int32_t* seed, float prob, float keep_in, uint32_t r_in,
+                                                            int in_W) {
+  extern __shared__ float lg_s[];          // [V] logits of this utterance
+  __shared__ float part[8][33];
+  __shared__ int tok_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int vc = tid & 31, ks = tid >> 5;
+  const uint32_t sd0 = seed ? (uint32_t)seed[0] : 0u;
+  const int label = (l + 1 < L) ? labels[(long)b * L + l] : 0;
+  const bool valid = !(steplen && l >= steplen[b]);
+  const float* xr = x + (long)b * x_sb;
+  const int kper = ((O + 31) / 32) * 4;    // K slice length, multiple of 4
+  const int k0 = ks * kper, k1 = min(O, k0 + kper);
+  for (int v0 = 0; v0 < V; v0 += 32) {
+    const int v = v0 + vc;
+    float a = 0.f;
+    if (v < V) {
+      const float* wr = wout_t + (long)v * O;
+      for (int k = k0; k < k1; k += 4) {
+        const f32x4 xv = ld4(xr + k), wv = ld4(wr + k);
+        a += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+      }
+    }
+    part[ks][vc] = a;
+    __syncthreads();
+    if (ks == 0 && v < V) {
+      float z = ((part[0][vc] + part[1][vc]) + (part[2][vc] + part[3][vc])) + ((part[4][vc] + part[5][vc]) + (part[6][vc] + part[7][vc]));
+      z = valid ? z + (bout ? bout[v] : 0.f) : 0.f;
+      lg_s[v] = z;
+      logits[(long)b * logits_sb + v] = z;
+    }
+    __syncthreads();
+  }
+  if (l + 1 >= L) return;
+  if (tid == 0) {
+    const uint32_t idx = (uint32_t)(b * L + l);
+    int tok = label;
+    if (prob > 0.f && uniform01(sd0, 1000u, idx) < prob) {
+      float mx = lg_s[0];
+      for (int v = 1; v < V; ++v) mx = fmaxf(mx, lg_s[v]);
+      float tot = 0.f;
+      for (int v = 0; v < V; ++v) tot += expf(lg_s[v] - mx);
+      const float target = uniform01(sd0, 1001u, idx) * tot;
+      float run = 0.f;
+      tok = V - 1;
+      for (int v = 0; v < V; ++v) {
+        run += expf(lg_s[v] - mx);
+        if (run > target) { tok = v; break; }
+      }
+    }
+    fed[(long)b * L + l + 1] = tok;
+    tok_s = tok;
+  }
+  __syncthreads();
+  const int tok = tok_s;
+  const bool on = keep_in < 1.0f;
+  for (int e = tid; e < E; e += blockDim.x) {
+    float v = emb[(long)tok * E + e];
+    if (on) v = uniform01(sd0, r_in, (uint32_t)(((long)b * L + l + 1) * in_W + e)) < keep_in ? v / keep_in : 0.f;
+    xs[((long)b * L + l + 1) * E + e] = v;
+  }
+}
+
 // One BeamSearchDecoder step for one utterance (block): see avsr_hip.h mode 3 and oracle.beam_search_decode.
 __global__ void beam_step_kernel(const float* logits, long logits_sb, int V, int K, int l, int eos, float w,
                                  const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
@@ -374,12 +446,21 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
       // ---- K4/K5: output layer + greedy / scheduled sample / beam step ------------------------
       const bool oa = d.output_attention && A > 0;
       const int O = oa ? A : H;
+      const float* xa = oa ? d.att + (long)(l + 1) * A : d.cell_out + (long)(l + 1) * H;
+      const long xsb = oa ? (long)(L + 1) * A : (long)(L + 1) * H;
+      const bool fused_sample = d.mode == 2 && O % 4 == 0 && d.V <= 8192;
+      if (fused_sample) {
+        hipLaunchKernelGGL(logits_sample_kernel, dim3(B), dim3(256), sizeof(float) * d.V, s, xa, xsb, O, d.wout_t, d.bout,
+                           d.logits + (long)l * d.V, (long)L * d.V, d.V, d.steplen, d.labels, d.fed, d.xs, d.embedding, B, L, E, l, d.seed,
+                           d.sampling_prob, drop ? d.keep_in : 1.0f, cid4, E + A);
+        AVSR_CHECK_LAUNCH();
+        continue;
+      }
       SL.ntask = 1;
       StepTask& tk = SL.task[0];
       tk = StepTask{};
       StepSrc& x = tk.src[tk.nsrc++];
-      if (oa) { x.a = d.att + (long)(l + 1) * A; x.sb = (long)(L + 1) * A; }
-      else { x.a = d.cell_out + (long)(l + 1) * H; x.sb = (long)(L + 1) * H; }
+      x.a = xa; x.sb = xsb;
       x.K = O; x.w = d.wout_t; x.ldw = O; x.kind = SRC_PLAIN;
       tk.B = B; tk.N = d.V; tk.mode = EP_LINEAR; tk.t = l; tk.T = L; tk.len = (d.mode == 3) ? nullptr : d.steplen; tk.bias = d.bout;
       tk.p0 = d.logits + (long)l * d.V; tk.s0 = (long)L * d.V;
