@@ -1,0 +1,218 @@
+"""Lip-crop CNN front-end: `video.resnet_cnn` (avsr/video.py:143-195, wired at avsr/avsr.py:684-696) on the HIP engine.
+
+[N, H, W, C] frames (N = B*T, zero padding frames included, exactly as `cnn_layers` reshapes them, video.py:224-233)
+-> conv3x3(C->f0)+bias -> BN-ReLU -> residual block (identity shortcut, no leading BN) -> one strided residual block
+per further filter count (BN-ReLU, 1x1/2 projection shortcut on the un-normalised input, conv3x3/2, BN-ReLU, conv3x3,
+add) -> VALID conv over the remaining map -> cnn_dense_units, ReLU.  BN: epsilon 1e-5, momentum 0.98 (video.py:8-11);
+every conv kernel carries l2(0.001) (video.py:26, summed into the loss at seq2seq.py:180-184).
+
+Every convolution is avsr_im2col + avsr_gemm (the TF kernel [kh,kw,cin,cout] IS the [kh*kw*cin, cout] operand), its
+data gradient the transposed GEMM + avsr_col2im, its weight gradient a split-K TN GEMM; BN through avsr_batchnorm_fwd_ex /
+avsr_batchnorm_bwd.  This file only owns buffers and the op order; all arithmetic is in csrc/conv.hip, gemm.hip,
+elementwise.hip."""
+import torch
+
+from . import ops
+
+
+def same_pad(n, k, s):
+    """TF 'SAME': out = ceil(n / s); total = max((out-1)*s + k - n, 0); the odd pixel goes after (bottom / right)."""
+    out = (n + s - 1) // s
+    total = max((out - 1) * s + k - n, 0)
+    return out, total // 2
+
+
+def layout(hw, filters, dense):
+    """Op list of resnet_cnn.  ('conv', name, src, dst, k, stride, cin, cout) | ('bnrelu', name, src, dst, c) |
+    ('add', name, a, b, dst) | ('flatten', name, src, dst, kh, kw, cin, cout);  shapes[name] = (H, W, C) of every map."""
+    H, W, C = hw
+    f = list(filters)
+    shapes = {"in": (H, W, C)}
+    ops_ = []
+
+    def conv(name, src, dst, k, s, cout):
+        h, w, cin = shapes[src]
+        ho, _ = same_pad(h, k, s)
+        wo, _ = same_pad(w, k, s)
+        shapes[dst] = (ho, wo, cout)
+        ops_.append(("conv", name, src, dst, k, s, cin, cout))
+
+    def bnrelu(name, src, dst):
+        shapes[dst] = shapes[src]
+        ops_.append(("bnrelu", name, src, dst, shapes[src][2]))
+
+    def add(name, a, b, dst):
+        shapes[dst] = shapes[a]
+        ops_.append(("add", name, a, b, dst))
+
+    conv("layer0", "in", "a0", 3, 1, f[0])
+    bnrelu("layer0_bn", "a0", "b0")
+    conv("res_block_0_conv1", "b0", "r0a", 3, 1, f[0])
+    bnrelu("res_block_0_second_bn", "r0a", "r0b")
+    conv("res_block_0_conv2", "r0b", "r0c", 3, 1, f[0])
+    add("res_block_0", "r0c", "b0", "x0")
+    prev = "x0"
+    for i, c in enumerate(f[1:], start=1):
+        n = "res_block_%d" % i
+        bnrelu(n + "_first_bn", prev, n + "_p")
+        conv(n + "_shortcut", prev, n + "_s", 1, 2, c)
+        conv(n + "_conv1", n + "_p", n + "_a", 3, 2, c)
+        bnrelu(n + "_second_bn", n + "_a", n + "_b")
+        conv(n + "_conv2", n + "_b", n + "_c", 3, 1, c)
+        add(n, n + "_c", n + "_s", "x%d" % i)
+        prev = "x%d" % i
+    h, w, cin = shapes[prev]
+    shapes["out"] = (1, 1, dense)
+    ops_.append(("flatten", "flatten", prev, "out", h, w, cin, dense))
+    return ops_, shapes
+
+
+def param_shapes(hw, filters, dense):
+    """[(name, tf_shape, role)] in graph order; role: conv_kernel | bias | gamma | beta | moving_mean | moving_variance."""
+    out = []
+    for op in layout(hw, filters, dense)[0]:
+        if op[0] == "conv":
+            _, name, _, _, k, _, cin, cout = op
+            out += [(name + "/kernel", (k, k, cin, cout), "conv_kernel"), (name + "/bias", (cout,), "bias")]
+        elif op[0] == "flatten":
+            _, name, _, _, kh, kw, cin, cout = op
+            out += [(name + "/kernel", (kh, kw, cin, cout), "conv_kernel"), (name + "/bias", (cout,), "bias")]
+        elif op[0] == "bnrelu":
+            c = op[4]
+            out += [(op[1] + "/gamma", (c,), "gamma"), (op[1] + "/beta", (c,), "beta"),
+                    (op[1] + "/moving_mean", (c,), "moving_mean"), (op[1] + "/moving_variance", (c,), "moving_variance")]
+    return out
+
+
+class LipCNN:
+    BN_EPS, BN_MOMENTUM, L2 = 1e-5, 0.98, 1e-3
+
+    def __init__(self, model, N, prefix="video/cnn/"):
+        cfg = model.cfg
+        self.m, self.N, self.pre = model, N, prefix
+        self.ops, self.shapes = layout(cfg.video_hw, cfg.cnn_filters, cfg.cnn_dense_units)
+        dev = model.dev
+        z = lambda *s: torch.zeros(*s, device=dev)
+        self.maps, self.gmaps, self.col, self.bn = {}, {}, {}, {}
+        max_col = 4
+        for op in self.ops:
+            kind = op[0]
+            if kind == "conv":
+                _, name, src, dst, k, s, cin, cout = op
+                ho, wo, _ = self.shapes[dst]
+                self.col[name] = z(N * ho * wo, k * k * cin)
+                max_col = max(max_col, self.col[name].numel())
+            elif kind == "bnrelu":
+                c = op[4]
+                self.bn[op[1]] = (z(c), z(c))                      # batch mean, inverse std (training statistics)
+            if kind == "flatten":
+                self.pre_act = z(N, op[7])
+            dst = op[3] if kind in ("conv", "bnrelu", "flatten") else op[4]
+            h, w, c = self.shapes[dst]
+            self.maps[dst] = z(N, h, w, c)
+        for name, (h, w, c) in self.shapes.items():
+            if name != "in":
+                self.gmaps[name] = z(N, h, w, c)
+        self.dcol = torch.empty(max_col, device=dev)              # d col of the layer being differentiated (transient)
+
+    # parameters live in the model's flat buffers
+    def _p(self, n):
+        return self.m.P[self.pre + n]
+
+    def _g(self, n):
+        return self.m.Gr[self.pre + n]
+
+    def _pv(self, n):
+        return self.m._pp(self.pre + n)
+
+    def forward(self, frames, training):
+        m, N = self.m, self.N
+        H, W, C = self.shapes["in"]
+        assert frames.shape == (N, H, W, C) and frames.is_contiguous() and frames.dtype == torch.float32
+        self.maps["in"] = frames
+        self.training = training
+        for op in self.ops:
+            kind = op[0]
+            if kind == "conv":
+                _, name, src, dst, k, s, cin, cout = op
+                h, w, _ = self.shapes[src]
+                ho, pt = same_pad(h, k, s)
+                wo, pl = same_pad(w, k, s)
+                col = self.col[name]
+                ops.im2col(self.maps[src], col, N, h, w, cin, k, k, s, pt, pl, ho, wo)
+                rows, K = N * ho * wo, k * k * cin
+                ops.gemm(ops.mat(col, K), self._p(name + "/kernel").mat(cout), ops.mat(self.maps[dst], cout), rows, cout, K,
+                         bias=self._pv(name + "/bias"))
+            elif kind == "bnrelu":
+                _, name, src, dst, c = op
+                h, w, _ = self.shapes[src]
+                mean, invstd = self.bn[name]
+                ops.batchnorm_fwd_ex(self.maps[src], self.maps[dst], N * h * w, c, self._pv(name + "/gamma"), self._pv(name + "/beta"),
+                                     m._sp(self.pre + name + "/moving_mean"), m._sp(self.pre + name + "/moving_variance"), mean, invstd,
+                                     training, self.BN_EPS, self.BN_MOMENTUM, 1, m.scratch)
+            elif kind == "add":
+                _, name, a, b, dst = op
+                ops.add(self.maps[a], self.maps[b], self.maps[dst], self.maps[dst].numel())
+            else:
+                _, name, src, dst, kh, kw, cin, cout = op
+                K = kh * kw * cin
+                ops.gemm(ops.mat(self.maps[src], K), self._p(name + "/kernel").mat(cout), ops.mat(self.pre_act, cout), N, cout, K,
+                         bias=self._pv(name + "/bias"))
+                ops.relu(self.pre_act, self.maps[dst], N * cout)
+        return self.maps["out"].view(N, -1)
+
+    def backward(self, dfeat):
+        """dfeat [N, cnn_dense_units]: gradient of the loss wrt the CNN output.  Accumulates into the model's gradient buffer."""
+        m, N = self.m, self.N
+        written = set()
+
+        def target(name):
+            """(gradient map of `name`, beta): first contribution overwrites, later ones accumulate."""
+            beta = 1.0 if name in written else 0.0
+            written.add(name)
+            return self.gmaps[name], beta
+
+        gout = self.gmaps["out"].view(N, -1)
+        gout.copy_(dfeat)
+        written.add("out")
+        for op in reversed(self.ops):
+            kind = op[0]
+            if kind == "flatten":
+                _, name, src, dst, kh, kw, cin, cout = op
+                K = kh * kw * cin
+                dpre = self.pre_act                                           # overwritten in place: d(pre-activation)
+                ops.relu_bwd(self.maps[dst], self.gmaps[dst], dpre, N * cout)
+                m._gemm_tn(ops.mat(self.maps[src], K), ops.mat(dpre, cout), self._g(name + "/kernel").mat(cout), K, cout, N)
+                ops.colsum(ops.mat(dpre, cout), N, cout, m.grads, m.scratch, beta=1.0, out_offset=self._g(name + "/bias").off)
+                g, beta = target(src)
+                ops.gemm(ops.mat(dpre, cout), self._p(name + "/kernel").mat(cout), ops.mat(g, K), N, K, cout, trans_b=1, beta=beta)
+            elif kind == "add":
+                _, name, a, b, dst = op
+                for t in (a, b):
+                    g, beta = target(t)
+                    if beta:
+                        ops.add(g, self.gmaps[dst], g, g.numel())
+                    else:
+                        g.copy_(self.gmaps[dst])
+            elif kind == "bnrelu":
+                _, name, src, dst, c = op
+                h, w, _ = self.shapes[src]
+                mean, invstd = self.bn[name]
+                g, beta = target(src)
+                gg, gb = self._g(name + "/gamma"), self._g(name + "/beta")
+                ops.batchnorm_bwd(self.maps[src], self.gmaps[dst], self._pv(name + "/gamma"), self._pv(name + "/beta"), mean, invstd, g,
+                                  gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c], N * h * w, c, 1, m.scratch, dx_beta=beta)
+            else:
+                _, name, src, dst, k, s, cin, cout = op
+                h, w, _ = self.shapes[src]
+                ho, pt = same_pad(h, k, s)
+                wo, pl = same_pad(w, k, s)
+                rows, K = N * ho * wo, k * k * cin
+                dy = ops.mat(self.gmaps[dst], cout)
+                m._gemm_tn(ops.mat(self.col[name], K), dy, self._g(name + "/kernel").mat(cout), K, cout, rows)
+                ops.colsum(dy, rows, cout, m.grads, m.scratch, beta=1.0, out_offset=self._g(name + "/bias").off)
+                if src != "in":                                                # pixels are data: no gradient needed
+                    dcol = self.dcol[:rows * K]
+                    ops.gemm(dy, self._p(name + "/kernel").mat(cout), ops.mat(dcol, K), rows, K, cout, trans_b=1)
+                    g, beta = target(src)
+                    ops.col2im(dcol, g, N, h, w, cin, k, k, s, pt, pl, ho, wo, beta=beta)

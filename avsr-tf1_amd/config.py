@@ -43,6 +43,12 @@ class ModelConfig:
     audio_dropout: Tuple[float, float, float] = (0.9, 0.9, 0.9)
     decoder_dropout: Tuple[float, float, float] = (0.9, 0.9, 0.9)
     sampling_probability: float = 0.0
+    # visual front-end (avsr/avsr.py:24, :33-34): "features" = records already hold cnn_dense_units-d vectors,
+    # "resnet_cnn" = lip crops [B, T, H, W, C] through video.resnet_cnn (cnn.py)
+    video_processing: str = "features"
+    cnn_filters: Tuple[int, ...] = (8, 16, 32, 64)
+    cnn_dense_units: int = 128
+    video_hw: Tuple[int, int, int] = (36, 36, 3)
 
     # -- same helpers/validation rules as the reference wiring (error types as in the reference) --
     def streams(self) -> List[str]:
@@ -101,6 +107,13 @@ class ModelConfig:
                 raise ValueError("AttentiveEncoder implements only `unidirectional` (encoder.py:229)")
             if self.video_units is None or self.audio_units is None:
                 raise ValueError("av_align needs both a video and an audio stream")
+        if self.video_processing not in ("features", "resnet_cnn"):
+            raise Exception("unknown visual content")                                   # avsr/avsr.py:713 (2dconv_cnn / 3dconv_cnn: not built)
+        if self.video_units is not None and self.video_processing == "resnet_cnn":
+            if self.video_feat != self.cnn_dense_units:
+                raise ValueError("video_feat must equal cnn_dense_units when the CNN front-end produces the video features")
+            if any(c % 4 for c in self.cnn_filters) or self.cnn_dense_units % 4 or len(self.cnn_filters) < 1:
+                raise ValueError("cnn_filters / cnn_dense_units must be multiples of 4 for the HIP engine")
         if len(self.decoder_units) != 1:
             raise NotImplementedError("multi-layer decoders are not built yet")
         if not self.streams():

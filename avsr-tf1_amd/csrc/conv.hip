@@ -1,0 +1,186 @@
+// Lip-crop CNN front-end pieces (video.resnet_cnn, avsr/video.py:143-195): NHWC im2col / col2im around the fp32 MFMA GEMM,
+// batch-norm backward (optionally through the ReLU that follows it), ReLU and residual-add helpers.
+//
+// Convolutions are lowered to GEMMs: col[(n,ho,wo)][(i,j,c)] = x[n, ho*s - pad_t + i, wo*s - pad_l + j, c] (zero outside)
+// times the TF kernel [kh, kw, cin, cout] read as a [kh*kw*cin, cout] matrix (HWIO is already that matrix, row-major).
+// The data gradient is the transposed GEMM followed by the gather-form col2im below (no atomics, deterministic).
+#include "common.h"
+#include "avsr_hip.h"
+
+namespace avsr {
+
+__global__ void im2col_kernel(const float* x, float* col, int N, int H, int W, int C, int kh, int kw, int s, int pt, int pl,
+                              int Ho, int Wo) {
+  const long K = (long)kh * kw * C;
+  const long total = (long)N * Ho * Wo * K;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    long r = idx / C;
+    const int j = (int)(r % kw); r /= kw;
+    const int i = (int)(r % kh); r /= kh;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const int h = ho * s - pt + i, w = wo * s - pl + j;
+    col[idx] = (h >= 0 && h < H && w >= 0 && w < W) ? x[(((long)n * H + h) * W + w) * C + c] : 0.f;
+  }
+}
+
+// dx[n,h,w,c] = sum over kernel taps (i,j) of dcol[(n,ho,wo)][(i,j,c)] with ho*s - pt + i == h, wo*s - pl + j == w
+__global__ void col2im_kernel(const float* dcol, float* dx, int N, int H, int W, int C, int kh, int kw, int s, int pt, int pl,
+                              int Ho, int Wo, float beta) {
+  const long K = (long)kh * kw * C;
+  const long total = (long)N * H * W * C;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    long r = idx / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc = 0.f;
+    for (int i = 0; i < kh; ++i) {
+      const int hn = h + pt - i;
+      if (hn < 0 || hn % s) continue;
+      const int ho = hn / s;
+      if (ho >= Ho) continue;
+      for (int j = 0; j < kw; ++j) {
+        const int wn = w + pl - j;
+        if (wn < 0 || wn % s) continue;
+        const int wo = wn / s;
+        if (wo >= Wo) continue;
+        acc += dcol[(((long)n * Ho + ho) * Wo + wo) * K + ((long)i * kw + j) * C + c];
+      }
+    }
+    dx[idx] = beta != 0.f ? acc + beta * dx[idx] : acc;
+  }
+}
+
+// ---- batch-norm backward (training statistics), optionally through a following ReLU -------------------------------
+// dy' = dy * [bn(x) > 0] (relu) ;  d beta = sum dy' ;  d gamma = sum dy' * xhat ;
+// dx = gamma * invstd * (dy' - (sum dy' + xhat * sum dy' xhat) / rows)
+__global__ void bn_bwd_partial_kernel(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
+                                      const float* invstd, float* part, int rows, int F, int rows_per_blk, int relu) {
+  const int G = F < 256 ? 256 / F : 1;
+  const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+  for (int idx = threadIdx.x; idx < G * F; idx += blockDim.x) {
+    const int f = idx % F, g = idx / F;
+    const float m = mean[f], is = invstd[f], ga = gamma[f], be = beta[f];
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = r0 + g; r < r1; r += G) {
+      const float xh = (x[(long)r * F + f] - m) * is;
+      float d = dy[(long)r * F + f];
+      if (relu && !(xh * ga + be > 0.f)) d = 0.f;
+      s1 += d;
+      s2 += d * xh;
+    }
+    float* p = part + ((long)blockIdx.x * G + g) * 2 * F;
+    p[f] = s1;
+    p[F + f] = s2;
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
+                                    const float* invstd, const float* sums, float* dx, long n, int rows, int F, int relu,
+                                    float dx_beta) {
+  const float inv_rows = 1.0f / (float)rows;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int f = (int)(i % F);
+    const float is = invstd[f], ga = gamma[f];
+    const float xh = (x[i] - mean[f]) * is;
+    float d = dy[i];
+    if (relu && !(xh * ga + beta[f] > 0.f)) d = 0.f;
+    const float v = ga * is * (d - (sums[f] + xh * sums[F + f]) * inv_rows);
+    dx[i] = dx_beta != 0.f ? v + dx_beta * dx[i] : v;
+  }
+}
+
+__global__ void relu_kernel(const float* x, float* y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = fmaxf(x[i], 0.f);
+}
+// dx = dy * [y > 0]
+__global__ void relu_bwd_kernel(const float* y, const float* dy, float* dx, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+// out = a + b
+__global__ void add_kernel(const float* a, const float* b, float* out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+
+static inline int blocks_for_n(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace avsr
+
+// out[f] = alpha * sum_i part[i][f] + beta * out[f]  (elementwise.hip)
+int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, float alpha, float beta, void* stream);
+
+using namespace avsr;
+#define S_(x) ((hipStream_t)(x))
+
+extern "C" int avsr_im2col(const float* x, float* col, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw,
+                           int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, void* stream) {
+  if (!x || !col || N <= 0 || H <= 0 || W <= 0 || C <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || Ho <= 0 || Wo <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(im2col_kernel, dim3(blocks_for_n((long)N * Ho * Wo * kh * kw * C)), dim3(256), 0, S_(stream), x, col, N, H, W, C, kh,
+                     kw, stride, pad_t, pad_l, Ho, Wo);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_col2im(const float* dcol, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw,
+                           int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, float beta, void* stream) {
+  if (!dcol || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || Ho <= 0 || Wo <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(col2im_kernel, dim3(blocks_for_n((long)N * H * W * C)), dim3(256), 0, S_(stream), dcol, dx, N, H, W, C, kh, kw,
+                     stride, pad_t, pad_l, Ho, Wo, beta);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_batchnorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
+                                  const float* invstd, float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t F, int32_t relu,
+                                  float dx_beta, float* scratch, int64_t scratch_floats, void* stream) {
+  if (!x || !dy || !gamma || !beta || !mean || !invstd || !scratch || rows <= 0 || F <= 0) return AVSR_ERR_ARG;
+  const int G = F < 256 ? 256 / F : 1;
+  int rpb = 64;
+  int nblk = (rows + rpb - 1) / rpb;
+  if ((long)nblk * G * 2 * F + 2 * F > scratch_floats) {
+    nblk = (int)((scratch_floats - 2 * F) / ((long)G * 2 * F));
+    if (nblk < 1) return AVSR_ERR_ARG;
+    rpb = (rows + nblk - 1) / nblk;
+    nblk = (rows + rpb - 1) / rpb;
+  }
+  float* part = scratch;
+  float* sums = scratch + (long)nblk * G * 2 * F;      // [2F]: sum dy' | sum dy' xhat
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, part, rows, F, rpb, relu);
+  AVSR_CHECK_LAUNCH();
+  { const int rc = avsr_colsum_final_launch(part, nblk * G, sums, 2 * F, 1.0f, 0.0f, stream); if (rc) return rc; }
+  if (dx) {
+    const long n = (long)rows * F;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for_n(n)), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, sums, dx, n, rows,
+                       F, relu, dx_beta);
+    AVSR_CHECK_LAUNCH();
+  }
+  if (dbeta && hipMemcpyAsync(dbeta, sums, sizeof(float) * F, hipMemcpyDeviceToDevice, S_(stream)) != hipSuccess) return AVSR_ERR_HIP;
+  if (dgamma && hipMemcpyAsync(dgamma, sums + F, sizeof(float) * F, hipMemcpyDeviceToDevice, S_(stream)) != hipSuccess) return AVSR_ERR_HIP;
+  return AVSR_OK;
+}
+
+extern "C" int avsr_relu(const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(relu_kernel, dim3(blocks_for_n(n)), dim3(256), 0, S_(stream), x, y, (long)n);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+extern "C" int avsr_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream) {
+  if (!y || !dy || !dx || n <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks_for_n(n)), dim3(256), 0, S_(stream), y, dy, dx, (long)n);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+extern "C" int avsr_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  if (!a || !b || !out || n <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(add_kernel, dim3(blocks_for_n(n)), dim3(256), 0, S_(stream), a, b, out, (long)n);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(1024) void bn_var_kernel(const float* part, int npa
 
 // y = (x - mean) * invstd * gamma + beta, flat over rows * F (F % 4 == 0: one float4 per thread-iteration)
 __global__ void bn_apply_kernel(const float* x, const float* mean_v, const float* invstd_v, const float* mov_mean, const float* mov_var,
-                                const float* gamma, const float* beta, float* y, long n4, int F, int training, float eps) {
+                                const float* gamma, const float* beta, float* y, long n4, int F, int training, float eps, int relu) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const int f = (int)((i * 4) % F);
     const f32x4 xv = ld4(x + i * 4);
@@ -169,6 +169,7 @@ __global__ void bn_apply_kernel(const float* x, const float* mean_v, const float
       const float mean = training ? mean_v[f + e] : mov_mean[f + e];
       const float istd = training ? invstd_v[f + e] : rsqrtf(mov_var[f + e] + eps);
       yv[e] = (xv[e] - mean) * (gamma[f + e] * istd) + beta[f + e];
+      if (relu) yv[e] = fmaxf(yv[e], 0.f);
     }
     st4(y + i * 4, yv);
   }
@@ -416,6 +417,12 @@ extern "C" int avsr_transpose(const avsr_transpose_job* jobs, int32_t n, void* s
   return AVSR_OK;
 }
 
+int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, float alpha, float beta, void* stream) {
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, nblk, out, F, alpha, beta);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
 extern "C" int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, int32_t F, float alpha, float beta,
                            float* out, float* scratch, int64_t scratch_floats, void* stream) {
   if (!a || !a->ptr || !out || !scratch || rows <= 0 || F <= 0) return AVSR_ERR_ARG;
@@ -436,10 +443,21 @@ extern "C" int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, i
   return AVSR_OK;
 }
 
+extern "C" int avsr_batchnorm_fwd_ex(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta,
+                                     float* moving_mean, float* moving_var, float* save_mean, float* save_invstd, int32_t training,
+                                     float eps, float momentum, int32_t relu, float* scratch, int64_t scratch_floats, void* stream);
+
 extern "C" int avsr_batchnorm_fwd(const float* x, float* y, int32_t rows, int32_t F, const float* gamma,
                                   const float* beta, float* moving_mean, float* moving_var, float* save_mean,
                                   float* save_invstd, int32_t training, float* scratch, int64_t scratch_floats,
                                   void* stream) {
+  return avsr_batchnorm_fwd_ex(x, y, rows, F, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, training, 1e-3f, 0.99f, 0,
+                               scratch, scratch_floats, stream);
+}
+
+extern "C" int avsr_batchnorm_fwd_ex(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta,
+                                     float* moving_mean, float* moving_var, float* save_mean, float* save_invstd, int32_t training,
+                                     float eps, float momentum, int32_t relu, float* scratch, int64_t scratch_floats, void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0 || F <= 0 || !scratch) return AVSR_ERR_ARG;
   if (F % 4) return AVSR_ERR_ARG;
   const int G = F < 256 ? 256 / F : 1;
@@ -463,7 +481,7 @@ extern "C" int avsr_batchnorm_fwd(const float* x, float* y, int32_t rows, int32_
     hipLaunchKernelGGL(bn_partial_sq_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, mean_v, part, rows, F, rpb);
     AVSR_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_var_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, nblk * G, mean_v, invstd_v, moving_mean,
-                       moving_var, rows, F, 1e-3f, 0.99f);
+                       moving_var, rows, F, eps, momentum);
     AVSR_CHECK_LAUNCH();
   } else if (!moving_mean || !moving_var) {
     return AVSR_ERR_ARG;
@@ -472,7 +490,7 @@ extern "C" int avsr_batchnorm_fwd(const float* x, float* y, int32_t rows, int32_
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, S_(stream), x, mean_v, invstd_v, moving_mean, moving_var, gamma, beta, y,
-                     n4, F, training, 1e-3f);
+                     n4, F, training, eps, relu);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

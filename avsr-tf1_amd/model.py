@@ -120,11 +120,14 @@ class Seq2SeqModel:
         self.Gr = {n: Ref(self.grads, o, self._eshape(n)) for n, o in self._train_off.items()}
         self.S = {n: Ref(self.stats, o, self.inv[n][0]) for n, o in self._stat_off.items()}
         self.l2_segments = [(self._train_off[n], int(np.prod(self.inv[n][0]))) for n in self._train_off if PR.is_l2(n)]
+        self.cnn_l2_segments = [(self._train_off[n], int(np.prod(self.inv[n][0]))) for n in self._train_off if PR.is_cnn_l2(n)]
+        self.use_cnn = cfg.video_units is not None and cfg.video_processing == "resnet_cnn"
         # ---- derived transposed operands -----------------------------------------------------------
         self._tjobs, self.Tr = [], {}
         tn = 0
         for name in self._train_off:
-            if name.endswith(("/kernel", "/query_kernel", "/layer_kernel", "/gates_kernel", "/cand_kernel")) and not name.startswith(("video/au", "audio/au")):
+            if name.endswith(("/kernel", "/query_kernel", "/layer_kernel", "/gates_kernel", "/cand_kernel")) and \
+                    not name.startswith(("video/au", "audio/au", "video/cnn/")):
                 if name.endswith("memory_kernel"):
                     continue
                 r, c = self._eshape(name)
@@ -206,6 +209,10 @@ class Seq2SeqModel:
             nplain = len(units) - 1 if attentive else len(units)
             E = {"T": T, "F": F, "units": units, "nplain": nplain, "attentive": attentive}
             E["xn"], E["dxn"], E["xhat"] = z(B * T, F), z(B * T, F), z(B * T, F)
+            if s == "video" and self.use_cnn:
+                from .cnn import LipCNN
+                E["cnn"] = LipCNN(self, B * T)                       # lip crops -> F = cnn_dense_units features
+                E["dfeat"] = z(B * T, F)
             if cfg.use_dropout:
                 E["xd"] = {d: z(B * T, F) for d in cfg.directions()}     # layer-0 input after each direction's input mask
                 E["dx_tmp"] = z(B * T, F)
@@ -367,6 +374,10 @@ class Seq2SeqModel:
             T, F = E["T"], E["F"]
             x = batch.video if s == "video" else batch.audio
             len_t = batch.video_len if s == "video" else batch.audio_len
+            if "cnn" in E:                                           # avsr/avsr.py:684-696: frames -> visual features
+                Hh, Ww, Cc = cfg.video_hw
+                assert x.shape == (B, T, Hh, Ww, Cc) and x.is_contiguous() and x.dtype == torch.float32
+                x = E["cnn"].forward(x.view(B * T, Hh, Ww, Cc), training).view(B, T, F)
             assert x.shape == (B, T, F) and x.is_contiguous() and x.dtype == torch.float32
             E["x"], E["len"] = x, len_t
             if cfg.batch_normalisation:
@@ -529,7 +540,7 @@ class Seq2SeqModel:
                         self._gemm_tn(ops.mat(Ld["rh"], u), dpc, Gc.mat(u, row0=i), u, u, B * T)
                         ops.colsum(dpc, B * T, u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/enc/{d}/l{l}/cand_bias"].off)
                     i = u
-                if E["nplain"] > 0 and cfg.batch_normalisation:
+                if E["nplain"] > 0 and (cfg.batch_normalisation or "cnn" in E):
                     u0, G = E["units"][0], self.G
                     W0 = self.P[self._kn(f"{s}/enc/{d}/l0")[0]]
                     L0 = E["layers"][(d, 0)]
@@ -549,6 +560,13 @@ class Seq2SeqModel:
                 ops.colsum(ops.mat(E["dxn"], F), B * T, F, self.grads, self.scratch, b=ops.mat(E["xhat"], F), beta=1.0,
                            out_offset=self.Gr[f"{s}/bn/gamma"].off)
                 ops.colsum(ops.mat(E["dxn"], F), B * T, F, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/bn/beta"].off)
+            if "cnn" in E:                       # gradient wrt the visual features, then through the CNN
+                if cfg.batch_normalisation:
+                    ops.batchnorm_bwd(E["x"], E["dxn"], self._pp(f"{s}/bn/gamma"), self._pp(f"{s}/bn/beta"), E["mean"], E["invstd"],
+                                      E["dfeat"], None, None, B * T, F, 0, self.scratch)
+                    E["cnn"].backward(E["dfeat"])
+                else:
+                    E["cnn"].backward(E["dxn"])
 
     def _ensure_gemm_ws(self):
         if self.gemm_ws is None:
@@ -907,6 +925,8 @@ class Seq2SeqModel:
         cfg = self.cfg
         if cfg.recurrent_l2 is not None:
             ops.l2_regularise(self.l2_segments, self.params, self.grads, cfg.recurrent_l2, self.loss, self.scratch)
+        if self.use_cnn:                         # conv2d kernel_regularizer l2(0.001), seq2seq.py:180-184
+            ops.l2_regularise(self.cnn_l2_segments, self.params, self.grads, 1e-3, self.loss, self.scratch)
         ops.global_norm(self.grads, self.n_train, self.gnorm, self.scratch)
         ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.n_train, self.gnorm, self.step,
                       cfg.learning_rate, cfg.warmup_steps, cfg.max_gradient_norm if cfg.clip_gradients else 0.0)

@@ -230,3 +230,35 @@ def rnn_set_persistent(on, device="cuda", ints=1 << 20, mode=3, scratch_floats=6
 def rnn_persistent_error():
     """Sticky flag: a device-side bounded wait of the persistent kernel expired (results of that call are invalid)."""
     return bool(_persist_sync is not None and int(_persist_sync[:1].item()) != 0)
+
+
+# ---- lip-crop CNN front-end helpers (csrc/conv.hip) -------------------------------------------------------------------
+def batchnorm_fwd_ex(x, y, rows, F, gamma, beta, mov_mean, mov_var, save_mean, save_invstd, training, eps, momentum, relu, scratch):
+    check(_L().avsr_batchnorm_fwd_ex(fptr(x), fptr(y), rows, F, fptr(gamma), fptr(beta), fptr(mov_mean), fptr(mov_var), fptr(save_mean),
+                                     fptr(save_invstd), int(training), float(eps), float(momentum), int(relu), fptr(scratch), scratch.numel(),
+                                     _s()), "avsr_batchnorm_fwd_ex")
+
+
+def batchnorm_bwd(x, dy, gamma, beta, mean, invstd, dx, dgamma, dbeta, rows, F, relu, scratch, dx_beta=0.0):
+    check(_L().avsr_batchnorm_bwd(fptr(x), fptr(dy), fptr(gamma), fptr(beta), fptr(mean), fptr(invstd), fptr(dx), fptr(dgamma), fptr(dbeta),
+                                  rows, F, int(relu), float(dx_beta), fptr(scratch), scratch.numel(), _s()), "avsr_batchnorm_bwd")
+
+
+def im2col(x, col, N, H, W, Cc, kh, kw, stride, pad_t, pad_l, Ho, Wo):
+    check(_L().avsr_im2col(fptr(x), fptr(col), N, H, W, Cc, kh, kw, stride, pad_t, pad_l, Ho, Wo, _s()), "avsr_im2col")
+
+
+def col2im(dcol, dx, N, H, W, Cc, kh, kw, stride, pad_t, pad_l, Ho, Wo, beta=0.0):
+    check(_L().avsr_col2im(fptr(dcol), fptr(dx), N, H, W, Cc, kh, kw, stride, pad_t, pad_l, Ho, Wo, float(beta), _s()), "avsr_col2im")
+
+
+def relu(x, y, n):
+    check(_L().avsr_relu(fptr(x), fptr(y), int(n), _s()), "avsr_relu")
+
+
+def relu_bwd(y, dy, dx, n):
+    check(_L().avsr_relu_bwd(fptr(y), fptr(dy), fptr(dx), int(n), _s()), "avsr_relu_bwd")
+
+
+def add(a, b, out, n):
+    check(_L().avsr_add(fptr(a), fptr(b), fptr(out), int(n), _s()), "avsr_add")

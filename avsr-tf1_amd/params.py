@@ -93,6 +93,11 @@ def inventory(cfg: ModelConfig):
         if stream == "video" and cfg.regress_aus:
             inv["video/au/kernel"] = ((cfg.memory_depth("video"), 2), "plain", "glorot")
             inv["video/au/bias"] = ((2,), "plain", "zeros")
+    if cfg.video_units is not None and cfg.video_processing == "resnet_cnn":
+        from .cnn import param_shapes
+        init_of = {"conv_kernel": "conv_vs", "bias": "zeros", "gamma": "ones", "beta": "zeros", "moving_mean": "zeros", "moving_variance": "ones"}
+        for name, shape, role in param_shapes(cfg.video_hw, cfg.cnn_filters, cfg.cnn_dense_units):
+            inv["video/cnn/" + name] = (shape, "plain", init_of[role])
     V, E = cfg.vocab_size, cfg.embedding_size
     inv["dec/embedding"] = ((V, E), "plain", "emb")
     mems = cfg.decoder_memories()
@@ -132,6 +137,11 @@ def _attention(inv, prefix, att_type, depth, units):
     inv[prefix + "/layer_kernel"] = ((units + depth, units), "plain", "glorot")
 
 
+def is_cnn_l2(name):
+    """conv2d kernel_regularizer l2(0.001) of the lip CNN (video.py:26; summed at seq2seq.py:180-184)."""
+    return name.startswith("video/cnn/") and name.endswith("/kernel")
+
+
 def is_l2(name):
     """seq2seq.py:283-290: variables whose name contains 'lstm_' and not 'bias' = the RNN cell kernels."""
     return name.endswith(("/kernel", "/gates_kernel", "/cand_kernel")) and \
@@ -146,6 +156,14 @@ def initialise(cfg: ModelConfig, seed=0):
     for name, (shape, _kind, init) in inventory(cfg).items():
         if init == "vs":
             std = math.sqrt(1.0 / shape[0]) / 0.87962566103423978
+            x = rng.standard_normal(shape)
+            bad = np.abs(x) > 2.0
+            while bad.any():
+                x[bad] = rng.standard_normal(int(bad.sum()))
+                bad = np.abs(x) > 2.0
+            a = x * std
+        elif init == "conv_vs":                 # variance_scaling(scale=2.0, fan_in) on [kh, kw, cin, cout] (video.py:24)
+            std = math.sqrt(2.0 / (shape[0] * shape[1] * shape[2])) / 0.87962566103423978
             x = rng.standard_normal(shape)
             bad = np.abs(x) > 2.0
             while bad.any():

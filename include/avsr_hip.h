@@ -320,6 +320,32 @@ int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, int32_t F, f
 int avsr_batchnorm_fwd(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta,
                        float* moving_mean, float* moving_var, float* save_mean, float* save_invstd, int32_t training,
                        float* scratch, int64_t scratch_floats, void* stream);
+/* As avsr_batchnorm_fwd with explicit epsilon / momentum and an optional fused ReLU: batch_norm_relu of the lip-crop CNN
+ * (avsr/video.py:4-14: epsilon 1e-5, momentum 0.98) and any tf.layers.batch_normalization(axis=-1) over [rows, F]. */
+int avsr_batchnorm_fwd_ex(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta,
+                          float* moving_mean, float* moving_var, float* save_mean, float* save_invstd, int32_t training,
+                          float eps, float momentum, int32_t relu, float* scratch, int64_t scratch_floats, void* stream);
+/* Gradient of batch normalisation with training statistics (tf.gradients through fused batch norm), optionally through
+ * the ReLU after it: dy' = dy * [gamma*xhat + beta > 0];  dbeta = sum dy';  dgamma = sum dy'*xhat;
+ * dx = gamma*invstd*(dy' - (sum dy' + xhat*sum dy'*xhat)/rows), written as dx = that + dx_beta*dx.  dx / dgamma / dbeta may
+ * be NULL.  scratch >= (rows/64 + 1) * max(1, 256/F) * 2F + 2F floats. */
+int avsr_batchnorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
+                       const float* invstd, float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t F, int32_t relu,
+                       float dx_beta, float* scratch, int64_t scratch_floats, void* stream);
+
+/* ---- lip-crop CNN front-end (avsr/video.py:143-195 resnet_cnn): convolutions are im2col + avsr_gemm ----
+ * im2col over NHWC maps with TF "SAME"/"VALID" geometry given explicitly: col[(n,ho,wo)][(i,j,c)] =
+ * x[n, ho*stride - pad_t + i, wo*stride - pad_l + j, c] (0 outside); the TF kernel [kh,kw,cin,cout] is the GEMM's
+ * [kh*kw*cin, cout] operand as stored.  col2im is its adjoint (gather form, deterministic): dx = col2im(dcol) + beta*dx. */
+int avsr_im2col(const float* x, float* col, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride,
+                int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, void* stream);
+int avsr_col2im(const float* dcol, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride,
+                int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, float beta, void* stream);
+/* y = max(x, 0);  dx = dy * [y > 0];  out = a + b (tf.nn.relu / residual tf.add of video.py) */
+int avsr_relu(const float* x, float* y, int64_t n, void* stream);
+int avsr_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
+int avsr_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+
 int avsr_batchnorm_xhat(const float* x, const float* mean, const float* invstd, float* xhat, int32_t rows, int32_t F,
                         void* stream);
 

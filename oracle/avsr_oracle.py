@@ -68,6 +68,12 @@ class OracleConfig:
     audio_dropout: Tuple[float, float, float] = (0.9, 0.9, 0.9)
     decoder_dropout: Tuple[float, float, float] = (0.9, 0.9, 0.9)
     sampling_probability: float = 0.0
+    # visual front-end (avsr.py:24, :33-34; video.py): "features" = the record already holds cnn_dense_units-d vectors,
+    # "resnet_cnn" = lip crops [B, T, H, W, C] through video.resnet_cnn
+    video_processing: str = "features"
+    cnn_filters: Tuple[int, ...] = (8, 16, 32, 64)
+    cnn_dense_units: int = 128
+    video_hw: Tuple[int, int, int] = (36, 36, 3)
 
     def streams(self) -> List[str]:
         s = []
@@ -178,6 +184,98 @@ def _attention_params(rng, prefix: str, att_type: str, depth: int, units: int, P
     P[prefix + "/layer_kernel"] = _glorot_uniform(rng, (units + depth, units))  # attention_layer, no bias
 
 
+def cnn_layout(cfg: OracleConfig):
+    """resnet_cnn (video.py:143-195) as a list of ops over NHWC maps; SAME padding as TF computes it
+    (total = max((ceil(in/s) - 1) * s + k - in, 0), the odd pixel goes to the bottom / right).
+    Returns (ops, out_hw) with ops = [(kind, name, dict)]."""
+    H, W, C = cfg.video_hw
+    f = cfg.cnn_filters
+    ops = [("conv", "layer0", dict(k=3, s=1, cin=C, cout=f[0], src="in", dst="a0")),
+           ("bnrelu", "layer0_bn", dict(c=f[0], src="a0", dst="b0")),
+           # res_block_0: skip_bn, identity shortcut
+           ("conv", "res_block_0_conv1", dict(k=3, s=1, cin=f[0], cout=f[0], src="b0", dst="r0a")),
+           ("bnrelu", "res_block_0_second_bn", dict(c=f[0], src="r0a", dst="r0b")),
+           ("conv", "res_block_0_conv2", dict(k=3, s=1, cin=f[0], cout=f[0], src="r0b", dst="r0c")),
+           ("add", "res_block_0", dict(a="r0c", b="b0", dst="x0"))]
+    prev, cin = "x0", f[0]
+    for i, c in enumerate(f[1:], start=1):
+        n = "res_block_%d" % i
+        ops += [("bnrelu", n + "_first_bn", dict(c=cin, src=prev, dst=n + "_p")),
+                ("conv", n + "_shortcut", dict(k=1, s=2, cin=cin, cout=c, src=prev, dst=n + "_s")),
+                ("conv", n + "_conv1", dict(k=3, s=2, cin=cin, cout=c, src=n + "_p", dst=n + "_a")),
+                ("bnrelu", n + "_second_bn", dict(c=c, src=n + "_a", dst=n + "_b")),
+                ("conv", n + "_conv2", dict(k=3, s=1, cin=c, cout=c, src=n + "_b", dst=n + "_c")),
+                ("add", n, dict(a=n + "_c", b=n + "_s", dst="x%d" % i))]
+        prev, cin = "x%d" % i, c
+        H, W = (H + 1) // 2, (W + 1) // 2
+    ops.append(("flatten", "flatten", dict(kh=H, kw=W, cin=cin, cout=cfg.cnn_dense_units, src=prev, dst="out")))
+    return ops, (H, W)
+
+
+def _conv_init(rng, shape):
+    """tf.variance_scaling_initializer(scale=2.0, mode='fan_in') on a [kh, kw, cin, cout] kernel (video.py:24)."""
+    fan_in = shape[0] * shape[1] * shape[2]
+    std = math.sqrt(2.0 / fan_in) / 0.87962566103423978
+    x = rng.standard_normal(size=shape)
+    bad = np.abs(x) > 2.0
+    while bad.any():
+        x[bad] = rng.standard_normal(size=int(bad.sum()))
+        bad = np.abs(x) > 2.0
+    return (x * std).astype(np.float32)
+
+
+def _cnn_params(rng, cfg: OracleConfig, P):
+    for kind, name, a in cnn_layout(cfg)[0]:
+        if kind == "conv":
+            P[f"video/cnn/{name}/kernel"] = _conv_init(rng, (a["k"], a["k"], a["cin"], a["cout"]))
+            P[f"video/cnn/{name}/bias"] = np.zeros((a["cout"],), np.float32)
+        elif kind == "flatten":
+            P[f"video/cnn/{name}/kernel"] = _conv_init(rng, (a["kh"], a["kw"], a["cin"], a["cout"]))
+            P[f"video/cnn/{name}/bias"] = np.zeros((a["cout"],), np.float32)
+        elif kind == "bnrelu":
+            P[f"video/cnn/{name}/gamma"] = np.ones((a["c"],), np.float32)
+            P[f"video/cnn/{name}/beta"] = np.zeros((a["c"],), np.float32)
+            P[f"video/cnn/{name}/moving_mean"] = np.zeros((a["c"],), np.float32)
+            P[f"video/cnn/{name}/moving_variance"] = np.ones((a["c"],), np.float32)
+
+
+def _same_pad(n, k, s):
+    out = (n + s - 1) // s
+    total = max((out - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
+
+
+def cnn_forward(P, cfg: OracleConfig, frames: Tensor, training: bool, updates: Optional[dict]) -> Tensor:
+    """video.resnet_cnn on [N, H, W, C] frames -> [N, cnn_dense_units] (video.py:143-195, cnn_layers :224-233).
+    Every frame goes through, zero padding frames included (the reference reshapes [B*T, H, W, C] without a mask)."""
+    F = torch.nn.functional
+    maps = {"in": frames.permute(0, 3, 1, 2)}                      # NCHW for torch
+    for kind, name, a in cnn_layout(cfg)[0]:
+        pre = f"video/cnn/{name}"
+        if kind == "conv":
+            x = maps[a["src"]]
+            pt, pb = _same_pad(x.shape[2], a["k"], a["s"])
+            pl, pr = _same_pad(x.shape[3], a["k"], a["s"])
+            w = P[pre + "/kernel"].permute(3, 2, 0, 1)             # HWIO -> OIHW
+            maps[a["dst"]] = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, P[pre + "/bias"], stride=a["s"])
+        elif kind == "bnrelu":
+            x = maps[a["src"]].permute(0, 2, 3, 1)                 # channels last for the statistics
+            y = batch_norm(x, P, pre, training, updates, eps=1e-5, momentum=0.98)
+            maps[a["dst"]] = torch.relu(y).permute(0, 3, 1, 2)
+        elif kind == "add":
+            maps[a["dst"]] = maps[a["a"]] + maps[a["b"]]
+        elif kind == "flatten":
+            x = maps[a["src"]]
+            w = P[pre + "/kernel"].permute(3, 2, 0, 1)
+            maps[a["dst"]] = torch.relu(F.conv2d(x, w, P[pre + "/bias"])).reshape(x.shape[0], -1)
+    return maps["out"]
+
+
+def cnn_l2_names(P) -> List[str]:
+    """conv2d kernel_regularizer l2(0.001) (video.py:26), summed into the loss at seq2seq.py:180-184."""
+    return [k for k in P if k.startswith("video/cnn/") and k.endswith("/kernel")]
+
+
 def init_params(cfg: OracleConfig, seed: int = 2001) -> Dict[str, np.ndarray]:
     """All trainable variables + BN moving stats, TF layout, reference initialisers."""
     cfg.validate()
@@ -227,6 +325,8 @@ def init_params(cfg: OracleConfig, seed: int = 2001) -> Dict[str, np.ndarray]:
     P["dec/out/bias"] = np.zeros((V,), np.float32)
     if cfg.architecture == "bimodal":
         P["dec/state_proj"] = _glorot_uniform(rng, (2 * dec_units, dec_units))  # decoder_bimodal.py:482
+    if cfg.video_units is not None and cfg.video_processing == "resnet_cnn":
+        _cnn_params(np.random.default_rng(seed + 77), cfg, P)     # own stream: the other tensors keep their values
     return P
 
 
@@ -275,9 +375,10 @@ def synthetic_batch(cfg: OracleConfig, B: int, T_a: int = 500, T_v: int = 75, L:
         b.audio_len = (r(2).integers(T_a // 2, T_a + 1, size=B) if ragged else np.full(B, T_a)).astype(np.int32)
         b.audio *= (np.arange(T_a)[None, :, None] < b.audio_len[:, None, None])   # padded_batch zero pads
     if cfg.video_units is not None:
-        b.video = r(3).standard_normal((B, T_v, cfg.video_feat)).astype(np.float32)
+        vshape = tuple(cfg.video_hw) if cfg.video_processing == "resnet_cnn" else (cfg.video_feat,)
+        b.video = r(3).standard_normal((B, T_v) + vshape).astype(np.float32)
         b.video_len = (r(4).integers((T_v + 1) // 2, T_v + 1, size=B) if ragged else np.full(B, T_v)).astype(np.int32)
-        b.video *= (np.arange(T_v)[None, :, None] < b.video_len[:, None, None])
+        b.video *= (np.arange(T_v)[None, :] < b.video_len[:, None]).reshape((B, T_v) + (1,) * len(vshape))
         b.aus = r(5).uniform(0.0, 3.0, size=(B, T_v, 2)).astype(np.float32)
     lab = r(6).integers(1, cfg.eos_id, size=(B, L)).astype(np.int32)
     ll = (r(7).integers(max(1, L // 2), L + 1, size=B) if ragged else np.full(B, L)).astype(np.int32)
@@ -454,10 +555,9 @@ def attention_wrapper_step(cell: _Cell, mechs: List[_Mechanism], output_attentio
 # ----------------------------------------------------------------------------------------
 # encoders
 # ----------------------------------------------------------------------------------------
-def batch_norm(x: Tensor, P, prefix: str, training: bool, updates: Optional[dict]):
-    """tf.layers.batch_normalization(axis=-1, fused=True), momentum .99 eps 1e-3 (encoder.py:44-50).
-    Statistics over B*T rows INCLUDING zero padding."""
-    eps = 1e-3
+def batch_norm(x: Tensor, P, prefix: str, training: bool, updates: Optional[dict], eps: float = 1e-3, momentum: float = 0.99):
+    """tf.layers.batch_normalization(axis=-1, fused=True), momentum .99 eps 1e-3 (encoder.py:44-50); the CNN front-end
+    uses momentum .98 eps 1e-5 (video.py:8-11).  Statistics over all rows INCLUDING zero padding."""
     if training:
         flat = x.reshape(-1, x.shape[-1])
         mean = flat.mean(dim=0)
@@ -465,8 +565,8 @@ def batch_norm(x: Tensor, P, prefix: str, training: bool, updates: Optional[dict
         if updates is not None:
             n = flat.shape[0]
             unbiased = var.detach() * (n / max(1, n - 1))       # fused kernel feeds Bessel-corrected var to the moving average
-            updates[prefix + "/moving_mean"] = 0.99 * P[prefix + "/moving_mean"] + 0.01 * mean.detach()
-            updates[prefix + "/moving_variance"] = 0.99 * P[prefix + "/moving_variance"] + 0.01 * unbiased
+            updates[prefix + "/moving_mean"] = momentum * P[prefix + "/moving_mean"] + (1 - momentum) * mean.detach()
+            updates[prefix + "/moving_variance"] = momentum * P[prefix + "/moving_variance"] + (1 - momentum) * unbiased
     else:
         mean, var = P[prefix + "/moving_mean"], P[prefix + "/moving_variance"]
     return (x - mean) * torch.rsqrt(var + eps) * P[prefix + "/gamma"] + P[prefix + "/beta"]
@@ -600,7 +700,11 @@ class _Model:
         self.aux_loss = None
         if cfg.video_units is not None:
             self.lens["video"] = ti(batch.video_len)
-            self.enc["video"] = encode_stream(P, cfg, "video", tt(batch.video), self.lens["video"],
+            vid = tt(batch.video)
+            if cfg.video_processing == "resnet_cnn":            # avsr.py:684-696: [B, T, H, W, C] -> [B, T, cnn_dense_units]
+                Bv, Tv = vid.shape[0], vid.shape[1]
+                vid = cnn_forward(P, cfg, vid.reshape((Bv * Tv,) + tuple(vid.shape[2:])), training, self.bn_updates).reshape(Bv, Tv, -1)
+            self.enc["video"] = encode_stream(P, cfg, "video", vid, self.lens["video"],
                                               training, self.bn_updates, seed=seed)
             if cfg.regress_aus and training:
                 self.aux_loss = au_loss(P, self.enc["video"], tt(batch.aus), self.lens["video"])
@@ -713,6 +817,9 @@ def loss_fn(P, cfg: OracleConfig, batch: Batch, logits: Tensor, m: _Model):
     if cfg.recurrent_l2 is not None:
         for k in l2_names(P, cfg):
             total = total + cfg.recurrent_l2 * 0.5 * torch.sum(P[k] ** 2)
+    if cfg.video_units is not None and cfg.video_processing == "resnet_cnn":
+        for k in cnn_l2_names(P):                                # seq2seq.py:180-184
+            total = total + 0.001 * 0.5 * torch.sum(P[k] ** 2)
     if cfg.regress_aus and m.aux_loss is not None:
         total = total + cfg.au_loss_weight * m.aux_loss
     return total, seq

@@ -34,6 +34,13 @@ CASES = {
                                   cell_type="gru", attention_type=(("bahdanau",), ("bahdanau",)), regress_aus=True),
     "gru_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
                          cell_type="gru", attention_type=(("scaled_luong",), ("normed_bahdanau",))),
+    # lip crops through video.resnet_cnn: [B, T, 36, 36, 3] frames, CNN BN in training mode, conv L2
+    "c3_video_cnn_bi": dict(architecture="unimodal", encoder_type="bidirectional", video_units=(32, 32), audio_units=None,
+                            attention_type=(("scaled_luong",), ("scaled_luong",)), regress_aus=True, video_processing="resnet_cnn",
+                            cnn_filters=(8, 8, 16, 16), cnn_dense_units=16, video_feat=16),
+    "c4_bimodal_cnn": dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
+                           attention_type=(("scaled_luong",), ("scaled_luong",)), regress_aus=True, video_processing="resnet_cnn",
+                           cnn_filters=(8, 16, 32, 64), cnn_dense_units=16, video_feat=16),
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
