@@ -6,8 +6,9 @@ try_restore_latest_checkpoint)` / `evaluate(checkpoint_path, epoch)` behaviour a
 (own .npz format: TF-layout weights + Adam slots + step; epoch parsed from the file name on resume, :233-249),
 `predictions/<name>/predicted_epoch_<N>.mlf`.  TensorFlow graphs/sessions/summaries do not exist here.
 
-Not built yet (raise explicitly): lip-CNN front-ends (`video_processing='resnet_cnn'|...`), `'wav'` audio
-(non-functional in the reference too), non-default cell types / losses / optimisers.
+`video_processing='resnet_cnn'` runs the lip crops through the HIP lip-CNN front-end (cnn.py; avsr/video.py:143-195).
+Not built (raise explicitly): the `2dconv_cnn` / `3dconv_cnn` front-ends, `'wav'` audio (non-functional in the
+reference too), non-default losses / optimisers.
 """
 import glob
 import os
@@ -98,8 +99,10 @@ class AVSR(object):
                 raise NotImplementedError("%s=%r is a non-default option of the reference that the HIP engine does not build" % (name, val))
         if tuple(input_dense_layers) != (0,) or label_smoothing != 0.0:
             raise NotImplementedError("input_dense_layers / label_smoothing are not built")
-        if video_processing is not None and video_processing != 'features':
-            raise NotImplementedError("video_processing=%r: the lip-CNN front-end is not built yet; feed 128-d features" % video_processing)
+        if video_processing is not None and video_processing not in ('features', 'resnet_cnn'):
+            if 'cnn' in video_processing:
+                raise NotImplementedError("video_processing=%r: only the default `resnet_cnn` front-end is built" % video_processing)
+            raise Exception('unknown visual content')                                             # avsr/avsr.py:713
         if audio_processing is not None and audio_processing != 'features':
             raise NotImplementedError("audio_processing=%r (the reference's 'wav' path is non-functional as well)" % audio_processing)
         if decoding_algorithm not in ('greedy', 'beam_search'):
@@ -107,13 +110,18 @@ class AVSR(object):
         self._decoding_algorithm, self._beam_width = decoding_algorithm, beam_width
 
         reverse = {v: k for k, v in self._unit_dict.items()}
-        feats = {}
+        feats, video_hw = {}, (36, 36, 3)
         for idx, (proc, key) in enumerate(((video_processing, 'video'), (audio_processing, 'audio'))):
             rec = self._records['train'][idx] or self._records['evaluate'][idx]
             if proc is not None:
                 shape, _ = _get_input_shape_from_record(rec)
+                if key == 'video' and proc == 'resnet_cnn':
+                    if len(shape) != 3:
+                        raise ValueError("video_processing='resnet_cnn' needs raw [width, height, channels] frames in the video record")
+                    video_hw, feats[key] = tuple(shape), cnn_dense_units
+                    continue
                 if len(shape) != 1:
-                    raise NotImplementedError("raw video records need the lip-CNN front-end")
+                    raise ValueError("raw video records need video_processing='resnet_cnn'")
                 feats[key] = shape[0]
         self._cfg = ModelConfig(
             architecture=architecture, encoder_type=encoder_type, cell_type=cell_type,
@@ -130,7 +138,9 @@ class AVSR(object):
             max_label_length={'viseme': 150, 'phoneme': 150, 'character': 150}[unit],
             use_dropout=use_dropout, video_dropout=tuple(video_encoder_dropout_probability),
             audio_dropout=tuple(audio_encoder_dropout_probability), decoder_dropout=tuple(decoder_dropout_probability),
-            sampling_probability=sampling_probability_outputs)
+            sampling_probability=sampling_probability_outputs,
+            video_processing=video_processing if video_processing is not None else 'features',
+            cnn_filters=tuple(cnn_filters), cnn_dense_units=cnn_dense_units, video_hw=video_hw)
         self._model = Seq2SeqModel(self._cfg, seed=kwargs.get('seed', 0))
         self._trainer = DataParallelTrainer(self._model, None, use_graph=False)   # bucketed batches: shapes vary per step
 

@@ -142,7 +142,8 @@ extern "C" int avsr_batchnorm_bwd(const float* x, const float* dy, const float* 
                                   float dx_beta, float* scratch, int64_t scratch_floats, void* stream) {
   if (!x || !dy || !gamma || !beta || !mean || !invstd || !scratch || rows <= 0 || F <= 0) return AVSR_ERR_ARG;
   const int G = F < 256 ? 256 / F : 1;
-  int rpb = 64;
+  const int maxblk = 4096 / G > 64 ? 4096 / G : 64;            // ~4096 partial rows at most
+  int rpb = rows > 64 * maxblk ? (rows + maxblk - 1) / maxblk : 64;
   int nblk = (rows + rpb - 1) / rpb;
   if ((long)nblk * G * 2 * F + 2 * F > scratch_floats) {
     nblk = (int)((scratch_floats - 2 * F) / ((long)G * 2 * F));

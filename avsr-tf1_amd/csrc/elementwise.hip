@@ -41,14 +41,17 @@ __device__ __forceinline__ long rowoff(int r, long ld, int T, long ldo) {
 
 __global__ void colsum_partial_kernel(const float* a, long lda, int Ta, long ldoa, const float* b, long ldb, int Tb,
                                       long ldob, float* part, int rows, int F, int rows_per_blk) {
+  // G = 256 / F row sub-groups of F columns when F < 256 (narrow matrices still use the whole block); partials per (block, sub-group)
+  const int G = F < 256 ? 256 / F : 1;
   const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+  for (int idx = threadIdx.x; idx < (G > 1 ? G * F : F); idx += blockDim.x) {
+    const int f = G > 1 ? idx % F : idx, g = G > 1 ? idx / F : 0;
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) {
+    for (int r = r0 + g; r < r1; r += G) {
       const float x = a[rowoff(r, lda, Ta, ldoa) + f];
       s += b ? x * b[rowoff(r, ldb, Tb, ldob) + f] : x;
     }
-    part[(long)blockIdx.x * F + f] = s;
+    part[((long)blockIdx.x * G + g) * F + f] = s;
   }
 }
 
@@ -426,19 +429,21 @@ int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, flo
 extern "C" int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, int32_t F, float alpha, float beta,
                            float* out, float* scratch, int64_t scratch_floats, void* stream) {
   if (!a || !a->ptr || !out || !scratch || rows <= 0 || F <= 0) return AVSR_ERR_ARG;
-  int rpb = 32;
+  const int G = F < 256 ? 256 / F : 1;
+  const int maxblk = G > 1 ? (4096 / G > 64 ? 4096 / G : 64) : 2048;   // ~4096 partial rows at most: the final pass stays one short launch
+  int rpb = rows > 32 * maxblk ? (rows + maxblk - 1) / maxblk : 32;
   int nblk = (rows + rpb - 1) / rpb;
-  if ((long)nblk * F > scratch_floats) {
-    nblk = (int)(scratch_floats / F);
+  if ((long)nblk * G * F > scratch_floats) {
+    nblk = (int)(scratch_floats / ((long)G * F));
     if (nblk < 1) return AVSR_ERR_ARG;
     rpb = (rows + nblk - 1) / nblk;
     nblk = (rows + rpb - 1) / rpb;
   }
-  const int th = F >= 256 ? 256 : ((F + 63) / 64) * 64;
+  const int th = 256;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(th), 0, S_(stream), a->ptr, (long)a->ld, a->T, (long)a->ldo,
                      b ? b->ptr : nullptr, b ? (long)b->ld : 0, b ? b->T : 0, b ? (long)b->ldo : 0, scratch, rows, F, rpb);
   AVSR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), scratch, nblk, out, F, alpha, beta);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), scratch, nblk * G, out, F, alpha, beta);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
@@ -461,7 +466,8 @@ extern "C" int avsr_batchnorm_fwd_ex(const float* x, float* y, int32_t rows, int
   if (!x || !y || !gamma || !beta || rows <= 0 || F <= 0 || !scratch) return AVSR_ERR_ARG;
   if (F % 4) return AVSR_ERR_ARG;
   const int G = F < 256 ? 256 / F : 1;
-  int rpb = 64;
+  const int maxblk = 4096 / G > 64 ? 4096 / G : 64;            // ~4096 partial rows at most
+  int rpb = rows > 64 * maxblk ? (rows + maxblk - 1) / maxblk : 64;
   int nblk = (rows + rpb - 1) / rpb;
   if ((long)nblk * G * F + 2 * F > scratch_floats) {
     nblk = (int)((scratch_floats - 2 * F) / ((long)G * F));

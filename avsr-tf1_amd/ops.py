@@ -45,6 +45,8 @@ def auto_splitk(M, N, K, batch=1):
     if tiles >= 128:
         return 1
     sk = min(768 // tiles, K // 64, 64)
+    if K > (1 << 19):            # convolution weight gradients: a handful of output tiles, K = N*Ho*Wo rows in the millions
+        sk = min(max(sk, K // 4096), 2048)
     return sk if sk >= 2 else 1
 
 

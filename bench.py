@@ -54,7 +54,8 @@ def synth(cfg, B, rank):
         d["audio"] = r(1).standard_normal((B, TA, FA)).astype(np.float32)
         d["audio_len"] = np.full(B, TA, np.int32)
     if cfg.video_units is not None:
-        d["video"] = r(3).standard_normal((B, TV, FV)).astype(np.float32)
+        vshape = tuple(cfg.video_hw) if cfg.video_processing == "resnet_cnn" else (FV,)
+        d["video"] = r(3).standard_normal((B, TV) + vshape).astype(np.float32)
         d["video_len"] = np.full(B, TV, np.int32)
         d["aus"] = r(5).uniform(0, 3, (B, TV, 2)).astype(np.float32)
     lab = r(6).integers(1, 29, (B, LDEC)).astype(np.int32)
@@ -104,7 +105,7 @@ def work_model(cfg, B):
     return dict(attn_bytes=attn_bytes, lstm_fwd_flops=fl_f / max(1, n_f), lstm_bwd_flops=fl_b / max(1, n_b))
 
 
-def cpu_baseline(wl, stoch, sample_B=8, steps=3):
+def cpu_baseline(wl, stoch, sample_B=8, steps=3, video_frontend="features"):
     """The CPU oracle (torch-CPU fp32 restatement, all host threads) on a bounded sample: sample_B utterances at
     full T_a/T_v/L.  'TF-1.13.1 CPU number unavailable' -- see BASELINE.md section 2."""
     from oracle import avsr_oracle as O
@@ -112,7 +113,7 @@ def cpu_baseline(wl, stoch, sample_B=8, steps=3):
     # synchronisation cost (256 hardware threads on the GPU node made a step take minutes), so cap it
     ncores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(ncores)
-    ocfg = O.OracleConfig(**wl["cfg"], **stoch)
+    ocfg = O.OracleConfig(video_processing=video_frontend, **wl["cfg"], **stoch)
     P = O.init_params(ocfg, seed=2001)
     b = O.synthetic_batch(ocfg, B=sample_B, T_a=TA, T_v=TV, L=LDEC)
     O.train_step(P, None, ocfg, b, dtype=torch.float32)          # warm-up
@@ -134,6 +135,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: the workload's B)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-dropout", action="store_true", help="disable DropoutWrapper + scheduled sampling (reference defaults are ON)")
+    ap.add_argument("--video-frontend", default="features", choices=["features", "resnet_cnn"],
+                    help="features: 128-d lip features in the batch (default); resnet_cnn: 36x36x3 lip crops through the CNN front-end")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -158,7 +161,7 @@ def main():
     wl = WORKLOADS[args.workload]
     B = args.batch or wl["B"]
     stoch = {} if args.no_dropout else dict(use_dropout=True, sampling_probability=0.1)   # avsr/avsr.py:51-56 defaults
-    cfg = ModelConfig(audio_feat=FA, video_feat=FV, **wl["cfg"], **stoch)
+    cfg = ModelConfig(audio_feat=FA, video_feat=FV, video_processing=args.video_frontend, **wl["cfg"], **stoch)
     model = Seq2SeqModel(cfg, seed=2001)
     trainer = DataParallelTrainer(model, dist, use_graph=not args.no_graph)
     batch = Batch.from_numpy(NS(synth(cfg, B, rank)))
@@ -191,7 +194,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload + ": " + wl["desc"], "utterances_per_gpu": B, "global_batch": B * world,
                    "T_a": TA, "F_a": FA, "T_v": TV, "F_v": FV, "T_dec": LDEC, "parallelism": "dp%d" % world,
-                   "launch": trainer.mode, "dropout": bool(cfg.use_dropout), "dropout_keep": list(cfg.decoder_dropout) if cfg.use_dropout else None,
+                   "video_frontend": (cfg.video_processing if cfg.video_units is not None else None), "launch": trainer.mode, "dropout": bool(cfg.use_dropout), "dropout_keep": list(cfg.decoder_dropout) if cfg.use_dropout else None,
                    "scheduled_sampling": cfg.sampling_probability,
                    "parity": "vs CPU restatement of TF-1.13.1 semantics; TF parity unpinned"},
         "final_loss": round(loss, 5),
@@ -255,7 +258,7 @@ def main():
         out["roofline_other"] = [roof(k) for k in kinds if k != dom and k != "step_dense"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(wl, stoch)
+            out["cpu_baseline"] = cpu_baseline(wl, stoch, video_frontend=args.video_frontend)
         except Exception as e:  # the oracle is optional test infrastructure
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:

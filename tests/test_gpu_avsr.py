@@ -66,3 +66,35 @@ def test_run_experiment_bimodal(tmp_path, monkeypatch):
                         decoding_algorithm="beam_search", beam_width=4)
     log = open("logs/exp_av").read()
     assert log.count("Average batch_loss") == 3 and "=====" in log
+
+
+def test_avsr_visual_only_from_lip_crops(tmp_path, monkeypatch):
+    """run_video.py-style experiment from raw frames: video_processing='resnet_cnn' (avsr/video.py:143-195)."""
+    import avsr_tf1_amd as avsr
+    from avsr_tf1_amd import io_utils as IO
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(1)
+    unit_file = os.path.join(str(tmp_path), "character_list")
+    open(unit_file, "w").write("\n".join(list("' abcdefghijklmnopqrstuvwxyz")) + "\n")
+    vrec, lrec = os.path.join(str(tmp_path), "video.tfrecord"), os.path.join(str(tmp_path), "labels.tfrecord")
+    with IO.TFRecordFileWriter(vrec) as fv, IO.TFRecordFileWriter(lrec) as fl:
+        for i in range(8):
+            L = int(rng.integers(2, 5))
+            lab = rng.integers(3, 10, size=L)
+            T = 3 * L + int(rng.integers(0, 3))
+            frames = rng.standard_normal((T, 36, 36, 3)).astype(np.float32) * 0.1
+            for j, c in enumerate(lab):
+                frames[3 * j:3 * j + 3, int(c) * 3:int(c) * 3 + 3, :, :] += 1.0        # label-dependent stripe
+            fv.write(IO.make_video_example("utt%02d" % i, frames))
+            fl.write(IO.make_label_example("utt%02d" % i, lab.tolist(), "character"))
+    exp = avsr.AVSR(unit="character", unit_file=unit_file, video_processing="resnet_cnn", video_train_record=vrec, video_test_record=vrec,
+                    labels_train_record=lrec, labels_test_record=lrec, batch_size=(4, 4), encoder_units_per_layer=((32,), (32,)),
+                    decoder_units_per_layer=(32,), embedding_size=16, decoding_algorithm="greedy", cnn_filters=(8, 8, 16, 16),
+                    cnn_dense_units=32, warmup_steps=0, learning_rate=0.01)
+    exp.train(logfile="logs/video", num_epochs=4)
+    log = open("logs/video").read()
+    losses = [float(l.split()[-1]) for l in log.splitlines() if l.startswith("Average")]
+    assert len(losses) == 3 and np.isfinite(losses).all() and losses[-1] < losses[0]
+    exp.save("checkpoints/video/checkpoint.ckp-3")
+    w = np.load("checkpoints/video/checkpoint.ckp-3.npz")
+    assert "params:video/cnn/flatten/kernel" in w.files and w["params:video/cnn/flatten/kernel"].shape == (5, 5, 16, 32)
