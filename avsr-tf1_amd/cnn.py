@@ -93,15 +93,19 @@ class LipCNN:
         self.ops, self.shapes = layout(cfg.video_hw, cfg.cnn_filters, cfg.cnn_dense_units)
         dev = model.dev
         z = lambda *s: torch.zeros(*s, device=dev)
-        self.maps, self.gmaps, self.col, self.bn = {}, {}, {}, {}
+        self.maps, self.gmaps, self.col, self.bn, self.direct = {}, {}, {}, {}, set()
         max_col = 4
         for op in self.ops:
             kind = op[0]
             if kind == "conv":
                 _, name, src, dst, k, s, cin, cout = op
                 ho, wo, _ = self.shapes[dst]
-                self.col[name] = z(N * ho * wo, k * k * cin)
-                max_col = max(max_col, self.col[name].numel())
+                h, w, _ = self.shapes[src]
+                if k == 3 and ops.conv3x3_supported(cin, cout, h, w):   # shallow wide layers: direct kernels, no im2col operand
+                    self.direct.add(name)
+                else:
+                    self.col[name] = z(N * ho * wo, k * k * cin)
+                    max_col = max(max_col, self.col[name].numel())
             elif kind == "bnrelu":
                 c = op[4]
                 self.bn[op[1]] = (z(c), z(c))                      # batch mean, inverse std (training statistics)
@@ -138,6 +142,10 @@ class LipCNN:
                 h, w, _ = self.shapes[src]
                 ho, pt = same_pad(h, k, s)
                 wo, pl = same_pad(w, k, s)
+                if name in self.direct:
+                    kw_ = self._p(name + "/kernel")
+                    ops.conv3x3(self.maps[src], kw_.t[kw_.off:], self._pv(name + "/bias"), self.maps[dst], N, h, w, cin, cout, s, pt, pl, ho, wo)
+                    continue
                 col = self.col[name]
                 ops.im2col(self.maps[src], col, N, h, w, cin, k, k, s, pt, pl, ho, wo)
                 rows, K = N * ho * wo, k * k * cin
@@ -209,6 +217,17 @@ class LipCNN:
                 wo, pl = same_pad(w, k, s)
                 rows, K = N * ho * wo, k * k * cin
                 dy = ops.mat(self.gmaps[dst], cout)
+                if name in self.direct:
+                    gk, kw_ = self._g(name + "/kernel"), self._p(name + "/kernel")
+                    ops.conv3x3_bwd_weight(self.maps[src], self.gmaps[dst], gk.t[gk.off:], N, h, w, cin, cout, s, pt, pl, ho, wo, m.scratch)
+                    ops.colsum(dy, rows, cout, m.grads, m.scratch, beta=1.0, out_offset=self._g(name + "/bias").off)
+                    if src != "in":
+                        g, beta = target(src)
+                        if s == 1:       # the same kernel on dy with the kernel flipped and transposed
+                            ops.conv3x3(self.gmaps[dst], kw_.t[kw_.off:], None, g, N, ho, wo, cout, cin, 1, 1, 1, h, w, flip=1, beta=beta)
+                        else:
+                            ops.conv3x3_bwd_data_s2(self.gmaps[dst], kw_.t[kw_.off:], g, N, h, w, cin, cout, pt, pl, ho, wo, beta=beta)
+                    continue
                 m._gemm_tn(ops.mat(self.col[name], K), dy, self._g(name + "/kernel").mat(cout), K, cout, rows)
                 ops.colsum(dy, rows, cout, m.grads, m.scratch, beta=1.0, out_offset=self._g(name + "/bias").off)
                 if src != "in":                                                # pixels are data: no gradient needed

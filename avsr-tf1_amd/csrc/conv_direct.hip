@@ -1,0 +1,241 @@
+// Direct 3x3 convolutions for the wide, shallow layers of the lip-crop CNN (video.resnet_cnn, avsr/video.py:143-195):
+// 36x36 and 18x18 maps with 3..16 channels.  As GEMMs these layers are [N*H*W, 9*cin] x [9*cin, cout<=16]: a 128x128 MFMA
+// tile is >87 % padding and the im2col operand is 9x the map (1.8 GB per layer at 4800 frames), so here they run on
+// the fp32 VALU instead (same 157 TF/s peak as the f32-input MFMA on gfx950), straight from the NHWC maps:
+//   forward / stride-1 data gradient : one thread per output pixel, all taps x input channels, weights broadcast from LDS
+//                                      (the data gradient is the same kernel on dy with the kernel flipped and transposed)
+//   stride-2 data gradient           : one thread per INPUT pixel, gather over the taps whose parity matches
+//   weight gradient                  : one block per group of frames; x (with a zero halo) and dy staged in LDS, one thread
+//                                      per (tap, cin, cout) element walking the pixels; per-block partials are summed in block
+//                                      order by the column-sum finaliser (deterministic)
+// Layers with more channels (32, 64: 9x9 and 5x5 maps, few rows) stay on im2col + avsr_gemm (conv.hip).
+#include "common.h"
+#include "avsr_hip.h"
+
+namespace avsr {
+
+// y[n,ho,wo,co] = bias[co] + sum_{i,j,ci} x[n, ho*s - pt + i, wo*s - pl + j, ci] * wk(i,j,ci,co)  (+ beta * y)
+// flip = 0: wk = w[((i*3+j)*Ci + ci)*Co + co]                      (TF kernel [3,3,Ci,Co])
+// flip = 1: wk = w[(((2-i)*3+(2-j))*Co + co)*Ci + ci]              (data gradient: w is the forward kernel [3,3,Co,Ci])
+template <int COT>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                      float* __restrict__ y, int N, int H, int W, int Ci, int Co, int s, int pt, int pl,
+                                                      int Ho, int Wo, int flip, float beta) {
+  extern __shared__ float ws[];                        // [9][Ci][Co]
+  const int nw = 9 * Ci * Co;
+  for (int idx = threadIdx.x; idx < nw; idx += 256) {
+    const int co = idx % Co, ci = (idx / Co) % Ci, t = idx / (Co * Ci);
+    ws[idx] = flip ? w[((8 - t) * Co + co) * Ci + ci] : w[idx];
+  }
+  __syncthreads();
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= (long)N * Ho * Wo) return;
+  const int co0 = blockIdx.y * COT;
+  const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), n = (int)(pix / ((long)Wo * Ho));
+  float acc[COT];
+#pragma unroll
+  for (int c = 0; c < COT; ++c) acc[c] = 0.f;
+  for (int i = 0; i < 3; ++i) {
+    const int h = ho * s - pt + i;
+    if (h < 0 || h >= H) continue;
+    for (int j = 0; j < 3; ++j) {
+      const int ww = wo * s - pl + j;
+      if (ww < 0 || ww >= W) continue;
+      const float* xp = x + (((long)n * H + h) * W + ww) * Ci;
+      const float* wp = ws + (i * 3 + j) * Ci * Co + co0;
+      if (Ci % 4 == 0) {
+        for (int ci = 0; ci < Ci; ci += 4) {
+          const f32x4 xv = ld4(xp + ci);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float* wr = wp + (ci + e) * Co;
+#pragma unroll
+            for (int c = 0; c < COT; c += 4) {
+              const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
+              acc[c] += xv[e] * wv[0]; acc[c + 1] += xv[e] * wv[1]; acc[c + 2] += xv[e] * wv[2]; acc[c + 3] += xv[e] * wv[3];
+            }
+          }
+        }
+      } else {
+        for (int ci = 0; ci < Ci; ++ci) {
+          const float xv = xp[ci];
+          const float* wr = wp + ci * Co;
+#pragma unroll
+          for (int c = 0; c < COT; c += 4) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
+            acc[c] += xv * wv[0]; acc[c + 1] += xv * wv[1]; acc[c + 2] += xv * wv[2]; acc[c + 3] += xv * wv[3];
+          }
+        }
+      }
+    }
+  }
+  float* yp = y + pix * Co + co0;
+#pragma unroll
+  for (int c = 0; c < COT; c += 4) {
+    f32x4 v = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+    if (bias) v += ld4(bias + co0 + c);
+    if (beta != 0.f) v += beta * ld4(yp + c);
+    st4(yp + c, v);
+  }
+}
+
+// stride-2 data gradient: dx[n,h,w,ci] = sum over taps (i,j) with (h + pt - i), (w + pl - j) even and in range, over co, of
+// dy[n, (h+pt-i)/2, (w+pl-j)/2, co] * w[i,j,ci,co]      (+ beta * dx)
+template <int CIT>
+__global__ __launch_bounds__(256) void conv3x3_bwd_data_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                                  int N, int H, int W, int Ci, int Co, int pt, int pl, int Ho, int Wo,
+                                                                  float beta) {
+  extern __shared__ float ws[];                        // [9][Ci][Co] as stored
+  const int nw = 9 * Ci * Co;
+  for (int idx = threadIdx.x; idx < nw; idx += 256) ws[idx] = w[idx];
+  __syncthreads();
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= (long)N * H * W) return;
+  const int ci0 = blockIdx.y * CIT;
+  const int ww = (int)(pix % W), h = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+  float acc[CIT];
+#pragma unroll
+  for (int c = 0; c < CIT; ++c) acc[c] = 0.f;
+  for (int i = 0; i < 3; ++i) {
+    const int hn = h + pt - i;
+    if (hn < 0 || (hn & 1) || (hn >> 1) >= Ho) continue;
+    for (int j = 0; j < 3; ++j) {
+      const int wn = ww + pl - j;
+      if (wn < 0 || (wn & 1) || (wn >> 1) >= Wo) continue;
+      const float* dp = dy + (((long)n * Ho + (hn >> 1)) * Wo + (wn >> 1)) * Co;
+      const float* wp = ws + ((i * 3 + j) * Ci + ci0) * Co;
+      for (int co = 0; co < Co; co += 4) {
+        const f32x4 dv = ld4(dp + co);
+#pragma unroll
+        for (int c = 0; c < CIT; ++c) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + c * Co + co);
+          acc[c] += dv[0] * wv[0] + dv[1] * wv[1] + dv[2] * wv[2] + dv[3] * wv[3];
+        }
+      }
+    }
+  }
+  float* xp = dx + pix * Ci + ci0;
+#pragma unroll
+  for (int c = 0; c < CIT; c += 4) {
+    f32x4 v = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
+    if (beta != 0.f) v += beta * ld4(xp + c);
+    st4(xp + c, v);
+  }
+}
+
+// weight gradient partials: part[blk][(i*3+j)*Ci*Co + ci*Co + co] = sum over the block's frames and pixels of
+// x[n, ho*s - pt + i, wo*s - pl + j, ci] * dy[n, ho, wo, co]
+__global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                                 int N, int H, int W, int Ci, int Co, int s, int pt, int pl, int Ho, int Wo,
+                                                                 int frames_per_blk) {
+  extern __shared__ float sm[];
+  const int Hp = H + 2, Wp = W + 2;                    // zero halo of one pixel on every side covers pt, pl in {0, 1}
+  float* xs = sm;                                       // [Hp][Wp][Ci]
+  float* ds = sm + Hp * Wp * Ci;                        // [Ho][Wo][Co]
+  const int nout = 9 * Ci * Co;
+  constexpr int MAXO = 9;                               // outputs per thread: 9*16*16 / 256
+  float acc[MAXO];
+#pragma unroll
+  for (int k = 0; k < MAXO; ++k) acc[k] = 0.f;
+  const int n0 = blockIdx.x * frames_per_blk, n1 = min(N, n0 + frames_per_blk);
+  for (int n = n0; n < n1; ++n) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < Hp * Wp * Ci; idx += 256) {
+      const int c = idx % Ci, wq = (idx / Ci) % Wp, hq = idx / (Ci * Wp);
+      const int h = hq - 1, ww = wq - 1;
+      xs[idx] = (h >= 0 && h < H && ww >= 0 && ww < W) ? x[(((long)n * H + h) * W + ww) * Ci + c] : 0.f;
+    }
+    for (int idx = threadIdx.x; idx < Ho * Wo * Co; idx += 256) ds[idx] = dy[(long)n * Ho * Wo * Co + idx];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXO; ++k) {
+      const int o = threadIdx.x + k * 256;
+      if (o >= nout) break;
+      const int co = o % Co, ci = (o / Co) % Ci, t = o / (Co * Ci);
+      const int i = t / 3, j = t % 3;
+      float a = 0.f;
+      for (int ho = 0; ho < Ho; ++ho) {
+        const float* xr = xs + ((ho * s - pt + i + 1) * Wp + (1 - pl + j)) * Ci + ci;
+        const float* dr = ds + ho * Wo * Co + co;
+        for (int wo = 0; wo < Wo; ++wo) a += xr[wo * s * Ci] * dr[wo * Co];
+      }
+      acc[k] += a;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXO; ++k) {
+    const int o = threadIdx.x + k * 256;
+    if (o < nout) part[(long)blockIdx.x * nout + o] = acc[k];
+  }
+}
+
+}  // namespace avsr
+
+int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, float alpha, float beta, void* stream);
+
+using namespace avsr;
+#define S_(x) ((hipStream_t)(x))
+
+static bool direct_ok(int Ci, int Co) { return Ci * Co <= 256 && Co % 4 == 0 && (Ci % 4 == 0 || Ci < 4); }
+
+extern "C" int avsr_conv3x3_supported(int32_t Ci, int32_t Co, int32_t H, int32_t W) {
+  return direct_ok(Ci, Co) && (long)((H + 2) * (W + 2) * Ci + H * W * Co) * 4 <= 150 * 1024;
+}
+
+// flip = 0: forward conv (x [N,H,W,Ci] -> y [N,Ho,Wo,Co], w = TF kernel [3,3,Ci,Co], bias may be NULL).
+// flip = 1: stride-1 data gradient (x = dy [N,H,W,Ci=cout], y = dx [N,H,W,Co=cin], w = the forward kernel [3,3,Co,Ci]).
+extern "C" int avsr_conv3x3(const float* x, const float* w, const float* bias, float* y, int32_t N, int32_t H, int32_t W, int32_t Ci,
+                            int32_t Co, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, int32_t flip, float beta,
+                            void* stream) {
+  if (!x || !w || !y || N <= 0 || !direct_ok(flip ? Co : Ci, flip ? Ci : Co) || Co % 4 || (flip && stride != 1)) return AVSR_ERR_ARG;
+  const long pix = (long)N * Ho * Wo;
+  const size_t lds = sizeof(float) * 9 * Ci * Co;
+  if (Co % 16 == 0) hipLaunchKernelGGL((conv3x3_kernel<16>), dim3((unsigned)((pix + 255) / 256), Co / 16), dim3(256), lds, S_(stream), x, w, bias, y, N, H,
+                                       W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, flip, beta);
+  else if (Co % 8 == 0) hipLaunchKernelGGL((conv3x3_kernel<8>), dim3((unsigned)((pix + 255) / 256), Co / 8), dim3(256), lds, S_(stream), x, w, bias, y, N, H,
+                                           W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, flip, beta);
+  else hipLaunchKernelGGL((conv3x3_kernel<4>), dim3((unsigned)((pix + 255) / 256), Co / 4), dim3(256), lds, S_(stream), x, w, bias, y, N, H, W, Ci, Co,
+                          stride, pad_t, pad_l, Ho, Wo, flip, beta);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_conv3x3_bwd_data_s2(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                                        int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, float beta, void* stream) {
+  if (!dy || !w || !dx || N <= 0 || !direct_ok(Ci, Co) || Ci % 4) return AVSR_ERR_ARG;
+  const long pix = (long)N * H * W;
+  const size_t lds = sizeof(float) * 9 * Ci * Co;
+  if (Ci % 8 == 0) hipLaunchKernelGGL((conv3x3_bwd_data_s2_kernel<8>), dim3((unsigned)((pix + 255) / 256), Ci / 8), dim3(256), lds, S_(stream), dy, w, dx, N,
+                                      H, W, Ci, Co, pad_t, pad_l, Ho, Wo, beta);
+  else hipLaunchKernelGGL((conv3x3_bwd_data_s2_kernel<4>), dim3((unsigned)((pix + 255) / 256), Ci / 4), dim3(256), lds, S_(stream), dy, w, dx, N, H, W, Ci,
+                          Co, pad_t, pad_l, Ho, Wo, beta);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+// dw (+)= weight gradient [3,3,Ci,Co] (TF layout).  scratch >= ceil(N / frames_per_block) * 9*Ci*Co floats (frames_per_block = 4).
+extern "C" int avsr_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                                       int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, float beta, float* scratch,
+                                       int64_t scratch_floats, void* stream) {
+  if (!x || !dy || !dw || !scratch || N <= 0 || !avsr_conv3x3_supported(Ci, Co, H, W) || pad_t > 1 || pad_l > 1) return AVSR_ERR_ARG;
+  const int nout = 9 * Ci * Co;
+  int fpb = 4;
+  int nblk = (N + fpb - 1) / fpb;
+  if ((long)nblk * nout > scratch_floats) {
+    nblk = (int)(scratch_floats / nout);
+    if (nblk < 1) return AVSR_ERR_ARG;
+    fpb = (N + nblk - 1) / nblk;
+    nblk = (N + fpb - 1) / fpb;
+  }
+  const size_t lds = sizeof(float) * ((size_t)(H + 2) * (W + 2) * Ci + (size_t)Ho * Wo * Co);
+  static bool big_lds = false;                          // more than 64 KB of dynamic LDS needs the attribute (set once, outside any capture)
+  if (!big_lds) {
+    if (hipFuncSetAttribute((const void*)conv3x3_bwd_weight_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return AVSR_ERR_HIP;
+    big_lds = true;
+  }
+  hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(nblk), dim3(256), lds, S_(stream), x, dy, scratch, N, H, W, Ci, Co, stride, pad_t, pad_l, Ho,
+                     Wo, fpb);
+  AVSR_CHECK_LAUNCH();
+  return avsr_colsum_final_launch(scratch, nblk, dw, nout, 1.0f, beta, stream);
+}

@@ -264,3 +264,22 @@ def relu_bwd(y, dy, dx, n):
 
 def add(a, b, out, n):
     check(_L().avsr_add(fptr(a), fptr(b), fptr(out), int(n), _s()), "avsr_add")
+
+
+def conv3x3_supported(Ci, Co, H, W):
+    return bool(_L().avsr_conv3x3_supported(Ci, Co, H, W))
+
+
+def conv3x3(x, w, bias, y, N, H, W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, flip=0, beta=0.0):
+    check(_L().avsr_conv3x3(fptr(x), fptr(w), fptr(bias), fptr(y), N, H, W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, int(flip), float(beta), _s()),
+          "avsr_conv3x3")
+
+
+def conv3x3_bwd_data_s2(dy, w, dx, N, H, W, Ci, Co, pad_t, pad_l, Ho, Wo, beta=0.0):
+    check(_L().avsr_conv3x3_bwd_data_s2(fptr(dy), fptr(w), fptr(dx), N, H, W, Ci, Co, pad_t, pad_l, Ho, Wo, float(beta), _s()),
+          "avsr_conv3x3_bwd_data_s2")
+
+
+def conv3x3_bwd_weight(x, dy, dw, N, H, W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, scratch, beta=1.0):
+    check(_L().avsr_conv3x3_bwd_weight(fptr(x), fptr(dy), fptr(dw), N, H, W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, float(beta), fptr(scratch),
+                                       scratch.numel(), _s()), "avsr_conv3x3_bwd_weight")

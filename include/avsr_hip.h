@@ -341,6 +341,20 @@ int avsr_im2col(const float* x, float* col, int32_t N, int32_t H, int32_t W, int
                 int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, void* stream);
 int avsr_col2im(const float* dcol, float* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t kh, int32_t kw, int32_t stride,
                 int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, float beta, void* stream);
+/* Direct 3x3 convolutions on NHWC maps for the shallow layers of the lip CNN (cin*cout <= 256; avsr_conv3x3_supported):
+ * the same tf.layers.conv2d(3x3, SAME) and its gradients as the im2col + avsr_gemm route, without the 9x operand.
+ *   avsr_conv3x3(flip=0): y = conv(x, w[3,3,Ci,Co]) + bias (+ beta*y).
+ *   avsr_conv3x3(flip=1): stride-1 data gradient: x = dy [.,Ci = cout], y = dx [.,Co = cin], w = the FORWARD kernel [3,3,Co,Ci].
+ *   avsr_conv3x3_bwd_data_s2: data gradient of a stride-2 conv (dx [N,H,W,Ci] from dy [N,Ho,Wo,Co]).
+ *   avsr_conv3x3_bwd_weight: dw[3,3,Ci,Co] = beta*dw + sum x (x) dy; scratch >= ceil(N/4) * 9*Ci*Co floats. */
+int avsr_conv3x3_supported(int32_t Ci, int32_t Co, int32_t H, int32_t W);
+int avsr_conv3x3(const float* x, const float* w, const float* bias, float* y, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                 int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, int32_t flip, float beta, void* stream);
+int avsr_conv3x3_bwd_data_s2(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                             int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, float beta, void* stream);
+int avsr_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                            int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, float beta, float* scratch,
+                            int64_t scratch_floats, void* stream);
 /* y = max(x, 0);  dx = dy * [y > 0];  out = a + b (tf.nn.relu / residual tf.add of video.py) */
 int avsr_relu(const float* x, float* y, int64_t n, void* stream);
 int avsr_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
