@@ -60,22 +60,34 @@ __global__ void col2im_kernel(const float* dcol, float* dx, int N, int H, int W,
 // dx = gamma * invstd * (dy' - (sum dy' + xhat * sum dy' xhat) / rows)
 __global__ void bn_bwd_partial_kernel(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
                                       const float* invstd, float* part, int rows, int F, int rows_per_blk, int relu) {
+  __shared__ float red[512];
   const int G = F < 256 ? 256 / F : 1;
   const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-  for (int idx = threadIdx.x; idx < G * F; idx += blockDim.x) {
-    const int f = idx % F, g = idx / F;
-    const float m = mean[f], is = invstd[f], ga = gamma[f], be = beta[f];
+  float* prow = part + (long)blockIdx.x * 2 * F;
+  for (int base = 0; base < (G > 1 ? 1 : F); base += blockDim.x) {      // G > 1: a single pass (G*F <= 256)
+    const int idx = base + threadIdx.x;
+    const bool on = G > 1 ? idx < G * F : idx < F;
+    const int f = G > 1 ? idx % F : idx, g = G > 1 ? idx / F : 0;
     float s1 = 0.f, s2 = 0.f;
-    for (int r = r0 + g; r < r1; r += G) {
-      const float xh = (x[(long)r * F + f] - m) * is;
-      float d = dy[(long)r * F + f];
-      if (relu && !(xh * ga + be > 0.f)) d = 0.f;
-      s1 += d;
-      s2 += d * xh;
+    if (on) {
+      const float m = mean[f], is = invstd[f], ga = gamma[f], be = beta[f];
+      for (int r = r0 + g; r < r1; r += G) {
+        const float xh = (x[(long)r * F + f] - m) * is;
+        float d = dy[(long)r * F + f];
+        if (relu && !(xh * ga + be > 0.f)) d = 0.f;
+        s1 += d;
+        s2 += d * xh;
+      }
     }
-    float* p = part + ((long)blockIdx.x * G + g) * 2 * F;
-    p[f] = s1;
-    p[F + f] = s2;
+    if (G > 1) {                                     // sub-groups combined through LDS in group order: one partial row per block
+      if (on) { red[idx] = s1; red[256 + idx] = s2; }
+      __syncthreads();
+      if (idx < F) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int gg = 0; gg < G; ++gg) { t1 += red[gg * F + idx]; t2 += red[256 + gg * F + idx]; }
+        prow[idx] = t1; prow[F + idx] = t2;
+      }
+    } else if (on) { prow[f] = s1; prow[F + f] = s2; }
   }
 }
 
@@ -141,21 +153,20 @@ extern "C" int avsr_batchnorm_bwd(const float* x, const float* dy, const float* 
                                   const float* invstd, float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t F, int32_t relu,
                                   float dx_beta, float* scratch, int64_t scratch_floats, void* stream) {
   if (!x || !dy || !gamma || !beta || !mean || !invstd || !scratch || rows <= 0 || F <= 0) return AVSR_ERR_ARG;
-  const int G = F < 256 ? 256 / F : 1;
-  const int maxblk = 4096 / G > 64 ? 4096 / G : 64;            // ~4096 partial rows at most
+  const int maxblk = 2048;
   int rpb = rows > 64 * maxblk ? (rows + maxblk - 1) / maxblk : 64;
   int nblk = (rows + rpb - 1) / rpb;
-  if ((long)nblk * G * 2 * F + 2 * F > scratch_floats) {
-    nblk = (int)((scratch_floats - 2 * F) / ((long)G * 2 * F));
+  if ((long)nblk * 2 * F + 2 * F > scratch_floats) {
+    nblk = (int)((scratch_floats - 2 * F) / (2L * F));
     if (nblk < 1) return AVSR_ERR_ARG;
     rpb = (rows + nblk - 1) / nblk;
     nblk = (rows + rpb - 1) / rpb;
   }
   float* part = scratch;
-  float* sums = scratch + (long)nblk * G * 2 * F;      // [2F]: sum dy' | sum dy' xhat
+  float* sums = scratch + (long)nblk * 2 * F;          // [2F]: sum dy' | sum dy' xhat
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, part, rows, F, rpb, relu);
   AVSR_CHECK_LAUNCH();
-  { const int rc = avsr_colsum_final_launch(part, nblk * G, sums, 2 * F, 1.0f, 0.0f, stream); if (rc) return rc; }
+  { const int rc = avsr_colsum_final_launch(part, nblk, sums, 2 * F, 1.0f, 0.0f, stream); if (rc) return rc; }
   if (dx) {
     const long n = (long)rows * F;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for_n(n)), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, sums, dx, n, rows,

@@ -123,49 +123,56 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_data_s2_kernel(const float* _
   }
 }
 
-// weight gradient partials: part[blk][(i*3+j)*Ci*Co + ci*Co + co] = sum over the block's frames and pixels of
+// weight gradient partials.  Thread = one (tap, cin) pair of one row group g (G = 256 / (9*Ci) groups share the frame's rows);
+// it keeps the Co accumulators of that pair in registers: per pixel ONE x read and Co/4 broadcast 16-byte dy reads feed Co FMAs.
+// part[(blk*G + g)][(i*3+j)*Ci*Co + ci*Co + co] = sum over the block's frames and the group's pixels of
 // x[n, ho*s - pt + i, wo*s - pl + j, ci] * dy[n, ho, wo, co]
+template <int CO>
 __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
-                                                                 int N, int H, int W, int Ci, int Co, int s, int pt, int pl, int Ho, int Wo,
+                                                                 int N, int H, int W, int Ci, int s, int pt, int pl, int Ho, int Wo,
                                                                  int frames_per_blk) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Hp = H + 2, Wp = W + 2;                    // zero halo of one pixel on every side covers pt, pl in {0, 1}
-  float* xs = sm;                                       // [Hp][Wp][Ci]
-  float* ds = sm + Hp * Wp * Ci;                        // [Ho][Wo][Co]
-  const int nout = 9 * Ci * Co;
-  constexpr int MAXO = 9;                               // outputs per thread: 9*16*16 / 256
-  float acc[MAXO];
+  float* ds = sm;                                       // [Ho][Wo][CO]   (first: 16-byte aligned rows)
+  float* xs = sm + ((Ho * Wo * CO + 3) & ~3);           // [Hp][Wp][Ci]
+  const int npair = 9 * Ci, G = 256 / npair;
+  const int g = threadIdx.x / npair, pr = threadIdx.x % npair;
+  const bool active = g < G;
+  const int ci = pr % Ci, t = pr / Ci, i = t / 3, j = t % 3;
+  float acc[CO];
 #pragma unroll
-  for (int k = 0; k < MAXO; ++k) acc[k] = 0.f;
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
   const int n0 = blockIdx.x * frames_per_blk, n1 = min(N, n0 + frames_per_blk);
+  const int nx = Hp * Wp * Ci, nd = Ho * Wo * CO;
   for (int n = n0; n < n1; ++n) {
     __syncthreads();
-    for (int idx = threadIdx.x; idx < Hp * Wp * Ci; idx += 256) {
+    for (int idx = threadIdx.x; idx < nx; idx += 256) {
       const int c = idx % Ci, wq = (idx / Ci) % Wp, hq = idx / (Ci * Wp);
       const int h = hq - 1, ww = wq - 1;
       xs[idx] = (h >= 0 && h < H && ww >= 0 && ww < W) ? x[(((long)n * H + h) * W + ww) * Ci + c] : 0.f;
     }
-    for (int idx = threadIdx.x; idx < Ho * Wo * Co; idx += 256) ds[idx] = dy[(long)n * Ho * Wo * Co + idx];
+    const float* dn = dy + (long)n * nd;
+    for (int idx = threadIdx.x * 4; idx < nd; idx += 1024) st4(ds + idx, ld4(dn + idx));
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < MAXO; ++k) {
-      const int o = threadIdx.x + k * 256;
-      if (o >= nout) break;
-      const int co = o % Co, ci = (o / Co) % Ci, t = o / (Co * Ci);
-      const int i = t / 3, j = t % 3;
-      float a = 0.f;
-      for (int ho = 0; ho < Ho; ++ho) {
+    if (active) {
+      for (int ho = g; ho < Ho; ho += G) {
         const float* xr = xs + ((ho * s - pt + i + 1) * Wp + (1 - pl + j)) * Ci + ci;
-        const float* dr = ds + ho * Wo * Co + co;
-        for (int wo = 0; wo < Wo; ++wo) a += xr[wo * s * Ci] * dr[wo * Co];
+        const float* dr = ds + ho * Wo * CO;
+        for (int wo = 0; wo < Wo; ++wo) {
+          const float xv = xr[wo * s * Ci];
+#pragma unroll
+          for (int c = 0; c < CO; c += 4) {
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(dr + wo * CO + c);
+            acc[c] += xv * dv[0]; acc[c + 1] += xv * dv[1]; acc[c + 2] += xv * dv[2]; acc[c + 3] += xv * dv[3];
+          }
+        }
       }
-      acc[k] += a;
     }
   }
+  if (active) {
+    float* p = part + ((long)blockIdx.x * G + g) * (npair * CO) + (long)pr * CO;
 #pragma unroll
-  for (int k = 0; k < MAXO; ++k) {
-    const int o = threadIdx.x + k * 256;
-    if (o < nout) part[(long)blockIdx.x * nout + o] = acc[k];
+    for (int c = 0; c < CO; c += 4) st4(p + c, f32x4{acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
   }
 }
 
@@ -176,10 +183,10 @@ int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, flo
 using namespace avsr;
 #define S_(x) ((hipStream_t)(x))
 
-static bool direct_ok(int Ci, int Co) { return Ci * Co <= 256 && Co % 4 == 0 && (Ci % 4 == 0 || Ci < 4); }
+static bool direct_ok(int Ci, int Co) { return Ci * Co <= 256 && 9 * Ci <= 256 && Co % 4 == 0 && (Ci % 4 == 0 || Ci < 4); }
 
 extern "C" int avsr_conv3x3_supported(int32_t Ci, int32_t Co, int32_t H, int32_t W) {
-  return direct_ok(Ci, Co) && (long)((H + 2) * (W + 2) * Ci + H * W * Co) * 4 <= 150 * 1024;
+  return direct_ok(Ci, Co) && (Co == 4 || Co == 8 || Co == 16) && (long)((H + 2) * (W + 2) * Ci + H * W * Co) * 4 <= 150 * 1024;
 }
 
 // flip = 0: forward conv (x [N,H,W,Ci] -> y [N,Ho,Wo,Co], w = TF kernel [3,3,Ci,Co], bias may be NULL).
@@ -218,24 +225,30 @@ extern "C" int avsr_conv3x3_bwd_weight(const float* x, const float* dy, float* d
                                        int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, float beta, float* scratch,
                                        int64_t scratch_floats, void* stream) {
   if (!x || !dy || !dw || !scratch || N <= 0 || !avsr_conv3x3_supported(Ci, Co, H, W) || pad_t > 1 || pad_l > 1) return AVSR_ERR_ARG;
-  const int nout = 9 * Ci * Co;
+  if (Co != 4 && Co != 8 && Co != 16) return AVSR_ERR_ARG;
+  const int nout = 9 * Ci * Co, G = 256 / (9 * Ci);
+  if (G < 1) return AVSR_ERR_ARG;
   int fpb = 4;
   int nblk = (N + fpb - 1) / fpb;
-  if ((long)nblk * nout > scratch_floats) {
-    nblk = (int)(scratch_floats / nout);
+  if ((long)nblk * G * nout > scratch_floats) {
+    nblk = (int)(scratch_floats / ((long)G * nout));
     if (nblk < 1) return AVSR_ERR_ARG;
     fpb = (N + nblk - 1) / nblk;
     nblk = (N + fpb - 1) / fpb;
   }
-  const size_t lds = sizeof(float) * ((size_t)(H + 2) * (W + 2) * Ci + (size_t)Ho * Wo * Co);
+  const size_t lds = sizeof(float) * ((size_t)(H + 2) * (W + 2) * Ci + (size_t)((Ho * Wo * Co + 3) & ~3));
   static bool big_lds = false;                          // more than 64 KB of dynamic LDS needs the attribute (set once, outside any capture)
   if (!big_lds) {
-    if (hipFuncSetAttribute((const void*)conv3x3_bwd_weight_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3x3_bwd_weight_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_bwd_weight_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_bwd_weight_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return AVSR_ERR_HIP;
     big_lds = true;
   }
-  hipLaunchKernelGGL(conv3x3_bwd_weight_kernel, dim3(nblk), dim3(256), lds, S_(stream), x, dy, scratch, N, H, W, Ci, Co, stride, pad_t, pad_l, Ho,
-                     Wo, fpb);
+#define BW_GO(CO_) hipLaunchKernelGGL((conv3x3_bwd_weight_kernel<CO_>), dim3(nblk), dim3(256), lds, S_(stream), x, dy, scratch, N, H, W, Ci, stride, \
+                                      pad_t, pad_l, Ho, Wo, fpb)
+  if (Co == 16) BW_GO(16); else if (Co == 8) BW_GO(8); else BW_GO(4);
+#undef BW_GO
   AVSR_CHECK_LAUNCH();
-  return avsr_colsum_final_launch(scratch, nblk, dw, nout, 1.0f, beta, stream);
+  return avsr_colsum_final_launch(scratch, nblk * G, dw, nout, 1.0f, beta, stream);
 }

@@ -39,19 +39,43 @@ __device__ __forceinline__ long rowoff(int r, long ld, int T, long ldo) {
   return T ? (long)(r / T) * ldo + (long)(r % T) * ld : (long)r * ld;
 }
 
+// Narrow matrices (F < 256): G = 256 / F row sub-groups of F columns share a block; their sums are combined through LDS in
+// group order, so every block emits ONE partial row whatever G is (deterministic).
+__device__ __forceinline__ void block_group_reduce(float s, int idx, int F, int G, float* red, float* out_row) {
+  if (G == 1) { if (idx < F) out_row[idx] = s; return; }
+  if (idx < G * F) red[idx] = s;
+  __syncthreads();
+  if (idx < F) {
+    float t = 0.f;
+    for (int g = 0; g < G; ++g) t += red[g * F + idx];
+    out_row[idx] = t;
+  }
+  __syncthreads();
+}
+
 __global__ void colsum_partial_kernel(const float* a, long lda, int Ta, long ldoa, const float* b, long ldb, int Tb,
                                       long ldob, float* part, int rows, int F, int rows_per_blk) {
-  // G = 256 / F row sub-groups of F columns when F < 256 (narrow matrices still use the whole block); partials per (block, sub-group)
+  __shared__ float red[256];
   const int G = F < 256 ? 256 / F : 1;
   const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-  for (int idx = threadIdx.x; idx < (G > 1 ? G * F : F); idx += blockDim.x) {
-    const int f = G > 1 ? idx % F : idx, g = G > 1 ? idx / F : 0;
+  if (G > 1) {
+    const int idx = threadIdx.x, f = idx % F, g = idx / F;
     float s = 0.f;
-    for (int r = r0 + g; r < r1; r += G) {
+    if (idx < G * F)
+      for (int r = r0 + g; r < r1; r += G) {
+        const float x = a[rowoff(r, lda, Ta, ldoa) + f];
+        s += b ? x * b[rowoff(r, ldb, Tb, ldob) + f] : x;
+      }
+    block_group_reduce(s, idx, F, G, red, part + (long)blockIdx.x * F);
+    return;
+  }
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) {
       const float x = a[rowoff(r, lda, Ta, ldoa) + f];
       s += b ? x * b[rowoff(r, ldb, Tb, ldob) + f] : x;
     }
-    part[((long)blockIdx.x * G + g) * F + f] = s;
+    part[(long)blockIdx.x * F + f] = s;
   }
 }
 
@@ -88,15 +112,20 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* part, i
 // Thread layout of the row-walking BN kernels: G = 256 / F row sub-groups of F columns (F < 256), so narrow feature
 // vectors (80 audio / 128 video) still use the whole block; partials are per (block, sub-group).
 __global__ void bn_partial_sum_kernel(const float* x, float* part, int rows, int F, int rows_per_blk) {
+  __shared__ float red[256];
   const int G = F < 256 ? 256 / F : 1;
   const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-  for (int idx = threadIdx.x; idx < G * F; idx += blockDim.x) {     // G > 1: a single pass (G*F <= 256)
-    const int f = idx % F, g = idx / F;
+  for (int base = 0; base < (G > 1 ? 1 : F); base += blockDim.x) {      // G > 1: a single pass (G*F <= 256)
+    const int idx = base + threadIdx.x;
+    const int f = G > 1 ? idx % F : idx, g = G > 1 ? idx / F : 0;
     float s0 = 0.f, s1 = 0.f;
-    int r = r0 + g;
-    for (; r + G < r1; r += 2 * G) { s0 += x[(long)r * F + f]; s1 += x[(long)(r + G) * F + f]; }
-    if (r < r1) s0 += x[(long)r * F + f];
-    part[((long)blockIdx.x * G + g) * F + f] = s0 + s1;
+    if (G > 1 ? idx < G * F : idx < F) {
+      int r = r0 + g;
+      for (; r + G < r1; r += 2 * G) { s0 += x[(long)r * F + f]; s1 += x[(long)(r + G) * F + f]; }
+      if (r < r1) s0 += x[(long)r * F + f];
+    }
+    if (G > 1) block_group_reduce(s0 + s1, idx, F, G, red, part + (long)blockIdx.x * F);
+    else if (idx < F) part[(long)blockIdx.x * F + idx] = s0 + s1;
   }
 }
 
@@ -119,19 +148,24 @@ __global__ __launch_bounds__(1024) void bn_mean_kernel(const float* part, int np
 }
 
 __global__ void bn_partial_sq_kernel(const float* x, const float* mean_v, float* part, int rows, int F, int rows_per_blk) {
+  __shared__ float red[256];
   const int G = F < 256 ? 256 / F : 1;
   const int r0 = blockIdx.x * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
-  for (int idx = threadIdx.x; idx < G * F; idx += blockDim.x) {
-    const int f = idx % F, g = idx / F;
-    const float mean = mean_v[f];
+  for (int base = 0; base < (G > 1 ? 1 : F); base += blockDim.x) {
+    const int idx = base + threadIdx.x;
+    const int f = G > 1 ? idx % F : idx, g = G > 1 ? idx / F : 0;
     float s0 = 0.f, s1 = 0.f;
-    int r = r0 + g;
-    for (; r + G < r1; r += 2 * G) {
-      const float d0 = x[(long)r * F + f] - mean, d1 = x[(long)(r + G) * F + f] - mean;
-      s0 += d0 * d0; s1 += d1 * d1;
+    if (G > 1 ? idx < G * F : idx < F) {
+      const float mean = mean_v[f];
+      int r = r0 + g;
+      for (; r + G < r1; r += 2 * G) {
+        const float d0 = x[(long)r * F + f] - mean, d1 = x[(long)(r + G) * F + f] - mean;
+        s0 += d0 * d0; s1 += d1 * d1;
+      }
+      if (r < r1) { const float d0 = x[(long)r * F + f] - mean; s0 += d0 * d0; }
     }
-    if (r < r1) { const float d0 = x[(long)r * F + f] - mean; s0 += d0 * d0; }
-    part[((long)blockIdx.x * G + g) * F + f] = s0 + s1;
+    if (G > 1) block_group_reduce(s0 + s1, idx, F, G, red, part + (long)blockIdx.x * F);
+    else if (idx < F) part[(long)blockIdx.x * F + idx] = s0 + s1;
   }
 }
 
@@ -429,12 +463,11 @@ int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, flo
 extern "C" int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, int32_t F, float alpha, float beta,
                            float* out, float* scratch, int64_t scratch_floats, void* stream) {
   if (!a || !a->ptr || !out || !scratch || rows <= 0 || F <= 0) return AVSR_ERR_ARG;
-  const int G = F < 256 ? 256 / F : 1;
-  const int maxblk = G > 1 ? (4096 / G > 64 ? 4096 / G : 64) : 2048;   // ~4096 partial rows at most: the final pass stays one short launch
+  const int maxblk = 2048;                                     // at most 2048 partial rows: the final pass stays one short launch
   int rpb = rows > 32 * maxblk ? (rows + maxblk - 1) / maxblk : 32;
   int nblk = (rows + rpb - 1) / rpb;
-  if ((long)nblk * G * F > scratch_floats) {
-    nblk = (int)(scratch_floats / ((long)G * F));
+  if ((long)nblk * F > scratch_floats) {
+    nblk = (int)(scratch_floats / F);
     if (nblk < 1) return AVSR_ERR_ARG;
     rpb = (rows + nblk - 1) / nblk;
     nblk = (rows + rpb - 1) / rpb;
@@ -443,7 +476,7 @@ extern "C" int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, i
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(th), 0, S_(stream), a->ptr, (long)a->ld, a->T, (long)a->ldo,
                      b ? b->ptr : nullptr, b ? (long)b->ld : 0, b ? b->T : 0, b ? (long)b->ldo : 0, scratch, rows, F, rpb);
   AVSR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), scratch, nblk * G, out, F, alpha, beta);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), scratch, nblk, out, F, alpha, beta);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
@@ -465,28 +498,27 @@ extern "C" int avsr_batchnorm_fwd_ex(const float* x, float* y, int32_t rows, int
                                      float eps, float momentum, int32_t relu, float* scratch, int64_t scratch_floats, void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0 || F <= 0 || !scratch) return AVSR_ERR_ARG;
   if (F % 4) return AVSR_ERR_ARG;
-  const int G = F < 256 ? 256 / F : 1;
-  const int maxblk = 4096 / G > 64 ? 4096 / G : 64;            // ~4096 partial rows at most
+  const int maxblk = 2048;
   int rpb = rows > 64 * maxblk ? (rows + maxblk - 1) / maxblk : 64;
   int nblk = (rows + rpb - 1) / rpb;
-  if ((long)nblk * G * F + 2 * F > scratch_floats) {
-    nblk = (int)((scratch_floats - 2 * F) / ((long)G * F));
+  if ((long)nblk * F + 2 * F > scratch_floats) {
+    nblk = (int)((scratch_floats - 2 * F) / F);
     if (nblk < 1) return AVSR_ERR_ARG;
     rpb = (rows + nblk - 1) / nblk;
     nblk = (rows + rpb - 1) / rpb;
   }
-  // scratch: partials [nblk*G][F] | mean [F] | invstd [F]  (mean / invstd go to save_mean / save_invstd when given)
+  // scratch: partials [nblk][F] | mean [F] | invstd [F]  (mean / invstd go to save_mean / save_invstd when given)
   float* part = scratch;
-  float* mean_v = save_mean ? save_mean : scratch + (long)nblk * G * F;
-  float* invstd_v = save_invstd ? save_invstd : scratch + (long)nblk * G * F + F;
+  float* mean_v = save_mean ? save_mean : scratch + (long)nblk * F;
+  float* invstd_v = save_invstd ? save_invstd : scratch + (long)nblk * F + F;
   if (training) {
     hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, part, rows, F, rpb);
     AVSR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_mean_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, nblk * G, mean_v, rows, F);
+    hipLaunchKernelGGL(bn_mean_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, nblk, mean_v, rows, F);
     AVSR_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_partial_sq_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, mean_v, part, rows, F, rpb);
     AVSR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_var_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, nblk * G, mean_v, invstd_v, moving_mean,
+    hipLaunchKernelGGL(bn_var_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, nblk, mean_v, invstd_v, moving_mean,
                        moving_var, rows, F, eps, momentum);
     AVSR_CHECK_LAUNCH();
   } else if (!moving_mean || !moving_var) {

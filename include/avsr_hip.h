@@ -346,7 +346,7 @@ int avsr_col2im(const float* dcol, float* dx, int32_t N, int32_t H, int32_t W, i
  *   avsr_conv3x3(flip=0): y = conv(x, w[3,3,Ci,Co]) + bias (+ beta*y).
  *   avsr_conv3x3(flip=1): stride-1 data gradient: x = dy [.,Ci = cout], y = dx [.,Co = cin], w = the FORWARD kernel [3,3,Co,Ci].
  *   avsr_conv3x3_bwd_data_s2: data gradient of a stride-2 conv (dx [N,H,W,Ci] from dy [N,Ho,Wo,Co]).
- *   avsr_conv3x3_bwd_weight: dw[3,3,Ci,Co] = beta*dw + sum x (x) dy; scratch >= ceil(N/4) * 9*Ci*Co floats. */
+ *   avsr_conv3x3_bwd_weight: dw[3,3,Ci,Co] = beta*dw + sum x (x) dy; Co in {4, 8, 16}; scratch >= ceil(N/4) * (256/(9*Ci)) * 9*Ci*Co floats (fewer blocks if smaller). */
 int avsr_conv3x3_supported(int32_t Ci, int32_t Co, int32_t H, int32_t W);
 int avsr_conv3x3(const float* x, const float* w, const float* bias, float* y, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                  int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, int32_t flip, float beta, void* stream);
