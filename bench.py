@@ -54,8 +54,10 @@ def synth(cfg, B, rank):
         d["audio"] = r(1).standard_normal((B, TA, FA)).astype(np.float32)
         d["audio_len"] = np.full(B, TA, np.int32)
     if cfg.video_units is not None:
-        vshape = tuple(cfg.video_hw) if cfg.video_processing == "resnet_cnn" else (FV,)
-        d["video"] = r(3).standard_normal((B, TV) + vshape).astype(np.float32)
+        if cfg.video_processing == "resnet_cnn":      # lip crops ~ U(-1, 1), i.e. (x - 128) / 128 of dataset_writer.py:537
+            d["video"] = r(3).uniform(-1.0, 1.0, (B, TV) + tuple(cfg.video_hw)).astype(np.float32)
+        else:
+            d["video"] = r(3).standard_normal((B, TV, FV)).astype(np.float32)
         d["video_len"] = np.full(B, TV, np.int32)
         d["aus"] = r(5).uniform(0, 3, (B, TV, 2)).astype(np.float32)
     lab = r(6).integers(1, 29, (B, LDEC)).astype(np.int32)
@@ -256,6 +258,29 @@ def main():
 
         out["roofline"] = roof(dom)
         out["roofline_other"] = [roof(k) for k in kinds if k != dom and k != "step_dense"]
+    if rank == 0 and world == 1 and not args.no_profile and cfg.video_units is not None and args.video_frontend == "features":
+        # The same workload fed with 36x36x3 lip crops through the CNN front-end (SURVEY 8(d) allows either video input; the
+        # front-end is a "next" row outside north_star's replaced subsystems, so the headline keeps the feature input).
+        try:
+            del trainer, model
+            torch.cuda.empty_cache()
+            cfg2 = ModelConfig(audio_feat=FA, video_feat=FV, video_processing="resnet_cnn", **wl["cfg"], **stoch)
+            m2 = Seq2SeqModel(cfg2, seed=2001)
+            t2 = DataParallelTrainer(m2, None, use_graph=not args.no_graph)
+            b2 = Batch.from_numpy(NS(synth(cfg2, B, rank)))
+            for _ in range(3):
+                t2.train_step(b2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                t2.train_step(b2)
+            torch.cuda.synchronize()
+            dt2 = (time.perf_counter() - t0) / 5
+            out["with_lip_cnn"] = {"value": round(B / dt2, 2), "unit": "utterances/sec", "ms_per_step": round(1e3 * dt2, 4),
+                                   "video_input": "[B,%d,36,36,3] lip crops through video.resnet_cnn (avsr_tf1_amd/cnn.py)" % TV,
+                                   "final_loss": round(float(m2.loss.item()), 5)}
+        except Exception as e:
+            out["with_lip_cnn"] = {"value": None, "error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(wl, stoch, video_frontend=args.video_frontend)
