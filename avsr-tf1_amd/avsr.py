@@ -142,6 +142,7 @@ class AVSR(object):
             video_processing=video_processing if video_processing is not None else 'features',
             cnn_filters=tuple(cnn_filters), cnn_dense_units=cnn_dense_units, video_hw=video_hw)
         self._model = Seq2SeqModel(self._cfg, seed=kwargs.get('seed', 0))
+        self._shuffle_seed = kwargs.get('shuffle_seed')        # None = a fresh order every run, as tf.data's unseeded shuffle(5000)
         self._trainer = DataParallelTrainer(self._model, None, use_graph=False)   # bucketed batches: shapes vary per step
 
     # ------------------------------------------------------------------------------------------------
@@ -150,10 +151,12 @@ class AVSR(object):
         bs = self._batch_size[0 if mode == 'train' else 1]
         shuffle = mode == 'train'
         if self._video_processing is not None and self._audio_processing is not None:
-            return make_iterator_from_two_records(vrec, arec, lrec, bs, self._unit_dict, shuffle=shuffle, bucket_width=45)
+            return make_iterator_from_two_records(vrec, arec, lrec, bs, self._unit_dict, shuffle=shuffle, bucket_width=45,
+                                                  seed=self._shuffle_seed)
         rec = vrec if self._video_processing is not None else arec
         return make_iterator_from_one_record(rec, lrec, self._unit_dict, bs, shuffle=shuffle, bucket_width=45,
-                                             max_sentence_length=self._max_sentence_length if self._audio_processing is not None else None)
+                                             max_sentence_length=self._max_sentence_length if self._audio_processing is not None else None,
+                                             seed=self._shuffle_seed)
 
     def _to_batch(self, bd):
         t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda()

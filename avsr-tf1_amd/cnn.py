@@ -114,9 +114,23 @@ class LipCNN:
             dst = op[3] if kind in ("conv", "bnrelu", "flatten") else op[4]
             h, w, c = self.shapes[dst]
             self.maps[dst] = z(N, h, w, c)
+        # how many ops read each map: the gradient of a single-consumer input of a residual add is the add's output gradient
+        # itself (aliased, no copy); maps with several consumers own a buffer their contributions accumulate into
+        self.consumers = {}
+        for op in self.ops:
+            for src in ((op[2],) if op[0] != "add" else (op[2], op[3])):
+                self.consumers[src] = self.consumers.get(src, 0) + 1
+        self.alias = {}
+        for op in self.ops:
+            if op[0] == "add":
+                for t in (op[2], op[3]):
+                    if self.consumers.get(t, 0) == 1:
+                        self.alias[t] = op[4]
         for name, (h, w, c) in self.shapes.items():
-            if name != "in":
+            if name != "in" and name not in self.alias:
                 self.gmaps[name] = z(N, h, w, c)
+        for t, dst in self.alias.items():
+            self.gmaps[t] = self.gmaps[dst]
         self.dcol = torch.empty(max_col, device=dev)              # d col of the layer being differentiated (transient)
 
     # parameters live in the model's flat buffers
@@ -197,6 +211,9 @@ class LipCNN:
             elif kind == "add":
                 _, name, a, b, dst = op
                 for t in (a, b):
+                    if t in self.alias:                                        # same buffer as the add's output gradient
+                        written.add(t)
+                        continue
                     g, beta = target(t)
                     if beta:
                         ops.add(g, self.gmaps[dst], g, g.numel())

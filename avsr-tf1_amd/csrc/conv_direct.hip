@@ -144,12 +144,16 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float* __
   for (int c = 0; c < CO; ++c) acc[c] = 0.f;
   const int n0 = blockIdx.x * frames_per_blk, n1 = min(N, n0 + frames_per_blk);
   const int nx = Hp * Wp * Ci, nd = Ho * Wo * CO;
+  for (int idx = threadIdx.x; idx < nx; idx += 256) xs[idx] = 0.f;       // the halo stays zero; frames only overwrite the interior
+  const int rowf = W * Ci, rowq = rowf >> 2;                              // floats / 16-byte pieces per map row (W*Ci % 4 == 0)
   for (int n = n0; n < n1; ++n) {
     __syncthreads();
-    for (int idx = threadIdx.x; idx < nx; idx += 256) {
-      const int c = idx % Ci, wq = (idx / Ci) % Wp, hq = idx / (Ci * Wp);
-      const int h = hq - 1, ww = wq - 1;
-      xs[idx] = (h >= 0 && h < H && ww >= 0 && ww < W) ? x[(((long)n * H + h) * W + ww) * Ci + c] : 0.f;
+    const float* xn = x + (long)n * H * rowf;
+    for (int idx = threadIdx.x; idx < H * rowq; idx += 256) {
+      const int h = idx / rowq, p4 = idx % rowq;
+      const f32x4 v = ld4(xn + (long)h * rowf + p4 * 4);
+      float* d = xs + ((h + 1) * Wp + 1) * Ci + p4 * 4;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
     }
     const float* dn = dy + (long)n * nd;
     for (int idx = threadIdx.x * 4; idx < nd; idx += 1024) st4(ds + idx, ld4(dn + idx));

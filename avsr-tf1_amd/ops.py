@@ -44,9 +44,10 @@ def auto_splitk(M, N, K, batch=1):
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * max(1, batch)
     if tiles >= 128:
         return 1
-    sk = min(768 // tiles, K // 64, 64)
-    if K > (1 << 19):            # convolution weight gradients: a handful of output tiles, K = N*Ho*Wo rows in the millions
-        sk = min(max(sk, K // 4096), 2048)
+    if K < 65536:
+        sk = min(768 // tiles, K // 64, 64)
+    else:                        # weight gradients over 10^5..10^7 rows (encoder BPTT, convolutions): ~4 workgroups per CU
+        sk = min(1024 // tiles, K // 256, 2048)
     return sk if sk >= 2 else 1
 
 

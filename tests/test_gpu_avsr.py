@@ -35,7 +35,7 @@ def test_avsr_train_evaluate_and_resume(tmp_path, monkeypatch):
     kw = dict(unit="character", unit_file=unit_file, audio_processing="features", audio_train_record=p["audio"],
               audio_test_record=p["audio"], labels_train_record=p["labels"], labels_test_record=p["labels"], batch_size=(4, 4),
               encoder_units_per_layer=((32,), (32, 32)), decoder_units_per_layer=(32,), embedding_size=16, decoding_algorithm="greedy",
-              warmup_steps=0, learning_rate=0.01)
+              warmup_steps=0, learning_rate=0.01, shuffle_seed=0)      # fixed shuffle order: the assertions below see one trajectory
     exp = avsr.AVSR(**kw)
     exp.train(logfile="logs/smoke", num_epochs=11)               # 10 epochs -> checkpoint + evaluation at epoch 10
     assert os.path.exists("checkpoints/smoke/checkpoint.ckp-10.npz")
@@ -45,7 +45,8 @@ def test_avsr_train_evaluate_and_resume(tmp_path, monkeypatch):
     losses = [float(l.split()[-1]) for l in log.splitlines() if l.startswith("Average")]
     assert losses[-1] < losses[0]
     err = exp.evaluate("checkpoints/smoke/checkpoint.ckp-10", epoch=10)
-    assert set(err) == {"character", "word"} and 0.0 <= err["character"] <= 2.0
+    # (an under-trained model may never emit EOS: 150 decoded symbols against 2-5 reference ones, so only sanity-bound the rate)
+    assert set(err) == {"character", "word"} and np.isfinite(err["character"]) and err["character"] >= 0.0
     # a fresh object resumes from the newest checkpoint and continues the epoch count from its file name
     exp2 = avsr.AVSR(**kw)
     exp2.train(logfile="logs/smoke", num_epochs=2, try_restore_latest_checkpoint=True)
@@ -90,7 +91,7 @@ def test_avsr_visual_only_from_lip_crops(tmp_path, monkeypatch):
     exp = avsr.AVSR(unit="character", unit_file=unit_file, video_processing="resnet_cnn", video_train_record=vrec, video_test_record=vrec,
                     labels_train_record=lrec, labels_test_record=lrec, batch_size=(4, 4), encoder_units_per_layer=((32,), (32,)),
                     decoder_units_per_layer=(32,), embedding_size=16, decoding_algorithm="greedy", cnn_filters=(8, 8, 16, 16),
-                    cnn_dense_units=32, warmup_steps=0, learning_rate=0.01)
+                    cnn_dense_units=32, warmup_steps=0, learning_rate=0.01, shuffle_seed=0)
     exp.train(logfile="logs/video", num_epochs=4)
     log = open("logs/video").read()
     losses = [float(l.split()[-1]) for l in log.splitlines() if l.startswith("Average")]
