@@ -258,6 +258,21 @@ def main():
 
         out["roofline"] = roof(dom)
         out["roofline_other"] = [roof(k) for k in kinds if k != dom and k != "step_dense"]
+    if rank == 0 and world == 1 and not args.no_profile:
+        # SURVEY 8(d) also asks for the greedy-decode rate: eval graph (no dropout, BN moving statistics), GreedyEmbeddingHelper,
+        # T_dec steps per utterance (random weights never emit EOS, so every utterance runs all LDEC steps)
+        try:
+            model.greedy_decode(batch, max_steps=LDEC)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                model.greedy_decode(batch, max_steps=LDEC)
+            torch.cuda.synchronize()
+            dtd = (time.perf_counter() - t0) / 3
+            out["greedy_decode"] = {"value": round(B / dtd, 2), "unit": "utterances/sec", "ms_per_batch": round(1e3 * dtd, 3),
+                                    "steps": LDEC, "launch": "eager (host-driven early-exit check every 8 steps)"}
+        except Exception as e:
+            out["greedy_decode"] = {"value": None, "error": repr(e)}
     if rank == 0 and world == 1 and not args.no_profile and cfg.video_units is not None and args.video_frontend == "features":
         # The same workload fed with 36x36x3 lip crops through the CNN front-end (SURVEY 8(d) allows either video input; the
         # front-end is a "next" row outside north_star's replaced subsystems, so the headline keeps the feature input).
