@@ -1,0 +1,127 @@
+"""Kernel-level parity of the lip-CNN building blocks (csrc/conv.hip, conv_direct.hip) through the C ABI against a plain
+PyTorch fp32/fp64 reference on the CPU (torch.nn.functional.conv2d + autograd), with TensorFlow's SAME geometry.
+Tolerance: 2e-5 of the tensor's magnitude (fp32 accumulation order differs)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(n, k, s):
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return out, total // 2, total - total // 2
+
+
+def _ref_conv(x, w, b, s):
+    """x [N,H,W,C] float64, w [k,k,Ci,Co]: TF conv2d(padding='SAME')."""
+    k = w.shape[0]
+    Ho, pt, pb = _same(x.shape[1], k, s)
+    Wo, pl, pr = _same(x.shape[2], k, s)
+    xt = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    y = torch.nn.functional.conv2d(xt, w.permute(3, 2, 0, 1), b, stride=s)
+    return y.permute(0, 2, 3, 1)
+
+
+def _close(a, b, tol=2e-5):
+    b = np.asarray(b)
+    return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,s", [(3, 12, 3, 8, 1), (2, 12, 8, 8, 1), (2, 12, 8, 16, 2), (2, 9, 16, 16, 1), (5, 9, 16, 16, 2), (2, 7, 4, 4, 2)])
+def test_direct_conv3x3_forward_and_gradients(N, H, Ci, Co, s):
+    from avsr_tf1_amd import ops
+    rng = np.random.default_rng(H * 100 + Ci * 10 + Co + s)
+    W = H
+    x = torch.tensor(rng.standard_normal((N, H, W, Ci)), dtype=torch.float64, requires_grad=True)
+    w = torch.tensor(rng.standard_normal((3, 3, Ci, Co)) * 0.3, dtype=torch.float64, requires_grad=True)
+    b = torch.tensor(rng.standard_normal(Co), dtype=torch.float64, requires_grad=True)
+    y = _ref_conv(x, w, b, s)
+    dy = torch.tensor(rng.standard_normal(tuple(y.shape)), dtype=torch.float64)
+    (y * dy).sum().backward()
+    Ho, pt, _ = _same(H, 3, s)
+    Wo, pl, _ = _same(W, 3, s)
+    assert ops.conv3x3_supported(Ci, Co, H, W)
+    dev = lambda t: t.detach().to(torch.float32).cuda().contiguous()
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    yd = torch.zeros(N, Ho, Wo, Co, device="cuda")
+    ops.conv3x3(xd, wd, bd, yd, N, H, W, Ci, Co, s, pt, pl, Ho, Wo)
+    torch.cuda.synchronize()
+    assert _close(yd.cpu().numpy(), y.detach().numpy())
+    # weight gradient accumulates into dw (beta = 1): start from a known offset
+    dw = torch.full((3, 3, Ci, Co), 0.5, device="cuda")
+    scratch = torch.empty(1 << 20, device="cuda")
+    ops.conv3x3_bwd_weight(xd, dyd, dw, N, H, W, Ci, Co, s, pt, pl, Ho, Wo, scratch)
+    torch.cuda.synchronize()
+    assert _close(dw.cpu().numpy() - 0.5, w.grad.numpy(), 5e-5)
+    if Ci % 4 == 0:
+        dx = torch.full((N, H, W, Ci), 0.25, device="cuda")
+        if s == 1:
+            ops.conv3x3(dyd, wd, None, dx, N, Ho, Wo, Co, Ci, 1, 1, 1, H, W, flip=1, beta=1.0)
+        else:
+            ops.conv3x3_bwd_data_s2(dyd, wd, dx, N, H, W, Ci, Co, pt, pl, Ho, Wo, beta=1.0)
+        torch.cuda.synchronize()
+        assert _close(dx.cpu().numpy() - 0.25, x.grad.numpy(), 5e-5)
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,k,s", [(2, 9, 32, 64, 3, 2), (3, 10, 16, 32, 1, 2), (2, 5, 64, 64, 3, 1)])
+def test_im2col_gemm_conv_and_col2im(N, H, Ci, Co, k, s):
+    from avsr_tf1_amd import ops
+    rng = np.random.default_rng(7 + H + Ci)
+    W = H
+    x = torch.tensor(rng.standard_normal((N, H, W, Ci)), dtype=torch.float64, requires_grad=True)
+    w = torch.tensor(rng.standard_normal((k, k, Ci, Co)) * 0.2, dtype=torch.float64)
+    y = _ref_conv(x, w, None, s)
+    dy = torch.tensor(rng.standard_normal(tuple(y.shape)), dtype=torch.float64)
+    (y * dy).sum().backward()
+    Ho, pt, _ = _same(H, k, s)
+    Wo, pl, _ = _same(W, k, s)
+    dev = lambda t: t.detach().to(torch.float32).cuda().contiguous()
+    xd, wd, dyd = dev(x), dev(w), dev(dy)
+    rows, K = N * Ho * Wo, k * k * Ci
+    col = torch.zeros(rows, K, device="cuda")
+    ops.im2col(xd, col, N, H, W, Ci, k, k, s, pt, pl, Ho, Wo)
+    yd = torch.zeros(rows, Co, device="cuda")
+    ops.gemm(ops.mat(col, K), ops.mat(wd, Co), ops.mat(yd, Co), rows, Co, K, splitk=1)
+    torch.cuda.synchronize()
+    assert _close(yd.cpu().numpy().reshape(y.shape), y.detach().numpy())
+    dcol = torch.zeros(rows, K, device="cuda")
+    ops.gemm(ops.mat(dyd, Co), ops.mat(wd, Co), ops.mat(dcol, K), rows, K, Co, trans_b=1, splitk=1)
+    dx = torch.zeros(N, H, W, Ci, device="cuda")
+    ops.col2im(dcol, dx, N, H, W, Ci, k, k, s, pt, pl, Ho, Wo)
+    torch.cuda.synchronize()
+    assert _close(dx.cpu().numpy(), x.grad.numpy(), 5e-5)
+
+
+@pytest.mark.parametrize("rows,F,relu", [(700, 8, 1), (5000, 16, 1), (333, 64, 0), (130000, 8, 1)])
+def test_batchnorm_forward_backward(rows, F, relu):
+    from avsr_tf1_amd import ops
+    rng = np.random.default_rng(rows + F)
+    x = torch.tensor(rng.standard_normal((rows, F)) * 2 + 0.5, dtype=torch.float64, requires_grad=True)
+    g = torch.tensor(rng.uniform(0.5, 1.5, F), dtype=torch.float64, requires_grad=True)
+    b = torch.tensor(rng.standard_normal(F) * 0.3, dtype=torch.float64, requires_grad=True)
+    eps, mom = 1e-5, 0.98
+    mean = x.mean(0)
+    var = ((x - mean) ** 2).mean(0)
+    y = (x - mean) * torch.rsqrt(var + eps) * g + b
+    if relu:
+        y = torch.relu(y)
+    dy = torch.tensor(rng.standard_normal((rows, F)), dtype=torch.float64)
+    (y * dy).sum().backward()
+    dev = lambda t: t.detach().to(torch.float32).cuda().contiguous()
+    xd, gd, bd, dyd = dev(x), dev(g), dev(b), dev(dy)
+    yd = torch.zeros(rows, F, device="cuda")
+    mm, mv = torch.zeros(F, device="cuda"), torch.ones(F, device="cuda")
+    sm, si = torch.zeros(F, device="cuda"), torch.zeros(F, device="cuda")
+    scratch = torch.empty(1 << 20, device="cuda")
+    ops.batchnorm_fwd_ex(xd, yd, rows, F, gd, bd, mm, mv, sm, si, True, eps, mom, relu, scratch)
+    torch.cuda.synchronize()
+    assert _close(yd.cpu().numpy(), y.detach().numpy(), 5e-5)
+    assert _close(mm.cpu().numpy(), (1 - mom) * mean.detach().numpy(), 5e-5)
+    assert _close(mv.cpu().numpy(), mom + (1 - mom) * var.detach().numpy() * rows / (rows - 1), 5e-5)
+    dx, dg, db = torch.zeros(rows, F, device="cuda"), torch.zeros(F, device="cuda"), torch.zeros(F, device="cuda")
+    ops.batchnorm_bwd(xd, dyd, gd, bd, sm, si, dx, dg, db, rows, F, relu, scratch)
+    torch.cuda.synchronize()
+    assert _close(dx.cpu().numpy(), x.grad.numpy(), 2e-4)
+    assert _close(dg.cpu().numpy(), g.grad.numpy(), 2e-4) and _close(db.cpu().numpy(), b.grad.numpy(), 2e-4)
