@@ -21,61 +21,72 @@ template <int COT>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                       float* __restrict__ y, int N, int H, int W, int Ci, int Co, int s, int pt, int pl,
                                                       int Ho, int Wo, int flip, float beta) {
-  extern __shared__ float ws[];                        // [9][Ci][Co]
+  extern __shared__ __attribute__((aligned(16))) float ws[];     // [9][Ci][Co]
   const int nw = 9 * Ci * Co;
   for (int idx = threadIdx.x; idx < nw; idx += 256) {
     const int co = idx % Co, ci = (idx / Co) % Ci, t = idx / (Co * Ci);
     ws[idx] = flip ? w[((8 - t) * Co + co) * Ci + ci] : w[idx];
   }
   __syncthreads();
-  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= (long)N * Ho * Wo) return;
+  // one thread = two horizontally adjacent output pixels: every weight read from LDS feeds both
+  const int Wh = (Wo + 1) >> 1;
+  const long pr = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pr >= (long)N * Ho * Wh) return;
   const int co0 = blockIdx.y * COT;
-  const int wo = (int)(pix % Wo), ho = (int)((pix / Wo) % Ho), n = (int)(pix / ((long)Wo * Ho));
-  float acc[COT];
+  const int wo = 2 * (int)(pr % Wh), ho = (int)((pr / Wh) % Ho), n = (int)(pr / ((long)Wh * Ho));
+  const bool two = wo + 1 < Wo;
+  float acc0[COT], acc1[COT];
 #pragma unroll
-  for (int c = 0; c < COT; ++c) acc[c] = 0.f;
+  for (int c = 0; c < COT; ++c) { acc0[c] = 0.f; acc1[c] = 0.f; }
   for (int i = 0; i < 3; ++i) {
     const int h = ho * s - pt + i;
     if (h < 0 || h >= H) continue;
+    const float* xrow = x + ((long)n * H + h) * W * Ci;
     for (int j = 0; j < 3; ++j) {
-      const int ww = wo * s - pl + j;
-      if (ww < 0 || ww >= W) continue;
-      const float* xp = x + (((long)n * H + h) * W + ww) * Ci;
+      const int w0 = wo * s - pl + j, w1 = w0 + s;
+      const bool v0 = w0 >= 0 && w0 < W, v1 = two && w1 >= 0 && w1 < W;
+      if (!v0 && !v1) continue;
+      const float* x0 = xrow + (long)(v0 ? w0 : 0) * Ci;
+      const float* x1 = xrow + (long)(v1 ? w1 : 0) * Ci;
       const float* wp = ws + (i * 3 + j) * Ci * Co + co0;
       if (Ci % 4 == 0) {
         for (int ci = 0; ci < Ci; ci += 4) {
-          const f32x4 xv = ld4(xp + ci);
+          f32x4 a = ld4(x0 + ci), b = ld4(x1 + ci);
+          if (!v0) a = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (!v1) b = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float* wr = wp + (ci + e) * Co;
 #pragma unroll
             for (int c = 0; c < COT; c += 4) {
               const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
-              acc[c] += xv[e] * wv[0]; acc[c + 1] += xv[e] * wv[1]; acc[c + 2] += xv[e] * wv[2]; acc[c + 3] += xv[e] * wv[3];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { acc0[c + k] += a[e] * wv[k]; acc1[c + k] += b[e] * wv[k]; }
             }
           }
         }
       } else {
         for (int ci = 0; ci < Ci; ++ci) {
-          const float xv = xp[ci];
+          const float a = v0 ? x0[ci] : 0.f, b = v1 ? x1[ci] : 0.f;
           const float* wr = wp + ci * Co;
 #pragma unroll
           for (int c = 0; c < COT; c += 4) {
             const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + c);
-            acc[c] += xv * wv[0]; acc[c + 1] += xv * wv[1]; acc[c + 2] += xv * wv[2]; acc[c + 3] += xv * wv[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc0[c + k] += a * wv[k]; acc1[c + k] += b * wv[k]; }
           }
         }
       }
     }
   }
-  float* yp = y + pix * Co + co0;
+  float* yp = y + (((long)n * Ho + ho) * Wo + wo) * Co + co0;
 #pragma unroll
   for (int c = 0; c < COT; c += 4) {
-    f32x4 v = {acc[c], acc[c + 1], acc[c + 2], acc[c + 3]};
-    if (bias) v += ld4(bias + co0 + c);
-    if (beta != 0.f) v += beta * ld4(yp + c);
-    st4(yp + c, v);
+    f32x4 v0 = {acc0[c], acc0[c + 1], acc0[c + 2], acc0[c + 3]}, v1 = {acc1[c], acc1[c + 1], acc1[c + 2], acc1[c + 3]};
+    if (bias) { const f32x4 bv = ld4(bias + co0 + c); v0 += bv; v1 += bv; }
+    if (beta != 0.f) { v0 += beta * ld4(yp + c); if (two) v1 += beta * ld4(yp + Co + c); }
+    st4(yp + c, v0);
+    if (two) st4(yp + Co + c, v1);
   }
 }
 
@@ -123,11 +134,12 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_data_s2_kernel(const float* _
   }
 }
 
-// weight gradient partials.  Thread = one (tap, cin) pair of one row group g (G = 256 / (9*Ci) groups share the frame's rows);
-// it keeps the Co accumulators of that pair in registers: per pixel ONE x read and Co/4 broadcast 16-byte dy reads feed Co FMAs.
+// weight gradient partials.  Thread = PP (tap, cin) pairs of one row group g (PP = 1: G = 256 / (9*Ci) groups share the frame's
+// rows; PP = 2 for 9*Ci > 256: one group); it keeps the Co accumulators of its pairs in registers: per pixel ONE x read and
+// Co/4 broadcast 16-byte dy reads feed Co FMAs.
 // part[(blk*G + g)][(i*3+j)*Ci*Co + ci*Co + co] = sum over the block's frames and the group's pixels of
 // x[n, ho*s - pt + i, wo*s - pl + j, ci] * dy[n, ho, wo, co]
-template <int CO>
+template <int CO, int PP>
 __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
                                                                  int N, int H, int W, int Ci, int s, int pt, int pl, int Ho, int Wo,
                                                                  int frames_per_blk) {
@@ -135,13 +147,23 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float* __
   const int Hp = H + 2, Wp = W + 2;                    // zero halo of one pixel on every side covers pt, pl in {0, 1}
   float* ds = sm;                                       // [Ho][Wo][CO]   (first: 16-byte aligned rows)
   float* xs = sm + ((Ho * Wo * CO + 3) & ~3);           // [Hp][Wp][Ci]
-  const int npair = 9 * Ci, G = 256 / npair;
-  const int g = threadIdx.x / npair, pr = threadIdx.x % npair;
+  const int npair = 9 * Ci, G = PP == 1 ? 256 / npair : 1;
+  const int g = PP == 1 ? threadIdx.x / npair : 0;
   const bool active = g < G;
-  const int ci = pr % Ci, t = pr / Ci, i = t / 3, j = t % 3;
-  float acc[CO];
+  int xoff[PP];                                         // xs offset of (tap, ci) relative to the output pixel's window origin
+  bool on[PP];
 #pragma unroll
-  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  for (int q = 0; q < PP; ++q) {
+    const int pr = (PP == 1 ? threadIdx.x % npair : threadIdx.x + q * 256);
+    on[q] = active && pr < npair;
+    const int ci = pr % Ci, t = pr / Ci, i = t / 3, j = t % 3;
+    xoff[q] = ((i + 1 - pt) * Wp + (1 - pl + j)) * Ci + ci;
+  }
+  float acc[PP][CO];
+#pragma unroll
+  for (int q = 0; q < PP; ++q)
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[q][c] = 0.f;
   const int n0 = blockIdx.x * frames_per_blk, n1 = min(N, n0 + frames_per_blk);
   const int nx = Hp * Wp * Ci, nd = Ho * Wo * CO;
   for (int idx = threadIdx.x; idx < nx; idx += 256) xs[idx] = 0.f;       // the halo stays zero; frames only overwrite the interior
@@ -160,23 +182,31 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float* __
     __syncthreads();
     if (active) {
       for (int ho = g; ho < Ho; ho += G) {
-        const float* xr = xs + ((ho * s - pt + i + 1) * Wp + (1 - pl + j)) * Ci + ci;
         const float* dr = ds + ho * Wo * CO;
+        const int rbase = ho * s * Wp * Ci;
         for (int wo = 0; wo < Wo; ++wo) {
-          const float xv = xr[wo * s * Ci];
+          float xv[PP];
+#pragma unroll
+          for (int q = 0; q < PP; ++q) xv[q] = on[q] ? xs[rbase + wo * s * Ci + xoff[q]] : 0.f;
 #pragma unroll
           for (int c = 0; c < CO; c += 4) {
             const f32x4 dv = *reinterpret_cast<const f32x4*>(dr + wo * CO + c);
-            acc[c] += xv * dv[0]; acc[c + 1] += xv * dv[1]; acc[c + 2] += xv * dv[2]; acc[c + 3] += xv * dv[3];
+#pragma unroll
+            for (int q = 0; q < PP; ++q) {
+              acc[q][c] += xv[q] * dv[0]; acc[q][c + 1] += xv[q] * dv[1]; acc[q][c + 2] += xv[q] * dv[2]; acc[q][c + 3] += xv[q] * dv[3];
+            }
           }
         }
       }
     }
   }
-  if (active) {
+#pragma unroll
+  for (int q = 0; q < PP; ++q) {
+    if (!on[q]) continue;
+    const int pr = (PP == 1 ? threadIdx.x % npair : threadIdx.x + q * 256);
     float* p = part + ((long)blockIdx.x * G + g) * (npair * CO) + (long)pr * CO;
 #pragma unroll
-    for (int c = 0; c < CO; c += 4) st4(p + c, f32x4{acc[c], acc[c + 1], acc[c + 2], acc[c + 3]});
+    for (int c = 0; c < CO; c += 4) st4(p + c, f32x4{acc[q][c], acc[q][c + 1], acc[q][c + 2], acc[q][c + 3]});
   }
 }
 
@@ -187,10 +217,10 @@ int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, flo
 using namespace avsr;
 #define S_(x) ((hipStream_t)(x))
 
-static bool direct_ok(int Ci, int Co) { return Ci * Co <= 256 && 9 * Ci <= 256 && Co % 4 == 0 && (Ci % 4 == 0 || Ci < 4); }
+static bool direct_ok(int Ci, int Co) { return Ci * Co <= 1024 && 9 * Ci <= 512 && Co % 4 == 0 && (Ci % 4 == 0 || Ci < 4); }
 
 extern "C" int avsr_conv3x3_supported(int32_t Ci, int32_t Co, int32_t H, int32_t W) {
-  return direct_ok(Ci, Co) && (Co == 4 || Co == 8 || Co == 16) && (long)((H + 2) * (W + 2) * Ci + H * W * Co) * 4 <= 150 * 1024;
+  return direct_ok(Ci, Co) && (Co == 4 || Co == 8 || Co == 16 || Co == 32) && (long)((H + 2) * (W + 2) * Ci + H * W * Co) * 4 <= 150 * 1024;
 }
 
 // flip = 0: forward conv (x [N,H,W,Ci] -> y [N,Ho,Wo,Co], w = TF kernel [3,3,Ci,Co], bias may be NULL).
@@ -199,7 +229,7 @@ extern "C" int avsr_conv3x3(const float* x, const float* w, const float* bias, f
                             int32_t Co, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, int32_t flip, float beta,
                             void* stream) {
   if (!x || !w || !y || N <= 0 || !direct_ok(flip ? Co : Ci, flip ? Ci : Co) || Co % 4 || (flip && stride != 1)) return AVSR_ERR_ARG;
-  const long pix = (long)N * Ho * Wo;
+  const long pix = (long)N * Ho * ((Wo + 1) / 2);       // one thread per pair of output pixels
   const size_t lds = sizeof(float) * 9 * Ci * Co;
   if (Co % 16 == 0) hipLaunchKernelGGL((conv3x3_kernel<16>), dim3((unsigned)((pix + 255) / 256), Co / 16), dim3(256), lds, S_(stream), x, w, bias, y, N, H,
                                        W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, flip, beta);
@@ -229,10 +259,10 @@ extern "C" int avsr_conv3x3_bwd_weight(const float* x, const float* dy, float* d
                                        int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, float beta, float* scratch,
                                        int64_t scratch_floats, void* stream) {
   if (!x || !dy || !dw || !scratch || N <= 0 || !avsr_conv3x3_supported(Ci, Co, H, W) || pad_t > 1 || pad_l > 1) return AVSR_ERR_ARG;
-  if (Co != 4 && Co != 8 && Co != 16) return AVSR_ERR_ARG;
-  const int nout = 9 * Ci * Co, G = 256 / (9 * Ci);
-  if (G < 1) return AVSR_ERR_ARG;
-  int fpb = 4;
+  if (Co != 4 && Co != 8 && Co != 16 && Co != 32) return AVSR_ERR_ARG;
+  const int PP = 9 * Ci > 256 ? 2 : 1;
+  const int nout = 9 * Ci * Co, G = PP == 1 ? 256 / (9 * Ci) : 1;
+  int fpb = H * W <= 128 ? 16 : 4;                      // small maps: more frames per block (fewer partial rows)
   int nblk = (N + fpb - 1) / fpb;
   if ((long)nblk * G * nout > scratch_floats) {
     nblk = (int)(scratch_floats / ((long)G * nout));
@@ -243,15 +273,16 @@ extern "C" int avsr_conv3x3_bwd_weight(const float* x, const float* dy, float* d
   const size_t lds = sizeof(float) * ((size_t)(H + 2) * (W + 2) * Ci + (size_t)((Ho * Wo * Co + 3) & ~3));
   static bool big_lds = false;                          // more than 64 KB of dynamic LDS needs the attribute (set once, outside any capture)
   if (!big_lds) {
-    if (hipFuncSetAttribute((const void*)conv3x3_bwd_weight_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv3x3_bwd_weight_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv3x3_bwd_weight_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return AVSR_ERR_HIP;
+#define BW_ATTR(CO_, PP_) \
+    if (hipFuncSetAttribute((const void*)conv3x3_bwd_weight_kernel<CO_, PP_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return AVSR_ERR_HIP;
+    BW_ATTR(4, 1) BW_ATTR(8, 1) BW_ATTR(16, 1) BW_ATTR(32, 1) BW_ATTR(4, 2) BW_ATTR(8, 2) BW_ATTR(16, 2) BW_ATTR(32, 2)
+#undef BW_ATTR
     big_lds = true;
   }
-#define BW_GO(CO_) hipLaunchKernelGGL((conv3x3_bwd_weight_kernel<CO_>), dim3(nblk), dim3(256), lds, S_(stream), x, dy, scratch, N, H, W, Ci, stride, \
-                                      pad_t, pad_l, Ho, Wo, fpb)
-  if (Co == 16) BW_GO(16); else if (Co == 8) BW_GO(8); else BW_GO(4);
+#define BW_GO(CO_, PP_) hipLaunchKernelGGL((conv3x3_bwd_weight_kernel<CO_, PP_>), dim3(nblk), dim3(256), lds, S_(stream), x, dy, scratch, N, H, W, Ci, \
+                                           stride, pad_t, pad_l, Ho, Wo, fpb)
+  if (PP == 1) { if (Co == 32) BW_GO(32, 1); else if (Co == 16) BW_GO(16, 1); else if (Co == 8) BW_GO(8, 1); else BW_GO(4, 1); }
+  else { if (Co == 32) BW_GO(32, 2); else if (Co == 16) BW_GO(16, 2); else if (Co == 8) BW_GO(8, 2); else BW_GO(4, 2); }
 #undef BW_GO
   AVSR_CHECK_LAUNCH();
   return avsr_colsum_final_launch(scratch, nblk * G, dw, nout, 1.0f, beta, stream);

@@ -29,7 +29,8 @@ def _close(a, b, tol=2e-5):
     return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
 
 
-@pytest.mark.parametrize("N,H,Ci,Co,s", [(3, 12, 3, 8, 1), (2, 12, 8, 8, 1), (2, 12, 8, 16, 2), (2, 9, 16, 16, 1), (5, 9, 16, 16, 2), (2, 7, 4, 4, 2)])
+@pytest.mark.parametrize("N,H,Ci,Co,s", [(3, 12, 3, 8, 1), (2, 12, 8, 8, 1), (2, 12, 8, 16, 2), (2, 9, 16, 16, 1), (5, 9, 16, 16, 2), (2, 7, 4, 4, 2),
+                                        (3, 18, 16, 32, 2), (19, 9, 32, 32, 1)])
 def test_direct_conv3x3_forward_and_gradients(N, H, Ci, Co, s):
     from avsr_tf1_amd import ops
     rng = np.random.default_rng(H * 100 + Ci * 10 + Co + s)
