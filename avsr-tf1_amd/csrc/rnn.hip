@@ -11,6 +11,7 @@
 
 extern "C" int avsr_step_launch_raw(const void* launch, void* stream);
 int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
+int avsr_rnn_fwd_persistent_pair(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
 int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
 int avsr_rnn_bwd_persistent_split(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
 
@@ -61,7 +62,9 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
   if (!st || n <= 0 || n > AVSR_MAX_STACKS) return AVSR_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   {
-    const int rc = run_persistent(avsr_rnn_fwd_persistent, st, n, stream);   // one launch for the whole sequence when it fits
+    int rc = run_persistent(avsr_rnn_fwd_persistent_pair, st, n, stream);    // one launch for the whole sequence when it fits:
+    if (rc != AVSR_ERR_UNSUPPORTED) return rc;                                // 16-row groups on XCD pairs first (mode bit 3),
+    rc = run_persistent(avsr_rnn_fwd_persistent, st, n, stream);             // then 8-row groups per XCD / the agent-scope form
     if (rc != AVSR_ERR_UNSUPPORTED) return rc;
   }
   int nsteps = 0, ntask_max = 0;

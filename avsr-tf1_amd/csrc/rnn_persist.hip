@@ -350,8 +350,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int len_a = aok ? (tk.len ? tk.len[ab] : T) : 0;
   const int xrow = (int)(ab * tk.x_sb) + 4 * q, hrow = (int)(ab * tk.hsr_sb) + 4 * q;
   const int x_st = (int)tk.x_st, h_st = (int)tk.hsr_st;
-  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)tk.x_r, 0, 0xffffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t h_rs = __builtin_amdgcn_make_buffer_rsrc((void*)tk.hs_r, 0, 0xffffffff, 0x00020000);
+  // unconditional raw buffer loads, out-of-range offset = reads zero: exact vmcnt counting keeps the prefetches in flight
+  const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(tk.x_r), h_rs = make_rsrc(tk.hs_r), z_rs = make_rsrc(tk.gates);
   const bool has_low = !hoisted;
   // progress words: 32 per (task, group); wave 0 polls own (lanes 0-31) and lower (lanes 32-63) in one load
   int* const my_flag = tk.done + g * 32 + ct;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int c = 0; c < P_XC; ++c) {
       const int k = (xg0 + c) * 16;
-      dst[c] = (c < nxw && v && k + 4 * q < Kx) ? ldx_sc1(x_rs, xo + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      dst[c] = ldb_sc1(x_rs, (c < nxw && v && k + 4 * q < Kx) ? (xo + k) * 4 : P_OOB);
     }
   };
   if (has_low) {
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     load_x(0, xcur);
   }
   f32x4 znext = {0.f, 0.f, 0.f, 0.f};
-  if (eok && hoisted && 0 < len_b) znext = ld4(gates_p + (long)(rec_b + (reverse ? len_b - 1 : 0) * H) * 4);
+  znext = ldb4(z_rs, (eok && hoisted && 0 < len_b) ? (rec_b + (reverse ? len_b - 1 : 0) * H) * 16 : P_OOB);
 #ifdef PERSIST_TIMING
   long tm[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int c = 0; c < P_HC; ++c) {
       const int k = (hg0 + c) * 16;
-      hv[c] = (c < nhw && avalid && t > 0 && k + 4 * q < H) ? ldx_sc1(h_rs, ho_ + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      hv[c] = ldb_sc1(h_rs, (c < nhw && avalid && t > 0 && k + 4 * q < H) ? (ho_ + k) * 4 : P_OOB);
     }
 #ifdef PERSIST_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // timing build only: isolate the recurrent-operand latency
@@ -444,11 +444,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int e = 0; e < 4; ++e)
               acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xcur[c][e], wa[c][nt][e], acc[nt], 0, 0, 0);
         }
-      if (t + 1 < T) load_x(t + 1, xcur);      // refill in place: consumed a step from now
+      load_x(t + 1 < T ? t + 1 : T, xcur);     // refill in place: consumed a step from now (past the end: nothing is fetched)
     }
     // hoisted x.Wx of the NEXT step (cold in HBM).  Issued last: vmcnt retires in order, so a slow load must be
     // younger than the recurrent operands or it would stall their wait.
-    if (eok && hoisted && t + 1 < len_b) znext = ld4(gates_p + (long)(rec_b + (reverse ? len_b - 2 - t : t + 1) * H) * 4);
+    znext = ldb4(z_rs, (eok && hoisted && t + 1 < len_b) ? (rec_b + (reverse ? len_b - 2 - t : t + 1) * H) * 16 : P_OOB);
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int c = 0; c < P_HC; ++c)
@@ -556,7 +556,7 @@ static int build_tasks(const avsr_rnn_stack* st, int n, bool local, int32_t* syn
       const avsr_rnn_layer& Ly = S.layer[l];
       if (L.ntask >= P_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
       const int H = Ly.units, in = Ly.in_dim;
-      if ((long)S.B * (S.T + 2) * (Ly.ld_out > 4 * H ? Ly.ld_out : 4 * H) >= (1L << 30)) return AVSR_ERR_UNSUPPORTED;
+      if ((long)S.B * (S.T + 2) * (Ly.ld_out > 4 * H ? Ly.ld_out : 4 * H) >= (1L << 29)) return AVSR_ERR_UNSUPPORTED;   // byte offsets < 2^31
       if (H % 8 || !Ly.out || H > 64 * P_HC || (!Ly.hoisted && in > 64 * P_XC) || in % 4) return AVSR_ERR_UNSUPPORTED;
       if (!Ly.hoisted && l == 0) return AVSR_ERR_UNSUPPORTED;
       if (S.seed && !Ly.hs_seq) return AVSR_ERR_UNSUPPORTED;

@@ -153,7 +153,8 @@ int avsr_rnn_bwd(const avsr_rnn_stack* stacks, int32_t n_stacks, void* stream);
 int avsr_rnn_set_persistent(int32_t* sync, int64_t ints);
 /* Which persistent kernels may be used: bit 0 = agent-scope (any placement, 16-row tiles), bit 1 = XCD-local
  * (8-row groups bound to the XCD their workgroups actually run on; tried first) and the fused persistent BPTT,
- * bit 2 = split persistent BPTT (needs avsr_rnn_set_persistent_scratch; opt-in).  Default 3. */
+ * bit 2 = split persistent BPTT (needs avsr_rnn_set_persistent_scratch; opt-in), bit 3 = pair-layout forward (16-row groups
+ * on XCD pairs; opt-in).  Default 3: the two opt-in forms measured slower on the benchmark shape. */
 int avsr_rnn_set_persistent_mode(int mode);
 /* Float device scratch for the split persistent BPTT (bit 2 of the mode): one [B,T,units] operand per encoder cell that has a
  * layer above it.  NULL / too small: that form is skipped (the fused form or the per-step launches run instead). */

@@ -98,7 +98,7 @@ def _oracle_stack(x, lens, Ws, bs, reverse, R_out, R_h, R_c):
 
 
 @pytest.mark.parametrize("B", [19, 70])      # 70: more than one 64-row slice of the persistent kernels
-@pytest.mark.parametrize("persistent", [0, 1, 2, 6])     # 6: + split persistent BPTT
+@pytest.mark.parametrize("persistent", [0, 1, 2, 6, 10])     # 6: + split persistent BPTT; 10: pair-layout forward
 @pytest.mark.parametrize("reverse", [0, 1])
 @pytest.mark.parametrize("units", [(32,), (32, 48, 32)])
 def test_rnn_stack_fwd_bwd(units, reverse, persistent, B):

@@ -198,7 +198,7 @@ FULL_WIDTH = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["0", "3", "7"])
+@pytest.mark.parametrize("mode", ["0", "3", "7", "11"])
 @pytest.mark.parametrize("case,over", FULL_WIDTH)
 def test_full_width_train_step(case, over, mode, monkeypatch):
     from avsr_tf1_amd import ops
