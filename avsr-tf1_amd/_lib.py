@@ -103,7 +103,7 @@ _STRUCTS = {"avsr_mat": Mat, "avsr_gemm_desc": GemmDesc, "avsr_rnn_layer": RnnLa
 EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_rnn_set_persistent", "avsr_rnn_set_persistent_mode", "avsr_rnn_set_persistent_scratch", "avsr_attn_rnn_fwd",
            "avsr_attn_rnn_bwd", "avsr_beam_gather_tree", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_colsum",
            "avsr_batchnorm_fwd", "avsr_batchnorm_fwd_ex", "avsr_batchnorm_bwd", "avsr_batchnorm_xhat", "avsr_im2col", "avsr_col2im",
-           "avsr_relu", "avsr_relu_bwd", "avsr_add", "avsr_conv3x3_supported", "avsr_conv3x3", "avsr_conv3x3_bwd_data_s2",
+           "avsr_relu", "avsr_relu_bwd", "avsr_add", "avsr_selu", "avsr_selu_bwd", "avsr_conv3x3_supported", "avsr_conv3x3", "avsr_conv3x3_bwd_data_s2",
            "avsr_conv3x3_bwd_weight", "avsr_embed_labels", "avsr_embed_grad", "avsr_dropout_rows", "avsr_seq_loss",
            "avsr_au_loss", "avsr_normed_v", "avsr_normed_v_bwd", "avsr_reduce_scalar", "avsr_l2_regularise",
            "avsr_global_norm", "avsr_adam_step", "avsr_prof_begin", "avsr_prof_end"]
@@ -158,6 +158,8 @@ def load():
         "avsr_relu": [vp, vp, i64, vp],
         "avsr_relu_bwd": [vp, vp, vp, i64, vp],
         "avsr_add": [vp, vp, vp, i64, vp],
+        "avsr_selu": [vp, vp, i64, vp],
+        "avsr_selu_bwd": [vp, vp, vp, i64, vp],
         "avsr_conv3x3_supported": [i32, i32, i32, i32],
         "avsr_conv3x3": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
         "avsr_conv3x3_bwd_data_s2": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],

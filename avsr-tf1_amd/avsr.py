@@ -97,8 +97,8 @@ class AVSR(object):
                               ("optimiser", optimiser, 'Adam')):
             if val != ok:
                 raise NotImplementedError("%s=%r is a non-default option of the reference that the HIP engine does not build" % (name, val))
-        if tuple(input_dense_layers) != (0,) or label_smoothing != 0.0:
-            raise NotImplementedError("input_dense_layers / label_smoothing are not built")
+        if label_smoothing != 0.0:
+            raise NotImplementedError("label_smoothing is not built")
         if video_processing is not None and video_processing not in ('features', 'resnet_cnn'):
             if 'cnn' in video_processing:
                 raise NotImplementedError("video_processing=%r: only the default `resnet_cnn` front-end is built" % video_processing)
@@ -140,7 +140,8 @@ class AVSR(object):
             audio_dropout=tuple(audio_encoder_dropout_probability), decoder_dropout=tuple(decoder_dropout_probability),
             sampling_probability=sampling_probability_outputs,
             video_processing=video_processing if video_processing is not None else 'features',
-            cnn_filters=tuple(cnn_filters), cnn_dense_units=cnn_dense_units, video_hw=video_hw)
+            cnn_filters=tuple(cnn_filters), cnn_dense_units=cnn_dense_units, video_hw=video_hw,
+            input_dense_layers=tuple(input_dense_layers))
         self._model = Seq2SeqModel(self._cfg, seed=kwargs.get('seed', 0))
         self._shuffle_seed = kwargs.get('shuffle_seed')        # None = a fresh order every run, as tf.data's unseeded shuffle(5000)
         self._trainer = DataParallelTrainer(self._model, None, use_graph=False)   # bucketed batches: shapes vary per step

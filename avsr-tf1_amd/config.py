@@ -49,6 +49,7 @@ class ModelConfig:
     cnn_filters: Tuple[int, ...] = (8, 16, 32, 64)
     cnn_dense_units: int = 128
     video_hw: Tuple[int, int, int] = (36, 36, 3)
+    input_dense_layers: Tuple[int, ...] = (0,)                      # avsr/avsr.py:38, encoder.py:148-171
 
     # -- same helpers/validation rules as the reference wiring (error types as in the reference) --
     def streams(self) -> List[str]:
@@ -67,6 +68,10 @@ class ModelConfig:
 
     def feat(self, stream):
         return self.video_feat if stream == "video" else self.audio_feat
+
+    def layer0_in(self, stream: str) -> int:
+        """Width of the first encoder layer's input: the last input Dense layer if any, else the feature size."""
+        return self.input_dense_layers[-1] if self.input_dense_layers[0] > 0 else self.feat(stream)
 
     def memory_depth(self, stream: str) -> int:
         return self.units(stream)[-1] * (2 if self.encoder_type == "bidirectional" else 1)
@@ -114,6 +119,8 @@ class ModelConfig:
                 raise ValueError("video_feat must equal cnn_dense_units when the CNN front-end produces the video features")
             if any(c % 4 for c in self.cnn_filters) or self.cnn_dense_units % 4 or len(self.cnn_filters) < 1:
                 raise ValueError("cnn_filters / cnn_dense_units must be multiples of 4 for the HIP engine")
+        if self.input_dense_layers[0] > 0 and any(u <= 0 or u % 4 for u in self.input_dense_layers):
+            raise ValueError("input_dense_layers must be positive multiples of 4 for the HIP engine")
         if len(self.decoder_units) != 1:
             raise NotImplementedError("multi-layer decoders are not built yet")
         if not self.streams():

@@ -113,6 +113,22 @@ __global__ void relu_kernel(const float* x, float* y, long n) {
 __global__ void relu_bwd_kernel(const float* y, const float* dy, float* dx, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
+// tf.nn.selu: scale * (x > 0 ? x : alpha * (exp(x) - 1))   (input Dense layers, encoder.py:148-171)
+#define SELU_SCALE 1.0507009873554805f
+#define SELU_ALPHA 1.6732632423543772f
+__global__ void selu_kernel(const float* z, float* y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float x = z[i];
+    y[i] = SELU_SCALE * (x > 0.f ? x : SELU_ALPHA * (expf(x) - 1.0f));
+  }
+}
+// dz = dy * selu'(z)
+__global__ void selu_bwd_kernel(const float* z, const float* dy, float* dz, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float x = z[i];
+    dz[i] = dy[i] * SELU_SCALE * (x > 0.f ? 1.0f : SELU_ALPHA * expf(x));
+  }
+}
 // out = a + b
 __global__ void add_kernel(const float* a, const float* b, float* out, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
@@ -193,6 +209,19 @@ extern "C" int avsr_relu_bwd(const float* y, const float* dy, float* dx, int64_t
 extern "C" int avsr_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
   if (!a || !b || !out || n <= 0) return AVSR_ERR_ARG;
   hipLaunchKernelGGL(add_kernel, dim3(blocks_for_n(n)), dim3(256), 0, S_(stream), a, b, out, (long)n);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_selu(const float* z, float* y, int64_t n, void* stream) {
+  if (!z || !y || n <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(selu_kernel, dim3(blocks_for_n(n)), dim3(256), 0, S_(stream), z, y, (long)n);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+extern "C" int avsr_selu_bwd(const float* z, const float* dy, float* dz, int64_t n, void* stream) {
+  if (!z || !dy || !dz || n <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(selu_bwd_kernel, dim3(blocks_for_n(n)), dim3(256), 0, S_(stream), z, dy, dz, (long)n);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

@@ -122,6 +122,8 @@ class Seq2SeqModel:
         self.l2_segments = [(self._train_off[n], int(np.prod(self.inv[n][0]))) for n in self._train_off if PR.is_l2(n)]
         self.cnn_l2_segments = [(self._train_off[n], int(np.prod(self.inv[n][0]))) for n in self._train_off if PR.is_cnn_l2(n)]
         self.use_cnn = cfg.video_units is not None and cfg.video_processing == "resnet_cnn"
+        self.dense_l2_segments = [(self._train_off[n], int(np.prod(self.inv[n][0]))) for n in self._train_off if PR.is_dense_l2(n)]
+        self.n_dense = len(cfg.input_dense_layers) if cfg.input_dense_layers[0] > 0 else 0
         # ---- derived transposed operands -----------------------------------------------------------
         self._tjobs, self.Tr = [], {}
         tn = 0
@@ -207,15 +209,18 @@ class Seq2SeqModel:
             F, units = cfg.feat(s), cfg.units(s)
             attentive = cfg.architecture == "av_align" and s == "audio"
             nplain = len(units) - 1 if attentive else len(units)
-            E = {"T": T, "F": F, "units": units, "nplain": nplain, "attentive": attentive}
+            F0 = cfg.layer0_in(s)                                     # width of the first RNN layer's input (after the input Dense stack)
+            E = {"T": T, "F": F, "F0": F0, "units": units, "nplain": nplain, "attentive": attentive}
+            if self.n_dense:                                          # encoder.py:148-171: pre-activations, outputs and their gradients
+                E["dense"] = [dict(z=z(B * T, u), a=z(B * T, u), da=z(B * T, u)) for u in cfg.input_dense_layers]
             E["xn"], E["dxn"], E["xhat"] = z(B * T, F), z(B * T, F), z(B * T, F)
             if s == "video" and self.use_cnn:
                 from .cnn import LipCNN
                 E["cnn"] = LipCNN(self, B * T)                       # lip crops -> F = cnn_dense_units features
                 E["dfeat"] = z(B * T, F)
             if cfg.use_dropout:
-                E["xd"] = {d: z(B * T, F) for d in cfg.directions()}     # layer-0 input after each direction's input mask
-                E["dx_tmp"] = z(B * T, F)
+                E["xd"] = {d: z(B * T, F0) for d in cfg.directions()}    # layer-0 input after each direction's input mask
+                E["dx_tmp"] = z(B * T, F0)
             E["mean"], E["invstd"] = z(F), z(F)
             Dm = units[-1] * ndir
             if not attentive:
@@ -248,7 +253,7 @@ class Seq2SeqModel:
         if cfg.architecture == "av_align":
             A = ws["enc"]["audio"]
             u = cfg.audio_units[-1]
-            in_w = cfg.audio_units[-2] if len(cfg.audio_units) > 1 else cfg.audio_feat
+            in_w = cfg.audio_units[-2] if len(cfg.audio_units) > 1 else cfg.layer0_in("audio")
             A["blk"] = self._make_block(ws, B, Ta, u, in_w, [("video", cfg.attention_type[0][0])], "audio/enc/fw/l%d" % (len(cfg.audio_units) - 1),
                                         ["audio/enc/att0"], Tv=Tv, Ta=Ta, greedy=False)
         Ldec = L
@@ -334,7 +339,7 @@ class Seq2SeqModel:
                 st.consumer_keep = k[0]
                 st.consumer_stream = encoder_cell_id(s, d, E["nplain"]) * 4
                 st.consumer_width = E["units"][-2] + E["units"][-1]
-        i = E["F"]
+        i = E["F0"]
         for l in range(E["nplain"]):
             u = E["units"][l]
             Ld = E["layers"][(d, l)]
@@ -387,20 +392,30 @@ class Seq2SeqModel:
                 E["xin"] = E["xn"]
             else:
                 E["xin"] = x
+            F0 = E["F0"]
+            E["xin0"], E["dxin0"] = E["xin"], E["dxn"]
+            if self.n_dense:                     # Dense(units, selu, use_bias=False) stack between BN and the RNN
+                a_prev, w_prev = E["xin"], F
+                for k, Dn in enumerate(E["dense"]):
+                    u = cfg.input_dense_layers[k]
+                    ops.gemm(ops.mat(a_prev, w_prev), self.P[f"{s}/dense{k}/kernel"].mat(u), ops.mat(Dn["z"], u), B * T, u, w_prev)
+                    ops.selu(Dn["z"], Dn["a"], B * T * u)
+                    a_prev, w_prev = Dn["a"], u
+                E["xin0"], E["dxin0"] = a_prev, E["dense"][-1]["da"]
             if E["nplain"] == 0:
                 continue
             for d in cfg.directions():
                 u0 = E["units"][0]
                 W0 = self.P[self._kn(f"{s}/enc/{d}/l0")[0]]
-                xin = E["xin"]
+                xin = E["xin0"]
                 if self._sdrop(s):               # DropoutWrapper input mask of the layer-0 cell of this direction
                     xin = E["xd"][d]
-                    ops.dropout_rows(ops.mat(E["xin"], F), ops.mat(xin, F), B * T, F, self.step, encoder_cell_id(s, d, 0) * 4,
-                                     self._keeps(s)[0], F)
+                    ops.dropout_rows(ops.mat(E["xin0"], F0), ops.mat(xin, F0), B * T, F0, self.step, encoder_cell_id(s, d, 0) * 4,
+                                     self._keeps(s)[0], F0)
                 G = self.G
-                ops.gemm(ops.mat(xin, F), W0.mat(G * u0), ops.mat(E["layers"][(d, 0)]["gates"], G * u0), B * T, G * u0, F)
+                ops.gemm(ops.mat(xin, F0), W0.mat(G * u0), ops.mat(E["layers"][(d, 0)]["gates"], G * u0), B * T, G * u0, F0)
                 if self.gru:                     # candidate kernel's input part, hoisted into the c~ record
-                    ops.gemm(ops.mat(xin, F), self.P[f"{s}/enc/{d}/l0/cand_kernel"].mat(u0), ops.mat(E["layers"][(d, 0)]["cs"], u0), B * T, u0, F)
+                    ops.gemm(ops.mat(xin, F0), self.P[f"{s}/enc/{d}/l0/cand_kernel"].mat(u0), ops.mat(E["layers"][(d, 0)]["cs"], u0), B * T, u0, F0)
                 stacks.append(self._rnn_stack(ws, s, d, B, len_t))
         self._run_stacks(stacks, ops.rnn_fwd)
         for s in cfg.streams():
@@ -510,10 +525,10 @@ class Seq2SeqModel:
         self._run_stacks(stacks, ops.rnn_bwd)
         for s in cfg.streams():
             E = ws["enc"][s]
-            T, F = E["T"], E["F"]
+            T, F, F0 = E["T"], E["F"], E["F0"]
             first = True
             for d in cfg.directions():
-                i = F
+                i = F0
                 for l in range(E["nplain"]):
                     u = E["units"][l]
                     Ld = E["layers"][(d, l)]
@@ -523,7 +538,7 @@ class Seq2SeqModel:
                     dg = ops.mat(Ld["dgates"], G * u)
                     drop = self._sdrop(s)
                     if l == 0:
-                        a_x = ops.mat(E["xd"][d] if drop else E["xin"], F)
+                        a_x = ops.mat(E["xd"][d] if drop else E["xin0"], F0)
                     elif drop:
                         a_x = E["layers"][(d, l - 1)]["xt_seq"].mat(0)
                     else:
@@ -540,20 +555,29 @@ class Seq2SeqModel:
                         self._gemm_tn(ops.mat(Ld["rh"], u), dpc, Gc.mat(u, row0=i), u, u, B * T)
                         ops.colsum(dpc, B * T, u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/enc/{d}/l{l}/cand_bias"].off)
                     i = u
-                if E["nplain"] > 0 and (cfg.batch_normalisation or "cnn" in E):
+                if E["nplain"] > 0 and (cfg.batch_normalisation or "cnn" in E or self.n_dense):
                     u0, G = E["units"][0], self.G
                     W0 = self.P[self._kn(f"{s}/enc/{d}/l0")[0]]
                     L0 = E["layers"][(d, 0)]
-                    tgt = E["dx_tmp"] if self._sdrop(s) else E["dxn"]
+                    tgt = E["dx_tmp"] if self._sdrop(s) else E["dxin0"]
                     beta0 = 0.0 if (self._sdrop(s) or first) else 1.0
-                    ops.gemm(ops.mat(L0["dgates"], G * u0), W0.mat(G * u0), ops.mat(tgt, F), B * T, F, G * u0, trans_b=1, beta=beta0)
+                    ops.gemm(ops.mat(L0["dgates"], G * u0), W0.mat(G * u0), ops.mat(tgt, F0), B * T, F0, G * u0, trans_b=1, beta=beta0)
                     if self.gru:
-                        ops.gemm(ops.mat(L0["dpc"], u0), self.P[f"{s}/enc/{d}/l0/cand_kernel"].mat(u0), ops.mat(tgt, F), B * T, F, u0,
+                        ops.gemm(ops.mat(L0["dpc"], u0), self.P[f"{s}/enc/{d}/l0/cand_kernel"].mat(u0), ops.mat(tgt, F0), B * T, F0, u0,
                                  trans_b=1, beta=1.0)
                     if self._sdrop(s):
-                        ops.dropout_rows(ops.mat(E["dx_tmp"], F), ops.mat(E["dxn"], F), B * T, F, self.step,
-                                         encoder_cell_id(s, d, 0) * 4, self._keeps(s)[0], F, accumulate=not first)
+                        ops.dropout_rows(ops.mat(E["dx_tmp"], F0), ops.mat(E["dxin0"], F0), B * T, F0, self.step,
+                                         encoder_cell_id(s, d, 0) * 4, self._keeps(s)[0], F0, accumulate=not first)
                     first = False
+            if self.n_dense:
+                # back through the input Dense stack: d z = d a * selu'(z);  d W += a_prev^T d z;  d a_prev = d z W^T
+                for k in reversed(range(self.n_dense)):
+                    Dn, u = E["dense"][k], cfg.input_dense_layers[k]
+                    a_prev, w_prev = (E["dense"][k - 1]["a"], cfg.input_dense_layers[k - 1]) if k else (E["xin"], F)
+                    ops.selu_bwd(Dn["z"], Dn["da"], Dn["z"], B * T * u)          # in place: z is not needed again
+                    self._gemm_tn(ops.mat(a_prev, w_prev), ops.mat(Dn["z"], u), self.Gr[f"{s}/dense{k}/kernel"].mat(u), w_prev, u, B * T)
+                    g_prev = E["dense"][k - 1]["da"] if k else E["dxn"]
+                    ops.gemm(ops.mat(Dn["z"], u), self.P[f"{s}/dense{k}/kernel"].mat(u), ops.mat(g_prev, w_prev), B * T, w_prev, u, trans_b=1)
             if cfg.batch_normalisation:
                 # (a 1-layer attentive encoder wrote dxn in _av_align_backward)
                 ops.batchnorm_xhat(E["x"], E["mean"], E["invstd"], E["xhat"], B * T, F)
@@ -741,7 +765,7 @@ class Seq2SeqModel:
         T, H, Ein = E["T"], blk["H"], blk["E"]
         kname = self._kn(blk["cell"])[0]
         if self._sdrop("audio") and E["nplain"] == 0:
-            ops.dropout_rows(ops.mat(E["xin"], E["F"]), ops.mat(E["xd"]["fw"], E["F"]), B * T, E["F"], self.step, blk["cell_id"] * 4,
+            ops.dropout_rows(ops.mat(E["xin0"], E["F0"]), ops.mat(E["xd"]["fw"], E["F0"]), B * T, E["F0"], self.step, blk["cell_id"] * 4,
                              blk["keep"][0], Ein + blk["A"])
         xin = self._av_xin(E)
         ops.gemm(xin, self.P[kname].mat(self.G * H), ops.mat(blk["gates"], self.G * H), B * T, self.G * H, Ein)
@@ -755,7 +779,7 @@ class Seq2SeqModel:
     def _av_xin(self, E):
         """Hoisted input of the attention-wrapped layer (already carrying that cell's input mask under dropout)."""
         if E["nplain"] == 0:
-            return ops.mat(E["xd"]["fw"] if self._sdrop("audio") else E["xin"], E["F"])
+            return ops.mat(E["xd"]["fw"] if self._sdrop("audio") else E["xin0"], E["F0"])
         Ld = E["layers"][("fw", E["nplain"] - 1)]
         return (Ld["xt_seq"] if self._sdrop("audio") else Ld["out"]).mat(0)
 
@@ -769,7 +793,7 @@ class Seq2SeqModel:
         d.dcell_ext = None if luong else ops.fptr(blk["dcell_ext"])
         d.dh_final, d.dc_final = ops.fptr(blk["dhf_in"]), ops.fptr(blk["dcf_in"])
         if E["nplain"] == 0:
-            dxin, beta = ops.mat(E["dx_tmp"] if self._sdrop("audio") else E["dxn"], E["F"]), 0.0
+            dxin, beta = ops.mat(E["dx_tmp"] if self._sdrop("audio") else E["dxin0"], E["F0"]), 0.0
         else:
             Ld = E["layers"][("fw", E["nplain"] - 1)]
             dxin, beta = Ld["dout"].mat(0), 0.0
@@ -777,7 +801,7 @@ class Seq2SeqModel:
         if self._sdrop("audio"):                 # gradient of the DROPPED input -> gradient of the layer below's output
             keep, W = blk["keep"][0], blk["E"] + blk["A"]
             if E["nplain"] == 0:
-                ops.dropout_rows(dxin, ops.mat(E["dxn"], E["F"]), B * E["T"], E["F"], self.step, blk["cell_id"] * 4, keep, W)
+                ops.dropout_rows(dxin, ops.mat(E["dxin0"], E["F0"]), B * E["T"], E["F0"], self.step, blk["cell_id"] * 4, keep, W)
             else:
                 ops.dropout_rows(dxin, dxin, B * E["T"], blk["E"], self.step, blk["cell_id"] * 4, keep, W)
 
@@ -927,6 +951,8 @@ class Seq2SeqModel:
             ops.l2_regularise(self.l2_segments, self.params, self.grads, cfg.recurrent_l2, self.loss, self.scratch)
         if self.use_cnn:                         # conv2d kernel_regularizer l2(0.001), seq2seq.py:180-184
             ops.l2_regularise(self.cnn_l2_segments, self.params, self.grads, 1e-3, self.loss, self.scratch)
+            if self.dense_l2_segments:           # the input Dense layers' l2(0.0001) sit in the same collection (reference quirk)
+                ops.l2_regularise(self.dense_l2_segments, self.params, self.grads, 1e-4, self.loss, self.scratch)
         ops.global_norm(self.grads, self.n_train, self.gnorm, self.scratch)
         ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.n_train, self.gnorm, self.step,
                       cfg.learning_rate, cfg.warmup_steps, cfg.max_gradient_norm if cfg.clip_gradients else 0.0)

@@ -284,3 +284,11 @@ def conv3x3_bwd_data_s2(dy, w, dx, N, H, W, Ci, Co, pad_t, pad_l, Ho, Wo, beta=0
 def conv3x3_bwd_weight(x, dy, dw, N, H, W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, scratch, beta=1.0):
     check(_L().avsr_conv3x3_bwd_weight(fptr(x), fptr(dy), fptr(dw), N, H, W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, float(beta), fptr(scratch),
                                        scratch.numel(), _s()), "avsr_conv3x3_bwd_weight")
+
+
+def selu(z, y, n):
+    check(_L().avsr_selu(fptr(z), fptr(y), int(n), _s()), "avsr_selu")
+
+
+def selu_bwd(z, dy, dz, n):
+    check(_L().avsr_selu_bwd(fptr(z), fptr(dy), fptr(dz), int(n), _s()), "avsr_selu_bwd")

@@ -76,8 +76,13 @@ def inventory(cfg: ModelConfig):
             inv[f"{stream}/bn/moving_mean"] = ((feat,), "plain", "zeros")
             inv[f"{stream}/bn/moving_variance"] = ((feat,), "plain", "ones")
         attentive = cfg.architecture == "av_align" and stream == "audio"
+        if cfg.input_dense_layers[0] > 0:                     # encoder.py:148-171: Dense(units, selu, use_bias=False)
+            w_in = feat
+            for k, u in enumerate(cfg.input_dense_layers):
+                inv[f"{stream}/dense{k}/kernel"] = ((w_in, u), "plain", "vs")
+                w_in = u
         for d in cfg.directions():
-            i = feat
+            i = cfg.layer0_in(stream)
             for l, u in enumerate(units):
                 extra = units[-1] if (attentive and l == len(units) - 1) else 0
                 _cell(inv, cfg, f"{stream}/enc/{d}/l{l}", i + extra, u)
@@ -140,6 +145,11 @@ def _attention(inv, prefix, att_type, depth, units):
 def is_cnn_l2(name):
     """conv2d kernel_regularizer l2(0.001) of the lip CNN (video.py:26; summed at seq2seq.py:180-184)."""
     return name.startswith("video/cnn/") and name.endswith("/kernel")
+
+
+def is_dense_l2(name):
+    """input Dense layers' l2(0.0001) (encoder.py:164): summed into the loss only on the CNN branch of seq2seq.py:180-184."""
+    return "/dense" in name and name.endswith("/kernel")
 
 
 def is_l2(name):

@@ -360,6 +360,9 @@ int avsr_conv3x3_bwd_weight(const float* x, const float* dy, float* dw, int32_t 
 int avsr_relu(const float* x, float* y, int64_t n, void* stream);
 int avsr_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
 int avsr_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* tf.nn.selu and its gradient (dz = dy * selu'(z)): the optional input Dense stack of the encoders (encoder.py:148-171) */
+int avsr_selu(const float* z, float* y, int64_t n, void* stream);
+int avsr_selu_bwd(const float* z, const float* dy, float* dz, int64_t n, void* stream);
 
 int avsr_batchnorm_xhat(const float* x, const float* mean, const float* invstd, float* xhat, int32_t rows, int32_t F,
                         void* stream);

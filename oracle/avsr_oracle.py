@@ -74,6 +74,13 @@ class OracleConfig:
     cnn_filters: Tuple[int, ...] = (8, 16, 32, 64)
     cnn_dense_units: int = 128
     video_hw: Tuple[int, int, int] = (36, 36, 3)
+    input_dense_layers: Tuple[int, ...] = (0,)                    # avsr.py:38; encoder.py:148-171 (SELU Dense stack, no bias)
+
+    def layer0_in(self, stream: str) -> int:
+        """Width of the first encoder layer's input: the last input Dense layer if any, else the feature size."""
+        if self.input_dense_layers[0] > 0:
+            return self.input_dense_layers[-1]
+        return self.video_feat if stream == "video" else self.audio_feat
 
     def streams(self) -> List[str]:
         s = []
@@ -291,8 +298,13 @@ def init_params(cfg: OracleConfig, seed: int = 2001) -> Dict[str, np.ndarray]:
             P[f"{stream}/bn/moving_mean"] = np.zeros((feat,), np.float32)
             P[f"{stream}/bn/moving_variance"] = np.ones((feat,), np.float32)
         attentive = cfg.architecture == "av_align" and stream == "audio"
+        if cfg.input_dense_layers[0] > 0:                        # Dense(units, selu, use_bias=False), variance-scaling init
+            w_in = feat
+            for i, u in enumerate(cfg.input_dense_layers):
+                P[f"{stream}/dense{i}/kernel"] = _variance_scaling(rng, (w_in, u))
+                w_in = u
         for d in cfg.directions():
-            in_dim = feat
+            in_dim = cfg.layer0_in(stream)
             for l, u in enumerate(units):
                 extra = units[-1] if (attentive and l == len(units) - 1) else 0   # + attention feedback
                 _cell_params(rng, cfg, f"{stream}/enc/{d}/l{l}", in_dim + extra, u, P)
@@ -634,6 +646,9 @@ def encode_stream(P, cfg: OracleConfig, stream: str, x: Tensor, lens: Tensor, tr
     T = x.shape[1]
     if cfg.batch_normalisation:
         x = batch_norm(x, P, f"{stream}/bn", training, bn_updates)
+    if cfg.input_dense_layers[0] > 0:                            # encoder.py:148-171, after _init_data (BN), before the RNN
+        for i in range(len(cfg.input_dense_layers)):
+            x = torch.selu(x @ P[f"{stream}/dense{i}/kernel"])
     if attended is not None:                                   # av_align: top layer attention-wrapped
         cells = _make_cells(P, cfg, stream, "fw", units, training, seed, T, lens)
         mech = _Mechanism(P, "audio/enc/att0", cfg.attention_type[0][0], attended[0], attended[1])
@@ -820,6 +835,11 @@ def loss_fn(P, cfg: OracleConfig, batch: Batch, logits: Tensor, m: _Model):
     if cfg.video_units is not None and cfg.video_processing == "resnet_cnn":
         for k in cnn_l2_names(P):                                # seq2seq.py:180-184
             total = total + 0.001 * 0.5 * torch.sum(P[k] ** 2)
+        # the same collection also holds the input Dense layers' l2(0.0001) regularisers (encoder.py:164): they reach the loss
+        # ONLY on this branch, i.e. only when a CNN front-end is configured -- a quirk of the reference, restated as is
+        for k in P:
+            if "/dense" in k and k.endswith("/kernel"):
+                total = total + 0.0001 * 0.5 * torch.sum(P[k] ** 2)
     if cfg.regress_aus and m.aux_loss is not None:
         total = total + cfg.au_loss_weight * m.aux_loss
     return total, seq

@@ -41,6 +41,16 @@ CASES = {
     "c4_bimodal_cnn": dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
                            attention_type=(("scaled_luong",), ("scaled_luong",)), regress_aus=True, video_processing="resnet_cnn",
                            cnn_filters=(8, 16, 32, 64), cnn_dense_units=16, video_feat=16),
+    # input_dense_layers (encoder.py:148-171): SELU Dense stack between BN and the first RNN layer
+    "bimodal_input_dense": dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
+                                attention_type=(("scaled_luong",), ("scaled_luong",)), regress_aus=True, input_dense_layers=(24, 16)),
+    "av_align_1layer_dense": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32,), audio_units=(32,),
+                                  attention_type=(("bahdanau",), ("luong",)), input_dense_layers=(24,)),
+    "video_cnn_dense_bi": dict(architecture="unimodal", encoder_type="bidirectional", video_units=(32, 32), audio_units=None,
+                               attention_type=(("scaled_luong",), ("scaled_luong",)), video_processing="resnet_cnn",
+                               cnn_filters=(8, 8, 16, 16), cnn_dense_units=16, video_feat=16, input_dense_layers=(24,)),
+    "dense_no_bn": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32),
+                        batch_normalisation=False, input_dense_layers=(16,)),
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
@@ -150,6 +160,9 @@ STOCH = [
     ("gru_audio_uni", dict(use_dropout=True, sampling_probability=0.3)),
     ("gru_video_bi_bahdanau", dict(use_dropout=True)),
     ("gru_av_align", dict(use_dropout=True, sampling_probability=0.3)),
+    ("bimodal_input_dense", dict(use_dropout=True, sampling_probability=0.2)),
+    ("av_align_1layer_dense", dict(use_dropout=True)),
+    ("video_cnn_dense_bi", dict(use_dropout=True)),
 ]
 
 

@@ -66,9 +66,11 @@ def _small(arch="bimodal", **kw):
     return cfg, O.init_params(cfg, seed=5), O.synthetic_batch(cfg, B=3, T_a=7, T_v=4, L=4, ragged=True)
 
 
-@pytest.mark.parametrize("arch,att", [("bimodal", "scaled_luong"), ("av_align", "scaled_luong"), ("unimodal", "normed_bahdanau")])
-def test_gradients_by_finite_differences(arch, att):
-    cfg, W, b = _small(arch, attention_type=((att,), (att,)))
+@pytest.mark.parametrize("arch,att,extra", [("bimodal", "scaled_luong", {}), ("av_align", "scaled_luong", {}),
+                                            ("unimodal", "normed_bahdanau", {}),
+                                            ("bimodal", "scaled_luong", dict(input_dense_layers=(6, 5)))])   # encoder.py:148-171
+def test_gradients_by_finite_differences(arch, att, extra):
+    cfg, W, b = _small(arch, attention_type=((att,), (att,)), **extra)
     r = O.train_step(W, None, cfg, b)
 
     def loss_of(Wn):
@@ -78,7 +80,8 @@ def test_gradients_by_finite_differences(arch, att):
 
     rng = np.random.default_rng(1)
     names = [k for k in O.trainable_names(W)]
-    for k in [names[i] for i in rng.choice(len(names), size=min(8, len(names)), replace=False)]:
+    picked = [names[i] for i in rng.choice(len(names), size=min(8, len(names)), replace=False)]
+    for k in picked + [n for n in names if "/dense" in n and n not in picked]:
         idx = tuple(int(rng.integers(0, s)) for s in W[k].shape)
         eps = 1e-5
         Wp = {n: v.astype(np.float64).copy() for n, v in W.items()}
