@@ -37,6 +37,7 @@ class ModelConfig:
     max_gradient_norm: float = 1.0
     learning_rate: float = 1e-3
     warmup_steps: int = 750
+    lr_decay_steps: int = 0                   # lr_decay=('cosine_restarts', N) (seq2seq.py:266-270); 0 = constant lr
     max_label_length: int = 150
     use_dropout: bool = False
     video_dropout: Tuple[float, float, float] = (0.9, 0.9, 0.9)     # keep probabilities (input, state, output), avsr.py:52-54

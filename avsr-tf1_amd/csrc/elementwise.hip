@@ -404,9 +404,17 @@ __global__ void reduce_scalar_kernel(const float* part, int n, float* out, int d
 
 // hyper: [0] step (as float-exact int32 via reinterpret), see avsr_adam_step
 __global__ void adam_kernel(float* p, float* g, float* m, float* v, long n, const float* gnorm, int32_t* step,
-                            float lr, int warmup, float clip, float b1, float b2, float eps, float grad_scale) {
+                            float lr, int warmup, float clip, float b1, float b2, float eps, float grad_scale,
+                            int decay_steps) {
   const int t = step[0] + 1;
   float lr_now = lr;
+  if (decay_steps > 0) {   // tf.train.cosine_decay_restarts(lr, global_step, first_decay_steps, t_mul=2, m_mul=1, alpha=0)
+    const float frac = (float)(t - 1) / (float)decay_steps;
+    const float i_restart = floorf(logf(1.0f + frac) / logf(2.0f));
+    const float pw = exp2f(i_restart);
+    const float within = (frac - (pw - 1.0f)) / pw;
+    lr_now *= 0.5f * (1.0f + cosf(3.14159265358979323846f * within));
+  }
   if (warmup > 0) lr_now *= fminf(1.0f, (float)t / (float)warmup);   // min(1, (global_step + 1) / warmup)
   const double c1 = 1.0 - exp((double)t * log((double)b1));
   const double c2 = 1.0 - exp((double)t * log((double)b2));
@@ -652,10 +660,16 @@ extern "C" int avsr_global_norm(const float* grads, int64_t n, float grad_scale,
 extern "C" int avsr_adam_step(float* params, float* grads, float* m, float* v, int64_t n, const float* global_norm,
                               int32_t* step, float lr, int32_t warmup_steps, float clip_norm, float grad_scale,
                               void* stream) {
-  if (!params || !grads || !m || !v || !step || n <= 0) return AVSR_ERR_ARG;
+  return avsr_adam_step_decay(params, grads, m, v, n, global_norm, step, lr, warmup_steps, 0, clip_norm, grad_scale, stream);
+}
+
+extern "C" int avsr_adam_step_decay(float* params, float* grads, float* m, float* v, int64_t n, const float* global_norm,
+                                    int32_t* step, float lr, int32_t warmup_steps, int32_t first_decay_steps,
+                                    float clip_norm, float grad_scale, void* stream) {
+  if (!params || !grads || !m || !v || !step || n <= 0 || first_decay_steps < 0) return AVSR_ERR_ARG;
   if (clip_norm > 0.f && !global_norm) return AVSR_ERR_ARG;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 1024, 2048)), dim3(256), 0, S_(stream), params, grads, m, v, (long)n,
-                     global_norm, step, lr, warmup_steps, clip_norm, 0.9f, 0.999f, 1e-8f, grad_scale);
+                     global_norm, step, lr, warmup_steps, clip_norm, 0.9f, 0.999f, 1e-8f, grad_scale, first_decay_steps);
   AVSR_CHECK_LAUNCH();
   hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, S_(stream), step);
   AVSR_CHECK_LAUNCH();

@@ -955,7 +955,8 @@ class Seq2SeqModel:
                 ops.l2_regularise(self.dense_l2_segments, self.params, self.grads, 1e-4, self.loss, self.scratch)
         ops.global_norm(self.grads, self.n_train, self.gnorm, self.scratch)
         ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.n_train, self.gnorm, self.step,
-                      cfg.learning_rate, cfg.warmup_steps, cfg.max_gradient_norm if cfg.clip_gradients else 0.0)
+                      cfg.learning_rate, cfg.warmup_steps, cfg.max_gradient_norm if cfg.clip_gradients else 0.0,
+                      first_decay_steps=cfg.lr_decay_steps)
 
     def train_step(self, batch: Batch):
         """One `session.run([train_op, batch_loss, global_norm])` (avsr/avsr.py:265-271); returns device scalars."""

@@ -187,9 +187,10 @@ def global_norm(grads, n, norm_out, scratch, grad_scale=1.0):
           "avsr_global_norm")
 
 
-def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, grad_scale=1.0):
-    check(_L().avsr_adam_step(fptr(params), fptr(grads), fptr(m), fptr(v), n, fptr(gnorm), fptr(step), float(lr),
-                              int(warmup_steps), float(clip_norm), float(grad_scale), _s()), "avsr_adam_step")
+def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, grad_scale=1.0, first_decay_steps=0):
+    check(_L().avsr_adam_step_decay(fptr(params), fptr(grads), fptr(m), fptr(v), n, fptr(gnorm), fptr(step), float(lr),
+                                    int(warmup_steps), int(first_decay_steps), float(clip_norm), float(grad_scale), _s()),
+          "avsr_adam_step_decay")
 
 
 PROF_KINDS = ("gemm", "step_lstm_fwd", "step_lstm_bwd", "step_dense", "attn_fwd", "attn_bwd", "rnn_persist_fwd", "rnn_persist_bwd")

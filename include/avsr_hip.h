@@ -409,6 +409,12 @@ int avsr_global_norm(const float* grads, int64_t n, float grad_scale, float* nor
  * :275-280).  step[0] (device int32) is read as global_step and incremented. clip_norm <= 0 disables clipping. */
 int avsr_adam_step(float* params, float* grads, float* m, float* v, int64_t n, const float* global_norm, int32_t* step,
                    float lr, int32_t warmup_steps, float clip_norm, float grad_scale, void* stream);
+/* Same with lr_decay=('cosine_restarts', first_decay_steps) (avsr/seq2seq.py:266-270: tf.train.cosine_decay_restarts
+ * with its defaults t_mul=2, m_mul=1, alpha=0, evaluated at global_step; the warm-up factor multiplies the result).
+ * first_decay_steps == 0: constant learning rate. */
+int avsr_adam_step_decay(float* params, float* grads, float* m, float* v, int64_t n, const float* global_norm,
+                         int32_t* step, float lr, int32_t warmup_steps, int32_t first_decay_steps, float clip_norm,
+                         float grad_scale, void* stream);
 
 /* Optional per-launch HIP-event timing of the engine's own kernels (bench.py roofline figures).  Between
  * begin and end every gemm / step / attention launch is bracketed by an event pair on its stream; end

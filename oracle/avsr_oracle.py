@@ -61,6 +61,7 @@ class OracleConfig:
     max_gradient_norm: float = 1.0
     learning_rate: float = 1e-3
     warmup_steps: int = 750                   # seq2seq.py:275
+    lr_decay_steps: int = 0                   # lr_decay=('cosine_restarts', N), seq2seq.py:266-270; 0 = constant
     max_label_length: int = 150               # avsr.py:157
     # stochastic train-time features (off for parity fixtures; SURVEY section 7 "hard parts")
     use_dropout: bool = False
@@ -856,8 +857,15 @@ def to_torch(P_np: Dict[str, np.ndarray], dtype=torch.float64, requires_grad=Fal
 
 
 def lr_at(cfg: OracleConfig, step: int) -> float:
-    """seq2seq.py:259-280 (constant lr, linear warm-up)."""
+    """seq2seq.py:259-280: constant lr or tf.train.cosine_decay_restarts(lr, global_step, first_decay_steps) with its
+    defaults t_mul=2, m_mul=1, alpha=0 (recalled from TF r1.13 learning_rate_decay_v2.py), then the linear warm-up."""
     lr = cfg.learning_rate
+    if cfg.lr_decay_steps:
+        frac = step / float(cfg.lr_decay_steps)
+        i_restart = np.floor(np.log(1.0 - frac * (1.0 - 2.0)) / np.log(2.0))
+        sum_r = (1.0 - 2.0 ** i_restart) / (1.0 - 2.0)
+        within = (frac - sum_r) / 2.0 ** i_restart
+        lr *= 0.5 * (1.0 + np.cos(np.pi * within))
     if cfg.warmup_steps:
         lr *= min(1.0, (step + 1) / float(cfg.warmup_steps))
     return lr

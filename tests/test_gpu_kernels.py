@@ -205,3 +205,28 @@ def test_rnn_stack_fwd_bwd(units, reverse, persistent, B):
     ops.gemm(ops.mat(bufs[0]["dgates"], 4 * u0), ops.mat(bufs[0]["We"], 4 * u0), ops.mat(dx, F), B * T, F, 4 * u0, trans_b=1)
     torch.cuda.synchronize()
     assert np.abs(dx.cpu().numpy() - o_dx).max() < 2e-4 * max(1.0, np.abs(o_dx).max())
+
+
+@pytest.mark.parametrize("start", [0, 7, 10, 25, 31])
+def test_adam_step_with_cosine_restarts(start):
+    """avsr_adam_step_decay against the oracle's lr_at + Adam formula at several global steps (seq2seq.py:259-280)."""
+    from avsr_tf1_amd import ops
+    from oracle import avsr_oracle as O
+    cfg = O.OracleConfig(architecture="unimodal", video_units=None, audio_units=(8,), warmup_steps=4, lr_decay_steps=10)
+    rng = np.random.default_rng(start)
+    n = 1000
+    p, g = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    m, v = (0.1 * rng.standard_normal(n)).astype(np.float32), (0.01 * rng.random(n)).astype(np.float32)
+    dp, dg, dm, dv = (torch.tensor(a, device="cuda") for a in (p, g, m, v))
+    step = torch.tensor([start], dtype=torch.int32, device="cuda")
+    gn = torch.tensor([float(np.linalg.norm(g))], device="cuda")
+    ops.adam_step(dp, dg, dm, dv, n, gn, step, cfg.learning_rate, cfg.warmup_steps, 1.0, first_decay_steps=cfg.lr_decay_steps)
+    torch.cuda.synchronize()
+    t = start + 1
+    gc = g.astype(np.float64) * min(1.0, 1.0 / np.linalg.norm(g.astype(np.float64)))
+    m2, v2 = 0.9 * m + 0.1 * gc, 0.999 * v + 0.001 * gc * gc
+    lr_t = O.lr_at(cfg, start) * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+    want = p - lr_t * m2 / (np.sqrt(v2) + 1e-8)
+    assert int(step.item()) == t
+    assert np.abs(dp.cpu().numpy() - want).max() < 2e-6 * max(1.0, lr_t / 1e-3)
+    assert np.abs((dp.cpu().numpy() - p) - (want - p)).max() < 1e-3 * np.abs(want - p).max() + 1e-9

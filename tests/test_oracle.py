@@ -131,3 +131,14 @@ def test_adam_and_warmup_formula():
     m, v = 0.1 * g, 0.001 * g * g
     lr_t = O.lr_at(cfg, 0) * np.sqrt(1 - 0.999) / (1 - 0.9)
     assert np.abs(r["params"][k] - (W[k] - lr_t * m / (np.sqrt(v) + 1e-8))).max() < 1e-7
+
+
+def test_cosine_restarts_schedule():
+    """lr_decay=('cosine_restarts', 10): periods 10, 20, 40 ... (t_mul=2), full lr at every restart, half-way = lr/2."""
+    cfg, _, _ = _small("unimodal", warmup_steps=0, lr_decay_steps=10)
+    lr = cfg.learning_rate
+    for step, want in ((0, lr), (5, lr / 2), (10, lr), (20, lr / 2), (30, lr), (50, lr / 2), (70, lr)):
+        assert abs(O.lr_at(cfg, step) - want) < 1e-12, (step, O.lr_at(cfg, step), want)
+    assert 0 < O.lr_at(cfg, 9) < 0.03 * lr
+    cfg2, _, _ = _small("unimodal", warmup_steps=4, lr_decay_steps=10)
+    assert abs(O.lr_at(cfg2, 1) - O.lr_at(cfg, 1) * 0.5) < 1e-12         # warm-up multiplies the decayed rate
