@@ -130,7 +130,10 @@ __global__ void bn_partial_sum_kernel(const float* x, float* part, int rows, int
 }
 
 // mean[f] = sum of partials / rows   (one launch, one block per 32 columns; npart = nblk * G)
-__global__ __launch_bounds__(1024) void bn_mean_kernel(const float* part, int npart, float* mean, int rows, int F) {
+// total != nullptr: the divisor is the (all-reduced) row count total[0] instead of `rows` (sync batch-norm).
+__global__ __launch_bounds__(1024) void bn_mean_kernel(const float* part, int npart, float* mean, int rows, int F,
+                                                       const float* total = nullptr) {
+  if (total) rows = (int)total[0];
   __shared__ double red[32][33];
   const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int f = blockIdx.x * 32 + fl;
@@ -171,7 +174,9 @@ __global__ void bn_partial_sq_kernel(const float* x, const float* mean_v, float*
 
 // var from the centred-square partials, inverse std, moving-average update (one launch, one block per 32 columns)
 __global__ __launch_bounds__(1024) void bn_var_kernel(const float* part, int npart, const float* mean_v, float* invstd_v, float* mov_mean,
-                                                      float* mov_var, int rows, int F, float eps, float momentum) {
+                                                      float* mov_var, int rows, int F, float eps, float momentum,
+                                                      const float* total = nullptr) {
+  if (total) rows = (int)total[0];
   __shared__ double red[32][33];
   const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int f = blockIdx.x * 32 + fl;
@@ -537,6 +542,68 @@ extern "C" int avsr_batchnorm_fwd_ex(const float* x, float* y, int32_t rows, int
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, S_(stream), x, mean_v, invstd_v, moving_mean, moving_var, gamma, beta, y,
                      n4, F, training, eps, relu);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+// ---- sync batch-norm over data-parallel ranks: the three local phases around the two host-side all-reduces ----
+static int bn_blocks(int rows, int F, int64_t scratch_floats, int* rpb_out) {
+  const int maxblk = 2048;
+  int rpb = rows > 64 * maxblk ? (rows + maxblk - 1) / maxblk : 64;
+  int nblk = (rows + rpb - 1) / rpb;
+  if ((long)nblk * F > scratch_floats) {
+    nblk = (int)(scratch_floats / F);
+    if (nblk < 1) return 0;
+    rpb = (rows + nblk - 1) / nblk;
+    nblk = (rows + rpb - 1) / rpb;
+  }
+  *rpb_out = rpb;
+  return nblk;
+}
+
+extern "C" int avsr_batchnorm_sync_sum(const float* x, int32_t rows, int32_t F, float* sum_out, float* scratch,
+                                       int64_t scratch_floats, void* stream) {
+  if (!x || !sum_out || !scratch || rows <= 0 || F <= 0 || F % 4) return AVSR_ERR_ARG;
+  int rpb;
+  const int nblk = bn_blocks(rows, F, scratch_floats, &rpb);
+  if (!nblk) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(bn_partial_sum_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, scratch, rows, F, rpb);
+  AVSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_mean_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), scratch, nblk, sum_out, 1, F, nullptr);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_batchnorm_sync_sqsum(const float* x, int32_t rows, int32_t F, const float* sum_global,
+                                         const float* total_rows, float* mean_out, float* sq_out, float* scratch,
+                                         int64_t scratch_floats, void* stream) {
+  if (!x || !sum_global || !total_rows || !mean_out || !sq_out || !scratch || rows <= 0 || F <= 0 || F % 4) return AVSR_ERR_ARG;
+  int rpb;
+  const int nblk = bn_blocks(rows, F, scratch_floats, &rpb);
+  if (!nblk) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(bn_mean_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), sum_global, 1, mean_out, 1, F, total_rows);
+  AVSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_partial_sq_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, mean_out, scratch, rows, F, rpb);
+  AVSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_mean_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), scratch, nblk, sq_out, 1, F, nullptr);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_batchnorm_sync_apply(const float* x, float* y, int32_t rows, int32_t F, const float* gamma,
+                                         const float* beta, float* moving_mean, float* moving_var, const float* mean,
+                                         const float* sq_global, const float* total_rows, float* invstd_out, float eps,
+                                         float momentum, int32_t relu, void* stream) {
+  if (!x || !y || !gamma || !beta || !mean || !sq_global || !total_rows || !invstd_out || rows <= 0 || F <= 0 || F % 4)
+    return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(bn_var_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), sq_global, 1, mean, invstd_out, moving_mean,
+                     moving_var, 1, F, eps, momentum, total_rows);
+  AVSR_CHECK_LAUNCH();
+  const long n4 = (long)rows * F / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, S_(stream), x, mean, invstd_out, moving_mean, moving_var, gamma, beta, y,
+                     n4, F, 1, eps, relu);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

@@ -123,6 +123,7 @@ class Seq2SeqModel:
         self.cnn_l2_segments = [(self._train_off[n], int(np.prod(self.inv[n][0]))) for n in self._train_off if PR.is_cnn_l2(n)]
         self.use_cnn = cfg.video_units is not None and cfg.video_processing == "resnet_cnn"
         self.dense_l2_segments = [(self._train_off[n], int(np.prod(self.inv[n][0]))) for n in self._train_off if PR.is_dense_l2(n)]
+        self.bn_sync = None                       # set by bn_sync_enable() under data parallelism
         self.n_dense = len(cfg.input_dense_layers) if cfg.input_dense_layers[0] > 0 else 0
         # ---- derived transposed operands -----------------------------------------------------------
         self._tjobs, self.Tr = [], {}
@@ -221,7 +222,8 @@ class Seq2SeqModel:
             if cfg.use_dropout:
                 E["xd"] = {d: z(B * T, F0) for d in cfg.directions()}    # layer-0 input after each direction's input mask
                 E["dx_tmp"] = z(B * T, F0)
-            E["mean"], E["invstd"] = z(F), z(F)
+            E["mean_own"], E["invstd"] = z(F), z(F)
+            E["mean"] = E["mean_own"]
             Dm = units[-1] * ndir
             if not attentive:
                 E["mem"] = SeqBuf(B, T, Dm, 1, 1, dev)
@@ -370,6 +372,49 @@ class Seq2SeqModel:
             st.dh_final, st.dc_final = ops.fptr(top["dhf"]), (None if self.gru else ops.fptr(top["dcf"]))
         return st
 
+    # ---- sync batch-norm of the encoder inputs across data-parallel ranks (SURVEY 8(e) collective (3)) ----
+    def bn_sync_enable(self):
+        """Called by DataParallelTrainer when world > 1.  Streams whose input BN is synchronised: the feature inputs.
+        (A CNN-fed stream keeps per-rank statistics: its input gradient would need an all-reduce inside BPTT.)
+        The per-stream row counts ride at the tail of the first buffer so that one all-reduce carries sums and counts
+        (ranks may hold different B and T)."""
+        cfg = self.cfg
+        streams = [s for s in cfg.streams() if cfg.batch_normalisation and not (s == "video" and self.use_cnn)]
+        if not streams:
+            return None
+        off, n = {}, 0
+        for s in streams:
+            off[s], n = n, n + cfg.feat(s)
+        z = lambda k: torch.zeros(k, dtype=torch.float32, device=self.dev)
+        buf = z(n + len(streams))
+        self.bn_sync = dict(streams=streams, off=off, sum=buf, sq=z(n), mean=z(n), rows=[buf[n + i:n + i + 1] for i in range(len(streams))])
+        return self.bn_sync
+
+    def _bn_sync_x(self, batch, s):
+        x = batch.video if s == "video" else batch.audio
+        F = self.cfg.feat(s)
+        assert x.is_contiguous() and x.dtype == torch.float32 and x.shape[-1] == F
+        return x, x.shape[0] * x.shape[1], F
+
+    def bn_sync_sums(self, batch):
+        """Phase 1: local sum over rows of every synchronised stream + its local row count; returns the buffer to all-reduce."""
+        bs = self.bn_sync
+        for i, s in enumerate(bs["streams"]):
+            x, rows, F = self._bn_sync_x(batch, s)
+            o = bs["off"][s]
+            ops.batchnorm_sync_sum(x, rows, F, bs["sum"][o:o + F], self.scratch)
+            bs["rows"][i].fill_(float(rows))
+        return bs["sum"]
+
+    def bn_sync_squares(self, batch):
+        """Phase 2 (after the all-reduce of phase 1): global mean, local centred squares; returns the buffer to all-reduce."""
+        bs = self.bn_sync
+        for i, s in enumerate(bs["streams"]):
+            x, rows, F = self._bn_sync_x(batch, s)
+            o = bs["off"][s]
+            ops.batchnorm_sync_sqsum(x, rows, F, bs["sum"][o:o + F], bs["rows"][i], bs["mean"][o:o + F], bs["sq"][o:o + F], self.scratch)
+        return bs["sq"]
+
     def _encode(self, ws, batch: Batch, training: bool):
         cfg, B = self.cfg, ws["B"]
         self._dropping = bool(cfg.use_dropout and training)       # cells.py:46: DropoutWrapper only in the train graph
@@ -386,9 +431,19 @@ class Seq2SeqModel:
             assert x.shape == (B, T, F) and x.is_contiguous() and x.dtype == torch.float32
             E["x"], E["len"] = x, len_t
             if cfg.batch_normalisation:
-                ops.batchnorm_fwd(x, E["xn"], B * T, F, self._pp(f"{s}/bn/gamma"), self._pp(f"{s}/bn/beta"),
-                                  self._sp(f"{s}/bn/moving_mean"), self._sp(f"{s}/bn/moving_variance"),
-                                  E["mean"], E["invstd"], training, self.scratch)
+                if training and self.bn_sync is not None and s in self.bn_sync["streams"]:
+                    # statistics of the GLOBAL batch: mean / centred squares were all-reduced by the trainer (bn_sync_*)
+                    o = self.bn_sync["off"][s]
+                    ops.batchnorm_sync_apply(x, E["xn"], B * T, F, self._pp(f"{s}/bn/gamma"), self._pp(f"{s}/bn/beta"),
+                                             self._sp(f"{s}/bn/moving_mean"), self._sp(f"{s}/bn/moving_variance"),
+                                             self.bn_sync["mean"][o:o + F], self.bn_sync["sq"][o:o + F],
+                                             self.bn_sync["rows"][self.bn_sync["streams"].index(s)], E["invstd"])
+                    E["mean"] = self.bn_sync["mean"][o:o + F]
+                else:
+                    E["mean"] = E["mean_own"]
+                    ops.batchnorm_fwd(x, E["xn"], B * T, F, self._pp(f"{s}/bn/gamma"), self._pp(f"{s}/bn/beta"),
+                                      self._sp(f"{s}/bn/moving_mean"), self._sp(f"{s}/bn/moving_variance"),
+                                      E["mean"], E["invstd"], training, self.scratch)
                 E["xin"] = E["xn"]
             else:
                 E["xin"] = x

@@ -130,6 +130,22 @@ def batchnorm_fwd(x, y, rows, F, gamma, beta, mov_mean, mov_var, save_mean, save
                                   _s()), "avsr_batchnorm_fwd")
 
 
+def batchnorm_sync_sum(x, rows, F, sum_out, scratch):
+    check(_L().avsr_batchnorm_sync_sum(fptr(x), rows, F, fptr(sum_out), fptr(scratch), scratch.numel(), _s()), "avsr_batchnorm_sync_sum")
+
+
+def batchnorm_sync_sqsum(x, rows, F, sum_global, total_rows, mean_out, sq_out, scratch):
+    check(_L().avsr_batchnorm_sync_sqsum(fptr(x), rows, F, fptr(sum_global), fptr(total_rows), fptr(mean_out), fptr(sq_out),
+                                         fptr(scratch), scratch.numel(), _s()), "avsr_batchnorm_sync_sqsum")
+
+
+def batchnorm_sync_apply(x, y, rows, F, gamma, beta, mov_mean, mov_var, mean, sq_global, total_rows, invstd_out, eps=1e-3, momentum=0.99,
+                         relu=0):
+    check(_L().avsr_batchnorm_sync_apply(fptr(x), fptr(y), rows, F, fptr(gamma), fptr(beta), fptr(mov_mean), fptr(mov_var), fptr(mean),
+                                         fptr(sq_global), fptr(total_rows), fptr(invstd_out), float(eps), float(momentum), int(relu), _s()),
+          "avsr_batchnorm_sync_apply")
+
+
 def batchnorm_xhat(x, mean, invstd, xhat, rows, F):
     check(_L().avsr_batchnorm_xhat(fptr(x), fptr(mean), fptr(invstd), fptr(xhat), rows, F, _s()), "avsr_batchnorm_xhat")
 

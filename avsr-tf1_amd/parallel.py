@@ -7,8 +7,12 @@ hot path on its shard of the utterances, and the only collectives are
       count (seq2seq.py:165-171), before the backward pass;
   (2) ONE all-reduce (sum) of the flat fp32 gradient buffer (RCCL over xGMI) between BPTT and the
       clip/Adam update, so global-norm clipping and Adam see identical gradients on every rank.
-Encoder-input batch-norm statistics stay per rank (no sync-BN) and the AU regression term is averaged
-over ranks; both are noted in DESIGN.md.
+  (3) sync batch-norm of the encoder inputs (encoder.py:44-50 computes the statistics over the whole batch):
+      two small all-reduces before the forward pass -- per-feature sums with the row counts, then the centred
+      squares -- so mean / variance / moving averages are those of the GLOBAL batch on every rank.  The BN
+      gamma / beta gradients ride in (2).  `sync_bn=False` keeps per-rank statistics; the batch-norms inside the
+      lip-crop CNN (and the input BN of a CNN-fed stream) are always per rank.
+The AU regression term is averaged over ranks (noted in DESIGN.md).
 
 Launch overhead: a train step is ~1.3k dependent kernel launches; they are captured once per batch
 shape into a hipGraph (torch.cuda.CUDAGraph is only the capture/replay plumbing -- every node is one
@@ -18,7 +22,7 @@ import torch
 
 
 class DataParallelTrainer:
-    def __init__(self, model, dist=None, use_graph=True):
+    def __init__(self, model, dist=None, use_graph=True, sync_bn=True):
         self.model, self.dist = model, dist
         self.world = dist.get_world_size() if dist is not None else 1
         self.use_graph = use_graph
@@ -27,6 +31,7 @@ class DataParallelTrainer:
         self._checked = False
         self._static = {}
         model.au_scale = 1.0 / self.world
+        self.sync_bn = bool(sync_bn and self.world > 1 and getattr(model, "bn_sync_enable", None) and model.bn_sync_enable())
 
     # -- helpers ----------------------------------------------------------------------------------
     @staticmethod
@@ -72,6 +77,9 @@ class DataParallelTrainer:
             L = batch.labels.shape[1]
             m.denom.copy_(batch.labels_len.clamp(0, L).sum().to(torch.float32).reshape(1))
             dist.all_reduce(m.denom)
+            if self.sync_bn:
+                dist.all_reduce(m.bn_sync_sums(batch))
+                dist.all_reduce(m.bn_sync_squares(batch))
         if not self.use_graph:
             self._fwd_bwd(batch)
             if not self._checked:                      # first step: make sure the persistent kernels were co-resident

@@ -326,6 +326,18 @@ int avsr_batchnorm_fwd(const float* x, float* y, int32_t rows, int32_t F, const 
 int avsr_batchnorm_fwd_ex(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta,
                           float* moving_mean, float* moving_var, float* save_mean, float* save_invstd, int32_t training,
                           float eps, float momentum, int32_t relu, float* scratch, int64_t scratch_floats, void* stream);
+/* Sync batch-norm across data-parallel ranks (SURVEY 8(e) collective (3); statistics of encoder.py:44-50 over the
+ * GLOBAL batch).  Three local phases; the host all-reduces sum_out (with the row count) after the first and sq_out
+ * after the second:  (1) sum_out[f] = sum_rows x;  (2) mean_out = sum_global / total_rows[0], sq_out[f] = sum_rows
+ * (x - mean)^2;  (3) invstd = rsqrt(sq_global / total + eps), moving-average update with the Bessel-corrected global
+ * variance, y = (x - mean) * invstd * gamma + beta.  total_rows is a DEVICE float (the all-reduced count). */
+int avsr_batchnorm_sync_sum(const float* x, int32_t rows, int32_t F, float* sum_out, float* scratch, int64_t scratch_floats,
+                            void* stream);
+int avsr_batchnorm_sync_sqsum(const float* x, int32_t rows, int32_t F, const float* sum_global, const float* total_rows,
+                              float* mean_out, float* sq_out, float* scratch, int64_t scratch_floats, void* stream);
+int avsr_batchnorm_sync_apply(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta,
+                              float* moving_mean, float* moving_var, const float* mean, const float* sq_global,
+                              const float* total_rows, float* invstd_out, float eps, float momentum, int32_t relu, void* stream);
 /* Gradient of batch normalisation with training statistics (tf.gradients through fused batch norm), optionally through
  * the ReLU after it: dy' = dy * [gamma*xhat + beta > 0];  dbeta = sum dy';  dgamma = sum dy'*xhat;
  * dx = gamma*invstd*(dy' - (sum dy' + xhat*sum dy'*xhat)/rows), written as dx = that + dx_beta*dx.  dx / dgamma / dbeta may

@@ -568,15 +568,19 @@ def attention_wrapper_step(cell: _Cell, mechs: List[_Mechanism], output_attentio
 # ----------------------------------------------------------------------------------------
 # encoders
 # ----------------------------------------------------------------------------------------
-def batch_norm(x: Tensor, P, prefix: str, training: bool, updates: Optional[dict], eps: float = 1e-3, momentum: float = 0.99):
+def batch_norm(x: Tensor, P, prefix: str, training: bool, updates: Optional[dict], eps: float = 1e-3, momentum: float = 0.99,
+               stats=None):
     """tf.layers.batch_normalization(axis=-1, fused=True), momentum .99 eps 1e-3 (encoder.py:44-50); the CNN front-end
     uses momentum .98 eps 1e-5 (video.py:8-11).  Statistics over all rows INCLUDING zero padding."""
     if training:
         flat = x.reshape(-1, x.shape[-1])
-        mean = flat.mean(dim=0)
-        var = ((flat - mean) ** 2).mean(dim=0)
-        if updates is not None:
+        if stats is not None:                                  # data-parallel shard: (mean, biased var, rows) of the GLOBAL batch
+            mean, var, n = stats
+        else:
+            mean = flat.mean(dim=0)
+            var = ((flat - mean) ** 2).mean(dim=0)
             n = flat.shape[0]
+        if updates is not None:
             unbiased = var.detach() * (n / max(1, n - 1))       # fused kernel feeds Bessel-corrected var to the moving average
             updates[prefix + "/moving_mean"] = momentum * P[prefix + "/moving_mean"] + (1 - momentum) * mean.detach()
             updates[prefix + "/moving_variance"] = momentum * P[prefix + "/moving_variance"] + (1 - momentum) * unbiased
@@ -640,13 +644,14 @@ def _make_cells(P, cfg: OracleConfig, stream: str, direction: str, units, traini
 
 
 def encode_stream(P, cfg: OracleConfig, stream: str, x: Tensor, lens: Tensor, training: bool,
-                  bn_updates: Optional[dict], attended: Optional[Tuple[Tensor, Tensor]] = None, seed: int = 0) -> EncoderOut:
+                  bn_updates: Optional[dict], attended: Optional[Tuple[Tensor, Tensor]] = None, seed: int = 0,
+                  bn_stats=None) -> EncoderOut:
     """Seq2SeqEncoder / AttentiveEncoder (encoder.py:14-196, :199-335)."""
     units = cfg.video_units if stream == "video" else cfg.audio_units
     B, dtype = x.shape[0], x.dtype
     T = x.shape[1]
     if cfg.batch_normalisation:
-        x = batch_norm(x, P, f"{stream}/bn", training, bn_updates)
+        x = batch_norm(x, P, f"{stream}/bn", training, bn_updates, stats=bn_stats)
     if cfg.input_dense_layers[0] > 0:                            # encoder.py:148-171, after _init_data (BN), before the RNN
         for i in range(len(cfg.input_dense_layers)):
             x = torch.selu(x @ P[f"{stream}/dense{i}/kernel"])
@@ -706,8 +711,9 @@ def au_loss(P, enc: EncoderOut, aus: Tensor, lens: Tensor) -> Tensor:
 # the model: encoders + decoder (seq2seq.py:30-126)
 # ----------------------------------------------------------------------------------------
 class _Model:
-    def __init__(self, P: Dict[str, Tensor], cfg: OracleConfig, batch: Batch, training: bool, dtype, seed: int = 0):
+    def __init__(self, P: Dict[str, Tensor], cfg: OracleConfig, batch: Batch, training: bool, dtype, seed: int = 0, bn_stats=None):
         self.P, self.cfg, self.training, self.seed = P, cfg, training, seed
+        bn_stats = bn_stats or {}
         self.bn_updates: dict = {}
         tt = lambda a: None if a is None else torch.as_tensor(np.asarray(a), dtype=dtype)
         ti = lambda a: None if a is None else torch.as_tensor(np.asarray(a), dtype=torch.int64)
@@ -721,7 +727,7 @@ class _Model:
                 Bv, Tv = vid.shape[0], vid.shape[1]
                 vid = cnn_forward(P, cfg, vid.reshape((Bv * Tv,) + tuple(vid.shape[2:])), training, self.bn_updates).reshape(Bv, Tv, -1)
             self.enc["video"] = encode_stream(P, cfg, "video", vid, self.lens["video"],
-                                              training, self.bn_updates, seed=seed)
+                                              training, self.bn_updates, seed=seed, bn_stats=bn_stats.get("video"))
             if cfg.regress_aus and training:
                 self.aux_loss = au_loss(P, self.enc["video"], tt(batch.aus), self.lens["video"])
         if cfg.audio_units is not None:
@@ -730,7 +736,7 @@ class _Model:
             if cfg.architecture == "av_align":
                 attended = (self.enc["video"].outputs, self.lens["video"])
             self.enc["audio"] = encode_stream(P, cfg, "audio", tt(batch.audio), self.lens["audio"],
-                                              training, self.bn_updates, attended, seed=seed)
+                                              training, self.bn_updates, attended, seed=seed, bn_stats=bn_stats.get("audio"))
         self.B = (batch.audio if batch.audio is not None else batch.video).shape[0]
         self.dtype = dtype
         self._init_decoder()
@@ -784,11 +790,11 @@ def categorical_f32(logits_row: np.ndarray, u: np.float32) -> int:
     return len(p) - 1
 
 
-def forward_train(P: Dict[str, Tensor], cfg: OracleConfig, batch: Batch, dtype=torch.float64, seed: int = 0):
+def forward_train(P: Dict[str, Tensor], cfg: OracleConfig, batch: Batch, dtype=torch.float64, seed: int = 0, bn_stats=None):
     """Train-graph forward: teacher forcing with optional scheduled sampling (ScheduledEmbeddingTrainingHelper,
     decoder_unimodal.py:304-309) and DropoutWrapper'd cells; `seed` = global step keys the stateless RNG.
     Returns logits [B,L,V] and the model."""
-    m = _Model(P, cfg, batch, True, dtype, seed)
+    m = _Model(P, cfg, batch, True, dtype, seed, bn_stats=bn_stats)         # bn_stats: {stream: (mean, var, rows)} of a global batch
     labels = torch.as_tensor(batch.labels, dtype=torch.int64)
     ll = torch.as_tensor(batch.labels_len, dtype=torch.int64)
     B, L = labels.shape

@@ -18,7 +18,7 @@ from oracle import avsr_oracle as O
 
 def _cfg():
     return O.OracleConfig(architecture="bimodal", video_units=(8,), audio_units=(8, 8), decoder_units=(8,), embedding_size=4,
-                          video_feat=4, audio_feat=8, batch_normalisation=False, regress_aus=False)
+                          video_feat=4, audio_feat=8, batch_normalisation=True, regress_aus=False)
 
 
 class OracleBackedModel:
@@ -29,12 +29,56 @@ class OracleBackedModel:
         self.grads = torch.zeros(sum(self.sizes), dtype=torch.float64)
         self.denom, self.loss, self.gnorm = torch.zeros(1), torch.zeros(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64)
         self.au_scale = 1.0
+        self.bn_sync = None
+
+    # the three sync-BN hooks DataParallelTrainer drives (model.py: bn_sync_enable / bn_sync_sums / bn_sync_squares)
+    def bn_sync_enable(self):
+        feats = {"video": self.cfg.video_feat, "audio": self.cfg.audio_feat}
+        streams = [s for s in ("video", "audio") if getattr(self.cfg, s + "_units") is not None]
+        n = sum(feats[s] for s in streams)
+        self.bn_sync = dict(streams=streams, feats=feats, sum=torch.zeros(n + len(streams), dtype=torch.float64),
+                            sq=torch.zeros(n, dtype=torch.float64), n=n)
+        return self.bn_sync
+
+    def _rows(self, batch, s):
+        x = getattr(batch, s).to(torch.float64)
+        return x.reshape(-1, x.shape[-1])
+
+    def bn_sync_sums(self, batch):
+        bs, o = self.bn_sync, 0
+        for i, s in enumerate(bs["streams"]):
+            x = self._rows(batch, s)
+            bs["sum"][o:o + x.shape[1]] = x.sum(0)
+            bs["sum"][bs["n"] + i] = x.shape[0]
+            o += x.shape[1]
+        return bs["sum"]
+
+    def bn_sync_squares(self, batch):
+        bs, o = self.bn_sync, 0
+        bs["mean"] = {}
+        for i, s in enumerate(bs["streams"]):
+            x = self._rows(batch, s)
+            bs["mean"][s] = bs["sum"][o:o + x.shape[1]] / bs["sum"][bs["n"] + i]
+            bs["sq"][o:o + x.shape[1]] = ((x - bs["mean"][s]) ** 2).sum(0)
+            o += x.shape[1]
+        return bs["sq"]
+
+    def _bn_stats(self):
+        if self.bn_sync is None:
+            return None
+        bs, o, out = self.bn_sync, 0, {}
+        for i, s in enumerate(bs["streams"]):
+            F, n = bs["feats"][s], float(bs["sum"][bs["n"] + i])
+            out[s] = (bs["mean"][s].clone(), bs["sq"][o:o + F] / n, n)
+            o += F
+        return out
 
     def forward_train(self, batch, compute_denom=True):
         nb = O.Batch(**{k: (None if getattr(batch, k) is None else getattr(batch, k).numpy())
                         for k in ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len")})
         self._P = O.to_torch(self.W, torch.float64, requires_grad=True)
-        logits, _m = O.forward_train(self._P, self.cfg, nb)
+        logits, _m = O.forward_train(self._P, self.cfg, nb, bn_stats=self._bn_stats())
+        self._bn_updates = _m.bn_updates
         labels = torch.as_tensor(nb.labels, dtype=torch.int64)
         ll = torch.as_tensor(nb.labels_len, dtype=torch.int64)
         w = (torch.arange(labels.shape[1])[None, :] < ll[:, None]).to(torch.float64)
@@ -68,6 +112,8 @@ class OracleBackedModel:
             upd = lr_t * self.opt["m"][k] / (np.sqrt(self.opt["v"][k]) + 1e-8)
             self.W[k] = (self.W[k].astype(np.float64) - upd.reshape(self.W[k].shape)).astype(np.float32)
         self.opt["step"] = t
+        for k, v in self._bn_updates.items():                    # UPDATE_OPS: moving statistics of the (global) batch
+            self.W[k] = v.detach().numpy().astype(np.float32)
 
 
 def _shard(b, lo, hi):
@@ -108,3 +154,6 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path):
     for k in O.trainable_names(W):
         assert np.array_equal(r0[k], r1[k]), k                  # replicas stay bit-identical
         assert np.abs(r0[k] - b["params"][k]).max() < 1e-6, k   # and equal the single-process step on the whole batch
+    for k in W:                                                 # sync-BN: moving statistics are those of the GLOBAL batch
+        if "moving_" in k:
+            assert np.array_equal(r0[k], r1[k]) and np.abs(r0[k] - b["params"][k]).max() < 1e-6, k

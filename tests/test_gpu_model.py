@@ -258,3 +258,45 @@ def test_beam_search_parity(case, K):
         T = min(g.shape[1], ref.shape[1])
         gg = np.where(np.cumsum(g[:, :T] == ocfg.eos_id, axis=1) - (g[:, :T] == ocfg.eos_id) > 0, ocfg.eos_id, g[:, :T])
         assert (gg == ref[:, :T, 0]).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# data-parallel algebra on ONE GPU: two engine instances hold the two halves of a batch, the test plays RCCL (sums the
+# buffers the trainer would all-reduce).  With sync batch-norm the summed gradients, loss and moving statistics must be
+# those of ONE engine on the whole batch; the real 2-process collective logic is tests/test_dp_gloo.py.
+@pytest.mark.parametrize("case", ["c4_bimodal_uni", "c2_audio_bi_bahdanau", "c5_av_align"])
+def test_two_shards_with_sync_bn_equal_whole_batch(case):
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    O, ocfg, mcfg, W, batch = make(case, B=6, ragged=True, regress_aus=False)
+    whole = Seq2SeqModel(mcfg, weights=W)
+    whole.forward_train(Batch.from_numpy(batch))
+    whole.backward()
+    torch.cuda.synchronize()
+
+    def shard(lo, hi):
+        return O.Batch(**{k: (None if getattr(batch, k) is None else np.ascontiguousarray(getattr(batch, k)[lo:hi]))
+                          for k in ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len")})
+    models = [Seq2SeqModel(mcfg, weights=W) for _ in range(2)]
+    shards = [Batch.from_numpy(shard(0, 2)), Batch.from_numpy(shard(2, 6))]          # unequal shards on purpose
+    for m in models:
+        assert m.bn_sync_enable() is not None
+    L = batch.labels.shape[1]
+    denom = float(np.minimum(batch.labels_len, L).sum())
+    tot = sum(m.bn_sync_sums(b).clone() for m, b in zip(models, shards))
+    for m in models:
+        m.bn_sync["sum"].copy_(tot)
+    tot = sum(m.bn_sync_squares(b).clone() for m, b in zip(models, shards))
+    for m, b in zip(models, shards):
+        m.bn_sync["sq"].copy_(tot)
+        m.denom.fill_(denom)
+        m.forward_train(b, compute_denom=False)
+        m.backward()
+    torch.cuda.synchronize()
+    g = models[0].grads + models[1].grads
+    gw = whole.grads
+    assert float((g - gw).abs().max()) < 2e-5 * max(1.0, float(gw.abs().max())), float((g - gw).abs().max())
+    assert abs(float(models[0].loss.item() + models[1].loss.item()) - float(whole.loss.item())) < 1e-4
+    for s in mcfg.streams():
+        for k in ("moving_mean", "moving_variance"):
+            a, b_ = whole.export_tf_weights("params")[f"{s}/bn/{k}"], models[1].export_tf_weights("params")[f"{s}/bn/{k}"]
+            assert np.abs(a - b_).max() < 1e-6, (s, k)
