@@ -300,3 +300,57 @@ def test_two_shards_with_sync_bn_equal_whole_batch(case):
         for k in ("moving_mean", "moving_variance"):
             a, b_ = whole.export_tf_weights("params")[f"{s}/bn/{k}"], models[1].export_tf_weights("params")[f"{s}/bn/{k}"]
             assert np.abs(a - b_).max() < 1e-6, (s, k)
+
+
+# ------------------------------------------------------------------------------------------------
+# edge shapes: a single utterance, one-frame / one-token sequences, utterances at the minimum length next to full ones,
+# zero-length memories (an all-padding row), and a batch wider than one 64-row slice of the persistent kernels
+def _edge_batch(O, ocfg, B, Ta, Tv, L, alen, vlen, llen):
+    b = O.synthetic_batch(ocfg, B=B, T_a=Ta, T_v=Tv, L=L, ragged=False)
+    if b.audio is not None:
+        b.audio_len = np.asarray(alen, np.int32)
+        b.audio *= (np.arange(Ta)[None, :, None] < b.audio_len[:, None, None])
+    if b.video is not None:
+        b.video_len = np.asarray(vlen, np.int32)
+        b.video *= (np.arange(Tv)[None, :, None] < b.video_len[:, None, None])
+    b.labels_len = np.asarray(llen, np.int32)
+    for i in range(B):
+        b.labels[i, b.labels_len[i] - 1] = ocfg.eos_id
+        b.labels[i, b.labels_len[i]:] = 0
+    return b
+
+
+EDGE = [
+    ("c1_audio_uni_luong", dict(B=1, Ta=1, Tv=1, L=1, alen=[1], vlen=[1], llen=[1])),
+    ("c4_bimodal_uni", dict(B=1, Ta=9, Tv=3, L=4, alen=[9], vlen=[3], llen=[4])),
+    ("c4_bimodal_uni", dict(B=3, Ta=12, Tv=5, L=6, alen=[1, 12, 7], vlen=[5, 1, 2], llen=[6, 1, 2])),
+    ("c2_audio_bi_bahdanau", dict(B=3, Ta=10, Tv=4, L=5, alen=[1, 10, 2], vlen=[1, 1, 1], llen=[1, 5, 3])),
+    ("c5_av_align", dict(B=2, Ta=8, Tv=4, L=3, alen=[8, 1], vlen=[1, 4], llen=[3, 1])),
+    ("gru_av_align", dict(B=2, Ta=6, Tv=3, L=3, alen=[1, 6], vlen=[3, 1], llen=[1, 3])),
+    ("c3_video_bi_normed", dict(B=2, Ta=4, Tv=7, L=4, alen=[4, 4], vlen=[1, 7], llen=[4, 2])),
+    ("c4_bimodal_uni", dict(B=67, Ta=6, Tv=3, L=3, alen=[6] * 30 + [1] * 7 + [3] * 30, vlen=[3] * 40 + [1] * 27, llen=[3] * 50 + [1] * 17)),
+]
+
+
+@pytest.mark.parametrize("case,shape", EDGE)
+def test_edge_shapes_train_and_greedy(case, shape):
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    O, ocfg, mcfg, W, _ = make(case, B=2)
+    batch = _edge_batch(O, ocfg, **shape)
+    ref = O.train_step(W, None, ocfg, batch)
+    model = Seq2SeqModel(mcfg, weights=W)
+    db = Batch.from_numpy(batch)
+    logits = model.forward_train(db)
+    model.backward()
+    model.apply_update()
+    torch.cuda.synchronize()
+    assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
+    assert abs(float(model.loss.item()) - ref["loss"]) < 1e-4
+    assert abs(float(model.gnorm.item()) - ref["global_norm"]) < 1e-4 * max(1.0, ref["global_norm"])
+    grads = model.export_tf_weights("grads")
+    for k, g in ref["grads"].items():
+        scale = max(1e-3, np.abs(g).max())
+        assert np.abs(grads[k] - g).max() < 2e-4 * scale + 1e-6, k
+    ids_ref = O.greedy_decode(ref["params"], ocfg, batch, max_steps=6)
+    ids = model.greedy_decode(db, max_steps=6).cpu().numpy()
+    assert ids.shape == ids_ref.shape and (ids == ids_ref).all()
