@@ -23,7 +23,7 @@ from .io_utils import (_get_input_shape_from_record, create_unit_dict, make_iter
                        make_iterator_from_two_records)
 from .model import Batch, Seq2SeqModel
 from .parallel import DataParallelTrainer
-from .utils import compute_wer, write_sequences_to_labelfile
+from .utils import alignment_image, compute_wer, write_png_gray, write_sequences_to_labelfile
 
 
 class AVSR(object):
@@ -114,6 +114,10 @@ class AVSR(object):
         if decoding_algorithm not in ('greedy', 'beam_search'):
             raise Exception('The only supported algorithms are `greedy` and `beam_search`')     # decoder_unimodal.py:124
         self._decoding_algorithm, self._beam_width = decoding_algorithm, beam_width
+        self._write_attention_alignment = bool(write_attention_alignment)
+        if self._write_attention_alignment and decoding_algorithm != 'greedy':
+            raise NotImplementedError("write_attention_alignment=True needs decoding_algorithm='greedy' (the alignment history is "
+                                      "kept by the greedy decode only)")
 
         reverse = {v: k for k, v in self._unit_dict.items()}
         feats, video_hw = {}, (36, 36, 3)
@@ -251,6 +255,24 @@ class AVSR(object):
                 f.flush()
         f.close()
 
+    def _write_alignments(self, names, alignments_outdir):
+        """`<file>.png` (unimodal / av_align decoder), `<file>_video.png` + `<file>_audio.png` (bimodal), `<file>_av.png`
+        (AV-Align cross-modal), one greyscale image [T_memory x T_decoder] per utterance (avsr/avsr.py:404-436)."""
+        al = self._model.attention_alignments()
+        dec = [a.cpu().numpy() for a in al["decoder"]]
+        enc = None if al["encoder"] is None else al["encoder"].cpu().numpy()
+        arch = self._cfg.architecture
+        for idx in range(len(names)):
+            base = path.join(alignments_outdir, names[idx].decode('utf-8'))
+            makedirs(path.dirname(base), exist_ok=True)
+            if arch == 'bimodal':
+                write_png_gray(base + '_video.png', alignment_image(dec[0][idx]))
+                write_png_gray(base + '_audio.png', alignment_image(dec[-1][idx]))
+            else:
+                write_png_gray(base + '.png', alignment_image(dec[0][idx]))
+                if arch == 'av_align':
+                    write_png_gray(base + '_av.png', alignment_image(enc[idx]))
+
     def evaluate(self, checkpoint_path, epoch=None, alignments_outdir='./alignments/tmp/', beam_graphs_outdir='./beam_graphs/tmp/'):
         self.restore(checkpoint_path)                         # the path argument is honoured, as in avsr.py:328-331
         predictions_dict, labels_dict = {}, {}
@@ -261,6 +283,8 @@ class AVSR(object):
             else:
                 ids = self._model.greedy_decode(batch, max_steps=self._cfg.max_label_length)
             ids = ids.cpu().numpy()
+            if self._write_attention_alignment:
+                self._write_alignments(names, alignments_outdir)
             for idx in range(len(names)):
                 file = names[idx].decode('utf-8')
                 predictions_dict[file] = [self._unit_dict[int(s)] for s in ids[idx]]

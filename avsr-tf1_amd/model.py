@@ -1124,8 +1124,35 @@ class Seq2SeqModel:
                 break
         t_out = min(int(D["steplen"].max().item()), l)   # dynamic_decode stops once every utterance has finished
         self._last_greedy = (ws, t_out)
+        self._last_align = None
         self.check_persistent()
         return D["ids"][:, :t_out].contiguous()
+
+    def attention_alignments(self):
+        """alignment_history of the LAST greedy_decode (decoder_unimodal.py:273-290, decoder_bimodal.py:447-475,
+        encoder.py:296-310): {"decoder": [alpha [B, T_out, T_mem] per mechanism, video first], "encoder": alpha
+        [B, T_a, T_v] of the AV-Align layer or None}.  The raw scores the attention kernels kept are normalised in place
+        (masked softmax over the valid memory frames); steps after an utterance finished are rows of zeros."""
+        if self._last_align is not None:
+            return self._last_align
+        ws, t_out = self._last_greedy
+        out = {"decoder": [], "encoder": None}
+
+        def alphas(blk, steplen):
+            res = []
+            for m in blk["mems"]:
+                md = self._mem_desc(ws, m["stream"])
+                g_t = self._pp(m["prefix"] + "/g") if m["type"] == "scaled_luong" else None
+                ops.attn_alpha_rows(m["scores"], m["scores"], md["len"], steplen, g_t, None, blk["B"], blk["L"], m["T"])
+                res.append(m["scores"].view(blk["B"], blk["L"], m["T"]))
+            return res
+        D = ws["dec"]
+        out["decoder"] = [a[:, :t_out] for a in alphas(D, D["steplen"])]
+        if self.cfg.architecture == "av_align":
+            E = ws["enc"]["audio"]
+            out["encoder"] = alphas(E["blk"], E["len"])[0]
+        self._last_align = out
+        return out
 
 
 class _Tiled:

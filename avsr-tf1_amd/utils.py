@@ -59,3 +59,33 @@ def get_files(file_list, dataset_dir, remove_sa=True, shuffle_sentences=False):
         from random import shuffle
         shuffle(names)
     return names
+
+
+# ------------------------------------------------------------------------------------------------
+# attention-alignment images (write_attention_alignment=True: avsr/avsr.py:354-366, :404-436)
+def alignment_image(alpha):
+    """uint8 [T_mem, T_dec] image of one utterance's alignment alpha [T_dec, T_mem], as tf.summary.image renders the
+    reference's `1 - transpose(alignment)` float tensor (decoder_unimodal.py:283-288): per image, non-negative values are
+    scaled so the largest becomes 255 (0 if it is below 1e-6) and truncated to uint8."""
+    import numpy as np
+    img = 1.0 - np.asarray(alpha, dtype=np.float32).T
+    top = float(img.max()) if img.size else 0.0
+    scale = 0.0 if top < 1e-6 else 255.0 / top
+    return (img * scale).astype(np.uint8)
+
+
+def write_png_gray(fname, img):
+    """Minimal 8-bit greyscale PNG writer (signature, IHDR, one IDAT of filter-0 scanlines, IEND)."""
+    import struct
+    import zlib
+    import numpy as np
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+
+    def chunk(tag, data):
+        body = tag + data
+        return struct.pack(">I", len(data)) + body + struct.pack(">I", zlib.crc32(body) & 0xFFFFFFFF)
+    raw = b"".join(b"\x00" + img[r].tobytes() for r in range(h))
+    with open(fname, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))

@@ -916,9 +916,12 @@ def train_step(P_np: Dict[str, np.ndarray], opt: Optional[dict], cfg: OracleConf
 
 @torch.no_grad()
 def greedy_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Batch, max_steps: Optional[int] = None,
-                  dtype=torch.float64, return_logits: bool = False):
+                  dtype=torch.float64, return_logits: bool = False, return_alignments: bool = False):
     """Eval graph: BN moving stats, GreedyEmbeddingHelper, dynamic_decode(impute_finished=True)
-    (decoder_unimodal.py:176-217; decoder_bimodal.py:279-323).  Returns int32 [B, T_out]."""
+    (decoder_unimodal.py:176-217; decoder_bimodal.py:279-323).  Returns int32 [B, T_out].
+    return_alignments: also {"decoder": [alpha [B, T_out, T_mem] per mechanism], "encoder": AV-Align alpha [B, T_a, T_v] | None}
+    (alignment_history, decoder_unimodal.py:273-290); rows of steps after an utterance finished are reported as zeros
+    (TF keeps writing whatever the un-imputed cell call produced there -- don't-care values under the image)."""
     P = to_torch(P_np, dtype)
     m = _Model(P, cfg, batch, False, dtype)
     B = m.B
@@ -926,9 +929,10 @@ def greedy_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Batch, 
     tok = torch.full((B,), cfg.go_id, dtype=torch.int64)
     state, att = m.init_state, torch.zeros(B, m.att_dim, dtype=dtype)
     finished = torch.zeros(B, dtype=torch.bool)
-    ids, lgs = [], []
+    ids, lgs, als = [], [], []
     for t in range(max_steps):
-        out, ns, natt, _ = m.step(P["dec/embedding"][tok], state, att)
+        out, ns, natt, al = m.step(P["dec/embedding"][tok], state, att)
+        als.append([torch.where(finished[:, None], torch.zeros_like(a), a) for a in al])
         lg = m.logits(out)
         sample = torch.argmax(lg, dim=-1)
         f = finished[:, None]
@@ -941,6 +945,13 @@ def greedy_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Batch, 
         if bool(finished.all()):
             break
     ids = torch.stack(ids, dim=1).to(torch.int32).numpy()
+    if return_alignments:
+        dec = [torch.stack([a[i] for a in als], dim=1).numpy() for i in range(len(als[0]))]
+        enc = None
+        if cfg.architecture == "av_align":
+            enc = m.enc["audio"].alignments.numpy()
+            enc = enc * (np.arange(enc.shape[1])[None, :, None] < np.asarray(batch.audio_len)[:, None, None])
+        return ids, {"decoder": dec, "encoder": enc}
     if return_logits:
         return ids, torch.stack(lgs, dim=1).numpy()
     return ids

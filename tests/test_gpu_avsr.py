@@ -99,3 +99,26 @@ def test_avsr_visual_only_from_lip_crops(tmp_path, monkeypatch):
     exp.save("checkpoints/video/checkpoint.ckp-3")
     w = np.load("checkpoints/video/checkpoint.ckp-3.npz")
     assert "params:video/cnn/flatten/kernel" in w.files and w["params:video/cnn/flatten/kernel"].shape == (5, 5, 16, 32)
+
+
+def test_avsr_writes_attention_alignment_images(tmp_path, monkeypatch):
+    """write_attention_alignment=True (avsr/avsr.py:354-366, :404-436): <file>.png + <file>_av.png for AV-Align,
+    <file>_video.png + <file>_audio.png for the bimodal decoder."""
+    import avsr_tf1_amd as avsr
+    monkeypatch.chdir(tmp_path)
+    unit_file, p = _dataset(str(tmp_path), n=5)
+    common = dict(unit="character", unit_file=unit_file, video_processing="features", video_train_record=p["video"], video_test_record=p["video"],
+                  audio_processing="features", audio_train_record=p["audio"], audio_test_record=p["audio"], labels_train_record=p["labels"],
+                  labels_test_record=p["labels"], batch_size=(4, 4), encoder_units_per_layer=((32,), (32, 32)), decoder_units_per_layer=(32,),
+                  embedding_size=16, decoding_algorithm="greedy", write_attention_alignment=True, warmup_steps=0)
+    for arch, suffixes in (("av_align", (".png", "_av.png")), ("bimodal", ("_video.png", "_audio.png"))):
+        exp = avsr.AVSR(architecture=arch, **common)
+        exp.train(logfile="logs/al_" + arch, num_epochs=2)
+        exp.save("checkpoints/al_%s/checkpoint.ckp-1" % arch)
+        exp.evaluate("checkpoints/al_%s/checkpoint.ckp-1" % arch, epoch=1, alignments_outdir="alignments/" + arch)
+        for i in range(5):
+            for suf in suffixes:
+                f = "alignments/%s/utt%02d%s" % (arch, i, suf)
+                assert os.path.exists(f) and open(f, "rb").read(8) == b"\x89PNG\r\n\x1a\n", f
+    with pytest.raises(NotImplementedError):
+        avsr.AVSR(architecture="bimodal", **dict(common, decoding_algorithm="beam_search"))

@@ -354,3 +354,32 @@ def test_edge_shapes_train_and_greedy(case, shape):
     ids_ref = O.greedy_decode(ref["params"], ocfg, batch, max_steps=6)
     ids = model.greedy_decode(db, max_steps=6).cpu().numpy()
     assert ids.shape == ids_ref.shape and (ids == ids_ref).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# alignment_history of the greedy decode (write_attention_alignment=True): decoder mechanisms + the AV-Align layer
+@pytest.mark.parametrize("case", ["c1_audio_uni_luong", "c2_audio_bi_bahdanau", "c3_video_bi_normed", "c4_bimodal_uni", "bimodal_bi_mixed",
+                                  "c5_av_align", "av_align_1layer_bahdanau", "gru_av_align"])
+def test_greedy_attention_alignments(case):
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    O, ocfg, mcfg, W, batch = make(case)
+    r1 = O.train_step(W, None, ocfg, batch)
+    W2 = {k: v.copy() for k, v in r1["params"].items()}
+    W2["dec/out/bias"][ocfg.eos_id] += 1.5                       # some utterances finish early -> zero rows after EOS
+    ids_ref, al_ref = O.greedy_decode(W2, ocfg, batch, max_steps=9, return_alignments=True)
+    model = Seq2SeqModel(mcfg, weights=W2)
+    ids = model.greedy_decode(Batch.from_numpy(batch), max_steps=9).cpu().numpy()
+    assert (ids == ids_ref).all()
+    al = model.attention_alignments()
+    assert al is model.attention_alignments()                    # idempotent (scores are normalised in place once)
+    assert len(al["decoder"]) == len(al_ref["decoder"])
+    for a, r in zip(al["decoder"], al_ref["decoder"]):
+        a = a.cpu().numpy()
+        assert a.shape == r.shape and np.abs(a - r).max() < 1e-5
+        live = r.sum(-1) > 0
+        assert np.abs(a.sum(-1)[live] - 1.0).max() < 1e-5        # rows of a live step sum to one over the valid frames
+    if ocfg.architecture == "av_align":
+        a = al["encoder"].cpu().numpy()
+        assert a.shape == al_ref["encoder"].shape and np.abs(a - al_ref["encoder"]).max() < 1e-5
+    else:
+        assert al["encoder"] is None

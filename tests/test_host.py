@@ -136,3 +136,34 @@ def test_cer_wer_against_reference_outputs():
     assert abs(cer - g["cer"]) < 1e-12 and all(abs(per[k] - v) < 1e-12 for k, v in g["cer_per_file"].items())
     wer, per = utils.compute_wer(g["predictions"], g["truth"], split_words=True)
     assert abs(wer - g["wer"]) < 1e-12 and all(abs(per[k] - v) < 1e-12 for k, v in g["wer_per_file"].items())
+
+
+def test_alignment_image_and_png_writer(tmp_path):
+    """tf.summary.image rendering of 1 - alpha (per-image max -> 255, truncation) and a PNG any decoder can read back."""
+    import struct
+    import zlib
+    from avsr_tf1_amd.utils import alignment_image, write_png_gray
+    rng = np.random.default_rng(3)
+    alpha = rng.random((5, 7)).astype(np.float32)
+    alpha /= alpha.sum(-1, keepdims=True)
+    alpha[3:] = 0.0                                            # steps after EOS
+    img = alignment_image(alpha)
+    assert img.shape == (7, 5) and img.dtype == np.uint8 and img.max() == 255 and (img[:, 3:] == 255).all()
+    want = np.floor((1 - alpha.T) * (255.0 / (1 - alpha.T).max())).astype(np.uint8)
+    assert np.abs(img.astype(int) - want.astype(int)).max() <= 1
+    assert (alignment_image(np.ones((2, 1), np.float32)) == 0).all()      # an all-zero image stays zero (max < 1e-6)
+    f = tmp_path / "a.png"
+    write_png_gray(str(f), img)
+    raw = f.read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, {}
+    while pos < len(raw):
+        n, tag = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data) & 0xFFFFFFFF
+        chunks[tag] = data
+        pos += 12 + n
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[b"IHDR"][:10])
+    assert (w, h, depth, ctype) == (5, 7, 8, 0)
+    rows = np.frombuffer(zlib.decompress(chunks[b"IDAT"]), np.uint8).reshape(h, w + 1)
+    assert (rows[:, 0] == 0).all() and (rows[:, 1:] == img).all()
