@@ -7,11 +7,14 @@ __version__ = "0.1.0"
 
 
 def __getattr__(name):
-    """Lazy exports of the reference's public surface (avsr/__init__.py:1-3): AVSR, run_experiment."""
+    """Lazy exports of the reference's public surface (avsr/__init__.py:1-3): AVSR, run_experiment, LM."""
     if name == "AVSR":
         from .avsr import AVSR
         return AVSR
     if name == "run_experiment":
         from .experiment import run_experiment
         return run_experiment
+    if name == "LM":
+        from .lm import LM
+        return LM
     raise AttributeError(name)

@@ -79,7 +79,7 @@ class ModelConfig:
 
     def decoder_memories(self) -> List[Tuple[str, str]]:
         """[(stream, attention_type)] in AttentionWrapper order (decoder_bimodal.py:184-223: video first)."""
-        if not self.enable_attention:
+        if not self.enable_attention or self.architecture == "lm":
             return []
         if self.architecture == "bimodal":
             out = []
@@ -96,7 +96,10 @@ class ModelConfig:
         return bool(mems) and mems[-1][1] in LUONG_TYPES
 
     def validate(self):
-        if self.architecture not in ("unimodal", "bimodal", "av_align"):
+        if self.architecture == "lm":                                                 # avsr.LM (lm.py:275-471): labels only, no encoders
+            if self.video_units is not None or self.audio_units is not None:
+                raise ValueError("the language model has no encoders")
+        elif self.architecture not in ("unimodal", "bimodal", "av_align"):
             raise Exception("Unknown architecture")                                   # seq2seq.py:66
         if self.encoder_type not in ("unidirectional", "bidirectional"):
             raise Exception("Allowed encoder types: `unidirectional`, `bidirectional`")  # encoder.py:146
@@ -124,7 +127,7 @@ class ModelConfig:
             raise ValueError("input_dense_layers must be positive multiples of 4 for the HIP engine")
         if len(self.decoder_units) != 1:
             raise NotImplementedError("multi-layer decoders are not built yet")
-        if not self.streams():
+        if not self.streams() and self.architecture != "lm":
             raise Exception("labels are None")                                         # seq2seq.py:94
         dims = [self.embedding_size, self.decoder_units[0]]
         for s in self.streams():

@@ -311,6 +311,16 @@ __global__ void seq_loss_kernel(float* logits, const int32_t* labels, const int3
   if (dl) for (int v = 0; v < V; ++v) dl[v] = (expf(lg[v] - lse) - (v == y ? 1.f : 0.f)) * inv;
 }
 
+// per-utterance average of the masked step losses: out[b] = sum_l row_loss[b,l] * (denom + 1e-12) / (min(len,L) + 1e-12)
+// (sequence_loss(average_across_batch=False, average_across_timesteps=True), avsr/lm.py:390-401; row_loss carries 1/denom)
+__global__ void seq_avg_kernel(const float* row_loss, const int32_t* len, const float* denom, float* out, int B, int L) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int l = 0; l < L; ++l) s += row_loss[(long)b * L + l];
+  out[b] = s * (denom[0] + 1e-12f) / ((float)min(max(len[b], 0), L) + 1e-12f);
+}
+
 // ---------------------------------------------------------------------------------------------
 // AU regression loss (encoder.py:173-189): pred = sigmoid(z), target = clip(aus,0,3)/3,
 // loss = sum_w (pred - tgt)^2 / sum_w  over valid frames x 2 units;  dz = weight * 2 (pred-tgt) pred (1-pred) / sum_w
@@ -661,6 +671,14 @@ extern "C" int avsr_seq_loss(float* logits, const int32_t* labels, const int32_t
   }
   hipLaunchKernelGGL(seq_loss_kernel, dim3((B * L + 127) / 128), dim3(128), 0, S_(stream), logits, labels, labels_len,
                      denom, row_loss, dlogits, B, L, V);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_seq_loss_per_utterance(const float* row_loss, const int32_t* labels_len, const float* denom, float* out,
+                                           int32_t B, int32_t L, void* stream) {
+  if (!row_loss || !labels_len || !denom || !out || B <= 0 || L <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(seq_avg_kernel, dim3((B + 63) / 64), dim3(64), 0, S_(stream), row_loss, labels_len, denom, out, B, L);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

@@ -306,6 +306,10 @@ class _Pipeline:
         self.shapes = [_get_input_shape_from_record(r) for r in data_records]
         self.batch_size, self.shuffle, self.bucket_width, self.max_len = batch_size, shuffle, bucket_width, max_sentence_length
         self.rng = random.Random(seed)
+        self.shuffle_buffer = 5000
+
+    def _key(self, ex):
+        return ex[0][0][2] // self.bucket_width                # first stream's input_length (video for AV)
 
     def _examples(self):
         its = [read_tfrecord(r) for r in self.data_records] + [read_tfrecord(self.label_record)]
@@ -323,12 +327,16 @@ class _Pipeline:
         buf = []
         for ex in self._examples():
             buf.append(ex)
-            if len(buf) >= 5000:
+            if len(buf) >= self.shuffle_buffer:
                 yield buf.pop(self.rng.randrange(len(buf)))
         self.rng.shuffle(buf)
         yield from buf
 
     def _batch(self, exs):
+        if not exs[0][0]:                                       # label-only pipelines (language model)
+            names = [e[1][2] for e in exs]
+            return BatchedData(None, None, None, None, _pad_stack([e[1][0] for e in exs]), np.array([e[1][1] for e in exs], np.int32),
+                               None if names[0] is None else names, None)
         streams = list(zip(*[e[0] for e in exs]))
         inputs = [_pad_stack([s[0] for s in st]) for st in streams]
         lens = [np.array([s[2] for s in st], np.int32) for st in streams]
@@ -357,7 +365,7 @@ class _Pipeline:
             return
         windows = collections.OrderedDict()
         for ex in self._shuffled():
-            key = ex[0][0][2] // self.bucket_width             # first stream's input_length (video for AV)
+            key = self._key(ex)
             w = windows.setdefault(key, [])
             w.append(ex)
             if len(w) == self.batch_size:
@@ -379,3 +387,41 @@ def make_iterator_from_two_records(video_record, audio_record, label_record, bat
                                    reverse_input=False, bucket_width=-1, num_cores=4, seed=None):
     """Iterable of BatchedData with (video, audio) tuples (avsr/io_utils.py:168-259); buckets on the VIDEO length."""
     return _Pipeline([video_record, audio_record], label_record, unit_dict, batch_size, shuffle, bucket_width, None, seed)
+
+
+class _LabelPipeline(_Pipeline):
+    """Label-only batches for avsr.LM: TFRecord labels (EOS appended, shuffle buffer 45000; avsr/io_utils.py:262-308) or a
+    text file, one sentence per line split into characters and looked up in the unit list (no EOS, unknown symbols -> -1,
+    shuffle buffer 1000000; avsr/io_utils.py:383-440).  Buckets on the label length."""
+
+    def __init__(self, label_record, text_dataset, unit_dict, batch_size, shuffle, bucket_width, seed=None):
+        self.label_record, self.text_dataset = label_record, text_dataset
+        self.eos = {v: k for k, v in unit_dict.items()}["EOS"]
+        self.lookup = {v: k for k, v in unit_dict.items()}
+        self.batch_size, self.shuffle, self.bucket_width = batch_size, shuffle, bucket_width
+        self.rng = random.Random(seed)
+        self.shuffle_buffer = 45000 if text_dataset is None else 1000000
+
+    def _key(self, ex):
+        return ex[1][1] // self.bucket_width
+
+    def _examples(self):
+        if self.text_dataset is None:
+            for rec in read_tfrecord(self.label_record):
+                yield (), _parse_labels(rec, self.eos)
+            return
+        with open(self.text_dataset, "r") as f:
+            for line in f:
+                chars = list(line.rstrip("\n"))
+                yield (), (np.array([self.lookup.get(c, -1) for c in chars], dtype=np.int32), len(chars), None)
+
+
+def make_iterator_from_label_record(label_record, batch_size, unit_dict, shuffle=False, reverse_input=False, bucket_width=-1, num_cores=4,
+                                    seed=None):
+    """Iterable of label-only BatchedData (avsr/io_utils.py:262-308)."""
+    return _LabelPipeline(label_record, None, unit_dict, batch_size, shuffle, bucket_width, seed)
+
+
+def make_iterator_from_text_dataset(text_dataset, batch_size, unit_dict, shuffle=False, bucket_width=-1, num_cores=4, seed=None):
+    """Iterable of label-only BatchedData from a text file (avsr/io_utils.py:383-440)."""
+    return _LabelPipeline(None, text_dataset, unit_dict, batch_size, shuffle, bucket_width, seed)

@@ -868,6 +868,11 @@ class Seq2SeqModel:
         cfg, B = self.cfg, ws["B"]
         D = ws["dec"]
         H = cfg.decoder_units[0]
+        if cfg.architecture == "lm":                         # lm.py:352-353: MultiRNNCell.zero_state
+            if "h0buf" not in D:
+                D["c0buf"], D["h0buf"] = torch.zeros(B, H, device=self.dev), torch.zeros(B, H, device=self.dev)
+            D["h0"], D["c0"] = D["h0buf"], (None if self.gru else D["c0buf"])
+            return
         if cfg.architecture != "bimodal":
             s = "audio" if "audio" in ws["enc"] else "video"
             E = ws["enc"][s]
@@ -889,6 +894,8 @@ class Seq2SeqModel:
         cfg, B = self.cfg, ws["B"]
         D = ws["dec"]
         H = cfg.decoder_units[0]
+        if cfg.architecture == "lm":
+            return
         if cfg.architecture != "bimodal":
             s = "audio" if "audio" in ws["enc"] else "video"
             self._final_state_bwd(ws, s, D["dc0"], D["dh0"])
@@ -964,6 +971,18 @@ class Seq2SeqModel:
             ops.reduce_scalar(Ev["au_row"], B * Ev["T"], self.loss, accumulate=True)
         return D["logits"]
 
+    def sequence_likelihoods(self, batch: Batch):
+        """Teacher-forced forward, then the per-utterance average step loss [B] (the LM's evaluate graph, lm.py:362-401:
+        `average_log_likelihoods`).  Uses this engine's own dropout / sampling settings: build the evaluation engine with
+        use_dropout=False, sampling_probability=0 as the reference builds its evaluate graph."""
+        self.forward_train(batch)
+        ws, _ = self._cur
+        D = ws["dec"]
+        if "utt_loss" not in D:
+            D["utt_loss"] = torch.zeros(ws["B"], device=self.dev)
+        ops.seq_loss_per_utterance(D["row_loss"], batch.labels_len, self.denom, D["utt_loss"], ws["B"], ws["L"])
+        return D["utt_loss"]
+
     def backward(self):
         """BPTT through decoder and encoders; leaves the full gradient in self.grads (engine layout)."""
         cfg = self.cfg
@@ -1026,7 +1045,7 @@ class Seq2SeqModel:
         int32 [B, T_out]; positions after the first EOS hold EOS (gather_tree).  length_penalty_weight defaults to the
         reference's 0.6 (unimodal / av_align) or 0.5 (bimodal)."""
         cfg, K = self.cfg, int(beam_width)
-        B = (batch.audio if batch.audio is not None else batch.video).shape[0]
+        B = (batch.audio if batch.audio is not None else batch.video if batch.video is not None else batch.labels).shape[0]
         L = cfg.max_label_length if max_steps is None else max_steps
         w = length_penalty_weight if length_penalty_weight is not None else (0.5 if cfg.architecture == "bimodal" else 0.6)
         Ta = batch.audio.shape[1] if batch.audio is not None else 0
@@ -1096,7 +1115,7 @@ class Seq2SeqModel:
     def greedy_decode(self, batch: Batch, max_steps: Optional[int] = None, check_every: int = 8):
         """Eval graph with GreedyEmbeddingHelper (decoder_unimodal.py:176-217): int32 ids [B, T_out], zeros after EOS."""
         cfg = self.cfg
-        B = (batch.audio if batch.audio is not None else batch.video).shape[0]
+        B = (batch.audio if batch.audio is not None else batch.video if batch.video is not None else batch.labels).shape[0]
         L = cfg.max_label_length if max_steps is None else max_steps
         Ta = batch.audio.shape[1] if batch.audio is not None else 0
         Tv = batch.video.shape[1] if batch.video is not None else 0

@@ -203,6 +203,11 @@ def global_norm(grads, n, norm_out, scratch, grad_scale=1.0):
           "avsr_global_norm")
 
 
+def seq_loss_per_utterance(row_loss, labels_len, denom, out, B, L):
+    check(_L().avsr_seq_loss_per_utterance(fptr(row_loss), fptr(labels_len), fptr(denom), fptr(out), B, L, _s()),
+          "avsr_seq_loss_per_utterance")
+
+
 def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, grad_scale=1.0, first_decay_steps=0):
     check(_L().avsr_adam_step_decay(fptr(params), fptr(grads), fptr(m), fptr(v), n, fptr(gnorm), fptr(step), float(lr),
                                     int(warmup_steps), int(first_decay_steps), float(clip_norm), float(grad_scale), _s()),

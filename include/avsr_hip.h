@@ -400,6 +400,11 @@ int avsr_dropout_rows(const avsr_mat* x, const avsr_mat* y, int32_t rows, int32_
 int avsr_seq_loss(float* logits, const int32_t* labels, const int32_t* labels_len, float* denom,
                   int32_t compute_denom, float* row_loss, float* dlogits, int32_t B, int32_t L, int32_t V, void* stream);
 
+/* Per-utterance average of the step losses avsr_seq_loss left in row_loss (which carry the 1/denom factor):
+ * out[b] = sum_l CE[b,l] w[b,l] / (sum_l w[b,l] + 1e-12) -- the language model's `average_log_likelihoods`
+ * (avsr/lm.py:390-401: sequence_loss(average_across_batch=False, average_across_timesteps=True)). */
+int avsr_seq_loss_per_utterance(const float* row_loss, const int32_t* labels_len, const float* denom, float* out, int32_t B,
+                                int32_t L, void* stream);
 /* AU regression loss (avsr/encoder.py:173-189); z = pre-sigmoid Dense(2) outputs [B][T][2]. */
 int avsr_au_loss(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz, int32_t B, int32_t T,
                  float weight, void* stream);

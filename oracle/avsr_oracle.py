@@ -105,7 +105,7 @@ class OracleConfig:
         bimodal: video mechanisms first, then audio (decoder_bimodal.py:184-223).
         unimodal / av_align: audio if present else video, types = attention_type[1]
         (seq2seq.py:96-112, decoder_unimodal.py:322)."""
-        if not self.enable_attention:
+        if not self.enable_attention or self.architecture == "lm":
             return []
         if self.architecture == "bimodal":
             out = []
@@ -126,7 +126,10 @@ class OracleConfig:
         return mems[-1][1] in LUONG_TYPES
 
     def validate(self):
-        if self.architecture not in ("unimodal", "bimodal", "av_align"):
+        if self.architecture == "lm":                                     # avsr.LM (lm.py:275-471): labels only
+            if self.video_units is not None or self.audio_units is not None:
+                raise ValueError("the language model has no encoders")
+        elif self.architecture not in ("unimodal", "bimodal", "av_align"):
             raise Exception("Unknown architecture")                       # seq2seq.py:66
         if self.encoder_type not in ("unidirectional", "bidirectional"):
             raise Exception("Allowed encoder types: `unidirectional`, `bidirectional`")  # encoder.py:146
@@ -737,7 +740,7 @@ class _Model:
                 attended = (self.enc["video"].outputs, self.lens["video"])
             self.enc["audio"] = encode_stream(P, cfg, "audio", tt(batch.audio), self.lens["audio"],
                                               training, self.bn_updates, attended, seed=seed, bn_stats=bn_stats.get("audio"))
-        self.B = (batch.audio if batch.audio is not None else batch.video).shape[0]
+        self.B = (batch.audio if batch.audio is not None else batch.video if batch.video is not None else batch.labels).shape[0]
         self.dtype = dtype
         self._init_decoder()
 
@@ -758,6 +761,9 @@ class _Model:
             c = torch.cat([vs[0], as_[0]], dim=-1) @ P["dec/state_proj"]
             h = torch.cat([vs[1], as_[1]], dim=-1) @ P["dec/state_proj"]
             self.init_state = (c, h)
+        elif cfg.architecture == "lm":                            # lm.py:352-353: cells.zero_state
+            z = torch.zeros(self.B, cfg.decoder_units[0], dtype=self.dtype)
+            self.init_state = (z, z) if cfg.cell_type == "lstm" else (z,)
         else:
             s = "audio" if "audio" in self.enc else "video"
             self.init_state = self.enc[s].final_state             # decoder_unimodal.py:144-145
@@ -912,6 +918,21 @@ def train_step(P_np: Dict[str, np.ndarray], opt: Optional[dict], cfg: OracleConf
     return {"loss": float(loss.detach()), "seq_loss": float(seq.detach()), "global_norm": float(gnorm.detach()),
             "grads": {k: g.detach().numpy() for k, g in grads.items()}, "params": newP, "opt": new_opt,
             "logits": logits.detach().numpy(), "fed_tokens": m.fed_tokens}
+
+
+@torch.no_grad()
+def lm_likelihoods(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Batch, dtype=torch.float64) -> np.ndarray:
+    """avsr.LM evaluate graph (lm.py:362-401): TrainingHelper (teacher forcing, no dropout) and
+    sequence_loss(average_across_batch=False, average_across_timesteps=True): per utterance
+    sum_t CE[b,t] w[b,t] / (sum_t w[b,t] + 1e-12) -- the reference calls these `average_log_likelihoods`."""
+    import dataclasses
+    ecfg = dataclasses.replace(cfg, use_dropout=False, sampling_probability=0.0)
+    logits, _ = forward_train(to_torch(P_np, dtype), ecfg, batch, dtype)
+    labels = torch.as_tensor(batch.labels, dtype=torch.int64)
+    ll = torch.as_tensor(batch.labels_len, dtype=torch.int64)
+    w = (torch.arange(labels.shape[1])[None, :] < ll[:, None]).to(dtype)
+    ce = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1), reduction="none").reshape(labels.shape)
+    return (torch.sum(ce * w, dim=1) / (torch.sum(w, dim=1) + 1e-12)).numpy()
 
 
 @torch.no_grad()

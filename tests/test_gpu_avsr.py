@@ -122,3 +122,51 @@ def test_avsr_writes_attention_alignment_images(tmp_path, monkeypatch):
                 assert os.path.exists(f) and open(f, "rb").read(8) == b"\x89PNG\r\n\x1a\n", f
     with pytest.raises(NotImplementedError):
         avsr.AVSR(architecture="bimodal", **dict(common, decoding_algorithm="beam_search"))
+
+
+def test_lm_train_checkpoints_and_evaluate(tmp_path, monkeypatch):
+    """avsr.LM (avsr/lm.py): label-record language model -- loss falls, a checkpoint per epoch with the newest five kept,
+    resume by epoch number, evaluate() writes per-sentence average losses that match the oracle's evaluate graph."""
+    import avsr_tf1_amd as avsr
+    from avsr_tf1_amd import io_utils as IO
+    from oracle import avsr_oracle as O
+    monkeypatch.chdir(tmp_path)
+    unit_file = os.path.join(str(tmp_path), "character_list")
+    open(unit_file, "w").write("\n".join(list("' abcdefghijklmnopqrstuvwxyz")) + "\n")
+    rec = os.path.join(str(tmp_path), "labels.tfrecord")
+    rng = np.random.default_rng(0)
+    sents = []
+    with IO.TFRecordFileWriter(rec) as f:
+        for i in range(24):
+            start = int(rng.integers(3, 9))
+            lab = [(start + j) % 9 + 3 for j in range(int(rng.integers(4, 12)))]      # a cyclic "language": next symbol is predictable
+            sents.append(lab)
+            f.write(IO.make_label_example("s%02d" % i, lab, "character"))
+    kw = dict(unit="character", unit_file=unit_file, labels_train_record=rec, labels_test_record=rec, batch_size=(8, 8),
+              decoder_units_per_layer=(32,), embedding_size=16, learning_rate=0.02, shuffle_seed=0)
+    lm = avsr.LM(**kw)
+    lm.train(logfile="logs/lm", num_epochs=8)
+    losses = [float(l.split()[-1]) for l in open("logs/lm").read().splitlines() if l.startswith("Average")]
+    assert len(losses) == 7 and losses[-1] < 0.7 * losses[0]
+    kept = sorted(os.listdir("checkpoints/lm"))
+    assert kept == ["checkpoint.ckp-%d.npz" % e for e in (3, 4, 5, 6, 7)]
+    like = lm.evaluate("checkpoints/lm/checkpoint.ckp-7", epoch=7)
+    lines = open("predictions/lm/predicted_epoch_7.mlf").read().splitlines()
+    assert len(lines) == 24 and lines[0].split()[0] in like
+    # the evaluate engine against the oracle's evaluate graph on the checkpointed weights
+    z = np.load("checkpoints/lm/checkpoint.ckp-7.npz")
+    W = {k[7:]: z[k] for k in z.files if k.startswith("params:")}
+    ocfg = O.OracleConfig(architecture="lm", video_units=None, audio_units=None, decoder_units=(32,), embedding_size=16, warmup_steps=0)
+    L = max(len(s) for s in sents) + 1
+    lab = np.zeros((24, L), np.int32)
+    for i, s in enumerate(sents):
+        lab[i, :len(s)] = s
+        lab[i, len(s)] = ocfg.eos_id
+    b = O.Batch()
+    b.labels, b.labels_len = lab, np.array([len(s) + 1 for s in sents], np.int32)
+    ref = O.lm_likelihoods(W, ocfg, b)
+    got = np.array([like["s%02d" % i] for i in range(24)])
+    assert np.abs(got - ref).max() < 1e-4
+    lm2 = avsr.LM(**kw)
+    lm2.train(logfile="logs/lm", num_epochs=2, try_restore_latest_checkpoint=True)
+    assert "Average batch_loss as epoch 8" in open("logs/lm").read()

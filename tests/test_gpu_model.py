@@ -51,6 +51,14 @@ CASES = {
                                cnn_filters=(8, 8, 16, 16), cnn_dense_units=16, video_feat=16, input_dense_layers=(24,)),
     "dense_no_bn": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32),
                         batch_normalisation=False, input_dense_layers=(16,)),
+    # enable_attention=False (decoder_unimodal.py:320: plain decoder cell from the encoder's final state, no memory)
+    "no_attention": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32),
+                         enable_attention=False),
+    "no_attention_gru_bi": dict(architecture="unimodal", encoder_type="bidirectional", video_units=None, audio_units=(32,),
+                                cell_type="gru", enable_attention=False),
+    # avsr.LM (lm.py:275-471): labels only -- embedding, decoder cell from the zero state, Dense(V), no warm-up
+    "lm_lstm": dict(architecture="lm", video_units=None, audio_units=None, warmup_steps=0),
+    "lm_gru": dict(architecture="lm", video_units=None, audio_units=None, cell_type="gru", warmup_steps=0),
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
@@ -106,7 +114,7 @@ def test_train_step_parity(case):
         assert err < 2e-5, (k, err)     # one Adam step moves each weight by <= lr_t ~ 4e-5 at step 1 of warm-up
 
 
-@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("case", [c for c in CASES if not c.startswith("lm_")])
 def test_greedy_decode_parity(case):
     from avsr_tf1_amd.model import Batch, Seq2SeqModel
     O, ocfg, mcfg, W, batch = make(case)
@@ -163,6 +171,8 @@ STOCH = [
     ("bimodal_input_dense", dict(use_dropout=True, sampling_probability=0.2)),
     ("av_align_1layer_dense", dict(use_dropout=True)),
     ("video_cnn_dense_bi", dict(use_dropout=True)),
+    ("no_attention", dict(use_dropout=True, sampling_probability=0.3)),
+    ("lm_lstm", dict(use_dropout=True, sampling_probability=0.1)),
 ]
 
 
@@ -383,3 +393,13 @@ def test_greedy_attention_alignments(case):
         assert a.shape == al_ref["encoder"].shape and np.abs(a - al_ref["encoder"]).max() < 1e-5
     else:
         assert al["encoder"] is None
+
+
+@pytest.mark.parametrize("case", ["lm_lstm", "lm_gru"])
+def test_lm_sequence_likelihoods(case):
+    """The language model's evaluate graph: per-utterance average step loss of a teacher-forced pass (lm.py:390-401)."""
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    O, ocfg, mcfg, W, batch = make(case, B=7, L=9)
+    ref = O.lm_likelihoods(W, ocfg, batch)
+    got = Seq2SeqModel(mcfg, weights=W).sequence_likelihoods(Batch.from_numpy(batch)).cpu().numpy()
+    assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-5

@@ -153,3 +153,39 @@ def test_two_record_pipeline_and_shuffle(tmp_path):
             assert np.array_equal(b.payload["aus"][i, :vlen[i]], vids[idx][1])
             n += 1
     assert n == 11
+
+
+def test_label_only_and_text_iterators(tmp_path):
+    """make_iterator_from_label_record / make_iterator_from_text_dataset (avsr/io_utils.py:262-308, :383-440)."""
+    from avsr_tf1_amd import io_utils as IO
+    unit_file = tmp_path / "character_list"
+    unit_file.write_text("\n".join(list("' abcdefghijklmnopqrstuvwxyz")) + "\n")
+    ud = IO.create_unit_dict(str(unit_file))
+    eos = {v: k for k, v in ud.items()}["EOS"]
+    rec = str(tmp_path / "labels.tfrecord")
+    rng = np.random.default_rng(0)
+    labs = [rng.integers(1, 28, size=int(n)).tolist() for n in (3, 35, 4, 31, 2, 40, 5)]
+    with IO.TFRecordFileWriter(rec) as f:
+        for i, lab in enumerate(labs):
+            f.write(IO.make_label_example("s%d" % i, lab, "character"))
+    batches = list(IO.make_iterator_from_label_record(rec, 2, ud, shuffle=False, bucket_width=30))
+    seen = {}
+    for bd in batches:
+        assert bd.inputs is None and bd.labels.dtype == np.int32
+        keys = {int(n) // 30 for n in bd.labels_length}
+        assert len(keys) == 1                                        # one bucket per batch (length incl. EOS // 30)
+        for row, n, name in zip(bd.labels, bd.labels_length, bd.labels_filenames):
+            assert row[n - 1] == eos and (row[n:] == 0).all()
+            seen[name.decode()] = row[:n - 1].tolist()
+    assert seen == {"s%d" % i: lab for i, lab in enumerate(labs)}
+    assert [len(bd.labels) for bd in batches] == [2, 2, 2, 1]        # full windows first, partial windows flushed at the end
+    txt = tmp_path / "corpus.txt"
+    txt.write_text("hello world\nab\nit's\n")
+    bds = list(IO.make_iterator_from_text_dataset(str(txt), 2, ud, shuffle=False, bucket_width=-1))
+    rev = {v: k for k, v in ud.items()}
+    assert bds[0].labels_length.tolist() == [11, 2] and bds[0].labels_filenames is None
+    assert bds[0].labels[0].tolist() == [rev[c] for c in "hello world"]          # no EOS on this path
+    assert bds[0].labels[1].tolist() == [rev["a"], rev["b"]] + [0] * 9
+    assert bds[1].labels[0].tolist() == [rev[c] for c in "it's"]
+    shuffled = list(IO.make_iterator_from_label_record(rec, 3, ud, shuffle=True, bucket_width=-1, seed=1))
+    assert sorted(n.decode() for bd in shuffled for n in bd.labels_filenames) == sorted(seen)
