@@ -167,3 +167,15 @@ def test_alignment_image_and_png_writer(tmp_path):
     assert (w, h, depth, ctype) == (5, 7, 8, 0)
     rows = np.frombuffer(zlib.decompress(chunks[b"IDAT"]), np.uint8).reshape(h, w + 1)
     assert (rows[:, 0] == 0).all() and (rows[:, 1:] == img).all()
+
+
+def test_integration_doc_lists_every_entry_point():
+    """INTEGRATION.md section 4 maps each C entry point declared in include/avsr_hip.h to the reference call site it replaces."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "avsr_hip.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = set(re.findall(r"^(?:int|int32_t|int64_t|const char\*|void)\s+(avsr_[a-z0-9_]+)\(", hdr, flags=re.M))
+    assert len(names) > 40
+    missing = sorted(n for n in names if not re.search(r"\b%s\b" % n, doc))
+    assert not missing, missing
