@@ -93,7 +93,7 @@ class AVSR(object):
 
         for name, val, ok in (("instance_normalisation", instance_normalisation, False), ("highway_encoder", highway_encoder, False),
                               ("residual_encoder", residual_encoder, False), ("encoder_weight_sharing", encoder_weight_sharing, False),
-                              ("loss_fun", loss_fun, None), ("precision", precision, 'float32'),
+                              ("precision", precision, 'float32'),
                               ("optimiser", optimiser, 'Adam')):
             if val != ok:
                 raise NotImplementedError("%s=%r is a non-default option of the reference that the HIP engine does not build" % (name, val))
@@ -103,8 +103,8 @@ class AVSR(object):
                 lr_decay_steps = int(lr_decay[1])
             else:
                 print('learning rate policy not implemented, falling back to constant learning rate')
-        if label_smoothing != 0.0:
-            raise NotImplementedError("label_smoothing is not built")
+        if loss_fun not in (None, 'focal_loss', 'mc_loss'):
+            raise ValueError('Unknown loss function {}'.format(loss_fun))                           # seq2seq.py:163
         if video_processing is not None and video_processing not in ('features', 'resnet_cnn'):
             if 'cnn' in video_processing:
                 raise NotImplementedError("video_processing=%r: only the default `resnet_cnn` front-end is built" % video_processing)
@@ -144,7 +144,7 @@ class AVSR(object):
             batch_normalisation=batch_normalisation, regress_aus=regress_aus,
             au_loss_weight=kwargs.get('au_loss_weight', 10.0),
             recurrent_l2=recurrent_l2_regularisation, clip_gradients=clip_gradients, max_gradient_norm=max_gradient_norm,
-            learning_rate=learning_rate, warmup_steps=kwargs.get('warmup_steps', 750), lr_decay_steps=lr_decay_steps,
+            learning_rate=learning_rate, warmup_steps=kwargs.get('warmup_steps', 750), lr_decay_steps=lr_decay_steps, loss_fun=loss_fun, label_smoothing=float(label_smoothing),
             max_label_length={'viseme': 150, 'phoneme': 150, 'character': 150}[unit],
             use_dropout=use_dropout, video_dropout=tuple(video_encoder_dropout_probability),
             audio_dropout=tuple(audio_encoder_dropout_probability), decoder_dropout=tuple(decoder_dropout_probability),

@@ -37,6 +37,8 @@ class ModelConfig:
     max_gradient_norm: float = 1.0
     learning_rate: float = 1e-3
     warmup_steps: int = 750
+    loss_fun: Optional[str] = None            # None | 'focal_loss' | 'mc_loss' (seq2seq.py:147-163, avsr/devel.py:12-51)
+    label_smoothing: float = 0.0              # > 0: tf.losses.softmax_cross_entropy path (seq2seq.py:151-155)
     lr_decay_steps: int = 0                   # lr_decay=('cosine_restarts', N) (seq2seq.py:266-270); 0 = constant lr
     max_label_length: int = 150
     use_dropout: bool = False
@@ -60,6 +62,14 @@ class ModelConfig:
         if self.audio_units is not None:
             s.append("audio")
         return s
+
+    def loss_code(self) -> int:
+        """avsr_seq_loss_fun's loss_fun argument."""
+        if self.loss_fun is None:
+            return 1 if self.label_smoothing > 0.0 else 0
+        if self.loss_fun not in ("focal_loss", "mc_loss"):
+            raise ValueError('Unknown loss function {}'.format(self.loss_fun))          # seq2seq.py:163
+        return 2 if self.loss_fun == "focal_loss" else 3
 
     def directions(self) -> List[str]:
         return ["fw", "bw"] if self.encoder_type == "bidirectional" else ["fw"]
@@ -116,6 +126,7 @@ class ModelConfig:
                 raise ValueError("AttentiveEncoder implements only `unidirectional` (encoder.py:229)")
             if self.video_units is None or self.audio_units is None:
                 raise ValueError("av_align needs both a video and an audio stream")
+        self.loss_code()
         if self.video_processing not in ("features", "resnet_cnn"):
             raise Exception("unknown visual content")                                   # avsr/avsr.py:713 (2dconv_cnn / 3dconv_cnn: not built)
         if self.video_units is not None and self.video_processing == "resnet_cnn":

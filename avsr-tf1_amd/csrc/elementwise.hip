@@ -286,29 +286,73 @@ __global__ void seqlen_sum_kernel(const int32_t* len, int B, int L, float* denom
   if (threadIdx.x == 0) denom[0] = s;
 }
 
+__global__ void set_scalar_kernel(float* p, float v) { p[0] = v; }
+
+// mode 0: sparse softmax cross-entropy; 1: tf.losses.softmax_cross_entropy with label smoothing, whose default reduction makes
+// the sequence loss the plain mean over ALL B*L rows (padding rows: imputed zero logits -> log V each, no gradient);
+// 2: focal loss (gamma 2), 3: multi-class sigmoid-style cross-entropy on the clipped softmax (avsr/devel.py:12-51).
 __global__ void seq_loss_kernel(float* logits, const int32_t* labels, const int32_t* len, const float* denom,
-                                float* row_loss, float* dlogits, int B, int L, int V) {
+                                float* row_loss, float* dlogits, int B, int L, int V, int mode, float smooth) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= B * L) return;
   const int b = row / L, l = row % L;
   float* lg = logits + (long)row * V;
   float* dl = dlogits ? dlogits + (long)row * V : nullptr;
   const bool valid = l < len[b];
+  const float inv = 1.f / (denom[0] + 1e-12f);     // mode 1: denom = number of rows B*L (of the GLOBAL batch under data parallelism)
   if (!valid) {
-    row_loss[row] = 0.f;
+    row_loss[row] = mode == 1 ? logf((float)V) * inv : 0.f;
     for (int v = 0; v < V; ++v) lg[v] = 0.f;       // dynamic_decode(impute_finished=True): zero outputs once finished
     if (dl) for (int v = 0; v < V; ++v) dl[v] = 0.f;
     return;
   }
-  const float inv = 1.f / (denom[0] + 1e-12f);
   float mx = lg[0];
   for (int v = 1; v < V; ++v) mx = fmaxf(mx, lg[v]);
   float s = 0.f;
   for (int v = 0; v < V; ++v) s += expf(lg[v] - mx);
   const float lse = mx + logf(s);
   const int y = labels[row];
-  row_loss[row] = (lse - lg[y]) * inv;
-  if (dl) for (int v = 0; v < V; ++v) dl[v] = (expf(lg[v] - lse) - (v == y ? 1.f : 0.f)) * inv;
+  if (mode == 0) {
+    row_loss[row] = (lse - lg[y]) * inv;
+    if (dl) for (int v = 0; v < V; ++v) dl[v] = (expf(lg[v] - lse) - (v == y ? 1.f : 0.f)) * inv;
+    return;
+  }
+  if (mode == 1) {
+    const float off = smooth / (float)V, on = 1.f - smooth + off;
+    float ce = 0.f;
+    for (int v = 0; v < V; ++v) ce += (v == y ? on : off) * (lse - lg[v]);
+    row_loss[row] = ce * inv;
+    if (dl) for (int v = 0; v < V; ++v) dl[v] = (expf(lg[v] - lse) - (v == y ? on : off)) * inv;
+    return;
+  }
+  // modes 2 / 3: loss = sum_v f_v(q_v), q = clip(softmax, 1e-7, 1 - 1e-7);  d/dz_k = p_k (a_k - sum_v a_v p_v), a_v = f_v'(q_v) [inside the clip]
+  float loss = 0.f, dot = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float p = expf(lg[v] - lse);
+    const float q = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+    const bool inside = (p >= 1e-7f) && (p <= 1.f - 1e-7f);
+    float f, a;
+    if (mode == 3) {
+      f = (v == y) ? -logf(q) : -logf(1.f - q);
+      a = (v == y) ? -1.f / q : 1.f / (1.f - q);
+    } else {
+      if (v == y) { f = -(1.f - q) * (1.f - q) * logf(q); a = 2.f * (1.f - q) * logf(q) - (1.f - q) * (1.f - q) / q; }
+      else        { f = -q * q * logf(1.f - q);           a = -2.f * q * logf(1.f - q) + q * q / (1.f - q); }
+    }
+    loss += f;
+    dot += inside ? a * p : 0.f;
+  }
+  row_loss[row] = loss * inv;
+  if (dl)
+    for (int v = 0; v < V; ++v) {
+      const float p = expf(lg[v] - lse);
+      const float q = fminf(fmaxf(p, 1e-7f), 1.f - 1e-7f);
+      const bool inside = (p >= 1e-7f) && (p <= 1.f - 1e-7f);
+      float a;
+      if (mode == 3) a = (v == y) ? -1.f / q : 1.f / (1.f - q);
+      else a = (v == y) ? 2.f * (1.f - q) * logf(q) - (1.f - q) * (1.f - q) / q : -2.f * q * logf(1.f - q) + q * q / (1.f - q);
+      dl[v] = p * ((inside ? a : 0.f) - dot) * inv;
+    }
 }
 
 // per-utterance average of the masked step losses: out[b] = sum_l row_loss[b,l] * (denom + 1e-12) / (min(len,L) + 1e-12)
@@ -664,13 +708,20 @@ extern "C" int avsr_dropout_rows(const avsr_mat* x, const avsr_mat* y, int32_t r
 extern "C" int avsr_seq_loss(float* logits, const int32_t* labels, const int32_t* labels_len, float* denom,
                              int32_t compute_denom, float* row_loss, float* dlogits, int32_t B, int32_t L, int32_t V,
                              void* stream) {
-  if (!logits || !labels || !labels_len || !denom || !row_loss) return AVSR_ERR_ARG;
+  return avsr_seq_loss_fun(logits, labels, labels_len, denom, compute_denom, row_loss, dlogits, B, L, V, 0, 0.f, stream);
+}
+
+extern "C" int avsr_seq_loss_fun(float* logits, const int32_t* labels, const int32_t* labels_len, float* denom,
+                                 int32_t compute_denom, float* row_loss, float* dlogits, int32_t B, int32_t L, int32_t V,
+                                 int32_t loss_fun, float label_smoothing, void* stream) {
+  if (!logits || !labels || !labels_len || !denom || !row_loss || loss_fun < 0 || loss_fun > 3) return AVSR_ERR_ARG;
   if (compute_denom) {
-    hipLaunchKernelGGL(seqlen_sum_kernel, dim3(1), dim3(256), 0, S_(stream), labels_len, B, L, denom);
+    if (loss_fun == 1) hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, S_(stream), denom, (float)B * (float)L);
+    else hipLaunchKernelGGL(seqlen_sum_kernel, dim3(1), dim3(256), 0, S_(stream), labels_len, B, L, denom);
     AVSR_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(seq_loss_kernel, dim3((B * L + 127) / 128), dim3(128), 0, S_(stream), logits, labels, labels_len,
-                     denom, row_loss, dlogits, B, L, V);
+                     denom, row_loss, dlogits, B, L, V, loss_fun, label_smoothing);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

@@ -964,12 +964,21 @@ class Seq2SeqModel:
         if not sampling:
             ov, O = self._out_vec(D)
             ops.gemm(ov, self.P["dec/out/kernel"].mat(V), ops.mat(D["logits"], V), B * L, V, O, bias=self._pp("dec/out/bias"))
-        ops.seq_loss(D["logits"], batch.labels, batch.labels_len, self.denom, compute_denom, D["row_loss"], D["dlogits"], B, L, V)
+        ops.seq_loss(D["logits"], batch.labels, batch.labels_len, self.denom, compute_denom, D["row_loss"], D["dlogits"], B, L, V,
+                     loss_fun=cfg.loss_code(), label_smoothing=cfg.label_smoothing)
         ops.reduce_scalar(D["row_loss"], B * L, self.loss)
         if cfg.regress_aus and "video" in ws["enc"]:
             Ev = ws["enc"]["video"]
             ops.reduce_scalar(Ev["au_row"], B * Ev["T"], self.loss, accumulate=True)
         return D["logits"]
+
+    def local_loss_denominator(self, batch: Batch):
+        """What this rank contributes to the loss normaliser the data-parallel trainer all-reduces: the number of valid label
+        steps (seq2seq.py:165-171), or the number of label ROWS when label smoothing makes the loss a mean over all rows."""
+        B, L = batch.labels.shape
+        if self.cfg.loss_code() == 1:
+            return torch.full((1,), float(B * L), device=self.dev)
+        return batch.labels_len.clamp(0, L).sum().to(torch.float32).reshape(1)
 
     def sequence_likelihoods(self, batch: Batch):
         """Teacher-forced forward, then the per-utterance average step loss [B] (the LM's evaluate graph, lm.py:362-401:

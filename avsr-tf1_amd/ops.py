@@ -165,9 +165,12 @@ def dropout_rows(x, y, rows, cols, seed, stream_id, keep, idx_width, idx_coff=0,
                                  int(idx_coff), int(accumulate), _s()), "avsr_dropout_rows")
 
 
-def seq_loss(logits, labels, labels_len, denom, compute_denom, row_loss, dlogits, B, L, V):
-    check(_L().avsr_seq_loss(fptr(logits), fptr(labels), fptr(labels_len), fptr(denom), int(compute_denom),
-                             fptr(row_loss), fptr(dlogits), B, L, V, _s()), "avsr_seq_loss")
+LOSS_FUN = {None: 0, "label_smoothing": 1, "focal_loss": 2, "mc_loss": 3}
+
+
+def seq_loss(logits, labels, labels_len, denom, compute_denom, row_loss, dlogits, B, L, V, loss_fun=0, label_smoothing=0.0):
+    check(_L().avsr_seq_loss_fun(fptr(logits), fptr(labels), fptr(labels_len), fptr(denom), int(compute_denom),
+                                 fptr(row_loss), fptr(dlogits), B, L, V, int(loss_fun), float(label_smoothing), _s()), "avsr_seq_loss_fun")
 
 
 def au_loss(z, aus, lens, row_loss, dz, B, T, weight):

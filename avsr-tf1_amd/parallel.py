@@ -74,8 +74,12 @@ class DataParallelTrainer:
         key = self._key(batch)
         if self.world > 1:
             # global loss normaliser: sum over ALL ranks of min(labels_len, L)
-            L = batch.labels.shape[1]
-            m.denom.copy_(batch.labels_len.clamp(0, L).sum().to(torch.float32).reshape(1))
+            local = getattr(m, "local_loss_denominator", None)
+            if local is not None:
+                m.denom.copy_(local(batch))
+            else:
+                L = batch.labels.shape[1]
+                m.denom.copy_(batch.labels_len.clamp(0, L).sum().to(torch.float32).reshape(1))
             dist.all_reduce(m.denom)
             if self.sync_bn:
                 dist.all_reduce(m.bn_sync_sums(batch))

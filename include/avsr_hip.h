@@ -399,6 +399,13 @@ int avsr_dropout_rows(const avsr_mat* x, const avsr_mat* y, int32_t rows, int32_
  * (dynamic_decode impute_finished=True, avsr/decoder_unimodal.py:344-350). */
 int avsr_seq_loss(float* logits, const int32_t* labels, const int32_t* labels_len, float* denom,
                   int32_t compute_denom, float* row_loss, float* dlogits, int32_t B, int32_t L, int32_t V, void* stream);
+/* The non-default per-step losses of avsr/seq2seq.py:147-163.  loss_fun: 0 sparse softmax cross-entropy (= avsr_seq_loss);
+ * 1 label smoothing through tf.losses.softmax_cross_entropy (avsr/devel.py:54-61), whose default reduction turns the
+ * sequence loss into the mean over ALL B*L rows -- denom is then the row count (compute_denom=1 sets B*L), padding rows
+ * contribute log V each and no gradient; 2 focal_loss (gamma 2) and 3 mc_loss on the clipped softmax (avsr/devel.py:12-51). */
+int avsr_seq_loss_fun(float* logits, const int32_t* labels, const int32_t* labels_len, float* denom, int32_t compute_denom,
+                      float* row_loss, float* dlogits, int32_t B, int32_t L, int32_t V, int32_t loss_fun,
+                      float label_smoothing, void* stream);
 
 /* Per-utterance average of the step losses avsr_seq_loss left in row_loss (which carry the 1/denom factor):
  * out[b] = sum_l CE[b,l] w[b,l] / (sum_l w[b,l] + 1e-12) -- the language model's `average_log_likelihoods`

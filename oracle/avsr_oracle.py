@@ -61,6 +61,8 @@ class OracleConfig:
     max_gradient_norm: float = 1.0
     learning_rate: float = 1e-3
     warmup_steps: int = 750                   # seq2seq.py:275
+    loss_fun: Optional[str] = None            # None | 'focal_loss' | 'mc_loss'  (seq2seq.py:147-163, devel.py)
+    label_smoothing: float = 0.0              # avsr.py:57; > 0 switches to tf.losses.softmax_cross_entropy (seq2seq.py:151-155)
     lr_decay_steps: int = 0                   # lr_decay=('cosine_restarts', N), seq2seq.py:266-270; 0 = constant
     max_label_length: int = 150               # avsr.py:157
     # stochastic train-time features (off for parity fixtures; SURVEY section 7 "hard parts")
@@ -838,8 +840,28 @@ def loss_fn(P, cfg: OracleConfig, batch: Batch, logits: Tensor, m: _Model):
     labels = torch.as_tensor(batch.labels, dtype=torch.int64)
     ll = torch.as_tensor(batch.labels_len, dtype=torch.int64)
     w = (torch.arange(labels.shape[1])[None, :] < ll[:, None]).to(logits.dtype)
-    ce = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1),
-                                           reduction="none").reshape(labels.shape)
+    V = logits.shape[-1]
+    flat = logits.reshape(-1, V)
+    onehot = torch.nn.functional.one_hot(labels.reshape(-1), V).to(logits.dtype)
+    if cfg.loss_fun is None and cfg.label_smoothing <= 0.0:      # seq2seq.py:147-150: sparse softmax cross-entropy
+        ce = torch.nn.functional.cross_entropy(flat, labels.reshape(-1), reduction="none")
+    elif cfg.loss_fun is None:
+        # seq2seq.py:151-155 -> devel.py:54-61: tf.losses.softmax_cross_entropy(onehot, logits, label_smoothing) keeps its default
+        # reduction SUM_BY_NONZERO_WEIGHTS, i.e. it returns ONE SCALAR = mean over all B*L rows (padding included, whose
+        # imputed logits are zeros and whose label is 0); sequence_loss then multiplies that scalar by the mask and divides by
+        # the mask sum, which gives the scalar back.  Restated as is (TF r1.13 losses_impl.py, recalled).
+        soft = onehot * (1.0 - cfg.label_smoothing) + cfg.label_smoothing / V
+        scalar = torch.mean(-torch.sum(soft * torch.log_softmax(flat, dim=-1), dim=-1))
+        ce = scalar.expand(flat.shape[0])
+    elif cfg.loss_fun in ("focal_loss", "mc_loss"):              # devel.py:12-51 (gamma = 2)
+        p = torch.clamp(torch.softmax(flat, dim=-1), 1e-7, 1.0 - 1e-7)
+        if cfg.loss_fun == "focal_loss":
+            ce = torch.sum(-onehot * (1.0 - p) ** 2.0 * torch.log(p) - (1 - onehot) * p ** 2.0 * torch.log(1.0 - p), dim=1)
+        else:
+            ce = torch.sum(-onehot * torch.log(p) - (1 - onehot) * torch.log(1.0 - p), dim=1)
+    else:
+        raise ValueError('Unknown loss function {}'.format(cfg.loss_fun))      # seq2seq.py:163
+    ce = ce.reshape(labels.shape)
     seq = torch.sum(ce * w) / (torch.sum(w) + 1e-12)
     total = seq
     if cfg.recurrent_l2 is not None:

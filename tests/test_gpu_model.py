@@ -59,6 +59,11 @@ CASES = {
     # avsr.LM (lm.py:275-471): labels only -- embedding, decoder cell from the zero state, Dense(V), no warm-up
     "lm_lstm": dict(architecture="lm", video_units=None, audio_units=None, warmup_steps=0),
     "lm_gru": dict(architecture="lm", video_units=None, audio_units=None, cell_type="gru", warmup_steps=0),
+    # the non-default per-step losses (seq2seq.py:147-163, avsr/devel.py): focal, multi-class, label smoothing
+    "loss_focal": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,), loss_fun="focal_loss"),
+    "loss_mc_bimodal": dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32,), audio_units=(32,), loss_fun="mc_loss"),
+    "label_smoothing": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
+                            attention_type=(("bahdanau",), ("bahdanau",)), label_smoothing=0.1),
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
@@ -173,6 +178,8 @@ STOCH = [
     ("video_cnn_dense_bi", dict(use_dropout=True)),
     ("no_attention", dict(use_dropout=True, sampling_probability=0.3)),
     ("lm_lstm", dict(use_dropout=True, sampling_probability=0.1)),
+    ("label_smoothing", dict(use_dropout=True, sampling_probability=0.3)),
+    ("loss_focal", dict(sampling_probability=0.3)),
 ]
 
 
