@@ -22,16 +22,18 @@ import torch
 
 
 class DataParallelTrainer:
-    def __init__(self, model, dist=None, use_graph=True, sync_bn=True):
+    def __init__(self, model, dist=None, use_graph=True, sync_bn=True, force_collectives=False):
         self.model, self.dist = model, dist
         self.world = dist.get_world_size() if dist is not None else 1
+        # force_collectives: issue every collective even at world size 1 (exercises the RCCL path on a single-GPU box)
+        self.collective = self.world > 1 or bool(force_collectives and dist is not None)
         self.use_graph = use_graph
         self.mode = "eager"
         self._graphs = {}
         self._checked = False
         self._static = {}
         model.au_scale = 1.0 / self.world
-        self.sync_bn = bool(sync_bn and self.world > 1 and getattr(model, "bn_sync_enable", None) and model.bn_sync_enable())
+        self.sync_bn = bool(sync_bn and self.collective and getattr(model, "bn_sync_enable", None) and model.bn_sync_enable())
 
     # -- helpers ----------------------------------------------------------------------------------
     @staticmethod
@@ -55,7 +57,7 @@ class DataParallelTrainer:
         return st
 
     def _fwd_bwd(self, batch):
-        self.model.forward_train(batch, compute_denom=(self.world == 1))
+        self.model.forward_train(batch, compute_denom=not self.collective)
         self.model.backward()
 
     def _persistent_failed(self):
@@ -72,7 +74,7 @@ class DataParallelTrainer:
     def train_step(self, batch):
         m, dist = self.model, self.dist
         key = self._key(batch)
-        if self.world > 1:
+        if self.collective:
             # global loss normaliser: sum over ALL ranks of min(labels_len, L)
             local = getattr(m, "local_loss_denominator", None)
             if local is not None:
@@ -90,7 +92,7 @@ class DataParallelTrainer:
                 self._checked = True
                 if self._persistent_failed():
                     self._fwd_bwd(batch)
-            if self.world > 1:
+            if self.collective:
                 dist.all_reduce(m.grads)
             m.apply_update()
             return m.loss, m.gnorm
@@ -101,7 +103,7 @@ class DataParallelTrainer:
             self._fwd_bwd(st)
             if self._persistent_failed():              # persistent kernels not co-resident: redo through the launch path
                 self._fwd_bwd(st)
-            if self.world > 1:
+            if self.collective:
                 dist.all_reduce(m.grads)
             m.apply_update()
             torch.cuda.synchronize()
@@ -116,7 +118,7 @@ class DataParallelTrainer:
             return m.loss, m.gnorm
         ga, gb = gr
         ga.replay()
-        if self.world > 1:
+        if self.collective:
             dist.all_reduce(m.grads)
         gb.replay()
         return m.loss, m.gnorm
