@@ -53,6 +53,7 @@ class ModelConfig:
     cnn_dense_units: int = 128
     video_hw: Tuple[int, int, int] = (36, 36, 3)
     input_dense_layers: Tuple[int, ...] = (0,)                      # avsr/avsr.py:38, encoder.py:148-171
+    encoder_weight_sharing: bool = False                            # cells.py:77: encoder layers >= 2 reuse layer 1's cell
 
     # -- same helpers/validation rules as the reference wiring (error types as in the reference) --
     def streams(self) -> List[str]:
@@ -62,6 +63,11 @@ class ModelConfig:
         if self.audio_units is not None:
             s.append("audio")
         return s
+
+    def shared_layer(self, l: int) -> int:
+        """Index of the encoder layer whose variables layer l uses (cells.py:77 quirk: `layer > 1` reuses cell_list[-1], so
+        layers 0 and 1 stay distinct and every layer from 2 up is layer 1's cell)."""
+        return 1 if (self.encoder_weight_sharing and l > 1) else l
 
     def loss_code(self) -> int:
         """avsr_seq_loss_fun's loss_fun argument."""
@@ -127,6 +133,13 @@ class ModelConfig:
             if self.video_units is None or self.audio_units is None:
                 raise ValueError("av_align needs both a video and an audio stream")
         self.loss_code()
+        if self.encoder_weight_sharing:
+            for st in self.streams():
+                u = self.units(st)
+                if len(u) > 2 and (len(set(u[1:])) != 1 or u[0] != u[1]):
+                    raise ValueError("encoder_weight_sharing needs equal layer sizes: layers >= 2 reuse layer 1's kernel")
+                if len(u) > 2 and self.architecture == "av_align" and st == "audio":
+                    raise ValueError("encoder_weight_sharing: the attention-wrapped top layer cannot reuse layer 1's kernel")
         if self.video_processing not in ("features", "resnet_cnn"):
             raise Exception("unknown visual content")                                   # avsr/avsr.py:713 (2dconv_cnn / 3dconv_cnn: not built)
         if self.video_units is not None and self.video_processing == "resnet_cnn":

@@ -345,16 +345,16 @@ class Seq2SeqModel:
         for l in range(E["nplain"]):
             u = E["units"][l]
             Ld = E["layers"][(d, l)]
-            name, bname = self._kn(f"{s}/enc/{d}/l{l}")
+            name, bname = self._kn(f"{s}/enc/{d}/l{cfg.shared_layer(l)}")
             Ly = st.layer[l]
             Ly.units, Ly.in_dim, Ly.hoisted, Ly.out_col = u, i, int(l == 0), Ld["col"]
             Ly.wt = ops.fptr(self.derived, self.Tr[name].off)
             Ly.w = ops.fptr(self.params, self.P[name].off)
             Ly.bias = ops.fptr(self.params, self.P[bname].off)
             if self.gru:
-                cn = f"{s}/enc/{d}/l{l}/cand_kernel"
+                cn = f"{s}/enc/{d}/l{cfg.shared_layer(l)}/cand_kernel"
                 Ly.wt2, Ly.w2 = ops.fptr(self.derived, self.Tr[cn].off), ops.fptr(self.params, self.P[cn].off)
-                Ly.bias2 = ops.fptr(self.params, self.P[f"{s}/enc/{d}/l{l}/cand_bias"].off)
+                Ly.bias2 = ops.fptr(self.params, self.P[f"{s}/enc/{d}/l{cfg.shared_layer(l)}/cand_bias"].off)
                 Ly.rh_seq, Ly.dgates2 = ops.fptr(Ld["rh"]), ops.fptr(Ld["dpc"])
             Ly.gates, Ly.cs = ops.fptr(Ld["gates"]), ops.fptr(Ld["cs"])
             Ly.out, Ly.ld_out = ops.fptr(Ld["out"].t), Ld["out"].D
@@ -587,7 +587,7 @@ class Seq2SeqModel:
                 for l in range(E["nplain"]):
                     u = E["units"][l]
                     Ld = E["layers"][(d, l)]
-                    kname, bname = self._kn(f"{s}/enc/{d}/l{l}")
+                    kname, bname = self._kn(f"{s}/enc/{d}/l{cfg.shared_layer(l)}")
                     Gk = self.Gr[kname]
                     G = self.G
                     dg = ops.mat(Ld["dgates"], G * u)
@@ -604,11 +604,11 @@ class Seq2SeqModel:
                     self._gemm_tn(a_h, dg, Gk.mat(G * u, row0=i), u, G * u, B * T)
                     ops.colsum(dg, B * T, G * u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
                     if self.gru:                 # candidate kernel: inputs [x ; r*h]
-                        Gc = self.Gr[f"{s}/enc/{d}/l{l}/cand_kernel"]
+                        Gc = self.Gr[f"{s}/enc/{d}/l{cfg.shared_layer(l)}/cand_kernel"]
                         dpc = ops.mat(Ld["dpc"], u)
                         self._gemm_tn(a_x, dpc, Gc.mat(u), i, u, B * T)
                         self._gemm_tn(ops.mat(Ld["rh"], u), dpc, Gc.mat(u, row0=i), u, u, B * T)
-                        ops.colsum(dpc, B * T, u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/enc/{d}/l{l}/cand_bias"].off)
+                        ops.colsum(dpc, B * T, u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/enc/{d}/l{cfg.shared_layer(l)}/cand_bias"].off)
                     i = u
                 if E["nplain"] > 0 and (cfg.batch_normalisation or "cnn" in E or self.n_dense):
                     u0, G = E["units"][0], self.G

@@ -85,7 +85,8 @@ def inventory(cfg: ModelConfig):
             i = cfg.layer0_in(stream)
             for l, u in enumerate(units):
                 extra = units[-1] if (attentive and l == len(units) - 1) else 0
-                _cell(inv, cfg, f"{stream}/enc/{d}/l{l}", i + extra, u)
+                if cfg.shared_layer(l) == l:                  # encoder_weight_sharing: layers >= 2 own no variables
+                    _cell(inv, cfg, f"{stream}/enc/{d}/l{l}", i + extra, u)
                 i = u
         if attentive:
             _attention(inv, "audio/enc/att0", cfg.attention_type[0][0], cfg.memory_depth("video"), units[-1])

@@ -61,6 +61,7 @@ class OracleConfig:
     max_gradient_norm: float = 1.0
     learning_rate: float = 1e-3
     warmup_steps: int = 750                   # seq2seq.py:275
+    encoder_weight_sharing: bool = False      # avsr.py:49, cells.py:77
     loss_fun: Optional[str] = None            # None | 'focal_loss' | 'mc_loss'  (seq2seq.py:147-163, devel.py)
     label_smoothing: float = 0.0              # avsr.py:57; > 0 switches to tf.losses.softmax_cross_entropy (seq2seq.py:151-155)
     lr_decay_steps: int = 0                   # lr_decay=('cosine_restarts', N), seq2seq.py:266-270; 0 = constant
@@ -313,7 +314,8 @@ def init_params(cfg: OracleConfig, seed: int = 2001) -> Dict[str, np.ndarray]:
             in_dim = cfg.layer0_in(stream)
             for l, u in enumerate(units):
                 extra = units[-1] if (attentive and l == len(units) - 1) else 0   # + attention feedback
-                _cell_params(rng, cfg, f"{stream}/enc/{d}/l{l}", in_dim + extra, u, P)
+                if not (cfg.encoder_weight_sharing and l > 1):                     # shared layers own no variables
+                    _cell_params(rng, cfg, f"{stream}/enc/{d}/l{l}", in_dim + extra, u, P)
                 in_dim = u
         if attentive:
             _attention_params(rng, "audio/enc/att0", cfg.attention_type[0][0],
@@ -640,7 +642,9 @@ class EncoderOut:
 
 
 def _make_cells(P, cfg: OracleConfig, stream: str, direction: str, units, training: bool, seed: int, T: int, lens: Tensor):
-    cells = [_Cell(P, f"{stream}/enc/{direction}/l{l}", cfg.cell_type, u) for l, u in enumerate(units)]
+    # encoder_weight_sharing (cells.py:77): `layer > 1` reuses the previous cell object -> layers >= 2 share layer 1's variables
+    shared = lambda l: 1 if (cfg.encoder_weight_sharing and l > 1) else l
+    cells = [_Cell(P, f"{stream}/enc/{direction}/l{shared(l)}", cfg.cell_type, u) for l, u in enumerate(units)]
     if cfg.use_dropout and training:                                  # cells.py:46: only in the train graph
         keep = cfg.video_dropout if stream == "video" else cfg.audio_dropout
         for l, c in enumerate(cells):

@@ -64,6 +64,11 @@ CASES = {
     "loss_mc_bimodal": dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32,), audio_units=(32,), loss_fun="mc_loss"),
     "label_smoothing": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                             attention_type=(("bahdanau",), ("bahdanau",)), label_smoothing=0.1),
+    # encoder_weight_sharing (cells.py:77): layers >= 2 reuse layer 1's variables; their gradients accumulate
+    "weight_sharing_uni4": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32, 32, 32),
+                                encoder_weight_sharing=True),
+    "weight_sharing_bi_gru": dict(architecture="unimodal", encoder_type="bidirectional", video_units=(16, 16, 16), audio_units=None,
+                                  cell_type="gru", encoder_weight_sharing=True, attention_type=(("bahdanau",), ("bahdanau",))),
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
@@ -180,6 +185,7 @@ STOCH = [
     ("lm_lstm", dict(use_dropout=True, sampling_probability=0.1)),
     ("label_smoothing", dict(use_dropout=True, sampling_probability=0.3)),
     ("loss_focal", dict(sampling_probability=0.3)),
+    ("weight_sharing_uni4", dict(use_dropout=True)),
 ]
 
 
