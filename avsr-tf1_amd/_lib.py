@@ -69,6 +69,15 @@ class AttnMech(C.Structure):
                 ("pdq", C.c_void_p)]
 
 
+class DecLayer(C.Structure):
+    _fields_ = [("wt", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("gates", C.c_void_p), ("cs", C.c_void_p),
+                ("out", C.c_void_p), ("state", C.c_void_p), ("hs_seq", C.c_void_p), ("xin_seq", C.c_void_p),
+                ("dgates", C.c_void_p), ("dstate", C.c_void_p), ("cell_id", C.c_int32), ("pad_", C.c_int32)]
+
+
+MAX_DEC_EXTRA = 3
+
+
 class AttnRnn(C.Structure):
     _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("E", C.c_int32),
                 ("n_mech", C.c_int32), ("output_attention", C.c_int32), ("V", C.c_int32), ("mode", C.c_int32),
@@ -90,14 +99,15 @@ class AttnRnn(C.Structure):
                 ("rh_seq", C.c_void_p), ("dgates2", C.c_void_p),
                 ("beam_width", C.c_int32), ("pad5_", C.c_int32), ("length_penalty", C.c_float), ("pad6_", C.c_float),
                 ("beam_logp", C.c_void_p), ("beam_fin", C.c_void_p), ("beam_len", C.c_void_p), ("step_ids", C.c_void_p),
-                ("parent_ids", C.c_void_p), ("parent_rows", C.c_void_p)]
+                ("parent_ids", C.c_void_p), ("parent_rows", C.c_void_p),
+                ("n_extra", C.c_int32), ("pad7_", C.c_int32), ("out0", C.c_void_p), ("extra", DecLayer * MAX_DEC_EXTRA)]
 
 
 class TransposeJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
-_STRUCTS = {"avsr_mat": Mat, "avsr_gemm_desc": GemmDesc, "avsr_rnn_layer": RnnLayer, "avsr_rnn_stack": RnnStack,
+_STRUCTS = {"avsr_dec_layer": DecLayer, "avsr_mat": Mat, "avsr_gemm_desc": GemmDesc, "avsr_rnn_layer": RnnLayer, "avsr_rnn_stack": RnnStack,
             "avsr_attn_mech": AttnMech, "avsr_attn_rnn": AttnRnn, "avsr_transpose_job": TransposeJob}
 
 EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_rnn_set_persistent", "avsr_rnn_set_persistent_mode", "avsr_rnn_set_persistent_scratch", "avsr_attn_rnn_fwd",

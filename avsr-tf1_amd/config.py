@@ -149,8 +149,10 @@ class ModelConfig:
                 raise ValueError("cnn_filters / cnn_dense_units must be multiples of 4 for the HIP engine")
         if self.input_dense_layers[0] > 0 and any(u <= 0 or u % 4 for u in self.input_dense_layers):
             raise ValueError("input_dense_layers must be positive multiples of 4 for the HIP engine")
-        if len(self.decoder_units) != 1:
-            raise NotImplementedError("multi-layer decoders are not built yet")
+        if len(set(self.decoder_units)) != 1 or len(self.decoder_units) > 4:
+            raise NotImplementedError("multi-layer decoders: up to 4 layers of equal width")
+        if len(self.decoder_units) > 1 and self.cell_type != "lstm":
+            raise NotImplementedError("multi-layer decoders: LSTM cells only")
         if not self.streams() and self.architecture != "lm":
             raise Exception("labels are None")                                         # seq2seq.py:94
         dims = [self.embedding_size, self.decoder_units[0]]

@@ -266,6 +266,14 @@ static inline float* cbuf(const avsr_attn_rnn& d, int p) { return d.state + (lon
 static inline float* dgroll(const avsr_attn_rnn& d, int p) { return d.dstate + (long)p * d.B * 4 * d.H; }
 static inline float* dcbuf(const avsr_attn_rnn& d, int p) { return d.dstate + (long)(8 + p) * d.B * d.H; }
 static inline float* dhcarry(const avsr_attn_rnn& d, int p) { return d.dstate + (long)(10 + p) * d.B * d.H; }
+// extra decoder layers (MultiRNNCell above the attention-fed cell): same buffer conventions as the block's own cell
+static inline float* xhbuf(const avsr_attn_rnn& d, int j, int p) { return d.extra[j].state + (long)p * d.B * d.H; }
+static inline float* xcbuf(const avsr_attn_rnn& d, int j, int p) { return d.extra[j].state + (long)(2 + p) * d.B * d.H; }
+static inline float* xdgroll(const avsr_attn_rnn& d, int j, int p) { return d.extra[j].dstate + (long)p * d.B * 4 * d.H; }
+static inline float* xdcbuf(const avsr_attn_rnn& d, int j, int p) { return d.extra[j].dstate + (long)(8 + p) * d.B * d.H; }
+static inline float* xdhcarry(const avsr_attn_rnn& d, int j, int p) { return d.extra[j].dstate + (long)(10 + p) * d.B * d.H; }
+// output record of decoder layer j (0 = the attention-fed cell): [B][L+1][H], slot l+1 = step l
+static inline float* layer_out(const avsr_attn_rnn& d, int j) { return j == 0 ? (d.n_extra > 0 ? d.out0 : d.cell_out) : d.extra[j - 1].out; }
 static inline int nchunk(const avsr_attn_mech& m) { return (m.T + m.chunk - 1) / m.chunk; }
 static inline bool is_bahdanau(const avsr_attn_mech& m) { return m.type >= ATT_BAHDANAU; }
 
@@ -274,6 +282,15 @@ static int validate(const avsr_attn_rnn* d) {
     return AVSR_ERR_ARG;
   if (!d->wt || !d->gates || !d->cs || !d->cell_out || !d->state || !d->steplen) return AVSR_ERR_ARG;
   if (d->n_mech > 0 && !d->att) return AVSR_ERR_ARG;
+  if (d->n_extra < 0 || d->n_extra > AVSR_MAX_DEC_EXTRA) return AVSR_ERR_ARG;
+  if (d->n_extra > 0) {
+    if (d->cell == 1) return AVSR_ERR_UNSUPPORTED;                      // multi-layer decoder cells: LSTM only
+    if (!d->out0 || d->extra[d->n_extra - 1].out != d->cell_out) return AVSR_ERR_ARG;
+    for (int j = 0; j < d->n_extra; ++j) {
+      const avsr_dec_layer& X = d->extra[j];
+      if (!X.wt || !X.gates || !X.cs || !X.out || !X.state) return AVSR_ERR_ARG;
+    }
+  }
   for (int m = 0; m < d->n_mech; ++m) {
     const avsr_attn_mech& M = d->mech[m];
     if (M.T <= 0 || M.D % 4 || M.chunk <= 0 || M.chunk > ATTN_MAX_CHUNK || nchunk(M) > STEP_MAX_SLAB) return AVSR_ERR_ARG;
@@ -333,6 +350,9 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
   if (gru && (!d.wt2 || !d.rh_seq)) return AVSR_ERR_ARG;
   const bool drop = d.seed && d.mode != 1 && (d.keep_in < 1.f || d.keep_state < 1.f || d.keep_out < 1.f);
   if (drop && (!d.hs_seq || (A > 0 && !d.attd))) return AVSR_ERR_ARG;
+  if (drop)
+    for (int j = 0; j < d.n_extra; ++j)
+      if (!d.extra[j].hs_seq || !d.extra[j].xin_seq) return AVSR_ERR_ARG;
   const uint32_t cid4 = (uint32_t)d.cell_id * 4;
   const size_t bh = sizeof(float) * B * H;
 
@@ -342,8 +362,15 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
     else if (hipMemsetAsync(hbuf(d, 0), 0, bh, s) != hipSuccess) return AVSR_ERR_HIP;
     if (d.c0) { if (hipMemcpyAsync(cbuf(d, 0), d.c0, bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP; }
     else if (hipMemsetAsync(cbuf(d, 0), 0, bh, s) != hipSuccess) return AVSR_ERR_HIP;
-    if (hipMemcpy2DAsync(d.cell_out, sizeof(float) * (L + 1) * H, hbuf(d, 0), sizeof(float) * H, sizeof(float) * H, B,
+    if (hipMemcpy2DAsync(layer_out(d, 0), sizeof(float) * (L + 1) * H, hbuf(d, 0), sizeof(float) * H, sizeof(float) * H, B,
                          hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+    for (int j = 0; j < d.n_extra; ++j) {            // layers above start from the zero state (decoder_unimodal.py:151-157)
+      const avsr_dec_layer& X = d.extra[j];
+      if (hipMemsetAsync(X.state, 0, 4 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (hipMemset2DAsync(X.out, sizeof(float) * (L + 1) * H, 0, sizeof(float) * H, B, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (drop && X.hs_seq && hipMemset2DAsync(X.hs_seq, sizeof(float) * (L + 1) * H, 0, sizeof(float) * H, B, s) != hipSuccess)
+        return AVSR_ERR_HIP;
+    }
     if (A > 0 && hipMemset2DAsync(d.att, sizeof(float) * (L + 1) * A, 0, sizeof(float) * A, B, s) != hipSuccess)
       return AVSR_ERR_HIP;
     if (drop) {
@@ -388,12 +415,42 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
         if (gru) { tk.N = H; tk.mode = EP_GRU_CAND; tk.bias = d.bias2; tk.p0 = d.cs; tk.p1 = d.gates; }
         else { tk.N = 4 * H; tk.mode = EP_LSTM_FWD; tk.bias = d.bias; tk.p0 = d.gates; tk.p1 = d.cs;
                tk.p3 = cbuf(d, l & 1); tk.p5 = cbuf(d, (l + 1) & 1); }
-        tk.p2 = d.cell_out + H; tk.s0 = (long)(L + 1) * H; tk.s1 = H;
+        tk.p2 = layer_out(d, 0) + H; tk.s0 = (long)(L + 1) * H; tk.s1 = H;
         tk.p6 = hbuf(d, (l + 1) & 1);
         if (drop) {
           tk.seed = d.seed; tk.k_st = d.keep_state; tk.k_out = d.keep_out; tk.k_in = 1.0f;
           tk.r_st = cid4 + 1; tk.r_out = cid4 + 2;
           tk.p9 = d.hs_seq + H; tk.s4 = (long)(L + 1) * H; tk.s5 = H;
+          if (d.n_extra > 0) {   // what layer 1 consumes: this output under layer 1's input mask
+            tk.p11 = d.extra[0].xin_seq + H; tk.k_in = d.keep_in; tk.r_in = (uint32_t)d.extra[0].cell_id * 4; tk.in_W = H; tk.in_coff = 0;
+          }
+        }
+      }
+      if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+    }
+    // ---- K1b: the layers above (MultiRNNCell): layer j consumes layer j-1's output of this step -----------------------
+    for (int j = 0; j < d.n_extra; ++j) {
+      const avsr_dec_layer& X = d.extra[j];
+      SL.ntask = 1;
+      StepTask& tk = SL.task[0];
+      tk = StepTask{};
+      StepSrc& x = tk.src[tk.nsrc++];
+      x.a = (drop ? X.xin_seq : layer_out(d, j)) + (long)(l + 1) * H; x.sb = (long)(L + 1) * H; x.K = H; x.w = X.wt; x.ldw = 2 * H;
+      x.kind = SRC_OWNROW;
+      StepSrc& h = tk.src[tk.nsrc++];
+      h.a = xhbuf(d, j, l & 1); h.sb = H; h.K = H; h.w = X.wt + H; h.ldw = 2 * H; h.kind = SRC_PLAIN;
+      if (d.mode == 3) tk.gather2 = d.parent_rows;
+      tk.B = B; tk.t = l; tk.T = L; tk.reverse = 0; tk.len = d.steplen;
+      tk.N = 4 * H; tk.mode = EP_LSTM_FWD; tk.bias = X.bias; tk.p0 = X.gates; tk.p1 = X.cs;
+      tk.p3 = xcbuf(d, j, l & 1); tk.p4 = xhbuf(d, j, l & 1); tk.p5 = xcbuf(d, j, (l + 1) & 1); tk.p6 = xhbuf(d, j, (l + 1) & 1);
+      tk.p2 = X.out + H; tk.s0 = (long)(L + 1) * H; tk.s1 = H;
+      if (drop) {
+        const uint32_t c4 = (uint32_t)X.cell_id * 4;
+        tk.seed = d.seed; tk.k_st = d.keep_state; tk.k_out = d.keep_out; tk.k_in = 1.0f;
+        tk.r_st = c4 + 1; tk.r_out = c4 + 2;
+        tk.p9 = X.hs_seq + H; tk.s4 = (long)(L + 1) * H; tk.s5 = H;
+        if (j + 1 < d.n_extra) {
+          tk.p11 = d.extra[j + 1].xin_seq + H; tk.k_in = d.keep_in; tk.r_in = (uint32_t)d.extra[j + 1].cell_id * 4; tk.in_W = H; tk.in_coff = 0;
         }
       }
       if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
@@ -519,6 +576,12 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
   const bool use_dq = (n_luong > 0) || d.dcell_ext;
   if (use_dq && !d.dq) return AVSR_ERR_ARG;
   const size_t bh = sizeof(float) * B * H;
+  const int NX = d.n_extra;
+  for (int j = 0; j < NX; ++j) {
+    if (!d.extra[j].w || !d.extra[j].dgates || !d.extra[j].dstate) return AVSR_ERR_ARG;
+    if (hipMemsetAsync(d.extra[j].dstate, 0, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
+  }
+  if (NX > 0 && (d.dh_final || d.dc_final)) return AVSR_ERR_UNSUPPORTED;     // final-state gradients: single-cell blocks only
   if (hipMemsetAsync(d.dstate, 0, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
   if (!gru && d.dc_final && hipMemcpyAsync(dcbuf(d, L & 1), d.dc_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
   if (d.dh_final && hipMemcpyAsync(gru ? g_carry(L & 1) : dhcarry(d, L & 1), d.dh_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
@@ -589,21 +652,35 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
       hipLaunchKernelGGL(slab_sum_kernel, dim3(gx, BL.njob), dim3(256), 0, s, BL);
       AVSR_CHECK_LAUNCH();
     }
-    // ---- KB2: LSTM backward ----------------------------------------------------------------------
-    SL.ntask = 1;
-    {
+    // ---- KB2: LSTM backward, top layer first.  The TOP layer's emitted output is what the attention mechanisms and the
+    // attention layers consumed; every layer below receives d(output) from the layer above of the SAME step (through that
+    // layer's input mask) next to its own recurrent path.
+    for (int j = NX; j >= 0; --j) {
+      SL.ntask = 1;
       StepTask& tk = SL.task[0];
       tk = StepTask{};
+      const bool top = (j == NX);
+      const uint32_t c4 = j == 0 ? cid4 : (uint32_t)d.extra[j - 1].cell_id * 4;
       StepSrc& a = tk.src[tk.nsrc++];
-      a.a = gru ? g_dgg((l + 1) & 1) : dgroll(d, (l + 1) & 1); a.sb = G * H; a.K = G * H; a.w = d.w + (long)(E + A) * G * H; a.ldw = G * H; a.kind = SRC_PLAIN;
-      for (int m = 0; m < d.n_mech; ++m) {
-        const avsr_attn_mech& M = d.mech[m];
-        StepSrc& x = tk.src[tk.nsrc++];
-        x.a = d.datt + (long)l * A + (long)m * H; x.sb = (long)L * A; x.K = H; x.w = M.watt; x.ldw = H; x.kind = SRC_PLAIN;
-        if (is_bahdanau(M)) {
-          StepSrc& q = tk.src[tk.nsrc++];
-          q.a = M.dpq + (long)l * H; q.sb = (long)L * H; q.K = H; q.w = M.wq; q.ldw = H; q.kind = SRC_PLAIN;
+      if (j == 0) {
+        a.a = gru ? g_dgg((l + 1) & 1) : dgroll(d, (l + 1) & 1); a.sb = G * H; a.K = G * H; a.w = d.w + (long)(E + A) * G * H; a.ldw = G * H;
+      } else {
+        a.a = xdgroll(d, j - 1, (l + 1) & 1); a.sb = 4 * H; a.K = 4 * H; a.w = d.extra[j - 1].w + (long)H * 4 * H; a.ldw = 4 * H;
+      }
+      a.kind = SRC_PLAIN;
+      if (top) {
+        for (int m = 0; m < d.n_mech; ++m) {
+          const avsr_attn_mech& M = d.mech[m];
+          StepSrc& x = tk.src[tk.nsrc++];
+          x.a = d.datt + (long)l * A + (long)m * H; x.sb = (long)L * A; x.K = H; x.w = M.watt; x.ldw = H; x.kind = SRC_PLAIN;
+          if (is_bahdanau(M)) {
+            StepSrc& q = tk.src[tk.nsrc++];
+            q.a = M.dpq + (long)l * H; q.sb = (long)L * H; q.K = H; q.w = M.wq; q.ldw = H; q.kind = SRC_PLAIN;
+          }
         }
+      } else {   // d(output of layer j) = dG_{j+1}(l) . Wx_{j+1}^T  (dG of the layer above, computed a moment ago)
+        StepSrc& x = tk.src[tk.nsrc++];
+        x.a = xdgroll(d, j, l & 1); x.sb = 4 * H; x.K = 4 * H; x.w = d.extra[j].w; x.ldw = 4 * H; x.kind = SRC_PLAIN;
       }
       tk.B = B; tk.N = H; tk.t = l; tk.T = L; tk.reverse = 0; tk.len = d.steplen;
       if (gru) {
@@ -611,29 +688,38 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
         tk.p0 = d.gates; tk.p1 = d.cs;
         tk.p2 = drop ? d.hs_seq : d.cell_out; tk.s2 = (long)(L + 1) * H; tk.s3 = H;     // slot l = h consumed by step l
         tk.p4 = g_carry((l + 1) & 1); tk.p5 = g_dpc(l & 1); tk.p3 = d.dgates2; tk.p6 = g_tmp(0); tk.p7 = g_tmp(1);
-      } else {
+      } else if (j == 0) {
         tk.mode = EP_LSTM_BWD;
         tk.bias = d.c0;
         tk.p0 = d.gates; tk.p1 = d.cs; tk.p2 = d.dgates; tk.p3 = dgroll(d, l & 1);
         tk.p4 = dcbuf(d, (l + 1) & 1); tk.p5 = dcbuf(d, l & 1);
         tk.p6 = dhcarry(d, (l + 1) & 1); tk.p7 = dhcarry(d, l & 1);
+      } else {
+        const avsr_dec_layer& X = d.extra[j - 1];
+        tk.mode = EP_LSTM_BWD;                       // c_init = 0: bias stays NULL
+        tk.p0 = X.gates; tk.p1 = X.cs; tk.p2 = X.dgates; tk.p3 = xdgroll(d, j - 1, l & 1);
+        tk.p4 = xdcbuf(d, j - 1, (l + 1) & 1); tk.p5 = xdcbuf(d, j - 1, l & 1);
+        tk.p6 = xdhcarry(d, j - 1, (l + 1) & 1); tk.p7 = xdhcarry(d, j - 1, l & 1);
       }
-      if (fold_dq) {
-        if (d.dcell_ext) { tk.p8 = const_cast<float*>(d.dcell_ext); tk.s0 = (long)L * H; tk.s1 = H; }
-        int k = 0;
-        for (int m = 0; m < d.n_mech; ++m) {
-          if (is_bahdanau(d.mech[m])) continue;
-          if (k == 0) { tk.pm = d.mech[m].pdq; tk.nslab = nchunk(d.mech[m]); }
-          else { tk.pl = d.mech[m].pdq; tk.pad0 = nchunk(d.mech[m]); }
-          ++k;
-        }
-      } else if (use_dq) { tk.p8 = d.dq; tk.s0 = (long)L * H; tk.s1 = H; }
+      if (top) {
+        if (fold_dq) {
+          if (d.dcell_ext) { tk.p8 = const_cast<float*>(d.dcell_ext); tk.s0 = (long)L * H; tk.s1 = H; }
+          int k = 0;
+          for (int m = 0; m < d.n_mech; ++m) {
+            if (is_bahdanau(d.mech[m])) continue;
+            if (k == 0) { tk.pm = d.mech[m].pdq; tk.nslab = nchunk(d.mech[m]); }
+            else { tk.pl = d.mech[m].pdq; tk.pad0 = nchunk(d.mech[m]); }
+            ++k;
+          }
+        } else if (use_dq) { tk.p8 = d.dq; tk.s0 = (long)L * H; tk.s1 = H; }
+      }
       if (drop) {
         tk.seed = d.seed; tk.k_st = d.keep_state; tk.k_out = d.keep_out; tk.k_in = 1.0f;
-        tk.r_st = cid4 + 1; tk.r_out = cid4 + 2;
+        tk.r_st = c4 + 1; tk.r_out = c4 + 2;
+        if (!top) { tk.k_in = d.keep_in; tk.r_in = (uint32_t)d.extra[j].cell_id * 4; tk.in_W = H; tk.in_coff = 0; }
       }
+      if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
     }
-    if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
     if (gru) {   // second phase: through r*h and the gate pre-activations
       SL.ntask = 1;
       StepTask& tk = SL.task[0];

@@ -9,7 +9,7 @@ extern "C" int64_t avsr_sizeof(const char* name) {
 #define SZ(T) if (!strcmp(name, #T)) return (int64_t)sizeof(T);
   SZ(avsr_mat) SZ(avsr_gemm_desc) SZ(avsr_rnn_layer) SZ(avsr_rnn_stack)
 #ifdef AVSR_HAVE_ATTN
-  SZ(avsr_attn_mech) SZ(avsr_attn_rnn) SZ(avsr_transpose_job)
+  SZ(avsr_attn_mech) SZ(avsr_attn_rnn) SZ(avsr_transpose_job) SZ(avsr_dec_layer)
 #endif
 #undef SZ
   return -1;

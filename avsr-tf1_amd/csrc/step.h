@@ -18,7 +18,7 @@ enum StepMode {
   EP_GRU_BWD_GATES = 6,
 };
 
-enum SrcKind { SRC_PLAIN = 0, SRC_SLABSUM = 1, SRC_SOFTMAX = 2 };
+enum SrcKind { SRC_PLAIN = 0, SRC_SLABSUM = 1, SRC_SOFTMAX = 2, SRC_OWNROW = 3 };   // SRC_OWNROW: plain, never row-gathered
 
 // One K-segment of the concatenated A operand and the matching weight rows.
 //   A row b        : a + (gather ? gather[b] : b) * sb

@@ -58,7 +58,7 @@ __device__ __forceinline__ void mm16_partial(const StepTask& tk, int row0, int c
     cbase += nch;
     if (c0 >= c1) continue;
     const float* wp = S.w + (long)wcol * S.ldw + (q << 2);
-    if (S.kind == SRC_PLAIN) {
+    if (S.kind == SRC_PLAIN || S.kind == SRC_OWNROW) {
       const float* ap[RM];
       bool aok[RM];
 #pragma unroll
@@ -67,7 +67,8 @@ __device__ __forceinline__ void mm16_partial(const StepTask& tk, int row0, int c
         aok[r] = arow < tk.B;
         long rb = arow;
         if (aok[r]) {
-          if (s == 0 && tk.gather) rb = tk.gather[arow];
+          if (S.kind == SRC_OWNROW) {}                    // current-step data of this very row (beam search: not the parent's)
+          else if (s == 0 && tk.gather) rb = tk.gather[arow];
           else if (tk.gather2) rb = tk.gather2[arow];
         }
         ap[r] = S.a + rb * S.sb + (q << 2);

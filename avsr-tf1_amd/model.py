@@ -294,6 +294,19 @@ class Seq2SeqModel:
                    hf=z(B, H), cf=z(B, H), dcell_ext=z(B, L, H))
         if A:
             blk.update(att=SeqBuf(B, L, A, 1, 0, dev), datt=z(B, L, A), datt_ext=z(B, L, A))
+        blk["extra"] = []
+        if cell_prefix == "dec/l0":
+            # multi-layer decoder cell (MultiRNNCell, decoder_unimodal.py:101-108): layers 1.. above the attention-fed one; the top
+            # layer's output record IS cell_out, the attention-fed layer records into out0
+            n_extra = len(cfg.decoder_units) - 1
+            if n_extra:
+                blk["out0"] = SeqBuf(B, L, H, 1, 0, dev)
+            for j in range(1, n_extra + 1):
+                X = dict(prefix="dec/l%d" % j, cell_id=CELL_ID_DECODER + j, gates=z(B, L, H, 4), cs=z(B, L, H), state=z(4 * B * H),
+                         dgates=z(B, L, H, 4), dstate=z(12 * B * H), out=(blk["cell_out"] if j == n_extra else SeqBuf(B, L, H, 1, 0, dev)))
+                if cfg.use_dropout:
+                    X["hs_seq"], X["xin_seq"] = SeqBuf(B, L, H, 1, 0, dev), SeqBuf(B, L, H, 1, 0, dev)
+                blk["extra"].append(X)
         for (stream, att_type), pre in zip(mems, att_prefixes):
             T = Ta if stream == "audio" else Tv
             D = cfg.memory_depth(stream)
@@ -729,6 +742,19 @@ class Seq2SeqModel:
             d.dgates, d.dstate, d.dq = ops.fptr(blk["dgates"]), ops.fptr(blk["dstate"]), ops.fptr(blk["dq"])
             d.datt = ops.fptr(blk["datt"]) if A else None
             d.dh0, d.dc0 = ops.fptr(blk["dh0"]), ops.fptr(blk["dc0"])
+        d.n_extra = len(blk["extra"])
+        if d.n_extra:
+            d.out0 = ops.fptr(blk["out0"].t)
+        for j, X in enumerate(blk["extra"]):
+            Xd = d.extra[j]
+            kn, bn = self._kn(X["prefix"])
+            Xd.wt, Xd.w, Xd.bias = ops.fptr(self.derived, self.Tr[kn].off), ops.fptr(self.params, self.P[kn].off), ops.fptr(self.params, self.P[bn].off)
+            Xd.gates, Xd.cs, Xd.out, Xd.state = ops.fptr(X["gates"]), ops.fptr(X["cs"]), ops.fptr(X["out"].t), ops.fptr(X["state"])
+            Xd.cell_id = X["cell_id"]
+            if self._bdrop(blk) and mode != 1:
+                Xd.hs_seq, Xd.xin_seq = ops.fptr(X["hs_seq"].t), ops.fptr(X["xin_seq"].t)
+            if with_bwd:
+                Xd.dgates, Xd.dstate = ops.fptr(X["dgates"]), ops.fptr(X["dstate"])
         return d
 
     def _block_prepare(self, ws, blk):
@@ -792,7 +818,16 @@ class Seq2SeqModel:
         dg = ops.mat(blk["dgates"], G * H)
         drop = self._bdrop(blk)
         a_att = (blk["attd"] if drop else blk["att"]).mat(-1) if A else None
-        a_h = (blk["hs_seq"] if drop else co).mat(-1)
+        out0 = blk["out0"] if blk["extra"] else co               # output record of the attention-fed layer
+        a_h = (blk["hs_seq"] if drop else out0).mat(-1)
+        below = out0
+        for X in blk["extra"]:                                    # MultiRNNCell layers above: kernel rows [0:H] input, [H:2H] previous h
+            kx, bx = self._kn(X["prefix"])
+            dgx = ops.mat(X["dgates"], 4 * H)
+            self._gemm_tn((X["xin_seq"] if drop else below).mat(0), dgx, self.Gr[kx].mat(4 * H), H, 4 * H, rows)
+            self._gemm_tn((X["hs_seq"] if drop else X["out"]).mat(-1), dgx, self.Gr[kx].mat(4 * H, row0=H), H, 4 * H, rows)
+            ops.colsum(dgx, rows, 4 * H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bx].off)
+            below = X["out"]
         self._gemm_tn(xin_mat, dg, Gk.mat(G * H), E, G * H, rows)
         if A:
             self._gemm_tn(a_att, dg, Gk.mat(G * H, row0=E), A, G * H, rows)

@@ -109,6 +109,8 @@ def inventory(cfg: ModelConfig):
     mems = cfg.decoder_memories()
     A = dec * len(mems)
     _cell(inv, cfg, "dec/l0", E + A, dec)
+    for j in range(1, len(cfg.decoder_units)):                # MultiRNNCell: layer j consumes layer j-1's output
+        _cell(inv, cfg, "dec/l%d" % j, cfg.decoder_units[j - 1], cfg.decoder_units[j])
     for i, (stream, t) in enumerate(mems):
         _attention(inv, f"dec/att{i}", t, cfg.memory_depth(stream), dec)
     O = A if cfg.output_attention() else dec

@@ -215,6 +215,30 @@ typedef struct avsr_attn_mech {
   float* pdq;
 } avsr_attn_mech;
 
+/* One extra decoder layer above the attention-fed cell: the wrapped cell is a MultiRNNCell (cells.py:96-100,
+ * decoder_unimodal.py:101-108 with len(decoder_units_per_layer) > 1).  LSTM only, width = H of the block.  Layer j consumes
+ * the emitted output of layer j-1 of the same step; the TOP layer's output is what the attention mechanisms query and
+ * what `cell_out` records, so the top layer's `out` must be the block's cell_out.  State starts at zero
+ * (decoder_unimodal.py:151-157).  Buffers: wt [4H][2H] / w [2H][4H] (rows: input part, then recurrent part), bias [H][4],
+ * gates [B][L][H][4], cs [B][L][H], out [B][L+1][H] (slot l+1 = step l, slot 0 = 0), state 4*B*H, dgates [B][L][H][4],
+ * dstate 12*B*H; dropout only: hs_seq [B][L+1][H] state-dropped h, xin_seq [B][L+1][H] = the input as this layer consumed it
+ * (slot l+1 = step l: lower layer's output mask x this layer's input mask). */
+typedef struct avsr_dec_layer {
+  const float* wt;
+  const float* w;
+  const float* bias;
+  float* gates;
+  float* cs;
+  float* out;
+  float* state;
+  float* hs_seq;
+  float* xin_seq;
+  float* dgates;
+  float* dstate;
+  int32_t cell_id, pad_;
+} avsr_dec_layer;
+#define AVSR_MAX_DEC_EXTRA 3
+
 typedef struct avsr_attn_rnn {
   int32_t B, L, H, E, n_mech, output_attention, V, mode;
   int32_t go_id, eos_id;
@@ -287,6 +311,11 @@ typedef struct avsr_attn_rnn {
   int32_t* step_ids;            /* [L][B] */
   int32_t* parent_ids;          /* [L][B] */
   int32_t* parent_rows;         /* [B] */
+  /* multi-layer decoder cell: n_extra layers above the attention-fed one (0 = the plain single cell).  out0 = output
+   * record of the attention-fed layer [B][L+1][H] (slot 0 = h0), needed because cell_out then belongs to the top layer. */
+  int32_t n_extra, pad7_;
+  float* out0;
+  avsr_dec_layer extra[AVSR_MAX_DEC_EXTRA];
 } avsr_attn_rnn;
 
 int avsr_attn_rnn_fwd(const avsr_attn_rnn* d, int32_t l_begin, int32_t l_end, void* stream);

@@ -149,8 +149,10 @@ class OracleConfig:
                 raise ValueError("AttentiveEncoder implements only unidirectional")  # encoder.py:229
             if self.video_units is None or self.audio_units is None:
                 raise ValueError("av_align needs both streams")
-        if len(self.decoder_units) != 1:
-            raise NotImplementedError("multi-layer decoders are out of scope this round")
+        if len(set(self.decoder_units)) != 1:
+            raise NotImplementedError("multi-layer decoders: equal layer widths only")
+        if len(self.decoder_units) > 1 and self.cell_type != "lstm":
+            raise NotImplementedError("multi-layer decoders: LSTM cells only")
 
 
 # ----------------------------------------------------------------------------------------
@@ -338,6 +340,8 @@ def init_params(cfg: OracleConfig, seed: int = 2001) -> Dict[str, np.ndarray]:
     mems = cfg.decoder_memories()
     att_total = dec_units * len(mems)
     _cell_params(rng, cfg, "dec/l0", E + att_total, dec_units, P)
+    for j in range(1, len(cfg.decoder_units)):                  # MultiRNNCell: layer j consumes layer j-1's output
+        _cell_params(rng, cfg, f"dec/l{j}", cfg.decoder_units[j - 1], cfg.decoder_units[j], P)
     for i, (stream, t) in enumerate(mems):
         _attention_params(rng, f"dec/att{i}", t, cfg.memory_depth(stream), dec_units, P)
     out_dim = att_total if cfg.output_attention() else dec_units
@@ -515,6 +519,33 @@ class _Cell:
             if mo is not None:
                 out = out * mo
         return out, ns
+
+
+class _MultiCell:
+    """MultiRNNCell of _Cell layers (cells.py:96-100) behind the single-cell interface; the state is the FLAT tuple
+    (c0, h0, c1, h1, ...).  Each layer's DropoutWrapper draws from its own RNG stream family (cell id + layer)."""
+
+    def __init__(self, cells):
+        self.cells = cells
+        self.t, self.units = cells[0].t, cells[-1].units
+        self.ns = 2 if self.t == "lstm" else 1
+
+    def set_dropout(self, keep, cid, T, seed, lens=None, reverse=False):
+        for j, c in enumerate(self.cells):
+            c.set_dropout(keep, cid + j, T, seed, lens, reverse)
+
+    def zero_state(self, B, dtype):
+        out = ()
+        for c in self.cells:
+            out += c.zero_state(B, dtype)
+        return out
+
+    def __call__(self, x, state, t=0):
+        new = ()
+        for j, c in enumerate(self.cells):
+            x, ns = c(x, tuple(state[j * self.ns:(j + 1) * self.ns]), t)
+            new += ns
+        return x, new
 
 
 def _select(mask: Tensor, new, old):
@@ -753,6 +784,8 @@ class _Model:
     def _init_decoder(self):
         P, cfg = self.P, self.cfg
         self.cell = _Cell(P, "dec/l0", cfg.cell_type, cfg.decoder_units[0])
+        if len(cfg.decoder_units) > 1:
+            self.cell = _MultiCell([self.cell] + [_Cell(P, f"dec/l{j}", cfg.cell_type, u) for j, u in enumerate(cfg.decoder_units) if j > 0])
         self.mechs = [
             _Mechanism(P, f"dec/att{i}", t, self.enc[s].outputs, self.lens[s])
             for i, (s, t) in enumerate(cfg.decoder_memories())
@@ -773,7 +806,10 @@ class _Model:
         else:
             s = "audio" if "audio" in self.enc else "video"
             self.init_state = self.enc[s].final_state             # decoder_unimodal.py:144-145
-        self.att_dim = cfg.decoder_units[0] * len(self.mechs)
+        if len(cfg.decoder_units) > 1:
+            # decoder_unimodal.py:151-157 / decoder_bimodal.py:159-166: layer 0 from the encoder(s), the layers above start at zero
+            self.init_state = tuple(self.init_state) + self.cell.zero_state(self.B, self.dtype)[len(self.init_state):]
+        self.att_dim = cfg.decoder_units[-1] * len(self.mechs)
 
     def step(self, x, state, att, t=0):
         if self.mechs:

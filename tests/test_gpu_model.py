@@ -69,6 +69,15 @@ CASES = {
                                 encoder_weight_sharing=True),
     "weight_sharing_bi_gru": dict(architecture="unimodal", encoder_type="bidirectional", video_units=(16, 16, 16), audio_units=None,
                                   cell_type="gru", encoder_weight_sharing=True, attention_type=(("bahdanau",), ("bahdanau",))),
+    # multi-layer decoder cells (MultiRNNCell under the AttentionWrapper; decoder_unimodal.py:101-108, :151-157): layer 0 starts from
+    # the encoder state, the layers above from zero; the TOP layer's output queries the attention
+    "dec2_unimodal": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32),
+                          decoder_units=(32, 32)),
+    "dec3_bimodal_mixed": dict(architecture="bimodal", encoder_type="bidirectional", video_units=(16,), audio_units=(16, 16),
+                               decoder_units=(32, 32, 32), attention_type=(("normed_bahdanau",), ("scaled_luong",))),
+    "dec2_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
+                          decoder_units=(32, 32), attention_type=(("scaled_luong",), ("bahdanau",))),
+    "dec2_lm": dict(architecture="lm", video_units=None, audio_units=None, decoder_units=(32, 32), warmup_steps=0),
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
@@ -124,7 +133,7 @@ def test_train_step_parity(case):
         assert err < 2e-5, (k, err)     # one Adam step moves each weight by <= lr_t ~ 4e-5 at step 1 of warm-up
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if not c.startswith("lm_")])
+@pytest.mark.parametrize("case", [c for c in CASES if not c.startswith("lm_") and c != "dec2_lm"])
 def test_greedy_decode_parity(case):
     from avsr_tf1_amd.model import Batch, Seq2SeqModel
     O, ocfg, mcfg, W, batch = make(case)
@@ -186,6 +195,10 @@ STOCH = [
     ("label_smoothing", dict(use_dropout=True, sampling_probability=0.3)),
     ("loss_focal", dict(sampling_probability=0.3)),
     ("weight_sharing_uni4", dict(use_dropout=True)),
+    ("dec2_unimodal", dict(use_dropout=True, sampling_probability=0.3)),
+    ("dec3_bimodal_mixed", dict(use_dropout=True, decoder_dropout=(0.8, 0.9, 0.7))),
+    ("dec2_av_align", dict(use_dropout=True, sampling_probability=0.2)),
+    ("dec2_lm", dict(use_dropout=True, sampling_probability=0.1)),
 ]
 
 
@@ -263,7 +276,8 @@ def test_full_width_train_step(case, over, mode, monkeypatch):
 
 # ------------------------------------------------------------------------------------------------
 # beam search (the reference's default decoding_algorithm, avsr.py:58): engine vs the oracle restatement
-@pytest.mark.parametrize("case", ["c1_audio_uni_luong", "c2_audio_bi_bahdanau", "c4_bimodal_uni", "c5_av_align", "gru_audio_uni"])
+@pytest.mark.parametrize("case", ["c1_audio_uni_luong", "c2_audio_bi_bahdanau", "c4_bimodal_uni", "c5_av_align", "gru_audio_uni", "dec2_unimodal",
+                                  "dec3_bimodal_mixed"])
 @pytest.mark.parametrize("K", [1, 4])
 def test_beam_search_parity(case, K):
     from avsr_tf1_amd.model import Batch, Seq2SeqModel
@@ -408,7 +422,7 @@ def test_greedy_attention_alignments(case):
         assert al["encoder"] is None
 
 
-@pytest.mark.parametrize("case", ["lm_lstm", "lm_gru"])
+@pytest.mark.parametrize("case", ["lm_lstm", "lm_gru", "dec2_lm"])
 def test_lm_sequence_likelihoods(case):
     """The language model's evaluate graph: per-utterance average step loss of a teacher-forced pass (lm.py:390-401)."""
     from avsr_tf1_amd.model import Batch, Seq2SeqModel
