@@ -44,7 +44,7 @@ class RnnLayer(C.Structure):
                 ("gates", C.c_void_p), ("cs", C.c_void_p), ("out", C.c_void_p), ("ld_out", C.c_int64),
                 ("state", C.c_void_p), ("h_final", C.c_void_p), ("c_final", C.c_void_p),
                 ("dgates", C.c_void_p), ("dstate", C.c_void_p), ("dout", C.c_void_p), ("ld_dout", C.c_int64),
-                ("dout_col", C.c_int32), ("pad_", C.c_int32), ("hs_seq", C.c_void_p), ("xt_seq", C.c_void_p),
+                ("dout_col", C.c_int32), ("residual", C.c_int32), ("hs_seq", C.c_void_p), ("xt_seq", C.c_void_p),
                 ("wt2", C.c_void_p), ("w2", C.c_void_p), ("bias2", C.c_void_p), ("rh_seq", C.c_void_p), ("dgates2", C.c_void_p)]
 
 

@@ -54,6 +54,7 @@ class ModelConfig:
     video_hw: Tuple[int, int, int] = (36, 36, 3)
     input_dense_layers: Tuple[int, ...] = (0,)                      # avsr/avsr.py:38, encoder.py:148-171
     encoder_weight_sharing: bool = False                            # cells.py:77: encoder layers >= 2 reuse layer 1's cell
+    residual_encoder: bool = False                                  # cells.py:91-92: ResidualWrapper on encoder layers > 0
 
     # -- same helpers/validation rules as the reference wiring (error types as in the reference) --
     def streams(self) -> List[str]:
@@ -133,6 +134,14 @@ class ModelConfig:
             if self.video_units is None or self.audio_units is None:
                 raise ValueError("av_align needs both a video and an audio stream")
         self.loss_code()
+        if self.residual_encoder:
+            for st in self.streams():
+                if len(set(self.units(st))) != 1:
+                    raise ValueError("residual_encoder needs equal layer widths")
+                if self.architecture == "av_align" and st == "audio" and len(self.units(st)) > 1:
+                    raise ValueError("residual_encoder: the attention-wrapped top layer cannot be residual (input and output widths differ)")
+            if self.cell_type != "lstm":
+                raise NotImplementedError("residual_encoder: LSTM cells only")
         if self.encoder_weight_sharing:
             for st in self.streams():
                 u = self.units(st)

@@ -18,6 +18,9 @@ int avsr_rnn_bwd_persistent_split(const avsr_rnn_stack* st, int32_t n, void* str
 // Persistent execution: all stacks in one launch when they fit together, else one launch per stack when every
 // stack fits on its own (checked first: nothing runs unless everything can), else AVSR_ERR_UNSUPPORTED.
 static int run_persistent(int (*fn)(const avsr_rnn_stack*, int32_t, void*, int), const avsr_rnn_stack* st, int32_t n, void* stream) {
+  for (int i = 0; i < n; ++i)                      // ResidualWrapper'd layers run through the per-step launches
+    for (int l = 0; l < st[i].n_layers && l < AVSR_MAX_LAYERS; ++l)
+      if (st[i].layer[l].residual) return AVSR_ERR_UNSUPPORTED;
   int rc = fn(st, n, stream, 0);
   if (rc != AVSR_ERR_UNSUPPORTED || n == 1) return rc;
   for (int i = 0; i < n; ++i)
@@ -49,6 +52,8 @@ static inline void set_cell_dropout(StepTask& tk, const avsr_rnn_stack& S, int l
 static inline float* dgroll(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)parity * B * 4 * l.units; }
 static inline float* dcbuf(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)(8 + parity) * B * l.units; }
 static inline float* dhcarry(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)(10 + parity) * B * l.units; }
+// residual layers only: d(emitted output) handed to the layer below, rolling [2][B][H] after the 12*B*H of the rest
+static inline float* dresbuf(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)(12 + parity) * B * l.units; }
 // GRU dstate: d(gate pre-act) rolling [2][B][2H] | d(cand pre-act) rolling [2][B][H] | carry [2][B][H] | tmp du | tmp dh*u
 static inline float* g_dgg(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)parity * B * 2 * l.units; }
 static inline float* g_dpc(const avsr_rnn_layer& l, int B, int parity) { return l.dstate + (long)(4 + parity) * B * l.units; }
@@ -77,6 +82,8 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
       const avsr_rnn_layer& Ly = S.layer[l];
       if (Ly.units % 4 || Ly.in_dim % 4 || !Ly.wt || !Ly.gates || !Ly.cs || !Ly.state) return AVSR_ERR_ARG;
       if (Ly.hoisted && l != 0) return AVSR_ERR_ARG;
+      if (Ly.residual && (l == 0 || Ly.in_dim != Ly.units || !S.layer[l - 1].out)) return AVSR_ERR_ARG;
+      if (Ly.residual && S.cell != 0) return AVSR_ERR_UNSUPPORTED;
       // zero initial state: h parity 0, c parity 0
       if (hipMemsetAsync(hbuf(Ly, S.B, 0), 0, sizeof(float) * S.B * Ly.units, s) != hipSuccess) return AVSR_ERR_HIP;
       if (hipMemsetAsync(cbuf(Ly, S.B, 0), 0, sizeof(float) * S.B * Ly.units, s) != hipSuccess) return AVSR_ERR_HIP;
@@ -137,7 +144,11 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
           if (l == 0) return AVSR_ERR_UNSUPPORTED;  // layer 0 input projection must be hoisted (avsr_gemm)
           const avsr_rnn_layer& Lo = S.layer[l - 1];
           StepSrc& x = tk.src[tk.nsrc++];
-          x.a = S.seed ? xbuf(Lo, S.B, (t + 1) & 1) : hbuf(Lo, S.B, (t + 1) & 1); x.sb = Lo.units; x.K = in; x.w = Ly.wt; x.ldw = in + H; x.kind = SRC_PLAIN;
+          // the lower layer's EMITTED output: its h state, unless dropout masks or a residual sum make the two differ
+          x.a = (S.seed || Lo.residual) ? xbuf(Lo, S.B, (t + 1) & 1) : hbuf(Lo, S.B, (t + 1) & 1); x.sb = Lo.units; x.K = in; x.w = Ly.wt; x.ldw = in + H; x.kind = SRC_PLAIN;
+          if (Ly.residual) {   // + raw input = the lower layer's output record (slot 1 = time 0)
+            tk.p8 = Lo.out + Lo.ld_out + Lo.out_col; tk.pad0 = (int)((long)(S.T + 2) * Lo.ld_out); tk.pad1 = (int)Lo.ld_out;
+          }
         }
         StepSrc& h = tk.src[tk.nsrc++];
         h.a = hbuf(Ly, S.B, t & 1); h.sb = H; h.K = H; h.w = Ly.wt + in; h.ldw = in + H; h.kind = SRC_PLAIN;
@@ -154,6 +165,9 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
           if (Ly.hs_seq) tk.p9 = Ly.hs_seq + H;                       // slot 1 = time 0
           if (l + 1 < S.n_layers) tk.p10 = xbuf(Ly, S.B, (t + 1) & 1);
           if (Ly.xt_seq) tk.p11 = Ly.xt_seq + H;
+        } else if (Ly.residual) {
+          if (l + 1 < S.n_layers) tk.p10 = xbuf(Ly, S.B, (t + 1) & 1);   // no masks: the plain residual sum, for the layer above
+          if (Ly.hs_seq) { tk.p9 = Ly.hs_seq + H; tk.s4 = (long)(S.T + 2) * H; tk.s5 = H; }   // h itself (dWh operand): `out` holds h + x
         }
       }
     }
@@ -190,7 +204,7 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
       if (!Ly.w || !Ly.dgates || !Ly.dstate || !Ly.gates || !Ly.cs) return AVSR_ERR_ARG;
       const size_t bh = sizeof(float) * S.B * Ly.units;
       // rolling dG (both parities), dc / dh_carry at parity T&1 = gradient of the final state
-      if (hipMemsetAsync(Ly.dstate, 0, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (hipMemsetAsync(Ly.dstate, 0, (Ly.residual ? 14 : 12) * bh, s) != hipSuccess) return AVSR_ERR_HIP;
       if (l == S.n_layers - 1) {
         if (S.cell == 1) {
           if (S.dh_final && hipMemcpyAsync(g_carry(Ly, S.B, S.T & 1), S.dh_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
@@ -284,7 +298,10 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
         if (Ly.dout) {
           tk.p8 = const_cast<float*>(Ly.dout) + Ly.ld_dout + Ly.dout_col;  // slot 1 = time 0
           tk.s0 = (long)(S.T + 2) * Ly.ld_dout; tk.s1 = Ly.ld_dout;
+        } else if (l + 1 < nl && S.layer[l + 1].residual) {
+          tk.p8 = dresbuf(S.layer[l + 1], S.B, t & 1); tk.s0 = H; tk.s1 = 0;   // d(output) through the upper layer's residual sum
         }
+        if (Ly.residual) tk.p10 = dresbuf(Ly, S.B, t & 1);
         if (S.seed) {
           set_cell_dropout(tk, S, l);
           if (l + 1 >= nl) tk.k_in = 1.0f;   // no upper layer inside the stack: external d out is already wrt the output

@@ -451,6 +451,7 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
       const float dout = pre2b + zB * drop_scale(tk.seed, tk.r_in, iidx, tk.k_in);
       const float dh = dout * drop_scale(tk.seed, tk.r_out, oidx, tk.k_out) +
                        (zA + pre1) * drop_scale(tk.seed, tk.r_st, oidx, tk.k_st);
+      if (tk.p10) tk.p10[bh] = dout;          // ResidualWrapper: the same gradient also reaches the lower layer's output
       const f32x4 g = pre4a;
       const float c = pre2, cprev = pre3;
       const float tc = ftanh(c);
@@ -498,7 +499,10 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
       tk.p1[bt * H + n] = c;
       // DropoutWrapper: emitted output and recurrent h carry independent masks; c is never dropped
       const uint32_t oidx = (uint32_t)(bt * H + n);
-      const float ho = h * drop_scale(tk.seed, tk.r_out, oidx, tk.k_out);
+      float ho = h * drop_scale(tk.seed, tk.r_out, oidx, tk.k_out);
+      // ResidualWrapper (cells.py:91-92): emitted output = (dropped) cell output + the layer's raw input, read from the
+      // lower layer's output record: p8 base, pad0 batch stride, pad1 time stride
+      if (tk.p8) ho += tk.p8[(long)b * tk.pad0 + (long)tau * tk.pad1 + n];
       const float hs = h * drop_scale(tk.seed, tk.r_st, oidx, tk.k_st);
       if (tk.p2) tk.p2[(long)b * tk.s0 + (long)tau * tk.s1 + n] = ho;
       tk.p5[bh] = c;

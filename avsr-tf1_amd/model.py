@@ -233,7 +233,7 @@ class Seq2SeqModel:
                 for l in range(nplain):
                     u = units[l]
                     Ld = {"gates": z(B, T, u, 4), "cs": z(B, T, u), "state": z(6 * B * u), "dgates": z(B, T, u, 4),
-                          "dstate": z(12 * B * u), "hf": z(B, u), "cf": z(B, u), "dhf": z(B, u), "dcf": z(B, u)}
+                          "dstate": z(14 * B * u), "hf": z(B, u), "cf": z(B, u), "dhf": z(B, u), "dcf": z(B, u)}
                     top = (l == len(units) - 1)
                     if top:
                         Ld["out"], Ld["col"], Ld["dout"] = E["mem"], di * u, E["dmem"]
@@ -242,8 +242,9 @@ class Seq2SeqModel:
                         Ld["dout"] = SeqBuf(B, T, u, 1, 1, dev) if (attentive and l == nplain - 1) else None
                     if self.gru:
                         Ld["rh"], Ld["dpc"] = z(B, T, u), z(B, T, u)
+                    if cfg.use_dropout or (cfg.residual_encoder and l > 0):
+                        Ld["hs_seq"] = SeqBuf(B, T, u, 1, 1, dev)   # the recurrent h as consumed (residual: the output record holds h + x)
                     if cfg.use_dropout:
-                        Ld["hs_seq"] = SeqBuf(B, T, u, 1, 1, dev)
                         if not top or attentive:
                             Ld["xt_seq"] = SeqBuf(B, T, u, 1, 1, dev)
                     E["layers"][(d, l)] = Ld
@@ -373,8 +374,10 @@ class Seq2SeqModel:
             Ly.out, Ly.ld_out = ops.fptr(Ld["out"].t), Ld["out"].D
             Ly.state, Ly.h_final, Ly.c_final = ops.fptr(Ld["state"]), ops.fptr(Ld["hf"]), ops.fptr(Ld["cf"])
             Ly.dgates, Ly.dstate = ops.fptr(Ld["dgates"]), ops.fptr(Ld["dstate"])
-            if drop:
+            Ly.residual = int(cfg.residual_encoder and l > 0)
+            if drop or Ly.residual:
                 Ly.hs_seq = ops.fptr(Ld["hs_seq"].t)
+            if drop:
                 if "xt_seq" in Ld:
                     Ly.xt_seq = ops.fptr(Ld["xt_seq"].t)
             if backward and Ld["dout"] is not None:
@@ -613,7 +616,7 @@ class Seq2SeqModel:
                         a_x = E["layers"][(d, l - 1)]["out"].mat(0, E["layers"][(d, l - 1)]["col"])
                     self._gemm_tn(a_x, dg, Gk.mat(G * u), i, G * u, B * T)
                     sh = 1 if d == "bw" else -1
-                    a_h = Ld["hs_seq"].mat(sh) if drop else Ld["out"].mat(sh, Ld["col"])
+                    a_h = Ld["hs_seq"].mat(sh) if (drop or (cfg.residual_encoder and l > 0)) else Ld["out"].mat(sh, Ld["col"])
                     self._gemm_tn(a_h, dg, Gk.mat(G * u, row0=i), u, G * u, B * T)
                     ops.colsum(dg, B * T, G * u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
                     if self.gru:                 # candidate kernel: inputs [x ; r*h]

@@ -109,7 +109,11 @@ typedef struct avsr_rnn_layer {
   float* dstate;
   const float* dout;
   int64_t ld_dout;
-  int32_t dout_col, pad_;
+  int32_t dout_col;
+  int32_t residual;             /* ResidualWrapper around this layer's cell (cells.py:91-92; layers > 0, LSTM, units == in_dim):
+                                 * emitted output = cell output + layer input.  Runs through the per-step launches; `state`
+                                 * must hold 6*B*units and `dstate` 14*B*units floats, and hs_seq must be given (it then records
+                                 * the recurrent h even without dropout: `out` holds h + input). */
   /* DropoutWrapper buffers (NULL when dropout is off): both [B][T+2][units], slot s = time s-1 */
   float* hs_seq;                /* state-dropped h (what the next time step consumed): dWh operand */
   float* xt_seq;                /* output as seen by the consumer above (output mask x its input mask): dWx operand */

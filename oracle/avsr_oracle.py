@@ -62,6 +62,7 @@ class OracleConfig:
     learning_rate: float = 1e-3
     warmup_steps: int = 750                   # seq2seq.py:275
     encoder_weight_sharing: bool = False      # avsr.py:49, cells.py:77
+    residual_encoder: bool = False            # avsr.py:42, cells.py:91-92: ResidualWrapper on encoder layers > 0
     loss_fun: Optional[str] = None            # None | 'focal_loss' | 'mc_loss'  (seq2seq.py:147-163, devel.py)
     label_smoothing: float = 0.0              # avsr.py:57; > 0 switches to tf.losses.softmax_cross_entropy (seq2seq.py:151-155)
     lr_decay_steps: int = 0                   # lr_decay=('cosine_restarts', N), seq2seq.py:266-270; 0 = constant
@@ -149,6 +150,15 @@ class OracleConfig:
                 raise ValueError("AttentiveEncoder implements only unidirectional")  # encoder.py:229
             if self.video_units is None or self.audio_units is None:
                 raise ValueError("av_align needs both streams")
+        if self.residual_encoder:
+            for st in self.streams():
+                u = self.video_units if st == "video" else self.audio_units
+                if len(set(u)) != 1:
+                    raise ValueError("residual_encoder needs equal layer widths")
+                if self.architecture == "av_align" and st == "audio" and len(u) > 1:
+                    raise ValueError("residual_encoder: the attention-wrapped top layer cannot be residual (input and output widths differ)")
+            if self.cell_type != "lstm":
+                raise NotImplementedError("residual_encoder: LSTM cells only")
         if len(set(self.decoder_units)) != 1:
             raise NotImplementedError("multi-layer decoders: equal layer widths only")
         if len(self.decoder_units) > 1 and self.cell_type != "lstm":
@@ -655,11 +665,13 @@ def _map_state(fn, new, old):
     return tuple(_map_state(fn, n, o) for n, o in zip(new, old))
 
 
-def _stack_step(cells: List[_Cell]):
+def _stack_step(cells: List[_Cell], residual: bool = False):
+    """MultiRNNCell step; residual: ResidualWrapper around every cell but the first (cells.py:89-92): output + raw input."""
     def step(x, states, t=0):
         new_states = []
-        for c, s in zip(cells, states):
-            x, ns = c(x, s, t)
+        for l, (c, s) in enumerate(zip(cells, states)):
+            y, ns = c(x, s, t)
+            x = y + x if (residual and l > 0) else y
             new_states.append(ns)
         return x, tuple(new_states)
     return step
@@ -704,8 +716,9 @@ def encode_stream(P, cfg: OracleConfig, stream: str, x: Tensor, lens: Tensor, tr
         def step(x_t, state, t=0):
             lower, (top_state, att) = state
             new_lower = []
-            for c, s in zip(cells[:-1], lower):
-                x_t, ns = c(x_t, s, t)
+            for l, (c, s) in enumerate(zip(cells[:-1], lower)):
+                y_t, ns = c(x_t, s, t)
+                x_t = y_t + x_t if (cfg.residual_encoder and l > 0) else y_t
                 new_lower.append(ns)
             out, ns, new_att, al = attention_wrapper_step(cells[-1], [mech], out_att, x_t, top_state, att, t)
             aligns.append(al[0])
@@ -717,13 +730,13 @@ def encode_stream(P, cfg: OracleConfig, stream: str, x: Tensor, lens: Tensor, tr
         return EncoderOut(outs, st[1][0], torch.stack(aligns, dim=1))
     if cfg.encoder_type == "unidirectional":
         cells = _make_cells(P, cfg, stream, "fw", units, training, seed, T, lens)
-        outs, st = dynamic_rnn(_stack_step(cells), tuple(c.zero_state(B, dtype) for c in cells), x, lens)
+        outs, st = dynamic_rnn(_stack_step(cells, cfg.residual_encoder), tuple(c.zero_state(B, dtype) for c in cells), x, lens)
         return EncoderOut(outs, st[-1])
     # bidirectional: two independent stacks, concat at the top only (encoder.py:92-121)
     fw = _make_cells(P, cfg, stream, "fw", units, training, seed, T, lens)
     bw = _make_cells(P, cfg, stream, "bw", units, training, seed, T, lens)
-    o_fw, s_fw = dynamic_rnn(_stack_step(fw), tuple(c.zero_state(B, dtype) for c in fw), x, lens)
-    o_bw, s_bw = dynamic_rnn(_stack_step(bw), tuple(c.zero_state(B, dtype) for c in bw),
+    o_fw, s_fw = dynamic_rnn(_stack_step(fw, cfg.residual_encoder), tuple(c.zero_state(B, dtype) for c in fw), x, lens)
+    o_bw, s_bw = dynamic_rnn(_stack_step(bw, cfg.residual_encoder), tuple(c.zero_state(B, dtype) for c in bw),
                              _reverse_sequence(x, lens), lens)
     o_bw = _reverse_sequence(o_bw, lens)
     outs = torch.cat([o_fw, o_bw], dim=-1)

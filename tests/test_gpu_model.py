@@ -78,6 +78,11 @@ CASES = {
     "dec2_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
                           decoder_units=(32, 32), attention_type=(("scaled_luong",), ("bahdanau",))),
     "dec2_lm": dict(architecture="lm", video_units=None, audio_units=None, decoder_units=(32, 32), warmup_steps=0),
+    # residual_encoder (cells.py:91-92): ResidualWrapper on encoder layers > 0; those stacks run through the per-step launches
+    "residual_uni3": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32, 32),
+                          residual_encoder=True),
+    "residual_bimodal_bi": dict(architecture="bimodal", encoder_type="bidirectional", video_units=(16, 16), audio_units=(16, 16, 16),
+                                decoder_units=(32,), residual_encoder=True),
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
@@ -199,6 +204,8 @@ STOCH = [
     ("dec3_bimodal_mixed", dict(use_dropout=True, decoder_dropout=(0.8, 0.9, 0.7))),
     ("dec2_av_align", dict(use_dropout=True, sampling_probability=0.2)),
     ("dec2_lm", dict(use_dropout=True, sampling_probability=0.1)),
+    ("residual_uni3", dict(use_dropout=True)),
+    ("residual_bimodal_bi", dict(use_dropout=True, audio_dropout=(0.8, 0.9, 0.7))),
 ]
 
 
