@@ -54,6 +54,7 @@ class ModelConfig:
     video_hw: Tuple[int, int, int] = (36, 36, 3)
     input_dense_layers: Tuple[int, ...] = (0,)                      # avsr/avsr.py:38, encoder.py:148-171
     encoder_weight_sharing: bool = False                            # cells.py:77: encoder layers >= 2 reuse layer 1's cell
+    instance_normalisation: bool = False                            # encoder.py:51-55: instance_norm after the batch norm
     residual_encoder: bool = False                                  # cells.py:91-92: ResidualWrapper on encoder layers > 0
 
     # -- same helpers/validation rules as the reference wiring (error types as in the reference) --

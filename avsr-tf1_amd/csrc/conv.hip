@@ -225,3 +225,84 @@ extern "C" int avsr_selu_bwd(const float* z, const float* dy, float* dz, int64_t
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// tf.contrib.layers.instance_norm on [B, T, F] encoder inputs (avsr/encoder.py:51-55): statistics over the time axis per
+// (utterance, feature) -- zero padding included -- epsilon 1e-6, learned gamma / beta per feature.
+// One workgroup per (utterance, 64 features): 256 threads = 64 features x 4 time lanes.
+namespace avsr {
+
+__global__ __launch_bounds__(256) void instnorm_fwd_kernel(const float* x, float* y, const float* gamma, const float* beta, float* mean_o,
+                                                           float* invstd_o, int T, int F, float eps) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.x, f = blockIdx.y * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  const bool ok = f < F;
+  const float* xb = x + (long)b * T * F + f;
+  float s = 0.f;
+  if (ok) for (int t = g; t < T; t += 4) s += xb[(long)t * F];
+  red[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]) / (float)T;
+  __syncthreads();
+  float q = 0.f;
+  if (ok) for (int t = g; t < T; t += 4) { const float d = xb[(long)t * F] - mean; q += d * d; }
+  red[g][threadIdx.x & 63] = q;
+  __syncthreads();
+  const float var = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]) / (float)T;
+  const float istd = rsqrtf(var + eps);
+  if (!ok) return;
+  if (g == 0) { mean_o[(long)b * F + f] = mean; invstd_o[(long)b * F + f] = istd; }
+  const float ga = gamma[f] * istd, be = beta[f];
+  float* yb = y + (long)b * T * F + f;
+  for (int t = g; t < T; t += 4) yb[(long)t * F] = (xb[(long)t * F] - mean) * ga + be;
+}
+
+// dx may alias dy.  dgamma_part / dbeta_part [B][F]: per-utterance sums (the caller column-sums them over B).
+__global__ __launch_bounds__(256) void instnorm_bwd_kernel(const float* x, const float* dy, const float* gamma, const float* mean_i,
+                                                           const float* invstd_i, float* dx, float* dgamma_part, float* dbeta_part,
+                                                           int T, int F) {
+  __shared__ float red[2][4][64];
+  const int b = blockIdx.x, fl = threadIdx.x & 63, f = blockIdx.y * 64 + fl, g = threadIdx.x >> 6;
+  const bool ok = f < F;
+  const long base = (long)b * T * F + f;
+  const float mean = ok ? mean_i[(long)b * F + f] : 0.f, istd = ok ? invstd_i[(long)b * F + f] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  if (ok)
+    for (int t = g; t < T; t += 4) {
+      const float d = dy[base + (long)t * F];
+      s1 += d;
+      s2 += d * (x[base + (long)t * F] - mean) * istd;
+    }
+  red[0][g][fl] = s1; red[1][g][fl] = s2;
+  __syncthreads();
+  s1 = red[0][0][fl] + red[0][1][fl] + red[0][2][fl] + red[0][3][fl];
+  s2 = red[1][0][fl] + red[1][1][fl] + red[1][2][fl] + red[1][3][fl];
+  if (!ok) return;
+  if (g == 0) { dgamma_part[(long)b * F + f] = s2; dbeta_part[(long)b * F + f] = s1; }
+  const float k = gamma[f] * istd, m1 = s1 / (float)T, m2 = s2 / (float)T;
+  for (int t = g; t < T; t += 4) {
+    const float xh = (x[base + (long)t * F] - mean) * istd;
+    dx[base + (long)t * F] = k * (dy[base + (long)t * F] - m1 - xh * m2);
+  }
+}
+
+}  // namespace avsr
+
+extern "C" int avsr_instnorm_fwd(const float* x, float* y, int32_t B, int32_t T, int32_t F, const float* gamma, const float* beta,
+                                 float* mean_out, float* invstd_out, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta || !mean_out || !invstd_out || B <= 0 || T <= 0 || F <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(avsr::instnorm_fwd_kernel, dim3(B, (F + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, y, gamma, beta, mean_out,
+                     invstd_out, T, F, eps);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_instnorm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* invstd, float* dx,
+                                 float* dgamma_part, float* dbeta_part, int32_t B, int32_t T, int32_t F, void* stream) {
+  if (!x || !dy || !gamma || !mean || !invstd || !dx || !dgamma_part || !dbeta_part || B <= 0 || T <= 0 || F <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(avsr::instnorm_bwd_kernel, dim3(B, (F + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, dy, gamma, mean, invstd, dx,
+                     dgamma_part, dbeta_part, T, F);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}

@@ -215,6 +215,8 @@ class Seq2SeqModel:
             if self.n_dense:                                          # encoder.py:148-171: pre-activations, outputs and their gradients
                 E["dense"] = [dict(z=z(B * T, u), a=z(B * T, u), da=z(B * T, u)) for u in cfg.input_dense_layers]
             E["xn"], E["dxn"], E["xhat"] = z(B * T, F), z(B * T, F), z(B * T, F)
+            if cfg.instance_normalisation:
+                E["xi"], E["in_mean"], E["in_invstd"], E["in_dg"], E["in_db"] = z(B * T, F), z(B, F), z(B, F), z(B, F), z(B, F)
             if s == "video" and self.use_cnn:
                 from .cnn import LipCNN
                 E["cnn"] = LipCNN(self, B * T)                       # lip crops -> F = cnn_dense_units features
@@ -463,6 +465,10 @@ class Seq2SeqModel:
                 E["xin"] = E["xn"]
             else:
                 E["xin"] = x
+            if cfg.instance_normalisation:       # contrib.layers.instance_norm over the time axis (encoder.py:51-55)
+                E["in_x"] = E["xin"]
+                ops.instnorm_fwd(E["xin"], E["xi"], B, T, F, self._pp(f"{s}/in/gamma"), self._pp(f"{s}/in/beta"), E["in_mean"], E["in_invstd"])
+                E["xin"] = E["xi"]
             F0 = E["F0"]
             E["xin0"], E["dxin0"] = E["xin"], E["dxn"]
             if self.n_dense:                     # Dense(units, selu, use_bias=False) stack between BN and the RNN
@@ -626,7 +632,7 @@ class Seq2SeqModel:
                         self._gemm_tn(ops.mat(Ld["rh"], u), dpc, Gc.mat(u, row0=i), u, u, B * T)
                         ops.colsum(dpc, B * T, u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/enc/{d}/l{cfg.shared_layer(l)}/cand_bias"].off)
                     i = u
-                if E["nplain"] > 0 and (cfg.batch_normalisation or "cnn" in E or self.n_dense):
+                if E["nplain"] > 0 and (cfg.batch_normalisation or "cnn" in E or self.n_dense or cfg.instance_normalisation):
                     u0, G = E["units"][0], self.G
                     W0 = self.P[self._kn(f"{s}/enc/{d}/l0")[0]]
                     L0 = E["layers"][(d, 0)]
@@ -649,6 +655,11 @@ class Seq2SeqModel:
                     self._gemm_tn(ops.mat(a_prev, w_prev), ops.mat(Dn["z"], u), self.Gr[f"{s}/dense{k}/kernel"].mat(u), w_prev, u, B * T)
                     g_prev = E["dense"][k - 1]["da"] if k else E["dxn"]
                     ops.gemm(ops.mat(Dn["z"], u), self.P[f"{s}/dense{k}/kernel"].mat(u), ops.mat(g_prev, w_prev), B * T, w_prev, u, trans_b=1)
+            if cfg.instance_normalisation:       # dxn holds d(instance-norm output): turn it into d(input) in place
+                ops.instnorm_bwd(E["in_x"], E["dxn"], self._pp(f"{s}/in/gamma"), E["in_mean"], E["in_invstd"], E["dxn"], E["in_dg"], E["in_db"],
+                                 B, T, F)
+                ops.colsum(ops.mat(E["in_dg"], F), B, F, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/in/gamma"].off)
+                ops.colsum(ops.mat(E["in_db"], F), B, F, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/in/beta"].off)
             if cfg.batch_normalisation:
                 # (a 1-layer attentive encoder wrote dxn in _av_align_backward)
                 ops.batchnorm_xhat(E["x"], E["mean"], E["invstd"], E["xhat"], B * T, F)

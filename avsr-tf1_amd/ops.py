@@ -211,6 +211,16 @@ def seq_loss_per_utterance(row_loss, labels_len, denom, out, B, L):
           "avsr_seq_loss_per_utterance")
 
 
+def instnorm_fwd(x, y, B, T, F, gamma, beta, mean_out, invstd_out, eps=1e-6):
+    check(_L().avsr_instnorm_fwd(fptr(x), fptr(y), B, T, F, fptr(gamma), fptr(beta), fptr(mean_out), fptr(invstd_out), float(eps), _s()),
+          "avsr_instnorm_fwd")
+
+
+def instnorm_bwd(x, dy, gamma, mean, invstd, dx, dgamma_part, dbeta_part, B, T, F):
+    check(_L().avsr_instnorm_bwd(fptr(x), fptr(dy), fptr(gamma), fptr(mean), fptr(invstd), fptr(dx), fptr(dgamma_part), fptr(dbeta_part),
+                                 B, T, F, _s()), "avsr_instnorm_bwd")
+
+
 def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, grad_scale=1.0, first_decay_steps=0):
     check(_L().avsr_adam_step_decay(fptr(params), fptr(grads), fptr(m), fptr(v), n, fptr(gnorm), fptr(step), float(lr),
                                     int(warmup_steps), int(first_decay_steps), float(clip_norm), float(grad_scale), _s()),

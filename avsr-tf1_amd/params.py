@@ -75,6 +75,9 @@ def inventory(cfg: ModelConfig):
             inv[f"{stream}/bn/beta"] = ((feat,), "plain", "zeros")
             inv[f"{stream}/bn/moving_mean"] = ((feat,), "plain", "zeros")
             inv[f"{stream}/bn/moving_variance"] = ((feat,), "plain", "ones")
+        if cfg.instance_normalisation:                        # encoder.py:51-55
+            inv[f"{stream}/in/gamma"] = ((feat,), "plain", "ones")
+            inv[f"{stream}/in/beta"] = ((feat,), "plain", "zeros")
         attentive = cfg.architecture == "av_align" and stream == "audio"
         if cfg.input_dense_layers[0] > 0:                     # encoder.py:148-171: Dense(units, selu, use_bias=False)
             w_in = feat

@@ -445,6 +445,13 @@ int avsr_seq_loss_fun(float* logits, const int32_t* labels, const int32_t* label
  * (avsr/lm.py:390-401: sequence_loss(average_across_batch=False, average_across_timesteps=True)). */
 int avsr_seq_loss_per_utterance(const float* row_loss, const int32_t* labels_len, const float* denom, float* out, int32_t B,
                                 int32_t L, void* stream);
+/* tf.contrib.layers.instance_norm on the [B,T,F] encoder inputs (avsr/encoder.py:51-55): mean / variance over the T axis per
+ * (utterance, feature), zero padding included, epsilon 1e-6, per-feature gamma / beta.  mean_out / invstd_out [B][F].
+ * Backward: dx (may alias dy) and the per-utterance sums dgamma_part / dbeta_part [B][F] (column-sum them over B). */
+int avsr_instnorm_fwd(const float* x, float* y, int32_t B, int32_t T, int32_t F, const float* gamma, const float* beta,
+                      float* mean_out, float* invstd_out, float eps, void* stream);
+int avsr_instnorm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* invstd, float* dx,
+                      float* dgamma_part, float* dbeta_part, int32_t B, int32_t T, int32_t F, void* stream);
 /* AU regression loss (avsr/encoder.py:173-189); z = pre-sigmoid Dense(2) outputs [B][T][2]. */
 int avsr_au_loss(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz, int32_t B, int32_t T,
                  float weight, void* stream);

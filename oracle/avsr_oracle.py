@@ -62,6 +62,7 @@ class OracleConfig:
     learning_rate: float = 1e-3
     warmup_steps: int = 750                   # seq2seq.py:275
     encoder_weight_sharing: bool = False      # avsr.py:49, cells.py:77
+    instance_normalisation: bool = False      # avsr.py:37, encoder.py:51-55: contrib.layers.instance_norm after the batch norm
     residual_encoder: bool = False            # avsr.py:42, cells.py:91-92: ResidualWrapper on encoder layers > 0
     loss_fun: Optional[str] = None            # None | 'focal_loss' | 'mc_loss'  (seq2seq.py:147-163, devel.py)
     label_smoothing: float = 0.0              # avsr.py:57; > 0 switches to tf.losses.softmax_cross_entropy (seq2seq.py:151-155)
@@ -317,6 +318,9 @@ def init_params(cfg: OracleConfig, seed: int = 2001) -> Dict[str, np.ndarray]:
             P[f"{stream}/bn/moving_mean"] = np.zeros((feat,), np.float32)
             P[f"{stream}/bn/moving_variance"] = np.ones((feat,), np.float32)
         attentive = cfg.architecture == "av_align" and stream == "audio"
+        if cfg.instance_normalisation:
+            P[f"{stream}/in/gamma"] = np.ones((feat,), np.float32)
+            P[f"{stream}/in/beta"] = np.zeros((feat,), np.float32)
         if cfg.input_dense_layers[0] > 0:                        # Dense(units, selu, use_bias=False), variance-scaling init
             w_in = feat
             for i, u in enumerate(cfg.input_dense_layers):
@@ -704,6 +708,12 @@ def encode_stream(P, cfg: OracleConfig, stream: str, x: Tensor, lens: Tensor, tr
     T = x.shape[1]
     if cfg.batch_normalisation:
         x = batch_norm(x, P, f"{stream}/bn", training, bn_updates, stats=bn_stats)
+    if cfg.instance_normalisation:
+        # tf.contrib.layers.instance_norm(inputs) on [B,T,F] (encoder.py:51-55): moments over the time axis per (utterance, feature),
+        # padding included; center + scale per feature, epsilon 1e-6 (contrib/layers/python/layers/normalization.py, recalled)
+        mu = x.mean(dim=1, keepdim=True)
+        var = ((x - mu) ** 2).mean(dim=1, keepdim=True)
+        x = (x - mu) * torch.rsqrt(var + 1e-6) * P[f"{stream}/in/gamma"] + P[f"{stream}/in/beta"]
     if cfg.input_dense_layers[0] > 0:                            # encoder.py:148-171, after _init_data (BN), before the RNN
         for i in range(len(cfg.input_dense_layers)):
             x = torch.selu(x @ P[f"{stream}/dense{i}/kernel"])

@@ -83,6 +83,13 @@ CASES = {
                           residual_encoder=True),
     "residual_bimodal_bi": dict(architecture="bimodal", encoder_type="bidirectional", video_units=(16, 16), audio_units=(16, 16, 16),
                                 decoder_units=(32,), residual_encoder=True),
+    # instance_normalisation (encoder.py:51-55): contrib.layers.instance_norm over the time axis, after the batch norm
+    "instnorm_bimodal": dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
+                             instance_normalisation=True, regress_aus=True),
+    "instnorm_only_bi": dict(architecture="unimodal", encoder_type="bidirectional", video_units=None, audio_units=(32,),
+                             batch_normalisation=False, instance_normalisation=True, audio_feat=72),
+    "instnorm_dense_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32,), audio_units=(32,),
+                                    instance_normalisation=True, input_dense_layers=(24,)),
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
@@ -205,6 +212,7 @@ STOCH = [
     ("dec2_av_align", dict(use_dropout=True, sampling_probability=0.2)),
     ("dec2_lm", dict(use_dropout=True, sampling_probability=0.1)),
     ("residual_uni3", dict(use_dropout=True)),
+    ("instnorm_bimodal", dict(use_dropout=True, sampling_probability=0.2)),
     ("residual_bimodal_bi", dict(use_dropout=True, audio_dropout=(0.8, 0.9, 0.7))),
 ]
 
