@@ -143,6 +143,14 @@ class LipCNN:
     def _pv(self, n):
         return self.m._pp(self.pre + n)
 
+    @staticmethod
+    def _copy(src, dst):
+        """dst = src with an engine kernel.  (A torch copy_ of these 100+ MB maps is captured as a D2D memcpy node; back-to-back
+        replays of a graph holding such nodes were observed to overlap on ROCm 7.0 -- wrong results and GPU memory faults.)"""
+        n = src.numel()
+        c = 64 if n % 64 == 0 else 4
+        ops.dropout_rows(ops.mat(src, c), ops.mat(dst, c), n // c, c, None, 0, 1.0, c)
+
     def forward(self, frames, training):
         m, N = self.m, self.N
         H, W, C = self.shapes["in"]
@@ -195,7 +203,7 @@ class LipCNN:
             return self.gmaps[name], beta
 
         gout = self.gmaps["out"].view(N, -1)
-        gout.copy_(dfeat)
+        self._copy(dfeat, gout)
         written.add("out")
         for op in reversed(self.ops):
             kind = op[0]
@@ -218,7 +226,7 @@ class LipCNN:
                     if beta:
                         ops.add(g, self.gmaps[dst], g, g.numel())
                     else:
-                        g.copy_(self.gmaps[dst])
+                        self._copy(self.gmaps[dst], g)
             elif kind == "bnrelu":
                 _, name, src, dst, c = op
                 h, w, _ = self.shapes[src]

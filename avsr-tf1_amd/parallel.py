@@ -42,19 +42,48 @@ class DataParallelTrainer:
                      (batch.audio, batch.video, batch.labels))
 
     def _stage(self, key, batch):
-        """Copy the batch into the static buffers the captured graph reads."""
+        """The static buffers the captured graph reads.  The first batch of a shape is adopted as is (its tensors become the
+        static buffers: a caller that keeps feeding the same tensors pays no copy and, more importantly, puts nothing between
+        the graph launches); any other batch is copied in by a kernel, after draining the stream (see _drain)."""
         st = self._static.get(key)
         if st is None:
-            st = type(batch)(*[None if t is None else t.clone() for t in
-                               (batch.audio, batch.audio_len, batch.video, batch.video_len, batch.aus, batch.labels,
-                                batch.labels_len)])
-            self._static[key] = st
+            self._static[key] = st = batch
             return st
-        for name in ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len"):
-            src, dst = getattr(batch, name), getattr(st, name)
-            if src is not None and src.data_ptr() != dst.data_ptr():
-                dst.copy_(src)
+        todo = [(getattr(st, name), getattr(batch, name)) for name in ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len")
+                if getattr(batch, name) is not None and getattr(batch, name).data_ptr() != getattr(st, name).data_ptr()]
+        if todo:
+            self._drain()
+            for dst, src in todo:
+                self._copy_into(dst, src)
         return st
+
+    @staticmethod
+    def _drain():
+        """Host-wait for everything queued on the stream.  Measured on ROCm 7.0 / MI355X (tools/_probe): with
+        several steps queued, a LARGE eagerly launched kernel or D2D copy between two launches of the captured graphs let the
+        next launch start before the previous one had finished -- overlapping train steps, wrong results, persistent-kernel
+        waits expiring and GPU memory faults (a tiny kernel in between, or graph launches alone at any depth, were fine).  So
+        eager work that has to sit between graph launches (batch staging, the RCCL all-reduces) is only issued on a drained
+        stream; the cost is one host round trip per step in those modes."""
+        torch.cuda.current_stream().synchronize()
+
+    @staticmethod
+    def _copy_into(dst, src):
+        """dst = src through an engine KERNEL on the current stream, not a device-to-device memcpy.  Measured on ROCm 7.0 /
+        MI355X: a large D2D memcpy (DMA-engine path; the 75 MB lip-crop batch) enqueued between two launches of a captured
+        graph let the second launch start before the first had finished once several steps were queued -- overlapping
+        steps, wrong results, GPU memory faults.  A kernel stays on the compute queue and keeps the stream order."""
+        from . import ops
+        assert src.shape == dst.shape and src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous()
+        a, b = src.reshape(-1), dst.reshape(-1)
+        if a.element_size() == 4 and a.dtype != torch.float32:
+            a, b = a.view(torch.float32), b.view(torch.float32)          # bit-exact move of int32 payloads
+        if a.dtype != torch.float32:
+            dst.copy_(src)
+            return
+        n = a.numel()
+        c = 64 if n % 64 == 0 else (4 if n % 4 == 0 else 1)
+        ops.dropout_rows(ops.mat(a, c), ops.mat(b, c), n // c, c, None, 0, 1.0, c)
 
     def _fwd_bwd(self, batch):
         self.model.forward_train(batch, compute_denom=not self.collective)
@@ -74,6 +103,8 @@ class DataParallelTrainer:
     def train_step(self, batch):
         m, dist = self.model, self.dist
         key = self._key(batch)
+        if self.collective and self.use_graph:
+            self._drain()
         if self.collective:
             # global loss normaliser: sum over ALL ranks of min(labels_len, L)
             local = getattr(m, "local_loss_denominator", None)

@@ -32,3 +32,40 @@ def test_bench_json_contract_and_forced_collectives():
     forced = _bench({"AVSR_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
     assert forced["config"]["launch"] == "hipgraph"
     assert abs(forced["final_loss"] - plain["final_loss"]) < 1e-4 * max(1.0, abs(plain["final_loss"]))
+
+
+@pytest.mark.parametrize("front,fresh", [("features", False), ("resnet_cnn", False), ("resnet_cnn", True)])
+def test_queued_graph_replays_equal_eager_steps(front, fresh):
+    """Train steps queued back to back (no host sync) through the captured graphs must equal eager steps bit for bit, at the
+    benchmark's full batch size.  Regression test for a ROCm 7.0 hazard found with the 75 MB lip-crop batch: a large eager kernel
+    or D2D copy between two launches of a captured graph let queued launches overlap (wrong losses, expired persistent-kernel
+    waits, GPU memory faults).  `fresh`: a different batch object every step, i.e. the staging copy is exercised."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    import bench
+    from avsr_tf1_amd import ops
+    from avsr_tf1_amd.config import ModelConfig
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    from avsr_tf1_amd.parallel import DataParallelTrainer
+    wl = bench.WORKLOADS["c4"]
+    cfg = ModelConfig(audio_feat=bench.FA, video_feat=bench.FV, video_processing=front, use_dropout=True, sampling_probability=0.1, **wl["cfg"])
+    batch = Batch.from_numpy(bench.NS(bench.synth(cfg, 64, 0)))
+    names = ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len")
+    other = Batch(*[None if getattr(batch, n) is None else getattr(batch, n).clone() for n in names])
+    losses = {}
+    for mode in ("eager", "graph"):
+        m = Seq2SeqModel(cfg, seed=2001)
+        t = DataParallelTrainer(m, None, use_graph=(mode == "graph"))
+        t.train_step(batch)
+        torch.cuda.synchronize()
+        for chunk in range(3):
+            for i in range(10):
+                t.train_step(other if (fresh and i % 2) else batch)
+            torch.cuda.synchronize()
+        assert mode == "eager" or t.mode == "hipgraph"
+        assert not ops.rnn_persistent_error()
+        losses[mode] = (float(m.loss.item()), float(m.gnorm.item()))
+        del t, m
+        torch.cuda.empty_cache()
+    assert losses["eager"] == losses["graph"], losses
