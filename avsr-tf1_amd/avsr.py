@@ -92,8 +92,7 @@ class AVSR(object):
         self._required_graphs = required_grahps
 
         for name, val, ok in (("highway_encoder", highway_encoder, False),
-                              ("precision", precision, 'float32'),
-                              ("optimiser", optimiser, 'Adam')):
+                              ("precision", precision, 'float32')):
             if val != ok:
                 raise NotImplementedError("%s=%r is a non-default option of the reference that the HIP engine does not build" % (name, val))
         lr_decay_steps = 0
@@ -142,7 +141,8 @@ class AVSR(object):
             video_feat=feats.get('video', 128), audio_feat=feats.get('audio', 80),
             batch_normalisation=batch_normalisation, regress_aus=regress_aus,
             au_loss_weight=kwargs.get('au_loss_weight', 10.0),
-            recurrent_l2=recurrent_l2_regularisation, clip_gradients=clip_gradients, max_gradient_norm=max_gradient_norm,
+            recurrent_l2=None if optimiser == 'AdamW' else recurrent_l2_regularisation,     # avsr.py:168
+            optimiser=optimiser, weight_decay=weight_decay, clip_gradients=clip_gradients, max_gradient_norm=max_gradient_norm,
             learning_rate=learning_rate, warmup_steps=kwargs.get('warmup_steps', 750), lr_decay_steps=lr_decay_steps, loss_fun=loss_fun, label_smoothing=float(label_smoothing),
             max_label_length={'viseme': 150, 'phoneme': 150, 'character': 150}[unit],
             use_dropout=use_dropout, video_dropout=tuple(video_encoder_dropout_probability),

@@ -37,6 +37,8 @@ class ModelConfig:
     max_gradient_norm: float = 1.0
     learning_rate: float = 1e-3
     warmup_steps: int = 750
+    optimiser: str = "Adam"                   # Adam | Nadam | AdamW | Momentum (seq2seq.py:195-218)
+    weight_decay: float = 1e-4                # AdamW only (avsr.py:45)
     loss_fun: Optional[str] = None            # None | 'focal_loss' | 'mc_loss' (seq2seq.py:147-163, avsr/devel.py:12-51)
     label_smoothing: float = 0.0              # > 0: tf.losses.softmax_cross_entropy path (seq2seq.py:151-155)
     lr_decay_steps: int = 0                   # lr_decay=('cosine_restarts', N) (seq2seq.py:266-270); 0 = constant lr
@@ -135,6 +137,8 @@ class ModelConfig:
             if self.video_units is None or self.audio_units is None:
                 raise ValueError("av_align needs both a video and an audio stream")
         self.loss_code()
+        if self.optimiser not in ("Adam", "Nadam", "AdamW", "Momentum"):
+            raise Exception('Unsupported optimiser, try Adam')                            # seq2seq.py:218
         if self.residual_encoder:
             for st in self.streams():
                 if len(set(self.units(st))) != 1:

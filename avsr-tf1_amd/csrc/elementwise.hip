@@ -464,7 +464,7 @@ __global__ void reduce_scalar_kernel(const float* part, int n, float* out, int d
 // hyper: [0] step (as float-exact int32 via reinterpret), see avsr_adam_step
 __global__ void adam_kernel(float* p, float* g, float* m, float* v, long n, const float* gnorm, int32_t* step,
                             float lr, int warmup, float clip, float b1, float b2, float eps, float grad_scale,
-                            int decay_steps) {
+                            int decay_steps, int opt, float weight_decay) {
   const int t = step[0] + 1;
   float lr_now = lr;
   if (decay_steps > 0) {   // tf.train.cosine_decay_restarts(lr, global_step, first_decay_steps, t_mul=2, m_mul=1, alpha=0)
@@ -480,13 +480,24 @@ __global__ void adam_kernel(float* p, float* g, float* m, float* v, long n, cons
   const float lr_t = (float)((double)lr_now * sqrt(c2) / c1);
   float scale = grad_scale;
   if (clip > 0.f) scale *= clip / fmaxf(gnorm[0], clip);   // gnorm is the norm of the already-scaled gradient   // tf.clip_by_global_norm
+  // opt: 0 Adam, 1 Nadam (ApplyAdam use_nesterov), 2 AdamW (decoupled decay: var -= weight_decay * var, then Adam),
+  //      3 Momentum(0.9, no Nesterov): accum = 0.9 accum + g, var -= lr accum (accum lives in m)   (avsr/seq2seq.py:195-218)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * scale;
+    if (opt == 3) {
+      const float acc = 0.9f * m[i] + gi;
+      m[i] = acc;
+      p[i] -= lr_now * acc;
+      continue;
+    }
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
     v[i] = vi;
-    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    float pi = p[i];
+    if (opt == 2) pi -= weight_decay * pi;
+    const float num = opt == 1 ? b1 * mi + (1.f - b1) * gi : mi;
+    p[i] = pi - lr_t * num / (sqrtf(vi) + eps);
   }
 }
 __global__ void step_inc_kernel(int32_t* step) { step[0] += 1; }
@@ -802,10 +813,17 @@ extern "C" int avsr_adam_step(float* params, float* grads, float* m, float* v, i
 extern "C" int avsr_adam_step_decay(float* params, float* grads, float* m, float* v, int64_t n, const float* global_norm,
                                     int32_t* step, float lr, int32_t warmup_steps, int32_t first_decay_steps,
                                     float clip_norm, float grad_scale, void* stream) {
-  if (!params || !grads || !m || !v || !step || n <= 0 || first_decay_steps < 0) return AVSR_ERR_ARG;
+  return avsr_optimiser_step(params, grads, m, v, n, global_norm, step, lr, warmup_steps, first_decay_steps, clip_norm, grad_scale, 0, 0.f,
+                             stream);
+}
+
+extern "C" int avsr_optimiser_step(float* params, float* grads, float* m, float* v, int64_t n, const float* global_norm,
+                                   int32_t* step, float lr, int32_t warmup_steps, int32_t first_decay_steps, float clip_norm,
+                                   float grad_scale, int32_t optimiser, float weight_decay, void* stream) {
+  if (!params || !grads || !m || !v || !step || n <= 0 || first_decay_steps < 0 || optimiser < 0 || optimiser > 3) return AVSR_ERR_ARG;
   if (clip_norm > 0.f && !global_norm) return AVSR_ERR_ARG;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n, 1024, 2048)), dim3(256), 0, S_(stream), params, grads, m, v, (long)n,
-                     global_norm, step, lr, warmup_steps, clip_norm, 0.9f, 0.999f, 1e-8f, grad_scale, first_decay_steps);
+                     global_norm, step, lr, warmup_steps, clip_norm, 0.9f, 0.999f, 1e-8f, grad_scale, first_decay_steps, optimiser, weight_decay);
   AVSR_CHECK_LAUNCH();
   hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, S_(stream), step);
   AVSR_CHECK_LAUNCH();

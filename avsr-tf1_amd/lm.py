@@ -51,8 +51,8 @@ class LM(object):
         self._text_dataset = text_dataset
         self._batch_size = batch_size
         self._required_graphs = required_grahps
-        if optimiser != 'Adam':
-            raise NotImplementedError("optimiser=%r: the HIP engine builds Adam (the reference's default)" % (optimiser,))
+        if optimiser not in ('Adam', 'AdamW', 'Momentum'):
+            raise Exception('Unsupported optimiser, try Adam')                                     # lm.py:453
         if precision != 'float32':
             raise NotImplementedError("precision=%r: the HIP engine computes in float32" % (precision,))
         if cell_type not in ('lstm', 'gru'):
@@ -61,7 +61,8 @@ class LM(object):
         common = dict(architecture='lm', video_units=None, audio_units=None, cell_type=cell_type,
                       decoder_units=tuple(decoder_units_per_layer), embedding_size=embedding_size,
                       vocab_size=len(self._unit_dict) - 1, go_id=reverse['GO'], eos_id=reverse['EOS'],
-                      recurrent_l2=recurrent_l2_regularisation, clip_gradients=clip_gradients, max_gradient_norm=max_gradient_norm,
+                      recurrent_l2=None if optimiser == 'AdamW' else recurrent_l2_regularisation,   # lm.py:56
+                      optimiser=optimiser, weight_decay=kwargs.get('weight_decay', 0.0001), clip_gradients=clip_gradients, max_gradient_norm=max_gradient_norm,
                       learning_rate=learning_rate, warmup_steps=0,                                # lm.py:408: constant learning rate
                       max_label_length={'viseme': 65, 'phoneme': 70, 'character': 100}[unit],
                       decoder_dropout=tuple(decoder_dropout_probability))

@@ -1088,7 +1088,7 @@ class Seq2SeqModel:
         ops.global_norm(self.grads, self.n_train, self.gnorm, self.scratch)
         ops.adam_step(self.params, self.grads, self.adam_m, self.adam_v, self.n_train, self.gnorm, self.step,
                       cfg.learning_rate, cfg.warmup_steps, cfg.max_gradient_norm if cfg.clip_gradients else 0.0,
-                      first_decay_steps=cfg.lr_decay_steps)
+                      first_decay_steps=cfg.lr_decay_steps, optimiser=cfg.optimiser, weight_decay=cfg.weight_decay)
 
     def train_step(self, batch: Batch):
         """One `session.run([train_op, batch_loss, global_norm])` (avsr/avsr.py:265-271); returns device scalars."""

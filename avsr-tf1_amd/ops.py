@@ -221,10 +221,14 @@ def instnorm_bwd(x, dy, gamma, mean, invstd, dx, dgamma_part, dbeta_part, B, T, 
                                  B, T, F, _s()), "avsr_instnorm_bwd")
 
 
-def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, grad_scale=1.0, first_decay_steps=0):
-    check(_L().avsr_adam_step_decay(fptr(params), fptr(grads), fptr(m), fptr(v), n, fptr(gnorm), fptr(step), float(lr),
-                                    int(warmup_steps), int(first_decay_steps), float(clip_norm), float(grad_scale), _s()),
-          "avsr_adam_step_decay")
+OPTIMISER = {"Adam": 0, "Nadam": 1, "AdamW": 2, "Momentum": 3}
+
+
+def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, grad_scale=1.0, first_decay_steps=0, optimiser="Adam",
+              weight_decay=0.0):
+    check(_L().avsr_optimiser_step(fptr(params), fptr(grads), fptr(m), fptr(v), n, fptr(gnorm), fptr(step), float(lr),
+                                   int(warmup_steps), int(first_decay_steps), float(clip_norm), float(grad_scale), OPTIMISER[optimiser],
+                                   float(weight_decay), _s()), "avsr_optimiser_step")
 
 
 PROF_KINDS = ("gemm", "step_lstm_fwd", "step_lstm_bwd", "step_dense", "attn_fwd", "attn_bwd", "rnn_persist_fwd", "rnn_persist_bwd")

@@ -479,6 +479,12 @@ int avsr_adam_step(float* params, float* grads, float* m, float* v, int64_t n, c
 int avsr_adam_step_decay(float* params, float* grads, float* m, float* v, int64_t n, const float* global_norm,
                          int32_t* step, float lr, int32_t warmup_steps, int32_t first_decay_steps, float clip_norm,
                          float grad_scale, void* stream);
+/* The reference's other optimisers (avsr/seq2seq.py:195-218).  optimiser: 0 Adam (= avsr_adam_step_decay), 1 Nadam
+ * (contrib.opt.NadamOptimizer: Adam with the Nesterov numerator beta1*m + (1-beta1)*g), 2 AdamW (contrib.opt.AdamWOptimizer:
+ * var -= weight_decay * var, then Adam), 3 Momentum(0.9, use_nesterov=False) with the accumulator in m (v unused). */
+int avsr_optimiser_step(float* params, float* grads, float* m, float* v, int64_t n, const float* global_norm, int32_t* step,
+                        float lr, int32_t warmup_steps, int32_t first_decay_steps, float clip_norm, float grad_scale,
+                        int32_t optimiser, float weight_decay, void* stream);
 
 /* Optional per-launch HIP-event timing of the engine's own kernels (bench.py roofline figures).  Between
  * begin and end every gemm / step / attention launch is bracketed by an event pair on its stream; end

@@ -64,6 +64,8 @@ class OracleConfig:
     encoder_weight_sharing: bool = False      # avsr.py:49, cells.py:77
     instance_normalisation: bool = False      # avsr.py:37, encoder.py:51-55: contrib.layers.instance_norm after the batch norm
     residual_encoder: bool = False            # avsr.py:42, cells.py:91-92: ResidualWrapper on encoder layers > 0
+    optimiser: str = "Adam"                   # Adam | Nadam | AdamW | Momentum (seq2seq.py:195-218)
+    weight_decay: float = 1e-4                # AdamW only (avsr.py:45)
     loss_fun: Optional[str] = None            # None | 'focal_loss' | 'mc_loss'  (seq2seq.py:147-163, devel.py)
     label_smoothing: float = 0.0              # avsr.py:57; > 0 switches to tf.losses.softmax_cross_entropy (seq2seq.py:151-155)
     lr_decay_steps: int = 0                   # lr_decay=('cosine_restarts', N), seq2seq.py:266-270; 0 = constant
@@ -994,10 +996,19 @@ def train_step(P_np: Dict[str, np.ndarray], opt: Optional[dict], cfg: OracleConf
     new_opt = {"step": t, "m": {}, "v": {}}
     for k in names:
         g = grads[k].detach().numpy().astype(np.float64) * scale
+        p0 = P_np[k].astype(np.float64)
+        if cfg.optimiser == "Momentum":                     # tf.train.MomentumOptimizer(lr, 0.9, use_nesterov=False)
+            acc = 0.9 * opt["m"][k] + g
+            new_opt["m"][k], new_opt["v"][k] = acc, opt["v"][k]
+            newP[k] = (p0 - lr * acc).astype(P_np[k].dtype)
+            continue
         mm = b1 * opt["m"][k] + (1 - b1) * g
         vv = b2 * opt["v"][k] + (1 - b2) * g * g
         new_opt["m"][k], new_opt["v"][k] = mm, vv
-        newP[k] = (P_np[k].astype(np.float64) - lr_t * mm / (np.sqrt(vv) + eps)).astype(P_np[k].dtype)
+        if cfg.optimiser == "AdamW":                        # contrib.opt.AdamWOptimizer: var -= weight_decay * var, then Adam
+            p0 = p0 - cfg.weight_decay * p0
+        num = b1 * mm + (1 - b1) * g if cfg.optimiser == "Nadam" else mm      # NadamOptimizer: ApplyAdam(use_nesterov=True)
+        newP[k] = (p0 - lr_t * num / (np.sqrt(vv) + eps)).astype(P_np[k].dtype)
     for k, v in m.bn_updates.items():
         newP[k] = v.detach().numpy().astype(P_np[k].dtype)
     return {"loss": float(loss.detach()), "seq_loss": float(seq.detach()), "global_norm": float(gnorm.detach()),

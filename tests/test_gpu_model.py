@@ -90,6 +90,12 @@ CASES = {
                              batch_normalisation=False, instance_normalisation=True, audio_feat=72),
     "instnorm_dense_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32,), audio_units=(32,),
                                     instance_normalisation=True, input_dense_layers=(24,)),
+    # the reference's other optimisers (seq2seq.py:195-218)
+    "opt_nadam": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,), optimiser="Nadam"),
+    "opt_adamw": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,), optimiser="AdamW",
+                      weight_decay=0.01, recurrent_l2=None),
+    "opt_momentum": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,), optimiser="Momentum",
+                         warmup_steps=0),
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
@@ -212,6 +218,9 @@ STOCH = [
     ("dec2_av_align", dict(use_dropout=True, sampling_probability=0.2)),
     ("dec2_lm", dict(use_dropout=True, sampling_probability=0.1)),
     ("residual_uni3", dict(use_dropout=True)),
+    ("opt_nadam", dict(use_dropout=True)),
+    ("opt_adamw", dict(use_dropout=True)),
+    ("opt_momentum", dict(use_dropout=True)),
     ("instnorm_bimodal", dict(use_dropout=True, sampling_probability=0.2)),
     ("residual_bimodal_bi", dict(use_dropout=True, audio_dropout=(0.8, 0.9, 0.7))),
 ]
