@@ -5,6 +5,8 @@ Tolerances: logits / loss / global norm 1e-4 absolute (north_star), gradients 2e
 magnitude, greedy ids bit-exact."""
 import dataclasses
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -454,3 +456,42 @@ def test_lm_sequence_likelihoods(case):
     ref = O.lm_likelihoods(W, ocfg, batch)
     got = Seq2SeqModel(mcfg, weights=W).sequence_likelihoods(Batch.from_numpy(batch)).cpu().numpy()
     assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs at their FULL sequence lengths and widths (T_a = 500 x 80, T_v = 75 x 128, T_dec = 40, 256 units), 8 ragged
+# utterances so that the fp64 oracle finishes in seconds: the 500-step recurrences, the persistent kernels' full time loops and
+# the 40-step decoder are compared directly (no size-independent proxy needed).
+FULL_LENGTH = [
+    ("c4_bimodal_uni", dict(video_units=(256,), audio_units=(256, 256, 256), decoder_units=(256,), embedding_size=128,
+                            video_feat=128, audio_feat=80, regress_aus=True)),
+    ("c5_av_align", dict(video_units=(256,), audio_units=(256, 256), decoder_units=(256,), embedding_size=128,
+                         video_feat=128, audio_feat=80, regress_aus=True)),
+    ("c2_audio_bi_bahdanau", dict(audio_units=(256, 256, 256), decoder_units=(256,), embedding_size=128, audio_feat=80)),
+]
+
+
+@pytest.mark.skipif(not os.environ.get("AVSR_LONG_TESTS"), reason="8 minutes of fp64 oracle time: run with AVSR_LONG_TESTS=1 "
+                    "(last run: profiles/r01_full_length_parity.txt)")
+@pytest.mark.parametrize("case,over", FULL_LENGTH)
+def test_full_length_train_step_and_greedy(case, over):
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    O, ocfg, mcfg, W, batch = make(case, B=8, Ta=500, Tv=75, L=40, ragged=True, **over)
+    ref = O.train_step(W, None, ocfg, batch)
+    model = Seq2SeqModel(mcfg, weights=W)
+    db = Batch.from_numpy(batch)
+    logits = model.forward_train(db)
+    model.backward()
+    model.apply_update()
+    torch.cuda.synchronize()
+    assert not model.check_persistent()
+    assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
+    assert abs(float(model.loss.item()) - ref["loss"]) < 1e-4
+    assert abs(float(model.gnorm.item()) - ref["global_norm"]) < 1e-4 * max(1.0, ref["global_norm"])
+    grads = model.export_tf_weights("grads")
+    for k, g in ref["grads"].items():
+        scale = max(1e-3, np.abs(g).max())
+        assert np.abs(grads[k] - g).max() < 5e-4 * scale + 1e-6, (k, np.abs(grads[k] - g).max(), scale)
+    ids_ref = O.greedy_decode(ref["params"], ocfg, batch, max_steps=40)
+    ids = model.greedy_decode(db, max_steps=40).cpu().numpy()
+    assert ids.shape == ids_ref.shape and (ids == ids_ref).all()
