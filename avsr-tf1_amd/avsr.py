@@ -7,8 +7,11 @@ try_restore_latest_checkpoint)` / `evaluate(checkpoint_path, epoch)` behaviour a
 `predictions/<name>/predicted_epoch_<N>.mlf`.  TensorFlow graphs/sessions/summaries do not exist here.
 
 `video_processing='resnet_cnn'` runs the lip crops through the HIP lip-CNN front-end (cnn.py; avsr/video.py:143-195).
-Not built (raise explicitly): the `2dconv_cnn` / `3dconv_cnn` front-ends, `'wav'` audio (non-functional in the
-reference too), non-default losses / optimisers.
+Built besides the defaults: `input_dense_layers`, `instance_normalisation`, `residual_encoder`, `encoder_weight_sharing`, multi-layer
+decoders (equal widths, LSTM), `enable_attention=False`, `loss_fun` / `label_smoothing`, `lr_decay=('cosine_restarts', N)`, the Nadam /
+AdamW / Momentum optimisers, `write_attention_alignment` (greedy decoding).
+Not built (raise explicitly): `highway_encoder`, `precision='float16'`, the `2dconv_cnn` / `3dconv_cnn` front-ends, `'wav'` audio
+(non-functional in the reference too), the monotonic attention variants and the non-default cell types.
 """
 import glob
 import os
