@@ -287,8 +287,15 @@ def main():
                 return {"kernel": kind, "bound": "mfma", "achieved": None, "peak": MFMA_PEAK, "unit": "TFLOP/s", "frac": None,
                         "traffic": None, "avg_launch_us": us}
             ach = fl / (us * 1e-6) / 1e12
-            return {"kernel": kind, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK, 4), "traffic": traffic(kind), "algorithmic_flops_per_launch": int(fl), "avg_launch_us": us}
+            r = {"kernel": kind, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
+                 "frac": round(ach / MFMA_PEAK, 4), "traffic": traffic(kind), "algorithmic_flops_per_launch": int(fl), "avg_launch_us": us}
+            if kind.startswith("rnn_persist"):
+                # the recurrent chain is latency-bound -- the meaningful figure is the time per sequential time step
+                # (one launch walks the T_a-step layer/time wavefront), next to the ~1.45 us launch floor it replaces
+                r["sequential_steps"] = TA + 2
+                r["us_per_sequential_step"] = round(us / (TA + 2), 3)
+                r["note"] = "latency-bound recurrence: one persistent launch for the whole sequence; compare us_per_sequential_step with the ~1.45 us per-launch floor x 3 layers of a launch-per-step design"
+            return r
 
         out["roofline"] = roof(dom)
         out["roofline_other"] = [roof(k) for k in kinds if k != dom and k != "step_dense"]
