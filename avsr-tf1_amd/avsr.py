@@ -156,7 +156,7 @@ class AVSR(object):
             input_dense_layers=tuple(input_dense_layers), encoder_weight_sharing=bool(encoder_weight_sharing), residual_encoder=bool(residual_encoder), instance_normalisation=bool(instance_normalisation))
         self._model = Seq2SeqModel(self._cfg, seed=kwargs.get('seed', 0))
         self._shuffle_seed = kwargs.get('shuffle_seed')        # None = a fresh order every run, as tf.data's unseeded shuffle(5000)
-        self._trainer = DataParallelTrainer(self._model, None, use_graph=False)   # bucketed batches: shapes vary per step
+        self._trainer = DataParallelTrainer(self._model, None, use_graph=False, check_every_step=True)   # bucketed batches: shapes vary per step
 
     # ------------------------------------------------------------------------------------------------
     def _iterator(self, mode):

@@ -71,7 +71,7 @@ class LM(object):
         if 'train' in required_grahps:
             self._cfg = ModelConfig(use_dropout=use_dropout, sampling_probability=sampling_probability_outputs, **common)
             self._model = Seq2SeqModel(self._cfg, seed=kwargs.get('seed', 0))
-            self._trainer = DataParallelTrainer(self._model, None, use_graph=False)
+            self._trainer = DataParallelTrainer(self._model, None, use_graph=False, check_every_step=True)
         if 'eval' in required_grahps:                                                             # lm.py:371-375: TrainingHelper, mode != 'train'
             self._eval_cfg = ModelConfig(use_dropout=False, sampling_probability=0.0, **common)
             self._eval_model = Seq2SeqModel(self._eval_cfg, seed=kwargs.get('seed', 0))

@@ -22,7 +22,7 @@ import torch
 
 
 class DataParallelTrainer:
-    def __init__(self, model, dist=None, use_graph=True, sync_bn=True, force_collectives=False):
+    def __init__(self, model, dist=None, use_graph=True, sync_bn=True, force_collectives=False, check_every_step=False):
         self.model, self.dist = model, dist
         self.world = dist.get_world_size() if dist is not None else 1
         # force_collectives: issue every collective even at world size 1 (exercises the RCCL path on a single-GPU box)
@@ -31,6 +31,9 @@ class DataParallelTrainer:
         self.mode = "eager"
         self._graphs = {}
         self._checked = False
+        # eager mode only: read the persistent kernels' sticky "wait expired" flag before EVERY update (one small host sync per
+        # step) and redo the pass through the per-step launches if it is set; off by default (first step only) for benchmarking
+        self.check_every_step = bool(check_every_step)
         self._static = {}
         model.au_scale = 1.0 / self.world
         self.sync_bn = bool(sync_bn and self.collective and getattr(model, "bn_sync_enable", None) and model.bn_sync_enable())
@@ -119,7 +122,7 @@ class DataParallelTrainer:
                 dist.all_reduce(m.bn_sync_squares(batch))
         if not self.use_graph:
             self._fwd_bwd(batch)
-            if not self._checked:                      # first step: make sure the persistent kernels were co-resident
+            if not self._checked or self.check_every_step:   # make sure the persistent kernels were co-resident
                 self._checked = True
                 if self._persistent_failed():
                     self._fwd_bwd(batch)
