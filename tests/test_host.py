@@ -107,6 +107,28 @@ def test_config_validation_errors_follow_the_reference():
         ModelConfig(architecture="bimodal", video_units=(256,), cell_type="gru").validate()   # decoder_bimodal.py:130-142
     ModelConfig(cell_type="gru").validate()
     ModelConfig(architecture="bimodal", video_units=(256,)).validate()
+    # the non-default options built this round, and the combinations the reference's graph construction would reject
+    with pytest.raises(ValueError, match="Unknown loss function"):
+        ModelConfig(loss_fun="hinge").validate()                                          # seq2seq.py:163
+    with pytest.raises(Exception, match="Unsupported optimiser"):
+        ModelConfig(optimiser="SGD").validate()                                           # seq2seq.py:218
+    with pytest.raises(ValueError, match="residual_encoder needs equal layer widths"):
+        ModelConfig(residual_encoder=True, audio_units=(128, 256)).validate()
+    with pytest.raises(ValueError, match="attention-wrapped top layer"):
+        ModelConfig(architecture="av_align", video_units=(64,), audio_units=(64, 64), residual_encoder=True).validate()
+    with pytest.raises(ValueError, match="encoder_weight_sharing"):
+        ModelConfig(encoder_weight_sharing=True, audio_units=(128, 256, 256)).validate()
+    with pytest.raises(NotImplementedError):
+        ModelConfig(decoder_units=(256, 128)).validate()                                   # multi-layer decoders: equal widths only
+    with pytest.raises(NotImplementedError):
+        ModelConfig(decoder_units=(256, 256), cell_type="gru").validate()
+    with pytest.raises(ValueError, match="no encoders"):
+        ModelConfig(architecture="lm").validate()                                          # default audio_units is set
+    for ok in (dict(architecture="lm", video_units=None, audio_units=None), dict(decoder_units=(256, 256, 256)),
+               dict(residual_encoder=True), dict(encoder_weight_sharing=True), dict(instance_normalisation=True),
+               dict(optimiser="AdamW"), dict(loss_fun="focal_loss"), dict(label_smoothing=0.1), dict(lr_decay_steps=1000),
+               dict(input_dense_layers=(128, 64))):
+        ModelConfig(**ok).validate()
 
 
 def test_product_never_imports_the_oracle():
