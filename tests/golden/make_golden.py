@@ -27,6 +27,12 @@ CASES = {
     "av_align": dict(architecture="av_align", video_units=(16,), audio_units=(16, 16), regress_aus=True),
     "video_bi_normed": dict(architecture="unimodal", encoder_type="bidirectional", video_units=(16,), audio_units=None,
                             attention_type=(("normed_bahdanau",), ("normed_bahdanau",))),
+    # options added later in round 1: multi-layer decoder, residual + instance norm + Dense inputs, weight sharing, focal loss
+    "bimodal_dec2": dict(architecture="bimodal", video_units=(16,), audio_units=(16, 16), decoder_units=(16, 16)),
+    "audio_residual_instnorm_dense": dict(architecture="unimodal", video_units=None, audio_units=(16, 16, 16), residual_encoder=True,
+                                          instance_normalisation=True, input_dense_layers=(16,)),
+    "audio_shared_focal": dict(architecture="unimodal", video_units=None, audio_units=(16, 16, 16, 16), encoder_weight_sharing=True,
+                               loss_fun="focal_loss", optimiser="Nadam"),
 }
 COMMON = dict(decoder_units=(16,), embedding_size=8, video_feat=8, audio_feat=12)
 
@@ -34,7 +40,7 @@ COMMON = dict(decoder_units=(16,), embedding_size=8, video_feat=8, audio_feat=12
 def oracle_fixtures():
     from oracle import avsr_oracle as O
     for name, kw in CASES.items():
-        cfg = O.OracleConfig(**COMMON, **kw)
+        cfg = O.OracleConfig(**dict(COMMON, **kw))
         W = O.init_params(cfg, seed=2001)
         rng = np.random.default_rng(11)
         for k in W:
