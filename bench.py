@@ -199,7 +199,9 @@ def main():
     batch = Batch.from_numpy(NS(synth(cfg, B, rank)))
 
     trace("model built")
-    for _ in range(max(1, args.warmup)):
+    # the first step runs eagerly and captures the graphs, the second is the first replay (one-time upload of the executable
+    # graph): both always stay outside the timed region, whatever --warmup says
+    for _ in range(max(2, args.warmup) if not args.no_graph else max(1, args.warmup)):
         trainer.train_step(batch)
         trace("warm-up step done")
     torch.cuda.synchronize()
