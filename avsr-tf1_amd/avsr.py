@@ -94,8 +94,7 @@ class AVSR(object):
         self._max_sentence_length = max_sentence_length
         self._required_graphs = required_grahps
 
-        for name, val, ok in (("highway_encoder", highway_encoder, False),
-                              ("precision", precision, 'float32')):
+        for name, val, ok in (("precision", precision, 'float32'),):
             if val != ok:
                 raise NotImplementedError("%s=%r is a non-default option of the reference that the HIP engine does not build" % (name, val))
         lr_decay_steps = 0
@@ -153,7 +152,7 @@ class AVSR(object):
             sampling_probability=sampling_probability_outputs,
             video_processing=video_processing if video_processing is not None else 'features',
             cnn_filters=tuple(cnn_filters), cnn_dense_units=cnn_dense_units, video_hw=video_hw,
-            input_dense_layers=tuple(input_dense_layers), encoder_weight_sharing=bool(encoder_weight_sharing), residual_encoder=bool(residual_encoder), instance_normalisation=bool(instance_normalisation))
+            input_dense_layers=tuple(input_dense_layers), encoder_weight_sharing=bool(encoder_weight_sharing), residual_encoder=bool(residual_encoder), highway_encoder=bool(highway_encoder), instance_normalisation=bool(instance_normalisation))
         self._model = Seq2SeqModel(self._cfg, seed=kwargs.get('seed', 0))
         self._shuffle_seed = kwargs.get('shuffle_seed')        # None = a fresh order every run, as tf.data's unseeded shuffle(5000)
         self._trainer = DataParallelTrainer(self._model, None, use_graph=False, check_every_step=True)   # bucketed batches: shapes vary per step

@@ -57,6 +57,7 @@ class ModelConfig:
     input_dense_layers: Tuple[int, ...] = (0,)                      # avsr/avsr.py:38, encoder.py:148-171
     encoder_weight_sharing: bool = False                            # cells.py:77: encoder layers >= 2 reuse layer 1's cell
     instance_normalisation: bool = False                            # encoder.py:51-55: instance_norm after the batch norm
+    highway_encoder: bool = False                                   # cells.py:89-90: HighwayWrapper on encoder layers > 0 (wins over residual)
     residual_encoder: bool = False                                  # cells.py:91-92: ResidualWrapper on encoder layers > 0
 
     # -- same helpers/validation rules as the reference wiring (error types as in the reference) --
@@ -139,7 +140,10 @@ class ModelConfig:
         self.loss_code()
         if self.optimiser not in ("Adam", "Nadam", "AdamW", "Momentum"):
             raise Exception('Unsupported optimiser, try Adam')                            # seq2seq.py:218
-        if self.residual_encoder:
+        if self.highway_encoder:
+            if self.cell_type != "lstm" or self.encoder_weight_sharing:
+                raise NotImplementedError("highway_encoder: LSTM cells without weight sharing only")
+        if self.residual_encoder or self.highway_encoder:
             for st in self.streams():
                 if len(set(self.units(st))) != 1:
                     raise ValueError("residual_encoder needs equal layer widths")

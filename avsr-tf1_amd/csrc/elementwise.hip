@@ -502,6 +502,47 @@ __global__ void adam_kernel(float* p, float* g, float* m, float* v, long n, cons
 }
 __global__ void step_inc_kernel(int32_t* step) { step[0] += 1; }
 
+// ---------------------------------------------------------------------------------------------
+// tf.contrib.rnn.HighwayWrapper around an encoder cell (cells.py:89-90), applied per layer over the whole sequence:
+//   carry = sigmoid(cpre),  y = x * carry + h * (1 - carry)  for t < len[b], 0 past the utterance (dynamic_rnn zero-fills)
+// x = the layer's raw input, h = the (dropout-wrapped) cell output, cpre = x W_c + b_c.  All operands are row views [B*T, H].
+struct HwView { float* p; long ld; int T; long ldo; };
+__device__ __forceinline__ long hw_off(const HwView& v, int r) { return rowoff(r, v.ld, v.T, v.ldo); }
+
+__global__ void highway_fwd_kernel(HwView x, HwView h, HwView cpre, HwView y, const int32_t* len, int rows, int H, int T) {
+  const long total = (long)rows * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / H), c = (int)(i % H);
+    float out = 0.f;
+    if (!len || (r % T) < len[r / T]) {
+      const float g = 1.f / (1.f + expf(-cpre.p[hw_off(cpre, r) + c]));
+      out = x.p[hw_off(x, r) + c] * g + h.p[hw_off(h, r) + c] * (1.f - g);
+    }
+    y.p[hw_off(y, r) + c] = out;
+  }
+}
+
+// dh = dy (1 - carry);  dcpre = dy (x - h) carry (1 - carry);  dx (+)= dy carry      (zero past the utterance)
+__global__ void highway_bwd_kernel(HwView x, HwView h, HwView cpre, HwView dy, HwView dh, HwView dcpre, HwView dx, const int32_t* len,
+                                   int rows, int H, int T, int accumulate_dx) {
+  const long total = (long)rows * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / H), c = (int)(i % H);
+    float vdh = 0.f, vdc = 0.f, vdx = 0.f;
+    if (!len || (r % T) < len[r / T]) {
+      const float g = 1.f / (1.f + expf(-cpre.p[hw_off(cpre, r) + c]));
+      const float d = dy.p[hw_off(dy, r) + c];
+      vdh = d * (1.f - g);
+      vdc = d * (x.p[hw_off(x, r) + c] - h.p[hw_off(h, r) + c]) * g * (1.f - g);
+      vdx = d * g;
+    }
+    dh.p[hw_off(dh, r) + c] = vdh;
+    dcpre.p[hw_off(dcpre, r) + c] = vdc;
+    float* px = dx.p + hw_off(dx, r) + c;
+    *px = accumulate_dx ? *px + vdx : vdx;
+  }
+}
+
 static inline int blocks_for(long n, int per = 256, int cap = 2048) {
   long b = (n + per - 1) / per;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -733,6 +774,28 @@ extern "C" int avsr_seq_loss_fun(float* logits, const int32_t* labels, const int
   }
   hipLaunchKernelGGL(seq_loss_kernel, dim3((B * L + 127) / 128), dim3(128), 0, S_(stream), logits, labels, labels_len,
                      denom, row_loss, dlogits, B, L, V, loss_fun, label_smoothing);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+static inline avsr::HwView hwv(const avsr_mat* m) { return avsr::HwView{m->ptr, (long)m->ld, m->T, (long)m->ldo}; }
+
+extern "C" int avsr_highway_fwd(const avsr_mat* x, const avsr_mat* h, const avsr_mat* carry_pre, const avsr_mat* y, const int32_t* len,
+                                int32_t B, int32_t T, int32_t H, void* stream) {
+  if (!x || !h || !carry_pre || !y || !x->ptr || !h->ptr || !carry_pre->ptr || !y->ptr || B <= 0 || T <= 0 || H <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(highway_fwd_kernel, dim3(blocks_for((long)B * T * H)), dim3(256), 0, S_(stream), hwv(x), hwv(h), hwv(carry_pre), hwv(y),
+                     len, B * T, H, T);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_highway_bwd(const avsr_mat* x, const avsr_mat* h, const avsr_mat* carry_pre, const avsr_mat* dy, const avsr_mat* dh,
+                                const avsr_mat* dcarry_pre, const avsr_mat* dx, const int32_t* len, int32_t B, int32_t T, int32_t H,
+                                int32_t accumulate_dx, void* stream) {
+  if (!x || !h || !carry_pre || !dy || !dh || !dcarry_pre || !dx || !x->ptr || !h->ptr || !carry_pre->ptr || !dy->ptr || !dh->ptr ||
+      !dcarry_pre->ptr || !dx->ptr || B <= 0 || T <= 0 || H <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(highway_bwd_kernel, dim3(blocks_for((long)B * T * H)), dim3(256), 0, S_(stream), hwv(x), hwv(h), hwv(carry_pre), hwv(dy),
+                     hwv(dh), hwv(dcarry_pre), hwv(dx), len, B * T, H, T, accumulate_dx);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

@@ -244,11 +244,20 @@ class Seq2SeqModel:
                         Ld["dout"] = SeqBuf(B, T, u, 1, 1, dev) if (attentive and l == nplain - 1) else None
                     if self.gru:
                         Ld["rh"], Ld["dpc"] = z(B, T, u), z(B, T, u)
-                    if cfg.use_dropout or (cfg.residual_encoder and l > 0):
+                    if cfg.use_dropout or (cfg.residual_encoder and not cfg.highway_encoder and l > 0):
                         Ld["hs_seq"] = SeqBuf(B, T, u, 1, 1, dev)   # the recurrent h as consumed (residual: the output record holds h + x)
                     if cfg.use_dropout:
                         if not top or attentive:
                             Ld["xt_seq"] = SeqBuf(B, T, u, 1, 1, dev)
+                    if cfg.highway_encoder:
+                        # HighwayWrapper stacks run layer by layer (every input projection hoisted): `out` is the layer's emitted
+                        # (highway) output, `hout` the cell's own output, `dy` / `dhout` their gradients, cpre the carry pre-activation
+                        Ld["dy"] = E["dmem"] if top else SeqBuf(B, T, u, 1, 1, dev)
+                        if l > 0:
+                            Ld.update(hout=SeqBuf(B, T, u, 1, 1, dev), dhout=SeqBuf(B, T, u, 1, 1, dev), cpre=z(B * T, u), dcpre=z(B * T, u),
+                                      dxtmp=z(B * T, u))
+                            if cfg.use_dropout:
+                                Ld["xd"] = z(B * T, u)
                     E["layers"][(d, l)] = Ld
             H = cfg.decoder_units[0]
             E["c_dec"], E["h_dec"], E["dc_dec"], E["dh_dec"] = z(B, H), z(B, H), z(B, H), z(B, H)
@@ -376,7 +385,7 @@ class Seq2SeqModel:
             Ly.out, Ly.ld_out = ops.fptr(Ld["out"].t), Ld["out"].D
             Ly.state, Ly.h_final, Ly.c_final = ops.fptr(Ld["state"]), ops.fptr(Ld["hf"]), ops.fptr(Ld["cf"])
             Ly.dgates, Ly.dstate = ops.fptr(Ld["dgates"]), ops.fptr(Ld["dstate"])
-            Ly.residual = int(cfg.residual_encoder and l > 0)
+            Ly.residual = int(cfg.residual_encoder and not cfg.highway_encoder and l > 0)
             if drop or Ly.residual:
                 Ly.hs_seq = ops.fptr(Ld["hs_seq"].t)
             if drop:
@@ -389,6 +398,142 @@ class Seq2SeqModel:
             top = E["layers"][(d, E["nplain"] - 1)]
             st.dh_final, st.dc_final = ops.fptr(top["dhf"]), (None if self.gru else ops.fptr(top["dcf"]))
         return st
+
+    # ---- HighwayWrapper encoders (cells.py:89-90): layer-by-layer execution with every input projection hoisted ----
+    def _rnn_stack_single(self, ws, s, d, l, B, len_t, backward=False):
+        """One-layer stack descriptor for layer l of (stream, direction): input projection already in `gates`, cell output into
+        `hout` (layer 0: straight into `out`), external output gradient from `dhout` (layer 0: `dy`)."""
+        cfg = self.cfg
+        E = ws["enc"][s]
+        Ld = E["layers"][(d, l)]
+        u = E["units"][l]
+        st = RnnStack()
+        st.B, st.T, st.reverse, st.n_layers, st.cell = B, E["T"], int(d == "bw"), 1, 0
+        st.len = ops.fptr(len_t)
+        drop = self._sdrop(s)
+        if drop:
+            st.seed = ops.fptr(self.step)
+            st.keep_in, st.keep_state, st.keep_out = self._keeps(s)
+            st.cell_id_base = encoder_cell_id(s, d, l)
+        name, bname = self._kn(f"{s}/enc/{d}/l{l}")
+        Ly = st.layer[0]
+        Ly.units, Ly.in_dim, Ly.hoisted = u, (E["F0"] if l == 0 else u), 1
+        Ly.wt, Ly.w = ops.fptr(self.derived, self.Tr[name].off), ops.fptr(self.params, self.P[name].off)
+        Ly.bias = ops.fptr(self.params, self.P[bname].off)
+        Ly.gates, Ly.cs = ops.fptr(Ld["gates"]), ops.fptr(Ld["cs"])
+        if l == 0:
+            Ly.out, Ly.ld_out, Ly.out_col = ops.fptr(Ld["out"].t), Ld["out"].D, Ld["col"]
+        else:
+            Ly.out, Ly.ld_out, Ly.out_col = ops.fptr(Ld["hout"].t), u, 0
+        Ly.state, Ly.h_final, Ly.c_final = ops.fptr(Ld["state"]), ops.fptr(Ld["hf"]), ops.fptr(Ld["cf"])
+        Ly.dgates, Ly.dstate = ops.fptr(Ld["dgates"]), ops.fptr(Ld["dstate"])
+        if drop:
+            Ly.hs_seq = ops.fptr(Ld["hs_seq"].t)
+        if backward:
+            if l == 0:
+                Ly.dout, Ly.ld_dout, Ly.dout_col = ops.fptr(Ld["dy"].t), Ld["dy"].D, Ld["col"]
+            else:
+                Ly.dout, Ly.ld_dout, Ly.dout_col = ops.fptr(Ld["dhout"].t), u, 0
+            if l == E["nplain"] - 1 and not E["attentive"]:
+                st.dh_final, st.dc_final = ops.fptr(Ld["dhf"]), ops.fptr(Ld["dcf"])
+        return st
+
+    def _highway_x(self, E, d, l):
+        """Row view of layer l's RAW input (what the HighwayWrapper carries through): the emitted output of the layer below."""
+        Lo = E["layers"][(d, l - 1)]
+        return Lo["out"].mat(0, Lo["col"])
+
+    def _encode_highway(self, ws, B):
+        cfg = self.cfg
+        nmax = max(ws["enc"][s]["nplain"] for s in cfg.streams())
+        for l in range(nmax):
+            stacks = []
+            for s in cfg.streams():
+                E = ws["enc"][s]
+                if l >= E["nplain"]:
+                    continue
+                T, u, F0 = E["T"], E["units"][l], E["F0"]
+                for d in cfg.directions():
+                    Ld = E["layers"][(d, l)]
+                    in_w = F0 if l == 0 else u
+                    x = ops.mat(E["xin0"], F0) if l == 0 else self._highway_x(E, d, l)
+                    xin = x
+                    if self._sdrop(s):           # DropoutWrapper input mask of this cell
+                        xin = ops.mat(E["xd"][d] if l == 0 else Ld["xd"], in_w)
+                        ops.dropout_rows(x, xin, B * T, in_w, self.step, encoder_cell_id(s, d, l) * 4, self._keeps(s)[0], in_w)
+                    Wk = self.P[self._kn(f"{s}/enc/{d}/l{l}")[0]]
+                    ops.gemm(xin, Wk.mat(4 * u), ops.mat(Ld["gates"], 4 * u), B * T, 4 * u, in_w)
+                    stacks.append(self._rnn_stack_single(ws, s, d, l, B, E["len"]))
+            self._run_stacks(stacks, ops.rnn_fwd)
+            if l == 0:
+                continue
+            for s in cfg.streams():
+                E = ws["enc"][s]
+                if l >= E["nplain"]:
+                    continue
+                T, u = E["T"], E["units"][l]
+                for d in cfg.directions():
+                    Ld = E["layers"][(d, l)]
+                    x = self._highway_x(E, d, l)
+                    pre = f"{s}/enc/{d}/l{l}"
+                    ops.gemm(x, self.P[pre + "/carry_w"].mat(u), ops.mat(Ld["cpre"], u), B * T, u, u, bias=self._pp(pre + "/carry_b"))
+                    ops.highway_fwd(x, Ld["hout"].mat(0), ops.mat(Ld["cpre"], u, T=T, ldo=T * u), Ld["out"].mat(0, Ld["col"]), E["len"], B, T, u)
+
+    def _encode_highway_backward(self, ws, B):
+        """Top-down, layer by layer: highway gate backward, one-layer BPTT, weight gradients, input gradient into the layer below."""
+        cfg = self.cfg
+        nmax = max(ws["enc"][s]["nplain"] for s in cfg.streams())
+        for l in reversed(range(nmax)):
+            stacks = []
+            for s in cfg.streams():
+                E = ws["enc"][s]
+                if l >= E["nplain"]:
+                    continue
+                T, u = E["T"], E["units"][l]
+                for d in cfg.directions():
+                    Ld = E["layers"][(d, l)]
+                    if l > 0:
+                        Lo = E["layers"][(d, l - 1)]
+                        x, pre = self._highway_x(E, d, l), f"{s}/enc/{d}/l{l}"
+                        cp, dcp = ops.mat(Ld["cpre"], u, T=T, ldo=T * u), ops.mat(Ld["dcpre"], u, T=T, ldo=T * u)
+                        dy_below = Lo["dy"].mat(0, Lo["col"])
+                        # bidirectional top layers write into column halves of one memory gradient: never accumulate across directions here
+                        ops.highway_bwd(x, Ld["hout"].mat(0), cp, Ld["dy"].mat(0, Ld["col"]), Ld["dhout"].mat(0), dcp, dy_below, E["len"], B, T, u,
+                                        accumulate_dx=False)
+                        self._gemm_tn(x, ops.mat(Ld["dcpre"], u), self.Gr[pre + "/carry_w"].mat(u), u, u, B * T)
+                        ops.colsum(ops.mat(Ld["dcpre"], u), B * T, u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[pre + "/carry_b"].off)
+                        ops.gemm(ops.mat(Ld["dcpre"], u), self.P[pre + "/carry_w"].mat(u), dy_below, B * T, u, u, trans_b=1, beta=1.0)
+                    stacks.append(self._rnn_stack_single(ws, s, d, l, B, E["len"], backward=True))
+            self._run_stacks(stacks, ops.rnn_bwd)
+            for s in cfg.streams():
+                E = ws["enc"][s]
+                if l >= E["nplain"]:
+                    continue
+                T, u, F0 = E["T"], E["units"][l], E["F0"]
+                drop = self._sdrop(s)
+                for d in cfg.directions():
+                    Ld = E["layers"][(d, l)]
+                    kname, bname = self._kn(f"{s}/enc/{d}/l{l}")
+                    Gk, dg = self.Gr[kname], ops.mat(Ld["dgates"], 4 * u)
+                    in_w = F0 if l == 0 else u
+                    if l == 0:
+                        a_x = ops.mat(E["xd"][d] if drop else E["xin0"], F0)
+                    else:
+                        a_x = ops.mat(Ld["xd"], u) if drop else self._highway_x(E, d, l)
+                    self._gemm_tn(a_x, dg, Gk.mat(4 * u), in_w, 4 * u, B * T)
+                    sh = 1 if d == "bw" else -1
+                    hrec = Ld["hs_seq"].mat(sh) if drop else (Ld["out"].mat(sh, Ld["col"]) if l == 0 else Ld["hout"].mat(sh))
+                    self._gemm_tn(hrec, dg, Gk.mat(4 * u, row0=in_w), u, 4 * u, B * T)
+                    ops.colsum(dg, B * T, 4 * u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
+                    if l > 0:                    # gradient of the cell's (masked) input -> the layer below's emitted output
+                        Lo = E["layers"][(d, l - 1)]
+                        dy_below = Lo["dy"].mat(0, Lo["col"])
+                        if drop:
+                            ops.gemm(dg, self.P[kname].mat(4 * u), ops.mat(Ld["dxtmp"], u), B * T, u, 4 * u, trans_b=1)
+                            ops.dropout_rows(ops.mat(Ld["dxtmp"], u), dy_below, B * T, u, self.step, encoder_cell_id(s, d, l) * 4,
+                                             self._keeps(s)[0], u, accumulate=True)
+                        else:
+                            ops.gemm(dg, self.P[kname].mat(4 * u), dy_below, B * T, u, 4 * u, trans_b=1, beta=1.0)
 
     # ---- sync batch-norm of the encoder inputs across data-parallel ranks (SURVEY 8(e) collective (3)) ----
     def bn_sync_enable(self):
@@ -479,7 +624,7 @@ class Seq2SeqModel:
                     ops.selu(Dn["z"], Dn["a"], B * T * u)
                     a_prev, w_prev = Dn["a"], u
                 E["xin0"], E["dxin0"] = a_prev, E["dense"][-1]["da"]
-            if E["nplain"] == 0:
+            if E["nplain"] == 0 or cfg.highway_encoder:
                 continue
             for d in cfg.directions():
                 u0 = E["units"][0]
@@ -495,6 +640,8 @@ class Seq2SeqModel:
                     ops.gemm(ops.mat(xin, F0), self.P[f"{s}/enc/{d}/l0/cand_kernel"].mat(u0), ops.mat(E["layers"][(d, 0)]["cs"], u0), B * T, u0, F0)
                 stacks.append(self._rnn_stack(ws, s, d, B, len_t))
         self._run_stacks(stacks, ops.rnn_fwd)
+        if cfg.highway_encoder:
+            self._encode_highway(ws, B)
         for s in cfg.streams():
             E = ws["enc"][s]
             if E["attentive"]:
@@ -595,18 +742,20 @@ class Seq2SeqModel:
         stacks = []
         for s in cfg.streams():
             E = ws["enc"][s]
-            if E["nplain"] == 0:
+            if E["nplain"] == 0 or cfg.highway_encoder:
                 continue
             for d in cfg.directions():
                 stacks.append(self._rnn_stack(ws, s, d, B, E["len"], backward=True))
         self._run_stacks(stacks, ops.rnn_bwd)
+        if cfg.highway_encoder:
+            self._encode_highway_backward(ws, B)
         for s in cfg.streams():
             E = ws["enc"][s]
             T, F, F0 = E["T"], E["F"], E["F0"]
             first = True
             for d in cfg.directions():
                 i = F0
-                for l in range(E["nplain"]):
+                for l in range(0 if cfg.highway_encoder else E["nplain"]):
                     u = E["units"][l]
                     Ld = E["layers"][(d, l)]
                     kname, bname = self._kn(f"{s}/enc/{d}/l{cfg.shared_layer(l)}")

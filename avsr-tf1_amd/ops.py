@@ -211,6 +211,15 @@ def seq_loss_per_utterance(row_loss, labels_len, denom, out, B, L):
           "avsr_seq_loss_per_utterance")
 
 
+def highway_fwd(x, h, cpre, y, lens, B, T, H):
+    check(_L().avsr_highway_fwd(C.byref(x), C.byref(h), C.byref(cpre), C.byref(y), fptr(lens), B, T, H, _s()), "avsr_highway_fwd")
+
+
+def highway_bwd(x, h, cpre, dy, dh, dcpre, dx, lens, B, T, H, accumulate_dx=False):
+    check(_L().avsr_highway_bwd(C.byref(x), C.byref(h), C.byref(cpre), C.byref(dy), C.byref(dh), C.byref(dcpre), C.byref(dx), fptr(lens),
+                                B, T, H, int(accumulate_dx), _s()), "avsr_highway_bwd")
+
+
 def instnorm_fwd(x, y, B, T, F, gamma, beta, mean_out, invstd_out, eps=1e-6):
     check(_L().avsr_instnorm_fwd(fptr(x), fptr(y), B, T, F, fptr(gamma), fptr(beta), fptr(mean_out), fptr(invstd_out), float(eps), _s()),
           "avsr_instnorm_fwd")

@@ -452,6 +452,15 @@ int avsr_instnorm_fwd(const float* x, float* y, int32_t B, int32_t T, int32_t F,
                       float* mean_out, float* invstd_out, float eps, void* stream);
 int avsr_instnorm_bwd(const float* x, const float* dy, const float* gamma, const float* mean, const float* invstd, float* dx,
                       float* dgamma_part, float* dbeta_part, int32_t B, int32_t T, int32_t F, void* stream);
+/* tf.contrib.rnn.HighwayWrapper around an encoder cell (`highway_encoder=True`, avsr/cells.py:89-90), applied to a whole layer:
+ * carry = sigmoid(carry_pre), y = x * carry + h * (1 - carry) for t < len[b], zero past the utterance.  x = the layer's raw
+ * input, h = the cell's emitted output, carry_pre = x W_c + b_c (avsr_gemm).  Operands are [B*T, H] row views (avsr_mat with
+ * T = rows per utterance).  Backward: dh = dy (1 - carry), dcarry_pre = dy (x - h) carry (1 - carry), dx (+)= dy carry. */
+int avsr_highway_fwd(const avsr_mat* x, const avsr_mat* h, const avsr_mat* carry_pre, const avsr_mat* y, const int32_t* len,
+                     int32_t B, int32_t T, int32_t H, void* stream);
+int avsr_highway_bwd(const avsr_mat* x, const avsr_mat* h, const avsr_mat* carry_pre, const avsr_mat* dy, const avsr_mat* dh,
+                     const avsr_mat* dcarry_pre, const avsr_mat* dx, const int32_t* len, int32_t B, int32_t T, int32_t H,
+                     int32_t accumulate_dx, void* stream);
 /* AU regression loss (avsr/encoder.py:173-189); z = pre-sigmoid Dense(2) outputs [B][T][2]. */
 int avsr_au_loss(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz, int32_t B, int32_t T,
                  float weight, void* stream);

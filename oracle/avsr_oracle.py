@@ -64,6 +64,7 @@ class OracleConfig:
     encoder_weight_sharing: bool = False      # avsr.py:49, cells.py:77
     instance_normalisation: bool = False      # avsr.py:37, encoder.py:51-55: contrib.layers.instance_norm after the batch norm
     residual_encoder: bool = False            # avsr.py:42, cells.py:91-92: ResidualWrapper on encoder layers > 0
+    highway_encoder: bool = False             # avsr.py:41, cells.py:89-90: HighwayWrapper on encoder layers > 0 (wins over residual)
     optimiser: str = "Adam"                   # Adam | Nadam | AdamW | Momentum (seq2seq.py:195-218)
     weight_decay: float = 1e-4                # AdamW only (avsr.py:45)
     loss_fun: Optional[str] = None            # None | 'focal_loss' | 'mc_loss'  (seq2seq.py:147-163, devel.py)
@@ -153,7 +154,7 @@ class OracleConfig:
                 raise ValueError("AttentiveEncoder implements only unidirectional")  # encoder.py:229
             if self.video_units is None or self.audio_units is None:
                 raise ValueError("av_align needs both streams")
-        if self.residual_encoder:
+        if self.residual_encoder or self.highway_encoder:
             for st in self.streams():
                 u = self.video_units if st == "video" else self.audio_units
                 if len(set(u)) != 1:
@@ -161,7 +162,9 @@ class OracleConfig:
                 if self.architecture == "av_align" and st == "audio" and len(u) > 1:
                     raise ValueError("residual_encoder: the attention-wrapped top layer cannot be residual (input and output widths differ)")
             if self.cell_type != "lstm":
-                raise NotImplementedError("residual_encoder: LSTM cells only")
+                raise NotImplementedError("residual_encoder / highway_encoder: LSTM cells only")
+            if self.highway_encoder and self.encoder_weight_sharing:
+                raise NotImplementedError("highway_encoder with encoder_weight_sharing")
         if len(set(self.decoder_units)) != 1:
             raise NotImplementedError("multi-layer decoders: equal layer widths only")
         if len(self.decoder_units) > 1 and self.cell_type != "lstm":
@@ -334,6 +337,9 @@ def init_params(cfg: OracleConfig, seed: int = 2001) -> Dict[str, np.ndarray]:
                 extra = units[-1] if (attentive and l == len(units) - 1) else 0   # + attention feedback
                 if not (cfg.encoder_weight_sharing and l > 1):                     # shared layers own no variables
                     _cell_params(rng, cfg, f"{stream}/enc/{d}/l{l}", in_dim + extra, u, P)
+                if cfg.highway_encoder and l > 0 and not extra:                    # HighwayWrapper's carry gate over the layer input
+                    P[f"{stream}/enc/{d}/l{l}/carry_w"] = _glorot_uniform(rng, (in_dim, in_dim))
+                    P[f"{stream}/enc/{d}/l{l}/carry_b"] = np.ones((in_dim,), np.float32)
                 in_dim = u
         if attentive:
             _attention_params(rng, "audio/enc/att0", cfg.attention_type[0][0],
@@ -671,13 +677,27 @@ def _map_state(fn, new, old):
     return tuple(_map_state(fn, n, o) for n, o in zip(new, old))
 
 
-def _stack_step(cells: List[_Cell], residual: bool = False):
-    """MultiRNNCell step; residual: ResidualWrapper around every cell but the first (cells.py:89-92): output + raw input."""
+def _wrap_output(cfg, P, prefix: str, l: int, x: Tensor, y: Tensor) -> Tensor:
+    """cells.py:89-92 for layer l > 0: HighwayWrapper (tf.contrib.rnn.HighwayWrapper defaults: coupled gates, carry bias init 1.0:
+    carry = sigmoid(x W_c + b_c); out = x * carry + y * (1 - carry)) takes precedence over ResidualWrapper (out = y + x).
+    x is the layer's RAW input, y the (dropout-wrapped) cell's output.  (rnn_cell.py of TF r1.13, recalled.)"""
+    if l == 0:
+        return y
+    if cfg.highway_encoder:
+        carry = torch.sigmoid(x @ P[f"{prefix}/l{l}/carry_w"] + P[f"{prefix}/l{l}/carry_b"])
+        return x * carry + y * (1.0 - carry)
+    if cfg.residual_encoder:
+        return y + x
+    return y
+
+
+def _stack_step(cells: List[_Cell], cfg=None, P=None, prefix: str = ""):
+    """MultiRNNCell step with the optional Highway / Residual wrappers around every cell but the first."""
     def step(x, states, t=0):
         new_states = []
         for l, (c, s) in enumerate(zip(cells, states)):
             y, ns = c(x, s, t)
-            x = y + x if (residual and l > 0) else y
+            x = _wrap_output(cfg, P, prefix, l, x, y) if cfg is not None else y
             new_states.append(ns)
         return x, tuple(new_states)
     return step
@@ -730,7 +750,7 @@ def encode_stream(P, cfg: OracleConfig, stream: str, x: Tensor, lens: Tensor, tr
             new_lower = []
             for l, (c, s) in enumerate(zip(cells[:-1], lower)):
                 y_t, ns = c(x_t, s, t)
-                x_t = y_t + x_t if (cfg.residual_encoder and l > 0) else y_t
+                x_t = _wrap_output(cfg, P, f"{stream}/enc/fw", l, x_t, y_t)
                 new_lower.append(ns)
             out, ns, new_att, al = attention_wrapper_step(cells[-1], [mech], out_att, x_t, top_state, att, t)
             aligns.append(al[0])
@@ -742,13 +762,13 @@ def encode_stream(P, cfg: OracleConfig, stream: str, x: Tensor, lens: Tensor, tr
         return EncoderOut(outs, st[1][0], torch.stack(aligns, dim=1))
     if cfg.encoder_type == "unidirectional":
         cells = _make_cells(P, cfg, stream, "fw", units, training, seed, T, lens)
-        outs, st = dynamic_rnn(_stack_step(cells, cfg.residual_encoder), tuple(c.zero_state(B, dtype) for c in cells), x, lens)
+        outs, st = dynamic_rnn(_stack_step(cells, cfg, P, f"{stream}/enc/fw"), tuple(c.zero_state(B, dtype) for c in cells), x, lens)
         return EncoderOut(outs, st[-1])
     # bidirectional: two independent stacks, concat at the top only (encoder.py:92-121)
     fw = _make_cells(P, cfg, stream, "fw", units, training, seed, T, lens)
     bw = _make_cells(P, cfg, stream, "bw", units, training, seed, T, lens)
-    o_fw, s_fw = dynamic_rnn(_stack_step(fw, cfg.residual_encoder), tuple(c.zero_state(B, dtype) for c in fw), x, lens)
-    o_bw, s_bw = dynamic_rnn(_stack_step(bw, cfg.residual_encoder), tuple(c.zero_state(B, dtype) for c in bw),
+    o_fw, s_fw = dynamic_rnn(_stack_step(fw, cfg, P, f"{stream}/enc/fw"), tuple(c.zero_state(B, dtype) for c in fw), x, lens)
+    o_bw, s_bw = dynamic_rnn(_stack_step(bw, cfg, P, f"{stream}/enc/bw"), tuple(c.zero_state(B, dtype) for c in bw),
                              _reverse_sequence(x, lens), lens)
     o_bw = _reverse_sequence(o_bw, lens)
     outs = torch.cat([o_fw, o_bw], dim=-1)

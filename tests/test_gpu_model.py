@@ -98,6 +98,13 @@ CASES = {
                       weight_decay=0.01, recurrent_l2=None),
     "opt_momentum": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,), optimiser="Momentum",
                          warmup_steps=0),
+    # highway_encoder (cells.py:89-90): HighwayWrapper on encoder layers > 0; those encoders run layer by layer with hoisted inputs
+    "highway_uni3": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32, 32),
+                         highway_encoder=True),
+    "highway_bimodal_bi": dict(architecture="bimodal", encoder_type="bidirectional", video_units=(16, 16), audio_units=(16, 16, 16),
+                               decoder_units=(32,), highway_encoder=True, regress_aus=True),
+    "highway_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32, 32), audio_units=(32,),
+                             highway_encoder=True, residual_encoder=True),
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
@@ -220,6 +227,8 @@ STOCH = [
     ("dec2_av_align", dict(use_dropout=True, sampling_probability=0.2)),
     ("dec2_lm", dict(use_dropout=True, sampling_probability=0.1)),
     ("residual_uni3", dict(use_dropout=True)),
+    ("highway_uni3", dict(use_dropout=True, sampling_probability=0.2)),
+    ("highway_bimodal_bi", dict(use_dropout=True, video_dropout=(0.8, 0.9, 0.7))),
     ("opt_nadam", dict(use_dropout=True)),
     ("opt_adamw", dict(use_dropout=True)),
     ("opt_momentum", dict(use_dropout=True)),

@@ -70,6 +70,8 @@ def _small(arch="bimodal", **kw):
                                             ("unimodal", "normed_bahdanau", {}),
                                             ("bimodal", "scaled_luong", dict(input_dense_layers=(6, 5))),    # encoder.py:148-171
                                             ("unimodal", "scaled_luong", dict(decoder_units=(8, 8))),        # MultiRNNCell decoder
+                                            ("unimodal", "bahdanau", dict(highway_encoder=True, audio_units=(8, 8, 8),
+                                                                          encoder_type="bidirectional")),
                                             ("bimodal", "scaled_luong", dict(instance_normalisation=True, residual_encoder=True,
                                                                              audio_units=(8, 8, 8))),
                                             ("bimodal", "bahdanau", dict(decoder_units=(8, 8, 8), encoder_weight_sharing=True,
@@ -86,7 +88,7 @@ def test_gradients_by_finite_differences(arch, att, extra):
     rng = np.random.default_rng(1)
     names = [k for k in O.trainable_names(W)]
     picked = [names[i] for i in rng.choice(len(names), size=min(8, len(names)), replace=False)]
-    for k in picked + [n for n in names if ("/dense" in n or "/in/" in n or n.startswith("dec/l")) and n not in picked]:
+    for k in picked + [n for n in names if ("/dense" in n or "/in/" in n or "carry" in n or n.startswith("dec/l")) and n not in picked]:
         idx = tuple(int(rng.integers(0, s)) for s in W[k].shape)
         eps = 1e-5
         Wp = {n: v.astype(np.float64).copy() for n, v in W.items()}
