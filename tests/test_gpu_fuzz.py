@@ -1,0 +1,91 @@
+"""Seeded random walks over the option space: every valid combination of the reference's model options must give the same train
+step and the same greedy ids on the HIP engine as on the CPU oracle.  Catches interactions the hand-picked cases miss
+(e.g. highway + input Dense + instance norm + bidirectional + dropout + multi-layer decoder + label smoothing)."""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ATT = ["luong", "scaled_luong", "bahdanau", "normed_bahdanau"]
+
+
+def _sample(rng):
+    from oracle import avsr_oracle as O
+    for _ in range(200):
+        arch = rng.choice(["unimodal", "unimodal", "bimodal", "av_align"])
+        cell = rng.choice(["lstm", "lstm", "gru"])
+        u = int(rng.choice([16, 32]))
+        na, nv = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+        kw = dict(architecture=arch, cell_type=cell, encoder_type=rng.choice(["unidirectional", "bidirectional"]),
+                  audio_units=(u,) * na, video_units=(u,) * nv if (arch != "unimodal" or rng.random() < 0.3) else None,
+                  decoder_units=(u,) * int(rng.choice([1, 1, 2, 3])), embedding_size=int(rng.choice([8, 16])),
+                  attention_type=((rng.choice(ATT),), (rng.choice(ATT),)), video_feat=12, audio_feat=20,
+                  batch_normalisation=bool(rng.random() < 0.7), instance_normalisation=bool(rng.random() < 0.3),
+                  input_dense_layers=(int(rng.choice([16, 24])),) if rng.random() < 0.3 else (0,),
+                  residual_encoder=bool(rng.random() < 0.25), highway_encoder=bool(rng.random() < 0.25),
+                  encoder_weight_sharing=bool(rng.random() < 0.2), enable_attention=bool(rng.random() < 0.9),
+                  regress_aus=bool(rng.random() < 0.4), use_dropout=bool(rng.random() < 0.5),
+                  sampling_probability=float(rng.choice([0.0, 0.0, 0.3])),
+                  loss_fun=rng.choice([None, None, None, "focal_loss", "mc_loss"]),
+                  label_smoothing=float(rng.choice([0.0, 0.0, 0.1])), optimiser=rng.choice(["Adam", "Adam", "Nadam", "AdamW", "Momentum"]),
+                  lr_decay_steps=int(rng.choice([0, 0, 7])), warmup_steps=int(rng.choice([0, 5, 750])),
+                  clip_gradients=bool(rng.random() < 0.8), recurrent_l2=rng.choice([None, 1e-4]))
+        if cell == "gru":                        # GRU: the options the reference (and the engine) restrict to LSTM are switched off
+            kw.update(residual_encoder=False, highway_encoder=False, decoder_units=(u,))
+            if arch == "bimodal":
+                kw["architecture"] = arch = "unimodal"
+        if kw["video_units"] is None and arch == "unimodal" and rng.random() < 0.2:
+            kw["audio_units"], kw["video_units"] = None, (u,) * nv
+        if kw["video_units"] is None:
+            kw["regress_aus"] = False
+        if kw["loss_fun"] is not None:
+            kw["label_smoothing"] = 0.0
+        try:
+            cfg = O.OracleConfig(**kw)
+            cfg.validate()
+            return cfg
+        except Exception:
+            continue
+    raise RuntimeError("no valid configuration sampled")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AVSR_FUZZ_N", "32"))))
+def test_random_configuration(seed):
+    from avsr_tf1_amd.config import ModelConfig
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    from oracle import avsr_oracle as O
+    rng = np.random.default_rng(1000 + seed)
+    ocfg = _sample(rng)
+    mcfg = ModelConfig(**{f.name: getattr(ocfg, f.name) for f in dataclasses.fields(ModelConfig) if hasattr(ocfg, f.name)})
+    mcfg.validate()
+    W = O.init_params(ocfg, seed=seed)
+    for k in W:
+        if k.endswith(("bias", "/b", "beta")):
+            W[k] = (rng.standard_normal(W[k].shape) * 0.1).astype(np.float32)
+    B, Ta, Tv, L = int(rng.integers(1, 7)), int(rng.integers(3, 24)), int(rng.integers(2, 10)), int(rng.integers(2, 8))
+    batch = O.synthetic_batch(ocfg, B=B, T_a=Ta, T_v=Tv, L=L, ragged=True)
+    r1 = O.train_step(W, None, ocfg, batch)
+    r2 = O.train_step(r1["params"], r1["opt"], ocfg, batch)
+    model = Seq2SeqModel(mcfg, weights=W)
+    db = Batch.from_numpy(batch)
+    logits = model.forward_train(db)
+    model.backward()
+    model.apply_update()
+    torch.cuda.synchronize()
+    desc = repr(ocfg)
+    assert np.abs(logits.cpu().numpy() - r1["logits"]).max() < 1e-4, desc
+    assert abs(float(model.loss.item()) - r1["loss"]) < 1e-4, desc
+    if ocfg.clip_gradients:
+        assert abs(float(model.gnorm.item()) - r1["global_norm"]) < 1e-4 * max(1.0, r1["global_norm"]), desc
+    grads = model.export_tf_weights("grads")
+    for k, g in r1["grads"].items():
+        scale = max(1e-3, np.abs(g).max())
+        assert np.abs(grads[k] - g).max() < 2e-4 * scale + 1e-6, (k, desc)
+    loss2, _ = model.train_step(db)
+    torch.cuda.synchronize()
+    assert abs(float(loss2.item()) - r2["loss"]) < 3e-4, desc
+    ids_ref = O.greedy_decode(r2["params"], ocfg, batch, max_steps=6)
+    assert (model.greedy_decode(db, max_steps=6).cpu().numpy() == ids_ref).all(), desc
