@@ -89,3 +89,11 @@ def test_random_configuration(seed):
     assert abs(float(loss2.item()) - r2["loss"]) < 3e-4, desc
     ids_ref = O.greedy_decode(r2["params"], ocfg, batch, max_steps=6)
     assert (model.greedy_decode(db, max_steps=6).cpu().numpy() == ids_ref).all(), desc
+    # beam search on the same weights with EOS made reachable (all kept beams compared, not only the best)
+    W2 = {k: v.copy() for k, v in r2["params"].items()}
+    W2["dec/out/bias"][ocfg.eos_id] += 1.0
+    K = int(rng.integers(1, 5))
+    ref = O.beam_search_decode(W2, ocfg, batch, beam_width=K, max_steps=7, return_all=True)[0]
+    m2 = Seq2SeqModel(mcfg, weights=W2)
+    out = m2.beam_search_decode(db, beam_width=K, max_steps=7, check_every=3, return_all=True).cpu().numpy()
+    assert out.shape == ref.shape and (out == ref).all(), desc
