@@ -34,6 +34,8 @@ class DataParallelTrainer:
         # eager mode only: read the persistent kernels' sticky "wait expired" flag before EVERY update (one small host sync per
         # step) and redo the pass through the per-step launches if it is set; off by default (first step only) for benchmarking
         self.check_every_step = bool(check_every_step)
+        import os
+        self.drain_around_collectives = os.environ.get("AVSR_DP_DRAIN", "1") != "0"
         self._static = {}
         model.au_scale = 1.0 / self.world
         self.sync_bn = bool(sync_bn and self.collective and getattr(model, "bn_sync_enable", None) and model.bn_sync_enable())
@@ -106,7 +108,7 @@ class DataParallelTrainer:
     def train_step(self, batch):
         m, dist = self.model, self.dist
         key = self._key(batch)
-        if self.collective and self.use_graph:
+        if self.collective and self.use_graph and self.drain_around_collectives:
             self._drain()
         if self.collective:
             # global loss normaliser: sum over ALL ranks of min(labels_len, L)
@@ -153,6 +155,8 @@ class DataParallelTrainer:
         ga, gb = gr
         ga.replay()
         if self.collective:
+            if self.drain_around_collectives:          # the 13 MB gradient all-reduce is a large eager kernel between two graph launches
+                self._drain()
             dist.all_reduce(m.grads)
         gb.replay()
         return m.loss, m.gnorm
