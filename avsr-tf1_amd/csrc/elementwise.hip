@@ -368,12 +368,14 @@ __global__ void seq_avg_kernel(const float* row_loss, const int32_t* len, const 
 // ---------------------------------------------------------------------------------------------
 // AU regression loss (encoder.py:173-189): pred = sigmoid(z), target = clip(aus,0,3)/3,
 // loss = sum_w (pred - tgt)^2 / sum_w  over valid frames x 2 units;  dz = weight * 2 (pred-tgt) pred (1-pred) / sum_w
+// total != nullptr: normalise by total[0] (the all-reduced count of valid frame-units of the GLOBAL batch) instead of the local count
 __global__ void au_loss_kernel(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz,
-                               int B, int T, float weight) {
+                               int B, int T, float weight, const float* total) {
   __shared__ float red[4];
   float cnt = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) cnt += 2.f * (float)min(max(len[b], 0), T);
   cnt = block_sum_256(cnt, red);
+  if (total) cnt = total[0];
   const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
   for (int row = blockIdx.x * 256 + threadIdx.x; row < B * T; row += gridDim.x * 256) {
     const int b = row / T, t = row % T;
@@ -810,9 +812,14 @@ extern "C" int avsr_seq_loss_per_utterance(const float* row_loss, const int32_t*
 
 extern "C" int avsr_au_loss(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz, int32_t B,
                             int32_t T, float weight, void* stream) {
+  return avsr_au_loss_dp(z, aus, len, row_loss, dz, B, T, weight, nullptr, stream);
+}
+
+extern "C" int avsr_au_loss_dp(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz, int32_t B,
+                               int32_t T, float weight, const float* total_count, void* stream) {
   if (!z || !aus || !len || !row_loss) return AVSR_ERR_ARG;
   hipLaunchKernelGGL(au_loss_kernel, dim3(blocks_for((long)B * T, 256, 256)), dim3(256), 0, S_(stream), z, aus, len,
-                     row_loss, dz, B, T, weight);
+                     row_loss, dz, B, T, weight, total_count);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

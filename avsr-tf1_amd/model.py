@@ -142,14 +142,16 @@ class Seq2SeqModel:
         self._ws_cache = OrderedDict()
         self.max_cached_shapes = 8
         self._dropping = False
-        self.au_scale = 1.0          # data parallel: 1 / world_size (AU term averaged over ranks)
+        self.au_scale = 1.0
+        self.au_external = False     # data parallel: the AU loss is normalised by the all-reduced frame count in dp_norm[1]
         self.load_tf_weights(weights if weights is not None else PR.initialise(cfg, seed))
         self.scratch = z(1 << 22)
         self.gemm_ws = None
         self._ensure_gemm_ws()               # split-K scratch, also used by forward GEMMs with few output tiles
         self.loss = z(1)[:1]
         self.gnorm = z(1)[:1]
-        self.denom = z(1)[:1]
+        self.dp_norm = z(4)          # [sum(mask) of the sequence loss, AU frame-unit count]: what the DP trainer all-reduces per step
+        self.denom, self.au_total = self.dp_norm[0:1], self.dp_norm[1:2]
 
     # ------------------------------------------------------------------------------------------------
     def _eshape(self, name):
@@ -651,7 +653,8 @@ class Seq2SeqModel:
             if s == "video" and cfg.regress_aus and training:
                 Wau = self.P["video/au/kernel"]
                 ops.gemm(E["mem"].mat(), Wau.mat(2), ops.mat(E["au_z"], 2), B * E["T"], 2, E["mem"].D, bias=self._pp("video/au/bias"))
-                ops.au_loss(E["au_z"], batch.aus, E["len"], E["au_row"], E["au_dz"], B, E["T"], cfg.au_loss_weight * self.au_scale)
+                ops.au_loss(E["au_z"], batch.aus, E["len"], E["au_row"], E["au_dz"], B, E["T"], cfg.au_loss_weight * self.au_scale,
+                            total_count=self.au_total if self.au_external else None)
 
     def check_persistent(self, disable=True):
         """Synchronise and read the persistent kernels' sticky error word (a bounded device-side wait expired: some
@@ -1177,6 +1180,12 @@ class Seq2SeqModel:
         if self.cfg.loss_code() == 1:
             return torch.full((1,), float(B * L), device=self.dev)
         return batch.labels_len.clamp(0, L).sum().to(torch.float32).reshape(1)
+
+    def local_au_count(self, batch: Batch):
+        """This rank's share of the AU loss normaliser: 2 units per valid video frame (encoder.py:173-189)."""
+        if not (self.cfg.regress_aus and batch.video is not None):
+            return torch.zeros(1, device=self.dev)
+        return (2.0 * batch.video_len.clamp(0, batch.video.shape[1]).sum()).to(torch.float32).reshape(1)
 
     def sequence_likelihoods(self, batch: Batch):
         """Teacher-forced forward, then the per-utterance average step loss [B] (the LM's evaluate graph, lm.py:362-401:

@@ -173,9 +173,9 @@ def seq_loss(logits, labels, labels_len, denom, compute_denom, row_loss, dlogits
                                  fptr(row_loss), fptr(dlogits), B, L, V, int(loss_fun), float(label_smoothing), _s()), "avsr_seq_loss_fun")
 
 
-def au_loss(z, aus, lens, row_loss, dz, B, T, weight):
-    check(_L().avsr_au_loss(fptr(z), fptr(aus), fptr(lens), fptr(row_loss), fptr(dz), B, T, float(weight), _s()),
-          "avsr_au_loss")
+def au_loss(z, aus, lens, row_loss, dz, B, T, weight, total_count=None):
+    check(_L().avsr_au_loss_dp(fptr(z), fptr(aus), fptr(lens), fptr(row_loss), fptr(dz), B, T, float(weight), fptr(total_count), _s()),
+          "avsr_au_loss_dp")
 
 
 def normed_v(v, g, vn, H):

@@ -12,7 +12,7 @@ hot path on its shard of the utterances, and the only collectives are
       squares -- so mean / variance / moving averages are those of the GLOBAL batch on every rank.  The BN
       gamma / beta gradients ride in (2).  `sync_bn=False` keeps per-rank statistics; the batch-norms inside the
       lip-crop CNN (and the input BN of a CNN-fed stream) are always per rank.
-The AU regression term is averaged over ranks (noted in DESIGN.md).
+The AU regression term is a masked mean over the GLOBAL batch too: its frame count rides with sum(mask) in one 4-float all-reduce.
 
 Launch overhead: a train step is ~1.3k dependent kernel launches; they are captured once per batch
 shape into a hipGraph (torch.cuda.CUDAGraph is only the capture/replay plumbing -- every node is one
@@ -37,7 +37,7 @@ class DataParallelTrainer:
         import os
         self.drain_around_collectives = os.environ.get("AVSR_DP_DRAIN", "1") != "0"
         self._static = {}
-        model.au_scale = 1.0 / self.world
+        model.au_scale = 1.0 / self.world          # stand-in models without dp_norm: the AU term is averaged over ranks
         self.sync_bn = bool(sync_bn and self.collective and getattr(model, "bn_sync_enable", None) and model.bn_sync_enable())
 
     # -- helpers ----------------------------------------------------------------------------------
@@ -118,7 +118,12 @@ class DataParallelTrainer:
             else:
                 L = batch.labels.shape[1]
                 m.denom.copy_(batch.labels_len.clamp(0, L).sum().to(torch.float32).reshape(1))
-            dist.all_reduce(m.denom)
+            if getattr(m, "dp_norm", None) is not None:      # one collective for both normalisers: sum(mask) and the AU frame count
+                m.au_total.copy_(m.local_au_count(batch))
+                m.au_scale, m.au_external = 1.0, True
+                dist.all_reduce(m.dp_norm)
+            else:
+                dist.all_reduce(m.denom)
             if self.sync_bn:
                 dist.all_reduce(m.bn_sync_sums(batch))
                 dist.all_reduce(m.bn_sync_squares(batch))

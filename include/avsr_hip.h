@@ -464,6 +464,10 @@ int avsr_highway_bwd(const avsr_mat* x, const avsr_mat* h, const avsr_mat* carry
 /* AU regression loss (avsr/encoder.py:173-189); z = pre-sigmoid Dense(2) outputs [B][T][2]. */
 int avsr_au_loss(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz, int32_t B, int32_t T,
                  float weight, void* stream);
+/* Data-parallel form: the masked mean runs over the GLOBAL batch -- total_count[0] (device) = all-reduced 2 * sum_b min(len_b, T);
+ * every rank then contributes its share of the numerator.  NULL = the local count (= avsr_au_loss). */
+int avsr_au_loss_dp(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz, int32_t B, int32_t T,
+                    float weight, const float* total_count, void* stream);
 
 int avsr_normed_v(const float* v, const float* g, float* vn, int32_t H, void* stream);
 int avsr_normed_v_bwd(const float* v, const float* g, const float* dvn, float* dv, float* dg, int32_t H, void* stream);

@@ -1,0 +1,78 @@
+"""The REAL engine under the REAL DataParallelTrainer with two ranks: both processes share the box's single GPU and talk over
+gloo (RCCL refuses two ranks on one device), so everything except the transport of the collectives is what runs on an 8-GPU
+node: per-rank shards, all-reduced loss normaliser, sync batch-norm phases, summed gradients, captured graphs replayed around the
+collectives.  After four steps every rank must hold the parameters of ONE engine trained on the whole batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASE = dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32), decoder_units=(32,),
+            embedding_size=16, video_feat=12, audio_feat=20, regress_aus=True, use_dropout=False, warmup_steps=0)
+STEPS = 4
+
+
+def _setup():
+    import dataclasses
+    from avsr_tf1_amd.config import ModelConfig
+    from oracle import avsr_oracle as O
+    ocfg = O.OracleConfig(**CASE)
+    mcfg = ModelConfig(**{f.name: getattr(ocfg, f.name) for f in dataclasses.fields(ModelConfig) if hasattr(ocfg, f.name)})
+    W = O.init_params(ocfg, seed=5)
+    full = O.synthetic_batch(ocfg, B=6, T_a=17, T_v=7, L=6, ragged=True)
+    return O, mcfg, W, full
+
+
+def _shard(O, b, lo, hi):
+    return O.Batch(**{k: (None if getattr(b, k) is None else np.ascontiguousarray(getattr(b, k)[lo:hi]))
+                      for k in ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len")})
+
+
+def _worker(rank, world, port, out_dir, use_graph):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["AVSR_PERSISTENT_RNN"] = "0"          # two processes on ONE GPU must not both claim the whole chip
+    import torch.distributed as dist
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    from avsr_tf1_amd.parallel import DataParallelTrainer
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    O, mcfg, W, full = _setup()
+    cut = [0, 2, 6]                                   # unequal shards
+    model = Seq2SeqModel(mcfg, weights=W)
+    trainer = DataParallelTrainer(model, dist, use_graph=use_graph)
+    batch = Batch.from_numpy(_shard(O, full, cut[rank], cut[rank + 1]))
+    for _ in range(STEPS):
+        trainer.train_step(batch)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mode=np.array(trainer.mode), sync_bn=np.array(trainer.sync_bn),
+             **model.export_tf_weights("params"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_ranks_equal_one_engine_on_the_whole_batch(tmp_path, use_graph):
+    import torch.multiprocessing as mp
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path), use_graph), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert bool(r0["sync_bn"]) and (not use_graph or str(r0["mode"]) == "hipgraph")
+    os.environ["AVSR_PERSISTENT_RNN"] = "0"
+    O, mcfg, W, full = _setup()
+    model = Seq2SeqModel(mcfg, weights=W)
+    batch = Batch.from_numpy(full)
+    for _ in range(STEPS):
+        model.train_step(batch)
+    torch.cuda.synchronize()
+    ref = model.export_tf_weights("params")
+    for k, v in ref.items():
+        assert np.array_equal(r0[k], r1[k]), k                       # replicas stay bit-identical
+        assert np.abs(r0[k] - v).max() < 5e-6 + 1e-4 * np.abs(v).max() * 0.01, (k, np.abs(r0[k] - v).max())
