@@ -29,6 +29,7 @@ class DataParallelTrainer:
         self.collective = self.world > 1 or bool(force_collectives and dist is not None)
         self.use_graph = use_graph
         self.mode = "eager"
+        self._want_graph = use_graph
         self._graphs = {}
         self._checked = False
         # eager mode only: read the persistent kernels' sticky "wait expired" flag before EVERY update (one small host sync per
@@ -36,6 +37,13 @@ class DataParallelTrainer:
         self.check_every_step = bool(check_every_step)
         import os
         self.drain_around_collectives = os.environ.get("AVSR_DP_DRAIN", "1") != "0"
+        self.drain_after_collectives = os.environ.get("AVSR_DP_DRAIN", "1") == "2"
+        if self.collective and self.use_graph and os.environ.get("AVSR_DP_GRAPH") != "1":
+            # Measured with two real engine ranks at the benchmark size (tools/_probe): replaying the captured
+            # graphs around collectives gave inf / NaN gradients within 24 steps however the stream was drained, while eager
+            # launches are exact (and cost 1-2 % on this GPU-bound step).  Collective mode therefore launches eagerly.
+            self.use_graph = False
+            self.mode = "eager (captured graphs are not replayed around collectives)"
         self._static = {}
         model.au_scale = 1.0 / self.world          # stand-in models without dp_norm: the AU term is averaged over ranks
         self.sync_bn = bool(sync_bn and self.collective and getattr(model, "bn_sync_enable", None) and model.bn_sync_enable())
@@ -137,6 +145,8 @@ class DataParallelTrainer:
                 dist.all_reduce(m.grads)
             m.apply_update()
             return m.loss, m.gnorm
+        if self.collective and self.use_graph and self.drain_after_collectives:
+            torch.cuda.synchronize()
         st = self._stage(key, batch)
         gr = self._graphs.get(key)
         if gr is None:
@@ -163,5 +173,7 @@ class DataParallelTrainer:
             if self.drain_around_collectives:          # the 13 MB gradient all-reduce is a large eager kernel between two graph launches
                 self._drain()
             dist.all_reduce(m.grads)
+            if self.drain_after_collectives:
+                torch.cuda.synchronize()
         gb.replay()
         return m.loss, m.gnorm

@@ -64,7 +64,9 @@ def test_two_ranks_equal_one_engine_on_the_whole_batch(tmp_path, use_graph):
         port = s.getsockname()[1]
     mp.spawn(_worker, args=(2, port, str(tmp_path), use_graph), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    assert bool(r0["sync_bn"]) and (not use_graph or str(r0["mode"]) == "hipgraph")
+    # with collectives the trainer launches eagerly whatever use_graph says (graphs replayed around collectives
+    # went wrong at the benchmark size); AVSR_DP_GRAPH=1 would force them
+    assert bool(r0["sync_bn"]) and str(r0["mode"]).startswith("eager")
     os.environ["AVSR_PERSISTENT_RNN"] = "0"
     O, mcfg, W, full = _setup()
     model = Seq2SeqModel(mcfg, weights=W)
