@@ -39,7 +39,7 @@ class DataParallelTrainer:
         self.drain_around_collectives = os.environ.get("AVSR_DP_DRAIN", "1") != "0"
         self.drain_after_collectives = os.environ.get("AVSR_DP_DRAIN", "1") == "2"
         if self.collective and self.use_graph and os.environ.get("AVSR_DP_GRAPH") != "1":
-            # Measured with two real engine ranks at the benchmark size (tools/_probe): replaying the captured
+            # Measured with two real engine ranks at the benchmark size (tools/graph_queue_probe.py, tools/dp_full_check.py): replaying the captured
             # graphs around collectives gave inf / NaN gradients within 24 steps however the stream was drained, while eager
             # launches are exact (and cost 1-2 % on this GPU-bound step).  Collective mode therefore launches eagerly.
             self.use_graph = False
@@ -72,7 +72,7 @@ class DataParallelTrainer:
 
     @staticmethod
     def _drain():
-        """Host-wait for everything queued on the stream.  Measured on ROCm 7.0 / MI355X (tools/_probe): with
+        """Host-wait for everything queued on the stream.  Measured on ROCm 7.0 / MI355X (tools/graph_queue_probe.py, tools/dp_full_check.py): with
         several steps queued, a LARGE eagerly launched kernel or D2D copy between two launches of the captured graphs let the
         next launch start before the previous one had finished -- overlapping train steps, wrong results, persistent-kernel
         waits expiring and GPU memory faults (a tiny kernel in between, or graph launches alone at any depth, were fine).  So
