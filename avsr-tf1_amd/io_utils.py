@@ -169,6 +169,50 @@ def _parse_feature(buf):
     return "none", None
 
 
+def _fast_float_steps(x):
+    """FeatureList whose steps are equally sized packed float Features (every feature / frame vector of one stream is):
+    the steps sit at a constant stride, so the whole [T, k] array is ONE strided view of the payload instead of T parsed messages.
+    Returns None when the layout is anything else (the generic parser then handles it)."""
+    n = len(x)
+    if n < 8 or x[0] != 0x0A:
+        return None
+    l1, i = _varint(x, 1)                                # Feature length
+    stride = i + l1
+    if stride <= 0 or n % stride or x[i] != 0x12:        # Feature.float_list
+        return None
+    l2, j = _varint(x, i + 1)
+    if x[j] != 0x0A:                                     # FloatList.value, packed
+        return None
+    l3, h = _varint(x, j + 1)
+    if l3 % 4 or h + l3 != stride or l2 != (h - j) + l3:
+        return None
+    rows = np.frombuffer(x, dtype=np.uint8).reshape(n // stride, stride)
+    if not (rows[:, :h] == rows[0, :h]).all():           # every step carries the same header bytes
+        return None
+    return np.ascontiguousarray(rows[:, h:]).view("<f4")
+
+
+def _fast_small_int_steps(x):
+    """FeatureList of single small (< 128, one-byte varint) packed int64 values per step -- the label lists: constant stride again."""
+    n = len(x)
+    if n < 7 or x[0] != 0x0A:
+        return None
+    l1, i = _varint(x, 1)
+    stride = i + l1
+    if stride <= 0 or n % stride or x[i] != 0x1A:        # Feature.int64_list
+        return None
+    l2, j = _varint(x, i + 1)
+    if x[j] != 0x0A:                                     # Int64List.value, packed
+        return None
+    l3, h = _varint(x, j + 1)
+    if l3 != 1 or h + 1 != stride:
+        return None
+    rows = np.frombuffer(x, dtype=np.uint8).reshape(n // stride, stride)
+    if not (rows[:, :h] == rows[0, :h]).all() or (rows[:, h] >= 0x80).any():
+        return None
+    return rows[:, h:h + 1].astype(np.int64)
+
+
 def parse_sequence_example(payload: bytes):
     """-> (context: {name: value-list}, feature_lists: {name: [value per step]})."""
     buf = memoryview(payload)
@@ -194,7 +238,11 @@ def parse_sequence_example(payload: bytes):
                     if f3 == 1:
                         key = bytes(x).decode("utf-8")
                     elif f3 == 2:                     # FeatureList { repeated Feature feature = 1; }
-                        steps = [_parse_feature(fx)[1] for f4, _w4, fx in _fields(x) if f4 == 1]
+                        steps = _fast_float_steps(x)
+                        if steps is None:
+                            steps = _fast_small_int_steps(x)
+                        if steps is None:
+                            steps = [_parse_feature(fx)[1] for f4, _w4, fx in _fields(x) if f4 == 1]
                 flists[key] = steps
     return context, flists
 
@@ -270,7 +318,7 @@ def _get_input_shape_from_record(record):
     else:
         ch = int(ctx["channels"][0]) if "channels" in ctx else 1
         shape, content["stream"] = [int(ctx["width"][0]), int(ctx["height"][0]), ch], "video"
-    if fl.get("aus"):
+    if fl.get("aus") is not None and len(fl["aus"]):
         content["aus"] = True
     return shape, content
 
@@ -278,8 +326,12 @@ def _get_input_shape_from_record(record):
 def _parse_input(payload, input_shape):
     ctx, fl = parse_sequence_example(payload)
     T = int(ctx["input_length"][0])
-    x = np.stack(fl["inputs"]).astype(np.float32).reshape([T] + list(input_shape)) if T else np.zeros([0] + list(input_shape), np.float32)
-    aus = np.stack(fl["aus"]).astype(np.float32).reshape(T, 2) if fl.get("aus") else None
+    x = np.asarray(fl["inputs"] if isinstance(fl["inputs"], np.ndarray) else np.stack(fl["inputs"]), dtype=np.float32).reshape(
+        [T] + list(input_shape)) if T else np.zeros([0] + list(input_shape), np.float32)
+    aus_l = fl.get("aus")
+    aus = None
+    if aus_l is not None and len(aus_l):
+        aus = np.asarray(aus_l if isinstance(aus_l, np.ndarray) else np.stack(aus_l), dtype=np.float32).reshape(T, 2)
     return x, aus, T, ctx["filename"][0]
 
 

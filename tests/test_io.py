@@ -189,3 +189,23 @@ def test_label_only_and_text_iterators(tmp_path):
     assert bds[1].labels[0].tolist() == [rev[c] for c in "it's"]
     shuffled = list(IO.make_iterator_from_label_record(rec, 3, ud, shuffle=True, bucket_width=-1, seed=1))
     assert sorted(n.decode() for bd in shuffled for n in bd.labels_filenames) == sorted(seen)
+
+
+def test_fast_step_paths_agree_with_the_generic_parser(monkeypatch):
+    """The constant-stride fast paths (float vectors, small label ids) and the generic per-step parser give the same arrays; layouts the
+    fast paths do not cover (ids >= 128, ragged step sizes) fall through to the generic parser."""
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((37, 20)).astype(np.float32)
+    pay = IO.make_feature_example("utt", x)
+    lab = IO.make_label_example("utt", [3, 27, 1, 5], "character")
+    big = IO.make_label_example("utt", [3, 300, 1], "character")          # 300 needs a two-byte varint: no constant stride
+    fast = [IO.parse_sequence_example(p) for p in (pay, lab, big)]
+    monkeypatch.setattr(IO, "_fast_float_steps", lambda b: None)
+    monkeypatch.setattr(IO, "_fast_small_int_steps", lambda b: None)
+    slow = [IO.parse_sequence_example(p) for p in (pay, lab, big)]
+    assert isinstance(fast[0][1]["inputs"], np.ndarray) and isinstance(slow[0][1]["inputs"], list)
+    assert np.array_equal(np.asarray(fast[0][1]["inputs"]), np.stack(slow[0][1]["inputs"])) and np.array_equal(np.asarray(fast[0][1]["inputs"]), x)
+    for f, s in zip(fast[1:], slow[1:]):
+        assert [int(v[0]) for v in f[1]["labels"]] == [int(v[0]) for v in s[1]["labels"]]
+    assert [int(v[0]) for v in fast[2][1]["labels"]] == [3, 300, 1]
+    assert fast[0][0]["filename"] == slow[0][0]["filename"]
