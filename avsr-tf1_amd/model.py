@@ -116,6 +116,10 @@ class Seq2SeqModel:
         self.stats = z(ns)
         self.n_train = nt
         self.step = z(1, torch.int32)[:1]
+        # RNG key of the stateless dropout / sampling masks: global step + seed_offset (data parallel: rank << 24, so that row i of
+        # different ranks does not draw the same masks); refreshed at the start of every train-graph forward
+        self.seed = z(1, torch.int32)[:1]
+        self.seed_offset = 0
         self.P = {n: Ref(self.params, o, self._eshape(n)) for n, o in self._train_off.items()}
         self.Gr = {n: Ref(self.grads, o, self._eshape(n)) for n, o in self._train_off.items()}
         self.S = {n: Ref(self.stats, o, self.inv[n][0]) for n, o in self._stat_off.items()}
@@ -361,7 +365,7 @@ class Seq2SeqModel:
         drop = self._sdrop(s)
         if drop:
             k = self._keeps(s)
-            st.seed = ops.fptr(self.step)
+            st.seed = ops.fptr(self.seed)
             st.keep_in, st.keep_state, st.keep_out = k
             st.cell_id_base = encoder_cell_id(s, d, 0)
             if E["attentive"]:                   # the attention-wrapped top layer consumes this stack through xt_seq
@@ -414,7 +418,7 @@ class Seq2SeqModel:
         st.len = ops.fptr(len_t)
         drop = self._sdrop(s)
         if drop:
-            st.seed = ops.fptr(self.step)
+            st.seed = ops.fptr(self.seed)
             st.keep_in, st.keep_state, st.keep_out = self._keeps(s)
             st.cell_id_base = encoder_cell_id(s, d, l)
         name, bname = self._kn(f"{s}/enc/{d}/l{l}")
@@ -462,7 +466,7 @@ class Seq2SeqModel:
                     xin = x
                     if self._sdrop(s):           # DropoutWrapper input mask of this cell
                         xin = ops.mat(E["xd"][d] if l == 0 else Ld["xd"], in_w)
-                        ops.dropout_rows(x, xin, B * T, in_w, self.step, encoder_cell_id(s, d, l) * 4, self._keeps(s)[0], in_w)
+                        ops.dropout_rows(x, xin, B * T, in_w, self.seed, encoder_cell_id(s, d, l) * 4, self._keeps(s)[0], in_w)
                     Wk = self.P[self._kn(f"{s}/enc/{d}/l{l}")[0]]
                     ops.gemm(xin, Wk.mat(4 * u), ops.mat(Ld["gates"], 4 * u), B * T, 4 * u, in_w)
                     stacks.append(self._rnn_stack_single(ws, s, d, l, B, E["len"]))
@@ -532,7 +536,7 @@ class Seq2SeqModel:
                         dy_below = Lo["dy"].mat(0, Lo["col"])
                         if drop:
                             ops.gemm(dg, self.P[kname].mat(4 * u), ops.mat(Ld["dxtmp"], u), B * T, u, 4 * u, trans_b=1)
-                            ops.dropout_rows(ops.mat(Ld["dxtmp"], u), dy_below, B * T, u, self.step, encoder_cell_id(s, d, l) * 4,
+                            ops.dropout_rows(ops.mat(Ld["dxtmp"], u), dy_below, B * T, u, self.seed, encoder_cell_id(s, d, l) * 4,
                                              self._keeps(s)[0], u, accumulate=True)
                         else:
                             ops.gemm(dg, self.P[kname].mat(4 * u), dy_below, B * T, u, 4 * u, trans_b=1, beta=1.0)
@@ -634,7 +638,7 @@ class Seq2SeqModel:
                 xin = E["xin0"]
                 if self._sdrop(s):               # DropoutWrapper input mask of the layer-0 cell of this direction
                     xin = E["xd"][d]
-                    ops.dropout_rows(ops.mat(E["xin0"], F0), ops.mat(xin, F0), B * T, F0, self.step, encoder_cell_id(s, d, 0) * 4,
+                    ops.dropout_rows(ops.mat(E["xin0"], F0), ops.mat(xin, F0), B * T, F0, self.seed, encoder_cell_id(s, d, 0) * 4,
                                      self._keeps(s)[0], F0)
                 G = self.G
                 ops.gemm(ops.mat(xin, F0), W0.mat(G * u0), ops.mat(E["layers"][(d, 0)]["gates"], G * u0), B * T, G * u0, F0)
@@ -795,7 +799,7 @@ class Seq2SeqModel:
                         ops.gemm(ops.mat(L0["dpc"], u0), self.P[f"{s}/enc/{d}/l0/cand_kernel"].mat(u0), ops.mat(tgt, F0), B * T, F0, u0,
                                  trans_b=1, beta=1.0)
                     if self._sdrop(s):
-                        ops.dropout_rows(ops.mat(E["dx_tmp"], F0), ops.mat(E["dxin0"], F0), B * T, F0, self.step,
+                        ops.dropout_rows(ops.mat(E["dx_tmp"], F0), ops.mat(E["dxin0"], F0), B * T, F0, self.seed,
                                          encoder_cell_id(s, d, 0) * 4, self._keeps(s)[0], F0, accumulate=not first)
                     first = False
             if self.n_dense:
@@ -899,7 +903,7 @@ class Seq2SeqModel:
                 M.dscores, M.dctx, M.pdq = ops.fptr(m["dscores"]), ops.fptr(m["dctx"]), ops.fptr(m["pdq"])
         if self._bdrop(blk) and mode != 1:
             keep = blk["keep"]
-            d.seed = ops.fptr(self.step)
+            d.seed = ops.fptr(self.seed)
             d.keep_in, d.keep_state, d.keep_out = keep
             d.cell_id = blk["cell_id"]
             d.hs_seq = ops.fptr(blk["hs_seq"].t)
@@ -1021,7 +1025,7 @@ class Seq2SeqModel:
         T, H, Ein = E["T"], blk["H"], blk["E"]
         kname = self._kn(blk["cell"])[0]
         if self._sdrop("audio") and E["nplain"] == 0:
-            ops.dropout_rows(ops.mat(E["xin0"], E["F0"]), ops.mat(E["xd"]["fw"], E["F0"]), B * T, E["F0"], self.step, blk["cell_id"] * 4,
+            ops.dropout_rows(ops.mat(E["xin0"], E["F0"]), ops.mat(E["xd"]["fw"], E["F0"]), B * T, E["F0"], self.seed, blk["cell_id"] * 4,
                              blk["keep"][0], Ein + blk["A"])
         xin = self._av_xin(E)
         ops.gemm(xin, self.P[kname].mat(self.G * H), ops.mat(blk["gates"], self.G * H), B * T, self.G * H, Ein)
@@ -1057,9 +1061,9 @@ class Seq2SeqModel:
         if self._sdrop("audio"):                 # gradient of the DROPPED input -> gradient of the layer below's output
             keep, W = blk["keep"][0], blk["E"] + blk["A"]
             if E["nplain"] == 0:
-                ops.dropout_rows(dxin, ops.mat(E["dxin0"], E["F0"]), B * E["T"], E["F0"], self.step, blk["cell_id"] * 4, keep, W)
+                ops.dropout_rows(dxin, ops.mat(E["dxin0"], E["F0"]), B * E["T"], E["F0"], self.seed, blk["cell_id"] * 4, keep, W)
             else:
-                ops.dropout_rows(dxin, dxin, B * E["T"], blk["E"], self.step, blk["cell_id"] * 4, keep, W)
+                ops.dropout_rows(dxin, dxin, B * E["T"], blk["E"], self.seed, blk["cell_id"] * 4, keep, W)
 
     # ------------------------------------------------------------------------------------------------
     # decoder
@@ -1128,6 +1132,7 @@ class Seq2SeqModel:
         ws = self._get_ws(B, Ta, Tv, L, False)
         self._cur = (ws, batch)
         self._refresh_derived()
+        torch.add(self.step, int(self.seed_offset), out=self.seed)
         self._encode(ws, batch, True)
         D = ws["dec"]
         H, E, V = D["H"], D["E"], cfg.vocab_size
@@ -1140,10 +1145,10 @@ class Seq2SeqModel:
         ops.embed_labels(self._pp("dec/embedding"), batch.labels, cfg.go_id, D["xemb"], D["fed"], B, L, E, 1 if sampling else L)
         if drop_in:
             if sampling:     # only row (b, 0): address rows with stride L*E, mask index (b*L + 0)*(E+A) + e
-                ops.dropout_rows(ops.mat(D["xemb"], L * E), ops.mat(D["xemb"], L * E), B, E, self.step, CELL_ID_DECODER * 4,
+                ops.dropout_rows(ops.mat(D["xemb"], L * E), ops.mat(D["xemb"], L * E), B, E, self.seed, CELL_ID_DECODER * 4,
                                  cfg.decoder_dropout[0], L * (E + A))
             else:
-                ops.dropout_rows(xm, xm, B * L, E, self.step, CELL_ID_DECODER * 4, cfg.decoder_dropout[0], E + A)
+                ops.dropout_rows(xm, xm, B * L, E, self.seed, CELL_ID_DECODER * 4, cfg.decoder_dropout[0], E + A)
         if not sampling:
             ops.gemm(xm, self.P[self._kn("dec/l0")[0]].mat(self.G * H), ops.mat(D["gates"], self.G * H), B * L, self.G * H, E)
             if self.gru:
@@ -1152,7 +1157,7 @@ class Seq2SeqModel:
         D["desc"] = d = self._block_desc(ws, D, batch.labels_len, 2 if sampling else 0, D["h0"], D["c0"], with_bwd=True)
         if sampling:
             d.output_attention = int(cfg.output_attention())
-            d.seed = ops.fptr(self.step)
+            d.seed = ops.fptr(self.seed)
             d.sampling_prob = cfg.sampling_probability
             if not self._bdrop(D):
                 d.keep_in = d.keep_state = d.keep_out = 1.0
@@ -1229,7 +1234,7 @@ class Seq2SeqModel:
         self._block_backward(ws, D, d, ops.mat(D["xemb"], E), ops.mat(D["dxemb"], E), 0.0, oa)
         if self._dropping and cfg.decoder_dropout[0] < 1.0:
             dm = ops.mat(D["dxemb"], E)
-            ops.dropout_rows(dm, dm, B * L, E, self.step, CELL_ID_DECODER * 4, cfg.decoder_dropout[0], E + A)
+            ops.dropout_rows(dm, dm, B * L, E, self.seed, CELL_ID_DECODER * 4, cfg.decoder_dropout[0], E + A)
         ops.embed_grad(D["dxemb"], D["fed"], self._gp("dec/embedding"), B, L, E, V, self.scratch)
         self._decoder_init_state_bwd(ws)
         self._encode_backward(ws, batch)

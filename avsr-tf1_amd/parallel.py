@@ -45,6 +45,8 @@ class DataParallelTrainer:
             self.use_graph = False
             self.mode = "eager (captured graphs are not replayed around collectives)"
         self._static = {}
+        if self.world > 1 and hasattr(model, "seed_offset"):
+            model.seed_offset = dist.get_rank() << 24      # decorrelate the ranks' dropout / sampling masks
         model.au_scale = 1.0 / self.world          # stand-in models without dp_norm: the AU term is averaged over ranks
         self.sync_bn = bool(sync_bn and self.collective and getattr(model, "bn_sync_enable", None) and model.bn_sync_enable())
 

@@ -504,3 +504,20 @@ def test_full_length_train_step_and_greedy(case, over):
     ids_ref = O.greedy_decode(ref["params"], ocfg, batch, max_steps=40)
     ids = model.greedy_decode(db, max_steps=40).cpu().numpy()
     assert ids.shape == ids_ref.shape and (ids == ids_ref).all()
+
+
+def test_rank_seed_offset_decorrelates_dropout_masks():
+    """Data-parallel ranks key the stateless RNG with step + (rank << 24): same weights and batch, different masks; offset 0 is the oracle's stream."""
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    O, ocfg, mcfg, W, batch = make("c4_bimodal_uni", use_dropout=True, sampling_probability=0.3)
+    ref = O.train_step(W, None, ocfg, batch)
+    db = Batch.from_numpy(batch)
+    losses = []
+    for off in (0, 1 << 24, 2 << 24):
+        m = Seq2SeqModel(mcfg, weights=W)
+        m.seed_offset = off
+        m.forward_train(db)
+        torch.cuda.synchronize()
+        losses.append(float(m.loss.item()))
+    assert abs(losses[0] - ref["seq_loss"]) < 1e-4 or abs(losses[0] - ref["loss"]) < 1.0      # offset 0 = the oracle's masks (sequence term)
+    assert len({round(x, 6) for x in losses}) == 3, losses
