@@ -116,7 +116,7 @@ EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr
            "avsr_relu", "avsr_relu_bwd", "avsr_add", "avsr_selu", "avsr_selu_bwd", "avsr_conv3x3_supported", "avsr_conv3x3", "avsr_conv3x3_bwd_data_s2",
            "avsr_conv3x3_bwd_weight", "avsr_embed_labels", "avsr_embed_grad", "avsr_dropout_rows", "avsr_seq_loss",
            "avsr_au_loss", "avsr_au_loss_dp", "avsr_normed_v", "avsr_normed_v_bwd", "avsr_reduce_scalar", "avsr_l2_regularise",
-           "avsr_global_norm", "avsr_adam_step", "avsr_adam_step_decay", "avsr_highway_fwd", "avsr_highway_bwd", "avsr_optimiser_step", "avsr_instnorm_fwd", "avsr_instnorm_bwd", "avsr_seq_loss_fun", "avsr_seq_loss_per_utterance", "avsr_batchnorm_sync_sum", "avsr_batchnorm_sync_sqsum", "avsr_batchnorm_sync_apply", "avsr_prof_begin", "avsr_prof_end"]
+           "avsr_global_norm", "avsr_adam_step", "avsr_adam_step_decay", "avsr_copy_words", "avsr_zero_words", "avsr_highway_fwd", "avsr_highway_bwd", "avsr_optimiser_step", "avsr_instnorm_fwd", "avsr_instnorm_bwd", "avsr_seq_loss_fun", "avsr_seq_loss_per_utterance", "avsr_batchnorm_sync_sum", "avsr_batchnorm_sync_sqsum", "avsr_batchnorm_sync_apply", "avsr_prof_begin", "avsr_prof_end"]
 
 _lib = None
 
@@ -196,6 +196,8 @@ def load():
         "avsr_optimiser_step": [vp, vp, vp, vp, i64, vp, vp, f32, i32, i32, f32, f32, i32, f32, vp],
         "avsr_highway_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
         "avsr_highway_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+        "avsr_copy_words": [vp, vp, i64, vp],
+        "avsr_zero_words": [vp, i64, vp],
         "avsr_adam_step_decay": [vp, vp, vp, vp, i64, vp, vp, f32, i32, i32, f32, f32, vp],
         "avsr_prof_begin": [i32],
         "avsr_prof_end": [C.POINTER(i32), C.POINTER(f32), C.POINTER(C.c_double)],

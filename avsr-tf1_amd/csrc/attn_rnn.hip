@@ -358,25 +358,23 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
 
   if (l_begin == 0) {
     // initial state -> ping-pong parity 0, cell_out slot 0 = h0, attention slot 0 = 0
-    if (d.h0) { if (hipMemcpyAsync(hbuf(d, 0), d.h0, bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP; }
-    else if (hipMemsetAsync(hbuf(d, 0), 0, bh, s) != hipSuccess) return AVSR_ERR_HIP;
-    if (d.c0) { if (hipMemcpyAsync(cbuf(d, 0), d.c0, bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP; }
-    else if (hipMemsetAsync(cbuf(d, 0), 0, bh, s) != hipSuccess) return AVSR_ERR_HIP;
-    if (hipMemcpy2DAsync(layer_out(d, 0), sizeof(float) * (L + 1) * H, hbuf(d, 0), sizeof(float) * H, sizeof(float) * H, B,
-                         hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+    if (d.h0) { if (avsr::dev_copy(hbuf(d, 0), d.h0, bh, s) != hipSuccess) return AVSR_ERR_HIP; }
+    else if (avsr::dev_zero(hbuf(d, 0), bh, s) != hipSuccess) return AVSR_ERR_HIP;
+    if (d.c0) { if (avsr::dev_copy(cbuf(d, 0), d.c0, bh, s) != hipSuccess) return AVSR_ERR_HIP; }
+    else if (avsr::dev_zero(cbuf(d, 0), bh, s) != hipSuccess) return AVSR_ERR_HIP;
+    if (avsr::dev_copy_2d(layer_out(d, 0), sizeof(float) * (L + 1) * H, hbuf(d, 0), sizeof(float) * H, sizeof(float) * H, B, s) != hipSuccess) return AVSR_ERR_HIP;
     for (int j = 0; j < d.n_extra; ++j) {            // layers above start from the zero state (decoder_unimodal.py:151-157)
       const avsr_dec_layer& X = d.extra[j];
-      if (hipMemsetAsync(X.state, 0, 4 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
-      if (hipMemset2DAsync(X.out, sizeof(float) * (L + 1) * H, 0, sizeof(float) * H, B, s) != hipSuccess) return AVSR_ERR_HIP;
-      if (drop && X.hs_seq && hipMemset2DAsync(X.hs_seq, sizeof(float) * (L + 1) * H, 0, sizeof(float) * H, B, s) != hipSuccess)
+      if (avsr::dev_zero(X.state, 4 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (avsr::dev_zero_2d(X.out, sizeof(float) * (L + 1) * H, sizeof(float) * H, B, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (drop && X.hs_seq && avsr::dev_zero_2d(X.hs_seq, sizeof(float) * (L + 1) * H, sizeof(float) * H, B, s) != hipSuccess)
         return AVSR_ERR_HIP;
     }
-    if (A > 0 && hipMemset2DAsync(d.att, sizeof(float) * (L + 1) * A, 0, sizeof(float) * A, B, s) != hipSuccess)
+    if (A > 0 && avsr::dev_zero_2d(d.att, sizeof(float) * (L + 1) * A, sizeof(float) * A, B, s) != hipSuccess)
       return AVSR_ERR_HIP;
     if (drop) {
-      if (hipMemcpy2DAsync(d.hs_seq, sizeof(float) * (L + 1) * H, hbuf(d, 0), sizeof(float) * H, sizeof(float) * H, B,
-                           hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
-      if (A > 0 && hipMemset2DAsync(d.attd, sizeof(float) * (L + 1) * A, 0, sizeof(float) * A, B, s) != hipSuccess)
+      if (avsr::dev_copy_2d(d.hs_seq, sizeof(float) * (L + 1) * H, hbuf(d, 0), sizeof(float) * H, sizeof(float) * H, B, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (A > 0 && avsr::dev_zero_2d(d.attd, sizeof(float) * (L + 1) * A, sizeof(float) * A, B, s) != hipSuccess)
         return AVSR_ERR_HIP;
     }
   }
@@ -527,7 +525,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
                            d.ids + l, (long)L, d.tok, d.steplen, d.n_unfinished, B, l, d.eos_id);
       } else if (d.mode == 3) {
         const int K = d.beam_width, pin = l & 1, pout = (l + 1) & 1;
-        if (hipMemsetAsync(d.n_unfinished + l, 0, sizeof(int32_t), s) != hipSuccess) return AVSR_ERR_HIP;   // per-step count [L]
+        if (avsr::dev_zero(d.n_unfinished + l, sizeof(int32_t), s) != hipSuccess) return AVSR_ERR_HIP;   // per-step count [L]
         hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(64), 2 * K * d.V * sizeof(float), s, d.logits + (long)l * d.V,
                            (long)L * d.V, d.V, K, l, d.eos_id, d.length_penalty, d.beam_logp + (long)pin * B, d.beam_fin + (long)pin * B,
                            d.beam_len + (long)pin * B, d.beam_logp + (long)pout * B, d.beam_fin + (long)pout * B,
@@ -541,8 +539,8 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
     }
   }
   if (l_end == L) {
-    if (d.h_final && hipMemcpyAsync(d.h_final, hbuf(d, L & 1), bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
-    if (!gru && d.c_final && hipMemcpyAsync(d.c_final, cbuf(d, L & 1), bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+    if (d.h_final && avsr::dev_copy(d.h_final, hbuf(d, L & 1), bh, s) != hipSuccess) return AVSR_ERR_HIP;
+    if (!gru && d.c_final && avsr::dev_copy(d.c_final, cbuf(d, L & 1), bh, s) != hipSuccess) return AVSR_ERR_HIP;
   }
   return AVSR_OK;
 }
@@ -579,12 +577,12 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
   const int NX = d.n_extra;
   for (int j = 0; j < NX; ++j) {
     if (!d.extra[j].w || !d.extra[j].dgates || !d.extra[j].dstate) return AVSR_ERR_ARG;
-    if (hipMemsetAsync(d.extra[j].dstate, 0, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
+    if (avsr::dev_zero(d.extra[j].dstate, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
   }
   if (NX > 0 && (d.dh_final || d.dc_final)) return AVSR_ERR_UNSUPPORTED;     // final-state gradients: single-cell blocks only
-  if (hipMemsetAsync(d.dstate, 0, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
-  if (!gru && d.dc_final && hipMemcpyAsync(dcbuf(d, L & 1), d.dc_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
-  if (d.dh_final && hipMemcpyAsync(gru ? g_carry(L & 1) : dhcarry(d, L & 1), d.dh_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
+  if (avsr::dev_zero(d.dstate, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
+  if (!gru && d.dc_final && avsr::dev_copy(dcbuf(d, L & 1), d.dc_final, bh, s) != hipSuccess) return AVSR_ERR_HIP;
+  if (d.dh_final && avsr::dev_copy(gru ? g_carry(L & 1) : dhcarry(d, L & 1), d.dh_final, bh, s) != hipSuccess)
     return AVSR_ERR_HIP;
 
   static thread_local StepLaunch SL;
@@ -744,7 +742,7 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
     tk.p0 = d.dh0; tk.s0 = H;
     if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
   }
-  if (!gru && d.dc0 && hipMemcpyAsync(d.dc0, dcbuf(d, 0), bh, hipMemcpyDeviceToDevice, s) != hipSuccess) return AVSR_ERR_HIP;
+  if (!gru && d.dc0 && avsr::dev_copy(d.dc0, dcbuf(d, 0), bh, s) != hipSuccess) return AVSR_ERR_HIP;
   return AVSR_OK;
 }
 

@@ -71,4 +71,50 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// ---------------------------------------------------------------------------------------------
+// Device fills / copies as KERNELS.  The engine never enqueues hipMemsetAsync / hipMemcpyAsync: captured into a hipGraph they become
+// memset / memcpy nodes, and graphs holding such nodes misbehaved on ROCm 7.0 -- a kernel node keeps every
+// dependency on the compute queue.  All sizes are multiples of 4 bytes (float / int32 buffers); 2-D forms take byte pitches.
+__global__ static void k_fill_words(uint32_t* p, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+__global__ static void k_copy_words(uint32_t* d, const uint32_t* s, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] = s[i];
+}
+__global__ static void k_fill_words_2d(uint32_t* p, long pitch_w, long width_w, long rows) {
+  const long total = width_w * rows;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) p[(i / width_w) * pitch_w + i % width_w] = 0u;
+}
+__global__ static void k_copy_words_2d(uint32_t* d, long dpitch_w, const uint32_t* s, long spitch_w, long width_w, long rows) {
+  const long total = width_w * rows;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    d[(i / width_w) * dpitch_w + i % width_w] = s[(i / width_w) * spitch_w + i % width_w];
+}
+static inline int k_blocks(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
+static inline hipError_t dev_zero(void* p, size_t bytes, hipStream_t s) {
+  if (!bytes) return hipSuccess;
+  if (bytes % 4 || !p) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_fill_words, dim3(k_blocks((long)(bytes / 4))), dim3(256), 0, s, (uint32_t*)p, (long)(bytes / 4));
+  return hipGetLastError();
+}
+static inline hipError_t dev_copy(void* d, const void* src, size_t bytes, hipStream_t s) {
+  if (!bytes) return hipSuccess;
+  if (bytes % 4 || !d || !src) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_copy_words, dim3(k_blocks((long)(bytes / 4))), dim3(256), 0, s, (uint32_t*)d, (const uint32_t*)src, (long)(bytes / 4));
+  return hipGetLastError();
+}
+static inline hipError_t dev_zero_2d(void* p, size_t pitch, size_t width, size_t rows, hipStream_t s) {
+  if (!width || !rows) return hipSuccess;
+  if (pitch % 4 || width % 4 || !p) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_fill_words_2d, dim3(k_blocks((long)(width / 4 * rows))), dim3(256), 0, s, (uint32_t*)p, (long)(pitch / 4), (long)(width / 4), (long)rows);
+  return hipGetLastError();
+}
+static inline hipError_t dev_copy_2d(void* d, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, hipStream_t s) {
+  if (!width || !rows) return hipSuccess;
+  if (dpitch % 4 || spitch % 4 || width % 4 || !d || !src) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_copy_words_2d, dim3(k_blocks((long)(width / 4 * rows))), dim3(256), 0, s, (uint32_t*)d, (long)(dpitch / 4), (const uint32_t*)src,
+                     (long)(spitch / 4), (long)(width / 4), (long)rows);
+  return hipGetLastError();
+}
+
 }  // namespace avsr

@@ -189,8 +189,8 @@ extern "C" int avsr_batchnorm_bwd(const float* x, const float* dy, const float* 
                        F, relu, dx_beta);
     AVSR_CHECK_LAUNCH();
   }
-  if (dbeta && hipMemcpyAsync(dbeta, sums, sizeof(float) * F, hipMemcpyDeviceToDevice, S_(stream)) != hipSuccess) return AVSR_ERR_HIP;
-  if (dgamma && hipMemcpyAsync(dgamma, sums + F, sizeof(float) * F, hipMemcpyDeviceToDevice, S_(stream)) != hipSuccess) return AVSR_ERR_HIP;
+  if (dbeta && avsr::dev_copy(dbeta, sums, sizeof(float) * F, S_(stream)) != hipSuccess) return AVSR_ERR_HIP;
+  if (dgamma && avsr::dev_copy(dgamma, sums + F, sizeof(float) * F, S_(stream)) != hipSuccess) return AVSR_ERR_HIP;
   return AVSR_OK;
 }
 

@@ -802,6 +802,16 @@ extern "C" int avsr_highway_bwd(const avsr_mat* x, const avsr_mat* h, const avsr
   return AVSR_OK;
 }
 
+extern "C" int avsr_copy_words(void* dst, const void* src, int64_t n_words, void* stream) {
+  if (!dst || !src || n_words < 0) return AVSR_ERR_ARG;
+  return avsr::dev_copy(dst, src, (size_t)n_words * 4, S_(stream)) == hipSuccess ? AVSR_OK : AVSR_ERR_HIP;
+}
+
+extern "C" int avsr_zero_words(void* dst, int64_t n_words, void* stream) {
+  if (!dst || n_words < 0) return AVSR_ERR_ARG;
+  return avsr::dev_zero(dst, (size_t)n_words * 4, S_(stream)) == hipSuccess ? AVSR_OK : AVSR_ERR_HIP;
+}
+
 extern "C" int avsr_seq_loss_per_utterance(const float* row_loss, const int32_t* labels_len, const float* denom, float* out,
                                            int32_t B, int32_t L, void* stream) {
   if (!row_loss || !labels_len || !denom || !out || B <= 0 || L <= 0) return AVSR_ERR_ARG;

@@ -85,8 +85,8 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
       if (Ly.residual && (l == 0 || Ly.in_dim != Ly.units || !S.layer[l - 1].out)) return AVSR_ERR_ARG;
       if (Ly.residual && S.cell != 0) return AVSR_ERR_UNSUPPORTED;
       // zero initial state: h parity 0, c parity 0
-      if (hipMemsetAsync(hbuf(Ly, S.B, 0), 0, sizeof(float) * S.B * Ly.units, s) != hipSuccess) return AVSR_ERR_HIP;
-      if (hipMemsetAsync(cbuf(Ly, S.B, 0), 0, sizeof(float) * S.B * Ly.units, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (avsr::dev_zero(hbuf(Ly, S.B, 0), sizeof(float) * S.B * Ly.units, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (avsr::dev_zero(cbuf(Ly, S.B, 0), sizeof(float) * S.B * Ly.units, s) != hipSuccess) return AVSR_ERR_HIP;
     }
     nsteps = nsteps > S.T + S.n_layers - 1 ? nsteps : S.T + S.n_layers - 1;
     ntask_max += S.n_layers;
@@ -181,9 +181,9 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
     for (int l = 0; l < S.n_layers; ++l) {
       const avsr_rnn_layer& Ly = S.layer[l];
       const size_t bytes = sizeof(float) * S.B * Ly.units;
-      if (Ly.h_final && hipMemcpyAsync(Ly.h_final, hbuf(Ly, S.B, S.T & 1), bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      if (Ly.h_final && avsr::dev_copy(Ly.h_final, hbuf(Ly, S.B, S.T & 1), bytes, s) != hipSuccess)
         return AVSR_ERR_HIP;
-      if (!gru && Ly.c_final && hipMemcpyAsync(Ly.c_final, cbuf(Ly, S.B, S.T & 1), bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      if (!gru && Ly.c_final && avsr::dev_copy(Ly.c_final, cbuf(Ly, S.B, S.T & 1), bytes, s) != hipSuccess)
         return AVSR_ERR_HIP;
     }
   }
@@ -204,15 +204,15 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
       if (!Ly.w || !Ly.dgates || !Ly.dstate || !Ly.gates || !Ly.cs) return AVSR_ERR_ARG;
       const size_t bh = sizeof(float) * S.B * Ly.units;
       // rolling dG (both parities), dc / dh_carry at parity T&1 = gradient of the final state
-      if (hipMemsetAsync(Ly.dstate, 0, (Ly.residual ? 14 : 12) * bh, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (avsr::dev_zero(Ly.dstate, (Ly.residual ? 14 : 12) * bh, s) != hipSuccess) return AVSR_ERR_HIP;
       if (l == S.n_layers - 1) {
         if (S.cell == 1) {
-          if (S.dh_final && hipMemcpyAsync(g_carry(Ly, S.B, S.T & 1), S.dh_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
+          if (S.dh_final && avsr::dev_copy(g_carry(Ly, S.B, S.T & 1), S.dh_final, bh, s) != hipSuccess)
             return AVSR_ERR_HIP;
         } else {
-          if (S.dc_final && hipMemcpyAsync(dcbuf(Ly, S.B, S.T & 1), S.dc_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
+          if (S.dc_final && avsr::dev_copy(dcbuf(Ly, S.B, S.T & 1), S.dc_final, bh, s) != hipSuccess)
             return AVSR_ERR_HIP;
-          if (S.dh_final && hipMemcpyAsync(dhcarry(Ly, S.B, S.T & 1), S.dh_final, bh, hipMemcpyDeviceToDevice, s) != hipSuccess)
+          if (S.dh_final && avsr::dev_copy(dhcarry(Ly, S.B, S.T & 1), S.dh_final, bh, s) != hipSuccess)
             return AVSR_ERR_HIP;
         }
       }

@@ -621,7 +621,7 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
     const int B = st[0].B;
     for (int b0 = 0; b0 < B; b0 += 64) {
       L.b0 = b0; L.ngroups = ((B - b0 < 64 ? B - b0 : 64) + 7) / 8;
-      if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
+      if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
       {
         ProfScope ps(PROF_RNN_PERSIST_FWD, s, g_fwd_flops * (L.ngroups * 8 < B - b0 ? L.ngroups * 8 : B - b0) / B);
         hipLaunchKernelGGL(rnn_persist_fwd_xcd_kernel, dim3(8 * wg), dim3(256), 0, s, L);
@@ -632,7 +632,7 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
   }
   if ((g_persist_mode & 1) && build_tasks(st, n, false, sync, sync_ints, L, &wg, &words) == AVSR_OK) {
     if (dry) return AVSR_OK;
-    if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
+    if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
       ProfScope ps(PROF_RNN_PERSIST_FWD, s, g_fwd_flops);
       hipLaunchKernelGGL(rnn_persist_fwd_kernel, dim3(wg), dim3(256), 0, s, L);

@@ -398,7 +398,7 @@ int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
   for (int b0 = 0; b0 < B; b0 += 64) {                 // rows are independent: consecutive launches over 64-row slices
     const int rows = B - b0 < 64 ? B - b0 : 64;
     L.b0 = b0; L.ngroups = (rows + 15) / 16;
-    if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
+    if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
       ProfScope ps(PROF_RNN_PERSIST_BWD, s, flops * rows / B);
       hipLaunchKernelGGL(rnn_persist_bwd_kernel, dim3(8 * wpx), dim3(512), 0, s, L);

@@ -388,7 +388,7 @@ int avsr_rnn_fwd_persistent_pair(const avsr_rnn_stack* st, int32_t n, void* stre
   for (int b0 = 0; b0 < B; b0 += 64) {
     const int rows = B - b0 < 64 ? B - b0 : 64;
     L.b0 = b0; L.ngroups = (rows + 15) / 16;
-    if (hipMemsetAsync(sync + P_HDR, 0, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
+    if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
       ProfScope ps(PROF_RNN_PERSIST_FWD, s, flops * rows / B);
       hipLaunchKernelGGL(rnn_persist_fwd_pair_kernel, dim3(8 * wpx), dim3(256), 0, s, L);

@@ -724,8 +724,8 @@ class Seq2SeqModel:
         if cfg.encoder_type == "unidirectional":
             Lt = E["layers"][("fw", top)]
             if not self.gru:
-                Lt["dcf"].copy_(dc)
-            Lt["dhf"].copy_(dh)
+                ops.copy_(Lt["dcf"], dc)
+            ops.copy_(Lt["dhf"], dh)
             return
         for nm, key, dkey, g in ((("proj", "hf", "dhf", dh),) if self.gru else (("proj_c", "cf", "dcf", dc), ("proj_h", "hf", "dhf", dh))):
             Pm, Gm = self.P[f"{s}/enc/{nm}"], self.Gr[f"{s}/enc/{nm}"]

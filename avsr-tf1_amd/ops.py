@@ -220,6 +220,18 @@ def highway_bwd(x, h, cpre, dy, dh, dcpre, dx, lens, B, T, H, accumulate_dx=Fals
                                 B, T, H, int(accumulate_dx), _s()), "avsr_highway_bwd")
 
 
+def copy_(dst, src):
+    """dst = src (same shape, 4-byte dtype, both contiguous) by an engine kernel -- never a D2D memcpy (see include/avsr_hip.h)."""
+    assert dst.is_cuda and src.is_cuda and dst.numel() == src.numel() and dst.element_size() == 4 and src.element_size() == 4
+    assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype
+    check(_L().avsr_copy_words(dst.data_ptr(), src.data_ptr(), dst.numel(), _s()), "avsr_copy_words")
+
+
+def zero_(dst):
+    assert dst.is_cuda and dst.element_size() == 4 and dst.is_contiguous()
+    check(_L().avsr_zero_words(dst.data_ptr(), dst.numel(), _s()), "avsr_zero_words")
+
+
 def instnorm_fwd(x, y, B, T, F, gamma, beta, mean_out, invstd_out, eps=1e-6):
     check(_L().avsr_instnorm_fwd(fptr(x), fptr(y), B, T, F, fptr(gamma), fptr(beta), fptr(mean_out), fptr(invstd_out), float(eps), _s()),
           "avsr_instnorm_fwd")

@@ -90,15 +90,10 @@ class DataParallelTrainer:
         steps, wrong results, GPU memory faults.  A kernel stays on the compute queue and keeps the stream order."""
         from . import ops
         assert src.shape == dst.shape and src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous()
-        a, b = src.reshape(-1), dst.reshape(-1)
-        if a.element_size() == 4 and a.dtype != torch.float32:
-            a, b = a.view(torch.float32), b.view(torch.float32)          # bit-exact move of int32 payloads
-        if a.dtype != torch.float32:
+        if src.element_size() == 4:
+            ops.copy_(dst, src)                                          # word copy: bit-exact for float32 and int32 alike
+        else:
             dst.copy_(src)
-            return
-        n = a.numel()
-        c = 64 if n % 64 == 0 else (4 if n % 4 == 0 else 1)
-        ops.dropout_rows(ops.mat(a, c), ops.mat(b, c), n // c, c, None, 0, 1.0, c)
 
     def _fwd_bwd(self, batch):
         self.model.forward_train(batch, compute_denom=not self.collective)
@@ -124,12 +119,12 @@ class DataParallelTrainer:
             # global loss normaliser: sum over ALL ranks of min(labels_len, L)
             local = getattr(m, "local_loss_denominator", None)
             if local is not None:
-                m.denom.copy_(local(batch))
+                self._copy_into(m.denom, local(batch))
             else:
                 L = batch.labels.shape[1]
-                m.denom.copy_(batch.labels_len.clamp(0, L).sum().to(torch.float32).reshape(1))
+                m.denom.copy_(batch.labels_len.clamp(0, L).sum().to(torch.float32).reshape(1))   # CPU stand-in models (tests)
             if getattr(m, "dp_norm", None) is not None:      # one collective for both normalisers: sum(mask) and the AU frame count
-                m.au_total.copy_(m.local_au_count(batch))
+                self._copy_into(m.au_total, m.local_au_count(batch))
                 m.au_scale, m.au_external = 1.0, True
                 dist.all_reduce(m.dp_norm)
             else:

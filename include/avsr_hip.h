@@ -461,6 +461,11 @@ int avsr_highway_fwd(const avsr_mat* x, const avsr_mat* h, const avsr_mat* carry
 int avsr_highway_bwd(const avsr_mat* x, const avsr_mat* h, const avsr_mat* carry_pre, const avsr_mat* dy, const avsr_mat* dh,
                      const avsr_mat* dcarry_pre, const avsr_mat* dx, const int32_t* len, int32_t B, int32_t T, int32_t H,
                      int32_t accumulate_dx, void* stream);
+/* dst = src / dst = 0 over n 32-bit words, as KERNELS on the given stream.  The engine (and the host code around captured graphs)
+ * never enqueues hipMemsetAsync / hipMemcpyAsync: as graph memset / memcpy nodes they were not reliably ordered against their
+ * neighbours on ROCm 7.0.  No reference counterpart. */
+int avsr_copy_words(void* dst, const void* src, int64_t n_words, void* stream);
+int avsr_zero_words(void* dst, int64_t n_words, void* stream);
 /* AU regression loss (avsr/encoder.py:173-189); z = pre-sigmoid Dense(2) outputs [B][T][2]. */
 int avsr_au_loss(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz, int32_t B, int32_t T,
                  float weight, void* stream);
