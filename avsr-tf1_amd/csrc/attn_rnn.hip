@@ -402,7 +402,10 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
         a.a = (drop ? d.attd : d.att) + (long)l * A; a.sb = (long)(L + 1) * A; a.K = A; a.w = wt + E; a.ldw = KW; a.kind = SRC_PLAIN;
       }
       StepSrc& h = tk.src[tk.nsrc++];
-      h.a = (gru && phase == 1) ? hbuf(d, 2) /* r*h */ : hbuf(d, l & 1); h.sb = H; h.K = H; h.w = wt + E + A; h.ldw = KW; h.kind = SRC_PLAIN;
+      h.a = (gru && phase == 1) ? hbuf(d, 2) /* r*h */ : hbuf(d, l & 1); h.sb = H; h.K = H; h.w = wt + E + A; h.ldw = KW;
+      // r*h was written by the gate phase of THIS step into this hypothesis' own row: under beam search only the previous state
+      // (h, and the attention fed back) lives in the parent's row
+      h.kind = (gru && phase == 1) ? SRC_OWNROW : SRC_PLAIN;
       tk.B = B; tk.t = l; tk.T = L; tk.reverse = 0; tk.len = d.steplen;
       tk.s2 = (d.mode == 0) ? 1 : 0;
       tk.p4 = hbuf(d, l & 1);

@@ -165,6 +165,13 @@ class OracleConfig:
                 raise NotImplementedError("residual_encoder / highway_encoder: LSTM cells only")
             if self.highway_encoder and self.encoder_weight_sharing:
                 raise NotImplementedError("highway_encoder with encoder_weight_sharing")
+        if self.encoder_weight_sharing:
+            for st in self.streams():
+                u = self.video_units if st == "video" else self.audio_units
+                if len(u) > 2 and (len(set(u[1:])) != 1 or u[0] != u[1]):
+                    raise ValueError("encoder_weight_sharing needs equal layer sizes: layers >= 2 reuse layer 1's kernel")
+                if len(u) > 2 and self.architecture == "av_align" and st == "audio":
+                    raise ValueError("encoder_weight_sharing: the attention-wrapped top layer cannot reuse layer 1's kernel")
         if len(set(self.decoder_units)) != 1:
             raise NotImplementedError("multi-layer decoders: equal layer widths only")
         if len(self.decoder_units) > 1 and self.cell_type != "lstm":
