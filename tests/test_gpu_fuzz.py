@@ -17,7 +17,7 @@ def _sample(rng):
     for _ in range(200):
         arch = rng.choice(["unimodal", "unimodal", "bimodal", "av_align"])
         cell = rng.choice(["lstm", "lstm", "gru"])
-        u = int(rng.choice([16, 32]))
+        u = int(rng.choice([64, 128, 256])) if os.environ.get("AVSR_FUZZ_BIG") else int(rng.choice([16, 32]))
         na, nv = int(rng.integers(1, 4)), int(rng.integers(1, 3))
         kw = dict(architecture=arch, cell_type=cell, encoder_type=rng.choice(["unidirectional", "bidirectional"]),
                   audio_units=(u,) * na, video_units=(u,) * nv if (arch != "unimodal" or rng.random() < 0.3) else None,
@@ -67,6 +67,8 @@ def test_random_configuration(seed):
         if k.endswith(("bias", "/b", "beta")):
             W[k] = (rng.standard_normal(W[k].shape) * 0.1).astype(np.float32)
     B, Ta, Tv, L = int(rng.integers(1, 7)), int(rng.integers(3, 24)), int(rng.integers(2, 10)), int(rng.integers(2, 8))
+    if os.environ.get("AVSR_FUZZ_BIG"):              # sizes at which the persistent encoder kernels (and their 64-row slices) run
+        B, Ta, Tv = int(rng.integers(8, 71)), int(rng.integers(20, 60)), int(rng.integers(8, 20))
     batch = O.synthetic_batch(ocfg, B=B, T_a=Ta, T_v=Tv, L=L, ragged=True)
     r1 = O.train_step(W, None, ocfg, batch)
     r2 = O.train_step(r1["params"], r1["opt"], ocfg, batch)
