@@ -108,3 +108,48 @@ def test_random_configuration(seed):
         for b in np.unique(np.nonzero(out != ref)[0]):
             gaps = np.abs(np.diff(np.sort(score[b])))
             assert gaps.min() < 5e-3, (desc, score[b])
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AVSR_FUZZ_DP_N", "16"))))
+def test_random_configuration_two_shards(seed):
+    """Data-parallel algebra under random options: two engine instances hold unequal shards of a batch, the test plays the collectives
+    (loss normalisers, sync batch-norm phases, gradient sum) exactly as DataParallelTrainer issues them; the summed gradient and the
+    summed loss must be those of one engine on the whole batch."""
+    import dataclasses as dc
+    from avsr_tf1_amd.config import ModelConfig
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    from oracle import avsr_oracle as O
+    rng = np.random.default_rng(5000 + seed)
+    ocfg = dc.replace(_sample(rng), use_dropout=False, sampling_probability=0.0)
+    mcfg = ModelConfig(**{f.name: getattr(ocfg, f.name) for f in dc.fields(ModelConfig) if hasattr(ocfg, f.name)})
+    W = O.init_params(ocfg, seed=seed)
+    B = int(rng.integers(3, 9))
+    batch = O.synthetic_batch(ocfg, B=B, T_a=int(rng.integers(5, 24)), T_v=int(rng.integers(3, 10)), L=int(rng.integers(2, 8)), ragged=True)
+    cut = int(rng.integers(1, B))
+    names = ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len")
+
+    def shard(lo, hi):
+        return Batch.from_numpy(O.Batch(**{k: (None if getattr(batch, k) is None else np.ascontiguousarray(getattr(batch, k)[lo:hi])) for k in names}))
+    whole = Seq2SeqModel(mcfg, weights=W)
+    whole.forward_train(Batch.from_numpy(batch))
+    whole.backward()
+    models, shards = [Seq2SeqModel(mcfg, weights=W) for _ in range(2)], [shard(0, cut), shard(cut, B)]
+    sync = [m.bn_sync_enable() is not None for m in models][0]
+    norm = sum(torch.cat([m.local_loss_denominator(b), m.local_au_count(b)]) for m, b in zip(models, shards))
+    if sync:
+        tot = sum(m.bn_sync_sums(b).clone() for m, b in zip(models, shards))
+        for m in models:
+            m.bn_sync["sum"].copy_(tot)
+        tot = sum(m.bn_sync_squares(b).clone() for m, b in zip(models, shards))
+        for m in models:
+            m.bn_sync["sq"].copy_(tot)
+    for m, b in zip(models, shards):
+        m.dp_norm[:2].copy_(norm)
+        m.au_scale, m.au_external = 1.0, True
+        m.forward_train(b, compute_denom=False)
+        m.backward()
+    torch.cuda.synchronize()
+    g, gw = models[0].grads + models[1].grads, whole.grads
+    desc = repr(ocfg)
+    assert float((g - gw).abs().max()) < 3e-5 * max(1.0, float(gw.abs().max())), (float((g - gw).abs().max()), desc)
+    assert abs(float(models[0].loss.item() + models[1].loss.item()) - float(whole.loss.item())) < 2e-4, desc
