@@ -319,6 +319,18 @@ def main():
                                     "steps": LDEC, "launch": "eager (host-driven early-exit check every 8 steps)"}
         except Exception as e:
             out["greedy_decode"] = {"value": None, "error": repr(e)}
+        try:   # the reference's DEFAULT evaluation algorithm: beam search, width 10 (avsr/avsr.py:58-59)
+            model.beam_search_decode(batch, beam_width=10, max_steps=LDEC)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                model.beam_search_decode(batch, beam_width=10, max_steps=LDEC)
+            torch.cuda.synchronize()
+            dtb = (time.perf_counter() - t0) / 3
+            out["beam_search_decode"] = {"value": round(B / dtb, 2), "unit": "utterances/sec", "ms_per_batch": round(1e3 * dtb, 3),
+                                         "beam_width": 10, "steps": LDEC}
+        except Exception as e:
+            out["beam_search_decode"] = {"value": None, "error": repr(e)}
     if rank == 0 and world == 1 and not args.no_profile and cfg.video_units is not None and args.video_frontend == "features":
         # The same workload fed with 36x36x3 lip crops through the CNN front-end (SURVEY 8(d) allows either video input; the
         # front-end is a "next" row outside north_star's replaced subsystems, so the headline keeps the feature input).
