@@ -161,7 +161,7 @@ def load():
         "avsr_colsum": [C.POINTER(Mat), C.POINTER(Mat), i32, i32, f32, f32, vp, vp, i64, vp],
         "avsr_batchnorm_fwd": [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, i64, vp],
         "avsr_batchnorm_xhat": [vp, vp, vp, vp, i32, i32, vp],
-        "avsr_batchnorm_fwd_ex": [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, vp, i64, vp],
+        "avsr_batchnorm_fwd_ex": [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, f32, f32, i32, i32, vp, i64, vp],
         "avsr_batchnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, i64, vp],
         "avsr_im2col": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
         "avsr_col2im": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],

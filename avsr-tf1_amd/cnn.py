@@ -175,9 +175,12 @@ class LipCNN:
                 _, name, src, dst, c = op
                 h, w, _ = self.shapes[src]
                 mean, invstd = self.bn[name]
+                # seq2seq.py:241-250: the UPDATE_OPS (moving averages) only run with the train op under batch_normalisation=True
+                upd = not training or m.cfg.batch_normalisation
                 ops.batchnorm_fwd_ex(self.maps[src], self.maps[dst], N * h * w, c, self._pv(name + "/gamma"), self._pv(name + "/beta"),
-                                     m._sp(self.pre + name + "/moving_mean"), m._sp(self.pre + name + "/moving_variance"), mean, invstd,
-                                     training, self.BN_EPS, self.BN_MOMENTUM, 1, m.scratch)
+                                     m._sp(self.pre + name + "/moving_mean") if upd else None,
+                                     m._sp(self.pre + name + "/moving_variance") if upd else None, mean, invstd,
+                                     training, self.BN_EPS, self.BN_MOMENTUM, 1, m.scratch, bessel=1)
             elif kind == "add":
                 _, name, a, b, dst = op
                 ops.add(self.maps[a], self.maps[b], self.maps[dst], self.maps[dst].numel())

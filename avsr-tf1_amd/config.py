@@ -69,10 +69,23 @@ class ModelConfig:
             s.append("audio")
         return s
 
-    def shared_layer(self, l: int) -> int:
+    def wrapped(self, stream: str) -> bool:
+        """Do residual_encoder / highway_encoder / encoder_weight_sharing reach this stream's stack?  Only the unidirectional
+        branch of Seq2SeqEncoder hands them to build_rnn_layers (encoder.py:67-78); the bidirectional branch builds _fw_cells /
+        _bw_cells without them (encoder.py:92-108) and so does AttentiveEncoder for the AV-Align audio stack (encoder.py:225-233):
+        there the reference silently ignores the flags, and so does this engine."""
+        return self.encoder_type == "unidirectional" and not (self.architecture == "av_align" and stream == "audio")
+
+    def highway(self, stream: str) -> bool:
+        return self.highway_encoder and self.wrapped(stream)
+
+    def residual(self, stream: str) -> bool:
+        return self.residual_encoder and not self.highway_encoder and self.wrapped(stream)      # cells.py:89-92: highway wins
+
+    def shared_layer(self, stream: str, l: int) -> int:
         """Index of the encoder layer whose variables layer l uses (cells.py:77 quirk: `layer > 1` reuses cell_list[-1], so
         layers 0 and 1 stay distinct and every layer from 2 up is layer 1's cell)."""
-        return 1 if (self.encoder_weight_sharing and l > 1) else l
+        return 1 if (self.encoder_weight_sharing and self.wrapped(stream) and l > 1) else l
 
     def loss_code(self) -> int:
         """avsr_seq_loss_fun's loss_fun argument."""
@@ -140,24 +153,18 @@ class ModelConfig:
         self.loss_code()
         if self.optimiser not in ("Adam", "Nadam", "AdamW", "Momentum"):
             raise Exception('Unsupported optimiser, try Adam')                            # seq2seq.py:218
-        if self.highway_encoder:
-            if self.cell_type != "lstm" or self.encoder_weight_sharing:
+        for st in self.streams():                 # the wrapper flags only where the reference applies them (see `wrapped`)
+            u = self.units(st)
+            if self.highway(st) and (self.cell_type != "lstm" or self.encoder_weight_sharing):
                 raise NotImplementedError("highway_encoder: LSTM cells without weight sharing only")
-        if self.residual_encoder or self.highway_encoder:
-            for st in self.streams():
-                if len(set(self.units(st))) != 1:
+            if self.highway(st) or self.residual(st):
+                if len(set(u)) != 1:
                     raise ValueError("residual_encoder needs equal layer widths")
-                if self.architecture == "av_align" and st == "audio" and len(self.units(st)) > 1:
-                    raise ValueError("residual_encoder: the attention-wrapped top layer cannot be residual (input and output widths differ)")
-            if self.cell_type != "lstm":
-                raise NotImplementedError("residual_encoder: LSTM cells only")
-        if self.encoder_weight_sharing:
-            for st in self.streams():
-                u = self.units(st)
+                if self.cell_type != "lstm":
+                    raise NotImplementedError("residual_encoder: LSTM cells only")
+            if self.encoder_weight_sharing and self.wrapped(st):
                 if len(u) > 2 and (len(set(u[1:])) != 1 or u[0] != u[1]):
                     raise ValueError("encoder_weight_sharing needs equal layer sizes: layers >= 2 reuse layer 1's kernel")
-                if len(u) > 2 and self.architecture == "av_align" and st == "audio":
-                    raise ValueError("encoder_weight_sharing: the attention-wrapped top layer cannot reuse layer 1's kernel")
         if self.video_processing not in ("features", "resnet_cnn"):
             raise Exception("unknown visual content")                                   # avsr/avsr.py:713 (2dconv_cnn / 3dconv_cnn: not built)
         if self.video_units is not None and self.video_processing == "resnet_cnn":

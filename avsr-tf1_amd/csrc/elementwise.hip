@@ -175,7 +175,7 @@ __global__ void bn_partial_sq_kernel(const float* x, const float* mean_v, float*
 // var from the centred-square partials, inverse std, moving-average update (one launch, one block per 32 columns)
 __global__ __launch_bounds__(1024) void bn_var_kernel(const float* part, int npart, const float* mean_v, float* invstd_v, float* mov_mean,
                                                       float* mov_var, int rows, int F, float eps, float momentum,
-                                                      const float* total = nullptr) {
+                                                      int bessel, const float* total = nullptr) {
   if (total) rows = (int)total[0];
   __shared__ double red[32][33];
   const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -192,7 +192,9 @@ __global__ __launch_bounds__(1024) void bn_var_kernel(const float* part, int npa
     const float var = (float)(t / rows), mean = mean_v[f];
     invstd_v[f] = rsqrtf(var + eps);
     if (mov_mean) {
-      const float unbiased = var * ((float)rows / (float)max(1, rows - 1));   // fused BN feeds Bessel-corrected var
+      // bessel = 1: the fused kernel (rank-4 CNN maps) feeds the Bessel-corrected variance to the moving average;
+      // 0: the non-fused path TF 1.13 takes for the rank-3 [B,T,F] encoder input feeds the biased tf.nn.moments variance
+      const float unbiased = bessel ? var * ((float)rows / (float)max(1, rows - 1)) : var;
       mov_mean[f] = momentum * mov_mean[f] + (1.f - momentum) * mean;
       mov_var[f] = momentum * mov_var[f] + (1.f - momentum) * unbiased;
     }
@@ -604,19 +606,19 @@ extern "C" int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, i
 
 extern "C" int avsr_batchnorm_fwd_ex(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta,
                                      float* moving_mean, float* moving_var, float* save_mean, float* save_invstd, int32_t training,
-                                     float eps, float momentum, int32_t relu, float* scratch, int64_t scratch_floats, void* stream);
+                                     float eps, float momentum, int32_t relu, int32_t bessel, float* scratch, int64_t scratch_floats, void* stream);
 
 extern "C" int avsr_batchnorm_fwd(const float* x, float* y, int32_t rows, int32_t F, const float* gamma,
                                   const float* beta, float* moving_mean, float* moving_var, float* save_mean,
                                   float* save_invstd, int32_t training, float* scratch, int64_t scratch_floats,
                                   void* stream) {
   return avsr_batchnorm_fwd_ex(x, y, rows, F, gamma, beta, moving_mean, moving_var, save_mean, save_invstd, training, 1e-3f, 0.99f, 0,
-                               scratch, scratch_floats, stream);
+                               0 /* rank-3 input: non-fused path, biased moving variance */, scratch, scratch_floats, stream);
 }
 
 extern "C" int avsr_batchnorm_fwd_ex(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta,
                                      float* moving_mean, float* moving_var, float* save_mean, float* save_invstd, int32_t training,
-                                     float eps, float momentum, int32_t relu, float* scratch, int64_t scratch_floats, void* stream) {
+                                     float eps, float momentum, int32_t relu, int32_t bessel, float* scratch, int64_t scratch_floats, void* stream) {
   if (!x || !y || !gamma || !beta || rows <= 0 || F <= 0 || !scratch) return AVSR_ERR_ARG;
   if (F % 4) return AVSR_ERR_ARG;
   const int maxblk = 2048;
@@ -640,7 +642,7 @@ extern "C" int avsr_batchnorm_fwd_ex(const float* x, float* y, int32_t rows, int
     hipLaunchKernelGGL(bn_partial_sq_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, mean_v, part, rows, F, rpb);
     AVSR_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_var_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, nblk, mean_v, invstd_v, moving_mean,
-                       moving_var, rows, F, eps, momentum);
+                       moving_var, rows, F, eps, momentum, bessel);
     AVSR_CHECK_LAUNCH();
   } else if (!moving_mean || !moving_var) {
     return AVSR_ERR_ARG;
@@ -705,7 +707,7 @@ extern "C" int avsr_batchnorm_sync_apply(const float* x, float* y, int32_t rows,
   if (!x || !y || !gamma || !beta || !mean || !sq_global || !total_rows || !invstd_out || rows <= 0 || F <= 0 || F % 4)
     return AVSR_ERR_ARG;
   hipLaunchKernelGGL(bn_var_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), sq_global, 1, mean, invstd_out, moving_mean,
-                     moving_var, 1, F, eps, momentum, total_rows);
+                     moving_var, 1, F, eps, momentum, 0, total_rows);
   AVSR_CHECK_LAUNCH();
   const long n4 = (long)rows * F / 4;
   int blocks = (int)((n4 + 255) / 256);

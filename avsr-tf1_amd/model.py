@@ -250,12 +250,12 @@ class Seq2SeqModel:
                         Ld["dout"] = SeqBuf(B, T, u, 1, 1, dev) if (attentive and l == nplain - 1) else None
                     if self.gru:
                         Ld["rh"], Ld["dpc"] = z(B, T, u), z(B, T, u)
-                    if cfg.use_dropout or (cfg.residual_encoder and not cfg.highway_encoder and l > 0):
+                    if cfg.use_dropout or (cfg.residual(s) and l > 0):
                         Ld["hs_seq"] = SeqBuf(B, T, u, 1, 1, dev)   # the recurrent h as consumed (residual: the output record holds h + x)
                     if cfg.use_dropout:
                         if not top or attentive:
                             Ld["xt_seq"] = SeqBuf(B, T, u, 1, 1, dev)
-                    if cfg.highway_encoder:
+                    if cfg.highway(s):
                         # HighwayWrapper stacks run layer by layer (every input projection hoisted): `out` is the layer's emitted
                         # (highway) output, `hout` the cell's own output, `dy` / `dhout` their gradients, cpre the carry pre-activation
                         Ld["dy"] = E["dmem"] if top else SeqBuf(B, T, u, 1, 1, dev)
@@ -376,22 +376,22 @@ class Seq2SeqModel:
         for l in range(E["nplain"]):
             u = E["units"][l]
             Ld = E["layers"][(d, l)]
-            name, bname = self._kn(f"{s}/enc/{d}/l{cfg.shared_layer(l)}")
+            name, bname = self._kn(f"{s}/enc/{d}/l{cfg.shared_layer(s, l)}")
             Ly = st.layer[l]
             Ly.units, Ly.in_dim, Ly.hoisted, Ly.out_col = u, i, int(l == 0), Ld["col"]
             Ly.wt = ops.fptr(self.derived, self.Tr[name].off)
             Ly.w = ops.fptr(self.params, self.P[name].off)
             Ly.bias = ops.fptr(self.params, self.P[bname].off)
             if self.gru:
-                cn = f"{s}/enc/{d}/l{cfg.shared_layer(l)}/cand_kernel"
+                cn = f"{s}/enc/{d}/l{cfg.shared_layer(s, l)}/cand_kernel"
                 Ly.wt2, Ly.w2 = ops.fptr(self.derived, self.Tr[cn].off), ops.fptr(self.params, self.P[cn].off)
-                Ly.bias2 = ops.fptr(self.params, self.P[f"{s}/enc/{d}/l{cfg.shared_layer(l)}/cand_bias"].off)
+                Ly.bias2 = ops.fptr(self.params, self.P[f"{s}/enc/{d}/l{cfg.shared_layer(s, l)}/cand_bias"].off)
                 Ly.rh_seq, Ly.dgates2 = ops.fptr(Ld["rh"]), ops.fptr(Ld["dpc"])
             Ly.gates, Ly.cs = ops.fptr(Ld["gates"]), ops.fptr(Ld["cs"])
             Ly.out, Ly.ld_out = ops.fptr(Ld["out"].t), Ld["out"].D
             Ly.state, Ly.h_final, Ly.c_final = ops.fptr(Ld["state"]), ops.fptr(Ld["hf"]), ops.fptr(Ld["cf"])
             Ly.dgates, Ly.dstate = ops.fptr(Ld["dgates"]), ops.fptr(Ld["dstate"])
-            Ly.residual = int(cfg.residual_encoder and not cfg.highway_encoder and l > 0)
+            Ly.residual = int(cfg.residual(s) and l > 0)
             if drop or Ly.residual:
                 Ly.hs_seq = ops.fptr(Ld["hs_seq"].t)
             if drop:
@@ -451,10 +451,11 @@ class Seq2SeqModel:
 
     def _encode_highway(self, ws, B):
         cfg = self.cfg
-        nmax = max(ws["enc"][s]["nplain"] for s in cfg.streams())
+        hw_streams = [s for s in cfg.streams() if cfg.highway(s)]
+        nmax = max(ws["enc"][s]["nplain"] for s in hw_streams)
         for l in range(nmax):
             stacks = []
-            for s in cfg.streams():
+            for s in hw_streams:
                 E = ws["enc"][s]
                 if l >= E["nplain"]:
                     continue
@@ -473,7 +474,7 @@ class Seq2SeqModel:
             self._run_stacks(stacks, ops.rnn_fwd)
             if l == 0:
                 continue
-            for s in cfg.streams():
+            for s in hw_streams:
                 E = ws["enc"][s]
                 if l >= E["nplain"]:
                     continue
@@ -488,10 +489,11 @@ class Seq2SeqModel:
     def _encode_highway_backward(self, ws, B):
         """Top-down, layer by layer: highway gate backward, one-layer BPTT, weight gradients, input gradient into the layer below."""
         cfg = self.cfg
-        nmax = max(ws["enc"][s]["nplain"] for s in cfg.streams())
+        hw_streams = [s for s in cfg.streams() if cfg.highway(s)]
+        nmax = max(ws["enc"][s]["nplain"] for s in hw_streams)
         for l in reversed(range(nmax)):
             stacks = []
-            for s in cfg.streams():
+            for s in hw_streams:
                 E = ws["enc"][s]
                 if l >= E["nplain"]:
                     continue
@@ -511,7 +513,7 @@ class Seq2SeqModel:
                         ops.gemm(ops.mat(Ld["dcpre"], u), self.P[pre + "/carry_w"].mat(u), dy_below, B * T, u, u, trans_b=1, beta=1.0)
                     stacks.append(self._rnn_stack_single(ws, s, d, l, B, E["len"], backward=True))
             self._run_stacks(stacks, ops.rnn_bwd)
-            for s in cfg.streams():
+            for s in hw_streams:
                 E = ws["enc"][s]
                 if l >= E["nplain"]:
                     continue
@@ -630,7 +632,7 @@ class Seq2SeqModel:
                     ops.selu(Dn["z"], Dn["a"], B * T * u)
                     a_prev, w_prev = Dn["a"], u
                 E["xin0"], E["dxin0"] = a_prev, E["dense"][-1]["da"]
-            if E["nplain"] == 0 or cfg.highway_encoder:
+            if E["nplain"] == 0 or cfg.highway(s):
                 continue
             for d in cfg.directions():
                 u0 = E["units"][0]
@@ -646,7 +648,7 @@ class Seq2SeqModel:
                     ops.gemm(ops.mat(xin, F0), self.P[f"{s}/enc/{d}/l0/cand_kernel"].mat(u0), ops.mat(E["layers"][(d, 0)]["cs"], u0), B * T, u0, F0)
                 stacks.append(self._rnn_stack(ws, s, d, B, len_t))
         self._run_stacks(stacks, ops.rnn_fwd)
-        if cfg.highway_encoder:
+        if any(cfg.highway(s) for s in cfg.streams()):
             self._encode_highway(ws, B)
         for s in cfg.streams():
             E = ws["enc"][s]
@@ -749,12 +751,12 @@ class Seq2SeqModel:
         stacks = []
         for s in cfg.streams():
             E = ws["enc"][s]
-            if E["nplain"] == 0 or cfg.highway_encoder:
+            if E["nplain"] == 0 or cfg.highway(s):
                 continue
             for d in cfg.directions():
                 stacks.append(self._rnn_stack(ws, s, d, B, E["len"], backward=True))
         self._run_stacks(stacks, ops.rnn_bwd)
-        if cfg.highway_encoder:
+        if any(cfg.highway(s) for s in cfg.streams()):
             self._encode_highway_backward(ws, B)
         for s in cfg.streams():
             E = ws["enc"][s]
@@ -762,10 +764,10 @@ class Seq2SeqModel:
             first = True
             for d in cfg.directions():
                 i = F0
-                for l in range(0 if cfg.highway_encoder else E["nplain"]):
+                for l in range(0 if cfg.highway(s) else E["nplain"]):
                     u = E["units"][l]
                     Ld = E["layers"][(d, l)]
-                    kname, bname = self._kn(f"{s}/enc/{d}/l{cfg.shared_layer(l)}")
+                    kname, bname = self._kn(f"{s}/enc/{d}/l{cfg.shared_layer(s, l)}")
                     Gk = self.Gr[kname]
                     G = self.G
                     dg = ops.mat(Ld["dgates"], G * u)
@@ -778,15 +780,15 @@ class Seq2SeqModel:
                         a_x = E["layers"][(d, l - 1)]["out"].mat(0, E["layers"][(d, l - 1)]["col"])
                     self._gemm_tn(a_x, dg, Gk.mat(G * u), i, G * u, B * T)
                     sh = 1 if d == "bw" else -1
-                    a_h = Ld["hs_seq"].mat(sh) if (drop or (cfg.residual_encoder and l > 0)) else Ld["out"].mat(sh, Ld["col"])
+                    a_h = Ld["hs_seq"].mat(sh) if (drop or (cfg.residual(s) and l > 0)) else Ld["out"].mat(sh, Ld["col"])
                     self._gemm_tn(a_h, dg, Gk.mat(G * u, row0=i), u, G * u, B * T)
                     ops.colsum(dg, B * T, G * u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
                     if self.gru:                 # candidate kernel: inputs [x ; r*h]
-                        Gc = self.Gr[f"{s}/enc/{d}/l{cfg.shared_layer(l)}/cand_kernel"]
+                        Gc = self.Gr[f"{s}/enc/{d}/l{cfg.shared_layer(s, l)}/cand_kernel"]
                         dpc = ops.mat(Ld["dpc"], u)
                         self._gemm_tn(a_x, dpc, Gc.mat(u), i, u, B * T)
                         self._gemm_tn(ops.mat(Ld["rh"], u), dpc, Gc.mat(u, row0=i), u, u, B * T)
-                        ops.colsum(dpc, B * T, u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/enc/{d}/l{cfg.shared_layer(l)}/cand_bias"].off)
+                        ops.colsum(dpc, B * T, u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/enc/{d}/l{cfg.shared_layer(s, l)}/cand_bias"].off)
                     i = u
                 if E["nplain"] > 0 and (cfg.batch_normalisation or "cnn" in E or self.n_dense or cfg.instance_normalisation):
                     u0, G = E["units"][0], self.G

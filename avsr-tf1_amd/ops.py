@@ -296,10 +296,10 @@ def rnn_persistent_error():
 
 
 # ---- lip-crop CNN front-end helpers (csrc/conv.hip) -------------------------------------------------------------------
-def batchnorm_fwd_ex(x, y, rows, F, gamma, beta, mov_mean, mov_var, save_mean, save_invstd, training, eps, momentum, relu, scratch):
+def batchnorm_fwd_ex(x, y, rows, F, gamma, beta, mov_mean, mov_var, save_mean, save_invstd, training, eps, momentum, relu, scratch, bessel=1):
     check(_L().avsr_batchnorm_fwd_ex(fptr(x), fptr(y), rows, F, fptr(gamma), fptr(beta), fptr(mov_mean), fptr(mov_var), fptr(save_mean),
-                                     fptr(save_invstd), int(training), float(eps), float(momentum), int(relu), fptr(scratch), scratch.numel(),
-                                     _s()), "avsr_batchnorm_fwd_ex")
+                                     fptr(save_invstd), int(training), float(eps), float(momentum), int(relu), int(bessel), fptr(scratch),
+                                     scratch.numel(), _s()), "avsr_batchnorm_fwd_ex")
 
 
 def batchnorm_bwd(x, dy, gamma, beta, mean, invstd, dx, dgamma, dbeta, rows, F, relu, scratch, dx_beta=0.0):

@@ -88,9 +88,9 @@ def inventory(cfg: ModelConfig):
             i = cfg.layer0_in(stream)
             for l, u in enumerate(units):
                 extra = units[-1] if (attentive and l == len(units) - 1) else 0
-                if cfg.shared_layer(l) == l:                  # encoder_weight_sharing: layers >= 2 own no variables
+                if cfg.shared_layer(stream, l) == l:                  # encoder_weight_sharing: layers >= 2 own no variables
                     _cell(inv, cfg, f"{stream}/enc/{d}/l{l}", i + extra, u)
-                if cfg.highway_encoder and l > 0 and not extra:   # HighwayWrapper carry gate over the layer's input (cells.py:89-90)
+                if cfg.highway(stream) and l > 0:   # HighwayWrapper carry gate over the layer's input (cells.py:89-90)
                     inv[f"{stream}/enc/{d}/l{l}/carry_w"] = ((i, i), "plain", "glorot")
                     inv[f"{stream}/enc/{d}/l{l}/carry_b"] = ((i,), "plain", "ones")
                 i = u

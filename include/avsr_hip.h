@@ -350,20 +350,25 @@ int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, int32_t F, f
                 float* scratch, int64_t scratch_floats, void* stream);
 
 /* tf.layers.batch_normalization(axis=-1, momentum=.99, eps=1e-3) over `rows` = B*T rows incl. padding
- * (avsr/encoder.py:44-50).  training=1: batch statistics + moving-average update; 0: moving statistics. */
+ * (avsr/encoder.py:44-50).  training=1: batch statistics + moving-average update; 0: moving statistics.
+ * The input is rank 3, so TF 1.13 drops `fused=True` and the moving variance takes the BIASED batch variance.
+ * moving_mean / moving_var may be NULL in training (no update: seq2seq.py:241-250 runs UPDATE_OPS only under
+ * batch_normalisation=True). */
 int avsr_batchnorm_fwd(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta,
                        float* moving_mean, float* moving_var, float* save_mean, float* save_invstd, int32_t training,
                        float* scratch, int64_t scratch_floats, void* stream);
 /* As avsr_batchnorm_fwd with explicit epsilon / momentum and an optional fused ReLU: batch_norm_relu of the lip-crop CNN
- * (avsr/video.py:4-14: epsilon 1e-5, momentum 0.98) and any tf.layers.batch_normalization(axis=-1) over [rows, F]. */
+ * (avsr/video.py:4-14: epsilon 1e-5, momentum 0.98) and any tf.layers.batch_normalization(axis=-1) over [rows, F].
+ * bessel=1 restates the fused kernel (rank-4 inputs): the moving variance takes var * rows / (rows - 1). */
 int avsr_batchnorm_fwd_ex(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta,
                           float* moving_mean, float* moving_var, float* save_mean, float* save_invstd, int32_t training,
-                          float eps, float momentum, int32_t relu, float* scratch, int64_t scratch_floats, void* stream);
+                          float eps, float momentum, int32_t relu, int32_t bessel, float* scratch, int64_t scratch_floats,
+                          void* stream);
 /* Sync batch-norm across data-parallel ranks (SURVEY 8(e) collective (3); statistics of encoder.py:44-50 over the
  * GLOBAL batch).  Three local phases; the host all-reduces sum_out (with the row count) after the first and sq_out
  * after the second:  (1) sum_out[f] = sum_rows x;  (2) mean_out = sum_global / total_rows[0], sq_out[f] = sum_rows
- * (x - mean)^2;  (3) invstd = rsqrt(sq_global / total + eps), moving-average update with the Bessel-corrected global
- * variance, y = (x - mean) * invstd * gamma + beta.  total_rows is a DEVICE float (the all-reduced count). */
+ * (x - mean)^2;  (3) invstd = rsqrt(sq_global / total + eps), moving-average update with the (biased, rank-3
+ * non-fused path) global variance, y = (x - mean) * invstd * gamma + beta.  total_rows is a DEVICE float (the all-reduced count). */
 int avsr_batchnorm_sync_sum(const float* x, int32_t rows, int32_t F, float* sum_out, float* scratch, int64_t scratch_floats,
                             void* stream);
 int avsr_batchnorm_sync_sqsum(const float* x, int32_t rows, int32_t F, const float* sum_global, const float* total_rows,

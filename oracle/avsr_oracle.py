@@ -133,6 +133,23 @@ class OracleConfig:
             return False
         return mems[-1][1] in LUONG_TYPES
 
+    def wrapped(self, stream: str) -> bool:
+        """Do residual_encoder / highway_encoder / encoder_weight_sharing reach this stream's stack?  Only the unidirectional
+        branch of Seq2SeqEncoder hands them to build_rnn_layers (encoder.py:67-78); the bidirectional branch builds _fw_cells /
+        _bw_cells without them (encoder.py:92-108) and so does AttentiveEncoder for the AV-Align audio stack (encoder.py:225-233):
+        there the flags are silently inert."""
+        return self.encoder_type == "unidirectional" and not (self.architecture == "av_align" and stream == "audio")
+
+    def highway(self, stream: str) -> bool:
+        return self.highway_encoder and self.wrapped(stream)
+
+    def residual(self, stream: str) -> bool:
+        return self.residual_encoder and not self.highway_encoder and self.wrapped(stream)      # cells.py:89-92: highway wins
+
+    def shared_layer(self, stream: str, l: int) -> int:
+        """cells.py:77: `layer > 1 and weight_sharing` reuses cell_list[-1] -> layers >= 2 are layer 1's cell object."""
+        return 1 if (self.encoder_weight_sharing and self.wrapped(stream) and l > 1) else l
+
     def validate(self):
         if self.architecture == "lm":                                     # avsr.LM (lm.py:275-471): labels only
             if self.video_units is not None or self.audio_units is not None:
@@ -154,24 +171,18 @@ class OracleConfig:
                 raise ValueError("AttentiveEncoder implements only unidirectional")  # encoder.py:229
             if self.video_units is None or self.audio_units is None:
                 raise ValueError("av_align needs both streams")
-        if self.residual_encoder or self.highway_encoder:
-            for st in self.streams():
-                u = self.video_units if st == "video" else self.audio_units
+        for st in self.streams():
+            u = self.video_units if st == "video" else self.audio_units
+            if self.highway(st) or self.residual(st):
                 if len(set(u)) != 1:
                     raise ValueError("residual_encoder needs equal layer widths")
-                if self.architecture == "av_align" and st == "audio" and len(u) > 1:
-                    raise ValueError("residual_encoder: the attention-wrapped top layer cannot be residual (input and output widths differ)")
-            if self.cell_type != "lstm":
-                raise NotImplementedError("residual_encoder / highway_encoder: LSTM cells only")
-            if self.highway_encoder and self.encoder_weight_sharing:
-                raise NotImplementedError("highway_encoder with encoder_weight_sharing")
-        if self.encoder_weight_sharing:
-            for st in self.streams():
-                u = self.video_units if st == "video" else self.audio_units
+                if self.cell_type != "lstm":
+                    raise NotImplementedError("residual_encoder / highway_encoder: LSTM cells only")
+                if self.highway(st) and self.encoder_weight_sharing:
+                    raise NotImplementedError("highway_encoder with encoder_weight_sharing")
+            if self.encoder_weight_sharing and self.wrapped(st):
                 if len(u) > 2 and (len(set(u[1:])) != 1 or u[0] != u[1]):
                     raise ValueError("encoder_weight_sharing needs equal layer sizes: layers >= 2 reuse layer 1's kernel")
-                if len(u) > 2 and self.architecture == "av_align" and st == "audio":
-                    raise ValueError("encoder_weight_sharing: the attention-wrapped top layer cannot reuse layer 1's kernel")
         if len(set(self.decoder_units)) != 1:
             raise NotImplementedError("multi-layer decoders: equal layer widths only")
         if len(self.decoder_units) > 1 and self.cell_type != "lstm":
@@ -299,7 +310,7 @@ def cnn_forward(P, cfg: OracleConfig, frames: Tensor, training: bool, updates: O
             maps[a["dst"]] = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w, P[pre + "/bias"], stride=a["s"])
         elif kind == "bnrelu":
             x = maps[a["src"]].permute(0, 2, 3, 1)                 # channels last for the statistics
-            y = batch_norm(x, P, pre, training, updates, eps=1e-5, momentum=0.98)
+            y = batch_norm(x, P, pre, training, updates, eps=1e-5, momentum=0.98, fused=True)   # rank 4: the fused kernel
             maps[a["dst"]] = torch.relu(y).permute(0, 3, 1, 2)
         elif kind == "add":
             maps[a["dst"]] = maps[a["a"]] + maps[a["b"]]
@@ -342,9 +353,9 @@ def init_params(cfg: OracleConfig, seed: int = 2001) -> Dict[str, np.ndarray]:
             in_dim = cfg.layer0_in(stream)
             for l, u in enumerate(units):
                 extra = units[-1] if (attentive and l == len(units) - 1) else 0   # + attention feedback
-                if not (cfg.encoder_weight_sharing and l > 1):                     # shared layers own no variables
+                if cfg.shared_layer(stream, l) == l:                               # shared layers own no variables
                     _cell_params(rng, cfg, f"{stream}/enc/{d}/l{l}", in_dim + extra, u, P)
-                if cfg.highway_encoder and l > 0 and not extra:                    # HighwayWrapper's carry gate over the layer input
+                if cfg.highway(stream) and l > 0:                                  # HighwayWrapper's carry gate over the layer input
                     P[f"{stream}/enc/{d}/l{l}/carry_w"] = _glorot_uniform(rng, (in_dim, in_dim))
                     P[f"{stream}/enc/{d}/l{l}/carry_b"] = np.ones((in_dim,), np.float32)
                 in_dim = u
@@ -636,7 +647,7 @@ def attention_wrapper_step(cell: _Cell, mechs: List[_Mechanism], output_attentio
 # encoders
 # ----------------------------------------------------------------------------------------
 def batch_norm(x: Tensor, P, prefix: str, training: bool, updates: Optional[dict], eps: float = 1e-3, momentum: float = 0.99,
-               stats=None):
+               stats=None, fused: bool = False):
     """tf.layers.batch_normalization(axis=-1, fused=True), momentum .99 eps 1e-3 (encoder.py:44-50); the CNN front-end
     uses momentum .98 eps 1e-5 (video.py:8-11).  Statistics over all rows INCLUDING zero padding."""
     if training:
@@ -648,7 +659,10 @@ def batch_norm(x: Tensor, P, prefix: str, training: bool, updates: Optional[dict
             var = ((flat - mean) ** 2).mean(dim=0)
             n = flat.shape[0]
         if updates is not None:
-            unbiased = var.detach() * (n / max(1, n - 1))       # fused kernel feeds Bessel-corrected var to the moving average
+            # TF 1.13 keras BatchNormalization.build: `fused=True` survives only for rank-4 inputs (the CNN maps, video.py:8-12);
+            # the rank-3 [B,T,F] encoder input (encoder.py:44-50) silently falls back to the non-fused path, whose moving variance
+            # takes the BIASED batch variance of tf.nn.moments.  The fused kernel feeds the Bessel-corrected one.
+            unbiased = var.detach() * (n / max(1, n - 1)) if fused else var.detach()
             updates[prefix + "/moving_mean"] = momentum * P[prefix + "/moving_mean"] + (1 - momentum) * mean.detach()
             updates[prefix + "/moving_variance"] = momentum * P[prefix + "/moving_variance"] + (1 - momentum) * unbiased
     else:
@@ -684,27 +698,28 @@ def _map_state(fn, new, old):
     return tuple(_map_state(fn, n, o) for n, o in zip(new, old))
 
 
-def _wrap_output(cfg, P, prefix: str, l: int, x: Tensor, y: Tensor) -> Tensor:
+def _wrap_output(wrap, P, prefix: str, l: int, x: Tensor, y: Tensor) -> Tensor:
     """cells.py:89-92 for layer l > 0: HighwayWrapper (tf.contrib.rnn.HighwayWrapper defaults: coupled gates, carry bias init 1.0:
     carry = sigmoid(x W_c + b_c); out = x * carry + y * (1 - carry)) takes precedence over ResidualWrapper (out = y + x).
     x is the layer's RAW input, y the (dropout-wrapped) cell's output.  (rnn_cell.py of TF r1.13, recalled.)"""
-    if l == 0:
+    if l == 0 or wrap is None:
         return y
-    if cfg.highway_encoder:
+    if wrap == "highway":
         carry = torch.sigmoid(x @ P[f"{prefix}/l{l}/carry_w"] + P[f"{prefix}/l{l}/carry_b"])
         return x * carry + y * (1.0 - carry)
-    if cfg.residual_encoder:
+    if wrap == "residual":
         return y + x
     return y
 
 
-def _stack_step(cells: List[_Cell], cfg=None, P=None, prefix: str = ""):
-    """MultiRNNCell step with the optional Highway / Residual wrappers around every cell but the first."""
+def _stack_step(cells: List[_Cell], wrap=None, P=None, prefix: str = ""):
+    """MultiRNNCell step; wrap in (None, "highway", "residual") = the wrapper cells.py:89-92 puts around every cell but the first
+    (unidirectional Seq2SeqEncoder stacks only: OracleConfig.wrapped)."""
     def step(x, states, t=0):
         new_states = []
         for l, (c, s) in enumerate(zip(cells, states)):
             y, ns = c(x, s, t)
-            x = _wrap_output(cfg, P, prefix, l, x, y) if cfg is not None else y
+            x = _wrap_output(wrap, P, prefix, l, x, y)
             new_states.append(ns)
         return x, tuple(new_states)
     return step
@@ -719,8 +734,7 @@ class EncoderOut:
 
 def _make_cells(P, cfg: OracleConfig, stream: str, direction: str, units, training: bool, seed: int, T: int, lens: Tensor):
     # encoder_weight_sharing (cells.py:77): `layer > 1` reuses the previous cell object -> layers >= 2 share layer 1's variables
-    shared = lambda l: 1 if (cfg.encoder_weight_sharing and l > 1) else l
-    cells = [_Cell(P, f"{stream}/enc/{direction}/l{shared(l)}", cfg.cell_type, u) for l, u in enumerate(units)]
+    cells = [_Cell(P, f"{stream}/enc/{direction}/l{cfg.shared_layer(stream, l)}", cfg.cell_type, u) for l, u in enumerate(units)]
     if cfg.use_dropout and training:                                  # cells.py:46: only in the train graph
         keep = cfg.video_dropout if stream == "video" else cfg.audio_dropout
         for l, c in enumerate(cells):
@@ -757,7 +771,7 @@ def encode_stream(P, cfg: OracleConfig, stream: str, x: Tensor, lens: Tensor, tr
             new_lower = []
             for l, (c, s) in enumerate(zip(cells[:-1], lower)):
                 y_t, ns = c(x_t, s, t)
-                x_t = _wrap_output(cfg, P, f"{stream}/enc/fw", l, x_t, y_t)
+                x_t = y_t                                       # encoder.py:225-233: no wrappers on the AttentiveEncoder's cells
                 new_lower.append(ns)
             out, ns, new_att, al = attention_wrapper_step(cells[-1], [mech], out_att, x_t, top_state, att, t)
             aligns.append(al[0])
@@ -769,13 +783,14 @@ def encode_stream(P, cfg: OracleConfig, stream: str, x: Tensor, lens: Tensor, tr
         return EncoderOut(outs, st[1][0], torch.stack(aligns, dim=1))
     if cfg.encoder_type == "unidirectional":
         cells = _make_cells(P, cfg, stream, "fw", units, training, seed, T, lens)
-        outs, st = dynamic_rnn(_stack_step(cells, cfg, P, f"{stream}/enc/fw"), tuple(c.zero_state(B, dtype) for c in cells), x, lens)
+        wrap = "highway" if cfg.highway(stream) else "residual" if cfg.residual(stream) else None   # encoder.py:67-78
+        outs, st = dynamic_rnn(_stack_step(cells, wrap, P, f"{stream}/enc/fw"), tuple(c.zero_state(B, dtype) for c in cells), x, lens)
         return EncoderOut(outs, st[-1])
     # bidirectional: two independent stacks, concat at the top only (encoder.py:92-121)
     fw = _make_cells(P, cfg, stream, "fw", units, training, seed, T, lens)
     bw = _make_cells(P, cfg, stream, "bw", units, training, seed, T, lens)
-    o_fw, s_fw = dynamic_rnn(_stack_step(fw, cfg, P, f"{stream}/enc/fw"), tuple(c.zero_state(B, dtype) for c in fw), x, lens)
-    o_bw, s_bw = dynamic_rnn(_stack_step(bw, cfg, P, f"{stream}/enc/bw"), tuple(c.zero_state(B, dtype) for c in bw),
+    o_fw, s_fw = dynamic_rnn(_stack_step(fw), tuple(c.zero_state(B, dtype) for c in fw), x, lens)
+    o_bw, s_bw = dynamic_rnn(_stack_step(bw), tuple(c.zero_state(B, dtype) for c in bw),
                              _reverse_sequence(x, lens), lens)
     o_bw = _reverse_sequence(o_bw, lens)
     outs = torch.cat([o_fw, o_bw], dim=-1)
@@ -1036,8 +1051,9 @@ def train_step(P_np: Dict[str, np.ndarray], opt: Optional[dict], cfg: OracleConf
             p0 = p0 - cfg.weight_decay * p0
         num = b1 * mm + (1 - b1) * g if cfg.optimiser == "Nadam" else mm      # NadamOptimizer: ApplyAdam(use_nesterov=True)
         newP[k] = (p0 - lr_t * num / (np.sqrt(vv) + eps)).astype(P_np[k].dtype)
-    for k, v in m.bn_updates.items():
-        newP[k] = v.detach().numpy().astype(P_np[k].dtype)
+    if cfg.batch_normalisation:                             # seq2seq.py:241-250: UPDATE_OPS ride with the train op only then
+        for k, v in m.bn_updates.items():                   # (the CNN's batch norms exist either way; their moving stats then stay put)
+            newP[k] = v.detach().numpy().astype(P_np[k].dtype)
     return {"loss": float(loss.detach()), "seq_loss": float(seq.detach()), "global_norm": float(gnorm.detach()),
             "grads": {k: g.detach().numpy() for k, g in grads.items()}, "params": newP, "opt": new_opt,
             "logits": logits.detach().numpy(), "fed_tokens": m.fed_tokens}

@@ -69,8 +69,11 @@ CASES = {
     # encoder_weight_sharing (cells.py:77): layers >= 2 reuse layer 1's variables; their gradients accumulate
     "weight_sharing_uni4": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32, 32, 32),
                                 encoder_weight_sharing=True),
-    "weight_sharing_bi_gru": dict(architecture="unimodal", encoder_type="bidirectional", video_units=(16, 16, 16), audio_units=None,
-                                  cell_type="gru", encoder_weight_sharing=True, attention_type=(("bahdanau",), ("bahdanau",))),
+    "weight_sharing_uni_gru": dict(architecture="unimodal", encoder_type="unidirectional", video_units=(16, 16, 16), audio_units=None,
+                                   cell_type="gru", encoder_weight_sharing=True, attention_type=(("bahdanau",), ("bahdanau",))),
+    # ... and is silently ignored on bidirectional stacks (encoder.py:92-108 does not pass it): every layer owns its variables
+    "weight_sharing_bi_gru_inert": dict(architecture="unimodal", encoder_type="bidirectional", video_units=(16, 16, 16), audio_units=None,
+                                        cell_type="gru", encoder_weight_sharing=True, attention_type=(("bahdanau",), ("bahdanau",))),
     # multi-layer decoder cells (MultiRNNCell under the AttentionWrapper; decoder_unimodal.py:101-108, :151-157): layer 0 starts from
     # the encoder state, the layers above from zero; the TOP layer's output queries the attention
     "dec2_unimodal": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32),
@@ -83,8 +86,13 @@ CASES = {
     # residual_encoder (cells.py:91-92): ResidualWrapper on encoder layers > 0; those stacks run through the per-step launches
     "residual_uni3": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32, 32),
                           residual_encoder=True),
-    "residual_bimodal_bi": dict(architecture="bimodal", encoder_type="bidirectional", video_units=(16, 16), audio_units=(16, 16, 16),
-                                decoder_units=(32,), residual_encoder=True),
+    "residual_bimodal_uni": dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32, 32), audio_units=(32, 32, 32),
+                                 decoder_units=(32,), residual_encoder=True),
+    # inert on bidirectional stacks (encoder.py:92-108) -- unequal widths are therefore fine -- and on the AV-Align audio stack (:225-233)
+    "residual_bimodal_bi_inert": dict(architecture="bimodal", encoder_type="bidirectional", video_units=(16, 16), audio_units=(16, 32, 16),
+                                      decoder_units=(32,), residual_encoder=True),
+    "residual_av_align_audio_inert": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32, 32), audio_units=(16, 32, 32),
+                                          residual_encoder=True, encoder_weight_sharing=True),
     # instance_normalisation (encoder.py:51-55): contrib.layers.instance_norm over the time axis, after the batch norm
     "instnorm_bimodal": dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
                              instance_normalisation=True, regress_aus=True),
@@ -101,10 +109,14 @@ CASES = {
     # highway_encoder (cells.py:89-90): HighwayWrapper on encoder layers > 0; those encoders run layer by layer with hoisted inputs
     "highway_uni3": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32, 32),
                          highway_encoder=True),
-    "highway_bimodal_bi": dict(architecture="bimodal", encoder_type="bidirectional", video_units=(16, 16), audio_units=(16, 16, 16),
-                               decoder_units=(32,), highway_encoder=True, regress_aus=True),
+    "highway_bimodal_uni": dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32, 32), audio_units=(32, 32, 32),
+                                decoder_units=(32,), highway_encoder=True, regress_aus=True),
+    "highway_bimodal_bi_inert": dict(architecture="bimodal", encoder_type="bidirectional", video_units=(16, 16), audio_units=(16, 16, 16),
+                                     decoder_units=(32,), highway_encoder=True, regress_aus=True),
     "highway_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32, 32), audio_units=(32,),
                              highway_encoder=True, residual_encoder=True),
+    "highway_av_align_audio3": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32, 32), audio_units=(16, 32, 32),
+                                    highway_encoder=True),       # video stack highway, the 3-layer audio stack plain
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
@@ -228,12 +240,12 @@ STOCH = [
     ("dec2_lm", dict(use_dropout=True, sampling_probability=0.1)),
     ("residual_uni3", dict(use_dropout=True)),
     ("highway_uni3", dict(use_dropout=True, sampling_probability=0.2)),
-    ("highway_bimodal_bi", dict(use_dropout=True, video_dropout=(0.8, 0.9, 0.7))),
+    ("highway_bimodal_uni", dict(use_dropout=True, video_dropout=(0.8, 0.9, 0.7))),
     ("opt_nadam", dict(use_dropout=True)),
     ("opt_adamw", dict(use_dropout=True)),
     ("opt_momentum", dict(use_dropout=True)),
     ("instnorm_bimodal", dict(use_dropout=True, sampling_probability=0.2)),
-    ("residual_bimodal_bi", dict(use_dropout=True, audio_dropout=(0.8, 0.9, 0.7))),
+    ("residual_bimodal_uni", dict(use_dropout=True, audio_dropout=(0.8, 0.9, 0.7))),
 ]
 
 

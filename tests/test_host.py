@@ -114,8 +114,19 @@ def test_config_validation_errors_follow_the_reference():
         ModelConfig(optimiser="SGD").validate()                                           # seq2seq.py:218
     with pytest.raises(ValueError, match="residual_encoder needs equal layer widths"):
         ModelConfig(residual_encoder=True, audio_units=(128, 256)).validate()
-    with pytest.raises(ValueError, match="attention-wrapped top layer"):
-        ModelConfig(architecture="av_align", video_units=(64,), audio_units=(64, 64), residual_encoder=True).validate()
+    # the reference hands residual / highway / weight sharing to build_rnn_layers only from the unidirectional Seq2SeqEncoder branch
+    # (encoder.py:67-78); bidirectional stacks (:92-108) and the AV-Align audio stack (:225-233) ignore them -> accepted, inert
+    for inert in (dict(architecture="av_align", video_units=(64,), audio_units=(64, 128), residual_encoder=True),
+                  dict(architecture="av_align", video_units=(64,), audio_units=(64, 128, 64), encoder_weight_sharing=True),
+                  dict(encoder_type="bidirectional", audio_units=(128, 256), residual_encoder=True),
+                  dict(encoder_type="bidirectional", audio_units=(128, 256, 64), highway_encoder=True, encoder_weight_sharing=True),
+                  dict(encoder_type="bidirectional", audio_units=(128, 256), cell_type="gru", highway_encoder=True)):
+        c = ModelConfig(**inert)
+        c.validate()
+        assert not any(c.highway(s) or c.residual(s) or c.shared_layer(s, 2) != 2 for s in ("audio",))
+    c = ModelConfig(architecture="av_align", video_units=(64, 64, 64), audio_units=(64, 128), residual_encoder=True, encoder_weight_sharing=True)
+    c.validate()
+    assert c.residual("video") and not c.residual("audio") and c.shared_layer("video", 2) == 1 and c.shared_layer("audio", 2) == 2
     with pytest.raises(ValueError, match="encoder_weight_sharing"):
         ModelConfig(encoder_weight_sharing=True, audio_units=(128, 256, 256)).validate()
     with pytest.raises(NotImplementedError):

@@ -70,8 +70,7 @@ def _small(arch="bimodal", **kw):
                                             ("unimodal", "normed_bahdanau", {}),
                                             ("bimodal", "scaled_luong", dict(input_dense_layers=(6, 5))),    # encoder.py:148-171
                                             ("unimodal", "scaled_luong", dict(decoder_units=(8, 8))),        # MultiRNNCell decoder
-                                            ("unimodal", "bahdanau", dict(highway_encoder=True, audio_units=(8, 8, 8),
-                                                                          encoder_type="bidirectional")),
+                                            ("unimodal", "bahdanau", dict(highway_encoder=True, audio_units=(8, 8, 8))),
                                             ("bimodal", "scaled_luong", dict(instance_normalisation=True, residual_encoder=True,
                                                                              audio_units=(8, 8, 8))),
                                             ("bimodal", "bahdanau", dict(decoder_units=(8, 8, 8), encoder_weight_sharing=True,
@@ -98,6 +97,51 @@ def test_gradients_by_finite_differences(arch, att, extra):
         fd = (loss_of(Wp) - loss_of(Wm)) / (2 * eps)
         an = float(r["grads"][k][idx])
         assert abs(fd - an) < 1e-6 + 1e-4 * abs(an), (k, idx, fd, an)
+
+
+@pytest.mark.parametrize("base,flags", [
+    (dict(arch="unimodal", encoder_type="bidirectional", audio_units=(8, 8, 8)), dict(residual_encoder=True)),
+    (dict(arch="bimodal", encoder_type="bidirectional", audio_units=(8, 8, 8), video_units=(8, 8)), dict(highway_encoder=True)),
+    (dict(arch="unimodal", encoder_type="bidirectional", audio_units=(8, 8, 8)), dict(encoder_weight_sharing=True)),
+    (dict(arch="av_align", audio_units=(8, 8, 8), video_units=(8,)), dict(residual_encoder=True, encoder_weight_sharing=True)),
+    (dict(arch="av_align", audio_units=(8, 8, 8), video_units=(8,)), dict(highway_encoder=True))])
+def test_wrapper_flags_are_inert_where_the_reference_ignores_them(base, flags):
+    """residual / highway / weight sharing reach build_rnn_layers only from the unidirectional Seq2SeqEncoder branch
+    (encoder.py:67-78); bidirectional stacks (encoder.py:92-108) and the AV-Align audio stack (encoder.py:225-233) never see them:
+    same variables, same loss, same gradients with and without the flags."""
+    base = dict(base)
+    arch = base.pop("arch")
+    cfg0, W0, b = _small(arch, **base)
+    cfg1, W1, _ = _small(arch, **base, **flags)
+    assert sorted(W0) == sorted(W1) and all(np.array_equal(W0[k], W1[k]) for k in W0)
+    r0, r1 = O.train_step(W0, None, cfg0, b), O.train_step(W1, None, cfg1, b)
+    assert r0["loss"] == r1["loss"]
+    assert all(np.array_equal(r0["grads"][k], r1["grads"][k]) for k in r0["grads"])
+
+
+def test_wrapper_flags_apply_to_unidirectional_stacks():
+    cfg0, W0, b = _small("bimodal", audio_units=(8, 8, 8), video_units=(8, 8))
+    for flags, extra_vars in ((dict(residual_encoder=True), 0), (dict(highway_encoder=True), 2 * (2 + 1)),
+                              (dict(encoder_weight_sharing=True), -2)):
+        cfg1, W1, _ = _small("bimodal", audio_units=(8, 8, 8), video_units=(8, 8), **flags)
+        assert len(W1) - len(W0) == extra_vars, (flags, sorted(set(W1) ^ set(W0)))
+        if extra_vars == 0:
+            assert O.train_step(W0, None, cfg0, b)["loss"] != O.train_step(W1, None, cfg1, b)["loss"]
+
+
+def test_input_batch_norm_moving_variance_is_the_biased_one():
+    """Rank-3 [B,T,F] input: TF 1.13 drops fused=True (encoder.py:44-50) -> moving variance from tf.nn.moments' biased variance;
+    the rank-4 CNN maps keep the fused kernel and its Bessel-corrected update (video.py:8-12)."""
+    x = torch.randn(3, 5, 4, dtype=torch.float64)
+    P = {"p/gamma": torch.ones(4, dtype=torch.float64), "p/beta": torch.zeros(4, dtype=torch.float64),
+         "p/moving_mean": torch.zeros(4, dtype=torch.float64), "p/moving_variance": torch.ones(4, dtype=torch.float64)}
+    var = x.reshape(-1, 4).var(dim=0, unbiased=False)
+    up = {}
+    O.batch_norm(x, P, "p", True, up)
+    assert torch.allclose(up["p/moving_variance"], 0.99 + 0.01 * var)
+    up = {}
+    O.batch_norm(x, P, "p", True, up, fused=True)
+    assert torch.allclose(up["p/moving_variance"], 0.99 + 0.01 * var * 15 / 14)
 
 
 def test_masking_invariants():
