@@ -70,7 +70,8 @@ CASES = {
     "weight_sharing_uni4": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32, 32, 32),
                                 encoder_weight_sharing=True),
     "weight_sharing_uni_gru": dict(architecture="unimodal", encoder_type="unidirectional", video_units=(16, 16, 16), audio_units=None,
-                                   cell_type="gru", encoder_weight_sharing=True, attention_type=(("bahdanau",), ("bahdanau",))),
+                                   decoder_units=(16,), cell_type="gru", encoder_weight_sharing=True,
+                                   attention_type=(("bahdanau",), ("bahdanau",))),
     # ... and is silently ignored on bidirectional stacks (encoder.py:92-108 does not pass it): every layer owns its variables
     "weight_sharing_bi_gru_inert": dict(architecture="unimodal", encoder_type="bidirectional", video_units=(16, 16, 16), audio_units=None,
                                         cell_type="gru", encoder_weight_sharing=True, attention_type=(("bahdanau",), ("bahdanau",))),
