@@ -100,7 +100,8 @@ class AttnRnn(C.Structure):
                 ("beam_width", C.c_int32), ("pad5_", C.c_int32), ("length_penalty", C.c_float), ("pad6_", C.c_float),
                 ("beam_logp", C.c_void_p), ("beam_fin", C.c_void_p), ("beam_len", C.c_void_p), ("step_ids", C.c_void_p),
                 ("parent_ids", C.c_void_p), ("parent_rows", C.c_void_p),
-                ("n_extra", C.c_int32), ("pad7_", C.c_int32), ("out0", C.c_void_p), ("extra", DecLayer * MAX_DEC_EXTRA)]
+                ("n_extra", C.c_int32), ("pad7_", C.c_int32), ("out0", C.c_void_p), ("extra", DecLayer * MAX_DEC_EXTRA),
+                ("fused_ws", C.c_void_p), ("fused_ws_floats", C.c_int64)]
 
 
 class TransposeJob(C.Structure):
@@ -111,6 +112,7 @@ _STRUCTS = {"avsr_dec_layer": DecLayer, "avsr_mat": Mat, "avsr_gemm_desc": GemmD
             "avsr_attn_mech": AttnMech, "avsr_attn_rnn": AttnRnn, "avsr_transpose_job": TransposeJob}
 
 EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_rnn_set_persistent", "avsr_rnn_set_persistent_mode", "avsr_rnn_set_persistent_scratch", "avsr_attn_rnn_fwd",
+           "avsr_attn_rnn_fused_ws_floats", "avsr_attn_rnn_fused_eligible", "avsr_attn_rnn_set_fused",
            "avsr_attn_rnn_bwd", "avsr_beam_gather_tree", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_colsum",
            "avsr_batchnorm_fwd", "avsr_batchnorm_fwd_ex", "avsr_batchnorm_bwd", "avsr_batchnorm_xhat", "avsr_im2col", "avsr_col2im",
            "avsr_relu", "avsr_relu_bwd", "avsr_add", "avsr_selu", "avsr_selu_bwd", "avsr_conv3x3_supported", "avsr_conv3x3", "avsr_conv3x3_bwd_data_s2",
@@ -153,6 +155,8 @@ def load():
         "avsr_rnn_set_persistent_mode": [i32],
         "avsr_rnn_set_persistent_scratch": [vp, i64],
         "avsr_attn_rnn_fwd": [C.POINTER(AttnRnn), i32, i32, vp],
+        "avsr_attn_rnn_fused_eligible": [C.POINTER(AttnRnn)],
+        "avsr_attn_rnn_set_fused": [i32],
         "avsr_attn_rnn_bwd": [C.POINTER(AttnRnn), vp],
         "avsr_beam_gather_tree": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "avsr_attn_alpha_rows": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
@@ -206,6 +210,8 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = at
         fn.restype = C.c_int
+    lib.avsr_attn_rnn_fused_ws_floats.argtypes = [i32, i32, i32]
+    lib.avsr_attn_rnn_fused_ws_floats.restype = C.c_int64
     for name, st in _STRUCTS.items():
         n = lib.avsr_sizeof(name.encode())
         if n != C.sizeof(st):

@@ -12,6 +12,7 @@
 
 extern "C" int avsr_step_launch_raw(const void* launch, void* stream);
 extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stream);
+int avsr_dec_persist_fwd(const avsr_attn_rnn* d, int32_t l_begin, int32_t l_end, void* stream);   // dec_persist.hip
 
 namespace avsr {
 
@@ -381,7 +382,14 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
 
   static thread_local StepLaunch SL;
   static thread_local AttnLaunch AL;
-  for (int l = l_begin; l < l_end; ++l) {
+  // the whole range as ONE persistent launch where the fused decode kernel covers the configuration (dec_persist.hip)
+  int l_first = l_begin;
+  {
+    const int prc = avsr_dec_persist_fwd(dp, l_begin, l_end, stream);
+    if (prc == AVSR_OK) l_first = l_end;
+    else if (prc != AVSR_ERR_UNSUPPORTED) return prc;
+  }
+  for (int l = l_first; l < l_end; ++l) {
     // ---- K1: LSTM step -------------------------------------------------------------------
     for (int phase = 0; phase < (gru ? 2 : 1); ++phase) {
       SL.ntask = 1;

@@ -98,6 +98,8 @@ class Seq2SeqModel:
         pm = int(os.environ.get("AVSR_PERSISTENT_RNN", "3"))
         self.persistent_rnn = pm != 0
         ops.rnn_set_persistent(self.persistent_rnn, device=device, mode=pm or 3)
+        # one-launch fused persistent decoder / AV-Align attentive layer forward (csrc/dec_persist.hip); needs the sync scratch above
+        self.fused_decode = self.persistent_rnn and os.environ.get("AVSR_FUSED_DECODE", "1") != "0"
         self.G = 2 if self.gru else 4                       # gate pre-activations per unit of the main cell kernel
         self.inv = PR.inventory(cfg)
         # ---- flat parameter storage (engine layout) ------------------------------------------------
@@ -312,6 +314,9 @@ class Seq2SeqModel:
                    hf=z(B, H), cf=z(B, H), dcell_ext=z(B, L, H))
         if A:
             blk.update(att=SeqBuf(B, L, A, 1, 0, dev), datt=z(B, L, A), datt_ext=z(B, L, A))
+        # scratch of the fused persistent decode kernel (quarter softmax partials, split-K logits); LSTM, 1-2 mechanisms only
+        if mems and len(mems) <= 2 and not self.gru:
+            blk["fused_ws"] = z(ops.attn_rnn_fused_ws_floats(B, len(mems), 256))
         blk["extra"] = []
         if cell_prefix == "dec/l0":
             # multi-layer decoder cell (MultiRNNCell, decoder_unimodal.py:101-108): layers 1.. above the attention-fed one; the top
@@ -914,6 +919,8 @@ class Seq2SeqModel:
             d.dgates, d.dstate, d.dq = ops.fptr(blk["dgates"]), ops.fptr(blk["dstate"]), ops.fptr(blk["dq"])
             d.datt = ops.fptr(blk["datt"]) if A else None
             d.dh0, d.dc0 = ops.fptr(blk["dh0"]), ops.fptr(blk["dc0"])
+        if blk.get("fused_ws") is not None and self.fused_decode:
+            d.fused_ws, d.fused_ws_floats = ops.fptr(blk["fused_ws"]), blk["fused_ws"].numel()
         d.n_extra = len(blk["extra"])
         if d.n_extra:
             d.out0 = ops.fptr(blk["out0"].t)

@@ -252,7 +252,7 @@ def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, 
                                    float(weight_decay), _s()), "avsr_optimiser_step")
 
 
-PROF_KINDS = ("gemm", "step_lstm_fwd", "step_lstm_bwd", "step_dense", "attn_fwd", "attn_bwd", "rnn_persist_fwd", "rnn_persist_bwd")
+PROF_KINDS = ("gemm", "step_lstm_fwd", "step_lstm_bwd", "step_dense", "attn_fwd", "attn_bwd", "rnn_persist_fwd", "rnn_persist_bwd", "dec_persist_fwd")
 
 
 def prof_begin(max_launches=65536):
@@ -288,6 +288,19 @@ def rnn_set_persistent(on, device="cuda", ints=1 << 20, mode=3, scratch_floats=6
         check(_L().avsr_rnn_set_persistent(_persist_sync.data_ptr(), ints), "avsr_rnn_set_persistent")
     else:
         check(_L().avsr_rnn_set_persistent(None, 0), "avsr_rnn_set_persistent")
+
+
+def attn_rnn_fused_ws_floats(B, n_mech, Dmax=256):
+    return int(_L().avsr_attn_rnn_fused_ws_floats(int(B), int(n_mech), int(Dmax)))
+
+
+def attn_rnn_fused_eligible(desc):
+    """Would avsr_attn_rnn_fwd run this block as the one-launch fused persistent decode kernel (csrc/dec_persist.hip)?"""
+    return bool(_L().avsr_attn_rnn_fused_eligible(C.byref(desc)))
+
+
+def attn_rnn_set_fused(on):
+    check(_L().avsr_attn_rnn_set_fused(int(bool(on))), "avsr_attn_rnn_set_fused")
 
 
 def rnn_persistent_error():

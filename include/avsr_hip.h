@@ -320,7 +320,17 @@ typedef struct avsr_attn_rnn {
   int32_t n_extra, pad7_;
   float* out0;
   avsr_dec_layer extra[AVSR_MAX_DEC_EXTRA];
+  /* Scratch of the fused persistent decode kernel (csrc/dec_persist.hip; avsr/decoder_bimodal.py:241-275,
+   * avsr/decoder_unimodal.py:320-350 as ONE launch per call): per-quarter softmax partials and split-K logits.
+   * >= avsr_attn_rnn_fused_ws_floats(B, n_mech, Dmax) floats; NULL = always use one launch per step and phase. */
+  float* fused_ws;
+  int64_t fused_ws_floats;
 } avsr_attn_rnn;
+int64_t avsr_attn_rnn_fused_ws_floats(int32_t B, int32_t n_mech, int32_t Dmax);
+/* 1 if avsr_attn_rnn_fwd(d, ...) would run the fused persistent decode kernel for this descriptor, else 0. */
+int avsr_attn_rnn_fused_eligible(const avsr_attn_rnn* d);
+/* Process-wide switch (default on); the path also needs avsr_rnn_set_persistent's sync scratch. */
+int avsr_attn_rnn_set_fused(int32_t on);
 
 int avsr_attn_rnn_fwd(const avsr_attn_rnn* d, int32_t l_begin, int32_t l_end, void* stream);
 int avsr_attn_rnn_bwd(const avsr_attn_rnn* d, void* stream);
@@ -513,9 +523,9 @@ int avsr_optimiser_step(float* params, float* grads, float* m, float* v, int64_t
  * begin and end every gemm / step / attention launch is bracketed by an event pair on its stream; end
  * synchronises the device and returns per-kind launch counts and summed milliseconds.
  * kinds: 0 gemm, 1 LSTM-forward step, 2 LSTM-backward step, 3 dense step, 4 attention fwd, 5 attention bwd,
- * 6 persistent RNN forward, 7 persistent RNN backward.  out_flops (may be NULL): algorithmic FLOPs summed per kind
+ * 6 persistent RNN forward, 7 persistent RNN backward, 8 fused persistent decoder forward.  out_flops (may be NULL): algorithmic FLOPs summed per kind
  * where the launcher knows them (gemm, persistent RNN kernels), else 0. */
-#define AVSR_PROF_NKIND 8
+#define AVSR_PROF_NKIND 9
 int avsr_prof_begin(int32_t max_launches);
 int avsr_prof_end(int32_t* out_count, float* out_ms, double* out_flops);
 
