@@ -62,6 +62,7 @@ struct DPLaunch {
   int l_begin, l_end, b0, ngroups;
   int go_id, eos_id, A, KW;
   int UW, AW, NWA, drop;
+  int uwsh, awsh;
   int* err; int* claim; int* flags;
   const float* wt; const float* bias;
   float* gates; float* cs; float* cell_out; float* att; float* attd; float* hs_seq; float* state;
@@ -84,236 +85,254 @@ __device__ __forceinline__ void stb4(__amdgpu_buffer_rsrc_t r, int byte_off, f32
 __device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
 // KR0 / KR1: register capacity of the resident keys of mechanism 0 / 1, in frames per 16-lane group (32 groups per workgroup)
+//
+// Register discipline (two waves per SIMD -> 256 registers per lane): the resident operands take 152 of them (keys 80, cell
+// kernel 56, attention layers 16).  Everything else a thread needs per step is RE-DERIVED from an opaque copy of its thread id
+// inside the step loop -- otherwise the compiler hoists ~100 loop-invariant indices / 64-bit addresses out of the loop and
+// spills them, and every reload sits on the critical path behind a full vmcnt wait.  Chunk tables are wave-uniform (SGPRs).
 template <int KR0, int KR1, int MODE>
 __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const red = lds;                       // [8][2][8][16] cell / [8][256] context partials / [8][8][16] attention layer
-  float* const s_p = lds + 2048;                // [2][128] scores -> softmax numerators of this quarter (P2) ...
+  float* const red = lds;                       // [8][2][8][16] cell / [2][2][256] context partials / [8][8][16] attention layer / [8][32] exp
+  float* const s_p = lds + 2048;                // [2][128] scaled scores of this quarter (P2) ...
   float* const s_logit = lds + 2048;            // ... [8][32] logits of the group's rows (P4)
   float* const s_x = lds + 2304;                // [8][128] input rows of the next step
   float* const s_att = lds + 3328;              // [8][16]  this workgroup's attention columns
-  float* const s_redw = lds + 3456;             // [32] wave partials of the block reductions
-  int* const s_int = reinterpret_cast<int*>(lds + 3488);   // [0..7] tokens, [8..15] step lengths, [16] slot, [17] unfinished
+  int* const s_int = reinterpret_cast<int*>(lds + 3488);   // [0..7] tokens, [8..15] step lengths, [16] slot, [17] unfinished, [24..27] zero pad
   float* const s_wo = lds + 3520;               // [16][32] this workgroup's rows of the output kernel
-  constexpr int ZPAD = 3512;                    // 4 zero floats (tail of s_int): where operand chunks of another source "read" LDS
+  constexpr int ZPAD = 3512;                    // 4 zero floats: where operand slots of another source "read" LDS
   float* const vals = lds + DP_MISC;            // resident value rows of this workgroup's quarter
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int g = __builtin_amdgcn_readfirstlane(xcc_id());
-  if (tid == 0) s_int[16] = __hip_atomic_fetch_add(L.claim + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid0 == 0) s_int[16] = __hip_atomic_fetch_add(L.claim + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const int j = __builtin_amdgcn_readfirstlane(s_int[16]);
   if (g >= L.ngroups || j >= DP_NW) return;
 
   const int B = L.B, Ls = L.L, H = L.H, E = L.E, A = L.A, KW = L.KW, V = L.V;
   constexpr int mode = MODE;
-  const int i = lane & 15, q = lane >> 4;
-  const int s16 = tid & 15, rg = tid >> 4;      // attention: 16 lanes per frame, 32 frames per pass
   const int rowbase = L.b0 + g * DP_R;
   const bool drop = L.drop != 0;
   const uint32_t seedv = L.seed ? (uint32_t)L.seed[0] : 0u;
   const uint32_t cid4 = L.cid4;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const long BH = (long)B * H;
+  float* const hbuf = L.state;                  // [2][B][H] ping-pong, then c [2][B][H]
+  float* const cbuf = L.state + 2 * BH;
 
   // ---------------------------------------------------------------------------------------------------------
-  // resident operands
+  // wave-uniform chunk tables (E, A, H, D are multiples of 16: a 16-wide chunk never straddles a source)
   // ---------------------------------------------------------------------------------------------------------
-  // (1) cell kernel slice: gate columns of units [unit0, unit0 + UW); K split over the 8 waves
-  const int UW = L.UW, unit0 = j * UW, col0 = unit0 * 4;
-  const int nx = (mode == 0) ? 0 : (E + 15) >> 4, na = (A + 15) >> 4, nh = (H + 15) >> 4;
-  const int NC = nx + na + nh;
-  const int g0 = (wave * NC) / DP_WV, ncw = ((wave + 1) * NC) / DP_WV - g0;
-  // MFMA A-operand row of this lane (rows 8..15 of the tile are padding)
-  const int ab = rowbase + i;
-  const bool aok = i < DP_R && ab < B;
-  f32x4 wc[DP_CPW][2];
-  // Branch-free operand fetch: every chunk slot issues one load per possible source (attention record, h state, LDS input
-  // rows) each step; a slot's byte offset is P_OOB (reads 0, no memory access) / the LDS zero pad for the sources it is not of.
-  unsigned ko[DP_CPW];
-  int xa[DP_CPW], seg_att[DP_CPW];              // seg_att: wave-uniform "this slot reads the attention record" (else the h state)
-#pragma unroll
-  for (int cc = 0; cc < DP_CPW; ++cc) {
-    const int gch = g0 + cc;
-    int kk, kseg, wbase, seg;
-    if (gch < nx) { kk = gch << 4; kseg = E; wbase = 0; seg = 0; }
-    else if (gch < nx + na) { kk = (gch - nx) << 4; kseg = A; wbase = E; seg = 1; }
-    else { kk = (gch - nx - na) << 4; kseg = H; wbase = E + A; seg = 2; }
-    const int k = kk + 4 * q;
-    const bool in = cc < ncw && k < kseg;
-    ko[cc] = (in && seg != 0 && aok) ? (unsigned)(k * 4) : (unsigned)P_OOB;
-    seg_att[cc] = __builtin_amdgcn_readfirstlane(seg == 1 ? 1 : 0);
-    xa[cc] = (in && seg == 0 && i < DP_R) ? 2304 + i * 128 + k : ZPAD;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int cl = nt * 16 + i, col = col0 + cl;
-      wc[cc][nt] = (in && cl < 4 * UW && col < 4 * H) ? ld4(L.wt + (long)col * KW + wbase + k) : zero4;
-    }
-  }
-  // (2) attention-layer slice: attention columns [an0, an0 + AW) of mechanism ma
-  const int AW = L.AW, an0 = j * AW;
+  const int UW = L.UW, uwsh = L.uwsh, unit0 = j * UW, col0 = unit0 * 4;
+  // cell slots of a wave: 0 = input rows (LDS), 1..4 = attention record, 5..6 = h state; every wave takes an eighth of each source
+  const int nx = (mode == 0) ? 0 : E >> 4, na = A >> 4, nh = H >> 4;
+  const int xg0 = (wave * nx) / DP_WV, nxw = ((wave + 1) * nx) / DP_WV - xg0;
+  const int ag0 = (wave * na) / DP_WV, naw = ((wave + 1) * na) / DP_WV - ag0;
+  const int hg0 = (wave * nh) / DP_WV, nhw = ((wave + 1) * nh) / DP_WV - hg0;
+  unsigned uk1[DP_CPW];                         // byte offset of the slot's chunk inside its global source row; P_OOB: slot unused
+  const int uxa = nxw > 0 ? 2304 + (xg0 << 4) : -1;   // LDS float index of the input-row chunk
+  const int AW = L.AW, awsh = L.awsh, an0 = j * AW;
   const bool has_att = an0 < A;
   const int ma = has_att ? an0 / H : 0;
   const int nl0 = an0 - ma * H;
   const DPMech& Ma = L.m[ma];
   const int Da = Ma.D;
-  const int nq = (H + 15) >> 4, nd = (Da + 15) >> 4, NCa = nq + nd;
-  const int ga0 = (wave * NCa) / DP_WV, ncaw = ((wave + 1) * NCa) / DP_WV - ga0;
-  f32x4 wa[DP_APW];
-  unsigned ko3[DP_APW];
-  int seg_q[DP_APW];                             // wave-uniform "this slot reads the cell output" (else the context partials)
-#pragma unroll
-  for (int cc = 0; cc < DP_APW; ++cc) {
-    const int gch = ga0 + cc;
-    const bool qs = gch < nq;
-    const int kk = qs ? gch << 4 : (gch - nq) << 4, kseg = qs ? H : Da, wbase = qs ? 0 : H;
-    const int k = kk + 4 * q;
-    const bool in = has_att && cc < ncaw && k < kseg;
-    ko3[cc] = (in && aok) ? (unsigned)(k * 4) : (unsigned)P_OOB;
-    seg_q[cc] = __builtin_amdgcn_readfirstlane(qs ? 1 : 0);
-    wa[cc] = (in && i < AW) ? ld4(Ma.watt_t + (long)(nl0 + i) * (H + Da) + wbase + k) : zero4;
-  }
-  // (3) output-layer rows [an0, an0 + AW) -> LDS [k][symbol]
-  {
-    const int k = tid >> 5, v = tid & 31;
-    s_wo[tid] = (mode >= 1 && L.oa && has_att && v < V && k < AW) ? L.wout_t[(long)v * A + an0 + k] : 0.f;
-  }
-  // (4) attention memories of row r_att, quarter cq: keys -> registers (16 lanes per frame), values -> LDS
+  // attention-layer slots: 0..1 = cell output, 2..3 = context partials
+  const int nq = H >> 4, nd = Da >> 4;
+  const int qg0 = (wave * nq) / DP_WV, nqw = ((wave + 1) * nq) / DP_WV - qg0;
+  const int dg0 = (wave * nd) / DP_WV, ndw = ((wave + 1) * nd) / DP_WV - dg0;
+  unsigned uk3[DP_APW];
+
+  // ---------------------------------------------------------------------------------------------------------
+  // resident operands
+  // ---------------------------------------------------------------------------------------------------------
+  f32x4 wc[DP_CPW][2], wa[DP_APW];
+  f32x4 k0[KR0 > 0 ? KR0 : 1][4], k1[KR1 > 0 ? KR1 : 1][4];
+  int n_m[2] = {0, 0}, t0_m[2] = {0, 0};
   const int r_att = j >> 2, cq = j & 3;
   const int b_att = rowbase + r_att;
   const bool att_row = b_att < B;
-  f32x4 k0[KR0 > 0 ? KR0 : 1][4], k1[KR1 > 0 ? KR1 : 1][4];
-  int n_m[2] = {0, 0}, t0_m[2] = {0, 0};
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    if (m >= L.n_mech) continue;
-    const DPMech& M = L.m[m];
-    const int len = att_row ? min(M.len ? M.len[b_att] : M.T, M.T) : 0;
-    const int t0 = cq * M.ch;
-    const int n = max(0, min(M.ch, len - t0));
-    n_m[m] = n; t0_m[m] = t0;
-    const float* kb = M.keys + ((long)b_att * M.T + t0) * H;
-    if (m == 0) {
-#pragma unroll
-      for (int u = 0; u < KR0; ++u)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int fr = rg + 32 * u, k = 4 * s16 + 64 * jj;
-          k0[u][jj] = (fr < n && k < H) ? ld4(kb + (long)fr * H + k) : zero4;
-        }
-    } else {
-#pragma unroll
-      for (int u = 0; u < KR1; ++u)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int fr = rg + 32 * u, k = 4 * s16 + 64 * jj;
-          k1[u][jj] = (fr < n && k < H) ? ld4(kb + (long)fr * H + k) : zero4;
-        }
-    }
-    const int d4 = M.D >> 2;
-    const float* vb = M.values + (long)b_att * M.values_sb + (long)t0 * M.values_st;
-    for (int idx = tid; idx < n * d4; idx += DP_NT) {
-      const int fr = idx / d4, c4 = idx - fr * d4;
-      st4(vals + M.lds_off + fr * M.D + 4 * c4, ld4(vb + (long)fr * M.values_st + 4 * c4));
-    }
-  }
-
-  // ---------------------------------------------------------------------------------------------------------
-  // per-thread roles and state
-  // ---------------------------------------------------------------------------------------------------------
-  // cell epilogue: thread e < 8*UW owns (row er, unit eu)
-  const int er = tid / UW, eu = tid - er * UW;
-  const int eb = rowbase + er, eun = unit0 + eu;
-  const bool eok = tid < DP_R * UW && eb < B && eun < H;
-  const long BH = (long)B * H;
-  float* const hbuf = L.state;                  // [2][B][H] ping-pong, then c [2][B][H]
-  float* const cbuf = L.state + 2 * BH;
   float c_state = 0.f, h_state = 0.f;
-  f32x4 bias4 = zero4;
-  int e_steplen = 0;
-  if (eok) {
-    c_state = cbuf[(long)(L.l_begin & 1) * BH + (long)eb * H + eun];
-    h_state = hbuf[(long)(L.l_begin & 1) * BH + (long)eb * H + eun];
-    if (L.bias) bias4 = ld4(L.bias + eun * 4);
-    e_steplen = L.steplen[eb];
+  {
+    const int tid = tid0, lane = tid & 63, i = lane & 15, q = lane >> 4, s16 = tid & 15, rg = tid >> 4;
+    // (1) cell kernel slice: gate columns of units [unit0, unit0 + UW); K split over the 8 waves
+#pragma unroll
+    for (int cc = 0; cc < DP_CPW; ++cc) {
+      int kk, wbase;
+      bool in;
+      if (cc == 0) { kk = xg0 << 4; wbase = 0; in = nxw > 0; }
+      else if (cc < 5) { kk = (ag0 + cc - 1) << 4; wbase = E; in = cc - 1 < naw; }
+      else { kk = (hg0 + cc - 5) << 4; wbase = E + A; in = cc - 5 < nhw; }
+      uk1[cc] = (in && cc > 0) ? (unsigned)(kk * 4) : (unsigned)P_OOB;
+      const int k = kk + 4 * q;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int cl = nt * 16 + i, col = col0 + cl;
+        wc[cc][nt] = (in && cl < 4 * UW && col < 4 * H) ? ld4(L.wt + (long)col * KW + wbase + k) : zero4;
+      }
+    }
+    // (2) attention-layer slice: attention columns [an0, an0 + AW) of mechanism ma
+#pragma unroll
+    for (int cc = 0; cc < DP_APW; ++cc) {
+      const bool qs = cc < 2;
+      const int kk = qs ? (qg0 + cc) << 4 : (dg0 + cc - 2) << 4, wbase = qs ? 0 : H;
+      const bool in = has_att && (qs ? cc < nqw : cc - 2 < ndw);
+      uk3[cc] = in ? (unsigned)(kk * 4) : (unsigned)P_OOB;
+      wa[cc] = (in && i < AW) ? ld4(Ma.watt_t + (long)(nl0 + i) * (H + Da) + wbase + kk + 4 * q) : zero4;
+    }
+    // (3) output-layer rows [an0, an0 + AW) -> LDS [k][symbol]
+    {
+      const int k = tid >> 5, v = tid & 31;
+      s_wo[tid] = (mode >= 1 && L.oa && has_att && v < V && k < AW) ? L.wout_t[(long)v * A + an0 + k] : 0.f;
+    }
+    // (4) attention memories of row r_att, quarter cq: keys -> registers (16 lanes per frame), values -> LDS
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      if (m >= L.n_mech) continue;
+      const DPMech& M = L.m[m];
+      const int len = att_row ? min(M.len ? M.len[b_att] : M.T, M.T) : 0;
+      const int t0 = cq * M.ch;
+      const int n = max(0, min(M.ch, len - t0));
+      n_m[m] = n; t0_m[m] = t0;
+      const float* kb = M.keys + ((long)b_att * M.T + t0) * H;
+      if (m == 0) {
+#pragma unroll
+        for (int u = 0; u < KR0; ++u)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int fr = rg + 32 * u, k = 4 * s16 + 64 * jj;
+            k0[u][jj] = (fr < n && k < H) ? ld4(kb + (long)fr * H + k) : zero4;
+          }
+      } else {
+#pragma unroll
+        for (int u = 0; u < KR1; ++u)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int fr = rg + 32 * u, k = 4 * s16 + 64 * jj;
+            k1[u][jj] = (fr < n && k < H) ? ld4(kb + (long)fr * H + k) : zero4;
+          }
+      }
+      const int d4 = M.D >> 2;
+      const float* vb = M.values + (long)b_att * M.values_sb + (long)t0 * M.values_st;
+      for (int idx = tid; idx < n * d4; idx += DP_NT) {
+        const int fr = idx / d4, c4 = idx - fr * d4;
+        st4(vals + M.lds_off + fr * M.D + 4 * c4, ld4(vb + (long)fr * M.values_st + 4 * c4));
+      }
+    }
+    // (5) recurrent state of (row er, unit eu), tokens / step lengths of the group's rows, first input rows
+    const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
+    if (tid < DP_R * UW && eb < B && eun < H) {
+      c_state = cbuf[(long)(L.l_begin & 1) * BH + (long)eb * H + eun];
+      h_state = hbuf[(long)(L.l_begin & 1) * BH + (long)eb * H + eun];
+    }
+    if (tid < DP_R) {
+      const int b = rowbase + tid;
+      s_int[tid] = (b < B && mode == 1) ? L.tok[b] : 0;
+      s_int[8 + tid] = (b < B) ? L.steplen[b] : 0;
+    }
+    if (tid == 0) s_int[17] = 0;
+    if (tid < 4) lds[ZPAD + tid] = 0.f;
+    __syncthreads();
+    if (mode >= 1) {
+      const int e4n = E >> 2;
+      for (int idx = tid; idx < DP_R * e4n; idx += DP_NT) {
+        const int r = idx / e4n, e4 = idx - r * e4n, b = rowbase + r;
+        f32x4 v = zero4;
+        if (b < B) v = (mode == 2) ? ld4(L.xs + ((long)b * Ls + L.l_begin) * E + 4 * e4) : ld4(L.embedding + (long)s_int[r] * E + 4 * e4);
+        st4(s_x + r * 128 + 4 * e4, v);
+      }
+    }
+    __syncthreads();
   }
   const __amdgpu_buffer_rsrc_t ctx_rs = make_rsrc(Ma.ctx);
   const __amdgpu_buffer_rsrc_t att_rs = make_rsrc(drop ? L.attd : L.att), h_rs = make_rsrc(hbuf), co_rs = make_rsrc(L.cell_out);
   const __amdgpu_buffer_rsrc_t pc_rs = make_rsrc(Ma.ppctx), pm_rs = make_rsrc(Ma.ppm), pl_rs = make_rsrc(Ma.ppl);
-  const __amdgpu_buffer_rsrc_t plog_rs = make_rsrc(L.plog);
-  // attention-layer epilogue: thread < 8*AW owns (row ar, column ac)
-  const int ar = tid / AW, ac = tid - ar * AW;
-  const int arb = rowbase + ar;
-  const bool a_ok = has_att && tid < DP_R * AW && arb < B;
-  int a_steplen = a_ok ? L.steplen[arb] : 0;
-  // logits / sampling: thread (pr, pv), tid < 256; per-row tokens and step lengths of the group in s_int
-  const int pr = (tid >> 5) & 7, pv = tid & 31;
-  const bool p_on = tid < 256;
-  const int pb = rowbase + pr;
-  const float bout_v = (mode >= 1 && L.bout && pv < V) ? L.bout[pv] : 0.f;
-  if (tid < DP_R) {
-    const int b = rowbase + tid;
-    s_int[tid] = (b < B && mode == 1) ? L.tok[b] : 0;
-    s_int[8 + tid] = (b < B) ? L.steplen[b] : 0;
-  }
-  if (tid == 0) s_int[17] = 0;
-  if (tid < 4) lds[ZPAD + tid] = 0.f;
-  __syncthreads();
-  // input rows of the first step of this call
-  if (mode >= 1) {
-    const int e4n = E >> 2;
-    for (int idx = tid; idx < DP_R * e4n; idx += DP_NT) {
-      const int r = idx / e4n, e4 = idx - r * e4n, b = rowbase + r;
-      f32x4 v = zero4;
-      if (b < B) v = (mode == 2) ? ld4(L.xs + ((long)b * Ls + L.l_begin) * E + 4 * e4) : ld4(L.embedding + (long)s_int[r] * E + 4 * e4);
-      st4(s_x + r * 128 + 4 * e4, v);
-    }
-  }
-  __syncthreads();
+  const __amdgpu_buffer_rsrc_t plog_rs = make_rsrc(L.plog), gates_rs = make_rsrc(L.gates), bias_rs = make_rsrc(L.bias);
 
   int* const flag_base = L.flags + g * 3 * 32;
   auto wait_all = [&](int phase, int need) {
     if (wave == 0) {
-      const int* fp = flag_base + phase * 32 + (lane & 31);
+      const int* fp = flag_base + phase * 32 + (threadIdx.x & 31);
       bool ok = false;
       for (int spins = 0; spins < (1 << 21); ++spins) {
         const int v = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (__all(v >= need)) { ok = true; break; }
         if ((spins & 1023) == 1023 && __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = true; break; }
       }
-      if (!ok && lane == 0) __hip_atomic_store(L.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!ok && threadIdx.x == 0) __hip_atomic_store(L.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     lds_barrier();
   };
   auto publish = [&](int phase, int value) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(flag_base + phase * 32 + j, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (threadIdx.x == 0) __hip_atomic_store(flag_base + phase * 32 + j, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
 
+#ifdef DP_TIMING
+  long tm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long last_ = __builtin_amdgcn_s_memtime();
+#define DTICK(k) { const long now_ = __builtin_amdgcn_s_memtime(); tm[k] += now_ - last_; last_ = now_; }
+#else
+#define DTICK(k)
+#endif
+  // recurrent operand rows of the NEXT cell step: h(l) is complete once every workgroup has published P1 of step l, so the
+  // rows are fetched right after that wait (during P2) and consumed a step later, off the critical path
+  f32x4 hv[2];
+  {
+    const int lane = tid0 & 63, i = lane & 15, q = lane >> 4, ab = rowbase + i;
+    const unsigned h_o = ((i < DP_R && ab < B) ? (unsigned)((long)(L.l_begin & 1) * BH + (long)ab * H) * 4u : 0u) + (unsigned)(q * 16);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) hv[cc] = ldb_sc1(h_rs, (int)(h_o + uk1[5 + cc]));
+  }
   for (int l = L.l_begin; l < L.l_end; ++l) {
     const int epoch = l - L.l_begin + 1;
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));                 // opaque: per-thread indices below are recomputed, not kept across steps
+    const int lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int ab = rowbase + i;
+    const bool aok = i < DP_R && ab < B;          // MFMA A-operand row of this lane (rows 8..15 of the tile are padding)
+    DTICK(11)
     // =====================================================================================================
     // P1: LSTM cell (cells.py:14-18 LSTMCell clip 1.0, forget bias 1.0; DropoutWrapper cells.py:46-54)
     // =====================================================================================================
     {
-      f32x4 zpre = zero4;
-      if (mode == 0 && eok && l < e_steplen) zpre = ld4(L.gates + (((long)eb * Ls + l) * H + eun) * 4);
-      f32x4 av[DP_CPW];
-      const unsigned att_o = (unsigned)(((long)ab * (Ls + 1) + l) * A) * 4u, h_o = (unsigned)((long)(l & 1) * BH + (long)ab * H) * 4u;
+      const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
+      const bool eok = tid < DP_R * UW && eb < B && eun < H;
+      const int e_steplen = s_int[8 + (er & 7)];
+      const bool valid = eok && l < e_steplen;
+      const long bt = (long)eb * Ls + l;
+      // rows that are padding / beyond the batch read row 0: their tile rows are never used
+      const unsigned att_o = (aok ? (unsigned)(((long)ab * (Ls + 1) + l) * A) * 4u : 0u) + (unsigned)(q * 16);
+      const int x_o = (i & 7) * 128 + 4 * q;
+      f32x4 av[4];
 #pragma unroll
-      for (int cc = 0; cc < DP_CPW; ++cc)
-        av[cc] = ldb_sc1(seg_att[cc] ? att_rs : h_rs, (int)((seg_att[cc] ? att_o : h_o) + ko[cc]));
+      for (int cc = 0; cc < 4; ++cc) av[cc] = ldb_sc1(att_rs, (int)(att_o + uk1[1 + cc]));
+      const f32x4 zpre = (MODE == 0) ? ldb4(gates_rs, valid ? (int)((bt * H + eun) * 16) : P_OOB) : zero4;
+      const f32x4 bias4 = ldb4(bias_rs, (eok && L.bias) ? eun * 16 : P_OOB);
       f32x4 acc[2] = {zero4, zero4};
-#pragma unroll
-      for (int cc = 0; cc < DP_CPW; ++cc) {
-        f32x4 a4 = av[cc];                                         // an input-row slot read 0 from memory: its operand is in LDS
-        if (MODE != 0) a4 += ld4(lds + xa[cc]);
+      // input rows (LDS) and the recurrent h (fetched during the previous step) first: they run under the attention loads
+      if (MODE != 0) {
+        const f32x4 a4 = ld4(lds + (uxa >= 0 ? uxa + x_o : ZPAD));
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], wc[cc][nt][e], acc[nt], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], wc[0][nt][e], acc[nt], 0, 0, 0);
       }
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[cc][e], wc[5 + cc][nt][e], acc[nt], 0, 0, 0);
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc][e], wc[1 + cc][nt][e], acc[nt], 0, 0, 0);
       if (q < 2) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -321,10 +340,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
           for (int r = 0; r < 4; ++r) red[((wave * 2 + nt) * 8 + q * 4 + r) * 16 + i] = acc[nt][r];
       }
       lds_barrier();
+      DTICK(0)
       if (eok) {
-        if (mode == 1) e_steplen = s_int[8 + er];
-        const bool valid = l < e_steplen;
-        const long bt = (long)eb * Ls + l;
         const long so = ((long)eb * (Ls + 1) + l + 1) * H + eun;
         float hnext = h_state;
         if (valid) {
@@ -356,21 +373,27 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         }
         hbuf[(long)((l + 1) & 1) * BH + (long)eb * H + eun] = hnext;
       }
+      DTICK(1)
       publish(0, epoch);
+      DTICK(2)
     }
     // =====================================================================================================
     // P2: scores, masked softmax partials, partial contexts of (row r_att, quarter cq)
     //     (attention.py:25-72 Luong / scaled Luong; contrib.seq2seq _compute_attention)
     // =====================================================================================================
     wait_all(0, epoch);
+    DTICK(3)
     {
-      f32x4 q4[4];
-      const int qo = (int)(((long)b_att * (Ls + 1) + l + 1) * H);
+      {
+        const unsigned h_o = (aok ? (unsigned)((long)((l + 1) & 1) * BH + (long)ab * H) * 4u : 0u) + (unsigned)(q * 16);
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int k = 4 * s16 + 64 * jj;
-        q4[jj] = ldb_sc1(co_rs, (att_row && k < H) ? (qo + k) * 4 : P_OOB);
+        for (int cc = 0; cc < 2; ++cc) hv[cc] = ldb_sc1(h_rs, (int)(h_o + uk1[5 + cc]));
       }
+      const int s16 = tid & 15, rg = tid >> 4;
+      f32x4 q4[4];
+      const unsigned qo = att_row ? (unsigned)(((long)b_att * (Ls + 1) + l + 1) * H) * 4u + (unsigned)(s16 * 16) : (unsigned)P_OOB;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) q4[jj] = ldb_sc1(co_rs, (4 * s16 + 64 * jj < H) ? (int)(qo + 256 * jj) : P_OOB);
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         if (m >= L.n_mech) continue;
@@ -398,70 +421,73 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         }
       }
       lds_barrier();
-      // quarter max / exp / sum of both mechanisms together (one element per thread: ch <= 128)
-      float mx[2], lsum[2], pnum[2];
+      // every wave derives the quarter's max / exp-sum itself (two frames per lane): no block reduction, no barrier;
+      // a lane keeps the numerators of frames (lane, lane + 64) and the context loop broadcasts them with readlane.
+      // Partial contexts: the 8 waves are shared out between the mechanisms in proportion to their frame counts; a wave
+      // walks every nw-th frame of its mechanism with one float4 column per lane, 4 frames in flight.
+      const int nw0 = (L.n_mech < 2) ? DP_WV : max(1, min(DP_WV - 1, (DP_WV * n_m[0] + (n_m[0] + n_m[1]) / 2) / max(1, n_m[0] + n_m[1])));
+      const int mw = (wave < nw0) ? 0 : 1, wl = mw ? wave - nw0 : wave, nwm = mw ? DP_WV - nw0 : nw0;
+      {
+        const DPMech& M = L.m[mw];
+        const int D = M.D, n = n_m[mw];
+        const float v0 = (lane < n) ? s_p[mw * 128 + lane] : -INFINITY, v1 = (lane + 64 < n) ? s_p[mw * 128 + 64 + lane] : -INFINITY;
+        const float mx = wave_max(fmaxf(v0, v1));
+        const float p0 = (lane < n) ? expf(v0 - mx) : 0.f, p1 = (lane + 64 < n) ? expf(v1 - mx) : 0.f;
+        const float lsum = wave_sum(p0) + wave_sum(p1);
+        if (wl == 0 && lane == 0 && att_row) {
+          M.ppm[(long)cq * B + b_att] = (n > 0) ? mx : -INFINITY;
+          M.ppl[(long)cq * B + b_att] = lsum;
+        }
+        f32x4 a4 = zero4;
+        {
+          // no divergence around the readlane broadcasts (a VALU select executed under a partial exec mask would leave the
+          // source lanes of later frames stale): lanes beyond the value width walk column 0 and their sums are never read
+          const float* vp = vals + M.lds_off + (4 * lane < D ? 4 * lane : 0);
+          auto pbc = [&](int f) -> float {
+            const int a = __builtin_amdgcn_readlane(__builtin_bit_cast(int, p0), f & 63), b = __builtin_amdgcn_readlane(__builtin_bit_cast(int, p1), f & 63);
+            return __builtin_bit_cast(float, f < 64 ? a : b);
+          };
+          int fr = wl;
+          for (; fr + 3 * nwm < n; fr += 4 * nwm) {
+            f32x4 x[4];
+            float pf[4];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const float v = (tid < n_m[m]) ? s_p[m * 128 + tid] : -INFINITY;
-        pnum[m] = v;
-        const float wm = wave_max(v);
-        if (lane == 0) s_redw[m * 8 + wave] = wm;
+            for (int u = 0; u < 4; ++u) {
+              const int f = fr + u * nwm;
+              x[u] = ld4(vp + f * D);
+              pf[u] = pbc(f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4 += pf[u] * x[u];
+          }
+          for (; fr < n; fr += nwm) a4 += pbc(fr) * ld4(vp + fr * D);
+        }
+        st4(red + wave * 256 + 4 * lane, a4);
       }
       lds_barrier();
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float t = s_redw[m * 8];
-#pragma unroll
-        for (int w = 1; w < DP_WV; ++w) t = fmaxf(t, s_redw[m * 8 + w]);
-        mx[m] = t;
-        const float p = (tid < n_m[m]) ? expf(pnum[m] - t) : 0.f;
-        if (tid < n_m[m]) s_p[m * 128 + tid] = p;
-        const float ws = wave_sum(p);
-        if (lane == 0) s_redw[16 + m * 8 + wave] = ws;
-      }
-      lds_barrier();
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < DP_WV; ++w) t += s_redw[16 + m * 8 + w];
-        lsum[m] = t;
-      }
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        if (m >= L.n_mech) continue;
-        const DPMech& M = L.m[m];
-        const int D = M.D, d4 = D >> 2, n = n_m[m];
-        if (tid == 0 && att_row) {
-          M.ppm[(long)cq * B + b_att] = (n > 0) ? mx[m] : -INFINITY;
-          M.ppl[(long)cq * B + b_att] = lsum[m];
+      if (tid < 128 && att_row) {
+        const int m = tid >> 6, c4 = tid & 63;
+        if (m < L.n_mech && 4 * c4 < L.m[m].D) {
+          const int w0 = m ? nw0 : 0, w1 = (m || L.n_mech < 2) ? DP_WV : nw0;
+          f32x4 sacc = ld4(red + w0 * 256 + 4 * c4);
+          for (int w = w0 + 1; w < w1; ++w) sacc += ld4(red + w * 256 + 4 * c4);
+          st4(L.m[m].ppctx + ((long)cq * B + b_att) * L.m[m].D + 4 * c4, sacc);
         }
-        if (lane < d4) {
-          f32x4 a4 = zero4;
-          const float* vp = vals + M.lds_off + 4 * lane;
-          const float* pp = s_p + m * 128;
-          for (int fr = wave; fr < n; fr += DP_WV) a4 += pp[fr] * ld4(vp + fr * D);
-          st4(red + wave * 256 + 4 * lane, a4);
-        }
-        lds_barrier();
-        if (tid < d4 && att_row) {
-          f32x4 s = ld4(red + 4 * tid);
-#pragma unroll
-          for (int w = 1; w < DP_WV; ++w) s += ld4(red + w * 256 + 4 * tid);
-          st4(M.ppctx + ((long)cq * B + b_att) * D + 4 * tid, s);
-        }
-        lds_barrier();
       }
+      DTICK(4)
       publish(1, epoch);
+      DTICK(5)
     }
     // =====================================================================================================
     // P3: attention layer att_m = [cell_out, ctx_m] . W_att,m (attention.py:173-181), split-K share of the logits
     // =====================================================================================================
     wait_all(1, epoch);
+    DTICK(6)
     {
       if (has_att) {
-        // softmax merge weights of this lane's row over the four quarters
+        // every operand of the phase is requested in one batch: statistics, 2 cell-output slots, 2 x 4 context partials
         float wgt[4], Mx = -INFINITY, Lsum = 0.f;
+        f32x4 aq[2], sv[2][4];
         {
           float pmv[4], plv[4];
 #pragma unroll
@@ -469,6 +495,17 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
             const int o = aok ? (c * B + ab) * 4 : P_OOB;
             pmv[c] = ld1_sc1(pm_rs, o);
             plv[c] = ld1_sc1(pl_rs, o);
+          }
+          {
+            const unsigned qo_ = (aok ? (unsigned)(((long)ab * (Ls + 1) + l + 1) * H) * 4u : 0u) + (unsigned)(q * 16);
+            const unsigned pc0_ = (aok ? (unsigned)((long)ab * Da) * 4u : 0u) + (unsigned)(q * 16);
+            const unsigned pcs_ = (unsigned)((long)B * Da) * 4u;
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+              aq[cc] = ldb_sc1(co_rs, (int)(qo_ + uk3[cc]));
+#pragma unroll
+              for (int c = 0; c < 4; ++c) sv[cc][c] = ldb_sc1(pc_rs, (int)(pc0_ + c * pcs_ + uk3[2 + cc]));
+            }
           }
 #pragma unroll
           for (int c = 0; c < 4; ++c) { wgt[c] = aok ? pmv[c] : -INFINITY; Mx = fmaxf(Mx, wgt[c]); }
@@ -489,29 +526,22 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
           pmr[ab] = Mx; plr[ab] = Lsum;
           for (int c = 1; c < Ma.nc_rec; ++c) { pmr[(long)c * B + ab] = -INFINITY; plr[(long)c * B + ab] = 0.f; }
         }
-        const unsigned qo = (unsigned)(((long)ab * (Ls + 1) + l + 1) * H) * 4u;
-        const unsigned cso = (unsigned)(((long)ab * Ls + l) * Da) * 4u;
-        const unsigned pcs = (unsigned)((long)B * Da) * 4u, pc0 = (unsigned)((long)ab * Da) * 4u;
+        const unsigned qo = (aok ? (unsigned)(((long)ab * (Ls + 1) + l + 1) * H) * 4u : 0u) + (unsigned)(q * 16);
+        const unsigned pc0 = (aok ? (unsigned)((long)ab * Da) * 4u : 0u) + (unsigned)(q * 16);
+        const unsigned cso = (aok && saver) ? (unsigned)(((long)ab * Ls + l) * Da) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
+        const unsigned pcs = (unsigned)((long)B * Da) * 4u;
         f32x4 acc = zero4;
-        // two slots at a time: slot = 1 load of the cell output, or the 4 quarter partials of the context (merged here)
 #pragma unroll
-        for (int c0 = 0; c0 < DP_APW; c0 += 2) {
-          f32x4 sv[2][4];
+        for (int cc = 0; cc < 2; ++cc) {
 #pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const int cc = c0 + d;
-            sv[d][0] = ldb_sc1(seg_q[cc] ? co_rs : pc_rs, (int)((seg_q[cc] ? qo : pc0) + ko3[cc]));
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cc][e], wa[cc][e], acc, 0, 0, 0);
+        }
 #pragma unroll
-            for (int c = 1; c < 4; ++c) sv[d][c] = ldb_sc1(pc_rs, seg_q[cc] ? P_OOB : (int)(pc0 + c * pcs + ko3[cc]));
-          }
+        for (int cc = 0; cc < 2; ++cc) {
+          const f32x4 a4 = (wgt[0] * sv[cc][0] + wgt[1] * sv[cc][1]) + (wgt[2] * sv[cc][2] + wgt[3] * sv[cc][3]);
+          stb4(ctx_rs, (uk3[2 + cc] != (unsigned)P_OOB) ? (int)(cso + uk3[2 + cc]) : P_OOB, a4);   // context record
 #pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const int cc = c0 + d;
-            const f32x4 a4 = ((seg_q[cc] ? 1.0f : wgt[0]) * sv[d][0] + wgt[1] * sv[d][1]) + (wgt[2] * sv[d][2] + wgt[3] * sv[d][3]);
-            stb4(ctx_rs, (saver && !seg_q[cc]) ? (int)(cso + ko3[cc]) : P_OOB, a4);   // context record (out of range: dropped)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], wa[cc][e], acc, 0, 0, 0);
-          }
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], wa[2 + cc][e], acc, 0, 0, 0);
         }
         if (q < 2) {
 #pragma unroll
@@ -519,13 +549,14 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         }
       }
       lds_barrier();
+      const int pr = (tid >> 5) & 7, pv = tid & 31;
       if (tid < DP_R * AW && has_att) {
+        const int ar = tid >> awsh, ac = tid & (AW - 1), arb = rowbase + ar;
         float a = 0.f;
-        if (a_ok) {
-          if (mode == 1) a_steplen = s_int[8 + ar];
+        if (arb < B) {
           const int o = ar * 16 + ac;
           a = ((red[o] + red[128 + o]) + (red[256 + o] + red[384 + o])) + ((red[512 + o] + red[640 + o]) + (red[768 + o] + red[896 + o]));
-          if (!(l < a_steplen)) a = 0.f;
+          if (!(l < s_int[8 + ar])) a = 0.f;
           const long ao = ((long)arb * (Ls + 1) + l + 1) * A + an0 + ac;
           L.att[ao] = a;
           if (drop) L.attd[ao] = a * p_drop(true, seedv, cid4, (uint32_t)(((long)arb * Ls + l + 1) * (E + A) + E + an0 + ac), L.k_in);
@@ -533,50 +564,58 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         s_att[ar * 16 + ac] = a;
       }
       lds_barrier();
-      if (mode >= 1 && L.oa && has_att && p_on && pv < V) {
+      if (mode >= 1 && L.oa && has_att && tid < 256 && pv < V) {
         float s = 0.f;
         for (int k = 0; k < AW; ++k) s += s_att[pr * 16 + k] * s_wo[k * 32 + pv];
         L.plog[(((long)g * DP_NW + j) * DP_R + pr) * 32 + pv] = s;
       }
+      DTICK(7)
       publish(2, epoch);
+      DTICK(8)
     }
     // =====================================================================================================
     // P4: logits, sample / arg-max, next input rows (decoder_unimodal.py:304-309 ScheduledEmbeddingTrainingHelper,
     //     :176-217 GreedyEmbeddingHelper + dynamic_decode(impute_finished=True))
     // =====================================================================================================
     wait_all(2, epoch);
+    DTICK(9)
     if (mode >= 1) {
-      if (p_on) {
+      const int pr = (tid >> 5) & 7, pv = tid & 31, pb = rowbase + pr;
+      if (tid < 256) {
         float z = 0.f;
+        const unsigned po = (unsigned)((((long)g * DP_NW) * DP_R + pr) * 32 + pv) * 4u;
+        float part[DP_NW];
 #pragma unroll
-        for (int w0 = 0; w0 < DP_NW; w0 += 8) {
-          float part[8];
+        for (int w = 0; w < DP_NW; ++w) part[w] = ld1_sc1(plog_rs, (w < L.NWA && pv < V) ? (int)(po + (unsigned)(w * DP_R * 32 * 4)) : P_OOB);
 #pragma unroll
-          for (int w = 0; w < 8; ++w) {
-            const int o = (w0 + w < L.NWA && pv < V) ? (int)(((((long)g * DP_NW + w0 + w) * DP_R + pr) * 32 + pv) * 4) : P_OOB;
-            part[w] = ld1_sc1(plog_rs, o);
-          }
-#pragma unroll
-          for (int w = 0; w < 8; ++w) z += part[w];
-        }
+        for (int w = 0; w < DP_NW; ++w) z += part[w];
         const bool valid = l < s_int[8 + pr];
-        z = valid ? z + bout_v : 0.f;
+        const float bo = (L.bout && pv < V) ? L.bout[pv] : 0.f;
+        z = valid ? z + bo : 0.f;
         if (pv < V) {
           s_logit[pr * 32 + pv] = z;
           if (j == 0 && pb < B) L.logits[((long)pb * Ls + l) * V + pv] = z;
+        }
+        // row maximum over the 32 lanes of this row (exact, order-free), then the softmax numerators for the sampler
+        float m0 = pv < V ? z : -INFINITY;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) m0 = fmaxf(m0, __shfl_xor(m0, o, 64));
+        if (mode == 2) red[pr * 32 + pv] = pv < V ? expf(z - m0) : 0.f;
+        if (mode == 1) {
+          // first maximum (tf.argmax): lowest symbol whose logit equals the row maximum
+          const unsigned long long bal = __ballot(pv < V && z == m0);
+          const unsigned half = (unsigned)(bal >> (32 * ((tid >> 5) & 1)));
+          if (pv == 0) red[pr] = __builtin_bit_cast(float, (int)(__builtin_ffs((int)half) - 1));
         }
       }
       lds_barrier();
       if (tid < DP_R) {
         const int r = tid, b = rowbase + r;
-        const float* lg = s_logit + r * 32;
         if (mode == 1) {
           int id = 0;
           bool unfin = false;
           if (b < B && l < s_int[8 + r]) {
-            float best = lg[0];
-            for (int v = 1; v < V; ++v)
-              if (lg[v] > best) { best = lg[v]; id = v; }       // first maximum (tf.argmax)
+            id = __builtin_bit_cast(int, red[r]);
             s_int[r] = id;
             if (id == L.eos_id) s_int[8 + r] = l + 1; else unfin = true;
           }
@@ -589,15 +628,14 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
           const uint32_t idx = (uint32_t)(b * Ls + l);
           int tk = L.labels[(long)b * Ls + l];
           if (L.prob > 0.f && uniform01(seedv, 1000u, idx) < L.prob) {
-            float m0 = lg[0];
-            for (int v = 1; v < V; ++v) m0 = fmaxf(m0, lg[v]);
+            const float* ex = red + r * 32;       // expf(logit - max) per symbol; summed in index order as the per-step sampler does
             float tot = 0.f;
-            for (int v = 0; v < V; ++v) tot += expf(lg[v] - m0);
+            for (int v = 0; v < V; ++v) tot += ex[v];
             const float target = uniform01(seedv, 1001u, idx) * tot;
             float run = 0.f;
             tk = V - 1;
             for (int v = 0; v < V; ++v) {
-              run += expf(lg[v] - m0);
+              run += ex[v];
               if (run > target) { tk = v; break; }
             }
           }
@@ -627,15 +665,24 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
       }
       lds_barrier();
     }
+    DTICK(10)
   }
+#ifdef DP_TIMING
+  if (tid0 == 0 && j == 0 && g == 0)
+    for (int k = 0; k < 12; ++k) L.err[16 + k] = (int)(tm[k] / (L.l_end - L.l_begin));
+#endif
   // ---- state back to the ping-pong buffers (the next call / the caller's h_final, c_final copies read them) ----
-  if (eok) cbuf[(long)(L.l_end & 1) * BH + (long)eb * H + eun] = c_state;
-  if (mode == 1 && j == 0) {
-    if (tid < DP_R && rowbase + tid < B) {
-      L.steplen[rowbase + tid] = s_int[8 + tid];
-      L.tok[rowbase + tid] = s_int[tid];
+  {
+    const int tid = tid0;
+    const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
+    if (tid < DP_R * UW && eb < B && eun < H) cbuf[(long)(L.l_end & 1) * BH + (long)eb * H + eun] = c_state;
+    if (mode == 1 && j == 0) {
+      if (tid < DP_R && rowbase + tid < B) {
+        L.steplen[rowbase + tid] = s_int[8 + tid];
+        L.tok[rowbase + tid] = s_int[tid];
+      }
+      if (tid == 0 && s_int[17] > 0) atomicAdd(L.n_unfinished, s_int[17]);
     }
-    if (tid == 0 && s_int[17] > 0) atomicAdd(L.n_unfinished, s_int[17]);
   }
 }
 
@@ -659,13 +706,16 @@ static int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* ld
   if (d.mode >= 1 && !d.output_attention) return AVSR_ERR_UNSUPPORTED;
   const int nx = d.mode == 0 ? 0 : (E + 15) / 16, NC = nx + (A + 15) / 16 + (H + 15) / 16;
   if ((NC + DP_WV - 1) / DP_WV > DP_CPW) return AVSR_ERR_UNSUPPORTED;
-  const int UW = (H + DP_NW - 1) / DP_NW, AW = (A + DP_NW - 1) / DP_NW;
+  if (H % 16 || E % 16) return AVSR_ERR_UNSUPPORTED;           // 16-wide operand chunks never straddle a source
+  int UW = 1, AW = 1, uwsh = 0, awsh = 0;
+  while (UW * DP_NW < H) { UW *= 2; ++uwsh; }
+  while (AW * DP_NW < A) { AW *= 2; ++awsh; }
   if (UW > 8 || AW > 16 || H % AW) return AVSR_ERR_UNSUPPORTED;
   if ((long)B * (d.L + 1) * (A > H ? A : H) >= (1L << 29) || (long)4 * B * 256 >= (1L << 29)) return AVSR_ERR_UNSUPPORTED;
   if (avsr_attn_rnn_fused_ws_floats(B, d.n_mech, 256) > d.fused_ws_floats) return AVSR_ERR_UNSUPPORTED;
   L = DPLaunch{};
   L.B = B; L.L = d.L; L.H = H; L.E = E; L.V = d.V; L.n_mech = d.n_mech; L.mode = d.mode; L.oa = d.output_attention;
-  L.go_id = d.go_id; L.eos_id = d.eos_id; L.A = A; L.KW = KW; L.UW = UW; L.AW = AW; L.NWA = (A + AW - 1) / AW;
+  L.go_id = d.go_id; L.eos_id = d.eos_id; L.A = A; L.KW = KW; L.UW = UW; L.AW = AW; L.NWA = (A + AW - 1) / AW; L.uwsh = uwsh; L.awsh = awsh;
   L.drop = (d.seed && d.mode != 1 && (d.keep_in < 1.f || d.keep_state < 1.f || d.keep_out < 1.f)) ? 1 : 0;
   L.wt = d.wt; L.bias = d.bias; L.gates = d.gates; L.cs = d.cs; L.cell_out = d.cell_out; L.att = d.att; L.attd = d.attd;
   L.hs_seq = d.hs_seq; L.state = d.state; L.steplen = d.steplen;
@@ -679,7 +729,7 @@ static int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* ld
   int lds_off = 0;
   for (int m = 0; m < d.n_mech; ++m) {
     const avsr_attn_mech& M = d.mech[m];
-    if (M.type > ATT_SCALED_LUONG || M.D > 256 || M.D % 4 || M.T <= 0) return AVSR_ERR_UNSUPPORTED;
+    if (M.type > ATT_SCALED_LUONG || M.D > 256 || M.D % 16 || M.T <= 0) return AVSR_ERR_UNSUPPORTED;
     if ((H + 15) / 16 + (M.D + 15) / 16 > DP_WV * DP_APW) return AVSR_ERR_UNSUPPORTED;
     if ((long)B * M.T * H >= (1L << 29)) return AVSR_ERR_UNSUPPORTED;
     DPMech& X = L.m[m];

@@ -123,11 +123,20 @@ def main():
             D = m._cur[0]["dec"]
             d = D["desc"]
             torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for rep in range(3):
-                t0 = time.perf_counter()
-                ops.attn_rnn_fwd(d, 0, 40)
                 torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
+                e0.record()
+                for _ in range(5):
+                    ops.attn_rnn_fwd(d, 0, 40)
+                e1.record()
+                torch.cuda.synchronize()
+                dt = e0.elapsed_time(e1) * 1e-3 / 5
+            if fused and os.environ.get("AVSR_HIPCC_FLAGS", "").find("DP_TIMING") >= 0:
+                tk = ops._persist_sync[16:28].cpu().numpy()
+                names = ["P1 loads+mfma", "P1 epilogue", "publish0", "wait0", "P2 attention", "publish1", "wait1", "P3 attlayer", "publish2",
+                         "wait2", "P4 sample", "loop"]
+                print("   per-step shader-clock ticks of workgroup 0:", ", ".join(f"{n} {int(v)}" for n, v in zip(names, tk)), "sum", int(tk.sum()))
             print(f"c4 decoder forward (40 steps) fused={fused}: {dt * 1e3:.3f} ms = {dt * 1e6 / 40:.2f} us/step; "
                   f"75.37 MB/step -> {75.37e6 / (dt / 40) / 1e12:.2f} TB/s algorithmic; err={ops.rnn_persistent_error()}")
             for rep in range(2):
