@@ -82,6 +82,36 @@ __device__ __forceinline__ void stb4(__amdgpu_buffer_rsrc_t r, int byte_off, f32
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r, byte_off, 0, 0);
 }
+// DPP reductions: __shfl_xor lowers to ds_bpermute (an LDS round trip per step); inside a row of 16 lanes the data-parallel
+// primitives rotate for one VALU issue.  row16_*: every lane of the row gets the row's result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0x128>(v);      // row_ror:8
+  v += dpp_f<0x124>(v);      // row_ror:4
+  v += dpp_f<0x122>(v);      // row_ror:2
+  v += dpp_f<0x121>(v);      // row_ror:1
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<0x128>(v));
+  v = fmaxf(v, dpp_f<0x124>(v));
+  v = fmaxf(v, dpp_f<0x122>(v));
+  v = fmaxf(v, dpp_f<0x121>(v));
+  return v;
+}
+__device__ __forceinline__ float rdlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+// whole-wave results (uniform): the four row results combined in a fixed order
+__device__ __forceinline__ float wave64_sum(float v) {
+  v = row16_sum(v);
+  return (rdlane_f(v, 0) + rdlane_f(v, 16)) + (rdlane_f(v, 32) + rdlane_f(v, 48));
+}
+__device__ __forceinline__ float wave64_max(float v) {
+  v = row16_max(v);
+  return fmaxf(fmaxf(rdlane_f(v, 0), rdlane_f(v, 16)), fmaxf(rdlane_f(v, 32), rdlane_f(v, 48)));
+}
 __device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
 // KR0 / KR1: register capacity of the resident keys of mechanism 0 / 1, in frames per 16-lane group (32 groups per workgroup)
@@ -272,12 +302,13 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   };
 
 #ifdef DP_TIMING
-  long tm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long tm[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long last_ = __builtin_amdgcn_s_memtime();
 #define DTICK(k) { const long now_ = __builtin_amdgcn_s_memtime(); tm[k] += now_ - last_; last_ = now_; }
 #else
 #define DTICK(k)
 #endif
+  const float bout_v = (mode >= 1 && L.bout && (tid0 & 31) < V) ? L.bout[tid0 & 31] : 0.f;
   // recurrent operand rows of the NEXT cell step: h(l) is complete once every workgroup has published P1 of step l, so the
   // rows are fetched right after that wait (during P2) and consumed a step later, off the critical path
   f32x4 hv[2];
@@ -312,7 +343,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
       for (int cc = 0; cc < 4; ++cc) av[cc] = ldb_sc1(att_rs, (int)(att_o + uk1[1 + cc]));
       const f32x4 zpre = (MODE == 0) ? ldb4(gates_rs, valid ? (int)((bt * H + eun) * 16) : P_OOB) : zero4;
       const f32x4 bias4 = ldb4(bias_rs, (eok && L.bias) ? eun * 16 : P_OOB);
-      f32x4 acc[2] = {zero4, zero4};
+      f32x4 acc[2] = {zero4, zero4}, accb[2] = {zero4, zero4};       // two chains per column tile (40-cycle dependent latency)
       // input rows (LDS) and the recurrent h (fetched during the previous step) first: they run under the attention loads
       if (MODE != 0) {
         const f32x4 a4 = ld4(lds + (uxa >= 0 ? uxa + x_o : ZPAD));
@@ -322,17 +353,22 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
           for (int e = 0; e < 4; ++e) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], wc[0][nt][e], acc[nt], 0, 0, 0);
       }
 #pragma unroll
-      for (int cc = 0; cc < 2; ++cc)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt) {
+          accb[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[0][e], wc[5][nt][e], accb[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[1][e], wc[6][nt][e], acc[nt], 0, 0, 0);
+        }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[cc][e], wc[5 + cc][nt][e], acc[nt], 0, 0, 0);
+      for (int cc = 0; cc < 4; cc += 2)
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc][e], wc[1 + cc][nt][e], acc[nt], 0, 0, 0);
+          for (int nt = 0; nt < 2; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc][e], wc[1 + cc][nt][e], acc[nt], 0, 0, 0);
+            accb[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc + 1][e], wc[2 + cc][nt][e], accb[nt], 0, 0, 0);
+          }
+      acc[0] += accb[0]; acc[1] += accb[1];
       if (q < 2) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -406,7 +442,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
 #pragma unroll
           for (int u = 0; u < KR0; ++u) {
             float a = (dot4(k0[u][0], q4[0]) + dot4(k0[u][1], q4[1])) + (dot4(k0[u][2], q4[2]) + dot4(k0[u][3], q4[3]));
-            a = group16_sum(a);
+            a = row16_sum(a);
             const int fr = rg + 32 * u;
             if (s16 == 0 && fr < n) { srow[fr] = a; sc[fr] = a * gsc; }
           }
@@ -414,13 +450,14 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
 #pragma unroll
           for (int u = 0; u < KR1; ++u) {
             float a = (dot4(k1[u][0], q4[0]) + dot4(k1[u][1], q4[1])) + (dot4(k1[u][2], q4[2]) + dot4(k1[u][3], q4[3]));
-            a = group16_sum(a);
+            a = row16_sum(a);
             const int fr = rg + 32 * u;
             if (s16 == 0 && fr < n) { srow[fr] = a; sc[fr] = a * gsc; }
           }
         }
       }
       lds_barrier();
+      DTICK(12)
       // every wave derives the quarter's max / exp-sum itself (two frames per lane): no block reduction, no barrier;
       // a lane keeps the numerators of frames (lane, lane + 64) and the context loop broadcasts them with readlane.
       // Partial contexts: the 8 waves are shared out between the mechanisms in proportion to their frame counts; a wave
@@ -431,40 +468,43 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         const DPMech& M = L.m[mw];
         const int D = M.D, n = n_m[mw];
         const float v0 = (lane < n) ? s_p[mw * 128 + lane] : -INFINITY, v1 = (lane + 64 < n) ? s_p[mw * 128 + 64 + lane] : -INFINITY;
-        const float mx = wave_max(fmaxf(v0, v1));
-        const float p0 = (lane < n) ? expf(v0 - mx) : 0.f, p1 = (lane + 64 < n) ? expf(v1 - mx) : 0.f;
-        const float lsum = wave_sum(p0) + wave_sum(p1);
+        const float mx = wave64_max(fmaxf(v0, v1));
+        const float p0 = (lane < n) ? __expf(v0 - mx) : 0.f, p1 = (lane + 64 < n) ? __expf(v1 - mx) : 0.f;
+        const float lsum = wave64_sum(p0) + wave64_sum(p1);
         if (wl == 0 && lane == 0 && att_row) {
           M.ppm[(long)cq * B + b_att] = (n > 0) ? mx : -INFINITY;
           M.ppl[(long)cq * B + b_att] = lsum;
         }
+        DTICK(13)
         f32x4 a4 = zero4;
         {
           // no divergence around the readlane broadcasts (a VALU select executed under a partial exec mask would leave the
           // source lanes of later frames stale): lanes beyond the value width walk column 0 and their sums are never read
           const float* vp = vals + M.lds_off + (4 * lane < D ? 4 * lane : 0);
-          auto pbc = [&](int f) -> float {
-            const int a = __builtin_amdgcn_readlane(__builtin_bit_cast(int, p0), f & 63), b = __builtin_amdgcn_readlane(__builtin_bit_cast(int, p1), f & 63);
-            return __builtin_bit_cast(float, f < 64 ? a : b);
-          };
           int fr = wl;
-          for (; fr + 3 * nwm < n; fr += 4 * nwm) {
-            f32x4 x[4];
-            float pf[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int f = fr + u * nwm;
-              x[u] = ld4(vp + f * D);
-              pf[u] = pbc(f);
+          for (int half = 0; half < 2; ++half) {
+            const float ph = half ? p1 : p0;                 // numerators of frames [64*half, 64*half + 64)
+            const int nend = half ? n : min(n, 64);
+            for (; fr + 3 * nwm < nend; fr += 4 * nwm) {
+              f32x4 x[4];
+              float pf[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int f = fr + u * nwm;
+                x[u] = ld4(vp + f * D);
+                pf[u] = rdlane_f(ph, f & 63);
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) a4 += pf[u] * x[u];
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a4 += pf[u] * x[u];
+            for (; fr < nend; fr += nwm) a4 += rdlane_f(ph, fr & 63) * ld4(vp + fr * D);
           }
-          for (; fr < n; fr += nwm) a4 += pbc(fr) * ld4(vp + fr * D);
         }
         st4(red + wave * 256 + 4 * lane, a4);
       }
       lds_barrier();
+      DTICK(14)
       if (tid < 128 && att_row) {
         const int m = tid >> 6, c4 = tid & 63;
         if (m < L.n_mech && 4 * c4 < L.m[m].D) {
@@ -483,6 +523,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
     // =====================================================================================================
     wait_all(1, epoch);
     DTICK(6)
+    int label_pf = 0;                               // label of this step for the sampler (row tid < 8), fetched a phase early
+    if (MODE == 2 && tid < DP_R && rowbase + tid < B && l + 1 < Ls) label_pf = L.labels[(long)(rowbase + tid) * Ls + l];
     {
       if (has_att) {
         // every operand of the phase is requested in one batch: statistics, 2 cell-output slots, 2 x 4 context partials
@@ -511,7 +553,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
           for (int c = 0; c < 4; ++c) { wgt[c] = aok ? pmv[c] : -INFINITY; Mx = fmaxf(Mx, wgt[c]); }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float e = (wgt[c] == -INFINITY) ? 0.f : expf(wgt[c] - Mx);
+            const float e = (wgt[c] == -INFINITY) ? 0.f : __expf(wgt[c] - Mx);
             Lsum += e * plv[c];
             wgt[c] = e;
           }
@@ -519,6 +561,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) wgt[c] *= inv;
         }
+        DTICK(15)
         const bool saver = nl0 == 0;                                   // first workgroup of a mechanism keeps the records
         if (saver && aok && q == 0 && wave == 0) {                     // merged statistics in chunk 0, neutral elsewhere
           float* pmr = Ma.pstat + (long)(2 * l) * Ma.nc_rec * B;
@@ -530,25 +573,31 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         const unsigned pc0 = (aok ? (unsigned)((long)ab * Da) * 4u : 0u) + (unsigned)(q * 16);
         const unsigned cso = (aok && saver) ? (unsigned)(((long)ab * Ls + l) * Da) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
         const unsigned pcs = (unsigned)((long)B * Da) * 4u;
-        f32x4 acc = zero4;
+        f32x4 acc = zero4, acc2 = zero4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[0][e], wa[0][e], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[1][e], wa[1][e], acc2, 0, 0, 0);
+        }
+        f32x4 c4[2];
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cc][e], wa[cc][e], acc, 0, 0, 0);
+          c4[cc] = (wgt[0] * sv[cc][0] + wgt[1] * sv[cc][1]) + (wgt[2] * sv[cc][2] + wgt[3] * sv[cc][3]);
+          stb4(ctx_rs, (uk3[2 + cc] != (unsigned)P_OOB) ? (int)(cso + uk3[2 + cc]) : P_OOB, c4[cc]);   // context record
         }
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-          const f32x4 a4 = (wgt[0] * sv[cc][0] + wgt[1] * sv[cc][1]) + (wgt[2] * sv[cc][2] + wgt[3] * sv[cc][3]);
-          stb4(ctx_rs, (uk3[2 + cc] != (unsigned)P_OOB) ? (int)(cso + uk3[2 + cc]) : P_OOB, a4);   // context record
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], wa[2 + cc][e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c4[0][e], wa[2][e], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(c4[1][e], wa[3][e], acc2, 0, 0, 0);
         }
+        acc += acc2;
         if (q < 2) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) red[(wave * 8 + q * 4 + r) * 16 + i] = acc[r];
         }
       }
       lds_barrier();
+      DTICK(16)
       const int pr = (tid >> 5) & 7, pv = tid & 31;
       if (tid < DP_R * AW && has_att) {
         const int ar = tid >> awsh, ac = tid & (AW - 1), arb = rowbase + ar;
@@ -590,16 +639,17 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
 #pragma unroll
         for (int w = 0; w < DP_NW; ++w) z += part[w];
         const bool valid = l < s_int[8 + pr];
-        const float bo = (L.bout && pv < V) ? L.bout[pv] : 0.f;
-        z = valid ? z + bo : 0.f;
+        z = valid ? z + bout_v : 0.f;
         if (pv < V) {
           s_logit[pr * 32 + pv] = z;
           if (j == 0 && pb < B) L.logits[((long)pb * Ls + l) * V + pv] = z;
         }
         // row maximum over the 32 lanes of this row (exact, order-free), then the softmax numerators for the sampler
-        float m0 = pv < V ? z : -INFINITY;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) m0 = fmaxf(m0, __shfl_xor(m0, o, 64));
+        float m0 = row16_max(pv < V ? z : -INFINITY);          // the row's 32 lanes are two DPP rows of this wave half
+        {
+          const float mlo = fmaxf(rdlane_f(m0, 0), rdlane_f(m0, 16)), mhi = fmaxf(rdlane_f(m0, 32), rdlane_f(m0, 48));
+          m0 = (lane & 32) ? mhi : mlo;
+        }
         if (mode == 2) red[pr * 32 + pv] = pv < V ? expf(z - m0) : 0.f;
         if (mode == 1) {
           // first maximum (tf.argmax): lowest symbol whose logit equals the row maximum
@@ -609,6 +659,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         }
       }
       lds_barrier();
+      DTICK(17)
       if (tid < DP_R) {
         const int r = tid, b = rowbase + r;
         if (mode == 1) {
@@ -626,17 +677,24 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
           }
         } else if (l + 1 < Ls && b < B) {
           const uint32_t idx = (uint32_t)(b * Ls + l);
-          int tk = L.labels[(long)b * Ls + l];
+          int tk = label_pf;
           if (L.prob > 0.f && uniform01(seedv, 1000u, idx) < L.prob) {
-            const float* ex = red + r * 32;       // expf(logit - max) per symbol; summed in index order as the per-step sampler does
+            // expf(logit - max) per symbol, summed in index order exactly as the per-step sampler does; the row is pulled into
+            // registers first (one dependent LDS read per symbol made this the longest stretch of the step)
+            f32x4 ex4[8];
+#pragma unroll
+            for (int v4 = 0; v4 < 8; ++v4) ex4[v4] = ld4(red + r * 32 + 4 * v4);
             float tot = 0.f;
-            for (int v = 0; v < V; ++v) tot += ex[v];
+#pragma unroll
+            for (int v = 0; v < 32; ++v) tot += (v < V) ? ex4[v >> 2][v & 3] : 0.f;
             const float target = uniform01(seedv, 1001u, idx) * tot;
             float run = 0.f;
             tk = V - 1;
-            for (int v = 0; v < V; ++v) {
-              run += ex[v];
-              if (run > target) { tk = v; break; }
+            bool found = false;
+#pragma unroll
+            for (int v = 0; v < 32; ++v) {
+              run += (v < V) ? ex4[v >> 2][v & 3] : 0.f;
+              if (!found && v < V && run > target) { tk = v; found = true; }
             }
           }
           s_int[r] = tk;
@@ -644,6 +702,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         }
       }
       lds_barrier();
+      DTICK(18)
       if (l + 1 < Ls) {
         const int e4n = E >> 2;
         for (int idx = tid; idx < DP_R * e4n; idx += DP_NT) {
@@ -669,7 +728,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   }
 #ifdef DP_TIMING
   if (tid0 == 0 && j == 0 && g == 0)
-    for (int k = 0; k < 12; ++k) L.err[16 + k] = (int)(tm[k] / (L.l_end - L.l_begin));
+    for (int k = 0; k < 24; ++k) L.err[16 + k] = (int)(tm[k] / (L.l_end - L.l_begin));
 #endif
   // ---- state back to the ping-pong buffers (the next call / the caller's h_final, c_final copies read them) ----
   {

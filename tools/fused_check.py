@@ -133,10 +133,10 @@ def main():
                 torch.cuda.synchronize()
                 dt = e0.elapsed_time(e1) * 1e-3 / 5
             if fused and os.environ.get("AVSR_HIPCC_FLAGS", "").find("DP_TIMING") >= 0:
-                tk = ops._persist_sync[16:28].cpu().numpy()
+                tk = ops._persist_sync[16:40].cpu().numpy()
                 names = ["P1 loads+mfma", "P1 epilogue", "publish0", "wait0", "P2 attention", "publish1", "wait1", "P3 attlayer", "publish2",
-                         "wait2", "P4 sample", "loop"]
-                print("   per-step shader-clock ticks of workgroup 0:", ", ".join(f"{n} {int(v)}" for n, v in zip(names, tk)), "sum", int(tk.sum()))
+                         "wait2", "P4 sample", "loop", "p2:scores", "p2:softmax", "p2:ctx", "p3:loads+wgt", "p3:mfma", "p4:logits", "p4:sample", "-", "-", "-", "-", "-"]
+                print("   per-step shader-clock ticks of workgroup 0:", ", ".join(f"{n} {int(v)}" for n, v in zip(names, tk) if n != "-"), "sum", int(tk.sum()))
             print(f"c4 decoder forward (40 steps) fused={fused}: {dt * 1e3:.3f} ms = {dt * 1e6 / 40:.2f} us/step; "
                   f"75.37 MB/step -> {75.37e6 / (dt / 40) / 1e12:.2f} TB/s algorithmic; err={ops.rnn_persistent_error()}")
             for rep in range(2):
