@@ -161,7 +161,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   const int xg0 = (wave * nx) / DP_WV, nxw = ((wave + 1) * nx) / DP_WV - xg0;
   const int ag0 = (wave * na) / DP_WV, naw = ((wave + 1) * na) / DP_WV - ag0;
   const int hg0 = (wave * nh) / DP_WV, nhw = ((wave + 1) * nh) / DP_WV - hg0;
-  unsigned uk1[DP_CPW];                         // byte offset of the slot's chunk inside its global source row; P_OOB: slot unused
+  unsigned uk1[DP_CPW];                         // byte offset of the slot's chunk inside its global source row
   const int uxa = nxw > 0 ? 2304 + (xg0 << 4) : -1;   // LDS float index of the input-row chunk
   const int AW = L.AW, awsh = L.awsh, an0 = j * AW;
   const bool has_att = an0 < A;
@@ -174,6 +174,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   const int qg0 = (wave * nq) / DP_WV, nqw = ((wave + 1) * nq) / DP_WV - qg0;
   const int dg0 = (wave * nd) / DP_WV, ndw = ((wave + 1) * nd) / DP_WV - dg0;
   unsigned uk3[DP_APW];
+  int cin[2];                                    // context slot in use (its merged rows go to the context record)
 
   // ---------------------------------------------------------------------------------------------------------
   // resident operands
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
       if (cc == 0) { kk = xg0 << 4; wbase = 0; in = nxw > 0; }
       else if (cc < 5) { kk = (ag0 + cc - 1) << 4; wbase = E; in = cc - 1 < naw; }
       else { kk = (hg0 + cc - 5) << 4; wbase = E + A; in = cc - 5 < nhw; }
-      uk1[cc] = (in && cc > 0) ? (unsigned)(kk * 4) : (unsigned)P_OOB;
+      uk1[cc] = (in && cc > 0) ? (unsigned)(kk * 4) : 0u;      // unused slot: chunk 0 of the row against zero weights
       const int k = kk + 4 * q;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
       const bool qs = cc < 2;
       const int kk = qs ? (qg0 + cc) << 4 : (dg0 + cc - 2) << 4, wbase = qs ? 0 : H;
       const bool in = has_att && (qs ? cc < nqw : cc - 2 < ndw);
-      uk3[cc] = in ? (unsigned)(kk * 4) : (unsigned)P_OOB;
+      uk3[cc] = in ? (unsigned)(kk * 4) : 0u;
+      if (cc >= 2) cin[cc - 2] = in ? 1 : 0;
       wa[cc] = (in && i < AW) ? ld4(Ma.watt_t + (long)(nl0 + i) * (H + Da) + wbase + kk + 4 * q) : zero4;
     }
     // (3) output-layer rows [an0, an0 + AW) -> LDS [k][symbol]
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   f32x4 hv[2];
   {
     const int lane = tid0 & 63, i = lane & 15, q = lane >> 4, ab = rowbase + i;
-    const unsigned h_o = ((i < DP_R && ab < B) ? (unsigned)((long)(L.l_begin & 1) * BH + (long)ab * H) * 4u : 0u) + (unsigned)(q * 16);
+    const unsigned h_o = (i < DP_R && ab < B) ? (unsigned)((long)(L.l_begin & 1) * BH + (long)ab * H) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) hv[cc] = ldb_sc1(h_rs, (int)(h_o + uk1[5 + cc]));
   }
@@ -335,8 +337,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
       const int e_steplen = s_int[8 + (er & 7)];
       const bool valid = eok && l < e_steplen;
       const long bt = (long)eb * Ls + l;
-      // rows that are padding / beyond the batch read row 0: their tile rows are never used
-      const unsigned att_o = (aok ? (unsigned)(((long)ab * (Ls + 1) + l) * A) * 4u : 0u) + (unsigned)(q * 16);
+      // padding rows of the tile / rows beyond the batch: out-of-range offset, the load returns 0 without touching memory
+      const unsigned att_o = aok ? (unsigned)(((long)ab * (Ls + 1) + l) * A) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
       const int x_o = (i & 7) * 128 + 4 * q;
       f32x4 av[4];
 #pragma unroll
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
     DTICK(3)
     {
       {
-        const unsigned h_o = (aok ? (unsigned)((long)((l + 1) & 1) * BH + (long)ab * H) * 4u : 0u) + (unsigned)(q * 16);
+        const unsigned h_o = aok ? (unsigned)((long)((l + 1) & 1) * BH + (long)ab * H) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) hv[cc] = ldb_sc1(h_rs, (int)(h_o + uk1[5 + cc]));
       }
@@ -539,9 +541,9 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
             plv[c] = ld1_sc1(pl_rs, o);
           }
           {
-            const unsigned qo_ = (aok ? (unsigned)(((long)ab * (Ls + 1) + l + 1) * H) * 4u : 0u) + (unsigned)(q * 16);
-            const unsigned pc0_ = (aok ? (unsigned)((long)ab * Da) * 4u : 0u) + (unsigned)(q * 16);
-            const unsigned pcs_ = (unsigned)((long)B * Da) * 4u;
+            const unsigned qo_ = aok ? (unsigned)(((long)ab * (Ls + 1) + l + 1) * H) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
+            const unsigned pc0_ = aok ? (unsigned)((long)ab * Da) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
+            const unsigned pcs_ = aok ? (unsigned)((long)B * Da) * 4u : 0u;
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
               aq[cc] = ldb_sc1(co_rs, (int)(qo_ + uk3[cc]));
@@ -569,10 +571,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
           pmr[ab] = Mx; plr[ab] = Lsum;
           for (int c = 1; c < Ma.nc_rec; ++c) { pmr[(long)c * B + ab] = -INFINITY; plr[(long)c * B + ab] = 0.f; }
         }
-        const unsigned qo = (aok ? (unsigned)(((long)ab * (Ls + 1) + l + 1) * H) * 4u : 0u) + (unsigned)(q * 16);
-        const unsigned pc0 = (aok ? (unsigned)((long)ab * Da) * 4u : 0u) + (unsigned)(q * 16);
         const unsigned cso = (aok && saver) ? (unsigned)(((long)ab * Ls + l) * Da) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
-        const unsigned pcs = (unsigned)((long)B * Da) * 4u;
         f32x4 acc = zero4, acc2 = zero4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -583,7 +582,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
           c4[cc] = (wgt[0] * sv[cc][0] + wgt[1] * sv[cc][1]) + (wgt[2] * sv[cc][2] + wgt[3] * sv[cc][3]);
-          stb4(ctx_rs, (uk3[2 + cc] != (unsigned)P_OOB) ? (int)(cso + uk3[2 + cc]) : P_OOB, c4[cc]);   // context record
+          stb4(ctx_rs, cin[cc] ? (int)(cso + uk3[2 + cc]) : P_OOB, c4[cc]);   // context record
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
