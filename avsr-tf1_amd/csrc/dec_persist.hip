@@ -760,7 +760,7 @@ static int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* ld
   if (!g_dec_fused || !g_sync || !d.fused_ws) return AVSR_ERR_UNSUPPORTED;
   if (d.cell != 0 || d.n_extra != 0 || d.n_mech < 1 || d.n_mech > 2 || d.mode < 0 || d.mode > 2) return AVSR_ERR_UNSUPPORTED;
   const int B = d.B, H = d.H, E = d.E, A = d.n_mech * H, KW = E + A + H;
-  if (H > 256 || H % 4 || E % 4 || E > 128 || d.V > 32) return AVSR_ERR_UNSUPPORTED;
+  if (H > 256 || H % 4 || E % 4 || (d.mode != 0 && (E > 128 || d.V > 32))) return AVSR_ERR_UNSUPPORTED;   // mode 0: inputs hoisted, no logits
   if (d.mode >= 1 && !d.output_attention) return AVSR_ERR_UNSUPPORTED;
   const int nx = d.mode == 0 ? 0 : (E + 15) / 16, NC = nx + (A + 15) / 16 + (H + 15) / 16;
   if ((NC + DP_WV - 1) / DP_WV > DP_CPW) return AVSR_ERR_UNSUPPORTED;

@@ -1054,7 +1054,8 @@ def train_step(P_np: Dict[str, np.ndarray], opt: Optional[dict], cfg: OracleConf
     if cfg.batch_normalisation:                             # seq2seq.py:241-250: UPDATE_OPS ride with the train op only then
         for k, v in m.bn_updates.items():                   # (the CNN's batch norms exist either way; their moving stats then stay put)
             newP[k] = v.detach().numpy().astype(P_np[k].dtype)
-    return {"loss": float(loss.detach()), "seq_loss": float(seq.detach()), "global_norm": float(gnorm.detach()),
+    au_term = float((cfg.au_loss_weight * m.aux_loss).detach()) if (cfg.regress_aus and m.aux_loss is not None) else 0.0
+    return {"loss": float(loss.detach()), "seq_loss": float(seq.detach()), "au_term": au_term, "global_norm": float(gnorm.detach()),
             "grads": {k: g.detach().numpy() for k, g in grads.items()}, "params": newP, "opt": new_opt,
             "logits": logits.detach().numpy(), "fed_tokens": m.fed_tokens}
 

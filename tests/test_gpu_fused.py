@@ -1,0 +1,111 @@
+"""The fused persistent decode kernel (csrc/dec_persist.hip: avsr/decoder_bimodal.py:241-275, avsr/decoder_unimodal.py:320-350 and the
+AV-Align attentive layer avsr/encoder.py:265-290 as ONE launch per call) against the per-step launch path of the same engine and
+against the CPU oracle ("vs CPU restatement; TF-1.13.1 parity unpinned").  Tolerances: records / logits / gradients 2e-4 of the
+tensor's largest entry between the two engine paths (different summation orders), fed tokens and greedy ids bit-exact."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # (config overrides, B, T_a, T_v, L)
+    "bimodal_teacher_forcing": (dict(architecture="bimodal", video_units=(32,), audio_units=(32, 32), regress_aus=True), 5, 19, 8, 6),
+    "bimodal_dropout_sampling_2groups": (dict(architecture="bimodal", video_units=(32,), audio_units=(32, 32), use_dropout=True,
+                                              sampling_probability=0.3), 11, 37, 9, 7),
+    "unimodal_luong_h48": (dict(architecture="unimodal", video_units=None, audio_units=(48,), decoder_units=(48,), embedding_size=32,
+                                attention_type=(("luong",), ("luong",)), sampling_probability=0.2), 9, 70, 0, 9),
+    "av_align": (dict(architecture="av_align", video_units=(32,), audio_units=(32, 32)), 6, 23, 9, 5),
+    "c4_width_64_utterances": (dict(architecture="bimodal", video_units=(256,), audio_units=(256,), decoder_units=(256,), embedding_size=128,
+                                    video_feat=128, audio_feat=80, use_dropout=True, sampling_probability=0.1, regress_aus=True), 64, 60, 20, 10),
+    "long_memory_quarters_of_125": (dict(architecture="unimodal", video_units=None, audio_units=(64,), decoder_units=(64,), embedding_size=16),
+                                    3, 500, 0, 5),
+}
+
+
+def _setup(name):
+    from avsr_tf1_amd.config import ModelConfig
+    from oracle import avsr_oracle as O
+    over, B, Ta, Tv, L = CASES[name]
+    kw = dict(decoder_units=(32,), embedding_size=16, video_feat=12, audio_feat=20, encoder_type="unidirectional")
+    kw.update(over)
+    ocfg = O.OracleConfig(**kw)
+    mcfg = ModelConfig(**{f.name: getattr(ocfg, f.name) for f in dataclasses.fields(ModelConfig) if hasattr(ocfg, f.name)})
+    W = O.init_params(ocfg, seed=11)
+    batch = O.synthetic_batch(ocfg, B=B, T_a=max(Ta, 1), T_v=max(Tv, 1), L=L, ragged=True)
+    return O, ocfg, mcfg, W, batch
+
+
+def _run(mcfg, W, batch, fused, greedy_steps):
+    from avsr_tf1_amd import ops
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    ops.attn_rnn_set_fused(fused)
+    try:
+        m = Seq2SeqModel(mcfg, weights=W)
+        db = Batch.from_numpy(batch)
+        out = {}
+        m.forward_train(db)
+        D = m._cur[0]["dec"]
+        out["eligible"] = ops.attn_rnn_fused_eligible(D["desc"])
+        out["logits"], out["fed"] = D["logits"].clone(), D["fed"].clone()
+        for i, mm in enumerate(D["mems"]):
+            out["ctx%d" % i] = mm["ctx"].clone()
+        m.backward()
+        out["grads"] = m.grads.clone()
+        m.apply_update()
+        out["loss"], out["gnorm"] = m.loss.clone(), m.gnorm.clone()
+        out["ids"] = m.greedy_decode(db, max_steps=greedy_steps).clone()
+        torch.cuda.synchronize()
+        assert not ops.rnn_persistent_error()
+        return out
+    finally:
+        ops.attn_rnn_set_fused(True)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_fused_decode_equals_per_step_launches_and_oracle(name):
+    O, ocfg, mcfg, W, batch = _setup(name)
+    L = CASES[name][4]
+    a = _run(mcfg, W, batch, True, L + 3)
+    b = _run(mcfg, W, batch, False, L + 3)
+    assert a["eligible"], "the fused persistent kernel declined a configuration it is built for"
+    assert (a["fed"] == b["fed"]).all() and a["ids"].shape == b["ids"].shape and (a["ids"] == b["ids"]).all()
+    for k in a:
+        if k in ("eligible", "fed", "ids"):
+            continue
+        x, y = a[k].double(), b[k].double()
+        assert float((x - y).abs().max()) <= 2e-4 * max(1e-3, float(y.abs().max())), k
+    ref = O.train_step(W, None, ocfg, batch)
+    assert np.abs(a["logits"].cpu().numpy() - ref["logits"]).max() < 1e-4
+    assert abs(float(a["loss"].item()) - ref["loss"]) < 1e-4
+    consumed = np.arange(batch.labels.shape[1])[None, :] < batch.labels_len[:, None]      # draws behind finished rows feed frozen steps
+    assert (a["fed"].cpu().numpy()[consumed] == ref["fed_tokens"][consumed]).all()
+    ids_ref = O.greedy_decode(ref["params"], ocfg, batch, max_steps=L + 3)
+    assert (a["ids"].cpu().numpy() == ids_ref).all()
+
+
+def test_benchmark_decoders_take_the_fused_path():
+    """c4 (dual attention, B=64, T_a=500, T_v=75) and c5 (decoder over the audio memory + the attentive layer over the video memory,
+    B=128) at the benchmark shapes: both blocks are run by the fused kernel, in all three modes (teacher forcing, scheduled sampling
+    with dropout, greedy)."""
+    from avsr_tf1_amd import ops
+    from avsr_tf1_amd.config import ModelConfig
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    rng = np.random.default_rng(0)
+    for arch, B, kw in (("bimodal", 64, dict(use_dropout=True, sampling_probability=0.1)), ("bimodal", 64, {}), ("av_align", 128, dict(use_dropout=True))):
+        cfg = ModelConfig(architecture=arch, video_units=(256,), audio_units=(256, 256, 256), video_feat=128, audio_feat=80, **kw)
+        m = Seq2SeqModel(cfg, seed=1)
+        f = lambda *s: torch.tensor(rng.standard_normal(s), dtype=torch.float32).cuda()
+        lab = torch.tensor(rng.integers(1, 28, (B, 40)), dtype=torch.int32).cuda()
+        b = Batch(audio=f(B, 500, 80), audio_len=torch.full((B,), 500, dtype=torch.int32).cuda(), video=f(B, 75, 128),
+                  video_len=torch.full((B,), 75, dtype=torch.int32).cuda(), labels=lab, labels_len=torch.full((B,), 40, dtype=torch.int32).cuda())
+        m.forward_train(b)
+        ws = m._cur[0]
+        assert ops.attn_rnn_fused_eligible(ws["dec"]["desc"])
+        if arch == "av_align":
+            assert ops.attn_rnn_fused_eligible(ws["enc"]["audio"]["blk"]["desc"])
+        ids = m.greedy_decode(b, max_steps=16)
+        torch.cuda.synchronize()
+        assert ids.shape[0] == B and not ops.rnn_persistent_error()

@@ -295,6 +295,39 @@ FULL_WIDTH = [
 ]
 
 
+# BASELINE configs[2] (visual-only, lip-CNN (8,16,32,64) -> 128 -> 2 x bi-LSTM-256) and configs[4] (AV-Align at B = 128: two 64-row
+# slices of the persistent kernels), short sequences so that the fp64 oracle finishes in seconds
+WIDE_EXTRA = [
+    ("c3_video_cnn_bi", dict(video_units=(256, 256), decoder_units=(256,), embedding_size=128, cnn_filters=(8, 16, 32, 64),
+                             cnn_dense_units=128, video_feat=128), dict(B=3, Ta=4, Tv=7, L=5)),
+    ("c5_av_align", dict(video_units=(256,), audio_units=(256, 256, 256), decoder_units=(256,), embedding_size=128,
+                         video_feat=128, audio_feat=80, use_dropout=True, sampling_probability=0.1), dict(B=128, Ta=14, Tv=6, L=4)),
+]
+
+
+@pytest.mark.parametrize("case,over,shape", WIDE_EXTRA)
+def test_baseline_widths_c3_cnn_and_c5_b128(case, over, shape):
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    O, ocfg, mcfg, W, batch = make(case, **shape, **over)
+    ref = O.train_step(W, None, ocfg, batch)
+    model = Seq2SeqModel(mcfg, weights=W)
+    db = Batch.from_numpy(batch)
+    logits = model.forward_train(db)
+    model.backward()
+    model.apply_update()
+    torch.cuda.synchronize()
+    assert not model.check_persistent()
+    assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4
+    assert abs(float(model.loss.item()) - ref["loss"]) < 1e-4
+    assert abs(float(model.gnorm.item()) - ref["global_norm"]) < 1e-4 * max(1.0, ref["global_norm"])
+    grads = model.export_tf_weights("grads")
+    for k, g in ref["grads"].items():
+        scale = max(1e-3, np.abs(g).max())
+        assert np.abs(grads[k] - g).max() < 2e-4 * scale + 1e-6, k
+    ids_ref = O.greedy_decode(ref["params"], ocfg, batch, max_steps=6)
+    assert (model.greedy_decode(db, max_steps=6).cpu().numpy() == ids_ref).all()
+
+
 @pytest.mark.parametrize("mode", ["0", "3", "7", "11"])
 @pytest.mark.parametrize("case,over", FULL_WIDTH)
 def test_full_width_train_step(case, over, mode, monkeypatch):
@@ -493,12 +526,12 @@ FULL_LENGTH = [
 ]
 
 
-@pytest.mark.skipif(not os.environ.get("AVSR_LONG_TESTS"), reason="8 minutes of fp64 oracle time: run with AVSR_LONG_TESTS=1 "
-                    "(last run: profiles/r01_full_length_parity.txt)")
+# B = 2 utterances always (about 40 s of fp64 oracle time per case: the driver's GPU run covers T_a = 500 / T_dec = 40 directly);
+# AVSR_LONG_TESTS=1 widens it to 8 utterances (8 minutes; last run: profiles/r01_full_length_parity.txt)
 @pytest.mark.parametrize("case,over", FULL_LENGTH)
 def test_full_length_train_step_and_greedy(case, over):
     from avsr_tf1_amd.model import Batch, Seq2SeqModel
-    O, ocfg, mcfg, W, batch = make(case, B=8, Ta=500, Tv=75, L=40, ragged=True, **over)
+    O, ocfg, mcfg, W, batch = make(case, B=8 if os.environ.get("AVSR_LONG_TESTS") else 2, Ta=500, Tv=75, L=40, ragged=True, **over)
     ref = O.train_step(W, None, ocfg, batch)
     model = Seq2SeqModel(mcfg, weights=W)
     db = Batch.from_numpy(batch)
@@ -532,5 +565,6 @@ def test_rank_seed_offset_decorrelates_dropout_masks():
         m.forward_train(db)
         torch.cuda.synchronize()
         losses.append(float(m.loss.item()))
-    assert abs(losses[0] - ref["seq_loss"]) < 1e-4 or abs(losses[0] - ref["loss"]) < 1.0      # offset 0 = the oracle's masks (sequence term)
+    # offset 0 = the oracle's masks: the forward-only loss scalar is the sequence term + the AU term (L2 joins in apply_update)
+    assert abs(losses[0] - (ref["seq_loss"] + ref["au_term"])) < 1e-4, (losses[0], ref["seq_loss"], ref["au_term"])
     assert len({round(x, 6) for x in losses}) == 3, losses
