@@ -155,20 +155,39 @@ class AVSR(object):
             input_dense_layers=tuple(input_dense_layers), encoder_weight_sharing=bool(encoder_weight_sharing), residual_encoder=bool(residual_encoder), highway_encoder=bool(highway_encoder), instance_normalisation=bool(instance_normalisation))
         self._model = Seq2SeqModel(self._cfg, seed=kwargs.get('seed', 0))
         self._shuffle_seed = kwargs.get('shuffle_seed')        # None = a fresh order every run, as tf.data's unseeded shuffle(5000)
-        self._trainer = DataParallelTrainer(self._model, None, use_graph=False, check_every_step=True)   # bucketed batches: shapes vary per step
+        # Data parallelism (the reference's num_gpus is deprecated and ignored, avsr/avsr.py:67,:127): when the process was started
+        # under torch.distributed (one process per GPU, `torchrun`), every rank builds the same model, reads the same records,
+        # shards each bucketed batch by utterance and all-reduces normalisers / BN statistics / gradients over RCCL (parallel.py).
+        import torch.distributed as _dist
+        self._epoch_counter = 0
+        self._dist = _dist if (_dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1) else None
+        self._rank = self._dist.get_rank() if self._dist is not None else 0
+        self._world = self._dist.get_world_size() if self._dist is not None else 1
+        if self._dist is not None and self._shuffle_seed is None:      # every rank must draw the same shuffle order
+            seed_t = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64)
+            if _dist.get_backend() == 'nccl':
+                seed_t = seed_t.cuda()
+            _dist.broadcast(seed_t, src=0)
+            self._shuffle_seed = int(seed_t.item())
+        self._trainer = DataParallelTrainer(self._model, self._dist, use_graph=False, check_every_step=True)   # bucketed batches: shapes vary per step
 
     # ------------------------------------------------------------------------------------------------
     def _iterator(self, mode):
         vrec, arec, lrec = self._records[mode]
         bs = self._batch_size[0 if mode == 'train' else 1]
         shuffle = mode == 'train'
+        # training batches are sharded by utterance across the data-parallel ranks; evaluation runs whole on every rank
+        rank, world = (self._rank, self._world) if mode == 'train' else (0, 1)
+        seed = self._shuffle_seed
+        if seed is not None:
+            seed = seed + self._epoch_counter                     # a new order every epoch; under data parallelism identical on every rank
         if self._video_processing is not None and self._audio_processing is not None:
             return make_iterator_from_two_records(vrec, arec, lrec, bs, self._unit_dict, shuffle=shuffle, bucket_width=45,
-                                                  seed=self._shuffle_seed)
+                                                  seed=seed, rank=rank, world=world)
         rec = vrec if self._video_processing is not None else arec
         return make_iterator_from_one_record(rec, lrec, self._unit_dict, bs, shuffle=shuffle, bucket_width=45,
                                              max_sentence_length=self._max_sentence_length if self._audio_processing is not None else None,
-                                             seed=self._shuffle_seed)
+                                             seed=seed, rank=rank, world=world)
 
     def _to_batch(self, bd):
         t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda()
@@ -232,9 +251,11 @@ class AVSR(object):
                 print('Restoring checkpoint from epoch {}\n'.format(last_epoch))
             except Exception:
                 print('Could not restore from checkpoint, training from scratch!\n')
-        f = open(logfile, 'a')
+        lead = self._rank == 0                                  # side-effect files (log, checkpoints, predictions) are written by rank 0
+        f = open(logfile if lead else os.devnull, 'a')
         for current_epoch in range(1, num_epochs):            # num_epochs - 1 epochs actually run (avsr.py:253)
             epoch = last_epoch + current_epoch
+            self._epoch_counter = epoch
             sum_loss, batches = 0.0, 0
             start = time.time()
             for bd in self._iterator('train'):                # end of data = StopIteration (reference: OutOfRangeError)
@@ -242,13 +263,19 @@ class AVSR(object):
                 loss, gnorm = self._trainer.train_step(batch)
                 batch_loss, global_norm = float(loss.item()), float(gnorm.item())
                 sum_loss += batch_loss
-                print('batch: {}, batch loss: {:.2f}, gradient norm: {:.2f}'.format(batches, batch_loss, global_norm))
+                if lead:
+                    print('batch: {}, batch loss: {:.2f}, gradient norm: {:.2f}'.format(batches, batch_loss, global_norm))
                 batches += 1
-            print('epoch time: {}'.format(time.time() - start))
+            if lead:
+                print('epoch time: {}'.format(time.time() - start))
             f.write('Average batch_loss as epoch {} is {}\n'.format(epoch, sum_loss / max(1, batches)))
             f.flush()
             if epoch % 10 == 0:
-                save_path = self.save(checkpoint_path + '-{}'.format(epoch))
+                save_path = checkpoint_path + '-{}'.format(epoch)
+                if lead:
+                    self.save(save_path)
+                if self._dist is not None:
+                    self._dist.barrier()                          # the other ranks restore the file rank 0 has just written
                 error_rate = self.evaluate(save_path, epoch)
                 for (k, v) in error_rate.items():
                     f.write(k + ': {:.4f}% '.format(v * 100))
@@ -295,8 +322,9 @@ class AVSR(object):
         if self._unit == 'character':
             wer, _wer_dict = compute_wer(predictions_dict, labels_dict, split_words=True)
             error_rate['word'] = wer
-        outdir = path.join('predictions', path.split(path.split(checkpoint_path)[0])[-1])
-        makedirs(outdir, exist_ok=True)
-        write_sequences_to_labelfile(predictions_dict, path.join(outdir, 'predicted_epoch_{}.mlf'.format(epoch)), labels_dict,
-                                     uer_dict, sep=' ' if self._unit == 'phoneme' else '')
+        if self._rank == 0:
+            outdir = path.join('predictions', path.split(path.split(checkpoint_path)[0])[-1])
+            makedirs(outdir, exist_ok=True)
+            write_sequences_to_labelfile(predictions_dict, path.join(outdir, 'predicted_epoch_{}.mlf'.format(epoch)), labels_dict,
+                                         uer_dict, sep=' ' if self._unit == 'phoneme' else '')
         return error_rate

@@ -10,6 +10,7 @@
 //                                      order by the column-sum finaliser (deterministic)
 // Layers with more channels (32, 64: 9x9 and 5x5 maps, few rows) stay on im2col + avsr_gemm (conv.hip).
 #include "common.h"
+#include "prof.h"
 #include "avsr_hip.h"
 
 namespace avsr {
@@ -231,6 +232,7 @@ extern "C" int avsr_conv3x3(const float* x, const float* w, const float* bias, f
   if (!x || !w || !y || N <= 0 || !direct_ok(flip ? Co : Ci, flip ? Ci : Co) || Co % 4 || (flip && stride != 1)) return AVSR_ERR_ARG;
   const long pix = (long)N * Ho * ((Wo + 1) / 2);       // one thread per pair of output pixels
   const size_t lds = sizeof(float) * 9 * Ci * Co;
+  avsr::ProfScope ps(flip ? avsr::PROF_CONV_BWD_DATA : avsr::PROF_CONV_FWD, S_(stream), 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
   if (Co % 16 == 0) hipLaunchKernelGGL((conv3x3_kernel<16>), dim3((unsigned)((pix + 255) / 256), Co / 16), dim3(256), lds, S_(stream), x, w, bias, y, N, H,
                                        W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, flip, beta);
   else if (Co % 8 == 0) hipLaunchKernelGGL((conv3x3_kernel<8>), dim3((unsigned)((pix + 255) / 256), Co / 8), dim3(256), lds, S_(stream), x, w, bias, y, N, H,
@@ -246,6 +248,7 @@ extern "C" int avsr_conv3x3_bwd_data_s2(const float* dy, const float* w, float* 
   if (!dy || !w || !dx || N <= 0 || !direct_ok(Ci, Co) || Ci % 4) return AVSR_ERR_ARG;
   const long pix = (long)N * H * W;
   const size_t lds = sizeof(float) * 9 * Ci * Co;
+  avsr::ProfScope ps(avsr::PROF_CONV_BWD_DATA, S_(stream), 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
   if (Ci % 8 == 0) hipLaunchKernelGGL((conv3x3_bwd_data_s2_kernel<8>), dim3((unsigned)((pix + 255) / 256), Ci / 8), dim3(256), lds, S_(stream), dy, w, dx, N,
                                       H, W, Ci, Co, pad_t, pad_l, Ho, Wo, beta);
   else hipLaunchKernelGGL((conv3x3_bwd_data_s2_kernel<4>), dim3((unsigned)((pix + 255) / 256), Ci / 4), dim3(256), lds, S_(stream), dy, w, dx, N, H, W, Ci,
@@ -279,6 +282,7 @@ extern "C" int avsr_conv3x3_bwd_weight(const float* x, const float* dy, float* d
 #undef BW_ATTR
     big_lds = true;
   }
+  avsr::ProfScope ps(avsr::PROF_CONV_BWD_WEIGHT, S_(stream), 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
 #define BW_GO(CO_, PP_) hipLaunchKernelGGL((conv3x3_bwd_weight_kernel<CO_, PP_>), dim3(nblk), dim3(256), lds, S_(stream), x, dy, scratch, N, H, W, Ci, \
                                            stride, pad_t, pad_l, Ho, Wo, fpb)
   if (PP == 1) { if (Co == 32) BW_GO(32, 1); else if (Co == 16) BW_GO(16, 1); else if (Co == 8) BW_GO(8, 1); else BW_GO(4, 1); }

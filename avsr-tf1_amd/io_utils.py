@@ -341,8 +341,8 @@ def _parse_labels(payload, eos_id):
     return lab, int(ctx["labels_length"][0]) + 1, ctx["filename"][0]
 
 
-def _pad_stack(arrs):
-    T = max(a.shape[0] for a in arrs)
+def _pad_stack(arrs, T=None):
+    T = max(a.shape[0] for a in arrs) if T is None else T
     out = np.zeros((len(arrs), T) + arrs[0].shape[1:], arrs[0].dtype)
     for i, a in enumerate(arrs):
         out[i, :a.shape[0]] = a
@@ -352,7 +352,14 @@ def _pad_stack(arrs):
 class _Pipeline:
     """shuffle(5000) -> bucket(group_by_window) -> padded_batch over zipped (data streams..., labels)."""
 
-    def __init__(self, data_records, label_record, unit_dict, batch_size, shuffle, bucket_width, max_sentence_length, seed=None):
+    def __init__(self, data_records, label_record, unit_dict, batch_size, shuffle, bucket_width, max_sentence_length, seed=None,
+                 rank=0, world=1):
+        # data parallelism by utterance (SURVEY 8(e)): every rank runs the SAME pipeline (same shuffle seed) -- shuffle, bucket
+        # (avsr/io_utils.py:133-147: group_by_window on the input length) and batch exactly as one process would -- and then keeps
+        # its contiguous share of every bucketed batch.  "Bucket first, then split": the global batches are the reference's.
+        self.rank, self.world = int(rank), int(world)
+        if self.world > 1 and shuffle and seed is None:
+            raise ValueError("data-parallel input pipelines need a shared shuffle seed (every rank must draw the same order)")
         self.data_records, self.label_record = data_records, label_record
         self.eos = {v: k for k, v in unit_dict.items()}["EOS"]
         self.shapes = [_get_input_shape_from_record(r) for r in data_records]
@@ -384,20 +391,36 @@ class _Pipeline:
         self.rng.shuffle(buf)
         yield from buf
 
+    def _shard(self, exs):
+        """This rank's share of a global batch.  A batch with fewer utterances than ranks is processed whole by every rank: the
+        summed gradients and the summed loss normaliser then both carry the factor `world`, which cancels."""
+        if self.world == 1 or len(exs) < self.world:
+            return exs
+        n, w, r = len(exs), self.world, self.rank
+        lo, hi = (n * r) // w, (n * (r + 1)) // w
+        return exs[lo:hi]
+
     def _batch(self, exs):
+        # a rank's shard is padded to the lengths of the GLOBAL batch: padded_batch pads to the longest member of the whole batch, and
+        # the input batch-norm takes its statistics over the padded rows too (SURVEY A5), so the shard must keep that row count
+        full = exs
+        exs = self._shard(exs)
+        Lmax = max(e[1][0].shape[0] for e in full)
         if not exs[0][0]:                                       # label-only pipelines (language model)
             names = [e[1][2] for e in exs]
-            return BatchedData(None, None, None, None, _pad_stack([e[1][0] for e in exs]), np.array([e[1][1] for e in exs], np.int32),
+            return BatchedData(None, None, None, None, _pad_stack([e[1][0] for e in exs], Lmax), np.array([e[1][1] for e in exs], np.int32),
                                None if names[0] is None else names, None)
         streams = list(zip(*[e[0] for e in exs]))
-        inputs = [_pad_stack([s[0] for s in st]) for st in streams]
+        fstreams = list(zip(*[e[0] for e in full]))
+        Tmax = [max(s[0].shape[0] for s in st) for st in fstreams]
+        inputs = [_pad_stack([s[0] for s in st], T) for st, T in zip(streams, Tmax)]
         lens = [np.array([s[2] for s in st], np.int32) for st in streams]
         names = [[s[3] for s in st] for st in streams]
         payload = {}
-        for st in streams:
+        for st, T in zip(streams, Tmax):
             if st[0][1] is not None:
-                payload["aus"] = _pad_stack([s[1] for s in st])
-        labels = _pad_stack([e[1][0] for e in exs])
+                payload["aus"] = _pad_stack([s[1] for s in st], T)
+        labels = _pad_stack([e[1][0] for e in exs], Lmax)
         llen = np.array([e[1][1] for e in exs], np.int32)
         lnames = [e[1][2] for e in exs]
         one = len(inputs) == 1
@@ -428,17 +451,17 @@ class _Pipeline:
 
 
 def make_iterator_from_one_record(data_record, label_record, unit_dict, batch_size, shuffle=False, reverse_input=False,
-                                  bucket_width=-1, num_cores=4, max_sentence_length=None, seed=None):
+                                  bucket_width=-1, num_cores=4, max_sentence_length=None, seed=None, rank=0, world=1):
     """Iterable of BatchedData (avsr/io_utils.py:88-165).  reverse_input is always False in the reference's callers."""
     if reverse_input:
         raise NotImplementedError("reverse_input is never enabled by the reference (avsr/avsr.py:646, :658, :671)")
-    return _Pipeline([data_record], label_record, unit_dict, batch_size, shuffle, bucket_width, max_sentence_length, seed)
+    return _Pipeline([data_record], label_record, unit_dict, batch_size, shuffle, bucket_width, max_sentence_length, seed, rank, world)
 
 
 def make_iterator_from_two_records(video_record, audio_record, label_record, batch_size, unit_dict, shuffle=False,
-                                   reverse_input=False, bucket_width=-1, num_cores=4, seed=None):
+                                   reverse_input=False, bucket_width=-1, num_cores=4, seed=None, rank=0, world=1):
     """Iterable of BatchedData with (video, audio) tuples (avsr/io_utils.py:168-259); buckets on the VIDEO length."""
-    return _Pipeline([video_record, audio_record], label_record, unit_dict, batch_size, shuffle, bucket_width, None, seed)
+    return _Pipeline([video_record, audio_record], label_record, unit_dict, batch_size, shuffle, bucket_width, None, seed, rank, world)
 
 
 class _LabelPipeline(_Pipeline):
@@ -452,6 +475,7 @@ class _LabelPipeline(_Pipeline):
         self.lookup = {v: k for k, v in unit_dict.items()}
         self.batch_size, self.shuffle, self.bucket_width = batch_size, shuffle, bucket_width
         self.rng = random.Random(seed)
+        self.rank, self.world = 0, 1
         self.shuffle_buffer = 45000 if text_dataset is None else 1000000
 
     def _key(self, ex):

@@ -147,6 +147,7 @@ class Seq2SeqModel:
             self.Tr[name] = Ref(self.derived, off, (c, r))
         self._ws_cache = OrderedDict()
         self.max_cached_shapes = 8
+        self._ws_pinned = set()                  # keys whose buffers a captured hipGraph points into: never evicted (parallel.py)
         self._dropping = False
         self.au_scale = 1.0
         self.au_external = False     # data parallel: the AU loss is normalised by the all-reduced frame count in dp_norm[1]
@@ -207,8 +208,11 @@ class Seq2SeqModel:
         if key in self._ws_cache:
             self._ws_cache[key] = self._ws_cache.pop(key)          # most recently used last
             return self._ws_cache[key]
-        while len(self._ws_cache) >= self.max_cached_shapes:       # bucketed training visits many shapes
-            self._ws_cache.pop(next(iter(self._ws_cache)))
+        while len(self._ws_cache) - len(self._ws_pinned & set(self._ws_cache)) >= self.max_cached_shapes:   # bucketed training visits many shapes
+            victim = next((k for k in self._ws_cache if k not in self._ws_pinned), None)   # least recently used, not pinned
+            if victim is None:
+                break
+            self._ws_cache.pop(victim)
         cfg, dev = self.cfg, self.dev
         z = lambda *s: torch.zeros(*s, device=dev)
         ws = {"enc": {}}
@@ -293,6 +297,17 @@ class Seq2SeqModel:
         ws["B"], ws["L"] = B, L
         self._ws_cache[key] = ws
         return ws
+
+    def pin_workspace(self, ws):
+        """A captured graph holds raw pointers into this workspace: exempt it from the LRU eviction of _get_ws until unpinned."""
+        for k, v in self._ws_cache.items():
+            if v is ws:
+                self._ws_pinned.add(k)
+                return k
+        return None
+
+    def unpin_workspace(self, key):
+        self._ws_pinned.discard(key)
 
     def _make_block(self, ws, B, L, H, E, mems, cell_prefix, att_prefixes, Tv, Ta, greedy):
         cfg, dev = self.cfg, self.dev
@@ -677,7 +692,9 @@ class Seq2SeqModel:
             import warnings
             warnings.warn("avsr_tf1_amd: persistent RNN kernel timed out; falling back to per-step launches")
             self.persistent_rnn = False
+            self.fused_decode = False
             ops.rnn_set_persistent(False)
+            ops.rnn_persistent_clear()
         return True
 
     @staticmethod
@@ -1269,8 +1286,24 @@ class Seq2SeqModel:
         self.apply_update()
         return self.loss, self.gnorm
 
-    def beam_search_decode(self, batch: Batch, beam_width: int = 10, length_penalty_weight: Optional[float] = None,
-                           max_steps: Optional[int] = None, check_every: int = 8, return_all: bool = False):
+    def beam_search_decode(self, *args, **kw):
+        """See _beam_search_decode.  If a persistent kernel's bounded wait expired during the pass (workgroups not co-resident) the
+        results are invalid: check_persistent() has then switched the one-launch paths off and the pass is redone with one launch
+        per step (the ids written to .mlf files and error rates never come from a flagged pass)."""
+        out = self._beam_search_decode(*args, **kw)
+        if self.check_persistent():
+            out = self._beam_search_decode(*args, **kw)
+        return out
+
+    def greedy_decode(self, *args, **kw):
+        """See _greedy_decode; redone through the per-step launches if a persistent kernel flagged its pass (as above)."""
+        out = self._greedy_decode(*args, **kw)
+        if self.check_persistent():
+            out = self._greedy_decode(*args, **kw)
+        return out
+
+    def _beam_search_decode(self, batch: Batch, beam_width: int = 10, length_penalty_weight: Optional[float] = None,
+                            max_steps: Optional[int] = None, check_every: int = 8, return_all: bool = False):
         """Eval graph with BeamSearchDecoder (decoder_unimodal.py:222-271, decoder_bimodal.py:328-381): ids of beam 0,
         int32 [B, T_out]; positions after the first EOS hold EOS (gather_tree).  length_penalty_weight defaults to the
         reference's 0.6 (unimodal / av_align) or 0.5 (bimodal)."""
@@ -1337,12 +1370,10 @@ class Seq2SeqModel:
         ops.beam_gather_tree(sid, pid, ln[T & 1], out, B, K, T, cfg.eos_id)     # lengths after step T-1 live at parity T&1
         self._last_beam = (D, T)
         if return_all:
-            self.check_persistent()
             return out
-        self.check_persistent()
         return out[:, :, 0].contiguous()
 
-    def greedy_decode(self, batch: Batch, max_steps: Optional[int] = None, check_every: int = 8):
+    def _greedy_decode(self, batch: Batch, max_steps: Optional[int] = None, check_every: int = 8):
         """Eval graph with GreedyEmbeddingHelper (decoder_unimodal.py:176-217): int32 ids [B, T_out], zeros after EOS."""
         cfg = self.cfg
         B = (batch.audio if batch.audio is not None else batch.video if batch.video is not None else batch.labels).shape[0]
@@ -1374,7 +1405,6 @@ class Seq2SeqModel:
         t_out = min(int(D["steplen"].max().item()), l)   # dynamic_decode stops once every utterance has finished
         self._last_greedy = (ws, t_out)
         self._last_align = None
-        self.check_persistent()
         return D["ids"][:, :t_out].contiguous()
 
     def attention_alignments(self):

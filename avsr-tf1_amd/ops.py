@@ -252,7 +252,8 @@ def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, 
                                    float(weight_decay), _s()), "avsr_optimiser_step")
 
 
-PROF_KINDS = ("gemm", "step_lstm_fwd", "step_lstm_bwd", "step_dense", "attn_fwd", "attn_bwd", "rnn_persist_fwd", "rnn_persist_bwd", "dec_persist_fwd")
+PROF_KINDS = ("gemm", "step_lstm_fwd", "step_lstm_bwd", "step_dense", "attn_fwd", "attn_bwd", "rnn_persist_fwd", "rnn_persist_bwd", "dec_persist_fwd",
+              "conv_fwd", "conv_bwd_data", "conv_bwd_weight")
 
 
 def prof_begin(max_launches=65536):
@@ -288,6 +289,12 @@ def rnn_set_persistent(on, device="cuda", ints=1 << 20, mode=3, scratch_floats=6
         check(_L().avsr_rnn_set_persistent(_persist_sync.data_ptr(), ints), "avsr_rnn_set_persistent")
     else:
         check(_L().avsr_rnn_set_persistent(None, 0), "avsr_rnn_set_persistent")
+
+
+def rnn_persistent_clear():
+    """Reset the sticky error word (after the caller has switched the persistent paths off and is about to redo the pass)."""
+    if _persist_sync is not None:
+        _persist_sync[:1].zero_()
 
 
 def attn_rnn_fused_ws_floats(B, n_mech, Dmax=256):

@@ -18,11 +18,17 @@ Launch overhead: a train step is ~1.3k dependent kernel launches; they are captu
 shape into a hipGraph (torch.cuda.CUDAGraph is only the capture/replay plumbing -- every node is one
 of our kernels or a memset/memcpy) and replayed.
 """
+from collections import OrderedDict
+
 import torch
+
+_FIELDS = ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len")
 
 
 class DataParallelTrainer:
-    def __init__(self, model, dist=None, use_graph=True, sync_bn=True, force_collectives=False, check_every_step=False):
+    MAX_GRAPHS = 24          # captured shapes kept (bucketed training visits many): least recently used is dropped with its buffers
+
+    def __init__(self, model, dist=None, use_graph=True, sync_bn=True, force_collectives=False, check_every_step=True):
         self.model, self.dist = model, dist
         self.world = dist.get_world_size() if dist is not None else 1
         # force_collectives: issue every collective even at world size 1 (exercises the RCCL path on a single-GPU box)
@@ -30,10 +36,11 @@ class DataParallelTrainer:
         self.use_graph = use_graph
         self.mode = "eager"
         self._want_graph = use_graph
-        self._graphs = {}
+        self._graphs = OrderedDict()            # key -> (forward+backward graph, update graph, pinned workspace key)
         self._checked = False
-        # eager mode only: read the persistent kernels' sticky "wait expired" flag before EVERY update (one small host sync per
-        # step) and redo the pass through the per-step launches if it is set; off by default (first step only) for benchmarking
+        # read the persistent kernels' sticky "wait expired" flag before EVERY update (one small host sync per step) and redo the
+        # pass through the per-step launches if it is set.  Default ON: a flagged pass holds invalid activations, and training on
+        # them silently is worse than one host round trip per step; bench.py switches it off (first step only) for the timed loop.
         self.check_every_step = bool(check_every_step)
         import os
         self.drain_around_collectives = os.environ.get("AVSR_DP_DRAIN", "1") != "0"
@@ -53,24 +60,39 @@ class DataParallelTrainer:
     # -- helpers ----------------------------------------------------------------------------------
     @staticmethod
     def _key(batch):
-        return tuple((None if t is None else tuple(t.shape)) for t in
-                     (batch.audio, batch.video, batch.labels))
+        """Shapes of every field (None / not-None included: a batch with `aus` and one without are different graphs)."""
+        return tuple((None if getattr(batch, n, None) is None else tuple(getattr(batch, n).shape)) for n in _FIELDS)
 
     def _stage(self, key, batch):
-        """The static buffers the captured graph reads.  The first batch of a shape is adopted as is (its tensors become the
-        static buffers: a caller that keeps feeding the same tensors pays no copy and, more importantly, puts nothing between
-        the graph launches); any other batch is copied in by a kernel, after draining the stream (see _drain)."""
+        """The static buffers the captured graph reads: trainer-OWNED clones of the first batch of a shape (the caller's tensors are
+        never adopted -- a caller that keeps an epoch resident on the GPU must not find its first batch overwritten).  Every batch
+        is copied in by a kernel after draining the stream (see _drain); feeding the static batch object itself back (what a
+        benchmark loop does with the object returned by `static_batch`) costs no copy and puts nothing between the graph launches."""
         st = self._static.get(key)
         if st is None:
-            self._static[key] = st = batch
+            st = type(batch)(**{n: (None if getattr(batch, n, None) is None else getattr(batch, n).clone()) for n in _FIELDS})
+            self._static[key] = st
             return st
-        todo = [(getattr(st, name), getattr(batch, name)) for name in ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len")
-                if getattr(batch, name) is not None and getattr(batch, name).data_ptr() != getattr(st, name).data_ptr()]
+        todo = [(getattr(st, n), getattr(batch, n)) for n in _FIELDS
+                if getattr(batch, n) is not None and getattr(batch, n).data_ptr() != getattr(st, n).data_ptr()]
         if todo:
             self._drain()
             for dst, src in todo:
                 self._copy_into(dst, src)
         return st
+
+    def static_batch(self, batch):
+        """The trainer-owned buffers a batch of this shape is staged into (created from `batch` if the shape is new).  Training on the
+        returned object skips the staging copy."""
+        return self._stage(self._key(batch), batch)
+
+    def _evict_graphs(self):
+        while len(self._graphs) > self.MAX_GRAPHS:
+            key, (_ga, _gb, wskey) = self._graphs.popitem(last=False)
+            self._static.pop(key, None)
+            unpin = getattr(self.model, "unpin_workspace", None)
+            if unpin and wskey is not None:
+                unpin(wskey)
 
     @staticmethod
     def _drain():
@@ -140,6 +162,7 @@ class DataParallelTrainer:
                     self._fwd_bwd(batch)
             if self.collective:
                 dist.all_reduce(m.grads)
+                self._reduce_loss()
             m.apply_update()
             return m.loss, m.gnorm
         if self.collective and self.use_graph and self.drain_after_collectives:
@@ -153,24 +176,54 @@ class DataParallelTrainer:
                 self._fwd_bwd(st)
             if self.collective:
                 dist.all_reduce(m.grads)
+                self._reduce_loss()
             m.apply_update()
             torch.cuda.synchronize()
             try:
                 ga = self._capture(lambda: self._fwd_bwd(st))
                 gb = self._capture(m.apply_update)
-                self._graphs[key] = gr = (ga, gb)
+                # the graphs hold raw pointers into this shape's workspace: pin it against the model's LRU eviction
+                pin = getattr(m, "pin_workspace", None)
+                wskey = pin(m._cur[0]) if (pin and getattr(m, "_cur", None)) else None
+                self._graphs[key] = gr = (ga, gb, wskey)
+                self._evict_graphs()
                 self.mode = "hipgraph"
             except Exception as e:  # capture unsupported: stay eager (still the HIP engine, just host-launched)
                 self.use_graph = False
                 self.mode = "eager (graph capture failed: %s)" % type(e).__name__
             return m.loss, m.gnorm
-        ga, gb = gr
+        ga, gb, _ = gr
+        self._graphs.move_to_end(key)
         ga.replay()
+        if self.check_every_step and self._persistent_failed():
+            # a persistent kernel's bounded wait expired inside the replay: the activations are invalid.  check_persistent() has
+            # switched the one-launch paths off; drop the captured graphs (they contain those launches) and redo the step eagerly.
+            self._drop_graphs()
+            self.use_graph = False
+            self.mode = "eager (persistent kernel flagged a pass)"
+            self._fwd_bwd(st)
         if self.collective:
             if self.drain_around_collectives:          # the 13 MB gradient all-reduce is a large eager kernel between two graph launches
                 self._drain()
             dist.all_reduce(m.grads)
+            self._reduce_loss()
             if self.drain_after_collectives:
                 torch.cuda.synchronize()
-        gb.replay()
+        if self.use_graph:
+            gb.replay()
+        else:
+            m.apply_update()
         return m.loss, m.gnorm
+
+    def _drop_graphs(self):
+        unpin = getattr(self.model, "unpin_workspace", None)
+        for _k, (_ga, _gb, wskey) in self._graphs.items():
+            if unpin and wskey is not None:
+                unpin(wskey)
+        self._graphs.clear()
+
+    def _reduce_loss(self):
+        """The forward pass leaves this rank's share of the batch loss (its cross-entropy sum over the GLOBAL token count, its share
+        of the AU term): summed over the ranks it is the loss the reference reports; L2 joins once, in apply_update, on every rank."""
+        if getattr(self.model, "loss", None) is not None and torch.is_tensor(self.model.loss):
+            self.dist.all_reduce(self.model.loss)

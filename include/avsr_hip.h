@@ -523,9 +523,9 @@ int avsr_optimiser_step(float* params, float* grads, float* m, float* v, int64_t
  * begin and end every gemm / step / attention launch is bracketed by an event pair on its stream; end
  * synchronises the device and returns per-kind launch counts and summed milliseconds.
  * kinds: 0 gemm, 1 LSTM-forward step, 2 LSTM-backward step, 3 dense step, 4 attention fwd, 5 attention bwd,
- * 6 persistent RNN forward, 7 persistent RNN backward, 8 fused persistent decoder forward.  out_flops (may be NULL): algorithmic FLOPs summed per kind
+ * 6 persistent RNN forward, 7 persistent RNN backward, 8 fused persistent decoder forward, 9 / 10 / 11 direct 3x3 convolution forward / data gradient / weight gradient.  out_flops (may be NULL): algorithmic FLOPs summed per kind
  * where the launcher knows them (gemm, persistent RNN kernels), else 0. */
-#define AVSR_PROF_NKIND 9
+#define AVSR_PROF_NKIND 12
 int avsr_prof_begin(int32_t max_launches);
 int avsr_prof_end(int32_t* out_count, float* out_ms, double* out_flops);
 

@@ -78,3 +78,60 @@ def test_two_ranks_equal_one_engine_on_the_whole_batch(tmp_path, use_graph):
     for k, v in ref.items():
         assert np.array_equal(r0[k], r1[k]), k                       # replicas stay bit-identical
         assert np.abs(r0[k] - v).max() < 5e-6 + 1e-4 * np.abs(v).max() * 0.01, (k, np.abs(r0[k] - v).max())
+
+
+# ------------------------------------------------------------------------------------------------
+# data parallelism through the drop-in surface: AVSR(...).train under torch.distributed (two ranks on the box's one GPU, gloo)
+# on TFRecords must leave the parameters one rank leaves after training on the whole data (bucket first, then split by rank).
+def _avsr_kwargs(tmp):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_avsr import _dataset
+    unit_file = os.path.join(tmp, "character_list")
+    p = {k: os.path.join(tmp, k + ".tfrecord") for k in ("audio", "video", "labels")}
+    if not os.path.exists(unit_file):                                  # written once by the parent; the workers only read
+        unit_file, p = _dataset(tmp, n=14)
+    return dict(unit="character", unit_file=unit_file, audio_processing="features", audio_train_record=p["audio"],
+                audio_test_record=p["audio"], labels_train_record=p["labels"], labels_test_record=p["labels"], batch_size=(4, 4),
+                encoder_units_per_layer=((32,), (32, 32)), decoder_units_per_layer=(32,), embedding_size=16, decoding_algorithm="greedy",
+                warmup_steps=0, learning_rate=0.01, shuffle_seed=3, use_dropout=False, sampling_probability_outputs=0.0)
+
+
+def _avsr_worker(rank, world, port, tmp):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["AVSR_PERSISTENT_RNN"] = "0"
+    os.chdir(tmp)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import avsr_tf1_amd as avsr
+    exp = avsr.AVSR(**_avsr_kwargs(os.path.join(tmp, "data")))
+    assert exp._world == 2 and exp._trainer.collective
+    exp.train(logfile="logs/dp", num_epochs=3)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(tmp, "dp_rank%d.npz" % rank), **exp._model.export_tf_weights("params"))
+    dist.destroy_process_group()
+
+
+def test_avsr_train_two_ranks_equals_one_rank_on_the_whole_data(tmp_path, monkeypatch):
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, "data"))
+    kw = _avsr_kwargs(os.path.join(tmp, "data"))                       # writes the records once, before the workers read them
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_avsr_worker, args=(2, port, tmp), nprocs=2, join=True)
+    r0, r1 = np.load(os.path.join(tmp, "dp_rank0.npz")), np.load(os.path.join(tmp, "dp_rank1.npz"))
+    assert os.path.exists(os.path.join(tmp, "logs", "dp")) and open(os.path.join(tmp, "logs", "dp")).read().count("Average batch_loss") == 2
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("AVSR_PERSISTENT_RNN", "0")
+    import avsr_tf1_amd as avsr
+    one = avsr.AVSR(**kw)
+    one.train(logfile="logs/single", num_epochs=3)
+    ref = one._model.export_tf_weights("params")
+    for k, v in ref.items():
+        assert np.array_equal(r0[k], r1[k]), k                       # replicas stay bit-identical
+        assert np.abs(r0[k] - v).max() < 2e-5 + 2e-3 * np.abs(v).max(), (k, np.abs(r0[k] - v).max(), np.abs(v).max())

@@ -209,3 +209,30 @@ def test_fast_step_paths_agree_with_the_generic_parser(monkeypatch):
         assert [int(v[0]) for v in f[1]["labels"]] == [int(v[0]) for v in s[1]["labels"]]
     assert [int(v[0]) for v in fast[2][1]["labels"]] == [3, 300, 1]
     assert fast[0][0]["filename"] == slow[0][0]["filename"]
+
+
+def test_data_parallel_pipeline_buckets_first_then_splits_by_rank(tmp_path):
+    """every rank runs the same shuffle / bucket / batch pipeline and keeps its contiguous share of every bucketed
+    batch, so the GLOBAL batches are the reference's (avsr/io_utils.py:133-147); batches smaller than the world are processed
+    whole by every rank.  A shared seed is mandatory when shuffling."""
+    ud, a, l, v, feats, labs, vids = _write_dataset(str(tmp_path), n=23)
+    kw = dict(batch_size=4, shuffle=True, bucket_width=45, seed=9)
+    whole = list(IO.make_iterator_from_one_record(a, l, ud, **kw))
+    world = 3
+    shards = [list(IO.make_iterator_from_one_record(a, l, ud, rank=r, world=world, **kw)) for r in range(world)]
+    assert all(len(s) == len(whole) for s in shards)                                  # same number of steps on every rank
+    for i, b in enumerate(whole):
+        names = [n for n in b.inputs_filenames]
+        parts = [list(s[i].inputs_filenames) for s in shards]
+        if len(names) < world:
+            assert all(p == names for p in parts)                                      # replicated: the factor `world` cancels
+            continue
+        assert sum(parts, []) == names                                                 # contiguous, ordered, complete, disjoint
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+        for r, s in enumerate(shards):
+            lo = sum(len(p) for p in parts[:r])
+            # shards keep the padded lengths of the GLOBAL batch (the input batch-norm counts the padded rows)
+            assert np.array_equal(s[i].inputs, b.inputs[lo:lo + len(parts[r])]) and np.array_equal(s[i].labels, b.labels[lo:lo + len(parts[r])])
+            assert np.array_equal(s[i].labels_length, b.labels_length[lo:lo + len(parts[r])])
+    with pytest.raises(ValueError, match="shared shuffle seed"):
+        IO.make_iterator_from_one_record(a, l, ud, batch_size=4, shuffle=True, rank=0, world=2)
