@@ -112,7 +112,7 @@ _STRUCTS = {"avsr_dec_layer": DecLayer, "avsr_mat": Mat, "avsr_gemm_desc": GemmD
             "avsr_attn_mech": AttnMech, "avsr_attn_rnn": AttnRnn, "avsr_transpose_job": TransposeJob}
 
 EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_rnn_set_persistent", "avsr_rnn_set_persistent_mode", "avsr_rnn_set_persistent_scratch", "avsr_attn_rnn_fwd",
-           "avsr_attn_rnn_fused_ws_floats", "avsr_attn_rnn_fused_eligible", "avsr_attn_rnn_set_fused",
+           "avsr_attn_rnn_fused_ws_floats", "avsr_attn_rnn_fused_eligible", "avsr_attn_rnn_set_fused", "avsr_conv_set_mfma",
            "avsr_attn_rnn_bwd", "avsr_beam_gather_tree", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_colsum",
            "avsr_batchnorm_fwd", "avsr_batchnorm_fwd_ex", "avsr_batchnorm_bwd", "avsr_batchnorm_xhat", "avsr_im2col", "avsr_col2im",
            "avsr_relu", "avsr_relu_bwd", "avsr_add", "avsr_selu", "avsr_selu_bwd", "avsr_conv3x3_supported", "avsr_conv3x3", "avsr_conv3x3_bwd_data_s2",
@@ -157,6 +157,7 @@ def load():
         "avsr_attn_rnn_fwd": [C.POINTER(AttnRnn), i32, i32, vp],
         "avsr_attn_rnn_fused_eligible": [C.POINTER(AttnRnn)],
         "avsr_attn_rnn_set_fused": [i32],
+        "avsr_conv_set_mfma": [i32],
         "avsr_attn_rnn_bwd": [C.POINTER(AttnRnn), vp],
         "avsr_beam_gather_tree": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "avsr_attn_alpha_rows": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],

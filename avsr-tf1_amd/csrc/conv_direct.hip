@@ -214,6 +214,13 @@ __global__ __launch_bounds__(256) void conv3x3_bwd_weight_kernel(const float* __
 }  // namespace avsr
 
 int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, float alpha, float beta, void* stream);
+// conv_mfma.hip: frame-resident MFMA kernels (AVSR_ERR_UNSUPPORTED -> the direct kernels below)
+int avsr_conv3x3_mfma(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Ci, int Co, int stride, int pad_t,
+                      int pad_l, int Ho, int Wo, int flip, float beta, float* stats, int* nstat, void* stream);
+int avsr_conv3x3_bwd_data_s2_mfma(const float* dy, const float* w, float* dx, int N, int H, int W, int Ci, int Co, int pad_t, int pad_l, int Ho,
+                                  int Wo, float beta, void* stream);
+int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int N, int H, int W, int Ci, int Co, int stride, int pad_t,
+                                 int pad_l, int Ho, int Wo, float beta, float* scratch, long scratch_floats, void* stream);
 
 using namespace avsr;
 #define S_(x) ((hipStream_t)(x))
@@ -230,6 +237,10 @@ extern "C" int avsr_conv3x3(const float* x, const float* w, const float* bias, f
                             int32_t Co, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, int32_t flip, float beta,
                             void* stream) {
   if (!x || !w || !y || N <= 0 || !direct_ok(flip ? Co : Ci, flip ? Ci : Co) || Co % 4 || (flip && stride != 1)) return AVSR_ERR_ARG;
+  {
+    const int rc = avsr_conv3x3_mfma(x, w, bias, y, N, H, W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, flip, beta, nullptr, nullptr, stream);
+    if (rc != AVSR_ERR_UNSUPPORTED) return rc;
+  }
   const long pix = (long)N * Ho * ((Wo + 1) / 2);       // one thread per pair of output pixels
   const size_t lds = sizeof(float) * 9 * Ci * Co;
   avsr::ProfScope ps(flip ? avsr::PROF_CONV_BWD_DATA : avsr::PROF_CONV_FWD, S_(stream), 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
@@ -246,6 +257,10 @@ extern "C" int avsr_conv3x3(const float* x, const float* w, const float* bias, f
 extern "C" int avsr_conv3x3_bwd_data_s2(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                                         int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, float beta, void* stream) {
   if (!dy || !w || !dx || N <= 0 || !direct_ok(Ci, Co) || Ci % 4) return AVSR_ERR_ARG;
+  {
+    const int rc = avsr_conv3x3_bwd_data_s2_mfma(dy, w, dx, N, H, W, Ci, Co, pad_t, pad_l, Ho, Wo, beta, stream);
+    if (rc != AVSR_ERR_UNSUPPORTED) return rc;
+  }
   const long pix = (long)N * H * W;
   const size_t lds = sizeof(float) * 9 * Ci * Co;
   avsr::ProfScope ps(avsr::PROF_CONV_BWD_DATA, S_(stream), 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
@@ -263,6 +278,10 @@ extern "C" int avsr_conv3x3_bwd_weight(const float* x, const float* dy, float* d
                                        int64_t scratch_floats, void* stream) {
   if (!x || !dy || !dw || !scratch || N <= 0 || !avsr_conv3x3_supported(Ci, Co, H, W) || pad_t > 1 || pad_l > 1) return AVSR_ERR_ARG;
   if (Co != 4 && Co != 8 && Co != 16 && Co != 32) return AVSR_ERR_ARG;
+  {
+    const int rc = avsr_conv3x3_bwd_weight_mfma(x, dy, dw, N, H, W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, beta, scratch, scratch_floats, stream);
+    if (rc != AVSR_ERR_UNSUPPORTED) return rc;
+  }
   const int PP = 9 * Ci > 256 ? 2 : 1;
   const int nout = 9 * Ci * Co, G = PP == 1 ? 256 / (9 * Ci) : 1;
   int fpb = H * W <= 128 ? 16 : 4;                      // small maps: more frames per block (fewer partial rows)

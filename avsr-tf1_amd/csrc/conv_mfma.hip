@@ -1,0 +1,562 @@
+// Frame-resident MFMA convolutions of the lip-crop CNN (avsr/video.py:143-195: 3x3 SAME convolutions, stride 1 / 2, 3..64
+// channels, on 36x36 .. 5x5 maps, B*T = 4800 frames per step).
+//
+// The maps of ONE frame are tiny (36x36x8 fp32 = 41 KB), so a workgroup stages whole frames (+ a one-pixel zero halo) in LDS and
+// runs the convolution as an implicit GEMM on v_mfma_f32_16x16x4_f32 straight out of LDS:
+//   rows  (M) = 16 output positions of the staged frames,
+//   cols  (N) = 16 destination channels,
+//   depth (K) = (tap, source channel), 16 per chunk = four 16-byte LDS reads per row; the weight fragments of a wave's column
+//               tile stay in VGPRs for all frames.
+// One kernel covers every data-path convolution through a tap list: out[a, b] = sum_t src[a*S + da_t, b*S + db_t] . W_t
+//   forward, stride s:            S = s, taps (i - pt, j - pl)
+//   data gradient, stride 1:      src = dy, taps (pt - i, pl - j), weights read transposed
+//   data gradient, stride 2:      one launch per parity class (ph, pw) of the input pixels: the taps whose parity matches, OS = 2
+// The weight gradient is the transposed GEMM (rows = (tap, cin), cols = cout, depth = positions) with the frame and its output
+// gradient staged the same way; per-workgroup partial sums are reduced by avsr_colsum_final_launch.
+// The epilogue of the data-path kernel can emit per-channel sum / sum-of-squares partials of what it wrote (batch-norm
+// statistics of the producing convolution: removes two full passes over the map per batch norm).
+#include "common.h"
+#include "prof.h"
+#include "avsr_hip.h"
+
+namespace avsr {
+
+// exact n / d for n < 2^16, 0 < d < 2^16: one 32x32 -> high-32 multiply instead of the ~40-instruction integer division
+// (d = 1 has no 32-bit magic: encoded as 0)
+__device__ __forceinline__ int fdiv(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
+static inline unsigned fmagic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) / (unsigned)d) + 1ull); }
+__device__ __forceinline__ unsigned fmagic_dev(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) / (unsigned)d) + 1ull); }
+
+// Stage `nf4` 16-byte pieces global -> LDS with all of a thread's loads of a batch in flight before the first LDS store
+// (one load, one store per loop trip left every trip exposed to the full memory latency: 40 trips per 36x36x8 frame).
+template <class SrcOff, class DstOff>
+__device__ __forceinline__ void stage4(const float* __restrict__ src, float* __restrict__ lds, int nf4, int tid, SrcOff so, DstOff dof) {
+  for (int base = 0; base < nf4; base += 256 * 16) {
+    f32x4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * 256 + tid;
+      v[u] = idx < nf4 ? ld4(src + so(idx)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int idx = base + u * 256 + tid;
+      if (idx < nf4) st4(lds + dof(idx), v[u]);
+    }
+  }
+}
+
+// Row-structured staging of one [rows][rq pieces] block (16-byte pieces) into a pitched LDS image: a thread keeps its piece
+// column and walks rows by pointer increments; up to 16 loads in flight before the first LDS store.
+__device__ __forceinline__ void stage_rows(const float* __restrict__ src, float* __restrict__ dst, int rows, int rq, int dst_pitch, int tid,
+                                           int my_row, int my_p4, int rpp) {
+  if (my_row < 0) return;
+  const float* sp = src + ((long)my_row * rq + my_p4) * 4;
+  float* dp = dst + my_row * dst_pitch + my_p4 * 4;
+  const int sstep = rpp * rq * 4, dstep = rpp * dst_pitch;
+  int r = my_row;
+  while (r < rows) {
+    f32x4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = (r + u * rpp < rows) ? ld4(sp + u * sstep) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 16; ++u) if (r + u * rpp < rows) st4(dp + u * dstep, v[u]);
+    r += 16 * rpp; sp += 16 * sstep; dp += 16 * dstep;
+  }
+}
+
+#define CG_MAXTAP 9
+struct CGTap { int da, db, widx; };
+struct CGArgs {
+  const float* src; const float* w; const float* bias; float* dst; float* stats;
+  int N, SH, SW, Cs, CsL;
+  int DH, DW, Cd;
+  int OA, OB, S, OS, oh0, ow0;
+  int ntap, wmode, F;
+  float beta;
+  unsigned m_opf, m_ob, m_rq, m_per, m_sw;   // division magics: positions per frame, OB, pieces per source row / per frame (Cs % 4 == 0),
+                                          // or channels / floats per frame / SW (otherwise)
+  CGTap tap[CG_MAXTAP];
+};
+
+// MAXCH: K chunks (16 deep) held per wave
+template <int MAXCH, bool CH4>
+__global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int Cs = A.Cs, CsL = A.CsL, Cd = A.Cd, C4 = CsL >> 2;
+  const int PH = A.SH + 2, PW = A.SW + 2, fstride = PH * PW * CsL;
+  const int KQ = A.ntap * C4, nch = (KQ + 3) >> 2;
+  const int NT = (Cd + 15) >> 4;                      // 1, 2 or 4 column tiles; a wave keeps ONE
+  const int nt = wave % NT, mslot = wave / NT, mstep = 4 / NT;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // zero the LDS once: halos (and the padded 4th channel of a 3-channel source) stay zero, frames overwrite the interior
+  for (int idx = tid; idx < A.F * fstride; idx += 256) lds[idx] = 0.f;
+
+  // weight fragments of this wave's column tile + per-chunk LDS offsets of this lane's k-quad
+  f32x4 wreg[MAXCH];
+  int koff[MAXCH];
+  const int co = nt * 16 + i;
+#pragma unroll
+  for (int c = 0; c < MAXCH; ++c) {
+    const int kq = 4 * c + q;
+    const bool in = c < nch && kq < KQ;
+    const int t = in ? kq / C4 : 0, cs4 = in ? kq - t * C4 : 0;
+    koff[c] = in ? (A.tap[t].da * PW + A.tap[t].db) * CsL + cs4 * 4 : 0;
+    f32x4 wv = zero4;
+    if (in && co < Cd) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int cs = cs4 * 4 + e;
+        if (cs < Cs) wv[e] = A.wmode ? A.w[((long)A.tap[t].widx * Cd + co) * Cs + cs] : A.w[((long)A.tap[t].widx * Cs + cs) * Cd + co];
+      }
+    }
+    wreg[c] = wv;
+  }
+  const float bias_v = (A.bias && co < Cd) ? A.bias[co] : 0.f;
+  float ssum = 0.f, ssq = 0.f;
+  // staging role of this thread: piece column st_p4 of rows st_row, st_row + st_rpp, ...  (threads beyond rpp*rq idle)
+  const int st_rq = (A.SW * Cs) >> 2;
+  const int st_rpp = st_rq > 0 ? (256 / st_rq > 0 ? 256 / st_rq : 1) : 1;
+  const int st_row = (st_rq > 0 && st_rq <= 256) ? (tid < st_rpp * st_rq ? fdiv(tid, A.m_rq) : -1) : -1;
+  const int st_p4 = st_row >= 0 ? tid - st_row * st_rq : 0;
+  const bool lin = A.OS == 1 && A.oh0 == 0 && A.ow0 == 0 && A.DH == A.OA && A.DW == A.OB;   // destination index linear in the position
+  const int opf = A.OA * A.OB;                         // output positions per frame
+  const int rowf = A.SW * Cs;                          // floats per source row
+
+  // ---- software pipeline over passes: the NEXT pass's frames travel memory -> registers while the current pass runs on the matrix
+  // pipe; registers -> LDS between two barriers.  A thread's pieces of a pass: (frame f, row st_row + k*st_rpp, column st_p4) for
+  // 4-channel-multiple sources; 16-byte runs of the contiguous frames (element-wise scatter on store) for the 3-channel crops.
+  constexpr int PF = CH4 ? 12 : 4;
+  f32x4 pre[PF];
+  constexpr bool c4 = CH4;
+  const int ppf = c4 ? (A.SH + st_rpp - 1) / st_rpp : 0;            // pieces per frame per thread (row-structured)
+  const unsigned m_ppf = fmagic_dev(ppf > 0 ? ppf : 1);
+  const int per3 = A.SH * A.SW * Cs;                                // floats per frame (3-channel path)
+  auto fetch = [&](int n0) {
+    const int fcur = min(A.F, A.N - n0);
+    if (c4) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int f = fdiv(u, m_ppf), k = u - f * ppf, r = st_row + k * st_rpp;
+        pre[u] = (st_row >= 0 && f < fcur && r < A.SH) ? ld4(A.src + ((long)(n0 + f) * A.SH + r) * rowf + st_p4 * 4) : zero4;
+      }
+    } else {
+      const float* sp = A.src + (long)n0 * per3;
+      const int tot4 = (fcur * per3) >> 2;
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int idx = u * 256 + tid;
+        pre[u] = idx < tot4 ? ld4(sp + idx * 4) : zero4;
+      }
+    }
+  };
+  auto commit = [&](int n0) {
+    const int fcur = min(A.F, A.N - n0);
+    if (c4) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int f = fdiv(u, m_ppf), k = u - f * ppf, r = st_row + k * st_rpp;
+        if (st_row >= 0 && f < fcur && r < A.SH) st4(lds + f * fstride + ((r + 1) * PW + 1) * CsL + st_p4 * 4, pre[u]);
+      }
+    } else {
+      const int tot = fcur * per3, tot4 = tot >> 2;
+      auto put = [&](int e, float v) {
+        const int f = fdiv(e, A.m_per), r = e - f * per3, px = fdiv(r, A.m_rq), c = r - px * Cs, h = fdiv(px, A.m_sw), pw = px - h * A.SW;
+        lds[f * fstride + ((h + 1) * PW + pw + 1) * CsL + c] = v;
+      };
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int idx = u * 256 + tid;
+        if (idx < tot4) { put(idx * 4, pre[u][0]); put(idx * 4 + 1, pre[u][1]); put(idx * 4 + 2, pre[u][2]); put(idx * 4 + 3, pre[u][3]); }
+      }
+      const float* sp = A.src + (long)n0 * per3;
+      for (int e = tot4 * 4 + tid; e < tot; e += 256) put(e, sp[e]);
+    }
+  };
+  const int step_m = 16 * mstep;
+  int n0 = blockIdx.x * A.F;
+  if (n0 < A.N) fetch(n0);
+  for (; n0 < A.N; n0 += gridDim.x * A.F) {
+    const int fcur = min(A.F, A.N - n0);
+    __syncthreads();                                    // previous pass has finished reading the LDS
+    commit(n0);
+    __syncthreads();
+    if (n0 + gridDim.x * A.F < A.N) fetch(n0 + gridDim.x * A.F);      // in flight during the MFMAs below
+    // ---- implicit GEMM over the staged frames ----
+    const int Mtot = fcur * opf, mtiles = (Mtot + 15) >> 4;
+    float* const dlin = A.dst + ((long)n0 * opf + q * 4) * Cd + co;  // linear destination: position m lives at dlin + m*Cd
+    for (int mt = mslot; mt < mtiles; mt += mstep) {
+      const int m = mt * 16 + i;
+      const int mm = m < Mtot ? m : 0;
+      const int f = fdiv(mm, A.m_opf), r = mm - f * opf, a = fdiv(r, A.m_ob), b = r - a * A.OB;
+      const float* base = lds + f * fstride + ((a * A.S + 1) * PW + (b * A.S + 1)) * CsL;
+      f32x4 acc0 = zero4, acc1 = zero4;
+#pragma unroll
+      for (int c = 0; c < MAXCH; c += 2) {
+        if (c < nch) {
+          const f32x4 av = ld4(base + koff[c]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wreg[c][e], acc0, 0, 0, 0);
+        }
+        if (c + 1 < MAXCH && c + 1 < nch) {
+          const f32x4 av = ld4(base + koff[c + 1]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wreg[c + 1 < MAXCH ? c + 1 : c][e], acc1, 0, 0, 0);
+        }
+      }
+      f32x4 acc = acc0 + acc1;
+      // C layout: row = q*4 + r, column = i
+      if (co < Cd) {
+        const int mo0 = mt * 16 + q * 4;
+        if (lin && mo0 + 3 < Mtot) {                    // the common case: four in-range rows, destination linear in the position
+          float* dp = dlin + (long)(mt * 16) * Cd;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            float v = acc[rr] + bias_v;
+            if (A.beta != 0.f) v += A.beta * dp[rr * Cd];
+            dp[rr * Cd] = v;
+            acc[rr] = v;
+          }
+          if (A.stats) {
+            ssum += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            ssq += (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]);
+          }
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int mo = mo0 + rr;
+            if (mo < Mtot) {
+              float* dp;
+              if (lin) dp = A.dst + ((long)n0 * opf + mo) * Cd + co;
+              else {
+                const int fo = fdiv(mo, A.m_opf), ro = mo - fo * opf, ao = fdiv(ro, A.m_ob), bo = ro - ao * A.OB;
+                dp = A.dst + (((long)(n0 + fo) * A.DH + ao * A.OS + A.oh0) * A.DW + bo * A.OS + A.ow0) * Cd + co;
+              }
+              float v = acc[rr] + bias_v;
+              if (A.beta != 0.f) v += A.beta * *dp;
+              *dp = v;
+              ssum += v; ssq += v * v;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (A.stats) {
+    // per-channel partials of this workgroup: lanes (i, q = 0..3) of the waves holding column tile nt
+    __syncthreads();
+    float* red = lds;                                   // [4 waves][4 q][16][2]
+    red[((wave * 4 + q) * 16 + i) * 2] = ssum;
+    red[((wave * 4 + q) * 16 + i) * 2 + 1] = ssq;
+    __syncthreads();
+    if (tid < Cd) {
+      const int tnt = tid >> 4, ti = tid & 15;
+      float s = 0.f, s2 = 0.f;
+      for (int w = 0; w < 4; ++w)
+        if (w % NT == tnt)
+          for (int qq = 0; qq < 4; ++qq) { s += red[((w * 4 + qq) * 16 + ti) * 2]; s2 += red[((w * 4 + qq) * 16 + ti) * 2 + 1]; }
+      A.stats[(long)blockIdx.x * 2 * Cd + tid] = s;
+      A.stats[(long)blockIdx.x * 2 * Cd + Cd + tid] = s2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// weight gradient: part[blk][(t*Ci + ci)*Co + co] = sum over the block's frames and positions of x[pos(t)][ci] * dy[pos][co]
+struct WGArgs {
+  const float* x; const float* dy; float* part;
+  int N, H, W, Ci, CiL, Ho, Wo, Co, S, pt, pl, F;
+  unsigned m_opf, m_wo, m_rq, m_per, m_w;
+};
+
+// MT: row tiles (16 rows of (tap, ci)) held per wave; NTC: column tiles
+template <int MT, int NTC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int Ci = A.Ci, CiL = A.CiL, Co = A.Co;
+  const int PH = A.H + 2, PW = A.W + 2, xstride = PH * PW * CiL;
+  const int opf = A.Ho * A.Wo, dstride = (opf * Co + 3) & ~3;
+  float* const xs = lds;                               // [F][PH][PW][CiL]   (the output gradient is read straight from memory:
+                                                       //  every value is used once per row tile, 16 lanes = 64 contiguous bytes)
+  const int Mrows = 9 * CiL;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (int idx = tid; idx < A.F * xstride; idx += 256) xs[idx] = 0.f;
+
+  // row (t, ci) of this lane in every row tile -> LDS offset of its tap / channel
+  int roff[MT];
+  bool rok[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = mt * 16 + i;
+    rok[mt] = row < Mrows;
+    const int t = rok[mt] ? row / CiL : 0, ci = rok[mt] ? row - t * CiL : 0, ti = t / 3, tj = t - ti * 3;
+    roff[mt] = ((ti - A.pt) * PW + (tj - A.pl)) * CiL + ci;
+  }
+  f32x4 acc[MT][NTC];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) acc[mt][nt] = zero4;
+  const int rowf = A.W * Ci;
+  const int st_rq = rowf >> 2;
+  const int st_rpp = st_rq > 0 ? (256 / st_rq > 0 ? 256 / st_rq : 1) : 1;
+  const int st_row = (st_rq > 0 && st_rq <= 256 && (Ci & 3) == 0) ? (tid < st_rpp * st_rq ? fdiv(tid, A.m_rq) : -1) : -1;
+  const int st_p4 = st_row >= 0 ? tid - st_row * st_rq : 0;
+
+  for (int n0 = blockIdx.x * A.F; n0 < A.N; n0 += gridDim.x * A.F) {
+    const int fcur = min(A.F, A.N - n0);
+    __syncthreads();
+    if ((Ci & 3) == 0) {
+      const int rq = rowf >> 2;
+      for (int f = 0; f < fcur; ++f)
+        stage_rows(A.x + (long)(n0 + f) * A.H * rowf, xs + f * xstride + (PW + 1) * CiL, A.H, rq, PW * CiL, tid, st_row, st_p4, st_rpp);
+    } else {
+      const int per = A.H * A.W * Ci, tot = fcur * per, tot4 = tot >> 2;
+      const float* sp = A.x + (long)n0 * per;
+      const bool al = ((((size_t)sp) & 15) == 0);
+      auto put = [&](int e, float v) {
+        const int f = fdiv(e, A.m_per), r = e - f * per, px = fdiv(r, A.m_rq), c = r - px * Ci, h = fdiv(px, A.m_w), pw = px - h * A.W;
+        xs[f * xstride + ((h + 1) * PW + pw + 1) * CiL + c] = v;
+      };
+      if (al) {
+        for (int base = 0; base < tot4; base += 256 * 8) {
+          f32x4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { const int idx = base + u * 256 + tid; v[u] = idx < tot4 ? ld4(sp + idx * 4) : zero4; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 256 + tid;
+            if (idx < tot4) { put(idx * 4, v[u][0]); put(idx * 4 + 1, v[u][1]); put(idx * 4 + 2, v[u][2]); put(idx * 4 + 3, v[u][3]); }
+          }
+        }
+        for (int e = tot4 * 4 + tid; e < tot; e += 256) put(e, sp[e]);
+      } else {
+        for (int e = tid; e < tot; e += 256) put(e, sp[e]);
+      }
+    }
+    // depth = output positions, 16 per chunk (lane quad q takes positions 4q .. 4q+3 of the chunk); chunks are dealt to the waves.
+    // The output-gradient fragment of the NEXT chunk of this wave is requested before the current chunk's MFMAs.
+    const int Ktot = fcur * opf, kch = (Ktot + 15) >> 4;
+    const float* dyp = A.dy + (long)n0 * opf * Co;       // positions of the pass are contiguous: [fcur*opf][Co]
+    float bn[NTC][4];
+    auto load_b = [&](int kc, float (&b)[NTC][4]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int p = kc * 16 + q * 4 + e;
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) b[nt][e] = (p < Ktot && nt * 16 + i < Co) ? dyp[(long)p * Co + nt * 16 + i] : 0.f;
+      }
+    };
+    if (wave < kch) load_b(wave, bn);
+    __syncthreads();
+    for (int kc = wave; kc < kch; kc += 4) {
+      float av[MT][4], bv[NTC][4];
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[nt][e] = bn[nt][e];
+      if (kc + 4 < kch) load_b(kc + 4, bn);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int p = kc * 16 + q * 4 + e;
+        const bool pin = p < Ktot;
+        const int pp = pin ? p : 0;
+        const int f = fdiv(pp, A.m_opf), r = pp - f * opf, ho = fdiv(r, A.m_wo), wo = r - ho * A.Wo;
+        const float* xb = xs + f * xstride + ((ho * A.S + 1) * PW + (wo * A.S + 1)) * CiL;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt][e] = (pin && rok[mt]) ? xb[roff[mt]] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTC; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], bv[nt][e], acc[mt][nt], 0, 0, 0);
+    }
+  }
+  // cross-wave reduction (waves hold different depth slices of the same tiles), tile by tile through a 4 KB staging area, then
+  // one partial per workgroup
+  float* red = lds;                                     // [4][16][16]
+  const int nout = 9 * Ci * Co;
+  const int rr = tid >> 4, cc = tid & 15;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 16 + q * 4 + r) * 16 + i] = acc[mt][nt][r];
+      __syncthreads();
+      const int row = mt * 16 + rr, co = nt * 16 + cc;
+      if (row < Mrows && co < Co) {
+        const int t = row / CiL, ci = row - t * CiL;
+        if (ci < Ci) A.part[(long)blockIdx.x * nout + ((long)t * Ci + ci) * Co + co] = (red[rr * 16 + cc] + red[(16 + rr) * 16 + cc]) + (red[(32 + rr) * 16 + cc] + red[(48 + rr) * 16 + cc]);
+      }
+    }
+}
+
+static int g_conv_mfma = 1;
+
+}  // namespace avsr
+
+int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, float alpha, float beta, void* stream);
+
+using namespace avsr;
+#define S_(x) ((hipStream_t)(x))
+
+extern "C" int avsr_conv_set_mfma(int32_t on) { g_conv_mfma = on ? 1 : 0; return AVSR_OK; }
+
+static int cg_frames(int sh, int sw, int csl, int opf, int extra_floats_per_frame = 0) {
+  const long per = (long)(sh + 2) * (sw + 2) * csl + extra_floats_per_frame;
+  int F = (int)((60 * 1024 / 4) / per);                 // <= 60 KB of frames: two workgroups per CU
+  if (F < 1) F = 1;
+  int want = (1024 + opf - 1) / opf;                    // enough positions per pass to keep the four waves in row tiles
+  if (want < 1) want = 1;
+  if (F > want) F = want;
+  if (F > 16) F = 16;
+  return F;
+}
+
+static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops) {
+  const int KQ = A.ntap * (A.CsL / 4), nch = (KQ + 3) / 4;
+  const int NT = (A.Cd + 15) / 16;
+  if (!(NT == 1 || NT == 2 || NT == 4) || nch > 18) return AVSR_ERR_UNSUPPORTED;
+  // a pass (F frames) must fit the 16 prefetch registers of a thread
+  if (A.Cs % 4 == 0) {
+    const int rq = A.SW * A.Cs / 4;
+    if (rq > 256 || rq < 1) return AVSR_ERR_UNSUPPORTED;
+    const int rpp = 256 / rq;
+    while (A.F > 1 && A.F * ((A.SH + rpp - 1) / rpp) > 12) --A.F;
+    if (A.F * ((A.SH + rpp - 1) / rpp) > 12) return AVSR_ERR_UNSUPPORTED;
+    A.m_rq = fmagic(rq); A.m_per = fmagic(A.SH * rq); A.m_sw = fmagic(A.SW);
+  } else {
+    while (A.F > 1 && (A.F * A.SH * A.SW * A.Cs / 4 + 255) / 256 > 4) --A.F;
+    if ((A.F * A.SH * A.SW * A.Cs / 4 + 255) / 256 > 4 || (long)A.F * A.SH * A.SW * A.Cs >= 65536) return AVSR_ERR_UNSUPPORTED;
+    A.m_rq = fmagic(A.Cs); A.m_per = fmagic(A.SH * A.SW * A.Cs); A.m_sw = fmagic(A.SW);
+  }
+  if ((long)A.F * A.OA * A.OB >= 65536) return AVSR_ERR_UNSUPPORTED;
+  A.m_opf = fmagic(A.OA * A.OB); A.m_ob = fmagic(A.OB);
+  const size_t lds = sizeof(float) * (size_t)A.F * (A.SH + 2) * (A.SW + 2) * A.CsL;
+  if (lds > 64 * 1024 || lds < sizeof(float) * 4 * 4 * 16 * 2) return AVSR_ERR_UNSUPPORTED;
+  int grid = (A.N + A.F - 1) / A.F;
+  int wpc = (int)((150 * 1024) / (lds + 512));          // workgroups per CU that fit
+  if (wpc > 2) wpc = 2;
+  if (wpc < 1) wpc = 1;
+  if (grid > 256 * wpc) grid = 256 * wpc;
+  ProfScope ps(kind, s, flops);
+  if (A.Cs % 4) {
+    if (nch > 5) return AVSR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((conv_gen_kernel<5, false>), dim3(grid), dim3(256), lds, s, A);
+  } else if (nch <= 5) hipLaunchKernelGGL((conv_gen_kernel<5, true>), dim3(grid), dim3(256), lds, s, A);
+  else if (nch <= 9) hipLaunchKernelGGL((conv_gen_kernel<9, true>), dim3(grid), dim3(256), lds, s, A);
+  else if (nch <= 18) hipLaunchKernelGGL((conv_gen_kernel<18, true>), dim3(grid), dim3(256), lds, s, A);
+  else return AVSR_ERR_UNSUPPORTED;                     // K > 288 (64-channel sources) stays on im2col + GEMM
+  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+  return grid;
+}
+
+// Forward (flip = 0) / stride-1 data gradient (flip = 1) of a 3x3 convolution, same contract as avsr_conv3x3.
+// stats (may be NULL): >= 1024 * 2 * Co floats; returns the number of partial rows written through *nstat.
+int avsr_conv3x3_mfma(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Ci, int Co, int stride, int pad_t,
+                      int pad_l, int Ho, int Wo, int flip, float beta, float* stats, int* nstat, void* stream) {
+  if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
+  if (Co % 4 || (Ci % 4 && Ci >= 4) || pad_t > 1 || pad_l > 1 || (flip && stride != 1)) return AVSR_ERR_UNSUPPORTED;
+  CGArgs A = {};
+  A.src = x; A.w = w; A.bias = bias; A.dst = y; A.stats = stats;
+  A.N = N; A.SH = H; A.SW = W; A.Cs = Ci; A.CsL = (Ci + 3) & ~3;
+  A.DH = Ho; A.DW = Wo; A.Cd = Co; A.OA = Ho; A.OB = Wo; A.S = stride; A.OS = 1; A.oh0 = 0; A.ow0 = 0;
+  A.ntap = 9; A.wmode = flip; A.beta = beta;
+  for (int t = 0; t < 9; ++t) {
+    const int i = t / 3, j = t % 3;
+    if (!flip) A.tap[t] = CGTap{i - pad_t, j - pad_l, t};
+    else A.tap[t] = CGTap{pad_t - i, pad_l - j, t};      // dx[h, w] += dy[h + pt - i, w + pl - j] . W[i, j]^T
+  }
+  A.F = cg_frames(H, W, A.CsL, Ho * Wo);
+  const int rc = cg_launch(A, S_(stream), flip ? PROF_CONV_BWD_DATA : PROF_CONV_FWD, 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
+  if (rc < 0) return rc;
+  if (nstat) *nstat = rc;
+  return AVSR_OK;
+}
+
+// stride-2 data gradient: dx [N,H,W,Ci] (+)= from dy [N,Ho,Wo,Co]; one launch per parity class of the input pixels
+int avsr_conv3x3_bwd_data_s2_mfma(const float* dy, const float* w, float* dx, int N, int H, int W, int Ci, int Co, int pad_t, int pad_l, int Ho,
+                                  int Wo, float beta, void* stream) {
+  if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
+  if (Co % 4 || Ci % 4 || pad_t > 1 || pad_l > 1) return AVSR_ERR_UNSUPPORTED;
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw) {
+      CGArgs A = {};
+      A.src = dy; A.w = w; A.bias = nullptr; A.dst = dx; A.stats = nullptr;
+      A.N = N; A.SH = Ho; A.SW = Wo; A.Cs = Co; A.CsL = Co;
+      A.DH = H; A.DW = W; A.Cd = Ci; A.OA = (H - ph + 1) / 2; A.OB = (W - pw + 1) / 2; A.S = 1; A.OS = 2; A.oh0 = ph; A.ow0 = pw;
+      A.wmode = 1; A.beta = beta;
+      int nt = 0;
+      for (int i = 0; i < 3; ++i) {
+        if ((ph + pad_t - i) & 1) continue;
+        for (int j = 0; j < 3; ++j) {
+          if ((pw + pad_l - j) & 1) continue;
+          // dx[2a+ph, 2b+pw] += dy[a + (ph+pt-i)/2, b + (pw+pl-j)/2] . W[i, j]^T   (arithmetic shift: -1/2 -> floor)
+          A.tap[nt++] = CGTap{(ph + pad_t - i) >> 1, (pw + pad_l - j) >> 1, i * 3 + j};
+        }
+      }
+      A.ntap = nt;
+      if (A.OA <= 0 || A.OB <= 0) continue;
+      if (nt == 0) return AVSR_ERR_UNSUPPORTED;
+      A.F = cg_frames(Ho, Wo, A.CsL, A.OA * A.OB);
+      const int rc = cg_launch(A, S_(stream), PROF_CONV_BWD_DATA, 2.0 * N * A.OA * A.OB * nt * (double)Ci * Co);
+      if (rc < 0) return rc;
+    }
+  return AVSR_OK;
+}
+
+// weight gradient: dw[3,3,Ci,Co] = beta*dw + sum x (x) dy; scratch >= 256 * 9*Ci*Co floats
+int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int N, int H, int W, int Ci, int Co, int stride, int pad_t,
+                                 int pad_l, int Ho, int Wo, float beta, float* scratch, long scratch_floats, void* stream) {
+  if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
+  if (Co % 4 || (Ci % 4 && Ci >= 4) || pad_t > 1 || pad_l > 1) return AVSR_ERR_UNSUPPORTED;
+  WGArgs A = {};
+  A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo; A.Co = Co;
+  A.S = stride; A.pt = pad_t; A.pl = pad_l;
+  const int MT = (9 * A.CiL + 15) / 16, NTC = (Co + 15) / 16;
+  if (MT > 18 || NTC > 2 || MT * NTC > 36) return AVSR_ERR_UNSUPPORTED;
+  A.F = cg_frames(H, W, A.CiL, Ho * Wo);
+  const size_t red = sizeof(float) * 4 * 256;
+  size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * A.CiL;
+  if (lds < red) lds = red;
+  if (lds > 96 * 1024) return AVSR_ERR_UNSUPPORTED;
+  const int nout = 9 * Ci * Co;
+  if ((long)A.F * Ho * Wo >= 65536 || (long)A.F * H * W * A.CiL >= 65536) return AVSR_ERR_UNSUPPORTED;
+  A.m_opf = fmagic(Ho * Wo); A.m_wo = fmagic(Wo); A.m_w = fmagic(W);
+  if (Ci % 4 == 0) { if (W * Ci / 4 > 256) return AVSR_ERR_UNSUPPORTED; A.m_rq = fmagic(W * Ci / 4); A.m_per = fmagic(H * (W * Ci / 4)); }
+  else { A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci); }
+  int wpc = (int)((150 * 1024) / (lds + 512));
+  if (wpc > 2) wpc = 2;
+  if (wpc < 1) wpc = 1;
+  if (nout > 2048) wpc = 1;                              // large kernels: the partial slabs, not the staging, are the traffic
+  int grid = (N + A.F - 1) / A.F;
+  if (grid > 256 * wpc) grid = 256 * wpc;
+  if ((long)grid * nout > scratch_floats) grid = (int)(scratch_floats / nout);
+  if (grid < 1) return AVSR_ERR_ARG;
+  hipStream_t s = S_(stream);
+  static bool attr = false;
+  if (!attr) {
+#define WG_ATTR(M_, N_) if (hipFuncSetAttribute((const void*)conv_wgrad_kernel<M_, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return AVSR_ERR_HIP;
+    WG_ATTR(3, 1) WG_ATTR(5, 1) WG_ATTR(9, 1) WG_ATTR(5, 2) WG_ATTR(9, 2) WG_ATTR(18, 2) WG_ATTR(18, 1)
+#undef WG_ATTR
+    attr = true;
+  }
+  {
+    ProfScope ps(PROF_CONV_BWD_WEIGHT, s, 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
+#define WG_GO(M_, N_) hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_>), dim3(grid), dim3(256), lds, s, A)
+    if (NTC == 1) { if (MT <= 3) WG_GO(3, 1); else if (MT <= 5) WG_GO(5, 1); else if (MT <= 9) WG_GO(9, 1); else WG_GO(18, 1); }
+    else { if (MT <= 5) WG_GO(5, 2); else if (MT <= 9) WG_GO(9, 2); else WG_GO(18, 2); }
+#undef WG_GO
+    if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+  }
+  return avsr_colsum_final_launch(scratch, grid, dw, nout, 1.0f, beta, stream);
+}

@@ -409,6 +409,10 @@ int avsr_col2im(const float* dcol, float* dx, int32_t N, int32_t H, int32_t W, i
  *   avsr_conv3x3_bwd_data_s2: data gradient of a stride-2 conv (dx [N,H,W,Ci] from dy [N,Ho,Wo,Co]).
  *   avsr_conv3x3_bwd_weight: dw[3,3,Ci,Co] = beta*dw + sum x (x) dy; Co in {4, 8, 16}; scratch >= ceil(N/4) * (256/(9*Ci)) * 9*Ci*Co floats (fewer blocks if smaller). */
 int avsr_conv3x3_supported(int32_t Ci, int32_t Co, int32_t H, int32_t W);
+/* The three entry points below run the frame-resident MFMA kernels of csrc/conv_mfma.hip where they cover the shape (whole frames
+ * staged in LDS, implicit GEMM on v_mfma_f32_16x16x4_f32) and the direct VALU kernels otherwise; this switch (default 1) forces the
+ * latter (A/B timing, tests). */
+int avsr_conv_set_mfma(int32_t on);
 int avsr_conv3x3(const float* x, const float* w, const float* bias, float* y, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                  int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, int32_t flip, float beta, void* stream);
 int avsr_conv3x3_bwd_data_s2(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
