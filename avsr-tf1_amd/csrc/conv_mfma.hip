@@ -272,30 +272,30 @@ struct WGArgs {
   unsigned m_opf, m_wo, m_rq, m_per, m_w;
 };
 
-// MT: row tiles (16 rows of (tap, ci)) held per wave; NTC: column tiles
-template <int MT, int NTC>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGArgs A) {
+// MT: row tiles (16 rows of (tap, ci)) held per wave; NTC: column tiles; CH4: 4-channel-multiple input (row-structured staging)
+template <int MT, int NTC, bool CH4>
+__global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kernel(const WGArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int Ci = A.Ci, CiL = A.CiL, Co = A.Co;
   const int PH = A.H + 2, PW = A.W + 2, xstride = PH * PW * CiL;
-  const int opf = A.Ho * A.Wo, dstride = (opf * Co + 3) & ~3;
+  const int opf = A.Ho * A.Wo;
   float* const xs = lds;                               // [F][PH][PW][CiL]   (the output gradient is read straight from memory:
                                                        //  every value is used once per row tile, 16 lanes = 64 contiguous bytes)
   const int Mrows = 9 * CiL;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   for (int idx = tid; idx < A.F * xstride; idx += 256) xs[idx] = 0.f;
 
-  // row (t, ci) of this lane in every row tile -> LDS offset of its tap / channel
+  // row (t, ci) of this lane in every row tile -> LDS offset of its tap / channel (rows beyond 9*CiL read offset 0: their
+  // accumulators are never written out)
   int roff[MT];
-  bool rok[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int row = mt * 16 + i;
-    rok[mt] = row < Mrows;
-    const int t = rok[mt] ? row / CiL : 0, ci = rok[mt] ? row - t * CiL : 0, ti = t / 3, tj = t - ti * 3;
-    roff[mt] = ((ti - A.pt) * PW + (tj - A.pl)) * CiL + ci;
+    const bool ok = row < Mrows;
+    const int t = ok ? row / CiL : 0, ci = ok ? row - t * CiL : 0, ti = t / 3, tj = t - ti * 3;
+    roff[mt] = ok ? ((ti - A.pt) * PW + (tj - A.pl)) * CiL + ci : 0;
   }
   f32x4 acc[MT][NTC];
 #pragma unroll
@@ -304,56 +304,77 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGArgs A) {
     for (int nt = 0; nt < NTC; ++nt) acc[mt][nt] = zero4;
   const int rowf = A.W * Ci;
   const int st_rq = rowf >> 2;
-  const int st_rpp = st_rq > 0 ? (256 / st_rq > 0 ? 256 / st_rq : 1) : 1;
-  const int st_row = (st_rq > 0 && st_rq <= 256 && (Ci & 3) == 0) ? (tid < st_rpp * st_rq ? fdiv(tid, A.m_rq) : -1) : -1;
+  const int st_rpp = (CH4 && st_rq > 0) ? (256 / st_rq > 0 ? 256 / st_rq : 1) : 1;
+  const int st_row = CH4 ? (tid < st_rpp * st_rq ? fdiv(tid, A.m_rq) : -1) : -1;
   const int st_p4 = st_row >= 0 ? tid - st_row * st_rq : 0;
-
-  for (int n0 = blockIdx.x * A.F; n0 < A.N; n0 += gridDim.x * A.F) {
+  constexpr int PF = CH4 ? 12 : 4;
+  f32x4 pre[PF];
+  const int ppf = CH4 ? (A.H + st_rpp - 1) / st_rpp : 0;
+  const unsigned m_ppf = fmagic_dev(ppf > 0 ? ppf : 1);
+  const int per3 = A.H * A.W * Ci;
+  auto fetch = [&](int n0) {
     const int fcur = min(A.F, A.N - n0);
-    __syncthreads();
-    if ((Ci & 3) == 0) {
-      const int rq = rowf >> 2;
-      for (int f = 0; f < fcur; ++f)
-        stage_rows(A.x + (long)(n0 + f) * A.H * rowf, xs + f * xstride + (PW + 1) * CiL, A.H, rq, PW * CiL, tid, st_row, st_p4, st_rpp);
+    if (CH4) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int f = fdiv(u, m_ppf), k = u - f * ppf, r = st_row + k * st_rpp;
+        pre[u] = (st_row >= 0 && f < fcur && r < A.H) ? ld4(A.x + ((long)(n0 + f) * A.H + r) * rowf + st_p4 * 4) : zero4;
+      }
     } else {
-      const int per = A.H * A.W * Ci, tot = fcur * per, tot4 = tot >> 2;
-      const float* sp = A.x + (long)n0 * per;
-      const bool al = ((((size_t)sp) & 15) == 0);
+      const float* sp = A.x + (long)n0 * per3;
+      const int tot4 = (fcur * per3) >> 2;
+#pragma unroll
+      for (int u = 0; u < PF; ++u) { const int idx = u * 256 + tid; pre[u] = idx < tot4 ? ld4(sp + idx * 4) : zero4; }
+    }
+  };
+  auto commit = [&](int n0) {
+    const int fcur = min(A.F, A.N - n0);
+    if (CH4) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int f = fdiv(u, m_ppf), k = u - f * ppf, r = st_row + k * st_rpp;
+        if (st_row >= 0 && f < fcur && r < A.H) st4(xs + f * xstride + ((r + 1) * PW + 1) * CiL + st_p4 * 4, pre[u]);
+      }
+    } else {
+      const int tot = fcur * per3, tot4 = tot >> 2;
       auto put = [&](int e, float v) {
-        const int f = fdiv(e, A.m_per), r = e - f * per, px = fdiv(r, A.m_rq), c = r - px * Ci, h = fdiv(px, A.m_w), pw = px - h * A.W;
+        const int f = fdiv(e, A.m_per), r = e - f * per3, px = fdiv(r, A.m_rq), c = r - px * Ci, h = fdiv(px, A.m_w), pw = px - h * A.W;
         xs[f * xstride + ((h + 1) * PW + pw + 1) * CiL + c] = v;
       };
-      if (al) {
-        for (int base = 0; base < tot4; base += 256 * 8) {
-          f32x4 v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { const int idx = base + u * 256 + tid; v[u] = idx < tot4 ? ld4(sp + idx * 4) : zero4; }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * 256 + tid;
-            if (idx < tot4) { put(idx * 4, v[u][0]); put(idx * 4 + 1, v[u][1]); put(idx * 4 + 2, v[u][2]); put(idx * 4 + 3, v[u][3]); }
-          }
-        }
-        for (int e = tot4 * 4 + tid; e < tot; e += 256) put(e, sp[e]);
-      } else {
-        for (int e = tid; e < tot; e += 256) put(e, sp[e]);
+      for (int u = 0; u < PF; ++u) {
+        const int idx = u * 256 + tid;
+        if (idx < tot4) { put(idx * 4, pre[u][0]); put(idx * 4 + 1, pre[u][1]); put(idx * 4 + 2, pre[u][2]); put(idx * 4 + 3, pre[u][3]); }
       }
+      const float* sp = A.x + (long)n0 * per3;
+      for (int e = tot4 * 4 + tid; e < tot; e += 256) put(e, sp[e]);
     }
-    // depth = output positions, 16 per chunk (lane quad q takes positions 4q .. 4q+3 of the chunk); chunks are dealt to the waves.
-    // The output-gradient fragment of the NEXT chunk of this wave is requested before the current chunk's MFMAs.
-    const int Ktot = fcur * opf, kch = (Ktot + 15) >> 4;
-    const float* dyp = A.dy + (long)n0 * opf * Co;       // positions of the pass are contiguous: [fcur*opf][Co]
+  };
+
+  // depth = output positions; a chunk = 16 positions of ONE frame (the last chunk of a frame is partial), lane quad q takes
+  // positions 4q .. 4q+3 of the chunk; chunks are dealt to the waves round-robin.
+  const int cpf = (opf + 15) >> 4;                       // chunks per frame
+  const unsigned m_cpf = fmagic_dev(cpf);
+  int n0 = blockIdx.x * A.F;
+  if (n0 < A.N) fetch(n0);
+  for (; n0 < A.N; n0 += gridDim.x * A.F) {
+    const int fcur = min(A.F, A.N - n0);
+    __syncthreads();
+    commit(n0);
+    const int kch = fcur * cpf;
+    const float* dyp = A.dy + (long)n0 * opf * Co;       // [fcur][opf][Co]
     float bn[NTC][4];
     auto load_b = [&](int kc, float (&b)[NTC][4]) {
+      const int f = fdiv(kc, m_cpf), r0 = (kc - f * cpf) * 16 + q * 4;
+      const float* dp = dyp + ((long)f * opf + r0) * Co + i;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int p = kc * 16 + q * 4 + e;
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) b[nt][e] = (p < Ktot && nt * 16 + i < Co) ? dyp[(long)p * Co + nt * 16 + i] : 0.f;
-      }
+        for (int nt = 0; nt < NTC; ++nt) b[nt][e] = (r0 + e < opf && nt * 16 + i < Co) ? dp[e * Co + nt * 16] : 0.f;
     };
     if (wave < kch) load_b(wave, bn);
     __syncthreads();
+    if (n0 + gridDim.x * A.F < A.N) fetch(n0 + gridDim.x * A.F);      // next pass's frames: in flight during the MFMAs
     for (int kc = wave; kc < kch; kc += 4) {
       float av[MT][4], bv[NTC][4];
 #pragma unroll
@@ -361,15 +382,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WGArgs A) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[nt][e] = bn[nt][e];
       if (kc + 4 < kch) load_b(kc + 4, bn);
+      const int f = fdiv(kc, m_cpf), r0 = (kc - f * cpf) * 16 + q * 4;
+      int ho = fdiv(min(r0, opf - 1), A.m_wo), wo = min(r0, opf - 1) - ho * A.Wo;
+      const float* xf = xs + f * xstride + (PW + 1) * CiL;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int p = kc * 16 + q * 4 + e;
-        const bool pin = p < Ktot;
-        const int pp = pin ? p : 0;
-        const int f = fdiv(pp, A.m_opf), r = pp - f * opf, ho = fdiv(r, A.m_wo), wo = r - ho * A.Wo;
-        const float* xb = xs + f * xstride + ((ho * A.S + 1) * PW + (wo * A.S + 1)) * CiL;
+        const float* xb = xf + (ho * A.S * PW + wo * A.S) * CiL;
+        const bool pin = r0 + e < opf;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt][e] = (pin && rok[mt]) ? xb[roff[mt]] : 0.f;
+        for (int mt = 0; mt < MT; ++mt) av[mt][e] = pin ? xb[roff[mt]] : 0.f;
+        if (++wo == A.Wo) { wo = 0; ++ho; }
+        if (ho >= A.Ho) { ho = A.Ho - 1; }                 // (only reached by out-of-range positions: masked above)
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -525,15 +548,25 @@ int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int
   const int MT = (9 * A.CiL + 15) / 16, NTC = (Co + 15) / 16;
   if (MT > 18 || NTC > 2 || MT * NTC > 36) return AVSR_ERR_UNSUPPORTED;
   A.F = cg_frames(H, W, A.CiL, Ho * Wo);
+  const int nout = 9 * Ci * Co;
+  A.m_opf = fmagic(Ho * Wo); A.m_wo = fmagic(Wo); A.m_w = fmagic(W);
+  if (Ci % 4 == 0) {
+    const int rq = W * Ci / 4;
+    if (rq > 256 || rq < 1) return AVSR_ERR_UNSUPPORTED;
+    const int rpp = 256 / rq;
+    while (A.F > 1 && A.F * ((H + rpp - 1) / rpp) > 12) --A.F;
+    if (A.F * ((H + rpp - 1) / rpp) > 12) return AVSR_ERR_UNSUPPORTED;
+    A.m_rq = fmagic(rq); A.m_per = fmagic(H * rq);
+  } else {
+    while (A.F > 1 && (A.F * H * W * Ci / 4 + 255) / 256 > 4) --A.F;
+    if ((A.F * H * W * Ci / 4 + 255) / 256 > 4 || (long)A.F * H * W * Ci >= 65536) return AVSR_ERR_UNSUPPORTED;
+    A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci);
+  }
+  if ((long)A.F * ((Ho * Wo + 15) / 16) >= 65536) return AVSR_ERR_UNSUPPORTED;
   const size_t red = sizeof(float) * 4 * 256;
   size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * A.CiL;
   if (lds < red) lds = red;
-  if (lds > 96 * 1024) return AVSR_ERR_UNSUPPORTED;
-  const int nout = 9 * Ci * Co;
-  if ((long)A.F * Ho * Wo >= 65536 || (long)A.F * H * W * A.CiL >= 65536) return AVSR_ERR_UNSUPPORTED;
-  A.m_opf = fmagic(Ho * Wo); A.m_wo = fmagic(Wo); A.m_w = fmagic(W);
-  if (Ci % 4 == 0) { if (W * Ci / 4 > 256) return AVSR_ERR_UNSUPPORTED; A.m_rq = fmagic(W * Ci / 4); A.m_per = fmagic(H * (W * Ci / 4)); }
-  else { A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci); }
+  if (lds > 64 * 1024) return AVSR_ERR_UNSUPPORTED;
   int wpc = (int)((150 * 1024) / (lds + 512));
   if (wpc > 2) wpc = 2;
   if (wpc < 1) wpc = 1;
@@ -543,18 +576,12 @@ int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int
   if ((long)grid * nout > scratch_floats) grid = (int)(scratch_floats / nout);
   if (grid < 1) return AVSR_ERR_ARG;
   hipStream_t s = S_(stream);
-  static bool attr = false;
-  if (!attr) {
-#define WG_ATTR(M_, N_) if (hipFuncSetAttribute((const void*)conv_wgrad_kernel<M_, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return AVSR_ERR_HIP;
-    WG_ATTR(3, 1) WG_ATTR(5, 1) WG_ATTR(9, 1) WG_ATTR(5, 2) WG_ATTR(9, 2) WG_ATTR(18, 2) WG_ATTR(18, 1)
-#undef WG_ATTR
-    attr = true;
-  }
   {
     ProfScope ps(PROF_CONV_BWD_WEIGHT, s, 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
-#define WG_GO(M_, N_) hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_>), dim3(grid), dim3(256), lds, s, A)
-    if (NTC == 1) { if (MT <= 3) WG_GO(3, 1); else if (MT <= 5) WG_GO(5, 1); else if (MT <= 9) WG_GO(9, 1); else WG_GO(18, 1); }
-    else { if (MT <= 5) WG_GO(5, 2); else if (MT <= 9) WG_GO(9, 2); else WG_GO(18, 2); }
+#define WG_GO(M_, N_, C_) hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_, C_>), dim3(grid), dim3(256), lds, s, A)
+    if (Ci % 4) { if (MT <= 3 && NTC == 1) WG_GO(3, 1, false); else return AVSR_ERR_UNSUPPORTED; }
+    else if (NTC == 1) { if (MT <= 5) WG_GO(5, 1, true); else if (MT <= 9) WG_GO(9, 1, true); else WG_GO(18, 1, true); }
+    else { if (MT <= 5) WG_GO(5, 2, true); else if (MT <= 9) WG_GO(9, 2, true); else WG_GO(18, 2, true); }
 #undef WG_GO
     if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
   }
