@@ -104,15 +104,20 @@ class AttnRnn(C.Structure):
                 ("fused_ws", C.c_void_p), ("fused_ws_floats", C.c_int64)]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "Ci", "Co", "k", "stride", "pad_t", "pad_l", "Ho", "Wo", "pad_")] + \
+               [("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p)]
+
+
 class TransposeJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
 _STRUCTS = {"avsr_dec_layer": DecLayer, "avsr_mat": Mat, "avsr_gemm_desc": GemmDesc, "avsr_rnn_layer": RnnLayer, "avsr_rnn_stack": RnnStack,
-            "avsr_attn_mech": AttnMech, "avsr_attn_rnn": AttnRnn, "avsr_transpose_job": TransposeJob}
+            "avsr_conv_desc": ConvDesc, "avsr_attn_mech": AttnMech, "avsr_attn_rnn": AttnRnn, "avsr_transpose_job": TransposeJob}
 
 EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_rnn_set_persistent", "avsr_rnn_set_persistent_mode", "avsr_rnn_set_persistent_scratch", "avsr_attn_rnn_fwd",
-           "avsr_attn_rnn_fused_ws_floats", "avsr_attn_rnn_fused_eligible", "avsr_attn_rnn_set_fused", "avsr_conv_set_mfma",
+           "avsr_attn_rnn_fused_ws_floats", "avsr_attn_rnn_fused_eligible", "avsr_attn_rnn_set_fused", "avsr_conv_set_mfma", "avsr_conv_supported", "avsr_conv_fwd", "avsr_conv_bwd_data", "avsr_conv_bwd_weight", "avsr_bn_finalize", "avsr_batchnorm_apply",
            "avsr_attn_rnn_bwd", "avsr_beam_gather_tree", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_colsum",
            "avsr_batchnorm_fwd", "avsr_batchnorm_fwd_ex", "avsr_batchnorm_bwd", "avsr_batchnorm_xhat", "avsr_im2col", "avsr_col2im",
            "avsr_relu", "avsr_relu_bwd", "avsr_add", "avsr_selu", "avsr_selu_bwd", "avsr_conv3x3_supported", "avsr_conv3x3", "avsr_conv3x3_bwd_data_s2",
@@ -158,6 +163,12 @@ def load():
         "avsr_attn_rnn_fused_eligible": [C.POINTER(AttnRnn)],
         "avsr_attn_rnn_set_fused": [i32],
         "avsr_conv_set_mfma": [i32],
+        "avsr_conv_supported": [C.POINTER(ConvDesc)],
+        "avsr_conv_fwd": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i32), vp],
+        "avsr_conv_bwd_data": [C.POINTER(ConvDesc), vp, vp, vp, f32, vp],
+        "avsr_conv_bwd_weight": [C.POINTER(ConvDesc), vp, vp, vp, vp, f32, vp, i64, vp],
+        "avsr_bn_finalize": [vp, i32, i32, i64, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "avsr_batchnorm_apply": [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp],
         "avsr_attn_rnn_bwd": [C.POINTER(AttnRnn), vp],
         "avsr_beam_gather_tree": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "avsr_attn_alpha_rows": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],

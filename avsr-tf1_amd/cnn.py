@@ -6,9 +6,14 @@ per further filter count (BN-ReLU, 1x1/2 projection shortcut on the un-normalise
 add) -> VALID conv over the remaining map -> cnn_dense_units, ReLU.  BN: epsilon 1e-5, momentum 0.98 (video.py:8-11);
 every conv kernel carries l2(0.001) (video.py:26, summed into the loss at seq2seq.py:180-184).
 
-Every convolution is avsr_im2col + avsr_gemm (the TF kernel [kh,kw,cin,cout] IS the [kh*kw*cin, cout] operand), its
-data gradient the transposed GEMM + avsr_col2im, its weight gradient a split-K TN GEMM; BN through avsr_batchnorm_fwd_ex /
-avsr_batchnorm_bwd.  This file only owns buffers and the op order; all arithmetic is in csrc/conv.hip, gemm.hip,
+Convolutions run on the frame-resident MFMA kernels of csrc/conv_mfma.hip (avsr_conv_fwd / _bwd_data / _bwd_weight) with three
+fusions around them: the producing convolution's epilogue adds the residual and emits the batch-norm statistics of what it wrote;
+the batch norm itself is never materialised in training -- avsr_bn_finalize turns the statistics into per-channel scale / shift and
+the CONSUMING convolution (forward and weight gradient) applies max(x*scale + shift, 0) while it stages frames in LDS; the weight
+gradient kernel also produces the bias gradient.  Shapes those kernels do not cover fall back to the direct VALU kernels
+(avsr_conv3x3*) or to avsr_im2col + avsr_gemm (the TF kernel [kh,kw,cin,cout] IS the [kh*kw*cin, cout] operand; data gradient =
+transposed GEMM + avsr_col2im, weight gradient = split-K TN GEMM), with BN through avsr_batchnorm_fwd_ex / avsr_batchnorm_bwd.
+This file only owns buffers and the op order; all arithmetic is in csrc/conv_mfma.hip, conv_direct.hip, conv.hip, gemm.hip,
 elementwise.hip."""
 import torch
 
@@ -93,7 +98,7 @@ class LipCNN:
         self.ops, self.shapes = layout(cfg.video_hw, cfg.cnn_filters, cfg.cnn_dense_units)
         dev = model.dev
         z = lambda *s: torch.zeros(*s, device=dev)
-        self.maps, self.gmaps, self.col, self.bn, self.direct = {}, {}, {}, {}, set()
+        self.maps, self.gmaps, self.col, self.bn, self.direct, self.mfma = {}, {}, {}, {}, set(), {}
         max_col = 4
         for op in self.ops:
             kind = op[0]
@@ -101,19 +106,19 @@ class LipCNN:
                 _, name, src, dst, k, s, cin, cout = op
                 ho, wo, _ = self.shapes[dst]
                 h, w, _ = self.shapes[src]
-                if k == 3 and ops.conv3x3_supported(cin, cout, h, w):   # shallow wide layers: direct kernels, no im2col operand
+                geo = (N, h, w, cin, cout, k, s, same_pad(h, k, s)[1], same_pad(w, k, s)[1], ho, wo)
+                if ops.conv_supported(ops.conv_desc(*geo)):          # frame-resident MFMA kernels
+                    self.mfma[name] = geo
+                elif k == 3 and ops.conv3x3_supported(cin, cout, h, w):   # shallow wide layers: direct kernels, no im2col operand
                     self.direct.add(name)
                 else:
                     self.col[name] = z(N * ho * wo, k * k * cin)
                     max_col = max(max_col, self.col[name].numel())
             elif kind == "bnrelu":
                 c = op[4]
-                self.bn[op[1]] = (z(c), z(c))                      # batch mean, inverse std (training statistics)
+                self.bn[op[1]] = (z(c), z(c), z(c), z(c))          # batch mean, inverse std (training statistics); scale, shift
             if kind == "flatten":
                 self.pre_act = z(N, op[7])
-            dst = op[3] if kind in ("conv", "bnrelu", "flatten") else op[4]
-            h, w, c = self.shapes[dst]
-            self.maps[dst] = z(N, h, w, c)
         # how many ops read each map: the gradient of a single-consumer input of a residual add is the add's output gradient
         # itself (aliased, no copy); maps with several consumers own a buffer their contributions accumulate into
         self.consumers = {}
@@ -126,8 +131,48 @@ class LipCNN:
                 for t in (op[2], op[3]):
                     if self.consumers.get(t, 0) == 1:
                         self.alias[t] = op[4]
+        # fused conv epilogues (csrc/conv_mfma.hip): a conv whose output feeds a batch norm emits the statistics' partial sums, and
+        # the second conv of a residual block adds the shortcut itself (the separate add pass and its operand map disappear)
+        self.stat_buf = {}                                        # map name -> partial sums [512][2C] of the conv that produced it
+        self.fuse_add = {}                                        # conv name -> (shortcut map, add output map) when the add is fused
+        self.skip_add = set()
+        bn_src = {op[2] for op in self.ops if op[0] == "bnrelu"}
+        by_dst = {op[3]: op for op in self.ops if op[0] == "conv"}
+        for op in self.ops:
+            if op[0] == "add":
+                _, name, a, b, dst = op
+                prod = by_dst.get(a)
+                if prod is not None and prod[1] in self.mfma and self.consumers.get(a, 0) == 1:
+                    self.fuse_add[prod[1]] = (b, dst)
+                    self.skip_add.add(name)
+        for op in self.ops:
+            if op[0] == "conv" and op[1] in self.mfma:
+                out = self.fuse_add[op[1]][1] if op[1] in self.fuse_add else op[3]
+                if out in bn_src:
+                    self.stat_buf[out] = z(512 * 2 * op[7])
+        self.stat_rows = {}
+        # a batch norm whose every reader is an MFMA conv (as input) or a fused add (as the shortcut operand) is applied by those
+        # readers' loaders: its output map is never written in training (self.lazy[dst] = (pre-BN map, scale, shift) per forward)
+        self.lazy_ok = set()
+        for op in self.ops:
+            if op[0] != "bnrelu":
+                continue
+            dst, ok = op[3], op[4] % 4 == 0
+            for o in self.ops:
+                if o[0] == "conv" and o[2] == dst:
+                    ok = ok and o[1] in self.mfma
+                elif o[0] == "add" and dst in (o[2], o[3]):
+                    ok = ok and o[1] in self.skip_add and o[3] == dst
+                elif o[0] in ("bnrelu", "flatten") and o[2] == dst:
+                    ok = False
+            if ok:
+                self.lazy_ok.add(op[1])
+        self.lazy = {}
         for name, (h, w, c) in self.shapes.items():
-            if name != "in" and name not in self.alias:
+            if name == "in":
+                continue
+            self.maps[name] = z(N, h, w, c)
+            if name not in self.alias:
                 self.gmaps[name] = z(N, h, w, c)
         for t, dst in self.alias.items():
             self.gmaps[t] = self.gmaps[dst]
@@ -149,12 +194,18 @@ class LipCNN:
         replays of a graph holding such nodes were observed to overlap on ROCm 7.0 -- wrong results and GPU memory faults.)"""
         ops.copy_(dst, src)
 
+    def _src(self, name):
+        """(map to read, (scale, shift) | None): a lazily normalised map is read through its pre-BN map."""
+        lz = self.lazy.get(name)
+        return (self.maps[lz[0]], (lz[1], lz[2])) if lz else (self.maps[name], None)
+
     def forward(self, frames, training):
         m, N = self.m, self.N
         H, W, C = self.shapes["in"]
         assert frames.shape == (N, H, W, C) and frames.is_contiguous() and frames.dtype == torch.float32
         self.maps["in"] = frames
         self.training = training
+        self.lazy = {}
         for op in self.ops:
             kind = op[0]
             if kind == "conv":
@@ -162,27 +213,56 @@ class LipCNN:
                 h, w, _ = self.shapes[src]
                 ho, pt = same_pad(h, k, s)
                 wo, pl = same_pad(w, k, s)
+                kw_ = self._p(name + "/kernel")
+                if name in self.mfma:
+                    x, bn = self._src(src)
+                    res, res_bn, out = None, None, dst
+                    if name in self.fuse_add:
+                        res, res_bn = self._src(self.fuse_add[name][0])
+                        out = self.fuse_add[name][1]
+                    stats = self.stat_buf.get(out) if training else None
+                    n = ops.conv_fwd(ops.conv_desc(*self.mfma[name], bn=bn), x, kw_.t[kw_.off:], self._pv(name + "/bias"), self.maps[out],
+                                     res, res_bn, stats)
+                    if stats is not None:
+                        self.stat_rows[out] = n
+                    else:
+                        self.stat_rows.pop(out, None)
+                    continue
+                self.stat_rows.pop(dst, None)
                 if name in self.direct:
-                    kw_ = self._p(name + "/kernel")
                     ops.conv3x3(self.maps[src], kw_.t[kw_.off:], self._pv(name + "/bias"), self.maps[dst], N, h, w, cin, cout, s, pt, pl, ho, wo)
                     continue
                 col = self.col[name]
                 ops.im2col(self.maps[src], col, N, h, w, cin, k, k, s, pt, pl, ho, wo)
                 rows, K = N * ho * wo, k * k * cin
-                ops.gemm(ops.mat(col, K), self._p(name + "/kernel").mat(cout), ops.mat(self.maps[dst], cout), rows, cout, K,
-                         bias=self._pv(name + "/bias"))
+                ops.gemm(ops.mat(col, K), kw_.mat(cout), ops.mat(self.maps[dst], cout), rows, cout, K, bias=self._pv(name + "/bias"))
             elif kind == "bnrelu":
                 _, name, src, dst, c = op
                 h, w, _ = self.shapes[src]
-                mean, invstd = self.bn[name]
+                mean, invstd, scale, shift = self.bn[name]
                 # seq2seq.py:241-250: the UPDATE_OPS (moving averages) only run with the train op under batch_normalisation=True
                 upd = not training or m.cfg.batch_normalisation
+                if training and self.stat_rows.get(src):
+                    # statistics came with the producing convolution's epilogue: finalise (fp64 merge); no statistic passes, and no
+                    # normalisation pass either when every reader applies scale / shift in its loader
+                    ops.bn_finalize(self.stat_buf[src], self.stat_rows[src], c, N * h * w, self.BN_EPS, self.BN_MOMENTUM, mean, invstd,
+                                    m._sp(self.pre + name + "/moving_mean") if upd else None,
+                                    m._sp(self.pre + name + "/moving_variance") if upd else None,
+                                    self._pv(name + "/gamma"), self._pv(name + "/beta"), scale, shift)
+                    if name in self.lazy_ok:
+                        self.lazy[dst] = (src, scale, shift)
+                    else:
+                        ops.batchnorm_apply(self.maps[src], self.maps[dst], N * h * w, c, self._pv(name + "/gamma"), self._pv(name + "/beta"),
+                                            mean, invstd, 1)
+                    continue
                 ops.batchnorm_fwd_ex(self.maps[src], self.maps[dst], N * h * w, c, self._pv(name + "/gamma"), self._pv(name + "/beta"),
                                      m._sp(self.pre + name + "/moving_mean") if upd else None,
                                      m._sp(self.pre + name + "/moving_variance") if upd else None, mean, invstd,
                                      training, self.BN_EPS, self.BN_MOMENTUM, 1, m.scratch, bessel=1)
             elif kind == "add":
                 _, name, a, b, dst = op
+                if name in self.skip_add:                                  # done by the producing convolution's epilogue
+                    continue
                 ops.add(self.maps[a], self.maps[b], self.maps[dst], self.maps[dst].numel())
             else:
                 _, name, src, dst, kh, kw, cin, cout = op
@@ -196,6 +276,7 @@ class LipCNN:
         """dfeat [N, cnn_dense_units]: gradient of the loss wrt the CNN output.  Accumulates into the model's gradient buffer."""
         m, N = self.m, self.N
         written = set()
+        deferred = []                                                     # (map, thunk): contributions that can only accumulate
 
         def target(name):
             """(gradient map of `name`, beta): first contribution overwrites, later ones accumulate."""
@@ -231,7 +312,7 @@ class LipCNN:
             elif kind == "bnrelu":
                 _, name, src, dst, c = op
                 h, w, _ = self.shapes[src]
-                mean, invstd = self.bn[name]
+                mean, invstd = self.bn[name][:2]
                 g, beta = target(src)
                 gg, gb = self._g(name + "/gamma"), self._g(name + "/beta")
                 ops.batchnorm_bwd(self.maps[src], self.gmaps[dst], self._pv(name + "/gamma"), self._pv(name + "/beta"), mean, invstd, g,
@@ -243,21 +324,41 @@ class LipCNN:
                 wo, pl = same_pad(w, k, s)
                 rows, K = N * ho * wo, k * k * cin
                 dy = ops.mat(self.gmaps[dst], cout)
-                if name in self.direct:
-                    gk, kw_ = self._g(name + "/kernel"), self._p(name + "/kernel")
+                gk, kw_, gb = self._g(name + "/kernel"), self._p(name + "/kernel"), self._g(name + "/bias")
+                if name in self.mfma:
+                    x, bn = self._src(src)
+                    d = ops.conv_desc(*self.mfma[name], bn=bn)
+                    ops.conv_bwd_weight(d, x, self.gmaps[dst], gk.t[gk.off:], gb.t[gb.off:], m.scratch)
+                    if src != "in":
+                        def data_grad(d=d, src=src, dst=dst, kw_=kw_):
+                            g, beta = target(src)
+                            ops.conv_bwd_data(d, self.gmaps[dst], kw_.t[kw_.off:], g, beta=beta)
+                        if k == 1 and s == 2 and src not in written:          # reaches only the even pixels: must accumulate
+                            deferred.append((src, data_grad))
+                        else:
+                            data_grad()
+                elif name in self.direct:
                     ops.conv3x3_bwd_weight(self.maps[src], self.gmaps[dst], gk.t[gk.off:], N, h, w, cin, cout, s, pt, pl, ho, wo, m.scratch)
-                    ops.colsum(dy, rows, cout, m.grads, m.scratch, beta=1.0, out_offset=self._g(name + "/bias").off)
+                    ops.colsum(dy, rows, cout, m.grads, m.scratch, beta=1.0, out_offset=gb.off)
                     if src != "in":
                         g, beta = target(src)
                         if s == 1:       # the same kernel on dy with the kernel flipped and transposed
                             ops.conv3x3(self.gmaps[dst], kw_.t[kw_.off:], None, g, N, ho, wo, cout, cin, 1, 1, 1, h, w, flip=1, beta=beta)
                         else:
                             ops.conv3x3_bwd_data_s2(self.gmaps[dst], kw_.t[kw_.off:], g, N, h, w, cin, cout, pt, pl, ho, wo, beta=beta)
-                    continue
-                m._gemm_tn(ops.mat(self.col[name], K), dy, self._g(name + "/kernel").mat(cout), K, cout, rows)
-                ops.colsum(dy, rows, cout, m.grads, m.scratch, beta=1.0, out_offset=self._g(name + "/bias").off)
-                if src != "in":                                                # pixels are data: no gradient needed
-                    dcol = self.dcol[:rows * K]
-                    ops.gemm(dy, self._p(name + "/kernel").mat(cout), ops.mat(dcol, K), rows, K, cout, trans_b=1)
-                    g, beta = target(src)
-                    ops.col2im(dcol, g, N, h, w, cin, k, k, s, pt, pl, ho, wo, beta=beta)
+                else:
+                    m._gemm_tn(ops.mat(self.col[name], K), dy, gk.mat(cout), K, cout, rows)
+                    ops.colsum(dy, rows, cout, m.grads, m.scratch, beta=1.0, out_offset=gb.off)
+                    if src != "in":                                                # pixels are data: no gradient needed
+                        dcol = self.dcol[:rows * K]
+                        ops.gemm(dy, kw_.mat(cout), ops.mat(dcol, K), rows, K, cout, trans_b=1)
+                        g, beta = target(src)
+                        ops.col2im(dcol, g, N, h, w, cin, k, k, s, pt, pl, ho, wo, beta=beta)
+            for item in list(deferred):
+                if item[0] in written:
+                    deferred.remove(item)
+                    item[1]()
+        for src, fn in deferred:                                              # no other contribution ever arrived: zero, then accumulate
+            ops.zero_(self.gmaps[src])
+            written.add(src)
+            fn()

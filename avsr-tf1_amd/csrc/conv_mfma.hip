@@ -69,6 +69,10 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ src, float*
 struct CGTap { int da, db, widx; };
 struct CGArgs {
   const float* src; const float* w; const float* bias; float* dst; float* stats;
+  const float* res;                      // optional residual input, same shape / indexing as dst (linear destinations only)
+  const float* bn_sc; const float* bn_sh; // non-NULL: the source is relu(src * bn_sc[c] + bn_sh[c]) applied while staging (BN-ReLU of the
+                                          // consumer's loader: the normalised map is never written); halo / padding stays zero
+  const float* res_sc; const float* res_sh; // same for the residual input (per destination channel)
   int N, SH, SW, Cs, CsL;
   int DH, DW, Cd;
   int OA, OB, S, OS, oh0, ow0;
@@ -122,6 +126,11 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   const int st_rpp = st_rq > 0 ? (256 / st_rq > 0 ? 256 / st_rq : 1) : 1;
   const int st_row = (st_rq > 0 && st_rq <= 256) ? (tid < st_rpp * st_rq ? fdiv(tid, A.m_rq) : -1) : -1;
   const int st_p4 = st_row >= 0 ? tid - st_row * st_rq : 0;
+  f32x4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = zero4;
+  const bool bn_on = CH4 && A.bn_sc != nullptr;
+  if (bn_on && st_row >= 0) { const int cb = (st_p4 * 4) % Cs; bsc = ld4(A.bn_sc + cb); bsh = ld4(A.bn_sh + cb); }
+  const bool rbn = A.res_sc != nullptr;
+  const float rsc = (rbn && co < Cd) ? A.res_sc[co] : 1.f, rsh = (rbn && co < Cd) ? A.res_sh[co] : 0.f;
   const bool lin = A.OS == 1 && A.oh0 == 0 && A.ow0 == 0 && A.DH == A.OA && A.DW == A.OB;   // destination index linear in the position
   const int opf = A.OA * A.OB;                         // output positions per frame
   const int rowf = A.SW * Cs;                          // floats per source row
@@ -159,7 +168,14 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int f = fdiv(u, m_ppf), k = u - f * ppf, r = st_row + k * st_rpp;
-        if (st_row >= 0 && f < fcur && r < A.SH) st4(lds + f * fstride + ((r + 1) * PW + 1) * CsL + st_p4 * 4, pre[u]);
+        if (st_row >= 0 && f < fcur && r < A.SH) {
+          f32x4 v = pre[u];
+          if (bn_on) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], bsc[e], bsh[e]), 0.f);
+          }
+          st4(lds + f * fstride + ((r + 1) * PW + 1) * CsL + st_p4 * 4, v);
+        }
       }
     } else {
       const int tot = fcur * per3, tot4 = tot >> 2;
@@ -213,9 +229,11 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
         const int mo0 = mt * 16 + q * 4;
         if (lin && mo0 + 3 < Mtot) {                    // the common case: four in-range rows, destination linear in the position
           float* dp = dlin + (long)(mt * 16) * Cd;
+          const float* rp = A.res ? A.res + (dp - A.dst) : nullptr;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             float v = acc[rr] + bias_v;
+            if (rp) { const float rv = rp[rr * Cd]; v += rbn ? fmaxf(fmaf(rv, rsc, rsh), 0.f) : rv; }
             if (A.beta != 0.f) v += A.beta * dp[rr * Cd];
             dp[rr * Cd] = v;
             acc[rr] = v;
@@ -236,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
                 dp = A.dst + (((long)(n0 + fo) * A.DH + ao * A.OS + A.oh0) * A.DW + bo * A.OS + A.ow0) * Cd + co;
               }
               float v = acc[rr] + bias_v;
+              if (A.res) { const float rv = A.res[dp - A.dst]; v += rbn ? fmaxf(fmaf(rv, rsc, rsh), 0.f) : rv; }
               if (A.beta != 0.f) v += A.beta * *dp;
               *dp = v;
               ssum += v; ssq += v * v;
@@ -270,6 +289,9 @@ struct WGArgs {
   const float* x; const float* dy; float* part;
   int N, H, W, Ci, CiL, Ho, Wo, Co, S, pt, pl, F;
   unsigned m_opf, m_wo, m_rq, m_per, m_w;
+  int t0, nt, kw;                         // taps t0 .. t0+nt-1 of a kw x kw kernel: rows (t - t0, ci) of this launch's slab
+  int slab, want_bias;                    // floats per workgroup partial: nt*Ci*Co (+ Co column sums of dy = the bias gradient)
+  const float* bn_sc; const float* bn_sh; // BN-ReLU applied to x while staging (see CGArgs)
 };
 
 // MT: row tiles (16 rows of (tap, ci)) held per wave; NTC: column tiles; CH4: 4-channel-multiple input (row-structured staging)
@@ -283,7 +305,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   const int opf = A.Ho * A.Wo;
   float* const xs = lds;                               // [F][PH][PW][CiL]   (the output gradient is read straight from memory:
                                                        //  every value is used once per row tile, 16 lanes = 64 contiguous bytes)
-  const int Mrows = 9 * CiL;
+  const int Mrows = A.nt * CiL;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   for (int idx = tid; idx < A.F * xstride; idx += 256) xs[idx] = 0.f;
 
@@ -294,7 +316,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   for (int mt = 0; mt < MT; ++mt) {
     const int row = mt * 16 + i;
     const bool ok = row < Mrows;
-    const int t = ok ? row / CiL : 0, ci = ok ? row - t * CiL : 0, ti = t / 3, tj = t - ti * 3;
+    const int tl = ok ? row / CiL : 0, ci = ok ? row - tl * CiL : 0, t = A.t0 + tl, ti = t / A.kw, tj = t - ti * A.kw;
     roff[mt] = ok ? ((ti - A.pt) * PW + (tj - A.pl)) * CiL + ci : 0;
   }
   f32x4 acc[MT][NTC];
@@ -307,6 +329,12 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   const int st_rpp = (CH4 && st_rq > 0) ? (256 / st_rq > 0 ? 256 / st_rq : 1) : 1;
   const int st_row = CH4 ? (tid < st_rpp * st_rq ? fdiv(tid, A.m_rq) : -1) : -1;
   const int st_p4 = st_row >= 0 ? tid - st_row * st_rq : 0;
+  f32x4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = zero4;
+  const bool bn_on = CH4 && A.bn_sc != nullptr;
+  if (bn_on && st_row >= 0) { const int cb = (st_p4 * 4) % Ci; bsc = ld4(A.bn_sc + cb); bsh = ld4(A.bn_sh + cb); }
+  float bsum[NTC];
+#pragma unroll
+  for (int nt = 0; nt < NTC; ++nt) bsum[nt] = 0.f;
   constexpr int PF = CH4 ? 12 : 4;
   f32x4 pre[PF];
   const int ppf = CH4 ? (A.H + st_rpp - 1) / st_rpp : 0;
@@ -333,7 +361,14 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int f = fdiv(u, m_ppf), k = u - f * ppf, r = st_row + k * st_rpp;
-        if (st_row >= 0 && f < fcur && r < A.H) st4(xs + f * xstride + ((r + 1) * PW + 1) * CiL + st_p4 * 4, pre[u]);
+        if (st_row >= 0 && f < fcur && r < A.H) {
+          f32x4 v = pre[u];
+          if (bn_on) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], bsc[e], bsh[e]), 0.f);
+          }
+          st4(xs + f * xstride + ((r + 1) * PW + 1) * CiL + st_p4 * 4, v);
+        }
       }
     } else {
       const int tot = fcur * per3, tot4 = tot >> 2;
@@ -381,6 +416,8 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
       for (int nt = 0; nt < NTC; ++nt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[nt][e] = bn[nt][e];
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt) bsum[nt] += (bv[nt][0] + bv[nt][1]) + (bv[nt][2] + bv[nt][3]);
       if (kc + 4 < kch) load_b(kc + 4, bn);
       const int f = fdiv(kc, m_cpf), r0 = (kc - f * cpf) * 16 + q * 4;
       int ho = fdiv(min(r0, opf - 1), A.m_wo), wo = min(r0, opf - 1) - ho * A.Wo;
@@ -405,7 +442,6 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   // cross-wave reduction (waves hold different depth slices of the same tiles), tile by tile through a 4 KB staging area, then
   // one partial per workgroup
   float* red = lds;                                     // [4][16][16]
-  const int nout = 9 * Ci * Co;
   const int rr = tid >> 4, cc = tid & 15;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -418,9 +454,21 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
       const int row = mt * 16 + rr, co = nt * 16 + cc;
       if (row < Mrows && co < Co) {
         const int t = row / CiL, ci = row - t * CiL;
-        if (ci < Ci) A.part[(long)blockIdx.x * nout + ((long)t * Ci + ci) * Co + co] = (red[rr * 16 + cc] + red[(16 + rr) * 16 + cc]) + (red[(32 + rr) * 16 + cc] + red[(48 + rr) * 16 + cc]);
+        if (ci < Ci) A.part[(long)blockIdx.x * A.slab + ((long)t * Ci + ci) * Co + co] = (red[rr * 16 + cc] + red[(16 + rr) * 16 + cc]) + (red[(32 + rr) * 16 + cc] + red[(48 + rr) * 16 + cc]);
       }
     }
+  if (A.want_bias) {                                    // column sums of dy: lanes (q, wave) hold disjoint positions of column nt*16 + i
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt) red[((wave * 4 + q) * NTC + nt) * 16 + i] = bsum[nt];
+    __syncthreads();
+    if (tid < NTC * 16) {
+      const int nt = tid >> 4, ci = tid & 15;
+      float s = 0.f;
+      for (int g = 0; g < 16; ++g) s += red[(g * NTC + nt) * 16 + ci];
+      if (nt * 16 + ci < Co) A.part[(long)blockIdx.x * A.slab + (long)A.nt * Ci * Co + nt * 16 + ci] = s;
+    }
+  }
 }
 
 static int g_conv_mfma = 1;
@@ -445,7 +493,7 @@ static int cg_frames(int sh, int sw, int csl, int opf, int extra_floats_per_fram
   return F;
 }
 
-static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops) {
+static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry = false) {
   const int KQ = A.ntap * (A.CsL / 4), nch = (KQ + 3) / 4;
   const int NT = (A.Cd + 15) / 16;
   if (!(NT == 1 || NT == 2 || NT == 4) || nch > 18) return AVSR_ERR_UNSUPPORTED;
@@ -471,9 +519,10 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops) {
   if (wpc > 2) wpc = 2;
   if (wpc < 1) wpc = 1;
   if (grid > 256 * wpc) grid = 256 * wpc;
+  if (A.Cs % 4 && nch > 5) return AVSR_ERR_UNSUPPORTED;
+  if (dry) return grid;
   ProfScope ps(kind, s, flops);
   if (A.Cs % 4) {
-    if (nch > 5) return AVSR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((conv_gen_kernel<5, false>), dim3(grid), dim3(256), lds, s, A);
   } else if (nch <= 5) hipLaunchKernelGGL((conv_gen_kernel<5, true>), dim3(grid), dim3(256), lds, s, A);
   else if (nch <= 9) hipLaunchKernelGGL((conv_gen_kernel<9, true>), dim3(grid), dim3(256), lds, s, A);
@@ -503,6 +552,50 @@ int avsr_conv3x3_mfma(const float* x, const float* w, const float* bias, float* 
   const int rc = cg_launch(A, S_(stream), flip ? PROF_CONV_BWD_DATA : PROF_CONV_FWD, 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
   if (rc < 0) return rc;
   if (nstat) *nstat = rc;
+  return AVSR_OK;
+}
+
+// finalise batch-norm statistics from the per-workgroup partial sums the convolution epilogue wrote: part [nparts][2*C] (sum | sum of
+// squares), count = rows per channel.  fp64 merge; the moving averages take the Bessel-corrected variance (fused rank-4 path).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, int nparts, int C, double count, float eps, float momentum,
+                                                          float* mean, float* invstd, float* mov_mean, float* mov_var, const float* gamma,
+                                                          const float* beta, float* scale, float* shift) {
+  // one workgroup per 16 channels: 16 lanes read 16 consecutive channels of a partial row (64 B segments), 16 row groups stride the rows
+  __shared__ double red[2][16][17];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+  double s = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int p = rg; p < nparts; p += 16) { s += (double)part[(long)p * 2 * C + c]; s2 += (double)part[(long)p * 2 * C + C + c]; }
+  red[0][rg][cl] = s; red[1][rg][cl] = s2;
+  __syncthreads();
+  if (threadIdx.x >= 16 || c >= C) return;
+  s = 0.0; s2 = 0.0;
+  for (int r = 0; r < 16; ++r) { s += red[0][r][cl]; s2 += red[1][r][cl]; }
+  const double m = s / count;
+  double var = s2 / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = rsqrtf((float)var + eps);
+  mean[c] = (float)m;
+  invstd[c] = is;
+  if (scale) {                                          // y = x * scale + shift  ==  (x - mean) * invstd * gamma + beta
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)m * sc;
+  }
+  if (mov_mean) {
+    const float unbiased = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+    mov_mean[c] = momentum * mov_mean[c] + (1.f - momentum) * (float)m;
+    mov_var[c] = momentum * mov_var[c] + (1.f - momentum) * unbiased;
+  }
+}
+
+extern "C" int avsr_bn_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, float eps, float momentum, float* mean,
+                                float* invstd, float* mov_mean, float* mov_var, const float* gamma, const float* beta, float* scale,
+                                float* shift, void* stream) {
+  if (!part || nparts <= 0 || C <= 0 || count <= 0 || !mean || !invstd || (scale && (!gamma || !beta || !shift))) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, S_(stream), part, nparts, C, (double)count, eps, momentum, mean, invstd,
+                     mov_mean, mov_var, gamma, beta, scale, shift);
+  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
   return AVSR_OK;
 }
 
@@ -545,6 +638,7 @@ int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int
   WGArgs A = {};
   A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo; A.Co = Co;
   A.S = stride; A.pt = pad_t; A.pl = pad_l;
+  A.t0 = 0; A.nt = 9; A.kw = 3; A.slab = 9 * Ci * Co; A.want_bias = 0;
   const int MT = (9 * A.CiL + 15) / 16, NTC = (Co + 15) / 16;
   if (MT > 18 || NTC > 2 || MT * NTC > 36) return AVSR_ERR_UNSUPPORTED;
   A.F = cg_frames(H, W, A.CiL, Ho * Wo);
@@ -586,4 +680,200 @@ int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int
     if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
   }
   return avsr_colsum_final_launch(scratch, grid, dw, nout, 1.0f, beta, stream);
+}
+
+// =====================================================================================================================
+// Descriptor API (include/avsr_hip.h: avsr_conv_desc): k = 1 or 3, stride 1 or 2, 3..64 channels; BN-ReLU of the input applied by the
+// loader; kernels deeper than one wave's register budget run as several launches over tap groups (the later ones accumulate).
+int avsr_colsum_final_launch_ld(const float* part, long ld, int nblk, float* out, int F, float alpha, float beta, void* stream);
+
+static bool cd_ok(const avsr_conv_desc* c) {
+  return c && c->N > 0 && (c->k == 1 || c->k == 3) && (c->stride == 1 || c->stride == 2) && c->Co % 4 == 0 && (c->Ci % 4 == 0 || c->Ci < 4) &&
+         c->Ci > 0 && c->Co > 0 && c->Co <= 64 && c->pad_t >= 0 && c->pad_t <= 1 && c->pad_l >= 0 && c->pad_l <= 1 && (c->k == 3 || (c->pad_t == 0 && c->pad_l == 0));
+}
+
+// run the tap list in groups that fit the K chunks a wave holds; bias / beta on the first group, residual / statistics on the last
+static int cg_run(CGArgs A, const CGTap* taps, int ntaps, hipStream_t s, int kind, double flops_per_tap, bool dry, int* grid_out) {
+  const int C4 = A.CsL / 4;
+  int G = (18 * 4) / C4;
+  if (G < 1) return AVSR_ERR_UNSUPPORTED;
+  if (G > CG_MAXTAP) G = CG_MAXTAP;
+  const float* res = A.res; float* stats = A.stats; const float* bias = A.bias; const float beta = A.beta;
+  int grid = 0;
+  for (int t0 = 0; t0 < ntaps; t0 += G) {
+    const int nt = ntaps - t0 < G ? ntaps - t0 : G;
+    const bool first = t0 == 0, last = t0 + nt >= ntaps;
+    CGArgs B = A;
+    for (int t = 0; t < nt; ++t) B.tap[t] = taps[t0 + t];
+    B.ntap = nt;
+    B.bias = first ? bias : nullptr; B.beta = first ? beta : 1.f;
+    B.res = last ? res : nullptr; B.stats = last ? stats : nullptr;
+    if (!last) { B.res_sc = nullptr; B.res_sh = nullptr; }
+    const int rc = cg_launch(B, s, kind, flops_per_tap * nt, dry);
+    if (rc < 0) return rc;
+    grid = rc;
+  }
+  if (grid_out) *grid_out = grid;
+  return AVSR_OK;
+}
+
+static int conv_fwd_impl(const avsr_conv_desc* c, const float* x, const float* w, const float* bias, const float* res, const float* res_sc,
+                         const float* res_sh, float* y, float* stats, int32_t* nparts, void* stream, bool dry) {
+  CGArgs A = {};
+  A.src = x; A.w = w; A.bias = bias; A.dst = y; A.stats = stats; A.res = res; A.bn_sc = c->bn_scale; A.bn_sh = c->bn_shift;
+  A.res_sc = res ? res_sc : nullptr; A.res_sh = res ? res_sh : nullptr;
+  A.N = c->N; A.SH = c->H; A.SW = c->W; A.Cs = c->Ci; A.CsL = (c->Ci + 3) & ~3;
+  A.DH = c->Ho; A.DW = c->Wo; A.Cd = c->Co; A.OA = c->Ho; A.OB = c->Wo; A.S = c->stride; A.OS = 1; A.oh0 = 0; A.ow0 = 0;
+  A.wmode = 0; A.beta = 0.f;
+  CGTap taps[9];
+  const int nt = c->k * c->k;
+  for (int t = 0; t < nt; ++t) taps[t] = CGTap{t / c->k - c->pad_t, t % c->k - c->pad_l, t};
+  A.F = cg_frames(c->H, c->W, A.CsL, c->Ho * c->Wo);
+  int grid = 0;
+  const int rc = cg_run(A, taps, nt, S_(stream), PROF_CONV_FWD, 2.0 * c->N * c->Ho * c->Wo * (double)c->Ci * c->Co, dry, &grid);
+  if (rc < 0) return rc;
+  if (nparts) *nparts = grid;
+  return AVSR_OK;
+}
+
+static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const float* w, float* dx, float beta, void* stream, bool dry) {
+  if (c->Ci % 4) return AVSR_ERR_UNSUPPORTED;
+  const int k = c->k;
+  if (c->stride == 1) {
+    CGArgs A = {};
+    A.src = dy; A.w = w; A.dst = dx;
+    A.N = c->N; A.SH = c->Ho; A.SW = c->Wo; A.Cs = c->Co; A.CsL = c->Co;
+    A.DH = c->H; A.DW = c->W; A.Cd = c->Ci; A.OA = c->H; A.OB = c->W; A.S = 1; A.OS = 1;
+    A.wmode = 1; A.beta = beta;
+    CGTap taps[9];
+    for (int t = 0; t < k * k; ++t) taps[t] = CGTap{c->pad_t - t / k, c->pad_l - t % k, t};   // dx[h, w] += dy[h + pt - i, w + pl - j] . W[i, j]^T
+    A.F = cg_frames(c->Ho, c->Wo, A.CsL, c->H * c->W);
+    return cg_run(A, taps, k * k, S_(stream), PROF_CONV_BWD_DATA, 2.0 * c->N * c->H * c->W * (double)c->Ci * c->Co, dry, nullptr);
+  }
+  // stride 2: one launch per parity class (ph, pw) of the input pixels; a class no tap reaches receives no gradient from this
+  // convolution (beta == 0 is then refused: the caller orders its contributions so that this one accumulates)
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw) {
+      CGArgs A = {};
+      A.src = dy; A.w = w; A.dst = dx;
+      A.N = c->N; A.SH = c->Ho; A.SW = c->Wo; A.Cs = c->Co; A.CsL = c->Co;
+      A.DH = c->H; A.DW = c->W; A.Cd = c->Ci; A.OA = (c->H - ph + 1) / 2; A.OB = (c->W - pw + 1) / 2; A.S = 1; A.OS = 2; A.oh0 = ph; A.ow0 = pw;
+      A.wmode = 1; A.beta = beta;
+      CGTap taps[9];
+      int nt = 0;
+      for (int i = 0; i < k; ++i) {
+        if ((ph + c->pad_t - i) & 1) continue;
+        for (int j = 0; j < k; ++j) {
+          if ((pw + c->pad_l - j) & 1) continue;
+          taps[nt++] = CGTap{(ph + c->pad_t - i) >> 1, (pw + c->pad_l - j) >> 1, i * k + j};   // arithmetic shift: -1/2 -> floor
+        }
+      }
+      if (A.OA <= 0 || A.OB <= 0) continue;
+      if (nt == 0) {
+        if (beta == 0.f) return AVSR_ERR_UNSUPPORTED;
+        continue;
+      }
+      A.F = cg_frames(c->Ho, c->Wo, A.CsL, A.OA * A.OB);
+      const int rc = cg_run(A, taps, nt, S_(stream), PROF_CONV_BWD_DATA, 2.0 * c->N * A.OA * A.OB * (double)c->Ci * c->Co, dry, nullptr);
+      if (rc < 0) return rc;
+    }
+  return AVSR_OK;
+}
+
+static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const float* dy, float* dw, float* dbias, float beta, float* scratch,
+                                long scratch_floats, void* stream, bool dry) {
+  const int Ci = c->Ci, Co = c->Co, H = c->H, W = c->W, Ho = c->Ho, Wo = c->Wo, N = c->N, k = c->k;
+  WGArgs A = {};
+  A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo; A.Co = Co;
+  A.S = c->stride; A.pt = c->pad_t; A.pl = c->pad_l; A.kw = k; A.bn_sc = c->bn_scale; A.bn_sh = c->bn_shift;
+  const int NTC = (Co + 15) / 16;
+  if (NTC == 3) return AVSR_ERR_UNSUPPORTED;
+  const int mt_max = NTC == 4 ? 9 : 18;
+  int G = mt_max * 16 / A.CiL;                           // taps per launch
+  if (G < 1) return AVSR_ERR_UNSUPPORTED;
+  A.F = cg_frames(H, W, A.CiL, Ho * Wo);
+  A.m_opf = fmagic(Ho * Wo); A.m_wo = fmagic(Wo); A.m_w = fmagic(W);
+  if (Ci % 4 == 0) {
+    const int rq = W * Ci / 4;
+    if (rq > 256 || rq < 1) return AVSR_ERR_UNSUPPORTED;
+    const int rpp = 256 / rq;
+    while (A.F > 1 && A.F * ((H + rpp - 1) / rpp) > 12) --A.F;
+    if (A.F * ((H + rpp - 1) / rpp) > 12) return AVSR_ERR_UNSUPPORTED;
+    A.m_rq = fmagic(rq); A.m_per = fmagic(H * rq);
+  } else {
+    if (c->bn_scale) return AVSR_ERR_UNSUPPORTED;
+    while (A.F > 1 && (A.F * H * W * Ci / 4 + 255) / 256 > 4) --A.F;
+    if ((A.F * H * W * Ci / 4 + 255) / 256 > 4 || (long)A.F * H * W * Ci >= 65536) return AVSR_ERR_UNSUPPORTED;
+    A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci);
+  }
+  if ((long)A.F * ((Ho * Wo + 15) / 16) >= 65536) return AVSR_ERR_UNSUPPORTED;
+  const size_t red = sizeof(float) * 4 * 256;
+  size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * A.CiL;
+  if (lds < red) lds = red;
+  if (lds > 64 * 1024) return AVSR_ERR_UNSUPPORTED;
+  int wpc = (int)((150 * 1024) / (lds + 512));
+  if (wpc > 2) wpc = 2;
+  if (wpc < 1) wpc = 1;
+  hipStream_t s = S_(stream);
+  bool bias_done = dbias == nullptr;
+  for (int t0 = 0; t0 < k * k; t0 += G) {
+    A.t0 = t0; A.nt = k * k - t0 < G ? k * k - t0 : G;
+    A.want_bias = bias_done ? 0 : 1;
+    const int wF = A.nt * Ci * Co;
+    A.slab = wF + (A.want_bias ? Co : 0);
+    const int MT = (A.nt * A.CiL + 15) / 16;
+    if (Ci % 4 && (MT > 3 || NTC != 1)) return AVSR_ERR_UNSUPPORTED;
+    int grid = (N + A.F - 1) / A.F;
+    const int cap = 256 * (A.slab > 2048 ? 1 : wpc);      // large kernels: the partial slabs, not the staging, are the traffic
+    if (grid > cap) grid = cap;
+    if ((long)grid * A.slab > scratch_floats) grid = (int)(scratch_floats / A.slab);
+    if (grid < 1) return AVSR_ERR_ARG;
+    if (dry) continue;
+    {
+      ProfScope ps(PROF_CONV_BWD_WEIGHT, s, 2.0 * N * Ho * Wo * (double)A.nt * Ci * Co);
+#define WG_GO(M_, N_, C_) hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_, C_>), dim3(grid), dim3(256), lds, s, A)
+      if (Ci % 4) WG_GO(3, 1, false);
+      else if (NTC == 1) { if (MT <= 5) WG_GO(5, 1, true); else if (MT <= 9) WG_GO(9, 1, true); else WG_GO(18, 1, true); }
+      else if (NTC == 2) { if (MT <= 5) WG_GO(5, 2, true); else if (MT <= 9) WG_GO(9, 2, true); else WG_GO(18, 2, true); }
+      else { if (MT <= 5) WG_GO(5, 4, true); else WG_GO(9, 4, true); }
+#undef WG_GO
+      if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+    }
+    int rc = avsr_colsum_final_launch_ld(scratch, A.slab, grid, dw + (long)t0 * Ci * Co, wF, 1.0f, beta, stream);
+    if (rc != AVSR_OK) return rc;
+    if (A.want_bias) {
+      rc = avsr_colsum_final_launch_ld(scratch + wF, A.slab, grid, dbias, Co, 1.0f, beta, stream);
+      if (rc != AVSR_OK) return rc;
+      bias_done = true;
+    }
+  }
+  return AVSR_OK;
+}
+
+extern "C" int avsr_conv_supported(const avsr_conv_desc* c) {
+  if (!g_conv_mfma || !cd_ok(c)) return 0;
+  if (conv_fwd_impl(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true) != AVSR_OK) return 0;
+  if (c->Ci >= 4 && conv_bwd_data_impl(c, nullptr, nullptr, nullptr, 1.f, nullptr, true) != AVSR_OK) return 0;
+  if (conv_bwd_weight_impl(c, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, 1L << 40, nullptr, true) != AVSR_OK) return 0;
+  return 1;
+}
+
+extern "C" int avsr_conv_fwd(const avsr_conv_desc* c, const float* x, const float* w, const float* bias, const float* res, const float* res_scale,
+                             const float* res_shift, float* y, float* stats, int32_t* nparts, void* stream) {
+  if (!cd_ok(c) || !x || !w || !y) return AVSR_ERR_ARG;
+  if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
+  return conv_fwd_impl(c, x, w, bias, res, res_scale, res_shift, y, stats, nparts, stream, false);
+}
+
+extern "C" int avsr_conv_bwd_data(const avsr_conv_desc* c, const float* dy, const float* w, float* dx, float beta, void* stream) {
+  if (!cd_ok(c) || !dy || !w || !dx) return AVSR_ERR_ARG;
+  if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
+  return conv_bwd_data_impl(c, dy, w, dx, beta, stream, false);
+}
+
+extern "C" int avsr_conv_bwd_weight(const avsr_conv_desc* c, const float* x, const float* dy, float* dw, float* dbias, float beta, float* scratch,
+                                    int64_t scratch_floats, void* stream) {
+  if (!cd_ok(c) || !x || !dy || !dw || !scratch) return AVSR_ERR_ARG;
+  if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
+  return conv_bwd_weight_impl(c, x, dy, dw, dbias, beta, scratch, scratch_floats, stream, false);
 }

@@ -80,7 +80,7 @@ __global__ void colsum_partial_kernel(const float* a, long lda, int Ta, long ldo
 }
 
 // one block per 32 columns: 32 row-groups x 32 columns of threads walk the partials (4 loads in flight), then an LDS tree
-__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* part, int nblk, float* out, int F, float alpha, float beta) {
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* part, long ld, int nblk, float* out, int F, float alpha, float beta) {
   __shared__ double red[32][33];
   const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int f = blockIdx.x * 32 + fl;
@@ -88,11 +88,11 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* part, i
   if (f < F) {
     int i = g;
     for (; i + 96 < nblk; i += 128) {
-      const float a0 = part[(long)i * F + f], a1 = part[(long)(i + 32) * F + f];
-      const float a2 = part[(long)(i + 64) * F + f], a3 = part[(long)(i + 96) * F + f];
+      const float a0 = part[(long)i * ld + f], a1 = part[(long)(i + 32) * ld + f];
+      const float a2 = part[(long)(i + 64) * ld + f], a3 = part[(long)(i + 96) * ld + f];
       s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
     }
-    for (; i < nblk; i += 32) s += (double)part[(long)i * F + f];
+    for (; i < nblk; i += 32) s += (double)part[(long)i * ld + f];
   }
   red[g][fl] = s;
   __syncthreads();
@@ -578,7 +578,14 @@ extern "C" int avsr_transpose(const avsr_transpose_job* jobs, int32_t n, void* s
 }
 
 int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, float alpha, float beta, void* stream) {
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, nblk, out, F, alpha, beta);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, (long)F, nblk, out, F, alpha, beta);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+// partial rows `ld` floats apart (F <= ld): several column ranges of one slab are reduced to different destinations
+int avsr_colsum_final_launch_ld(const float* part, long ld, int nblk, float* out, int F, float alpha, float beta, void* stream) {
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, ld, nblk, out, F, alpha, beta);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
@@ -599,7 +606,7 @@ extern "C" int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, i
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(th), 0, S_(stream), a->ptr, (long)a->ld, a->T, (long)a->ldo,
                      b ? b->ptr : nullptr, b ? (long)b->ld : 0, b ? b->T : 0, b ? (long)b->ldo : 0, scratch, rows, F, rpb);
   AVSR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), scratch, nblk, out, F, alpha, beta);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), scratch, (long)F, nblk, out, F, alpha, beta);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
@@ -652,6 +659,17 @@ extern "C" int avsr_batchnorm_fwd_ex(const float* x, float* y, int32_t rows, int
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, S_(stream), x, mean_v, invstd_v, moving_mean, moving_var, gamma, beta, y,
                      n4, F, training, eps, relu);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+extern "C" int avsr_batchnorm_apply(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta, const float* mean,
+                                    const float* invstd, int32_t relu, void* stream) {
+  if (!x || !y || !gamma || !beta || !mean || !invstd || rows <= 0 || F <= 0 || F % 4) return AVSR_ERR_ARG;
+  const long n4 = (long)rows * F / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, S_(stream), x, mean, invstd, nullptr, nullptr, gamma, beta, y, n4, F, 1, 0.f, relu);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
@@ -745,7 +763,7 @@ extern "C" int avsr_embed_grad(const float* dx, const int32_t* fed, float* demb,
   hipLaunchKernelGGL(embed_grad_partial_kernel, dim3(V, nchunk), dim3(E >= 256 ? 256 : ((E + 63) / 64) * 64), 0, S_(stream), dx, fed,
                      scratch, rows, E, V);
   AVSR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((V * E + 31) / 32), dim3(1024), 0, S_(stream), scratch, nchunk, demb, V * E, 1.0f, 0.0f);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((V * E + 31) / 32), dim3(1024), 0, S_(stream), scratch, (long)V * E, nchunk, demb, V * E, 1.0f, 0.0f);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

@@ -356,6 +356,46 @@ def conv3x3(x, w, bias, y, N, H, W, Ci, Co, stride, pad_t, pad_l, Ho, Wo, flip=0
           "avsr_conv3x3")
 
 
+def conv_desc(N, H, W, Ci, Co, k, stride, pad_t, pad_l, Ho, Wo, bn=None):
+    """avsr_conv_desc; bn = (scale, shift) device vectors when the input is normalised by the loader."""
+    from ._lib import ConvDesc
+    d = ConvDesc(N, H, W, Ci, Co, k, stride, pad_t, pad_l, Ho, Wo, 0, None, None)
+    if bn is not None:
+        d.bn_scale, d.bn_shift = fptr(bn[0]), fptr(bn[1])
+    return d
+
+
+def conv_supported(d):
+    return bool(_L().avsr_conv_supported(C.byref(d)))
+
+
+def conv_fwd(d, x, w, bias, y, res=None, res_bn=None, stats=None):
+    """Returns the number of statistic partial rows written (0 without stats)."""
+    n = C.c_int32(0)
+    check(_L().avsr_conv_fwd(C.byref(d), fptr(x), fptr(w), fptr(bias), fptr(res), fptr(res_bn[0]) if res_bn else None,
+                             fptr(res_bn[1]) if res_bn else None, fptr(y), fptr(stats), C.byref(n), _s()), "avsr_conv_fwd")
+    return int(n.value)
+
+
+def conv_bwd_data(d, dy, w, dx, beta=0.0):
+    check(_L().avsr_conv_bwd_data(C.byref(d), fptr(dy), fptr(w), fptr(dx), float(beta), _s()), "avsr_conv_bwd_data")
+
+
+def conv_bwd_weight(d, x, dy, dw, dbias, scratch, beta=1.0):
+    check(_L().avsr_conv_bwd_weight(C.byref(d), fptr(x), fptr(dy), fptr(dw), fptr(dbias), float(beta), fptr(scratch), scratch.numel(), _s()),
+          "avsr_conv_bwd_weight")
+
+
+def bn_finalize(part, nparts, Cn, count, eps, momentum, mean, invstd, mov_mean, mov_var, gamma=None, beta=None, scale=None, shift=None):
+    check(_L().avsr_bn_finalize(fptr(part), int(nparts), int(Cn), int(count), float(eps), float(momentum), fptr(mean), fptr(invstd),
+                                fptr(mov_mean), fptr(mov_var), fptr(gamma), fptr(beta), fptr(scale), fptr(shift), _s()), "avsr_bn_finalize")
+
+
+def batchnorm_apply(x, y, rows, F, gamma, beta, mean, invstd, relu):
+    check(_L().avsr_batchnorm_apply(fptr(x), fptr(y), rows, F, fptr(gamma), fptr(beta), fptr(mean), fptr(invstd), int(relu), _s()),
+          "avsr_batchnorm_apply")
+
+
 def conv3x3_bwd_data_s2(dy, w, dx, N, H, W, Ci, Co, pad_t, pad_l, Ho, Wo, beta=0.0):
     check(_L().avsr_conv3x3_bwd_data_s2(fptr(dy), fptr(w), fptr(dx), N, H, W, Ci, Co, pad_t, pad_l, Ho, Wo, float(beta), _s()),
           "avsr_conv3x3_bwd_data_s2")

@@ -413,6 +413,35 @@ int avsr_conv3x3_supported(int32_t Ci, int32_t Co, int32_t H, int32_t W);
  * staged in LDS, implicit GEMM on v_mfma_f32_16x16x4_f32) and the direct VALU kernels otherwise; this switch (default 1) forces the
  * latter (A/B timing, tests). */
 int avsr_conv_set_mfma(int32_t on);
+/* Frame-resident MFMA convolutions of the lip CNN through ONE descriptor (csrc/conv_mfma.hip; tf.layers.conv2d of video.py:18-30 with
+ * k = 1 (the stride-2 projection shortcut, video.py:70-75) or 3, stride 1 / 2, Ci in {1..3, 4n}, Co = 4n <= 64):
+ *   bn_scale / bn_shift (may be NULL): the input map is the PRE-normalisation map x and the kernels apply the consumer-side
+ *     batch_norm_relu (video.py:4-14) max(x*scale[c] + shift[c], 0) while staging frames in LDS -- the normalised map is never
+ *     written (forward and weight gradient; the zero padding is applied after the BN-ReLU, as in the graph).
+ *   avsr_conv_fwd: y = conv(x) + bias (+ res: the residual of video.py:84 `tf.add`; res_scale/res_shift != NULL: the residual is
+ *     itself a lazily normalised map); stats != NULL (>= 512*2*Co floats): per-workgroup partial sums / sums of squares of y
+ *     [*nparts][2*Co] for the batch norm that consumes y; avsr_bn_finalize merges them in fp64 into mean / inverse std (+ the
+ *     moving averages with the Bessel-corrected variance of the fused rank-4 TF kernel) and the scale / shift vectors above.
+ *   avsr_conv_bwd_data: dx = beta*dx + conv_transpose(dy); a stride-2 1x1 kernel reaches only the even pixels, so beta must be 1.
+ *   avsr_conv_bwd_weight: dw = beta*dw + sum x (x) dy, dbias (may be NULL) = beta*dbias + column sums of dy (same pass over dy);
+ *     scratch >= 256 * (k*k*Ci*Co + Co) floats.
+ * AVSR_ERR_UNSUPPORTED (-3) for shapes outside the kernels' register / LDS budget (avsr_conv_supported == 0): the caller then uses
+ * im2col + avsr_gemm. */
+typedef struct avsr_conv_desc {
+  int32_t N, H, W, Ci, Co, k, stride, pad_t, pad_l, Ho, Wo, pad_;
+  const float* bn_scale;
+  const float* bn_shift;
+} avsr_conv_desc;
+int avsr_conv_supported(const avsr_conv_desc* c);
+int avsr_conv_fwd(const avsr_conv_desc* c, const float* x, const float* w, const float* bias, const float* res, const float* res_scale,
+                  const float* res_shift, float* y, float* stats, int32_t* nparts, void* stream);
+int avsr_conv_bwd_data(const avsr_conv_desc* c, const float* dy, const float* w, float* dx, float beta, void* stream);
+int avsr_conv_bwd_weight(const avsr_conv_desc* c, const float* x, const float* dy, float* dw, float* dbias, float beta, float* scratch,
+                         int64_t scratch_floats, void* stream);
+int avsr_bn_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, float eps, float momentum, float* mean, float* invstd,
+                     float* mov_mean, float* mov_var, const float* gamma, const float* beta, float* scale, float* shift, void* stream);
+int avsr_batchnorm_apply(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta, const float* mean,
+                         const float* invstd, int32_t relu, void* stream);
 int avsr_conv3x3(const float* x, const float* w, const float* bias, float* y, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                  int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, int32_t flip, float beta, void* stream);
 int avsr_conv3x3_bwd_data_s2(const float* dy, const float* w, float* dx, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,

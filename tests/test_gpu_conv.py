@@ -126,3 +126,69 @@ def test_batchnorm_forward_backward(rows, F, relu):
     torch.cuda.synchronize()
     assert _close(dx.cpu().numpy(), x.grad.numpy(), 2e-4)
     assert _close(dg.cpu().numpy(), g.grad.numpy(), 2e-4) and _close(db.cpu().numpy(), b.grad.numpy(), 2e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# descriptor API of csrc/conv_mfma.hip: k = 1 / 3, stride 1 / 2, up to 64 channels (tap-group launches), BN-ReLU applied by the loader,
+# residual + BN statistics in the epilogue, bias gradient from the weight-gradient pass.
+@pytest.mark.parametrize("N,H,Ci,Co,k,s,bn,res", [
+    (3, 12, 3, 8, 3, 1, False, False), (5, 12, 8, 8, 3, 1, True, True), (4, 12, 8, 16, 3, 2, True, False), (4, 12, 8, 16, 1, 2, False, False),
+    (7, 9, 16, 32, 1, 2, False, False), (6, 9, 32, 64, 3, 2, True, False), (6, 9, 32, 64, 1, 2, False, False), (9, 5, 64, 64, 3, 1, True, True),
+    (2, 36, 8, 8, 3, 1, True, True), (3, 18, 16, 16, 3, 1, True, False), (21, 5, 64, 64, 3, 1, False, False)])
+def test_conv_desc_forward_and_gradients(N, H, Ci, Co, k, s, bn, res):
+    from avsr_tf1_amd import ops
+    rng = np.random.default_rng(H * 100 + Ci * 10 + Co + s + k)
+    W = H
+    t64 = lambda a, g=True: torch.tensor(a, dtype=torch.float64, requires_grad=g)
+    x = t64(rng.standard_normal((N, H, W, Ci)))
+    w = t64(rng.standard_normal((k, k, Ci, Co)) * 0.3)
+    b = t64(rng.standard_normal(Co))
+    sc, sh = t64(rng.uniform(0.5, 1.5, Ci), False), t64(rng.standard_normal(Ci) * 0.3, False)
+    xin = torch.relu(x * sc + sh) if bn else x
+    y = _ref_conv(xin, w, b, s)
+    r = t64(rng.standard_normal(tuple(y.shape)), False)
+    rsc, rsh = t64(rng.uniform(0.5, 1.5, Co), False), t64(rng.standard_normal(Co) * 0.3, False)
+    if res:
+        y = y + torch.relu(r * rsc + rsh)
+    dy = torch.tensor(rng.standard_normal(tuple(y.shape)), dtype=torch.float64)
+    (y * dy).sum().backward(inputs=[x, w, b] if not bn else [w, b])
+    Ho, pt, _ = _same(H, k, s)
+    Wo, pl, _ = _same(W, k, s)
+    dev = lambda t: t.detach().to(torch.float32).cuda().contiguous()
+    bnv = (dev(sc), dev(sh)) if bn else None
+    d = ops.conv_desc(N, H, W, Ci, Co, k, s, pt if k == 3 else 0, pl if k == 3 else 0, Ho, Wo, bn=bnv)
+    assert ops.conv_supported(d)
+    xd, wd, bd, dyd = dev(x), dev(w), dev(b), dev(dy)
+    yd = torch.full((N, Ho, Wo, Co), 7.0, device="cuda")
+    stats = torch.zeros(512 * 2 * Co, device="cuda")
+    n = ops.conv_fwd(d, xd, wd, bd, yd, dev(r) if res else None, (dev(rsc), dev(rsh)) if res else None, stats)
+    torch.cuda.synchronize()
+    yr = y.detach().numpy()
+    assert _close(yd.cpu().numpy(), yr)
+    part = stats[:n * 2 * Co].view(n, 2, Co).double().sum(0).cpu().numpy()
+    assert np.abs(part[0] - yr.sum((0, 1, 2))).max() <= 1e-4 * max(1.0, np.abs(yr).sum((0, 1, 2)).max())
+    assert np.abs(part[1] - (yr ** 2).sum((0, 1, 2))).max() <= 1e-4 * (yr ** 2).sum((0, 1, 2)).max()
+    dw = torch.full((k, k, Ci, Co), 0.5, device="cuda")
+    db = torch.full((Co,), -0.25, device="cuda")
+    scratch = torch.empty(1 << 22, device="cuda")
+    ops.conv_bwd_weight(d, xd, dyd, dw, db, scratch)
+    torch.cuda.synchronize()
+    assert _close(dw.cpu().numpy() - 0.5, w.grad.numpy(), 5e-5)
+    assert _close(db.cpu().numpy() + 0.25, b.grad.numpy(), 5e-5)
+    if Ci % 4 == 0 and not bn:
+        dx = torch.full((N, H, W, Ci), 0.25, device="cuda")
+        ops.conv_bwd_data(d, dyd, wd, dx, beta=1.0)
+        torch.cuda.synchronize()
+        assert _close(dx.cpu().numpy() - 0.25, x.grad.numpy(), 5e-5)
+    elif Ci % 4 == 0:
+        # the data gradient is with respect to the NORMALISED map (the batch-norm backward takes it from there)
+        xn = xin.detach().clone().requires_grad_(True)
+        (_ref_conv(xn, w.detach(), b.detach(), s) * dy).sum().backward()
+        dx = torch.zeros((N, H, W, Ci), device="cuda")
+        if k == 1 and s == 2:
+            ops.conv_bwd_data(d, dyd, wd, dx, beta=1.0)
+        else:
+            dx.fill_(3.0)
+            ops.conv_bwd_data(d, dyd, wd, dx, beta=0.0)
+        torch.cuda.synchronize()
+        assert _close(dx.cpu().numpy(), xn.grad.numpy(), 5e-5)
