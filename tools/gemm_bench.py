@@ -1,45 +1,69 @@
-"""Time avsr_gemm on the shapes of the c4 train step (HIP events, 20 reps after 3 warm-ups).
-python tools/gemm_bench.py"""
+"""GEMM inventory of one c4 training step (shapes recorded by wrapping ops.gemm) and the time of every distinct shape, on the GPU.
+Usage: python tools/gemm_bench.py [--video-frontend features|resnet_cnn]"""
 import os
 import sys
+import collections
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from avsr_tf1_amd import ops  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                                       # noqa: E402
+from avsr_tf1_amd import ops                                        # noqa: E402
+from avsr_tf1_amd.model import Seq2SeqModel                          # noqa: E402
 
 
-def bench(M, N, K, ta, tb, sk, reps=20):
-    A = torch.randn((K, M) if ta else (M, K), device="cuda")
-    B = torch.randn((N, K) if tb else (K, N), device="cuda")
-    Cm = torch.zeros(M, N, device="cuda")
-    ws = torch.empty(max(4, sk * M * N), device="cuda")
-    f = lambda: ops.gemm(ops.mat(A, A.shape[1]), ops.mat(B, B.shape[1]), ops.mat(Cm, N), M, N, K, trans_a=ta, trans_b=tb,
-                         splitk=sk, workspace=ws)
-    for _ in range(3):
-        f()
+def main():
+    fe = "resnet_cnn" if "resnet_cnn" in sys.argv else "features"
+    from avsr_tf1_amd.config import ModelConfig
+    from avsr_tf1_amd.model import Batch
+    wl = bench.WORKLOADS["c5" if "c5" in sys.argv else "c4"]
+    cfg = ModelConfig(audio_feat=bench.FA, video_feat=bench.FV, video_processing=fe, use_dropout=True, sampling_probability=0.1, **wl["cfg"])
+    batch = Batch.from_numpy(bench.NS(bench.synth(cfg, wl["B"], 0)))
+    m = Seq2SeqModel(cfg, seed=1)
+    m.train_step(batch)
+    torch.cuda.synchronize()
+    calls = []
+    real = ops.gemm
+
+    def spy(A, B, Cm, M, N, K, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, batch=1, strides=(0, 0, 0), splitk=None,
+            workspace=None, alpha_dev=None):
+        calls.append((int(M), int(N), int(K), int(bool(trans_a)), int(bool(trans_b)), int(batch), float(beta), splitk,
+                      (A, B, Cm, bias, strides, workspace, alpha_dev, alpha)))
+        return real(A, B, Cm, M, N, K, trans_a, trans_b, alpha, beta, bias, batch, strides, splitk, workspace, alpha_dev)
+
+    ops.gemm = spy
+    m.train_step(batch)
+    torch.cuda.synchronize()
+    ops.gemm = real
+    groups = collections.OrderedDict()
+    for c in calls:
+        groups.setdefault(c[:6], []).append(c)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        f()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    return us, 2.0 * M * N * K / us / 1e6
+    tot, totf = 0.0, 0.0
+    rows = []
+    for key, cs in groups.items():
+        M, N, K, ta, tb, bt = key
+        c = cs[0]
+        A, B, Cm, bias, strides, workspace, alpha_dev, alpha = c[8]
+        # beta = 1 keeps every destination's meaning irrelevant here; timing only
+        for rep in range(2):
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                real(A, B, Cm, M, N, K, ta, tb, alpha, 1.0, bias, bt, strides, c[7], workspace, alpha_dev)
+            e1.record()
+            torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 100.0
+        fl = 2.0 * M * N * K * bt
+        rows.append((us * len(cs), len(cs), M, N, K, ta, tb, bt, us, fl / us * 1e-6))
+        tot += us * len(cs)
+        totf += fl * len(cs)
+    rows.sort(reverse=True)
+    for r in rows:
+        print("%8.1f us total  x%-3d  M=%-6d N=%-5d K=%-6d ta=%d tb=%d batch=%-3d  %7.1f us  %6.1f TF" % r)
+    print("python-level GEMMs per step: %d, %.3f ms, %.1f GFLOP, %.1f TF average" % (len(calls), tot * 1e-3, totf * 1e-9, totf / tot * 1e-6))
 
 
 if __name__ == "__main__":
-    shapes = [("enc dW h-part  ", 256, 1024, 32000, 1, 0), ("enc dW x(80)   ", 80, 1024, 32000, 1, 0),
-              ("hoisted x.Wx   ", 32000, 1024, 80, 0, 0), ("dx = dG.W0^T   ", 32000, 80, 1024, 0, 1),
-              ("keys = mem.Wk  ", 32000, 256, 256, 0, 0), ("video dx       ", 4800, 128, 1024, 0, 1),
-              ("small 64x256   ", 64, 256, 512, 0, 0), ("dec 2560x128   ", 2560, 31, 256, 0, 0),
-              ("dec dW 896x1024", 896, 1024, 2560, 1, 0)]
-    for name, M, N, K, ta, tb in shapes:
-        line = name
-        for sk in (1, 4, 8, 16, 32, 48, 64, 96):
-            if sk > 1 and K // sk < 64:
-                continue
-            us, tf = bench(M, N, K, ta, tb, sk)
-            line += " | sk%-2d %7.1fus %5.1fTF" % (sk, us, tf)
-        print(line)
+    main()
