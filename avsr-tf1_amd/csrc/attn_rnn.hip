@@ -13,6 +13,7 @@
 extern "C" int avsr_step_launch_raw(const void* launch, void* stream);
 extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stream);
 int avsr_dec_persist_fwd(const avsr_attn_rnn* d, int32_t l_begin, int32_t l_end, void* stream);   // dec_persist.hip
+int avsr_dec_persist_bwd(const avsr_attn_rnn* d, void* stream);                                      // dec_persist_bwd.hip
 
 namespace avsr {
 
@@ -599,7 +600,14 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
   static thread_local StepLaunch SL;
   static thread_local AttnLaunch AL;
   static thread_local SlabLaunch BL;
-  for (int l = L - 1; l >= 0; --l) {
+  // the whole loop as one persistent launch where the fused kernel covers the block (csrc/dec_persist_bwd.hip)
+  bool fused = false;
+  if (A > 0 && !gru && NX == 0 && n_bah == 0) {
+    const int frc = avsr_dec_persist_bwd(dp, stream);
+    if (frc == AVSR_OK) fused = true;
+    else if (frc != AVSR_ERR_UNSUPPORTED) return frc;
+  }
+  for (int l = fused ? -1 : L - 1; l >= 0; --l) {
     if (A > 0) {
       // ---- KB3: d attention_l = datt_ext[l] + dG_{l+1} . Wx_att^T ----------------------------
       SL.ntask = 1;

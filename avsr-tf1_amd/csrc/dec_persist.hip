@@ -31,88 +31,9 @@
 // rnn_persist.hip) and the host redoes the call with one launch per phase.  Declines (AVSR_ERR_UNSUPPORTED -> per-step
 // launches): GRU, multi-layer decoder cells, Bahdanau mechanisms, beam search, H or D > 256, V > 32, memories that
 // do not fit the resident budget.
-#include "step.h"
-#include "attn.h"
-#include "avsr_hip.h"
-#include "prof.h"
-#include "persist.h"
-
-#define DP_NW 32          // workgroups per row group (= CUs of one XCD)
-#define DP_R 8            // rows per group
-#define DP_WPR 4          // workgroups per row in the attention phase
-#define DP_NT 512         // threads per workgroup: 8 waves, two per SIMD (<= 256 registers per lane each)
-#define DP_WV 8
-#define DP_CPW 7          // 16-wide K chunks per wave, cell product   (E + A + H <= 896)
-#define DP_APW 4          // 16-wide K chunks per wave, attention layer (H + D <= 512)
-#define DP_MISC 4032      // floats of LDS ahead of the resident value rows
-#define DP_LDS_BYTES 163840
+#include "dec_persist.h"
 
 namespace avsr {
-
-struct DPMech {
-  const float* keys; const float* values; long values_sb, values_st; const int* len; const float* g;
-  const float* watt_t;
-  float* scores; float* ctx; float* pstat;      // records [B][L][T], [B][L][D], [L][2][nc_rec][B]
-  float* ppm; float* ppl; float* ppctx;         // quarter partials [4][B], [4][B], [4][B][D]
-  int T, D, type, nc_rec, ch, lds_off;
-};
-
-struct DPLaunch {
-  int B, L, H, E, V, n_mech, mode, oa;
-  int l_begin, l_end, b0, ngroups;
-  int go_id, eos_id, A, KW;
-  int UW, AW, NWA, drop;
-  int uwsh, awsh;
-  int* err; int* claim; int* flags;
-  const float* wt; const float* bias;
-  float* gates; float* cs; float* cell_out; float* att; float* attd; float* hs_seq; float* state;
-  int* steplen;
-  const float* embedding; const float* wout_t; const float* bout;
-  float* logits; int* ids; int* tok; int* n_unfinished;
-  float* xs; const int* labels; int* fed;
-  const int* seed; float k_in, k_st, k_out, prob; uint32_t cid4;
-  float* plog;
-  DPMech m[2];
-};
-
-__device__ __forceinline__ float ld1_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {
-  return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16));
-}
-__device__ __forceinline__ void stb4(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
-  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r, byte_off, 0, 0);
-}
-// DPP reductions: __shfl_xor lowers to ds_bpermute (an LDS round trip per step); inside a row of 16 lanes the data-parallel
-// primitives rotate for one VALU issue.  row16_*: every lane of the row gets the row's result.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_f<0x128>(v);      // row_ror:8
-  v += dpp_f<0x124>(v);      // row_ror:4
-  v += dpp_f<0x122>(v);      // row_ror:2
-  v += dpp_f<0x121>(v);      // row_ror:1
-  return v;
-}
-__device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, dpp_f<0x128>(v));
-  v = fmaxf(v, dpp_f<0x124>(v));
-  v = fmaxf(v, dpp_f<0x122>(v));
-  v = fmaxf(v, dpp_f<0x121>(v));
-  return v;
-}
-__device__ __forceinline__ float rdlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-// whole-wave results (uniform): the four row results combined in a fixed order
-__device__ __forceinline__ float wave64_sum(float v) {
-  v = row16_sum(v);
-  return (rdlane_f(v, 0) + rdlane_f(v, 16)) + (rdlane_f(v, 32) + rdlane_f(v, 48));
-}
-__device__ __forceinline__ float wave64_max(float v) {
-  v = row16_max(v);
-  return fmaxf(fmaxf(rdlane_f(v, 0), rdlane_f(v, 16)), fmaxf(rdlane_f(v, 32), rdlane_f(v, 48)));
-}
-__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
 // KR0 / KR1: register capacity of the resident keys of mechanism 0 / 1, in frames per 16-lane group (32 groups per workgroup)
 //
@@ -744,7 +665,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   }
 }
 
-static int g_dec_fused = 1;
+int g_dec_fused = 1;
 
 // variant: 0 = one mechanism (<= 128 frames per quarter); 1 = (<= 32, <= 128); 2 = (<= 128, <= 32) frames per quarter
 static const void* dp_kernel(int variant, int mode) {
@@ -756,7 +677,7 @@ static const void* dp_kernel(int variant, int mode) {
 static inline int dp_quarter(int T) { return (T + DP_WPR - 1) / DP_WPR; }
 
 // Fills L for the descriptor; returns AVSR_ERR_UNSUPPORTED when the fused kernel does not cover it.
-static int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* lds_bytes) {
+int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* lds_bytes) {
   if (!g_dec_fused || !g_sync || !d.fused_ws) return AVSR_ERR_UNSUPPORTED;
   if (d.cell != 0 || d.n_extra != 0 || d.n_mech < 1 || d.n_mech > 2 || d.mode < 0 || d.mode > 2) return AVSR_ERR_UNSUPPORTED;
   const int B = d.B, H = d.H, E = d.E, A = d.n_mech * H, KW = E + A + H;
@@ -812,12 +733,20 @@ static int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* ld
 
 }  // namespace avsr
 
-extern "C" int64_t avsr_attn_rnn_fused_ws_floats(int32_t B, int32_t n_mech, int32_t Dmax) {
+int64_t avsr_dec_persist_bwd_ws_floats(int32_t B, int32_t n_mech);
+
+// forward region of the fused workspace (the backward kernel's partials follow it)
+int64_t avsr_dec_persist_fwd_ws_floats(int32_t B, int32_t n_mech, int32_t Dmax) {
   const int64_t groups = (B + DP_R - 1) / DP_R;
   return groups * DP_NW * DP_R * 32 + (int64_t)n_mech * (8L * B + 4L * B * Dmax) + 64;
 }
 
-extern "C" int avsr_attn_rnn_set_fused(int32_t on) { avsr::g_dec_fused = on ? 1 : 0; return AVSR_OK; }
+extern "C" int64_t avsr_attn_rnn_fused_ws_floats(int32_t B, int32_t n_mech, int32_t Dmax) {
+  return avsr_dec_persist_fwd_ws_floats(B, n_mech, Dmax) + avsr_dec_persist_bwd_ws_floats(B, n_mech);
+}
+
+// 0: per-step launches; 1: fused forward and backward; 2: fused forward only; 3: fused backward only (A/B timing, tests)
+extern "C" int avsr_attn_rnn_set_fused(int32_t on) { avsr::g_dec_fused = (on >= 0 && on <= 3) ? on : 1; return AVSR_OK; }
 
 extern "C" int avsr_attn_rnn_fused_eligible(const avsr_attn_rnn* d) {
   using namespace avsr;
@@ -833,6 +762,7 @@ int avsr_dec_persist_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32_t l_end
   using namespace avsr;
   static thread_local DPLaunch L;
   int variant = 0; size_t lds = 0;
+  if (g_dec_fused == 3) return AVSR_ERR_UNSUPPORTED;
   const int rc = dp_plan(*dp, L, &variant, &lds);
   if (rc) return rc;
   if (l_begin >= l_end) return AVSR_OK;

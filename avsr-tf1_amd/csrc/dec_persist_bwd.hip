@@ -1,0 +1,540 @@
+// Fused persistent BPTT of the attention decoder / the AV-Align attentive layer: the backward loop of avsr_attn_rnn_bwd
+// (gradient of avsr/decoder_bimodal.py:241-275, decoder_unimodal.py:320-350, encoder.py:265-290 -- AttentionWrapper step = LSTM cell ->
+// Luong attention per memory -> attention layer) as ONE launch instead of four dependent launches per decode step.
+//
+// Same MI355X mapping as the forward kernel (dec_persist.hip): groups of 8 utterances bound to one XCD, 32 workgroups of 512
+// threads, the quarter of one utterance's keys resident in VGPRs and its values in LDS, XCD-local hand-offs through the L2 +
+// one progress word per workgroup.  Per step l (descending) three phases, i.e. three hand-offs:
+//   A  d attention(l) columns [j*AW, (j+1)*AW) and the recurrent part of d h(l) for units [j*UW, (j+1)*UW), all 8 rows:
+//      dG(l+1) . [W_att-rows | W_h-rows]^T on v_mfma_f32_16x16x4_f32 (K = 4H split over the 8 waves, the kernel rows resident in
+//      registers); + the external gradient, x the input-dropout mask; attention record.  Then, without a hand-off, the
+//      workgroup's K-slice of the attention layer's transpose: datt[:, slice] . W_att[:, slice]^T -> partial d cell_out (H) and
+//      partial d context (D) of its mechanism, published as split-K partials (16 KB per workgroup).
+//   B  attention backward of (row j/4, quarter j%4) of every memory: d context = sum of the 16 partials; d alpha_t = V_t . dctx from
+//      the LDS-resident values; d s_t = alpha_t (d alpha_t - ctx . dctx) (alpha from the forward's score / softmax-statistic records);
+//      partial d query = g sum_t d s_t K_t from the register-resident keys; score-gradient and context-gradient records.
+//   C  LSTM cell backward for (row, unit) of the workgroup's unit slice: d out = external + sum of the 32 attention-layer
+//      partials + the 4 x n_mech query partials; DropoutWrapper masks; gate gradients -> record + the rolling dG(l) of phase A.
+// Records (dgates, datt, dctx, dscores) keep the layouts the post-loop weight-gradient GEMMs consume.  The rolling buffers
+// (dstate) are left exactly as the per-step loop leaves them after step 0, so the caller's d h0 / d c0 tail is unchanged.
+// Every wait is bounded (sticky error word of the persistent scratch, as in dec_persist.hip).
+#include "dec_persist.h"
+
+#define DB_KPW 8          // 16-deep K chunks of dG per wave (4H <= 1024)
+#define DB_PART 512       // floats per (workgroup, row) partial: [d cell_out (H <= 256) | d context (D <= 256)]
+
+namespace avsr {
+
+struct DBMech {
+  const float* keys; const float* values; long values_sb, values_st; const int* len; const float* g; const float* watt_t;
+  const float* scores; const float* ctx; const float* pstat;       // forward records [B][L][T], [B][L][D], [L][2][nc_rec][B]
+  float* dscores; float* dctx; float* pdq;                         // records [B][L][T], [B][L][D]; quarter partials [4][B][H]
+  int T, D, type, nc_rec, ch, lds_off;
+};
+
+struct DBLaunch {
+  int B, L, H, E, A, KW, n_mech, b0, ngroups;
+  int UW, AW, NWA, drop, uwsh, awsh;
+  int* err; int* claim; int* flags;
+  const float* w;                                                  // cell kernel [E + A + H][4H]
+  const float* gates; const float* cs; const float* c0; const int* steplen;
+  const float* datt_ext; const float* dcell_ext;
+  float* dgates; float* dstate; float* datt;
+  float* part;                                                     // [groups][32][8][DB_PART]
+  const int* seed; float k_in, k_st, k_out; uint32_t cid4;
+  DBMech m[2];
+};
+
+template <int KR0, int KR1>
+__global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const red = lds;                       // [8][2][8][16] phase A partial sums / [8][256] query-gradient partials
+  float* const s_datt = lds + 2048;             // [8][16] this workgroup's d attention columns
+  float* const s_dctx = lds + 2176;             // [2][256] d context of the attention row
+  float* const s_ds = lds + 2688;               // [2][128] d score of this quarter's frames
+  float* const s_cd = lds + 2944;               // [2] ctx . dctx
+  int* const s_int = reinterpret_cast<int*>(lds + 2960);   // [0..7] step lengths, [16] slot
+  float* const vals = lds + DP_MISC;            // resident value rows of this workgroup's quarter
+
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int g = __builtin_amdgcn_readfirstlane(xcc_id());
+  if (tid0 == 0) s_int[16] = __hip_atomic_fetch_add(L.claim + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int j = __builtin_amdgcn_readfirstlane(s_int[16]);
+  if (g >= L.ngroups || j >= DP_NW) return;
+
+  const int B = L.B, Ls = L.L, H = L.H, E = L.E, A = L.A;
+  const int H4 = 4 * H;
+  const int rowbase = L.b0 + g * DP_R;
+  const int gg = rowbase / DP_R;                 // group index into the partial workspace
+  const bool drop = L.drop != 0;
+  const uint32_t seedv = L.seed ? (uint32_t)L.seed[0] : 0u;
+  const uint32_t cid4 = L.cid4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const long BH = (long)B * H;
+  float* const dgroll = L.dstate;                // [2][B][4H]
+  float* const dcbuf = L.dstate + 8 * BH;        // [2][B][H]
+  float* const dhcarry = L.dstate + 10 * BH;     // [2][B][H]
+
+  const int UW = L.UW, uwsh = L.uwsh, unit0 = j * UW;
+  const int AW = L.AW, awsh = L.awsh, an0 = j * AW;
+  const bool has_att = an0 < A;
+  const int ma = has_att ? an0 / H : 0;
+  const int nl0 = an0 - ma * H;
+  const DBMech& Ma = L.m[ma];
+  const int Da = Ma.D, ncols = H + Da;
+  const int nk = H >> 2;                          // 16-deep chunks of K = 4H
+  const int kg0 = (wave * nk) / DP_WV, nkw = ((wave + 1) * nk) / DP_WV - kg0;
+  unsigned ukA[DB_KPW];
+
+  // ---------------------------------------------------------------------------------------------------------
+  // resident operands
+  // ---------------------------------------------------------------------------------------------------------
+  f32x4 wp[DB_KPW][2], wb[4];
+  f32x4 k0[KR0 > 0 ? KR0 : 1][4], k1[KR1 > 0 ? KR1 : 1][4];
+  int n_m[2] = {0, 0}, t0_m[2] = {0, 0};
+  const int r_att = j >> 2, cq = j & 3;
+  const int b_att = rowbase + r_att;
+  const bool att_row = b_att < B;
+  float dc_state = 0.f, dh_carry = 0.f;
+  {
+    const int tid = tid0, lane = tid & 63, i = lane & 15, q = lane >> 4, s16 = tid & 15, rg = tid >> 4;
+    for (int idx = tid; idx < DP_MISC - 2048; idx += DP_NT) lds[2048 + idx] = 0.f;
+    // (1) rows of the cell kernel behind this workgroup's d attention columns (tile 0) and d h units (tile 1); K split over the waves
+#pragma unroll
+    for (int cc = 0; cc < DB_KPW; ++cc) {
+      const bool in = cc < nkw;
+      const int kk = (kg0 + cc) << 4;
+      ukA[cc] = in ? (unsigned)(kk * 4) : 0u;
+      wp[cc][0] = (in && has_att && i < AW) ? ld4(L.w + (long)(E + an0 + i) * H4 + kk + 4 * q) : zero4;
+      wp[cc][1] = (in && i < UW && unit0 + i < H) ? ld4(L.w + (long)(E + A + unit0 + i) * H4 + kk + 4 * q) : zero4;
+    }
+    // (2) this workgroup's K-slice of the attention layer's transpose: rows [nl0, nl0 + AW) of W_att^T, column tiles wave*4 .. wave*4+3
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = (wave * 4 + t) * 16 + i;
+      f32x4 v = zero4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (has_att && n < ncols && 4 * q + e < AW) v[e] = Ma.watt_t[(long)(nl0 + 4 * q + e) * ncols + n];
+      wb[t] = v;
+    }
+    // (3) attention memories of row r_att, quarter cq: keys -> registers (16 lanes per frame), values -> LDS
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      if (m >= L.n_mech) continue;
+      const DBMech& M = L.m[m];
+      const int len = att_row ? min(M.len ? M.len[b_att] : M.T, M.T) : 0;
+      const int t0 = cq * M.ch;
+      const int n = max(0, min(M.ch, len - t0));
+      n_m[m] = n; t0_m[m] = t0;
+      const float* kb = M.keys + ((long)b_att * M.T + t0) * H;
+      if (m == 0) {
+#pragma unroll
+        for (int u = 0; u < KR0; ++u)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int fr = rg + 32 * u, k = 4 * s16 + 64 * jj;
+            k0[u][jj] = (fr < n && k < H) ? ld4(kb + (long)fr * H + k) : zero4;
+          }
+      } else {
+#pragma unroll
+        for (int u = 0; u < KR1; ++u)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int fr = rg + 32 * u, k = 4 * s16 + 64 * jj;
+            k1[u][jj] = (fr < n && k < H) ? ld4(kb + (long)fr * H + k) : zero4;
+          }
+      }
+      const int d4 = M.D >> 2;
+      const float* vb = M.values + (long)b_att * M.values_sb + (long)t0 * M.values_st;
+      for (int idx = tid; idx < n * d4; idx += DP_NT) {
+        const int fr = idx / d4, c4 = idx - fr * d4;
+        st4(vals + M.lds_off + fr * M.D + 4 * c4, ld4(vb + (long)fr * M.values_st + 4 * c4));
+      }
+    }
+    // (4) gradient state of (row er, unit eu); step lengths of the group's rows
+    const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
+    if (tid < DP_R * UW && eb < B && eun < H) {
+      dc_state = dcbuf[(long)(Ls & 1) * BH + (long)eb * H + eun];
+      dh_carry = dhcarry[(long)(Ls & 1) * BH + (long)eb * H + eun];
+    }
+    __syncthreads();
+    if (tid < DP_R) s_int[tid] = (rowbase + tid < B) ? L.steplen[rowbase + tid] : 0;
+    __syncthreads();
+  }
+  const __amdgpu_buffer_rsrc_t dg_rs = make_rsrc(dgroll), part_rs = make_rsrc(L.part), gates_rs = make_rsrc(L.gates);
+  const __amdgpu_buffer_rsrc_t ctx_rs = make_rsrc(L.m[wave < 2 ? (wave < L.n_mech ? wave : 0) : 0].ctx);
+  const __amdgpu_buffer_rsrc_t pdq0_rs = make_rsrc(L.m[0].pdq), pdq1_rs = make_rsrc(L.m[L.n_mech > 1 ? 1 : 0].pdq);
+
+  int* const flag_base = L.flags + g * 3 * 32;
+  auto wait_all = [&](int phase, int need) {
+    if (wave == 0) {
+      const int* fp = flag_base + phase * 32 + (threadIdx.x & 31);
+      bool ok = false;
+      for (int spins = 0; spins < (1 << 21); ++spins) {
+        const int v = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v >= need)) { ok = true; break; }
+        if ((spins & 1023) == 1023 && __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = true; break; }
+      }
+      if (!ok && threadIdx.x == 0) __hip_atomic_store(L.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    lds_barrier();
+  };
+  auto publish = [&](int phase, int value) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag_base + phase * 32 + j, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+#ifdef DP_TIMING
+  long tm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long last_ = __builtin_amdgcn_s_memtime();
+#define BTICK(k) { const long now_ = __builtin_amdgcn_s_memtime(); tm[k] += now_ - last_; last_ = now_; }
+#else
+#define BTICK(k)
+#endif
+
+  for (int l = Ls - 1; l >= 0; --l) {
+    const int epoch = Ls - l;
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));                 // opaque: per-thread indices below are recomputed, not kept across steps
+    const int lane = tid & 63, i = lane & 15, q = lane >> 4;
+    const int ab = rowbase + i;
+    const bool aok = i < DP_R && ab < B;
+    const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
+    const bool eok = tid < DP_R * UW && eb < B && eun < H;
+    float zA = 0.f;
+    // =====================================================================================================
+    // A: d attention(l) columns and the recurrent d h(l) of this workgroup from dG(l+1); attention-layer transpose, split-K
+    // =====================================================================================================
+    if (epoch > 1) wait_all(2, epoch - 1);
+    BTICK(0)
+    {
+      const unsigned dg_o = aok ? (unsigned)(((long)((l + 1) & 1) * B + ab) * H4) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
+      f32x4 dv[DB_KPW];
+#pragma unroll
+      for (int cc = 0; cc < DB_KPW; ++cc) dv[cc] = ldb_sc1(dg_rs, (int)(dg_o + ukA[cc]));
+      f32x4 acc[2] = {zero4, zero4}, accb[2] = {zero4, zero4};
+#pragma unroll
+      for (int cc = 0; cc < DB_KPW; cc += 2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[cc][e], wp[cc][nt][e], acc[nt], 0, 0, 0);
+            accb[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[cc + 1][e], wp[cc + 1][nt][e], accb[nt], 0, 0, 0);
+          }
+      acc[0] += accb[0]; acc[1] += accb[1];
+      if (q < 2) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((wave * 2 + nt) * 8 + q * 4 + r) * 16 + i] = acc[nt][r];
+      }
+      lds_barrier();
+      BTICK(1)
+      if (tid < DP_R * AW && has_att) {
+        const int ar = tid >> awsh, ac = tid & (AW - 1), arb = rowbase + ar;
+        float a = 0.f;
+        if (arb < B && l < s_int[ar]) {
+          const int o = ar * 16 + ac;
+          float z = 0.f;
+#pragma unroll
+          for (int w = 0; w < DP_WV; ++w) z += red[(w * 2) * 128 + o];
+          // the product is the gradient of step l+1's DROPPED attention input (AttentionWrapper feeds [x | attention] through the
+          // DropoutWrapper's input mask, cells.py:46-54)
+          z *= p_drop(drop, seedv, cid4, (uint32_t)(((long)arb * Ls + l + 1) * (E + A) + E + an0 + ac), L.k_in);
+          a = z + (L.datt_ext ? L.datt_ext[((long)arb * Ls + l) * A + an0 + ac] : 0.f);
+        }
+        if (arb < B) L.datt[((long)arb * Ls + l) * A + an0 + ac] = a;
+        s_datt[ar * 16 + ac] = a;
+      }
+      if (tid < DP_R * UW) {
+        const int o = er * 16 + eu;
+#pragma unroll
+        for (int w = 0; w < DP_WV; ++w) zA += red[(w * 2 + 1) * 128 + o];
+      }
+      lds_barrier();
+      if (has_att) {
+        const f32x4 a4 = ld4(s_datt + (i & 7) * 16 + 4 * q);
+        float* const prow = L.part + (((long)gg * DP_NW + j) * DP_R + q * 4) * DB_PART + i;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int n0 = (wave * 4 + t) * 16;
+          if (n0 < ncols) {                          // wave-uniform
+            f32x4 c = zero4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], wb[t][e], c, 0, 0, 0);
+            if (q < 2) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) prow[(long)r * DB_PART + n0] = c[r];
+            }
+          }
+        }
+      }
+      BTICK(2)
+      publish(0, epoch);
+      BTICK(3)
+    }
+    // =====================================================================================================
+    // B: attention backward of (row r_att, quarter cq)  (gradient of attention.py:25-72 Luong / scaled Luong scores, the masked
+    //    softmax and the context of contrib.seq2seq _compute_attention)
+    // =====================================================================================================
+    wait_all(0, epoch);
+    BTICK(4)
+    {
+      const int s16 = tid & 15, rg = tid >> 4;
+      const bool vrow = att_row && l < s_int[r_att];
+      if (wave < 2 && wave < L.n_mech) {
+        const DBMech& M = L.m[wave];
+        const int D = M.D, c4 = lane;
+        const bool cok = att_row && 4 * c4 < D;
+        const int nwm = H >> awsh, w0 = wave * nwm;
+        const unsigned base = cok ? (unsigned)((((long)gg * DP_NW + w0) * DP_R + r_att) * DB_PART + H + 4 * c4) * 4u : (unsigned)P_OOB;
+        const f32x4 cv = ldb4(ctx_rs, cok ? (int)((((long)b_att * Ls + l) * D + 4 * c4) * 4) : P_OOB);
+        f32x4 acc = zero4;
+        for (int w = 0; w < nwm; w += 8) {
+          f32x4 x[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x[u] = ldb_sc1(part_rs, (w + u < nwm) ? (int)(base + (unsigned)((w + u) * DP_R * DB_PART * 4)) : P_OOB);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += x[u];
+        }
+        st4(s_dctx + wave * 256 + 4 * c4, acc);
+        if (cq == 0 && cok) st4(M.dctx + ((long)b_att * Ls + l) * D + 4 * c4, acc);
+        const float cd = wave64_sum(dot4(cv, acc));
+        if (lane == 0) s_cd[wave] = cd;
+      }
+      lds_barrier();
+      BTICK(5)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (m >= L.n_mech) continue;
+        const DBMech& M = L.m[m];
+        const int D = M.D, n = n_m[m];
+        const float gsc = (M.type == ATT_SCALED_LUONG) ? M.g[0] : 1.f;
+        // softmax statistics of this row and step from the forward's records (merged over the recorded chunks)
+        float Mx = -INFINITY, Lsum = 0.f;
+        {
+          const float* pm = M.pstat + (long)(2 * l) * M.nc_rec * B;
+          const float* pl = M.pstat + (long)(2 * l + 1) * M.nc_rec * B;
+          if (att_row) {
+            for (int c = 0; c < M.nc_rec; ++c) Mx = fmaxf(Mx, pm[(long)c * B + b_att]);
+            for (int c = 0; c < M.nc_rec; ++c) {
+              const float pmc = pm[(long)c * B + b_att];
+              if (pmc != -INFINITY) Lsum += __expf(pmc - Mx) * pl[(long)c * B + b_att];
+            }
+          }
+        }
+        const float invL = Lsum > 0.f ? 1.f / Lsum : 0.f;
+        const float cd = s_cd[m];
+        f32x4 d4[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) d4[jj] = ld4(s_dctx + m * 256 + 4 * s16 + 64 * jj);
+        const float* raws = M.scores + ((long)b_att * Ls + l) * M.T + t0_m[m];
+        float* dsr = M.dscores + ((long)b_att * Ls + l) * M.T + t0_m[m];
+        const int KR = m == 0 ? KR0 : KR1;
+#pragma unroll
+        for (int u = 0; u < (m == 0 ? KR0 : KR1); ++u) {
+          const int fr = rg + 32 * u;
+          float a = 0.f;
+          if (fr < n) {
+            const float* vp = vals + M.lds_off + fr * D + 4 * s16;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              if (4 * s16 + 64 * jj < D) a += dot4(ld4(vp + 64 * jj), d4[jj]);
+          }
+          a = row16_sum(a);
+          if (s16 == 0) {
+            float dsv = 0.f;
+            if (fr < n && vrow) dsv = __expf(raws[fr] * gsc - Mx) * invL * (a - cd);
+            s_ds[m * 128 + fr] = dsv;
+            if (att_row && fr < M.ch && t0_m[m] + fr < M.T) dsr[fr] = dsv;
+          }
+        }
+        (void)KR;
+        lds_barrier();
+        // partial d query over this quarter from the register-resident keys
+        f32x4 pa[4] = {zero4, zero4, zero4, zero4};
+        if (m == 0) {
+#pragma unroll
+          for (int u = 0; u < KR0; ++u) {
+            const float dsf = s_ds[rg + 32 * u];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) pa[jj] += dsf * k0[u][jj];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < KR1; ++u) {
+            const float dsf = s_ds[128 + rg + 32 * u];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) pa[jj] += dsf * k1[u][jj];
+          }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = pa[jj][e];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            pa[jj][e] = v;
+          }
+        if (q == 0) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) st4(red + wave * 256 + 4 * s16 + 64 * jj, pa[jj]);
+        }
+        lds_barrier();
+        if (tid < 64) {
+          f32x4 s = ld4(red + 4 * tid);
+#pragma unroll
+          for (int w = 1; w < DP_WV; ++w) s += ld4(red + w * 256 + 4 * tid);
+          if (att_row && 4 * tid < H) st4(M.pdq + (((long)cq * B + b_att) * H + 4 * tid), gsc * s);
+        }
+        lds_barrier();
+      }
+      BTICK(6)
+      publish(1, epoch);
+      BTICK(7)
+    }
+    // =====================================================================================================
+    // C: LSTM cell backward of (row er, unit eun)  (cells.py:14-18 LSTMCell clip 1.0, forget bias 1.0; DropoutWrapper cells.py:46-54)
+    // =====================================================================================================
+    wait_all(1, epoch);
+    BTICK(8)
+    {
+      const bool valid = eok && l < s_int[er & 7];
+      const long bt = (long)eb * Ls + l;
+      float pq[DP_NW], pd[8];
+      const unsigned po = eok ? (unsigned)((((long)gg * DP_NW) * DP_R + er) * DB_PART + eun) * 4u : (unsigned)P_OOB;
+#pragma unroll
+      for (int w = 0; w < DP_NW; ++w) pq[w] = ld1_sc1(part_rs, (w < L.NWA) ? (int)(po + (unsigned)(w * DP_R * DB_PART * 4)) : P_OOB);
+      const unsigned qo = eok ? (unsigned)((long)eb * H + eun) * 4u : (unsigned)P_OOB;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        pd[c] = ld1_sc1(pdq0_rs, (int)(qo + (unsigned)((long)c * BH * 4)));
+        pd[4 + c] = ld1_sc1(pdq1_rs, (L.n_mech > 1) ? (int)(qo + (unsigned)((long)c * BH * 4)) : P_OOB);
+      }
+      const f32x4 g4 = ldb4(gates_rs, valid ? (int)((bt * H + eun) * 16) : P_OOB);
+      float c = 0.f, cprev = 0.f, dext = 0.f;
+      if (valid) {
+        c = L.cs[bt * H + eun];
+        cprev = (l == 0) ? (L.c0 ? L.c0[(long)eb * H + eun] : 0.f) : L.cs[(bt - 1) * H + eun];
+        if (L.dcell_ext) dext = L.dcell_ext[bt * H + eun];
+      }
+      float dout = 0.f;
+#pragma unroll
+      for (int w = 0; w < DP_NW; ++w) dout += pq[w];
+      dout += ((pd[0] + pd[1]) + (pd[2] + pd[3])) + ((pd[4] + pd[5]) + (pd[6] + pd[7]));
+      dout += dext;
+      f32x4 dg = zero4;
+      if (valid) {
+        const uint32_t oidx = (uint32_t)(bt * H + eun);
+        const float dh = dout * p_drop(drop, seedv, cid4 + 2, oidx, L.k_out) + (zA + dh_carry) * p_drop(drop, seedv, cid4 + 1, oidx, L.k_st);
+        const float tc = p_tanh(c);
+        float dc = dh * g4[3] * (1.f - tc * tc) + dc_state;
+        if (!(fabsf(c) < 1.0f)) dc = 0.f;          // cell_clip = 1.0: no gradient through a clipped cell
+        dg[3] = dh * tc * g4[3] * (1.f - g4[3]);
+        dg[0] = dc * g4[1] * g4[0] * (1.f - g4[0]);
+        dg[1] = dc * g4[0] * (1.f - g4[1] * g4[1]);
+        dg[2] = dc * cprev * g4[2] * (1.f - g4[2]);
+        dc_state = dc * g4[2];
+        dh_carry = 0.f;
+      }
+      if (eok) {
+        st4(L.dgates + (bt * H + eun) * 4, dg);
+        st4(dgroll + ((long)(l & 1) * B + eb) * H4 + eun * 4, dg);
+      }
+      BTICK(9)
+      publish(2, epoch);
+      BTICK(10)
+    }
+  }
+#ifdef DP_TIMING
+  if (tid0 == 0 && j == 0 && g == 0)
+    for (int k = 0; k < 12; ++k) L.err[16 + k] = (int)(tm[k] / Ls);
+#endif
+  {
+    const int tid = tid0;
+    const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
+    if (tid < DP_R * UW && eb < B && eun < H) {
+      dcbuf[(long)eb * H + eun] = dc_state;
+      dhcarry[(long)eb * H + eun] = dh_carry;
+    }
+  }
+}
+
+static const void* db_kernel(int variant) {
+  return variant == 0 ? (const void*)dec_persist_bwd_kernel<4, 0> : variant == 1 ? (const void*)dec_persist_bwd_kernel<1, 4>
+                                                                                 : (const void*)dec_persist_bwd_kernel<4, 1>;
+}
+
+}  // namespace avsr
+
+int64_t avsr_dec_persist_fwd_ws_floats(int32_t B, int32_t n_mech, int32_t Dmax);
+
+// floats the backward kernel needs behind the forward region of the fused workspace
+int64_t avsr_dec_persist_bwd_ws_floats(int32_t B, int32_t n_mech) {
+  const int64_t groups = (B + DP_R - 1) / DP_R;
+  return groups * DP_NW * DP_R * DB_PART + (int64_t)n_mech * 4 * B * 256;
+}
+
+// The whole backward loop of avsr_attn_rnn_bwd as one persistent launch per 64-row slice.  The caller has zeroed dstate and copied
+// the final-state gradients into it exactly as for the per-step path, and runs its d h0 / d c0 tail afterwards.
+int avsr_dec_persist_bwd(const avsr_attn_rnn* dp, void* stream) {
+  using namespace avsr;
+  static thread_local DPLaunch F;
+  static thread_local DBLaunch L;
+  int variant = 0; size_t lds = 0;
+  const avsr_attn_rnn& d = *dp;
+  if (g_dec_fused == 2) return AVSR_ERR_UNSUPPORTED;
+  int rc = dp_plan(d, F, &variant, &lds);
+  if (rc) return rc;
+  if (!d.w || !d.dgates || !d.dstate || !d.datt) return AVSR_ERR_ARG;
+  if (avsr_dec_persist_fwd_ws_floats(d.B, d.n_mech, 256) + avsr_dec_persist_bwd_ws_floats(d.B, d.n_mech) > d.fused_ws_floats) return AVSR_ERR_UNSUPPORTED;
+  if ((long)d.B * d.L * d.H * 16 >= (1L << 31) || (long)((d.B + DP_R - 1) / DP_R) * DP_NW * DP_R * DB_PART * 4 >= (1L << 31) ||
+      (long)4 * d.B * d.H * 4 >= (1L << 31))
+    return AVSR_ERR_UNSUPPORTED;
+  L = DBLaunch{};
+  L.B = d.B; L.L = d.L; L.H = d.H; L.E = d.E; L.A = F.A; L.KW = F.KW; L.n_mech = d.n_mech;
+  L.UW = F.UW; L.AW = F.AW; L.NWA = F.NWA; L.uwsh = F.uwsh; L.awsh = F.awsh;
+  L.drop = (d.seed && (d.keep_in < 1.f || d.keep_state < 1.f || d.keep_out < 1.f)) ? 1 : 0;
+  L.w = d.w; L.gates = d.gates; L.cs = d.cs; L.c0 = d.c0; L.steplen = d.steplen;
+  L.datt_ext = d.datt_ext; L.dcell_ext = d.dcell_ext; L.dgates = d.dgates; L.dstate = d.dstate; L.datt = d.datt;
+  L.seed = d.seed; L.k_in = d.keep_in; L.k_st = d.keep_state; L.k_out = d.keep_out; L.cid4 = (uint32_t)d.cell_id * 4;
+  float* ws = d.fused_ws + avsr_dec_persist_fwd_ws_floats(d.B, d.n_mech, 256);
+  L.part = ws; ws += (long)((d.B + DP_R - 1) / DP_R) * DP_NW * DP_R * DB_PART;
+  for (int m = 0; m < d.n_mech; ++m) {
+    const avsr_attn_mech& M = d.mech[m];
+    if (!M.dscores || !M.dctx || !M.scores || !M.ctx || !M.pstat || !M.watt_t) return AVSR_ERR_ARG;
+    DBMech& X = L.m[m];
+    X.keys = M.keys; X.values = M.values; X.values_sb = M.values_sb; X.values_st = M.values_st; X.len = M.len; X.g = M.g; X.watt_t = M.watt_t;
+    X.scores = M.scores; X.ctx = M.ctx; X.pstat = M.pstat; X.dscores = M.dscores; X.dctx = M.dctx;
+    X.pdq = ws; ws += 4L * d.B * 256;
+    X.T = M.T; X.D = M.D; X.type = M.type; X.nc_rec = F.m[m].nc_rec; X.ch = F.m[m].ch; X.lds_off = F.m[m].lds_off;
+    if ((long)d.B * d.L * M.D * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* sync = g_sync;
+  const long words = P_HDR + 8 + 8 * 3 * 32;
+  if (words > g_sync_ints) return AVSR_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    for (int v = 0; v < 3; ++v)
+      if (hipFuncSetAttribute(db_kernel(v), hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES) != hipSuccess) return AVSR_ERR_HIP;
+    attr_set = true;
+  }
+  L.err = sync; L.claim = sync + P_HDR; L.flags = sync + P_HDR + 8;
+  for (int b0 = 0; b0 < d.B; b0 += 64) {
+    L.b0 = b0; L.ngroups = ((d.B - b0 < 64 ? d.B - b0 : 64) + DP_R - 1) / DP_R;
+    if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
+    {
+      ProfScope ps(PROF_DEC_PERSIST_BWD, s);
+      void* args[] = {(void*)&L};
+      if (hipLaunchKernel(db_kernel(variant), dim3(8 * DP_NW), dim3(DP_NT), args, lds, s) != hipSuccess) return AVSR_ERR_HIP;
+    }
+    AVSR_CHECK_LAUNCH();
+  }
+  return AVSR_OK;
+}

@@ -252,7 +252,7 @@ def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, 
                                    float(weight_decay), _s()), "avsr_optimiser_step")
 
 
-PROF_KINDS = ("gemm", "step_lstm_fwd", "step_lstm_bwd", "step_dense", "attn_fwd", "attn_bwd", "rnn_persist_fwd", "rnn_persist_bwd", "dec_persist_fwd",
+PROF_KINDS = ("gemm", "step_lstm_fwd", "step_lstm_bwd", "step_dense", "attn_fwd", "attn_bwd", "rnn_persist_fwd", "rnn_persist_bwd", "dec_persist_fwd", "dec_persist_bwd",
               "conv_fwd", "conv_bwd_data", "conv_bwd_weight")
 
 
@@ -307,7 +307,7 @@ def attn_rnn_fused_eligible(desc):
 
 
 def attn_rnn_set_fused(on):
-    check(_L().avsr_attn_rnn_set_fused(int(bool(on))), "avsr_attn_rnn_set_fused")
+    check(_L().avsr_attn_rnn_set_fused(int(on)), "avsr_attn_rnn_set_fused")   # 0 off, 1 / True both, 2 forward only, 3 backward only
 
 
 def rnn_persistent_error():

@@ -329,7 +329,9 @@ typedef struct avsr_attn_rnn {
 int64_t avsr_attn_rnn_fused_ws_floats(int32_t B, int32_t n_mech, int32_t Dmax);
 /* 1 if avsr_attn_rnn_fwd(d, ...) would run the fused persistent decode kernel for this descriptor, else 0. */
 int avsr_attn_rnn_fused_eligible(const avsr_attn_rnn* d);
-/* Process-wide switch (default on); the path also needs avsr_rnn_set_persistent's sync scratch. */
+/* avsr_attn_rnn_bwd runs the same block's BPTT loop as one launch of the fused persistent backward kernel (csrc/dec_persist_bwd.hip)
+ * under the same conditions.  Process-wide switch: 0 per-step launches, 1 (default) fused forward and backward, 2 forward only,
+ * 3 backward only; the path also needs avsr_rnn_set_persistent's sync scratch. */
 int avsr_attn_rnn_set_fused(int32_t on);
 
 int avsr_attn_rnn_fwd(const avsr_attn_rnn* d, int32_t l_begin, int32_t l_end, void* stream);
@@ -556,9 +558,9 @@ int avsr_optimiser_step(float* params, float* grads, float* m, float* v, int64_t
  * begin and end every gemm / step / attention launch is bracketed by an event pair on its stream; end
  * synchronises the device and returns per-kind launch counts and summed milliseconds.
  * kinds: 0 gemm, 1 LSTM-forward step, 2 LSTM-backward step, 3 dense step, 4 attention fwd, 5 attention bwd,
- * 6 persistent RNN forward, 7 persistent RNN backward, 8 fused persistent decoder forward, 9 / 10 / 11 direct 3x3 convolution forward / data gradient / weight gradient.  out_flops (may be NULL): algorithmic FLOPs summed per kind
+ * 6 persistent RNN forward, 7 persistent RNN backward, 8 / 9 fused persistent decoder forward / backward, 10 / 11 / 12 convolution forward / data gradient / weight gradient.  out_flops (may be NULL): algorithmic FLOPs summed per kind
  * where the launcher knows them (gemm, persistent RNN kernels), else 0. */
-#define AVSR_PROF_NKIND 12
+#define AVSR_PROF_NKIND 13
 int avsr_prof_begin(int32_t max_launches);
 int avsr_prof_end(int32_t* out_count, float* out_ms, double* out_flops);
 

@@ -1,4 +1,4 @@
-"""The fused persistent decode kernel (csrc/dec_persist.hip: avsr/decoder_bimodal.py:241-275, avsr/decoder_unimodal.py:320-350 and the
+"""The fused persistent decode kernels (csrc/dec_persist.hip forward, csrc/dec_persist_bwd.hip BPTT: avsr/decoder_bimodal.py:241-275, avsr/decoder_unimodal.py:320-350 and the
 AV-Align attentive layer avsr/encoder.py:265-290 as ONE launch per call) against the per-step launch path of the same engine and
 against the CPU oracle ("vs CPU restatement; TF-1.13.1 parity unpinned").  Tolerances: records / logits / gradients 2e-4 of the
 tensor's largest entry between the two engine paths (different summation orders), fed tokens and greedy ids bit-exact."""
@@ -84,6 +84,25 @@ def test_fused_decode_equals_per_step_launches_and_oracle(name):
     assert (a["fed"].cpu().numpy()[consumed] == ref["fed_tokens"][consumed]).all()
     ids_ref = O.greedy_decode(ref["params"], ocfg, batch, max_steps=L + 3)
     assert (a["ids"].cpu().numpy() == ids_ref).all()
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("name", ["bimodal_dropout_sampling_2groups", "av_align", "c4_width_64_utterances", "long_memory_quarters_of_125"])
+def test_fused_forward_only_and_backward_only(name, mode):
+    """avsr_attn_rnn_set_fused(2): fused forward, per-step BPTT; (3): per-step forward, fused BPTT (csrc/dec_persist_bwd.hip) -- the
+    two kernels only share the record layouts, so each must also work on the other path's records."""
+    O, ocfg, mcfg, W, batch = _setup(name)
+    L = CASES[name][4]
+    a = _run(mcfg, W, batch, mode, L + 3)
+    b = _run(mcfg, W, batch, 0, L + 3)
+    assert a["eligible"]
+    assert (a["fed"] == b["fed"]).all() and (a["ids"] == b["ids"]).all()
+    for k in ("logits", "grads", "loss", "gnorm"):
+        x, y = a[k].double(), b[k].double()
+        assert float((x - y).abs().max()) <= 2e-4 * max(1e-3, float(y.abs().max())), k
+    if mode == 3:       # same forward path: the gradients differ only by the backward kernels' summation order
+        x, y = a["grads"].double(), b["grads"].double()
+        assert float((x - y).abs().max()) <= 2e-5 * max(1e-3, float(y.abs().max()))
 
 
 def test_benchmark_decoders_take_the_fused_path():

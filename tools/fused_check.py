@@ -106,17 +106,18 @@ def main():
     for name, (kw, B, Ta, Tv, L) in CASES.items():
         cfg = ModelConfig(**kw)
         batch = synth(cfg, B, Ta, Tv, L)
-        a = run(cfg, batch, True)
-        b = run(cfg, batch, False)
-        print(f"{name}: fused eligible={a['elig']} persistent_error={a['err']}")
-        w = compare(name, a, b)
-        bad += int(w > 2e-4 or not a["elig"] or a["err"])
+        b = run(cfg, batch, 0)
+        for mode in (1, 2, 3):
+            a = run(cfg, batch, mode)
+            print(f"{name}: fused mode {mode} (1 both, 2 fwd only, 3 bwd only) eligible={a['elig']} persistent_error={a['err']}")
+            w = compare(name, a, b)
+            bad += int(w > 2e-4 or not a["elig"] or a["err"])
     print("RESULT", "FAIL" if bad else "OK", bad)
     if full:
         cfg = ModelConfig(architecture="bimodal", video_units=(256,), audio_units=(256, 256, 256), decoder_units=(256,), embedding_size=128,
                           video_feat=128, audio_feat=80, use_dropout=True, sampling_probability=0.1, regress_aus=True)
         batch = synth(cfg, 64, 500, 75, 40, ragged=False)
-        for fused in (True, False):
+        for fused in (1, 2, 0):
             ops.attn_rnn_set_fused(fused)
             m = Seq2SeqModel(cfg, seed=3)
             m.forward_train(batch)
@@ -145,6 +146,14 @@ def main():
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
             print(f"   eager train step: {dt * 1e3:.2f} ms")
+            for rep in range(3):
+                m.forward_train(batch)
+                torch.cuda.synchronize()
+                e0.record()
+                m.backward()
+                e1.record()
+                torch.cuda.synchronize()
+            print(f"   backward pass (all of it): {e0.elapsed_time(e1):.3f} ms; err={ops.rnn_persistent_error()}")
     return bad
 
 
