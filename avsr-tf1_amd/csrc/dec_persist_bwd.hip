@@ -45,6 +45,19 @@ struct DBLaunch {
   DBMech m[2];
 };
 
+// v[l] + v[l ^ 16] and v[l] + v[l ^ 32] with the gfx950 row / half swaps (one VALU issue each; __shfl_xor is an LDS-pipe round trip).
+// Inline asm: the builtin form with both operands equal was folded to a + a by the compiler.
+__device__ __forceinline__ float xor16_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
 template <int KR0, int KR1>
 __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -52,7 +65,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
   float* const s_datt = lds + 2048;             // [8][16] this workgroup's d attention columns
   float* const s_dctx = lds + 2176;             // [2][256] d context of the attention row
   float* const s_ds = lds + 2688;               // [2][128] d score of this quarter's frames
-  float* const s_cd = lds + 2944;               // [2] ctx . dctx
+  float* const s_cd = lds + 2944;               // [2] ctx . dctx, [2] softmax maximum, [2] 1 / softmax denominator
   int* const s_int = reinterpret_cast<int*>(lds + 2960);   // [0..7] step lengths, [16] slot
   float* const vals = lds + DP_MISC;            // resident value rows of this workgroup's quarter
 
@@ -167,7 +180,15 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
   const __amdgpu_buffer_rsrc_t dg_rs = make_rsrc(dgroll), part_rs = make_rsrc(L.part), gates_rs = make_rsrc(L.gates);
   const __amdgpu_buffer_rsrc_t ctx_rs = make_rsrc(L.m[wave < 2 ? (wave < L.n_mech ? wave : 0) : 0].ctx);
   const __amdgpu_buffer_rsrc_t pdq0_rs = make_rsrc(L.m[0].pdq), pdq1_rs = make_rsrc(L.m[L.n_mech > 1 ? 1 : 0].pdq);
+  const __amdgpu_buffer_rsrc_t sc0_rs = make_rsrc(L.m[0].scores), sc1_rs = make_rsrc(L.m[L.n_mech > 1 ? 1 : 0].scores);
+  const __amdgpu_buffer_rsrc_t ps0_rs = make_rsrc(L.m[0].pstat), ps1_rs = make_rsrc(L.m[L.n_mech > 1 ? 1 : 0].pstat);
+  const __amdgpu_buffer_rsrc_t cs_rs = make_rsrc(L.cs), c0_rs = make_rsrc(L.c0), dce_rs = make_rsrc(L.dcell_ext), dae_rs = make_rsrc(L.datt_ext);
 
+  // softmax temperature of scaled Luong (attention.py:43-54): read once, not inside the step loop
+  float gscv[2] = {1.f, 1.f};
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+    if (m < L.n_mech && L.m[m].type == ATT_SCALED_LUONG) gscv[m] = L.m[m].g[0];
   int* const flag_base = L.flags + g * 3 * 32;
   auto wait_all = [&](int phase, int need) {
     if (wave == 0) {
@@ -205,6 +226,18 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
     const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
     const bool eok = tid < DP_R * UW && eb < B && eun < H;
     float zA = 0.f;
+    const int s16 = tid & 15, rg = tid >> 4;
+    const bool c_valid = eok && l < s_int[er & 7];
+    const long c_bt = (long)eb * Ls + l;
+    f32x4 c_g4 = zero4;
+    float c_c = 0.f, c_prev = 0.f, c_dext = 0.f;
+    float raw0[KR0 > 0 ? KR0 : 1], raw1[KR1 > 0 ? KR1 : 1], pm_pf = 0.f, pl_pf = 0.f;
+    f32x4 ctx_pf = zero4;
+    float a_ext = 0.f;                            // external gradient of this thread's attention column: requested before the wait
+    {
+      const int ar = tid >> awsh, ac = tid & (AW - 1), arb = rowbase + ar;
+      a_ext = ldb1(dae_rs, (tid < DP_R * AW && has_att && L.datt_ext && arb < B) ? (int)((((long)arb * Ls + l) * A + an0 + ac) * 4) : P_OOB);
+    }
     // =====================================================================================================
     // A: d attention(l) columns and the recurrent d h(l) of this workgroup from dG(l+1); attention-layer transpose, split-K
     // =====================================================================================================
@@ -232,6 +265,27 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
 #pragma unroll
           for (int r = 0; r < 4; ++r) red[((wave * 2 + nt) * 8 + q * 4 + r) * 16 + i] = acc[nt][r];
       }
+      // forward records phase B consumes (raw scores of this lane's frames, softmax statistics, the context): requested here, so
+      // their latency runs under the rest of this phase and the hand-off
+      {
+        const bool lead = s16 == 0 && att_row;
+        const unsigned so0 = (unsigned)((((long)b_att * Ls + l) * L.m[0].T + t0_m[0]) * 4), so1 = (unsigned)((((long)b_att * Ls + l) * L.m[1].T + t0_m[1]) * 4);
+#pragma unroll
+        for (int u = 0; u < KR0; ++u) raw0[u] = ldb1(sc0_rs, (lead && rg + 32 * u < n_m[0]) ? (int)(so0 + (unsigned)((rg + 32 * u) * 4)) : P_OOB);
+#pragma unroll
+        for (int u = 0; u < KR1; ++u) raw1[u] = ldb1(sc1_rs, (lead && rg + 32 * u < n_m[1]) ? (int)(so1 + (unsigned)((rg + 32 * u) * 4)) : P_OOB);
+        if (wave < 2 && wave < L.n_mech) {
+          const int D = L.m[wave].D;
+          ctx_pf = ldb4(ctx_rs, (att_row && 4 * lane < D) ? (int)((((long)b_att * Ls + l) * D + 4 * lane) * 4) : P_OOB);
+          // softmax statistics of this row and step: lane c takes recorded chunk c (the fused forward records them merged in chunk 0,
+          // the per-step path one partial per chunk)
+          const int nc = L.m[wave].nc_rec;
+          const bool in = lane < nc && att_row;
+          const unsigned o = (unsigned)((((long)(2 * l) * nc + lane) * B + b_att) * 4);
+          pm_pf = ldb1(wave ? ps1_rs : ps0_rs, in ? (int)o : P_OOB);
+          pl_pf = ldb1(wave ? ps1_rs : ps0_rs, in ? (int)(o + (unsigned)((long)nc * B * 4)) : P_OOB);
+        }
+      }
       lds_barrier();
       BTICK(1)
       if (tid < DP_R * AW && has_att) {
@@ -245,7 +299,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
           // the product is the gradient of step l+1's DROPPED attention input (AttentionWrapper feeds [x | attention] through the
           // DropoutWrapper's input mask, cells.py:46-54)
           z *= p_drop(drop, seedv, cid4, (uint32_t)(((long)arb * Ls + l + 1) * (E + A) + E + an0 + ac), L.k_in);
-          a = z + (L.datt_ext ? L.datt_ext[((long)arb * Ls + l) * A + an0 + ac] : 0.f);
+          a = z + a_ext;
         }
         if (arb < B) L.datt[((long)arb * Ls + l) * A + an0 + ac] = a;
         s_datt[ar * 16 + ac] = a;
@@ -284,7 +338,6 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
     wait_all(0, epoch);
     BTICK(4)
     {
-      const int s16 = tid & 15, rg = tid >> 4;
       const bool vrow = att_row && l < s_int[r_att];
       if (wave < 2 && wave < L.n_mech) {
         const DBMech& M = L.m[wave];
@@ -292,7 +345,6 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
         const bool cok = att_row && 4 * c4 < D;
         const int nwm = H >> awsh, w0 = wave * nwm;
         const unsigned base = cok ? (unsigned)((((long)gg * DP_NW + w0) * DP_R + r_att) * DB_PART + H + 4 * c4) * 4u : (unsigned)P_OOB;
-        const f32x4 cv = ldb4(ctx_rs, cok ? (int)((((long)b_att * Ls + l) * D + 4 * c4) * 4) : P_OOB);
         f32x4 acc = zero4;
         for (int w = 0; w < nwm; w += 8) {
           f32x4 x[8];
@@ -303,38 +355,34 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
         }
         st4(s_dctx + wave * 256 + 4 * c4, acc);
         if (cq == 0 && cok) st4(M.dctx + ((long)b_att * Ls + l) * D + 4 * c4, acc);
-        const float cd = wave64_sum(dot4(cv, acc));
-        if (lane == 0) s_cd[wave] = cd;
+        const float cd = wave64_sum(dot4(ctx_pf, acc));
+        const bool in = lane < M.nc_rec && att_row;
+        const float Mx = wave64_max(in ? pm_pf : -INFINITY);
+        const float Lsum = wave64_sum((in && pm_pf != -INFINITY) ? __expf(pm_pf - Mx) * pl_pf : 0.f);
+        if (lane == 0) { s_cd[wave] = cd; s_cd[2 + wave] = Mx; s_cd[4 + wave] = Lsum > 0.f ? 1.f / Lsum : 0.f; }
       }
       lds_barrier();
       BTICK(5)
+      // records of phase C (gates, cell states): requested now, consumed after the next hand-off
+      c_g4 = ldb4(gates_rs, c_valid ? (int)((c_bt * H + eun) * 16) : P_OOB);
+      c_c = ldb1(cs_rs, c_valid ? (int)((c_bt * H + eun) * 4) : P_OOB);
+      c_prev = (l == 0) ? ldb1(c0_rs, (c_valid && L.c0) ? (int)(((long)eb * H + eun) * 4) : P_OOB)
+                        : ldb1(cs_rs, c_valid ? (int)(((c_bt - 1) * H + eun) * 4) : P_OOB);
+      c_dext = ldb1(dce_rs, (c_valid && L.dcell_ext) ? (int)((c_bt * H + eun) * 4) : P_OOB);
+      // d alpha_t = V_t . dctx, d s_t = alpha_t (d alpha_t - ctx . dctx) for the frames of this quarter, both memories
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         if (m >= L.n_mech) continue;
         const DBMech& M = L.m[m];
         const int D = M.D, n = n_m[m];
-        const float gsc = (M.type == ATT_SCALED_LUONG) ? M.g[0] : 1.f;
+        const float gsc = gscv[m];
         // softmax statistics of this row and step from the forward's records (merged over the recorded chunks)
-        float Mx = -INFINITY, Lsum = 0.f;
-        {
-          const float* pm = M.pstat + (long)(2 * l) * M.nc_rec * B;
-          const float* pl = M.pstat + (long)(2 * l + 1) * M.nc_rec * B;
-          if (att_row) {
-            for (int c = 0; c < M.nc_rec; ++c) Mx = fmaxf(Mx, pm[(long)c * B + b_att]);
-            for (int c = 0; c < M.nc_rec; ++c) {
-              const float pmc = pm[(long)c * B + b_att];
-              if (pmc != -INFINITY) Lsum += __expf(pmc - Mx) * pl[(long)c * B + b_att];
-            }
-          }
-        }
-        const float invL = Lsum > 0.f ? 1.f / Lsum : 0.f;
+        const float Mx = s_cd[2 + m], invL = s_cd[4 + m];
         const float cd = s_cd[m];
         f32x4 d4[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) d4[jj] = ld4(s_dctx + m * 256 + 4 * s16 + 64 * jj);
-        const float* raws = M.scores + ((long)b_att * Ls + l) * M.T + t0_m[m];
         float* dsr = M.dscores + ((long)b_att * Ls + l) * M.T + t0_m[m];
-        const int KR = m == 0 ? KR0 : KR1;
 #pragma unroll
         for (int u = 0; u < (m == 0 ? KR0 : KR1); ++u) {
           const int fr = rg + 32 * u;
@@ -347,15 +395,21 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
           }
           a = row16_sum(a);
           if (s16 == 0) {
+            const float raw = m == 0 ? raw0[m == 0 ? u : 0] : raw1[m == 0 ? 0 : u];
             float dsv = 0.f;
-            if (fr < n && vrow) dsv = __expf(raws[fr] * gsc - Mx) * invL * (a - cd);
+            if (fr < n && vrow) dsv = __expf(raw * gsc - Mx) * invL * (a - cd);
             s_ds[m * 128 + fr] = dsv;
             if (att_row && fr < M.ch && t0_m[m] + fr < M.T) dsr[fr] = dsv;
           }
         }
-        (void)KR;
-        lds_barrier();
-        // partial d query over this quarter from the register-resident keys
+      }
+      lds_barrier();
+      BTICK(11)
+      // partial d query over this quarter from the register-resident keys, one memory at a time through the reduction buffer
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (m >= L.n_mech) continue;
+        const DBMech& M = L.m[m];
         f32x4 pa[4] = {zero4, zero4, zero4, zero4};
         if (m == 0) {
 #pragma unroll
@@ -375,25 +429,21 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = pa[jj][e];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            pa[jj][e] = v;
-          }
+          for (int e = 0; e < 4; ++e) pa[jj][e] = xor32_sum(xor16_sum(pa[jj][e]));
+        if (m > 0) lds_barrier();                       // the previous memory's partials have been summed
         if (q == 0) {
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) st4(red + wave * 256 + 4 * s16 + 64 * jj, pa[jj]);
         }
         lds_barrier();
         if (tid < 64) {
-          f32x4 s = ld4(red + 4 * tid);
+          f32x4 sv = ld4(red + 4 * tid);
 #pragma unroll
-          for (int w = 1; w < DP_WV; ++w) s += ld4(red + w * 256 + 4 * tid);
-          if (att_row && 4 * tid < H) st4(M.pdq + (((long)cq * B + b_att) * H + 4 * tid), gsc * s);
+          for (int w = 1; w < DP_WV; ++w) sv += ld4(red + w * 256 + 4 * tid);
+          if (att_row && 4 * tid < H) st4(M.pdq + (((long)cq * B + b_att) * H + 4 * tid), gscv[m] * sv);
         }
-        lds_barrier();
       }
+      lds_barrier();
       BTICK(6)
       publish(1, epoch);
       BTICK(7)
@@ -404,28 +454,29 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
     wait_all(1, epoch);
     BTICK(8)
     {
-      const bool valid = eok && l < s_int[er & 7];
-      const long bt = (long)eb * Ls + l;
-      float pq[DP_NW], pd[8];
+      const bool valid = c_valid;
+      const long bt = c_bt;
+      float pq[DP_NW / 2], pd[8];
       const unsigned po = eok ? (unsigned)((((long)gg * DP_NW) * DP_R + er) * DB_PART + eun) * 4u : (unsigned)P_OOB;
 #pragma unroll
-      for (int w = 0; w < DP_NW; ++w) pq[w] = ld1_sc1(part_rs, (w < L.NWA) ? (int)(po + (unsigned)(w * DP_R * DB_PART * 4)) : P_OOB);
+      for (int w = 0; w < DP_NW / 2; ++w) pq[w] = ld1_sc1(part_rs, (w < L.NWA) ? (int)(po + (unsigned)(w * DP_R * DB_PART * 4)) : P_OOB);
       const unsigned qo = eok ? (unsigned)((long)eb * H + eun) * 4u : (unsigned)P_OOB;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         pd[c] = ld1_sc1(pdq0_rs, (int)(qo + (unsigned)((long)c * BH * 4)));
         pd[4 + c] = ld1_sc1(pdq1_rs, (L.n_mech > 1) ? (int)(qo + (unsigned)((long)c * BH * 4)) : P_OOB);
       }
-      const f32x4 g4 = ldb4(gates_rs, valid ? (int)((bt * H + eun) * 16) : P_OOB);
-      float c = 0.f, cprev = 0.f, dext = 0.f;
-      if (valid) {
-        c = L.cs[bt * H + eun];
-        cprev = (l == 0) ? (L.c0 ? L.c0[(long)eb * H + eun] : 0.f) : L.cs[(bt - 1) * H + eun];
-        if (L.dcell_ext) dext = L.dcell_ext[bt * H + eun];
-      }
+      const float c = c_c, cprev = c_prev, dext = c_dext;
+      const f32x4 g4 = c_g4;
       float dout = 0.f;
 #pragma unroll
-      for (int w = 0; w < DP_NW; ++w) dout += pq[w];
+      for (int w = 0; w < DP_NW / 2; ++w) dout += pq[w];
+      if (L.NWA > DP_NW / 2) {                       // wave-uniform: second half of the attention-layer partials
+#pragma unroll
+        for (int w = 0; w < DP_NW / 2; ++w) pq[w] = ld1_sc1(part_rs, (w + DP_NW / 2 < L.NWA) ? (int)(po + (unsigned)((w + DP_NW / 2) * DP_R * DB_PART * 4)) : P_OOB);
+#pragma unroll
+        for (int w = 0; w < DP_NW / 2; ++w) dout += pq[w];
+      }
       dout += ((pd[0] + pd[1]) + (pd[2] + pd[3])) + ((pd[4] + pd[5]) + (pd[6] + pd[7]));
       dout += dext;
       f32x4 dg = zero4;
@@ -513,7 +564,7 @@ int avsr_dec_persist_bwd(const avsr_attn_rnn* dp, void* stream) {
     X.scores = M.scores; X.ctx = M.ctx; X.pstat = M.pstat; X.dscores = M.dscores; X.dctx = M.dctx;
     X.pdq = ws; ws += 4L * d.B * 256;
     X.T = M.T; X.D = M.D; X.type = M.type; X.nc_rec = F.m[m].nc_rec; X.ch = F.m[m].ch; X.lds_off = F.m[m].lds_off;
-    if ((long)d.B * d.L * M.D * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
+    if ((long)d.B * d.L * M.D * 4 >= (1L << 31) || (long)d.B * d.L * M.T * 4 >= (1L << 31) || X.nc_rec > 64) return AVSR_ERR_UNSUPPORTED;
   }
   hipStream_t s = (hipStream_t)stream;
   int32_t* sync = g_sync;

@@ -154,6 +154,10 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
             print(f"   backward pass (all of it): {e0.elapsed_time(e1):.3f} ms; err={ops.rnn_persistent_error()}")
+            if fused == 1 and os.environ.get("AVSR_HIPCC_FLAGS", "").find("DP_TIMING") >= 0:
+                tk = ops._persist_sync[16:28].cpu().numpy()
+                names = ["wait2", "A loads+mfma", "A epilogue+stage2", "publish0", "wait0", "B dctx", "B dq", "publish1", "wait1", "C cell", "publish2", "B dalpha"]
+                print("   BPTT per-step shader-clock ticks of workgroup 0:", ", ".join(f"{n} {int(v)}" for n, v in zip(names, tk) if n != "-"), "sum", int(tk.sum()))
     return bad
 
 
