@@ -16,6 +16,7 @@
 // The epilogue of the data-path kernel can emit per-channel sum / sum-of-squares partials of what it wrote (batch-norm
 // statistics of the producing convolution: removes two full passes over the map per batch norm).
 #include "common.h"
+#include "persist.h"
 #include "prof.h"
 #include "avsr_hip.h"
 
@@ -65,8 +66,11 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ src, float*
   }
 }
 
-#define CG_MAXTAP 9
-struct CGTap { int da, db, widx; };
+#define CG_MAXTAP 16
+// One (wide) tap of the product's depth: source offset (da, db) from the row's base position; w[sp] = index of the kernel tap this
+// source pixel meets for sub-position sp of the row, or -1 (zero weights).
+struct CGTap { int da, db; short w[4]; };
+static inline CGTap cgtap1(int da, int db, int widx) { CGTap t; t.da = da; t.db = db; t.w[0] = (short)widx; t.w[1] = t.w[2] = t.w[3] = -1; return t; }
 struct CGArgs {
   const float* src; const float* w; const float* bias; float* dst; float* stats;
   const float* res;                      // optional residual input, same shape / indexing as dst (linear destinations only)
@@ -76,6 +80,15 @@ struct CGArgs {
   int N, SH, SW, Cs, CsL;
   int DH, DW, Cd;
   int OA, OB, S, OS, oh0, ow0;
+  // Sub-position columns: a row of the product is a SUPER position (a, b) of nsp destination pixels, its columns are (sp, channel).
+  //   nsp = 1: one pixel per row (SB = S, OSA = OSB = OS).
+  //   nsp = 2 (8-channel stride-1 layers): two horizontally adjacent pixels share one row over the union of their windows (3 x 4
+  //            taps): the 16 columns of a tile are all used (8 channels alone leave half of every MFMA multiplying padding).
+  //   nsp = 4 (stride-2 data gradient): the four parity classes of a 2x2 destination cell in ONE launch: dy staged once, whole
+  //            destination rows written instead of every other pixel per launch.
+  // source base of row (a, b): (a*S, b*SB); destination pixel of (a, b, sp): (a*OSA + oh0 + sp_dh[sp], b*OSB + ow0 + sp_dw[sp]).
+  int nsp, SB, OSA, OSB, lin;
+  signed char sp_dh[4], sp_dw[4];
   int ntap, wmode, F;
   float beta;
   unsigned m_opf, m_ob, m_rq, m_per, m_sw;   // division magics: positions per frame, OB, pieces per source row / per frame (Cs % 4 == 0),
@@ -92,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   const int Cs = A.Cs, CsL = A.CsL, Cd = A.Cd, C4 = CsL >> 2;
   const int PH = A.SH + 2, PW = A.SW + 2, fstride = PH * PW * CsL;
   const int KQ = A.ntap * C4, nch = (KQ + 3) >> 2;
-  const int NT = (Cd + 15) >> 4;                      // 1, 2 or 4 column tiles; a wave keeps ONE
+  const int NC = A.nsp * Cd;                          // columns of the product: (sub-position, channel)
+  const int NT = (NC + 15) >> 4;                      // 1, 2 or 4 column tiles; a wave keeps ONE
   const int nt = wave % NT, mslot = wave / NT, mstep = 4 / NT;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -100,26 +114,33 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   for (int idx = tid; idx < A.F * fstride; idx += 256) lds[idx] = 0.f;
 
   // weight fragments of this wave's column tile + per-chunk LDS offsets of this lane's k-quad
+  const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(A.w);
   f32x4 wreg[MAXCH];
   int koff[MAXCH];
-  const int co = nt * 16 + i;
+  const int cn = nt * 16 + i;                         // column of this lane
+  const bool colok = cn < NC;
+  const int sp = colok ? cn / Cd : 0, co = colok ? cn - sp * Cd : 0;
 #pragma unroll
   for (int c = 0; c < MAXCH; ++c) {
     const int kq = 4 * c + q;
     const bool in = c < nch && kq < KQ;
     const int t = in ? kq / C4 : 0, cs4 = in ? kq - t * C4 : 0;
     koff[c] = in ? (A.tap[t].da * PW + A.tap[t].db) * CsL + cs4 * 4 : 0;
-    f32x4 wv = zero4;
-    if (in && co < Cd) {
+    int widx = -1;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int cs = cs4 * 4 + e;
-        if (cs < Cs) wv[e] = A.wmode ? A.w[((long)A.tap[t].widx * Cd + co) * Cs + cs] : A.w[((long)A.tap[t].widx * Cs + cs) * Cd + co];
-      }
+    for (int k = 0; k < 4; ++k) widx = (k == sp) ? (int)A.tap[t].w[k] : widx;
+    // unconditional buffer loads (out-of-range offset = 0): all fragments of the wave are in flight together.  (Loads inside
+    // the branches that skip the padding were issued one at a time: MAXCH * 4 serial memory round trips before the first pass.)
+    f32x4 wv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int cs = cs4 * 4 + e;
+      const long wo = A.wmode ? ((long)widx * Cd + co) * Cs + cs : ((long)widx * Cs + cs) * Cd + co;
+      wv[e] = ldb1(w_rs, (in && colok && widx >= 0 && cs < Cs) ? (int)(wo * 4) : P_OOB);
     }
     wreg[c] = wv;
   }
-  const float bias_v = (A.bias && co < Cd) ? A.bias[co] : 0.f;
+  const float bias_v = (A.bias && colok) ? A.bias[co] : 0.f;
   float ssum = 0.f, ssq = 0.f;
   // staging role of this thread: piece column st_p4 of rows st_row, st_row + st_rpp, ...  (threads beyond rpp*rq idle)
   const int st_rq = (A.SW * Cs) >> 2;
@@ -130,9 +151,14 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   const bool bn_on = CH4 && A.bn_sc != nullptr;
   if (bn_on && st_row >= 0) { const int cb = (st_p4 * 4) % Cs; bsc = ld4(A.bn_sc + cb); bsh = ld4(A.bn_sh + cb); }
   const bool rbn = A.res_sc != nullptr;
-  const float rsc = (rbn && co < Cd) ? A.res_sc[co] : 1.f, rsh = (rbn && co < Cd) ? A.res_sh[co] : 0.f;
-  const bool lin = A.OS == 1 && A.oh0 == 0 && A.ow0 == 0 && A.DH == A.OA && A.DW == A.OB;   // destination index linear in the position
-  const int opf = A.OA * A.OB;                         // output positions per frame
+  const float rsc = (rbn && colok) ? A.res_sc[co] : 1.f, rsh = (rbn && colok) ? A.res_sh[co] : 0.f;
+  const __amdgpu_buffer_rsrc_t res_rs = make_rsrc(A.res), dst_rs = make_rsrc(A.dst);
+  const bool lin = A.lin != 0;                         // destination index linear in (row, column) of the product
+  const int opf = A.OA * A.OB;                         // rows (super positions) per frame
+  const int pixf = A.DH * A.DW;                        // destination pixels per frame
+  int sdh = 0, sdw = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sdh = (k == sp) ? (int)A.sp_dh[k] : sdh; sdw = (k == sp) ? (int)A.sp_dw[k] : sdw; }
   const int rowf = A.SW * Cs;                          // floats per source row
 
   // ---- software pipeline over passes: the NEXT pass's frames travel memory -> registers while the current pass runs on the matrix
@@ -203,39 +229,66 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
     if (n0 + gridDim.x * A.F < A.N) fetch(n0 + gridDim.x * A.F);      // in flight during the MFMAs below
     // ---- implicit GEMM over the staged frames ----
     const int Mtot = fcur * opf, mtiles = (Mtot + 15) >> 4;
-    float* const dlin = A.dst + ((long)n0 * opf + q * 4) * Cd + co;  // linear destination: position m lives at dlin + m*Cd
+    float* const dlin = A.dst + (long)n0 * pixf * Cd + (long)(q * 4) * NC + cn;  // linear destination: row m lives at dlin + m*NC
     for (int mt = mslot; mt < mtiles; mt += mstep) {
       const int m = mt * 16 + i;
       const int mm = m < Mtot ? m : 0;
       const int f = fdiv(mm, A.m_opf), r = mm - f * opf, a = fdiv(r, A.m_ob), b = r - a * A.OB;
-      const float* base = lds + f * fstride + ((a * A.S + 1) * PW + (b * A.S + 1)) * CsL;
+      const float* base = lds + f * fstride + ((a * A.S + 1) * PW + (b * A.SB + 1)) * CsL;
+      // residual / accumulate operands of a full linear tile: requested before the products (unconditional buffer loads; lanes and
+      // tiles that do not take the fast path below use an out-of-range offset)
+      const int mo0 = mt * 16 + q * 4;
+      const bool fastp = lin && mo0 + 3 < Mtot && colok;
+      const unsigned dbo = (unsigned)(((long)n0 * pixf * Cd + (long)mo0 * NC + cn) * 4);
+      float rv[4], ov[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        rv[rr] = ldb1(res_rs, (fastp && A.res) ? (int)(dbo + (unsigned)(rr * NC * 4)) : P_OOB);
+        ov[rr] = ldb1(dst_rs, (fastp && A.beta != 0.f) ? (int)(dbo + (unsigned)(rr * NC * 4)) : P_OOB);
+      }
+      // K chunks in blocks of CB: the LDS reads of the next block are in flight while the current block is on the matrix pipe.
+      // Chunks beyond the layer's depth read offset 0 against zero weights (no branch around any read).
       f32x4 acc0 = zero4, acc1 = zero4;
+      constexpr int CB = MAXCH < 6 ? MAXCH : 6;
+      f32x4 cur[CB], nxt[CB];
 #pragma unroll
-      for (int c = 0; c < MAXCH; c += 2) {
-        if (c < nch) {
-          const f32x4 av = ld4(base + koff[c]);
+      for (int c = 0; c < CB; ++c) cur[c] = ld4(base + koff[c]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wreg[c][e], acc0, 0, 0, 0);
-        }
-        if (c + 1 < MAXCH && c + 1 < nch) {
-          const f32x4 av = ld4(base + koff[c + 1]);
+      for (int b0 = 0; b0 < MAXCH; b0 += CB) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wreg[c + 1 < MAXCH ? c + 1 : c][e], acc1, 0, 0, 0);
-        }
+        for (int c = 0; c < CB; ++c)
+          if (b0 + CB + c < MAXCH) nxt[c] = ld4(base + koff[b0 + CB + c]);
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+          if (b0 + c < MAXCH) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#ifdef CG_EXP_NOMFMA
+              if ((b0 + c) & 1) acc1[e] += cur[c][e] * wreg[b0 + c][e]; else acc0[e] += cur[c][e] * wreg[b0 + c][e];
+#else
+              if ((b0 + c) & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c][e], wreg[b0 + c][e], acc1, 0, 0, 0);
+              else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c][e], wreg[b0 + c][e], acc0, 0, 0, 0);
+#endif
+            }
+          }
+#pragma unroll
+        for (int c = 0; c < CB; ++c) cur[c] = nxt[c];
       }
       f32x4 acc = acc0 + acc1;
       // C layout: row = q*4 + r, column = i
-      if (co < Cd) {
-        const int mo0 = mt * 16 + q * 4;
-        if (lin && mo0 + 3 < Mtot) {                    // the common case: four in-range rows, destination linear in the position
-          float* dp = dlin + (long)(mt * 16) * Cd;
-          const float* rp = A.res ? A.res + (dp - A.dst) : nullptr;
+      if (colok) {
+        if (fastp) {                                    // the common case: four in-range rows, destination linear in the row
+          float* dp = dlin + (long)(mt * 16) * NC;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             float v = acc[rr] + bias_v;
-            if (rp) { const float rv = rp[rr * Cd]; v += rbn ? fmaxf(fmaf(rv, rsc, rsh), 0.f) : rv; }
-            if (A.beta != 0.f) v += A.beta * dp[rr * Cd];
-            dp[rr * Cd] = v;
+            if (A.res) v += rbn ? fmaxf(fmaf(rv[rr], rsc, rsh), 0.f) : rv[rr];
+            if (A.beta != 0.f) v += A.beta * ov[rr];
+#ifndef CG_EXP_NOSTORE
+            dp[rr * NC] = v;
+#else
+            if (v == 12345.678f) dp[rr * NC] = v;
+#endif
             acc[rr] = v;
           }
           if (A.stats) {
@@ -248,10 +301,12 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
             const int mo = mo0 + rr;
             if (mo < Mtot) {
               float* dp;
-              if (lin) dp = A.dst + ((long)n0 * opf + mo) * Cd + co;
+              if (lin) dp = A.dst + (long)n0 * pixf * Cd + (long)mo * NC + cn;
               else {
                 const int fo = fdiv(mo, A.m_opf), ro = mo - fo * opf, ao = fdiv(ro, A.m_ob), bo = ro - ao * A.OB;
-                dp = A.dst + (((long)(n0 + fo) * A.DH + ao * A.OS + A.oh0) * A.DW + bo * A.OS + A.ow0) * Cd + co;
+                const int ph = ao * A.OSA + A.oh0 + sdh, pw = bo * A.OSB + A.ow0 + sdw;
+                if (ph >= A.DH || pw >= A.DW) continue;         // odd map sizes: the last cell of a row / column is partial
+                dp = A.dst + (((long)(n0 + fo) * A.DH + ph) * A.DW + pw) * Cd + co;
               }
               float v = acc[rr] + bias_v;
               if (A.res) { const float rv = A.res[dp - A.dst]; v += rbn ? fmaxf(fmaf(rv, rsc, rsh), 0.f) : rv; }
@@ -271,12 +326,14 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
     red[((wave * 4 + q) * 16 + i) * 2] = ssum;
     red[((wave * 4 + q) * 16 + i) * 2 + 1] = ssq;
     __syncthreads();
-    if (tid < Cd) {
-      const int tnt = tid >> 4, ti = tid & 15;
+    if (tid < Cd) {                                     // channel tid: its columns (sp, tid) of every sub-position
       float s = 0.f, s2 = 0.f;
-      for (int w = 0; w < 4; ++w)
-        if (w % NT == tnt)
-          for (int qq = 0; qq < 4; ++qq) { s += red[((w * 4 + qq) * 16 + ti) * 2]; s2 += red[((w * 4 + qq) * 16 + ti) * 2 + 1]; }
+      for (int k = 0; k < A.nsp; ++k) {
+        const int n = k * Cd + tid, tnt = n >> 4, ti = n & 15;
+        for (int w = 0; w < 4; ++w)
+          if (w % NT == tnt)
+            for (int qq = 0; qq < 4; ++qq) { s += red[((w * 4 + qq) * 16 + ti) * 2]; s2 += red[((w * 4 + qq) * 16 + ti) * 2 + 1]; }
+      }
       A.stats[(long)blockIdx.x * 2 * Cd + tid] = s;
       A.stats[(long)blockIdx.x * 2 * Cd + Cd + tid] = s2;
     }
@@ -388,6 +445,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
 
   // depth = output positions; a chunk = 16 positions of ONE frame (the last chunk of a frame is partial), lane quad q takes
   // positions 4q .. 4q+3 of the chunk; chunks are dealt to the waves round-robin.
+  const __amdgpu_buffer_rsrc_t dy_rs = make_rsrc(A.dy);
   const int cpf = (opf + 15) >> 4;                       // chunks per frame
   const unsigned m_cpf = fmagic_dev(cpf);
   int n0 = blockIdx.x * A.F;
@@ -397,15 +455,16 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
     __syncthreads();
     commit(n0);
     const int kch = fcur * cpf;
-    const float* dyp = A.dy + (long)n0 * opf * Co;       // [fcur][opf][Co]
+    const unsigned dyo = (unsigned)((long)n0 * opf * Co * 4);     // [fcur][opf][Co]
     float bn[NTC][4];
     auto load_b = [&](int kc, float (&b)[NTC][4]) {
+      // unconditional buffer loads (positions beyond the frame / columns beyond Co: out-of-range offset = 0)
       const int f = fdiv(kc, m_cpf), r0 = (kc - f * cpf) * 16 + q * 4;
-      const float* dp = dyp + ((long)f * opf + r0) * Co + i;
+      const unsigned o = dyo + (unsigned)(((f * opf + r0) * Co + i) * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) b[nt][e] = (r0 + e < opf && nt * 16 + i < Co) ? dp[e * Co + nt * 16] : 0.f;
+        for (int nt = 0; nt < NTC; ++nt) b[nt][e] = ldb1(dy_rs, (r0 + e < opf && nt * 16 + i < Co) ? (int)(o + (unsigned)((e * Co + nt * 16) * 4)) : P_OOB);
     };
     if (wave < kch) load_b(wave, bn);
     __syncthreads();
@@ -427,7 +486,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
         const float* xb = xf + (ho * A.S * PW + wo * A.S) * CiL;
         const bool pin = r0 + e < opf;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt][e] = pin ? xb[roff[mt]] : 0.f;
+        for (int mt = 0; mt < MT; ++mt) { const float xv = xb[roff[mt]]; av[mt][e] = pin ? xv : 0.f; }   // unconditional read, then select
         if (++wo == A.Wo) { wo = 0; ++ho; }
         if (ho >= A.Ho) { ho = A.Ho - 1; }                 // (only reached by out-of-range positions: masked above)
       }
@@ -494,8 +553,12 @@ static int cg_frames(int sh, int sw, int csl, int opf, int extra_floats_per_fram
 }
 
 static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry = false) {
+  if (A.nsp == 0) {                                     // one destination pixel per row of the product
+    A.nsp = 1; A.SB = A.S; A.OSA = A.OS; A.OSB = A.OS;
+    A.lin = (A.OS == 1 && A.oh0 == 0 && A.ow0 == 0 && A.DH == A.OA && A.DW == A.OB) ? 1 : 0;
+  }
   const int KQ = A.ntap * (A.CsL / 4), nch = (KQ + 3) / 4;
-  const int NT = (A.Cd + 15) / 16;
+  const int NT = (A.nsp * A.Cd + 15) / 16;
   if (!(NT == 1 || NT == 2 || NT == 4) || nch > 18) return AVSR_ERR_UNSUPPORTED;
   // a pass (F frames) must fit the 16 prefetch registers of a thread
   if (A.Cs % 4 == 0) {
@@ -511,6 +574,7 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
     A.m_rq = fmagic(A.Cs); A.m_per = fmagic(A.SH * A.SW * A.Cs); A.m_sw = fmagic(A.SW);
   }
   if ((long)A.F * A.OA * A.OB >= 65536) return AVSR_ERR_UNSUPPORTED;
+  if ((long)A.N * A.DH * A.DW * A.Cd * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;   // 32-bit byte offsets of the epilogue's buffer loads
   A.m_opf = fmagic(A.OA * A.OB); A.m_ob = fmagic(A.OB);
   const size_t lds = sizeof(float) * (size_t)A.F * (A.SH + 2) * (A.SW + 2) * A.CsL;
   if (lds > 64 * 1024 || lds < sizeof(float) * 4 * 4 * 16 * 2) return AVSR_ERR_UNSUPPORTED;
@@ -524,7 +588,8 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
   ProfScope ps(kind, s, flops);
   if (A.Cs % 4) {
     hipLaunchKernelGGL((conv_gen_kernel<5, false>), dim3(grid), dim3(256), lds, s, A);
-  } else if (nch <= 5) hipLaunchKernelGGL((conv_gen_kernel<5, true>), dim3(grid), dim3(256), lds, s, A);
+  } else if (nch <= 2) hipLaunchKernelGGL((conv_gen_kernel<2, true>), dim3(grid), dim3(256), lds, s, A);
+  else if (nch <= 5) hipLaunchKernelGGL((conv_gen_kernel<5, true>), dim3(grid), dim3(256), lds, s, A);
   else if (nch <= 9) hipLaunchKernelGGL((conv_gen_kernel<9, true>), dim3(grid), dim3(256), lds, s, A);
   else if (nch <= 18) hipLaunchKernelGGL((conv_gen_kernel<18, true>), dim3(grid), dim3(256), lds, s, A);
   else return AVSR_ERR_UNSUPPORTED;                     // K > 288 (64-channel sources) stays on im2col + GEMM
@@ -545,8 +610,8 @@ int avsr_conv3x3_mfma(const float* x, const float* w, const float* bias, float* 
   A.ntap = 9; A.wmode = flip; A.beta = beta;
   for (int t = 0; t < 9; ++t) {
     const int i = t / 3, j = t % 3;
-    if (!flip) A.tap[t] = CGTap{i - pad_t, j - pad_l, t};
-    else A.tap[t] = CGTap{pad_t - i, pad_l - j, t};      // dx[h, w] += dy[h + pt - i, w + pl - j] . W[i, j]^T
+    if (!flip) A.tap[t] = cgtap1(i - pad_t, j - pad_l, t);
+    else A.tap[t] = cgtap1(pad_t - i, pad_l - j, t);      // dx[h, w] += dy[h + pt - i, w + pl - j] . W[i, j]^T
   }
   A.F = cg_frames(H, W, A.CsL, Ho * Wo);
   const int rc = cg_launch(A, S_(stream), flip ? PROF_CONV_BWD_DATA : PROF_CONV_FWD, 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
@@ -617,7 +682,7 @@ int avsr_conv3x3_bwd_data_s2_mfma(const float* dy, const float* w, float* dx, in
         for (int j = 0; j < 3; ++j) {
           if ((pw + pad_l - j) & 1) continue;
           // dx[2a+ph, 2b+pw] += dy[a + (ph+pt-i)/2, b + (pw+pl-j)/2] . W[i, j]^T   (arithmetic shift: -1/2 -> floor)
-          A.tap[nt++] = CGTap{(ph + pad_t - i) >> 1, (pw + pad_l - j) >> 1, i * 3 + j};
+          A.tap[nt++] = cgtap1((ph + pad_t - i) >> 1, (pw + pad_l - j) >> 1, i * 3 + j);
         }
       }
       A.ntap = nt;
@@ -656,7 +721,7 @@ int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int
     if ((A.F * H * W * Ci / 4 + 255) / 256 > 4 || (long)A.F * H * W * Ci >= 65536) return AVSR_ERR_UNSUPPORTED;
     A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci);
   }
-  if ((long)A.F * ((Ho * Wo + 15) / 16) >= 65536) return AVSR_ERR_UNSUPPORTED;
+  if ((long)A.F * ((Ho * Wo + 15) / 16) >= 65536 || (long)N * Ho * Wo * Co * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
   const size_t red = sizeof(float) * 4 * 256;
   size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * A.CiL;
   if (lds < red) lds = red;
@@ -717,6 +782,30 @@ static int cg_run(CGArgs A, const CGTap* taps, int ntaps, hipStream_t s, int kin
   return AVSR_OK;
 }
 
+// Two horizontally adjacent destination pixels per row of the product (see CGArgs): rewrites the tap list of a stride-1 layer with 8
+// destination channels into the wide taps of the pair.  Returns the number of wide taps, or 0 when the layer does not qualify.
+static int cg_pair_taps(CGArgs& A, const CGTap* taps, int ntaps, CGTap* wide) {
+  if (A.Cd != 8 || A.S != 1 || A.OS != 1 || (A.OB & 1) || A.oh0 || A.ow0 || A.DH != A.OA || A.DW != A.OB) return 0;
+  int nw = 0;
+  for (int t = 0; t < ntaps; ++t)
+    for (int pp = 0; pp < 2; ++pp) {
+      const int da = taps[t].da, db = taps[t].db + pp;   // pixel 2b + pp reads source column 2b + pp + db
+      int k = 0;
+      for (; k < nw; ++k)
+        if (wide[k].da == da && wide[k].db == db) break;
+      if (k == nw) {
+        if (nw == CG_MAXTAP) return 0;
+        wide[nw] = cgtap1(da, db, -1);
+        ++nw;
+      }
+      wide[k].w[pp] = taps[t].w[0];
+    }
+  A.nsp = 2; A.SB = 2; A.OSA = 1; A.OSB = 2; A.lin = 1;
+  A.sp_dh[0] = A.sp_dh[1] = 0; A.sp_dw[0] = 0; A.sp_dw[1] = 1;
+  A.OB /= 2;
+  return nw;
+}
+
 static int conv_fwd_impl(const avsr_conv_desc* c, const float* x, const float* w, const float* bias, const float* res, const float* res_sc,
                          const float* res_sh, float* y, float* stats, int32_t* nparts, void* stream, bool dry) {
   CGArgs A = {};
@@ -727,10 +816,13 @@ static int conv_fwd_impl(const avsr_conv_desc* c, const float* x, const float* w
   A.wmode = 0; A.beta = 0.f;
   CGTap taps[9];
   const int nt = c->k * c->k;
-  for (int t = 0; t < nt; ++t) taps[t] = CGTap{t / c->k - c->pad_t, t % c->k - c->pad_l, t};
+  for (int t = 0; t < nt; ++t) taps[t] = cgtap1(t / c->k - c->pad_t, t % c->k - c->pad_l, t);
   A.F = cg_frames(c->H, c->W, A.CsL, c->Ho * c->Wo);
   int grid = 0;
-  const int rc = cg_run(A, taps, nt, S_(stream), PROF_CONV_FWD, 2.0 * c->N * c->Ho * c->Wo * (double)c->Ci * c->Co, dry, &grid);
+  CGTap wide[CG_MAXTAP];
+  const int nw = cg_pair_taps(A, taps, nt, wide);
+  const int rc = nw ? cg_run(A, wide, nw, S_(stream), PROF_CONV_FWD, 2.0 * c->N * c->Ho * c->Wo * (double)c->Ci * c->Co * nt / nw, dry, &grid)
+                    : cg_run(A, taps, nt, S_(stream), PROF_CONV_FWD, 2.0 * c->N * c->Ho * c->Wo * (double)c->Ci * c->Co, dry, &grid);
   if (rc < 0) return rc;
   if (nparts) *nparts = grid;
   return AVSR_OK;
@@ -746,9 +838,51 @@ static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const fl
     A.DH = c->H; A.DW = c->W; A.Cd = c->Ci; A.OA = c->H; A.OB = c->W; A.S = 1; A.OS = 1;
     A.wmode = 1; A.beta = beta;
     CGTap taps[9];
-    for (int t = 0; t < k * k; ++t) taps[t] = CGTap{c->pad_t - t / k, c->pad_l - t % k, t};   // dx[h, w] += dy[h + pt - i, w + pl - j] . W[i, j]^T
+    for (int t = 0; t < k * k; ++t) taps[t] = cgtap1(c->pad_t - t / k, c->pad_l - t % k, t);   // dx[h, w] += dy[h + pt - i, w + pl - j] . W[i, j]^T
     A.F = cg_frames(c->Ho, c->Wo, A.CsL, c->H * c->W);
+    CGTap wide[CG_MAXTAP];
+    const int nw = cg_pair_taps(A, taps, k * k, wide);
+    if (nw) return cg_run(A, wide, nw, S_(stream), PROF_CONV_BWD_DATA, 2.0 * c->N * c->H * c->W * (double)c->Ci * c->Co * (k * k) / nw, dry, nullptr);
     return cg_run(A, taps, k * k, S_(stream), PROF_CONV_BWD_DATA, 2.0 * c->N * c->H * c->W * (double)c->Ci * c->Co, dry, nullptr);
+  }
+  if (k == 3 && c->Ci * 4 <= 64) {
+    // all four parity classes of a 2x2 destination cell in one launch: columns (class, channel), rows = cells
+    CGArgs A = {};
+    A.src = dy; A.w = w; A.dst = dx;
+    A.N = c->N; A.SH = c->Ho; A.SW = c->Wo; A.Cs = c->Co; A.CsL = c->Co;
+    A.DH = c->H; A.DW = c->W; A.Cd = c->Ci; A.OA = (c->H + 1) / 2; A.OB = (c->W + 1) / 2; A.S = 1; A.OS = 2;
+    A.wmode = 1; A.beta = beta;
+    A.nsp = 4; A.SB = 1; A.OSA = 2; A.OSB = 2; A.lin = 0;
+    CGTap wide[CG_MAXTAP];
+    int nw = 0, ntot = 0;
+    bool fits = true;
+    for (int ph = 0; ph < 2 && fits; ++ph)
+      for (int pw = 0; pw < 2 && fits; ++pw) {
+        const int sp = ph * 2 + pw;
+        A.sp_dh[sp] = (signed char)ph; A.sp_dw[sp] = (signed char)pw;
+        for (int i = 0; i < 3; ++i) {
+          if ((ph + c->pad_t - i) & 1) continue;
+          for (int j = 0; j < 3; ++j) {
+            if ((pw + c->pad_l - j) & 1) continue;
+            const int da = (ph + c->pad_t - i) >> 1, db = (pw + c->pad_l - j) >> 1;      // arithmetic shift: -1/2 -> floor
+            int kk = 0;
+            for (; kk < nw; ++kk)
+              if (wide[kk].da == da && wide[kk].db == db) break;
+            if (kk == nw) {
+              if (nw == CG_MAXTAP) { fits = false; break; }
+              wide[nw] = cgtap1(da, db, -1);
+              ++nw;
+            }
+            wide[kk].w[sp] = (short)(i * 3 + j);
+            ++ntot;
+          }
+        }
+      }
+    if (fits && nw > 0) {
+      A.F = cg_frames(c->Ho, c->Wo, A.CsL, A.OA * A.OB);
+      const int rc = cg_run(A, wide, nw, S_(stream), PROF_CONV_BWD_DATA, 2.0 * c->N * A.OA * A.OB * (double)c->Ci * c->Co * ntot / nw, dry, nullptr);
+      if (rc != AVSR_ERR_UNSUPPORTED) return rc;
+    }
   }
   // stride 2: one launch per parity class (ph, pw) of the input pixels; a class no tap reaches receives no gradient from this
   // convolution (beta == 0 is then refused: the caller orders its contributions so that this one accumulates)
@@ -765,7 +899,7 @@ static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const fl
         if ((ph + c->pad_t - i) & 1) continue;
         for (int j = 0; j < k; ++j) {
           if ((pw + c->pad_l - j) & 1) continue;
-          taps[nt++] = CGTap{(ph + c->pad_t - i) >> 1, (pw + c->pad_l - j) >> 1, i * k + j};   // arithmetic shift: -1/2 -> floor
+          taps[nt++] = cgtap1((ph + c->pad_t - i) >> 1, (pw + c->pad_l - j) >> 1, i * k + j);   // arithmetic shift: -1/2 -> floor
         }
       }
       if (A.OA <= 0 || A.OB <= 0) continue;
@@ -806,7 +940,7 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
     if ((A.F * H * W * Ci / 4 + 255) / 256 > 4 || (long)A.F * H * W * Ci >= 65536) return AVSR_ERR_UNSUPPORTED;
     A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci);
   }
-  if ((long)A.F * ((Ho * Wo + 15) / 16) >= 65536) return AVSR_ERR_UNSUPPORTED;
+  if ((long)A.F * ((Ho * Wo + 15) / 16) >= 65536 || (long)N * Ho * Wo * Co * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
   const size_t red = sizeof(float) * 4 * 256;
   size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * A.CiL;
   if (lds < red) lds = red;

@@ -310,16 +310,17 @@ def main():
         out["kernel_time_events"] = kinds
         dom = max(kinds, key=lambda k: kinds[k]["total_ms"])
         HBM_PEAK, MFMA_PEAK = 8000.0, 157.3
-        # HBM traffic per launch from the committed PMC passes (profiles/r01_c4_pmc_v4.json: FETCH_SIZE / WRITE_SIZE collected in
+        # HBM traffic per launch from the committed PMC passes (profiles/r02_c4_lipcnn_pmc_v2.json: FETCH_SIZE / WRITE_SIZE collected in
         # separate rocprofv3 runs of this same workload, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); null
         # for workloads / kernels that were not profiled.
         pmc = {}
         try:
-            if args.workload == "c4":
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c4_pmc_v4.json")))["kernels"]
+            if args.workload == "c4" and args.video_frontend == "resnet_cnn":
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_c4_lipcnn_pmc_v2.json")))["kernels"]
         except Exception:
             pmc = {}
         pmc_name = {"attn_fwd": "avsr::attn_fwd_kernel", "attn_bwd": "avsr::attn_bwd_kernel",
+                    "dec_persist_fwd": "avsr::dec_persist_kernel<1, 4, 2>", "dec_persist_bwd": "avsr::dec_persist_bwd_kernel<1, 4>",
                     "step_lstm_fwd": "avsr::step_kernel<1, 1, 1, 4>", "step_lstm_bwd": "avsr::step_kernel<2, 1, 1, 8>",
                     "step_dense": "avsr::step_kernel<0, 1, 1, 4>",
                     "rnn_persist_fwd": "avsr::rnn_persist_fwd_xcd_kernel", "rnn_persist_bwd": "avsr::rnn_persist_bwd_kernel"}
@@ -330,7 +331,7 @@ def main():
 
         def roof(kind):
             us = kinds[kind]["avg_us"]
-            if kind == "dec_persist_fwd":
+            if kind in ("dec_persist_fwd", "dec_persist_bwd"):
                 # fused persistent decode kernel: ONE launch = all T_dec steps of the (dual-)attention decoder forward; a step's
                 # algorithmic bytes are the keys + values of every memory (what the per-step attention kernel streamed from HBM);
                 # here they are resident in VGPRs / LDS, so `achieved` exceeds what HBM streaming could deliver -- it is the
@@ -342,7 +343,10 @@ def main():
                 return {"kernel": kind, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK, 4), "traffic": traffic(kind), "algorithmic_bytes_per_decode_step": wm["attn_bytes"],
                         "decode_steps_per_launch": LDEC, "us_per_decode_step": round(per_step_us, 3), "avg_launch_us": us,
-                        "note": "whole decode step (cell + scores/softmax/context + attention layer + output layer + sample) fused; keys/values resident on chip"}
+                        "note": "whole decode step (cell + scores/softmax/context + attention layer + output layer + sample) fused; keys/values resident on chip"
+                        if kind == "dec_persist_fwd" else
+                        "whole BPTT step (attention-layer transpose + attention backward + cell backward) fused; the per-step attention backward "
+                        "streamed the same keys + values from HBM every step"}
             if kind in ("attn_fwd", "attn_bwd"):
                 ach = wm["attn_bytes"] / (us * 1e-6) / 1e9
                 return {"kernel": kind, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s",

@@ -134,7 +134,11 @@ def test_batchnorm_forward_backward(rows, F, relu):
 @pytest.mark.parametrize("N,H,Ci,Co,k,s,bn,res", [
     (3, 12, 3, 8, 3, 1, False, False), (5, 12, 8, 8, 3, 1, True, True), (4, 12, 8, 16, 3, 2, True, False), (4, 12, 8, 16, 1, 2, False, False),
     (7, 9, 16, 32, 1, 2, False, False), (6, 9, 32, 64, 3, 2, True, False), (6, 9, 32, 64, 1, 2, False, False), (9, 5, 64, 64, 3, 1, True, True),
-    (2, 36, 8, 8, 3, 1, True, True), (3, 18, 16, 16, 3, 1, True, False), (21, 5, 64, 64, 3, 1, False, False)])
+    (2, 36, 8, 8, 3, 1, True, True), (3, 18, 16, 16, 3, 1, True, False), (21, 5, 64, 64, 3, 1, False, False),
+    # pixel-pair rows (8 destination channels, even width) next to the odd width that cannot pair; stride-2 data gradients with all four
+    # parity classes in one launch on even and odd maps (partial 2x2 cells), 8 and 16 channels
+    (3, 7, 8, 8, 3, 1, False, False), (3, 10, 8, 8, 3, 1, False, True), (5, 9, 16, 32, 3, 2, False, False), (4, 11, 8, 16, 3, 2, False, False),
+    (3, 18, 16, 32, 3, 2, False, False), (70, 6, 8, 16, 3, 2, False, False)])
 def test_conv_desc_forward_and_gradients(N, H, Ci, Co, k, s, bn, res):
     from avsr_tf1_amd import ops
     rng = np.random.default_rng(H * 100 + Ci * 10 + Co + s + k)

@@ -1,5 +1,7 @@
-"""Per-layer timing of the lip-CNN convolutions at the benchmark size (N = 64*75 = 4800 frames): forward, data gradient, weight
-gradient through the C ABI (the frame-resident MFMA kernels of csrc/conv_mfma.hip unless AVSR_CONV_MFMA=0)."""
+"""Per-layer timing of the lip-CNN convolutions at the benchmark size (N = 64*75 = 4800 frames) through the descriptor API of
+csrc/conv_mfma.hip: forward (with the fused BN-ReLU loader / residual / statistics where the network uses them), data gradient,
+weight gradient (+ bias gradient).  Prints the time next to the time the layer's compulsory HBM bytes take at 8 TB/s and the
+time its padded MFMA work takes at 157.3 TF."""
 import os
 import sys
 
@@ -7,10 +9,13 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from avsr_tf1_amd import ops, _lib   # noqa: E402
+from avsr_tf1_amd import ops   # noqa: E402
 
-LAYERS = [("layer0 3->8 36x36", 36, 3, 8, 1), ("res0 8->8 36x36", 36, 8, 8, 1), ("b1c1 8->16 s2", 36, 8, 16, 2), ("b1c2 16->16 18x18", 18, 16, 16, 1),
-          ("b2c1 16->32 s2", 18, 16, 32, 2), ("b2c2 32->32 9x9", 9, 32, 32, 1)]
+#          name                 H   Ci  Co  k  s  bn     res
+LAYERS = [("layer0 3->8", 36, 3, 8, 3, 1, False, False), ("rb0 c1 8->8", 36, 8, 8, 3, 1, True, False), ("rb0 c2 8->8 +res", 36, 8, 8, 3, 1, True, True),
+          ("rb1 sc 1x1/2 8->16", 36, 8, 16, 1, 2, False, False), ("rb1 c1 /2 8->16", 36, 8, 16, 3, 2, True, False), ("rb1 c2 16->16 +res", 18, 16, 16, 3, 1, True, True),
+          ("rb2 sc 1x1/2 16->32", 18, 16, 32, 1, 2, False, False), ("rb2 c1 /2 16->32", 18, 16, 32, 3, 2, True, False), ("rb2 c2 32->32 +res", 9, 32, 32, 3, 1, True, True),
+          ("rb3 sc 1x1/2 32->64", 9, 32, 64, 1, 2, False, False), ("rb3 c1 /2 32->64", 9, 32, 64, 3, 2, True, False), ("rb3 c2 64->64 +res", 5, 64, 64, 3, 1, True, True)]
 
 
 def same(n, k, s):
@@ -34,31 +39,33 @@ def timeit(fn, reps=10):
 
 def main():
     N = int(os.environ.get("N", 4800))
-    if os.environ.get("AVSR_CONV_MFMA") == "0":
-        _lib.load().avsr_conv_set_mfma(0)
     scratch = torch.empty(1 << 24, device="cuda")
     tot = [0.0, 0.0, 0.0]
-    for name, H, Ci, Co, s in LAYERS:
-        Ho, pt = same(H, 3, s)
+    r16 = lambda v: -(-v // 16) * 16
+    for name, H, Ci, Co, k, s, bn, res in LAYERS:
+        Ho, pt = same(H, k, s)
         x = torch.randn(N, H, H, Ci, device="cuda")
-        w = torch.randn(3, 3, Ci, Co, device="cuda") * 0.1
+        w = torch.randn(k, k, Ci, Co, device="cuda") * 0.1
         b = torch.randn(Co, device="cuda")
         y = torch.zeros(N, Ho, Ho, Co, device="cuda")
+        r = torch.randn(N, Ho, Ho, Co, device="cuda") if res else None
         dy = torch.randn(N, Ho, Ho, Co, device="cuda")
         dx = torch.zeros(N, H, H, Ci, device="cuda")
-        dw = torch.zeros(3, 3, Ci, Co, device="cuda")
-        fl = 2.0 * N * Ho * Ho * 9 * Ci * Co
-        t_f = timeit(lambda: ops.conv3x3(x, w, b, y, N, H, H, Ci, Co, s, pt, pt, Ho, Ho))
-        t_w = timeit(lambda: ops.conv3x3_bwd_weight(x, dy, dw, N, H, H, Ci, Co, s, pt, pt, Ho, Ho, scratch))
-        if Ci % 4 == 0:
-            if s == 1:
-                t_d = timeit(lambda: ops.conv3x3(dy, w, None, dx, N, Ho, Ho, Co, Ci, 1, 1, 1, H, H, flip=1))
-            else:
-                t_d = timeit(lambda: ops.conv3x3_bwd_data_s2(dy, w, dx, N, H, H, Ci, Co, pt, pt, Ho, Ho))
-        else:
-            t_d = 0.0
+        dw, db = torch.zeros(k, k, Ci, Co, device="cuda"), torch.zeros(Co, device="cuda")
+        stats = torch.zeros(512 * 2 * Co, device="cuda")
+        bnv = (torch.rand(Ci, device="cuda") + 0.5, torch.randn(Ci, device="cuda")) if bn else None
+        d = ops.conv_desc(N, H, H, Ci, Co, k, s, pt if k == 3 else 0, pt if k == 3 else 0, Ho, Ho, bn=bnv)
+        assert ops.conv_supported(d), name
+        t_f = timeit(lambda: ops.conv_fwd(d, x, w, b, y, r, None, stats))
+        t_w = timeit(lambda: ops.conv_bwd_weight(d, x, dy, dw, db, scratch))
+        t_d = timeit(lambda: ops.conv_bwd_data(d, dy, w, dx, beta=1.0 if (k == 1 and s == 2) else 0.0)) if Ci % 4 == 0 else 0.0
+        xb, yb = 4.0 * N * H * H * Ci, 4.0 * N * Ho * Ho * Co
+        hbm_f = (xb + yb * (2 if res else 1)) / 8e6                 # us at 8 TB/s
+        hbm_d = (xb * (2 if (k == 1 and s == 2) else 1) + yb) / 8e6
+        hbm_w = (xb + yb) / 8e6
+        mfma = 2.0 * N * Ho * Ho * r16(k * k * ((Ci + 3) // 4 * 4)) * r16(Co) / 157.3e6
         tot[0] += t_f; tot[1] += t_d; tot[2] += t_w
-        print(f"{name:22s} fwd {t_f:7.1f} us ({fl / t_f / 1e6:6.1f} TF)  bwd-data {t_d:7.1f} us  bwd-weight {t_w:7.1f} us ({fl / t_w / 1e6:6.1f} TF)")
+        print(f"{name:22s} fwd {t_f:6.1f} us (hbm {hbm_f:5.1f}, mfma {mfma:5.1f})  bwd-data {t_d:6.1f} us (hbm {hbm_d:5.1f})  bwd-weight {t_w:6.1f} us (hbm {hbm_w:5.1f})")
     print(f"totals: fwd {tot[0]:.0f} us, bwd-data {tot[1]:.0f} us, bwd-weight {tot[2]:.0f} us")
 
 
