@@ -230,11 +230,23 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
     // ---- implicit GEMM over the staged frames ----
     const int Mtot = fcur * opf, mtiles = (Mtot + 15) >> 4;
     float* const dlin = A.dst + (long)n0 * pixf * Cd + (long)(q * 4) * NC + cn;  // linear destination: row m lives at dlin + m*NC
-    for (int mt = mslot; mt < mtiles; mt += mstep) {
+    // LDS address of product row m (clamped to row 0 beyond the pass: those rows are never written out)
+    auto row_base = [&](int mt) -> const float* {
       const int m = mt * 16 + i;
       const int mm = m < Mtot ? m : 0;
       const int f = fdiv(mm, A.m_opf), r = mm - f * opf, a = fdiv(r, A.m_ob), b = r - a * A.OB;
-      const float* base = lds + f * fstride + ((a * A.S + 1) * PW + (b * A.SB + 1)) * CsL;
+      return lds + f * fstride + ((a * A.S + 1) * PW + (b * A.SB + 1)) * CsL;
+    };
+    constexpr int CB = MAXCH <= 6 ? MAXCH : 3;          // K chunks per block of LDS reads (9 and 18 are multiples of 3)
+    constexpr bool XT = MAXCH <= 6;                     // whole tile in one block: the NEXT tile's reads run under this tile's MFMAs
+    f32x4 cur[CB], nxt[CB];
+    if (XT && mslot < mtiles) {
+      const float* base0 = row_base(mslot);
+#pragma unroll
+      for (int c = 0; c < CB; ++c) cur[c] = ld4(base0 + koff[c]);
+    }
+    for (int mt = mslot; mt < mtiles; mt += mstep) {
+      const float* base = XT ? row_base(mt + mstep < mtiles ? mt + mstep : mt) : row_base(mt);
       // residual / accumulate operands of a full linear tile: requested before the products (unconditional buffer loads; lanes and
       // tiles that do not take the fast path below use an out-of-range offset)
       const int mo0 = mt * 16 + q * 4;
@@ -246,31 +258,35 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
         rv[rr] = ldb1(res_rs, (fastp && A.res) ? (int)(dbo + (unsigned)(rr * NC * 4)) : P_OOB);
         ov[rr] = ldb1(dst_rs, (fastp && A.beta != 0.f) ? (int)(dbo + (unsigned)(rr * NC * 4)) : P_OOB);
       }
-      // K chunks in blocks of CB: the LDS reads of the next block are in flight while the current block is on the matrix pipe.
-      // Chunks beyond the layer's depth read offset 0 against zero weights (no branch around any read).
+      // Chunks beyond the layer's depth read offset 0 against zero weights (no branch around any read).  The reads of the next
+      // block (the next tile when the tile is one block) are issued BEFORE this block's MFMAs and kept there by the scheduling
+      // barrier: left to itself the compiler sank each read to just ahead of its first use, one exposed LDS round trip per chunk.
       f32x4 acc0 = zero4, acc1 = zero4;
-      constexpr int CB = MAXCH < 6 ? MAXCH : 6;
-      f32x4 cur[CB], nxt[CB];
+      if (!XT) {
 #pragma unroll
-      for (int c = 0; c < CB; ++c) cur[c] = ld4(base + koff[c]);
+        for (int c = 0; c < CB; ++c) cur[c] = ld4(base + koff[c]);
+      }
 #pragma unroll
       for (int b0 = 0; b0 < MAXCH; b0 += CB) {
+        if (XT) {
 #pragma unroll
-        for (int c = 0; c < CB; ++c)
-          if (b0 + CB + c < MAXCH) nxt[c] = ld4(base + koff[b0 + CB + c]);
+          for (int c = 0; c < CB; ++c) nxt[c] = ld4(base + koff[c]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < CB; ++c)
+            if (b0 + CB + c < MAXCH) nxt[c] = ld4(base + koff[b0 + CB + c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < CB; ++c)
           if (b0 + c < MAXCH) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-#ifdef CG_EXP_NOMFMA
-              if ((b0 + c) & 1) acc1[e] += cur[c][e] * wreg[b0 + c][e]; else acc0[e] += cur[c][e] * wreg[b0 + c][e];
-#else
               if ((b0 + c) & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c][e], wreg[b0 + c][e], acc1, 0, 0, 0);
               else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c][e], wreg[b0 + c][e], acc0, 0, 0, 0);
-#endif
             }
           }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < CB; ++c) cur[c] = nxt[c];
       }
@@ -284,11 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
             float v = acc[rr] + bias_v;
             if (A.res) v += rbn ? fmaxf(fmaf(rv[rr], rsc, rsh), 0.f) : rv[rr];
             if (A.beta != 0.f) v += A.beta * ov[rr];
-#ifndef CG_EXP_NOSTORE
             dp[rr * NC] = v;
-#else
-            if (v == 12345.678f) dp[rr * NC] = v;
-#endif
             acc[rr] = v;
           }
           if (A.stats) {
@@ -580,7 +592,7 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
   if (lds > 64 * 1024 || lds < sizeof(float) * 4 * 4 * 16 * 2) return AVSR_ERR_UNSUPPORTED;
   int grid = (A.N + A.F - 1) / A.F;
   int wpc = (int)((150 * 1024) / (lds + 512));          // workgroups per CU that fit
-  if (wpc > 2) wpc = 2;
+  if (wpc > 2) wpc = 2;                                 // (three per CU measured slower, one per CU 25 % slower)
   if (wpc < 1) wpc = 1;
   if (grid > 256 * wpc) grid = 256 * wpc;
   if (A.Cs % 4 && nch > 5) return AVSR_ERR_UNSUPPORTED;
@@ -589,7 +601,7 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
   if (A.Cs % 4) {
     hipLaunchKernelGGL((conv_gen_kernel<5, false>), dim3(grid), dim3(256), lds, s, A);
   } else if (nch <= 2) hipLaunchKernelGGL((conv_gen_kernel<2, true>), dim3(grid), dim3(256), lds, s, A);
-  else if (nch <= 5) hipLaunchKernelGGL((conv_gen_kernel<5, true>), dim3(grid), dim3(256), lds, s, A);
+  else if (nch <= 6) hipLaunchKernelGGL((conv_gen_kernel<6, true>), dim3(grid), dim3(256), lds, s, A);
   else if (nch <= 9) hipLaunchKernelGGL((conv_gen_kernel<9, true>), dim3(grid), dim3(256), lds, s, A);
   else if (nch <= 18) hipLaunchKernelGGL((conv_gen_kernel<18, true>), dim3(grid), dim3(256), lds, s, A);
   else return AVSR_ERR_UNSUPPORTED;                     // K > 288 (64-channel sources) stays on im2col + GEMM
