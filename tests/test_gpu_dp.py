@@ -56,7 +56,7 @@ def _worker(rank, world, port, out_dir, use_graph):
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_two_ranks_equal_one_engine_on_the_whole_batch(tmp_path, use_graph):
+def test_two_ranks_equal_one_engine_on_the_whole_batch(tmp_path, use_graph, monkeypatch):
     import torch.multiprocessing as mp
     from avsr_tf1_amd.model import Batch, Seq2SeqModel
     with socket.socket() as s:
@@ -67,7 +67,7 @@ def test_two_ranks_equal_one_engine_on_the_whole_batch(tmp_path, use_graph):
     # with collectives the trainer launches eagerly whatever use_graph says (graphs replayed around collectives
     # went wrong at the benchmark size); AVSR_DP_GRAPH=1 would force them
     assert bool(r0["sync_bn"]) and str(r0["mode"]).startswith("eager")
-    os.environ["AVSR_PERSISTENT_RNN"] = "0"
+    monkeypatch.setenv("AVSR_PERSISTENT_RNN", "0")      # same launch path as the two workers (restored after the test)
     O, mcfg, W, full = _setup()
     model = Seq2SeqModel(mcfg, weights=W)
     batch = Batch.from_numpy(full)

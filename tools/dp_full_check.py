@@ -5,7 +5,7 @@ import os, sys, socket
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 import torch.multiprocessing as mp
-STEPS = 12
+STEPS = int(os.environ.get("DP_CHECK_STEPS", "12"))
 
 def setup():
     import bench
