@@ -1230,8 +1230,9 @@ class Seq2SeqModel:
         ops.seq_loss_per_utterance(D["row_loss"], batch.labels_len, self.denom, D["utt_loss"], ws["B"], ws["L"])
         return D["utt_loss"]
 
-    def backward(self):
-        """BPTT through decoder and encoders; leaves the full gradient in self.grads (engine layout)."""
+    def backward_decoder(self):
+        """First half of the backward pass: zeroes the gradient buffer, output layer, decoder BPTT and every decoder-side weight gradient
+        (also the gradients flowing into the encoder memories / final states, which backward_encoders() continues from)."""
         cfg = self.cfg
         ws, batch = self._cur
         B, L = ws["B"], ws["L"]
@@ -1263,7 +1264,29 @@ class Seq2SeqModel:
             ops.dropout_rows(dm, dm, B * L, E, self.seed, CELL_ID_DECODER * 4, cfg.decoder_dropout[0], E + A)
         ops.embed_grad(D["dxemb"], D["fed"], self._gp("dec/embedding"), B, L, E, V, self.scratch)
         self._decoder_init_state_bwd(ws)
+
+    def backward_encoders(self):
+        """Second half of the backward pass: encoder BPTT, the lip CNN, every encoder-side weight gradient."""
+        ws, batch = self._cur
         self._encode_backward(ws, batch)
+
+    def backward(self):
+        """BPTT through decoder and encoders; leaves the full gradient in self.grads (engine layout)."""
+        self.backward_decoder()
+        self.backward_encoders()
+
+    def decoder_grad_bucket(self):
+        """(lo, hi) of the flat gradient buffer holding exactly the decoder's parameters (`dec/...`: embedding, cell, attention
+        mechanisms, output layer, state bridge) -- final once backward_decoder() has run, so a data-parallel trainer can reduce it while
+        backward_encoders() is still computing.  None when the layout does not keep them in one block."""
+        segs = [(g.off, g.off + g.n, n) for n, g in self.Gr.items()]
+        dec = [(lo, hi) for lo, hi, n in segs if n.startswith("dec/")]
+        if not dec:
+            return None
+        lo, hi = min(x[0] for x in dec), max(x[1] for x in dec)
+        if any(lo <= a < hi and not n.startswith("dec/") for a, b, n in segs):
+            return None
+        return lo, hi
 
     def apply_update(self):
         """L2 on the RNN kernels, global-norm clip, Adam, LR warm-up (seq2seq.py:175-178, :195-199, :245-257)."""

@@ -45,12 +45,23 @@ class DataParallelTrainer:
         import os
         self.drain_around_collectives = os.environ.get("AVSR_DP_DRAIN", "1") != "0"
         self.drain_after_collectives = os.environ.get("AVSR_DP_DRAIN", "1") == "2"
-        if self.collective and self.use_graph and os.environ.get("AVSR_DP_GRAPH") != "1":
-            # Measured with two real engine ranks at the benchmark size (tools/graph_queue_probe.py, tools/dp_full_check.py): replaying the captured
-            # graphs around collectives gave inf / NaN gradients within 24 steps however the stream was drained, while eager
-            # launches are exact (and cost 1-2 % on this GPU-bound step).  Collective mode therefore launches eagerly.
+        if self.collective and self.use_graph and os.environ.get("AVSR_DP_GRAPH") == "0":
+            # Escape hatch.  Round 1 replayed graphs that still held memset / memcpy nodes around the collectives and got inf / NaN
+            # gradients.  With every device fill / copy a kernel, two engine ranks replaying their graphs
+            # around the collectives are bit-identical to the same two ranks launching eagerly over 12, 50 and 200 steps at the
+            # benchmark size (tools/dp_full_check.py, AVSR_DP_GRAPH=1 vs unset), so graphs are the default at every world size;
+            # the stream is still drained around each collective (AVSR_DP_DRAIN).
             self.use_graph = False
-            self.mode = "eager (captured graphs are not replayed around collectives)"
+            self.mode = "eager (AVSR_DP_GRAPH=0)"
+        # Gradient all-reduce in two buckets (AVSR_DP_OVERLAP=1): the decoder's block of the flat buffer is final after the first half
+        # of the backward pass, so its all-reduce runs on a side stream under the encoder BPTT / lip-CNN backward; the rest follows
+        # at the end.  Opt-in: the side-stream collective then shares the GPU with the persistent encoder kernels, which cannot be
+        # exercised on this one-GPU box; the two-rank tests run it over gloo.
+        self._bucket = None
+        if self.collective and os.environ.get("AVSR_DP_OVERLAP") == "1" and hasattr(model, "decoder_grad_bucket"):
+            self._bucket = model.decoder_grad_bucket()
+        self._side = torch.cuda.Stream() if (self._bucket and torch.cuda.is_available()) else None
+        self._pending = None
         self._static = {}
         if self.world > 1 and hasattr(model, "seed_offset"):
             model.seed_offset = dist.get_rank() << 24      # decorrelate the ranks' dropout / sampling masks
@@ -121,6 +132,45 @@ class DataParallelTrainer:
         self.model.forward_train(batch, compute_denom=not self.collective)
         self.model.backward()
 
+    # collective mode with the overlapped bucket: the backward pass in two halves with the first all-reduce started in between
+    def _phase1(self, batch):
+        self.model.forward_train(batch, compute_denom=False)
+        self.model.backward_decoder()
+
+    def _phase2(self):
+        self.model.backward_encoders()
+
+    def _start_bucket(self):
+        lo, hi = self._bucket
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            self._pending = self.dist.all_reduce(self.model.grads[lo:hi], async_op=True)
+
+    def _reduce_grads(self):
+        """Sum the flat gradient buffer over the ranks: everything, or what the bucket started earlier does not cover."""
+        m = self.model
+        if self._bucket is None:
+            self.dist.all_reduce(m.grads)
+            return
+        lo, hi = self._bucket
+        if lo > 0:
+            self.dist.all_reduce(m.grads[:lo])
+        if hi < m.grads.numel():
+            self.dist.all_reduce(m.grads[hi:])
+        if self._pending is not None:
+            self._pending.wait()                       # the current stream waits for the side-stream collective
+            self._pending = None
+
+    def _fwd_bwd_collective(self, batch):
+        if self._bucket is None:
+            self._fwd_bwd(batch)
+            return
+        self._phase1(batch)
+        self._start_bucket()
+        self._phase2()
+
     def _persistent_failed(self):
         chk = getattr(self.model, "check_persistent", None)
         return bool(chk and chk())
@@ -155,13 +205,19 @@ class DataParallelTrainer:
                 dist.all_reduce(m.bn_sync_sums(batch))
                 dist.all_reduce(m.bn_sync_squares(batch))
         if not self.use_graph:
-            self._fwd_bwd(batch)
+            if self.collective:
+                self._fwd_bwd_collective(batch)
+            else:
+                self._fwd_bwd(batch)
             if not self._checked or self.check_every_step:   # make sure the persistent kernels were co-resident
                 self._checked = True
                 if self._persistent_failed():
-                    self._fwd_bwd(batch)
+                    if self._pending is not None:          # the bucket reduced an invalid pass: finish it, then redo everything
+                        self._pending.wait()
+                        self._pending = None
+                    self._fwd_bwd_collective(batch) if self.collective else self._fwd_bwd(batch)
             if self.collective:
-                dist.all_reduce(m.grads)
+                self._reduce_grads()
                 self._reduce_loss()
             m.apply_update()
             return m.loss, m.gnorm
@@ -180,7 +236,10 @@ class DataParallelTrainer:
             m.apply_update()
             torch.cuda.synchronize()
             try:
-                ga = self._capture(lambda: self._fwd_bwd(st))
+                if self._bucket is not None:           # two graphs: the bucket's all-reduce starts between them
+                    ga = (self._capture(lambda: self._phase1(st)), self._capture(self._phase2))
+                else:
+                    ga = self._capture(lambda: self._fwd_bwd(st))
                 gb = self._capture(m.apply_update)
                 # the graphs hold raw pointers into this shape's workspace: pin it against the model's LRU eviction
                 pin = getattr(m, "pin_workspace", None)
@@ -194,18 +253,28 @@ class DataParallelTrainer:
             return m.loss, m.gnorm
         ga, gb, _ = gr
         self._graphs.move_to_end(key)
-        ga.replay()
+        if isinstance(ga, tuple):
+            ga[0].replay()
+            if self.drain_around_collectives:
+                self._drain()
+            self._start_bucket()
+            ga[1].replay()
+        else:
+            ga.replay()
         if self.check_every_step and self._persistent_failed():
             # a persistent kernel's bounded wait expired inside the replay: the activations are invalid.  check_persistent() has
             # switched the one-launch paths off; drop the captured graphs (they contain those launches) and redo the step eagerly.
             self._drop_graphs()
             self.use_graph = False
             self.mode = "eager (persistent kernel flagged a pass)"
-            self._fwd_bwd(st)
+            if self._pending is not None:
+                self._pending.wait()
+                self._pending = None
+            self._fwd_bwd_collective(st) if self.collective else self._fwd_bwd(st)
         if self.collective:
-            if self.drain_around_collectives:          # the 13 MB gradient all-reduce is a large eager kernel between two graph launches
+            if self.drain_around_collectives:          # the gradient all-reduce is a large eager kernel between two graph launches
                 self._drain()
-            dist.all_reduce(m.grads)
+            self._reduce_grads()
             self._reduce_loss()
             if self.drain_after_collectives:
                 torch.cuda.synchronize()

@@ -290,6 +290,35 @@ def main():
         "final_loss": round(loss, 5),
     }
 
+    if world > 1 and not args.strong:
+        # the same job with the GLOBAL batch fixed at the workload's B (strong scaling): B / N utterances per GPU.  The headline above is
+        # weak scaling (B per GPU); both figures are labelled, neither is an efficiency.
+        Bs = max(1, wl["B"] // world)
+        try:
+            m_s = Seq2SeqModel(cfg, seed=2001)
+            t_s = DataParallelTrainer(m_s, dist, use_graph=not args.no_graph, check_every_step=False)
+            b_s = t_s.static_batch(Batch.from_numpy(NS(synth(cfg, Bs, rank))))
+            for _ in range(max(2, args.warmup) if not args.no_graph else max(1, args.warmup)):
+                t_s.train_step(b_s)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                t_s.train_step(b_s)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t.item())
+            out["strong_scaling"] = {"value": round(Bs * world * args.steps / dts, 2), "unit": "utterances/sec", "scaling": "strong",
+                                     "global_batch": Bs * world, "utterances_per_gpu": Bs, "ms_per_step": round(1e3 * dts / args.steps, 4),
+                                     "launch": t_s.mode, "persistent_wait_expired": bool(ops.rnn_persistent_error())}
+            del t_s, m_s
+        except Exception as e:      # an auxiliary figure must not take the headline line down
+            out["strong_scaling"] = {"value": None, "error": repr(e)}
+
     if rank == 0 and not args.no_profile:
         # per-kernel timing: one eager step with a HIP-event pair around every engine launch
         # The host enqueues slower than these kernels run, so a busy-wait kernel first holds the stream for ~0.4 s:

@@ -30,7 +30,10 @@ def test_bench_json_contract_and_forced_collectives():
         assert k in plain, k
     assert plain["n_gpus"] == 1 and plain["steps"] == 20 and plain["value"] > 0 and plain["config"]["launch"] == "hipgraph"
     forced = _bench({"AVSR_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
-    assert forced["config"]["launch"].startswith("eager")          # collective mode launches eagerly
+    assert forced["config"]["launch"] == "hipgraph"                # graphs are replayed around the collectives
+    eager = _bench({"AVSR_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29534", "AVSR_DP_GRAPH": "0"})
+    assert eager["config"]["launch"].startswith("eager")           # the escape hatch
+    assert abs(eager["final_loss"] - plain["final_loss"]) < 1e-4 * max(1.0, abs(plain["final_loss"]))
     assert abs(forced["final_loss"] - plain["final_loss"]) < 1e-4 * max(1.0, abs(plain["final_loss"]))
 
 

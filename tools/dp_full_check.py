@@ -1,5 +1,5 @@
 """Two REAL engine ranks (both processes on the one GPU of the box, gloo transport, unequal shards, ragged lengths) at the
-benchmark size against ONE engine on the whole batch.  python tools/dp_full_check.py   [AVSR_DP_GRAPH=1 replays the captured graphs
+benchmark size against ONE engine on the whole batch.  python tools/dp_full_check.py   [default: the captured graphs are replayed around the collectives; AVSR_DP_GRAPH=0 launches eagerly -- the graph
 around the collectives: that is the configuration that went wrong, DESIGN.md section 5]"""
 import os, sys, socket
 sys.path.insert(0, os.getcwd())
