@@ -290,10 +290,11 @@ def main():
         "final_loss": round(loss, 5),
     }
 
-    if world > 1 and not args.strong:
+    force_strong = force_dist and os.environ.get("AVSR_BENCH_FORCE_STRONG") == "1"      # test hook: this section with one rank
+    if (world > 1 or force_strong) and not args.strong and dist is not None:
         # the same job with the GLOBAL batch fixed at the workload's B (strong scaling): B / N utterances per GPU.  The headline above is
         # weak scaling (B per GPU); both figures are labelled, neither is an efficiency.
-        Bs = max(1, wl["B"] // world)
+        Bs = max(1, wl["B"] // (world if world > 1 else 8))
         try:
             m_s = Seq2SeqModel(cfg, seed=2001)
             t_s = DataParallelTrainer(m_s, dist, use_graph=not args.no_graph, check_every_step=False)

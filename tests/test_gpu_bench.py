@@ -31,6 +31,10 @@ def test_bench_json_contract_and_forced_collectives():
     assert plain["n_gpus"] == 1 and plain["steps"] == 20 and plain["value"] > 0 and plain["config"]["launch"] == "hipgraph"
     forced = _bench({"AVSR_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
     assert forced["config"]["launch"] == "hipgraph"                # graphs are replayed around the collectives
+    # the strong-scaling section `--gpus N > 1` adds (global batch fixed: here 64 / 8 utterances on the one rank)
+    strong = _bench({"AVSR_BENCH_FORCE_DIST": "1", "AVSR_BENCH_FORCE_STRONG": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29535"})
+    assert strong["strong_scaling"]["value"] > 0 and strong["strong_scaling"]["utterances_per_gpu"] == 8 and strong["scaling"] == "weak"
+    assert not strong["strong_scaling"]["persistent_wait_expired"]
     eager = _bench({"AVSR_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29534", "AVSR_DP_GRAPH": "0"})
     assert eager["config"]["launch"].startswith("eager")           # the escape hatch
     assert abs(eager["final_loss"] - plain["final_loss"]) < 1e-4 * max(1.0, abs(plain["final_loss"]))
