@@ -7,13 +7,16 @@ __version__ = "0.1.0"
 
 
 def __getattr__(name):
-    """Lazy exports of the reference's public surface (avsr/__init__.py:1-3): AVSR, run_experiment, LM."""
+    """Lazy exports of the reference's public surface (avsr/__init__.py:1-3): AVSR, run_experiment (+ run_experiment_mixedsnrs), LM."""
     if name == "AVSR":
         from .avsr import AVSR
         return AVSR
     if name == "run_experiment":
         from .experiment import run_experiment
         return run_experiment
+    if name == "run_experiment_mixedsnrs":
+        from .experiment import run_experiment_mixedsnrs
+        return run_experiment_mixedsnrs
     if name == "LM":
         from .lm import LM
         return LM

@@ -7,10 +7,10 @@ try_restore_latest_checkpoint)` / `evaluate(checkpoint_path, epoch)` behaviour a
 `predictions/<name>/predicted_epoch_<N>.mlf`.  TensorFlow graphs/sessions/summaries do not exist here.
 
 `video_processing='resnet_cnn'` runs the lip crops through the HIP lip-CNN front-end (cnn.py; avsr/video.py:143-195).
-Built besides the defaults: `input_dense_layers`, `instance_normalisation`, `residual_encoder`, `encoder_weight_sharing`, multi-layer
+Built besides the defaults: `input_dense_layers`, `instance_normalisation`, `residual_encoder`, `highway_encoder`, `encoder_weight_sharing`, multi-layer
 decoders (equal widths, LSTM), `enable_attention=False`, `loss_fun` / `label_smoothing`, `lr_decay=('cosine_restarts', N)`, the Nadam /
 AdamW / Momentum optimisers, `write_attention_alignment` (greedy decoding).
-Not built (raise explicitly): `highway_encoder`, `precision='float16'`, the `2dconv_cnn` / `3dconv_cnn` front-ends, `'wav'` audio
+Not built (raise explicitly): `precision='float16'`, the `2dconv_cnn` / `3dconv_cnn` front-ends, `'wav'` audio
 (non-functional in the reference too), the monotonic attention variants and the non-default cell types.
 """
 import glob
@@ -21,6 +21,7 @@ from os import makedirs, path
 import numpy as np
 import torch
 
+from . import ops
 from .config import ModelConfig
 from .io_utils import (_get_input_shape_from_record, create_unit_dict, make_iterator_from_one_record,
                        make_iterator_from_two_records)
@@ -97,6 +98,7 @@ class AVSR(object):
         for name, val, ok in (("precision", precision, 'float32'),):
             if val != ok:
                 raise NotImplementedError("%s=%r is a non-default option of the reference that the HIP engine does not build" % (name, val))
+        self._profiling = bool(profiling)
         lr_decay_steps = 0
         if lr_decay is not None:                                                                  # seq2seq.py:263-273
             if lr_decay[0] == 'cosine_restarts':
@@ -260,7 +262,11 @@ class AVSR(object):
             start = time.time()
             for bd in self._iterator('train'):                # end of data = StopIteration (reference: OutOfRangeError)
                 batch, _names = self._to_batch(bd)
+                if self._profiling:
+                    ops.prof_begin(1 << 16)
                 loss, gnorm = self._trainer.train_step(batch)
+                if self._profiling:
+                    self._write_timeline(ops.prof_end(), epoch, batches)
                 batch_loss, global_norm = float(loss.item()), float(gnorm.item())
                 sum_loss += batch_loss
                 if lead:
@@ -282,6 +288,18 @@ class AVSR(object):
                 f.write('\n')
                 f.flush()
         f.close()
+
+    @staticmethod
+    def _write_timeline(prof, epoch, batch):
+        """`profiling=True` (avsr/avsr.py:542-550, :274-290 drive tf.profiler with FULL_TRACE and write timelines to /tmp/timelines/):
+        here every engine launch of the step is bracketed by a HIP event pair (avsr_prof_begin / avsr_prof_end) and the per-kernel-
+        class launch counts, summed milliseconds and algorithmic FLOPs of the step go to /tmp/timelines/timeline_<epoch>_<batch>.json.
+        For a kernel-by-kernel trace run the same script under `rocprofv3 --kernel-trace --stats`."""
+        import json
+        makedirs('/tmp/timelines/', exist_ok=True)
+        rows = {k: {"launches": c, "ms": round(ms, 4), "algorithmic_gflop": round(fl / 1e9, 3)} for k, (c, ms, fl) in prof.items() if c}
+        with open('/tmp/timelines/timeline_{}_{}.json'.format(epoch, batch), 'w') as f:
+            json.dump({"epoch": epoch, "batch": batch, "kernel_classes": rows, "total_ms": round(sum(r["ms"] for r in rows.values()), 4)}, f, indent=1)
 
     def _write_alignments(self, names, alignments_outdir):
         """`<file>.png` (unimodal / av_align decoder), `<file>_video.png` + `<file>_audio.png` (bimodal), `<file>_av.png`

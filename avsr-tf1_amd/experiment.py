@@ -1,6 +1,8 @@
 """`run_experiment` -- the curriculum driver of avsr/experiment.py:5-136: per noise level, train `iterations[i][0]`
 epochs at `learning_rates[i][0]`, then `iterations[i][1]` at `learning_rates[i][1]`, each phase a fresh `AVSR`
-object resuming from the checkpoint directory; optional warm-up on short sentences."""
+object resuming from the checkpoint directory; optional warm-up on short sentences.
+`run_experiment_mixedsnrs` (avsr/experiment.py:140-211): the same two-phase schedule over ONE pair of audio records that already mixes
+the noise levels; the video front-end follows the architecture (`None` for 'unimodal', 'resnet_cnn' otherwise)."""
 from os import path
 
 from .avsr import AVSR
@@ -35,3 +37,17 @@ def run_experiment(video_train_record=None, video_test_record=None, labels_train
     for lr, iters, audio_train, audio_test in zip(learning_rates, iterations, audio_train_records, audio_test_records):
         _phase(full_logfile, lr[0], iters[0] + 1, 5, audio_train_record=audio_train, audio_test_record=audio_test, **common)
         _phase(full_logfile, lr[1], iters[1] + 1, 20, audio_train_record=audio_train, audio_test_record=audio_test, **common)
+
+
+def run_experiment_mixedsnrs(video_train_record=None, video_test_record=None, labels_train_record=None, labels_test_record=None,
+                             audio_train_record=None, audio_test_record=None, unit='character',
+                             unit_list_file='./avsr/misc/character_list', iterations=None, learning_rates=None,
+                             architecture='unimodal', logfile='tmp_experiment', **kwargs):
+    full_logfile = path.join('./logs', logfile)
+    common = dict(unit=unit, unit_file=unit_list_file, audio_processing='features', audio_train_record=audio_train_record,
+                  audio_test_record=audio_test_record, video_processing=None if architecture == 'unimodal' else 'resnet_cnn',
+                  video_train_record=video_train_record, video_test_record=video_test_record, labels_train_record=labels_train_record,
+                  labels_test_record=labels_test_record, architecture=architecture, **kwargs)
+    for lr, iters in zip(learning_rates, iterations):
+        _phase(full_logfile, lr[0], iters[0] + 1, 5, **common)
+        _phase(full_logfile, lr[1], iters[1] + 1, 20, **common)

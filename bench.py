@@ -7,8 +7,9 @@ The headline feeds north_star's synthetic input: T_v = 75 x 36 x 36 x 3 lip crop
 every workload with a video stream; the same step on pre-computed 128-d lip features is reported next to it as `without_lip_cnn`.
 
 N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL): utterances are
-sharded across ranks (weak scaling: B utterances PER GPU), the only collective on the data path is the
-gradient all-reduce (+ a scalar all-reduce of the loss normaliser).
+sharded across ranks (weak scaling: B utterances PER GPU; a `strong_scaling` object reports the same job at the workload's
+global B), the collectives on the data path are the gradient all-reduce, a 4-float all-reduce of the loss normalisers and the
+two sync-batch-norm reductions of the feature inputs.
 
 Prints ONE JSON line (rank 0).  `value` = utterances processed by all ranks / max-over-ranks wall time,
 inputs resident in HBM.  `roofline` = the dominant kernel of the step (by summed time, measured here with
@@ -39,7 +40,7 @@ WORKLOADS = {
     "c2": dict(desc="audio-only LAS 3x bi-LSTM-256 + LSTM-256 Bahdanau decoder, B=64 T_a=500x80 L=40",
                B=64, cfg=dict(architecture="unimodal", encoder_type="bidirectional", video_units=None, audio_units=(256, 256, 256),
                               attention_type=(("bahdanau",), ("bahdanau",)))),
-    # configs[2]: visual-only 2 x bi-LSTM-256 (lip CNN bypassed: video_processing='features')
+    # configs[2]: visual-only 2 x bi-LSTM-256 (lip crops through the CNN front-end by default; --video-frontend features bypasses it)
     "c3": dict(desc="visual-only lip-CNN -> 2x bi-LSTM-256, B=64 T_v=75 L=40",
                B=64, cfg=dict(architecture="unimodal", encoder_type="bidirectional", video_units=(256, 256), audio_units=None,
                               attention_type=(("scaled_luong",), ("scaled_luong",)), regress_aus=True)),

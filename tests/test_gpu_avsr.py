@@ -69,6 +69,39 @@ def test_run_experiment_bimodal(tmp_path, monkeypatch):
     assert log.count("Average batch_loss") == 3 and "=====" in log
 
 
+def test_run_experiment_mixedsnrs_audio_only(tmp_path, monkeypatch):
+    """avsr/experiment.py:140-211: one audio record pair, two (learning rate, epochs) phases per entry, '=====' / 20 x '=' separators."""
+    import avsr_tf1_amd as avsr
+    monkeypatch.chdir(tmp_path)
+    unit_file, p = _dataset(str(tmp_path))
+    os.makedirs("logs", exist_ok=True)
+    avsr.run_experiment_mixedsnrs(labels_train_record=p["labels"], labels_test_record=p["labels"], audio_train_record=p["audio"],
+                                  audio_test_record=p["audio"], unit="character", unit_list_file=unit_file, iterations=((1, 1), (0, 1)),
+                                  learning_rates=((0.01, 0.001), (0.001, 0.0005)), architecture="unimodal", logfile="exp_mixed",
+                                  batch_size=(4, 4), encoder_units_per_layer=((32,), (32, 32)), decoder_units_per_layer=(32,), embedding_size=16)
+    log = open("logs/exp_mixed").read()
+    assert log.count("=" * 20) == 2 and log.count("Average batch_loss") >= 2
+
+
+def test_avsr_profiling_writes_per_step_timelines(tmp_path, monkeypatch):
+    """AVSR(profiling=True) (avsr/avsr.py:542-550): one timeline file per train step under /tmp/timelines/."""
+    import glob
+    import json
+    import avsr_tf1_amd as avsr
+    monkeypatch.chdir(tmp_path)
+    unit_file, p = _dataset(str(tmp_path))
+    for f in glob.glob("/tmp/timelines/timeline_*.json"):
+        os.remove(f)
+    exp = avsr.AVSR(unit="character", unit_file=unit_file, audio_processing="features", audio_train_record=p["audio"], audio_test_record=p["audio"],
+                    labels_train_record=p["labels"], labels_test_record=p["labels"], batch_size=(4, 4), encoder_units_per_layer=((32,), (32, 32)),
+                    decoder_units_per_layer=(32,), embedding_size=16, profiling=True)
+    exp.train(logfile="logs/prof", num_epochs=2)
+    files = sorted(glob.glob("/tmp/timelines/timeline_1_*.json"))
+    assert len(files) == 3                                          # 12 utterances / batch 4
+    t = json.load(open(files[0]))
+    assert t["kernel_classes"]["gemm"]["launches"] > 0 and t["total_ms"] > 0
+
+
 def test_avsr_visual_only_from_lip_crops(tmp_path, monkeypatch):
     """run_video.py-style experiment from raw frames: video_processing='resnet_cnn' (avsr/video.py:143-195)."""
     import avsr_tf1_amd as avsr
