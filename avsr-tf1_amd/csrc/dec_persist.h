@@ -13,7 +13,8 @@
 #define DP_WV 8
 #define DP_CPW 7          // 16-wide K chunks per wave, cell product   (E + A + H <= 896)
 #define DP_APW 4          // 16-wide K chunks per wave, attention layer (H + D <= 512)
-#define DP_MISC 4032      // floats of LDS ahead of the resident value rows
+#define DP_MISC 4032      // floats of LDS ahead of the resident value rows (8-row groups)
+#define DP_MISC16 6272    // same for 16-row groups (the reduction buffer doubles)
 #define DP_LDS_BYTES 163840
 
 namespace avsr {
@@ -34,6 +35,7 @@ struct DPLaunch {
   int go_id, eos_id, A, KW;
   int UW, AW, NWA, drop;
   int uwsh, awsh;
+  int R;                                        // rows per group (8, or 16 for the attentive layer when its memories fit)
   int* err; int* claim; int* flags;
   const float* wt; const float* bias;
   float* gates; float* cs; float* cell_out; float* att; float* attd; float* hs_seq; float* state;

@@ -41,30 +41,39 @@ namespace avsr {
 // kernel 56, attention layers 16).  Everything else a thread needs per step is RE-DERIVED from an opaque copy of its thread id
 // inside the step loop -- otherwise the compiler hoists ~100 loop-invariant indices / 64-bit addresses out of the loop and
 // spills them, and every reload sits on the critical path behind a full vmcnt wait.  Chunk tables are wave-uniform (SGPRs).
-template <int KR0, int KR1, int MODE>
+// R: rows (utterances) per group.  8 everywhere except the AV-Align attentive layer (MODE 0) when its memories fit: there a group
+// is a FULL 16-row MFMA tile (no padding rows) and two workgroups instead of four share a row's memories -- half as many groups,
+// so a 128-utterance batch is one pass over the chip instead of two sequential 64-row slices.
+template <int KR0, int KR1, int MODE, int R>
 __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
+  static_assert(R == 8 || (R == 16 && MODE == 0), "16-row groups: attentive layer only");
+  constexpr int WPR = DP_NW / R;                // workgroups per row in the attention phase (4 quarters / 2 halves)
+  constexpr int RQ = R / 4;                     // lane groups q < RQ hold real rows of a C tile (row = 4q + r)
+  constexpr int RED_F = 256 * R;                // floats of the reduction buffer [8 waves][2 tiles][R][16]
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const red = lds;                       // [8][2][8][16] cell / [2][2][256] context partials / [8][8][16] attention layer / [8][32] exp
-  float* const s_p = lds + 2048;                // [2][128] scaled scores of this quarter (P2) ...
-  float* const s_logit = lds + 2048;            // ... [8][32] logits of the group's rows (P4)
-  float* const s_x = lds + 2304;                // [8][128] input rows of the next step
-  float* const s_att = lds + 3328;              // [8][16]  this workgroup's attention columns
-  int* const s_int = reinterpret_cast<int*>(lds + 3488);   // [0..7] tokens, [8..15] step lengths, [16] slot, [17] unfinished, [24..27] zero pad
-  float* const s_wo = lds + 3520;               // [16][32] this workgroup's rows of the output kernel
-  constexpr int ZPAD = 3512;                    // 4 zero floats: where operand slots of another source "read" LDS
-  float* const vals = lds + DP_MISC;            // resident value rows of this workgroup's quarter
+  float* const red = lds;                       // [8][2][R][16] cell / [2][2][256] context partials / [8][R][16] attention layer / [8][32] exp
+  float* const s_p = lds + RED_F;               // [2][128] scaled scores of this quarter (P2) ...
+  float* const s_logit = lds + RED_F;           // ... [8][32] logits of the group's rows (P4)
+  float* const s_x = lds + RED_F + 256;         // [8][128] input rows of the next step (MODE >= 1: R = 8)
+  float* const s_att = lds + RED_F + 1280;      // [R][16]  this workgroup's attention columns
+  int* const s_int = reinterpret_cast<int*>(lds + RED_F + 1280 + 16 * R + 32);   // [0..R) tokens, [R..2R) step lengths, [2R] slot, [2R+1] unfinished, [2R+8..+12) zero pad
+  constexpr int ZPAD = RED_F + 1280 + 16 * R + 32 + 2 * R + 8;                     // 4 zero floats: where operand slots of another source "read" LDS
+  float* const s_wo = lds + RED_F + 1280 + 16 * R + 32 + 2 * R + 16;             // [16][32] this workgroup's rows of the output kernel
+  float* const vals = lds + (R == 8 ? DP_MISC : DP_MISC16);                        // resident value rows of this workgroup's share
+  static_assert(2048 + 1280 + 128 + 32 + 16 + 16 + 512 == DP_MISC, "8-row layout");
+  static_assert(4096 + 1280 + 256 + 32 + 32 + 16 + 512 <= DP_MISC16, "16-row layout");
 
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int g = __builtin_amdgcn_readfirstlane(xcc_id());
-  if (tid0 == 0) s_int[16] = __hip_atomic_fetch_add(L.claim + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid0 == 0) s_int[2 * R] = __hip_atomic_fetch_add(L.claim + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  const int j = __builtin_amdgcn_readfirstlane(s_int[16]);
+  const int j = __builtin_amdgcn_readfirstlane(s_int[2 * R]);
   if (g >= L.ngroups || j >= DP_NW) return;
 
   const int B = L.B, Ls = L.L, H = L.H, E = L.E, A = L.A, KW = L.KW, V = L.V;
   constexpr int mode = MODE;
-  const int rowbase = L.b0 + g * DP_R;
+  const int rowbase = L.b0 + g * R;
   const bool drop = L.drop != 0;
   const uint32_t seedv = L.seed ? (uint32_t)L.seed[0] : 0u;
   const uint32_t cid4 = L.cid4;
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   f32x4 wc[DP_CPW][2], wa[DP_APW];
   f32x4 k0[KR0 > 0 ? KR0 : 1][4], k1[KR1 > 0 ? KR1 : 1][4];
   int n_m[2] = {0, 0}, t0_m[2] = {0, 0};
-  const int r_att = j >> 2, cq = j & 3;
+  const int r_att = j / WPR, cq = j % WPR;
   const int b_att = rowbase + r_att;
   const bool att_row = b_att < B;
   float c_state = 0.f, h_state = 0.f;
@@ -176,21 +185,21 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
     }
     // (5) recurrent state of (row er, unit eu), tokens / step lengths of the group's rows, first input rows
     const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
-    if (tid < DP_R * UW && eb < B && eun < H) {
+    if (tid < R * UW && eb < B && eun < H) {
       c_state = cbuf[(long)(L.l_begin & 1) * BH + (long)eb * H + eun];
       h_state = hbuf[(long)(L.l_begin & 1) * BH + (long)eb * H + eun];
     }
-    if (tid < DP_R) {
+    if (tid < R) {
       const int b = rowbase + tid;
       s_int[tid] = (b < B && mode == 1) ? L.tok[b] : 0;
-      s_int[8 + tid] = (b < B) ? L.steplen[b] : 0;
+      s_int[R + tid] = (b < B) ? L.steplen[b] : 0;
     }
-    if (tid == 0) s_int[17] = 0;
+    if (tid == 0) s_int[2 * R + 1] = 0;
     if (tid < 4) lds[ZPAD + tid] = 0.f;
     __syncthreads();
     if (mode >= 1) {
       const int e4n = E >> 2;
-      for (int idx = tid; idx < DP_R * e4n; idx += DP_NT) {
+      for (int idx = tid; idx < R * e4n; idx += DP_NT) {
         const int r = idx / e4n, e4 = idx - r * e4n, b = rowbase + r;
         f32x4 v = zero4;
         if (b < B) v = (mode == 2) ? ld4(L.xs + ((long)b * Ls + L.l_begin) * E + 4 * e4) : ld4(L.embedding + (long)s_int[r] * E + 4 * e4);
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   f32x4 hv[2];
   {
     const int lane = tid0 & 63, i = lane & 15, q = lane >> 4, ab = rowbase + i;
-    const unsigned h_o = (i < DP_R && ab < B) ? (unsigned)((long)(L.l_begin & 1) * BH + (long)ab * H) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
+    const unsigned h_o = (i < R && ab < B) ? (unsigned)((long)(L.l_begin & 1) * BH + (long)ab * H) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) hv[cc] = ldb_sc1(h_rs, (int)(h_o + uk1[5 + cc]));
   }
@@ -247,20 +256,20 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
     asm volatile("" : "+v"(tid));                 // opaque: per-thread indices below are recomputed, not kept across steps
     const int lane = tid & 63, i = lane & 15, q = lane >> 4;
     const int ab = rowbase + i;
-    const bool aok = i < DP_R && ab < B;          // MFMA A-operand row of this lane (rows 8..15 of the tile are padding)
+    const bool aok = i < R && ab < B;             // MFMA A-operand row of this lane (R = 8: rows 8..15 of the tile are padding)
     DTICK(11)
     // =====================================================================================================
     // P1: LSTM cell (cells.py:14-18 LSTMCell clip 1.0, forget bias 1.0; DropoutWrapper cells.py:46-54)
     // =====================================================================================================
     {
       const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
-      const bool eok = tid < DP_R * UW && eb < B && eun < H;
-      const int e_steplen = s_int[8 + (er & 7)];
+      const bool eok = tid < R * UW && eb < B && eun < H;
+      const int e_steplen = s_int[R + (er & (R - 1))];
       const bool valid = eok && l < e_steplen;
       const long bt = (long)eb * Ls + l;
       // padding rows of the tile / rows beyond the batch: out-of-range offset, the load returns 0 without touching memory
       const unsigned att_o = aok ? (unsigned)(((long)ab * (Ls + 1) + l) * A) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
-      const int x_o = (i & 7) * 128 + 4 * q;
+      const int x_o = (i & 7) * 128 + 4 * q;        // (MODE >= 1 only: R = 8)
       f32x4 av[4];
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) av[cc] = ldb_sc1(att_rs, (int)(att_o + uk1[1 + cc]));
@@ -292,11 +301,11 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
             accb[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc + 1][e], wc[2 + cc][nt][e], accb[nt], 0, 0, 0);
           }
       acc[0] += accb[0]; acc[1] += accb[1];
-      if (q < 2) {
+      if (q < RQ) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) red[((wave * 2 + nt) * 8 + q * 4 + r) * 16 + i] = acc[nt][r];
+          for (int r = 0; r < 4; ++r) red[((wave * 2 + nt) * R + q * 4 + r) * 16 + i] = acc[nt][r];
       }
       lds_barrier();
       DTICK(0)
@@ -308,8 +317,9 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
 #pragma unroll
           for (int gi = 0; gi < 4; ++gi) {
             const int cc = eu * 4 + gi;
-            const int o = ((cc >> 4) * 8 + er) * 16 + (cc & 15);
-            z[gi] += ((red[o] + red[256 + o]) + (red[512 + o] + red[768 + o])) + ((red[1024 + o] + red[1280 + o]) + (red[1536 + o] + red[1792 + o]));
+            const int o = ((cc >> 4) * R + er) * 16 + (cc & 15);
+            constexpr int WS = 32 * R;               // floats per wave
+            z[gi] += ((red[o] + red[WS + o]) + (red[2 * WS + o] + red[3 * WS + o])) + ((red[4 * WS + o] + red[5 * WS + o]) + (red[6 * WS + o] + red[7 * WS + o]));
           }
           f32x4 g4;
           g4[0] = p_sigmoid(z[0]); g4[1] = p_tanh(z[1]); g4[2] = p_sigmoid(z[2] + 1.0f); g4[3] = p_sigmoid(z[3]);
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
           float pmv[4], plv[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const int o = aok ? (c * B + ab) * 4 : P_OOB;
+            const int o = (aok && c < WPR) ? (c * B + ab) * 4 : P_OOB;
             pmv[c] = ld1_sc1(pm_rs, o);
             plv[c] = ld1_sc1(pl_rs, o);
           }
@@ -469,11 +479,11 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
             for (int cc = 0; cc < 2; ++cc) {
               aq[cc] = ldb_sc1(co_rs, (int)(qo_ + uk3[cc]));
 #pragma unroll
-              for (int c = 0; c < 4; ++c) sv[cc][c] = ldb_sc1(pc_rs, (int)(pc0_ + c * pcs_ + uk3[2 + cc]));
+              for (int c = 0; c < 4; ++c) sv[cc][c] = ldb_sc1(pc_rs, (c < WPR) ? (int)(pc0_ + c * pcs_ + uk3[2 + cc]) : P_OOB);
             }
           }
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { wgt[c] = aok ? pmv[c] : -INFINITY; Mx = fmaxf(Mx, wgt[c]); }
+          for (int c = 0; c < 4; ++c) { wgt[c] = (aok && c < WPR) ? pmv[c] : -INFINITY; Mx = fmaxf(Mx, wgt[c]); }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
             const float e = (wgt[c] == -INFINITY) ? 0.f : __expf(wgt[c] - Mx);
@@ -511,21 +521,22 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
           acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(c4[1][e], wa[3][e], acc2, 0, 0, 0);
         }
         acc += acc2;
-        if (q < 2) {
+        if (q < RQ) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) red[(wave * 8 + q * 4 + r) * 16 + i] = acc[r];
+          for (int r = 0; r < 4; ++r) red[(wave * R + q * 4 + r) * 16 + i] = acc[r];
         }
       }
       lds_barrier();
       DTICK(16)
       const int pr = (tid >> 5) & 7, pv = tid & 31;
-      if (tid < DP_R * AW && has_att) {
+      if (tid < R * AW && has_att) {
         const int ar = tid >> awsh, ac = tid & (AW - 1), arb = rowbase + ar;
         float a = 0.f;
         if (arb < B) {
           const int o = ar * 16 + ac;
-          a = ((red[o] + red[128 + o]) + (red[256 + o] + red[384 + o])) + ((red[512 + o] + red[640 + o]) + (red[768 + o] + red[896 + o]));
-          if (!(l < s_int[8 + ar])) a = 0.f;
+          constexpr int WS = 16 * R;                 // floats per wave
+          a = ((red[o] + red[WS + o]) + (red[2 * WS + o] + red[3 * WS + o])) + ((red[4 * WS + o] + red[5 * WS + o]) + (red[6 * WS + o] + red[7 * WS + o]));
+          if (!(l < s_int[R + ar])) a = 0.f;
           const long ao = ((long)arb * (Ls + 1) + l + 1) * A + an0 + ac;
           L.att[ao] = a;
           if (drop) L.attd[ao] = a * p_drop(true, seedv, cid4, (uint32_t)(((long)arb * Ls + l + 1) * (E + A) + E + an0 + ac), L.k_in);
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         for (int w = 0; w < DP_NW; ++w) part[w] = ld1_sc1(plog_rs, (w < L.NWA && pv < V) ? (int)(po + (unsigned)(w * DP_R * 32 * 4)) : P_OOB);
 #pragma unroll
         for (int w = 0; w < DP_NW; ++w) z += part[w];
-        const bool valid = l < s_int[8 + pr];
+        const bool valid = l < s_int[R + pr];
         z = valid ? z + bout_v : 0.f;
         if (pv < V) {
           s_logit[pr * 32 + pv] = z;
@@ -585,15 +596,15 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         if (mode == 1) {
           int id = 0;
           bool unfin = false;
-          if (b < B && l < s_int[8 + r]) {
+          if (b < B && l < s_int[R + r]) {
             id = __builtin_bit_cast(int, red[r]);
             s_int[r] = id;
-            if (id == L.eos_id) s_int[8 + r] = l + 1; else unfin = true;
+            if (id == L.eos_id) s_int[R + r] = l + 1; else unfin = true;
           }
           if (j == 0 && b < B) L.ids[(long)b * Ls + l] = id;
           if (l == L.l_end - 1) {
             const int cnt = __popcll(__ballot(unfin));
-            if (tid == 0) s_int[17] = cnt;
+            if (tid == 0) s_int[2 * R + 1] = cnt;
           }
         } else if (l + 1 < Ls && b < B) {
           const uint32_t idx = (uint32_t)(b * Ls + l);
@@ -654,27 +665,29 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   {
     const int tid = tid0;
     const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
-    if (tid < DP_R * UW && eb < B && eun < H) cbuf[(long)(L.l_end & 1) * BH + (long)eb * H + eun] = c_state;
+    if (tid < R * UW && eb < B && eun < H) cbuf[(long)(L.l_end & 1) * BH + (long)eb * H + eun] = c_state;
     if (mode == 1 && j == 0) {
       if (tid < DP_R && rowbase + tid < B) {
-        L.steplen[rowbase + tid] = s_int[8 + tid];
+        L.steplen[rowbase + tid] = s_int[R + tid];
         L.tok[rowbase + tid] = s_int[tid];
       }
-      if (tid == 0 && s_int[17] > 0) atomicAdd(L.n_unfinished, s_int[17]);
+      if (tid == 0 && s_int[2 * R + 1] > 0) atomicAdd(L.n_unfinished, s_int[2 * R + 1]);
     }
   }
 }
 
 int g_dec_fused = 1;
 
-// variant: 0 = one mechanism (<= 128 frames per quarter); 1 = (<= 32, <= 128); 2 = (<= 128, <= 32) frames per quarter
+// variant: 0 = one mechanism (<= 128 frames per quarter); 1 = (<= 32, <= 128); 2 = (<= 128, <= 32) frames per quarter;
+// 3 = attentive layer (mode 0) in 16-row groups, one mechanism, <= 64 frames per half
 static const void* dp_kernel(int variant, int mode) {
-#define DPK(a, b) (mode == 0 ? (const void*)dec_persist_kernel<a, b, 0> : mode == 1 ? (const void*)dec_persist_kernel<a, b, 1> : (const void*)dec_persist_kernel<a, b, 2>)
+#define DPK(a, b) (mode == 0 ? (const void*)dec_persist_kernel<a, b, 0, 8> : mode == 1 ? (const void*)dec_persist_kernel<a, b, 1, 8> : (const void*)dec_persist_kernel<a, b, 2, 8>)
+  if (variant == 3) return (const void*)dec_persist_kernel<2, 0, 0, 16>;
   return variant == 0 ? DPK(4, 0) : variant == 1 ? DPK(1, 4) : DPK(4, 1);
 #undef DPK
 }
 
-static inline int dp_quarter(int T) { return (T + DP_WPR - 1) / DP_WPR; }
+static int g_dec_rows16 = -1;                   // -1: read AVSR_DEC_ROWS16 once (default on)
 
 // Fills L for the descriptor; returns AVSR_ERR_UNSUPPORTED when the fused kernel does not cover it.
 int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* lds_bytes) {
@@ -695,6 +708,11 @@ int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* lds_bytes
   L = DPLaunch{};
   L.B = B; L.L = d.L; L.H = H; L.E = E; L.V = d.V; L.n_mech = d.n_mech; L.mode = d.mode; L.oa = d.output_attention;
   L.go_id = d.go_id; L.eos_id = d.eos_id; L.A = A; L.KW = KW; L.UW = UW; L.AW = AW; L.NWA = (A + AW - 1) / AW; L.uwsh = uwsh; L.awsh = awsh;
+  // 16-row groups (full MFMA row tiles, half as many groups): the attentive layer with ONE memory whose halves fit a workgroup
+  if (g_dec_rows16 < 0) { const char* e = getenv("AVSR_DEC_ROWS16"); g_dec_rows16 = (e && e[0] == '0') ? 0 : 1; }
+  L.R = DP_R;
+  if (g_dec_rows16 && d.mode == 0 && d.n_mech == 1 && (d.mech[0].T + 1) / 2 <= 64 && UW * 16 <= DP_NT && AW * 16 <= DP_NT) L.R = 16;
+  const int wpr = DP_NW / L.R;
   L.drop = (d.seed && d.mode != 1 && (d.keep_in < 1.f || d.keep_state < 1.f || d.keep_out < 1.f)) ? 1 : 0;
   L.wt = d.wt; L.bias = d.bias; L.gates = d.gates; L.cs = d.cs; L.cell_out = d.cell_out; L.att = d.att; L.attd = d.attd;
   L.hs_seq = d.hs_seq; L.state = d.state; L.steplen = d.steplen;
@@ -714,17 +732,18 @@ int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* lds_bytes
     DPMech& X = L.m[m];
     X.keys = M.keys; X.values = M.values; X.values_sb = M.values_sb; X.values_st = M.values_st; X.len = M.len; X.g = M.g;
     X.watt_t = M.watt_t; X.scores = M.scores; X.ctx = M.ctx; X.pstat = M.pstat;
-    X.T = M.T; X.D = M.D; X.type = M.type; X.nc_rec = (M.T + M.chunk - 1) / M.chunk; X.ch = dp_quarter(M.T);
+    X.T = M.T; X.D = M.D; X.type = M.type; X.nc_rec = (M.T + M.chunk - 1) / M.chunk; X.ch = (M.T + wpr - 1) / wpr;
     if (X.ch > 128) return AVSR_ERR_UNSUPPORTED;
     X.lds_off = lds_off; lds_off += X.ch * M.D;
     X.ppm = ws; ws += 4L * B; X.ppl = ws; ws += 4L * B; X.ppctx = ws; ws += 4L * B * M.D;
   }
-  const size_t bytes = sizeof(float) * ((size_t)DP_MISC + lds_off);
+  const size_t bytes = sizeof(float) * ((size_t)(L.R == 16 ? DP_MISC16 : DP_MISC) + lds_off);
   if (bytes > DP_LDS_BYTES) return AVSR_ERR_UNSUPPORTED;
   *lds_bytes = bytes;
   // register-resident key capacity (32 frames per pass): variant 0 = one mechanism up to 128 frames per quarter;
   // 1 = (<= 32, <= 128); 2 = (<= 128, <= 32)
-  if (d.n_mech == 1) *variant = 0;
+  if (L.R == 16) *variant = 3;
+  else if (d.n_mech == 1) *variant = 0;
   else if (L.m[0].ch <= 32 && L.m[1].ch <= 128) *variant = 1;
   else if (L.m[0].ch <= 128 && L.m[1].ch <= 32) *variant = 2;
   else return AVSR_ERR_UNSUPPORTED;
@@ -772,7 +791,7 @@ int avsr_dec_persist_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32_t l_end
   if (words > g_sync_ints) return AVSR_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    for (int v = 0; v < 3; ++v)
+    for (int v = 0; v < 4; ++v)
       for (int md = 0; md < 3; ++md)
         if (hipFuncSetAttribute(dp_kernel(v, md), hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES) != hipSuccess) return AVSR_ERR_HIP;
     attr_set = true;
@@ -781,8 +800,9 @@ int avsr_dec_persist_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32_t l_end
   L.err = sync; L.claim = sync + P_HDR; L.flags = sync + P_HDR + 8;
   if (L.mode == 1 && avsr::dev_zero(L.n_unfinished, sizeof(int32_t), s) != hipSuccess) return AVSR_ERR_HIP;
   const int B = L.B;
-  for (int b0 = 0; b0 < B; b0 += 64) {
-    L.b0 = b0; L.ngroups = ((B - b0 < 64 ? B - b0 : 64) + DP_R - 1) / DP_R;
+  const int slice = 8 * L.R;                       // utterances per launch: one group per XCD
+  for (int b0 = 0; b0 < B; b0 += slice) {
+    L.b0 = b0; L.ngroups = ((B - b0 < slice ? B - b0 : slice) + L.R - 1) / L.R;
     if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
       ProfScope ps(PROF_DEC_PERSIST_FWD, s);

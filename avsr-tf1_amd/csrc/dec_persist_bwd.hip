@@ -58,29 +58,35 @@ __device__ __forceinline__ float xor32_sum(float v) {
   return a + b;
 }
 
-template <int KR0, int KR1>
+// R: rows per group (8, or 16 = a full MFMA row tile for the attentive layer; see dec_persist.hip)
+template <int KR0, int KR1, int R>
 __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L) {
+  constexpr int WPR = DP_NW / R;                // workgroups per row in the attention phase
+  constexpr int RQ = R / 4;                     // lane groups q < RQ hold real rows of a C tile
+  constexpr int RED_F = 256 * R;                // [8 waves][2 tiles][R][16]
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const red = lds;                       // [8][2][8][16] phase A partial sums / [8][256] query-gradient partials
-  float* const s_datt = lds + 2048;             // [8][16] this workgroup's d attention columns
-  float* const s_dctx = lds + 2176;             // [2][256] d context of the attention row
-  float* const s_ds = lds + 2688;               // [2][128] d score of this quarter's frames
-  float* const s_cd = lds + 2944;               // [2] ctx . dctx, [2] softmax maximum, [2] 1 / softmax denominator
-  int* const s_int = reinterpret_cast<int*>(lds + 2960);   // [0..7] step lengths, [16] slot
-  float* const vals = lds + DP_MISC;            // resident value rows of this workgroup's quarter
+  float* const red = lds;                       // [8][2][R][16] phase A partial sums / [8][256] query-gradient partials
+  float* const s_datt = lds + RED_F;            // [R][16] this workgroup's d attention columns
+  float* const s_dctx = lds + RED_F + 16 * R;   // [2][256] d context of the attention row
+  float* const s_ds = s_dctx + 512;             // [2][128] d score of this share's frames
+  float* const s_cd = s_ds + 256;               // [2] ctx . dctx, [2] softmax maximum, [2] 1 / softmax denominator
+  int* const s_int = reinterpret_cast<int*>(s_cd + 16);   // [0..R) step lengths, [R] slot
+  constexpr int MISC = R == 8 ? DP_MISC : DP_MISC16;
+  float* const vals = lds + MISC;               // resident value rows of this workgroup's share
+  static_assert(RED_F + 16 * R + 512 + 256 + 16 + R + 16 <= MISC, "LDS layout");
 
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int g = __builtin_amdgcn_readfirstlane(xcc_id());
-  if (tid0 == 0) s_int[16] = __hip_atomic_fetch_add(L.claim + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid0 == 0) s_int[R] = __hip_atomic_fetch_add(L.claim + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  const int j = __builtin_amdgcn_readfirstlane(s_int[16]);
+  const int j = __builtin_amdgcn_readfirstlane(s_int[R]);
   if (g >= L.ngroups || j >= DP_NW) return;
 
   const int B = L.B, Ls = L.L, H = L.H, E = L.E, A = L.A;
   const int H4 = 4 * H;
-  const int rowbase = L.b0 + g * DP_R;
-  const int gg = rowbase / DP_R;                 // group index into the partial workspace
+  const int rowbase = L.b0 + g * R;
+  const int gg = rowbase / R;                 // group index into the partial workspace
   const bool drop = L.drop != 0;
   const uint32_t seedv = L.seed ? (uint32_t)L.seed[0] : 0u;
   const uint32_t cid4 = L.cid4;
@@ -107,13 +113,13 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
   f32x4 wp[DB_KPW][2], wb[4];
   f32x4 k0[KR0 > 0 ? KR0 : 1][4], k1[KR1 > 0 ? KR1 : 1][4];
   int n_m[2] = {0, 0}, t0_m[2] = {0, 0};
-  const int r_att = j >> 2, cq = j & 3;
+  const int r_att = j / WPR, cq = j % WPR;
   const int b_att = rowbase + r_att;
   const bool att_row = b_att < B;
   float dc_state = 0.f, dh_carry = 0.f;
   {
     const int tid = tid0, lane = tid & 63, i = lane & 15, q = lane >> 4, s16 = tid & 15, rg = tid >> 4;
-    for (int idx = tid; idx < DP_MISC - 2048; idx += DP_NT) lds[2048 + idx] = 0.f;
+    for (int idx = tid; idx < MISC - RED_F; idx += DP_NT) lds[RED_F + idx] = 0.f;
     // (1) rows of the cell kernel behind this workgroup's d attention columns (tile 0) and d h units (tile 1); K split over the waves
 #pragma unroll
     for (int cc = 0; cc < DB_KPW; ++cc) {
@@ -169,12 +175,12 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
     }
     // (4) gradient state of (row er, unit eu); step lengths of the group's rows
     const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
-    if (tid < DP_R * UW && eb < B && eun < H) {
+    if (tid < R * UW && eb < B && eun < H) {
       dc_state = dcbuf[(long)(Ls & 1) * BH + (long)eb * H + eun];
       dh_carry = dhcarry[(long)(Ls & 1) * BH + (long)eb * H + eun];
     }
     __syncthreads();
-    if (tid < DP_R) s_int[tid] = (rowbase + tid < B) ? L.steplen[rowbase + tid] : 0;
+    if (tid < R) s_int[tid] = (rowbase + tid < B) ? L.steplen[rowbase + tid] : 0;
     __syncthreads();
   }
   const __amdgpu_buffer_rsrc_t dg_rs = make_rsrc(dgroll), part_rs = make_rsrc(L.part), gates_rs = make_rsrc(L.gates);
@@ -222,12 +228,12 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
     asm volatile("" : "+v"(tid));                 // opaque: per-thread indices below are recomputed, not kept across steps
     const int lane = tid & 63, i = lane & 15, q = lane >> 4;
     const int ab = rowbase + i;
-    const bool aok = i < DP_R && ab < B;
+    const bool aok = i < R && ab < B;
     const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
-    const bool eok = tid < DP_R * UW && eb < B && eun < H;
+    const bool eok = tid < R * UW && eb < B && eun < H;
     float zA = 0.f;
     const int s16 = tid & 15, rg = tid >> 4;
-    const bool c_valid = eok && l < s_int[er & 7];
+    const bool c_valid = eok && l < s_int[er & (R - 1)];
     const long c_bt = (long)eb * Ls + l;
     f32x4 c_g4 = zero4;
     float c_c = 0.f, c_prev = 0.f, c_dext = 0.f;
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
     float a_ext = 0.f;                            // external gradient of this thread's attention column: requested before the wait
     {
       const int ar = tid >> awsh, ac = tid & (AW - 1), arb = rowbase + ar;
-      a_ext = ldb1(dae_rs, (tid < DP_R * AW && has_att && L.datt_ext && arb < B) ? (int)((((long)arb * Ls + l) * A + an0 + ac) * 4) : P_OOB);
+      a_ext = ldb1(dae_rs, (tid < R * AW && has_att && L.datt_ext && arb < B) ? (int)((((long)arb * Ls + l) * A + an0 + ac) * 4) : P_OOB);
     }
     // =====================================================================================================
     // A: d attention(l) columns and the recurrent d h(l) of this workgroup from dG(l+1); attention-layer transpose, split-K
@@ -259,11 +265,11 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
             accb[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[cc + 1][e], wp[cc + 1][nt][e], accb[nt], 0, 0, 0);
           }
       acc[0] += accb[0]; acc[1] += accb[1];
-      if (q < 2) {
+      if (q < RQ) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) red[((wave * 2 + nt) * 8 + q * 4 + r) * 16 + i] = acc[nt][r];
+          for (int r = 0; r < 4; ++r) red[((wave * 2 + nt) * R + q * 4 + r) * 16 + i] = acc[nt][r];
       }
       // forward records phase B consumes (raw scores of this lane's frames, softmax statistics, the context): requested here, so
       // their latency runs under the rest of this phase and the hand-off
@@ -288,14 +294,14 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
       }
       lds_barrier();
       BTICK(1)
-      if (tid < DP_R * AW && has_att) {
+      if (tid < R * AW && has_att) {
         const int ar = tid >> awsh, ac = tid & (AW - 1), arb = rowbase + ar;
         float a = 0.f;
         if (arb < B && l < s_int[ar]) {
           const int o = ar * 16 + ac;
           float z = 0.f;
 #pragma unroll
-          for (int w = 0; w < DP_WV; ++w) z += red[(w * 2) * 128 + o];
+          for (int w = 0; w < DP_WV; ++w) z += red[(w * 2) * 16 * R + o];
           // the product is the gradient of step l+1's DROPPED attention input (AttentionWrapper feeds [x | attention] through the
           // DropoutWrapper's input mask, cells.py:46-54)
           z *= p_drop(drop, seedv, cid4, (uint32_t)(((long)arb * Ls + l + 1) * (E + A) + E + an0 + ac), L.k_in);
@@ -304,15 +310,15 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
         if (arb < B) L.datt[((long)arb * Ls + l) * A + an0 + ac] = a;
         s_datt[ar * 16 + ac] = a;
       }
-      if (tid < DP_R * UW) {
+      if (tid < R * UW) {
         const int o = er * 16 + eu;
 #pragma unroll
-        for (int w = 0; w < DP_WV; ++w) zA += red[(w * 2 + 1) * 128 + o];
+        for (int w = 0; w < DP_WV; ++w) zA += red[(w * 2 + 1) * 16 * R + o];
       }
       lds_barrier();
       if (has_att) {
-        const f32x4 a4 = ld4(s_datt + (i & 7) * 16 + 4 * q);
-        float* const prow = L.part + (((long)gg * DP_NW + j) * DP_R + q * 4) * DB_PART + i;
+        const f32x4 a4 = ld4(s_datt + (i & (R - 1)) * 16 + 4 * q);
+        float* const prow = L.part + (((long)gg * DP_NW + j) * R + q * 4) * DB_PART + i;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int n0 = (wave * 4 + t) * 16;
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
             f32x4 c = zero4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], wb[t][e], c, 0, 0, 0);
-            if (q < 2) {
+            if (q < RQ) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) prow[(long)r * DB_PART + n0] = c[r];
             }
@@ -344,12 +350,12 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
         const int D = M.D, c4 = lane;
         const bool cok = att_row && 4 * c4 < D;
         const int nwm = H >> awsh, w0 = wave * nwm;
-        const unsigned base = cok ? (unsigned)((((long)gg * DP_NW + w0) * DP_R + r_att) * DB_PART + H + 4 * c4) * 4u : (unsigned)P_OOB;
+        const unsigned base = cok ? (unsigned)((((long)gg * DP_NW + w0) * R + r_att) * DB_PART + H + 4 * c4) * 4u : (unsigned)P_OOB;
         f32x4 acc = zero4;
         for (int w = 0; w < nwm; w += 8) {
           f32x4 x[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) x[u] = ldb_sc1(part_rs, (w + u < nwm) ? (int)(base + (unsigned)((w + u) * DP_R * DB_PART * 4)) : P_OOB);
+          for (int u = 0; u < 8; ++u) x[u] = ldb_sc1(part_rs, (w + u < nwm) ? (int)(base + (unsigned)((w + u) * R * DB_PART * 4)) : P_OOB);
 #pragma unroll
           for (int u = 0; u < 8; ++u) acc += x[u];
         }
@@ -457,14 +463,14 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
       const bool valid = c_valid;
       const long bt = c_bt;
       float pq[DP_NW / 2], pd[8];
-      const unsigned po = eok ? (unsigned)((((long)gg * DP_NW) * DP_R + er) * DB_PART + eun) * 4u : (unsigned)P_OOB;
+      const unsigned po = eok ? (unsigned)((((long)gg * DP_NW) * R + er) * DB_PART + eun) * 4u : (unsigned)P_OOB;
 #pragma unroll
-      for (int w = 0; w < DP_NW / 2; ++w) pq[w] = ld1_sc1(part_rs, (w < L.NWA) ? (int)(po + (unsigned)(w * DP_R * DB_PART * 4)) : P_OOB);
+      for (int w = 0; w < DP_NW / 2; ++w) pq[w] = ld1_sc1(part_rs, (w < L.NWA) ? (int)(po + (unsigned)(w * R * DB_PART * 4)) : P_OOB);
       const unsigned qo = eok ? (unsigned)((long)eb * H + eun) * 4u : (unsigned)P_OOB;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        pd[c] = ld1_sc1(pdq0_rs, (int)(qo + (unsigned)((long)c * BH * 4)));
-        pd[4 + c] = ld1_sc1(pdq1_rs, (L.n_mech > 1) ? (int)(qo + (unsigned)((long)c * BH * 4)) : P_OOB);
+        pd[c] = ld1_sc1(pdq0_rs, (c < WPR) ? (int)(qo + (unsigned)((long)c * BH * 4)) : P_OOB);
+        pd[4 + c] = ld1_sc1(pdq1_rs, (L.n_mech > 1 && c < WPR) ? (int)(qo + (unsigned)((long)c * BH * 4)) : P_OOB);
       }
       const float c = c_c, cprev = c_prev, dext = c_dext;
       const f32x4 g4 = c_g4;
@@ -473,7 +479,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
       for (int w = 0; w < DP_NW / 2; ++w) dout += pq[w];
       if (L.NWA > DP_NW / 2) {                       // wave-uniform: second half of the attention-layer partials
 #pragma unroll
-        for (int w = 0; w < DP_NW / 2; ++w) pq[w] = ld1_sc1(part_rs, (w + DP_NW / 2 < L.NWA) ? (int)(po + (unsigned)((w + DP_NW / 2) * DP_R * DB_PART * 4)) : P_OOB);
+        for (int w = 0; w < DP_NW / 2; ++w) pq[w] = ld1_sc1(part_rs, (w + DP_NW / 2 < L.NWA) ? (int)(po + (unsigned)((w + DP_NW / 2) * R * DB_PART * 4)) : P_OOB);
 #pragma unroll
         for (int w = 0; w < DP_NW / 2; ++w) dout += pq[w];
       }
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
   {
     const int tid = tid0;
     const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
-    if (tid < DP_R * UW && eb < B && eun < H) {
+    if (tid < R * UW && eb < B && eun < H) {
       dcbuf[(long)eb * H + eun] = dc_state;
       dhcarry[(long)eb * H + eun] = dh_carry;
     }
@@ -517,8 +523,9 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
 }
 
 static const void* db_kernel(int variant) {
-  return variant == 0 ? (const void*)dec_persist_bwd_kernel<4, 0> : variant == 1 ? (const void*)dec_persist_bwd_kernel<1, 4>
-                                                                                 : (const void*)dec_persist_bwd_kernel<4, 1>;
+  if (variant == 3) return (const void*)dec_persist_bwd_kernel<2, 0, 16>;
+  return variant == 0 ? (const void*)dec_persist_bwd_kernel<4, 0, 8> : variant == 1 ? (const void*)dec_persist_bwd_kernel<1, 4, 8>
+                                                                                    : (const void*)dec_persist_bwd_kernel<4, 1, 8>;
 }
 
 }  // namespace avsr
@@ -527,8 +534,8 @@ int64_t avsr_dec_persist_fwd_ws_floats(int32_t B, int32_t n_mech, int32_t Dmax);
 
 // floats the backward kernel needs behind the forward region of the fused workspace
 int64_t avsr_dec_persist_bwd_ws_floats(int32_t B, int32_t n_mech) {
-  const int64_t groups = (B + DP_R - 1) / DP_R;
-  return groups * DP_NW * DP_R * DB_PART + (int64_t)n_mech * 4 * B * 256;
+  const int64_t rows = ((B + 15) / 16) * 16;       // whole groups of 8 or 16 rows
+  return rows * DP_NW * DB_PART + (int64_t)n_mech * 4 * B * 256;
 }
 
 // The whole backward loop of avsr_attn_rnn_bwd as one persistent launch per 64-row slice.  The caller has zeroed dstate and copied
@@ -544,7 +551,7 @@ int avsr_dec_persist_bwd(const avsr_attn_rnn* dp, void* stream) {
   if (rc) return rc;
   if (!d.w || !d.dgates || !d.dstate || !d.datt) return AVSR_ERR_ARG;
   if (avsr_dec_persist_fwd_ws_floats(d.B, d.n_mech, 256) + avsr_dec_persist_bwd_ws_floats(d.B, d.n_mech) > d.fused_ws_floats) return AVSR_ERR_UNSUPPORTED;
-  if ((long)d.B * d.L * d.H * 16 >= (1L << 31) || (long)((d.B + DP_R - 1) / DP_R) * DP_NW * DP_R * DB_PART * 4 >= (1L << 31) ||
+  if ((long)d.B * d.L * d.H * 16 >= (1L << 31) || (long)((d.B + 15) / 16) * 16 * DP_NW * DB_PART * 4 >= (1L << 31) ||
       (long)4 * d.B * d.H * 4 >= (1L << 31))
     return AVSR_ERR_UNSUPPORTED;
   L = DBLaunch{};
@@ -555,7 +562,7 @@ int avsr_dec_persist_bwd(const avsr_attn_rnn* dp, void* stream) {
   L.datt_ext = d.datt_ext; L.dcell_ext = d.dcell_ext; L.dgates = d.dgates; L.dstate = d.dstate; L.datt = d.datt;
   L.seed = d.seed; L.k_in = d.keep_in; L.k_st = d.keep_state; L.k_out = d.keep_out; L.cid4 = (uint32_t)d.cell_id * 4;
   float* ws = d.fused_ws + avsr_dec_persist_fwd_ws_floats(d.B, d.n_mech, 256);
-  L.part = ws; ws += (long)((d.B + DP_R - 1) / DP_R) * DP_NW * DP_R * DB_PART;
+  L.part = ws; ws += (long)((d.B + 15) / 16) * 16 * DP_NW * DB_PART;
   for (int m = 0; m < d.n_mech; ++m) {
     const avsr_attn_mech& M = d.mech[m];
     if (!M.dscores || !M.dctx || !M.scores || !M.ctx || !M.pstat || !M.watt_t) return AVSR_ERR_ARG;
@@ -572,13 +579,14 @@ int avsr_dec_persist_bwd(const avsr_attn_rnn* dp, void* stream) {
   if (words > g_sync_ints) return AVSR_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    for (int v = 0; v < 3; ++v)
+    for (int v = 0; v < 4; ++v)
       if (hipFuncSetAttribute(db_kernel(v), hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES) != hipSuccess) return AVSR_ERR_HIP;
     attr_set = true;
   }
   L.err = sync; L.claim = sync + P_HDR; L.flags = sync + P_HDR + 8;
-  for (int b0 = 0; b0 < d.B; b0 += 64) {
-    L.b0 = b0; L.ngroups = ((d.B - b0 < 64 ? d.B - b0 : 64) + DP_R - 1) / DP_R;
+  const int slice = 8 * F.R;
+  for (int b0 = 0; b0 < d.B; b0 += slice) {
+    L.b0 = b0; L.ngroups = ((d.B - b0 < slice ? d.B - b0 : slice) + F.R - 1) / F.R;
     if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
       ProfScope ps(PROF_DEC_PERSIST_BWD, s);

@@ -42,6 +42,9 @@ def auto_splitk(M, N, K, batch=1):
     one 128x128 workgroup walks K at ~1.5 us per 16-deep tile, so few-tile GEMMs are latency-bound unless K is cut.
     Aim at ~768 workgroups, keep >= 64 of K per slice, never split when the grid already has >= 128 tiles."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * max(1, batch)
+    if 128 <= tiles < 384 and K >= 512:      # one partial wave of workgroups walking a long K (e.g. 32000 x 80 x 1024: 250 tiles, 64 K tiles each)
+        sk = min(768 // tiles, K // 256)
+        return sk if sk >= 2 else 1
     if tiles >= 128:
         return 1
     if K < 65536:

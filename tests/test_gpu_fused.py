@@ -128,3 +128,40 @@ def test_benchmark_decoders_take_the_fused_path():
         ids = m.greedy_decode(b, max_steps=16)
         torch.cuda.synchronize()
         assert ids.shape[0] == B and not ops.rnn_persistent_error()
+
+
+def test_a_flagged_pass_is_redone_through_the_per_step_launches():
+    """The safety net under every persistent kernel (encoders, fused decoder forward and BPTT): a bounded device-side wait that
+    expires raises the sticky error word, the pass is invalid, and the trainer / the decode wrappers redo it with per-step launches.
+    Here the word is raised by hand before the step, so every persistent kernel of the pass bails out of its waits and leaves garbage."""
+    import warnings
+    from avsr_tf1_amd import ops
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    from avsr_tf1_amd.parallel import DataParallelTrainer
+    O, ocfg, mcfg, W, batch = _setup("bimodal_dropout_sampling_2groups")
+    L = CASES["bimodal_dropout_sampling_2groups"][4]
+    ref = _run(mcfg, W, batch, 0, L + 3)                                 # per-step launches throughout
+    ops.attn_rnn_set_fused(1)
+    m = Seq2SeqModel(mcfg, weights=W)
+    assert m.persistent_rnn and m.fused_decode
+    db = Batch.from_numpy(batch)
+    t = DataParallelTrainer(m, None, use_graph=False, check_every_step=True)
+    ops._persist_sync[:1].fill_(1)                                        # "a wait expired"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss, gnorm = t.train_step(db)
+    torch.cuda.synchronize()
+    assert not m.persistent_rnn and not m.fused_decode and not ops.rnn_persistent_error()
+    assert abs(float(loss.item()) - float(ref["loss"].item())) <= 2e-4 * max(1.0, abs(float(ref["loss"].item())))
+    assert abs(float(gnorm.item()) - float(ref["gnorm"].item())) <= 2e-4 * max(1.0, abs(float(ref["gnorm"].item())))
+    # decode wrapper: same story on a fresh engine
+    m2 = Seq2SeqModel(mcfg, weights=W)
+    m2.forward_train(db); m2.backward(); m2.apply_update()               # same parameters as `ref` had when it decoded
+    torch.cuda.synchronize()
+    assert not ops.rnn_persistent_error()
+    ops._persist_sync[:1].fill_(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ids = m2.greedy_decode(db, max_steps=L + 3)
+    torch.cuda.synchronize()
+    assert (ids == ref["ids"]).all() and not ops.rnn_persistent_error()
