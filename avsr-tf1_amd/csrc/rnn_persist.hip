@@ -285,8 +285,12 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(const PLaunch L) {
 // Only liveness depends on the dispatcher handing each XCD its share of the grid; every wait is bounded and a
 // miss raises the sticky error word (the host then switches the path off).
 // ======================================================================================================
+// R: rows per group.  8 for batches up to 64 utterances (all eight XCDs busy); 16 -- a full MFMA row tile, no padding rows -- for
+// larger batches: the same instruction count per step then carries twice the rows, so 128 utterances are ONE pass over the chip
+// instead of two sequential 64-row slices.
+template <int R>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rnn_persist_fwd_xcd_kernel(const PLaunch L) {
-  __shared__ __attribute__((aligned(16))) float red[4][4][8][16];
+  __shared__ __attribute__((aligned(16))) float red[4][4][R][16];
   __shared__ int s_slot;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = __builtin_amdgcn_readfirstlane(xcc_id());
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const PTask& tk = L.task[ti];
   const int ct = slot - tk.wg_begin;
   const int UW = tk.uw, uw_shift = UW == 16 ? 4 : 3;
-  const int row0 = L.b0 + g * 8, col0 = ct * UW * 4, unit0 = ct * UW;
+  const int row0 = L.b0 + g * R, col0 = ct * UW * 4, unit0 = ct * UW;
   const int i = lane & 15, q = lane >> 4;
   const int H = tk.H, T = tk.T;
   const int hoisted = tk.hoisted, reverse = tk.reverse;
@@ -336,17 +340,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
   }
 
-  // epilogue ownership: thread e (< 8 * UW) owns (row er, unit eu) for all steps
+  // epilogue ownership: thread e (< R * UW <= 256) owns (row er, unit eu) for all steps
   const int er = tid >> uw_shift, eu = tid & (UW - 1);
   const int b = row0 + er, u = unit0 + eu;
-  const bool eok = tid < 8 * UW && b < tk.B && u < H;
+  const bool eok = tid < R * UW && b < tk.B && u < H;
   const int len_b = eok ? (tk.len ? tk.len[b] : T) : 0;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (eok && tk.bias) bias4 = ld4(tk.bias + u * 4);
   float c_state = 0.f, h_state = 0.f;
 
   const int ab = row0 + i;
-  const bool aok = i < 8 && ab < tk.B;
+  const bool aok = i < R && ab < tk.B;
   const int len_a = aok ? (tk.len ? tk.len[ab] : T) : 0;
   const int xrow = (int)(ab * tk.x_sb) + 4 * q, hrow = (int)(ab * tk.hsr_sb) + 4 * q;
   const int x_st = (int)tk.x_st, h_st = (int)tk.hsr_st;
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
               acc[2 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[c][e], wa[c][nt][e], acc[2 + nt], 0, 0, 0);
         }
       }
-    if (q < 2) {                                 // C rows (lane>>4)*4 + r: only rows 0-7 carry batch rows
+    if (q < R / 4) {                             // C rows (lane>>4)*4 + r: rows < R carry batch rows
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -617,14 +621,19 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
   int wg = 0; long words = 0;
   if ((g_persist_mode & 2) && build_tasks(st, n, true, sync, sync_ints, L, &wg, &words) == AVSR_OK) {
     if (dry) return AVSR_OK;
-    // 8 XCDs x 8 rows per launch; a larger batch runs as consecutive launches over 64-row slices (rows are independent)
+    // 8 XCDs x R rows per launch (R = 8 up to 64 utterances, 16 above); a larger batch runs as consecutive launches over slices
+    // (rows are independent)
     const int B = st[0].B;
-    for (int b0 = 0; b0 < B; b0 += 64) {
-      L.b0 = b0; L.ngroups = ((B - b0 < 64 ? B - b0 : 64) + 7) / 8;
+    static const int rows16 = getenv("AVSR_RNN_ROWS16") ? atoi(getenv("AVSR_RNN_ROWS16")) : 1;
+    const int R = (B > 64 && rows16) ? 16 : 8;
+    for (int b0 = 0; b0 < B; b0 += 8 * R) {
+      const int rows = B - b0 < 8 * R ? B - b0 : 8 * R;
+      L.b0 = b0; L.ngroups = (rows + R - 1) / R;
       if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
       {
-        ProfScope ps(PROF_RNN_PERSIST_FWD, s, g_fwd_flops * (L.ngroups * 8 < B - b0 ? L.ngroups * 8 : B - b0) / B);
-        hipLaunchKernelGGL(rnn_persist_fwd_xcd_kernel, dim3(8 * wg), dim3(256), 0, s, L);
+        ProfScope ps(PROF_RNN_PERSIST_FWD, s, g_fwd_flops * rows / B);
+        if (R == 16) hipLaunchKernelGGL(rnn_persist_fwd_xcd_kernel<16>, dim3(8 * wg), dim3(256), 0, s, L);
+        else hipLaunchKernelGGL(rnn_persist_fwd_xcd_kernel<8>, dim3(8 * wg), dim3(256), 0, s, L);
       }
       AVSR_CHECK_LAUNCH();
     }
