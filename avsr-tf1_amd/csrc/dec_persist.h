@@ -26,6 +26,7 @@ struct DPMech {
   const float* watt_t;
   float* scores; float* ctx; float* pstat;      // records [B][L][T], [B][L][D], [L][2][nc_rec][B]
   float* ppm; float* ppl; float* ppctx;         // quarter partials [4][B], [4][B], [4][B][D]
+  const float* v; const float* bq; const float* wq_t; float* pq;   // Bahdanau: v [H], bias [H] (normed only), query layer^T [H][H], processed-query record [B][L][H]
   int T, D, type, nc_rec, ch, lds_off;
 };
 
@@ -35,6 +36,7 @@ struct DPLaunch {
   int go_id, eos_id, A, KW;
   int UW, AW, NWA, drop;
   int uwsh, awsh;
+  int bah;                                      // the (one) mechanism is Bahdanau / normed Bahdanau: processed-query phase, tanh scores
   int R;                                        // rows per group (8, or 16 for the attentive layer when its memories fit)
   int* err; int* claim; int* flags;
   const float* wt; const float* bias;

@@ -44,9 +44,15 @@ namespace avsr {
 // R: rows (utterances) per group.  8 everywhere except the AV-Align attentive layer (MODE 0) when its memories fit: there a group
 // is a FULL 16-row MFMA tile (no padding rows) and two workgroups instead of four share a row's memories -- half as many groups,
 // so a 128-utterance batch is one pass over the chip instead of two sequential 64-row slices.
-template <int KR0, int KR1, int MODE, int R>
+// BAH: the block's one mechanism is (normed) Bahdanau (attention.py:25-42): an extra phase computes the processed query
+// pq = cell_out . W_q for the group (one more hand-off per step), the scores are v . tanh(keys + pq + b), and -- output_attention
+// being False for this family -- the logits come from the cell output (split-K shares published with the cell phase).
+template <int KR0, int KR1, int MODE, int R, bool BAH = false>
 __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   static_assert(R == 8 || (R == 16 && MODE == 0), "16-row groups: attentive layer only");
+  static_assert(!BAH || (R == 8 && KR1 == 0), "Bahdanau: one mechanism, 8-row groups");
+  constexpr int NPH = BAH ? 4 : 3;              // hand-offs per step
+  constexpr int PH_PQ = 1, PH_ATT = BAH ? 2 : 1, PH_LAYER = BAH ? 3 : 2;
   constexpr int WPR = DP_NW / R;                // workgroups per row in the attention phase (4 quarters / 2 halves)
   constexpr int RQ = R / 4;                     // lane groups q < RQ hold real rows of a C tile (row = 4q + r)
   constexpr int RED_F = 256 * R;                // floats of the reduction buffer [8 waves][2 tiles][R][16]
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   // ---------------------------------------------------------------------------------------------------------
   // resident operands
   // ---------------------------------------------------------------------------------------------------------
-  f32x4 wc[DP_CPW][2], wa[DP_APW];
+  f32x4 wc[DP_CPW][2], wa[DP_APW], wq[2];
   f32x4 k0[KR0 > 0 ? KR0 : 1][4], k1[KR1 > 0 ? KR1 : 1][4];
   int n_m[2] = {0, 0}, t0_m[2] = {0, 0};
   const int r_att = j / WPR, cq = j % WPR;
@@ -144,10 +150,25 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
       if (cc >= 2) cin[cc - 2] = in ? 1 : 0;
       wa[cc] = (in && i < AW) ? ld4(Ma.watt_t + (long)(nl0 + i) * (H + Da) + wbase + kk + 4 * q) : zero4;
     }
-    // (3) output-layer rows [an0, an0 + AW) -> LDS [k][symbol]
+    // (3) output-layer rows -> LDS [k][symbol]: the attention columns [an0, an0 + AW) (Luong family: logits from the attention
+    //     vector) or the cell-output units [unit0, unit0 + UW) (Bahdanau family: logits from the cell output)
     {
       const int k = tid >> 5, v = tid & 31;
-      s_wo[tid] = (mode >= 1 && L.oa && has_att && v < V && k < AW) ? L.wout_t[(long)v * A + an0 + k] : 0.f;
+      float wv = 0.f;
+      if (mode >= 1 && v < V) {
+        if (!BAH) { if (L.oa && has_att && k < AW) wv = L.wout_t[(long)v * A + an0 + k]; }
+        else if (k < UW && unit0 + k < H) wv = L.wout_t[(long)v * H + unit0 + k];
+      }
+      s_wo[tid] = wv;
+    }
+    // (3b) Bahdanau: this workgroup's columns [unit0, unit0 + UW) of the query layer, K split over the waves like the attention layer's
+    //      cell-output slots
+    if (BAH) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int kk = (qg0 + cc) << 4;
+        wq[cc] = (cc < nqw && i < UW && unit0 + i < H) ? ld4(L.m[0].wq_t + (long)(unit0 + i) * H + kk + 4 * q) : zero4;
+      }
     }
     // (4) attention memories of row r_att, quarter cq: keys -> registers (16 lanes per frame), values -> LDS
 #pragma unroll
@@ -212,8 +233,10 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   const __amdgpu_buffer_rsrc_t att_rs = make_rsrc(drop ? L.attd : L.att), h_rs = make_rsrc(hbuf), co_rs = make_rsrc(L.cell_out);
   const __amdgpu_buffer_rsrc_t pc_rs = make_rsrc(Ma.ppctx), pm_rs = make_rsrc(Ma.ppm), pl_rs = make_rsrc(Ma.ppl);
   const __amdgpu_buffer_rsrc_t plog_rs = make_rsrc(L.plog), gates_rs = make_rsrc(L.gates), bias_rs = make_rsrc(L.bias);
+  const __amdgpu_buffer_rsrc_t pq_rs = make_rsrc(L.m[0].pq);
+  const int NWL = BAH ? DP_NW : L.NWA;           // workgroups holding a split-K share of the logits
 
-  int* const flag_base = L.flags + g * 3 * 32;
+  int* const flag_base = L.flags + g * NPH * 32;
   auto wait_all = [&](int phase, int need) {
     if (wave == 0) {
       const int* fp = flag_base + phase * 32 + (threadIdx.x & 31);
@@ -309,6 +332,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
       }
       lds_barrier();
       DTICK(0)
+      float ho_keep = 0.f;
       if (eok) {
         const long so = ((long)eb * (Ls + 1) + l + 1) * H + eun;
         float hnext = h_state;
@@ -330,6 +354,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
           const float ho = h * p_drop(drop, seedv, cid4 + 2, oidx, L.k_out);
           const float hs = h * p_drop(drop, seedv, cid4 + 1, oidx, L.k_st);
           L.cell_out[so] = ho;
+          ho_keep = ho;
           hnext = hs;
           if (drop) L.hs_seq[so] = hs;
           st4(L.gates + (bt * H + eun) * 4, g4);
@@ -342,6 +367,18 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         }
         hbuf[(long)((l + 1) & 1) * BH + (long)eb * H + eun] = hnext;
       }
+      if (BAH && mode >= 1) {
+        // Bahdanau family (output_attention False): logits = cell_out . W_out; this workgroup's split-K share from its UW units (double-buffered by step
+        // parity: the shares of step l are read in P4 of step l while a faster workgroup already writes those of step l + 1)
+        if (tid < R * UW) s_att[er * 16 + eu] = ho_keep;
+        lds_barrier();
+        const int pr = (tid >> 5) & 7, pv = tid & 31;
+        if (tid < 256 && pv < V) {
+          float sacc = 0.f;
+          for (int k = 0; k < UW; ++k) sacc += s_att[pr * 16 + k] * s_wo[k * 32 + pv];
+          L.plog[((((long)(l & 1) * 8 + g) * DP_NW + j) * DP_R + pr) * 32 + pv] = sacc;
+        }
+      }
       DTICK(1)
       publish(0, epoch);
       DTICK(2)
@@ -352,6 +389,33 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
     // =====================================================================================================
     wait_all(0, epoch);
     DTICK(3)
+    if (BAH) {
+      // P1b: processed query pq = cell_out . W_q (attention.py:25-42 query_layer), columns [unit0, unit0 + UW) for the 8 rows
+      const unsigned qo_ = aok ? (unsigned)(((long)ab * (Ls + 1) + l + 1) * H) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
+      f32x4 aq[2];
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) aq[cc] = ldb_sc1(co_rs, (cc < nqw) ? (int)(qo_ + (unsigned)(((qg0 + cc) << 4) * 4)) : P_OOB);
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[cc][e], wq[cc][e], acc, 0, 0, 0);
+      if (q < RQ) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * R + q * 4 + r) * 16 + i] = acc[r];
+      }
+      lds_barrier();
+      if (tid < R * UW) {
+        const int er = tid >> uwsh, eu = tid & (UW - 1), eb = rowbase + er, eun = unit0 + eu;
+        if (eb < B && eun < H) {
+          const int o = er * 16 + eu;
+          constexpr int WS = 16 * R;
+          L.m[0].pq[((long)eb * Ls + l) * H + eun] = ((red[o] + red[WS + o]) + (red[2 * WS + o] + red[3 * WS + o])) + ((red[4 * WS + o] + red[5 * WS + o]) + (red[6 * WS + o] + red[7 * WS + o]));
+        }
+      }
+      publish(PH_PQ, epoch);
+      wait_all(PH_PQ, epoch);
+    }
     {
       {
         const unsigned h_o = aok ? (unsigned)((long)((l + 1) & 1) * BH + (long)ab * H) * 4u + (unsigned)(q * 16) : (unsigned)P_OOB;
@@ -372,9 +436,29 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         float* const sc = s_p + m * 128;
         const int n = n_m[m];
         if (m == 0) {
+          f32x4 v4[4], pb4[4];
+          if (BAH) {                                   // v . tanh(keys + pq + b): pq of this row from the phase above
+            const unsigned po_ = att_row ? (unsigned)(((long)b_att * Ls + l) * H) * 4u + (unsigned)(s16 * 16) : (unsigned)P_OOB;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const bool in = 4 * s16 + 64 * jj < H;
+              pb4[jj] = ldb_sc1(pq_rs, in ? (int)(po_ + 256 * jj) : P_OOB);
+              v4[jj] = in ? ld4(M.v + 4 * s16 + 64 * jj) : zero4;
+              if (in && M.bq) pb4[jj] += ld4(M.bq + 4 * s16 + 64 * jj);
+            }
+          }
 #pragma unroll
           for (int u = 0; u < KR0; ++u) {
-            float a = (dot4(k0[u][0], q4[0]) + dot4(k0[u][1], q4[1])) + (dot4(k0[u][2], q4[2]) + dot4(k0[u][3], q4[3]));
+            float a;
+            if (BAH) {
+              a = 0.f;
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a += v4[jj][e] * p_tanh(k0[u][jj][e] + pb4[jj][e]);
+            } else {
+              a = (dot4(k0[u][0], q4[0]) + dot4(k0[u][1], q4[1])) + (dot4(k0[u][2], q4[2]) + dot4(k0[u][3], q4[3]));
+            }
             a = row16_sum(a);
             const int fr = rg + 32 * u;
             if (s16 == 0 && fr < n) { srow[fr] = a; sc[fr] = a * gsc; }
@@ -448,13 +532,13 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         }
       }
       DTICK(4)
-      publish(1, epoch);
+      publish(PH_ATT, epoch);
       DTICK(5)
     }
     // =====================================================================================================
     // P3: attention layer att_m = [cell_out, ctx_m] . W_att,m (attention.py:173-181), split-K share of the logits
     // =====================================================================================================
-    wait_all(1, epoch);
+    wait_all(PH_ATT, epoch);
     DTICK(6)
     int label_pf = 0;                               // label of this step for the sampler (row tid < 8), fetched a phase early
     if (MODE == 2 && tid < DP_R && rowbase + tid < B && l + 1 < Ls) label_pf = L.labels[(long)(rowbase + tid) * Ls + l];
@@ -544,29 +628,29 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         s_att[ar * 16 + ac] = a;
       }
       lds_barrier();
-      if (mode >= 1 && L.oa && has_att && tid < 256 && pv < V) {
+      if (!BAH && mode >= 1 && L.oa && has_att && tid < 256 && pv < V) {
         float s = 0.f;
         for (int k = 0; k < AW; ++k) s += s_att[pr * 16 + k] * s_wo[k * 32 + pv];
-        L.plog[(((long)g * DP_NW + j) * DP_R + pr) * 32 + pv] = s;
+        L.plog[((((long)(l & 1) * 8 + g) * DP_NW + j) * DP_R + pr) * 32 + pv] = s;
       }
       DTICK(7)
-      publish(2, epoch);
+      publish(PH_LAYER, epoch);
       DTICK(8)
     }
     // =====================================================================================================
     // P4: logits, sample / arg-max, next input rows (decoder_unimodal.py:304-309 ScheduledEmbeddingTrainingHelper,
     //     :176-217 GreedyEmbeddingHelper + dynamic_decode(impute_finished=True))
     // =====================================================================================================
-    wait_all(2, epoch);
+    wait_all(PH_LAYER, epoch);
     DTICK(9)
     if (mode >= 1) {
       const int pr = (tid >> 5) & 7, pv = tid & 31, pb = rowbase + pr;
       if (tid < 256) {
         float z = 0.f;
-        const unsigned po = (unsigned)((((long)g * DP_NW) * DP_R + pr) * 32 + pv) * 4u;
+        const unsigned po = (unsigned)(((((long)(l & 1) * 8 + g) * DP_NW) * DP_R + pr) * 32 + pv) * 4u;
         float part[DP_NW];
 #pragma unroll
-        for (int w = 0; w < DP_NW; ++w) part[w] = ld1_sc1(plog_rs, (w < L.NWA && pv < V) ? (int)(po + (unsigned)(w * DP_R * 32 * 4)) : P_OOB);
+        for (int w = 0; w < DP_NW; ++w) part[w] = ld1_sc1(plog_rs, (w < NWL && pv < V) ? (int)(po + (unsigned)(w * DP_R * 32 * 4)) : P_OOB);
 #pragma unroll
         for (int w = 0; w < DP_NW; ++w) z += part[w];
         const bool valid = l < s_int[R + pr];
@@ -683,6 +767,7 @@ int g_dec_fused = 1;
 static const void* dp_kernel(int variant, int mode) {
 #define DPK(a, b) (mode == 0 ? (const void*)dec_persist_kernel<a, b, 0, 8> : mode == 1 ? (const void*)dec_persist_kernel<a, b, 1, 8> : (const void*)dec_persist_kernel<a, b, 2, 8>)
   if (variant == 3) return (const void*)dec_persist_kernel<2, 0, 0, 16>;
+  if (variant == 4) return mode == 1 ? (const void*)dec_persist_kernel<4, 0, 1, 8, true> : (const void*)dec_persist_kernel<4, 0, 2, 8, true>;   // Bahdanau decoders
   return variant == 0 ? DPK(4, 0) : variant == 1 ? DPK(1, 4) : DPK(4, 1);
 #undef DPK
 }
@@ -695,7 +780,9 @@ int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* lds_bytes
   if (d.cell != 0 || d.n_extra != 0 || d.n_mech < 1 || d.n_mech > 2 || d.mode < 0 || d.mode > 2) return AVSR_ERR_UNSUPPORTED;
   const int B = d.B, H = d.H, E = d.E, A = d.n_mech * H, KW = E + A + H;
   if (H > 256 || H % 4 || E % 4 || (d.mode != 0 && (E > 128 || d.V > 32))) return AVSR_ERR_UNSUPPORTED;   // mode 0: inputs hoisted, no logits
-  if (d.mode >= 1 && !d.output_attention) return AVSR_ERR_UNSUPPORTED;
+  const bool bah = d.n_mech == 1 && d.mech[0].type >= ATT_BAHDANAU;       // (normed) Bahdanau: one mechanism, decoder modes only
+  if (bah && (d.mode < 1 || d.output_attention || !d.mech[0].v || !d.mech[0].wq_t || !d.mech[0].pq)) return AVSR_ERR_UNSUPPORTED;
+  if (d.mode >= 1 && !d.output_attention && !bah) return AVSR_ERR_UNSUPPORTED;
   const int nx = d.mode == 0 ? 0 : (E + 15) / 16, NC = nx + (A + 15) / 16 + (H + 15) / 16;
   if ((NC + DP_WV - 1) / DP_WV > DP_CPW) return AVSR_ERR_UNSUPPORTED;
   if (H % 16 || E % 16) return AVSR_ERR_UNSUPPORTED;           // 16-wide operand chunks never straddle a source
@@ -722,16 +809,17 @@ int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* lds_bytes
   L.cid4 = (uint32_t)d.cell_id * 4;
   if (L.drop && (!d.hs_seq || !d.attd)) return AVSR_ERR_UNSUPPORTED;
   float* ws = d.fused_ws;
-  L.plog = ws; ws += (long)((B + DP_R - 1) / DP_R) * DP_NW * DP_R * 32;
+  L.plog = ws; ws += (long)((B + DP_R - 1) / DP_R + 16) * DP_NW * DP_R * 32;      // logit shares: [2 parities][8 groups of a slice][32][8][32]
   int lds_off = 0;
   for (int m = 0; m < d.n_mech; ++m) {
     const avsr_attn_mech& M = d.mech[m];
-    if (M.type > ATT_SCALED_LUONG || M.D > 256 || M.D % 16 || M.T <= 0) return AVSR_ERR_UNSUPPORTED;
+    if ((M.type > ATT_SCALED_LUONG && !bah) || M.D > 256 || M.D % 16 || M.T <= 0) return AVSR_ERR_UNSUPPORTED;
     if ((H + 15) / 16 + (M.D + 15) / 16 > DP_WV * DP_APW) return AVSR_ERR_UNSUPPORTED;
     if ((long)B * M.T * H >= (1L << 29)) return AVSR_ERR_UNSUPPORTED;
     DPMech& X = L.m[m];
     X.keys = M.keys; X.values = M.values; X.values_sb = M.values_sb; X.values_st = M.values_st; X.len = M.len; X.g = M.g;
     X.watt_t = M.watt_t; X.scores = M.scores; X.ctx = M.ctx; X.pstat = M.pstat;
+    X.v = M.v; X.bq = (M.type == ATT_NORMED_BAHDANAU) ? M.bq : nullptr; X.wq_t = M.wq_t; X.pq = M.pq;
     X.T = M.T; X.D = M.D; X.type = M.type; X.nc_rec = (M.T + M.chunk - 1) / M.chunk; X.ch = (M.T + wpr - 1) / wpr;
     if (X.ch > 128) return AVSR_ERR_UNSUPPORTED;
     X.lds_off = lds_off; lds_off += X.ch * M.D;
@@ -742,7 +830,10 @@ int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* lds_bytes
   *lds_bytes = bytes;
   // register-resident key capacity (32 frames per pass): variant 0 = one mechanism up to 128 frames per quarter;
   // 1 = (<= 32, <= 128); 2 = (<= 128, <= 32)
-  if (L.R == 16) *variant = 3;
+  L.bah = bah ? 1 : 0;
+  if (bah && (L.R != 8 || L.m[0].ch > 128)) return AVSR_ERR_UNSUPPORTED;
+  if (bah) *variant = 4;
+  else if (L.R == 16) *variant = 3;
   else if (d.n_mech == 1) *variant = 0;
   else if (L.m[0].ch <= 32 && L.m[1].ch <= 128) *variant = 1;
   else if (L.m[0].ch <= 128 && L.m[1].ch <= 32) *variant = 2;
@@ -756,7 +847,7 @@ int64_t avsr_dec_persist_bwd_ws_floats(int32_t B, int32_t n_mech);
 
 // forward region of the fused workspace (the backward kernel's partials follow it)
 int64_t avsr_dec_persist_fwd_ws_floats(int32_t B, int32_t n_mech, int32_t Dmax) {
-  const int64_t groups = (B + DP_R - 1) / DP_R;
+  const int64_t groups = (B + DP_R - 1) / DP_R + 16;
   return groups * DP_NW * DP_R * 32 + (int64_t)n_mech * (8L * B + 4L * B * Dmax) + 64;
 }
 
@@ -787,11 +878,11 @@ int avsr_dec_persist_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32_t l_end
   if (l_begin >= l_end) return AVSR_OK;
   hipStream_t s = (hipStream_t)stream;
   int32_t* sync = g_sync;
-  const long words = P_HDR + 8 + 8 * 3 * 32;
+  const long words = P_HDR + 8 + 8 * 4 * 32;
   if (words > g_sync_ints) return AVSR_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    for (int v = 0; v < 4; ++v)
+    for (int v = 0; v < 5; ++v)
       for (int md = 0; md < 3; ++md)
         if (hipFuncSetAttribute(dp_kernel(v, md), hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES) != hipSuccess) return AVSR_ERR_HIP;
     attr_set = true;

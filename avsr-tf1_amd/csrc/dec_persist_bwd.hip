@@ -549,6 +549,7 @@ int avsr_dec_persist_bwd(const avsr_attn_rnn* dp, void* stream) {
   if (g_dec_fused == 2) return AVSR_ERR_UNSUPPORTED;
   int rc = dp_plan(d, F, &variant, &lds);
   if (rc) return rc;
+  if (F.bah) return AVSR_ERR_UNSUPPORTED;          // Bahdanau blocks: fused forward, per-step BPTT
   if (!d.w || !d.dgates || !d.dstate || !d.datt) return AVSR_ERR_ARG;
   if (avsr_dec_persist_fwd_ws_floats(d.B, d.n_mech, 256) + avsr_dec_persist_bwd_ws_floats(d.B, d.n_mech) > d.fused_ws_floats) return AVSR_ERR_UNSUPPORTED;
   if ((long)d.B * d.L * d.H * 16 >= (1L << 31) || (long)((d.B + 15) / 16) * 16 * DP_NW * DB_PART * 4 >= (1L << 31) ||

@@ -22,6 +22,16 @@ CASES = {
                                     video_feat=128, audio_feat=80, use_dropout=True, sampling_probability=0.1, regress_aus=True), 64, 60, 20, 10),
     "long_memory_quarters_of_125": (dict(architecture="unimodal", video_units=None, audio_units=(64,), decoder_units=(64,), embedding_size=16),
                                     3, 500, 0, 5),
+    # Bahdanau family (attention.py:25-42; output_attention False: logits from the cell output): fused forward with the processed-query
+    # phase, per-step BPTT
+    "unimodal_bahdanau": (dict(architecture="unimodal", video_units=None, audio_units=(32, 32), attention_type=(("bahdanau",), ("bahdanau",)),
+                               sampling_probability=0.25), 9, 41, 0, 8),
+    "unimodal_normed_bahdanau_dropout_bi": (dict(architecture="unimodal", encoder_type="bidirectional", video_units=None, audio_units=(32,),
+                                                 decoder_units=(64,), attention_type=(("normed_bahdanau",), ("normed_bahdanau",)),
+                                                 use_dropout=True, sampling_probability=0.2), 11, 70, 0, 6),
+    "c2_width_bahdanau": (dict(architecture="unimodal", encoder_type="bidirectional", video_units=None, audio_units=(128,), decoder_units=(256,),
+                               embedding_size=128, audio_feat=80, attention_type=(("bahdanau",), ("bahdanau",)), use_dropout=True,
+                               sampling_probability=0.1), 64, 130, 0, 8),
 }
 
 
