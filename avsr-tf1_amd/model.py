@@ -353,8 +353,21 @@ class Seq2SeqModel:
                 chunk *= 2
             nc = (T + chunk - 1) // chunk
             m = {"stream": stream, "type": att_type, "prefix": pre, "T": T, "D": D, "chunk": chunk, "nc": nc}
-            m.update(keys=z(B, T, H), dkeys=z(B, T, H), scores=z(B, L, T), dscores=z(B, L, T), ctx=z(B, L, D), dctx=z(B, L, D),
-                     pstat=z(L, 2, nc, B), pctx=z(nc, B, D), pdq=z(nc, B, H), rowdot=z(B * L))
+            # Memories wider than 256 (the [fw | bw] outputs of bidirectional 256-unit encoders) are attended through their PROJECTION:
+            # the attention layer is linear, att = h.W_h + (sum_t alpha_t v_t).W_ctx = h.W_h + sum_t alpha_t (v_t.W_ctx), so the loop
+            # attends pvals = values.W_ctx [B,T,H] (one GEMM per pass) with the attention layer [W_h ; I]: same attention vector, half
+            # the bytes per frame, and the block fits the fused persistent decode kernels (values resident in LDS, D <= 256).  The
+            # `ctx` / `dctx` records then hold the projected context and its gradient (= d attention); d W_ctx and d values come from
+            # d pvals after the loop.
+            m["proj"] = D > 256 and H <= 256
+            Dv = H if m["proj"] else D
+            m["Dv"] = Dv
+            if m["proj"]:
+                eye = torch.eye(H, device=dev)
+                m.update(pvals=z(B, T, H), dpvals=z(B, T, H), eye=eye, watt_p=torch.cat([z(H, H), eye], 0).contiguous(),
+                         watt_p_t=torch.cat([z(H, H), eye], 1).contiguous())
+            m.update(keys=z(B, T, H), dkeys=z(B, T, H), scores=z(B, L, T), dscores=z(B, L, T), ctx=z(B, L, Dv), dctx=z(B, L, Dv),
+                     pstat=z(L, 2, nc, B), pctx=z(nc, B, Dv), pdq=z(nc, B, H), rowdot=z(B * L))
             if att_type in BAHDANAU_TYPES:
                 m.update(pq=z(B, L, H), dpq=z(B, L, H), vn=z(H), dvn=z(H), dv_part=z(((T + 15) // 16) * B, H))
             blk["mems"].append(m)
@@ -907,9 +920,12 @@ class Seq2SeqModel:
             md = self._mem_desc(ws, m["stream"])
             M = d.mech[i]
             pre = m["prefix"]
-            M.type, M.T, M.D, M.chunk = ATT_CODE[m["type"]], m["T"], m["D"], m["chunk"]
+            M.type, M.T, M.D, M.chunk = ATT_CODE[m["type"]], m["T"], m["Dv"], m["chunk"]
             M.len, M.keys = ops.fptr(md["len"]), ops.fptr(m["keys"])
-            M.values, M.values_sb, M.values_st = ops.fptr(md["t"], md["off"]), md["sb"], md["st"]
+            if m["proj"]:
+                M.values, M.values_sb, M.values_st = ops.fptr(m["pvals"]), m["T"] * H, H
+            else:
+                M.values, M.values_sb, M.values_st = ops.fptr(md["t"], md["off"]), md["sb"], md["st"]
             if m["type"] == "scaled_luong":
                 M.g = ops.fptr(self.params, self.P[pre + "/g"].off)
             if m["type"] in BAHDANAU_TYPES:
@@ -920,8 +936,11 @@ class Seq2SeqModel:
                 M.wq_t = ops.fptr(self.derived, self.Tr[pre + "/query_kernel"].off)
                 M.wq = ops.fptr(self.params, self.P[pre + "/query_kernel"].off)
                 M.pq, M.dpq = ops.fptr(m["pq"]), ops.fptr(m["dpq"])
-            M.watt_t = ops.fptr(self.derived, self.Tr[pre + "/layer_kernel"].off)
-            M.watt = ops.fptr(self.params, self.P[pre + "/layer_kernel"].off)
+            if m["proj"]:
+                M.watt_t, M.watt = ops.fptr(m["watt_p_t"]), ops.fptr(m["watt_p"])
+            else:
+                M.watt_t = ops.fptr(self.derived, self.Tr[pre + "/layer_kernel"].off)
+                M.watt = ops.fptr(self.params, self.P[pre + "/layer_kernel"].off)
             M.scores, M.ctx, M.pstat, M.pctx = ops.fptr(m["scores"]), ops.fptr(m["ctx"]), ops.fptr(m["pstat"]), ops.fptr(m["pctx"])
             if with_bwd:
                 M.dscores, M.dctx, M.pdq = ops.fptr(m["dscores"]), ops.fptr(m["dctx"]), ops.fptr(m["pdq"])
@@ -960,6 +979,11 @@ class Seq2SeqModel:
             md = self._mem_desc(ws, m["stream"])
             pre = m["prefix"]
             ops.gemm(md["vmat"], self.P[pre + "/memory_kernel"].mat(H), ops.mat(m["keys"], H), B * m["T"], H, m["D"])
+            if m["proj"]:
+                Wl = self.P[pre + "/layer_kernel"]
+                ops.gemm(md["vmat"], Wl.mat(H, row0=H), ops.mat(m["pvals"], H), B * m["T"], H, m["D"])          # pvals = values . W_ctx
+                ops.copy_(m["watt_p"].view(-1)[:H * H], Wl.t[Wl.off:Wl.off + H * H])                              # [W_h ; I]
+                ops.gemm(Wl.mat(H), ops.mat(m["eye"], H), ops.mat(m["watt_p_t"], 2 * H), H, H, H, trans_a=1)      # [W_h^T | I]
             if m["type"] == "normed_bahdanau":
                 ops.normed_v(self._pp(pre + "/v"), self._pp(pre + "/g"), m["vn"], H)
 
@@ -978,16 +1002,25 @@ class Seq2SeqModel:
             datt_m = ops.mat(blk["datt"], A, offset=i * H)
             Gl = self.Gr[pre + "/layer_kernel"]
             self._gemm_tn(co.mat(0), datt_m, Gl.mat(H), H, H, rows)                 # rows 0..H: cell_out part
-            self._gemm_tn(ops.mat(m["ctx"], D), datt_m, Gl.mat(H, row0=H), D, H, rows)   # rows H..H+D: context part
+            if not m["proj"]:
+                self._gemm_tn(ops.mat(m["ctx"], D), datt_m, Gl.mat(H, row0=H), D, H, rows)   # rows H..H+D: context part
             luong = m["type"] in LUONG_TYPES
             g_t = self._pp(pre + "/g") if m["type"] == "scaled_luong" else None
             # scores -> alpha (in place); rowdot = sum_t ds * raw  (d g for scaled_luong)
             ops.attn_alpha_rows(m["scores"], m["dscores"], md["len"], desc_steplen(desc), g_t if luong else None, m["rowdot"], B, L, T)
             if m["type"] == "scaled_luong":
                 ops.reduce_scalar(m["rowdot"], rows, self.grads, accumulate=True, out_offset=self.Gr[pre + "/g"].off)
-            # d values[b,t,:] += sum_l alpha[b,l,t] * dctx[b,l,:]        (batched over b)
-            ops.gemm(ops.mat(m["scores"], T), ops.mat(m["dctx"], D), ops.mat(md["gt"], md["st"], offset=md["goff"]), T, D, L,
-                     trans_a=1, beta=1.0, batch=B, strides=(L * T, L * D, md["gsb"]))
+            if m["proj"]:
+                # d pvals[b,t,:] = sum_l alpha[b,l,t] * dctx'[b,l,:];  d W_ctx = values^T . d pvals;  d values += d pvals . W_ctx^T
+                Wl = self.P[pre + "/layer_kernel"]
+                ops.gemm(ops.mat(m["scores"], T), ops.mat(m["dctx"], H), ops.mat(m["dpvals"], H), T, H, L,
+                         trans_a=1, batch=B, strides=(L * T, L * H, T * H))
+                self._gemm_tn(md["vmat"], ops.mat(m["dpvals"], H), Gl.mat(H, row0=H), D, H, B * T)
+                ops.gemm(ops.mat(m["dpvals"], H), Wl.mat(H, row0=H), md["gmat"], B * T, D, H, trans_b=1, beta=1.0)
+            else:
+                # d values[b,t,:] += sum_l alpha[b,l,t] * dctx[b,l,:]        (batched over b)
+                ops.gemm(ops.mat(m["scores"], T), ops.mat(m["dctx"], D), ops.mat(md["gt"], md["st"], offset=md["goff"]), T, D, L,
+                         trans_a=1, beta=1.0, batch=B, strides=(L * T, L * D, md["gsb"]))
             if luong:
                 # d keys[b,t,:] = g * sum_l ds[b,l,t] * cell_out[b,l,:]
                 ops.gemm(ops.mat(m["dscores"], T), ops.mat(co.t, H, offset=co.off(0)), ops.mat(m["dkeys"], H), T, H, L,

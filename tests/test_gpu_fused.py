@@ -22,6 +22,12 @@ CASES = {
                                     video_feat=128, audio_feat=80, use_dropout=True, sampling_probability=0.1, regress_aus=True), 64, 60, 20, 10),
     "long_memory_quarters_of_125": (dict(architecture="unimodal", video_units=None, audio_units=(64,), decoder_units=(64,), embedding_size=16),
                                     3, 500, 0, 5),
+    # memories wider than 256 (bidirectional encoders): attended through their projection values . W_ctx (model.py `proj`), which is what
+    # makes these blocks fit the fused kernels; train step, records and greedy ids must still equal the oracle's plain formulation
+    "wide_bi_memory_projected": (dict(architecture="unimodal", encoder_type="bidirectional", video_units=None, audio_units=(160,),
+                                      decoder_units=(64,), embedding_size=16, use_dropout=True, sampling_probability=0.2), 10, 45, 0, 7),
+    "wide_bi_memories_bimodal_projected": (dict(architecture="bimodal", encoder_type="bidirectional", video_units=(144,), audio_units=(160,),
+                                                decoder_units=(48,), embedding_size=16, regress_aus=True), 6, 33, 11, 6),
     # Bahdanau family (attention.py:25-42; output_attention False: logits from the cell output): fused forward with the processed-query
     # phase, per-step BPTT
     "unimodal_bahdanau": (dict(architecture="unimodal", video_units=None, audio_units=(32, 32), attention_type=(("bahdanau",), ("bahdanau",)),
