@@ -36,10 +36,13 @@ struct PTask {
   float* xt_w; long xt_sb, xt_st;           // this layer's output as ITS consumer sees it (dropout only)
   float* h_final; float* c_final;
   int* done; const int* done_lower;         // arrival counters [nrt][T]
-  int B, T, H, in, hoisted, reverse, nct, nct_lower, wg_begin, nrt, uw;
+  int B, T, H, in, hoisted, reverse, nct, nct_lower, wg_begin, nrt, uw, part;
   const int32_t* seed; float k_st, k_out, k_in; uint32_t r_st, r_out, r_in; int in_W, in_coff;
 };
-struct PLaunch { int ntask, wpx, ngroups, b0; int* err; int* claim; PTask task[P_MAX_TASKS]; };   // b0: first batch row of this launch
+// b0: first batch row of this launch.  npart = 2 (XCD-local kernel only): the launch holds TWO independent stacks (the directions of
+// a bidirectional encoder) that do not fit one XCD together: stack 0 lives on XCDs 0-3, stack 1 on XCDs 4-7, each in 16-row groups
+// (<= 64 utterances), wg_begin counted per stack, pwg[p] = workgroups of stack p per XCD.
+struct PLaunch { int ntask, wpx, ngroups, b0, npart, pwg[2]; int* err; int* claim; PTask task[P_MAX_TASKS]; };
 
 // bounded wait for (*c0 >= n0 && *c1 >= n1): both counters are fetched in the same round trip
 __device__ __forceinline__ bool wait_ge2(const int* c0, int n0, const int* c1, int n1, int* err) {
@@ -293,16 +296,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   __shared__ __attribute__((aligned(16))) float red[4][4][R][16];
   __shared__ int s_slot;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = __builtin_amdgcn_readfirstlane(xcc_id());
-  if (tid == 0) s_slot = __hip_atomic_fetch_add(L.claim + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int gx = __builtin_amdgcn_readfirstlane(xcc_id());
+  if (tid == 0) s_slot = __hip_atomic_fetch_add(L.claim + gx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const int slot = __builtin_amdgcn_readfirstlane(s_slot);
-  if (g >= L.ngroups || slot >= L.wpx) return;
-  int ti = 0;
+  const int part = L.npart == 2 ? gx >> 2 : 0;      // which stack this XCD works for
+  const int g = L.npart == 2 ? gx & 3 : gx;         // row group of that stack
+  if (g >= L.ngroups || slot >= (L.npart == 2 ? L.pwg[part] : L.wpx)) return;
+  int ti = -1;
 #pragma unroll
-  for (int i = 1; i < P_MAX_TASKS; ++i)
-    if (i < L.ntask && slot >= L.task[i].wg_begin) ti = i;
+  for (int i = 0; i < P_MAX_TASKS; ++i)
+    if (i < L.ntask && L.task[i].part == part && slot >= L.task[i].wg_begin) ti = i;
   ti = __builtin_amdgcn_readfirstlane(ti);
+  if (ti < 0) return;
   const PTask& tk = L.task[ti];
   const int ct = slot - tk.wg_begin;
   const int UW = tk.uw, uw_shift = UW == 16 ? 4 : 3;
@@ -358,11 +364,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(tk.x_r), h_rs = make_rsrc(tk.hs_r), z_rs = make_rsrc(tk.gates);
   const bool has_low = !hoisted;
   // progress words: 32 per (task, group); wave 0 polls own (lanes 0-31) and lower (lanes 32-63) in one load
-  int* const my_flag = tk.done + g * 32 + ct;
+  int* const my_flag = tk.done + gx * 32 + ct;    // progress words are per (task, XCD)
   const int* poll_ptr = nullptr;
   if (wave == 0) {
-    if (lane < 32) { if (lane < tk.nct) poll_ptr = tk.done + g * 32 + lane; }
-    else if (has_low && lane - 32 < tk.nct_lower) poll_ptr = tk.done_lower + g * 32 + (lane - 32);
+    if (lane < 32) { if (lane < tk.nct) poll_ptr = tk.done + gx * 32 + lane; }
+    else if (has_low && lane - 32 < tk.nct_lower) poll_ptr = tk.done_lower + gx * 32 + (lane - 32);
   }
   const int rec_b = b * T * H + u;
   const int out_b = (int)(b * tk.out_sb) + u, hsw_b = (int)(b * tk.hs_sb) + u, xtw_b = (int)(b * tk.xt_sb) + u;
@@ -547,15 +553,18 @@ namespace avsr {
 // Fill the task table for one persistent launch.  local = XCD-local variant (8-row groups, progress words),
 // else the agent-scope variant (16-row tiles, arrival counters).  Returns AVSR_ERR_UNSUPPORTED if it does not fit.
 static double g_fwd_flops = 0.0;      // algorithmic FLOPs of the launch being built (event profiler)
-static int build_tasks(const avsr_rnn_stack* st, int n, bool local, int32_t* sync, int64_t sync_ints, PLaunch& L, int* wg_out, long* words_out) {
+static int build_tasks(const avsr_rnn_stack* st, int n, bool local, int32_t* sync, int64_t sync_ints, PLaunch& L, int* wg_out, long* words_out,
+                       bool parts = false) {
   L = PLaunch{};
   g_fwd_flops = 0.0;
+  if (parts && (!local || n != 2 || st[0].B > 64)) return AVSR_ERR_UNSUPPORTED;
   int wg = 0;
   long ctr = P_HDR + 8;                 // [P_HDR, P_HDR+8): per-XCD slot claim counters
   for (int i = 0; i < n; ++i) {
     const avsr_rnn_stack& S = st[i];
     if (S.cell != 0 || S.B != st[0].B) return AVSR_ERR_UNSUPPORTED;
     const int nrt = local ? (S.B + 7) / 8 : (S.B + 15) / 16;
+    if (parts) { if (i == 1) L.pwg[0] = wg; wg = 0; }       // workgroup slots are counted per stack
     for (int l = 0; l < S.n_layers; ++l) {
       const avsr_rnn_layer& Ly = S.layer[l];
       if (L.ntask >= P_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
@@ -582,7 +591,7 @@ static int build_tasks(const avsr_rnn_stack* st, int n, bool local, int32_t* syn
       tk.B = S.B; tk.T = S.T; tk.H = H; tk.in = in; tk.hoisted = Ly.hoisted; tk.reverse = S.reverse;
       g_fwd_flops += 2.0 * S.B * S.T * ((Ly.hoisted ? 0 : in) + H) * 4.0 * H;
       tk.uw = (local && Ly.hoisted && H % 16 == 0) ? 16 : 8;
-      tk.nct = H / tk.uw; tk.nrt = nrt; tk.wg_begin = wg;
+      tk.nct = H / tk.uw; tk.nrt = nrt; tk.wg_begin = wg; tk.part = parts ? i : 0;
       if (tk.nct > 32) return AVSR_ERR_UNSUPPORTED;
       wg += local ? tk.nct : nrt * tk.nct;
       tk.done = sync + ctr;
@@ -600,6 +609,11 @@ static int build_tasks(const avsr_rnn_stack* st, int n, bool local, int32_t* syn
   // co-residency: every workgroup of the launch must be resident at once (they wait on each other).
   // agent-scope kernel: <= 2 per CU chip-wide; XCD-local kernel: <= 3 per CU of one XCD (its VGPR budget admits 3).
   if (ctr > sync_ints) return AVSR_ERR_UNSUPPORTED;
+  if (parts) {
+    L.pwg[1] = wg; L.npart = 2;
+    if (L.pwg[0] > 96 || L.pwg[1] > 96) return AVSR_ERR_UNSUPPORTED;
+    wg = L.pwg[0] > L.pwg[1] ? L.pwg[0] : L.pwg[1];
+  }
   if (local ? wg > 96 : wg > 512) return AVSR_ERR_UNSUPPORTED;
   L.err = sync; L.claim = sync + P_HDR; L.wpx = wg; L.ngroups = 0; L.b0 = 0;
   *wg_out = wg; *words_out = ctr;
@@ -637,6 +651,21 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
       }
       AVSR_CHECK_LAUNCH();
     }
+    return AVSR_OK;
+  }
+  // two stacks that do not fit one XCD together (the directions of a bidirectional encoder), <= 64 utterances: one launch, each
+  // stack on four XCDs in 16-row groups -- the directions run side by side instead of one after the other
+  static const int parts_on = getenv("AVSR_RNN_PARTS") ? atoi(getenv("AVSR_RNN_PARTS")) : 1;
+  if ((g_persist_mode & 2) && parts_on && build_tasks(st, n, true, sync, sync_ints, L, &wg, &words, true) == AVSR_OK) {
+    if (dry) return AVSR_OK;
+    const int B = st[0].B;
+    L.b0 = 0; L.ngroups = (B + 15) / 16;
+    if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
+    {
+      ProfScope ps(PROF_RNN_PERSIST_FWD, s, g_fwd_flops);
+      hipLaunchKernelGGL(rnn_persist_fwd_xcd_kernel<16>, dim3(8 * wg), dim3(256), 0, s, L);
+    }
+    AVSR_CHECK_LAUNCH();
     return AVSR_OK;
   }
   if ((g_persist_mode & 1) && build_tasks(st, n, false, sync, sync_ints, L, &wg, &words) == AVSR_OK) {
