@@ -602,7 +602,7 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
   static thread_local SlabLaunch BL;
   // the whole loop as one persistent launch where the fused kernel covers the block (csrc/dec_persist_bwd.hip)
   bool fused = false;
-  if (A > 0 && !gru && NX == 0 && n_bah == 0) {
+  if (A > 0 && !gru && NX == 0) {                 // (Luong blocks, and one-memory Bahdanau blocks)
     const int frc = avsr_dec_persist_bwd(dp, stream);
     if (frc == AVSR_OK) fused = true;
     else if (frc != AVSR_ERR_UNSUPPORTED) return frc;

@@ -29,6 +29,7 @@ struct DBMech {
   const float* keys; const float* values; long values_sb, values_st; const int* len; const float* g; const float* watt_t;
   const float* scores; const float* ctx; const float* pstat;       // forward records [B][L][T], [B][L][D], [L][2][nc_rec][B]
   float* dscores; float* dctx; float* pdq;                         // records [B][L][T], [B][L][D]; quarter partials [4][B][H]
+  const float* v; const float* bq; const float* wq; const float* pq; float* dpq;   // Bahdanau: v, bias (normed), query layer [H][H], pq / d pq records [B][L][H]
   int T, D, type, nc_rec, ch, lds_off;
 };
 
@@ -59,8 +60,12 @@ __device__ __forceinline__ float xor32_sum(float v) {
 }
 
 // R: rows per group (8, or 16 = a full MFMA row tile for the attentive layer; see dec_persist.hip)
-template <int KR0, int KR1, int R>
+// BAH: the block's one mechanism is (normed) Bahdanau: the quarter partial of phase B is the gradient of the PROCESSED query
+// (d pq[h] = sum_t ds_t v[h] (1 - tanh^2(keys_t[h] + pq[h] + b[h]))), and phase C pulls it through the query layer (d q = d pq . W_q^T,
+// an MFMA product over this workgroup's units) before the cell backward; the d pq record feeds the post-loop d W_q GEMM.
+template <int KR0, int KR1, int R, bool BAH = false>
 __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L) {
+  static_assert(!BAH || (R == 8 && KR1 == 0), "Bahdanau: one mechanism, 8-row groups");
   constexpr int WPR = DP_NW / R;                // workgroups per row in the attention phase
   constexpr int RQ = R / 4;                     // lane groups q < RQ hold real rows of a C tile
   constexpr int RED_F = 256 * R;                // [8 waves][2 tiles][R][16]
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
   // ---------------------------------------------------------------------------------------------------------
   // resident operands
   // ---------------------------------------------------------------------------------------------------------
-  f32x4 wp[DB_KPW][2], wb[4];
+  f32x4 wp[DB_KPW][2], wb[4], wqb[2];
   f32x4 k0[KR0 > 0 ? KR0 : 1][4], k1[KR1 > 0 ? KR1 : 1][4];
   int n_m[2] = {0, 0}, t0_m[2] = {0, 0};
   const int r_att = j / WPR, cq = j % WPR;
@@ -138,6 +143,14 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
       for (int e = 0; e < 4; ++e)
         if (has_att && n < ncols && 4 * q + e < AW) v[e] = Ma.watt_t[(long)(nl0 + 4 * q + e) * ncols + n];
       wb[t] = v;
+    }
+    // (2b) Bahdanau: rows [unit0, unit0 + UW) of the query layer (d q[n] = sum_k d pq[k] W_q[n][k]); K = H split over the waves
+    wqb[0] = zero4; wqb[1] = zero4;
+    if constexpr (BAH) {
+      const int nqc = H >> 4, qg0 = (wave * nqc) / DP_WV, nqw = ((wave + 1) * nqc) / DP_WV - qg0;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+        wqb[cc] = (cc < nqw && i < UW && unit0 + i < H) ? ld4(L.m[0].wq + (long)(unit0 + i) * H + ((qg0 + cc) << 4) + 4 * q) : zero4;
     }
     // (3) attention memories of row r_att, quarter cq: keys -> registers (16 lanes per frame), values -> LDS
 #pragma unroll
@@ -417,14 +430,36 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
         if (m >= L.n_mech) continue;
         const DBMech& M = L.m[m];
         f32x4 pa[4] = {zero4, zero4, zero4, zero4};
-        if (m == 0) {
+        if constexpr (BAH) if (m == 0) {
+          f32x4 v4[4], pb4[4];
+          const float* pqr = M.pq + ((long)b_att * Ls + l) * H;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const bool in = att_row && 4 * s16 + 64 * jj < H;
+            v4[jj] = in ? ld4(M.v + 4 * s16 + 64 * jj) : zero4;
+            pb4[jj] = in ? ld4(pqr + 4 * s16 + 64 * jj) : zero4;
+            if (in && M.bq) pb4[jj] += ld4(M.bq + 4 * s16 + 64 * jj);
+          }
+#pragma unroll
+          for (int u = 0; u < KR0; ++u) {
+            const float dsf = s_ds[rg + 32 * u];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float th = p_tanh(k0[u][jj][e] + pb4[jj][e]);
+                pa[jj][e] += dsf * v4[jj][e] * (1.f - th * th);
+              }
+          }
+        }
+        if (!BAH && m == 0) {
 #pragma unroll
           for (int u = 0; u < KR0; ++u) {
             const float dsf = s_ds[rg + 32 * u];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) pa[jj] += dsf * k0[u][jj];
           }
-        } else {
+        } else if (m != 0) {
 #pragma unroll
           for (int u = 0; u < KR1; ++u) {
             const float dsf = s_ds[128 + rg + 32 * u];
@@ -474,6 +509,37 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
       }
       const float c = c_c, cprev = c_prev, dext = c_dext;
       const f32x4 g4 = c_g4;
+      float dq_bah = 0.f;
+      if constexpr (BAH) {
+        // d pq of the 8 rows (sum of the four quarter partials) through the query layer: d q[r][unit] = sum_k d pq[r][k] W_q[unit][k]
+        const int nqc = H >> 4, qg0 = (wave * nqc) / DP_WV, nqw = ((wave + 1) * nqc) / DP_WV - qg0;
+        f32x4 a4[2] = {zero4, zero4};
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const unsigned ko = aok ? (unsigned)(((long)ab * H + ((qg0 + cc) << 4) + 4 * q) * 4) : (unsigned)P_OOB;
+#pragma unroll
+          for (int cqq = 0; cqq < 4; ++cqq)
+            a4[cc] += ldb_sc1(pdq0_rs, (cc < nqw && cqq < WPR) ? (int)(ko + (unsigned)((long)cqq * BH * 4)) : P_OOB);
+        }
+        f32x4 accq = zero4;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accq = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[cc][e], wqb[cc][e], accq, 0, 0, 0);
+        if (q < RQ) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(wave * R + q * 4 + r) * 16 + i] = accq[r];
+        }
+        lds_barrier();
+        if (tid < R * UW) {
+          const int o = er * 16 + eu;
+#pragma unroll
+          for (int w = 0; w < DP_WV; ++w) dq_bah += red[w * 16 * R + o];
+        }
+        lds_barrier();
+        // the d pq record of this step (post-loop d W_q GEMM, attention.py query_layer)
+        if (eok) L.m[0].dpq[bt * H + eun] = valid ? ((pd[0] + pd[1]) + (pd[2] + pd[3])) : 0.f;
+      }
       float dout = 0.f;
 #pragma unroll
       for (int w = 0; w < DP_NW / 2; ++w) dout += pq[w];
@@ -483,7 +549,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
 #pragma unroll
         for (int w = 0; w < DP_NW / 2; ++w) dout += pq[w];
       }
-      dout += ((pd[0] + pd[1]) + (pd[2] + pd[3])) + ((pd[4] + pd[5]) + (pd[6] + pd[7]));
+      if (BAH) dout += dq_bah;                          // the query gradient arrives through the query layer
+      else dout += ((pd[0] + pd[1]) + (pd[2] + pd[3])) + ((pd[4] + pd[5]) + (pd[6] + pd[7]));
       dout += dext;
       f32x4 dg = zero4;
       if (valid) {
@@ -524,6 +591,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
 
 static const void* db_kernel(int variant) {
   if (variant == 3) return (const void*)dec_persist_bwd_kernel<2, 0, 16>;
+  if (variant == 4) return (const void*)dec_persist_bwd_kernel<4, 0, 8, true>;
   return variant == 0 ? (const void*)dec_persist_bwd_kernel<4, 0, 8> : variant == 1 ? (const void*)dec_persist_bwd_kernel<1, 4, 8>
                                                                                     : (const void*)dec_persist_bwd_kernel<4, 1, 8>;
 }
@@ -549,7 +617,7 @@ int avsr_dec_persist_bwd(const avsr_attn_rnn* dp, void* stream) {
   if (g_dec_fused == 2) return AVSR_ERR_UNSUPPORTED;
   int rc = dp_plan(d, F, &variant, &lds);
   if (rc) return rc;
-  if (F.bah) return AVSR_ERR_UNSUPPORTED;          // Bahdanau blocks: fused forward, per-step BPTT
+  if (F.bah && (!d.mech[0].wq || !d.mech[0].dpq || !d.mech[0].pq || !d.mech[0].v)) return AVSR_ERR_ARG;
   if (!d.w || !d.dgates || !d.dstate || !d.datt) return AVSR_ERR_ARG;
   if (avsr_dec_persist_fwd_ws_floats(d.B, d.n_mech, 256) + avsr_dec_persist_bwd_ws_floats(d.B, d.n_mech) > d.fused_ws_floats) return AVSR_ERR_UNSUPPORTED;
   if ((long)d.B * d.L * d.H * 16 >= (1L << 31) || (long)((d.B + 15) / 16) * 16 * DP_NW * DB_PART * 4 >= (1L << 31) ||
@@ -570,6 +638,7 @@ int avsr_dec_persist_bwd(const avsr_attn_rnn* dp, void* stream) {
     DBMech& X = L.m[m];
     X.keys = M.keys; X.values = M.values; X.values_sb = M.values_sb; X.values_st = M.values_st; X.len = M.len; X.g = M.g; X.watt_t = M.watt_t;
     X.scores = M.scores; X.ctx = M.ctx; X.pstat = M.pstat; X.dscores = M.dscores; X.dctx = M.dctx;
+    X.v = M.v; X.bq = (M.type == ATT_NORMED_BAHDANAU) ? M.bq : nullptr; X.wq = M.wq; X.pq = M.pq; X.dpq = M.dpq;
     X.pdq = ws; ws += 4L * d.B * 256;
     X.T = M.T; X.D = M.D; X.type = M.type; X.nc_rec = F.m[m].nc_rec; X.ch = F.m[m].ch; X.lds_off = F.m[m].lds_off;
     if ((long)d.B * d.L * M.D * 4 >= (1L << 31) || (long)d.B * d.L * M.T * 4 >= (1L << 31) || X.nc_rec > 64) return AVSR_ERR_UNSUPPORTED;
@@ -580,7 +649,7 @@ int avsr_dec_persist_bwd(const avsr_attn_rnn* dp, void* stream) {
   if (words > g_sync_ints) return AVSR_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    for (int v = 0; v < 4; ++v)
+    for (int v = 0; v < 5; ++v)
       if (hipFuncSetAttribute(db_kernel(v), hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES) != hipSuccess) return AVSR_ERR_HIP;
     attr_set = true;
   }

@@ -29,7 +29,7 @@ CASES = {
     "wide_bi_memories_bimodal_projected": (dict(architecture="bimodal", encoder_type="bidirectional", video_units=(144,), audio_units=(160,),
                                                 decoder_units=(48,), embedding_size=16, regress_aus=True), 6, 33, 11, 6),
     # Bahdanau family (attention.py:25-42; output_attention False: logits from the cell output): fused forward with the processed-query
-    # phase, per-step BPTT
+    # phase, fused BPTT pulling d pq through the query layer
     "unimodal_bahdanau": (dict(architecture="unimodal", video_units=None, audio_units=(32, 32), attention_type=(("bahdanau",), ("bahdanau",)),
                                sampling_probability=0.25), 9, 41, 0, 8),
     "unimodal_normed_bahdanau_dropout_bi": (dict(architecture="unimodal", encoder_type="bidirectional", video_units=None, audio_units=(32,),
@@ -103,7 +103,8 @@ def test_fused_decode_equals_per_step_launches_and_oracle(name):
 
 
 @pytest.mark.parametrize("mode", [2, 3])
-@pytest.mark.parametrize("name", ["bimodal_dropout_sampling_2groups", "av_align", "c4_width_64_utterances", "long_memory_quarters_of_125"])
+@pytest.mark.parametrize("name", ["bimodal_dropout_sampling_2groups", "av_align", "c4_width_64_utterances", "long_memory_quarters_of_125",
+                                  "unimodal_normed_bahdanau_dropout_bi", "c2_width_bahdanau", "wide_bi_memory_projected"])
 def test_fused_forward_only_and_backward_only(name, mode):
     """avsr_attn_rnn_set_fused(2): fused forward, per-step BPTT; (3): per-step forward, fused BPTT (csrc/dec_persist_bwd.hip) -- the
     two kernels only share the record layouts, so each must also work on the other path's records."""
