@@ -106,6 +106,62 @@ __global__ void bn_bwd_apply_kernel(const float* x, const float* dy, const float
   }
 }
 
+// 16-byte versions for F | 1024 (every channel count of the lip CNN): a thread owns FOUR fixed channels -- the grid stride (1024 floats
+// per block) is a multiple of F -- so the per-channel constants are loaded once and there is no per-element modulo.
+// (The scalar kernels above spent a 64-bit modulo and six table loads per element: 4 TB/s on 600 MB maps.)
+__global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float* x, const float* dy, const float* gamma, const float* beta,
+                                                               const float* mean, const float* invstd, float* part, long n4, int F, int relu) {
+  __shared__ f32x4 red[2][256];
+  const int f = (int)((threadIdx.x * 4) % F);
+  const f32x4 m = ld4(mean + f), is = ld4(invstd + f), ga = ld4(gamma + f), be = ld4(beta + f);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 xv = ld4(x + i * 4), dv = ld4(dy + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xv[e] - m[e]) * is[e];
+      float d = dv[e];
+      if (relu && !(xh * ga[e] + be[e] > 0.f)) d = 0.f;
+      s1[e] += d;
+      s2[e] += d * xh;
+    }
+  }
+  red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+  __syncthreads();
+  const int tpf = F >> 2;                               // threads per channel period
+  if ((int)threadIdx.x < tpf) {                         // threads t, t + tpf, t + 2 tpf, ... own the same four channels
+    f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
+    for (int k = threadIdx.x; k < 256; k += tpf) { t1 += red[0][k]; t2 += red[1][k]; }
+    st4(part + (long)blockIdx.x * 2 * F + 4 * threadIdx.x, t1);
+    st4(part + (long)blockIdx.x * 2 * F + F + 4 * threadIdx.x, t2);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* x, const float* dy, const float* gamma, const float* beta,
+                                                             const float* mean, const float* invstd, const float* sums, float* dx, long n4,
+                                                             int rows, int F, int relu, float dx_beta) {
+  const int f = (int)((threadIdx.x * 4) % F);
+  const float inv_rows = 1.0f / (float)rows;
+  const f32x4 m = ld4(mean + f), is = ld4(invstd + f), ga = ld4(gamma + f), be = ld4(beta + f);
+  f32x4 c1 = ld4(sums + f), c2 = ld4(sums + F + f);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { c1[e] *= inv_rows; c2[e] *= inv_rows; }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 xv = ld4(x + i * 4), dv = ld4(dy + i * 4);
+    f32x4 o;
+    if (dx_beta != 0.f) o = ld4(dx + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xv[e] - m[e]) * is[e];
+      float d = dv[e];
+      if (relu && !(xh * ga[e] + be[e] > 0.f)) d = 0.f;
+      const float v = ga[e] * is[e] * (d - (c1[e] + xh * c2[e]));
+      o[e] = dx_beta != 0.f ? v + dx_beta * o[e] : v;
+    }
+    st4(dx + i * 4, o);
+  }
+}
+
 __global__ void relu_kernel(const float* x, float* y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = fmaxf(x[i], 0.f);
 }
@@ -179,14 +235,32 @@ extern "C" int avsr_batchnorm_bwd(const float* x, const float* dy, const float* 
     nblk = (rows + rpb - 1) / rpb;
   }
   float* part = scratch;
+  const long n = (long)rows * F;
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  const bool vec = F >= 4 && 1024 % F == 0 && al16(x) && al16(dy) && (!dx || al16(dx)) && al16(gamma) && al16(beta) && al16(mean) && al16(invstd) &&
+                   al16(scratch) && rows >= 4096;
+  if (vec) {
+    int vb = (int)((n / 4 + 255) / 256);
+    if (vb > 1024) vb = 1024;
+    if ((long)vb * 2 * F + 2 * F > scratch_floats) vb = (int)((scratch_floats - 2 * F) / (2L * F));
+    if (vb < 1) return AVSR_ERR_ARG;
+    nblk = vb;
+  }
   float* sums = scratch + (long)nblk * 2 * F;          // [2F]: sum dy' | sum dy' xhat
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, part, rows, F, rpb, relu);
+  if (vec) hipLaunchKernelGGL(bn_bwd_partial4_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, part, n / 4, F, relu);
+  else hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, part, rows, F, rpb, relu);
   AVSR_CHECK_LAUNCH();
   { const int rc = avsr_colsum_final_launch(part, nblk, sums, 2 * F, 1.0f, 0.0f, stream); if (rc) return rc; }
   if (dx) {
-    const long n = (long)rows * F;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for_n(n)), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, sums, dx, n, rows,
-                       F, relu, dx_beta);
+    if (vec) {
+      int ab = (int)((n / 4 + 255) / 256);
+      if (ab > 4096) ab = 4096;
+      hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(ab), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, sums, dx, n / 4, rows, F, relu,
+                         dx_beta);
+    } else {
+      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for_n(n)), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, sums, dx, n, rows,
+                         F, relu, dx_beta);
+    }
     AVSR_CHECK_LAUNCH();
   }
   if (dbeta && avsr::dev_copy(dbeta, sums, sizeof(float) * F, S_(stream)) != hipSuccess) return AVSR_ERR_HIP;

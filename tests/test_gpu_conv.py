@@ -95,7 +95,7 @@ def test_im2col_gemm_conv_and_col2im(N, H, Ci, Co, k, s):
     assert _close(dx.cpu().numpy(), x.grad.numpy(), 5e-5)
 
 
-@pytest.mark.parametrize("rows,F,relu", [(700, 8, 1), (5000, 16, 1), (333, 64, 0), (130000, 8, 1)])
+@pytest.mark.parametrize("rows,F,relu", [(700, 8, 1), (5000, 16, 1), (333, 64, 0), (130000, 8, 1), (6000, 64, 0), (4100, 12, 1), (40000, 32, 1)])
 def test_batchnorm_forward_backward(rows, F, relu):
     from avsr_tf1_amd import ops
     rng = np.random.default_rng(rows + F)
