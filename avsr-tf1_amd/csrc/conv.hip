@@ -92,7 +92,7 @@ __global__ void bn_bwd_partial_kernel(const float* x, const float* dy, const flo
 }
 
 __global__ void bn_bwd_apply_kernel(const float* x, const float* dy, const float* gamma, const float* beta, const float* mean,
-                                    const float* invstd, const float* sums, float* dx, long n, int rows, int F, int relu,
+                                    const float* invstd, const float* sum1, const float* sum2, float* dx, long n, int rows, int F, int relu,
                                     float dx_beta) {
   const float inv_rows = 1.0f / (float)rows;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -101,7 +101,7 @@ __global__ void bn_bwd_apply_kernel(const float* x, const float* dy, const float
     const float xh = (x[i] - mean[f]) * is;
     float d = dy[i];
     if (relu && !(xh * ga + beta[f] > 0.f)) d = 0.f;
-    const float v = ga * is * (d - (sums[f] + xh * sums[F + f]) * inv_rows);
+    const float v = ga * is * (d - (sum1[f] + xh * sum2[f]) * inv_rows);
     dx[i] = dx_beta != 0.f ? v + dx_beta * dx[i] : v;
   }
 }
@@ -138,12 +138,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float* x, co
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* x, const float* dy, const float* gamma, const float* beta,
-                                                             const float* mean, const float* invstd, const float* sums, float* dx, long n4,
-                                                             int rows, int F, int relu, float dx_beta) {
+                                                             const float* mean, const float* invstd, const float* sum1, const float* sum2, float* dx,
+                                                             long n4, int rows, int F, int relu, float dx_beta) {
   const int f = (int)((threadIdx.x * 4) % F);
   const float inv_rows = 1.0f / (float)rows;
   const f32x4 m = ld4(mean + f), is = ld4(invstd + f), ga = ld4(gamma + f), be = ld4(beta + f);
-  f32x4 c1 = ld4(sums + f), c2 = ld4(sums + F + f);
+  f32x4 c1 = ld4(sum1 + f), c2 = ld4(sum2 + f);
 #pragma unroll
   for (int e = 0; e < 4; ++e) { c1[e] *= inv_rows; c2[e] *= inv_rows; }
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -199,6 +199,8 @@ static inline int blocks_for_n(long n) {
 
 // out[f] = alpha * sum_i part[i][f] + beta * out[f]  (elementwise.hip)
 int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, float alpha, float beta, void* stream);
+int avsr_colsum_final_launch_split(const float* part, long ld, int nblk, float* out, float* out2, int split, int F, float alpha, float beta,
+                                   void* stream);
 
 using namespace avsr;
 #define S_(x) ((hipStream_t)(x))
@@ -250,21 +252,28 @@ extern "C" int avsr_batchnorm_bwd(const float* x, const float* dy, const float* 
   if (vec) hipLaunchKernelGGL(bn_bwd_partial4_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, part, n / 4, F, relu);
   else hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, part, rows, F, rpb, relu);
   AVSR_CHECK_LAUNCH();
-  { const int rc = avsr_colsum_final_launch(part, nblk, sums, 2 * F, 1.0f, 0.0f, stream); if (rc) return rc; }
+  // the reduced sums ARE d beta | d gamma: one reduction launch writes them where the caller wants them and the apply pass reads
+  // them from there (16-byte aligned destinations for the vector kernel; else through the scratch + two copies)
+  const bool direct = dbeta && dgamma && al16(dbeta) && al16(dgamma);
+  float* const s1 = direct ? dbeta : sums;
+  float* const s2 = direct ? dgamma : sums + F;
+  { const int rc = avsr_colsum_final_launch_split(part, 2L * F, nblk, s1, s2, F, 2 * F, 1.0f, 0.0f, stream); if (rc) return rc; }
   if (dx) {
     if (vec) {
       int ab = (int)((n / 4 + 255) / 256);
       if (ab > 4096) ab = 4096;
-      hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(ab), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, sums, dx, n / 4, rows, F, relu,
+      hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(ab), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, s1, s2, dx, n / 4, rows, F, relu,
                          dx_beta);
     } else {
-      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for_n(n)), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, sums, dx, n, rows,
+      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for_n(n)), dim3(256), 0, S_(stream), x, dy, gamma, beta, mean, invstd, s1, s2, dx, n, rows,
                          F, relu, dx_beta);
     }
     AVSR_CHECK_LAUNCH();
   }
-  if (dbeta && avsr::dev_copy(dbeta, sums, sizeof(float) * F, S_(stream)) != hipSuccess) return AVSR_ERR_HIP;
-  if (dgamma && avsr::dev_copy(dgamma, sums + F, sizeof(float) * F, S_(stream)) != hipSuccess) return AVSR_ERR_HIP;
+  if (!direct) {
+    if (dbeta && avsr::dev_copy(dbeta, sums, sizeof(float) * F, S_(stream)) != hipSuccess) return AVSR_ERR_HIP;
+    if (dgamma && avsr::dev_copy(dgamma, sums + F, sizeof(float) * F, S_(stream)) != hipSuccess) return AVSR_ERR_HIP;
+  }
   return AVSR_OK;
 }
 

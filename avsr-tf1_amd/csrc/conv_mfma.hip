@@ -763,6 +763,8 @@ int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int
 // Descriptor API (include/avsr_hip.h: avsr_conv_desc): k = 1 or 3, stride 1 or 2, 3..64 channels; BN-ReLU of the input applied by the
 // loader; kernels deeper than one wave's register budget run as several launches over tap groups (the later ones accumulate).
 int avsr_colsum_final_launch_ld(const float* part, long ld, int nblk, float* out, int F, float alpha, float beta, void* stream);
+int avsr_colsum_final_launch_split(const float* part, long ld, int nblk, float* out, float* out2, int split, int F, float alpha, float beta,
+                                   void* stream);
 
 static bool cd_ok(const avsr_conv_desc* c) {
   return c && c->N > 0 && (c->k == 1 || c->k == 3) && (c->stride == 1 || c->stride == 2) && c->Co % 4 == 0 && (c->Ci % 4 == 0 || c->Ci < 4) &&
@@ -985,13 +987,14 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
 #undef WG_GO
       if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
     }
-    int rc = avsr_colsum_final_launch_ld(scratch, A.slab, grid, dw + (long)t0 * Ci * Co, wF, 1.0f, beta, stream);
-    if (rc != AVSR_OK) return rc;
-    if (A.want_bias) {
-      rc = avsr_colsum_final_launch_ld(scratch + wF, A.slab, grid, dbias, Co, 1.0f, beta, stream);
-      if (rc != AVSR_OK) return rc;
+    int rc;
+    if (A.want_bias) {                                     // weight and bias gradients of the slab in one reduction launch
+      rc = avsr_colsum_final_launch_split(scratch, A.slab, grid, dw + (long)t0 * Ci * Co, dbias, wF, A.slab, 1.0f, beta, stream);
       bias_done = true;
+    } else {
+      rc = avsr_colsum_final_launch_ld(scratch, A.slab, grid, dw + (long)t0 * Ci * Co, wF, 1.0f, beta, stream);
     }
+    if (rc != AVSR_OK) return rc;
   }
   return AVSR_OK;
 }

@@ -80,7 +80,9 @@ __global__ void colsum_partial_kernel(const float* a, long lda, int Ta, long ldo
 }
 
 // one block per 32 columns: 32 row-groups x 32 columns of threads walk the partials (4 loads in flight), then an LDS tree
-__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* part, long ld, int nblk, float* out, int F, float alpha, float beta) {
+// columns f < split go to out[f], the rest to out2[f - split] (split = F: one destination)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* part, long ld, int nblk, float* out, int F, float alpha, float beta,
+                                                            float* out2 = nullptr, int split = 0x7fffffff) {
   __shared__ double red[32][33];
   const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int f = blockIdx.x * 32 + fl;
@@ -101,7 +103,8 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* part, l
 #pragma unroll
     for (int j = 0; j < 32; ++j) t += red[j][fl];
     const float v = alpha * (float)t;
-    out[f] = beta != 0.f ? v + beta * out[f] : v;
+    float* const o = f < split ? out + f : out2 + (f - split);
+    *o = beta != 0.f ? v + beta * *o : v;
   }
 }
 
@@ -579,6 +582,14 @@ extern "C" int avsr_transpose(const avsr_transpose_job* jobs, int32_t n, void* s
 
 int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, float alpha, float beta, void* stream) {
   hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, (long)F, nblk, out, F, alpha, beta);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+// one launch, two destinations: columns [0, split) -> out, [split, F) -> out2 (the weight and bias gradients of a convolution's slab)
+int avsr_colsum_final_launch_split(const float* part, long ld, int nblk, float* out, float* out2, int split, int F, float alpha, float beta,
+                                   void* stream) {
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, ld, nblk, out, F, alpha, beta, out2, split);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
