@@ -252,11 +252,14 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
       const int mo0 = mt * 16 + q * 4;
       const bool fastp = lin && mo0 + 3 < Mtot && colok;
       const unsigned dbo = (unsigned)(((long)n0 * pixf * Cd + (long)mo0 * NC + cn) * 4);
-      float rv[4], ov[4];
+      float rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
+      if (A.res) {                                      // kernel-uniform: launches without a residual issue no loads for it
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        rv[rr] = ldb1(res_rs, (fastp && A.res) ? (int)(dbo + (unsigned)(rr * NC * 4)) : P_OOB);
-        ov[rr] = ldb1(dst_rs, (fastp && A.beta != 0.f) ? (int)(dbo + (unsigned)(rr * NC * 4)) : P_OOB);
+        for (int rr = 0; rr < 4; ++rr) rv[rr] = ldb1(res_rs, fastp ? (int)(dbo + (unsigned)(rr * NC * 4)) : P_OOB);
+      }
+      if (A.beta != 0.f) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) ov[rr] = ldb1(dst_rs, fastp ? (int)(dbo + (unsigned)(rr * NC * 4)) : P_OOB);
       }
       // Chunks beyond the layer's depth read offset 0 against zero weights (no branch around any read).  The reads of the next
       // block (the next tile when the tile is one block) are issued BEFORE this block's MFMAs and kept there by the scheduling
@@ -496,9 +499,10 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float* xb = xf + (ho * A.S * PW + wo * A.S) * CiL;
-        const bool pin = r0 + e < opf;
+        // positions beyond the frame read a clamped (finite) LDS address: their dy operand is zero (out-of-range buffer load), so the
+        // product vanishes without a select per operand
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { const float xv = xb[roff[mt]]; av[mt][e] = pin ? xv : 0.f; }   // unconditional read, then select
+        for (int mt = 0; mt < MT; ++mt) av[mt][e] = xb[roff[mt]];
         if (++wo == A.Wo) { wo = 0; ++ho; }
         if (ho >= A.Ho) { ho = A.Ho - 1; }                 // (only reached by out-of-range positions: masked above)
       }
