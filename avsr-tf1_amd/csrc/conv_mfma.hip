@@ -229,7 +229,6 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
     if (n0 + gridDim.x * A.F < A.N) fetch(n0 + gridDim.x * A.F);      // in flight during the MFMAs below
     // ---- implicit GEMM over the staged frames ----
     const int Mtot = fcur * opf, mtiles = (Mtot + 15) >> 4;
-    float* const dlin = A.dst + (long)n0 * pixf * Cd + (long)(q * 4) * NC + cn;  // linear destination: row m lives at dlin + m*NC
     // LDS address of product row m (clamped to row 0 beyond the pass: those rows are never written out)
     auto row_base = [&](int mt) -> const float* {
       const int m = mt * 16 + i;
@@ -237,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
       const int f = fdiv(mm, A.m_opf), r = mm - f * opf, a = fdiv(r, A.m_ob), b = r - a * A.OB;
       return lds + f * fstride + ((a * A.S + 1) * PW + (b * A.SB + 1)) * CsL;
     };
+    const unsigned pass_o = (unsigned)((long)n0 * pixf * Cd * 4);     // (destination maps stay below 2 GB: checked by the host)
     constexpr int CB = MAXCH <= 6 ? MAXCH : 3;          // K chunks per block of LDS reads (9 and 18 are multiples of 3)
     constexpr bool XT = MAXCH <= 6;                     // whole tile in one block: the NEXT tile's reads run under this tile's MFMAs
     f32x4 cur[CB], nxt[CB];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
       // tiles that do not take the fast path below use an out-of-range offset)
       const int mo0 = mt * 16 + q * 4;
       const bool fastp = lin && mo0 + 3 < Mtot && colok;
-      const unsigned dbo = (unsigned)(((long)n0 * pixf * Cd + (long)mo0 * NC + cn) * 4);
+      const unsigned dbo = pass_o + (unsigned)((mo0 * NC + cn) * 4);   // byte offset of (row mo0, this lane's column) in the destination
       float rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
       if (A.res) {                                      // kernel-uniform: launches without a residual issue no loads for it
 #pragma unroll
@@ -297,13 +297,13 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
       // C layout: row = q*4 + r, column = i
       if (colok) {
         if (fastp) {                                    // the common case: four in-range rows, destination linear in the row
-          float* dp = dlin + (long)(mt * 16) * NC;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             float v = acc[rr] + bias_v;
             if (A.res) v += rbn ? fmaxf(fmaf(rv[rr], rsc, rsh), 0.f) : rv[rr];
             if (A.beta != 0.f) v += A.beta * ov[rr];
-            dp[rr * NC] = v;
+            // buffer store with the 32-bit byte offset the operand loads used (no 64-bit pointer arithmetic per row)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), dst_rs, (int)(dbo + (unsigned)(rr * NC * 4)), 0, 0);
             acc[rr] = v;
           }
           if (A.stats) {
