@@ -357,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // weight gradient: part[blk][(t*Ci + ci)*Co + co] = sum over the block's frames and positions of x[pos(t)][ci] * dy[pos][co]
+#define WG_PAD 2          // floats of padding per LDS pixel in the weight-gradient kernel (bank spreading, see the kernel)
 struct WGArgs {
   const float* x; const float* dy; float* part;
   int N, H, W, Ci, CiL, Ho, Wo, Co, S, pt, pl, F;
@@ -373,7 +374,12 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int Ci = A.Ci, CiL = A.CiL, Co = A.Co;
-  const int PH = A.H + 2, PW = A.W + 2, xstride = PH * PW * CiL;
+  // LDS pixel stride = channels + 2 floats: the A operand is read 4 bytes at a time by lanes (row = (tap, channel), q = position group);
+  // with a stride of 8 / 16 / 32 / 64 floats the four position groups hit the same banks (4-5 LDS cycles per read, SQ_LDS_BANK_CONFLICT =
+  // 53 % of the LDS-active cycles); + 2 floats spreads them (2 cycles per read, the minimum for 64 lanes on 32 banks).  Staging stores
+  // become 8-byte pairs.
+  const int CsP = CiL + WG_PAD;
+  const int PH = A.H + 2, PW = A.W + 2, xstride = PH * PW * CsP;
   const int opf = A.Ho * A.Wo;
   float* const xs = lds;                               // [F][PH][PW][CiL]   (the output gradient is read straight from memory:
                                                        //  every value is used once per row tile, 16 lanes = 64 contiguous bytes)
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
     const int row = mt * 16 + i;
     const bool ok = row < Mrows;
     const int tl = ok ? row / CiL : 0, ci = ok ? row - tl * CiL : 0, t = A.t0 + tl, ti = t / A.kw, tj = t - ti * A.kw;
-    roff[mt] = ok ? ((ti - A.pt) * PW + (tj - A.pl)) * CiL + ci : 0;
+    roff[mt] = ok ? ((ti - A.pt) * PW + (tj - A.pl)) * CsP + ci : 0;
   }
   f32x4 acc[MT][NTC];
 #pragma unroll
@@ -401,6 +407,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   const int st_rpp = (CH4 && st_rq > 0) ? (256 / st_rq > 0 ? 256 / st_rq : 1) : 1;
   const int st_row = CH4 ? (tid < st_rpp * st_rq ? fdiv(tid, A.m_rq) : -1) : -1;
   const int st_p4 = st_row >= 0 ? tid - st_row * st_rq : 0;
+  const int st_pad = (CH4 && st_row >= 0) ? (st_p4 / (Ci >> 2)) * WG_PAD : 0;     // padding floats ahead of this piece's pixel in its LDS row
   f32x4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = zero4;
   const bool bn_on = CH4 && A.bn_sc != nullptr;
   if (bn_on && st_row >= 0) { const int cb = (st_p4 * 4) % Ci; bsc = ld4(A.bn_sc + cb); bsh = ld4(A.bn_sh + cb); }
@@ -439,14 +446,16 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], bsc[e], bsh[e]), 0.f);
           }
-          st4(xs + f * xstride + ((r + 1) * PW + 1) * CiL + st_p4 * 4, v);
+          float* const dpx = xs + f * xstride + ((r + 1) * PW + 1) * CsP + st_pad + st_p4 * 4;
+          *reinterpret_cast<float2*>(dpx) = float2{v[0], v[1]};
+          *reinterpret_cast<float2*>(dpx + 2) = float2{v[2], v[3]};
         }
       }
     } else {
       const int tot = fcur * per3, tot4 = tot >> 2;
       auto put = [&](int e, float v) {
         const int f = fdiv(e, A.m_per), r = e - f * per3, px = fdiv(r, A.m_rq), c = r - px * Ci, h = fdiv(px, A.m_w), pw = px - h * A.W;
-        xs[f * xstride + ((h + 1) * PW + pw + 1) * CiL + c] = v;
+        xs[f * xstride + ((h + 1) * PW + pw + 1) * CsP + c] = v;
       };
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -495,10 +504,10 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
       if (kc + 4 < kch) load_b(kc + 4, bn);
       const int f = fdiv(kc, m_cpf), r0 = (kc - f * cpf) * 16 + q * 4;
       int ho = fdiv(min(r0, opf - 1), A.m_wo), wo = min(r0, opf - 1) - ho * A.Wo;
-      const float* xf = xs + f * xstride + (PW + 1) * CiL;
+      const float* xf = xs + f * xstride + (PW + 1) * CsP;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float* xb = xf + (ho * A.S * PW + wo * A.S) * CiL;
+        const float* xb = xf + (ho * A.S * PW + wo * A.S) * CsP;
         // positions beyond the frame read a clamped (finite) LDS address: their dy operand is zero (out-of-range buffer load), so the
         // product vanishes without a select per operand
 #pragma unroll
@@ -506,12 +515,15 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
         if (++wo == A.Wo) { wo = 0; ++ho; }
         if (ho >= A.Ho) { ho = A.Ho - 1; }                 // (only reached by out-of-range positions: masked above)
       }
+      // all LDS reads of the chunk first, then its MFMAs (left alone the compiler waits for each read just ahead of its first use)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NTC; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], bv[nt][e], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // cross-wave reduction (waves hold different depth slices of the same tiles), tile by tile through a 4 KB staging area, then
@@ -722,7 +734,7 @@ int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int
   A.t0 = 0; A.nt = 9; A.kw = 3; A.slab = 9 * Ci * Co; A.want_bias = 0;
   const int MT = (9 * A.CiL + 15) / 16, NTC = (Co + 15) / 16;
   if (MT > 18 || NTC > 2 || MT * NTC > 36) return AVSR_ERR_UNSUPPORTED;
-  A.F = cg_frames(H, W, A.CiL, Ho * Wo);
+  A.F = cg_frames(H, W, A.CiL + WG_PAD, Ho * Wo);
   const int nout = 9 * Ci * Co;
   A.m_opf = fmagic(Ho * Wo); A.m_wo = fmagic(Wo); A.m_w = fmagic(W);
   if (Ci % 4 == 0) {
@@ -739,7 +751,7 @@ int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int
   }
   if ((long)A.F * ((Ho * Wo + 15) / 16) >= 65536 || (long)N * Ho * Wo * Co * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
   const size_t red = sizeof(float) * 4 * 256;
-  size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * A.CiL;
+  size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + WG_PAD);
   if (lds < red) lds = red;
   if (lds > 64 * 1024) return AVSR_ERR_UNSUPPORTED;
   int wpc = (int)((150 * 1024) / (lds + 512));
@@ -943,7 +955,7 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
   const int mt_max = NTC == 4 ? 9 : 18;
   int G = mt_max * 16 / A.CiL;                           // taps per launch
   if (G < 1) return AVSR_ERR_UNSUPPORTED;
-  A.F = cg_frames(H, W, A.CiL, Ho * Wo);
+  A.F = cg_frames(H, W, A.CiL + WG_PAD, Ho * Wo);
   A.m_opf = fmagic(Ho * Wo); A.m_wo = fmagic(Wo); A.m_w = fmagic(W);
   if (Ci % 4 == 0) {
     const int rq = W * Ci / 4;
@@ -960,7 +972,7 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
   }
   if ((long)A.F * ((Ho * Wo + 15) / 16) >= 65536 || (long)N * Ho * Wo * Co * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
   const size_t red = sizeof(float) * 4 * 256;
-  size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * A.CiL;
+  size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + WG_PAD);
   if (lds < red) lds = red;
   if (lds > 64 * 1024) return AVSR_ERR_UNSUPPORTED;
   int wpc = (int)((150 * 1024) / (lds + 512));
