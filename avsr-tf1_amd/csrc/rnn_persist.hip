@@ -633,7 +633,8 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
   static thread_local PLaunch L;
   hipStream_t s = (hipStream_t)stream;
   int wg = 0; long words = 0;
-  if ((g_persist_mode & 2) && build_tasks(st, n, true, sync, sync_ints, L, &wg, &words) == AVSR_OK) {
+  static const int parts_first = getenv("AVSR_RNN_PARTS") ? atoi(getenv("AVSR_RNN_PARTS")) == 2 : 0;   // experiment: two stacks side by side even when they fit together
+  if ((g_persist_mode & 2) && !(parts_first && n == 2 && st[0].B <= 64) && build_tasks(st, n, true, sync, sync_ints, L, &wg, &words) == AVSR_OK) {
     if (dry) return AVSR_OK;
     // 8 XCDs x R rows per launch (R = 8 up to 64 utterances, 16 above); a larger batch runs as consecutive launches over slices
     // (rows are independent)
