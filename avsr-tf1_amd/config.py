@@ -1,11 +1,15 @@
 """Hyper-parameters the hot path reads (mirror of the HParams bag, avsr/avsr.py:150-198)."""
-from dataclasses import dataclass
+from dataclasses import dataclass, replace
 from typing import List, Optional, Tuple
 
 LUONG_TYPES = ("luong", "scaled_luong")
 BAHDANAU_TYPES = ("bahdanau", "normed_bahdanau")
 ATT_CODE = {"luong": 0, "scaled_luong": 1, "bahdanau": 2, "normed_bahdanau": 3}
 CELL_ID_DECODER = 40
+
+
+def round4(n: int) -> int:
+    return (n + 3) // 4 * 4
 
 
 def encoder_cell_id(stream, direction, layer):
@@ -59,6 +63,7 @@ class ModelConfig:
     instance_normalisation: bool = False                            # encoder.py:51-55: instance_norm after the batch norm
     highway_encoder: bool = False                                   # cells.py:89-90: HighwayWrapper on encoder layers > 0 (wins over residual)
     residual_encoder: bool = False                                  # cells.py:91-92: ResidualWrapper on encoder layers > 0
+    one_hot_embedding: bool = False      # set by engine(): embedding_size <= 0 -> tf.eye(vocab_size) decoder inputs (decoder_unimodal.py:76-77)
 
     # -- same helpers/validation rules as the reference wiring (error types as in the reference) --
     def streams(self) -> List[str]:
@@ -100,6 +105,25 @@ class ModelConfig:
 
     def units(self, stream):
         return self.video_units if stream == "video" else self.audio_units
+
+    def one_hot(self) -> bool:
+        """decoder_unimodal.py:76-77: a non-positive embedding_size falls back to one-hot decoder inputs (no embedding variable)."""
+        return self.one_hot_embedding or self.embedding_size <= 0
+
+    def emb_width(self) -> int:
+        return self.embedding_size if self.embedding_size > 0 else self.vocab_size
+
+    def engine(self) -> "ModelConfig":
+        """The configuration the kernels run: every feature / unit / embedding width rounded up to a multiple of 4 (16-byte rows,
+        whole MFMA unit groups).  Padding entries of every variable are zero and stay zero (a padded LSTM / GRU unit has zero
+        weights and bias: its candidate is tanh(0) = 0, so its cell and output stay 0; every consumer's rows for it are zero, so
+        it receives a zero gradient and so do its weights) - the padded model computes exactly the unpadded one.
+        `params.embed` / `params.extract` convert between the two layouts; the reference's shapes are what is imported / exported."""
+        r = lambda t: None if t is None else tuple(round4(u) for u in t)
+        dense = self.input_dense_layers if self.input_dense_layers[0] <= 0 else tuple(round4(u) for u in self.input_dense_layers)
+        return replace(self, video_units=r(self.video_units), audio_units=r(self.audio_units), decoder_units=r(self.decoder_units),
+                       embedding_size=round4(self.emb_width()), video_feat=round4(self.video_feat), audio_feat=round4(self.audio_feat),
+                       input_dense_layers=dense, one_hot_embedding=self.one_hot())
 
     def feat(self, stream):
         return self.video_feat if stream == "video" else self.audio_feat
@@ -172,16 +196,16 @@ class ModelConfig:
                 raise ValueError("video_feat must equal cnn_dense_units when the CNN front-end produces the video features")
             if any(c % 4 for c in self.cnn_filters) or self.cnn_dense_units % 4 or len(self.cnn_filters) < 1:
                 raise ValueError("cnn_filters / cnn_dense_units must be multiples of 4 for the HIP engine")
-        if self.input_dense_layers[0] > 0 and any(u <= 0 or u % 4 for u in self.input_dense_layers):
-            raise ValueError("input_dense_layers must be positive multiples of 4 for the HIP engine")
+        if self.input_dense_layers[0] > 0 and any(u <= 0 for u in self.input_dense_layers):
+            raise ValueError("input_dense_layers must be positive")
         if len(set(self.decoder_units)) != 1 or len(self.decoder_units) > 4:
             raise NotImplementedError("multi-layer decoders: up to 4 layers of equal width")
         if len(self.decoder_units) > 1 and self.cell_type != "lstm":
             raise NotImplementedError("multi-layer decoders: LSTM cells only")
         if not self.streams() and self.architecture != "lm":
             raise Exception("labels are None")                                         # seq2seq.py:94
-        dims = [self.embedding_size, self.decoder_units[0]]
+        dims = [self.decoder_units[0]]
         for s in self.streams():
             dims += list(self.units(s)) + [self.feat(s)]
-        if any(d % 4 for d in dims):
-            raise ValueError("feature / unit / embedding sizes must be multiples of 4 for the HIP engine")
+        if any(d <= 0 for d in dims):
+            raise ValueError("feature / unit sizes must be positive")       # other widths: padded inside the engine (`engine()`)

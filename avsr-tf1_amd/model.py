@@ -90,7 +90,9 @@ class Seq2SeqModel:
             raise RuntimeError("avsr_tf1_amd needs an MI355X GPU: the HIP engine has no CPU fallback")
         from . import _lib
         _lib.load()
-        self.cfg, self.dev = cfg, torch.device(device)
+        # the kernels run the 4-padded configuration (config.py `engine()`); cfg_tf keeps the reference's shapes for import / export
+        self.cfg_tf, self.dev = cfg, torch.device(device)
+        self.cfg = cfg = cfg.engine()
         self.gru = cfg.cell_type == "gru"
         # one-launch persistent encoder forward (csrc/rnn_persist.hip); process-wide engine switch
         # bits: 1 agent-scope forward | 2 XCD-local forward + fused BPTT | 4 split BPTT (measured slower on c4: 3.0 vs 2.7 ms,
@@ -101,7 +103,8 @@ class Seq2SeqModel:
         # one-launch fused persistent decoder / AV-Align attentive layer forward (csrc/dec_persist.hip); needs the sync scratch above
         self.fused_decode = self.persistent_rnn and os.environ.get("AVSR_FUSED_DECODE", "1") != "0"
         self.G = 2 if self.gru else 4                       # gate pre-activations per unit of the main cell kernel
-        self.inv = PR.inventory(cfg)
+        self.inv, self.inv_tf = PR.inventory(cfg), PR.inventory(self.cfg_tf)
+        self.seg, self.seg_tf = PR.segments(cfg), PR.segments(self.cfg_tf)
         # ---- flat parameter storage (engine layout) ------------------------------------------------
         self._train_off, self._stat_off = OrderedDict(), OrderedDict()
         nt = ns = 0
@@ -151,7 +154,11 @@ class Seq2SeqModel:
         self._dropping = False
         self.au_scale = 1.0
         self.au_external = False     # data parallel: the AU loss is normalised by the all-reduced frame count in dp_norm[1]
-        self.load_tf_weights(weights if weights is not None else PR.initialise(cfg, seed))
+        self.onehot = None
+        if cfg.one_hot():                       # decoder_unimodal.py:76-77: tf.eye(vocab_size) rows as decoder inputs, not a variable
+            self.onehot = torch.zeros(cfg.vocab_size, cfg.embedding_size, device=self.dev)
+            self.onehot[:, :cfg.vocab_size] = torch.eye(cfg.vocab_size, device=self.dev)
+        self.load_tf_weights(weights if weights is not None else PR.initialise(self.cfg_tf, seed))
         self.scratch = z(1 << 22)
         self.gemm_ws = None
         self._ensure_gemm_ws()               # split-K scratch, also used by forward GEMMs with few output tiles
@@ -164,20 +171,33 @@ class Seq2SeqModel:
     def _eshape(self, name):
         return self.inv[name][0]
 
+    def _to_engine(self, name, a):
+        """Reference-shaped array (TF layout) -> flat engine layout: zero padding to the engine widths, then the gate interleave."""
+        shape, kind, _i = self.inv_tf[name]
+        a = PR.embed(self.seg_tf[name], self.seg[name], np.asarray(a, dtype=np.float32).reshape(shape))
+        return PR.to_engine(kind, a).reshape(-1)
+
+    def _emb_t(self):
+        t, o = self._emb()
+        return t[o:]
+
+    def _emb(self):
+        """(tensor, element offset) of the decoder input table: the embedding variable, or the constant one-hot rows."""
+        return (self.onehot, 0) if self.onehot is not None else (self.params, self.P["dec/embedding"].off)
+
     def load_tf_weights(self, W: Dict[str, np.ndarray]):
         """Import a {name: array} dict in TF layout (same names as oracle / export_tf_weights)."""
-        for name, (shape, kind, _i) in self.inv.items():
-            a = np.asarray(W[name], dtype=np.float32).reshape(shape)
-            e = torch.from_numpy(PR.to_engine(kind, a).reshape(-1)).to(self.dev)
+        for name, (shape, kind, _i) in self.inv_tf.items():
+            e = torch.from_numpy(self._to_engine(name, W[name])).to(self.dev)
             ref = self.S[name] if name in self.S else self.P[name]
             ref.t[ref.off:ref.off + e.numel()].copy_(e)
         self._refresh_derived()
 
     def load_flat(self, buf, W: Dict[str, np.ndarray]):
         """Fill an optimiser-slot buffer (same layout as params) from a TF-layout dict."""
-        for name, (shape, kind, _i) in self.inv.items():
+        for name in self.inv_tf:
             if name in self._train_off and name in W:
-                e = torch.from_numpy(PR.to_engine(kind, np.asarray(W[name], np.float32).reshape(shape)).reshape(-1)).to(self.dev)
+                e = torch.from_numpy(self._to_engine(name, W[name])).to(self.dev)
                 o = self._train_off[name]
                 buf[o:o + e.numel()].copy_(e)
 
@@ -190,10 +210,10 @@ class Seq2SeqModel:
             if name in self._stat_off:
                 if which == "params":
                     o = self._stat_off[name]
-                    out[name] = self.stats[o:o + n].cpu().numpy().reshape(shape).copy()
+                    out[name] = PR.extract(self.seg_tf[name], self.seg[name], self.stats[o:o + n].cpu().numpy().reshape(shape)).copy()
                 continue
             o = self._train_off[name]
-            out[name] = PR.from_engine(kind, host[o:o + n].reshape(shape))
+            out[name] = PR.extract(self.seg_tf[name], self.seg[name], PR.from_engine(kind, host[o:o + n].reshape(shape)))
         return out
 
     def _refresh_derived(self):
@@ -227,6 +247,8 @@ class Seq2SeqModel:
             if self.n_dense:                                          # encoder.py:148-171: pre-activations, outputs and their gradients
                 E["dense"] = [dict(z=z(B * T, u), a=z(B * T, u), da=z(B * T, u)) for u in cfg.input_dense_layers]
             E["xn"], E["dxn"], E["xhat"] = z(B * T, F), z(B * T, F), z(B * T, F)
+            if self.cfg_tf.feat(s) != F:
+                E["xpad"] = z(B, T, F)                                # the batch's features, zero columns up to the engine width
             if cfg.instance_normalisation:
                 E["xi"], E["in_mean"], E["in_invstd"], E["in_dg"], E["in_db"] = z(B * T, F), z(B, F), z(B, F), z(B, F), z(B, F)
             if s == "video" and self.use_cnn:
@@ -594,9 +616,24 @@ class Seq2SeqModel:
         self.bn_sync = dict(streams=streams, off=off, sum=buf, sq=z(n), mean=z(n), rows=[buf[n + i:n + i + 1] for i in range(len(streams))])
         return self.bn_sync
 
+    def _fit_width(self, E, x, s):
+        """Reference-width features -> the workspace's copy with zero padding columns up to the engine width (config.py `engine()`)."""
+        F = E["F"]
+        if "xpad" in E and x.shape[-1] != F:
+            Ft = self.cfg_tf.feat(s)
+            assert x.shape == E["xpad"].shape[:2] + (Ft,) and x.is_contiguous() and x.dtype == torch.float32
+            ops.dropout_rows(ops.mat(x, Ft), ops.mat(E["xpad"], F), x.shape[0] * x.shape[1], Ft, None, 0, 1.0, Ft)
+            x = E["xpad"]
+        return x
+
     def _bn_sync_x(self, batch, s):
         x = batch.video if s == "video" else batch.audio
         F = self.cfg.feat(s)
+        if x.shape[-1] != F:
+            B, L = batch.labels.shape
+            ws = self._get_ws(B, batch.audio.shape[1] if batch.audio is not None else 0, batch.video.shape[1] if batch.video is not None else 0,
+                              L, False)
+            x = self._fit_width(ws["enc"][s], x, s)
         assert x.is_contiguous() and x.dtype == torch.float32 and x.shape[-1] == F
         return x, x.shape[0] * x.shape[1], F
 
@@ -632,6 +669,8 @@ class Seq2SeqModel:
                 Hh, Ww, Cc = cfg.video_hw
                 assert x.shape == (B, T, Hh, Ww, Cc) and x.is_contiguous() and x.dtype == torch.float32
                 x = E["cnn"].forward(x.view(B * T, Hh, Ww, Cc), training).view(B, T, F)
+            if "cnn" not in E:
+                x = self._fit_width(E, x, s)                          # reference-width features: copied next to zero padding columns
             assert x.shape == (B, T, F) and x.is_contiguous() and x.dtype == torch.float32
             E["x"], E["len"] = x, len_t
             if cfg.batch_normalisation:
@@ -1201,7 +1240,7 @@ class Seq2SeqModel:
         drop_in = self._dropping and cfg.decoder_dropout[0] < 1.0
         xm = ops.mat(D["xemb"], E)
         # decoder inputs = embedding of the GO-prefixed labels (all steps when teacher forcing, only step 0 when sampling)
-        ops.embed_labels(self._pp("dec/embedding"), batch.labels, cfg.go_id, D["xemb"], D["fed"], B, L, E, 1 if sampling else L)
+        ops.embed_labels(self._emb_t(), batch.labels, cfg.go_id, D["xemb"], D["fed"], B, L, E, 1 if sampling else L)
         if drop_in:
             if sampling:     # only row (b, 0): address rows with stride L*E, mask index (b*L + 0)*(E+A) + e
                 ops.dropout_rows(ops.mat(D["xemb"], L * E), ops.mat(D["xemb"], L * E), B, E, self.seed, CELL_ID_DECODER * 4,
@@ -1221,7 +1260,7 @@ class Seq2SeqModel:
             if not self._bdrop(D):
                 d.keep_in = d.keep_state = d.keep_out = 1.0
                 d.cell_id = CELL_ID_DECODER
-            d.embedding = ops.fptr(self.params, self.P["dec/embedding"].off)
+            d.embedding = ops.fptr(*self._emb())
             d.wout_t = ops.fptr(self.derived, self.Tr["dec/out/kernel"].off)
             d.bout = ops.fptr(self.params, self.P["dec/out/bias"].off)
             d.logits, d.xs, d.labels, d.fed = ops.fptr(D["logits"]), ops.fptr(D["xemb"]), ops.fptr(batch.labels), ops.fptr(D["fed"])
@@ -1295,7 +1334,8 @@ class Seq2SeqModel:
         if self._dropping and cfg.decoder_dropout[0] < 1.0:
             dm = ops.mat(D["dxemb"], E)
             ops.dropout_rows(dm, dm, B * L, E, self.seed, CELL_ID_DECODER * 4, cfg.decoder_dropout[0], E + A)
-        ops.embed_grad(D["dxemb"], D["fed"], self._gp("dec/embedding"), B, L, E, V, self.scratch)
+        if self.onehot is None:
+            ops.embed_grad(D["dxemb"], D["fed"], self._gp("dec/embedding"), B, L, E, V, self.scratch)
         self._decoder_init_state_bwd(ws)
 
     def backward_encoders(self):
@@ -1404,7 +1444,7 @@ class Seq2SeqModel:
         self._block_prepare(wsb, D)
         d = self._block_desc(wsb, D, D["steplen"], 3, D["h0"], D["c0"], with_bwd=False)
         d.output_attention = int(cfg.output_attention())
-        d.embedding = ops.fptr(self.params, self.P["dec/embedding"].off)
+        d.embedding = ops.fptr(*self._emb())
         d.wout_t = ops.fptr(self.derived, self.Tr["dec/out/kernel"].off)
         d.bout = ops.fptr(self.params, self.P["dec/out/bias"].off)
         d.logits, d.tok, d.n_unfinished = ops.fptr(D["logits"]), ops.fptr(D["tok"]), ops.fptr(D["nunf"])
@@ -1447,7 +1487,7 @@ class Seq2SeqModel:
         D["ids"].zero_()
         d = self._block_desc(ws, D, D["steplen"], 1, D["h0"], D["c0"], with_bwd=False)
         d.output_attention = int(cfg.output_attention())
-        d.embedding = ops.fptr(self.params, self.P["dec/embedding"].off)
+        d.embedding = ops.fptr(*self._emb())
         d.wout_t = ops.fptr(self.derived, self.Tr["dec/out/kernel"].off)
         d.bout = ops.fptr(self.params, self.P["dec/out/bias"].off)
         d.logits, d.ids, d.tok, d.n_unfinished = ops.fptr(D["logits"]), ops.fptr(D["ids"]), ops.fptr(D["tok"]), ops.fptr(D["nunf"])

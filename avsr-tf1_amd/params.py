@@ -63,92 +63,141 @@ def from_engine(kind, a):
     return np.ascontiguousarray(a)
 
 
-def inventory(cfg: ModelConfig):
-    """OrderedDict name -> (tf_shape, kind, init) for every variable of the model, in a fixed order.
-    kind: lstm_kernel | lstm_bias | plain;  init: vs (variance scaling) | glorot | zeros | ones | emb | const:x"""
+def _layout(cfg: ModelConfig):
+    """OrderedDict name -> (segments, kind, init).  `segments` lists, per axis, the widths of the logical parts the axis is a
+    concatenation of (a cell kernel's rows: [input parts..., recurrent part]; its columns: one part per gate block).  The
+    reference's shape of an axis is the sum of its parts; the engine's (`cfg.engine()`) pads every part separately, which is
+    why the parts are kept."""
     inv = OrderedDict()
     dec = cfg.decoder_units[0]
+    depth = lambda stream: [cfg.units(stream)[-1]] * (2 if cfg.encoder_type == "bidirectional" else 1)   # [fw | bw] memories
     for stream in cfg.streams():
         feat, units = cfg.feat(stream), cfg.units(stream)
         if cfg.batch_normalisation:
-            inv[f"{stream}/bn/gamma"] = ((feat,), "plain", "ones")
-            inv[f"{stream}/bn/beta"] = ((feat,), "plain", "zeros")
-            inv[f"{stream}/bn/moving_mean"] = ((feat,), "plain", "zeros")
-            inv[f"{stream}/bn/moving_variance"] = ((feat,), "plain", "ones")
+            inv[f"{stream}/bn/gamma"] = ([[feat]], "plain", "ones")
+            inv[f"{stream}/bn/beta"] = ([[feat]], "plain", "zeros")
+            inv[f"{stream}/bn/moving_mean"] = ([[feat]], "plain", "zeros")
+            inv[f"{stream}/bn/moving_variance"] = ([[feat]], "plain", "ones")
         if cfg.instance_normalisation:                        # encoder.py:51-55
-            inv[f"{stream}/in/gamma"] = ((feat,), "plain", "ones")
-            inv[f"{stream}/in/beta"] = ((feat,), "plain", "zeros")
+            inv[f"{stream}/in/gamma"] = ([[feat]], "plain", "ones")
+            inv[f"{stream}/in/beta"] = ([[feat]], "plain", "zeros")
         attentive = cfg.architecture == "av_align" and stream == "audio"
         if cfg.input_dense_layers[0] > 0:                     # encoder.py:148-171: Dense(units, selu, use_bias=False)
             w_in = feat
             for k, u in enumerate(cfg.input_dense_layers):
-                inv[f"{stream}/dense{k}/kernel"] = ((w_in, u), "plain", "vs")
+                inv[f"{stream}/dense{k}/kernel"] = ([[w_in], [u]], "plain", "vs")
                 w_in = u
         for d in cfg.directions():
             i = cfg.layer0_in(stream)
             for l, u in enumerate(units):
-                extra = units[-1] if (attentive and l == len(units) - 1) else 0
+                extra = [units[-1]] if (attentive and l == len(units) - 1) else []
                 if cfg.shared_layer(stream, l) == l:                  # encoder_weight_sharing: layers >= 2 own no variables
-                    _cell(inv, cfg, f"{stream}/enc/{d}/l{l}", i + extra, u)
+                    _cell(inv, cfg, f"{stream}/enc/{d}/l{l}", [i] + extra, u)
                 if cfg.highway(stream) and l > 0:   # HighwayWrapper carry gate over the layer's input (cells.py:89-90)
-                    inv[f"{stream}/enc/{d}/l{l}/carry_w"] = ((i, i), "plain", "glorot")
-                    inv[f"{stream}/enc/{d}/l{l}/carry_b"] = ((i,), "plain", "ones")
+                    inv[f"{stream}/enc/{d}/l{l}/carry_w"] = ([[i], [i]], "plain", "glorot")
+                    inv[f"{stream}/enc/{d}/l{l}/carry_b"] = ([[i]], "plain", "ones")
                 i = u
         if attentive:
-            _attention(inv, "audio/enc/att0", cfg.attention_type[0][0], cfg.memory_depth("video"), units[-1])
+            _attention(inv, "audio/enc/att0", cfg.attention_type[0][0], depth("video"), units[-1])
         if cfg.encoder_type == "bidirectional":
             if cfg.cell_type == "gru":                        # encoder.py:128-131
-                inv[f"{stream}/enc/proj"] = ((2 * units[-1], dec), "plain", "glorot")
+                inv[f"{stream}/enc/proj"] = ([[units[-1]] * 2, [dec]], "plain", "glorot")
             else:                                             # encoder.py:132-138
-                inv[f"{stream}/enc/proj_c"] = ((2 * units[-1], dec), "plain", "glorot")
-                inv[f"{stream}/enc/proj_h"] = ((2 * units[-1], dec), "plain", "glorot")
+                inv[f"{stream}/enc/proj_c"] = ([[units[-1]] * 2, [dec]], "plain", "glorot")
+                inv[f"{stream}/enc/proj_h"] = ([[units[-1]] * 2, [dec]], "plain", "glorot")
         if stream == "video" and cfg.regress_aus:
-            inv["video/au/kernel"] = ((cfg.memory_depth("video"), 2), "plain", "glorot")
-            inv["video/au/bias"] = ((2,), "plain", "zeros")
+            inv["video/au/kernel"] = ([depth("video"), [2]], "plain", "glorot")
+            inv["video/au/bias"] = ([[2]], "plain", "zeros")
     if cfg.video_units is not None and cfg.video_processing == "resnet_cnn":
         from .cnn import param_shapes
         init_of = {"conv_kernel": "conv_vs", "bias": "zeros", "gamma": "ones", "beta": "zeros", "moving_mean": "zeros", "moving_variance": "ones"}
         for name, shape, role in param_shapes(cfg.video_hw, cfg.cnn_filters, cfg.cnn_dense_units):
-            inv["video/cnn/" + name] = (shape, "plain", init_of[role])
-    V, E = cfg.vocab_size, cfg.embedding_size
-    inv["dec/embedding"] = ((V, E), "plain", "emb")
+            inv["video/cnn/" + name] = ([[n] for n in shape], "plain", init_of[role])
+    V, E = cfg.vocab_size, cfg.emb_width()
+    if not cfg.one_hot():                                     # decoder_unimodal.py:76-77: one-hot inputs own no variable
+        inv["dec/embedding"] = ([[V], [E]], "plain", "emb")
     mems = cfg.decoder_memories()
-    A = dec * len(mems)
-    _cell(inv, cfg, "dec/l0", E + A, dec)
+    _cell(inv, cfg, "dec/l0", [E] + [dec] * len(mems), dec)
     for j in range(1, len(cfg.decoder_units)):                # MultiRNNCell: layer j consumes layer j-1's output
-        _cell(inv, cfg, "dec/l%d" % j, cfg.decoder_units[j - 1], cfg.decoder_units[j])
+        _cell(inv, cfg, "dec/l%d" % j, [cfg.decoder_units[j - 1]], cfg.decoder_units[j])
     for i, (stream, t) in enumerate(mems):
-        _attention(inv, f"dec/att{i}", t, cfg.memory_depth(stream), dec)
-    O = A if cfg.output_attention() else dec
-    inv["dec/out/kernel"] = ((O, V), "plain", "glorot")
-    inv["dec/out/bias"] = ((V,), "plain", "zeros")
+        _attention(inv, f"dec/att{i}", t, depth(stream), dec)
+    O = [dec] * len(mems) if cfg.output_attention() else [dec]
+    inv["dec/out/kernel"] = ([O, [V]], "plain", "glorot")
+    inv["dec/out/bias"] = ([[V]], "plain", "zeros")
     if cfg.architecture == "bimodal":
-        inv["dec/state_proj"] = ((2 * dec, dec), "plain", "glorot")
+        inv["dec/state_proj"] = ([[dec, dec], [dec]], "plain", "glorot")
     return inv
 
 
-def _cell(inv, cfg, prefix, in_dim, u):
+def inventory(cfg: ModelConfig):
+    """OrderedDict name -> (shape, kind, init) for every variable of the model, in a fixed order.
+    kind: lstm_kernel | lstm_bias | plain;  init: vs (variance scaling) | glorot | zeros | ones | emb | const:x"""
+    return OrderedDict((n, (tuple(sum(ax) for ax in segs), kind, init)) for n, (segs, kind, init) in _layout(cfg).items())
+
+
+def segments(cfg: ModelConfig):
+    return OrderedDict((n, segs) for n, (segs, _k, _i) in _layout(cfg).items())
+
+
+def _place(a, segs_from, segs_to, out_shape):
+    """Copy every (part x part x ...) block of `a` (parts `segs_from` per axis) to the position the same block has in an array
+    whose axes are the parts `segs_to`; the rest of the result is zero.  Padding when segs_to >= segs_from, cropping otherwise."""
+    out = np.zeros(out_shape, a.dtype)
+    def starts(parts):
+        o, r = 0, []
+        for p in parts:
+            r.append(o)
+            o += p
+        return r
+    ax = [list(zip(starts(f), starts(t), [min(x, y) for x, y in zip(f, t)])) for f, t in zip(segs_from, segs_to)]
+    def rec(k, src, dst):
+        if k == len(ax):
+            out[tuple(dst)] = a[tuple(src)]
+            return
+        for so, do, n in ax[k]:
+            rec(k + 1, src + [slice(so, so + n)], dst + [slice(do, do + n)])
+    rec(0, [], [])
+    return out
+
+
+def embed(seg_tf, seg_e, a):
+    """Reference-shaped array (TF layout) -> the engine configuration's shape, padding entries zero (still TF gate order)."""
+    if seg_tf == seg_e:
+        return a
+    return _place(a, seg_tf, seg_e, tuple(sum(ax) for ax in seg_e))
+
+
+def extract(seg_tf, seg_e, a):
+    """Inverse of `embed`: drop the padding entries."""
+    if seg_tf == seg_e:
+        return a
+    return _place(a, seg_e, seg_tf, tuple(sum(ax) for ax in seg_tf))
+
+
+def _cell(inv, cfg, prefix, in_parts, u):
+    rows = list(in_parts) + [u]
     if cfg.cell_type == "lstm":                               # cells.py:14-18
-        inv[prefix + "/kernel"] = ((in_dim + u, 4 * u), "lstm_kernel", "vs")
-        inv[prefix + "/bias"] = ((4 * u,), "lstm_bias", "zeros")
+        inv[prefix + "/kernel"] = ([rows, [u] * 4], "lstm_kernel", "vs")
+        inv[prefix + "/bias"] = ([[u] * 4], "lstm_bias", "zeros")
     else:                                                     # cells.py:25-29: kernel AND bias variance-scaling initialised
-        inv[prefix + "/gates_kernel"] = ((in_dim + u, 2 * u), "gru_gates_kernel", "vs")
-        inv[prefix + "/gates_bias"] = ((2 * u,), "gru_gates_bias", "vs")
-        inv[prefix + "/cand_kernel"] = ((in_dim + u, u), "plain", "vs")
-        inv[prefix + "/cand_bias"] = ((u,), "plain", "vs")
+        inv[prefix + "/gates_kernel"] = ([rows, [u] * 2], "gru_gates_kernel", "vs")
+        inv[prefix + "/gates_bias"] = ([[u] * 2], "gru_gates_bias", "vs")
+        inv[prefix + "/cand_kernel"] = ([rows, [u]], "plain", "vs")
+        inv[prefix + "/cand_bias"] = ([[u]], "plain", "vs")
 
 
 def _attention(inv, prefix, att_type, depth, units):
-    inv[prefix + "/memory_kernel"] = ((depth, units), "plain", "glorot")
+    inv[prefix + "/memory_kernel"] = ([depth, [units]], "plain", "glorot")
     if att_type == "scaled_luong":
-        inv[prefix + "/g"] = ((1,), "plain", "const:1.0")
+        inv[prefix + "/g"] = ([[1]], "plain", "const:1.0")
     if att_type in BAHDANAU_TYPES:
-        inv[prefix + "/query_kernel"] = ((units, units), "plain", "glorot")
-        inv[prefix + "/v"] = ((units,), "plain", "glorot_vec")
+        inv[prefix + "/query_kernel"] = ([[units], [units]], "plain", "glorot")
+        inv[prefix + "/v"] = ([[units]], "plain", "glorot_vec")
         if att_type == "normed_bahdanau":
-            inv[prefix + "/g"] = ((1,), "plain", "const:%r" % math.sqrt(1.0 / units))
-            inv[prefix + "/b"] = ((units,), "plain", "zeros")
-    inv[prefix + "/layer_kernel"] = ((units + depth, units), "plain", "glorot")
+            inv[prefix + "/g"] = ([[1]], "plain", "const:%r" % math.sqrt(1.0 / units))
+            inv[prefix + "/b"] = ([[units]], "plain", "zeros")
+    inv[prefix + "/layer_kernel"] = ([[units] + depth, [units]], "plain", "glorot")
 
 
 def is_cnn_l2(name):

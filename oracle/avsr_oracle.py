@@ -376,7 +376,10 @@ def init_params(cfg: OracleConfig, seed: int = 2001) -> Dict[str, np.ndarray]:
     # decoder
     V, E = cfg.vocab_size, cfg.embedding_size
     lim = 1.732 / V
-    P["dec/embedding"] = rng.uniform(-lim, lim, size=(V, E)).astype(np.float32)
+    if E > 0:
+        P["dec/embedding"] = rng.uniform(-lim, lim, size=(V, E)).astype(np.float32)
+    else:                      # decoder_unimodal.py:76-77: non-positive embedding_size -> tf.eye(vocab_size), a constant, no variable
+        E = V
     mems = cfg.decoder_memories()
     att_total = dec_units * len(mems)
     _cell_params(rng, cfg, "dec/l0", E + att_total, dec_units, P)
@@ -395,6 +398,14 @@ def init_params(cfg: OracleConfig, seed: int = 2001) -> Dict[str, np.ndarray]:
 
 
 NON_TRAINABLE = ("moving_mean", "moving_variance")
+
+
+def _embedding(P, cfg):
+    """decoder_unimodal.py:72-91: the embedding variable, or the constant one-hot matrix when embedding_size <= 0."""
+    if "dec/embedding" in P:
+        return P["dec/embedding"]
+    ref = P["dec/out/kernel"]
+    return torch.eye(cfg.vocab_size, dtype=ref.dtype)
 
 
 def trainable_names(P: Dict[str, np.ndarray]) -> List[str]:
@@ -921,7 +932,7 @@ def forward_train(P: Dict[str, Tensor], cfg: OracleConfig, batch: Batch, dtype=t
     steps = int(ll.max())
     logits = []
     for t in range(steps):
-        out, ns, natt, _ = m.step(P["dec/embedding"][torch.as_tensor(fed[:, t].copy())], state, att, t)
+        out, ns, natt, _ = m.step(_embedding(P, cfg)[torch.as_tensor(fed[:, t].copy())], state, att, t)
         lg = m.logits(out)
         if cfg.sampling_probability > 0 and t + 1 < L:
             idx = (np.arange(B) * L + t).astype(np.uint32)
@@ -1092,7 +1103,7 @@ def greedy_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Batch, 
     finished = torch.zeros(B, dtype=torch.bool)
     ids, lgs, als = [], [], []
     for t in range(max_steps):
-        out, ns, natt, al = m.step(P["dec/embedding"][tok], state, att)
+        out, ns, natt, al = m.step(_embedding(P, cfg)[tok], state, att)
         als.append([torch.where(finished[:, None], torch.zeros_like(a), a) for a in al])
         lg = m.logits(out)
         sample = torch.argmax(lg, dim=-1)
@@ -1179,7 +1190,7 @@ def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Ba
     FMIN = torch.finfo(torch.float32).min
     step_ids, parent_ids = [], []
     for t in range(max_steps):
-        out, state, att, _ = m.step(P["dec/embedding"][tok], state, att, t)
+        out, state, att, _ = m.step(_embedding(P, cfg)[tok], state, att, t)
         step_lp = torch.log_softmax(m.logits(out), dim=-1).reshape(B, K, V)
         fin_row = torch.full((V,), FMIN, dtype=dtype)
         fin_row[eos] = 0.0

@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _dataset(tmp, n=12, feat=8):
+def _dataset(tmp, n=12, feat=8, vfeat=4):
     from avsr_tf1_amd import io_utils as IO
     rng = np.random.default_rng(0)
     unit_file = os.path.join(tmp, "character_list")
@@ -23,7 +23,7 @@ def _dataset(tmp, n=12, feat=8):
             for j, c in enumerate(lab):                          # make the task learnable: label-dependent bumps
                 x[6 * j:6 * j + 6, int(c) % feat] += 2.0
             fa.write(IO.make_feature_example("utt%02d" % i, x))
-            fv.write(IO.make_feature_example("utt%02d" % i, x[::3, :4].copy()))
+            fv.write(IO.make_feature_example("utt%02d" % i, x[::3, :vfeat].copy()))
             fl.write(IO.make_label_example("utt%02d" % i, lab.tolist(), "character"))
     return unit_file, paths
 
@@ -52,6 +52,35 @@ def test_avsr_train_evaluate_and_resume(tmp_path, monkeypatch):
     exp2.train(logfile="logs/smoke", num_epochs=2, try_restore_latest_checkpoint=True)
     assert "Average batch_loss as epoch 11" in open("logs/smoke").read()
     assert int(exp2._model.step.item()) > int(30)                # optimiser step restored and advanced
+
+
+def test_avsr_at_sizes_the_engine_pads(tmp_path, monkeypatch):
+    """13-d audio / 5-d video features, 14- and 10-unit layers, one-hot decoder inputs (embedding_size=0, decoder_unimodal.py:76-77):
+    none is a multiple of 4; the engine pads inside, the checkpoint holds the reference's shapes."""
+    import avsr_tf1_amd as avsr
+    monkeypatch.chdir(tmp_path)
+    unit_file, p = _dataset(str(tmp_path), feat=13, vfeat=5)
+    kw = dict(unit="character", unit_file=unit_file, architecture="bimodal", video_processing="features", audio_processing="features",
+              video_train_record=p["video"], video_test_record=p["video"], audio_train_record=p["audio"], audio_test_record=p["audio"],
+              labels_train_record=p["labels"], labels_test_record=p["labels"], batch_size=(4, 4),
+              encoder_units_per_layer=((10,), (14, 10)), decoder_units_per_layer=(10,), embedding_size=0, decoding_algorithm="beam_search",
+              beam_width=3, warmup_steps=0, learning_rate=0.01, shuffle_seed=0)
+    exp = avsr.AVSR(**kw)
+    exp.train(logfile="logs/odd", num_epochs=11)
+    ck = np.load("checkpoints/odd/checkpoint.ckp-10.npz")
+    shapes = {k: ck[k].shape for k in ck.files}
+    V = exp._cfg.vocab_size
+    assert V % 4 != 0
+    assert shapes["params:audio/enc/fw/l0/kernel"] == (13 + 14, 4 * 14) and shapes["adam_m:video/enc/fw/l0/kernel"] == (5 + 10, 4 * 10)
+    assert not any(k.endswith("dec/embedding") for k in shapes)              # one-hot inputs: no embedding variable
+    assert shapes["params:dec/l0/kernel"] == (V + 2 * 10 + 10, 4 * 10)       # one-hot symbols + two attention vectors + state
+    losses = [float(l.split()[-1]) for l in open("logs/odd").read().splitlines() if l.startswith("Average")]
+    assert len(losses) == 10 and losses[-1] < losses[0]
+    err = exp.evaluate("checkpoints/odd/checkpoint.ckp-10", epoch=10)
+    assert np.isfinite(err["character"])
+    exp2 = avsr.AVSR(**kw)
+    exp2.train(logfile="logs/odd", num_epochs=2, try_restore_latest_checkpoint=True)
+    assert "Average batch_loss as epoch 11" in open("logs/odd").read()
 
 
 def test_run_experiment_bimodal(tmp_path, monkeypatch):

@@ -13,14 +13,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASE = dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32), decoder_units=(32,),
             embedding_size=16, video_feat=12, audio_feat=20, regress_aus=True, use_dropout=False, warmup_steps=0)
+# widths the kernels do not take natively: the engine pads to multiples of 4, the batches keep the reference's widths
+CASE_ODD = dict(CASE, video_units=(26,), audio_units=(22, 26), decoder_units=(26,), embedding_size=0, video_feat=13, audio_feat=39)
 STEPS = 4
 
 
-def _setup():
+def _setup(odd=False):
     import dataclasses
     from avsr_tf1_amd.config import ModelConfig
     from oracle import avsr_oracle as O
-    ocfg = O.OracleConfig(**CASE)
+    ocfg = O.OracleConfig(**(CASE_ODD if odd else CASE))
     mcfg = ModelConfig(**{f.name: getattr(ocfg, f.name) for f in dataclasses.fields(ModelConfig) if hasattr(ocfg, f.name)})
     W = O.init_params(ocfg, seed=5)
     full = O.synthetic_batch(ocfg, B=6, T_a=17, T_v=7, L=6, ragged=True)
@@ -32,7 +34,7 @@ def _shard(O, b, lo, hi):
                       for k in ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len")})
 
 
-def _worker(rank, world, port, out_dir, use_graph, overlap):
+def _worker(rank, world, port, out_dir, use_graph, overlap, odd):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -43,7 +45,7 @@ def _worker(rank, world, port, out_dir, use_graph, overlap):
     from avsr_tf1_amd.parallel import DataParallelTrainer
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    O, mcfg, W, full = _setup()
+    O, mcfg, W, full = _setup(odd)
     cut = [0, 2, 6]                                   # unequal shards
     model = Seq2SeqModel(mcfg, weights=W)
     trainer = DataParallelTrainer(model, dist, use_graph=use_graph)
@@ -57,8 +59,9 @@ def _worker(rank, world, port, out_dir, use_graph, overlap):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph,overlap", [(False, False), (True, False), (False, True), (True, True)])
-def test_two_ranks_equal_one_engine_on_the_whole_batch(tmp_path, use_graph, overlap, monkeypatch):
+@pytest.mark.parametrize("use_graph,overlap,odd", [(False, False, False), (True, False, False), (False, True, False), (True, True, False),
+                                                   (True, True, True)])
+def test_two_ranks_equal_one_engine_on_the_whole_batch(tmp_path, use_graph, overlap, odd, monkeypatch):
     """overlap: the decoder's gradient block is all-reduced on a side stream between the two halves of the backward pass
     (AVSR_DP_OVERLAP=1; with graphs the pass is captured as two graphs)."""
     import torch.multiprocessing as mp
@@ -66,13 +69,13 @@ def test_two_ranks_equal_one_engine_on_the_whole_batch(tmp_path, use_graph, over
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path), use_graph, overlap), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), use_graph, overlap, odd), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     # graphs are replayed around the collectives when asked for (exact against eager launches once the captured
     # graphs held no memset / memcpy nodes)
     assert bool(r0["sync_bn"]) and str(r0["mode"]).startswith("hipgraph" if use_graph else "eager")
     monkeypatch.setenv("AVSR_PERSISTENT_RNN", "0")      # same launch path as the two workers (restored after the test)
-    O, mcfg, W, full = _setup()
+    O, mcfg, W, full = _setup(odd)
     model = Seq2SeqModel(mcfg, weights=W)
     batch = Batch.from_numpy(full)
     for _ in range(STEPS):
