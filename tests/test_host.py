@@ -91,6 +91,60 @@ def test_inventory_matches_oracle_variables(kw):
     assert mcfg.output_attention() == ocfg.output_attention() and mcfg.decoder_memories() == ocfg.decoder_memories()
 
 
+ODD_CONFIGS = [
+    dict(architecture="unimodal", video_units=None, audio_units=(7, 5), decoder_units=(5,), embedding_size=3, audio_feat=13),
+    dict(architecture="bimodal", encoder_type="bidirectional", video_units=(6,), audio_units=(7, 9), decoder_units=(10,), embedding_size=5,
+         video_feat=5, audio_feat=11, regress_aus=True, attention_type=(("normed_bahdanau",), ("bahdanau",))),
+    dict(architecture="av_align", video_units=(6,), audio_units=(7, 9), decoder_units=(9,), embedding_size=6, video_feat=5, audio_feat=11,
+         input_dense_layers=(7,)),
+    dict(architecture="unimodal", encoder_type="bidirectional", video_units=None, audio_units=(7,), decoder_units=(6,), embedding_size=5,
+         audio_feat=9, cell_type="gru", instance_normalisation=True, attention_type=(("scaled_luong",), ("scaled_luong",))),
+    dict(architecture="unimodal", video_units=None, audio_units=(6, 6, 6), decoder_units=(6, 6), embedding_size=0, audio_feat=9,
+         highway_encoder=True),
+]
+
+
+@pytest.mark.parametrize("kw", ODD_CONFIGS)
+def test_padding_to_engine_widths_computes_the_same_model(kw):
+    """`ModelConfig.engine()` + `params.embed`: the 4-padded model with zero padding entries IS the unpadded model.  Shown here with an
+    independent implementation - the CPU oracle run on the padded configuration / weights / inputs gives the same logits and loss,
+    gradients that crop to the unpadded ones, and exactly-zero gradients in every padding entry."""
+    from avsr_tf1_amd import params as PR
+    from avsr_tf1_amd.config import ModelConfig
+    from oracle import avsr_oracle as O
+    ocfg = O.OracleConfig(**kw)
+    mcfg = ModelConfig(**{f.name: getattr(ocfg, f.name) for f in dataclasses.fields(ModelConfig) if hasattr(ocfg, f.name)})
+    mcfg.validate()
+    ecfg = mcfg.engine()
+    assert all(d % 4 == 0 for d in [ecfg.embedding_size, *ecfg.decoder_units, *(ecfg.audio_units or ()), *(ecfg.video_units or ()),
+                                    ecfg.audio_feat, ecfg.video_feat])
+    ocfg_e = dataclasses.replace(ocfg, **{f.name: getattr(ecfg, f.name) for f in dataclasses.fields(ModelConfig)
+                                          if hasattr(ocfg, f.name) and f.name != "embedding_size"},
+                                 embedding_size=ecfg.embedding_size)
+    W = O.init_params(ocfg, seed=3)
+    rng = np.random.default_rng(1)
+    for k in W:
+        if k.endswith(("bias", "/b", "beta")):
+            W[k] = (rng.standard_normal(W[k].shape) * 0.1).astype(np.float32)
+    st, se = PR.segments(mcfg), PR.segments(ecfg)
+    We = {k: PR.embed(st[k], se[k], W[k]) for k in W}
+    inv_e = PR.inventory(ecfg)
+    assert all(We[k].shape == tuple(inv_e[k][0]) for k in We)
+    assert all(np.array_equal(PR.extract(st[k], se[k], We[k]), W[k]) for k in W)
+    if mcfg.one_hot():                      # the padded oracle needs the table as a (here: trainable) variable
+        We["dec/embedding"] = np.eye(mcfg.vocab_size, ecfg.embedding_size, dtype=np.float32)
+    batch = O.synthetic_batch(ocfg, B=3, T_a=9, T_v=5, L=4, ragged=True)
+    pad = lambda x, F: None if x is None else np.concatenate([x, np.zeros(x.shape[:2] + (F - x.shape[2],), x.dtype)], axis=2)
+    batch_e = dataclasses.replace(batch, audio=pad(batch.audio, ecfg.audio_feat), video=pad(batch.video, ecfg.video_feat))
+    r, re_ = O.train_step(W, None, ocfg, batch), O.train_step(We, None, ocfg_e, batch_e)
+    assert np.abs(r["logits"] - re_["logits"]).max() < 1e-6 and abs(r["loss"] - re_["loss"]) < 1e-6
+    assert abs(r["global_norm"] - re_["global_norm"]) < 1e-6 or mcfg.one_hot()
+    for k, g in r["grads"].items():
+        ge = re_["grads"][k]
+        assert np.abs(PR.extract(st[k], se[k], ge) - g).max() < 1e-6 * max(1.0, np.abs(g).max()), k
+        assert np.array_equal(PR.embed(st[k], se[k], PR.extract(st[k], se[k], ge)), ge), k       # padding entries: exactly zero gradients
+
+
 def test_config_validation_errors_follow_the_reference():
     from avsr_tf1_amd.config import ModelConfig
     with pytest.raises(Exception, match="Unknown architecture"):
