@@ -193,3 +193,55 @@ def test_cosine_restarts_schedule():
     assert 0 < O.lr_at(cfg, 9) < 0.03 * lr
     cfg2, _, _ = _small("unimodal", warmup_steps=4, lr_decay_steps=10)
     assert abs(O.lr_at(cfg2, 1) - O.lr_at(cfg, 1) * 0.5) < 1e-12         # warm-up multiplies the decayed rate
+
+
+@pytest.mark.parametrize("arch,cell,w", [("unimodal", "lstm", 0.0), ("unimodal", "gru", 0.6), ("bimodal", "lstm", 0.5), ("av_align", "lstm", 0.0)])
+def test_beam_search_with_a_beam_that_never_prunes_finds_the_exhaustive_optimum(arch, cell, w):
+    """Pins the search logic of the beam-search restatement ('low confidence') to an independent ground truth: with a
+    beam wide enough to hold every live prefix, the best hypothesis must be the arg-max over ALL output sequences of the
+    length-normalised log-probability, computed here by plain recursion over prefixes with the model's own step function
+    (finished-beam masking, score accumulation, parent gathering, gather_tree and the EOS padding all have to be right for that)."""
+    V, eos, go, steps = 5, 3, 4, 3
+    kw = dict(architecture=arch, cell_type=cell, encoder_type="unidirectional", audio_units=(8,), video_units=(8,) if arch != "unimodal" else None,
+              decoder_units=(8,), embedding_size=4, vocab_size=V, eos_id=eos, go_id=go, audio_feat=4, video_feat=4,
+              attention_type=(("luong",), ("scaled_luong",)))
+    cfg = O.OracleConfig(**kw)
+    cfg.validate()
+    rng = np.random.default_rng(11)
+    W = O.init_params(cfg, seed=4)
+    for k in W:                                             # sharpen the output distribution so that the optimum is not a near-tie
+        if k.startswith("dec/out"):
+            W[k] = (rng.standard_normal(W[k].shape) * 1.5).astype(np.float32)
+    batch = O.synthetic_batch(cfg, B=3, T_a=6, T_v=4, L=3, ragged=True)
+    K = V ** (steps - 1)
+    ids, scores, lens = O.beam_search_decode(W, cfg, batch, beam_width=K, length_penalty_weight=w, max_steps=steps, return_all=True)
+
+    P = O.to_torch(W, torch.float64)
+    m = O._Model(P, cfg, batch, False, torch.float64)
+    emb = O._embedding(P, cfg)
+    B = m.B
+    for b in range(B):
+        sel = lambda s: tuple(sel(x) for x in s) if isinstance(s, (tuple, list)) else s[b:b + 1]
+        best = [(-np.inf, None)]
+
+        def rec(prefix, logp, state, att, tok, t):
+            with torch.no_grad():
+                # the model's step runs the whole batch; row b is what we follow
+                x = emb[torch.full((B,), tok, dtype=torch.int64)]
+                out, ns, natt, _ = m.step(x, state, att, t)
+                lp = torch.log_softmax(m.logits(out), dim=-1)[b].numpy()
+            for v in range(V):
+                seq, tot = prefix + [v], logp + lp[v]
+                n_words = sum(1 for s in seq if s != eos)
+                if v == eos or t + 1 == steps:
+                    score = tot / (((5.0 + n_words) / 6.0) ** w)
+                    if score > best[0][0]:
+                        best[0] = (score, seq)
+                else:
+                    rec(seq, tot, ns, natt, v, t + 1)
+
+        with torch.no_grad():
+            rec([], 0.0, m.init_state, torch.zeros(B, m.att_dim, dtype=torch.float64), go, 0)
+        score, seq = best[0]
+        want = seq + [eos] * (ids.shape[1] - len(seq))
+        assert list(ids[b, :, 0]) == want[:ids.shape[1]], (b, list(ids[b, :, 0]), want, score)
