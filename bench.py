@@ -341,13 +341,13 @@ def main():
         out["kernel_time_events"] = kinds
         dom = max(kinds, key=lambda k: kinds[k]["total_ms"])
         HBM_PEAK, MFMA_PEAK = 8000.0, 157.3
-        # HBM traffic per launch from the committed PMC passes (profiles/r02_c4_lipcnn_pmc_v3.json: FETCH_SIZE / WRITE_SIZE collected in
+        # HBM traffic per launch from the committed PMC passes (profiles/r02_c4_lipcnn_pmc_v4.json: FETCH_SIZE / WRITE_SIZE collected in
         # separate rocprofv3 runs of this same workload, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); null
         # for workloads / kernels that were not profiled.
         pmc = {}
         try:
             if args.workload == "c4" and args.video_frontend == "resnet_cnn":
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_c4_lipcnn_pmc_v3.json")))["kernels"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_c4_lipcnn_pmc_v4.json")))["kernels"]
         except Exception:
             pmc = {}
         pmc_name = {"attn_fwd": "avsr::attn_fwd_kernel", "attn_bwd": "avsr::attn_bwd_kernel",
