@@ -22,7 +22,8 @@
 #include "prof.h"
 #include "persist.h"
 
-#define B_MAX_TASKS 8
+#define B_MAX_TASKS 12
+namespace avsr { extern float* g_persist_scratch; extern int64_t g_persist_scratch_floats; }
 #define B_CH 8            // 16-wide K chunks per wave per operand part (4H / 16 / 8 waves, H <= 256)
 
 namespace avsr {
@@ -32,6 +33,8 @@ struct BTask {
   const int* len;
   const float* gates; const float* cs;
   float* dgates; float* ring; const float* up_dgates;
+  float* part;                              // K-split kernel: partial d h slabs [2 parities][nct producers][B][H]
+  float* dx; int kind;                      // K-split kernel: kind 0 CELL (dx = input from its helper, or null), 1 HELP (dx = output [B,T,H])
   const float* dout; long dout_sb, dout_st;
   const float* dh_final; const float* dc_final;
   int* prog; const int* prog_up;
@@ -298,15 +301,281 @@ __global__ __launch_bounds__(512) void rnn_persist_bwd_kernel(const BLaunch L) {
 #endif
 }
 
+// ======================================================================================================
+// K-split variant (round 2; first choice of avsr_rnn_bwd_persistent, the kernel above takes what this one declines).
+// The kernel above partitions the recurrent product dh = dgates(t+1) . Wh^T by output UNITS, so every workgroup of a layer pulls the
+// whole [16 x 4H] dgates tile (64 KB at H = 256) through its CU's L2 port on the step-to-step chain and only then multiplies, and it
+// carries the product for the layer below (another 64 KB operand, 32 more MFMAs per wave) in the same workgroup: taking parts away
+//  showed that second product costing 2.3 us of the 5.4 us step although it is on no recurrence.  Here
+//   CELL  the recurrent product is partitioned by K: a workgroup multiplies the [16 x 64] dgates slice it has JUST produced (its own 16
+//         units x 4 gates, through LDS into the MFMA A layout) with its 64 rows of Wh^T into a partial dh for ALL units and publishes that
+//         [16 x H] slab (whole 128-byte rows, 16 bytes per lane: narrow stores retire one by one ahead of the drain); a consumer sums the nct
+//         partial values of its own (row, unit) - 16 scalar loads per thread instead of 64 KB per workgroup.  Chain per step: hand-off ->
+//         16 partial loads -> cell backward -> 32 MFMAs per wave -> publish.
+//   HELP  the product for the layer below is its own task (as in rnn_persist_bwd2.hip): dx(t) = input mask . dgates_above(t) . Wx^T by units,
+//         K over the 8 waves, written to a [B, T, H] record the cell below reads one step ahead with its forward records.  No recurrence:
+//         it follows the cell above as that cell publishes.
+// Both are 512-thread workgroups held to 128 VGPRs (two per CU, 64 per XCD); every cell is 16 units per workgroup (no 32-unit top cells:
+// their 64 MFMAs per wave would set the pace).  Crossing edges of the XCD pair are placed INTO helpers where possible (a cell polling
+// an agent-scope counter on its chain cost 2.46 vs 2.22 ms).  c4: 2.70 -> 2.2 ms per launch.
+__device__ __forceinline__ float ldb1_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16));
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void rnn_persist_bwdk_kernel(const BLaunch L) {
+  __shared__ __attribute__((aligned(16))) float red[8][16][16];
+  __shared__ __attribute__((aligned(16))) float dgs[16][68];
+  __shared__ __attribute__((aligned(16))) float stg[8][16][36];
+  __shared__ int s_slot;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int xcc = __builtin_amdgcn_readfirstlane(xcc_id());
+  if (tid == 0) s_slot = __hip_atomic_fetch_add(L.claim + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int slot = __builtin_amdgcn_readfirstlane(s_slot);
+  const int g = xcc >> 1, half = xcc & 1;
+  if (g >= L.ngroups || slot >= (half ? L.wpx1 : L.wpx0)) return;
+  int ti = -1, sb_best = -1;                       // the task of this half whose slot range holds my slot (ranges: cells first, then helpers)
+#pragma unroll
+  for (int i = 0; i < B_MAX_TASKS; ++i)
+    if (i < L.ntask && L.task[i].half == half && slot >= L.task[i].slot_begin && L.task[i].slot_begin > sb_best) { ti = i; sb_best = L.task[i].slot_begin; }
+  ti = __builtin_amdgcn_readfirstlane(ti);
+  const BTask& tk = L.task[ti];
+  const int ct = slot - tk.slot_begin;
+  const int H = tk.H, T = tk.T, reverse = tk.reverse, nct = tk.nct;
+  const bool helper = tk.kind == 1;
+  const int unit0 = ct * 16, row0 = L.b0 + g * 16;
+  const int i = lane & 15, q = lane >> 4;
+
+  // ---- ownership of (row, unit) by threads 0..255 for all steps ----
+  const int er = (tid & 255) >> 4, eu = tid & 15;
+  const int b = row0 + er, u = unit0 + eu;
+  const bool eok = tid < 256 && b < tk.B && u < H;
+  const int len_b = eok ? (tk.len ? tk.len[b] : T) : 0;
+  const int rec_b = b * T * H + u;
+  const bool drop_on = tk.seed != nullptr;
+  const uint32_t seedv = drop_on ? (uint32_t)tk.seed[0] : 0u;
+  const bool publish_remote = tk.ctr != nullptr;
+  const int ab = row0 + i;
+  const bool aok = ab < tk.B;
+  const int len_a = aok ? (tk.len ? tk.len[ab] : T) : 0;
+
+  // ---- progress polling (wave 0): lanes 0-31 own progress words (cells), lanes 32-63 the producer this task reads ----
+  int* const my_prog = tk.prog + g * 32 + ct;
+  int* const my_ctr = publish_remote ? tk.ctr + (long)g * T : nullptr;
+  const bool has_up = tk.prog_up != nullptr || tk.ctr_up != nullptr;
+  const int up_remote = tk.up_remote, nct_up = tk.nct_up;
+  const int* poll_own = nullptr; const int* poll_up = nullptr;
+  if (wave == 0) {
+    if (lane < 32) { if (!helper && lane < nct) poll_own = tk.prog + g * 32 + lane; }
+    else if (has_up) {
+      if (up_remote) { if (lane == 32) poll_up = tk.ctr_up + (long)g * T; }
+      else if (lane - 32 < nct_up) poll_up = tk.prog_up + g * 32 + (lane - 32);
+    }
+  }
+  // own: steps completed >= need_own.  producer: step index t_up completed (local: progress >= T - t_up; crossing: counter[t_up] >= nct_up)
+  auto wait_progress = [&](int need_own, int t_up) {
+    if (wave != 0) return;
+    const int* p = lane < 32 ? poll_own : (poll_up ? (up_remote ? poll_up + t_up : poll_up) : nullptr);
+    const int need = lane < 32 ? need_own : (up_remote ? nct_up : T - t_up);
+    for (int spins = 0; spins < (1 << 21); ++spins) {
+      const int v = p ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+      if (__all(v >= need)) return;
+      if ((spins & 1023) == 1023 && __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
+    if (lane == 0) __hip_atomic_store(L.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto publish = [&](int t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(my_prog, T - t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (my_ctr) __hip_atomic_fetch_add(my_ctr + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+
+  if (helper) {
+    // ================= HELP: dx(t) = input mask . (d gates of the layer above at step t) . Wx^T, by units, K over the 8 waves.
+    // No recurrence: it follows the cell above as closely as that cell publishes, off every step-to-step chain. =================
+    const int K_up = 4 * tk.H_up, ncu = K_up >> 4;
+    const int b0 = (wave * ncu) / 8, nB = ((wave + 1) * ncu) / 8 - b0;
+    f32x4 wB[B_CH];
+    {
+      const int uu = unit0 + i;
+#pragma unroll
+      for (int c = 0; c < B_CH; ++c)
+        wB[c] = (c < nB && uu < H) ? ld4(tk.w_up + (long)uu * tk.ldw_up + (b0 + c) * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const __amdgpu_buffer_rsrc_t up_rs = make_rsrc(tk.up_dgates);
+    const int up_row = (ab * T * K_up + b0 * 16 + 4 * q) * 4;
+    float* const dx_p = tk.dx;
+    const float k_in = tk.k_in; const uint32_t r_in = tk.r_in; const int in_W = tk.in_W, in_coff = tk.in_coff;
+    for (int t = T - 1; t >= 0; --t) {
+      wait_progress(0, t);
+      lds_barrier();
+      f32x4 aB[B_CH];
+      const int o = (aok && t < len_a) ? up_row + (reverse ? len_a - 1 - t : t) * (K_up * 4) : P_OOB;
+#pragma unroll
+      for (int c = 0; c < B_CH; ++c) aB[c] = ldb_sc1(up_rs, c < nB ? o + c * 64 : P_OOB);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cc = 0; cc < B_CH; cc += 2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[cc][e], wB[cc][e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aB[cc + 1][e], wB[cc + 1][e], acc1, 0, 0, 0);
+        }
+      acc0 += acc1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][q * 4 + r][i] = acc0[r];
+      lds_barrier();
+      if (eok && t < len_b) {
+        const int tau = reverse ? len_b - 1 - t : t;
+        const long bt = (long)b * T + tau;
+        float z = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) z += red[w][er][eu];
+        const float v = z * p_drop(drop_on, seedv, r_in, (uint32_t)(bt * in_W + in_coff + u), k_in);
+        if (publish_remote) st_sc1(dx_p + bt * H + u, v);
+        else dx_p[bt * H + u] = v;
+      }
+      publish(t);
+    }
+    return;
+  }
+
+  // ================= CELL =================
+  // my 64 rows of Wh^T for two 16-unit column tiles per wave (product by K), resident for the whole sequence
+  f32x4 wR[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = (wave * 2 + nt) * 16 + i;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      wR[nt][c] = (n < H && unit0 * 4 + c * 16 + 4 * q < 4 * H) ? ld4(tk.w_own + (long)n * tk.ldw_own + unit0 * 4 + c * 16 + 4 * q)
+                                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float dc_carry = (eok && tk.dc_final) ? tk.dc_final[(long)b * H + u] : 0.f;
+  float dh_carry = (eok && tk.dh_final) ? tk.dh_final[(long)b * H + u] : 0.f;
+  const __amdgpu_buffer_rsrc_t gates_rs = make_rsrc(tk.gates), cs_rs = make_rsrc(tk.cs), dout_rs = make_rsrc(tk.dout);
+  const __amdgpu_buffer_rsrc_t dx_rs = make_rsrc(tk.dx);
+  const bool has_dout = tk.dout != nullptr, has_dx = tk.dx != nullptr;
+  float* const dgates_p = tk.dgates;
+  const __amdgpu_buffer_rsrc_t dgates_rs = make_rsrc(tk.dgates);
+  const int dout_b = (int)(b * tk.dout_sb) + u, dout_st = (int)tk.dout_st;
+  const float k_st = tk.k_st, k_out = tk.k_out;
+  const uint32_t r_st = tk.r_st, r_out = tk.r_out;
+
+  // partial slabs [parity][producer][B][H]: consumer offsets of my (row, unit), producer rows of my accumulator tiles
+  const __amdgpu_buffer_rsrc_t part_rs = make_rsrc(tk.part);
+  const int slab = tk.B * H * 4;                                           // bytes per producer slab
+  const int par_bytes = nct * slab;                                        // bytes per parity
+  const int cons_off = (b * H + u) * 4;                                    // used by eok threads only
+  float* const part_p = tk.part;
+
+  // epilogue operands of the next step: forward records (cold in HBM) and the helper's dx, fetched a step ahead
+  f32x4 n_g = {0.f, 0.f, 0.f, 0.f};
+  float n_c = 0.f, n_cp = 0.f, n_do = 0.f, n_dx = 0.f;
+  auto load_rec = [&](int t) {
+    const bool v = eok && t >= 0 && t < len_b;
+    const int tau = reverse ? len_b - 1 - t : t;
+    const int o = v ? (rec_b + tau * H) * 4 : P_OOB;
+    n_g = ldb4(gates_rs, v ? o * 4 : P_OOB);
+    n_c = ldb1(cs_rs, o);
+    n_cp = ldb1(cs_rs, (v && t > 0) ? o + (reverse ? H : -H) * 4 : P_OOB);
+    n_do = ldb1(dout_rs, (v && has_dout) ? (dout_b + tau * dout_st) * 4 : P_OOB);
+    n_dx = ldb1_sc1(dx_rs, (v && has_dx) ? o : P_OOB);                  // produced during this launch
+  };
+  if (has_up) wait_progress(0, T - 1);
+  __syncthreads();
+  load_rec(T - 1);
+  for (int t = T - 1; t >= 0; --t) {
+    f32x4 g4 = n_g;
+    float c = n_c, cprev = n_cp, dout_ext = n_do + n_dx;
+    asm volatile("" : "+v"(g4), "+v"(c), "+v"(cprev), "+v"(dout_ext));
+    // dependencies: step t+1 of this cell (every producer of my rows); my helper one step ahead (t-1)
+    wait_progress(T - 1 - t, t > 0 ? t - 1 : 0);
+    lds_barrier();
+    // ---- recurrent operand: the nct partial d h values of my (row, unit) from step t+1 (nothing at t = T-1) ----
+    float ps[16];
+    {
+      const bool pv = eok && t + 1 < T;
+      const int o = cons_off + ((t + 1) & 1) * par_bytes;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) ps[p] = ldb1_sc1(part_rs, (pv && p < nct) ? o + p * slab : P_OOB);
+    }
+    load_rec(t - 1);
+    asm volatile("" ::: "memory");
+    // ---- LSTM cell backward (same arithmetic as EP_LSTM_BWD in step.hip; dx already carries the layer above's input mask) ----
+    if (tid < 256) {
+      f32x4 dg = {0.f, 0.f, 0.f, 0.f};
+      const bool valid = eok && t < len_b;
+      int tau = t;
+      if (valid) {
+        tau = reverse ? len_b - 1 - t : t;
+        float zA = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+        zA += ((ps[8] + ps[9]) + (ps[10] + ps[11])) + ((ps[12] + ps[13]) + (ps[14] + ps[15]));
+        const long bt = (long)b * T + tau;
+        const uint32_t oidx = (uint32_t)(bt * H + u);
+        const float dh = dout_ext * p_drop(drop_on, seedv, r_out, oidx, k_out) + (zA + dh_carry) * p_drop(drop_on, seedv, r_st, oidx, k_st);
+        const float tc = p_tanh(c);
+        float dc = dh * g4[3] * (1.f - tc * tc) + dc_carry;
+        if (!(fabsf(c) < 1.0f)) dc = 0.f;
+        dg[3] = dh * tc * g4[3] * (1.f - g4[3]);
+        dg[0] = dc * g4[1] * g4[0] * (1.f - g4[0]);
+        dg[1] = dc * g4[0] * (1.f - g4[1] * g4[1]);
+        dg[2] = dc * cprev * g4[2] * (1.f - g4[2]);
+        dc_carry = dc * g4[2];
+        dh_carry = 0.f;
+      }
+      *reinterpret_cast<f32x4*>(&dgs[er][eu * 4]) = dg;               // the recurrence's operand first, then the record
+      if (eok) {
+        const int ro = (rec_b + tau * H) * 4;
+        if (publish_remote) stx_sc1(dgates_rs, ro, dg);
+        else st4(dgates_p + ro, dg);
+      }
+    }
+    lds_barrier();
+    // ---- my K slice of the recurrent product: [16 x 64] d gates . 64 rows of Wh^T -> partial d h of ALL units, two tiles per wave ----
+    {
+      f32x4 A[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) A[cc] = *reinterpret_cast<const f32x4*>(&dgs[i][cc * 16 + 4 * q]);
+      float* const dst = part_p + ((long)((t & 1) * nct + ct) * tk.B) * H;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cc][e], wR[nt][cc][e], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[wave][q * 4 + r][nt * 16 + i] = acc[r];
+      }
+      // the wave's [16 x 32] tile leaves as whole 128-byte rows, 16 bytes per lane (narrow stores retire one by one ahead of the drain)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int idx = lane + 64 * j, rr = idx >> 3, c4 = idx & 7;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&stg[wave][rr][c4 * 4]);
+        const int n = wave * 32 + c4 * 4, rb = row0 + rr;
+        if (n < H && rb < tk.B) st4(dst + (long)rb * H + n, v);
+      }
+    }
+    publish(t);
+  }
+}
+
 // Choose the XCD half of every cell: all assignments are enumerated (<= 2^8); feasible ones keep each half within
 // `cap` workgroups; the winner has the fewest crossing layer edges, then the smallest larger half.
-static bool assign_halves(const int* cost, const int* upper, int n, int cap, int* half_out) {
+// ecost[i]: price of a crossing edge into task i (K-split kernel: 1 when the CONSUMER is a helper - its agent-scope poll and remote
+// operand loads are off every chain -, 3 when it is a cell, which would poll across the XCD pair on its step-to-step chain:
+// measured 2.22 vs 2.46 ms on c4); null = 1 each.
+static bool assign_halves(const int* cost, const int* upper, int n, int cap, int* half_out, const int* ecost = nullptr) {
   int best = -1, best_cross = 1 << 30, best_load = 1 << 30;
   for (int m = 0; m < (1 << n); ++m) {
     int load[2] = {0, 0}, cross = 0;
     for (int i = 0; i < n; ++i) {
       load[(m >> i) & 1] += cost[i];
-      if (upper[i] >= 0 && (((m >> i) ^ (m >> upper[i])) & 1)) ++cross;
+      if (upper[i] >= 0 && (((m >> i) ^ (m >> upper[i])) & 1)) cross += ecost ? ecost[i] : 1;
     }
     if (load[0] > cap || load[1] > cap) continue;
     const int mx = load[0] > load[1] ? load[0] : load[1];
@@ -317,6 +586,8 @@ static bool assign_halves(const int* cost, const int* upper, int n, int cap, int
   return true;
 }
 
+static_assert(sizeof(BLaunch) <= 4000, "launch descriptor must fit the kernel-argument segment");
+
 }  // namespace avsr
 
 // Returns AVSR_ERR_UNSUPPORTED when the persistent path is disabled or the configuration does not fit it
@@ -326,10 +597,24 @@ static bool assign_halves(const int* cost, const int* upper, int n, int cap, int
 #include <cstdlib>
 // AVSR_PERSIST_DEBUG=1 prints which precondition sent a call back to the per-step launches
 #define UNSUP(code) do { if (getenv("AVSR_PERSIST_DEBUG")) fprintf(stderr, "[avsr] persistent BPTT not used: reason %d (rnn_persist_bwd.hip)\n", code); return AVSR_ERR_UNSUPPORTED; } while (0)
+static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry, bool ksplit);
+
 int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry) {
+  // the K-split kernel first (16-unit cells everywhere, 32 workgroups per XCD); configurations it declines take the kernel above
+  static const int ksplit = getenv("AVSR_RNN_BWD_KSPLIT") ? atoi(getenv("AVSR_RNN_BWD_KSPLIT")) : 1;
+  if (ksplit) {
+    const int rc = bwd_persistent(st, n, stream, dry, true);
+    if (rc != AVSR_ERR_UNSUPPORTED) return rc;
+  }
+  return bwd_persistent(st, n, stream, dry, false);
+}
+
+static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry, bool ksplit) {
   using namespace avsr;
   int32_t* sync = g_sync; const int64_t sync_ints = g_sync_ints;
   if (!sync || !(g_persist_mode & 2)) return AVSR_ERR_UNSUPPORTED;
+  if (ksplit && !g_persist_scratch) return AVSR_ERR_UNSUPPORTED;
+  long part_used = 0;
   static thread_local BLaunch L;
   L = BLaunch{};
   double flops = 0.0;
@@ -351,34 +636,70 @@ int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
       const int t_i = L.ntask++;
       BTask& tk = L.task[t_i];
       tk.w_own = Ly.w + (long)in * 4 * H; tk.ldw_own = 4 * H;
-      if (!top) { const avsr_rnn_layer& Up = S.layer[l + 1]; tk.w_up = Up.w; tk.ldw_up = 4 * Up.units; tk.H_up = Up.units; tk.up_dgates = Up.dgates; }
+      if (!top && !ksplit) { const avsr_rnn_layer& Up = S.layer[l + 1]; tk.w_up = Up.w; tk.ldw_up = 4 * Up.units; tk.H_up = Up.units; tk.up_dgates = Up.dgates; }
       tk.len = S.len; tk.gates = Ly.gates; tk.cs = Ly.cs; tk.dgates = Ly.dgates; tk.ring = Ly.dstate;
       if (Ly.dout) { tk.dout = Ly.dout + Ly.ld_dout + Ly.dout_col; tk.dout_sb = (long)(S.T + 2) * Ly.ld_dout; tk.dout_st = Ly.ld_dout; }
       if (top) { tk.dh_final = S.dh_final; tk.dc_final = S.dc_final; }
       tk.B = S.B; tk.T = S.T; tk.H = H; tk.reverse = S.reverse;
       flops += 2.0 * S.B * S.T * (4.0 * H + (top ? 0.0 : 4.0 * S.layer[l + 1].units)) * H;
-      tk.ntile = (top && H % 32 == 0) ? 2 : 1;
+      tk.ntile = (!ksplit && top && H % 32 == 0) ? 2 : 1;
       tk.nct = H / (16 * tk.ntile);
       if (tk.nct > 32) UNSUP(8);
+      if (ksplit) {
+        if (tk.nct > 16 || (long)2 * tk.nct * S.B * H * 4 >= (1L << 30)) UNSUP(11);
+        const long need = (long)2 * tk.nct * S.B * H;
+        if (part_used + need > g_persist_scratch_floats) UNSUP(12);
+        tk.part = g_persist_scratch + part_used; part_used += need;
+      }
       cost[t_i] = tk.nct; upper[t_i] = top ? -1 : t_i + 1;
       if (S.seed) {
         const uint32_t cid = (uint32_t)(S.cell_id_base + l);
         tk.seed = S.seed; tk.k_st = S.keep_state; tk.k_out = S.keep_out; tk.k_in = 1.0f;
         tk.r_st = cid * 4 + 1; tk.r_out = cid * 4 + 2;
-        if (!top) { tk.k_in = S.keep_in; tk.r_in = (cid + 1) * 4; tk.in_W = H; tk.in_coff = 0; }
+        if (!top && !ksplit) { tk.k_in = S.keep_in; tk.r_in = (cid + 1) * 4; tk.in_W = H; tk.in_coff = 0; }
+      }
+      if (ksplit && !top) {
+        // HELP task right behind its cell: the cell reads the helper (upper[cell] = cell + 1), the helper reads the cell above
+        // (upper[helper] = helper + 1 = the next layer's cell)
+        if (L.ntask >= B_MAX_TASKS) UNSUP(4);
+        const avsr_rnn_layer& Up = S.layer[l + 1];
+        const int h_i = L.ntask++;
+        BTask& hk = L.task[h_i];
+        hk.kind = 1;
+        hk.w_up = Up.w; hk.ldw_up = 4 * Up.units; hk.H_up = Up.units; hk.up_dgates = Up.dgates;
+        hk.len = S.len; hk.B = S.B; hk.T = S.T; hk.H = H; hk.reverse = S.reverse;
+        hk.ntile = 1; hk.nct = H / 16;
+        const long need = (long)S.B * S.T * H;
+        if (part_used + need > g_persist_scratch_floats) UNSUP(13);
+        hk.dx = g_persist_scratch + part_used; part_used += need;
+        tk.dx = hk.dx;
+        cost[h_i] = hk.nct; upper[h_i] = h_i + 1;
+        if (S.seed) {
+          const uint32_t cid = (uint32_t)(S.cell_id_base + l);
+          hk.seed = S.seed; hk.k_in = S.keep_in; hk.r_in = (cid + 1) * 4; hk.in_W = H; hk.in_coff = 0;
+          hk.k_st = hk.k_out = 1.0f;
+        }
       }
     }
     (void)first;
   }
   // one 512-thread workgroup per CU (its register budget admits no second one): <= 32 per XCD, keep a margin
-  if (!assign_halves(cost, upper, L.ntask, 28, half)) UNSUP(9);
+  // (the K-split kernel fills an XCD: 32, like the forward kernel's 96 three-per-CU workgroups)
+  // (K-split kernel: 512-thread workgroups held to 128 VGPRs, two per CU)
+  int ecost[B_MAX_TASKS];
+  for (int i = 0; i < L.ntask; ++i) ecost[i] = L.task[i].kind == 1 ? 1 : 3;
+  if (!assign_halves(cost, upper, L.ntask, ksplit ? 64 : 28, half, ksplit ? ecost : nullptr)) UNSUP(9);
   long words = P_HDR + 8;
   int slots[2] = {0, 0};
-  for (int i = 0; i < L.ntask; ++i) {
-    BTask& tk = L.task[i];
-    tk.half = half[i]; tk.slot_begin = slots[half[i]]; slots[half[i]] += tk.nct;
-    tk.prog = sync + words; words += 4 * 32;
-  }
+  // slots are claimed in arrival order and the dispatcher fills every CU once before it doubles up: cells take the first slots (a CU
+  // to themselves as far as they go), helpers the rest
+  for (int pass = 0; pass < 2; ++pass)
+    for (int i = 0; i < L.ntask; ++i) {
+      BTask& tk = L.task[i];
+      if ((tk.kind == 1) != (pass == 1)) continue;
+      tk.half = half[i]; tk.slot_begin = slots[half[i]]; slots[half[i]] += tk.nct;
+      tk.prog = sync + words; words += 4 * 32;
+    }
   for (int i = 0; i < L.ntask; ++i) {
     BTask& tk = L.task[i];
     if (upper[i] < 0) continue;
@@ -401,7 +722,8 @@ int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
     if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
       ProfScope ps(PROF_RNN_PERSIST_BWD, s, flops * rows / B);
-      hipLaunchKernelGGL(rnn_persist_bwd_kernel, dim3(8 * wpx), dim3(512), 0, s, L);
+      if (ksplit) hipLaunchKernelGGL(rnn_persist_bwdk_kernel, dim3(8 * wpx), dim3(512), 0, s, L);
+      else hipLaunchKernelGGL(rnn_persist_bwd_kernel, dim3(8 * wpx), dim3(512), 0, s, L);
     }
     AVSR_CHECK_LAUNCH();
   }

@@ -284,7 +284,9 @@ def rnn_set_persistent(on, device="cuda", ints=1 << 20, mode=3, scratch_floats=6
     if on:
         if _persist_sync is None:
             _persist_sync = torch.zeros(ints, dtype=torch.int32, device=device)
-        if (mode & 4) and _persist_scratch is None:
+        if (mode & 6) and _persist_scratch is None:
+            # mode 2: the K-split BPTT kernel's partial-gradient slabs (2 x H/16 x B x H floats per cell) and its helpers' dx records
+            # ([B, T, H] per layer edge); mode 4: the split BPTT's dx operands
             _persist_scratch = torch.zeros(scratch_floats, dtype=torch.float32, device=device)
         if _persist_scratch is not None:
             check(_L().avsr_rnn_set_persistent_scratch(_persist_scratch.data_ptr(), _persist_scratch.numel()), "avsr_rnn_set_persistent_scratch")
