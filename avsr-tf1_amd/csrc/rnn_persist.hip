@@ -355,8 +355,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (eok && tk.bias) bias4 = ld4(tk.bias + u * 4);
   float c_state = 0.f, h_state = 0.f;
 
-  const int ab = row0 + i;
-  const bool aok = i < R && ab < tk.B;
+  // PT (8-row groups): the 16 rows of an MFMA tile are the group's 8 rows at TWO time steps - tile rows 0-7 serve even steps, rows 8-15
+  // odd steps.  The recurrent operand fills only the rows of the current step's parity (the other half is the padding an 8-row group
+  // cannot avoid there), but the input-part product of steps (t, t+1) is ONE full tile every second step: half its MFMAs.
+  constexpr bool PT = (R == 8);
+  const int sub = PT ? (i >> 3) : 0;               // which step of the pair this lane's tile row belongs to
+  const int ab = row0 + (PT ? (i & 7) : i);
+  const bool aok = (PT || i < R) && ab < tk.B;
   const int len_a = aok ? (tk.len ? tk.len[ab] : T) : 0;
   const int xrow = (int)(ab * tk.x_sb) + 4 * q, hrow = (int)(ab * tk.hsr_sb) + 4 * q;
   const int x_st = (int)tk.x_st, h_st = (int)tk.hsr_st;
@@ -399,7 +404,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   f32x4 xcur[P_XC];
 #pragma unroll
   for (int c = 0; c < P_XC; ++c) xcur[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto load_x = [&](int t, f32x4* dst) {
+  auto load_x = [&](int t0, f32x4* dst) {          // PT: rows of steps (t0, t0 + 1) side by side
+    const int t = t0 + sub;
     const bool v = aok && t < len_a;
     const int xo = xrow + (reverse ? len_a - 1 - t : t) * x_st;
 #pragma unroll
@@ -409,10 +415,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
   };
   if (has_low) {
-    wait_progress(0, 1);
+    wait_progress(0, PT ? (2 < T ? 2 : T) : 1);
     __syncthreads();
     load_x(0, xcur);
   }
+  f32x4 accx[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // PT: input part of the current pair of steps
   f32x4 znext = {0.f, 0.f, 0.f, 0.f};
   znext = ldb4(z_rs, (eok && hoisted && 0 < len_b) ? (rec_b + (reverse ? len_b - 1 : 0) * H) * 16 : P_OOB);
 #ifdef PERSIST_TIMING
@@ -425,10 +432,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     f32x4 zpre = znext;                          // prefetched during the previous step; handed over here (see rnn_persist_bwd.hip)
     asm volatile("" : "+v"(zpre));
     // dependencies: step t-1 of this layer (all column tiles of my rows); the layer below one step ahead
-    wait_progress(t, t + 2 < T ? t + 2 : T);
+    // (PT: the pair (t+1, t+2) is requested during the odd step t, so the layer below must then be three steps on)
+    wait_progress(t, PT ? ((t & 1) ? (t + 3 < T ? t + 3 : T) : 0) : (t + 2 < T ? t + 2 : T));
     lds_barrier();
     TICK(0)
-    const bool avalid = aok && t < len_a;
+    const bool avalid = aok && t < len_a && (!PT || sub == (t & 1));
     const int ho_ = hrow + (reverse ? len_a - 1 - t : t) * h_st;
     f32x4 hv[P_HC];
 #pragma unroll
@@ -445,16 +453,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!hoisted) {
       // input part first: its operands arrived a step ago, so these MFMAs run under the loads just issued
+      if (!PT || !(t & 1)) {
 #pragma unroll
-      for (int c = 0; c < P_XC; ++c)
-        if (c < nxw) {
+        for (int c = 0; c < P_XC; ++c)
+          if (c < nxw) {
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xcur[c][e], wa[c][nt][e], acc[nt], 0, 0, 0);
-        }
-      load_x(t + 1 < T ? t + 1 : T, xcur);     // refill in place: consumed a step from now (past the end: nothing is fetched)
+              for (int e = 0; e < 4; ++e)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xcur[c][e], wa[c][nt][e], acc[nt], 0, 0, 0);
+          }
+        if (PT) { accx[0] = acc[0]; accx[1] = acc[1]; }
+      } else {
+        acc[0] = accx[0]; acc[1] = accx[1];      // rows 8-15: the input part of this (odd) step, computed a step ago
+      }
+      if (!PT) load_x(t + 1 < T ? t + 1 : T, xcur);     // refill in place: consumed a step from now (past the end: nothing is fetched)
+      else if (t & 1) load_x(t + 1 < T ? t + 1 : T, xcur);
     }
     // hoisted x.Wx of the NEXT step (cold in HBM).  Issued last: vmcnt retires in order, so a slow load must be
     // younger than the recurrent operands or it would stall their wait.
@@ -476,11 +490,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
               acc[2 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[c][e], wa[c][nt][e], acc[2 + nt], 0, 0, 0);
         }
       }
-    if (q < R / 4) {                             // C rows (lane>>4)*4 + r: rows < R carry batch rows
+    if (PT ? (q >> 1) == (t & 1) : q < R / 4) {  // C rows (lane>>4)*4 + r carry batch rows (PT: the half of the tile of this step's parity)
+      const int rq = PT ? (q & 1) : q;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][nt][q * 4 + r][i] = acc[nt][r];
+        for (int r = 0; r < 4; ++r) red[wave][nt][rq * 4 + r][i] = acc[nt][r];
     }
     lds_barrier();
     TICK(2)
