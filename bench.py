@@ -341,24 +341,29 @@ def main():
         out["kernel_time_events"] = kinds
         dom = max(kinds, key=lambda k: kinds[k]["total_ms"])
         HBM_PEAK, MFMA_PEAK = 8000.0, 157.3
-        # HBM traffic per launch from the committed PMC passes (profiles/r02_c4_lipcnn_pmc_v4.json: FETCH_SIZE / WRITE_SIZE collected in
+        # HBM traffic per launch from the committed PMC passes (profiles/r02_c4_lipcnn_pmc_v5.json: FETCH_SIZE / WRITE_SIZE collected in
         # separate rocprofv3 runs of this same workload, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); null
         # for workloads / kernels that were not profiled.
         pmc = {}
         try:
             if args.workload == "c4" and args.video_frontend == "resnet_cnn":
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_c4_lipcnn_pmc_v4.json")))["kernels"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_c4_lipcnn_pmc_v5.json")))["kernels"]
         except Exception:
             pmc = {}
-        pmc_name = {"attn_fwd": "avsr::attn_fwd_kernel", "attn_bwd": "avsr::attn_bwd_kernel",
-                    "dec_persist_fwd": "avsr::dec_persist_kernel<1, 4, 2>", "dec_persist_bwd": "avsr::dec_persist_bwd_kernel<1, 4>",
-                    "step_lstm_fwd": "avsr::step_kernel<1, 1, 1, 4>", "step_lstm_bwd": "avsr::step_kernel<2, 1, 1, 8>",
-                    "step_dense": "avsr::step_kernel<0, 1, 1, 4>",
-                    "rnn_persist_fwd": "avsr::rnn_persist_fwd_xcd_kernel", "rnn_persist_bwd": "avsr::rnn_persist_bwd_kernel"}
+        # kernel-name prefixes of the PMC summary (template arguments vary with the configuration: the first match is taken)
+        pmc_name = {"attn_fwd": ["avsr::attn_fwd_kernel"], "attn_bwd": ["avsr::attn_bwd_kernel"],
+                    "dec_persist_fwd": ["avsr::dec_persist_kernel<"], "dec_persist_bwd": ["avsr::dec_persist_bwd_kernel<"],
+                    "step_lstm_fwd": ["avsr::step_kernel<1, 1, 1, 4>"], "step_lstm_bwd": ["avsr::step_kernel<2, 1, 1, 8>"],
+                    "step_dense": ["avsr::step_kernel<0, 1, 1, 4>"],
+                    "rnn_persist_fwd": ["avsr::rnn_persist_fwd_xcd_kernel"],
+                    "rnn_persist_bwd": ["avsr::rnn_persist_bwdk_kernel", "avsr::rnn_persist_bwd_kernel"]}
 
         def traffic(kind):
-            k = pmc.get(pmc_name.get(kind, ""))
-            return k["hbm_bytes_per_dispatch_corrected"] if k else None
+            for prefix in pmc_name.get(kind, []):
+                for name in sorted(pmc):
+                    if name.startswith(prefix):
+                        return pmc[name]["hbm_bytes_per_dispatch_corrected"]
+            return None
 
         def roof(kind):
             us = kinds[kind]["avg_us"]
