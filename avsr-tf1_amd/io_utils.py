@@ -366,12 +366,64 @@ class _Pipeline:
         self.batch_size, self.shuffle, self.bucket_width, self.max_len = batch_size, shuffle, bucket_width, max_sentence_length
         self.rng = random.Random(seed)
         self.shuffle_buffer = 5000
+        from . import _io_native
+        self.native = _io_native if _io_native.load() is not None else None
 
     def _key(self, ex):
         return ex[0][0][2] // self.bucket_width                # first stream's input_length (video for AV)
 
+    # Native path (include/avsr_io.h): the records of a chunk are INDEXED by the C helper (value regions, lengths, file names) and the
+    # examples that flow through shuffle / bucket carry (payload, index row) instead of parsed arrays; _batch fills the padded arrays
+    # straight from the payloads.  An example is a pair (streams, lab) either way:
+    #   stream = (x | None, aus | None, T, filename, payload, row)      lab = (labels | None, labels_length + 1, filename, payload, row, n + 1)
+    # with x / labels None for indexed records.  Records the helper does not recognise are parsed by the python parser (same tuples,
+    # arrays filled in).
+    def _examples_native(self, its):
+        N, F = self.native, self.native.F
+        ns = len(self.data_records)
+        sizes = [int(np.prod(shp[0])) for shp in self.shapes]
+
+        def flush(chunk):
+            info = N.index([p for recs in chunk for p in recs])
+            for ci, recs in enumerate(chunk):
+                rows = info[ci * (ns + 1):(ci + 1) * (ns + 1)]
+                lr = rows[ns]
+                ok = not rows[:, F["slow"]].any() and lr[F["labels_length"]] >= 0 and lr[F["fn_off"]] >= 0
+                for k in range(ns):
+                    r = rows[k]
+                    ok = ok and r[F["input_length"]] >= 0 and r[F["fn_off"]] >= 0 and \
+                        r[F["in_T"]] * r[F["in_F"]] == r[F["input_length"]] * sizes[k] and \
+                        (r[F["aus_T"]] == 0 or (r[F["aus_F"]] * r[F["aus_T"]] == 2 * r[F["input_length"]]))
+                if not ok:                                  # unusual layout: the generic parser decides (and raises what it raises)
+                    streams = [_parse_input(p, shp[0]) + (None, None) for p, shp in zip(recs[:-1], self.shapes)]
+                    lab = _parse_labels(recs[-1], self.eos)
+                    lab = lab + (None, None, lab[0].shape[0])
+                else:
+                    streams = []
+                    for k in range(ns):
+                        r, pl = rows[k], recs[k]
+                        streams.append((None, None, int(r[F["input_length"]]), pl[r[F["fn_off"]]:r[F["fn_off"]] + r[F["fn_len"]]], pl, r))
+                    pl = recs[ns]
+                    lab = (None, int(lr[F["labels_length"]]) + 1, pl[lr[F["fn_off"]]:lr[F["fn_off"]] + lr[F["fn_len"]]], pl, lr,
+                           int(lr[F["lab_n"]]) + 1)
+                if self.max_len is not None and not lab[1] < self.max_len:
+                    continue
+                yield streams, lab
+
+        chunk = []
+        for recs in zip(*its):
+            chunk.append(recs)
+            if len(chunk) == 256:
+                yield from flush(chunk)
+                chunk = []
+        if chunk:
+            yield from flush(chunk)
+
     def _examples(self):
         its = [read_tfrecord(r) for r in self.data_records] + [read_tfrecord(self.label_record)]
+        if self.native is not None:
+            yield from self._examples_native(its)
+            return
         for recs in zip(*its):
             streams = [_parse_input(p, shp[0]) for p, shp in zip(recs[:-1], self.shapes)]
             lab = _parse_labels(recs[-1], self.eos)
@@ -400,27 +452,69 @@ class _Pipeline:
         lo, hi = (n * r) // w, (n * (r + 1)) // w
         return exs[lo:hi]
 
+    def _stack_stream(self, st, k, T):
+        """Zero-padded [n, T, ...] inputs (and Action Units or None) of stream k from its per-utterance entries."""
+        shape = tuple(self.shapes[k][0])
+        idx = [i for i, s in enumerate(st) if s[0] is None]                    # indexed records: filled by the native helper
+        if not idx:
+            x = _pad_stack([s[0] for s in st], T)
+            aus = _pad_stack([s[1] for s in st], T) if st[0][1] is not None else None
+            return x, aus
+        N, F = self.native, self.native.F
+        pls = [s[4] if s[0] is None else b"" for s in st]
+        rows = [s[5] if s[0] is None else None for s in st]
+        col = lambda name: [0 if r is None else int(r[F[name]]) for r in rows]
+        step = max(col("in_F"))
+        x = N.fill_f32(pls, col("in_off"), col("in_stride"), col("in_T"), step, T, shape)
+        has_aus = any(r is not None and r[F["aus_T"]] > 0 for r in rows) or any(s[0] is not None and s[1] is not None for s in st)
+        aus = N.fill_f32(pls, col("aus_off"), col("aus_stride"), col("aus_T"), 2, T, (2,)) if has_aus else None
+        for i, s in enumerate(st):                                              # the few generically parsed ones
+            if s[0] is not None:
+                x[i, :s[0].shape[0]] = s[0]
+                if aus is not None and s[1] is not None:
+                    aus[i, :s[1].shape[0]] = s[1]
+        return x, aus
+
+    def _stack_labels(self, labs, Lmax):
+        if all(e[0] is not None for e in labs):
+            return _pad_stack([e[0] for e in labs], Lmax)
+        N, F = self.native, self.native.F
+        rows = [e[4] if e[0] is None else None for e in labs]
+        col = lambda name: [0 if r is None else int(r[F[name]]) for r in rows]
+        out = N.fill_labels([e[3] if e[0] is None else b"\0" for e in labs], col("lab_off"), col("lab_stride"), col("lab_n"), self.eos, Lmax)
+        for i, e in enumerate(labs):
+            if e[0] is not None:
+                out[i] = 0
+                out[i, :e[0].shape[0]] = e[0]
+        return out
+
+    @staticmethod
+    def _lab_len(lab):
+        return lab[0].shape[0] if lab[0] is not None else lab[5]
+
     def _batch(self, exs):
         # a rank's shard is padded to the lengths of the GLOBAL batch: padded_batch pads to the longest member of the whole batch, and
         # the input batch-norm takes its statistics over the padded rows too (SURVEY A5), so the shard must keep that row count
         full = exs
         exs = self._shard(exs)
-        Lmax = max(e[1][0].shape[0] for e in full)
+        Lmax = max(self._lab_len(e[1]) for e in full)
         if not exs[0][0]:                                       # label-only pipelines (language model)
             names = [e[1][2] for e in exs]
             return BatchedData(None, None, None, None, _pad_stack([e[1][0] for e in exs], Lmax), np.array([e[1][1] for e in exs], np.int32),
                                None if names[0] is None else names, None)
         streams = list(zip(*[e[0] for e in exs]))
         fstreams = list(zip(*[e[0] for e in full]))
-        Tmax = [max(s[0].shape[0] for s in st) for st in fstreams]
-        inputs = [_pad_stack([s[0] for s in st], T) for st, T in zip(streams, Tmax)]
+        # (an indexed record's frame count is its input_length: the consistency of the two was checked when it was indexed)
+        Tmax = [max((s[0].shape[0] if s[0] is not None else s[2]) for s in st) for st in fstreams]
+        inputs, payload = [], {}
+        for k, (st, T) in enumerate(zip(streams, Tmax)):
+            x, aus = self._stack_stream(st, k, T)
+            inputs.append(x)
+            if aus is not None:
+                payload["aus"] = aus
         lens = [np.array([s[2] for s in st], np.int32) for st in streams]
         names = [[s[3] for s in st] for st in streams]
-        payload = {}
-        for st, T in zip(streams, Tmax):
-            if st[0][1] is not None:
-                payload["aus"] = _pad_stack([s[1] for s in st], T)
-        labels = _pad_stack([e[1][0] for e in exs], Lmax)
+        labels = self._stack_labels([e[1] for e in exs], Lmax)
         llen = np.array([e[1][1] for e in exs], np.int32)
         lnames = [e[1][2] for e in exs]
         one = len(inputs) == 1

@@ -25,6 +25,26 @@ def test_library_builds_loads_and_exports_every_header_symbol():
         assert sym in _lib.EXPORTS, "%s missing from the ctypes binding" % sym
 
 
+def test_io_helper_builds_loads_and_exports_every_header_symbol():
+    """include/avsr_io.h / libavsr_io.so: the native record indexer + batch filler of the input pipeline (plain C99)."""
+    import subprocess
+    import tempfile
+    from avsr_tf1_amd import _io_native as N
+    lib = N.load()
+    assert lib is not None and lib.avsr_io_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "avsr_io.h")).read()
+    declared = sorted(set(re.findall(r"^\s*int\s+(avsr_io_\w+)\s*\(", hdr, flags=re.M)))
+    assert declared == ["avsr_io_abi_version", "avsr_io_fill_f32", "avsr_io_fill_labels", "avsr_io_index"]
+    for sym in declared:
+        assert hasattr(lib, sym)
+    with tempfile.TemporaryDirectory() as d:       # the record struct has the 16 int64 fields the binding indexes
+        src = os.path.join(d, "p.c")
+        open(src, "w").write('#include "avsr_io.h"\nint main(void){return sizeof(avsr_io_rec) == 16 * 8 ? 0 : 1;}\n')
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", src + ".exe"])
+        assert subprocess.call([src + ".exe"]) == 0
+    assert N.NFIELD == 16 and len(N.F) == 16
+
+
 def test_ctypes_structs_match_c_layout():
     from avsr_tf1_amd import _lib
     lib = _lib.load()

@@ -236,3 +236,53 @@ def test_data_parallel_pipeline_buckets_first_then_splits_by_rank(tmp_path):
             assert np.array_equal(s[i].labels_length, b.labels_length[lo:lo + len(parts[r])])
     with pytest.raises(ValueError, match="shared shuffle seed"):
         IO.make_iterator_from_one_record(a, l, ud, batch_size=4, shuffle=True, rank=0, world=2)
+
+
+def test_native_indexer_gives_the_python_parsers_batches(tmp_path, monkeypatch):
+    """libavsr_io.so (include/avsr_io.h): batches built from natively indexed records equal the python parser's, field by field -
+    one / two streams with Action Units, shuffle + buckets + length filter, a rank's shard - and records whose layout the helper does
+    not take (labels >= 128: two-byte varints; a label list of unequal steps) fall back to the python parser inside the same batch."""
+    from avsr_tf1_amd import _io_native as N
+    assert N.load() is not None, "the native input-pipeline helper must build here (gcc)"
+    ud, a, l, v, feats, labs, vids = _write_dataset(str(tmp_path), n=70)
+    # a second label file with some records outside the fast layout
+    l2 = str(tmp_path / "labels_odd.tfrecord")
+    with IO.TFRecordFileWriter(l2) as fl:
+        for i in range(70):
+            lab = list(labs[i])
+            if i % 7 == 3:
+                lab[0] = 300                                    # two-byte varint: not the one-byte fast layout
+            fl.write(IO.make_label_example("u%d" % i, lab, "character"))
+
+    def same(x, y):
+        if isinstance(x, tuple):
+            return len(x) == len(y) and all(same(p, q) for p, q in zip(x, y))
+        if isinstance(x, np.ndarray):
+            return x.shape == y.shape and x.dtype == y.dtype and np.array_equal(x, y)
+        if isinstance(x, dict):
+            return set(x) == set(y) and all(same(x[k], y[k]) for k in x)
+        if isinstance(x, list):
+            return len(x) == len(y) and all(same(p, q) for p, q in zip(x, y))
+        return x == y
+
+    makes = [lambda: IO.make_iterator_from_one_record(a, l, ud, batch_size=4, shuffle=True, bucket_width=45, seed=5, max_sentence_length=7),
+             lambda: IO.make_iterator_from_two_records(v, a, l, batch_size=3, unit_dict=ud, shuffle=True, bucket_width=45, seed=2),
+             lambda: IO.make_iterator_from_one_record(v, l2, ud, batch_size=5, shuffle=False, bucket_width=45),
+             lambda: IO.make_iterator_from_one_record(a, l2, ud, batch_size=5, shuffle=True, bucket_width=45, seed=1, rank=1, world=2)]
+    for make in makes:
+        nat = make()
+        assert nat.native is not None
+        py = make()
+        py.native = None
+        bn, bp = list(nat), list(py)
+        assert len(bn) == len(bp) and len(bn) > 3
+        for x, y in zip(bn, bp):
+            assert all(same(getattr(x, f), getattr(y, f)) for f in x._fields)
+    # the indexer itself: fields of one record of each kind
+    F = N.F
+    info = N.index([next(IO.read_tfrecord(a)), next(IO.read_tfrecord(l)), next(IO.read_tfrecord(v)), next(IO.read_tfrecord(l2)), b"\\x0a\\x05junk"])
+    assert info[0, F["slow"]] == 0 and info[0, F["in_T"]] == feats[0].shape[0] and info[0, F["in_F"]] == feats[0].shape[1]
+    assert info[1, F["slow"]] == 0 and info[1, F["lab_n"]] == len(labs[0]) and info[1, F["labels_length"]] == len(labs[0])
+    assert info[2, F["slow"]] == 0 and info[2, F["aus_T"]] == vids[0][1].shape[0] and info[2, F["aus_F"]] == 2
+    assert info[4, F["slow"]] == 1
+    monkeypatch.setenv("AVSR_IO_NATIVE", "0")
