@@ -230,3 +230,17 @@ def test_adam_step_with_cosine_restarts(start):
     assert int(step.item()) == t
     assert np.abs(dp.cpu().numpy() - want).max() < 2e-6 * max(1.0, lr_t / 1e-3)
     assert np.abs((dp.cpu().numpy() - p) - (want - p)).max() < 1e-3 * np.abs(want - p).max() + 1e-9
+
+
+def test_unit_partitioned_bptt_kernel_stays_covered():
+    """The K-split persistent BPTT is the default; the round-1 kernel partitioned by units takes what it declines (and AVSR_RNN_BWD_KSPLIT=0).
+    The switch is read once per process, so the same stack tests run in a child with the K-split form off."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AVSR_RNN_BWD_KSPLIT="0")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x", "-k",
+                        "test_rnn_stack_fwd_bwd and (2 or 6)"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout
