@@ -27,7 +27,15 @@ def build(force=False):
     gcc = shutil.which("gcc")
     if gcc is None:
         raise RuntimeError("gcc not found: the native input-pipeline helper cannot be built")
-    subprocess.check_call([gcc, "-O3", "-std=c99", "-Wall", "-shared", "-fPIC", "-pthread", "-I", INC, SRC, "-o", LIB])
+    # compile to a private temporary file and rename it into place: under torchrun several ranks may get here at once, and a rank
+    # must never CDLL a library another rank is still writing (os.replace is atomic on one file system)
+    tmp = "%s.%d.tmp" % (LIB, os.getpid())
+    try:
+        subprocess.check_call([gcc, "-O3", "-std=c99", "-Wall", "-shared", "-fPIC", "-pthread", "-I", INC, SRC, "-o", tmp])
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 
@@ -41,14 +49,19 @@ def load():
         return None
     try:
         lib = C.CDLL(build())
-        if lib.avsr_io_abi_version() != 1:
-            raise RuntimeError("libavsr_io.so: ABI version mismatch")
+        if lib.avsr_io_abi_version() != 2:
+            lib = C.CDLL(build(force=True))                  # a stale build of an older ABI: rebuild once
+            if lib.avsr_io_abi_version() != 2:
+                raise RuntimeError("libavsr_io.so: ABI version mismatch")
         pp, pl = C.POINTER(C.c_char_p), C.POINTER(C.c_int64)
         lib.avsr_io_index.argtypes = [C.c_int32, pp, pl, C.c_void_p, C.c_int32]
-        lib.avsr_io_fill_f32.argtypes = [C.c_int32, pp, pl, pl, pl, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32]
+        lib.avsr_io_fill_f32.argtypes = [C.c_int32, pp, pl, pl, pl, pl, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32]
         lib.avsr_io_fill_labels.argtypes = [C.c_int32, pp, pl, pl, pl, C.c_int32, C.c_void_p, C.c_int64]
         _lib = lib
-    except Exception:
+    except Exception as e:
+        # not silent: ranks that ended up on different parsers would be hard to notice (the batches are the same, the speed is not)
+        import warnings
+        warnings.warn("avsr_tf1_amd: native input-pipeline helper unavailable (%s: %s); using the python parser" % (type(e).__name__, e))
         _failed = True
     return _lib
 
@@ -72,8 +85,8 @@ def fill_f32(payloads, off, stride, steps, step_floats, Tmax, row_shape):
     n = len(payloads)
     row = int(np.prod(row_shape)) if len(row_shape) else 1
     dst = np.empty((n, Tmax) + tuple(row_shape), np.float32)          # the helper writes every byte (values, then zero padding)
-    (o, op), (s, sp), (t, tp) = _i64(off), _i64(stride), _i64(steps)
-    _lib.avsr_io_fill_f32(n, (C.c_char_p * n)(*payloads), op, sp, tp, int(step_floats), dst.ctypes.data, int(Tmax), row, THREADS)
+    (o, op), (s, sp), (t, tp), (ln, lp) = _i64(off), _i64(stride), _i64(steps), _i64([len(p) for p in payloads])
+    _lib.avsr_io_fill_f32(n, (C.c_char_p * n)(*payloads), lp, op, sp, tp, int(step_floats), dst.ctypes.data, int(Tmax), row, THREADS)
     return dst
 
 

@@ -358,7 +358,8 @@ class LipCNN:
                 if item[0] in written:
                     deferred.remove(item)
                     item[1]()
-        for src, fn in deferred:                                              # no other contribution ever arrived: zero, then accumulate
-            ops.zero_(self.gmaps[src])
-            written.add(src)
-            fn()
+        # A deferred 1x1/2 data gradient waits for another contribution to its map.  In resnet_cnn every such map is also read by the
+        # block's first batch norm, whose backward writes it -- and that backward is what the map's PRODUCER then consumes.  A layout
+        # in which the strided shortcut were the map's only reader would reach this point with the producer's backward already run on
+        # an unwritten gradient map: refuse it instead of flushing too late.
+        assert not deferred, "LipCNN.backward: a map read only by a strided 1x1 shortcut (%s) is not supported" % [d[0] for d in deferred]

@@ -39,7 +39,7 @@ static int64_t rd_field(const uint8_t* x, int64_t n, int64_t i, int* fn, int* wt
   if (*wt == 2) {
     uint64_t ln;
     i = rd_varint(x, n, i, &ln);
-    if (i < 0 || (int64_t)ln > n - i) return -1;
+    if (i < 0 || ln > (uint64_t)(n - i)) return -1;        /* unsigned: a length >= 2^63 must not turn into a negative span */
     sp->p = x + i; sp->n = (int64_t)ln;
     return i + (int64_t)ln;
   }
@@ -96,13 +96,13 @@ static int fast_float_steps(span x, int64_t* h_out, int64_t* stride_out, int64_t
   uint64_t l1, l2, l3;
   if (n < 8 || x.p[0] != 0x0A) return -1;
   const int64_t i = rd_varint(x.p, n, 1, &l1);
-  if (i < 0) return -1;
+  if (i < 0 || l1 > (uint64_t)(n - i)) return -1;          /* unsigned compares: corrupt lengths >= 2^63 are rejected, not cast */
   const int64_t stride = i + (int64_t)l1;
   if (stride <= 0 || n % stride || i >= n || x.p[i] != 0x12) return -1;
   const int64_t j = rd_varint(x.p, n, i + 1, &l2);
-  if (j < 0 || j >= n || x.p[j] != 0x0A) return -1;
+  if (j < 0 || j >= n || l2 > (uint64_t)n || x.p[j] != 0x0A) return -1;
   const int64_t h = rd_varint(x.p, n, j + 1, &l3);
-  if (h < 0) return -1;
+  if (h < 0 || h > stride || l3 > (uint64_t)n) return -1;
   if (l3 % 4 || h + (int64_t)l3 != stride || (int64_t)l2 != (h - j) + (int64_t)l3) return -1;
   const int64_t T = n / stride;
   for (int64_t t = 1; t < T; ++t)
@@ -117,13 +117,13 @@ static int fast_small_int_steps(span x, int64_t* h_out, int64_t* stride_out, int
   uint64_t l1, l2, l3;
   if (n < 7 || x.p[0] != 0x0A) return -1;
   const int64_t i = rd_varint(x.p, n, 1, &l1);
-  if (i < 0) return -1;
+  if (i < 0 || l1 > (uint64_t)(n - i)) return -1;
   const int64_t stride = i + (int64_t)l1;
   if (stride <= 0 || n % stride || i >= n || x.p[i] != 0x1A) return -1;
   const int64_t j = rd_varint(x.p, n, i + 1, &l2);
-  if (j < 0 || j >= n || x.p[j] != 0x0A) return -1;
+  if (j < 0 || j >= n || l2 > (uint64_t)n || x.p[j] != 0x0A) return -1;
   const int64_t h = rd_varint(x.p, n, j + 1, &l3);
-  if (h < 0 || l3 != 1 || h + 1 != stride) return -1;
+  if (h < 0 || h > stride || l3 != 1 || h + 1 != stride) return -1;
   const int64_t cnt = n / stride;
   for (int64_t t = 0; t < cnt; ++t) {
     if (t && memcmp(x.p + t * stride, x.p, (size_t)h) != 0) return -1;
@@ -201,9 +201,19 @@ static void* run_job(void* arg) {
     for (int b = j->lo; b < j->hi; ++b) {
       const uint8_t* src = j->bufs[b] + j->off[b];
       uint8_t* d = (uint8_t*)(j->dst + (int64_t)b * j->Tmax * j->row_floats);
-      if (j->stride[b] == sb) memcpy(d, src, (size_t)(sb * j->steps[b]));          /* values back to back */
-      else for (int64_t t = 0; t < j->steps[b]; ++t) memcpy(d + t * sb, src + t * j->stride[b], (size_t)sb);
-      const int64_t used = sb * j->steps[b], all = j->Tmax * j->row_floats * 4;     /* zero padding behind the utterance */
+      const int64_t all = j->Tmax * j->row_floats * 4;
+      /* never write past the utterance's slot, never read past its payload (lens may be NULL: callers that validated already) */
+      int64_t steps = j->steps[b] < 0 ? 0 : j->steps[b];
+      if (sb > 0 && steps * sb > all) steps = all / sb;
+      if (j->lens && sb > 0 && steps > 0) {
+        const int64_t st = j->stride[b] > 0 ? j->stride[b] : sb;
+        const int64_t avail = j->lens[b] - j->off[b];
+        if (j->off[b] < 0 || avail < sb) steps = 0;
+        else if ((steps - 1) * st + sb > avail) steps = (avail - sb) / st + 1;
+      }
+      if (j->stride[b] == sb) memcpy(d, src, (size_t)(sb * steps));                  /* values back to back */
+      else for (int64_t t = 0; t < steps; ++t) memcpy(d + t * sb, src + t * j->stride[b], (size_t)sb);
+      const int64_t used = sb * steps;                                               /* zero padding behind the utterance */
       if (all > used) memset(d + used, 0, (size_t)(all - used));
     }
   }
@@ -222,7 +232,7 @@ static void run_parallel(job* proto, int n, int nthreads) {
   for (int t = 1; t < nthreads; ++t) { if (started[t]) pthread_join(th[t], 0); else run_job(&jobs[t]); }
 }
 
-int avsr_io_abi_version(void) { return 1; }
+int avsr_io_abi_version(void) { return 2; }
 
 int avsr_io_index(int32_t n, const uint8_t* const* bufs, const int64_t* lens, avsr_io_rec* out, int32_t nthreads) {
   if (n <= 0) return 0;
@@ -232,11 +242,11 @@ int avsr_io_index(int32_t n, const uint8_t* const* bufs, const int64_t* lens, av
   return 0;
 }
 
-int avsr_io_fill_f32(int32_t n, const uint8_t* const* bufs, const int64_t* off, const int64_t* stride, const int64_t* steps,
-                     int64_t step_floats, float* dst, int64_t Tmax, int64_t row_floats, int32_t nthreads) {
+int avsr_io_fill_f32(int32_t n, const uint8_t* const* bufs, const int64_t* lens, const int64_t* off, const int64_t* stride,
+                     const int64_t* steps, int64_t step_floats, float* dst, int64_t Tmax, int64_t row_floats, int32_t nthreads) {
   if (n <= 0) return 0;
   job j; memset(&j, 0, sizeof(j));
-  j.kind = 1; j.bufs = bufs; j.off = off; j.stride = stride; j.steps = steps; j.step_floats = step_floats; j.dst = dst; j.Tmax = Tmax;
+  j.kind = 1; j.bufs = bufs; j.lens = lens; j.off = off; j.stride = stride; j.steps = steps; j.step_floats = step_floats; j.dst = dst; j.Tmax = Tmax;
   j.row_floats = row_floats;
   run_parallel(&j, n, nthreads);
   return 0;

@@ -391,9 +391,12 @@ class _Pipeline:
                 ok = not rows[:, F["slow"]].any() and lr[F["labels_length"]] >= 0 and lr[F["fn_off"]] >= 0
                 for k in range(ns):
                     r = rows[k]
+                    # exactly the layout _stack_stream fills from: one step per frame, `size` floats per step (2 for the Action
+                    # Units).  A record whose floats are split differently (same product) is legal for the generic parser and is
+                    # left to it -- the native filler copies steps[b] * step_floats per utterance and must never see another split.
                     ok = ok and r[F["input_length"]] >= 0 and r[F["fn_off"]] >= 0 and \
-                        r[F["in_T"]] * r[F["in_F"]] == r[F["input_length"]] * sizes[k] and \
-                        (r[F["aus_T"]] == 0 or (r[F["aus_F"]] * r[F["aus_T"]] == 2 * r[F["input_length"]]))
+                        r[F["in_T"]] == r[F["input_length"]] and r[F["in_F"]] == sizes[k] and \
+                        (r[F["aus_T"]] == 0 or (r[F["aus_F"]] == 2 and r[F["aus_T"]] == r[F["input_length"]]))
                 if not ok:                                  # unusual layout: the generic parser decides (and raises what it raises)
                     streams = [_parse_input(p, shp[0]) + (None, None) for p, shp in zip(recs[:-1], self.shapes)]
                     lab = _parse_labels(recs[-1], self.eos)

@@ -734,11 +734,18 @@ class Seq2SeqModel:
                 ops.au_loss(E["au_z"], batch.aus, E["len"], E["au_row"], E["au_dz"], B, E["T"], cfg.au_loss_weight * self.au_scale,
                             total_count=self.au_total if self.au_external else None)
 
-    def check_persistent(self, disable=True):
+    def persistent_flagged(self):
+        """Read-only form of check_persistent(): did a persistent kernel flag the last pass on THIS rank?"""
+        return bool(self.persistent_rnn and ops.rnn_persistent_error())
+
+    def check_persistent(self, disable=True, force=False):
         """Synchronise and read the persistent kernels' sticky error word (a bounded device-side wait expired: some
         workgroups were not co-resident).  Returns True if the last results are invalid; the persistent path is then
-        switched off so that the caller can simply redo the pass through the per-step launches."""
-        if not self.persistent_rnn or not ops.rnn_persistent_error():
+        switched off so that the caller can simply redo the pass through the per-step launches.  force=True: another
+        data-parallel rank flagged its pass -- switch off here as well so that every rank redoes the pass the same way."""
+        if not self.persistent_rnn:
+            return False
+        if not force and not ops.rnn_persistent_error():
             return False
         if disable:
             import warnings

@@ -172,8 +172,23 @@ class DataParallelTrainer:
         self._phase2()
 
     def _persistent_failed(self):
+        """Did a persistent kernel flag the pass -- on ANY rank?  The flag is a per-rank observation but the redo issues collectives
+        (the overlapped bucket's all-reduce), so the decision must be the same everywhere: the local flags are MAX-reduced first
+        (one 4-byte collective, only on steps that check) and a rank that was fine redoes its pass together with the one that was not;
+        ranks deciding alone would issue different collective sequences -- a hang or mismatched reductions."""
         chk = getattr(self.model, "check_persistent", None)
-        return bool(chk and chk())
+        if not chk:
+            return False
+        if not (self.collective and self.world > 1):
+            return bool(chk())
+        probe = getattr(self.model, "persistent_flagged", None)
+        local = bool(probe()) if probe else bool(chk(disable=False))
+        flag = torch.tensor([1.0 if local else 0.0], device=self.model.grads.device if hasattr(self.model, "grads") else "cpu")
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+        if float(flag.item()) == 0.0:
+            return False
+        chk(force=True)                                   # every rank switches to the per-step launches and clears its flag
+        return True
 
     def _capture(self, fn):
         g = torch.cuda.CUDAGraph()

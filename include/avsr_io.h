@@ -31,9 +31,11 @@ int avsr_io_index(int32_t n, const uint8_t* const* bufs, const int64_t* lens, av
 
 /* dst[b, t, :] = the row_floats floats of step t of record b for t < T[b], zeros behind (dst need not be initialised).
  * dst is [n, Tmax, row_floats] float32.  Steps are F floats each and row_floats * T[b] == F * steps (a step may hold a whole row,
- * as every layout of the writer does). */
-int avsr_io_fill_f32(int32_t n, const uint8_t* const* bufs, const int64_t* off, const int64_t* stride, const int64_t* steps,
-                     int64_t step_floats, float* dst, int64_t Tmax, int64_t row_floats, int32_t nthreads);
+ * as every layout of the writer does).  The copy of record b is clamped to its slot (Tmax * row_floats floats) and, when `lens`
+ * (payload byte lengths, may be NULL) is given, to its payload: an inconsistent index row can neither overrun dst nor read past
+ * the record.  (ABI version 2: `lens` added.) */
+int avsr_io_fill_f32(int32_t n, const uint8_t* const* bufs, const int64_t* lens, const int64_t* off, const int64_t* stride,
+                     const int64_t* steps, int64_t step_floats, float* dst, int64_t Tmax, int64_t row_floats, int32_t nthreads);
 
 /* dst[b, j] = label j of record b for j < cnt[b], dst[b, cnt[b]] = eos; dst is [n, Lmax] int32, zero on entry. */
 int avsr_io_fill_labels(int32_t n, const uint8_t* const* bufs, const int64_t* off, const int64_t* stride, const int64_t* cnt,

@@ -31,7 +31,7 @@ def test_io_helper_builds_loads_and_exports_every_header_symbol():
     import tempfile
     from avsr_tf1_amd import _io_native as N
     lib = N.load()
-    assert lib is not None and lib.avsr_io_abi_version() == 1
+    assert lib is not None and lib.avsr_io_abi_version() == 2
     hdr = open(os.path.join(ROOT, "include", "avsr_io.h")).read()
     declared = sorted(set(re.findall(r"^\s*int\s+(avsr_io_\w+)\s*\(", hdr, flags=re.M)))
     assert declared == ["avsr_io_abi_version", "avsr_io_fill_f32", "avsr_io_fill_labels", "avsr_io_index"]

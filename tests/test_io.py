@@ -286,3 +286,72 @@ def test_native_indexer_gives_the_python_parsers_batches(tmp_path, monkeypatch):
     assert info[2, F["slow"]] == 0 and info[2, F["aus_T"]] == vids[0][1].shape[0] and info[2, F["aus_F"]] == 2
     assert info[4, F["slow"]] == 1
     monkeypatch.setenv("AVSR_IO_NATIVE", "0")
+
+
+def test_native_path_leaves_differently_split_records_to_the_python_parser(tmp_path):
+    """A record whose floats are split into steps differently from (input_length x input_size) - same product - is legal for the
+    generic parser; the native filler copies `steps x step_floats` per utterance and must not see it (round-2 advisor finding: a mixed
+    batch came out wrong on the native path and overran the utterance's slot)."""
+    from avsr_tf1_amd import _io_native as N
+    assert N.load() is not None
+    ud, a, l, v, feats, labs, vids = _write_dataset(str(tmp_path), n=8)
+    a2 = str(tmp_path / "a_split.tfrecord")
+    with IO.TFRecordFileWriter(a2) as fa:
+        for i, x in enumerate(feats):
+            if i % 3 == 1 and x.shape[0] % 2 == 0:          # T steps of 6 floats stored as T/2 steps of 12 floats
+                ex = IO.make_sequence_example({"input_length": [x.shape[0]], "input_size": [x.shape[1]], "filename": "f%03d" % i},
+                                              {"inputs": list(x.reshape(x.shape[0] // 2, 12))})
+            elif i % 3 == 2:                                # 2T steps of 3 floats
+                ex = IO.make_sequence_example({"input_length": [x.shape[0]], "input_size": [x.shape[1]], "filename": "f%03d" % i},
+                                              {"inputs": list(x.reshape(x.shape[0] * 2, 3))})
+            else:
+                ex = IO.make_feature_example("f%03d" % i, x)
+            fa.write(ex)
+    recs = list(IO.read_tfrecord(a2))
+    info = N.index(recs)
+    odd = [i for i in range(8) if info[i, N.F["in_F"]] != 6]
+    assert odd, "the test data must contain a differently split record"
+
+    def run(native):
+        it = IO.make_iterator_from_one_record(a2, l, ud, batch_size=4, shuffle=False, bucket_width=-1)
+        if not native:
+            it.native = None
+        out = []
+        try:
+            out = list(it)
+        except Exception as e:                              # whatever the generic parser decides, both paths must decide the same
+            return type(e).__name__
+        return out
+    nat, py = run(True), run(False)
+    if isinstance(py, str):
+        assert nat == py
+    else:
+        assert len(nat) == len(py)
+        for x, y in zip(nat, py):
+            assert np.array_equal(x.inputs, y.inputs) and np.array_equal(x.inputs_length, y.inputs_length)
+
+
+def test_native_indexer_rejects_corrupt_lengths_and_the_filler_stays_inside_its_slot():
+    """Length varints >= 2^63 must not become negative spans (round-2 advisor finding: index_one looped forever on such a payload);
+    the filler clamps an inconsistent index row to the utterance's slot and to the payload."""
+    from avsr_tf1_amd import _io_native as N
+    assert N.load() is not None
+    huge = b"\xff" * 9 + b"\x01"                            # varint 2^63 + ... (ten bytes)
+    evil = [b"\x0a" + huge + b"abc",                        # top-level length-delimited field with a 2^63-class length
+            b"\x12" + huge,
+            b"\x0a\x03\x0a" + huge,                         # nested
+            b"\x0a" + b"\x80" * 12]                         # over-long varint
+    info = N.index(evil)
+    assert (info[:, N.F["slow"]] == 1).all()
+    # a feature list whose inner lengths are corrupt: fast_float_steps must refuse it without reading past the payload
+    fl = b"\x0a" + b"\x08" + b"\x12" + huge[:5] + b"\x00\x00"
+    rec = IO._ld(2, IO._ld(1, IO._ld(1, b"inputs") + IO._ld(2, fl)))
+    assert N.index([rec])[0, N.F["slow"]] == 1
+    # filler: claims 10 steps of 4 floats for a payload holding 3, slot of 2 steps: copies 2 steps, no overrun
+    pay = np.arange(12, dtype="<f4").tobytes()
+    out = N.fill_f32([pay, pay], [0, 0], [16, 16], [10, 1], 4, 2, (4,))
+    assert out.shape == (2, 2, 4)
+    assert np.array_equal(out[0].reshape(-1), np.arange(8, dtype=np.float32))
+    assert np.array_equal(out[1, 0], np.arange(4, dtype=np.float32)) and not out[1, 1].any()
+    out = N.fill_f32([pay], [40], [16], [5], 4, 8, (4,))                     # offset near the end of the payload: nothing readable
+    assert not out.any()
