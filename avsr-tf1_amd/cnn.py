@@ -168,6 +168,28 @@ class LipCNN:
             if ok:
                 self.lazy_ok.add(op[1])
         self.lazy = {}
+        # Batch-norm backward fused into the data gradient that produces the gradient of the BN's output (csrc/conv_mfma.hip,
+        # avsr_conv_bwd_data_bn): the LAST contribution to that gradient in the reverse pass comes from the output's FIRST reader in
+        # the graph; when that reader is an MFMA convolution with a single-launch data gradient its epilogue applies the ReLU mask and
+        # emits sum dz / sum dz*x, and the statistics pass over two maps disappears.  An earlier contribution over a residual
+        # connection (exactly one other reader, a fused add) is not copied into the gradient map first: the convolution reads it
+        # where it lies (`acc`).
+        self.bnb, self.bnb_conv, self.bnb_stat, self.bnb_k, self.bnb_rows, self.acc_src = {}, {}, {}, {}, {}, {}
+        self.acc_ok = set()
+        for op in self.ops:
+            if op[0] != "bnrelu" or op[1] not in self.lazy_ok:
+                continue
+            name, dst, c = op[1], op[3], op[4]
+            readers = [o for o in self.ops if (o[0] in ("conv", "bnrelu", "flatten") and o[2] == dst) or (o[0] == "add" and dst in (o[2], o[3]))]
+            first = readers[0] if readers else None
+            if first is None or first[0] != "conv" or first[1] not in self.mfma or first[2] != dst:
+                continue
+            if not ops.conv_bwd_data_bn_supported(ops.conv_desc(*self.mfma[first[1]])):
+                continue
+            self.bnb[name], self.bnb_conv[first[1]] = first[1], name
+            self.bnb_stat[name], self.bnb_k[name] = z(512 * 2 * c), z(3 * c)
+            if len(readers) == 2 and readers[1][0] == "add":
+                self.acc_ok.add(dst)
         for name, (h, w, c) in self.shapes.items():
             if name == "in":
                 continue
@@ -287,6 +309,7 @@ class LipCNN:
         gout = self.gmaps["out"].view(N, -1)
         self._copy(dfeat, gout)
         written.add("out")
+        self.bnb_rows, self.acc_src = {}, {}
         for op in reversed(self.ops):
             kind = op[0]
             if kind == "flatten":
@@ -304,6 +327,11 @@ class LipCNN:
                     if t in self.alias:                                        # same buffer as the add's output gradient
                         written.add(t)
                         continue
+                    if t in self.acc_ok and t not in written and t in self.lazy:
+                        # first of two contributions, the second being a fused data gradient: it reads this one in place
+                        written.add(t)
+                        self.acc_src[t] = self.gmaps[dst]
+                        continue
                     g, beta = target(t)
                     if beta:
                         ops.add(g, self.gmaps[dst], g, g.numel())
@@ -315,6 +343,11 @@ class LipCNN:
                 mean, invstd = self.bn[name][:2]
                 g, beta = target(src)
                 gg, gb = self._g(name + "/gamma"), self._g(name + "/beta")
+                if name in self.bnb_rows:            # stage 1 ran in the producing data gradient's epilogue: gmaps[dst] holds dz
+                    ops.bn_bwd_finalize(self.bnb_stat[name], self.bnb_rows.pop(name), c, N * h * w, mean, invstd, self._pv(name + "/gamma"),
+                                        gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c], self.bnb_k[name], grad_beta=0.0)
+                    ops.bn_bwd_apply(self.gmaps[dst], self.maps[src], self.bnb_k[name], g, N * h * w, c, beta=beta)
+                    continue
                 ops.batchnorm_bwd(self.maps[src], self.gmaps[dst], self._pv(name + "/gamma"), self._pv(name + "/beta"), mean, invstd, g,
                                   gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c], N * h * w, c, 1, m.scratch, dx_beta=beta)
             else:
@@ -329,7 +362,14 @@ class LipCNN:
                     x, bn = self._src(src)
                     d = ops.conv_desc(*self.mfma[name], bn=bn)
                     ops.conv_bwd_weight(d, x, self.gmaps[dst], gk.t[gk.off:], gb.t[gb.off:], m.scratch)
-                    if src != "in":
+                    fused_bn = self.bnb_conv.get(name)
+                    if src != "in" and fused_bn is not None and src in self.lazy:
+                        g, beta = target(src)
+                        pre, sc, sh = self.lazy[src]
+                        self.bnb_rows[fused_bn] = ops.conv_bwd_data_bn(d, self.gmaps[dst], kw_.t[kw_.off:], g, beta=beta,
+                                                                       acc=self.acc_src.pop(src, None), bn_x=self.maps[pre], bn=(sc, sh),
+                                                                       stats=self.bnb_stat[fused_bn])
+                    elif src != "in":
                         def data_grad(d=d, src=src, dst=dst, kw_=kw_):
                             g, beta = target(src)
                             ops.conv_bwd_data(d, self.gmaps[dst], kw_.t[kw_.off:], g, beta=beta)

@@ -73,10 +73,16 @@ struct CGTap { int da, db; short w[4]; };
 static inline CGTap cgtap1(int da, int db, int widx) { CGTap t; t.da = da; t.db = db; t.w[0] = (short)widx; t.w[1] = t.w[2] = t.w[3] = -1; return t; }
 struct CGArgs {
   const float* src; const float* w; const float* bias; float* dst; float* stats;
-  const float* res;                      // optional residual input, same shape / indexing as dst (linear destinations only)
+  const float* acc;                      // beta != 0: the map beta multiplies (NULL = dst itself); same shape / indexing as dst
+  const float* res;                      // optional residual input, same shape / indexing as dst
   const float* bn_sc; const float* bn_sh; // non-NULL: the source is relu(src * bn_sc[c] + bn_sh[c]) applied while staging (BN-ReLU of the
                                           // consumer's loader: the normalised map is never written); halo / padding stays zero
   const float* res_sc; const float* res_sh; // same for the residual input (per destination channel)
+  // Batch-norm backward, stage 1, fused into a data-gradient epilogue (bnb_x != NULL): dst is the gradient of y = relu(x*sc + sh) for the
+  // pre-normalisation map x (same shape / indexing as dst).  The epilogue writes dz = dst * [x*sc + sh > 0] instead and emits, in the
+  // statistics slots, the per-channel partial sums of dz and of dz*x -- what the separate two-map statistics pass of the batch-norm
+  // backward computed (d beta = sum dz, d gamma = invstd * (sum dz*x - mean * sum dz)).
+  const float* bnb_x; const float* bnb_sc; const float* bnb_sh;
   int N, SH, SW, Cs, CsL;
   int DH, DW, Cd;
   int OA, OB, S, OS, oh0, ow0;
@@ -96,8 +102,17 @@ struct CGArgs {
   CGTap tap[CG_MAXTAP];
 };
 
+// The product is computed TRANSPOSED: the weight fragments are the MFMA's A operand (rows = 16 destination columns), the staged
+// activations its B operand (columns = 16 positions), so a lane of the result holds FOUR CONSECUTIVE CHANNELS of ONE position
+// (D[4q + r][i] = out[position i][column 4q + r]): the epilogue is one 16-byte store per lane (and one 16-byte load per fused
+// operand: residual, accumulate, batch-norm-backward map), bias / scale / shift are per-lane constants, and one address is computed
+// per lane and tile instead of four.  (Round 2 computed D = X.W: four 4-byte stores per lane, 64-byte segments.)
+// Tile addressing comes from two tables built in LDS once per workgroup (they are the same for every pass): rowtab[m] = LDS offset of
+// the source window of product row m, dsttab[m] = byte offset of its destination cell (non-linear destinations) -- the per-tile
+// divisions / multiplications (about 40 VALU + quarter-rate integer multiplies per tile) become one ds_read each, issued a tile ahead.
 // MAXCH: K chunks (16 deep) held per wave
-template <int MAXCH, bool CH4>
+// EP: epilogue operands, bit 0 = an extra map (residual or batch-norm-backward x), bit 1 = accumulate onto the destination (beta != 0)
+template <int MAXCH, bool CH4, int EP>
 __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,39 +124,81 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   const int NT = (NC + 15) >> 4;                      // 1, 2 or 4 column tiles; a wave keeps ONE
   const int nt = wave % NT, mslot = wave / NT, mstep = 4 / NT;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const bool lin = A.lin != 0;                         // destination index linear in (row, column) of the product
+  const int opf = A.OA * A.OB;                         // rows (super positions) per frame
+  const int pixf = A.DH * A.DW;                        // destination pixels per frame
+  const int rows_all = A.F * opf, rows_pad = ((rows_all + 15) >> 4) << 4;
+  int* const rowtab = reinterpret_cast<int*>(lds + A.F * fstride);
+  int* const dsttab = rowtab + rows_pad;
 
   // zero the LDS once: halos (and the padded 4th channel of a 3-channel source) stay zero, frames overwrite the interior
   for (int idx = tid; idx < A.F * fstride; idx += 256) lds[idx] = 0.f;
+  // tile tables (rows beyond the staged frames read the window of row 0 and are never written out)
+  for (int m = tid; m < rows_pad; m += 256) {
+    int ro = 0, dt = 4;
+    if (m < rows_all) {
+      const int f = fdiv(m, A.m_opf), r = m - f * opf, a = fdiv(r, A.m_ob), b = r - a * A.OB;
+      ro = f * fstride + ((a * A.S + 1) * PW + (b * A.SB + 1)) * CsL;
+      const int ph = a * A.OSA + A.oh0, pw = b * A.OSB + A.ow0;
+      // low bits (offsets are multiples of 16 bytes): 1 = no pixel below this one (odd map heights), 2 = none to its right, 4 = no pixel at all
+      dt = (ph < A.DH && pw < A.DW) ? ((((f * A.DH + ph) * A.DW + pw) * Cd) << 2) | (ph + 1 >= A.DH ? 1 : 0) | (pw + 1 >= A.DW ? 2 : 0) : 4;
+    }
+    rowtab[m] = ro;
+    if (!lin) dsttab[m] = dt;
+  }
 
-  // weight fragments of this wave's column tile + per-chunk LDS offsets of this lane's k-quad
+  // weight fragments of this wave's column tile (A operand: row i of the fragment = column nt*16 + i of the product) + per-chunk LDS
+  // offsets of this lane's k-quad
   const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(A.w);
   f32x4 wreg[MAXCH];
   int koff[MAXCH];
-  const int cn = nt * 16 + i;                         // column of this lane
-  const bool colok = cn < NC;
-  const int sp = colok ? cn / Cd : 0, co = colok ? cn - sp * Cd : 0;
+  {
+    const int cn = nt * 16 + i;
+    const bool colok = cn < NC;
+    const int sp = colok ? cn / Cd : 0, co = colok ? cn - sp * Cd : 0;
 #pragma unroll
-  for (int c = 0; c < MAXCH; ++c) {
-    const int kq = 4 * c + q;
-    const bool in = c < nch && kq < KQ;
-    const int t = in ? kq / C4 : 0, cs4 = in ? kq - t * C4 : 0;
-    koff[c] = in ? (A.tap[t].da * PW + A.tap[t].db) * CsL + cs4 * 4 : 0;
-    int widx = -1;
+    for (int c = 0; c < MAXCH; ++c) {
+      const int kq = 4 * c + q;
+      const bool in = c < nch && kq < KQ;
+      const int t = in ? kq / C4 : 0, cs4 = in ? kq - t * C4 : 0;
+      koff[c] = in ? (A.tap[t].da * PW + A.tap[t].db) * CsL + cs4 * 4 : 0;
+      int widx = -1;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) widx = (k == sp) ? (int)A.tap[t].w[k] : widx;
-    // unconditional buffer loads (out-of-range offset = 0): all fragments of the wave are in flight together.  (Loads inside
-    // the branches that skip the padding were issued one at a time: MAXCH * 4 serial memory round trips before the first pass.)
-    f32x4 wv;
+      for (int k = 0; k < 4; ++k) widx = (k == sp) ? (int)A.tap[t].w[k] : widx;
+      // unconditional buffer loads (out-of-range offset = 0): all fragments of the wave are in flight together
+      f32x4 wv;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int cs = cs4 * 4 + e;
-      const long wo = A.wmode ? ((long)widx * Cd + co) * Cs + cs : ((long)widx * Cs + cs) * Cd + co;
-      wv[e] = ldb1(w_rs, (in && colok && widx >= 0 && cs < Cs) ? (int)(wo * 4) : P_OOB);
+      for (int e = 0; e < 4; ++e) {
+        const int cs = cs4 * 4 + e;
+        const long wo = A.wmode ? ((long)widx * Cd + co) * Cs + cs : ((long)widx * Cs + cs) * Cd + co;
+        wv[e] = ldb1(w_rs, (in && colok && widx >= 0 && cs < Cs) ? (int)(wo * 4) : P_OOB);
+      }
+      wreg[c] = wv;
     }
-    wreg[c] = wv;
   }
-  const float bias_v = (A.bias && colok) ? A.bias[co] : 0.f;
-  float ssum = 0.f, ssq = 0.f;
+  // result columns of this lane: cD0 .. cD0 + 3 = four consecutive channels of sub-position spD
+  const int cD0 = nt * 16 + q * 4;
+  const bool colok = cD0 < NC;
+  const int spD = colok ? cD0 / Cd : 0, coD = colok ? cD0 - spD * Cd : 0;
+  int sdh = 0, sdw = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sdh = (k == spD) ? (int)A.sp_dh[k] : sdh; sdw = (k == spD) ? (int)A.sp_dw[k] : sdw; }
+  const f32x4 bias4 = (A.bias && colok) ? ld4(A.bias + coD) : zero4;
+  // ONE extra epilogue operand map (same indexing as dst) with one scale / shift pair: the residual (forward; optionally a lazily
+  // normalised map) or the batch-norm-backward map x (data gradients) -- never both, so they share registers
+  const bool bnb = A.bnb_x != nullptr;
+  const bool rbn = !bnb && A.res_sc != nullptr;
+  const float* const e_map = bnb ? A.bnb_x : A.res;
+  const float* const e_scp = bnb ? A.bnb_sc : A.res_sc;
+  const float* const e_shp = bnb ? A.bnb_sh : A.res_sh;
+  const f32x4 esc4 = ((bnb || rbn) && colok) ? ld4(e_scp + coD) : zero4;
+  const f32x4 esh4 = ((bnb || rbn) && colok) ? ld4(e_shp + coD) : zero4;
+  f32x4 ssum = zero4, ssq = zero4;
+  const __amdgpu_buffer_rsrc_t e_rs = make_rsrc(e_map), dst_rs = make_rsrc(A.dst), acc_rs = make_rsrc(A.acc ? A.acc : A.dst);
+  // byte offset of this lane's 16 bytes inside a tile / a destination cell
+  const int lane_o = lin ? (i * NC + cD0) * 4 : ((sdh * A.DW + sdw) * Cd + coD) * 4;
+  const int tile_o = 16 * NC * 4;
+
   // staging role of this thread: piece column st_p4 of rows st_row, st_row + st_rpp, ...  (threads beyond rpp*rq idle)
   const int st_rq = (A.SW * Cs) >> 2;
   const int st_rpp = st_rq > 0 ? (256 / st_rq > 0 ? 256 / st_rq : 1) : 1;
@@ -150,21 +207,12 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   f32x4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = zero4;
   const bool bn_on = CH4 && A.bn_sc != nullptr;
   if (bn_on && st_row >= 0) { const int cb = (st_p4 * 4) % Cs; bsc = ld4(A.bn_sc + cb); bsh = ld4(A.bn_sh + cb); }
-  const bool rbn = A.res_sc != nullptr;
-  const float rsc = (rbn && colok) ? A.res_sc[co] : 1.f, rsh = (rbn && colok) ? A.res_sh[co] : 0.f;
-  const __amdgpu_buffer_rsrc_t res_rs = make_rsrc(A.res), dst_rs = make_rsrc(A.dst);
-  const bool lin = A.lin != 0;                         // destination index linear in (row, column) of the product
-  const int opf = A.OA * A.OB;                         // rows (super positions) per frame
-  const int pixf = A.DH * A.DW;                        // destination pixels per frame
-  int sdh = 0, sdw = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { sdh = (k == sp) ? (int)A.sp_dh[k] : sdh; sdw = (k == sp) ? (int)A.sp_dw[k] : sdw; }
   const int rowf = A.SW * Cs;                          // floats per source row
 
   // ---- software pipeline over passes: the NEXT pass's frames travel memory -> registers while the current pass runs on the matrix
   // pipe; registers -> LDS between two barriers.  A thread's pieces of a pass: (frame f, row st_row + k*st_rpp, column st_p4) for
   // 4-channel-multiple sources; 16-byte runs of the contiguous frames (element-wise scatter on store) for the 3-channel crops.
-  constexpr int PF = CH4 ? 12 : 4;
+  constexpr int PF = CH4 ? (MAXCH > 9 ? 9 : 12) : 4;                // (the 18-chunk instantiation has 72 registers of weights: 9 pieces)
   f32x4 pre[PF];
   constexpr bool c4 = CH4;
   const int ppf = c4 ? (A.SH + st_rpp - 1) / st_rpp : 0;            // pieces per frame per thread (row-structured)
@@ -218,49 +266,65 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
       for (int e = tot4 * 4 + tid; e < tot; e += 256) put(e, sp[e]);
     }
   };
-  const int step_m = 16 * mstep;
   int n0 = blockIdx.x * A.F;
   if (n0 < A.N) fetch(n0);
   for (; n0 < A.N; n0 += gridDim.x * A.F) {
     const int fcur = min(A.F, A.N - n0);
-    __syncthreads();                                    // previous pass has finished reading the LDS
+    __syncthreads();                                    // previous pass has finished reading the LDS (first pass: tables written)
     commit(n0);
     __syncthreads();
     if (n0 + gridDim.x * A.F < A.N) fetch(n0 + gridDim.x * A.F);      // in flight during the MFMAs below
     // ---- implicit GEMM over the staged frames ----
     const int Mtot = fcur * opf, mtiles = (Mtot + 15) >> 4;
-    // LDS address of product row m (clamped to row 0 beyond the pass: those rows are never written out)
-    auto row_base = [&](int mt) -> const float* {
-      const int m = mt * 16 + i;
-      const int mm = m < Mtot ? m : 0;
-      const int f = fdiv(mm, A.m_opf), r = mm - f * opf, a = fdiv(r, A.m_ob), b = r - a * A.OB;
-      return lds + f * fstride + ((a * A.S + 1) * PW + (b * A.SB + 1)) * CsL;
-    };
     const unsigned pass_o = (unsigned)((long)n0 * pixf * Cd * 4);     // (destination maps stay below 2 GB: checked by the host)
     constexpr int CB = MAXCH <= 6 ? MAXCH : 3;          // K chunks per block of LDS reads (9 and 18 are multiples of 3)
     constexpr bool XT = MAXCH <= 6;                     // whole tile in one block: the NEXT tile's reads run under this tile's MFMAs
-    f32x4 cur[CB], nxt[CB];
+    f32x4 bufa[CB], bufb[CB];
+    // table entries travel one tile (window offsets: two tiles) ahead of their use
+    const int last = mtiles - 1;
+    int rb_cur = rowtab[(mslot < mtiles ? mslot : 0) * 16 + i];
+    int rb_nxt = rowtab[(mslot + mstep < mtiles ? mslot + mstep : (last > 0 ? last : 0)) * 16 + i];
+    int dt_cur = lin ? 0 : dsttab[(mslot < mtiles ? mslot : 0) * 16 + i];
     if (XT && mslot < mtiles) {
-      const float* base0 = row_base(mslot);
 #pragma unroll
-      for (int c = 0; c < CB; ++c) cur[c] = ld4(base0 + koff[c]);
+      for (int c = 0; c < CB; ++c) bufa[c] = ld4(lds + rb_cur + koff[c]);
     }
-    for (int mt = mslot; mt < mtiles; mt += mstep) {
-      const float* base = XT ? row_base(mt + mstep < mtiles ? mt + mstep : mt) : row_base(mt);
-      // residual / accumulate operands of a full linear tile: requested before the products (unconditional buffer loads; lanes and
-      // tiles that do not take the fast path below use an out-of-range offset)
-      const int mo0 = mt * 16 + q * 4;
-      const bool fastp = lin && mo0 + 3 < Mtot && colok;
-      const unsigned dbo = pass_o + (unsigned)((mo0 * NC + cn) * 4);   // byte offset of (row mo0, this lane's column) in the destination
-      float rv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
-      if (A.res) {                                      // kernel-uniform: launches without a residual issue no loads for it
+    // one tile: `cur` holds its first block of operands (XT: the whole tile), `nxt` receives the next block / the next tile
+    // epilogue of one tile from its two accumulator chains: bias, fused operands, 16-byte store, statistics
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    auto epilogue = [&](const f32x4 a0, const f32x4 a1, const int dbo, const bool ok, const f32x4 ev, const f32x4 ov) {
+      // D layout: D[4q + r][i] = out[position mt*16 + i][column cD0 + r]
+      f32x4 v = (a0 + a1) + bias4;
+      if ((EP & 1) && !bnb) {
+        if (rbn) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) rv[rr] = ldb1(res_rs, fastp ? (int)(dbo + (unsigned)(rr * NC * 4)) : P_OOB);
+          for (int r = 0; r < 4; ++r) v[r] += fmaxf(fmaf(ev[r], esc4[r], esh4[r]), 0.f);
+        } else v += ev;
       }
-      if (A.beta != 0.f) {
+      if (EP & 2) v += A.beta * ov;
+      if ((EP & 1) && bnb) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) ov[rr] = ldb1(dst_rs, fastp ? (int)(dbo + (unsigned)(rr * NC * 4)) : P_OOB);
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(ev[r], esc4[r], esh4[r]) > 0.f ? v[r] : 0.f;
       }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), dst_rs, dbo, 0, 0);
+      // statistics are accumulated unconditionally (a few operations); only their final write is conditional
+      const f32x4 vs = ok ? v : zero4;
+      ssum += vs;
+      ssq += ((EP & 1) && bnb) ? vs * ev : vs * vs;
+    };
+    auto tile = [&](f32x4 (&cur)[CB], f32x4 (&nxt)[CB], const int mt) {
+      const int t1 = mt + mstep < mtiles ? mt + mstep : last, t2 = mt + 2 * mstep < mtiles ? mt + 2 * mstep : last;
+      const int rb_nn = rowtab[t2 * 16 + i];
+      const int dt_nxt = lin ? 0 : dsttab[t1 * 16 + i];
+      const float* base = lds + (XT ? rb_nxt : rb_cur);
+      // destination of this lane's four channels; rows beyond the pass / columns beyond the product / cells beyond an odd map use
+      // an out-of-range offset: their loads return zero and their store is dropped by the buffer bounds check (no branch)
+      const int bad = lin ? 0 : ((dt_cur & 4) | ((dt_cur & 1) & sdh) | (((dt_cur >> 1) & 1) & sdw));
+      const bool ok = (mt * 16 + i < Mtot) & colok & (bad == 0);
+      const int dbo = ok ? (int)(pass_o + (unsigned)((lin ? mt * tile_o : (dt_cur & ~15)) + lane_o)) : P_OOB;
+      f32x4 ev = zero4, ov = zero4;
+      if (EP & 1) ev = ldb4(e_rs, dbo);
+      if (EP & 2) ov = ldb4(acc_rs, dbo);
       // Chunks beyond the layer's depth read offset 0 against zero weights (no branch around any read).  The reads of the next
       // block (the next tile when the tile is one block) are issued BEFORE this block's MFMAs and kept there by the scheduling
       // barrier: left to itself the compiler sank each read to just ahead of its first use, one exposed LDS round trip per chunk.
@@ -284,71 +348,52 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
         for (int c = 0; c < CB; ++c)
           if (b0 + c < MAXCH) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if ((b0 + c) & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c][e], wreg[b0 + c][e], acc1, 0, 0, 0);
-              else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[c][e], wreg[b0 + c][e], acc0, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {               // two accumulator chains, alternating: no MFMA waits for its predecessor
+              if (e & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[b0 + c][e], cur[c][e], acc1, 0, 0, 0);
+              else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[b0 + c][e], cur[c][e], acc0, 0, 0, 0);
             }
           }
         __builtin_amdgcn_sched_barrier(0);
+        if (!XT) {
 #pragma unroll
-        for (int c = 0; c < CB; ++c) cur[c] = nxt[c];
-      }
-      f32x4 acc = acc0 + acc1;
-      // C layout: row = q*4 + r, column = i
-      if (colok) {
-        if (fastp) {                                    // the common case: four in-range rows, destination linear in the row
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            float v = acc[rr] + bias_v;
-            if (A.res) v += rbn ? fmaxf(fmaf(rv[rr], rsc, rsh), 0.f) : rv[rr];
-            if (A.beta != 0.f) v += A.beta * ov[rr];
-            // buffer store with the 32-bit byte offset the operand loads used (no 64-bit pointer arithmetic per row)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), dst_rs, (int)(dbo + (unsigned)(rr * NC * 4)), 0, 0);
-            acc[rr] = v;
-          }
-          if (A.stats) {
-            ssum += (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            ssq += (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]);
-          }
-        } else {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int mo = mo0 + rr;
-            if (mo < Mtot) {
-              float* dp;
-              if (lin) dp = A.dst + (long)n0 * pixf * Cd + (long)mo * NC + cn;
-              else {
-                const int fo = fdiv(mo, A.m_opf), ro = mo - fo * opf, ao = fdiv(ro, A.m_ob), bo = ro - ao * A.OB;
-                const int ph = ao * A.OSA + A.oh0 + sdh, pw = bo * A.OSB + A.ow0 + sdw;
-                if (ph >= A.DH || pw >= A.DW) continue;         // odd map sizes: the last cell of a row / column is partial
-                dp = A.dst + (((long)(n0 + fo) * A.DH + ph) * A.DW + pw) * Cd + co;
-              }
-              float v = acc[rr] + bias_v;
-              if (A.res) { const float rv = A.res[dp - A.dst]; v += rbn ? fmaxf(fmaf(rv, rsc, rsh), 0.f) : rv; }
-              if (A.beta != 0.f) v += A.beta * *dp;
-              *dp = v;
-              ssum += v; ssq += v * v;
-            }
-          }
+          for (int c = 0; c < CB; ++c) cur[c] = nxt[c];
         }
       }
+      // (Measured and not kept, round 3: deferring the epilogue by one tile and interleaving it with the MFMAs through
+      // sched_group_barrier -- 144 -> 158 us on the 36x36x8 layers; a static s_setprio by hardware wave-slot parity -- no change.)
+      epilogue(acc0, acc1, dbo, ok, ev, ov);
+      rb_cur = rb_nxt; rb_nxt = rb_nn; dt_cur = dt_nxt;
+    };
+    if (XT) {                                           // ping-pong between two operand buffers: no register copies between tiles
+      for (int mt = mslot; mt < mtiles; mt += 2 * mstep) {
+        tile(bufa, bufb, mt);
+        if (mt + mstep < mtiles) tile(bufb, bufa, mt + mstep);
+        else break;
+      }
+    } else {
+      for (int mt = mslot; mt < mtiles; mt += mstep) tile(bufa, bufb, mt);
     }
   }
   if (A.stats) {
-    // per-channel partials of this workgroup: lanes (i, q = 0..3) of the waves holding column tile nt
+    // per-channel partials of this workgroup: sum over the 16 positions of a lane group first (lanes q*16 .. q*16+15 hold the same
+    // four channels), then over the (wave, q, r) slots that carry the channel
     __syncthreads();
-    float* red = lds;                                   // [4 waves][4 q][16][2]
-    red[((wave * 4 + q) * 16 + i) * 2] = ssum;
-    red[((wave * 4 + q) * 16 + i) * 2 + 1] = ssq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[r] = group16_sum(ssum[r]); ssq[r] = group16_sum(ssq[r]); }
+    float* red = lds;                                   // [4 waves][4 q][2][4]
+    if (i == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { red[((wave * 4 + q) * 2) * 4 + r] = ssum[r]; red[((wave * 4 + q) * 2 + 1) * 4 + r] = ssq[r]; }
+    }
     __syncthreads();
-    if (tid < Cd) {                                     // channel tid: its columns (sp, tid) of every sub-position
+    if (tid < Cd) {
       float s = 0.f, s2 = 0.f;
-      for (int k = 0; k < A.nsp; ++k) {
-        const int n = k * Cd + tid, tnt = n >> 4, ti = n & 15;
-        for (int w = 0; w < 4; ++w)
-          if (w % NT == tnt)
-            for (int qq = 0; qq < 4; ++qq) { s += red[((w * 4 + qq) * 16 + ti) * 2]; s2 += red[((w * 4 + qq) * 16 + ti) * 2 + 1]; }
-      }
+      for (int w = 0; w < 4; ++w)
+        for (int qq = 0; qq < 4; ++qq)
+          for (int r = 0; r < 4; ++r) {
+            const int cD = (w % NT) * 16 + qq * 4 + r;
+            if (cD < NC && cD % Cd == tid) { s += red[((w * 4 + qq) * 2) * 4 + r]; s2 += red[((w * 4 + qq) * 2 + 1) * 4 + r]; }
+          }
       A.stats[(long)blockIdx.x * 2 * Cd + tid] = s;
       A.stats[(long)blockIdx.x * 2 * Cd + Cd + tid] = s2;
     }
@@ -592,9 +637,9 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
   if (A.Cs % 4 == 0) {
     const int rq = A.SW * A.Cs / 4;
     if (rq > 256 || rq < 1) return AVSR_ERR_UNSUPPORTED;
-    const int rpp = 256 / rq;
-    while (A.F > 1 && A.F * ((A.SH + rpp - 1) / rpp) > 12) --A.F;
-    if (A.F * ((A.SH + rpp - 1) / rpp) > 12) return AVSR_ERR_UNSUPPORTED;
+    const int rpp = 256 / rq, pfmax = nch > 9 ? 9 : 12;     // prefetch registers of the instantiation that takes this depth
+    while (A.F > 1 && A.F * ((A.SH + rpp - 1) / rpp) > pfmax) --A.F;
+    if (A.F * ((A.SH + rpp - 1) / rpp) > pfmax) return AVSR_ERR_UNSUPPORTED;
     A.m_rq = fmagic(rq); A.m_per = fmagic(A.SH * rq); A.m_sw = fmagic(A.SW);
   } else {
     while (A.F > 1 && (A.F * A.SH * A.SW * A.Cs / 4 + 255) / 256 > 4) --A.F;
@@ -604,8 +649,15 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
   if ((long)A.F * A.OA * A.OB >= 65536) return AVSR_ERR_UNSUPPORTED;
   if ((long)A.N * A.DH * A.DW * A.Cd * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;   // 32-bit byte offsets of the epilogue's buffer loads
   A.m_opf = fmagic(A.OA * A.OB); A.m_ob = fmagic(A.OB);
-  const size_t lds = sizeof(float) * (size_t)A.F * (A.SH + 2) * (A.SW + 2) * A.CsL;
-  if (lds > 64 * 1024 || lds < sizeof(float) * 4 * 4 * 16 * 2) return AVSR_ERR_UNSUPPORTED;
+  // frames + the tile tables (window offsets; destination cells of non-linear destinations): <= 64 KB, two workgroups per CU
+  auto lds_bytes = [&](int F) {
+    const size_t rows_pad = (((size_t)F * A.OA * A.OB + 15) / 16) * 16;
+    return sizeof(float) * (size_t)F * (A.SH + 2) * (A.SW + 2) * A.CsL + 4 * rows_pad * (A.lin ? 1 : 2);
+  };
+  while (A.F > 1 && lds_bytes(A.F) > 64 * 1024) --A.F;
+  size_t lds = lds_bytes(A.F);
+  if (lds > 64 * 1024) return AVSR_ERR_UNSUPPORTED;
+  if (lds < sizeof(float) * 4 * 4 * 2 * 4) lds = sizeof(float) * 4 * 4 * 2 * 4;      // the statistics reduction's staging area
   int grid = (A.N + A.F - 1) / A.F;
   int wpc = (int)((150 * 1024) / (lds + 512));          // workgroups per CU that fit
   if (wpc > 2) wpc = 2;                                 // (three per CU measured slower, one per CU 25 % slower)
@@ -614,13 +666,25 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
   if (A.Cs % 4 && nch > 5) return AVSR_ERR_UNSUPPORTED;
   if (dry) return grid;
   ProfScope ps(kind, s, flops);
+  const bool emap = A.res != nullptr || A.bnb_x != nullptr;
+  if (A.res && A.bnb_x) return AVSR_ERR_ARG;            // one extra epilogue map at a time
+  const int ep = (emap ? 1 : 0) | (A.beta != 0.f ? 2 : 0);
+#define CG_GO(M_, C_)                                                                                              \
+  switch (ep) {                                                                                                    \
+    case 0: hipLaunchKernelGGL((conv_gen_kernel<M_, C_, 0>), dim3(grid), dim3(256), lds, s, A); break;             \
+    case 1: hipLaunchKernelGGL((conv_gen_kernel<M_, C_, 1>), dim3(grid), dim3(256), lds, s, A); break;             \
+    case 2: hipLaunchKernelGGL((conv_gen_kernel<M_, C_, 2>), dim3(grid), dim3(256), lds, s, A); break;             \
+    default: hipLaunchKernelGGL((conv_gen_kernel<M_, C_, 3>), dim3(grid), dim3(256), lds, s, A); break;            \
+  }
   if (A.Cs % 4) {
-    hipLaunchKernelGGL((conv_gen_kernel<5, false>), dim3(grid), dim3(256), lds, s, A);
-  } else if (nch <= 2) hipLaunchKernelGGL((conv_gen_kernel<2, true>), dim3(grid), dim3(256), lds, s, A);
-  else if (nch <= 6) hipLaunchKernelGGL((conv_gen_kernel<6, true>), dim3(grid), dim3(256), lds, s, A);
-  else if (nch <= 9) hipLaunchKernelGGL((conv_gen_kernel<9, true>), dim3(grid), dim3(256), lds, s, A);
-  else if (nch <= 18) hipLaunchKernelGGL((conv_gen_kernel<18, true>), dim3(grid), dim3(256), lds, s, A);
+    if (ep != 0) return AVSR_ERR_UNSUPPORTED;           // the 3-channel crops are only ever a forward source
+    hipLaunchKernelGGL((conv_gen_kernel<5, false, 0>), dim3(grid), dim3(256), lds, s, A);
+  } else if (nch <= 2) { CG_GO(2, true) }
+  else if (nch <= 6) { CG_GO(6, true) }
+  else if (nch <= 9) { CG_GO(9, true) }
+  else if (nch <= 18) { CG_GO(18, true) }
   else return AVSR_ERR_UNSUPPORTED;                     // K > 288 (64-channel sources) stays on im2col + GEMM
+#undef CG_GO
   if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
   return grid;
 }
@@ -794,6 +858,7 @@ static int cg_run(CGArgs A, const CGTap* taps, int ntaps, hipStream_t s, int kin
   if (G < 1) return AVSR_ERR_UNSUPPORTED;
   if (G > CG_MAXTAP) G = CG_MAXTAP;
   const float* res = A.res; float* stats = A.stats; const float* bias = A.bias; const float beta = A.beta;
+  const float* acc = A.acc; const float* bnb_x = A.bnb_x;
   int grid = 0;
   for (int t0 = 0; t0 < ntaps; t0 += G) {
     const int nt = ntaps - t0 < G ? ntaps - t0 : G;
@@ -801,8 +866,8 @@ static int cg_run(CGArgs A, const CGTap* taps, int ntaps, hipStream_t s, int kin
     CGArgs B = A;
     for (int t = 0; t < nt; ++t) B.tap[t] = taps[t0 + t];
     B.ntap = nt;
-    B.bias = first ? bias : nullptr; B.beta = first ? beta : 1.f;
-    B.res = last ? res : nullptr; B.stats = last ? stats : nullptr;
+    B.bias = first ? bias : nullptr; B.beta = first ? beta : 1.f; B.acc = first ? acc : nullptr;
+    B.res = last ? res : nullptr; B.stats = last ? stats : nullptr; B.bnb_x = last ? bnb_x : nullptr;
     if (!last) { B.res_sc = nullptr; B.res_sh = nullptr; }
     const int rc = cg_launch(B, s, kind, flops_per_tap * nt, dry);
     if (rc < 0) return rc;
@@ -858,22 +923,28 @@ static int conv_fwd_impl(const avsr_conv_desc* c, const float* x, const float* w
   return AVSR_OK;
 }
 
-static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const float* w, float* dx, float beta, void* stream, bool dry) {
+// acc (may be NULL): dx = beta*acc + ... instead of beta*dx.  bnb_x != NULL: batch-norm backward stage 1 in the epilogue (see CGArgs):
+// needs ONE launch group that writes every destination pixel once; stats [>= grid][2*Ci] receives the partial sums, *nparts the grid.
+static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const float* w, float* dx, float beta, void* stream, bool dry,
+                              const float* acc = nullptr, const float* bnb_x = nullptr, const float* bnb_sc = nullptr,
+                              const float* bnb_sh = nullptr, float* stats = nullptr, int32_t* nparts = nullptr) {
   if (c->Ci % 4) return AVSR_ERR_UNSUPPORTED;
   const int k = c->k;
+  auto fuse = [&](CGArgs& A) { A.acc = acc; A.bnb_x = bnb_x; A.bnb_sc = bnb_sc; A.bnb_sh = bnb_sh; A.stats = stats; };
   if (c->stride == 1) {
     CGArgs A = {};
     A.src = dy; A.w = w; A.dst = dx;
     A.N = c->N; A.SH = c->Ho; A.SW = c->Wo; A.Cs = c->Co; A.CsL = c->Co;
     A.DH = c->H; A.DW = c->W; A.Cd = c->Ci; A.OA = c->H; A.OB = c->W; A.S = 1; A.OS = 1;
     A.wmode = 1; A.beta = beta;
+    fuse(A);
     CGTap taps[9];
     for (int t = 0; t < k * k; ++t) taps[t] = cgtap1(c->pad_t - t / k, c->pad_l - t % k, t);   // dx[h, w] += dy[h + pt - i, w + pl - j] . W[i, j]^T
     A.F = cg_frames(c->Ho, c->Wo, A.CsL, c->H * c->W);
     CGTap wide[CG_MAXTAP];
     const int nw = cg_pair_taps(A, taps, k * k, wide);
-    if (nw) return cg_run(A, wide, nw, S_(stream), PROF_CONV_BWD_DATA, 2.0 * c->N * c->H * c->W * (double)c->Ci * c->Co * (k * k) / nw, dry, nullptr);
-    return cg_run(A, taps, k * k, S_(stream), PROF_CONV_BWD_DATA, 2.0 * c->N * c->H * c->W * (double)c->Ci * c->Co, dry, nullptr);
+    if (nw) return cg_run(A, wide, nw, S_(stream), PROF_CONV_BWD_DATA, 2.0 * c->N * c->H * c->W * (double)c->Ci * c->Co * (k * k) / nw, dry, nparts);
+    return cg_run(A, taps, k * k, S_(stream), PROF_CONV_BWD_DATA, 2.0 * c->N * c->H * c->W * (double)c->Ci * c->Co, dry, nparts);
   }
   if (k == 3 && c->Ci * 4 <= 64) {
     // all four parity classes of a 2x2 destination cell in one launch: columns (class, channel), rows = cells
@@ -882,6 +953,7 @@ static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const fl
     A.N = c->N; A.SH = c->Ho; A.SW = c->Wo; A.Cs = c->Co; A.CsL = c->Co;
     A.DH = c->H; A.DW = c->W; A.Cd = c->Ci; A.OA = (c->H + 1) / 2; A.OB = (c->W + 1) / 2; A.S = 1; A.OS = 2;
     A.wmode = 1; A.beta = beta;
+    fuse(A);
     A.nsp = 4; A.SB = 1; A.OSA = 2; A.OSB = 2; A.lin = 0;
     CGTap wide[CG_MAXTAP];
     int nw = 0, ntot = 0;
@@ -910,10 +982,13 @@ static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const fl
       }
     if (fits && nw > 0) {
       A.F = cg_frames(c->Ho, c->Wo, A.CsL, A.OA * A.OB);
-      const int rc = cg_run(A, wide, nw, S_(stream), PROF_CONV_BWD_DATA, 2.0 * c->N * A.OA * A.OB * (double)c->Ci * c->Co * ntot / nw, dry, nullptr);
+      const int rc = cg_run(A, wide, nw, S_(stream), PROF_CONV_BWD_DATA, 2.0 * c->N * A.OA * A.OB * (double)c->Ci * c->Co * ntot / nw, dry, nparts);
       if (rc != AVSR_ERR_UNSUPPORTED) return rc;
     }
   }
+  // the per-class launches below write disjoint pixel classes from separate grids: no single set of partial sums, and `acc` would
+  // have to be applied class by class -- the fused forms are only offered on the single-launch paths above
+  if (acc || bnb_x) return AVSR_ERR_UNSUPPORTED;
   // stride 2: one launch per parity class (ph, pw) of the input pixels; a class no tap reaches receives no gradient from this
   // convolution (beta == 0 is then refused: the caller orders its contributions so that this one accumulates)
   for (int ph = 0; ph < 2; ++ph)
@@ -1034,6 +1109,84 @@ extern "C" int avsr_conv_bwd_data(const avsr_conv_desc* c, const float* dy, cons
   if (!cd_ok(c) || !dy || !w || !dx) return AVSR_ERR_ARG;
   if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
   return conv_bwd_data_impl(c, dy, w, dx, beta, stream, false);
+}
+
+extern "C" int avsr_conv_bwd_data_bn(const avsr_conv_desc* c, const float* dy, const float* w, float* dx, float beta, const float* acc,
+                                     const float* bn_x, const float* bn_scale, const float* bn_shift, float* stats, int32_t* nparts,
+                                     void* stream) {
+  if (!cd_ok(c) || !dy || !w || !dx || (bn_x && (!bn_scale || !bn_shift || !stats || !nparts))) return AVSR_ERR_ARG;
+  if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
+  return conv_bwd_data_impl(c, dy, w, dx, beta, stream, false, acc, bn_x, bn_scale, bn_shift, bn_x ? stats : nullptr, nparts);
+}
+
+// can avsr_conv_bwd_data_bn run this layer's data gradient with the fused forms (accumulate source / batch-norm backward epilogue)?
+extern "C" int avsr_conv_bwd_data_bn_supported(const avsr_conv_desc* c) {
+  if (!g_conv_mfma || !cd_ok(c) || c->Ci < 4) return 0;
+  static float dummy;
+  int32_t n = 0;
+  return conv_bwd_data_impl(c, nullptr, nullptr, nullptr, 1.f, nullptr, true, &dummy, &dummy, &dummy, &dummy, &dummy, &n) == AVSR_OK;
+}
+
+// Batch-norm backward, stage 2 (after avsr_conv_bwd_data_bn wrote dz and the partial sums [nparts][2*C] = (sum dz | sum dz*x)):
+//   d beta (+)= sum dz;  d gamma (+)= invstd * (sum dz*x - mean * sum dz);
+//   k[0..C) = gamma*invstd, k[C..2C) = -gamma*invstd^2 * b, k[2C..3C) = -gamma*invstd*a + gamma*invstd^2 * b * mean
+// with a = sum dz / count, b = invstd * (sum dz*x - mean * sum dz) / count, so that dx = k1*dz + k2*x + k3 (avsr_bn_bwd_apply) is
+// gamma*invstd * (dz - a - xhat*b).  fp64 merge of the partials.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int nparts, int C, double count, const float* mean,
+                                                              const float* invstd, const float* gamma, float* dgamma, float* dbeta,
+                                                              float grad_beta, float* k) {
+  __shared__ double red[2][16][17];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+  double s = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int p = rg; p < nparts; p += 16) { s += (double)part[(long)p * 2 * C + c]; s2 += (double)part[(long)p * 2 * C + C + c]; }
+  red[0][rg][cl] = s; red[1][rg][cl] = s2;
+  __syncthreads();
+  if (threadIdx.x >= 16 || c >= C) return;
+  s = 0.0; s2 = 0.0;
+  for (int r = 0; r < 16; ++r) { s += red[0][r][cl]; s2 += red[1][r][cl]; }
+  const double m = mean[c], is = invstd[c], g = gamma[c];
+  const double sxh = is * (s2 - m * s);                  // sum dz * xhat
+  if (dbeta) dbeta[c] = (grad_beta != 0.f ? grad_beta * dbeta[c] : 0.f) + (float)s;
+  if (dgamma) dgamma[c] = (grad_beta != 0.f ? grad_beta * dgamma[c] : 0.f) + (float)sxh;
+  const double a = s / count, b = sxh / count;
+  k[c] = (float)(g * is);
+  k[C + c] = (float)(-g * is * is * b);
+  k[2 * C + c] = (float)(-g * is * a + g * is * is * b * m);
+}
+
+extern "C" int avsr_bn_bwd_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, const float* mean, const float* invstd,
+                                    const float* gamma, float* dgamma, float* dbeta, float grad_beta, float* k, void* stream) {
+  if (!part || nparts <= 0 || C <= 0 || count <= 0 || !mean || !invstd || !gamma || !k) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, S_(stream), part, nparts, C, (double)count, mean, invstd, gamma,
+                     dgamma, dbeta, grad_beta, k);
+  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+  return AVSR_OK;
+}
+
+// dx = beta*dx + k1[c]*dz + k2[c]*x + k3[c] over [rows][C] maps, C % 4 == 0 (16-byte accesses, one channel quad per lane)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ k,
+                                                           float* __restrict__ dx, long n4, int C4, int C, float beta) {
+  const long stride = (long)gridDim.x * 256;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += stride) {
+    const int c = (int)(idx % C4) * 4;
+    const f32x4 k1 = ld4(k + c), k2 = ld4(k + C + c), k3 = ld4(k + 2 * C + c);
+    const f32x4 a = ld4(dz + idx * 4), b = ld4(x + idx * 4);
+    f32x4 v = k1 * a + k2 * b + k3;
+    if (beta != 0.f) v += beta * ld4(dx + idx * 4);
+    st4(dx + idx * 4, v);
+  }
+}
+
+extern "C" int avsr_bn_bwd_apply(const float* dz, const float* x, const float* k, float* dx, int64_t rows, int32_t C, float beta, void* stream) {
+  if (!dz || !x || !k || !dx || rows <= 0 || C <= 0 || C % 4) return AVSR_ERR_ARG;
+  const long n4 = rows * (C / 4);
+  long blocks = (n4 + 256 * 8 - 1) / (256 * 8);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)blocks), dim3(256), 0, S_(stream), dz, x, k, dx, n4, C / 4, C, beta);
+  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+  return AVSR_OK;
 }
 
 extern "C" int avsr_conv_bwd_weight(const avsr_conv_desc* c, const float* x, const float* dy, float* dw, float* dbias, float beta, float* scratch,

@@ -386,6 +386,27 @@ def conv_bwd_data(d, dy, w, dx, beta=0.0):
     check(_L().avsr_conv_bwd_data(C.byref(d), fptr(dy), fptr(w), fptr(dx), float(beta), _s()), "avsr_conv_bwd_data")
 
 
+def conv_bwd_data_bn_supported(d):
+    return bool(_L().avsr_conv_bwd_data_bn_supported(C.byref(d)))
+
+
+def conv_bwd_data_bn(d, dy, w, dx, beta=0.0, acc=None, bn_x=None, bn=None, stats=None):
+    """Data gradient with an accumulate source and / or the batch-norm backward epilogue; returns the number of partial rows."""
+    n = C.c_int32(0)
+    check(_L().avsr_conv_bwd_data_bn(C.byref(d), fptr(dy), fptr(w), fptr(dx), float(beta), fptr(acc), fptr(bn_x),
+                                     fptr(bn[0]) if bn else None, fptr(bn[1]) if bn else None, fptr(stats), C.byref(n), _s()), "avsr_conv_bwd_data_bn")
+    return int(n.value)
+
+
+def bn_bwd_finalize(part, nparts, Cn, count, mean, invstd, gamma, dgamma, dbeta, k, grad_beta=1.0):
+    check(_L().avsr_bn_bwd_finalize(fptr(part), int(nparts), int(Cn), int(count), fptr(mean), fptr(invstd), fptr(gamma), fptr(dgamma), fptr(dbeta),
+                                    float(grad_beta), fptr(k), _s()), "avsr_bn_bwd_finalize")
+
+
+def bn_bwd_apply(dz, x, k, dx, rows, Cn, beta=0.0):
+    check(_L().avsr_bn_bwd_apply(fptr(dz), fptr(x), fptr(k), fptr(dx), int(rows), int(Cn), float(beta), _s()), "avsr_bn_bwd_apply")
+
+
 def conv_bwd_weight(d, x, dy, dw, dbias, scratch, beta=1.0):
     check(_L().avsr_conv_bwd_weight(C.byref(d), fptr(x), fptr(dy), fptr(dw), fptr(dbias), float(beta), fptr(scratch), scratch.numel(), _s()),
           "avsr_conv_bwd_weight")

@@ -440,6 +440,21 @@ int avsr_conv_fwd(const avsr_conv_desc* c, const float* x, const float* w, const
 int avsr_conv_bwd_data(const avsr_conv_desc* c, const float* dy, const float* w, float* dx, float beta, void* stream);
 int avsr_conv_bwd_weight(const avsr_conv_desc* c, const float* x, const float* dy, float* dw, float* dbias, float beta, float* scratch,
                          int64_t scratch_floats, void* stream);
+/* Data gradient with the fused forms of the lip CNN's backward pass (avsr/video.py:4-14 batch_norm_relu, :57-88 residual blocks):
+ *   acc (may be NULL): dx = beta*acc + conv_transpose(dy) -- the gradient arriving over a residual connection is read where it lies
+ *     instead of being copied into dx first;
+ *   bn_x != NULL: dx is the gradient of y = relu(bn_x*bn_scale + bn_shift) (the lazily normalised input of the forward conv): the
+ *     epilogue writes dz = dx * [y > 0] and the per-workgroup partial sums [*nparts][2*Ci] of (dz | dz*bn_x) into stats
+ *     (>= 512*2*Ci floats) -- stage 1 of tf.layers.batch_normalization's backward without its own two-map pass;
+ *   avsr_bn_bwd_finalize: d beta / d gamma (grad_beta = 1 accumulates) and the three coefficient vectors k [3*C];
+ *   avsr_bn_bwd_apply: dx = beta*dx + k1*dz + k2*x + k3  ==  gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).
+ * AVSR_ERR_UNSUPPORTED where the data gradient needs several launches over disjoint pixel classes (avsr_conv_bwd_data_bn_supported == 0). */
+int avsr_conv_bwd_data_bn(const avsr_conv_desc* c, const float* dy, const float* w, float* dx, float beta, const float* acc,
+                          const float* bn_x, const float* bn_scale, const float* bn_shift, float* stats, int32_t* nparts, void* stream);
+int avsr_conv_bwd_data_bn_supported(const avsr_conv_desc* c);
+int avsr_bn_bwd_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, const float* mean, const float* invstd,
+                         const float* gamma, float* dgamma, float* dbeta, float grad_beta, float* k, void* stream);
+int avsr_bn_bwd_apply(const float* dz, const float* x, const float* k, float* dx, int64_t rows, int32_t C, float beta, void* stream);
 int avsr_bn_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, float eps, float momentum, float* mean, float* invstd,
                      float* mov_mean, float* mov_var, const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 int avsr_batchnorm_apply(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta, const float* mean,

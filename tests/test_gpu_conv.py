@@ -196,3 +196,52 @@ def test_conv_desc_forward_and_gradients(N, H, Ci, Co, k, s, bn, res):
             ops.conv_bwd_data(d, dyd, wd, dx, beta=0.0)
         torch.cuda.synchronize()
         assert _close(dx.cpu().numpy(), xn.grad.numpy(), 5e-5)
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,s,acc", [(5, 12, 8, 8, 1, True), (3, 36, 8, 8, 1, False), (4, 12, 8, 16, 2, False), (5, 9, 16, 32, 2, False),
+                                             (6, 9, 16, 16, 1, True), (9, 5, 64, 64, 1, False), (4, 11, 8, 16, 2, False), (7, 9, 32, 32, 1, False),
+                                             (300, 6, 8, 8, 1, True)])
+def test_data_gradient_with_fused_batchnorm_backward(N, H, Ci, Co, s, acc):
+    """avsr_conv_bwd_data_bn + avsr_bn_bwd_finalize + avsr_bn_bwd_apply against torch autograd (fp64) through
+    x -> batch_norm(training statistics) -> relu -> conv (avsr/video.py:4-14, :57-88), with an optional second consumer of the
+    normalised map (a residual connection) whose gradient arrives as `acc` and is read in place."""
+    from avsr_tf1_amd import ops
+    rng = np.random.default_rng(N * 1000 + H * 10 + Ci + Co + s)
+    W, k, eps = H, 3, 1e-5
+    t64 = lambda a, g=True: torch.tensor(a, dtype=torch.float64, requires_grad=g)
+    x = t64(rng.standard_normal((N, H, W, Ci)) * 1.5 + 0.2)
+    gamma, beta = t64(rng.uniform(0.5, 1.5, Ci)), t64(rng.standard_normal(Ci) * 0.3)
+    w = t64(rng.standard_normal((k, k, Ci, Co)) * 0.3, False)
+    mean = x.mean((0, 1, 2))
+    var = ((x - mean) ** 2).mean((0, 1, 2))
+    invstd = torch.rsqrt(var + eps)
+    y = torch.relu((x - mean) * invstd * gamma + beta)
+    out = _ref_conv(y, w, None, s)
+    dy = torch.tensor(rng.standard_normal(tuple(out.shape)), dtype=torch.float64)
+    racc = torch.tensor(rng.standard_normal(tuple(y.shape)), dtype=torch.float64)
+    loss = (out * dy).sum() + ((y * racc).sum() if acc else 0.0)
+    loss.backward()
+    Ho, pt, _ = _same(H, k, s)
+    Wo, pl, _ = _same(W, k, s)
+    dev = lambda t: t.detach().to(torch.float32).cuda().contiguous()
+    scale = (gamma * invstd).detach()
+    shift = (beta - mean * gamma * invstd).detach()
+    d = ops.conv_desc(N, H, W, Ci, Co, k, s, pt, pl, Ho, Wo)
+    assert ops.conv_supported(d) and ops.conv_bwd_data_bn_supported(d)
+    xd, wd, dyd = dev(x), dev(w), dev(dy)
+    dz = torch.full((N, H, W, Ci), 3.0, device="cuda")
+    stats = torch.zeros(512 * 2 * Ci, device="cuda")
+    n = ops.conv_bwd_data_bn(d, dyd, wd, dz, beta=1.0 if acc else 0.0, acc=dev(racc) if acc else None, bn_x=xd, bn=(dev(scale), dev(shift)),
+                             stats=stats)
+    assert n > 0
+    k3 = torch.zeros(3 * Ci, device="cuda")
+    dg, db = torch.full((Ci,), 9.0, device="cuda"), torch.full((Ci,), 9.0, device="cuda")
+    ops.bn_bwd_finalize(stats, n, Ci, N * H * W, dev(mean), dev(invstd), dev(gamma), dg, db, k3, grad_beta=0.0)
+    dx = torch.full((N, H, W, Ci), 0.5, device="cuda")
+    ops.bn_bwd_apply(dz, xd, k3, dx, N * H * W, Ci, beta=1.0)
+    torch.cuda.synchronize()
+    assert _close(dg.cpu().numpy(), gamma.grad.numpy(), 2e-4) and _close(db.cpu().numpy(), beta.grad.numpy(), 2e-4)
+    assert _close(dx.cpu().numpy() - 0.5, x.grad.numpy(), 2e-4)
+    # the masked gradient itself: zero exactly where the normalised map is not positive
+    yn = y.detach().numpy()
+    assert not np.any(dz.cpu().numpy()[yn <= 0])
