@@ -109,12 +109,17 @@ class ConvDesc(C.Structure):
                [("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p)]
 
 
+class ColsumJob(C.Structure):
+    _fields_ = [("a", Mat), ("b", Mat), ("out", C.c_void_p), ("rows", C.c_int32), ("F", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float)]
+
+
 class TransposeJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
 _STRUCTS = {"avsr_dec_layer": DecLayer, "avsr_mat": Mat, "avsr_gemm_desc": GemmDesc, "avsr_rnn_layer": RnnLayer, "avsr_rnn_stack": RnnStack,
-            "avsr_conv_desc": ConvDesc, "avsr_attn_mech": AttnMech, "avsr_attn_rnn": AttnRnn, "avsr_transpose_job": TransposeJob}
+            "avsr_conv_desc": ConvDesc, "avsr_attn_mech": AttnMech, "avsr_attn_rnn": AttnRnn, "avsr_transpose_job": TransposeJob,
+            "avsr_colsum_job": ColsumJob}
 
 EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_rnn_set_persistent", "avsr_rnn_set_persistent_mode", "avsr_rnn_set_persistent_scratch", "avsr_attn_rnn_fwd",
            "avsr_attn_rnn_fused_ws_floats", "avsr_attn_rnn_fused_eligible", "avsr_attn_rnn_set_fused", "avsr_conv_set_mfma", "avsr_conv_supported", "avsr_conv_fwd", "avsr_conv_bwd_data", "avsr_conv_bwd_weight", "avsr_bn_finalize", "avsr_batchnorm_apply", "avsr_conv_bwd_data_bn", "avsr_conv_bwd_data_bn_supported", "avsr_bn_bwd_finalize", "avsr_bn_bwd_apply",
@@ -123,7 +128,7 @@ EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr
            "avsr_relu", "avsr_relu_bwd", "avsr_add", "avsr_selu", "avsr_selu_bwd", "avsr_conv3x3_supported", "avsr_conv3x3", "avsr_conv3x3_bwd_data_s2",
            "avsr_conv3x3_bwd_weight", "avsr_embed_labels", "avsr_embed_grad", "avsr_dropout_rows", "avsr_seq_loss",
            "avsr_au_loss", "avsr_au_loss_dp", "avsr_normed_v", "avsr_normed_v_bwd", "avsr_reduce_scalar", "avsr_l2_regularise",
-           "avsr_global_norm", "avsr_adam_step", "avsr_adam_step_decay", "avsr_copy_words", "avsr_zero_words", "avsr_highway_fwd", "avsr_highway_bwd", "avsr_optimiser_step", "avsr_instnorm_fwd", "avsr_instnorm_bwd", "avsr_seq_loss_fun", "avsr_seq_loss_per_utterance", "avsr_batchnorm_sync_sum", "avsr_batchnorm_sync_sqsum", "avsr_batchnorm_sync_apply", "avsr_prof_begin", "avsr_prof_end"]
+           "avsr_global_norm", "avsr_adam_step", "avsr_adam_step_decay", "avsr_copy_words", "avsr_zero_words", "avsr_zero_multi", "avsr_add_int", "avsr_colsum_multi", "avsr_highway_fwd", "avsr_highway_bwd", "avsr_optimiser_step", "avsr_instnorm_fwd", "avsr_instnorm_bwd", "avsr_seq_loss_fun", "avsr_seq_loss_per_utterance", "avsr_batchnorm_sync_sum", "avsr_batchnorm_sync_sqsum", "avsr_batchnorm_sync_apply", "avsr_prof_begin", "avsr_prof_end"]
 
 _lib = None
 
@@ -218,6 +223,9 @@ def load():
         "avsr_highway_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "avsr_copy_words": [vp, vp, i64, vp],
         "avsr_zero_words": [vp, i64, vp],
+        "avsr_zero_multi": [C.POINTER(vp), C.POINTER(i64), i32, vp],
+        "avsr_add_int": [vp, i32, vp, vp],
+        "avsr_colsum_multi": [C.POINTER(ColsumJob), i32, vp, i64, vp],
         "avsr_adam_step_decay": [vp, vp, vp, vp, i64, vp, vp, f32, i32, i32, f32, f32, vp],
         "avsr_prof_begin": [i32],
         "avsr_prof_end": [C.POINTER(i32), C.POINTER(f32), C.POINTER(C.c_double)],

@@ -7,7 +7,7 @@ extern "C" int avsr_abi_version(void) { return 1; }
 extern "C" int64_t avsr_sizeof(const char* name) {
   if (!name) return -1;
 #define SZ(T) if (!strcmp(name, #T)) return (int64_t)sizeof(T);
-  SZ(avsr_mat) SZ(avsr_gemm_desc) SZ(avsr_conv_desc) SZ(avsr_rnn_layer) SZ(avsr_rnn_stack)
+  SZ(avsr_mat) SZ(avsr_gemm_desc) SZ(avsr_conv_desc) SZ(avsr_rnn_layer) SZ(avsr_rnn_stack) SZ(avsr_colsum_job)
 #ifdef AVSR_HAVE_ATTN
   SZ(avsr_attn_mech) SZ(avsr_attn_rnn) SZ(avsr_transpose_job) SZ(avsr_dec_layer)
 #endif

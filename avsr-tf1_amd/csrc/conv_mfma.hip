@@ -714,20 +714,21 @@ int avsr_conv3x3_mfma(const float* x, const float* w, const float* bias, float* 
 
 // finalise batch-norm statistics from the per-workgroup partial sums the convolution epilogue wrote: part [nparts][2*C] (sum | sum of
 // squares), count = rows per channel.  fp64 merge; the moving averages take the Bessel-corrected variance (fused rank-4 path).
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, int nparts, int C, double count, float eps, float momentum,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* part, int nparts, int C, double count, float eps, float momentum,
                                                           float* mean, float* invstd, float* mov_mean, float* mov_var, const float* gamma,
                                                           const float* beta, float* scale, float* shift) {
-  // one workgroup per 16 channels: 16 lanes read 16 consecutive channels of a partial row (64 B segments), 16 row groups stride the rows
-  __shared__ double red[2][16][17];
+  // one workgroup per 16 channels: 16 lanes read 16 consecutive channels of a partial row (64 B segments), 64 row groups stride the rows
+  // (1024 threads: the 512 partial rows are eight loads per thread -- the kernel is a latency chain, not a bandwidth one)
+  __shared__ double red[2][64][17];
   const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
   double s = 0.0, s2 = 0.0;
   if (c < C)
-    for (int p = rg; p < nparts; p += 16) { s += (double)part[(long)p * 2 * C + c]; s2 += (double)part[(long)p * 2 * C + C + c]; }
+    for (int p = rg; p < nparts; p += 64) { s += (double)part[(long)p * 2 * C + c]; s2 += (double)part[(long)p * 2 * C + C + c]; }
   red[0][rg][cl] = s; red[1][rg][cl] = s2;
   __syncthreads();
   if (threadIdx.x >= 16 || c >= C) return;
   s = 0.0; s2 = 0.0;
-  for (int r = 0; r < 16; ++r) { s += red[0][r][cl]; s2 += red[1][r][cl]; }
+  for (int r = 0; r < 64; ++r) { s += red[0][r][cl]; s2 += red[1][r][cl]; }
   const double m = s / count;
   double var = s2 / count - m * m;
   if (var < 0.0) var = 0.0;
@@ -750,7 +751,7 @@ extern "C" int avsr_bn_finalize(const float* part, int32_t nparts, int32_t C, in
                                 float* invstd, float* mov_mean, float* mov_var, const float* gamma, const float* beta, float* scale,
                                 float* shift, void* stream) {
   if (!part || nparts <= 0 || C <= 0 || count <= 0 || !mean || !invstd || (scale && (!gamma || !beta || !shift))) return AVSR_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, S_(stream), part, nparts, C, (double)count, eps, momentum, mean, invstd,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), part, nparts, C, (double)count, eps, momentum, mean, invstd,
                      mov_mean, mov_var, gamma, beta, scale, shift);
   if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
   return AVSR_OK;
@@ -1132,19 +1133,19 @@ extern "C" int avsr_conv_bwd_data_bn_supported(const avsr_conv_desc* c) {
 //   k[0..C) = gamma*invstd, k[C..2C) = -gamma*invstd^2 * b, k[2C..3C) = -gamma*invstd*a + gamma*invstd^2 * b * mean
 // with a = sum dz / count, b = invstd * (sum dz*x - mean * sum dz) / count, so that dx = k1*dz + k2*x + k3 (avsr_bn_bwd_apply) is
 // gamma*invstd * (dz - a - xhat*b).  fp64 merge of the partials.
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int nparts, int C, double count, const float* mean,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part, int nparts, int C, double count, const float* mean,
                                                               const float* invstd, const float* gamma, float* dgamma, float* dbeta,
                                                               float grad_beta, float* k) {
-  __shared__ double red[2][16][17];
+  __shared__ double red[2][64][17];
   const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
   double s = 0.0, s2 = 0.0;
   if (c < C)
-    for (int p = rg; p < nparts; p += 16) { s += (double)part[(long)p * 2 * C + c]; s2 += (double)part[(long)p * 2 * C + C + c]; }
+    for (int p = rg; p < nparts; p += 64) { s += (double)part[(long)p * 2 * C + c]; s2 += (double)part[(long)p * 2 * C + C + c]; }
   red[0][rg][cl] = s; red[1][rg][cl] = s2;
   __syncthreads();
   if (threadIdx.x >= 16 || c >= C) return;
   s = 0.0; s2 = 0.0;
-  for (int r = 0; r < 16; ++r) { s += red[0][r][cl]; s2 += red[1][r][cl]; }
+  for (int r = 0; r < 64; ++r) { s += red[0][r][cl]; s2 += red[1][r][cl]; }
   const double m = mean[c], is = invstd[c], g = gamma[c];
   const double sxh = is * (s2 - m * s);                  // sum dz * xhat
   if (dbeta) dbeta[c] = (grad_beta != 0.f ? grad_beta * dbeta[c] : 0.f) + (float)s;
@@ -1158,7 +1159,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
 extern "C" int avsr_bn_bwd_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, const float* mean, const float* invstd,
                                     const float* gamma, float* dgamma, float* dbeta, float grad_beta, float* k, void* stream) {
   if (!part || nparts <= 0 || C <= 0 || count <= 0 || !mean || !invstd || !gamma || !k) return AVSR_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, S_(stream), part, nparts, C, (double)count, mean, invstd, gamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), part, nparts, C, (double)count, mean, invstd, gamma,
                      dgamma, dbeta, grad_beta, k);
   if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
   return AVSR_OK;

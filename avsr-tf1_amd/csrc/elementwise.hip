@@ -601,6 +601,147 @@ int avsr_colsum_final_launch_ld(const float* part, long ld, int nblk, float* out
   return AVSR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Many column sums in TWO launches (bias gradients of a train step: one per cell / layer, each a pass over a [B*T, F] record
+// followed by a tiny reduction -- 12 + 33 launches of ~5-20 us before; seq2seq.py:222 tf.gradients of the `bias` variables).
+// The jobs are independent; every block finds its job by its block index in the jobs' prefix sums.
+#define CSM_MAX 32
+struct CsmJob { const float* a; const float* b; float* out; float* part; long lda, ldoa, ldb, ldob; int Ta, Tb, rows, F, rpb, blk0, fblk0; float alpha, beta; };
+struct CsmLaunch { int n; CsmJob job[CSM_MAX]; };
+
+__global__ __launch_bounds__(256) void colsum_multi_partial_kernel(const CsmLaunch L) {
+  __shared__ float red[256];
+  int j = 0;
+#pragma unroll 1
+  for (int k = 1; k < L.n; ++k) if ((int)blockIdx.x >= L.job[k].blk0) j = k;
+  const CsmJob& J = L.job[j];
+  const int blk = blockIdx.x - J.blk0, F = J.F;
+  const int G = F < 256 ? 256 / F : 1;
+  const int r0 = blk * J.rpb, r1 = min(J.rows, r0 + J.rpb);
+  const float* a = J.a; const float* b = J.b;
+  if (G > 1) {
+    const int idx = threadIdx.x, f = idx % F, g = idx / F;
+    float s = 0.f;
+    if (idx < G * F)
+      for (int r = r0 + g; r < r1; r += G) {
+        const float x = a[rowoff(r, J.lda, J.Ta, J.ldoa) + f];
+        s += b ? x * b[rowoff(r, J.ldb, J.Tb, J.ldob) + f] : x;
+      }
+    block_group_reduce(s, idx, F, G, red, J.part + (long)blk * F);
+    return;
+  }
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float s0 = 0.f, s1 = 0.f;
+    int r = r0;
+    for (; r + 1 < r1; r += 2) {                        // two independent chains: two loads in flight per thread
+      const float x0 = a[rowoff(r, J.lda, J.Ta, J.ldoa) + f], x1 = a[rowoff(r + 1, J.lda, J.Ta, J.ldoa) + f];
+      s0 += b ? x0 * b[rowoff(r, J.ldb, J.Tb, J.ldob) + f] : x0;
+      s1 += b ? x1 * b[rowoff(r + 1, J.ldb, J.Tb, J.ldob) + f] : x1;
+    }
+    if (r < r1) { const float x0 = a[rowoff(r, J.lda, J.Ta, J.ldoa) + f]; s0 += b ? x0 * b[rowoff(r, J.ldb, J.Tb, J.ldob) + f] : x0; }
+    J.part[(long)blk * F + f] = s0 + s1;
+  }
+}
+
+__global__ __launch_bounds__(1024) void colsum_multi_final_kernel(const CsmLaunch L) {
+  __shared__ double red[32][33];
+  int j = 0;
+#pragma unroll 1
+  for (int k = 1; k < L.n; ++k) if ((int)blockIdx.x >= L.job[k].fblk0) j = k;
+  const CsmJob& J = L.job[j];
+  const int F = J.F, nblk = (J.rows + J.rpb - 1) / J.rpb;
+  const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int f = (blockIdx.x - J.fblk0) * 32 + fl;
+  const float* part = J.part;
+  double s = 0.0;
+  if (f < F)
+    for (int i = g; i < nblk; i += 32) s += (double)part[(long)i * F + f];
+  red[g][fl] = s;
+  __syncthreads();
+  if (g == 0 && f < F) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += red[k][fl];
+    const float v = J.alpha * (float)t;
+    J.out[f] = J.beta != 0.f ? v + J.beta * J.out[f] : v;
+  }
+}
+
+extern "C" int avsr_colsum_multi(const avsr_colsum_job* jobs, int32_t n, float* scratch, int64_t scratch_floats, void* stream) {
+  if (n <= 0) return AVSR_OK;
+  if (!jobs || !scratch) return AVSR_ERR_ARG;
+  for (int j0 = 0; j0 < n; j0 += CSM_MAX) {              // more than 32 jobs: consecutive launch pairs
+    const int m = n - j0 < CSM_MAX ? n - j0 : CSM_MAX;
+    CsmLaunch L = {};
+    L.n = m;
+    long used = 0;
+    int blocks = 0, fblocks = 0;
+    for (int k = 0; k < m; ++k) {
+      const avsr_colsum_job& Q = jobs[j0 + k];
+      if (!Q.a.ptr || !Q.out || Q.rows <= 0 || Q.F <= 0) return AVSR_ERR_ARG;
+      CsmJob& J = L.job[k];
+      J.a = Q.a.ptr; J.lda = Q.a.ld; J.Ta = Q.a.T; J.ldoa = Q.a.ldo;
+      J.b = Q.b.ptr; J.ldb = Q.b.ld; J.Tb = Q.b.T; J.ldob = Q.b.ldo;
+      J.out = Q.out; J.rows = Q.rows; J.F = Q.F; J.alpha = Q.alpha; J.beta = Q.beta;
+      // <= 256 partial rows per job (the big records are [32000, 1024]: 125 rows per block), >= 32 rows per block
+      int rpb = (Q.rows + 255) / 256;
+      if (rpb < 32) rpb = 32;
+      J.rpb = rpb;
+      const int nblk = (Q.rows + rpb - 1) / rpb;
+      J.part = scratch + used;
+      used += (long)nblk * Q.F;
+      J.blk0 = blocks; blocks += nblk;
+      J.fblk0 = fblocks; fblocks += (Q.F + 31) / 32;
+    }
+    if (used > scratch_floats) return AVSR_ERR_ARG;
+    hipLaunchKernelGGL(colsum_multi_partial_kernel, dim3(blocks), dim3(256), 0, S_(stream), L);
+    AVSR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_multi_final_kernel, dim3(fblocks), dim3(1024), 0, S_(stream), L);
+    AVSR_CHECK_LAUNCH();
+  }
+  return AVSR_OK;
+}
+
+// Zero up to 8 buffers (32-bit words) per launch: the fills at the start of the backward pass as ONE engine kernel.
+struct ZmLaunch { uint32_t* p[8]; long n[8]; int cnt; };
+__global__ __launch_bounds__(256) void zero_multi_kernel(const ZmLaunch L) {
+  const long stride = (long)gridDim.x * 256;
+#pragma unroll 1
+  for (int k = 0; k < L.cnt; ++k) {
+    uint32_t* p = L.p[k];
+    const long n = L.n[k], n4 = ((uintptr_t)p & 15) == 0 ? n >> 2 : 0;
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) reinterpret_cast<u32x4_*>(p)[i] = u32x4_{0u, 0u, 0u, 0u};
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0u;
+  }
+}
+extern "C" int avsr_zero_multi(void* const* ptrs, const int64_t* n_words, int32_t count, void* stream) {
+  if (count <= 0) return AVSR_OK;
+  if (!ptrs || !n_words) return AVSR_ERR_ARG;
+  for (int c0 = 0; c0 < count; c0 += 8) {
+    ZmLaunch L = {};
+    long tot = 0;
+    for (int k = 0; k < 8 && c0 + k < count; ++k) {
+      if (!ptrs[c0 + k] || n_words[c0 + k] < 0) return AVSR_ERR_ARG;
+      L.p[k] = (uint32_t*)ptrs[c0 + k]; L.n[k] = n_words[c0 + k]; L.cnt = k + 1; tot += n_words[c0 + k];
+    }
+    long blocks = (tot / 4 + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(zero_multi_kernel, dim3((int)blocks), dim3(256), 0, S_(stream), L);
+    AVSR_CHECK_LAUNCH();
+  }
+  return AVSR_OK;
+}
+// out[0] = a[0] + b on the device: the RNG key of the step's dropout / sampling masks = global step + per-rank offset
+__global__ void add_int_kernel(const int32_t* a, int32_t b, int32_t* out) { out[0] = a[0] + b; }
+extern "C" int avsr_add_int(const int32_t* a, int32_t b, int32_t* out, void* stream) {
+  if (!a || !out) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(add_int_kernel, dim3(1), dim3(1), 0, S_(stream), a, b, out);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
 extern "C" int avsr_colsum(const avsr_mat* a, const avsr_mat* b, int32_t rows, int32_t F, float alpha, float beta,
                            float* out, float* scratch, int64_t scratch_floats, void* stream) {
   if (!a || !a->ptr || !out || !scratch || rows <= 0 || F <= 0) return AVSR_ERR_ARG;

@@ -1236,8 +1236,9 @@ class Seq2SeqModel:
         Tv = batch.video.shape[1] if batch.video is not None else 0
         ws = self._get_ws(B, Ta, Tv, L, False)
         self._cur = (ws, batch)
+        ops.colsum_batch_abort()                 # (a backward pass that raised half-way must not leave its collection open)
         self._refresh_derived()
-        torch.add(self.step, int(self.seed_offset), out=self.seed)
+        ops.add_int(self.step, int(self.seed_offset), self.seed)
         self._encode(ws, batch, True)
         D = ws["dec"]
         H, E, V = D["H"], D["E"], cfg.vocab_size
@@ -1318,14 +1319,11 @@ class Seq2SeqModel:
         D = ws["dec"]
         H, E, A, V = D["H"], D["E"], D["A"], cfg.vocab_size
         self._ensure_gemm_ws()
-        self.grads.zero_()
-        for s in cfg.streams():
-            Es = ws["enc"][s]
-            if "dmem" in Es:
-                Es["dmem"].t.zero_()
+        zs = [self.grads] + [ws["enc"][s]["dmem"].t for s in cfg.streams() if "dmem" in ws["enc"][s]]
         if cfg.architecture == "av_align":
-            ws["enc"]["audio"]["blk"]["datt_ext"].zero_()
-            ws["enc"]["audio"]["blk"]["dcell_ext"].zero_()
+            zs += [ws["enc"]["audio"]["blk"]["datt_ext"], ws["enc"]["audio"]["blk"]["dcell_ext"]]
+        ops.zero_multi(zs)                        # one engine launch (every fill of the step is an engine kernel)
+        ops.colsum_batch_begin(self.grads)        # bias gradients: collected, run in two launches when the half-pass ends
         # output layer
         ov, O = self._out_vec(D)
         dl = ops.mat(D["dlogits"], V)
@@ -1344,11 +1342,16 @@ class Seq2SeqModel:
         if self.onehot is None:
             ops.embed_grad(D["dxemb"], D["fed"], self._gp("dec/embedding"), B, L, E, V, self.scratch)
         self._decoder_init_state_bwd(ws)
+        ops.colsum_batch_end(self.scratch)        # the decoder's block of the gradient buffer is final here (decoder_grad_bucket)
 
     def backward_encoders(self):
         """Second half of the backward pass: encoder BPTT, the lip CNN, every encoder-side weight gradient."""
         ws, batch = self._cur
-        self._encode_backward(ws, batch)
+        ops.colsum_batch_begin(self.grads)
+        try:
+            self._encode_backward(ws, batch)
+        finally:
+            ops.colsum_batch_end(self.scratch)
 
     def backward(self):
         """BPTT through decoder and encoders; leaves the full gradient in self.grads (engine layout)."""

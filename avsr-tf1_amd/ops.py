@@ -122,7 +122,50 @@ def transpose(jobs):
     check(_L().avsr_transpose(arr, len(jobs), _s()), "avsr_transpose")
 
 
+_colsum_batch = None      # (gradient buffer the deferred sums write into, [jobs]) while a backward pass collects its bias gradients
+
+
+def colsum_batch_begin(grads):
+    """From here on, column sums whose destination is `grads` (bias / gamma / beta gradients: read by nothing before the optimiser)
+    are collected instead of launched; colsum_batch_flush() runs them all in two launches (avsr_colsum_multi)."""
+    global _colsum_batch
+    _colsum_batch = (grads, [])
+
+
+def colsum_batch_flush(scratch):
+    global _colsum_batch
+    if _colsum_batch is None:
+        return
+    grads, jobs = _colsum_batch
+    _colsum_batch = (grads, [])
+    if jobs:
+        from ._lib import ColsumJob
+        arr = (ColsumJob * len(jobs))(*jobs)
+        check(_L().avsr_colsum_multi(arr, len(jobs), fptr(scratch), scratch.numel(), _s()), "avsr_colsum_multi")
+
+
+def colsum_batch_abort():
+    global _colsum_batch
+    _colsum_batch = None
+
+
+def colsum_batch_end(scratch):
+    global _colsum_batch
+    colsum_batch_flush(scratch)
+    _colsum_batch = None
+
+
 def colsum(a, rows, F, out, scratch, b=None, alpha=1.0, beta=0.0, out_offset=0):
+    if _colsum_batch is not None and out is _colsum_batch[0]:
+        from ._lib import ColsumJob, Mat
+        dst = fptr(out, out_offset)
+        if any(j.out == dst for j in _colsum_batch[1]):
+            # a second sum into the same destination (shared encoder weights, cells.py:77: several layers accumulate into one bias):
+            # jobs of one launch run concurrently, so the earlier ones go first
+            colsum_batch_flush(scratch)
+        _colsum_batch[1].append(ColsumJob(a, b if b is not None else Mat(None, 0, 0, 0, 0), fptr(out, out_offset), int(rows), int(F),
+                                          float(alpha), float(beta)))
+        return
     check(_L().avsr_colsum(C.byref(a), C.byref(b) if b is not None else None, rows, F, alpha, beta,
                            fptr(out, out_offset), fptr(scratch), scratch.numel(), _s()), "avsr_colsum")
 
@@ -233,6 +276,23 @@ def copy_(dst, src):
 def zero_(dst):
     assert dst.is_cuda and dst.element_size() == 4 and dst.is_contiguous()
     check(_L().avsr_zero_words(dst.data_ptr(), dst.numel(), _s()), "avsr_zero_words")
+
+
+def zero_multi(tensors):
+    """Zero several 4-byte-element buffers with one engine launch per eight of them."""
+    ts = [t for t in tensors if t is not None and t.numel()]
+    if not ts:
+        return
+    for t in ts:
+        assert t.is_cuda and t.element_size() == 4 and t.is_contiguous()
+    ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    cnt = (C.c_int64 * len(ts))(*[t.numel() for t in ts])
+    check(_L().avsr_zero_multi(ptrs, cnt, len(ts), _s()), "avsr_zero_multi")
+
+
+def add_int(a, b, out):
+    """out[0] = a[0] + b (int32, on the device)."""
+    check(_L().avsr_add_int(fptr(a), int(b), fptr(out), _s()), "avsr_add_int")
 
 
 def instnorm_fwd(x, y, B, T, F, gamma, beta, mean_out, invstd_out, eps=1e-6):

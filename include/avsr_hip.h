@@ -531,6 +531,20 @@ int avsr_highway_bwd(const avsr_mat* x, const avsr_mat* h, const avsr_mat* carry
  * neighbours on ROCm 7.0.  No reference counterpart. */
 int avsr_copy_words(void* dst, const void* src, int64_t n_words, void* stream);
 int avsr_zero_words(void* dst, int64_t n_words, void* stream);
+/* Any number of buffers zeroed eight per launch (the gradient buffers at the start of the backward pass), and
+ * out[0] = a[0] + b on the device (the step's dropout / sampling RNG key = global step + per-rank offset, avsr/cells.py:46-54 masks). */
+int avsr_zero_multi(void* const* ptrs, const int64_t* n_words, int32_t count, void* stream);
+int avsr_add_int(const int32_t* a, int32_t b, int32_t* out, void* stream);
+/* Many independent column sums (avsr_colsum semantics per job: out[f] = alpha * sum_r a[r][f] (* b[r][f]) + beta*out[f]) in two
+ * launches: the bias gradients of a train step (seq2seq.py:222).  scratch >= sum_j ceil(rows_j / max(32, ceil(rows_j/256))) * F_j floats. */
+typedef struct avsr_colsum_job {
+  avsr_mat a;
+  avsr_mat b;              /* b.ptr == NULL: plain column sums */
+  float* out;
+  int32_t rows, F;
+  float alpha, beta;
+} avsr_colsum_job;
+int avsr_colsum_multi(const avsr_colsum_job* jobs, int32_t n, float* scratch, int64_t scratch_floats, void* stream);
 /* AU regression loss (avsr/encoder.py:173-189); z = pre-sigmoid Dense(2) outputs [B][T][2]. */
 int avsr_au_loss(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz, int32_t B, int32_t T,
                  float weight, void* stream);
