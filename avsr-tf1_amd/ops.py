@@ -159,13 +159,16 @@ def colsum(a, rows, F, out, scratch, b=None, alpha=1.0, beta=0.0, out_offset=0):
     if _colsum_batch is not None and out is _colsum_batch[0]:
         from ._lib import ColsumJob, Mat
         dst = fptr(out, out_offset)
-        if any(j.out == dst for j in _colsum_batch[1]):
-            # a second sum into the same destination (shared encoder weights, cells.py:77: several layers accumulate into one bias):
-            # jobs of one launch run concurrently, so the earlier ones go first
+        dup = any(j.out == dst for j in _colsum_batch[1])
+        if dup and beta != 1.0:
             colsum_batch_flush(scratch)
-        _colsum_batch[1].append(ColsumJob(a, b if b is not None else Mat(None, 0, 0, 0, 0), fptr(out, out_offset), int(rows), int(F),
-                                          float(alpha), float(beta)))
-        return
+            dup = False
+        if not dup:
+            _colsum_batch[1].append(ColsumJob(a, b if b is not None else Mat(None, 0, 0, 0, 0), dst, int(rows), int(F),
+                                              float(alpha), float(beta)))
+            return
+        # a second ACCUMULATING sum into the same destination (shared encoder weights, cells.py:77: several layers add into one
+        # bias): jobs of one launch run concurrently, so this one is launched now, on its own -- additions commute
     check(_L().avsr_colsum(C.byref(a), C.byref(b) if b is not None else None, rows, F, alpha, beta,
                            fptr(out, out_offset), fptr(scratch), scratch.numel(), _s()), "avsr_colsum")
 
