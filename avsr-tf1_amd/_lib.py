@@ -97,7 +97,7 @@ class AttnRnn(C.Structure):
                 ("hs_seq", C.c_void_p), ("attd", C.c_void_p), ("xs", C.c_void_p), ("labels", C.c_void_p), ("fed", C.c_void_p),
                 ("cell", C.c_int32), ("pad4_", C.c_int32), ("wt2", C.c_void_p), ("w2", C.c_void_p), ("bias2", C.c_void_p),
                 ("rh_seq", C.c_void_p), ("dgates2", C.c_void_p),
-                ("beam_width", C.c_int32), ("pad5_", C.c_int32), ("length_penalty", C.c_float), ("pad6_", C.c_float),
+                ("beam_width", C.c_int32), ("mem_shared", C.c_int32), ("length_penalty", C.c_float), ("pad6_", C.c_float),
                 ("beam_logp", C.c_void_p), ("beam_fin", C.c_void_p), ("beam_len", C.c_void_p), ("step_ids", C.c_void_p),
                 ("parent_ids", C.c_void_p), ("parent_rows", C.c_void_p),
                 ("n_extra", C.c_int32), ("pad7_", C.c_int32), ("out0", C.c_void_p), ("extra", DecLayer * MAX_DEC_EXTRA),

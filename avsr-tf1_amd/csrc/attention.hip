@@ -97,11 +97,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnLaunch L) {
   locate(L, mi, b, c);
   const AttnMechDev& M = L.m[mi];
   const int tid = threadIdx.x;
-  const int len = min(M.len ? M.len[b] : M.T, M.T);
+  const int mb = M.mem_div > 1 ? b / M.mem_div : b;          // memory row of this hypothesis (beam search shares the utterance's memory)
+  const int len = min(M.len ? M.len[mb] : M.T, M.T);
   const int t0 = c * M.chunk;
   const int n = max(0, min(M.chunk, len - t0));  // valid rows in this chunk
   const int H = M.H, D = M.D;
-  const float* keys = M.keys + (long)b * M.T * H;
+  const float* keys = M.keys + (long)mb * M.T * H;
   const float* q = M.query + (long)b * M.query_sb;
 
   // ---- phase 1: scores for rows t0 .. t0+n-1 (16 lanes per row) ----
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnLaunch L) {
 
   // ---- phase 3: partial context = sum_r p_r * values[t0+r, :] ----
   const int cols = D >> 2;                 // float4 columns
-  const float* vals = M.values + (long)b * M.values_sb;
+  const float* vals = M.values + (long)mb * M.values_sb;
   float* pout = M.pctx + ((long)c * L.B + b) * D;
   for (int cb = 0; cb < cols; cb += 256) {
     const int ccols = min(256, cols - cb);

@@ -24,6 +24,7 @@ struct AttnMechDev {
   float* pm; float* pl; // [nchunk][B] chunk max / chunk exp-sum
   float* pctx;          // [nchunk][B][D] un-normalised partial contexts
   int T, D, H, type, nchunk, chunk;
+  int mem_div;          // hypothesis row b attends memory row b / mem_div (beam search over un-tiled memories; 1 otherwise)
   // backward
   const float* dctx; long dctx_sb;   // [B][D]
   const float* ctx; long ctx_sb;     // [B][D] forward context of this step

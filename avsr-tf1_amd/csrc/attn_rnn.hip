@@ -183,60 +183,75 @@ __global__ __launch_bounds__(256) void logits_sample_kernel(const float* x, long
   }
 }
 
-// One BeamSearchDecoder step for one utterance (block): see avsr_hip.h mode 3 and oracle.beam_search_decode.
-__global__ void beam_step_kernel(const float* logits, long logits_sb, int V, int K, int l, int eos, float w,
+// One BeamSearchDecoder step for one utterance (one wave per utterance): see avsr_hip.h mode 3 and oracle.beam_search_decode.
+// Candidate scores of all K*V continuations are computed by the whole wave; the top K are K rounds of a wave arg-max (value, then
+// LOWER index on ties = tf.nn.top_k's order).  (Round 2: one thread selected serially -- 165 us per step, the largest kernel of the
+// reference's default evaluation path.)  The per-beam log-sum-exp keeps its serial summation order (bit-identical candidates).
+__global__ __launch_bounds__(64) void beam_step_kernel(const float* logits, long logits_sb, int V, int K, int l, int eos, float w,
                                  const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
                                  float* logp_out, int32_t* fin_out, int32_t* len_out, int32_t* tok, int32_t* parent_rows,
                                  int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished) {
-  extern __shared__ float sm[];          // scores [K*V] | totals [K*V]
+  extern __shared__ float sm[];          // scores [K*V] | totals [K*V] | lse [K]
   float* score = sm;
   float* total = sm + K * V;
-  const int b = blockIdx.x;
+  float* lse_s = sm + 2 * K * V;
+  const int b = blockIdx.x, lane = threadIdx.x;
   const float FMIN = -3.4028234663852886e38f;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const int r = b * K + k;
-    const float* lg = logits + (long)r * logits_sb;
+  for (int k = lane; k < K; k += 64) {
+    const float* lg = logits + (long)(b * K + k) * logits_sb;
     float mx = lg[0];
     for (int v = 1; v < V; ++v) mx = fmaxf(mx, lg[v]);
     float s = 0.f;
     for (int v = 0; v < V; ++v) s += expf(lg[v] - mx);
-    const float lse = mx + logf(s);
-    const bool fin = fin_in[r] != 0;
-    const float prev = logp_in[r];
-    const int ln = len_in[r];
-    for (int v = 0; v < V; ++v) {
-      const float sl = fin ? (v == eos ? 0.f : FMIN) : lg[v] - lse;
-      const float tot = prev + sl;
-      const int nl = ln + ((fin || v == eos) ? 0 : 1);
-      total[k * V + v] = tot;
-      score[k * V + v] = tot / powf((5.0f + (float)nl) / 6.0f, w);
-    }
+    lse_s[k] = mx + logf(s);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int alive = 0;
-    for (int j = 0; j < K; ++j) {                      // top-K by repeated arg-max, first index wins ties (tf.nn.top_k)
-      int best = -1;
-      float bs = 0.f;
-      for (int i = 0; i < K * V; ++i) {
-        const float sc = score[i];
-        if (sc != sc) continue;                         // NaN marks an already selected candidate
-        if (best < 0 || sc > bs) { best = i; bs = sc; }
-      }
+  const int n = K * V;
+  for (int i = lane; i < n; i += 64) {
+    const int k = i / V, v = i - k * V, r = b * K + k;
+    const bool fin = fin_in[r] != 0;
+    const float lgv = logits[(long)r * logits_sb + v];
+    const float sl = fin ? (v == eos ? 0.f : FMIN) : lgv - lse_s[k];
+    const float tot = logp_in[r] + sl;
+    const int nl = len_in[r] + ((fin || v == eos) ? 0 : 1);
+    total[i] = tot;
+    score[i] = tot / powf((5.0f + (float)nl) / 6.0f, w);
+  }
+  __syncthreads();
+  int alive = 0;
+  for (int j = 0; j < K; ++j) {
+    // this lane's best remaining candidate (NaN marks a selected one), then the wave's: larger score, lower index on ties
+    float bs = 0.f;
+    int best = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+      const float sc = score[i];
+      if (sc != sc) continue;
+      if (best == 0x7fffffff || sc > bs) { best = i; bs = sc; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float os = __shfl_xor(bs, o, 64);
+      const int ob = __shfl_xor(best, o, 64);
+      const bool take = ob != 0x7fffffff && (best == 0x7fffffff || os > bs || (os == bs && ob < best));
+      if (take) { bs = os; best = ob; }
+    }
+    if (lane == 0) {
       score[best] = __builtin_nanf("");
       const int word = best % V, parent = best / V, r = b * K + j, pr = b * K + parent;
       const bool pf = fin_in[pr] != 0;
+      const int f = (pf || word == eos) ? 1 : 0;
       logp_out[r] = total[best];
-      fin_out[r] = (pf || word == eos) ? 1 : 0;
+      fin_out[r] = f;
       len_out[r] = len_in[pr] + (pf ? 0 : 1);
       tok[r] = word;
       parent_rows[r] = pr;
       step_ids[r] = word;
       parent_ids[r] = parent;
-      if (!fin_out[r]) ++alive;
+      if (!f) ++alive;
     }
-    if (alive) atomicAdd(n_unfinished, alive);
+    __syncthreads();
   }
+  if (lane == 0 && alive) atomicAdd(n_unfinished, alive);
 }
 
 __global__ void beam_gather_tree_kernel(const int32_t* step_ids, const int32_t* parent_ids, const int32_t* beam_len, int32_t* out,
@@ -324,6 +339,7 @@ static void fill_attn_launch(const avsr_attn_rnn& d, int l, AttnLaunch& AL) {
     X.pm = M.pstat + (long)(2 * l) * nc * B; X.pl = M.pstat + (long)(2 * l + 1) * nc * B;
     X.pctx = M.pctx;
     X.T = M.T; X.D = M.D; X.H = H; X.type = M.type; X.nchunk = nc; X.chunk = M.chunk;
+    X.mem_div = (d.mode == 3 && d.mem_shared && d.beam_width > 1) ? d.beam_width : 1;
     if (M.dctx) { X.dctx = M.dctx + (long)l * M.D; X.dctx_sb = (long)L * M.D; }
     X.ctx = M.ctx + (long)l * M.D; X.ctx_sb = (long)L * M.D;
     if (M.dscores) { X.dscores = M.dscores + (long)l * M.T; X.dscores_sb = (long)L * M.T; }
@@ -538,7 +554,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
       } else if (d.mode == 3) {
         const int K = d.beam_width, pin = l & 1, pout = (l + 1) & 1;
         if (avsr::dev_zero(d.n_unfinished + l, sizeof(int32_t), s) != hipSuccess) return AVSR_ERR_HIP;   // per-step count [L]
-        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(64), 2 * K * d.V * sizeof(float), s, d.logits + (long)l * d.V,
+        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(64), (2 * K * d.V + K) * sizeof(float), s, d.logits + (long)l * d.V,
                            (long)L * d.V, d.V, K, l, d.eos_id, d.length_penalty, d.beam_logp + (long)pin * B, d.beam_fin + (long)pin * B,
                            d.beam_len + (long)pin * B, d.beam_logp + (long)pout * B, d.beam_fin + (long)pout * B,
                            d.beam_len + (long)pout * B, d.tok, d.parent_rows, d.step_ids + (long)l * B, d.parent_ids + (long)l * B,

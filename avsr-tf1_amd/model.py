@@ -331,11 +331,14 @@ class Seq2SeqModel:
     def unpin_workspace(self, key):
         self._ws_pinned.discard(key)
 
-    def _make_block(self, ws, B, L, H, E, mems, cell_prefix, att_prefixes, Tv, Ta, greedy):
+    def _make_block(self, ws, B, L, H, E, mems, cell_prefix, att_prefixes, Tv, Ta, greedy, mem_B=None):
+        """mem_B: rows of the attention memories when they are shared by several block rows (beam search: one memory per utterance,
+        beam_width hypotheses attending it); default = one memory per row."""
         cfg, dev = self.cfg, self.dev
         z = lambda *s: torch.zeros(*s, device=dev)
         A = H * len(mems)
-        blk = {"B": B, "L": L, "H": H, "E": E, "A": A, "cell": cell_prefix, "mems": []}
+        mem_B = B if mem_B is None else mem_B
+        blk = {"B": B, "L": L, "H": H, "E": E, "A": A, "cell": cell_prefix, "mems": [], "mem_B": mem_B}
         if cell_prefix.startswith("dec/"):
             blk["cell_id"], blk["keep"] = CELL_ID_DECODER, cfg.decoder_dropout
         else:
@@ -386,9 +389,9 @@ class Seq2SeqModel:
             m["Dv"] = Dv
             if m["proj"]:
                 eye = torch.eye(H, device=dev)
-                m.update(pvals=z(B, T, H), dpvals=z(B, T, H), eye=eye, watt_p=torch.cat([z(H, H), eye], 0).contiguous(),
+                m.update(pvals=z(mem_B, T, H), dpvals=z(mem_B, T, H), eye=eye, watt_p=torch.cat([z(H, H), eye], 0).contiguous(),
                          watt_p_t=torch.cat([z(H, H), eye], 1).contiguous())
-            m.update(keys=z(B, T, H), dkeys=z(B, T, H), scores=z(B, L, T), dscores=z(B, L, T), ctx=z(B, L, Dv), dctx=z(B, L, Dv),
+            m.update(keys=z(mem_B, T, H), dkeys=z(mem_B, T, H), scores=z(B, L, T), dscores=z(B, L, T), ctx=z(B, L, Dv), dctx=z(B, L, Dv),
                      pstat=z(L, 2, nc, B), pctx=z(nc, B, Dv), pdq=z(nc, B, H), rowdot=z(B * L))
             if att_type in BAHDANAU_TYPES:
                 m.update(pq=z(B, L, H), dpq=z(B, L, H), vn=z(H), dvn=z(H), dv_part=z(((T + 15) // 16) * B, H))
@@ -1020,7 +1023,7 @@ class Seq2SeqModel:
 
     def _block_prepare(self, ws, blk):
         """Per-batch attention memory preparation: keys = values . W_mem (attention.py memory_layer)."""
-        B, H = blk["B"], blk["H"]
+        B, H = blk.get("mem_B", blk["B"]), blk["H"]
         for m in blk["mems"]:
             md = self._mem_desc(ws, m["stream"])
             pre = m["prefix"]
@@ -1422,34 +1425,49 @@ class Seq2SeqModel:
         ws = self._get_ws(B, Ta, Tv, 1, True)                  # encoders at batch B (decoder block of this ws is unused)
         self._refresh_derived()
         self._encode(ws, batch, False)
-        # tile_batch: memories, lengths and final states repeated K times; the decoder block runs on B*K rows
-        wsb = {"enc": {}, "B": B * K, "L": L}
+        # tile_batch (attention.py:100-106): the decoder block runs on B*K rows and the final states are repeated K times; the MEMORIES
+        # are not copied -- hypothesis row r attends memory row r // K (avsr_attn_rnn.mem_shared): keys are computed once per
+        # utterance and the K hypotheses of an utterance read the same bytes (tiled: K x 75 MB streamed from HBM every step)
+        R, V, dev, H = B * K, cfg.vocab_size, self.dev, cfg.decoder_units[0]
+        mems = cfg.decoder_memories()
+        ck = (B, K, L, Ta, Tv)
+        cache = getattr(self, "_beam_ws", None)
+        if cache is None or cache[0] != ck:              # buffers of the last beam-search shape are kept (a decode allocates ~100)
+            wsb = {"enc": {s: {} for s in cfg.streams()}, "B": R, "L": L}
+            D = None
+            logp0 = torch.full((2, B, K), float("-inf"), device=dev)
+            logp0[0, :, 0] = 0.0
+            X = dict(logp0=logp0, logp=torch.empty_like(logp0), fin=torch.zeros(2, R, dtype=torch.int32, device=dev),
+                     ln=torch.zeros(2, R, dtype=torch.int32, device=dev), sid=torch.zeros(L, R, dtype=torch.int32, device=dev),
+                     pid=torch.zeros(L, R, dtype=torch.int32, device=dev), prow0=torch.arange(R, dtype=torch.int32, device=dev),
+                     prow=torch.zeros(R, dtype=torch.int32, device=dev),
+                     c_dec={s: torch.zeros(R, H, device=dev) for s in cfg.streams()}, h_dec={s: torch.zeros(R, H, device=dev) for s in cfg.streams()})
+            self._beam_ws = cache = (ck, wsb, X)
+        _ck, wsb, X = cache
         for s in cfg.streams():
             E = ws["enc"][s]
             md = self._mem_desc(ws, s)
             src = E["mem"] if not E["attentive"] else (E["blk"]["att"] if E["blk"]["mems"][0]["type"] in LUONG_TYPES else E["blk"]["cell_out"])
-            Eb = {"attentive": False, "mem": _Tiled(src.t, src.lead, src.T, src.D, K), "dmem": None,
-                  "len": md["len"].repeat_interleave(K).contiguous(), "T": E["T"], "units": E["units"],
-                  "h_fin": E["h_fin"].repeat_interleave(K, dim=0).contiguous(),
-                  "c_fin": None if E["c_fin"] is None else E["c_fin"].repeat_interleave(K, dim=0).contiguous()}
-            Eb["dmem"] = Eb["mem"]
-            H = cfg.decoder_units[0]
-            Eb["c_dec"], Eb["h_dec"] = torch.zeros(B * K, H, device=self.dev), torch.zeros(B * K, H, device=self.dev)
-            wsb["enc"][s] = Eb
-        mems = cfg.decoder_memories()
-        D = self._make_block(wsb, B * K, L, cfg.decoder_units[0], cfg.embedding_size, mems, "dec/l0",
-                             ["dec/att%d" % i for i in range(len(mems))], Tv=Tv, Ta=Ta, greedy=True)
-        wsb["dec"] = D
-        R, V, dev = B * K, cfg.vocab_size, self.dev
-        D["logits"] = torch.zeros(R, L, V, device=dev)
-        D["tok"] = torch.full((R,), cfg.go_id, dtype=torch.int32, device=dev)
-        D["nunf"] = torch.ones(L, dtype=torch.int32, device=dev)
-        D["steplen"] = torch.full((R,), L, dtype=torch.int32, device=dev)
-        logp = torch.full((2, B, K), float("-inf"), device=dev)
-        logp[0, :, 0] = 0.0
-        fin, ln = torch.zeros(2, R, dtype=torch.int32, device=dev), torch.zeros(2, R, dtype=torch.int32, device=dev)
-        sid, pid = torch.zeros(L, R, dtype=torch.int32, device=dev), torch.zeros(L, R, dtype=torch.int32, device=dev)
-        prow = torch.arange(R, dtype=torch.int32, device=dev)
+            Eb = wsb["enc"][s]
+            Eb.update({"attentive": False, "mem": src, "dmem": src, "len": md["len"], "T": E["T"], "units": E["units"],
+                       "h_fin": E["h_fin"].repeat_interleave(K, dim=0).contiguous(),
+                       "c_fin": None if E["c_fin"] is None else E["c_fin"].repeat_interleave(K, dim=0).contiguous(),
+                       "c_dec": X["c_dec"][s], "h_dec": X["h_dec"][s]})
+        if "dec" not in wsb:
+            D = self._make_block(wsb, R, L, H, cfg.embedding_size, mems, "dec/l0",
+                                 ["dec/att%d" % i for i in range(len(mems))], Tv=Tv, Ta=Ta, greedy=True, mem_B=B)
+            wsb["dec"] = D
+            D["logits"] = torch.zeros(R, L, V, device=dev)
+            D["tok"] = torch.zeros(R, dtype=torch.int32, device=dev)
+            D["nunf"] = torch.zeros(L, dtype=torch.int32, device=dev)
+            D["steplen"] = torch.full((R,), L, dtype=torch.int32, device=dev)
+        D = wsb["dec"]
+        D["tok"].fill_(cfg.go_id)
+        D["nunf"].fill_(1)
+        logp, fin, ln, sid, pid, prow = X["logp"], X["fin"], X["ln"], X["sid"], X["pid"], X["prow"]
+        logp.copy_(X["logp0"])
+        prow.copy_(X["prow0"])
+        ops.zero_multi([fin, ln])
         self._decoder_init_state(wsb)
         self._block_prepare(wsb, D)
         d = self._block_desc(wsb, D, D["steplen"], 3, D["h0"], D["c0"], with_bwd=False)
@@ -1458,7 +1476,7 @@ class Seq2SeqModel:
         d.wout_t = ops.fptr(self.derived, self.Tr["dec/out/kernel"].off)
         d.bout = ops.fptr(self.params, self.P["dec/out/bias"].off)
         d.logits, d.tok, d.n_unfinished = ops.fptr(D["logits"]), ops.fptr(D["tok"]), ops.fptr(D["nunf"])
-        d.beam_width, d.length_penalty = K, float(w)
+        d.beam_width, d.length_penalty, d.mem_shared = K, float(w), 1
         d.beam_logp, d.beam_fin, d.beam_len = ops.fptr(logp), ops.fptr(fin), ops.fptr(ln)
         d.step_ids, d.parent_ids, d.parent_rows = ops.fptr(sid), ops.fptr(pid), ops.fptr(prow)
         l = 0
@@ -1538,22 +1556,6 @@ class Seq2SeqModel:
             out["encoder"] = alphas(E["blk"], E["len"])[0]
         self._last_align = out
         return out
-
-
-class _Tiled:
-    """tile_batch view of a [B, slots, D] sequence buffer for beam search (each utterance repeated beam_width times)."""
-
-    def __init__(self, t, lead, T, D, K):
-        self.t = t.repeat_interleave(K, dim=0).contiguous()
-        self.T, self.D, self.lead = T, D, lead
-        self.slots = t.shape[1]
-        self.sb, self.st = self.slots * D, D
-
-    def off(self, dt=0, col=0):
-        return (self.lead + dt) * self.D + col
-
-    def mat(self, dt=0, col=0):
-        return ops.mat(self.t, self.D, T=self.T, ldo=self.sb, offset=self.off(dt, col))
 
 
 def desc_steplen(desc):

@@ -305,8 +305,11 @@ typedef struct avsr_attn_rnn {
    * beam_width*V continuations per utterance (ties -> lower index), and records step_ids / parent_ids [L][B].  The next
    * step reads its previous state through parent_rows (no state copies).  Caller initialises tok = GO, parent_rows = identity,
    * beam_logp[0] = {0, -inf, ...} per utterance, beam_fin = beam_len = 0, steplen = L.  In this mode n_unfinished is an
-   * [L] array: entry l = number of unfinished beams after step l (dynamic_decode stops at the first 0). */
-  int32_t beam_width, pad5_;
+   * [L] array: entry l = number of unfinished beams after step l (dynamic_decode stops at the first 0).
+   * mem_shared != 0: the attention memories are NOT tiled -- keys / values / len of every mechanism hold one entry per UTTERANCE
+   * (B / beam_width rows) and hypothesis row b attends memory row b / beam_width: the beam_width hypotheses of an utterance read the
+   * same bytes (L2 / Infinity-Cache hits) instead of beam_width copies streamed from HBM every step. */
+  int32_t beam_width, mem_shared;
   float length_penalty;
   float pad6_;
   float* beam_logp;             /* [2][B] ping-pong */
