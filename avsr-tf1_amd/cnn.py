@@ -277,6 +277,12 @@ class LipCNN:
                         ops.batchnorm_apply(self.maps[src], self.maps[dst], N * h * w, c, self._pv(name + "/gamma"), self._pv(name + "/beta"),
                                             mean, invstd, 1)
                     continue
+                if not training and name in self.lazy_ok:
+                    # evaluation graph: the same loader-applied affine, from the moving statistics -- no normalised map is written
+                    ops.bn_eval_affine(self._pv(name + "/gamma"), self._pv(name + "/beta"), m._sp(self.pre + name + "/moving_mean"),
+                                       m._sp(self.pre + name + "/moving_variance"), self.BN_EPS, scale, shift, c)
+                    self.lazy[dst] = (src, scale, shift)
+                    continue
                 ops.batchnorm_fwd_ex(self.maps[src], self.maps[dst], N * h * w, c, self._pv(name + "/gamma"), self._pv(name + "/beta"),
                                      m._sp(self.pre + name + "/moving_mean") if upd else None,
                                      m._sp(self.pre + name + "/moving_variance") if upd else None, mean, invstd,

@@ -191,10 +191,11 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* logits, long
                                  const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
                                  float* logp_out, int32_t* fin_out, int32_t* len_out, int32_t* tok, int32_t* parent_rows,
                                  int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished) {
-  extern __shared__ float sm[];          // scores [K*V] | totals [K*V] | lse [K]
+  extern __shared__ float sm[];          // scores [K*V] | totals [K*V] | lse [K] | length penalties [K][2]
   float* score = sm;
   float* total = sm + K * V;
   float* lse_s = sm + 2 * K * V;
+  float* pen = lse_s + K;
   const int b = blockIdx.x, lane = threadIdx.x;
   const float FMIN = -3.4028234663852886e38f;
   for (int k = lane; k < K; k += 64) {
@@ -204,6 +205,10 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* logits, long
     float s = 0.f;
     for (int v = 0; v < V; ++v) s += expf(lg[v] - mx);
     lse_s[k] = mx + logf(s);
+    // a beam's continuations have one of two lengths: the same powf(...) values as one call per candidate, 2 instead of V per beam
+    const int ln = len_in[b * K + k];
+    pen[2 * k] = powf((5.0f + (float)ln) / 6.0f, w);
+    pen[2 * k + 1] = powf((5.0f + (float)(ln + 1)) / 6.0f, w);
   }
   __syncthreads();
   const int n = K * V;
@@ -213,9 +218,8 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* logits, long
     const float lgv = logits[(long)r * logits_sb + v];
     const float sl = fin ? (v == eos ? 0.f : FMIN) : lgv - lse_s[k];
     const float tot = logp_in[r] + sl;
-    const int nl = len_in[r] + ((fin || v == eos) ? 0 : 1);
     total[i] = tot;
-    score[i] = tot / powf((5.0f + (float)nl) / 6.0f, w);
+    score[i] = tot / pen[2 * k + ((fin || v == eos) ? 0 : 1)];
   }
   __syncthreads();
   int alive = 0;
@@ -554,7 +558,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
       } else if (d.mode == 3) {
         const int K = d.beam_width, pin = l & 1, pout = (l + 1) & 1;
         if (avsr::dev_zero(d.n_unfinished + l, sizeof(int32_t), s) != hipSuccess) return AVSR_ERR_HIP;   // per-step count [L]
-        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(64), (2 * K * d.V + K) * sizeof(float), s, d.logits + (long)l * d.V,
+        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(64), (2 * K * d.V + 3 * K) * sizeof(float), s, d.logits + (long)l * d.V,
                            (long)L * d.V, d.V, K, l, d.eos_id, d.length_penalty, d.beam_logp + (long)pin * B, d.beam_fin + (long)pin * B,
                            d.beam_len + (long)pin * B, d.beam_logp + (long)pout * B, d.beam_fin + (long)pout * B,
                            d.beam_len + (long)pout * B, d.tok, d.parent_rows, d.step_ids + (long)l * B, d.parent_ids + (long)l * B,

@@ -747,6 +747,23 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* part, in
   }
 }
 
+// evaluation graph (training=False, video.py:8-12): scale / shift of the loader-applied batch norm from the MOVING statistics
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, float eps, float* scale,
+                                      float* shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] * rsqrtf(mov_var[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - mov_mean[c] * sc;
+}
+extern "C" int avsr_bn_eval_affine(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, float eps, float* scale,
+                                   float* shift, int32_t C, void* stream) {
+  if (!gamma || !beta || !mov_mean || !mov_var || !scale || !shift || C <= 0) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), gamma, beta, mov_mean, mov_var, eps, scale, shift, C);
+  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+  return AVSR_OK;
+}
+
 extern "C" int avsr_bn_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, float eps, float momentum, float* mean,
                                 float* invstd, float* mov_mean, float* mov_var, const float* gamma, const float* beta, float* scale,
                                 float* shift, void* stream) {

@@ -466,6 +466,11 @@ def bn_bwd_finalize(part, nparts, Cn, count, mean, invstd, gamma, dgamma, dbeta,
                                     float(grad_beta), fptr(k), _s()), "avsr_bn_bwd_finalize")
 
 
+def bn_eval_affine(gamma, beta, mov_mean, mov_var, eps, scale, shift, Cn):
+    check(_L().avsr_bn_eval_affine(fptr(gamma), fptr(beta), fptr(mov_mean), fptr(mov_var), float(eps), fptr(scale), fptr(shift), int(Cn), _s()),
+          "avsr_bn_eval_affine")
+
+
 def bn_bwd_apply(dz, x, k, dx, rows, Cn, beta=0.0):
     check(_L().avsr_bn_bwd_apply(fptr(dz), fptr(x), fptr(k), fptr(dx), int(rows), int(Cn), float(beta), _s()), "avsr_bn_bwd_apply")
 

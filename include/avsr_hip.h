@@ -460,6 +460,10 @@ int avsr_bn_bwd_finalize(const float* part, int32_t nparts, int32_t C, int64_t c
 int avsr_bn_bwd_apply(const float* dz, const float* x, const float* k, float* dx, int64_t rows, int32_t C, float beta, void* stream);
 int avsr_bn_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, float eps, float momentum, float* mean, float* invstd,
                      float* mov_mean, float* mov_var, const float* gamma, const float* beta, float* scale, float* shift, void* stream);
+/* scale = gamma * rsqrt(moving_variance + eps), shift = beta - moving_mean * scale: the evaluation graph's batch norm as the
+ * loader-applied affine of avsr_conv_desc (no normalised map is written in evaluation either). */
+int avsr_bn_eval_affine(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, float eps, float* scale,
+                        float* shift, int32_t C, void* stream);
 int avsr_batchnorm_apply(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta, const float* mean,
                          const float* invstd, int32_t relu, void* stream);
 int avsr_conv3x3(const float* x, const float* w, const float* bias, float* y, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
