@@ -128,7 +128,7 @@ EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr
            "avsr_relu", "avsr_relu_bwd", "avsr_add", "avsr_selu", "avsr_selu_bwd", "avsr_conv3x3_supported", "avsr_conv3x3", "avsr_conv3x3_bwd_data_s2",
            "avsr_conv3x3_bwd_weight", "avsr_embed_labels", "avsr_embed_grad", "avsr_dropout_rows", "avsr_seq_loss",
            "avsr_au_loss", "avsr_au_loss_dp", "avsr_normed_v", "avsr_normed_v_bwd", "avsr_reduce_scalar", "avsr_l2_regularise",
-           "avsr_global_norm", "avsr_adam_step", "avsr_adam_step_decay", "avsr_copy_words", "avsr_zero_words", "avsr_zero_multi", "avsr_add_int", "avsr_colsum_multi", "avsr_highway_fwd", "avsr_highway_bwd", "avsr_optimiser_step", "avsr_instnorm_fwd", "avsr_instnorm_bwd", "avsr_seq_loss_fun", "avsr_seq_loss_per_utterance", "avsr_batchnorm_sync_sum", "avsr_batchnorm_sync_sqsum", "avsr_batchnorm_sync_apply", "avsr_prof_begin", "avsr_prof_end"]
+           "avsr_global_norm", "avsr_adam_step", "avsr_adam_step_decay", "avsr_copy_words", "avsr_zero_words", "avsr_zero_multi", "avsr_add_int", "avsr_colsum_multi", "avsr_highway_fwd", "avsr_highway_bwd", "avsr_optimiser_step", "avsr_instnorm_fwd", "avsr_instnorm_bwd", "avsr_seq_loss_fun", "avsr_seq_loss_per_utterance", "avsr_batchnorm_sync_sum", "avsr_batchnorm_sync_sqsum", "avsr_batchnorm_sync_apply", "avsr_batchnorm_sync_moments", "avsr_dp_sync_unpack", "avsr_prof_begin", "avsr_prof_end"]
 
 _lib = None
 
@@ -216,6 +216,8 @@ def load():
         "avsr_batchnorm_sync_sum": [vp, i32, i32, vp, vp, i64, vp],
         "avsr_batchnorm_sync_sqsum": [vp, i32, i32, vp, vp, vp, vp, vp, i64, vp],
         "avsr_batchnorm_sync_apply": [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp],
+        "avsr_batchnorm_sync_moments": [vp, i32, i32, vp, vp, i64, vp],
+        "avsr_dp_sync_unpack": [vp, vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp],
         "avsr_seq_loss_per_utterance": [vp, vp, vp, vp, i32, i32, vp],
         "avsr_instnorm_fwd": [vp, vp, i32, i32, i32, vp, vp, vp, vp, f32, vp],
         "avsr_instnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],

@@ -870,6 +870,78 @@ extern "C" int avsr_batchnorm_sync_sqsum(const float* x, int32_t rows, int32_t F
   return AVSR_OK;
 }
 
+// ---- ONE small collective per data-parallel step (SURVEY 8(e) collectives (2) + (3) fused) ----
+// avsr_batchnorm_sync_moments: per-feature sum x | sum x^2 of this rank's rows in DOUBLE precision into out64 [2F] (the global
+// variance is then E[x^2] - mean^2 evaluated in fp64: exact to ~1e-13 relative for feature-scale inputs, so the second,
+// mean-dependent reduction -- and its all-reduce -- is not needed).
+__global__ __launch_bounds__(256) void bn_moments_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int rows, int F, int rpb) {
+  const int r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
+  for (int f = threadIdx.x; f < F; f += 256) {
+    double s = 0.0, s2 = 0.0;
+    for (int r = r0; r < r1; ++r) { const double v = (double)x[(long)r * F + f]; s += v; s2 += v * v; }
+    part[(long)blockIdx.x * 2 * F + f] = s;
+    part[(long)blockIdx.x * 2 * F + F + f] = s2;
+  }
+}
+__global__ __launch_bounds__(256) void bn_moments_final_kernel(const double* __restrict__ part, int nblk, int F2, double* __restrict__ out) {
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F2) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += part[(long)i * F2 + f];
+  out[f] = s;
+}
+extern "C" int avsr_batchnorm_sync_moments(const float* x, int32_t rows, int32_t F, double* out64, float* scratch, int64_t scratch_floats,
+                                           void* stream) {
+  if (!x || !out64 || !scratch || rows <= 0 || F <= 0 || ((uintptr_t)scratch & 7)) return AVSR_ERR_ARG;
+  int nblk = (rows + 63) / 64;
+  if (nblk > 1024) nblk = 1024;
+  while (nblk > 1 && (long)nblk * 2 * F * 2 > scratch_floats) nblk /= 2;
+  if ((long)nblk * 2 * F * 2 > scratch_floats) return AVSR_ERR_ARG;
+  const int rpb = (rows + nblk - 1) / nblk;
+  nblk = (rows + rpb - 1) / rpb;
+  double* part = reinterpret_cast<double*>(scratch);
+  hipLaunchKernelGGL(bn_moments_partial_kernel, dim3(nblk), dim3(256), 0, S_(stream), x, part, rows, F, rpb);
+  AVSR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_moments_final_kernel, dim3((2 * F + 255) / 256), dim3(256), 0, S_(stream), part, nblk, 2 * F, out64);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+// avsr_dp_sync_unpack: the all-reduced buffer [sum(mask), AU count | per stream: sum x [F], sum x^2 [F], rows] -> the float32 operands
+// the step's kernels read: dp_norm[0..1]; per stream mean [F], centred squares sum (x - mean)^2 [F] = sum x^2 - rows*mean^2, rows.
+struct DpUnpack { const double* buf; float* dp_norm; int nstream; int off[4]; int F[4]; float* mean[4]; float* sq[4]; float* rows[4]; };
+__global__ void dp_sync_unpack_kernel(const DpUnpack U) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 2 && U.dp_norm) U.dp_norm[t] = (float)U.buf[t];
+  for (int s = 0; s < U.nstream; ++s) {
+    const double* b = U.buf + U.off[s];
+    const int F = U.F[s];
+    const double n = b[2 * F];
+    if (t == 0) U.rows[s][0] = (float)n;
+    if (t < F) {
+      const double m = n > 0.0 ? b[t] / n : 0.0;
+      double c = b[F + t] - n * m * m;
+      if (c < 0.0) c = 0.0;
+      U.mean[s][t] = (float)m;
+      U.sq[s][t] = (float)c;
+    }
+  }
+}
+extern "C" int avsr_dp_sync_unpack(const double* buf, float* dp_norm, int32_t nstream, const int32_t* off, const int32_t* F,
+                                   float* const* mean, float* const* sq, float* const* rows, void* stream) {
+  if (!buf || nstream < 0 || nstream > 4) return AVSR_ERR_ARG;
+  DpUnpack U = {};
+  U.buf = buf; U.dp_norm = dp_norm; U.nstream = nstream;
+  int maxF = 2;
+  for (int s = 0; s < nstream; ++s) {
+    if (!off || !F || !mean || !sq || !rows || !mean[s] || !sq[s] || !rows[s] || F[s] <= 0) return AVSR_ERR_ARG;
+    U.off[s] = off[s]; U.F[s] = F[s]; U.mean[s] = mean[s]; U.sq[s] = sq[s]; U.rows[s] = rows[s];
+    if (F[s] > maxF) maxF = F[s];
+  }
+  hipLaunchKernelGGL(dp_sync_unpack_kernel, dim3((maxF + 255) / 256), dim3(256), 0, S_(stream), U);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
 extern "C" int avsr_batchnorm_sync_apply(const float* x, float* y, int32_t rows, int32_t F, const float* gamma,
                                          const float* beta, float* moving_mean, float* moving_var, const float* mean,
                                          const float* sq_global, const float* total_rows, float* invstd_out, float eps,

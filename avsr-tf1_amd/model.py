@@ -117,7 +117,11 @@ class Seq2SeqModel:
                 self._train_off[name] = nt
                 nt += n
         z = lambda n, dt=torch.float32: torch.zeros(max(n, 4), dtype=dt, device=self.dev)
-        self.params, self.grads, self.adam_m, self.adam_v = z(nt), z(nt), z(nt), z(nt)
+        self.params, self.adam_m, self.adam_v = z(nt), z(nt), z(nt)
+        # the batch loss lives in the 4-float tail of the gradient buffer: a data-parallel trainer sums gradients AND loss over the
+        # ranks with ONE all-reduce of grads_and_loss (parallel.py)
+        self.grads_and_loss = z(max(nt, 4) + 4)
+        self.grads = self.grads_and_loss[:max(nt, 4)]
         self.stats = z(ns)
         self.n_train = nt
         self.step = z(1, torch.int32)[:1]
@@ -162,7 +166,7 @@ class Seq2SeqModel:
         self.scratch = z(1 << 22)
         self.gemm_ws = None
         self._ensure_gemm_ws()               # split-K scratch, also used by forward GEMMs with few output tiles
-        self.loss = z(1)[:1]
+        self.loss = self.grads_and_loss[max(nt, 4):max(nt, 4) + 1]
         self.gnorm = z(1)[:1]
         self.dp_norm = z(4)          # [sum(mask) of the sequence loss, AU frame-unit count]: what the DP trainer all-reduces per step
         self.denom, self.au_total = self.dp_norm[0:1], self.dp_norm[1:2]
@@ -639,6 +643,38 @@ class Seq2SeqModel:
             x = self._fit_width(ws["enc"][s], x, s)
         assert x.is_contiguous() and x.dtype == torch.float32 and x.shape[-1] == F
         return x, x.shape[0] * x.shape[1], F
+
+    def dp_sync_pack(self, batch):
+        """ONE small collective per data-parallel step: this rank's [sum(mask) of the sequence loss, AU frame-unit count | per
+        synchronised stream: sum x, sum x^2 (fp64), rows] in one fp64 buffer the trainer all-reduces; dp_sync_unpack() then turns the
+        global sums into the operands the step reads (dp_norm; mean / centred squares / rows of the input batch norms)."""
+        bs = self.bn_sync
+        streams = bs["streams"] if bs else []
+        if getattr(self, "_dp_buf", None) is None:
+            offs, n = [], 2
+            for s in streams:
+                offs.append(n)
+                n += 2 * self.cfg.feat(s) + 1
+            self._dp_buf, self._dp_offs = torch.zeros(n, dtype=torch.float64, device=self.dev), offs
+        buf = self._dp_buf
+        buf[0:1].copy_(self.local_loss_denominator(batch))
+        buf[1:2].copy_(self.local_au_count(batch))
+        for i, s in enumerate(streams):
+            x, rows, F = self._bn_sync_x(batch, s)
+            o = self._dp_offs[i]
+            ops.batchnorm_sync_moments(x, rows, F, buf[o:o + 2 * F], self.scratch)
+            buf[o + 2 * F:o + 2 * F + 1].fill_(float(rows))
+        self.au_scale, self.au_external = 1.0, True
+        return buf
+
+    def dp_sync_unpack(self):
+        bs = self.bn_sync
+        streams = bs["streams"] if bs else []
+        jobs = []
+        for i, s in enumerate(streams):
+            F, o = self.cfg.feat(s), bs["off"][s]
+            jobs.append((self._dp_offs[i], F, bs["mean"][o:o + F], bs["sq"][o:o + F], bs["rows"][i]))
+        ops.dp_sync_unpack(self._dp_buf, self.dp_norm, jobs)
 
     def bn_sync_sums(self, batch):
         """Phase 1: local sum over rows of every synchronised stream + its local row count; returns the buffer to all-reduce."""

@@ -195,6 +195,20 @@ def batchnorm_sync_apply(x, y, rows, F, gamma, beta, mov_mean, mov_var, mean, sq
           "avsr_batchnorm_sync_apply")
 
 
+def batchnorm_sync_moments(x, rows, F, out64, scratch):
+    assert out64.dtype == torch.float64
+    check(_L().avsr_batchnorm_sync_moments(fptr(x), rows, F, out64.data_ptr(), fptr(scratch), scratch.numel(), _s()), "avsr_batchnorm_sync_moments")
+
+
+def dp_sync_unpack(buf64, dp_norm, streams):
+    """streams: [(offset in buf64, F, mean, sq, rows)] float32 destinations."""
+    n = len(streams)
+    off = (C.c_int32 * max(n, 1))(*[int(s[0]) for s in streams])
+    Fs = (C.c_int32 * max(n, 1))(*[int(s[1]) for s in streams])
+    mk = lambda k: (C.c_void_p * max(n, 1))(*[s[k].data_ptr() for s in streams])
+    check(_L().avsr_dp_sync_unpack(buf64.data_ptr(), fptr(dp_norm), n, off, Fs, mk(2), mk(3), mk(4), _s()), "avsr_dp_sync_unpack")
+
+
 def batchnorm_xhat(x, mean, invstd, xhat, rows, F):
     check(_L().avsr_batchnorm_xhat(fptr(x), fptr(mean), fptr(invstd), fptr(xhat), rows, F, _s()), "avsr_batchnorm_xhat")
 

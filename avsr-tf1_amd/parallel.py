@@ -149,16 +149,20 @@ class DataParallelTrainer:
             self._pending = self.dist.all_reduce(self.model.grads[lo:hi], async_op=True)
 
     def _reduce_grads(self):
-        """Sum the flat gradient buffer over the ranks: everything, or what the bucket started earlier does not cover."""
+        """Sum the flat gradient buffer over the ranks: everything, or what the bucket started earlier does not cover.  The batch
+        loss rides in the buffer's tail (model.grads_and_loss): one collective instead of two."""
         m = self.model
+        full = getattr(m, "grads_and_loss", None)
+        self._loss_reduced = full is not None
         if self._bucket is None:
-            self.dist.all_reduce(m.grads)
+            self.dist.all_reduce(full if full is not None else m.grads)
             return
         lo, hi = self._bucket
         if lo > 0:
             self.dist.all_reduce(m.grads[:lo])
-        if hi < m.grads.numel():
-            self.dist.all_reduce(m.grads[hi:])
+        tail = full if full is not None else m.grads
+        if hi < tail.numel():
+            self.dist.all_reduce(tail[hi:])
         if self._pending is not None:
             self._pending.wait()                       # the current stream waits for the side-stream collective
             self._pending = None
@@ -202,7 +206,13 @@ class DataParallelTrainer:
         key = self._key(batch)
         if self.collective and self.use_graph and self.drain_around_collectives:
             self._drain()
-        if self.collective:
+        fused_sync = self.collective and hasattr(m, "dp_sync_pack") and (self.sync_bn or getattr(m, "bn_sync", None) is None)
+        if fused_sync:
+            # ONE small collective: both loss normalisers and the fp64 moments of every synchronised input batch norm
+            buf = m.dp_sync_pack(batch)
+            dist.all_reduce(buf)
+            m.dp_sync_unpack()
+        elif self.collective:
             # global loss normaliser: sum over ALL ranks of min(labels_len, L)
             local = getattr(m, "local_loss_denominator", None)
             if local is not None:
@@ -246,8 +256,10 @@ class DataParallelTrainer:
             if self._persistent_failed():              # persistent kernels not co-resident: redo through the launch path
                 self._fwd_bwd(st)
             if self.collective:
-                dist.all_reduce(m.grads)
-                self._reduce_loss()
+                full = getattr(m, "grads_and_loss", None)
+                dist.all_reduce(full if full is not None else m.grads)
+                if full is None:
+                    self._reduce_loss()
             m.apply_update()
             torch.cuda.synchronize()
             try:
@@ -309,5 +321,8 @@ class DataParallelTrainer:
     def _reduce_loss(self):
         """The forward pass leaves this rank's share of the batch loss (its cross-entropy sum over the GLOBAL token count, its share
         of the AU term): summed over the ranks it is the loss the reference reports; L2 joins once, in apply_update, on every rank."""
+        if getattr(self, "_loss_reduced", False):
+            self._loss_reduced = False                      # summed with the gradients (grads_and_loss)
+            return
         if getattr(self.model, "loss", None) is not None and torch.is_tensor(self.model.loss):
             self.dist.all_reduce(self.model.loss)

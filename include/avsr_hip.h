@@ -388,6 +388,16 @@ int avsr_batchnorm_sync_sum(const float* x, int32_t rows, int32_t F, float* sum_
                             void* stream);
 int avsr_batchnorm_sync_sqsum(const float* x, int32_t rows, int32_t F, const float* sum_global, const float* total_rows,
                               float* mean_out, float* sq_out, float* scratch, int64_t scratch_floats, void* stream);
+/* Data-parallel step, ONE small collective (the loss normalisers and the sync-batch-norm statistics fused):
+ *   avsr_batchnorm_sync_moments: out64[0..F) = sum x, out64[F..2F) = sum x^2 over this rank's rows, fp64 (scratch 8-byte aligned,
+ *     >= 4*F*min(1024, ceil(rows/64)) floats); the caller packs them with its row count and the two loss normalisers into one fp64
+ *     buffer and all-reduces that (sum);
+ *   avsr_dp_sync_unpack: the reduced buffer -> dp_norm[0..1] and per stream mean / centred squares (sum x^2 - rows*mean^2, fp64) /
+ *     rows as the float32 operands avsr_batchnorm_sync_apply and the loss kernels read.  encoder.py:44-50 statistics over the GLOBAL
+ *     batch; no reference counterpart for the transport. */
+int avsr_batchnorm_sync_moments(const float* x, int32_t rows, int32_t F, double* out64, float* scratch, int64_t scratch_floats, void* stream);
+int avsr_dp_sync_unpack(const double* buf, float* dp_norm, int32_t nstream, const int32_t* off, const int32_t* F, float* const* mean,
+                        float* const* sq, float* const* rows, void* stream);
 int avsr_batchnorm_sync_apply(const float* x, float* y, int32_t rows, int32_t F, const float* gamma, const float* beta,
                               float* moving_mean, float* moving_var, const float* mean, const float* sq_global,
                               const float* total_rows, float* invstd_out, float eps, float momentum, int32_t relu, void* stream);

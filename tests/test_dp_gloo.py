@@ -116,6 +116,51 @@ class OracleBackedModel:
             self.W[k] = v.detach().numpy().astype(np.float32)
 
 
+class FusedSyncModel(OracleBackedModel):
+    """The same stand-in with the hooks of the fused transport (model.py dp_sync_pack / dp_sync_unpack / grads_and_loss): ONE small
+    fp64 collective carrying the loss normaliser and the batch-norm moments (variance = E[x^2] - mean^2 in fp64), and the loss summed
+    with the gradients in the tail of one buffer."""
+
+    def __init__(self, cfg, W):
+        super().__init__(cfg, W)
+        n = sum(self.sizes)
+        self.grads_and_loss = torch.zeros(n + 4, dtype=torch.float64)
+        self.grads = self.grads_and_loss[:n]
+        self.loss = self.grads_and_loss[n:n + 1]
+        self.calls = []
+
+    def dp_sync_pack(self, batch):
+        bs = self.bn_sync
+        streams = bs["streams"] if bs else []
+        L = batch.labels.shape[1]
+        parts = [batch.labels_len.clamp(0, L).sum().to(torch.float64).reshape(1), torch.zeros(1, dtype=torch.float64)]
+        for s in streams:
+            x = self._rows(batch, s)
+            parts += [x.sum(0), (x * x).sum(0), torch.tensor([float(x.shape[0])], dtype=torch.float64)]
+        self._buf = torch.cat(parts)
+        self.calls.append("pack")
+        return self._buf
+
+    def dp_sync_unpack(self):
+        self.denom.copy_(self._buf[0:1].to(torch.float32))
+        bs, o = self.bn_sync, 2
+        if bs:
+            bs["mean"], self._var = {}, {}
+            for s in bs["streams"]:
+                F = bs["feats"][s]
+                n = float(self._buf[o + 2 * F])
+                mean = self._buf[o:o + F] / n
+                bs["mean"][s] = mean
+                self._var[s] = (torch.clamp(self._buf[o + F:o + 2 * F] / n - mean * mean, min=0.0), n)
+                o += 2 * F + 1
+        self.calls.append("unpack")
+
+    def _bn_stats(self):
+        if self.bn_sync is None:
+            return None
+        return {s: (self.bn_sync["mean"][s].clone(), self._var[s][0], self._var[s][1]) for s in self.bn_sync["streams"]}
+
+
 def _shard(b, lo, hi):
     def f(a, dt):
         return None if a is None else torch.as_tensor(np.ascontiguousarray(a[lo:hi]), dtype=dt)
@@ -123,7 +168,7 @@ def _shard(b, lo, hi):
                  f(b.aus, torch.float32), f(b.labels, torch.int32), f(b.labels_len, torch.int32))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, fused=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
@@ -131,19 +176,30 @@ def _worker(rank, world, port, out_dir):
     W = O.init_params(cfg, seed=9)
     full = O.synthetic_batch(cfg, B=4, T_a=7, T_v=4, L=5, ragged=True)
     per = 4 // world
-    model = OracleBackedModel(cfg, W)
+    model = (FusedSyncModel if fused else OracleBackedModel)(cfg, W)
     trainer = DataParallelTrainer(model, dist, use_graph=False)
+    ncoll = [0]
+    real = dist.all_reduce
+
+    def counting(*a, **k):
+        ncoll[0] += 1
+        return real(*a, **k)
+    dist.all_reduce = counting
     for _ in range(2):
         trainer.train_step(_shard(full, rank * per, (rank + 1) * per))
+    dist.all_reduce = real
+    if fused:                                                   # two collectives per step: the packed normalisers, gradients + loss
+        assert ncoll[0] == 4 and model.calls == ["pack", "unpack"] * 2, (ncoll, model.calls)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), gnorm=model.gnorm.numpy(), **model.W)
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_equals_single_process(tmp_path):
+@pytest.mark.parametrize("fused", [False, True])
+def test_two_rank_data_parallel_equals_single_process(tmp_path, fused):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), fused), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     cfg = _cfg()
     W = O.init_params(cfg, seed=9)
