@@ -203,27 +203,56 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   }
 
   // epilogue: C/D layout of mfma 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // Per 32x32 tile: the 16 destination addresses of the lane first (the two-level row address by an exact multiply-high division for
+  // row counts below 2^16), then -- beta != 0 -- its 16 old values with all loads in flight together, then the 16 stores.  (The
+  // first version read, combined and stored one element at a time: 64 dependent memory round trips per lane whenever beta != 0 --
+  // a 256 x 256 x 64 accumulating GEMM took 31 us for 4 us of work -- and an integer division per element on two-level outputs.)
   const bool split = g.splitk > 1;
   const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
+  const unsigned mTc = (g.Tc > 1 && g.M < 65536) ? (unsigned)(((1ull << 32) / (unsigned)g.Tc) + 1ull) : 0u;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 64 + j * 32 + (lane & 31);
       if (col >= g.N) continue;
+      const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+      if (split) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= g.M) continue;
-        if (split) {
-          g.ws[((long)z * g.M + row) * g.N + col] = acc[i][j][r];
-        } else {
-          float* c = g.C + (long)bz * g.sC +
-                     (g.Tc ? (long)(row / g.Tc) * g.ldoc + (long)(row % g.Tc) * g.ldc : (long)row * g.ldc) + col;
-          float v = alpha * acc[i][j][r];
-          if (g.beta != 0.f) v += g.beta * *c;
-          if (g.bias) v += g.bias[col];
-          *c = v;
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (row < g.M) g.ws[((long)z * g.M + row) * g.N + col] = acc[i][j][r];
+        }
+        continue;
+      }
+      float* const cbase = g.C + (long)bz * g.sC + col;
+      const float bias_v = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                       // eight rows at a time (register budget: 168 per lane at 3 waves per SIMD)
+        float* cp[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int r = h * 8 + rr;
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          long o;
+          if (!g.Tc) o = (long)row * g.ldc;
+          else {
+            const int qd = mTc ? (int)__umulhi((unsigned)row, mTc) : (g.Tc == 1 ? row : row / g.Tc);
+            o = (long)qd * g.ldoc + (long)(row - qd * g.Tc) * g.ldc;
+          }
+          cp[rr] = row < g.M ? cbase + o : nullptr;
+        }
+        float old[8];
+        if (g.beta != 0.f) {
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) old[rr] = cp[rr] ? *cp[rr] : 0.f;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          float v = alpha * acc[i][j][h * 8 + rr];
+          if (g.beta != 0.f) v += g.beta * old[rr];
+          v += bias_v;
+          if (cp[rr]) *cp[rr] = v;
         }
       }
     }
