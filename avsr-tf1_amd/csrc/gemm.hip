@@ -210,52 +210,65 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   const bool split = g.splitk > 1;
   const float alpha = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
   const unsigned mTc = (g.Tc > 1 && g.M < 65536) ? (unsigned)(((1ull << 32) / (unsigned)g.Tc) + 1ull) : 0u;
+  if (split) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-      if (col >= g.N) continue;
-      const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
-      if (split) {
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (col >= g.N) continue;
+        const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
           if (row < g.M) g.ws[((long)z * g.M + row) * g.N + col] = acc[i][j][r];
         }
-        continue;
       }
-      float* const cbase = g.C + (long)bz * g.sC + col;
-      const float bias_v = g.bias ? g.bias[col] : 0.f;
+    return;
+  }
+  // eight half-tiles (i, j, h) of eight rows each, software-pipelined: the offsets and old values of half-tile t + 1 are requested
+  // BEFORE half-tile t is stored (the compiler cannot move a load above a store that may alias it, so the program order does it).
+  // Raw buffer accesses with 32-bit byte offsets (an output matrix stays below 2 GB: checked by the host); rows / columns outside the
+  // matrix use an out-of-range offset -- their loads return 0 and their stores are dropped.
+  const __amdgpu_buffer_rsrc_t c_rs = __builtin_amdgcn_make_buffer_rsrc(g.C + (long)bz * g.sC, 0, 0x80000000u, 0x00020000);
+  int co[2][8];
+  float old[2][8];
+  auto prep = [&](int t, int (&cot)[8], float (&oldt)[8]) {
+    const int i = t >> 2, j = (t >> 1) & 1, h = t & 1;
+    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {                       // eight rows at a time (register budget: 168 per lane at 3 waves per SIMD)
-        float* cp[8];
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-          const int r = h * 8 + rr;
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          long o;
-          if (!g.Tc) o = (long)row * g.ldc;
-          else {
-            const int qd = mTc ? (int)__umulhi((unsigned)row, mTc) : (g.Tc == 1 ? row : row / g.Tc);
-            o = (long)qd * g.ldoc + (long)(row - qd * g.Tc) * g.ldc;
-          }
-          cp[rr] = row < g.M ? cbase + o : nullptr;
-        }
-        float old[8];
-        if (g.beta != 0.f) {
-#pragma unroll
-          for (int rr = 0; rr < 8; ++rr) old[rr] = cp[rr] ? *cp[rr] : 0.f;
-        }
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-          float v = alpha * acc[i][j][h * 8 + rr];
-          if (g.beta != 0.f) v += g.beta * old[rr];
-          v += bias_v;
-          if (cp[rr]) *cp[rr] = v;
-        }
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = h * 8 + rr;
+      const int row = rbase + (r & 3) + 8 * (r >> 2);
+      int o;
+      if (!g.Tc) o = row * (int)g.ldc;
+      else {
+        const int qd = mTc ? (int)__umulhi((unsigned)row, mTc) : (g.Tc == 1 ? row : row / g.Tc);
+        o = qd * (int)g.ldoc + (row - qd * g.Tc) * (int)g.ldc;
       }
+      cot[rr] = (row < g.M && col < g.N) ? (o + col) * 4 : G_OOB;
     }
+    if (g.beta != 0.f) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) oldt[rr] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(c_rs, cot[rr], 0, 0));
+    }
+  };
+  prep(0, co[0], old[0]);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    if (t + 1 < 8) prep(t + 1, co[(t + 1) & 1], old[(t + 1) & 1]);
+    const int i = t >> 2, j = (t >> 1) & 1, h = t & 1;
+    const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    const float bias_v = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      float v = alpha * acc[i][j][h * 8 + rr];
+      if (g.beta != 0.f) v += g.beta * old[t & 1][rr];
+      v += bias_v;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, co[t & 1][rr], 0, 0);
+    }
+  }
 }
 
 __global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
@@ -317,6 +330,11 @@ extern "C" int avsr_gemm(const avsr_gemm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(PROF_GEMM, s, 2.0 * g.M * g.N * g.K * g.batch);
   if ((long)d->A.ld * 4 >= (1L << 31) || (long)d->B.ld * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
+  {   // the epilogue addresses C with 32-bit byte offsets per batch entry
+    const long rows = g.M - 1;
+    const long last = (g.Tc ? (rows / g.Tc) * g.ldoc + (rows % g.Tc) * g.ldc : rows * g.ldc) + g.N;
+    if (last * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
+  }
 #define GEMM_GO(AK, BK_) \
   { if (va && vb) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, true, true>), grid, dim3(256), 0, s, g); \
     else if (va) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, true, false>), grid, dim3(256), 0, s, g); \
