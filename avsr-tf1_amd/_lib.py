@@ -121,7 +121,7 @@ _STRUCTS = {"avsr_dec_layer": DecLayer, "avsr_mat": Mat, "avsr_gemm_desc": GemmD
             "avsr_conv_desc": ConvDesc, "avsr_attn_mech": AttnMech, "avsr_attn_rnn": AttnRnn, "avsr_transpose_job": TransposeJob,
             "avsr_colsum_job": ColsumJob}
 
-EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_rnn_set_persistent", "avsr_rnn_set_persistent_mode", "avsr_rnn_set_persistent_scratch", "avsr_attn_rnn_fwd",
+EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_gemm_batch", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_rnn_set_persistent", "avsr_rnn_set_persistent_mode", "avsr_rnn_set_persistent_scratch", "avsr_attn_rnn_fwd",
            "avsr_attn_rnn_fused_ws_floats", "avsr_attn_rnn_fused_eligible", "avsr_attn_rnn_set_fused", "avsr_conv_set_mfma", "avsr_conv_supported", "avsr_conv_fwd", "avsr_conv_bwd_data", "avsr_conv_bwd_weight", "avsr_bn_finalize", "avsr_batchnorm_apply", "avsr_conv_bwd_data_bn", "avsr_conv_bwd_data_bn_supported", "avsr_bn_bwd_finalize", "avsr_bn_bwd_apply", "avsr_bn_eval_affine",
            "avsr_attn_rnn_bwd", "avsr_beam_gather_tree", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_colsum",
            "avsr_batchnorm_fwd", "avsr_batchnorm_fwd_ex", "avsr_batchnorm_bwd", "avsr_batchnorm_xhat", "avsr_im2col", "avsr_col2im",
@@ -159,6 +159,7 @@ def load():
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     sigs = {
         "avsr_gemm": [C.POINTER(GemmDesc), vp],
+        "avsr_gemm_batch": [C.POINTER(GemmDesc), i32, vp],
         "avsr_rnn_fwd": [C.POINTER(RnnStack), i32, vp],
         "avsr_rnn_bwd": [C.POINTER(RnnStack), i32, vp],
         "avsr_rnn_set_persistent": [vp, i64],

@@ -137,16 +137,15 @@ __device__ __forceinline__ void store_tile(float* T, const f32x4 (&r)[2]) {
 }
 
 template <bool AKC, bool BKC, bool VECA, bool VECB>
-__global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const int by, const int z) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][BK * BM];  // [buf][A|B][k][mn]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int z = blockIdx.z;
   const int bz = z / g.splitk, sz = z % g.splitk;
   MatView A = g.A, B = g.B;
   A.p += (long)bz * g.sA;
   B.p += (long)bz * g.sB;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   const int kbeg = sz * g.kper;
   const int kend = min(g.K, kbeg + g.kper);
 
@@ -271,9 +270,33 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-__global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
+template <bool AKC, bool BKC, bool VECA, bool VECB>
+__global__ __launch_bounds__(256, 3) void gemm_f32_kernel(GemmArgs g) {
+  gemm_body<AKC, BKC, VECA, VECB>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several INDEPENDENT GEMMs of one operand-layout class in one launch (avsr_gemm_batch): the small matmuls of a train step -- state
+// bridges, per-memory attention gradients, the row blocks of a cell kernel's gradient -- are a few workgroups each and cost a
+// dependent launch (and a split-K reduction launch) apiece when issued one by one; side by side they fill the chip together.
+// Workgroup b of the launch belongs to problem p with blk_off[p] <= b < blk_off[p + 1]; inside the problem the usual (x, y, z) grid.
+#define GEMM_GROUP_MAX 8
+struct GemmGroup { int n; int blk_off[GEMM_GROUP_MAX + 1]; int gx[GEMM_GROUP_MAX], gy[GEMM_GROUP_MAX]; int red_off[GEMM_GROUP_MAX + 1]; GemmArgs g[GEMM_GROUP_MAX]; };
+
+template <bool AKC, bool BKC, bool VECA, bool VECB>
+__global__ __launch_bounds__(256, 3) void gemm_f32_group_kernel(const GemmGroup G) {
+  int p = 0;
+#pragma unroll
+  for (int k = 1; k < GEMM_GROUP_MAX; ++k) if (k < G.n && (int)blockIdx.x >= G.blk_off[k]) p = k;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const int b = blockIdx.x - G.blk_off[p];
+  const int gx = G.gx[p], gy = G.gy[p];
+  const int bx = b % gx, by = (b / gx) % gy, z = b / (gx * gy);
+  gemm_body<AKC, BKC, VECA, VECB>(G.g[p], bx, by, z);
+}
+
+__device__ __forceinline__ void splitk_reduce_body(const GemmArgs& g, const long first, const long stride) {
   const long total = (long)g.batch * g.M * g.N;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = first; i < total; i += stride) {
     const int col = (int)(i % g.N);
     const int row = (int)((i / g.N) % g.M);
     const int bz = (int)(i / ((long)g.M * g.N));
@@ -295,6 +318,18 @@ __global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
     *c = v;
   }
 }
+__global__ void gemm_splitk_reduce_kernel(GemmArgs g) {
+  splitk_reduce_body(g, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+__global__ void gemm_splitk_reduce_group_kernel(const GemmGroup G) {
+  int p = 0;
+#pragma unroll
+  for (int k = 1; k < GEMM_GROUP_MAX; ++k) if (k < G.n && (int)blockIdx.x >= G.red_off[k]) p = k;
+  p = __builtin_amdgcn_readfirstlane(p);
+  if (G.g[p].splitk <= 1) return;
+  const int nb = G.red_off[p + 1] - G.red_off[p];
+  splitk_reduce_body(G.g[p], (long)(blockIdx.x - G.red_off[p]) * blockDim.x + threadIdx.x, (long)nb * blockDim.x);
+}
 
 static bool vec_ok(const avsr_mat* m, bool contig_is_k, int MN, int K) {
   const int contig = contig_is_k ? K : MN;
@@ -303,10 +338,10 @@ static bool vec_ok(const avsr_mat* m, bool contig_is_k, int MN, int K) {
 
 }  // namespace avsr
 
-extern "C" int avsr_gemm(const avsr_gemm_desc* d, void* stream) {
+// descriptor -> kernel arguments; *cls = operand-layout class (akc, bkc, vec a, vec b as bits 3..0); AVSR_OK or an error code
+static int gemm_prepare(const avsr_gemm_desc* d, avsr::GemmArgs& g, dim3* grid, int* cls) {
   using namespace avsr;
   if (!d || d->M <= 0 || d->N <= 0 || d->K < 0 || !d->A.ptr || !d->B.ptr || !d->C.ptr) return AVSR_ERR_ARG;
-  GemmArgs g;
   g.A = MatView{d->A.ptr, d->A.ld, d->A.T, d->A.ldo};
   g.B = MatView{d->B.ptr, d->B.ld, d->B.T, d->B.ldo};
   g.C = d->C.ptr; g.ldc = d->C.ld; g.Tc = d->C.T; g.ldoc = d->C.ldo;
@@ -326,28 +361,99 @@ extern "C" int avsr_gemm(const avsr_gemm_desc* d, void* stream) {
   g.splitk = splitk; g.kper = kper; g.ws = d->workspace;
   const bool va = vec_ok(&d->A, g.ta == 0, g.M, g.K);
   const bool vb = vec_ok(&d->B, g.tb != 0, g.N, g.K);
-  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * splitk);
-  hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(PROF_GEMM, s, 2.0 * g.M * g.N * g.K * g.batch);
+  *grid = dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * splitk);
   if ((long)d->A.ld * 4 >= (1L << 31) || (long)d->B.ld * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
   {   // the epilogue addresses C with 32-bit byte offsets per batch entry
     const long rows = g.M - 1;
     const long last = (g.Tc ? (rows / g.Tc) * g.ldoc + (rows % g.Tc) * g.ldc : rows * g.ldc) + g.N;
     if (last * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
   }
-#define GEMM_GO(AK, BK_) \
-  { if (va && vb) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, true, true>), grid, dim3(256), 0, s, g); \
-    else if (va) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, true, false>), grid, dim3(256), 0, s, g); \
-    else if (vb) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, false, true>), grid, dim3(256), 0, s, g); \
-    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, false, false>), grid, dim3(256), 0, s, g); }
-  const bool akc = g.ta == 0, bkc = g.tb != 0;
-  if (akc && bkc) GEMM_GO(true, true)
-  else if (akc) GEMM_GO(true, false)
-  else if (bkc) GEMM_GO(false, true)
-  else GEMM_GO(false, false)
-#undef GEMM_GO
+  *cls = ((g.ta == 0) ? 8 : 0) | ((g.tb != 0) ? 4 : 0) | (va ? 2 : 0) | (vb ? 1 : 0);
+  return AVSR_OK;
+}
+
+extern "C" int avsr_gemm_batch(const avsr_gemm_desc* descs, int32_t n, void* stream) {
+  using namespace avsr;
+  if (n <= 0) return AVSR_OK;
+  if (!descs) return AVSR_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  static thread_local GemmArgs ga[64];
+  dim3 grids[64];
+  int cls[64];
+  if (n > 64) return AVSR_ERR_ARG;
+  for (int i = 0; i < n; ++i) {
+    const int rc = gemm_prepare(&descs[i], ga[i], &grids[i], &cls[i]);
+    if (rc != AVSR_OK) return rc;
+  }
+  bool done[64] = {};
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
+    static thread_local GemmGroup G;
+    G.n = 0;
+    int blocks = 0, rblocks = 0;
+    double flops = 0.0;
+    bool any_split = false;
+    for (int j = i; j < n && G.n < GEMM_GROUP_MAX; ++j) {
+      if (done[j] || cls[j] != cls[i]) continue;
+      const int p = G.n++;
+      G.g[p] = ga[j];
+      G.gx[p] = grids[j].x; G.gy[p] = grids[j].y;
+      G.blk_off[p] = blocks; blocks += grids[j].x * grids[j].y * grids[j].z;
+      G.red_off[p] = rblocks;
+      if (ga[j].splitk > 1) {
+        long tot = ((long)ga[j].batch * ga[j].M * ga[j].N + 255) / 256;
+        rblocks += (int)(tot > 1024 ? 1024 : tot);
+        any_split = true;
+      } else rblocks += 1;
+      flops += 2.0 * ga[j].M * ga[j].N * ga[j].K * ga[j].batch;
+      done[j] = true;
+    }
+    G.blk_off[G.n] = blocks; G.red_off[G.n] = rblocks;
+    ProfScope ps(PROF_GEMM, s, flops);
+#define GG(AK, BK_, VA, VB) hipLaunchKernelGGL((gemm_f32_group_kernel<AK, BK_, VA, VB>), dim3(blocks), dim3(256), 0, s, G)
+    switch (cls[i]) {
+      case 15: GG(true, true, true, true); break;   case 14: GG(true, true, true, false); break;
+      case 13: GG(true, true, false, true); break;  case 12: GG(true, true, false, false); break;
+      case 11: GG(true, false, true, true); break;  case 10: GG(true, false, true, false); break;
+      case 9: GG(true, false, false, true); break;  case 8: GG(true, false, false, false); break;
+      case 7: GG(false, true, true, true); break;   case 6: GG(false, true, true, false); break;
+      case 5: GG(false, true, false, true); break;  case 4: GG(false, true, false, false); break;
+      case 3: GG(false, false, true, true); break;  case 2: GG(false, false, true, false); break;
+      case 1: GG(false, false, false, true); break; default: GG(false, false, false, false); break;
+    }
+#undef GG
+    AVSR_CHECK_LAUNCH();
+    if (any_split) {
+      hipLaunchKernelGGL(gemm_splitk_reduce_group_kernel, dim3(rblocks), dim3(256), 0, s, G);
+      AVSR_CHECK_LAUNCH();
+    }
+  }
+  return AVSR_OK;
+}
+
+extern "C" int avsr_gemm(const avsr_gemm_desc* d, void* stream) {
+  using namespace avsr;
+  GemmArgs g;
+  dim3 grid;
+  int cls = 0;
+  const int rc = gemm_prepare(d, g, &grid, &cls);
+  if (rc != AVSR_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(PROF_GEMM, s, 2.0 * g.M * g.N * g.K * g.batch);
+#define GO(AK, BK_, VA, VB) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, VA, VB>), grid, dim3(256), 0, s, g)
+  switch (cls) {
+    case 15: GO(true, true, true, true); break;   case 14: GO(true, true, true, false); break;
+    case 13: GO(true, true, false, true); break;  case 12: GO(true, true, false, false); break;
+    case 11: GO(true, false, true, true); break;  case 10: GO(true, false, true, false); break;
+    case 9: GO(true, false, false, true); break;  case 8: GO(true, false, false, false); break;
+    case 7: GO(false, true, true, true); break;   case 6: GO(false, true, true, false); break;
+    case 5: GO(false, true, false, true); break;  case 4: GO(false, true, false, false); break;
+    case 3: GO(false, false, true, true); break;  case 2: GO(false, false, true, false); break;
+    case 1: GO(false, false, false, true); break; default: GO(false, false, false, false); break;
+  }
+#undef GO
   AVSR_CHECK_LAUNCH();
-  if (splitk > 1) {
+  if (g.splitk > 1) {
     const long total = (long)g.batch * g.M * g.N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;

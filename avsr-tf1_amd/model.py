@@ -898,17 +898,18 @@ class Seq2SeqModel:
                         a_x = E["layers"][(d, l - 1)]["xt_seq"].mat(0)
                     else:
                         a_x = E["layers"][(d, l - 1)]["out"].mat(0, E["layers"][(d, l - 1)]["col"])
-                    self._gemm_tn(a_x, dg, Gk.mat(G * u), i, G * u, B * T)
-                    sh = 1 if d == "bw" else -1
-                    a_h = Ld["hs_seq"].mat(sh) if (drop or (cfg.residual(s) and l > 0)) else Ld["out"].mat(sh, Ld["col"])
-                    self._gemm_tn(a_h, dg, Gk.mat(G * u, row0=i), u, G * u, B * T)
-                    ops.colsum(dg, B * T, G * u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
-                    if self.gru:                 # candidate kernel: inputs [x ; r*h]
-                        Gc = self.Gr[f"{s}/enc/{d}/l{cfg.shared_layer(s, l)}/cand_kernel"]
-                        dpc = ops.mat(Ld["dpc"], u)
-                        self._gemm_tn(a_x, dpc, Gc.mat(u), i, u, B * T)
-                        self._gemm_tn(ops.mat(Ld["rh"], u), dpc, Gc.mat(u, row0=i), u, u, B * T)
-                        ops.colsum(dpc, B * T, u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/enc/{d}/l{cfg.shared_layer(s, l)}/cand_bias"].off)
+                    with ops.gemm_group():       # the row blocks of one layer's kernel gradient(s): independent, one launch
+                        self._gemm_tn(a_x, dg, Gk.mat(G * u), i, G * u, B * T)
+                        sh = 1 if d == "bw" else -1
+                        a_h = Ld["hs_seq"].mat(sh) if (drop or (cfg.residual(s) and l > 0)) else Ld["out"].mat(sh, Ld["col"])
+                        self._gemm_tn(a_h, dg, Gk.mat(G * u, row0=i), u, G * u, B * T)
+                        ops.colsum(dg, B * T, G * u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
+                        if self.gru:                 # candidate kernel: inputs [x ; r*h]
+                            Gc = self.Gr[f"{s}/enc/{d}/l{cfg.shared_layer(s, l)}/cand_kernel"]
+                            dpc = ops.mat(Ld["dpc"], u)
+                            self._gemm_tn(a_x, dpc, Gc.mat(u), i, u, B * T)
+                            self._gemm_tn(ops.mat(Ld["rh"], u), dpc, Gc.mat(u, row0=i), u, u, B * T)
+                            ops.colsum(dpc, B * T, u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/enc/{d}/l{cfg.shared_layer(s, l)}/cand_bias"].off)
                     i = u
                 if E["nplain"] > 0 and (cfg.batch_normalisation or "cnn" in E or self.n_dense or cfg.instance_normalisation):
                     u0, G = E["units"][0], self.G
@@ -1060,17 +1061,18 @@ class Seq2SeqModel:
     def _block_prepare(self, ws, blk):
         """Per-batch attention memory preparation: keys = values . W_mem (attention.py memory_layer)."""
         B, H = blk.get("mem_B", blk["B"]), blk["H"]
-        for m in blk["mems"]:
-            md = self._mem_desc(ws, m["stream"])
-            pre = m["prefix"]
-            ops.gemm(md["vmat"], self.P[pre + "/memory_kernel"].mat(H), ops.mat(m["keys"], H), B * m["T"], H, m["D"])
-            if m["proj"]:
-                Wl = self.P[pre + "/layer_kernel"]
-                ops.gemm(md["vmat"], Wl.mat(H, row0=H), ops.mat(m["pvals"], H), B * m["T"], H, m["D"])          # pvals = values . W_ctx
-                ops.copy_(m["watt_p"].view(-1)[:H * H], Wl.t[Wl.off:Wl.off + H * H])                              # [W_h ; I]
-                ops.gemm(Wl.mat(H), ops.mat(m["eye"], H), ops.mat(m["watt_p_t"], 2 * H), H, H, H, trans_a=1)      # [W_h^T | I]
-            if m["type"] == "normed_bahdanau":
-                ops.normed_v(self._pp(pre + "/v"), self._pp(pre + "/g"), m["vn"], H)
+        with ops.gemm_group():                   # the memories' GEMMs are independent of each other: one launch
+            for m in blk["mems"]:
+                md = self._mem_desc(ws, m["stream"])
+                pre = m["prefix"]
+                ops.gemm(md["vmat"], self.P[pre + "/memory_kernel"].mat(H), ops.mat(m["keys"], H), B * m["T"], H, m["D"])
+                if m["proj"]:
+                    Wl = self.P[pre + "/layer_kernel"]
+                    ops.gemm(md["vmat"], Wl.mat(H, row0=H), ops.mat(m["pvals"], H), B * m["T"], H, m["D"])          # pvals = values . W_ctx
+                    ops.copy_(m["watt_p"].view(-1)[:H * H], Wl.t[Wl.off:Wl.off + H * H])                              # [W_h ; I]
+                    ops.gemm(Wl.mat(H), ops.mat(m["eye"], H), ops.mat(m["watt_p_t"], 2 * H), H, H, H, trans_a=1)      # [W_h^T | I]
+                if m["type"] == "normed_bahdanau":
+                    ops.normed_v(self._pp(pre + "/v"), self._pp(pre + "/g"), m["vn"], H)
 
     def _block_backward(self, ws, blk, desc, xin_mat, dxin_mat, dxin_beta, out_att):
         """attention-RNN BPTT + every deferred (post-loop) gradient GEMM of the block.
@@ -1081,51 +1083,77 @@ class Seq2SeqModel:
         ops.attn_rnn_bwd(desc)
         rows = B * L
         co = blk["cell_out"]
-        for i, m in enumerate(blk["mems"]):
-            pre, T, D = m["prefix"], m["T"], m["D"]
+        mems = list(enumerate(blk["mems"]))
+        # The per-memory gradient GEMMs are small (a few workgroups each) and independent across memories: they are issued in phases,
+        # every phase ONE grouped launch (ops.gemm_group): attention-layer kernels | alignments (kernels) | d values, d keys |
+        # memory-layer gradients.  Two GEMMs that accumulate into the same matrix never share a phase.
+        with ops.gemm_group():
+            for i, m in mems:
+                pre, D = m["prefix"], m["D"]
+                datt_m = ops.mat(blk["datt"], A, offset=i * H)
+                Gl = self.Gr[pre + "/layer_kernel"]
+                self._gemm_tn(co.mat(0), datt_m, Gl.mat(H), H, H, rows)                 # rows 0..H: cell_out part
+                if not m["proj"]:
+                    self._gemm_tn(ops.mat(m["ctx"], D), datt_m, Gl.mat(H, row0=H), D, H, rows)   # rows H..H+D: context part
+        for i, m in mems:
+            pre, T = m["prefix"], m["T"]
             md = self._mem_desc(ws, m["stream"])
-            datt_m = ops.mat(blk["datt"], A, offset=i * H)
-            Gl = self.Gr[pre + "/layer_kernel"]
-            self._gemm_tn(co.mat(0), datt_m, Gl.mat(H), H, H, rows)                 # rows 0..H: cell_out part
-            if not m["proj"]:
-                self._gemm_tn(ops.mat(m["ctx"], D), datt_m, Gl.mat(H, row0=H), D, H, rows)   # rows H..H+D: context part
             luong = m["type"] in LUONG_TYPES
             g_t = self._pp(pre + "/g") if m["type"] == "scaled_luong" else None
             # scores -> alpha (in place); rowdot = sum_t ds * raw  (d g for scaled_luong)
             ops.attn_alpha_rows(m["scores"], m["dscores"], md["len"], desc_steplen(desc), g_t if luong else None, m["rowdot"], B, L, T)
             if m["type"] == "scaled_luong":
                 ops.reduce_scalar(m["rowdot"], rows, self.grads, accumulate=True, out_offset=self.Gr[pre + "/g"].off)
-            if m["proj"]:
-                # d pvals[b,t,:] = sum_l alpha[b,l,t] * dctx'[b,l,:];  d W_ctx = values^T . d pvals;  d values += d pvals . W_ctx^T
-                Wl = self.P[pre + "/layer_kernel"]
-                ops.gemm(ops.mat(m["scores"], T), ops.mat(m["dctx"], H), ops.mat(m["dpvals"], H), T, H, L,
-                         trans_a=1, batch=B, strides=(L * T, L * H, T * H))
-                self._gemm_tn(md["vmat"], ops.mat(m["dpvals"], H), Gl.mat(H, row0=H), D, H, B * T)
-                ops.gemm(ops.mat(m["dpvals"], H), Wl.mat(H, row0=H), md["gmat"], B * T, D, H, trans_b=1, beta=1.0)
-            else:
-                # d values[b,t,:] += sum_l alpha[b,l,t] * dctx[b,l,:]        (batched over b)
-                ops.gemm(ops.mat(m["scores"], T), ops.mat(m["dctx"], D), ops.mat(md["gt"], md["st"], offset=md["goff"]), T, D, L,
-                         trans_a=1, beta=1.0, batch=B, strides=(L * T, L * D, md["gsb"]))
-            if luong:
-                # d keys[b,t,:] = g * sum_l ds[b,l,t] * cell_out[b,l,:]
-                ops.gemm(ops.mat(m["dscores"], T), ops.mat(co.t, H, offset=co.off(0)), ops.mat(m["dkeys"], H), T, H, L,
-                         trans_a=1, batch=B, strides=(L * T, co.sb, T * H), alpha_dev=g_t)
-            else:
-                v_t = m["vn"] if m["type"] == "normed_bahdanau" else self._pp(pre + "/v")
-                bq = self._pp(pre + "/b") if m["type"] == "normed_bahdanau" else None
-                ops.bahdanau_dkeys(m["keys"], m["pq"], L * H, H, m["dscores"], v_t, bq, md["len"], m["dkeys"], m["dv_part"], B, L, T, H)
-                nblk = m["dv_part"].shape[0]
-                if m["type"] == "normed_bahdanau":
-                    ops.colsum(ops.mat(m["dv_part"], H), nblk, H, m["dvn"], self.scratch)
-                    ops.normed_v_bwd(self._pp(pre + "/v"), self._pp(pre + "/g"), m["dvn"], self._gp(pre + "/v"), self._gp(pre + "/g"), H)
-                    ops.colsum(ops.mat(m["dpq"], H), rows, H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[pre + "/b"].off)
+        with ops.gemm_group():
+            for i, m in mems:
+                pre, T, D = m["prefix"], m["T"], m["D"]
+                md = self._mem_desc(ws, m["stream"])
+                if m["proj"]:
+                    # d pvals[b,t,:] = sum_l alpha[b,l,t] * dctx'[b,l,:]
+                    ops.gemm(ops.mat(m["scores"], T), ops.mat(m["dctx"], H), ops.mat(m["dpvals"], H), T, H, L,
+                             trans_a=1, batch=B, strides=(L * T, L * H, T * H))
                 else:
-                    ops.colsum(ops.mat(m["dv_part"], H), nblk, H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[pre + "/v"].off)
-                self._gemm_tn(co.mat(0), ops.mat(m["dpq"], H), self.Gr[pre + "/query_kernel"].mat(H), H, H, rows)
-            # memory_layer: d values += d keys . W_mem^T ; d W_mem = values^T . d keys
-            Wm, Gm = self.P[pre + "/memory_kernel"], self.Gr[pre + "/memory_kernel"]
-            ops.gemm(ops.mat(m["dkeys"], H), Wm.mat(H), md["gmat"], B * T, D, H, trans_b=1, beta=1.0)
-            self._gemm_tn(md["vmat"], ops.mat(m["dkeys"], H), Gm.mat(H), D, H, B * T)
+                    # d values[b,t,:] += sum_l alpha[b,l,t] * dctx[b,l,:]        (batched over b)
+                    ops.gemm(ops.mat(m["scores"], T), ops.mat(m["dctx"], D), ops.mat(md["gt"], md["st"], offset=md["goff"]), T, D, L,
+                             trans_a=1, beta=1.0, batch=B, strides=(L * T, L * D, md["gsb"]))
+                if m["type"] in LUONG_TYPES:
+                    # d keys[b,t,:] = g * sum_l ds[b,l,t] * cell_out[b,l,:]
+                    g_t = self._pp(pre + "/g") if m["type"] == "scaled_luong" else None
+                    ops.gemm(ops.mat(m["dscores"], T), ops.mat(co.t, H, offset=co.off(0)), ops.mat(m["dkeys"], H), T, H, L,
+                             trans_a=1, batch=B, strides=(L * T, co.sb, T * H), alpha_dev=g_t)
+        for i, m in mems:
+            if m["type"] in LUONG_TYPES:
+                continue
+            pre, T = m["prefix"], m["T"]
+            md = self._mem_desc(ws, m["stream"])
+            v_t = m["vn"] if m["type"] == "normed_bahdanau" else self._pp(pre + "/v")
+            bq = self._pp(pre + "/b") if m["type"] == "normed_bahdanau" else None
+            ops.bahdanau_dkeys(m["keys"], m["pq"], L * H, H, m["dscores"], v_t, bq, md["len"], m["dkeys"], m["dv_part"], B, L, T, H)
+            nblk = m["dv_part"].shape[0]
+            if m["type"] == "normed_bahdanau":
+                ops.colsum(ops.mat(m["dv_part"], H), nblk, H, m["dvn"], self.scratch)
+                ops.normed_v_bwd(self._pp(pre + "/v"), self._pp(pre + "/g"), m["dvn"], self._gp(pre + "/v"), self._gp(pre + "/g"), H)
+                ops.colsum(ops.mat(m["dpq"], H), rows, H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[pre + "/b"].off)
+            else:
+                ops.colsum(ops.mat(m["dv_part"], H), nblk, H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[pre + "/v"].off)
+        with ops.gemm_group():
+            for i, m in mems:
+                pre, D = m["prefix"], m["D"]
+                md = self._mem_desc(ws, m["stream"])
+                if m["proj"]:
+                    # d W_ctx = values^T . d pvals;  d values += d pvals . W_ctx^T
+                    Wl, Gl = self.P[pre + "/layer_kernel"], self.Gr[pre + "/layer_kernel"]
+                    self._gemm_tn(md["vmat"], ops.mat(m["dpvals"], H), Gl.mat(H, row0=H), D, H, B * m["T"])
+                    ops.gemm(ops.mat(m["dpvals"], H), Wl.mat(H, row0=H), md["gmat"], B * m["T"], D, H, trans_b=1, beta=1.0)
+                if m["type"] not in LUONG_TYPES:
+                    self._gemm_tn(co.mat(0), ops.mat(m["dpq"], H), self.Gr[pre + "/query_kernel"].mat(H), H, H, rows)
+                # memory_layer: d W_mem = values^T . d keys
+                self._gemm_tn(md["vmat"], ops.mat(m["dkeys"], H), self.Gr[pre + "/memory_kernel"].mat(H), D, H, B * m["T"])
+        with ops.gemm_group():
+            for i, m in mems:                     # memory_layer: d values += d keys . W_mem^T (after the projected-context term above)
+                pre, D = m["prefix"], m["D"]
+                md = self._mem_desc(ws, m["stream"])
+                ops.gemm(ops.mat(m["dkeys"], H), self.P[pre + "/memory_kernel"].mat(H), md["gmat"], B * m["T"], D, H, trans_b=1, beta=1.0)
         # cell kernel: rows [0:E] inputs, [E:E+A] previous attention, [E+A:] previous h
         kname, bname = self._kn(blk["cell"])
         Gk, G = self.Gr[kname], self.G
@@ -1142,12 +1170,15 @@ class Seq2SeqModel:
             self._gemm_tn((X["hs_seq"] if drop else X["out"]).mat(-1), dgx, self.Gr[kx].mat(4 * H, row0=H), H, 4 * H, rows)
             ops.colsum(dgx, rows, 4 * H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bx].off)
             below = X["out"]
-        self._gemm_tn(xin_mat, dg, Gk.mat(G * H), E, G * H, rows)
-        if A:
-            self._gemm_tn(a_att, dg, Gk.mat(G * H, row0=E), A, G * H, rows)
-        self._gemm_tn(a_h, dg, Gk.mat(G * H, row0=E + A), H, G * H, rows)
-        ops.colsum(dg, rows, G * H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
-        if dxin_mat is not None:
+        with ops.gemm_group():                   # the row blocks of the cell kernel's gradient and d inputs: independent
+            self._gemm_tn(xin_mat, dg, Gk.mat(G * H), E, G * H, rows)
+            if A:
+                self._gemm_tn(a_att, dg, Gk.mat(G * H, row0=E), A, G * H, rows)
+            self._gemm_tn(a_h, dg, Gk.mat(G * H, row0=E + A), H, G * H, rows)
+            ops.colsum(dg, rows, G * H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
+            if dxin_mat is not None and not self.gru:
+                ops.gemm(dg, self.P[kname].mat(G * H), dxin_mat, rows, E, G * H, trans_b=1, beta=dxin_beta)
+        if dxin_mat is not None and self.gru:
             ops.gemm(dg, self.P[kname].mat(G * H), dxin_mat, rows, E, G * H, trans_b=1, beta=dxin_beta)
         if self.gru:                             # candidate kernel: inputs [x ; attention ; r*h]
             cn = blk["cell"] + "/cand_kernel"
@@ -1230,13 +1261,14 @@ class Seq2SeqModel:
         if "c0buf" not in D:
             D["c0buf"], D["h0buf"] = torch.zeros(B, H, device=self.dev), torch.zeros(B, H, device=self.dev)
         SP = self.P["dec/state_proj"]
-        for key, dst in (("c_fin", "c0buf"), ("h_fin", "h0buf")):
-            first = True
-            for si, s in enumerate(("video", "audio")):
-                if s not in ws["enc"]:
-                    continue
-                ops.gemm(ops.mat(ws["enc"][s][key], H), SP.mat(H, row0=si * H), ops.mat(D[dst], H), B, H, H, beta=0.0 if first else 1.0)
-                first = False
+        first = True
+        for si, s in enumerate(("video", "audio")):           # per stream ONE launch for (c, h); the second stream accumulates
+            if s not in ws["enc"]:
+                continue
+            with ops.gemm_group():
+                for key, dst in (("c_fin", "c0buf"), ("h_fin", "h0buf")):
+                    ops.gemm(ops.mat(ws["enc"][s][key], H), SP.mat(H, row0=si * H), ops.mat(D[dst], H), B, H, H, beta=0.0 if first else 1.0)
+            first = False
         D["h0"], D["c0"] = D["h0buf"], D["c0buf"]
 
     def _decoder_init_state_bwd(self, ws):
@@ -1250,13 +1282,18 @@ class Seq2SeqModel:
             self._final_state_bwd(ws, s, D["dc0"], D["dh0"])
             return
         SP, GSP = self.P["dec/state_proj"], self.Gr["dec/state_proj"]
-        for si, s in enumerate(("video", "audio")):
-            if s not in ws["enc"]:
-                continue
+        present = [(si, s) for si, s in enumerate(("video", "audio")) if s in ws["enc"]]
+        with ops.gemm_group():                    # d (c, h) of every stream: independent
+            for si, s in present:
+                E = ws["enc"][s]
+                for key, g, dst in (("c_fin", D["dc0"], "dc_dec"), ("h_fin", D["dh0"], "dh_dec")):
+                    ops.gemm(ops.mat(g, H), SP.mat(H, row0=si * H), ops.mat(E[dst], H), B, H, H, trans_b=1)
+        for key, g in (("c_fin", D["dc0"]), ("h_fin", D["dh0"])):      # the c and the h term of a stream accumulate into the same rows
+            with ops.gemm_group():
+                for si, s in present:
+                    ops.gemm(ops.mat(ws["enc"][s][key], H), ops.mat(g, H), GSP.mat(H, row0=si * H), H, H, B, trans_a=1, beta=1.0)
+        for si, s in present:
             E = ws["enc"][s]
-            for key, g, dst in (("c_fin", D["dc0"], "dc_dec"), ("h_fin", D["dh0"], "dh_dec")):
-                ops.gemm(ops.mat(g, H), SP.mat(H, row0=si * H), ops.mat(E[dst], H), B, H, H, trans_b=1)
-                ops.gemm(ops.mat(E[key], H), ops.mat(g, H), GSP.mat(H, row0=si * H), H, H, B, trans_a=1, beta=1.0)
             self._final_state_bwd(ws, s, E["dc_dec"], E["dh_dec"])
 
     def _out_vec(self, D):
@@ -1366,11 +1403,12 @@ class Seq2SeqModel:
         # output layer
         ov, O = self._out_vec(D)
         dl = ops.mat(D["dlogits"], V)
-        self._gemm_tn(ov, dl, self.Gr["dec/out/kernel"].mat(V), O, V, B * L)
-        ops.colsum(dl, B * L, V, self.grads, self.scratch, beta=1.0, out_offset=self.Gr["dec/out/bias"].off)
         oa = cfg.output_attention()
         dext = D["datt_ext"] if oa else D["dcell_ext"]
-        ops.gemm(dl, self.P["dec/out/kernel"].mat(V), ops.mat(dext, O), B * L, O, V, trans_b=1)
+        with ops.gemm_group():
+            self._gemm_tn(ov, dl, self.Gr["dec/out/kernel"].mat(V), O, V, B * L)
+            ops.colsum(dl, B * L, V, self.grads, self.scratch, beta=1.0, out_offset=self.Gr["dec/out/bias"].off)
+            ops.gemm(dl, self.P["dec/out/kernel"].mat(V), ops.mat(dext, O), B * L, O, V, trans_b=1)
         d = D["desc"]
         d.datt_ext = ops.fptr(dext) if oa else None
         d.dcell_ext = None if oa else ops.fptr(dext)

@@ -54,6 +54,38 @@ def auto_splitk(M, N, K, batch=1):
     return sk if sk >= 2 else 1
 
 
+_gemm_group = None        # [descs], workspace cursor while a `with gemm_group():` block collects independent GEMMs
+
+
+class gemm_group:
+    """`with ops.gemm_group():` -- the GEMMs issued inside are INDEPENDENT of each other (no output is an operand or the output of
+    another): they are collected and launched side by side by avsr_gemm_batch on exit (one launch per operand-layout class + one
+    split-K reduction launch).  Split-K slabs of the collected GEMMs take consecutive regions of the shared workspace.  Nested
+    blocks join the outer one.  AVSR_GEMM_GROUP=0 turns the collection off (every GEMM is launched where it is issued)."""
+
+    def __enter__(self):
+        global _gemm_group
+        self.outer = _gemm_group is not None
+        if not self.outer and _GROUP_ON:
+            _gemm_group = {"descs": [], "cursor": 0, "keep": []}
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _gemm_group
+        if self.outer or _gemm_group is None:
+            return False
+        grp, _gemm_group = _gemm_group, None
+        if et is None and grp["descs"]:
+            n = len(grp["descs"])
+            arr = (GemmDesc * n)(*grp["descs"])
+            check(_L().avsr_gemm_batch(arr, n, _s()), "avsr_gemm_batch")
+        return False
+
+
+import os as _os
+_GROUP_ON = _os.environ.get("AVSR_GEMM_GROUP", "1") != "0"
+
+
 def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None,
          batch=1, strides=(0, 0, 0), splitk=None, workspace=None, alpha_dev=None):
     """C = alpha*op(A)*op(B) + beta*C + bias.  A, B, Cm are `Mat` views (see `mat`).
@@ -73,12 +105,37 @@ def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, b
         while splitk > 1 and batch * splitk * M * N > workspace.numel():
             splitk //= 2
     d.splitk = int(splitk)
+    grp = _gemm_group
     if splitk > 1:
         need = batch * splitk * M * N
         assert workspace is not None and workspace.numel() >= need, "split-K workspace too small"
-        d.workspace = fptr(workspace)
-        d.workspace_floats = workspace.numel()
+        if grp is not None:
+            # concurrent entries need disjoint slabs: carve consecutive regions; when the workspace is used up the collected
+            # GEMMs are launched and the collection restarts
+            if grp["cursor"] + need > workspace.numel() or (grp["descs"] and grp.get("ws_ptr") not in (None, workspace.data_ptr())):
+                _flush_group(grp)
+            grp["ws_ptr"] = workspace.data_ptr()
+            d.workspace = fptr(workspace, grp["cursor"])
+            d.workspace_floats = workspace.numel() - grp["cursor"]
+            grp["cursor"] += (need + 3) // 4 * 4
+        else:
+            d.workspace = fptr(workspace)
+            d.workspace_floats = workspace.numel()
+    if grp is not None:
+        if len(grp["descs"]) >= 48:
+            _flush_group(grp)
+        grp["descs"].append(d)
+        grp["keep"] += [A, B, Cm]
+        return
     check(_L().avsr_gemm(C.byref(d), _s()), "avsr_gemm")
+
+
+def _flush_group(grp):
+    if grp["descs"]:
+        n = len(grp["descs"])
+        arr = (GemmDesc * n)(*grp["descs"])
+        check(_L().avsr_gemm_batch(arr, n, _s()), "avsr_gemm_batch")
+    grp["descs"], grp["cursor"], grp["keep"] = [], 0, []
 
 
 def rnn_fwd(stacks):

@@ -72,6 +72,11 @@ typedef struct avsr_gemm_desc {
 } avsr_gemm_desc;
 
 int avsr_gemm(const avsr_gemm_desc* d, void* stream);
+/* n INDEPENDENT GEMMs (no output of one is an operand or the output of another; split-K workspaces disjoint) issued side by side:
+ * entries of one operand-layout class share a launch (and one split-K reduction launch) -- the many few-workgroup matmuls of a train
+ * step (state bridges decoder_bimodal.py:480-490, per-memory attention gradients, the row blocks of a cell kernel's gradient,
+ * seq2seq.py:222) cost one dependent launch each when issued one by one.  Same per-entry semantics as avsr_gemm; n <= 64. */
+int avsr_gemm_batch(const avsr_gemm_desc* descs, int32_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-layer masked RNN over a sequence.  Replaces tf.nn.dynamic_rnn(MultiRNNCell(LSTMCell...),
