@@ -406,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
 struct WGArgs {
   const float* x; const float* dy; float* part;
   int N, H, W, Ci, CiL, Ho, Wo, Co, S, pt, pl, F;
+  int SW;                                 // source step along W per output column (0 = S): 2 for the pixel-pair form, see conv_bwd_weight_impl
   unsigned m_opf, m_wo, m_rq, m_per, m_w;
   int t0, nt, kw;                         // taps t0 .. t0+nt-1 of a kw x kw kernel: rows (t - t0, ci) of this launch's slab
   int slab, want_bias;                    // floats per workgroup partial: nt*Ci*Co (+ Co column sums of dy = the bias gradient)
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
       const float* xf = xs + f * xstride + (PW + 1) * CsP;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float* xb = xf + (ho * A.S * PW + wo * A.S) * CsP;
+        const float* xb = xf + (ho * A.S * PW + wo * (A.SW ? A.SW : A.S)) * CsP;
         // positions beyond the frame read a clamped (finite) LDS address: their dy operand is zero (out-of-range buffer load), so the
         // product vanishes without a select per operand
 #pragma unroll
@@ -1037,9 +1038,93 @@ static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const fl
   return AVSR_OK;
 }
 
+// final reduction of the pixel-pair weight gradient (below): part [nblk][12*Ci*16 (+16)] with rows (ti, tj', ci), columns (pp, co):
+// dw[ti][tj][ci][co] = sum_blk part[(ti*4 + tj)*Ci + ci][co] + part[(ti*4 + tj + 1)*Ci + ci][8 + co];  dbias[co] = sum_blk bias[co] + bias[8 + co]
+__global__ __launch_bounds__(256) void wgrad_pair_final_kernel(const float* __restrict__ part, int nblk, int slab, int Ci, float* __restrict__ dw,
+                                                              float* __restrict__ dbias, float beta) {
+  __shared__ double red[8][33];
+  const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int nw = 9 * Ci * 8, f = blockIdx.x * 32 + fl;              // outputs: 9*Ci*8 kernel entries, then 8 bias entries
+  int o0 = -1, o1 = -1;
+  if (f < nw) {
+    const int co = f & 7, ci = (f >> 3) % Ci, t = (f >> 3) / Ci, ti = t / 3, tj = t - ti * 3;
+    o0 = ((ti * 4 + tj) * Ci + ci) * 16 + co;
+    o1 = ((ti * 4 + tj + 1) * Ci + ci) * 16 + 8 + co;
+  } else if (f < nw + 8 && dbias) {
+    o0 = 12 * Ci * 16 + (f - nw);
+    o1 = o0 + 8;
+  }
+  double s = 0.0;
+  if (o0 >= 0)
+    for (int i = g; i < nblk; i += 8) s += (double)part[(long)i * slab + o0] + (double)part[(long)i * slab + o1];
+  red[g][fl] = s;
+  __syncthreads();
+  if (g == 0 && o0 >= 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][fl];
+    float* const o = f < nw ? dw + f : dbias + (f - nw);
+    *o = beta != 0.f ? (float)t + beta * *o : (float)t;
+  }
+}
+
 static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const float* dy, float* dw, float* dbias, float beta, float* scratch,
                                 long scratch_floats, void* stream, bool dry) {
   const int Ci = c->Ci, Co = c->Co, H = c->H, W = c->W, Ho = c->Ho, Wo = c->Wo, N = c->N, k = c->k;
+  // Pixel-pair form for 8 destination channels (the 36x36 layers, the most expensive weight gradients): with 8 columns half of
+  // every 16-column MFMA tile multiplies padding.  dy is read as [N, Ho, Wo/2, 16] (the same bytes): a column is (pixel parity pp,
+  // channel), the depth index a PAIR of horizontally adjacent output pixels; the rows run over the union of the two pixels' windows
+  // (3 x 4 taps, source step 2 along W): C[(ti, tj', ci)][(pp, co)] is the gradient of tap (ti, tj' - pp) where that is a tap at all.
+  // 6 row tiles per pair instead of 2 x 5 per two positions; the reduction kernel above adds the two parities' valid entries.
+  if (Co == 8 && c->stride == 1 && k == 3 && (Wo & 1) == 0 && Wo == W && Ho == H && !getenv("AVSR_WGRAD_NOPAIR")) {
+    WGArgs A = {};
+    A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo / 2; A.Co = 16;
+    A.S = 1; A.SW = 2; A.pt = c->pad_t; A.pl = c->pad_l; A.kw = 4; A.bn_sc = c->bn_scale; A.bn_sh = c->bn_shift;
+    A.t0 = 0; A.nt = 12; A.want_bias = dbias ? 1 : 0;
+    A.slab = 12 * Ci * 16 + (A.want_bias ? 16 : 0);
+    const int MT = (12 * A.CiL + 15) / 16;
+    bool ok = (Ci % 4 == 0) ? MT <= 6 : (MT <= 3 && !c->bn_scale);
+    A.F = cg_frames(H, W, A.CiL + WG_PAD, Ho * A.Wo);
+    A.m_opf = fmagic(Ho * A.Wo); A.m_wo = fmagic(A.Wo); A.m_w = fmagic(W);
+    if (Ci % 4 == 0) {
+      const int rq = W * Ci / 4;
+      ok = ok && rq <= 256 && rq >= 1;
+      if (ok) {
+        const int rpp = 256 / rq;
+        while (A.F > 1 && A.F * ((H + rpp - 1) / rpp) > 12) --A.F;
+        ok = A.F * ((H + rpp - 1) / rpp) <= 12;
+        A.m_rq = fmagic(rq); A.m_per = fmagic(H * rq);
+      }
+    } else {
+      while (A.F > 1 && (A.F * H * W * Ci / 4 + 255) / 256 > 4) --A.F;
+      ok = ok && (A.F * H * W * Ci / 4 + 255) / 256 <= 4 && (long)A.F * H * W * Ci < 65536;
+      A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci);
+    }
+    size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + WG_PAD);
+    if (lds < sizeof(float) * 4 * 256) lds = sizeof(float) * 4 * 256;
+    ok = ok && lds <= 64 * 1024 && (long)A.F * ((Ho * A.Wo + 15) / 16) < 65536 && (long)N * Ho * Wo * Co * 4 < (1L << 31);
+    if (ok) {
+      int wpc = (int)((150 * 1024) / (lds + 512));
+      if (wpc > 2) wpc = 2;
+      if (wpc < 1) wpc = 1;
+      int grid = (N + A.F - 1) / A.F;
+      if (grid > 256 * wpc) grid = 256 * wpc;
+      if ((long)grid * A.slab > scratch_floats) grid = (int)(scratch_floats / A.slab);
+      if (grid < 1) return AVSR_ERR_ARG;
+      if (dry) return AVSR_OK;
+      hipStream_t s = S_(stream);
+      {
+        ProfScope ps(PROF_CONV_BWD_WEIGHT, s, 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
+        if (Ci % 4) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, false>), dim3(grid), dim3(256), lds, s, A);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<6, 1, true>), dim3(grid), dim3(256), lds, s, A);
+        if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+      }
+      const int nout = 9 * Ci * 8 + 8;
+      hipLaunchKernelGGL(wgrad_pair_final_kernel, dim3((nout + 31) / 32), dim3(256), 0, s, scratch, grid, A.slab, Ci, dw, dbias, beta);
+      if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+      return AVSR_OK;
+    }
+  }
   WGArgs A = {};
   A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo; A.Co = Co;
   A.S = c->stride; A.pt = c->pad_t; A.pl = c->pad_l; A.kw = k; A.bn_sc = c->bn_scale; A.bn_sh = c->bn_shift;
