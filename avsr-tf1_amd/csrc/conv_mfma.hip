@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   // ---- software pipeline over passes: the NEXT pass's frames travel memory -> registers while the current pass runs on the matrix
   // pipe; registers -> LDS between two barriers.  A thread's pieces of a pass: (frame f, row st_row + k*st_rpp, column st_p4) for
   // 4-channel-multiple sources; 16-byte runs of the contiguous frames (element-wise scatter on store) for the 3-channel crops.
-  constexpr int PF = CH4 ? (MAXCH > 9 ? 9 : 12) : 4;                // (the 18-chunk instantiation has 72 registers of weights: 9 pieces)
+  constexpr int PF = CH4 ? (MAXCH > 9 ? 10 : 12) : 4;               // (the 18-chunk instantiation has 72 registers of weights: 10 pieces)
   f32x4 pre[PF];
   constexpr bool c4 = CH4;
   const int ppf = c4 ? (A.SH + st_rpp - 1) / st_rpp : 0;            // pieces per frame per thread (row-structured)
@@ -617,7 +617,7 @@ extern "C" int avsr_conv_set_mfma(int32_t on) { g_conv_mfma = on ? 1 : 0; return
 
 static int cg_frames(int sh, int sw, int csl, int opf, int extra_floats_per_frame = 0) {
   const long per = (long)(sh + 2) * (sw + 2) * csl + extra_floats_per_frame;
-  int F = (int)((60 * 1024 / 4) / per);                 // <= 60 KB of frames: two workgroups per CU
+  int F = (int)((63 * 1024 / 4) / per);                 // <= 63 KB of frames (+ tables <= 64 KB): two workgroups per CU
   if (F < 1) F = 1;
   int want = (1024 + opf - 1) / opf;                    // enough positions per pass to keep the four waves in row tiles
   if (want < 1) want = 1;
@@ -638,7 +638,7 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
   if (A.Cs % 4 == 0) {
     const int rq = A.SW * A.Cs / 4;
     if (rq > 256 || rq < 1) return AVSR_ERR_UNSUPPORTED;
-    const int rpp = 256 / rq, pfmax = nch > 9 ? 9 : 12;     // prefetch registers of the instantiation that takes this depth
+    const int rpp = 256 / rq, pfmax = nch > 9 ? 10 : 12;    // prefetch registers of the instantiation that takes this depth
     while (A.F > 1 && A.F * ((A.SH + rpp - 1) / rpp) > pfmax) --A.F;
     if (A.F * ((A.SH + rpp - 1) / rpp) > pfmax) return AVSR_ERR_UNSUPPORTED;
     A.m_rq = fmagic(rq); A.m_per = fmagic(A.SH * rq); A.m_sw = fmagic(A.SW);
@@ -656,6 +656,23 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
     return sizeof(float) * (size_t)F * (A.SH + 2) * (A.SW + 2) * A.CsL + 4 * rows_pad * (A.lin ? 1 : 2);
   };
   while (A.F > 1 && lds_bytes(A.F) > 64 * 1024) --A.F;
+  {
+    // Frames per pass: the kernel's time is (passes of the busiest workgroup) x (row tiles of a pass per wave); both are ceilings, and
+    // on the small maps their product swings by 30 % with F (4800 frames of 5x5 positions on 512 workgroups: F = 4 -> 3 rounds x 7
+    // tiles, F = 5 -> 2 rounds x 8 tiles).  Take the feasible F with the smallest product (ties: the larger F, fewer barriers).
+    const int slots = 512, mstep = 4 / NT, opf = A.OA * A.OB;
+    double best = -1.0;
+    int bestF = A.F;
+    for (int F = A.F; F >= 1; --F) {
+      const long units = (A.N + F - 1) / F, full = units / slots, rem = units - full * slots;
+      // a partial last round runs on a half-empty chip: cheaper than a full one (measured on the 9x9 layers), not free
+      const double rounds = (double)full + (rem ? 0.5 + 0.5 * (double)rem / slots : 0.0);
+      const long tiles = ((long)F * opf + 15) / 16, per_wave = (tiles + mstep - 1) / mstep;
+      const double cost = rounds * (double)(per_wave * 8 + 16);     // (+ a pass's fixed part: staging, barriers, pipeline fill ~ two tiles)
+      if (best < 0.0 || cost < 0.97 * best) { best = cost; bestF = F; }
+    }
+    A.F = bestF;
+  }
   size_t lds = lds_bytes(A.F);
   if (lds > 64 * 1024) return AVSR_ERR_UNSUPPORTED;
   if (lds < sizeof(float) * 4 * 4 * 2 * 4) lds = sizeof(float) * 4 * 4 * 2 * 4;      // the statistics reduction's staging area
@@ -1038,6 +1055,20 @@ static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const fl
   return AVSR_OK;
 }
 
+// frames per pass of the weight-gradient kernel: its time is (passes of the busiest workgroup) x (frames of a pass) -- chunks never span
+// frames --, so among the feasible F the one with the smallest rounds * F wins (4800 frames on 512 workgroups: F = 4 -> 3 x 4, F = 2 or 5
+// -> 10); ties: the larger F
+static int wg_pick_frames(int N, int Fmax, int slots) {
+  double best = -1.0;
+  int bestF = Fmax;
+  for (int F = Fmax; F >= 1; --F) {
+    const long units = (N + F - 1) / F, rounds = (units + slots - 1) / slots;    // (whole rounds: measured better here than a discounted tail)
+    const double cost = (double)rounds * (8.0 * F + 1.0);
+    if (best < 0.0 || cost < best) { best = cost; bestF = F; }
+  }
+  return bestF;
+}
+
 // final reduction of the pixel-pair weight gradient (below): part [nblk][12*Ci*16 (+16)] with rows (ti, tj', ci), columns (pp, co):
 // dw[ti][tj][ci][co] = sum_blk part[(ti*4 + tj)*Ci + ci][co] + part[(ti*4 + tj + 1)*Ci + ci][8 + co];  dbias[co] = sum_blk bias[co] + bias[8 + co]
 __global__ __launch_bounds__(256) void wgrad_pair_final_kernel(const float* __restrict__ part, int nblk, int slab, int Ci, float* __restrict__ dw,
@@ -1100,6 +1131,7 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
       ok = ok && (A.F * H * W * Ci / 4 + 255) / 256 <= 4 && (long)A.F * H * W * Ci < 65536;
       A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci);
     }
+    if (ok) A.F = wg_pick_frames(N, A.F, 512);
     size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + WG_PAD);
     if (lds < sizeof(float) * 4 * 256) lds = sizeof(float) * 4 * 256;
     ok = ok && lds <= 64 * 1024 && (long)A.F * ((Ho * A.Wo + 15) / 16) < 65536 && (long)N * Ho * Wo * Co * 4 < (1L << 31);
@@ -1147,6 +1179,11 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
     while (A.F > 1 && (A.F * H * W * Ci / 4 + 255) / 256 > 4) --A.F;
     if ((A.F * H * W * Ci / 4 + 255) / 256 > 4 || (long)A.F * H * W * Ci >= 65536) return AVSR_ERR_UNSUPPORTED;
     A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci);
+  }
+  while (A.F > 1 && sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + WG_PAD) > 64 * 1024) --A.F;
+  {
+    const int nt0 = k * k < G ? k * k : G;
+    A.F = wg_pick_frames(N, A.F, (nt0 * Ci * Co + Co > 2048) ? 256 : 512);
   }
   if ((long)A.F * ((Ho * Wo + 15) / 16) >= 65536 || (long)N * Ho * Wo * Co * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
   const size_t red = sizeof(float) * 4 * 256;
