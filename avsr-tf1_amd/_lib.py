@@ -100,7 +100,7 @@ class AttnRnn(C.Structure):
                 ("beam_width", C.c_int32), ("mem_shared", C.c_int32), ("length_penalty", C.c_float), ("pad6_", C.c_float),
                 ("beam_logp", C.c_void_p), ("beam_fin", C.c_void_p), ("beam_len", C.c_void_p), ("step_ids", C.c_void_p),
                 ("parent_ids", C.c_void_p), ("parent_rows", C.c_void_p),
-                ("n_extra", C.c_int32), ("pad7_", C.c_int32), ("out0", C.c_void_p), ("extra", DecLayer * MAX_DEC_EXTRA),
+                ("n_extra", C.c_int32), ("prof_tag", C.c_int32), ("out0", C.c_void_p), ("extra", DecLayer * MAX_DEC_EXTRA),
                 ("fused_ws", C.c_void_p), ("fused_ws_floats", C.c_int64)]
 
 

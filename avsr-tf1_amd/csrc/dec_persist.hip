@@ -896,7 +896,7 @@ int avsr_dec_persist_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32_t l_end
     L.b0 = b0; L.ngroups = ((B - b0 < slice ? B - b0 : slice) + L.R - 1) / L.R;
     if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
-      ProfScope ps(PROF_DEC_PERSIST_FWD, s);
+      ProfScope ps(dp->prof_tag == 1 ? PROF_ALIGN_PERSIST_FWD : PROF_DEC_PERSIST_FWD, s);
       void* args[] = {(void*)&L};
       if (hipLaunchKernel(dp_kernel(variant, L.mode), dim3(8 * DP_NW), dim3(DP_NT), args, lds, s) != hipSuccess) return AVSR_ERR_HIP;
     }

@@ -659,7 +659,7 @@ int avsr_dec_persist_bwd(const avsr_attn_rnn* dp, void* stream) {
     L.b0 = b0; L.ngroups = ((d.B - b0 < slice ? d.B - b0 : slice) + F.R - 1) / F.R;
     if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
-      ProfScope ps(PROF_DEC_PERSIST_BWD, s);
+      ProfScope ps(dp->prof_tag == 1 ? PROF_ALIGN_PERSIST_BWD : PROF_DEC_PERSIST_BWD, s);
       void* args[] = {(void*)&L};
       if (hipLaunchKernel(db_kernel(variant), dim3(8 * DP_NW), dim3(DP_NT), args, lds, s) != hipSuccess) return AVSR_ERR_HIP;
     }

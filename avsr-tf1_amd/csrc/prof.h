@@ -5,7 +5,9 @@
 
 namespace avsr {
 enum ProfKind { PROF_GEMM = 0, PROF_STEP_LSTM_FWD, PROF_STEP_LSTM_BWD, PROF_STEP_LINEAR, PROF_ATTN_FWD, PROF_ATTN_BWD,
-                PROF_RNN_PERSIST_FWD, PROF_RNN_PERSIST_BWD, PROF_DEC_PERSIST_FWD, PROF_DEC_PERSIST_BWD, PROF_CONV_FWD, PROF_CONV_BWD_DATA, PROF_CONV_BWD_WEIGHT, PROF_NKIND };
+                PROF_RNN_PERSIST_FWD, PROF_RNN_PERSIST_BWD, PROF_DEC_PERSIST_FWD, PROF_DEC_PERSIST_BWD, PROF_CONV_FWD, PROF_CONV_BWD_DATA, PROF_CONV_BWD_WEIGHT,
+                PROF_ALIGN_PERSIST_FWD, PROF_ALIGN_PERSIST_BWD,   // the AV-Align attentive encoder layer through the fused persistent kernels
+                PROF_NKIND };
 void prof_record(int kind, hipStream_t s, bool begin, double work = 0.0);
 extern bool g_prof_enabled;
 struct ProfScope {

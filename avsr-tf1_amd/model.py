@@ -1208,6 +1208,7 @@ class Seq2SeqModel:
             ops.gemm(xin, self.P[blk["cell"] + "/cand_kernel"].mat(H), ops.mat(blk["cs"], H), B * T, H, Ein)
         self._block_prepare(ws, blk)
         blk["desc"] = self._block_desc(ws, blk, E["len"], 0, None, None, with_bwd=training)
+        blk["desc"].prof_tag = 1                 # timed as the attentive encoder layer, not as a decoder (bench.py roofline classes)
         ops.attn_rnn_fwd(blk["desc"], 0, T)
         E["c_fin"], E["h_fin"] = (None if self.gru else blk["cf"]), blk["hf"]
 

@@ -390,7 +390,7 @@ def adam_step(params, grads, m, v, n, gnorm, step, lr, warmup_steps, clip_norm, 
 
 
 PROF_KINDS = ("gemm", "step_lstm_fwd", "step_lstm_bwd", "step_dense", "attn_fwd", "attn_bwd", "rnn_persist_fwd", "rnn_persist_bwd", "dec_persist_fwd", "dec_persist_bwd",
-              "conv_fwd", "conv_bwd_data", "conv_bwd_weight")
+              "conv_fwd", "conv_bwd_data", "conv_bwd_weight", "align_persist_fwd", "align_persist_bwd")
 
 
 def prof_begin(max_launches=65536):

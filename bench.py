@@ -287,6 +287,10 @@ def main():
                    "T_a": TA, "F_a": FA, "T_v": TV, "F_v": FV, "T_dec": LDEC, "parallelism": "dp%d" % world,
                    "video_frontend": (cfg.video_processing if cfg.video_units is not None else None), "launch": trainer.mode, "dropout": bool(cfg.use_dropout), "dropout_keep": list(cfg.decoder_dropout) if cfg.use_dropout else None,
                    "scheduled_sampling": cfg.sampling_probability,
+                   "collectives_per_step": (2 if world > 1 else 0),
+                   "dp_batch_norm": ("encoder-input batch norms use the statistics of the GLOBAL batch (fp64 moments in the step's one small "
+                                     "all-reduce); the batch norms inside the lip CNN (and the input batch norm of the CNN-fed stream) use PER-RANK "
+                                     "statistics -- a documented deviation from one engine on the whole batch") if world > 1 else None,
                    "parity": "vs CPU restatement of TF-1.13.1 semantics; TF parity unpinned"},
         "final_loss": round(loss, 5),
     }
@@ -341,18 +345,25 @@ def main():
         out["kernel_time_events"] = kinds
         # the dominant KERNEL: the event classes gemm / conv_* aggregate many launches of different shapes (their class averages are
         # reported in roofline_other), so the headline roofline is the single kernel with the most time per step
+        # (the AV-Align layer's class on c5 is several launches of one kernel: a class of its own since round 3)
         single = [k for k in kinds if not (k == "gemm" or k.startswith("conv_"))] or list(kinds)
         dom = max(single, key=lambda k: kinds[k]["total_ms"])
         HBM_PEAK, MFMA_PEAK = 8000.0, 157.3
         # HBM traffic per launch from the committed PMC passes (profiles/r02_c4_lipcnn_pmc_v5.json: FETCH_SIZE / WRITE_SIZE collected in
         # separate rocprofv3 runs of this same workload, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); null
         # for workloads / kernels that were not profiled.
-        pmc = {}
+        pmc, pmc_file = {}, None
         try:
             if args.workload == "c4" and args.video_frontend == "resnet_cnn":
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_c4_lipcnn_pmc_v5.json")))["kernels"]
+                for cand in ("r03_c4_lipcnn_pmc_v1.json", "r02_c4_lipcnn_pmc_v5.json"):
+                    path = os.path.join(ROOT, "profiles", cand)
+                    if os.path.exists(path):
+                        pmc, pmc_file = json.load(open(path))["kernels"], "profiles/" + cand
+                        break
         except Exception:
-            pmc = {}
+            pmc, pmc_file = {}, None
+        # `traffic` is NOT measured in this run: it is read from the committed PMC summary above (separate rocprofv3 --pmc passes)
+        out["traffic_source"] = pmc_file
         # kernel-name prefixes of the PMC summary (template arguments vary with the configuration: the first match is taken)
         pmc_name = {"attn_fwd": ["avsr::attn_fwd_kernel"], "attn_bwd": ["avsr::attn_bwd_kernel"],
                     "dec_persist_fwd": ["avsr::dec_persist_kernel<"], "dec_persist_bwd": ["avsr::dec_persist_bwd_kernel<"],
@@ -371,21 +382,34 @@ def main():
         def roof(kind):
             us = kinds[kind]["avg_us"]
             if kind in ("dec_persist_fwd", "dec_persist_bwd"):
-                # fused persistent decode kernel: ONE launch = all T_dec steps of the (dual-)attention decoder forward; a step's
-                # algorithmic bytes are the keys + values of every memory (what the per-step attention kernel streamed from HBM);
-                # here they are resident in VGPRs / LDS, so `achieved` exceeds what HBM streaming could deliver -- it is the
-                # north_star figure "75.37 MB / measured us per decode step" against the 8 TB/s peak
-                n_dec = max(1, kinds[kind]["launches"])
-                steps = LDEC * (1 if B <= 64 else (B + 63) // 64) / (1 if B <= 64 else (B + 63) // 64)
-                per_step_us = us / LDEC * (1 if B <= 64 else (B + 63) // 64)
-                ach = wm["attn_bytes"] / (per_step_us * 1e-6) / 1e9
+                # fused persistent decode kernel: ONE launch = all T_dec steps of the (dual-)attention decoder for up to 64 utterances
+                # (8 XCDs x 8 rows; a larger batch is consecutive launches over 64-row slices); a step's algorithmic bytes are the
+                # keys + values of every memory of the launch's rows (what the per-step attention kernel streamed from HBM); here they
+                # are resident in VGPRs / LDS, so `achieved` is the north_star figure "bytes / measured us per decode step" against the
+                # 8 TB/s peak, not an HBM counter
+                rows = min(B, 64)
+                per_step_us = us / LDEC
+                byts = wm["attn_bytes"] * rows / B
+                ach = byts / (per_step_us * 1e-6) / 1e9
                 return {"kernel": kind, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK, 4), "traffic": traffic(kind), "algorithmic_bytes_per_decode_step": wm["attn_bytes"],
-                        "decode_steps_per_launch": LDEC, "us_per_decode_step": round(per_step_us, 3), "avg_launch_us": us,
+                        "frac": round(ach / HBM_PEAK, 4), "traffic": traffic(kind), "algorithmic_bytes_per_decode_step": int(byts),
+                        "rows_per_launch": rows, "decode_steps_per_launch": LDEC, "us_per_decode_step": round(per_step_us, 3), "avg_launch_us": us,
                         "note": "whole decode step (cell + scores/softmax/context + attention layer + output layer + sample) fused; keys/values resident on chip"
                         if kind == "dec_persist_fwd" else
                         "whole BPTT step (attention-layer transpose + attention backward + cell backward) fused; the per-step attention backward "
                         "streamed the same keys + values from HBM every step"}
+            if kind in ("align_persist_fwd", "align_persist_bwd"):
+                # the AV-Align attentive encoder layer (encoder.py:265-290) through the same fused kernels (16-row groups, 128 utterances
+                # per launch): per AUDIO FRAME the layer attends the whole video memory: 4*rows*T_v*(H + D) bytes (19.66 MB at
+                # B = 128); one launch walks T_a frames
+                rows = min(B, 128)
+                byts = 4.0 * rows * TV * (cfg.audio_units[-1] + cfg.memory_depth("video"))
+                per_frame_us = us / TA
+                ach = byts / (per_frame_us * 1e-6) / 1e9
+                return {"kernel": kind, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK, 4), "traffic": None, "algorithmic_bytes_per_audio_frame": int(byts), "rows_per_launch": rows,
+                        "audio_frames_per_launch": TA, "us_per_audio_frame": round(per_frame_us, 3), "avg_launch_us": us,
+                        "note": "AV-Align attentive layer: LSTM step + attention over the video memory per audio frame, one persistent launch"}
             if kind in ("attn_fwd", "attn_bwd"):
                 ach = wm["attn_bytes"] / (us * 1e-6) / 1e9
                 return {"kernel": kind, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s",
@@ -401,7 +425,7 @@ def main():
                  "frac": round(ach / MFMA_PEAK, 4), "traffic": traffic(kind), "algorithmic_flops_per_launch": int(fl), "avg_launch_us": us}
             if kind.startswith("rnn_persist"):
                 # the recurrent chain is latency-bound -- the meaningful figure is the time per sequential time step
-                # (one launch walks the T_a-step layer/time wavefront), next to the ~1.45 us launch floor it replaces
+                # (one launch walks the T_a-step layer/time wavefront), next to the ~1.45 us per-launch floor it replaces
                 r["sequential_steps"] = TA + 2
                 r["us_per_sequential_step"] = round(us / (TA + 2), 3)
                 r["note"] = "latency-bound recurrence: one persistent launch for the whole sequence; compare us_per_sequential_step with the ~1.45 us per-launch floor x 3 layers of a launch-per-step design"

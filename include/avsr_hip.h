@@ -325,7 +325,8 @@ typedef struct avsr_attn_rnn {
   int32_t* parent_rows;         /* [B] */
   /* multi-layer decoder cell: n_extra layers above the attention-fed one (0 = the plain single cell).  out0 = output
    * record of the attention-fed layer [B][L+1][H] (slot 0 = h0), needed because cell_out then belongs to the top layer. */
-  int32_t n_extra, pad7_;
+  int32_t n_extra, prof_tag;    /* prof_tag: 1 = this block is the AV-Align attentive encoder layer (encoder.py:265-290): its fused launches are
+                                 * timed as their own avsr_prof classes (13 / 14) instead of the decoder's (8 / 9); no effect on results */
   float* out0;
   avsr_dec_layer extra[AVSR_MAX_DEC_EXTRA];
   /* Scratch of the fused persistent decode kernel (csrc/dec_persist.hip; avsr/decoder_bimodal.py:241-275,
@@ -609,9 +610,9 @@ int avsr_optimiser_step(float* params, float* grads, float* m, float* v, int64_t
  * begin and end every gemm / step / attention launch is bracketed by an event pair on its stream; end
  * synchronises the device and returns per-kind launch counts and summed milliseconds.
  * kinds: 0 gemm, 1 LSTM-forward step, 2 LSTM-backward step, 3 dense step, 4 attention fwd, 5 attention bwd,
- * 6 persistent RNN forward, 7 persistent RNN backward, 8 / 9 fused persistent decoder forward / backward, 10 / 11 / 12 convolution forward / data gradient / weight gradient.  out_flops (may be NULL): algorithmic FLOPs summed per kind
+ * 6 persistent RNN forward, 7 persistent RNN backward, 8 / 9 fused persistent decoder forward / backward, 10 / 11 / 12 convolution forward / data gradient / weight gradient, 13 / 14 the AV-Align attentive layer's fused persistent forward / backward.  out_flops (may be NULL): algorithmic FLOPs summed per kind
  * where the launcher knows them (gemm, persistent RNN kernels), else 0. */
-#define AVSR_PROF_NKIND 13
+#define AVSR_PROF_NKIND 15
 int avsr_prof_begin(int32_t max_launches);
 int avsr_prof_end(int32_t* out_count, float* out_ms, double* out_flops);
 
