@@ -310,11 +310,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   ti = __builtin_amdgcn_readfirstlane(ti);
   if (ti < 0) return;
   const PTask& tk = L.task[ti];
-#ifdef RNN_STAGGER_PRIO
-  // experiment: a static priority per cell, so that the cells sharing a SIMD's matrix pipe take it one after the other (staggered
-  // phases) instead of interleaving their products
-  switch (ti & 3) { case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; case 3: __builtin_amdgcn_s_setprio(3); break; default: break; }
-#endif
+  // The cells with an input product (layers > 0) set the pace of the wavefront; the recurrent-only layer-0 cells have slack (they run
+  // ~20 % ahead).  Three workgroups share each SIMD's matrix pipe: the pace-setters take it first.  Round 3: 2.42 -> 2.37 ms at c4; a
+  // distinct priority per cell (0..3) did nothing.  (`v_mfma_f32_4x4x1_16B_f32` for the 8-row products -- no padding rows -- was
+  // sized and dropped: K = 1 per instruction needs one weight register per k, 128 per wave against 64 with 16x16x4.)
+  if (!tk.hoisted) __builtin_amdgcn_s_setprio(2);
   const int ct = slot - tk.wg_begin;
   const int UW = tk.uw, uw_shift = UW == 16 ? 4 : 3;
   const int row0 = L.b0 + g * R, col0 = ct * UW * 4, unit0 = ct * UW;
