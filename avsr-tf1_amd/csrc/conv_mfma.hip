@@ -96,6 +96,7 @@ struct CGArgs {
   int nsp, SB, OSA, OSB, lin;
   signed char sp_dh[4], sp_dw[4];
   int ntap, wmode, F;
+  int dbg;                                // CONV_DEBUG builds only: bit 0 no stores, bit 1 no LDS operand reads, bit 2 no MFMAs
   float beta;
   unsigned m_opf, m_ob, m_rq, m_per, m_sw;   // division magics: positions per frame, OB, pieces per source row / per frame (Cs % 4 == 0),
                                           // or channels / floats per frame / SW (otherwise)
@@ -141,10 +142,11 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
       ro = f * fstride + ((a * A.S + 1) * PW + (b * A.SB + 1)) * CsL;
       const int ph = a * A.OSA + A.oh0, pw = b * A.OSB + A.ow0;
       // low bits (offsets are multiples of 16 bytes): 1 = no pixel below this one (odd map heights), 2 = none to its right, 4 = no pixel at all
-      dt = (ph < A.DH && pw < A.DW) ? ((((f * A.DH + ph) * A.DW + pw) * Cd) << 2) | (ph + 1 >= A.DH ? 1 : 0) | (pw + 1 >= A.DW ? 2 : 0) : 4;
+      dt = lin ? (m * NC) << 2
+               : (ph < A.DH && pw < A.DW) ? ((((f * A.DH + ph) * A.DW + pw) * Cd) << 2) | (ph + 1 >= A.DH ? 1 : 0) | (pw + 1 >= A.DW ? 2 : 0) : 4;
     }
     rowtab[m] = ro;
-    if (!lin) dsttab[m] = dt;
+    dsttab[m] = dt;
   }
 
   // weight fragments of this wave's column tile (A operand: row i of the fragment = column nt*16 + i of the product) + per-chunk LDS
@@ -196,8 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   f32x4 ssum = zero4, ssq = zero4;
   const __amdgpu_buffer_rsrc_t e_rs = make_rsrc(e_map), dst_rs = make_rsrc(A.dst), acc_rs = make_rsrc(A.acc ? A.acc : A.dst);
   // byte offset of this lane's 16 bytes inside a tile / a destination cell
-  const int lane_o = lin ? (i * NC + cD0) * 4 : ((sdh * A.DW + sdw) * Cd + coD) * 4;
-  const int tile_o = 16 * NC * 4;
+  const int lane_o = lin ? cD0 * 4 : ((sdh * A.DW + sdw) * Cd + coD) * 4;
 
   // staging role of this thread: piece column st_p4 of rows st_row, st_row + st_rpp, ...  (threads beyond rpp*rq idle)
   const int st_rq = (A.SW * Cs) >> 2;
@@ -218,26 +219,32 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   const int ppf = c4 ? (A.SH + st_rpp - 1) / st_rpp : 0;            // pieces per frame per thread (row-structured)
   const unsigned m_ppf = fmagic_dev(ppf > 0 ? ppf : 1);
   const int per3 = A.SH * A.SW * Cs;                                // floats per frame (3-channel path)
+  // (hidden loads, see persist.h: left to the compiler the whole prefetch is waited for BEFORE the tile loop it should overlap)
+  const i32x4_ src_rs = make_rsrc_words(A.src);                     // (source maps stay below 2 GB: checked by the host)
   auto fetch = [&](int n0) {
     const int fcur = min(A.F, A.N - n0);
     if (c4) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int f = fdiv(u, m_ppf), k = u - f * ppf, r = st_row + k * st_rpp;
-        pre[u] = (st_row >= 0 && f < fcur && r < A.SH) ? ld4(A.src + ((long)(n0 + f) * A.SH + r) * rowf + st_p4 * 4) : zero4;
+        // branch-free: pieces this thread does not have use an out-of-range offset (the load returns zeros)
+        ldb4_hidden(pre[u], src_rs, (st_row >= 0 && f < fcur && r < A.SH) ? (int)((((unsigned)(n0 + f) * A.SH + r) * rowf + st_p4 * 4) * 4u) : P_OOB);
       }
     } else {
-      const float* sp = A.src + (long)n0 * per3;
+      const unsigned so = (unsigned)n0 * per3 * 4u;
       const int tot4 = (fcur * per3) >> 2;
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int idx = u * 256 + tid;
-        pre[u] = idx < tot4 ? ld4(sp + idx * 4) : zero4;
+        ldb4_hidden(pre[u], src_rs, idx < tot4 ? (int)(so + idx * 16u) : P_OOB);
       }
     }
   };
   auto commit = [&](int n0) {
     const int fcur = min(A.F, A.N - n0);
+    vm_wait_all();
+#pragma unroll
+    for (int u = 0; u < PF; ++u) vm_landed(pre[u]);
     if (c4) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -267,12 +274,23 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
     }
   };
   int n0 = blockIdx.x * A.F;
+#ifdef CONV_DEBUG
+  long t_pro = 0, t_b1 = 0, t_commit = 0, t_b2 = 0, t_comp = 0, t_mark = __builtin_readcyclecounter();
+  const long t_start = t_mark;
+#define CG_STAMP(acc) { const long t_now = __builtin_readcyclecounter(); acc += t_now - t_mark; t_mark = t_now; }
+#else
+#define CG_STAMP(acc)
+#endif
   if (n0 < A.N) fetch(n0);
+  CG_STAMP(t_pro)
   for (; n0 < A.N; n0 += gridDim.x * A.F) {
     const int fcur = min(A.F, A.N - n0);
     __syncthreads();                                    // previous pass has finished reading the LDS (first pass: tables written)
+    CG_STAMP(t_b1)
     commit(n0);
+    CG_STAMP(t_commit)
     __syncthreads();
+    CG_STAMP(t_b2)
     if (n0 + gridDim.x * A.F < A.N) fetch(n0 + gridDim.x * A.F);      // in flight during the MFMAs below
     // ---- implicit GEMM over the staged frames ----
     const int Mtot = fcur * opf, mtiles = (Mtot + 15) >> 4;
@@ -284,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
     const int last = mtiles - 1;
     int rb_cur = rowtab[(mslot < mtiles ? mslot : 0) * 16 + i];
     int rb_nxt = rowtab[(mslot + mstep < mtiles ? mslot + mstep : (last > 0 ? last : 0)) * 16 + i];
-    int dt_cur = lin ? 0 : dsttab[(mslot < mtiles ? mslot : 0) * 16 + i];
+    int dt_cur = dsttab[(mslot < mtiles ? mslot : 0) * 16 + i];
     if (XT && mslot < mtiles) {
 #pragma unroll
       for (int c = 0; c < CB; ++c) bufa[c] = ld4(lds + rb_cur + koff[c]);
@@ -306,43 +324,43 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaf(ev[r], esc4[r], esh4[r]) > 0.f ? v[r] : 0.f;
       }
+#ifdef CONV_DEBUG
+      if (!(A.dbg & 1))
+#endif
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), dst_rs, dbo, 0, 0);
       // statistics are accumulated unconditionally (a few operations); only their final write is conditional
       const f32x4 vs = ok ? v : zero4;
       ssum += vs;
       ssq += ((EP & 1) && bnb) ? vs * ev : vs * vs;
     };
-    auto tile = [&](f32x4 (&cur)[CB], f32x4 (&nxt)[CB], const int mt) {
-      const int t1 = mt + mstep < mtiles ? mt + mstep : last, t2 = mt + 2 * mstep < mtiles ? mt + 2 * mstep : last;
-      const int rb_nn = rowtab[t2 * 16 + i];
-      const int dt_nxt = lin ? 0 : dsttab[t1 * 16 + i];
-      const float* base = lds + (XT ? rb_nxt : rb_cur);
-      // destination of this lane's four channels; rows beyond the pass / columns beyond the product / cells beyond an odd map use
-      // an out-of-range offset: their loads return zero and their store is dropped by the buffer bounds check (no branch)
-      const int bad = lin ? 0 : ((dt_cur & 4) | ((dt_cur & 1) & sdh) | (((dt_cur >> 1) & 1) & sdw));
-      const bool ok = (mt * 16 + i < Mtot) & colok & (bad == 0);
-      const int dbo = ok ? (int)(pass_o + (unsigned)((lin ? mt * tile_o : (dt_cur & ~15)) + lane_o)) : P_OOB;
+    // The tile bodies are branch-free (one basic block each: the instruction scheduler -- and the scheduling groups below -- only see
+    // a block): table entries come from the LDS for every destination layout, lanes without an output cell get the out-of-range
+    // bit OR-ed into their offset (loads return zero, the store is dropped by the buffer bounds check).
+    auto dest = [&](const int mt, const int dt, bool& ok) {
+      const int bad = (dt & 4) | ((dt & 1) & sdh) | (((dt >> 1) & 1) & sdw);
+      ok = (mt * 16 + i < Mtot) & colok & (bad == 0);
+      return (int)(pass_o + (unsigned)((dt & ~15) + lane_o)) | (ok ? 0 : P_OOB);
+    };
+    auto tile = [&](f32x4 (&cur)[CB], f32x4 (&nxt)[CB], const int mt) {          // MAXCH > 6: blocks of CB chunks, epilogue in place
+      const int t1 = mt + mstep < mtiles ? mt + mstep : last;
+      const int dt_nxt = dsttab[t1 * 16 + i];
+      const float* base = lds + rb_cur;
+      bool ok;
+      const int dbo = dest(mt, dt_cur, ok);
       f32x4 ev = zero4, ov = zero4;
       if (EP & 1) ev = ldb4(e_rs, dbo);
       if (EP & 2) ov = ldb4(acc_rs, dbo);
       // Chunks beyond the layer's depth read offset 0 against zero weights (no branch around any read).  The reads of the next
-      // block (the next tile when the tile is one block) are issued BEFORE this block's MFMAs and kept there by the scheduling
-      // barrier: left to itself the compiler sank each read to just ahead of its first use, one exposed LDS round trip per chunk.
+      // block are issued BEFORE this block's MFMAs and kept there by the scheduling barrier: left to itself the compiler sank each
+      // read to just ahead of its first use, one exposed LDS round trip per chunk.
       f32x4 acc0 = zero4, acc1 = zero4;
-      if (!XT) {
 #pragma unroll
-        for (int c = 0; c < CB; ++c) cur[c] = ld4(base + koff[c]);
-      }
+      for (int c = 0; c < CB; ++c) cur[c] = ld4(base + koff[c]);
 #pragma unroll
       for (int b0 = 0; b0 < MAXCH; b0 += CB) {
-        if (XT) {
 #pragma unroll
-          for (int c = 0; c < CB; ++c) nxt[c] = ld4(base + koff[c]);
-        } else {
-#pragma unroll
-          for (int c = 0; c < CB; ++c)
-            if (b0 + CB + c < MAXCH) nxt[c] = ld4(base + koff[b0 + CB + c]);
-        }
+        for (int c = 0; c < CB; ++c)
+          if (b0 + CB + c < MAXCH) nxt[c] = ld4(base + koff[b0 + CB + c]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < CB; ++c)
@@ -351,29 +369,114 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
             for (int e = 0; e < 4; ++e) {               // two accumulator chains, alternating: no MFMA waits for its predecessor
               if (e & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[b0 + c][e], cur[c][e], acc1, 0, 0, 0);
               else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[b0 + c][e], cur[c][e], acc0, 0, 0, 0);
+              // MFMAs keep their source order (everything else may move across): left alone the scheduler issues one chain after
+              // the other -- twelve dependent MFMAs at 40 cycles each instead of 32
+              __builtin_amdgcn_sched_barrier(0x7F6);
             }
           }
         __builtin_amdgcn_sched_barrier(0);
-        if (!XT) {
 #pragma unroll
-          for (int c = 0; c < CB; ++c) cur[c] = nxt[c];
-        }
+        for (int c = 0; c < CB; ++c) cur[c] = nxt[c];
       }
-      // (Measured and not kept, round 3: deferring the epilogue by one tile and interleaving it with the MFMAs through
-      // sched_group_barrier -- 144 -> 158 us on the 36x36x8 layers; a static s_setprio by hardware wave-slot parity -- no change.)
       epilogue(acc0, acc1, dbo, ok, ev, ov);
+      rb_cur = rb_nxt;
+      rb_nxt = rowtab[(mt + 2 * mstep < mtiles ? mt + 2 * mstep : last) * 16 + i];
+      dt_cur = dt_nxt;
+    };
+    // MAXCH <= 6 (the large maps: a tile is only 4 * MAXCH MFMAs, and the ~60 other instructions of a tile -- tables, addresses, the
+    // next tile's operand reads, the epilogue -- were issued by the same wave BEFORE / AFTER them, costing about as many cycles as
+    // the MFMAs themselves).  Here a tile's epilogue is deferred by one tile, which makes everything in the body independent of the
+    // MFMAs being issued, and the scheduling groups spread it between them.
+    f32x4 pa0 = zero4, pa1 = zero4, pev = zero4, pov = zero4;
+    int pdbo = P_OOB, poki = 0;                       // (the flag travels as an integer: one VGPR, no lane-mask phi around the loop)
+    auto tile_x = [&](f32x4 (&cur)[CB], f32x4 (&nxt)[CB], const int mt) {
+      // The issue order is written out by hand: one MFMA, one slice of the other work, a full scheduling fence.  (Asked through
+      // sched_group_barrier the compiler kept most of the other work behind the last MFMA; left alone it also issues one
+      // accumulator chain after the other -- dependent MFMAs at 40 cycles each instead of 32.)
+      const int t1 = mt + mstep < mtiles ? mt + mstep : last, t2 = mt + 2 * mstep < mtiles ? mt + 2 * mstep : last;
+      int rb_nn = 0, dt_nxt = 0, dbo = P_OOB, oki = 0;
+      bool ok = false;
+      f32x4 ev = zero4, ov = zero4, v = zero4, vs = zero4, acc0 = zero4, acc1 = zero4;
+      constexpr int W_RD = 1, W_DEST = W_RD + CB, W_EPI = W_DEST + 2, NWORK = W_EPI + 9, NM = 4 * MAXCH;
+      auto work = [&](const int k) {
+        if (k == 0) { rb_nn = rowtab[t2 * 16 + i]; dt_nxt = dsttab[t1 * 16 + i]; }
+        else if (k < W_DEST) {                          // the NEXT tile's operands (this tile's arrived during the previous one)
+#ifdef CONV_DEBUG
+          if (!(A.dbg & 2))
+#endif
+          nxt[k - W_RD] = ld4(lds + rb_nxt + koff[k - W_RD]);
+        } else if (k == W_DEST) {
+          dbo = dest(mt, dt_cur, ok);
+          oki = ok ? 1 : 0;
+          asm volatile("" : "+v"(dbo), "+v"(oki));       // computed HERE (otherwise sunk behind the MFMAs, to its first use in the next tile)
+        }
+        else if (k == W_DEST + 1) {
+          if (EP & 1) ev = ldb4(e_rs, dbo);
+          if (EP & 2) ov = ldb4(acc_rs, dbo);
+        }
+        // ---- the PREVIOUS tile's epilogue, in slices (same arithmetic and order as epilogue()) ----
+        else if (k == W_EPI) v = pa0 + pa1;
+        else if (k == W_EPI + 1) v += bias4;
+        else if (k == W_EPI + 2) {
+          if ((EP & 1) && !bnb) {
+            if (rbn) { v[0] += fmaxf(fmaf(pev[0], esc4[0], esh4[0]), 0.f); v[1] += fmaxf(fmaf(pev[1], esc4[1], esh4[1]), 0.f); }
+            else v += pev;
+          }
+        } else if (k == W_EPI + 3) {
+          if ((EP & 1) && !bnb && rbn) { v[2] += fmaxf(fmaf(pev[2], esc4[2], esh4[2]), 0.f); v[3] += fmaxf(fmaf(pev[3], esc4[3], esh4[3]), 0.f); }
+        } else if (k == W_EPI + 4) {
+          if (EP & 2) v += A.beta * pov;
+        } else if (k == W_EPI + 5) {
+          if ((EP & 1) && bnb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(pev[r], esc4[r], esh4[r]) > 0.f ? v[r] : 0.f;
+          }
+        } else if (k == W_EPI + 6) {
+#ifdef CONV_DEBUG
+          if (!(A.dbg & 1))
+#endif
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), dst_rs, pdbo, 0, 0);
+        } else if (k == W_EPI + 7) { vs = poki != 0 ? v : zero4; ssum += vs; }
+        else if (k == W_EPI + 8) ssq += ((EP & 1) && bnb) ? vs * pev : vs * vs;
+      };
+#pragma unroll
+      for (int k = 0; k < NM; ++k) {
+        const int c = k >> 2, e = k & 3;
+#ifdef CONV_DEBUG
+        if (!(A.dbg & 4)) {
+#endif
+        if (e & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][e], cur[c][e], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[c][e], cur[c][e], acc0, 0, 0, 0);
+#ifdef CONV_DEBUG
+        }
+#endif
+        if (k < NWORK) work(k);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int k = NM; k < NWORK; ++k) work(k);         // (shallow layers: more slices than MFMAs)
+      pa0 = acc0; pa1 = acc1; pdbo = dbo; poki = oki; pev = ev; pov = ov;
       rb_cur = rb_nxt; rb_nxt = rb_nn; dt_cur = dt_nxt;
     };
     if (XT) {                                           // ping-pong between two operand buffers: no register copies between tiles
       for (int mt = mslot; mt < mtiles; mt += 2 * mstep) {
-        tile(bufa, bufb, mt);
-        if (mt + mstep < mtiles) tile(bufb, bufa, mt + mstep);
+        tile_x(bufa, bufb, mt);
+        if (mt + mstep < mtiles) tile_x(bufb, bufa, mt + mstep);
         else break;
       }
+      epilogue(pa0, pa1, pdbo, poki != 0, pev, pov);    // the pass's last tile
     } else {
       for (int mt = mslot; mt < mtiles; mt += mstep) tile(bufa, bufb, mt);
     }
+    CG_STAMP(t_comp)
   }
+#ifdef CONV_DEBUG
+  if ((A.dbg & 8) && A.stats && lane == 0) {           // per-wave cycle counts behind the statistics partials (probe allocates them)
+    float* o = A.stats + (long)gridDim.x * 2 * Cd + ((long)blockIdx.x * 4 + wave) * 8;
+    o[0] = (float)t_pro; o[1] = (float)t_b1; o[2] = (float)t_commit; o[3] = (float)t_b2; o[4] = (float)t_comp;
+    o[5] = (float)(__builtin_readcyclecounter() - t_start);
+  }
+#endif
   if (A.stats) {
     // per-channel partials of this workgroup: sum over the 16 positions of a lane group first (lanes q*16 .. q*16+15 hold the same
     // four channels), then over the (wave, q, r) slots that carry the channel
@@ -631,39 +734,44 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
     A.nsp = 1; A.SB = A.S; A.OSA = A.OS; A.OSB = A.OS;
     A.lin = (A.OS == 1 && A.oh0 == 0 && A.ow0 == 0 && A.DH == A.OA && A.DW == A.OB) ? 1 : 0;
   }
+#ifdef CONV_DEBUG
+  { const char* e = getenv("AVSR_CONV_DBG"); A.dbg = e ? atoi(e) : 0; }
+#endif
   const int KQ = A.ntap * (A.CsL / 4), nch = (KQ + 3) / 4;
   const int NT = (A.nsp * A.Cd + 15) / 16;
   if (!(NT == 1 || NT == 2 || NT == 4) || nch > 18) return AVSR_ERR_UNSUPPORTED;
-  // a pass (F frames) must fit the 16 prefetch registers of a thread
+  if (A.Cs % 4 && nch > 5) return AVSR_ERR_UNSUPPORTED;
+  // a pass (F frames) must fit the prefetch registers of a staging thread
+  int Fcap = 16;
   if (A.Cs % 4 == 0) {
     const int rq = A.SW * A.Cs / 4;
     if (rq > 256 || rq < 1) return AVSR_ERR_UNSUPPORTED;
     const int rpp = 256 / rq, pfmax = nch > 9 ? 10 : 12;    // prefetch registers of the instantiation that takes this depth
-    while (A.F > 1 && A.F * ((A.SH + rpp - 1) / rpp) > pfmax) --A.F;
-    if (A.F * ((A.SH + rpp - 1) / rpp) > pfmax) return AVSR_ERR_UNSUPPORTED;
+    Fcap = pfmax / ((A.SH + rpp - 1) / rpp);
     A.m_rq = fmagic(rq); A.m_per = fmagic(A.SH * rq); A.m_sw = fmagic(A.SW);
   } else {
-    while (A.F > 1 && (A.F * A.SH * A.SW * A.Cs / 4 + 255) / 256 > 4) --A.F;
-    if ((A.F * A.SH * A.SW * A.Cs / 4 + 255) / 256 > 4 || (long)A.F * A.SH * A.SW * A.Cs >= 65536) return AVSR_ERR_UNSUPPORTED;
+    Fcap = (4 * 256 * 4) / (A.SH * A.SW * A.Cs);
+    while (Fcap > 0 && (long)Fcap * A.SH * A.SW * A.Cs >= 65536) --Fcap;
     A.m_rq = fmagic(A.Cs); A.m_per = fmagic(A.SH * A.SW * A.Cs); A.m_sw = fmagic(A.SW);
   }
-  if ((long)A.F * A.OA * A.OB >= 65536) return AVSR_ERR_UNSUPPORTED;
+  if (Fcap < 1) return AVSR_ERR_UNSUPPORTED;
   if ((long)A.N * A.DH * A.DW * A.Cd * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;   // 32-bit byte offsets of the epilogue's buffer loads
+  if ((long)A.N * A.SH * A.SW * A.Cs * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;   // ... and of the staging loads
   A.m_opf = fmagic(A.OA * A.OB); A.m_ob = fmagic(A.OB);
-  // frames + the tile tables (window offsets; destination cells of non-linear destinations): <= 64 KB, two workgroups per CU
+  const int opf = A.OA * A.OB, mstep = 4 / NT;
+  const size_t frame_b = sizeof(float) * (size_t)(A.SH + 2) * (A.SW + 2) * A.CsL;
   auto lds_bytes = [&](int F) {
-    const size_t rows_pad = (((size_t)F * A.OA * A.OB + 15) / 16) * 16;
-    return sizeof(float) * (size_t)F * (A.SH + 2) * (A.SW + 2) * A.CsL + 4 * rows_pad * (A.lin ? 1 : 2);
+    const size_t rows_pad = (((size_t)F * opf + 15) / 16) * 16;
+    return F * frame_b + 4 * rows_pad * 2;
   };
-  while (A.F > 1 && lds_bytes(A.F) > 64 * 1024) --A.F;
-  {
-    // Frames per pass: the kernel's time is (passes of the busiest workgroup) x (row tiles of a pass per wave); both are ceilings, and
-    // on the small maps their product swings by 30 % with F (4800 frames of 5x5 positions on 512 workgroups: F = 4 -> 3 rounds x 7
-    // tiles, F = 5 -> 2 rounds x 8 tiles).  Take the feasible F with the smallest product (ties: the larger F, fewer barriers).
-    const int slots = 512, mstep = 4 / NT, opf = A.OA * A.OB;
+  // Frames per pass: the kernel's time is (passes of the busiest workgroup) x (row tiles of a pass per wave); both are ceilings, and
+  // on the small maps their product swings by 30 % with F (4800 frames of 5x5 positions on 512 workgroups: F = 4 -> 3 rounds x 7
+  // tiles, F = 5 -> 2 rounds x 8 tiles).  Take the feasible F with the smallest product (ties: the larger F, fewer barriers).
+  auto pick = [&](size_t budget, int slots) {
     double best = -1.0;
-    int bestF = A.F;
-    for (int F = A.F; F >= 1; --F) {
+    int bestF = 0;
+    for (int F = (Fcap < 16 ? Fcap : 16); F >= 1; --F) {
+      if (lds_bytes(F) > budget || (long)F * opf >= 65536) continue;
       const long units = (A.N + F - 1) / F, full = units / slots, rem = units - full * slots;
       // a partial last round runs on a half-empty chip: cheaper than a full one (measured on the 9x9 layers), not free
       const double rounds = (double)full + (rem ? 0.5 + 0.5 * (double)rem / slots : 0.0);
@@ -671,38 +779,39 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
       const double cost = rounds * (double)(per_wave * 8 + 16);     // (+ a pass's fixed part: staging, barriers, pipeline fill ~ two tiles)
       if (best < 0.0 || cost < 0.97 * best) { best = cost; bestF = F; }
     }
-    A.F = bestF;
-  }
+    return bestF;
+  };
+  A.F = pick(64 * 1024, 512);                            // two 256-thread workgroups per CU
+  if (!A.F) return AVSR_ERR_UNSUPPORTED;
   size_t lds = lds_bytes(A.F);
-  if (lds > 64 * 1024) return AVSR_ERR_UNSUPPORTED;
   if (lds < sizeof(float) * 4 * 4 * 2 * 4) lds = sizeof(float) * 4 * 4 * 2 * 4;      // the statistics reduction's staging area
   int grid = (A.N + A.F - 1) / A.F;
-  int wpc = (int)((150 * 1024) / (lds + 512));          // workgroups per CU that fit
-  if (wpc > 2) wpc = 2;                                 // (three per CU measured slower, one per CU 25 % slower)
-  if (wpc < 1) wpc = 1;
-  if (grid > 256 * wpc) grid = 256 * wpc;
-  if (A.Cs % 4 && nch > 5) return AVSR_ERR_UNSUPPORTED;
+  if (grid > 512) grid = 512;
   if (dry) return grid;
   ProfScope ps(kind, s, flops);
   const bool emap = A.res != nullptr || A.bnb_x != nullptr;
   if (A.res && A.bnb_x) return AVSR_ERR_ARG;            // one extra epilogue map at a time
   const int ep = (emap ? 1 : 0) | (A.beta != 0.f ? 2 : 0);
+  if (A.Cs % 4 && ep != 0) return AVSR_ERR_UNSUPPORTED;   // the 3-channel crops are only ever a forward source
+#define CG_ONE(M_, C_, E_)                                                                                          \
+  {                                                                                                                 \
+    hipLaunchKernelGGL((conv_gen_kernel<M_, C_, E_>), dim3(grid), dim3(256), lds, s, A);                            \
+  }
 #define CG_GO(M_, C_)                                                                                              \
   switch (ep) {                                                                                                    \
-    case 0: hipLaunchKernelGGL((conv_gen_kernel<M_, C_, 0>), dim3(grid), dim3(256), lds, s, A); break;             \
-    case 1: hipLaunchKernelGGL((conv_gen_kernel<M_, C_, 1>), dim3(grid), dim3(256), lds, s, A); break;             \
-    case 2: hipLaunchKernelGGL((conv_gen_kernel<M_, C_, 2>), dim3(grid), dim3(256), lds, s, A); break;             \
-    default: hipLaunchKernelGGL((conv_gen_kernel<M_, C_, 3>), dim3(grid), dim3(256), lds, s, A); break;            \
+    case 0: CG_ONE(M_, C_, 0) break;                                                                               \
+    case 1: CG_ONE(M_, C_, 1) break;                                                                               \
+    case 2: CG_ONE(M_, C_, 2) break;                                                                               \
+    default: CG_ONE(M_, C_, 3) break;                                                                              \
   }
-  if (A.Cs % 4) {
-    if (ep != 0) return AVSR_ERR_UNSUPPORTED;           // the 3-channel crops are only ever a forward source
-    hipLaunchKernelGGL((conv_gen_kernel<5, false, 0>), dim3(grid), dim3(256), lds, s, A);
-  } else if (nch <= 2) { CG_GO(2, true) }
+  if (A.Cs % 4) CG_ONE(5, false, 0)
+  else if (nch <= 2) { CG_GO(2, true) }
   else if (nch <= 6) { CG_GO(6, true) }
   else if (nch <= 9) { CG_GO(9, true) }
   else if (nch <= 18) { CG_GO(18, true) }
   else return AVSR_ERR_UNSUPPORTED;                     // K > 288 (64-channel sources) stays on im2col + GEMM
 #undef CG_GO
+#undef CG_ONE
   if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
   return grid;
 }

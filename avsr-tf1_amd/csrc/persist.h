@@ -77,6 +77,22 @@ __device__ __forceinline__ f32x4 ldb4(__amdgpu_buffer_rsrc_t r, int byte_off) {
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
   return __builtin_bit_cast(f32x4, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+// A 16-byte buffer load the compiler's wait-count pass does not see (same 2 GiB resource as make_rsrc, as four SGPR words).  The
+// pass flushes vmcnt(0) in the preheader of any loop that contains stores whenever loads issued before the loop are still in flight
+// (SIInsertWaitcnts "flush in preheader"), which serialises a register prefetch with the very loop it is meant to overlap; a hidden
+// load leaves the wait to the caller (vm_wait_all() before the first use of the destination).  The compiler's own waits stay safe:
+// vmcnt counts in order, so extra older operations can only make one of its waits longer, never shorter.
+typedef int i32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_ make_rsrc_words(const void* p) {
+  const unsigned long a = reinterpret_cast<unsigned long>(p);
+  i32x4_ r = {__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu)), (int)0x80000000, 0x00020000};
+  return r;
+}
+__device__ __forceinline__ void ldb4_hidden(f32x4& d, i32x4_ rs, int byte_off) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d) : "v"(byte_off), "s"(rs));
+}
+__device__ __forceinline__ void vm_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void vm_landed(f32x4& d) { asm volatile("" : "+v"(d)); }   // orders the uses of d behind vm_wait_all()
 __device__ __forceinline__ float ldb1(__amdgpu_buffer_rsrc_t r, int byte_off) {
   return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
