@@ -120,9 +120,14 @@ class Seq2SeqModel:
         self.params, self.adam_m, self.adam_v = z(nt), z(nt), z(nt)
         # the batch loss lives in the 4-float tail of the gradient buffer: a data-parallel trainer sums gradients AND loss over the
         # ranks with ONE all-reduce of grads_and_loss (parallel.py)
-        self.grads_and_loss = z(max(nt, 4) + 4)
+        # ... and, behind the loss, a mirror of the non-trainable state (batch-norm moving statistics): under data parallelism each rank
+        # writes stats / world there at the end of the backward pass and reads the rank AVERAGE back before the update, so the replicas'
+        # moving statistics stay identical even for the batch norms that normalise with per-rank statistics (the lip CNN's)
+        self.grads_and_loss = z(max(nt, 4) + 4 + max(ns, 4))
         self.grads = self.grads_and_loss[:max(nt, 4)]
         self.stats = z(ns)
+        self.n_stats, self._stats_mirror_off = ns, max(nt, 4) + 4
+        self.dp_world = 1                         # set by DataParallelTrainer
         self.n_train = nt
         self.step = z(1, torch.int32)[:1]
         # RNG key of the stateless dropout / sampling masks: global step + seed_offset (data parallel: rank << 24, so that row i of
@@ -1430,11 +1435,22 @@ class Seq2SeqModel:
             self._encode_backward(ws, batch)
         finally:
             ops.colsum_batch_end(self.scratch)
+        self._dp_stats_pack()
 
     def backward(self):
         """BPTT through decoder and encoders; leaves the full gradient in self.grads (engine layout)."""
         self.backward_decoder()
         self.backward_encoders()
+
+    def _dp_stats_pack(self):
+        """Data parallel: this rank's share (1 / world) of the moving statistics into the all-reduced buffer's tail."""
+        if self.dp_world > 1 and self.n_stats > 0:
+            ops.colsum(ops.mat(self.stats, self.n_stats), 1, self.n_stats, self.grads_and_loss, self.scratch, alpha=1.0 / self.dp_world,
+                       out_offset=self._stats_mirror_off)
+
+    def _dp_stats_unpack(self):
+        if self.dp_world > 1 and self.n_stats > 0:
+            ops.colsum(ops.mat(self.grads_and_loss, self.n_stats, offset=self._stats_mirror_off), 1, self.n_stats, self.stats, self.scratch)
 
     def decoder_grad_bucket(self):
         """(lo, hi) of the flat gradient buffer holding exactly the decoder's parameters (`dec/...`: embedding, cell, attention
@@ -1452,6 +1468,7 @@ class Seq2SeqModel:
     def apply_update(self):
         """L2 on the RNN kernels, global-norm clip, Adam, LR warm-up (seq2seq.py:175-178, :195-199, :245-257)."""
         cfg = self.cfg
+        self._dp_stats_unpack()                  # (data parallel: the rank average of the moving statistics, summed with the gradients)
         if cfg.recurrent_l2 is not None:
             ops.l2_regularise(self.l2_segments, self.params, self.grads, cfg.recurrent_l2, self.loss, self.scratch)
         if self.use_cnn:                         # conv2d kernel_regularizer l2(0.001), seq2seq.py:180-184

@@ -33,6 +33,8 @@ class DataParallelTrainer:
         self.world = dist.get_world_size() if dist is not None else 1
         # force_collectives: issue every collective even at world size 1 (exercises the RCCL path on a single-GPU box)
         self.collective = self.world > 1 or bool(force_collectives and dist is not None)
+        if hasattr(model, "dp_world"):
+            model.dp_world = self.world           # the moving statistics travel (averaged) in the gradient all-reduce's tail
         self.use_graph = use_graph
         self.mode = "eager"
         self._want_graph = use_graph

@@ -289,8 +289,10 @@ def main():
                    "scheduled_sampling": cfg.sampling_probability,
                    "collectives_per_step": (2 if world > 1 else 0),
                    "dp_batch_norm": ("encoder-input batch norms use the statistics of the GLOBAL batch (fp64 moments in the step's one small "
-                                     "all-reduce); the batch norms inside the lip CNN (and the input batch norm of the CNN-fed stream) use PER-RANK "
-                                     "statistics -- a documented deviation from one engine on the whole batch") if world > 1 else None,
+                                     "all-reduce); the batch norms inside the lip CNN (and the input batch norm of the CNN-fed stream) NORMALISE with PER-RANK "
+                                     "statistics -- a documented deviation from one engine on the whole batch; their moving averages are averaged "
+                                     "over the ranks in the gradient all-reduce's tail, so replicas stay bit-identical "
+                                     "(tests/test_gpu_dp.py::test_two_ranks_with_the_lip_cnn)") if world > 1 else None,
                    "parity": "vs CPU restatement of TF-1.13.1 semantics; TF parity unpinned"},
         "final_loss": round(loss, 5),
     }
