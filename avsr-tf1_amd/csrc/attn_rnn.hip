@@ -410,6 +410,9 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
     if (prc == AVSR_OK) l_first = l_end;
     else if (prc != AVSR_ERR_UNSUPPORTED) return prc;
   }
+  // beam search: the per-step unfinished counters [L] of this call's range, zeroed once (not one fill per step)
+  if (d.mode == 3 && l_first < l_end && avsr::dev_zero(d.n_unfinished + l_first, sizeof(int32_t) * (l_end - l_first), s) != hipSuccess)
+    return AVSR_ERR_HIP;
   for (int l = l_first; l < l_end; ++l) {
     // ---- K1: LSTM step -------------------------------------------------------------------
     for (int phase = 0; phase < (gru ? 2 : 1); ++phase) {
@@ -557,7 +560,6 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
                            d.ids + l, (long)L, d.tok, d.steplen, d.n_unfinished, B, l, d.eos_id);
       } else if (d.mode == 3) {
         const int K = d.beam_width, pin = l & 1, pout = (l + 1) & 1;
-        if (avsr::dev_zero(d.n_unfinished + l, sizeof(int32_t), s) != hipSuccess) return AVSR_ERR_HIP;   // per-step count [L]
         hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(64), (2 * K * d.V + 3 * K) * sizeof(float), s, d.logits + (long)l * d.V,
                            (long)L * d.V, d.V, K, l, d.eos_id, d.length_penalty, d.beam_logp + (long)pin * B, d.beam_fin + (long)pin * B,
                            d.beam_len + (long)pin * B, d.beam_logp + (long)pout * B, d.beam_fin + (long)pout * B,
