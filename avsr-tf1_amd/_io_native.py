@@ -53,7 +53,7 @@ def load():
             lib = C.CDLL(build(force=True))                  # a stale build of an older ABI: rebuild once
             if lib.avsr_io_abi_version() != 2:
                 raise RuntimeError("libavsr_io.so: ABI version mismatch")
-        pp, pl = C.POINTER(C.c_char_p), C.POINTER(C.c_int64)
+        pp, pl = C.POINTER(C.c_void_p), C.POINTER(C.c_int64)
         lib.avsr_io_index.argtypes = [C.c_int32, pp, pl, C.c_void_p, C.c_int32]
         lib.avsr_io_fill_f32.argtypes = [C.c_int32, pp, pl, pl, pl, pl, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32]
         lib.avsr_io_fill_labels.argtypes = [C.c_int32, pp, pl, pl, pl, C.c_int32, C.c_void_p, C.c_int64]
@@ -71,22 +71,38 @@ def _i64(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_int64))
 
 
+def _ptrs(payloads):
+    """Pointer array over payloads that are `bytes` or memory-mapped record windows (io_utils._Rec: `.addr`).  The caller keeps the
+    payloads alive for the duration of the native call."""
+    n = len(payloads)
+    arr = (C.c_void_p * n)()
+    for i, p in enumerate(payloads):
+        a = getattr(p, "addr", None)
+        arr[i] = a if a is not None else C.cast(C.c_char_p(p), C.c_void_p).value
+    return arr
+
+
 def index(payloads):
     """[bytes] -> int64 array [n, NFIELD] (fields: F)."""
     n = len(payloads)
     out = np.zeros((n, NFIELD), np.int64)
     lens, lp = _i64([len(p) for p in payloads])
-    _lib.avsr_io_index(n, (C.c_char_p * n)(*payloads), lp, out.ctypes.data, THREADS)
+    _lib.avsr_io_index(n, _ptrs(payloads), lp, out.ctypes.data, THREADS)
     return out
 
 
-def fill_f32(payloads, off, stride, steps, step_floats, Tmax, row_shape):
-    """Zero-padded [n, Tmax, *row_shape] float32 batch from the records' value regions."""
+def fill_f32(payloads, off, stride, steps, step_floats, Tmax, row_shape, out=None):
+    """Zero-padded [n, Tmax, *row_shape] float32 batch from the records' value regions; `out`: a C-contiguous float32 array of that
+    shape to fill (a window of a reused, possibly page-locked buffer) instead of a fresh allocation."""
     n = len(payloads)
     row = int(np.prod(row_shape)) if len(row_shape) else 1
-    dst = np.empty((n, Tmax) + tuple(row_shape), np.float32)          # the helper writes every byte (values, then zero padding)
+    if out is not None:
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.shape == (n, Tmax) + tuple(row_shape)
+        dst = out
+    else:
+        dst = np.empty((n, Tmax) + tuple(row_shape), np.float32)      # the helper writes every byte (values, then zero padding)
     (o, op), (s, sp), (t, tp), (ln, lp) = _i64(off), _i64(stride), _i64(steps), _i64([len(p) for p in payloads])
-    _lib.avsr_io_fill_f32(n, (C.c_char_p * n)(*payloads), lp, op, sp, tp, int(step_floats), dst.ctypes.data, int(Tmax), row, THREADS)
+    _lib.avsr_io_fill_f32(n, _ptrs(payloads), lp, op, sp, tp, int(step_floats), dst.ctypes.data, int(Tmax), row, THREADS)
     return dst
 
 
@@ -94,5 +110,5 @@ def fill_labels(payloads, off, stride, cnt, eos, Lmax):
     n = len(payloads)
     dst = np.zeros((n, Lmax), np.int32)
     (o, op), (s, sp), (c, cp) = _i64(off), _i64(stride), _i64(cnt)
-    _lib.avsr_io_fill_labels(n, (C.c_char_p * n)(*payloads), op, sp, cp, int(eos), dst.ctypes.data, int(Lmax))
+    _lib.avsr_io_fill_labels(n, _ptrs(payloads), op, sp, cp, int(eos), dst.ctypes.data, int(Lmax))
     return dst

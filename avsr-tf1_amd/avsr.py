@@ -172,7 +172,12 @@ class AVSR(object):
                 seed_t = seed_t.cuda()
             _dist.broadcast(seed_t, src=0)
             self._shuffle_seed = int(seed_t.item())
-        self._trainer = DataParallelTrainer(self._model, self._dist, use_graph=False, check_every_step=True)   # bucketed batches: shapes vary per step
+        # bucketed batches: shapes vary per step, but full buckets at the longest lengths come back -- a shape is captured into a hipGraph
+        # at its second sighting and replayed from then on (AVSR_TRAIN_GRAPH=0: eager launches only)
+        # (profiling=True brackets every launch with an event pair: eager launches)
+        self._trainer = DataParallelTrainer(self._model, self._dist,
+                                            use_graph=os.environ.get("AVSR_TRAIN_GRAPH", "1") != "0" and not self._profiling,
+                                            check_every_step=True, graph_after=2)
 
     # ------------------------------------------------------------------------------------------------
     def _iterator(self, mode):
@@ -192,8 +197,37 @@ class AVSR(object):
                                              max_sentence_length=self._max_sentence_length if self._audio_processing is not None else None,
                                              seed=seed, rank=rank, world=world)
 
+    @staticmethod
+    def _prefetched(it, depth=2):
+        """Batches of `it`, produced by a helper thread up to `depth` ahead: TFRecord indexing and the padding copies (ctypes calls into
+        libavsr_io.so, which release the GIL) run while the launching thread waits for the GPU step -- with the step replayed from a
+        hipGraph that thread is idle almost all of the time.  depth + 3 <= the pipeline's buffer ring (io_utils._Pipeline.RING): `depth` queued, one being filled, two held by the training
+        loop (the step in flight and the batch whose upload overlaps it)."""
+        import queue
+        import threading
+        q, end = queue.Queue(maxsize=depth), object()
+
+        def run():
+            try:
+                for b in it:
+                    q.put(b)
+                q.put(end)
+            except BaseException as e:                        # surfaces in the consumer
+                q.put(e)
+
+        threading.Thread(target=run, daemon=True).start()
+        while True:
+            x = q.get()
+            if x is end:
+                return
+            if isinstance(x, BaseException):
+                raise x
+            yield x
+
     def _to_batch(self, bd):
-        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda()
+        # (non_blocking: the big input arrays of a training batch live in page-locked ring buffers -- an asynchronous DMA, stream-ordered
+        # ahead of the step's kernels; for pageable arrays the flag changes nothing)
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda(non_blocking=True)
         b = Batch(labels=t(bd.labels, torch.int32), labels_len=t(bd.labels_length, torch.int32))
         if isinstance(bd.inputs, tuple):
             b.video, b.audio = t(bd.inputs[0], torch.float32), t(bd.inputs[1], torch.float32)
@@ -261,8 +295,34 @@ class AVSR(object):
             self._epoch_counter = epoch
             sum_loss, batches = 0.0, 0
             start = time.time()
-            for bd in self._iterator('train'):                # end of data = StopIteration (reference: OutOfRangeError)
-                batch, _names = self._to_batch(bd)
+            it = self._iterator('train')
+            if hasattr(it, "reuse_buffers") and os.environ.get("AVSR_IO_PREFETCH", "1") != "0":
+                it.reuse_buffers = True                       # each batch is consumed (copied to the device) before the one after next is asked for
+                it = self._prefetched(it, depth=2)            # (+ 2 batches held by the loop below: RING >= 5)
+            # The NEXT batch's host-to-device copy (85 MB of lip crops + audio at the benchmark shape: ~1.5 ms of PCIe) runs on a copy
+            # stream while the current step computes: it is started before the step is launched (the trainer waits for the GPU inside
+            # train_step when it checks the persistent kernels' flag).
+            it = iter(it)
+            copy_stream = torch.cuda.Stream()
+
+            def upload(bd):
+                if bd is None:
+                    return None
+                with torch.cuda.stream(copy_stream):
+                    batch, _names = self._to_batch(bd)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                return batch, ev
+
+            nxt = upload(next(it, None))
+            while nxt is not None:                            # end of data = StopIteration (reference: OutOfRangeError)
+                batch, ev = nxt
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev)
+                for t_ in vars(batch).values():               # allocated on the copy stream, consumed on this one
+                    if torch.is_tensor(t_):
+                        t_.record_stream(cur)
+                nxt = upload(next(it, None))                  # (the prefetch thread is normally ahead: no wait here)
                 if self._profiling:
                     ops.prof_begin(1 << 16)
                 loss, gnorm = self._trainer.train_step(batch)

@@ -16,6 +16,7 @@ produced by the official `protobuf` runtime in tests/test_io.py (and CRC32C agai
 """
 import collections
 import random
+import os
 import struct
 
 import numpy as np
@@ -72,6 +73,57 @@ def read_tfrecord(path, verify_crc=False):
             if verify_crc and _masked_crc(data) != struct.unpack("<I", tail)[0]:
                 raise IOError("corrupt TFRecord payload crc in %s" % path)
             yield data
+
+
+class _Rec:
+    """One record payload as a window of a memory-mapped TFRecord file: no copy is made when the file is read -- the native filler
+    copies the values straight from the page cache into the (pinned) batch buffer.  Behaves like `bytes` where the pipeline needs it
+    (len, slicing to bytes, bytes())."""
+    __slots__ = ("base", "off", "n")
+
+    def __init__(self, base, off, n):
+        self.base, self.off, self.n = base, off, n             # base: read-only uint8 array over the whole mapping
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            a, b, _ = k.indices(self.n)
+            return self.base[self.off + a:self.off + max(a, b)].tobytes()
+        return int(self.base[self.off + (k if k >= 0 else self.n + k)])
+
+    def __bytes__(self):
+        return self.base[self.off:self.off + self.n].tobytes()
+
+    @property
+    def addr(self):
+        return self.base.ctypes.data + self.off
+
+
+def read_tfrecord_mapped(path):
+    """Yield a _Rec for every record of a TFRecord file (the file is memory-mapped; framing as read_tfrecord, no crc check).
+    Empty files and platforms without mmap fall back to read_tfrecord's bytes."""
+    import mmap
+    try:
+        f = open(path, "rb")
+        size = os.fstat(f.fileno()).st_size
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) if size else None
+    except (OSError, ValueError):
+        mm = None
+    if mm is None:
+        yield from read_tfrecord(path)
+        return
+    base = np.frombuffer(mm, dtype=np.uint8)                    # keeps the mapping alive for as long as a record refers to it
+    pos = 0
+    while pos < size:
+        if pos + 12 > size:
+            raise IOError("truncated TFRecord header in %s" % path)
+        length = int(base[pos:pos + 8].view("<u8")[0])
+        if pos + 12 + length + 4 > size:
+            raise IOError("truncated TFRecord payload in %s" % path)
+        yield _Rec(base, pos + 12, length)
+        pos += 12 + length + 4
 
 
 class TFRecordFileWriter:
@@ -368,6 +420,38 @@ class _Pipeline:
         self.shuffle_buffer = 5000
         from . import _io_native
         self.native = _io_native if _io_native.load() is not None else None
+        # reuse_buffers (set by AVSR.train / evaluate, which consume a batch before asking for the one after next): the padded input
+        # arrays of a batch are windows of a small ring of host buffers -- page-locked when a GPU is present, so the host-to-device
+        # copy is an asynchronous DMA from the very buffer the filler wrote -- instead of fresh allocations (a 75 MB lip-crop batch
+        # otherwise costs 18 000 page faults before the first byte is copied).  Off by default: a caller may keep batches.
+        self.reuse_buffers = False
+        self._ring, self._ring_pos, self.RING = {}, {}, 6
+
+    def _out_buffer(self, key, shape):
+        """A float32 array of `shape` inside the next slot of ring `key` (or None: let the filler allocate)."""
+        if not self.reuse_buffers:
+            return None
+        n = int(np.prod(shape))
+        slots = self._ring.get(key)
+        if slots is None or slots[0][1].size < n:
+            cap = max(n, 0 if slots is None else 2 * slots[0][1].size)
+            slots = []
+            for _ in range(self.RING):
+                keep, arr = None, None
+                try:
+                    import torch
+                    if torch.cuda.is_available():
+                        keep = torch.empty(cap, dtype=torch.float32, pin_memory=True)
+                        arr = keep.numpy()
+                except Exception:
+                    keep = None
+                if arr is None:
+                    arr = np.empty(cap, np.float32)
+                slots.append((keep, arr))
+            self._ring[key], self._ring_pos[key] = slots, 0
+        i = self._ring_pos[key]
+        self._ring_pos[key] = (i + 1) % self.RING
+        return slots[i][1][:n].reshape(shape)
 
     def _key(self, ex):
         return ex[0][0][2] // self.bucket_width                # first stream's input_length (video for AV)
@@ -398,8 +482,8 @@ class _Pipeline:
                         r[F["in_T"]] == r[F["input_length"]] and r[F["in_F"]] == sizes[k] and \
                         (r[F["aus_T"]] == 0 or (r[F["aus_F"]] == 2 and r[F["aus_T"]] == r[F["input_length"]]))
                 if not ok:                                  # unusual layout: the generic parser decides (and raises what it raises)
-                    streams = [_parse_input(p, shp[0]) + (None, None) for p, shp in zip(recs[:-1], self.shapes)]
-                    lab = _parse_labels(recs[-1], self.eos)
+                    streams = [_parse_input(bytes(p), shp[0]) + (None, None) for p, shp in zip(recs[:-1], self.shapes)]
+                    lab = _parse_labels(bytes(recs[-1]), self.eos)
                     lab = lab + (None, None, lab[0].shape[0])
                 else:
                     streams = []
@@ -423,10 +507,13 @@ class _Pipeline:
             yield from flush(chunk)
 
     def _examples(self):
-        its = [read_tfrecord(r) for r in self.data_records] + [read_tfrecord(self.label_record)]
         if self.native is not None:
+            # memory-mapped records: the shuffle buffer then holds 5000 (offset, length) windows, not 5000 payload copies, and a value
+            # is copied exactly once -- page cache -> batch buffer -- by the filler's threads
+            its = [read_tfrecord_mapped(r) for r in self.data_records] + [read_tfrecord_mapped(self.label_record)]
             yield from self._examples_native(its)
             return
+        its = [read_tfrecord(r) for r in self.data_records] + [read_tfrecord(self.label_record)]
         for recs in zip(*its):
             streams = [_parse_input(p, shp[0]) for p, shp in zip(recs[:-1], self.shapes)]
             lab = _parse_labels(recs[-1], self.eos)
@@ -468,9 +555,10 @@ class _Pipeline:
         rows = [s[5] if s[0] is None else None for s in st]
         col = lambda name: [0 if r is None else int(r[F[name]]) for r in rows]
         step = max(col("in_F"))
-        x = N.fill_f32(pls, col("in_off"), col("in_stride"), col("in_T"), step, T, shape)
+        x = N.fill_f32(pls, col("in_off"), col("in_stride"), col("in_T"), step, T, shape, out=self._out_buffer((k, "x"), (len(st), T) + shape))
         has_aus = any(r is not None and r[F["aus_T"]] > 0 for r in rows) or any(s[0] is not None and s[1] is not None for s in st)
-        aus = N.fill_f32(pls, col("aus_off"), col("aus_stride"), col("aus_T"), 2, T, (2,)) if has_aus else None
+        aus = N.fill_f32(pls, col("aus_off"), col("aus_stride"), col("aus_T"), 2, T, (2,),
+                         out=self._out_buffer((k, "aus"), (len(st), T, 2))) if has_aus else None
         for i, s in enumerate(st):                                              # the few generically parsed ones
             if s[0] is not None:
                 x[i, :s[0].shape[0]] = s[0]

@@ -28,7 +28,7 @@ _FIELDS = ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_
 class DataParallelTrainer:
     MAX_GRAPHS = 24          # captured shapes kept (bucketed training visits many): least recently used is dropped with its buffers
 
-    def __init__(self, model, dist=None, use_graph=True, sync_bn=True, force_collectives=False, check_every_step=True):
+    def __init__(self, model, dist=None, use_graph=True, sync_bn=True, force_collectives=False, check_every_step=True, graph_after=1):
         self.model, self.dist = model, dist
         self.world = dist.get_world_size() if dist is not None else 1
         # force_collectives: issue every collective even at world size 1 (exercises the RCCL path on a single-GPU box)
@@ -39,6 +39,11 @@ class DataParallelTrainer:
         self.mode = "eager"
         self._want_graph = use_graph
         self._graphs = OrderedDict()            # key -> (forward+backward graph, update graph, pinned workspace key)
+        # graph_after: a batch shape is captured at its graph_after-th sighting and launched eagerly before (bucketed training:
+        # most (B, T_a, T_v, L) shapes of an epoch never come back, and capturing one costs a second pass of python launches plus a
+        # pinned workspace; the shapes that do repeat -- full buckets at the maximum lengths -- are replayed from then on)
+        self.graph_after = max(1, int(graph_after))
+        self._seen = OrderedDict()
         self._checked = False
         # read the persistent kernels' sticky "wait expired" flag before EVERY update (one small host sync per step) and redo the
         # pass through the per-step launches if it is set.  Default ON: a flagged pass holds invalid activations, and training on
@@ -231,7 +236,14 @@ class DataParallelTrainer:
             if self.sync_bn:
                 dist.all_reduce(m.bn_sync_sums(batch))
                 dist.all_reduce(m.bn_sync_squares(batch))
-        if not self.use_graph:
+        eager_now = not self.use_graph
+        if self.use_graph and self.graph_after > 1 and key not in self._graphs:
+            n = self._seen.pop(key, 0) + 1
+            self._seen[key] = n
+            while len(self._seen) > 4096:
+                self._seen.popitem(last=False)
+            eager_now = n < self.graph_after
+        if eager_now:
             if self.collective:
                 self._fwd_bwd_collective(batch)
             else:

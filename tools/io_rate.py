@@ -1,5 +1,5 @@
 """Host-side rate of the TFRecord input pipeline (read + index/parse + shuffle + bucket + pad): the native indexer / batch filler
-(libavsr_io.so) against the python parser.  python tools/io_rate.py [n_utt] [video]   (video: 75 x 36x36x3 lip crops + audio)"""
+(libavsr_io.so) against the python parser.  python tools/io_rate.py [n_utt] [video] [reuse]   (video: 75 x 36x36x3 lip crops + audio)"""
 import os
 import sys
 import tempfile
@@ -27,6 +27,7 @@ if __name__ == "__main__":
             if video:
                 Tv = T * 75 // 500
                 fv.write(IO.make_video_example("u%d" % i, rng.standard_normal((Tv, 36, 36, 3)).astype(np.float32)))
+    reuse = "reuse" in sys.argv                      # batch buffers from the pipeline's ring (what AVSR.train asks for)
     for native in (False, True):
         if video:
             pipe = IO.make_iterator_from_two_records(v, a, l, batch_size=64, unit_dict=ud, shuffle=True, bucket_width=45, seed=0)
@@ -34,8 +35,9 @@ if __name__ == "__main__":
             pipe = IO.make_iterator_from_one_record(a, l, ud, batch_size=64, shuffle=True, bucket_width=45, seed=0)
         if not native:
             pipe.native = None
+        pipe.reuse_buffers = reuse and native
         for rep in range(2):
             t0 = time.perf_counter()
             cnt = sum(b.labels.shape[0] for b in pipe)
             dt = time.perf_counter() - t0
-        print("%s parser: %d utterances in %.2f s = %.0f utt/s" % ("native" if native else "python", cnt, dt, cnt / dt), flush=True)
+        print("%s parser%s: %d utterances in %.2f s = %.0f utt/s" % ("native" if native else "python", " + buffer ring" if pipe.reuse_buffers else "", cnt, dt, cnt / dt), flush=True)
