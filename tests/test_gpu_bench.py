@@ -76,3 +76,39 @@ def test_queued_graph_replays_equal_eager_steps(front, fresh):
         del t, m
         torch.cuda.empty_cache()
     assert losses["eager"] == losses["graph"], losses
+
+
+def test_graph_capture_at_the_second_sighting_of_a_batch_shape():
+    """AVSR.train's policy (graph_after=2): a batch shape runs eagerly the first time it is seen and is captured the second time, other
+    shapes in between stay eager; the parameters after the sequence equal those of eager-only training bit for bit."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import dataclasses
+    import numpy as np
+    import torch
+    from avsr_tf1_amd.config import ModelConfig
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    from avsr_tf1_amd.parallel import DataParallelTrainer
+    from oracle import avsr_oracle as O
+    ocfg = O.OracleConfig(architecture="bimodal", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32), decoder_units=(32,),
+                          embedding_size=16, video_feat=12, audio_feat=20, regress_aus=True, use_dropout=False, warmup_steps=0)
+    mcfg = ModelConfig(**{f.name: getattr(ocfg, f.name) for f in dataclasses.fields(ModelConfig) if hasattr(ocfg, f.name)})
+    W = O.init_params(ocfg, seed=3)
+    big = Batch.from_numpy(O.synthetic_batch(ocfg, B=4, T_a=17, T_v=7, L=6, ragged=True))
+    small = Batch.from_numpy(O.synthetic_batch(ocfg, B=3, T_a=11, T_v=5, L=4, ragged=True, seed=77))
+    order = [big, small, big, big, small, big]
+    out = {}
+    for mode in ("eager", "second"):
+        m = Seq2SeqModel(mcfg, weights=W)
+        t = DataParallelTrainer(m, None, use_graph=(mode == "second"), graph_after=2)
+        modes = []
+        for b in order:
+            t.train_step(b)
+            torch.cuda.synchronize()
+            modes.append((t.mode, len(t._graphs)))
+        if mode == "second":
+            # big: eager, (small: eager), big: captured, big: replayed, small: captured, big: replayed
+            assert [n for _, n in modes] == [0, 0, 1, 1, 2, 2] and modes[-1][0] == "hipgraph", modes
+        out[mode] = m.export_tf_weights("params")
+    for k, v in out["eager"].items():
+        assert np.array_equal(v, out["second"][k]), k

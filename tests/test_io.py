@@ -355,3 +355,43 @@ def test_native_indexer_rejects_corrupt_lengths_and_the_filler_stays_inside_its_
     assert np.array_equal(out[1, 0], np.arange(4, dtype=np.float32)) and not out[1, 1].any()
     out = N.fill_f32([pay], [40], [16], [5], 4, 8, (4,))                     # offset near the end of the payload: nothing readable
     assert not out.any()
+
+
+def test_mapped_records_ring_buffers_and_prefetch(tmp_path):
+    """The memory-mapped reader yields the records read_tfrecord yields; batches filled into the pipeline's buffer ring (what AVSR.train
+    asks for) equal freshly allocated ones when each is consumed before the next-but-RING-1 is produced, and really are windows of
+    RING reused buffers; the prefetch generator keeps the order and hands the producer's exception to the consumer."""
+    from avsr_tf1_amd import _io_native as N
+    from avsr_tf1_amd.avsr import AVSR
+    assert N.load() is not None
+    ud, a, l, v, feats, labs, vids = _write_dataset(str(tmp_path), n=40)
+    for rec in (a, l, v):
+        plain, mapped = list(IO.read_tfrecord(rec)), list(IO.read_tfrecord_mapped(rec))
+        assert len(plain) == len(mapped) == 40
+        assert all(bytes(m) == p and len(m) == len(p) and m[3:9] == p[3:9] and m[-1] == p[-1] for m, p in zip(mapped, plain))
+    empty = str(tmp_path / "empty.tfrecord")
+    open(empty, "wb").close()
+    assert list(IO.read_tfrecord_mapped(empty)) == []
+    make = lambda: IO.make_iterator_from_two_records(v, a, l, batch_size=3, unit_dict=ud, shuffle=True, bucket_width=45, seed=2)
+    fresh = list(make())
+    ring = make()
+    ring.reuse_buffers = True
+    seen, n = {}, 0
+    for got, want in zip(AVSR._prefetched(ring, depth=2), fresh):        # consumed one at a time, as the training loop does
+        for x, y in zip(got.inputs, want.inputs):
+            assert x.shape == y.shape and np.array_equal(x, y)
+            seen.setdefault(x.ctypes.data, 0)
+            seen[x.ctypes.data] += 1
+        assert np.array_equal(got.payload["aus"], want.payload["aus"]) and np.array_equal(got.labels, want.labels)
+        n += 1
+    assert n == len(fresh) > 2 * ring.RING
+    # two streams x RING slots, used again and again (a ring is re-allocated, geometrically, when a larger batch shape arrives)
+    assert max(seen.values()) > 1 and len(seen) < 2 * n
+
+    def broken():
+        yield 1
+        raise KeyError("producer failed")
+    g = AVSR._prefetched(broken(), depth=2)
+    assert next(g) == 1
+    with pytest.raises(KeyError):
+        next(g)
