@@ -193,6 +193,141 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnLaunch L) {
   }
 }
 
+// Beam search (avsr_attn_rnn.mem_shared): the K hypotheses of an utterance attend the SAME memory.  One workgroup per (mechanism,
+// utterance, chunk of <= 64 frames) keeps the chunk's keys -- then its values -- in registers (64 per lane) and runs the K queries
+// over them: the memory is read once per step instead of K times (attn_fwd_kernel with K = 10: 770 MB of L2 traffic per decode
+// step, the whole 40 us).  Same arithmetic and summation order per hypothesis as attn_fwd_kernel (dot products by 16-lane groups,
+// softmax partials by one wave, context rows in row order then row groups in order), same outputs (raw scores, chunk max / sum,
+// un-normalised partial contexts by hypothesis row).  Luong / scaled Luong, H <= 256, chunk <= 64, D <= 1024, K <= 16.
+#define ATTN_BEAM_KMAX 16
+__global__ __launch_bounds__(256) void attn_fwd_beam_kernel(const AttnLaunch L) {
+  __shared__ float sc[ATTN_BEAM_KMAX][64];
+  __shared__ __attribute__((aligned(16))) float qs[ATTN_BEAM_KMAX][256];
+  __shared__ __attribute__((aligned(16))) float cpart[8 * 1024];          // [8 queries][row groups x columns] float4
+  int blk = blockIdx.x, mi = 0;
+  for (int i = 0; i < L.nmech; ++i) {
+    const int nb = (L.B / L.m[i].mem_div) * L.m[i].nchunk;
+    if (blk < nb) { mi = i; break; }
+    blk -= nb;
+  }
+  const AttnMechDev& M = L.m[mi];
+  const int K = M.mem_div, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blk % M.nchunk, u = blk / M.nchunk;
+  const int len = min(M.len ? M.len[u] : M.T, M.T);
+  const int t0 = c * M.chunk;
+  const int n = max(0, min(M.chunk, len - t0));
+  const int H = M.H, D = M.D;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- keys of the chunk: 16 lanes per row, rows rg + 16*u4 ----
+  const int s16 = tid & 15, rg = tid >> 4;
+  {
+    const __amdgpu_buffer_rsrc_t krs = make_rsrc(M.keys + (long)u * M.T * H);
+    f32x4 kr[4][4];
+#pragma unroll
+    for (int u4 = 0; u4 < 4; ++u4) {
+      const int r = rg + 16 * u4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * s16 + 64 * j;
+        kr[u4][j] = ldb4(krs, (r < n && k < H) ? ((t0 + r) * H + k) * 4 : P_OOB);
+      }
+    }
+    const float gsc = (M.type == ATT_SCALED_LUONG) ? M.g[0] : 1.f;
+    // the K queries go to the LDS in one round of loads (fetched one by one inside the loop each cost an L2 round trip)
+    for (int e = tid * 4; e < K * 256; e += 1024) {
+      const int kq = e >> 8, k = e & 255;
+      st4(&qs[kq][k], k < H ? ld4(M.query + (long)(u * K + kq) * M.query_sb + k) : zero4);
+    }
+    __syncthreads();
+    for (int kq = 0; kq < K; ++kq) {
+      const int b = u * K + kq;
+      f32x4 q4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q4[j] = ld4(&qs[kq][4 * s16 + 64 * j]);
+      float* srow = M.scores + (long)b * M.scores_sb + t0;
+#pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc += kr[u4][j][0] * q4[j][0] + kr[u4][j][1] * q4[j][1] + kr[u4][j][2] * q4[j][2] + kr[u4][j][3] * q4[j][3];
+        acc = group16_sum(acc);
+        const int r = rg + 16 * u4;
+        if (s16 == 0 && r < n) { srow[r] = acc; sc[kq][r] = acc * gsc; }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- chunk max / exp / sum per hypothesis: one wave per query, one lane per row ----
+  for (int kq = wave; kq < K; kq += 4) {
+    const int b = u * K + kq;
+    const float v = lane < n ? sc[kq][lane] : -INFINITY;
+    const float mx = wave_max(v);
+    const float pr = lane < n ? expf(v - mx) : 0.f;
+    const float lsum = wave_sum(pr);
+    sc[kq][lane] = pr;
+    if (lane == 0) {
+      M.pm[(long)c * L.B + b] = (n > 0) ? mx : -INFINITY;
+      M.pl[(long)c * L.B + b] = lsum;
+    }
+  }
+  __syncthreads();
+  // ---- partial contexts: one float4 column per thread, G row groups; the chunk's values stay in registers for the K queries ----
+  const int cols = D >> 2;
+  const __amdgpu_buffer_rsrc_t vrs = make_rsrc(M.values + (long)u * M.values_sb);
+  const int vst = (int)M.values_st * 4;
+  for (int cb = 0; cb < cols; cb += 256) {
+    const int ccols = min(256, cols - cb);
+    const int G = 256 / ccols;                           // 64 columns (D = 256): four row groups of 16 rows
+    const int col = tid % ccols, grp = tid / ccols;
+    const bool act = grp < G;
+    for (int r0 = 0; r0 < n; r0 += 16 * G) {            // (G >= 4 at D <= 256: one trip)
+      f32x4 vr[16];
+#pragma unroll
+      for (int uu = 0; uu < 16; ++uu) {
+        const int r = r0 + grp + G * uu;
+        vr[uu] = ldb4(vrs, (act && r < n) ? (t0 + r) * vst + (cb + col) * 16 : P_OOB);
+      }
+      for (int k0 = 0; k0 < K; k0 += 8) {
+        const int kn = min(8, K - k0);
+        if (G > 1) __syncthreads();
+        for (int kk = 0; kk < kn; ++kk) {
+          const float* w = sc[k0 + kk];
+          f32x4 acc = zero4;
+#pragma unroll
+          for (int uu = 0; uu < 16; ++uu) {
+            const int r = r0 + grp + G * uu;
+            acc += ((r < n) ? w[r] * 1.0f : 0.f) * vr[uu];
+          }
+          float* pout = M.pctx + ((long)c * L.B + (u * K + k0 + kk)) * D;
+          if (G == 1) {
+            if (r0 == 0) st4(pout + 4 * (cb + col), acc);
+            else st4(pout + 4 * (cb + col), ld4(pout + 4 * (cb + col)) + acc);
+          } else if (act) st4(&cpart[4 * ((kk * G + grp) * ccols + col)], acc);
+        }
+        if (G > 1) {
+          __syncthreads();
+          for (int it = tid; it < kn * ccols; it += 256) {
+            const int kk = it / ccols, cc = it - kk * ccols;
+            f32x4 sum = zero4;
+            for (int g2 = 0; g2 < G; ++g2) sum += ld4(&cpart[4 * ((kk * G + g2) * ccols + cc)]);
+            float* pout = M.pctx + ((long)c * L.B + (u * K + k0 + kk)) * D;
+            if (r0 == 0) st4(pout + 4 * (cb + cc), sum);
+            else st4(pout + 4 * (cb + cc), ld4(pout + 4 * (cb + cc)) + sum);
+          }
+        }
+      }
+    }
+    if (n == 0) {                                       // an empty chunk still defines its (zero) partial contexts
+      for (int it = tid; it < K * ccols; it += 256) {
+        const int kk = it / ccols, cc = it - kk * ccols;
+        st4(M.pctx + ((long)c * L.B + (u * K + kk)) * D + 4 * (cb + cc), zero4);
+      }
+    }
+  }
+}
+
 // Per-step backward.  Inputs: d ctx [B,D] (gradient of this step's context), the forward context,
 // the saved raw scores and softmax partial statistics of this step.  Outputs: d score [B,T] (wrt the
 // softmax input) and per-chunk partial gradients of the query.
@@ -380,7 +515,19 @@ extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stre
   const int nblk = L->blk_off[L->nmech];
   if (nblk <= 0) return AVSR_ERR_ARG;
   ProfScope ps(backward ? PROF_ATTN_BWD : PROF_ATTN_FWD, (hipStream_t)stream);
+  // beam search over shared memories: one workgroup per (utterance, chunk) runs the K hypotheses (attn_fwd_beam_kernel)
+  bool beam = !backward;
+  int nbeam = 0;
+  static int beam_on = -1;
+  if (beam_on < 0) { const char* e = getenv("AVSR_ATTN_BEAM"); beam_on = e ? (atoi(e) != 0) : 1; }
+  for (int i = 0; i < L->nmech && beam; ++i) {
+    const AttnMechDev& M = L->m[i];
+    beam = beam_on && M.mem_div > 1 && M.mem_div <= ATTN_BEAM_KMAX && L->B % M.mem_div == 0 && M.type <= ATT_SCALED_LUONG && M.H <= 256 &&
+           M.chunk <= 64 && M.D % 4 == 0 && M.D <= 1024 && (long)M.T * M.H * 4 < (1L << 31) && (long)M.T * M.values_st * 4 < (1L << 31);
+    nbeam += (L->B / (M.mem_div > 0 ? M.mem_div : 1)) * M.nchunk;
+  }
   if (backward) hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *L);
+  else if (beam) hipLaunchKernelGGL(attn_fwd_beam_kernel, dim3(nbeam), dim3(256), 0, (hipStream_t)stream, *L);
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *L);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
