@@ -630,6 +630,30 @@ __global__ __launch_bounds__(256) void colsum_multi_partial_kernel(const CsmLaun
     block_group_reduce(s, idx, F, G, red, J.part + (long)blk * F);
     return;
   }
+  // wide records (the [B*T, 4H] gate gradients: 131 MB each): 16-byte loads, eight rows in flight per thread -- a bandwidth stream,
+  // not a latency chain (two 4-byte loads in flight per thread ran at 2.4 TB/s)
+  const bool vec = (F & 3) == 0 && ((uintptr_t)a & 15) == 0 && (J.lda & 3) == 0 && (J.ldoa & 3) == 0 &&
+                   (!b || (((uintptr_t)b & 15) == 0 && (J.ldb & 3) == 0 && (J.ldob & 3) == 0));
+  if (vec) {
+    for (int f = threadIdx.x * 4; f < F; f += 4 * blockDim.x) {
+      f32x4 acc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int r = r0; r < r1; r += 8) {
+        f32x4 x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool in = r + u < r1;
+          x[u] = in ? ld4(a + rowoff(r + u, J.lda, J.Ta, J.ldoa) + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (b) y[u] = in ? ld4(b + rowoff(r + u, J.ldb, J.Tb, J.ldob) + f) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += b ? x[u] * y[u] : x[u];
+      }
+      st4(J.part + (long)blk * F + f, ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])));
+    }
+    return;
+  }
   for (int f = threadIdx.x; f < F; f += blockDim.x) {
     float s0 = 0.f, s1 = 0.f;
     int r = r0;

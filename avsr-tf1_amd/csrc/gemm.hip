@@ -296,6 +296,37 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_group_kernel(const GemmGroup 
 
 __device__ __forceinline__ void splitk_reduce_body(const GemmArgs& g, const long first, const long stride) {
   const long total = (long)g.batch * g.M * g.N;
+  // four consecutive columns per thread with 16-byte loads, eight slices in flight (the K = 32000 weight gradients are reduced from
+  // ~48 one-megabyte slabs each: scalar loads, four in flight, ran at 1.5 TB/s).  Every element keeps its summation order.
+  const bool vec = (g.N & 3) == 0 && ((uintptr_t)g.ws & 15) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.ldc & 3) == 0 && (g.sC & 3) == 0 &&
+                   (g.Tc == 0 || (g.ldoc & 3) == 0) && (!g.bias || ((uintptr_t)g.bias & 15) == 0);
+  if (vec) {
+    const long zs = (long)g.M * g.N;
+    const float al = g.alpha_dev ? g.alpha * g.alpha_dev[0] : g.alpha;
+    for (long i = first * 4; i < total; i += stride * 4) {
+      const int col = (int)(i % g.N);
+      const int row = (int)((i / g.N) % g.M);
+      const int bz = (int)(i / zs);
+      const float* w = g.ws + ((long)bz * g.splitk * g.M + row) * g.N + col;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      int z = 0;
+      for (; z + 8 <= g.splitk; z += 8) {
+        f32x4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = ld4(w + (z + u) * zs);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += a[u];
+      }
+      for (; z < g.splitk; ++z) s += ld4(w + z * zs);
+      float* c = g.C + (long)bz * g.sC +
+                 (g.Tc ? (long)(row / g.Tc) * g.ldoc + (long)(row % g.Tc) * g.ldc : (long)row * g.ldc) + col;
+      f32x4 v = al * s;
+      if (g.beta != 0.f) v += g.beta * ld4(c);
+      if (g.bias) v += ld4(g.bias + col);
+      st4(c, v);
+    }
+    return;
+  }
   for (long i = first; i < total; i += stride) {
     const int col = (int)(i % g.N);
     const int row = (int)((i / g.N) % g.M);
