@@ -517,7 +517,10 @@ struct WGArgs {
 };
 
 // MT: row tiles (16 rows of (tap, ci)) held per wave; NTC: column tiles; CH4: 4-channel-multiple input (row-structured staging)
-template <int MT, int NTC, bool CH4>
+// RS (row split): the four waves own DIFFERENT row tiles (wave w: rows [w*MT*16, (w+1)*MT*16)) and each walks every chunk, instead of
+// all waves sharing MT row tiles and splitting the chunks: a deep layer whose (tap, channel) rows exceed one wave's accumulators then
+// takes ONE launch -- its input staged once -- instead of one per tap group, and no cross-wave reduction at the end.
+template <int MT, int NTC, bool CH4, bool RS = false>
 __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kernel(const WGArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   int roff[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int row = mt * 16 + i;
+    const int row = (RS ? wave * MT * 16 : 0) + mt * 16 + i;
     const bool ok = row < Mrows;
     const int tl = ok ? row / CiL : 0, ci = ok ? row - tl * CiL : 0, t = A.t0 + tl, ti = t / A.kw, tj = t - ti * A.kw;
     roff[mt] = ok ? ((ti - A.pt) * PW + (tj - A.pl)) * CsP + ci : 0;
@@ -639,10 +642,12 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt) b[nt][e] = ldb1(dy_rs, (r0 + e < opf && nt * 16 + i < Co) ? (int)(o + (unsigned)((e * Co + nt * 16) * 4)) : P_OOB);
     };
-    if (wave < kch) load_b(wave, bn);
+    constexpr int KC0 = RS ? 0 : -1, KCS = RS ? 1 : 4;                // first chunk / chunk step of a wave
+    const int kc0 = KC0 < 0 ? wave : KC0;
+    if (kc0 < kch) load_b(kc0, bn);
     __syncthreads();
     if (n0 + gridDim.x * A.F < A.N) fetch(n0 + gridDim.x * A.F);      // next pass's frames: in flight during the MFMAs
-    for (int kc = wave; kc < kch; kc += 4) {
+    for (int kc = kc0; kc < kch; kc += KCS) {
       float av[MT][4], bv[NTC][4];
 #pragma unroll
       for (int nt = 0; nt < NTC; ++nt)
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
         for (int e = 0; e < 4; ++e) bv[nt][e] = bn[nt][e];
 #pragma unroll
       for (int nt = 0; nt < NTC; ++nt) bsum[nt] += (bv[nt][0] + bv[nt][1]) + (bv[nt][2] + bv[nt][3]);
-      if (kc + 4 < kch) load_b(kc + 4, bn);
+      if (kc + KCS < kch) load_b(kc + KCS, bn);
       const int f = fdiv(kc, m_cpf), r0 = (kc - f * cpf) * 16 + q * 4;
       int ho = fdiv(min(r0, opf - 1), A.m_wo), wo = min(r0, opf - 1) - ho * A.Wo;
       const float* xf = xs + f * xstride + (PW + 1) * CsP;
@@ -679,6 +684,23 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   // one partial per workgroup
   float* red = lds;                                     // [4][16][16]
   const int rr = tid >> 4, cc = tid & 15;
+  if (RS) {                                             // every wave writes its own rows: C[4q + r][i] of tile (mt, nt)
+    __syncthreads();                                    // (the staging area is free: the bias sums below reuse it)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wave * MT * 16 + mt * 16 + q * 4 + r;
+        if (row < Mrows) {
+          const int t = row / CiL, ci = row - t * CiL;
+          if (ci < Ci) {
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt)
+              if (nt * 16 + i < Co) A.part[(long)blockIdx.x * A.slab + ((long)t * Ci + ci) * Co + nt * 16 + i] = acc[mt][nt][r];
+          }
+        }
+      }
+  } else
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -696,7 +718,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   if (A.want_bias) {                                    // column sums of dy: lanes (q, wave) hold disjoint positions of column nt*16 + i
     __syncthreads();
 #pragma unroll
-    for (int nt = 0; nt < NTC; ++nt) red[((wave * 4 + q) * NTC + nt) * 16 + i] = bsum[nt];
+    for (int nt = 0; nt < NTC; ++nt) red[((wave * 4 + q) * NTC + nt) * 16 + i] = (RS && wave) ? 0.f : bsum[nt];   // (RS: every wave saw every chunk)
     __syncthreads();
     if (tid < NTC * 16) {
       const int nt = tid >> 4, ci = tid & 15;
@@ -1304,12 +1326,18 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
   if (wpc < 1) wpc = 1;
   hipStream_t s = S_(stream);
   bool bias_done = dbias == nullptr;
+  // deep layers (64 destination channels, more (tap, channel) rows than one wave's accumulators hold): the row-split form, one launch
+  static int rs_on = -1;
+  if (rs_on < 0) { const char* e = getenv("AVSR_WGRAD_RS"); rs_on = e ? (atoi(e) != 0) : 1; }
+  const int Mall = k * k * A.CiL;
+  const bool rs = rs_on && NTC == 4 && Ci % 4 == 0 && G < k * k && Mall <= 4 * 9 * 16;   // (32-column layers fit one launch already: no gain measured)
+  if (rs) G = k * k;
   for (int t0 = 0; t0 < k * k; t0 += G) {
     A.t0 = t0; A.nt = k * k - t0 < G ? k * k - t0 : G;
     A.want_bias = bias_done ? 0 : 1;
     const int wF = A.nt * Ci * Co;
     A.slab = wF + (A.want_bias ? Co : 0);
-    const int MT = (A.nt * A.CiL + 15) / 16;
+    const int MT = rs ? ((A.nt * A.CiL + 3) / 4 + 15) / 16 : (A.nt * A.CiL + 15) / 16;      // (rs: row tiles per WAVE)
     if (Ci % 4 && (MT > 3 || NTC != 1)) return AVSR_ERR_UNSUPPORTED;
     int grid = (N + A.F - 1) / A.F;
     const int cap = 256 * (A.slab > 2048 ? 1 : wpc);      // large kernels: the partial slabs, not the staging, are the traffic
@@ -1320,7 +1348,10 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
     {
       ProfScope ps(PROF_CONV_BWD_WEIGHT, s, 2.0 * N * Ho * Wo * (double)A.nt * Ci * Co);
 #define WG_GO(M_, N_, C_) hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_, C_>), dim3(grid), dim3(256), lds, s, A)
-      if (Ci % 4) WG_GO(3, 1, false);
+      if (rs) {
+        if (MT <= 5) hipLaunchKernelGGL((conv_wgrad_kernel<5, 4, true, true>), dim3(grid), dim3(256), lds, s, A);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<9, 4, true, true>), dim3(grid), dim3(256), lds, s, A);
+      } else if (Ci % 4) WG_GO(3, 1, false);
       else if (NTC == 1) { if (MT <= 5) WG_GO(5, 1, true); else if (MT <= 9) WG_GO(9, 1, true); else WG_GO(18, 1, true); }
       else if (NTC == 2) { if (MT <= 5) WG_GO(5, 2, true); else if (MT <= 9) WG_GO(9, 2, true); else WG_GO(18, 2, true); }
       else { if (MT <= 5) WG_GO(5, 4, true); else WG_GO(9, 4, true); }
