@@ -291,9 +291,18 @@ __global__ __launch_bounds__(256) void rnn_persist_fwd_kernel(const PLaunch L) {
 // R: rows per group.  8 for batches up to 64 utterances (all eight XCDs busy); 16 -- a full MFMA row tile, no padding rows -- for
 // larger batches: the same instruction count per step then carries twice the rows, so 128 utterances are ONE pass over the chip
 // instead of two sequential 64-row slices.
-template <int R>
+// Q4 (8-row groups, H = 256): the RECURRENT product runs on v_mfma_f32_4x4x1_16B_f32 with A-block broadcast instead of 16x16x4 tiles whose
+// second half is padding.  One instruction = 16 blocks of a 4x4x1 outer product; with cbsz = 3 the A operand (4 rows of h at one k) of
+// block `abid` of each 8-block half is broadcast to the half, so the two halves multiply rows 0-3 at TWO different k with the 8 x 4 = 32
+// gate columns of the workgroup (B: one weight per lane, no duplication); a second instruction takes rows 4-7 with the same weights.
+// 8 rows x 32 columns x 64 k of a wave = 64 instructions x 8 cycles = 512 matrix-pipe cycles per step instead of 32 x 32 = 1024, the
+// same 32 weight registers, and the h operand is 2 x 16 bytes per lane instead of 4.  (Layer 0 -- 64 columns, no input part -- uses
+// cbsz = 4: all 16 blocks share the rows, one k per instruction.)  Layout probed on gfx950: tools/mfma4_probe.hip.
+template <int R, bool Q4 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void rnn_persist_fwd_xcd_kernel(const PLaunch L) {
+  static_assert(!Q4 || R == 8, "4x4 recurrent product: 8-row groups");
   __shared__ __attribute__((aligned(16))) float red[4][4][R][16];
+  __shared__ __attribute__((aligned(16))) float red4[Q4 ? 2048 : 4];   // [4 waves][2 k-halves][8 rows][32 cols] / wide: [4][8][64]
   __shared__ int s_slot;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gx = __builtin_amdgcn_readfirstlane(xcc_id());
@@ -329,20 +338,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const long ldw = tk.in + H;
 
   f32x4 wa[P_XC][2], wb[P_HC][2];
+  // Q4: wq[ab] = W[column of this lane][k0 + 4*ab .. + 3] for the recurrent product (wide: 16 A-blocks; else 8, and wq[8 + 2c + nt]
+  // holds the input part's fragments, i.e. wa)
+  f32x4 wq[Q4 ? 16 : 1];
+  const int q4_col = (hoisted && UW == 16) ? lane : (lane & 31);                 // column of the workgroup this lane multiplies (B operand)
+  const int q4_kb = hg0 * 16 + ((hoisted && UW == 16) ? 0 : 32 * (lane >> 5));   // first k of this lane's half
+  if constexpr (Q4) {
+    const int col = col0 + q4_col;
+#pragma unroll
+    for (int ab = 0; ab < 16; ++ab) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ab < ((hoisted && UW == 16) ? 16 : 8) && col < 4 * H) v = ld4(tk.wt + (long)col * ldw + tk.in + q4_kb + 4 * ab);
+      wq[ab] = v;
+    }
+  }
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int col = col0 + nt * 16 + i;
 #pragma unroll
     for (int c = 0; c < P_HC; ++c) {
       const int k = (hg0 + c) * 16 + 4 * q;
-      wb[c][nt] = (c < nhw && col < 4 * H && k < H) ? ld4(tk.wt + (long)col * ldw + tk.in + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      wb[c][nt] = (!Q4 && c < nhw && col < 4 * H && k < H) ? ld4(tk.wt + (long)col * ldw + tk.in + k) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int c = 0; c < P_XC; ++c) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (wide) {
         const int k = (hg0 + c) * 16 + 4 * q, col2 = col + 32;
-        if (c < nhw && col2 < 4 * H && k < H) v = ld4(tk.wt + (long)col2 * ldw + tk.in + k);
+        if (!Q4 && c < nhw && col2 < 4 * H && k < H) v = ld4(tk.wt + (long)col2 * ldw + tk.in + k);
       } else {
         const int k = (xg0 + c) * 16 + 4 * q;
         if (c < nxw && col < 4 * H && k < Kx) v = ld4(tk.wt + (long)col * ldw + k);
@@ -351,6 +374,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
   }
 
+  if constexpr (Q4) {
+    if (!wide) {
+#pragma unroll
+      for (int c = 0; c < P_XC; ++c)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) wq[8 + 2 * c + nt] = wa[c][nt];
+    }
+  }
   // epilogue ownership: thread e (< R * UW <= 256) owns (row er, unit eu) for all steps
   const int er = tid >> uw_shift, eu = tid & (UW - 1);
   const int b = row0 + er, u = unit0 + eu;
@@ -369,6 +400,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const bool aok = (PT || i < R) && ab < tk.B;
   const int len_a = aok ? (tk.len ? tk.len[ab] : T) : 0;
   const int xrow = (int)(ab * tk.x_sb) + 4 * q, hrow = (int)(ab * tk.hsr_sb) + 4 * q;
+  // Q4: this lane's A rows (block lane>>2 holds rows i4, i4 + 4 of the group at k = q4a_k .. + 3)
+  const int q4_r0 = row0 + (lane & 3), q4_r1 = q4_r0 + 4;
+  const int q4a_k = hg0 * 16 + 4 * (lane >> 2);
+  const int q4_len0 = (Q4 && q4_r0 < tk.B) ? (tk.len ? tk.len[q4_r0] : T) : 0, q4_len1 = (Q4 && q4_r1 < tk.B) ? (tk.len ? tk.len[q4_r1] : T) : 0;
+  const int q4_h0 = (int)(q4_r0 * tk.hsr_sb) + q4a_k, q4_h1 = (int)(q4_r1 * tk.hsr_sb) + q4a_k;
   const int x_st = (int)tk.x_st, h_st = (int)tk.hsr_st;
   // unconditional raw buffer loads, out-of-range offset = reads zero: exact vmcnt counting keeps the prefetches in flight
   const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(tk.x_r), h_rs = make_rsrc(tk.hs_r), z_rs = make_rsrc(tk.gates);
@@ -444,10 +480,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const bool avalid = aok && t < len_a && (!PT || sub == (t & 1));
     const int ho_ = hrow + (reverse ? len_a - 1 - t : t) * h_st;
     f32x4 hv[P_HC];
+    f32x4 a_lo = {0.f, 0.f, 0.f, 0.f}, a_hi = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (Q4) {
+      a_lo = ldb_sc1(h_rs, (t > 0 && t < q4_len0) ? (q4_h0 + (reverse ? q4_len0 - 1 - t : t) * h_st) * 4 : P_OOB);
+      a_hi = ldb_sc1(h_rs, (t > 0 && t < q4_len1) ? (q4_h1 + (reverse ? q4_len1 - 1 - t : t) * h_st) * 4 : P_OOB);
+    } else {
 #pragma unroll
-    for (int c = 0; c < P_HC; ++c) {
-      const int k = (hg0 + c) * 16;
-      hv[c] = ldb_sc1(h_rs, (c < nhw && avalid && t > 0 && k + 4 * q < H) ? (ho_ + k) * 4 : P_OOB);
+      for (int c = 0; c < P_HC; ++c) {
+        const int k = (hg0 + c) * 16;
+        hv[c] = ldb_sc1(h_rs, (c < nhw && avalid && t > 0 && k + 4 * q < H) ? (ho_ + k) * 4 : P_OOB);
+      }
     }
 #ifdef PERSIST_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // timing build only: isolate the recurrent-operand latency
@@ -466,7 +508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
               for (int e = 0; e < 4; ++e)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xcur[c][e], wa[c][nt][e], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xcur[c][e], Q4 ? wq[Q4 ? 8 + 2 * c + nt : 0][e] : wa[c][nt][e], acc[nt], 0, 0, 0);
           }
         if (PT) { accx[0] = acc[0]; accx[1] = acc[1]; }
       } else {
@@ -479,6 +521,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // younger than the recurrent operands or it would stall their wait.
     znext = ldb4(z_rs, (eok && hoisted && t + 1 < len_b) ? (rec_b + (reverse ? len_b - 2 - t : t + 1) * H) * 16 : P_OOB);
     asm volatile("" ::: "memory");
+    if constexpr (Q4) {
+      // two accumulator chains (rows 0-3 / 4-7) alternate: an instruction never waits for its predecessor
+      f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+#define Q4_STEP(CB, AB)                                                                                   \
+      _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                     \
+        r0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_lo[v], wq[AB][v], r0, CB, AB, 0);                       \
+        r1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a_hi[v], wq[AB][v], r1, CB, AB, 0);                       \
+      }
+      if (wide) {
+        Q4_STEP(4, 0) Q4_STEP(4, 1) Q4_STEP(4, 2) Q4_STEP(4, 3) Q4_STEP(4, 4) Q4_STEP(4, 5) Q4_STEP(4, 6) Q4_STEP(4, 7)
+        Q4_STEP(4, 8) Q4_STEP(4, 9) Q4_STEP(4, 10) Q4_STEP(4, 11) Q4_STEP(4, 12) Q4_STEP(4, 13) Q4_STEP(4, 14) Q4_STEP(4, 15)
+      } else {
+        Q4_STEP(3, 0) Q4_STEP(3, 1) Q4_STEP(3, 2) Q4_STEP(3, 3) Q4_STEP(3, 4) Q4_STEP(3, 5) Q4_STEP(3, 6) Q4_STEP(3, 7)
+      }
+#undef Q4_STEP
+      // D: lane (block, j) register r = (row r, this lane's column): partial over this lane-half's k
+      float* const dst = wide ? red4 + (wave * 8) * 64 + q4_col : red4 + ((wave * 2 + (lane >> 5)) * 8) * 32 + q4_col;
+      const int rs = wide ? 64 : 32;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { dst[r * rs] = r0[r]; dst[(4 + r) * rs] = r1[r]; }
+    } else {
 #pragma unroll
     for (int c = 0; c < P_HC; ++c)
       if (c < nhw) {
@@ -495,6 +558,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
               acc[2 + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[c][e], wa[c][nt][e], acc[2 + nt], 0, 0, 0);
         }
       }
+    }
     if (PT ? (q >> 1) == (t & 1) : q < R / 4) {  // C rows (lane>>4)*4 + r carry batch rows (PT: the half of the tile of this step's parity)
       const int rq = PT ? (q & 1) : q;
 #pragma unroll
@@ -513,6 +577,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
           const int cc = eu * 4 + gi;
+          if constexpr (Q4) {
+            float s4 = 0.f;
+            if (UW == 16) {
+#pragma unroll
+              for (int w = 0; w < 4; ++w) s4 += red4[(w * 8 + er) * 64 + cc];
+            } else {
+#pragma unroll
+              for (int w = 0; w < 8; ++w) s4 += red4[(w * 8 + er) * 32 + cc];          // (wave, k-half) pairs in order
+              s4 += (red[0][cc >> 4][er][cc & 15] + red[1][cc >> 4][er][cc & 15]) + (red[2][cc >> 4][er][cc & 15] + red[3][cc >> 4][er][cc & 15]);
+            }
+            z[gi] += s4;
+          } else
           z[gi] += (red[0][cc >> 4][er][cc & 15] + red[1][cc >> 4][er][cc & 15]) + (red[2][cc >> 4][er][cc & 15] + red[3][cc >> 4][er][cc & 15]);
         }
         f32x4 g4;
@@ -667,7 +743,12 @@ int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, i
       if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
       {
         ProfScope ps(PROF_RNN_PERSIST_FWD, s, g_fwd_flops * rows / B);
+        // 8-row groups at H = 256 everywhere: recurrent product on the 4x4x1 MFMA with A-block broadcast (no padding rows)
+        static const int q4_on = getenv("AVSR_RNN_Q4") ? atoi(getenv("AVSR_RNN_Q4")) : 1;
+        bool q4 = q4_on && R == 8;
+        for (int i = 0; i < L.ntask && q4; ++i) q4 = L.task[i].H == 256 && (L.task[i].hoisted ? L.task[i].uw == 16 : (L.task[i].uw == 8 && L.task[i].in == 256));
         if (R == 16) hipLaunchKernelGGL(rnn_persist_fwd_xcd_kernel<16>, dim3(8 * wg), dim3(256), 0, s, L);
+        else if (q4) hipLaunchKernelGGL((rnn_persist_fwd_xcd_kernel<8, true>), dim3(8 * wg), dim3(256), 0, s, L);
         else hipLaunchKernelGGL(rnn_persist_fwd_xcd_kernel<8>, dim3(8 * wg), dim3(256), 0, s, L);
       }
       AVSR_CHECK_LAUNCH();
