@@ -517,6 +517,255 @@ struct WGArgs {
 };
 
 // MT: row tiles (16 rows of (tap, ci)) held per wave; NTC: column tiles; CH4: 4-channel-multiple input (row-structured staging)
+// 8 destination channels, stride 1, linear destination (the 36x36 layers: layer 0 and residual block 0, forward and data gradient): the
+// product on v_mfma_f32_4x4x1_16B_f32 with cbsz = 4.  All 16 blocks of an instruction share the A block `abid` = 4 destination channels
+// at ONE k (a weight VGPR holds 4 channels x 16 k: the whole 3x3x8x8 kernel is ten registers), the B operand is one staged activation
+// per lane: ONE LANE = ONE OUTPUT POSITION, 64 positions per wave tile, two instructions (channels 0-3 / 4-7) per k.  Against the
+// pixel-pair 16x16x4 form: no 3x4-tap union (12 taps computed for 9: 18 instead of 24 matrix-pipe cycles per position), a lane's result is
+// its position's 8 channels (32 contiguous bytes), and the per-tile address / table / epilogue instructions serve 64 positions, not 32.
+template <int NTAP, int C4T, bool CH4, int EP>
+__global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NQ = NTAP * C4T, NA = (4 * NQ + 15) / 16, MAXCH = 6;
+  const int Cs = A.Cs, CsL = A.CsL;
+  constexpr int Cd = 8;
+  const int PH = A.SH + 2, PW = A.SW + 2, fstride = PH * PW * CsL;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int opf = A.OA * A.OB, pixf = A.DH * A.DW;
+  const int rows_all = A.F * opf, rows_pad = ((rows_all + 63) >> 6) << 6;
+  int* const rowtab = reinterpret_cast<int*>(lds + A.F * fstride);
+  for (int idx = tid; idx < A.F * fstride; idx += 256) lds[idx] = 0.f;
+  // window of position m: LDS offset of its centre pixel (floats), and -- 8-channel sources -- the swizzle phase of that pixel's column
+  for (int m = tid; m < rows_pad; m += 256) {
+    int ro = ((PW + 1) * CsL) | (1 << 24);             // rows beyond the staged frames: the window of position 0 (never written out)
+    if (m < rows_all) {
+      const int f = fdiv(m, A.m_opf), r = m - f * opf, a = fdiv(r, A.m_ob), b = r - a * A.OB;
+      ro = (f * fstride + ((a + 1) * PW + (b + 1)) * CsL) | ((b + 1) << 24);      // (frames stay below 64 KB: offsets below 2^14 floats)
+    }
+    rowtab[m] = ro;
+  }
+  // weights: lane (block bb, i) holds W[channel 4h + i][k = 16a + bb]; k = 4*(tap*C4T + quad) + e
+  float wA[2][NA];
+  {
+    const int bb = lane >> 2, i = lane & 3;
+    const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(A.w);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      const int k = 16 * a + bb, kq = k >> 2, e = k & 3;
+      const bool in = kq < NQ;
+      const int t = in ? kq / C4T : 0, cs = (kq - t * C4T) * 4 + e;
+      const int widx = in ? (int)A.tap[t].w[0] : -1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int co = 4 * h + i;
+        const long wo = A.wmode ? ((long)widx * Cd + co) * Cs + cs : ((long)widx * Cs + cs) * Cd + co;
+        wA[h][a] = ldb1(w_rs, (in && widx >= 0 && cs < Cs) ? (int)(wo * 4) : P_OOB);
+      }
+    }
+  }
+  // per-(tap, quad) window offsets (wave-uniform) and the tap's column shift (for the swizzle phase)
+  int koff[NQ];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+#pragma unroll
+    for (int c = 0; c < C4T; ++c) koff[t * C4T + c] = (A.tap[t].da * PW + A.tap[t].db) * CsL;
+  }
+  const f32x4 bias0 = A.bias ? ld4(A.bias) : zero4, bias1 = A.bias ? ld4(A.bias + 4) : zero4;
+  const bool bnb = A.bnb_x != nullptr;
+  const bool rbn = !bnb && A.res_sc != nullptr;
+  const float* const e_map = bnb ? A.bnb_x : A.res;
+  const float* const e_scp = bnb ? A.bnb_sc : A.res_sc;
+  const float* const e_shp = bnb ? A.bnb_sh : A.res_sh;
+  const f32x4 esc0 = (bnb || rbn) ? ld4(e_scp) : zero4, esc1 = (bnb || rbn) ? ld4(e_scp + 4) : zero4;
+  const f32x4 esh0 = (bnb || rbn) ? ld4(e_shp) : zero4, esh1 = (bnb || rbn) ? ld4(e_shp + 4) : zero4;
+  f32x4 ssum0 = zero4, ssum1 = zero4, ssq0 = zero4, ssq1 = zero4;
+  const __amdgpu_buffer_rsrc_t e_rs = make_rsrc(e_map), dst_rs = make_rsrc(A.dst), acc_rs = make_rsrc(A.acc ? A.acc : A.dst);
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+
+  // staging role of this thread: piece column st_p4 of rows st_row, st_row + st_rpp, ...  (threads beyond rpp*rq idle)
+  const int st_rq = (A.SW * Cs) >> 2;
+  const int st_rpp = st_rq > 0 ? (256 / st_rq > 0 ? 256 / st_rq : 1) : 1;
+  const int st_row = (st_rq > 0 && st_rq <= 256) ? (tid < st_rpp * st_rq ? fdiv(tid, A.m_rq) : -1) : -1;
+  const int st_p4 = st_row >= 0 ? tid - st_row * st_rq : 0;
+  f32x4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = zero4;
+  const bool bn_on = CH4 && A.bn_sc != nullptr;
+  if (bn_on && st_row >= 0) { const int cb = (st_p4 * 4) % Cs; bsc = ld4(A.bn_sc + cb); bsh = ld4(A.bn_sh + cb); }
+  const int rowf = A.SW * Cs;                          // floats per source row
+
+  // ---- software pipeline over passes: the NEXT pass's frames travel memory -> registers while the current pass runs on the matrix
+  // pipe; registers -> LDS between two barriers.  A thread's pieces of a pass: (frame f, row st_row + k*st_rpp, column st_p4) for
+  // 4-channel-multiple sources; 16-byte runs of the contiguous frames (element-wise scatter on store) for the 3-channel crops.
+  constexpr int PF = CH4 ? 12 : 4;
+  f32x4 pre[PF];
+  constexpr bool c4 = CH4;
+  const int ppf = c4 ? (A.SH + st_rpp - 1) / st_rpp : 0;            // pieces per frame per thread (row-structured)
+  const unsigned m_ppf = fmagic_dev(ppf > 0 ? ppf : 1);
+  const int per3 = A.SH * A.SW * Cs;                                // floats per frame (3-channel path)
+  // (hidden loads, see persist.h: left to the compiler the whole prefetch is waited for BEFORE the tile loop it should overlap)
+  const i32x4_ src_rs = make_rsrc_words(A.src);                     // (source maps stay below 2 GB: checked by the host)
+  auto fetch = [&](int n0) {
+    const int fcur = min(A.F, A.N - n0);
+    if (c4) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int f = fdiv(u, m_ppf), k = u - f * ppf, r = st_row + k * st_rpp;
+        // branch-free: pieces this thread does not have use an out-of-range offset (the load returns zeros)
+        ldb4_hidden(pre[u], src_rs, (st_row >= 0 && f < fcur && r < A.SH) ? (int)((((unsigned)(n0 + f) * A.SH + r) * rowf + st_p4 * 4) * 4u) : P_OOB);
+      }
+    } else {
+      const unsigned so = (unsigned)n0 * per3 * 4u;
+      const int tot4 = (fcur * per3) >> 2;
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int idx = u * 256 + tid;
+        ldb4_hidden(pre[u], src_rs, idx < tot4 ? (int)(so + idx * 16u) : P_OOB);
+      }
+    }
+  };
+  auto commit = [&](int n0) {
+    const int fcur = min(A.F, A.N - n0);
+    vm_wait_all();
+#pragma unroll
+    for (int u = 0; u < PF; ++u) vm_landed(pre[u]);
+    if (c4) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int f = fdiv(u, m_ppf), k = u - f * ppf, r = st_row + k * st_rpp;
+        if (st_row >= 0 && f < fcur && r < A.SH) {
+          f32x4 v = pre[u];
+          if (bn_on) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], bsc[e], bsh[e]), 0.f);
+          }
+          // (8-channel sources: the two 16-byte halves of a pixel are swapped in every other group of four pixels, so that 64 lanes
+          // reading the same half of 64 consecutive pixels -- 32-byte stride -- hit every LDS bank row fully: see the tile loop)
+          const int px1 = 1 + (st_p4 >> 1), qd = (st_p4 & 1) ^ (C4T == 2 ? (px1 >> 2) & 1 : 0);
+          st4(lds + f * fstride + ((r + 1) * PW) * CsL + (C4T == 2 ? px1 * 8 + qd * 4 : 4 + st_p4 * 4), v);
+        }
+      }
+    } else {
+      const int tot = fcur * per3, tot4 = tot >> 2;
+      auto put = [&](int e, float v) {
+        const int f = fdiv(e, A.m_per), r = e - f * per3, px = fdiv(r, A.m_rq), c = r - px * Cs, h = fdiv(px, A.m_sw), pw = px - h * A.SW;
+        lds[f * fstride + ((h + 1) * PW + pw + 1) * CsL + c] = v;
+      };
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int idx = u * 256 + tid;
+        if (idx < tot4) { put(idx * 4, pre[u][0]); put(idx * 4 + 1, pre[u][1]); put(idx * 4 + 2, pre[u][2]); put(idx * 4 + 3, pre[u][3]); }
+      }
+      const float* sp = A.src + (long)n0 * per3;
+      for (int e = tot4 * 4 + tid; e < tot; e += 256) put(e, sp[e]);
+    }
+  };
+  int n0 = blockIdx.x * A.F;
+#ifdef CONV_DEBUG
+  long t_pro = 0, t_b1 = 0, t_commit = 0, t_b2 = 0, t_comp = 0, t_mark = __builtin_readcyclecounter();
+  const long t_start = t_mark;
+#define CG_STAMP(acc) { const long t_now = __builtin_readcyclecounter(); acc += t_now - t_mark; t_mark = t_now; }
+#else
+#define CG_STAMP(acc)
+#endif
+  if (n0 < A.N) fetch(n0);
+  CG_STAMP(t_pro)
+  for (; n0 < A.N; n0 += gridDim.x * A.F) {
+    const int fcur = min(A.F, A.N - n0);
+    __syncthreads();                                    // previous pass has finished reading the LDS (first pass: tables written)
+    CG_STAMP(t_b1)
+    commit(n0);
+    CG_STAMP(t_commit)
+    __syncthreads();
+    CG_STAMP(t_b2)
+    if (n0 + gridDim.x * A.F < A.N) fetch(n0 + gridDim.x * A.F);      // in flight during the MFMAs below
+    // ---- the staged frames' positions, 64 per wave tile ----
+    const int Mtot = fcur * opf, mtiles = (Mtot + 63) >> 6;
+    const unsigned pass_o = (unsigned)((long)n0 * pixf * Cd * 4);     // (destination maps stay below 2 GB: checked by the host)
+    // Operand reads run HALF A TILE ahead of their MFMAs: reads of the second half are issued before the first half's MFMAs, reads of the
+    // NEXT tile's first half before the second half's MFMAs (issued chunk by chunk, each read's LDS round trip sat in front of its eight
+    // MFMAs: 4x the tile's matrix-pipe time).
+    constexpr int NH = (NQ + 1) / 2;                     // chunks of the first half
+    f32x4 xq[NQ];
+    int h0[3], h1[3];                                   // (LDS float offsets: integer arithmetic keeps the reads in the LDS address space)
+    // 8-channel sources: the two halves of a pixel are swapped in every other group of four columns (see commit): per tap COLUMN
+    // (db = -1, 0, +1) the offsets of half 0 / half 1, once per tile; tap t reads column t % 3 (forward) or 2 - t % 3 (flipped taps of
+    // the data gradient: A.wmode, checked by the host)
+    auto window = [&](const int rt) {
+      const int rb = rt & 0xffffff, bcol = rt >> 24;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int o = C4T == 2 ? (((bcol + d - 1) >> 2) & 1) << 2 : 0;
+        h0[d] = rb + o; h1[d] = rb + 4 - o;
+      }
+      if (A.wmode) { const int x0 = h0[0]; h0[0] = h0[2]; h0[2] = x0; const int x1 = h1[0]; h1[0] = h1[2]; h1[2] = x1; }
+    };
+#define Q4C_LD(KQ_) xq[KQ_] = ld4(lds + (((KQ_) % C4T ? h1[((KQ_) / C4T) % 3] : h0[((KQ_) / C4T) % 3]) + koff[KQ_]));
+#define Q4C_E(KQ_, E_)                                                                                              \
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[0][(4 * (KQ_) + (E_)) >> 4], x4[E_], acc0, 4, (4 * (KQ_) + (E_)) & 15, 0);   \
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wA[1][(4 * (KQ_) + (E_)) >> 4], x4[E_], acc1, 4, (4 * (KQ_) + (E_)) & 15, 0);
+#define Q4C_MFMA(KQ_) { const f32x4 x4 = xq[KQ_]; Q4C_E(KQ_, 0) Q4C_E(KQ_, 1) Q4C_E(KQ_, 2) Q4C_E(KQ_, 3) }
+    int rt_cur = rowtab[(wave < mtiles ? wave : 0) * 64 + lane];
+    window(rt_cur);
+    if constexpr (NQ == 18) { Q4C_LD(0) Q4C_LD(1) Q4C_LD(2) Q4C_LD(3) Q4C_LD(4) Q4C_LD(5) Q4C_LD(6) Q4C_LD(7) Q4C_LD(8) } else { Q4C_LD(0) Q4C_LD(1) Q4C_LD(2) Q4C_LD(3) Q4C_LD(4) }
+    for (int mt = wave; mt < mtiles; mt += 4) {
+      const int rt_nxt = rowtab[(mt + 4 < mtiles ? mt + 4 : mt) * 64 + lane];
+      const int m = mt * 64 + lane;
+      const bool ok = m < Mtot;
+      const int dbo = (int)(pass_o + (unsigned)(m * 32)) | (ok ? 0 : P_OOB);
+      f32x4 ev0 = zero4, ev1 = zero4, ov0 = zero4, ov1 = zero4;
+      if (EP & 1) { ev0 = ldb4(e_rs, dbo); ev1 = ldb4(e_rs, dbo | 16); }
+      if (EP & 2) { ov0 = ldb4(acc_rs, dbo); ov1 = ldb4(acc_rs, dbo | 16); }
+      f32x4 acc0 = zero4, acc1 = zero4;
+      if constexpr (NQ == 18) { Q4C_LD(9) Q4C_LD(10) Q4C_LD(11) Q4C_LD(12) Q4C_LD(13) Q4C_LD(14) Q4C_LD(15) Q4C_LD(16) Q4C_LD(17) } else { Q4C_LD(5) Q4C_LD(6) Q4C_LD(7) Q4C_LD(8) }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NQ == 18) { Q4C_MFMA(0) Q4C_MFMA(1) Q4C_MFMA(2) Q4C_MFMA(3) Q4C_MFMA(4) Q4C_MFMA(5) Q4C_MFMA(6) Q4C_MFMA(7) Q4C_MFMA(8) } else { Q4C_MFMA(0) Q4C_MFMA(1) Q4C_MFMA(2) Q4C_MFMA(3) Q4C_MFMA(4) }
+      __builtin_amdgcn_sched_barrier(0);
+      window(rt_nxt);                                   // the next tile's first half (the last tile re-reads its own: unused)
+      if constexpr (NQ == 18) { Q4C_LD(0) Q4C_LD(1) Q4C_LD(2) Q4C_LD(3) Q4C_LD(4) Q4C_LD(5) Q4C_LD(6) Q4C_LD(7) Q4C_LD(8) } else { Q4C_LD(0) Q4C_LD(1) Q4C_LD(2) Q4C_LD(3) Q4C_LD(4) }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NQ == 18) { Q4C_MFMA(9) Q4C_MFMA(10) Q4C_MFMA(11) Q4C_MFMA(12) Q4C_MFMA(13) Q4C_MFMA(14) Q4C_MFMA(15) Q4C_MFMA(16) Q4C_MFMA(17) } else { static_assert(NQ == 9, "3x3 taps, 4- or 8-channel sources"); Q4C_MFMA(5) Q4C_MFMA(6) Q4C_MFMA(7) Q4C_MFMA(8) }
+      __builtin_amdgcn_sched_barrier(0);
+      // epilogue: this lane's position, channels 0-3 / 4-7
+      f32x4 v0 = acc0 + bias0, v1 = acc1 + bias1;
+      if ((EP & 1) && !bnb) {
+        if (rbn) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v0[r] += fmaxf(fmaf(ev0[r], esc0[r], esh0[r]), 0.f); v1[r] += fmaxf(fmaf(ev1[r], esc1[r], esh1[r]), 0.f); }
+        } else { v0 += ev0; v1 += ev1; }
+      }
+      if (EP & 2) { v0 += A.beta * ov0; v1 += A.beta * ov1; }
+      if ((EP & 1) && bnb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v0[r] = fmaf(ev0[r], esc0[r], esh0[r]) > 0.f ? v0[r] : 0.f;
+          v1[r] = fmaf(ev1[r], esc1[r], esh1[r]) > 0.f ? v1[r] : 0.f;
+        }
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v0), dst_rs, dbo, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v1), dst_rs, dbo | 16, 0, 0);
+      const f32x4 s0 = ok ? v0 : zero4, s1 = ok ? v1 : zero4;
+      ssum0 += s0; ssum1 += s1;
+      ssq0 += ((EP & 1) && bnb) ? s0 * ev0 : s0 * s0;
+      ssq1 += ((EP & 1) && bnb) ? s1 * ev1 : s1 * s1;
+    }
+  }
+#undef Q4C_LD
+#undef Q4C_MFMA
+#undef Q4C_E
+  if (A.stats) {
+    // per-channel partials of this workgroup: every lane holds all 8 channels of its positions
+    __syncthreads();
+    float* red = lds;                                   // [4 waves][16]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a0 = wave_sum(ssum0[r]), a1 = wave_sum(ssum1[r]), q0 = wave_sum(ssq0[r]), q1 = wave_sum(ssq1[r]);
+      if (lane == 0) { red[wave * 16 + r] = a0; red[wave * 16 + 4 + r] = a1; red[wave * 16 + 8 + r] = q0; red[wave * 16 + 12 + r] = q1; }
+    }
+    __syncthreads();
+    if (tid < 16) A.stats[(long)blockIdx.x * 2 * Cd + tid] = (red[tid] + red[16 + tid]) + (red[32 + tid] + red[48 + tid]);
+  }
+}
+
 // RS (row split): the four waves own DIFFERENT row tiles (wave w: rows [w*MT*16, (w+1)*MT*16)) and each walks every chunk, instead of
 // all waves sharing MT row tiles and splitting the chunks: a deep layer whose (tap, channel) rows exceed one wave's accumulators then
 // takes ONE launch -- its input staged once -- instead of one per tap group, and no cross-wave reduction at the end.
@@ -751,6 +1000,75 @@ static int cg_frames(int sh, int sw, int csl, int opf, int extra_floats_per_fram
   return F;
 }
 
+// 8 destination channels, stride 1, 3x3 taps, whole map: the 4x4x1-MFMA kernel (conv_q4_kernel) instead of the pixel-pair form
+static int g_conv_q4 = -1;
+static bool cg_q4_ok(const CGArgs& A, int ntaps) {
+  if (g_conv_q4 < 0) { const char* e = getenv("AVSR_CONV_Q4"); g_conv_q4 = e ? (atoi(e) != 0) : 1; }
+  return g_conv_q4 && A.Cd == 8 && A.S == 1 && A.OS == 1 && !A.oh0 && !A.ow0 && A.DH == A.OA && A.DW == A.OB && ntaps == 9 &&
+         (A.Cs == 8 || A.Cs == 3) && A.SW + 1 < 256;
+}
+// the kernel derives a tap's column from its index: db = t % 3 - 1 (forward) or 1 - t % 3 (flipped, A.wmode)
+static bool cg_q4_taps_ok(const CGArgs& A) {
+  for (int t = 0; t < 9; ++t)
+    if (A.tap[t].db != (A.wmode ? 1 - t % 3 : t % 3 - 1)) return false;
+  return true;
+}
+static int cg_launch_q4(CGArgs& A, hipStream_t s, int kind, double flops, bool dry) {
+  int Fcap = 16;
+  if (A.Cs == 8) {
+    const int rq = A.SW * A.Cs / 4;
+    if (rq > 256 || rq < 1) return AVSR_ERR_UNSUPPORTED;
+    const int rpp = 256 / rq;
+    Fcap = 12 / ((A.SH + rpp - 1) / rpp);
+    A.m_rq = fmagic(rq); A.m_per = fmagic(A.SH * rq); A.m_sw = fmagic(A.SW);
+  } else {
+    Fcap = (4 * 256 * 4) / (A.SH * A.SW * A.Cs);
+    while (Fcap > 0 && (long)Fcap * A.SH * A.SW * A.Cs >= 65536) --Fcap;
+    A.m_rq = fmagic(A.Cs); A.m_per = fmagic(A.SH * A.SW * A.Cs); A.m_sw = fmagic(A.SW);
+  }
+  if (Fcap < 1) return AVSR_ERR_UNSUPPORTED;
+  if ((long)A.N * A.DH * A.DW * A.Cd * 4 >= (1L << 31) || (long)A.N * A.SH * A.SW * A.Cs * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
+  A.m_opf = fmagic(A.OA * A.OB); A.m_ob = fmagic(A.OB);
+  const int opf = A.OA * A.OB;
+  const size_t frame_b = sizeof(float) * (size_t)(A.SH + 2) * (A.SW + 2) * A.CsL;
+  auto lds_bytes = [&](int F) { return F * frame_b + 4 * ((((size_t)F * opf + 63) / 64) * 64); };
+  // frames per pass: (rounds of the busiest workgroup) x (64-position tiles of a pass per wave), as cg_launch
+  double best = -1.0;
+  int bestF = 0;
+  for (int F = (Fcap < 16 ? Fcap : 16); F >= 1; --F) {
+    if (lds_bytes(F) > 52 * 1024 || (long)F * frame_b / 4 >= (1 << 14) * 4 || (long)F * opf >= (1 << 24)) continue;
+    const long units = (A.N + F - 1) / F, full = units / 512, rem = units - full * 512;
+    const double rounds = (double)full + (rem ? 0.5 + 0.5 * (double)rem / 512 : 0.0);
+    const long tiles = ((long)F * opf + 63) / 64, per_wave = (tiles + 3) / 4;
+    const double cost = rounds * (double)(per_wave * 8 + 4);
+    if (best < 0.0 || cost < 0.97 * best) { best = cost; bestF = F; }
+  }
+  if (!bestF) return AVSR_ERR_UNSUPPORTED;
+  A.F = bestF;
+  size_t lds = lds_bytes(A.F);
+  if (lds < 256) lds = 256;
+  int grid = (A.N + A.F - 1) / A.F;
+  static int cap = 0;
+  if (!cap) { const char* e = getenv("AVSR_CONV_Q4_CAP"); cap = e ? atoi(e) : 512; }     // statistics buffers hold 512 partial rows (avsr_hip.h)
+  if (grid > cap) grid = cap;
+  if (dry) return grid;
+  ProfScope ps(kind, s, flops);
+  const bool emap = A.res != nullptr || A.bnb_x != nullptr;
+  if (A.res && A.bnb_x) return AVSR_ERR_ARG;
+  const int ep = (emap ? 1 : 0) | (A.beta != 0.f ? 2 : 0);
+  if (A.Cs == 3) {
+    if (ep) return AVSR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((conv_q4_kernel<9, 1, false, 0>), dim3(grid), dim3(256), lds, s, A);
+  } else switch (ep) {
+    case 0: hipLaunchKernelGGL((conv_q4_kernel<9, 2, true, 0>), dim3(grid), dim3(256), lds, s, A); break;
+    case 1: hipLaunchKernelGGL((conv_q4_kernel<9, 2, true, 1>), dim3(grid), dim3(256), lds, s, A); break;
+    case 2: hipLaunchKernelGGL((conv_q4_kernel<9, 2, true, 2>), dim3(grid), dim3(256), lds, s, A); break;
+    default: hipLaunchKernelGGL((conv_q4_kernel<9, 2, true, 3>), dim3(grid), dim3(256), lds, s, A); break;
+  }
+  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+  return grid;
+}
+
 static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry = false) {
   if (A.nsp == 0) {                                     // one destination pixel per row of the product
     A.nsp = 1; A.SB = A.S; A.OSA = A.OS; A.OSB = A.OS;
@@ -759,6 +1077,7 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
 #ifdef CONV_DEBUG
   { const char* e = getenv("AVSR_CONV_DBG"); A.dbg = e ? atoi(e) : 0; }
 #endif
+  if (cg_q4_ok(A, A.ntap) && A.nsp == 1 && A.lin && cg_q4_taps_ok(A)) return cg_launch_q4(A, s, kind, flops, dry);
   const int KQ = A.ntap * (A.CsL / 4), nch = (KQ + 3) / 4;
   const int NT = (A.nsp * A.Cd + 15) / 16;
   if (!(NT == 1 || NT == 2 || NT == 4) || nch > 18) return AVSR_ERR_UNSUPPORTED;
@@ -1048,6 +1367,7 @@ static int cg_run(CGArgs A, const CGTap* taps, int ntaps, hipStream_t s, int kin
 // destination channels into the wide taps of the pair.  Returns the number of wide taps, or 0 when the layer does not qualify.
 static int cg_pair_taps(CGArgs& A, const CGTap* taps, int ntaps, CGTap* wide) {
   if (A.Cd != 8 || A.S != 1 || A.OS != 1 || (A.OB & 1) || A.oh0 || A.ow0 || A.DH != A.OA || A.DW != A.OB) return 0;
+  if (cg_q4_ok(A, ntaps)) return 0;                  // the 4x4x1-MFMA kernel takes these layers, one pixel per lane
   int nw = 0;
   for (int t = 0; t < ntaps; ++t)
     for (int pp = 0; pp < 2; ++pp) {

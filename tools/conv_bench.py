@@ -52,7 +52,7 @@ def main():
         dy = torch.randn(N, Ho, Ho, Co, device="cuda")
         dx = torch.zeros(N, H, H, Ci, device="cuda")
         dw, db = torch.zeros(k, k, Ci, Co, device="cuda"), torch.zeros(Co, device="cuda")
-        stats = torch.zeros(512 * 2 * Co, device="cuda")
+        stats = torch.zeros(1024 * 2 * Co, device="cuda")
         bnv = (torch.rand(Ci, device="cuda") + 0.5, torch.randn(Ci, device="cuda")) if bn else None
         d = ops.conv_desc(N, H, H, Ci, Co, k, s, pt if k == 3 else 0, pt if k == 3 else 0, Ho, Ho, bn=bnv)
         assert ops.conv_supported(d), name
