@@ -165,7 +165,8 @@ def test_two_ranks_with_the_lip_cnn(tmp_path, duplicate, monkeypatch):
             continue    # a conv bias ahead of a batch norm has a zero gradient: Adam turns its rounding noise into +-lr steps
         # (moving variances take the Bessel-corrected batch variance: n / (n - 1) with n the rank's rows against the whole batch's)
         tol = 2e-3 if k.endswith("moving_variance") else 1e-4
-        assert np.abs(r0[k] - v).max() <= 5e-6 + tol * np.abs(v).max(), (k, np.abs(r0[k] - v).max(), np.abs(v).max())
+        # (absolute part: Adam turns the rounding noise of a near-zero gradient component into a visible fraction of lr = 1e-3)
+        assert np.abs(r0[k] - v).max() <= 2e-5 + tol * np.abs(v).max(), (k, np.abs(r0[k] - v).max(), np.abs(v).max())
 
 
 # ------------------------------------------------------------------------------------------------
