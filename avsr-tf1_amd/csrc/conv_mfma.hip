@@ -1036,7 +1036,7 @@ static int cg_launch_q4(CGArgs& A, hipStream_t s, int kind, double flops, bool d
   double best = -1.0;
   int bestF = 0;
   for (int F = (Fcap < 16 ? Fcap : 16); F >= 1; --F) {
-    if (lds_bytes(F) > 52 * 1024 || (long)F * frame_b / 4 >= (1 << 14) * 4 || (long)F * opf >= (1 << 24)) continue;
+    if (lds_bytes(F) > 64 * 1024 || (long)F * frame_b / 4 >= (1 << 14) * 4 || (long)F * opf >= (1 << 24)) continue;
     const long units = (A.N + F - 1) / F, full = units / 512, rem = units - full * 512;
     const double rounds = (double)full + (rem ? 0.5 + 0.5 * (double)rem / 512 : 0.0);
     const long tiles = ((long)F * opf + 63) / 64, per_wave = (tiles + 3) / 4;
