@@ -748,10 +748,18 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
       ssq0 += ((EP & 1) && bnb) ? s0 * ev0 : s0 * s0;
       ssq1 += ((EP & 1) && bnb) ? s1 * ev1 : s1 * s1;
     }
+    CG_STAMP(t_comp)
   }
 #undef Q4C_LD
 #undef Q4C_MFMA
 #undef Q4C_E
+#ifdef CONV_DEBUG
+  if ((A.dbg & 8) && A.stats && lane == 0) {           // per-wave cycle counts behind the statistics partials (tools/conv_dissect.py)
+    float* o = A.stats + (long)gridDim.x * 2 * Cd + ((long)blockIdx.x * 4 + wave) * 8;
+    o[0] = (float)t_pro; o[1] = (float)t_b1; o[2] = (float)t_commit; o[3] = (float)t_b2; o[4] = (float)t_comp;
+    o[5] = (float)(__builtin_readcyclecounter() - t_start);
+  }
+#endif
   if (A.stats) {
     // per-channel partials of this workgroup: every lane holds all 8 channels of its positions
     __syncthreads();
@@ -1044,6 +1052,9 @@ static int cg_launch_q4(CGArgs& A, hipStream_t s, int kind, double flops, bool d
     if (best < 0.0 || cost < 0.97 * best) { best = cost; bestF = F; }
   }
   if (!bestF) return AVSR_ERR_UNSUPPORTED;
+#ifdef CONV_DEBUG
+  { const char* e = getenv("AVSR_CONV_DBG"); A.dbg = e ? atoi(e) : 0; }
+#endif
   A.F = bestF;
   size_t lds = lds_bytes(A.F);
   if (lds < 256) lds = 256;
