@@ -425,6 +425,24 @@ def main():
             ach = fl / (us * 1e-6) / 1e12
             r = {"kernel": kind, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK, "unit": "TFLOP/s",
                  "frac": round(ach / MFMA_PEAK, 4), "traffic": traffic(kind), "algorithmic_flops_per_launch": int(fl), "avg_launch_us": us}
+            if kind.startswith("conv_"):
+                # the lip CNN's layers sit on both sides of the machine balance (24 FLOP/B): next to the class's MFMA fraction, the
+                # time of every layer's BINDING bound -- algorithmic bytes (source + destination map, + the residual a forward reads)
+                # at 8 TB/s or algorithmic FLOPs at 157.3 TF, whichever is larger -- summed over the class and divided by its time
+                try:
+                    cnn = model._cur[0]["enc"]["video"]["cnn"]
+                    hb = mb = bind = 0.0
+                    for name, (n_, h_, w_, ci, co, k_, s_, _pt, _pl, ho, wo) in cnn.mfma.items():
+                        if kind == "conv_bwd_data" and ci % 4:
+                            continue                                       # no gradient flows into the crops
+                        xb, yb = 4.0 * n_ * h_ * w_ * ci, 4.0 * n_ * ho * wo * co
+                        byt = xb + yb * (2 if (kind == "conv_fwd" and name in getattr(cnn, "fuse_add", {})) else 1)
+                        t_h, t_m = byt / (HBM_PEAK * 1e3), 2.0 * n_ * ho * wo * k_ * k_ * ci * co / (MFMA_PEAK * 1e6)     # us
+                        hb += t_h; mb += t_m; bind += max(t_h, t_m)
+                    r.update({"hbm_bound_us": round(hb, 1), "mfma_bound_us": round(mb, 1), "binding_bound_us": round(bind, 1),
+                              "frac_of_binding_bound": round(bind / (kinds[kind]["total_ms"] * 1e3), 4)})
+                except Exception:
+                    pass
             if kind.startswith("rnn_persist"):
                 # the recurrent chain is latency-bound -- the meaningful figure is the time per sequential time step
                 # (one launch walks the T_a-step layer/time wavefront), next to the ~1.45 us per-launch floor it replaces
