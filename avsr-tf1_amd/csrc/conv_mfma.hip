@@ -514,9 +514,9 @@ struct WGArgs {
   int t0, nt, kw;                         // taps t0 .. t0+nt-1 of a kw x kw kernel: rows (t - t0, ci) of this launch's slab
   int slab, want_bias;                    // floats per workgroup partial: nt*Ci*Co (+ Co column sums of dy = the bias gradient)
   const float* bn_sc; const float* bn_sh; // BN-ReLU applied to x while staging (see CGArgs)
+  int dbg;                                // CONV_DEBUG builds: bit 3 = per-wave cycle stamps behind the partial slabs
 };
 
-// MT: row tiles (16 rows of (tap, ci)) held per wave; NTC: column tiles; CH4: 4-channel-multiple input (row-structured staging)
 // 8 destination channels, stride 1, linear destination (the 36x36 layers: layer 0 and residual block 0, forward and data gradient): the
 // product on v_mfma_f32_4x4x1_16B_f32 with cbsz = 4.  All 16 blocks of an instruction share the A block `abid` = 4 destination channels
 // at ONE k (a weight VGPR holds 4 channels x 16 k: the whole 3x3x8x8 kernel is ten registers), the B operand is one staged activation
@@ -774,6 +774,7 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
   }
 }
 
+// MT: row tiles (16 rows of (tap, ci)) held per wave; NTC: column tiles; CH4: 4-channel-multiple input (row-structured staging)
 // RS (row split): the four waves own DIFFERENT row tiles (wave w: rows [w*MT*16, (w+1)*MT*16)) and each walks every chunk, instead of
 // all waves sharing MT row tiles and splitting the chunks: a deep layer whose (tap, channel) rows exceed one wave's accumulators then
 // takes ONE launch -- its input staged once -- instead of one per tap group, and no cross-wave reduction at the end.
@@ -882,11 +883,20 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   const int cpf = (opf + 15) >> 4;                       // chunks per frame
   const unsigned m_cpf = fmagic_dev(cpf);
   int n0 = blockIdx.x * A.F;
+#ifdef CONV_DEBUG
+  long w_b1 = 0, w_commit = 0, w_b2 = 0, w_comp = 0, w_mark = __builtin_readcyclecounter();
+  const long w_start = w_mark;
+#define WG_STAMP(acc) { const long t_now = __builtin_readcyclecounter(); acc += t_now - w_mark; w_mark = t_now; }
+#else
+#define WG_STAMP(acc)
+#endif
   if (n0 < A.N) fetch(n0);
   for (; n0 < A.N; n0 += gridDim.x * A.F) {
     const int fcur = min(A.F, A.N - n0);
     __syncthreads();
+    WG_STAMP(w_b1)
     commit(n0);
+    WG_STAMP(w_commit)
     const int kch = fcur * cpf;
     const unsigned dyo = (unsigned)((long)n0 * opf * Co * 4);     // [fcur][opf][Co]
     float bn[NTC][4];
@@ -903,6 +913,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
     const int kc0 = KC0 < 0 ? wave : KC0;
     if (kc0 < kch) load_b(kc0, bn);
     __syncthreads();
+    WG_STAMP(w_b2)
     if (n0 + gridDim.x * A.F < A.N) fetch(n0 + gridDim.x * A.F);      // next pass's frames: in flight during the MFMAs
     for (int kc = kc0; kc < kch; kc += KCS) {
       float av[MT][4], bv[NTC][4];
@@ -936,7 +947,14 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
           for (int nt = 0; nt < NTC; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], bv[nt][e], acc[mt][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    WG_STAMP(w_comp)
   }
+#ifdef CONV_DEBUG
+  if ((A.dbg & 8) && lane == 0) {
+    float* o = A.part + (long)gridDim.x * A.slab + ((long)blockIdx.x * 4 + wave) * 8;
+    o[0] = (float)w_b1; o[1] = (float)w_commit; o[2] = (float)w_b2; o[3] = (float)w_comp; o[4] = (float)(__builtin_readcyclecounter() - w_start);
+  }
+#endif
   // cross-wave reduction (waves hold different depth slices of the same tiles), tile by tile through a 4 KB staging area, then
   // one partial per workgroup
   float* red = lds;                                     // [4][16][16]
@@ -1574,6 +1592,9 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
     A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo / 2; A.Co = 16;
     A.S = 1; A.SW = 2; A.pt = c->pad_t; A.pl = c->pad_l; A.kw = 4; A.bn_sc = c->bn_scale; A.bn_sh = c->bn_shift;
     A.t0 = 0; A.nt = 12; A.want_bias = dbias ? 1 : 0;
+#ifdef CONV_DEBUG
+    { const char* e = getenv("AVSR_CONV_DBG"); A.dbg = e ? atoi(e) : 0; }
+#endif
     A.slab = 12 * Ci * 16 + (A.want_bias ? 16 : 0);
     const int MT = (12 * A.CiL + 15) / 16;
     bool ok = (Ci % 4 == 0) ? MT <= 6 : (MT <= 3 && !c->bn_scale);
