@@ -488,13 +488,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if (has_up) wait_progress(0, T - 1);
   __syncthreads();
   load_rec(T - 1);
+#ifdef PERSIST_TIMING
+  long tmk[6] = {0, 0, 0, 0, 0, 0};                   // tools/persist_probe.py: wait | partial slabs | cell | product + stores | publish
+#define KTICK(k_) { const long now_ = __builtin_amdgcn_s_memtime(); tmk[k_] += now_ - lastk_; lastk_ = now_; }
+#else
+#define KTICK(k_)
+#endif
   for (int t = T - 1; t >= 0; --t) {
+#ifdef PERSIST_TIMING
+    long lastk_ = __builtin_amdgcn_s_memtime();
+#endif
     f32x4 g4 = n_g;
     float c = n_c, cprev = n_cp, dout_ext = n_do + n_dx;
     asm volatile("" : "+v"(g4), "+v"(c), "+v"(cprev), "+v"(dout_ext));
     // dependencies: step t+1 of this cell (every producer of my rows); my helper one step ahead (t-1)
     wait_progress(T - 1 - t, t > 0 ? t - 1 : 0);
     lds_barrier();
+    KTICK(0)
     // ---- recurrent operand: the nct partial d h values of my (row, unit) from step t+1 (nothing at t = T-1) ----
     float ps[16];
     {
@@ -505,6 +515,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     load_rec(t - 1);
     asm volatile("" ::: "memory");
+#ifdef PERSIST_TIMING
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // timing build only: isolate the partial-slab latency (the 5 record loads stay in flight)
+    KTICK(1)
+#endif
     // ---- LSTM cell backward (same arithmetic as EP_LSTM_BWD in step.hip; dx already carries the layer above's input mask) ----
     if (tid < 256) {
       f32x4 dg = {0.f, 0.f, 0.f, 0.f};
@@ -535,6 +549,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
     lds_barrier();
+    KTICK(2)
     // ---- my K slice of the recurrent product: [16 x 64] d gates . 64 rows of Wh^T -> partial d h of ALL units, two tiles per wave ----
     {
       f32x4 A[4];
@@ -565,8 +580,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (n < H && rb < tk.B) st4(dst + (long)rb * H + n, v);
       }
     }
+    KTICK(3)
     publish(t);
+    KTICK(4)
   }
+#ifdef PERSIST_TIMING
+  if (tid == 0 && ct == 0 && g == 0)
+    for (int k_ = 0; k_ < 6; ++k_) L.err[80 + ti * 8 + k_] = (int)(tmk[k_] / T);
+#endif
 }
 
 // Choose the XCD half of every cell: all assignments are enumerated (<= 2^8); feasible ones keep each half within

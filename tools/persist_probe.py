@@ -18,4 +18,4 @@ for name, base in (("fwd", 16), ("bwd", 80)):
     for ti in range(8):
         r = h[base + ti * 8:base + ti * 8 + 6]
         if r.any():
-            print(name, "task", ti, "ticks/step: wait %d loads %d mfma %d epi %d drain %d publish %d  total %d" % (*r, r.sum()))
+            print(name, "task", ti, ("ticks/step: wait %d loads %d mfma %d epi %d drain %d publish %d  total %d" if name == "fwd" else "ticks/step: wait %d partials %d cell %d product+stores %d publish %d (-) %d  total %d") % (*r, r.sum()))
