@@ -383,7 +383,11 @@ class AVSR(object):
     def evaluate(self, checkpoint_path, epoch=None, alignments_outdir='./alignments/tmp/', beam_graphs_outdir='./beam_graphs/tmp/'):
         self.restore(checkpoint_path)                         # the path argument is honoured, as in avsr.py:328-331
         predictions_dict, labels_dict = {}, {}
-        for bd in self._iterator('evaluate'):
+        it = self._iterator('evaluate')
+        if hasattr(it, "reuse_buffers") and os.environ.get("AVSR_IO_PREFETCH", "1") != "0":
+            it.reuse_buffers = True                       # a batch is decoded (host-synchronised) before the next one is asked for
+            it = self._prefetched(it, depth=2)
+        for bd in it:
             batch, names = self._to_batch(bd)
             if self._decoding_algorithm == 'beam_search':     # avsr.py:58-59 default: width 10, first beam returned
                 ids = self._model.beam_search_decode(batch, beam_width=self._beam_width, max_steps=self._cfg.max_label_length)
