@@ -206,9 +206,12 @@ class AVSR(object):
         import queue
         import threading
         q, end = queue.Queue(maxsize=depth), object()
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
 
         def run():
             try:
+                if dev is not None:
+                    torch.cuda.set_device(dev)            # page-locked buffers are allocated here: on THIS rank's device, not on device 0
                 for b in it:
                     q.put(b)
                 q.put(end)
