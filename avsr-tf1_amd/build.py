@@ -34,7 +34,7 @@ def build(force=False, verbose=False):
     procs = []
     for s in srcs:
         o = s[:-4] + ".o"
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
                "-Wno-pass-failed", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", s, "-o", o]
         cmd[1:1] = os.environ.get("AVSR_HIPCC_FLAGS", "").split()     # e.g. -DPERSIST_TIMING for the probes
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

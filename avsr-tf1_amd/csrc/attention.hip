@@ -301,9 +301,11 @@ __global__ __launch_bounds__(256) void attn_fwd_beam_kernel(const AttnLaunch L) 
             acc += ((r < n) ? w[r] * 1.0f : 0.f) * vr[uu];
           }
           float* pout = M.pctx + ((long)c * L.B + (u * K + k0 + kk)) * D;
-          if (G == 1) {
-            if (r0 == 0) st4(pout + 4 * (cb + col), acc);
-            else st4(pout + 4 * (cb + col), ld4(pout + 4 * (cb + col)) + acc);
+          if (G == 1) {                                   // (ccols > 128: threads beyond the columns hold zeros and must not store)
+            if (act) {
+              if (r0 == 0) st4(pout + 4 * (cb + col), acc);
+              else st4(pout + 4 * (cb + col), ld4(pout + 4 * (cb + col)) + acc);
+            }
           } else if (act) st4(&cpart[4 * ((kk * G + grp) * ccols + col)], acc);
         }
         if (G > 1) {
@@ -508,6 +510,9 @@ __global__ void bahdanau_dkeys_kernel(const float* keys, const float* pq, long p
 
 }  // namespace avsr
 
+static int g_beam_on = -1;
+extern "C" int avsr_attn_rnn_set_beam_kernel(int32_t on) { g_beam_on = on ? 1 : 0; return AVSR_OK; }
+
 extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stream) {
   using namespace avsr;
   const AttnLaunch* L = (const AttnLaunch*)launch;
@@ -518,11 +523,11 @@ extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stre
   // beam search over shared memories: one workgroup per (utterance, chunk) runs the K hypotheses (attn_fwd_beam_kernel)
   bool beam = !backward;
   int nbeam = 0;
-  static int beam_on = -1;
-  if (beam_on < 0) { const char* e = getenv("AVSR_ATTN_BEAM"); beam_on = e ? (atoi(e) != 0) : 1; }
+  if (g_beam_on < 0) { const char* e = getenv("AVSR_ATTN_BEAM"); g_beam_on = e ? (atoi(e) != 0) : 1; }
+  const int beam_on = g_beam_on;
   for (int i = 0; i < L->nmech && beam; ++i) {
     const AttnMechDev& M = L->m[i];
-    beam = beam_on && M.mem_div > 1 && M.mem_div <= ATTN_BEAM_KMAX && L->B % M.mem_div == 0 && M.type <= ATT_SCALED_LUONG && M.H <= 256 &&
+    beam = beam_on && M.mem_div > 1 && M.mem_div <= ATTN_BEAM_KMAX && L->B % M.mem_div == 0 && M.type <= ATT_SCALED_LUONG && M.H <= 256 && M.H % 4 == 0 &&
            M.chunk <= 64 && M.D % 4 == 0 && M.D <= 1024 && (long)M.T * M.H * 4 < (1L << 31) && (long)M.T * M.values_st * 4 < (1L << 31);
     nbeam += (L->B / (M.mem_div > 0 ? M.mem_div : 1)) * M.nchunk;
   }

@@ -449,6 +449,11 @@ def attn_rnn_set_fused(on):
     check(_L().avsr_attn_rnn_set_fused(int(on)), "avsr_attn_rnn_set_fused")   # 0 off, 1 / True both, 2 forward only, 3 backward only
 
 
+def attn_rnn_set_beam_kernel(on):
+    """Beam search: the K-hypotheses-per-workgroup attention kernel (default) or the general per-hypothesis one."""
+    check(_L().avsr_attn_rnn_set_beam_kernel(int(bool(on))), "avsr_attn_rnn_set_beam_kernel")
+
+
 def rnn_persistent_error():
     """Sticky flag: a device-side bounded wait of the persistent kernel expired (results of that call are invalid)."""
     return bool(_persist_sync is not None and int(_persist_sync[:1].item()) != 0)

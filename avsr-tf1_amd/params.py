@@ -241,8 +241,8 @@ def initialise(cfg: ModelConfig, seed=0):
         elif init == "glorot":
             lim = math.sqrt(6.0 / (shape[0] + shape[1]))
             a = rng.uniform(-lim, lim, shape)
-        elif init == "glorot_vec":
-            lim = math.sqrt(6.0 / (shape[0] + 1))
+        elif init == "glorot_vec":              # TF-1.13 _compute_fans on a rank-1 shape: fan_in = fan_out = n  (attention_v, attention.py:25-42)
+            lim = math.sqrt(6.0 / (shape[0] + shape[0]))
             a = rng.uniform(-lim, lim, shape)
         elif init == "emb":
             lim = 1.732 / shape[0]

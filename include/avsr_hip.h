@@ -24,6 +24,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libavsr_hip.so is built with -fvisibility=hidden: exactly the functions declared in this header are exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define AVSR_OK 0
 #define AVSR_ERR_ARG (-1)
@@ -38,6 +42,9 @@ extern "C" {
 #define AVSR_MAX_SEGMENTS 32
 
 int avsr_abi_version(void);
+/* sizeof() of a struct of this header by name ("avsr_attn_rnn", ...), -1 if unknown: lets an FFI binding verify its
+ * struct layouts against the library before the first launch (avsr_tf1_amd/_lib.py does). */
+int64_t avsr_sizeof(const char* name);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense GEMM (fp32 MFMA).  Replaces tf.matmul / tf.layers.Dense over all B*T rows: hoisted
@@ -342,6 +349,10 @@ int avsr_attn_rnn_fused_eligible(const avsr_attn_rnn* d);
  * under the same conditions.  Process-wide switch: 0 per-step launches, 1 (default) fused forward and backward, 2 forward only,
  * 3 backward only; the path also needs avsr_rnn_set_persistent's sync scratch. */
 int avsr_attn_rnn_set_fused(int32_t on);
+/* Beam search over shared memories (mode 3, mem_shared): 1 (default; AVSR_ATTN_BEAM in the environment sets the initial value) =
+ * the per-step attention runs as one workgroup per (utterance, chunk) serving all K hypotheses (attn_fwd_beam_kernel), 0 = the
+ * general per-hypothesis kernel.  Both give bit-identical scores, statistics and contexts (tests/test_gpu_beam.py). */
+int avsr_attn_rnn_set_beam_kernel(int32_t on);
 
 int avsr_attn_rnn_fwd(const avsr_attn_rnn* d, int32_t l_begin, int32_t l_end, void* stream);
 int avsr_attn_rnn_bwd(const avsr_attn_rnn* d, void* stream);
@@ -616,6 +627,9 @@ int avsr_optimiser_step(float* params, float* grads, float* m, float* v, int64_t
 int avsr_prof_begin(int32_t max_launches);
 int avsr_prof_end(int32_t* out_count, float* out_ms, double* out_flops);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

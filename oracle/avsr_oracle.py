@@ -227,7 +227,7 @@ def _attention_params(rng, prefix: str, att_type: str, depth: int, units: int, P
         P[prefix + "/g"] = np.ones((1,), np.float32)                          # attention_g init 1.0
     if att_type in BAHDANAU_TYPES:
         P[prefix + "/query_kernel"] = _glorot_uniform(rng, (units, units))    # query_layer, no bias
-        P[prefix + "/v"] = _glorot_uniform(rng, (units, 1)).reshape(units)    # attention_v
+        P[prefix + "/v"] = _glorot_uniform(rng, (units,))                     # attention_v [num_units]: rank 1 -> fan_in = fan_out = units
         if att_type == "normed_bahdanau":
             P[prefix + "/g"] = np.full((1,), math.sqrt(1.0 / units), np.float32)
             P[prefix + "/b"] = np.zeros((units,), np.float32)
@@ -1169,7 +1169,7 @@ def gather_tree(step_ids: np.ndarray, parent_ids: np.ndarray, max_len: np.ndarra
 @torch.no_grad()
 def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Batch, beam_width: int = 10,
                        length_penalty_weight: Optional[float] = None, max_steps: Optional[int] = None, dtype=torch.float64,
-                       return_all: bool = False):
+                       return_all: bool = False, return_trace: bool = False):
     """Returns predicted ids of beam 0, int32 [B, T_out] (`outputs.predicted_ids[:, :, 0]`, decoder_unimodal.py:269).
     length_penalty_weight defaults to the reference's 0.6 (unimodal / av_align) or 0.5 (bimodal)."""
     P = to_torch(P_np, dtype)
@@ -1189,6 +1189,8 @@ def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Ba
     lengths = torch.zeros(B, K, dtype=torch.int64)
     FMIN = torch.finfo(torch.float32).min
     step_ids, parent_ids = [], []
+    min_gap = torch.full((B,), float("inf"), dtype=dtype)
+    step_gaps = []
     for t in range(max_steps):
         out, state, att, _ = m.step(_embedding(P, cfg)[tok], state, att, t)
         step_lp = torch.log_softmax(m.logits(out), dim=-1).reshape(B, K, V)
@@ -1202,7 +1204,15 @@ def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Ba
         penalty = ((5.0 + new_len.to(dtype)) / 6.0) ** w
         scores = (total / penalty).reshape(B, K * V)
         # tf.nn.top_k: descending, ties -> lower index first
-        order = torch.argsort(scores, dim=1, descending=True, stable=True)[:, :K]
+        order_all = torch.argsort(scores, dim=1, descending=True, stable=True)
+        order = order_all[:, :K]
+        # test aid: the smallest gap between consecutive DISTINCT scores among the best K + 1 candidates (an fp32 implementation may
+        # legitimately order two candidates closer than its rounding noise differently; exact ties follow the index rule for both)
+        top = torch.gather(scores, 1, order_all[:, :K + 1])
+        gap = top[:, :-1] - top[:, 1:]
+        gap = torch.where((top[:, :-1] == top[:, 1:]) | torch.isnan(gap), torch.full_like(gap, float("inf")), gap)
+        min_gap = torch.minimum(min_gap, gap.min(dim=1).values)
+        step_gaps.append(gap.min(dim=1).values.numpy())
         word = order % V
         parent = order // V
         logp = torch.gather(total.reshape(B, K * V), 1, order)
@@ -1220,6 +1230,8 @@ def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Ba
     sid, pid = np.stack(step_ids), np.stack(parent_ids)
     beams = gather_tree(sid, pid, lengths.max(dim=1).values.numpy(), eos)               # [T, B, K]
     ids = np.ascontiguousarray(beams.transpose(1, 0, 2))                                 # [B, T, K]
+    if return_trace:        # per-step selections before gather_tree ([T, B, K]) and per-step near-tie gaps ([T, B]): see tests/test_gpu_beam.py
+        return ids, logp.numpy(), lengths.numpy(), dict(step_ids=sid, parent_ids=pid, gaps=np.stack(step_gaps))
     if return_all:
-        return ids, logp.numpy(), lengths.numpy()
+        return ids, logp.numpy(), lengths.numpy(), min_gap.numpy()
     return ids[:, :, 0]

@@ -18,11 +18,19 @@ def test_library_builds_loads_and_exports_every_header_symbol():
     lib = _lib.load()                              # builds with hipcc (cross-compiles gfx950 without a GPU) if needed
     assert lib.avsr_abi_version() == 1
     hdr = open(os.path.join(ROOT, "include", "avsr_hip.h")).read()
-    declared = sorted(set(re.findall(r"^\s*int\s+(avsr_\w+)\s*\(", hdr, flags=re.M)))
+    declared = sorted(set(re.findall(r"^\s*(?:int|int64_t)\s+(avsr_\w+)\s*\(", hdr, flags=re.M)))
     assert len(declared) >= 20
     for sym in declared:
         assert hasattr(lib, sym), "header declares %s but the library does not export it" % sym
         assert sym in _lib.EXPORTS, "%s missing from the ctypes binding" % sym
+    # ... and nothing else: the library is built with -fvisibility=hidden, the header's declarations are its whole dynamic symbol table
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.lib_path()]).decode()
+    syms = [l.split() for l in out.splitlines() if len(l.split()) == 3]
+    exported = sorted(n for _a, k, n in syms if k == "T")          # strong functions (kernel handles are data objects, "D")
+    assert not [n for _a, k, n in syms if k == "W" and "avsr" in n]   # weak ones: libstdc++ template instances only
+    assert exported == declared, (sorted(set(exported) - set(declared)), sorted(set(declared) - set(exported)))
+    assert sorted(_lib.EXPORTS) == declared
 
 
 def test_io_helper_builds_loads_and_exports_every_header_symbol():

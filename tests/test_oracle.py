@@ -214,7 +214,7 @@ def test_beam_search_with_a_beam_that_never_prunes_finds_the_exhaustive_optimum(
             W[k] = (rng.standard_normal(W[k].shape) * 1.5).astype(np.float32)
     batch = O.synthetic_batch(cfg, B=3, T_a=6, T_v=4, L=3, ragged=True)
     K = V ** (steps - 1)
-    ids, scores, lens = O.beam_search_decode(W, cfg, batch, beam_width=K, length_penalty_weight=w, max_steps=steps, return_all=True)
+    ids, scores, lens, _gap = O.beam_search_decode(W, cfg, batch, beam_width=K, length_penalty_weight=w, max_steps=steps, return_all=True)
 
     P = O.to_torch(W, torch.float64)
     m = O._Model(P, cfg, batch, False, torch.float64)
