@@ -177,7 +177,10 @@ class AVSR(object):
         # (profiling=True brackets every launch with an event pair: eager launches)
         self._trainer = DataParallelTrainer(self._model, self._dist,
                                             use_graph=os.environ.get("AVSR_TRAIN_GRAPH", "1") != "0" and not self._profiling,
-                                            check_every_step=True, graph_after=2)
+                                            check_every_step=True, graph_after=2,
+                                            # every captured shape pins its workspace (lip-CNN activations: GBs at B = 64) next to the
+                                            # 8 unpinned ones of the model's LRU: keep few
+                                            max_graphs=int(os.environ.get("AVSR_TRAIN_MAX_GRAPHS", "8")))
 
     # ------------------------------------------------------------------------------------------------
     def _iterator(self, mode):

@@ -29,7 +29,7 @@
 //
 // Every wait is bounded; a miss raises the sticky error word of the persistent-RNN scratch (same protocol as
 // rnn_persist.hip) and the host redoes the call with one launch per phase.  Declines (AVSR_ERR_UNSUPPORTED -> per-step
-// launches): GRU, multi-layer decoder cells, Bahdanau mechanisms, beam search, H or D > 256, V > 32, memories that
+// launches): GRU, multi-layer decoder cells, beam search, H or D > 256, V > 64, memories that
 // do not fit the resident budget.
 #include "dec_persist.h"
 
@@ -47,10 +47,15 @@ namespace avsr {
 // BAH: the block's one mechanism is (normed) Bahdanau (attention.py:25-42): an extra phase computes the processed query
 // pq = cell_out . W_q for the group (one more hand-off per step), the scores are v . tanh(keys + pq + b), and -- output_attention
 // being False for this family -- the logits come from the cell output (split-K shares published with the cell phase).
-template <int KR0, int KR1, int MODE, int R, bool BAH = false>
+// V64: vocabularies of 33..64 symbols (`phoneme`: V = 41, io_utils.py:354-370): the (row, symbol) phases of the output layer use all 512
+// threads as 8 rows x 64 symbols (one wave per row) instead of 256 threads as 8 x 32, the output-kernel rows in LDS are 64 wide
+// (the resident values start 2 KB later), and the logit shares are [.][64].
+template <int KR0, int KR1, int MODE, int R, bool BAH = false, bool V64 = false>
 __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   static_assert(R == 8 || (R == 16 && MODE == 0), "16-row groups: attentive layer only");
   static_assert(!BAH || (R == 8 && KR1 == 0), "Bahdanau: one mechanism, 8-row groups");
+  static_assert(!V64 || (R == 8 && MODE >= 1), "64-symbol rows: decoder modes only");
+  constexpr int VW = V64 ? 64 : 32, VSH = V64 ? 6 : 5;      // symbols per row of the (row, symbol) thread layout
   constexpr int NPH = BAH ? 4 : 3;              // hand-offs per step
   constexpr int PH_PQ = 1, PH_ATT = BAH ? 2 : 1, PH_LAYER = BAH ? 3 : 2;
   constexpr int WPR = DP_NW / R;                // workgroups per row in the attention phase (4 quarters / 2 halves)
@@ -59,13 +64,12 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const red = lds;                       // [8][2][R][16] cell / [2][2][256] context partials / [8][R][16] attention layer / [8][32] exp
   float* const s_p = lds + RED_F;               // [2][128] scaled scores of this quarter (P2) ...
-  float* const s_logit = lds + RED_F;           // ... [8][32] logits of the group's rows (P4)
   float* const s_x = lds + RED_F + 256;         // [8][128] input rows of the next step (MODE >= 1: R = 8)
   float* const s_att = lds + RED_F + 1280;      // [R][16]  this workgroup's attention columns
   int* const s_int = reinterpret_cast<int*>(lds + RED_F + 1280 + 16 * R + 32);   // [0..R) tokens, [R..2R) step lengths, [2R] slot, [2R+1] unfinished, [2R+8..+12) zero pad
   constexpr int ZPAD = RED_F + 1280 + 16 * R + 32 + 2 * R + 8;                     // 4 zero floats: where operand slots of another source "read" LDS
-  float* const s_wo = lds + RED_F + 1280 + 16 * R + 32 + 2 * R + 16;             // [16][32] this workgroup's rows of the output kernel
-  float* const vals = lds + (R == 8 ? DP_MISC : DP_MISC16);                        // resident value rows of this workgroup's share
+  float* const s_wo = lds + RED_F + 1280 + 16 * R + 32 + 2 * R + 16;             // [16][VW] this workgroup's rows of the output kernel
+  float* const vals = lds + (R == 8 ? DP_MISC + (V64 ? 512 : 0) : DP_MISC16);      // resident value rows of this workgroup's share
   static_assert(2048 + 1280 + 128 + 32 + 16 + 16 + 512 == DP_MISC, "8-row layout");
   static_assert(4096 + 1280 + 256 + 32 + 32 + 16 + 512 <= DP_MISC16, "16-row layout");
 
@@ -152,14 +156,14 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
     }
     // (3) output-layer rows -> LDS [k][symbol]: the attention columns [an0, an0 + AW) (Luong family: logits from the attention
     //     vector) or the cell-output units [unit0, unit0 + UW) (Bahdanau family: logits from the cell output)
-    {
-      const int k = tid >> 5, v = tid & 31;
+    for (int e = tid; e < 16 * VW; e += DP_NT) {
+      const int k = e >> VSH, v = e & (VW - 1);
       float wv = 0.f;
       if (mode >= 1 && v < V) {
         if (!BAH) { if (L.oa && has_att && k < AW) wv = L.wout_t[(long)v * A + an0 + k]; }
         else if (k < UW && unit0 + k < H) wv = L.wout_t[(long)v * H + unit0 + k];
       }
-      s_wo[tid] = wv;
+      s_wo[e] = wv;
     }
     // (3b) Bahdanau: this workgroup's columns [unit0, unit0 + UW) of the query layer, K split over the waves like the attention layer's
     //      cell-output slots
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
 #else
 #define DTICK(k)
 #endif
-  const float bout_v = (mode >= 1 && L.bout && (tid0 & 31) < V) ? L.bout[tid0 & 31] : 0.f;
+  const float bout_v = (mode >= 1 && L.bout && (tid0 & (VW - 1)) < V) ? L.bout[tid0 & (VW - 1)] : 0.f;
   // recurrent operand rows of the NEXT cell step: h(l) is complete once every workgroup has published P1 of step l, so the
   // rows are fetched right after that wait (during P2) and consumed a step later, off the critical path
   f32x4 hv[2];
@@ -372,11 +376,11 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         // parity: the shares of step l are read in P4 of step l while a faster workgroup already writes those of step l + 1)
         if (tid < R * UW) s_att[er * 16 + eu] = ho_keep;
         lds_barrier();
-        const int pr = (tid >> 5) & 7, pv = tid & 31;
-        if (tid < 256 && pv < V) {
+        const int pr = (tid >> VSH) & 7, pv = tid & (VW - 1);
+        if (tid < 8 * VW && pv < V) {
           float sacc = 0.f;
-          for (int k = 0; k < UW; ++k) sacc += s_att[pr * 16 + k] * s_wo[k * 32 + pv];
-          L.plog[((((long)(l & 1) * 8 + g) * DP_NW + j) * DP_R + pr) * 32 + pv] = sacc;
+          for (int k = 0; k < UW; ++k) sacc += s_att[pr * 16 + k] * s_wo[k * VW + pv];
+          L.plog[((((long)(l & 1) * 8 + g) * DP_NW + j) * DP_R + pr) * VW + pv] = sacc;
         }
       }
       DTICK(1)
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
       }
       lds_barrier();
       DTICK(16)
-      const int pr = (tid >> 5) & 7, pv = tid & 31;
+      const int pr = (tid >> VSH) & 7, pv = tid & (VW - 1);
       if (tid < R * AW && has_att) {
         const int ar = tid >> awsh, ac = tid & (AW - 1), arb = rowbase + ar;
         float a = 0.f;
@@ -628,10 +632,10 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         s_att[ar * 16 + ac] = a;
       }
       lds_barrier();
-      if (!BAH && mode >= 1 && L.oa && has_att && tid < 256 && pv < V) {
+      if (!BAH && mode >= 1 && L.oa && has_att && tid < 8 * VW && pv < V) {
         float s = 0.f;
-        for (int k = 0; k < AW; ++k) s += s_att[pr * 16 + k] * s_wo[k * 32 + pv];
-        L.plog[((((long)(l & 1) * 8 + g) * DP_NW + j) * DP_R + pr) * 32 + pv] = s;
+        for (int k = 0; k < AW; ++k) s += s_att[pr * 16 + k] * s_wo[k * VW + pv];
+        L.plog[((((long)(l & 1) * 8 + g) * DP_NW + j) * DP_R + pr) * VW + pv] = s;
       }
       DTICK(7)
       publish(PH_LAYER, epoch);
@@ -644,33 +648,31 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
     wait_all(PH_LAYER, epoch);
     DTICK(9)
     if (mode >= 1) {
-      const int pr = (tid >> 5) & 7, pv = tid & 31, pb = rowbase + pr;
-      if (tid < 256) {
+      const int pr = (tid >> VSH) & 7, pv = tid & (VW - 1), pb = rowbase + pr;
+      if (tid < 8 * VW) {
         float z = 0.f;
-        const unsigned po = (unsigned)(((((long)(l & 1) * 8 + g) * DP_NW) * DP_R + pr) * 32 + pv) * 4u;
+        const unsigned po = (unsigned)(((((long)(l & 1) * 8 + g) * DP_NW) * DP_R + pr) * VW + pv) * 4u;
         float part[DP_NW];
 #pragma unroll
-        for (int w = 0; w < DP_NW; ++w) part[w] = ld1_sc1(plog_rs, (w < NWL && pv < V) ? (int)(po + (unsigned)(w * DP_R * 32 * 4)) : P_OOB);
+        for (int w = 0; w < DP_NW; ++w) part[w] = ld1_sc1(plog_rs, (w < NWL && pv < V) ? (int)(po + (unsigned)(w * DP_R * VW * 4)) : P_OOB);
 #pragma unroll
         for (int w = 0; w < DP_NW; ++w) z += part[w];
         const bool valid = l < s_int[R + pr];
         z = valid ? z + bout_v : 0.f;
-        if (pv < V) {
-          s_logit[pr * 32 + pv] = z;
-          if (j == 0 && pb < B) L.logits[((long)pb * Ls + l) * V + pv] = z;
-        }
-        // row maximum over the 32 lanes of this row (exact, order-free), then the softmax numerators for the sampler
-        float m0 = row16_max(pv < V ? z : -INFINITY);          // the row's 32 lanes are two DPP rows of this wave half
+        if (pv < V && j == 0 && pb < B) L.logits[((long)pb * Ls + l) * V + pv] = z;
+        // row maximum over the 32 (64) lanes of this row (exact, order-free), then the softmax numerators for the sampler
+        float m0 = row16_max(pv < V ? z : -INFINITY);          // the row's lanes are two (four) DPP rows of this wave
         {
           const float mlo = fmaxf(rdlane_f(m0, 0), rdlane_f(m0, 16)), mhi = fmaxf(rdlane_f(m0, 32), rdlane_f(m0, 48));
-          m0 = (lane & 32) ? mhi : mlo;
+          m0 = V64 ? fmaxf(mlo, mhi) : ((lane & 32) ? mhi : mlo);
         }
-        if (mode == 2) red[pr * 32 + pv] = pv < V ? expf(z - m0) : 0.f;
+        if (mode == 2) red[pr * VW + pv] = pv < V ? expf(z - m0) : 0.f;
         if (mode == 1) {
           // first maximum (tf.argmax): lowest symbol whose logit equals the row maximum
           const unsigned long long bal = __ballot(pv < V && z == m0);
           const unsigned half = (unsigned)(bal >> (32 * ((tid >> 5) & 1)));
-          if (pv == 0) red[pr] = __builtin_bit_cast(float, (int)(__builtin_ffs((int)half) - 1));
+          const int first = V64 ? __builtin_ffsll((long long)bal) - 1 : __builtin_ffs((int)half) - 1;
+          if (pv == 0) red[pr] = __builtin_bit_cast(float, first);
         }
       }
       lds_barrier();
@@ -696,18 +698,18 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
           if (L.prob > 0.f && uniform01(seedv, 1000u, idx) < L.prob) {
             // expf(logit - max) per symbol, summed in index order exactly as the per-step sampler does; the row is pulled into
             // registers first (one dependent LDS read per symbol made this the longest stretch of the step)
-            f32x4 ex4[8];
+            f32x4 ex4[VW / 4];
 #pragma unroll
-            for (int v4 = 0; v4 < 8; ++v4) ex4[v4] = ld4(red + r * 32 + 4 * v4);
+            for (int v4 = 0; v4 < VW / 4; ++v4) ex4[v4] = ld4(red + r * VW + 4 * v4);
             float tot = 0.f;
 #pragma unroll
-            for (int v = 0; v < 32; ++v) tot += (v < V) ? ex4[v >> 2][v & 3] : 0.f;
+            for (int v = 0; v < VW; ++v) tot += (v < V) ? ex4[v >> 2][v & 3] : 0.f;
             const float target = uniform01(seedv, 1001u, idx) * tot;
             float run = 0.f;
             tk = V - 1;
             bool found = false;
 #pragma unroll
-            for (int v = 0; v < 32; ++v) {
+            for (int v = 0; v < VW; ++v) {
               run += (v < V) ? ex4[v >> 2][v & 3] : 0.f;
               if (!found && v < V && run > target) { tk = v; found = true; }
             }
@@ -764,12 +766,18 @@ int g_dec_fused = 1;
 
 // variant: 0 = one mechanism (<= 128 frames per quarter); 1 = (<= 32, <= 128); 2 = (<= 128, <= 32) frames per quarter;
 // 3 = attentive layer (mode 0) in 16-row groups, one mechanism, <= 64 frames per half
-static const void* dp_kernel(int variant, int mode) {
+static const void* dp_kernel(int variant, int mode, bool v64 = false) {
 #define DPK(a, b) (mode == 0 ? (const void*)dec_persist_kernel<a, b, 0, 8> : mode == 1 ? (const void*)dec_persist_kernel<a, b, 1, 8> : (const void*)dec_persist_kernel<a, b, 2, 8>)
+#define DPK64(a, b) (mode == 1 ? (const void*)dec_persist_kernel<a, b, 1, 8, false, true> : (const void*)dec_persist_kernel<a, b, 2, 8, false, true>)
   if (variant == 3) return (const void*)dec_persist_kernel<2, 0, 0, 16>;
+  if (v64 && mode >= 1) {                                                                          // 33..64 symbols
+    if (variant == 4) return mode == 1 ? (const void*)dec_persist_kernel<4, 0, 1, 8, true, true> : (const void*)dec_persist_kernel<4, 0, 2, 8, true, true>;
+    return variant == 0 ? DPK64(4, 0) : variant == 1 ? DPK64(1, 4) : DPK64(4, 1);
+  }
   if (variant == 4) return mode == 1 ? (const void*)dec_persist_kernel<4, 0, 1, 8, true> : (const void*)dec_persist_kernel<4, 0, 2, 8, true>;   // Bahdanau decoders
   return variant == 0 ? DPK(4, 0) : variant == 1 ? DPK(1, 4) : DPK(4, 1);
 #undef DPK
+#undef DPK64
 }
 
 static int g_dec_rows16 = -1;                   // -1: read AVSR_DEC_ROWS16 once (default on)
@@ -779,7 +787,7 @@ int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* lds_bytes
   if (!g_dec_fused || !g_sync || !d.fused_ws) return AVSR_ERR_UNSUPPORTED;
   if (d.cell != 0 || d.n_extra != 0 || d.n_mech < 1 || d.n_mech > 2 || d.mode < 0 || d.mode > 2) return AVSR_ERR_UNSUPPORTED;
   const int B = d.B, H = d.H, E = d.E, A = d.n_mech * H, KW = E + A + H;
-  if (H > 256 || H % 4 || E % 4 || (d.mode != 0 && (E > 128 || d.V > 32))) return AVSR_ERR_UNSUPPORTED;   // mode 0: inputs hoisted, no logits
+  if (H > 256 || H % 4 || E % 4 || (d.mode != 0 && (E > 128 || d.V > 64))) return AVSR_ERR_UNSUPPORTED;   // mode 0: inputs hoisted, no logits
   const bool bah = d.n_mech == 1 && d.mech[0].type >= ATT_BAHDANAU;       // (normed) Bahdanau: one mechanism, decoder modes only
   if (bah && (d.mode < 1 || d.output_attention || !d.mech[0].v || !d.mech[0].wq_t || !d.mech[0].pq)) return AVSR_ERR_UNSUPPORTED;
   if (d.mode >= 1 && !d.output_attention && !bah) return AVSR_ERR_UNSUPPORTED;
@@ -809,7 +817,7 @@ int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* lds_bytes
   L.cid4 = (uint32_t)d.cell_id * 4;
   if (L.drop && (!d.hs_seq || !d.attd)) return AVSR_ERR_UNSUPPORTED;
   float* ws = d.fused_ws;
-  L.plog = ws; ws += (long)((B + DP_R - 1) / DP_R + 16) * DP_NW * DP_R * 32;      // logit shares: [2 parities][8 groups of a slice][32][8][32]
+  L.plog = ws; ws += (long)((B + DP_R - 1) / DP_R + 16) * DP_NW * DP_R * 64;      // logit shares: [2 parities][8 groups of a slice][32][8][32 or 64]
   int lds_off = 0;
   for (int m = 0; m < d.n_mech; ++m) {
     const avsr_attn_mech& M = d.mech[m];
@@ -825,7 +833,8 @@ int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* lds_bytes
     X.lds_off = lds_off; lds_off += X.ch * M.D;
     X.ppm = ws; ws += 4L * B; X.ppl = ws; ws += 4L * B; X.ppctx = ws; ws += 4L * B * M.D;
   }
-  const size_t bytes = sizeof(float) * ((size_t)(L.R == 16 ? DP_MISC16 : DP_MISC) + lds_off);
+  const bool v64 = d.mode >= 1 && d.V > 32;                                        // 64-wide output-kernel rows: 2 KB more ahead of the values
+  const size_t bytes = sizeof(float) * ((size_t)(L.R == 16 ? DP_MISC16 : DP_MISC + (v64 ? 512 : 0)) + lds_off);
   if (bytes > DP_LDS_BYTES) return AVSR_ERR_UNSUPPORTED;
   *lds_bytes = bytes;
   // register-resident key capacity (32 frames per pass): variant 0 = one mechanism up to 128 frames per quarter;
@@ -848,7 +857,7 @@ int64_t avsr_dec_persist_bwd_ws_floats(int32_t B, int32_t n_mech);
 // forward region of the fused workspace (the backward kernel's partials follow it)
 int64_t avsr_dec_persist_fwd_ws_floats(int32_t B, int32_t n_mech, int32_t Dmax) {
   const int64_t groups = (B + DP_R - 1) / DP_R + 16;
-  return groups * DP_NW * DP_R * 32 + (int64_t)n_mech * (8L * B + 4L * B * Dmax) + 64;
+  return groups * DP_NW * DP_R * 64 + (int64_t)n_mech * (8L * B + 4L * B * Dmax) + 64;
 }
 
 extern "C" int64_t avsr_attn_rnn_fused_ws_floats(int32_t B, int32_t n_mech, int32_t Dmax) {
@@ -884,7 +893,8 @@ int avsr_dec_persist_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32_t l_end
   if (!attr_set) {
     for (int v = 0; v < 5; ++v)
       for (int md = 0; md < 3; ++md)
-        if (hipFuncSetAttribute(dp_kernel(v, md), hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES) != hipSuccess) return AVSR_ERR_HIP;
+        for (int w = 0; w < 2; ++w)
+          if (hipFuncSetAttribute(dp_kernel(v, md, w != 0), hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_BYTES) != hipSuccess) return AVSR_ERR_HIP;
     attr_set = true;
   }
   L.l_begin = l_begin; L.l_end = l_end;
@@ -898,7 +908,7 @@ int avsr_dec_persist_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32_t l_end
     {
       ProfScope ps(dp->prof_tag == 1 ? PROF_ALIGN_PERSIST_FWD : PROF_DEC_PERSIST_FWD, s);
       void* args[] = {(void*)&L};
-      if (hipLaunchKernel(dp_kernel(variant, L.mode), dim3(8 * DP_NW), dim3(DP_NT), args, lds, s) != hipSuccess) return AVSR_ERR_HIP;
+      if (hipLaunchKernel(dp_kernel(variant, L.mode, L.V > 32), dim3(8 * DP_NW), dim3(DP_NT), args, lds, s) != hipSuccess) return AVSR_ERR_HIP;
     }
     AVSR_CHECK_LAUNCH();
   }

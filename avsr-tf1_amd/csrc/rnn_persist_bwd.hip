@@ -42,7 +42,10 @@ struct BTask {
   int B, T, H, H_up, reverse, nct, nct_up, slot_begin, half, ntile, up_remote;
   const int32_t* seed; float k_st, k_out, k_in; uint32_t r_st, r_out, r_in; int in_W, in_coff;
 };
-struct BLaunch { int ntask, ngroups, wpx0, wpx1, b0; int* err; int* claim; BTask task[B_MAX_TASKS]; };   // b0: first batch row of this launch
+// b0: first batch row of this launch.  solo (K-split kernel, batches above 64 utterances whose tasks fit ONE XCD's 64 slots): a
+// 16-row group owns one XCD instead of a pair -- eight groups per launch, so 128 utterances are one pass over the chip instead of
+// two sequential 64-row slices (every edge is XCD-local then).
+struct BLaunch { int ntask, ngroups, wpx0, wpx1, b0, solo; int* err; int* claim; BTask task[B_MAX_TASKS]; };
 
 __global__ __launch_bounds__(512) void rnn_persist_bwd_kernel(const BLaunch L) {
   __shared__ __attribute__((aligned(16))) float red[8][2][16][16];
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if (tid == 0) s_slot = __hip_atomic_fetch_add(L.claim + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const int slot = __builtin_amdgcn_readfirstlane(s_slot);
-  const int g = xcc >> 1, half = xcc & 1;
+  const int g = L.solo ? xcc : xcc >> 1, half = L.solo ? 0 : xcc & 1;
   if (g >= L.ngroups || slot >= (half ? L.wpx1 : L.wpx0)) return;
   int ti = -1, sb_best = -1;                       // the task of this half whose slot range holds my slot (ranges: cells first, then helpers)
 #pragma unroll
@@ -646,7 +649,7 @@ static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int
   double flops = 0.0;
   int cost[B_MAX_TASKS], upper[B_MAX_TASKS], half[B_MAX_TASKS];
   const int B = st[0].B;
-  const int ngroups = B < 64 ? (B + 15) / 16 : 4;      // per launch: 4 XCD pairs x 16 rows; larger batches run as 64-row slices
+  int ngroups = B < 64 ? (B + 15) / 16 : 4;            // per launch: 4 XCD pairs x 16 rows; larger batches run as 64-row slices
   for (int i = 0; i < n; ++i) {
     const avsr_rnn_stack& S = st[i];
     if (S.cell != 0 || S.B != B) UNSUP(3);
@@ -714,7 +717,12 @@ static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int
   // (K-split kernel: 512-thread workgroups held to 128 VGPRs, two per CU)
   int ecost[B_MAX_TASKS];
   for (int i = 0; i < L.ntask; ++i) ecost[i] = L.task[i].kind == 1 ? 1 : 3;
-  if (!assign_halves(cost, upper, L.ntask, ksplit ? 64 : 28, half, ksplit ? ecost : nullptr)) UNSUP(9);
+  static const int solo_on = getenv("AVSR_RNN_BWD_SOLO") ? atoi(getenv("AVSR_RNN_BWD_SOLO")) : 1;
+  int total_cost = 0;
+  for (int i = 0; i < L.ntask; ++i) total_cost += cost[i];
+  const bool solo = ksplit && solo_on && B > 64 && total_cost <= 64;      // one XCD per 16-row group, 128 rows per launch
+  if (solo) { for (int i = 0; i < L.ntask; ++i) half[i] = 0; ngroups = 8; }
+  else if (!assign_halves(cost, upper, L.ntask, ksplit ? 64 : 28, half, ksplit ? ecost : nullptr)) UNSUP(9);
   long words = P_HDR + 8;
   int slots[2] = {0, 0};
   // slots are claimed in arrival order and the dispatcher fills every CU once before it doubles up: cells take the first slots (a CU
@@ -724,7 +732,7 @@ static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int
       BTask& tk = L.task[i];
       if ((tk.kind == 1) != (pass == 1)) continue;
       tk.half = half[i]; tk.slot_begin = slots[half[i]]; slots[half[i]] += tk.nct;
-      tk.prog = sync + words; words += 4 * 32;
+      tk.prog = sync + words; words += 8 * 32;            // (solo: one row of progress words per XCD)
     }
   for (int i = 0; i < L.ntask; ++i) {
     BTask& tk = L.task[i];
@@ -739,11 +747,12 @@ static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int
   }
   if (words > sync_ints) UNSUP(10);
   if (dry) return AVSR_OK;
-  L.err = sync; L.claim = sync + P_HDR; L.wpx0 = slots[0]; L.wpx1 = slots[1];
+  L.err = sync; L.claim = sync + P_HDR; L.wpx0 = slots[0]; L.wpx1 = slots[1]; L.solo = solo ? 1 : 0;
+  const int slice = solo ? 128 : 64;
   hipStream_t s = (hipStream_t)stream;
   const int wpx = slots[0] > slots[1] ? slots[0] : slots[1];
-  for (int b0 = 0; b0 < B; b0 += 64) {                 // rows are independent: consecutive launches over 64-row slices
-    const int rows = B - b0 < 64 ? B - b0 : 64;
+  for (int b0 = 0; b0 < B; b0 += slice) {              // rows are independent: consecutive launches over 64-row (solo: 128-row) slices
+    const int rows = B - b0 < slice ? B - b0 : slice;
     L.b0 = b0; L.ngroups = (rows + 15) / 16;
     if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {

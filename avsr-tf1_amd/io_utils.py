@@ -443,8 +443,13 @@ class _Pipeline:
                     if torch.cuda.is_available():
                         keep = torch.empty(cap, dtype=torch.float32, pin_memory=True)
                         arr = keep.numpy()
-                except Exception:
+                except Exception as e:
                     keep = None
+                    if not getattr(self, "_pin_warned", False):
+                        self._pin_warned = True
+                        import warnings
+                        warnings.warn("input pipeline: page-locked batch buffer unavailable (%s: %s); falling back to pageable memory "
+                                      "-- host-to-device copies become synchronous" % (type(e).__name__, e))
                 if arr is None:
                     arr = np.empty(cap, np.float32)
                 slots.append((keep, arr))

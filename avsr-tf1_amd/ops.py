@@ -216,8 +216,10 @@ def colsum(a, rows, F, out, scratch, b=None, alpha=1.0, beta=0.0, out_offset=0):
     if _colsum_batch is not None and out is _colsum_batch[0]:
         from ._lib import ColsumJob, Mat
         dst = fptr(out, out_offset)
-        dup = any(j.out == dst for j in _colsum_batch[1])
-        if dup and beta != 1.0:
+        dups = [j for j in _colsum_batch[1] if j.out == dst]
+        dup = bool(dups)
+        if dup and (beta != 1.0 or any(j.beta != 1.0 for j in dups)):
+            # an overwriting job on either side: keep the program order (the queued job first, then this one in a fresh batch)
             colsum_batch_flush(scratch)
             dup = False
         if not dup:

@@ -28,8 +28,11 @@ _FIELDS = ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_
 class DataParallelTrainer:
     MAX_GRAPHS = 24          # captured shapes kept (bucketed training visits many): least recently used is dropped with its buffers
 
-    def __init__(self, model, dist=None, use_graph=True, sync_bn=True, force_collectives=False, check_every_step=True, graph_after=1):
+    def __init__(self, model, dist=None, use_graph=True, sync_bn=True, force_collectives=False, check_every_step=True, graph_after=1,
+                 max_graphs=None):
         self.model, self.dist = model, dist
+        if max_graphs is not None:               # bucketed training on large batches: every captured shape pins a workspace and a graph pool
+            self.MAX_GRAPHS = max(1, int(max_graphs))
         self.world = dist.get_world_size() if dist is not None else 1
         # force_collectives: issue every collective even at world size 1 (exercises the RCCL path on a single-GPU box)
         self.collective = self.world > 1 or bool(force_collectives and dist is not None)
@@ -202,8 +205,10 @@ class DataParallelTrainer:
         return True
 
     def _capture(self, fn):
+        # thread_local: only THIS thread's calls are checked against the capture -- the input pipeline's prefetch thread may allocate a
+        # page-locked buffer (hipHostMalloc) at any time, which the default global mode would reject and thereby invalidate the capture
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             fn()
         return g
 
@@ -236,6 +241,10 @@ class DataParallelTrainer:
             if self.sync_bn:
                 dist.all_reduce(m.bn_sync_sums(batch))
                 dist.all_reduce(m.bn_sync_squares(batch))
+        # whether this step reads the persistent kernels' flag must not depend on the path a rank takes (the check is a collective at
+        # world size > 1): decided from rank-independent state only
+        do_check = self.check_every_step or not self._checked
+        self._checked = True
         eager_now = not self.use_graph
         if self.use_graph and self.graph_after > 1 and key not in self._graphs:
             n = self._seen.pop(key, 0) + 1
@@ -244,20 +253,7 @@ class DataParallelTrainer:
                 self._seen.popitem(last=False)
             eager_now = n < self.graph_after
         if eager_now:
-            if self.collective:
-                self._fwd_bwd_collective(batch)
-            else:
-                self._fwd_bwd(batch)
-            if not self._checked or self.check_every_step:   # make sure the persistent kernels were co-resident
-                self._checked = True
-                if self._persistent_failed():
-                    if self._pending is not None:          # the bucket reduced an invalid pass: finish it, then redo everything
-                        self._pending.wait()
-                        self._pending = None
-                    self._fwd_bwd_collective(batch) if self.collective else self._fwd_bwd(batch)
-            if self.collective:
-                self._reduce_grads()
-                self._reduce_loss()
+            self._eager_pass(batch, do_check)
             m.apply_update()
             return m.loss, m.gnorm
         if self.collective and self.use_graph and self.drain_after_collectives:
@@ -265,15 +261,24 @@ class DataParallelTrainer:
         st = self._stage(key, batch)
         gr = self._graphs.get(key)
         if gr is None:
-            # one eager step allocates every workspace; then capture
-            self._fwd_bwd(st)
-            if self._persistent_failed():              # persistent kernels not co-resident: redo through the launch path
-                self._fwd_bwd(st)
-            if self.collective:
-                full = getattr(m, "grads_and_loss", None)
-                dist.all_reduce(full if full is not None else m.grads)
-                if full is None:
-                    self._reduce_loss()
+            # one eager step allocates every workspace, then capture.  The eager step issues EXACTLY the collectives of every other
+            # path (bucket, remainder, loss): ranks may reach the capture step of a shape at different times (their shard sizes, hence
+            # their shape keys and sighting counts, can differ), and a rank capturing must pair up with one that replays or runs eagerly.
+            try:
+                self._eager_pass(st, do_check)
+            except torch.cuda.OutOfMemoryError:
+                # too many captured shapes alive (each pins a workspace and a private graph pool): drop them all and stay eager
+                self._drop_graphs()
+                self._static.clear()
+                self.use_graph = False
+                self.mode = "eager (out of memory while allocating a shape's workspace; captured graphs dropped)"
+                torch.cuda.empty_cache()
+                if self._pending is not None:
+                    self._pending.wait()
+                    self._pending = None
+                self._eager_pass(batch, False)
+                m.apply_update()
+                return m.loss, m.gnorm
             m.apply_update()
             torch.cuda.synchronize()
             try:
@@ -302,7 +307,7 @@ class DataParallelTrainer:
             ga[1].replay()
         else:
             ga.replay()
-        if self.check_every_step and self._persistent_failed():
+        if do_check and self._persistent_failed():
             # a persistent kernel's bounded wait expired inside the replay: the activations are invalid.  check_persistent() has
             # switched the one-launch paths off; drop the captured graphs (they contain those launches) and redo the step eagerly.
             self._drop_graphs()
@@ -324,6 +329,22 @@ class DataParallelTrainer:
         else:
             m.apply_update()
         return m.loss, m.gnorm
+
+    def _eager_pass(self, batch, do_check):
+        """Forward + backward + gradient / loss reduction by host launches, with the collective schedule every path shares:
+        [bucket all-reduce on the side stream], [flag MAX-reduce iff do_check], remainder of the gradients (+ loss)."""
+        if self.collective:
+            self._fwd_bwd_collective(batch)
+        else:
+            self._fwd_bwd(batch)
+        if do_check and self._persistent_failed():       # a persistent kernel was not co-resident: redo through the launch path
+            if self._pending is not None:                # the bucket reduced an invalid pass: finish it, then redo everything
+                self._pending.wait()
+                self._pending = None
+            self._fwd_bwd_collective(batch) if self.collective else self._fwd_bwd(batch)
+        if self.collective:
+            self._reduce_grads()
+            self._reduce_loss()
 
     def _drop_graphs(self):
         unpin = getattr(self.model, "unpin_workspace", None)

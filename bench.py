@@ -201,6 +201,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    # test hook (tests/test_gpu_bench.py): AVSR_BENCH_BACKEND=gloo runs N ranks on however many GPUs the box has (ranks share a device;
+    # RCCL refuses two ranks on one GPU) -- the whole multi-rank path incl. the strong-scaling section, with the persistent kernels of
+    # the ranks contending for the same CUs.  Its numbers mean nothing; the driver's runs use RCCL, one rank per GPU.
+    backend = os.environ.get("AVSR_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist = None
     force_dist = world == 1 and os.environ.get("AVSR_BENCH_FORCE_DIST") == "1"   # test hook: RCCL path with one rank
@@ -208,7 +214,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     trace = (lambda m: (torch.cuda.synchronize(), sys.stderr.write("[bench] %s\n" % m), sys.stderr.flush())) \
         if os.environ.get("AVSR_BENCH_TRACE") else (lambda m: None)

@@ -41,6 +41,34 @@ def test_bench_json_contract_and_forced_collectives():
     assert abs(forced["final_loss"] - plain["final_loss"]) < 1e-4 * max(1.0, abs(plain["final_loss"]))
 
 
+def test_bench_two_ranks_over_gloo_with_persistent_kernels_contending():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), except that the transport
+    is gloo and both ranks sit on the box's one GPU: weak-scaling headline + the strong-scaling section, hipGraph replays around the
+    collectives, and -- what a one-rank run can never show -- the persistent encoder / decoder kernels of TWO processes contending for
+    the same XCDs.  Whatever the dispatcher does (both grids resident, one after the other, or a bounded wait expiring -> flag
+    MAX-reduced over the ranks -> both redo through the per-step launches), the run must finish with one JSON line, finite equal
+    losses on the replicas' shared step count, and report the flag truthfully."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, AVSR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "8",
+           "--video-frontend", "features", "--no-cpu-baseline", "--no-profile"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 16 and out["value"] > 0
+    assert out["config"]["collectives_per_step"] == 2
+    assert out["final_loss"] == out["final_loss"] and abs(out["final_loss"]) < 100.0            # finite
+    ss = out["strong_scaling"]
+    assert ss.get("value") and ss["utterances_per_gpu"] == 32 and ss["global_batch"] == 64, ss
+    assert isinstance(out["persistent_wait_expired"], bool) and isinstance(ss["persistent_wait_expired"], bool)   # reported either way
+
+
 @pytest.mark.parametrize("front,fresh", [("features", False), ("resnet_cnn", False), ("resnet_cnn", True)])
 def test_queued_graph_replays_equal_eager_steps(front, fresh):
     """Train steps queued back to back (no host sync) through the captured graphs must equal eager steps bit for bit, at the

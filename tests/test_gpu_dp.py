@@ -34,11 +34,15 @@ def _shard(O, b, lo, hi):
                       for k in ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len")})
 
 
-def _worker(rank, world, port, out_dir, use_graph, overlap, odd):
+def _worker(rank, world, port, out_dir, use_graph, overlap, odd, persistent=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    os.environ["AVSR_PERSISTENT_RNN"] = "0"          # two processes on ONE GPU must not both claim the whole chip
+    # persistent=False: two processes on ONE GPU do not both claim the chip.  persistent=True: they do -- each rank's shard (<= 8
+    # utterances) is one row group, i.e. BOTH ranks' persistent encoder / fused decoder kernels want the workgroup slots of XCD 0 at
+    # the same time.  The dispatcher may run them side by side, one after the other, or interleave them so that a bounded wait
+    # expires: then the flag is MAX-reduced, both ranks redo the pass through the per-step launches, and the result must not change.
+    os.environ["AVSR_PERSISTENT_RNN"] = "3" if persistent else "0"
     os.environ["AVSR_DP_OVERLAP"] = "1" if overlap else "0"
     import torch.distributed as dist
     from avsr_tf1_amd.model import Batch, Seq2SeqModel
@@ -54,9 +58,37 @@ def _worker(rank, world, port, out_dir, use_graph, overlap, odd):
         trainer.train_step(batch)
     torch.cuda.synchronize()
     assert (trainer._bucket is not None) == bool(overlap)
+    from avsr_tf1_amd import ops
+    assert not ops.rnn_persistent_error()            # every flagged pass was redone and the flag cleared (check_every_step)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mode=np.array(trainer.mode), sync_bn=np.array(trainer.sync_bn),
-             **model.export_tf_weights("params"))
+             persistent=np.array(bool(model.persistent_rnn)), **model.export_tf_weights("params"))
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph,overlap", [(False, False), (True, False), (True, True)])
+def test_two_ranks_with_persistent_kernels_contending_for_one_gpu(tmp_path, use_graph, overlap, monkeypatch):
+    """Both ranks run the persistent encoder kernels and the fused decoder on the SAME GPU (see _worker).  Replicas must stay
+    bit-identical and equal one engine on the whole batch, whether or not a pass was flagged and redone on the way."""
+    import torch.multiprocessing as mp
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path), use_graph, overlap, False, True), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert bool(r0["persistent"]) == bool(r1["persistent"])          # the ranks switched paths together (MAX-reduced flag) or not at all
+    print("mode", str(r0["mode"]), "| persistent kernels still on:", bool(r0["persistent"]))
+    monkeypatch.setenv("AVSR_PERSISTENT_RNN", "3")
+    O, mcfg, W, full = _setup(False)
+    model = Seq2SeqModel(mcfg, weights=W)
+    batch = Batch.from_numpy(full)
+    for _ in range(STEPS):
+        model.train_step(batch)
+    torch.cuda.synchronize()
+    ref = model.export_tf_weights("params")
+    for k, v in ref.items():
+        assert np.array_equal(r0[k], r1[k]), k
+        assert np.abs(r0[k] - v).max() < 5e-6 + 1e-4 * np.abs(v).max() * 0.01, (k, np.abs(r0[k] - v).max())
 
 
 @pytest.mark.parametrize("use_graph,overlap,odd", [(False, False, False), (True, False, False), (False, True, False), (True, True, False),

@@ -38,6 +38,19 @@ CASES = {
     "c2_width_bahdanau": (dict(architecture="unimodal", encoder_type="bidirectional", video_units=None, audio_units=(128,), decoder_units=(256,),
                                embedding_size=128, audio_feat=80, attention_type=(("bahdanau",), ("bahdanau",)), use_dropout=True,
                                sampling_probability=0.1), 64, 130, 0, 8),
+    # vocabularies other than characters (avsr/misc/phoneme_list: V = 41 -> the 64-symbol rows of dec_persist_kernel<.., V64>;
+    # viseme_list: V = 15), Luong and Bahdanau families, one and two memories, scheduled sampling over V classes
+    "phoneme_bimodal_sampling": (dict(architecture="bimodal", video_units=(32,), audio_units=(32, 32), use_dropout=True,
+                                      sampling_probability=0.4, vocab_size=41, eos_id=39, go_id=40), 11, 37, 9, 7),
+    "phoneme_bahdanau": (dict(architecture="unimodal", video_units=None, audio_units=(32, 32), attention_type=(("bahdanau",), ("bahdanau",)),
+                              sampling_probability=0.3, vocab_size=41, eos_id=39, go_id=40), 9, 41, 0, 8),
+    "phoneme_c4_width_64_utterances": (dict(architecture="bimodal", video_units=(256,), audio_units=(256,), decoder_units=(256,), embedding_size=128,
+                                            video_feat=128, audio_feat=80, use_dropout=True, sampling_probability=0.1, vocab_size=41, eos_id=39,
+                                            go_id=40), 64, 60, 20, 10),
+    "vocab64_unimodal": (dict(architecture="unimodal", video_units=None, audio_units=(48,), decoder_units=(48,), embedding_size=32,
+                              attention_type=(("luong",), ("luong",)), sampling_probability=0.3, vocab_size=64, eos_id=62, go_id=63), 9, 70, 0, 9),
+    "viseme_bimodal_sampling": (dict(architecture="bimodal", video_units=(32,), audio_units=(32, 32), use_dropout=True,
+                                     sampling_probability=0.4, vocab_size=15, eos_id=13, go_id=14), 11, 37, 9, 7),
 }
 
 
