@@ -511,7 +511,8 @@ __global__ void bahdanau_dkeys_kernel(const float* keys, const float* pq, long p
 }  // namespace avsr
 
 static int g_beam_on = -1;
-extern "C" int avsr_attn_rnn_set_beam_kernel(int32_t on) { g_beam_on = on ? 1 : 0; return AVSR_OK; }
+namespace avsr { extern int g_beam_dense; }
+extern "C" int avsr_attn_rnn_set_beam_kernel(int32_t on) { g_beam_on = on ? 1 : 0; avsr::g_beam_dense = on == 1 ? 1 : 0; return AVSR_OK; }
 
 extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stream) {
   using namespace avsr;

@@ -12,6 +12,11 @@
 
 extern "C" int avsr_step_launch_raw(const void* launch, void* stream);
 extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stream);
+namespace avsr {
+bool beam_dense_on();
+int beam_cell_launch(const avsr_attn_rnn& d, int l, hipStream_t s);
+int beam_attention_layer_launch(const avsr_attn_rnn& d, int l, hipStream_t s);
+}
 int avsr_dec_persist_fwd(const avsr_attn_rnn* d, int32_t l_begin, int32_t l_end, void* stream);   // dec_persist.hip
 int avsr_dec_persist_bwd(const avsr_attn_rnn* d, void* stream);                                      // dec_persist_bwd.hip
 
@@ -413,9 +418,17 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
   // beam search: the per-step unfinished counters [L] of this call's range, zeroed once (not one fill per step)
   if (d.mode == 3 && l_first < l_end && avsr::dev_zero(d.n_unfinished + l_first, sizeof(int32_t) * (l_end - l_first), s) != hipSuccess)
     return AVSR_ERR_HIP;
+  // beam search: the B * K-row cell and attention-layer steps as 64 x 64-tiled products with row-gathered operands (beam_gemm.hip)
+  const bool beam_dense = d.mode == 3 && !gru && d.n_extra == 0 && !drop && beam_dense_on();
   for (int l = l_first; l < l_end; ++l) {
     // ---- K1: LSTM step -------------------------------------------------------------------
-    for (int phase = 0; phase < (gru ? 2 : 1); ++phase) {
+    bool cell_done = false;
+    if (beam_dense) {
+      const int brc = beam_cell_launch(d, l, s);
+      if (brc == AVSR_OK) cell_done = true;
+      else if (brc != AVSR_ERR_UNSUPPORTED) return brc;
+    }
+    for (int phase = 0; phase < (gru ? 2 : 1) && !cell_done; ++phase) {
       SL.ntask = 1;
       StepTask& tk = SL.task[0];
       tk = StepTask{};
@@ -509,8 +522,14 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
       if ((rc = avsr_attn_launch_raw(&AL, 0, stream))) return rc;
 
       // ---- K3: attention layer  att_m = [cell_out, ctx_m] . W_att,m --------------------------
+      bool layer_done = false;
+      if (beam_dense) {
+        const int brc = beam_attention_layer_launch(d, l, s);
+        if (brc == AVSR_OK) layer_done = true;
+        else if (brc != AVSR_ERR_UNSUPPORTED) return brc;
+      }
       SL.ntask = 0;
-      for (int m = 0; m < d.n_mech; ++m) {
+      for (int m = 0; m < d.n_mech && !layer_done; ++m) {
         const avsr_attn_mech& M = d.mech[m];
         const int nc = nchunk(M);
         StepTask& tk = SL.task[SL.ntask++];
@@ -529,7 +548,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
           tk.p9 = d.attd + (long)(l + 1) * A + (long)m * H; tk.s4 = (long)(L + 1) * A;
         }
       }
-      if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+      if (!layer_done && (rc = avsr_step_launch_raw(&SL, stream))) return rc;
     }
 
     if (d.mode >= 1) {

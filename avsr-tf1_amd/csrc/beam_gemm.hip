@@ -1,0 +1,262 @@
+// Throughput-shaped dense steps of beam search (mode 3 of avsr_attn_rnn_fwd; BeamSearchDecoder at avsr/decoder_unimodal.py:248-271,
+// avsr/decoder_bimodal.py:358-381: the reference's default evaluation, width 10).
+//
+// Under beam search a decode step carries B * K rows (640 at the benchmark batch): the LSTM cell is a [640 x 896] x [896 x 1024]
+// product and the attention layers two [640 x 512] x [512 x 256] ones.  The per-step `step_kernel` (16 x 16 output tiles, built for
+// the 64-row steps of training, where only latency matters) runs them as 2560 / 1280 workgroups that re-read their operands from
+// L2 -- 46 + 41 us of the 145 us step (profiles/r03_decode_rates_v3.txt).  Here the same products are 64 x 64 output tiles walked
+// through LDS in 64-deep K stages (register prefetch of the next stage under the current stage's MFMAs), with the operand ROWS
+// GATHERED while they are staged -- token embedding by `tok`, attention record and recurrent state by the parent hypothesis'
+// row -- and the cell's gate math, clip and state update in the epilogue:
+//   beam_gemm_kernel<LSTM>    z = [emb[tok[r]] | att[parent[r]] | h[parent[r]]] . W + b -> i, j, f, o -> c, h of row r
+//   beam_gemm_kernel<LINEAR>  att_m[r] = [cell_out[r] | ctx_m[r]] . W_att,m            (all mechanisms in one launch)
+//   beam_ctx_merge_kernel     ctx_m[r] = softmax-merge of the per-chunk partial contexts the attention kernel left (the step kernel
+//                             did this inside its operand loader, once per column tile)
+// f32 MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products, the summation order differs from step_kernel's (K split over waves there),
+// i.e. results agree to rounding; tests/test_gpu_beam.py checks both against the fp64 oracle.
+#include "persist.h"
+#include "avsr_hip.h"
+#include "prof.h"
+#include "attn.h"
+#include "step.h"
+#include <cstdlib>
+
+namespace avsr {
+
+#define BG_MAX_SRC 3
+#define BG_MAX_PROB 4
+#define BG_T 64            // tile rows = tile columns = K per stage
+
+struct BGSrc { const float* a; long sb; const int* gather; int K, pad; };
+struct BGProb {
+  BGSrc src[BG_MAX_SRC];
+  int nsrc, R, N, tile0, ntx, pad;
+  const float* wt; long ldw;                     // weights [N][ldw], K contiguous
+  float* out; long out_sb;                       // LINEAR: out[r * out_sb + n]
+  const float* bias; const float* c_in; const int* parent; float* c_out; float* h_out; float* seq_out; long seq_sb;   // LSTM
+};
+struct BGLaunch { int nprob, ntiles; BGProb p[BG_MAX_PROB]; };
+
+template <bool LSTM>
+__global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][BG_T * BG_T];      // [buffer][A | B][k][row or column]: 64 KB
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < BG_MAX_PROB; ++i) if (i < L.nprob && (int)blockIdx.x >= L.p[i].tile0) pi = i;
+  pi = __builtin_amdgcn_readfirstlane(pi);
+  const BGProb& P = L.p[pi];
+  const int tile = blockIdx.x - P.tile0, tx = tile % P.ntx, ty = tile / P.ntx;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // ---- operand rows of this thread: A row (gathered per source) and weight row, both K-contiguous ----
+  const int mrow = ty * BG_T + lane, ncol = tx * BG_T + lane;
+  const bool rok = mrow < P.R, cok = ncol < P.N;
+  __amdgpu_buffer_rsrc_t ars[BG_MAX_SRC];
+  int aoff[BG_MAX_SRC], kbase[BG_MAX_SRC + 1];
+  kbase[0] = 0;
+#pragma unroll
+  for (int s = 0; s < BG_MAX_SRC; ++s) {
+    const bool on = s < P.nsrc;
+    ars[s] = make_rsrc(on ? P.src[s].a : P.wt);
+    long rb = mrow;
+    if (on && rok && P.src[s].gather) rb = P.src[s].gather[mrow];
+    aoff[s] = (on && rok) ? (int)(rb * P.src[s].sb * 4) : P_OOB;
+    kbase[s + 1] = kbase[s] + (on ? P.src[s].K : 0);
+  }
+  const int Ktot = kbase[BG_MAX_SRC];
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(P.wt);
+  const int woff = cok ? (int)((long)ncol * P.ldw * 4) : P_OOB;
+  const int nstage = (Ktot + BG_T - 1) / BG_T;
+
+  f32x4 ra[4], rb4[4];
+  auto fetch = [&](int st) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int k = st * BG_T + 16 * p + 4 * wave;          // wave-uniform: the source of a piece is found by scalar compares
+      int s = 0;
+#pragma unroll
+      for (int q = 1; q < BG_MAX_SRC; ++q) if (k >= kbase[q]) s = q;
+      const bool in = k < Ktot;
+      int ao = P_OOB;
+      __amdgpu_buffer_rsrc_t rs = ars[0];
+#pragma unroll
+      for (int q = 0; q < BG_MAX_SRC; ++q) if (q == s) { rs = ars[q]; ao = (in && aoff[q] != P_OOB) ? aoff[q] + (k - kbase[q]) * 4 : P_OOB; }
+      ra[p] = ldb4(rs, ao);
+      rb4[p] = ldb4(wrs, (in && cok) ? woff + k * 4 : P_OOB);
+    }
+  };
+  auto commit = [&](int buf) {
+    float* As = lds[buf][0];
+    float* Bs = lds[buf][1];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int k = 16 * p + 4 * wave;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { As[(k + e) * BG_T + lane] = ra[p][e]; Bs[(k + e) * BG_T + lane] = rb4[p][e]; }
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  fetch(0);
+  commit(0);
+  if (nstage > 1) fetch(1);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int buf = st & 1;
+    const float* As = lds[buf][0] + wm * 32 + (lane & 31);
+    const float* Bs = lds[buf][1] + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BG_T / 2; ++kk) {
+      const int k = 2 * kk + (lane >> 5);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * BG_T], Bs[k * BG_T], acc, 0, 0, 0);
+    }
+    if (st + 1 < nstage) {
+      commit(buf ^ 1);                                       // the stage fetched while the previous one was multiplied
+      if (st + 2 < nstage) fetch(st + 2);
+    }
+    lds_barrier();
+  }
+
+  // C layout of mfma 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  if constexpr (!LSTM) {
+    const int col = tx * BG_T + wn * 32 + (lane & 31);
+    const int rbase = ty * BG_T + wm * 32 + 4 * (lane >> 5);
+    if (col < P.N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row < P.R) P.out[(long)row * P.out_sb + col] = acc[r];
+      }
+    }
+  } else {
+    // gate pre-activations of a unit sit in four adjacent columns: through LDS into (row, unit) order
+    constexpr int CS = BG_T + 4;                               // row stride of the staged tile (16-byte aligned rows)
+    float* Cs = &lds[0][0][0];
+    {
+      const int col = wn * 32 + (lane & 31), rbase = wm * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Cs[(rbase + (r & 3) + 8 * (r >> 2)) * CS + col] = acc[r];
+    }
+    __syncthreads();
+    const int H = P.N >> 2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int item = tid + 256 * it, rl = item >> 4, ul = item & 15;
+      const int row = ty * BG_T + rl, u = tx * 16 + ul;
+      if (row >= P.R || u >= H) continue;
+      f32x4 z = *reinterpret_cast<const f32x4*>(&Cs[rl * CS + 4 * ul]);
+      if (P.bias) z += ld4(P.bias + 4 * u);
+      const long pr = P.parent ? P.parent[row] : row;         // the previous state lives in the parent hypothesis' row
+      const float cprev = P.c_in[pr * H + u];
+      const float gi = p_sigmoid(z[0]), gj = p_tanh(z[1]), gf = p_sigmoid(z[2] + 1.0f), go = p_sigmoid(z[3]);   // cells.py:14-18
+      float c = gf * cprev + gi * gj;
+      c = fminf(1.0f, fmaxf(-1.0f, c));                        // cell_clip = 1.0
+      const float h = go * p_tanh(c);
+      P.c_out[(long)row * H + u] = c;
+      P.h_out[(long)row * H + u] = h;
+      if (P.seq_out) P.seq_out[(long)row * P.seq_sb + u] = h;
+    }
+  }
+}
+
+// ctx[r] = sum_j w_j pctx[j][r] with the softmax-merge weights of SRC_SOFTMAX (step.hip): M = max_j pm_j, w_j = exp(pm_j - M) / sum_j exp(pm_j - M) pl_j
+struct BCMech { const float* pm; const float* pl; const float* pctx; float* ctx; long ctx_sb; int D, nslab; };
+struct BCLaunch { int nmech, R; BCMech m[AVSR_MAX_MECH]; };
+
+__global__ __launch_bounds__(256) void beam_ctx_merge_kernel(const BCLaunch L) {
+  const BCMech& M = L.m[blockIdx.y];
+  const int r = blockIdx.x, c4 = threadIdx.x;
+  if (4 * c4 >= M.D) return;
+  float w[STEP_MAX_SLAB];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < STEP_MAX_SLAB; ++j) {
+    w[j] = j < M.nslab ? M.pm[(long)j * L.R + r] : -INFINITY;
+    mx = fmaxf(mx, w[j]);
+  }
+  float ls = 0.f;
+#pragma unroll
+  for (int j = 0; j < STEP_MAX_SLAB; ++j) {
+    const float e = (w[j] == -INFINITY) ? 0.f : expf(w[j] - mx);
+    ls += e * (j < M.nslab ? M.pl[(long)j * L.R + r] : 0.f);
+    w[j] = e;
+  }
+  const float inv = ls > 0.f ? 1.0f / ls : 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < STEP_MAX_SLAB; ++j)
+    if (j < M.nslab) acc += (w[j] * inv) * ld4(M.pctx + ((long)j * L.R + r) * M.D + 4 * c4);
+  st4(M.ctx + (long)r * M.ctx_sb + 4 * c4, acc);
+}
+
+// ---- host side (called from avsr_attn_rnn_fwd, mode 3) --------------------------------------------------------------------------
+int g_beam_dense = -1;        // -1: read AVSR_BEAM_DENSE once (default on)
+
+bool beam_dense_on() {
+  if (g_beam_dense < 0) { const char* e = getenv("AVSR_BEAM_DENSE"); g_beam_dense = e ? (atoi(e) != 0) : 1; }
+  return g_beam_dense != 0;
+}
+
+// the LSTM cell step of all B rows.  Returns AVSR_ERR_UNSUPPORTED where the tiled kernel does not apply (the caller then runs step_kernel).
+int beam_cell_launch(const avsr_attn_rnn& d, int l, hipStream_t s) {
+  const int B = d.B, H = d.H, E = d.E, L = d.L, A = d.n_mech * H, KW = E + A + H;
+  if (d.cell != 0 || d.n_extra != 0 || E % 16 || H % 16 || E <= 0 || !d.embedding || !d.tok || !d.parent_rows) return AVSR_ERR_UNSUPPORTED;
+  if ((long)d.V * E * 4 >= (1L << 31) || (long)B * (L + 1) * (A > H ? A : H) * 4 >= (1L << 31) || (long)4 * H * KW * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
+  static thread_local BGLaunch G;
+  G = BGLaunch{};
+  BGProb& P = G.p[0];
+  BGSrc& x = P.src[P.nsrc++];
+  x.a = d.embedding; x.sb = E; x.gather = d.tok; x.K = E;
+  if (A > 0) { BGSrc& a = P.src[P.nsrc++]; a.a = d.att + (long)l * A; a.sb = (long)(L + 1) * A; a.gather = d.parent_rows; a.K = A; }
+  BGSrc& h = P.src[P.nsrc++];
+  h.a = d.state + (long)(l & 1) * B * H; h.sb = H; h.gather = d.parent_rows; h.K = H;
+  P.R = B; P.N = 4 * H; P.wt = d.wt; P.ldw = KW;
+  P.ntx = (P.N + BG_T - 1) / BG_T; P.tile0 = 0;
+  P.bias = d.bias; P.c_in = d.state + (long)(2 + (l & 1)) * B * H; P.parent = d.parent_rows;
+  P.c_out = d.state + (long)(2 + ((l + 1) & 1)) * B * H; P.h_out = d.state + (long)((l + 1) & 1) * B * H;
+  P.seq_out = d.cell_out + (long)(l + 1) * H; P.seq_sb = (long)(L + 1) * H;
+  G.nprob = 1; G.ntiles = P.ntx * ((B + BG_T - 1) / BG_T);
+  ProfScope ps(PROF_STEP_LSTM_FWD, s);
+  hipLaunchKernelGGL(beam_gemm_kernel<true>, dim3(G.ntiles), dim3(256), 0, s, G);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+// context merge + attention layers of all mechanisms (two launches).  nc[m] = chunks of mechanism m.
+int beam_attention_layer_launch(const avsr_attn_rnn& d, int l, hipStream_t s) {
+  const int B = d.B, H = d.H, L = d.L, A = d.n_mech * H;
+  if (d.n_mech < 1 || d.n_mech > BG_MAX_PROB || H % 16) return AVSR_ERR_UNSUPPORTED;
+  static thread_local BGLaunch G;
+  static thread_local BCLaunch C;
+  G = BGLaunch{}; C = BCLaunch{};
+  C.nmech = d.n_mech; C.R = B;
+  int tiles = 0, dmax = 0;
+  for (int m = 0; m < d.n_mech; ++m) {
+    const avsr_attn_mech& M = d.mech[m];
+    const int nc = (M.T + M.chunk - 1) / M.chunk;
+    if (M.D % 16 || nc > STEP_MAX_SLAB || M.D > 1024 || !M.ctx || (long)B * L * M.D * 4 >= (1L << 31) || (long)H * (H + M.D) * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
+    BCMech& X = C.m[m];
+    X.pm = M.pstat + (long)(2 * l) * nc * B; X.pl = M.pstat + (long)(2 * l + 1) * nc * B; X.pctx = M.pctx;
+    X.ctx = M.ctx + (long)l * M.D; X.ctx_sb = (long)L * M.D; X.D = M.D; X.nslab = nc;
+    dmax = M.D > dmax ? M.D : dmax;
+    BGProb& P = G.p[m];
+    BGSrc& q = P.src[P.nsrc++];
+    q.a = d.cell_out + (long)(l + 1) * H; q.sb = (long)(L + 1) * H; q.K = H;
+    BGSrc& c = P.src[P.nsrc++];
+    c.a = X.ctx; c.sb = X.ctx_sb; c.K = M.D;
+    P.R = B; P.N = H; P.wt = M.watt_t; P.ldw = H + M.D;
+    P.ntx = (H + BG_T - 1) / BG_T; P.tile0 = tiles;
+    tiles += P.ntx * ((B + BG_T - 1) / BG_T);
+    P.out = d.att + (long)(l + 1) * A + (long)m * H; P.out_sb = (long)(L + 1) * A;
+  }
+  G.nprob = d.n_mech; G.ntiles = tiles;
+  ProfScope ps(PROF_STEP_LINEAR, s);
+  hipLaunchKernelGGL(beam_ctx_merge_kernel, dim3(B, d.n_mech), dim3(((dmax / 4 + 63) / 64) * 64), 0, s, C);
+  hipLaunchKernelGGL(beam_gemm_kernel<false>, dim3(tiles), dim3(256), 0, s, G);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}
+
+}  // namespace avsr

@@ -452,8 +452,9 @@ def attn_rnn_set_fused(on):
 
 
 def attn_rnn_set_beam_kernel(on):
-    """Beam search: the K-hypotheses-per-workgroup attention kernel (default) or the general per-hypothesis one."""
-    check(_L().avsr_attn_rnn_set_beam_kernel(int(bool(on))), "avsr_attn_rnn_set_beam_kernel")
+    """Beam search kernels: 1 / True all beam-shaped kernels (default), 2 the K-hypotheses-per-workgroup attention kernel only, 0 the
+    general kernels everywhere (include/avsr_hip.h)."""
+    check(_L().avsr_attn_rnn_set_beam_kernel(int(on)), "avsr_attn_rnn_set_beam_kernel")
 
 
 def rnn_persistent_error():

@@ -349,9 +349,12 @@ int avsr_attn_rnn_fused_eligible(const avsr_attn_rnn* d);
  * under the same conditions.  Process-wide switch: 0 per-step launches, 1 (default) fused forward and backward, 2 forward only,
  * 3 backward only; the path also needs avsr_rnn_set_persistent's sync scratch. */
 int avsr_attn_rnn_set_fused(int32_t on);
-/* Beam search over shared memories (mode 3, mem_shared): 1 (default; AVSR_ATTN_BEAM in the environment sets the initial value) =
- * the per-step attention runs as one workgroup per (utterance, chunk) serving all K hypotheses (attn_fwd_beam_kernel), 0 = the
- * general per-hypothesis kernel.  Both give bit-identical scores, statistics and contexts (tests/test_gpu_beam.py). */
+/* Beam search (mode 3): which kernels run the B * K-row steps.  1 (default; AVSR_ATTN_BEAM / AVSR_BEAM_DENSE in the environment set
+ * the initial values) = all beam-shaped kernels: the per-step attention as one workgroup per (utterance, chunk) serving all K
+ * hypotheses over the shared memories (attn_fwd_beam_kernel), and the LSTM cell / attention layers as 64 x 64-tiled products with
+ * row-gathered operands (csrc/beam_gemm.hip); 2 = the attention kernel only, dense steps through the small-tile step kernel;
+ * 0 = the general kernels everywhere.  0 and 2 give bit-identical scores, statistics and contexts; 1 differs from them by the
+ * summation order of the dense products (tests/test_gpu_beam.py checks all three against the oracle). */
 int avsr_attn_rnn_set_beam_kernel(int32_t on);
 
 int avsr_attn_rnn_fwd(const avsr_attn_rnn* d, int32_t l_begin, int32_t l_end, void* stream);

@@ -89,6 +89,20 @@ def test_beam_width_parity(case, K):
         _beam_check(O, ocfg, mcfg, _trained(O, ocfg, W, batch, eos_bias), batch, K, 14, (case, K, eos_bias))
 
 
+@pytest.mark.parametrize("setting", [0, 2])
+@pytest.mark.parametrize("case", ["c4_bimodal_uni", "c2_audio_bi_bahdanau"])
+def test_beam_parity_with_the_general_kernels(case, setting):
+    """avsr_attn_rnn_set_beam_kernel(0 / 2): the small-tile step kernel for the dense steps (what GRU / multi-layer decoders still
+    take) with the general / the beam-shaped attention kernel -- the same oracle check as the default path above."""
+    from avsr_tf1_amd import ops
+    O, ocfg, mcfg, W, batch = make(case, B=5, Ta=70, Tv=9)
+    try:
+        ops.attn_rnn_set_beam_kernel(setting)
+        _beam_check(O, ocfg, mcfg, _trained(O, ocfg, W, batch, 1.0), batch, 10, 14, (case, setting))
+    finally:
+        ops.attn_rnn_set_beam_kernel(1)
+
+
 @pytest.mark.parametrize("unit", ["viseme", "phoneme"])
 @pytest.mark.parametrize("case", ["c1_audio_uni_luong", "c4_bimodal_uni", "c2_audio_bi_bahdanau", "c5_av_align", "gru_audio_uni"])
 def test_vocabulary_sizes_train_greedy_beam(case, unit):
@@ -168,7 +182,7 @@ def test_beam_attention_kernel_equals_general_kernel(case, K):
     db = Batch.from_numpy(batch)
     res = []
     try:
-        for on in (1, 0):
+        for on in (2, 0):                                        # 2: beam attention kernel, dense steps as in 0
             ops.attn_rnn_set_beam_kernel(on)
             m = Seq2SeqModel(mcfg, weights=W2)
             out = m.beam_search_decode(db, beam_width=K, max_steps=12, check_every=5, return_all=True)
@@ -196,7 +210,7 @@ def test_beam_search_over_768_wide_memories():
     db = Batch.from_numpy(batch)
     outs = []
     try:
-        for on in (1, 0):
+        for on in (2, 0):
             ops.attn_rnn_set_beam_kernel(on)
             for _rep in range(3):                                # the race was nondeterministic
                 outs.append(Seq2SeqModel(mcfg, weights=W2).beam_search_decode(db, beam_width=10, max_steps=10, check_every=4, return_all=True).cpu().numpy())
