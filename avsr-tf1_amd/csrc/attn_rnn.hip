@@ -196,33 +196,45 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* logits, long
                                  const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
                                  float* logp_out, int32_t* fin_out, int32_t* len_out, int32_t* tok, int32_t* parent_rows,
                                  int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished) {
-  extern __shared__ float sm[];          // scores [K*V] | totals [K*V] | lse [K] | length penalties [K][2]
+  extern __shared__ float sm[];          // scores [K*V] | totals [K*V] | lse [K] | length penalties [K][2] | logits [K*V] | fin [K] | len [K] | logp [K]
   float* score = sm;
   float* total = sm + K * V;
   float* lse_s = sm + 2 * K * V;
   float* pen = lse_s + K;
+  float* lg_s = pen + 2 * K;
+  int* fin_s = reinterpret_cast<int*>(lg_s + K * V);
+  int* len_s = fin_s + K;
+  float* logp_s = reinterpret_cast<float*>(len_s + K);
   const int b = blockIdx.x, lane = threadIdx.x;
   const float FMIN = -3.4028234663852886e38f;
+  const int n = K * V;
+  // everything the step reads from memory, in ONE round of loads (round 3 read the logits serially per beam and the parents' flags
+  // inside every selection round: ~10 dependent L2 round trips, most of the kernel's 22 us)
+  for (int i = lane; i < n; i += 64) {
+    const int k = i / V, v = i - k * V;
+    lg_s[i] = logits[(long)(b * K + k) * logits_sb + v];
+  }
+  for (int k = lane; k < K; k += 64) { fin_s[k] = fin_in[b * K + k]; len_s[k] = len_in[b * K + k]; logp_s[k] = logp_in[b * K + k]; }
+  __syncthreads();
   for (int k = lane; k < K; k += 64) {
-    const float* lg = logits + (long)(b * K + k) * logits_sb;
+    const float* lg = lg_s + k * V;
     float mx = lg[0];
     for (int v = 1; v < V; ++v) mx = fmaxf(mx, lg[v]);
     float s = 0.f;
     for (int v = 0; v < V; ++v) s += expf(lg[v] - mx);
     lse_s[k] = mx + logf(s);
     // a beam's continuations have one of two lengths: the same powf(...) values as one call per candidate, 2 instead of V per beam
-    const int ln = len_in[b * K + k];
+    const int ln = len_s[k];
     pen[2 * k] = powf((5.0f + (float)ln) / 6.0f, w);
     pen[2 * k + 1] = powf((5.0f + (float)(ln + 1)) / 6.0f, w);
   }
   __syncthreads();
-  const int n = K * V;
   for (int i = lane; i < n; i += 64) {
-    const int k = i / V, v = i - k * V, r = b * K + k;
-    const bool fin = fin_in[r] != 0;
-    const float lgv = logits[(long)r * logits_sb + v];
+    const int k = i / V, v = i - k * V;
+    const bool fin = fin_s[k] != 0;
+    const float lgv = lg_s[i];
     const float sl = fin ? (v == eos ? 0.f : FMIN) : lgv - lse_s[k];
-    const float tot = logp_in[r] + sl;
+    const float tot = logp_s[k] + sl;
     total[i] = tot;
     score[i] = tot / pen[2 * k + ((fin || v == eos) ? 0 : 1)];
   }
@@ -247,11 +259,11 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* logits, long
     if (lane == 0) {
       score[best] = __builtin_nanf("");
       const int word = best % V, parent = best / V, r = b * K + j, pr = b * K + parent;
-      const bool pf = fin_in[pr] != 0;
+      const bool pf = fin_s[parent] != 0;
       const int f = (pf || word == eos) ? 1 : 0;
       logp_out[r] = total[best];
       fin_out[r] = f;
-      len_out[r] = len_in[pr] + (pf ? 0 : 1);
+      len_out[r] = len_s[parent] + (pf ? 0 : 1);
       tok[r] = word;
       parent_rows[r] = pr;
       step_ids[r] = word;
@@ -371,7 +383,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
   if (d.mode == 2 && (!d.embedding || !d.wout_t || !d.logits || !d.xs || !d.labels || !d.fed || !d.seed)) return AVSR_ERR_ARG;
   if (d.mode == 3 && (!d.embedding || !d.wout_t || !d.logits || !d.tok || !d.n_unfinished || d.beam_width <= 0 || B % d.beam_width ||
                       !d.beam_logp || !d.beam_fin || !d.beam_len || !d.step_ids || !d.parent_ids || !d.parent_rows)) return AVSR_ERR_ARG;
-  if (d.mode == 3 && (size_t)2 * d.beam_width * d.V * sizeof(float) > 60000) return AVSR_ERR_UNSUPPORTED;
+  if (d.mode == 3 && (size_t)(3 * d.beam_width * d.V + 6 * d.beam_width) * sizeof(float) > 60000) return AVSR_ERR_UNSUPPORTED;
   const bool feed = (d.mode == 1 || d.mode == 3);      // inputs come from the embedding of the previous prediction
   const bool gru = d.cell == 1;
   if (gru && (!d.wt2 || !d.rh_seq)) return AVSR_ERR_ARG;
@@ -579,7 +591,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
                            d.ids + l, (long)L, d.tok, d.steplen, d.n_unfinished, B, l, d.eos_id);
       } else if (d.mode == 3) {
         const int K = d.beam_width, pin = l & 1, pout = (l + 1) & 1;
-        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(64), (2 * K * d.V + 3 * K) * sizeof(float), s, d.logits + (long)l * d.V,
+        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(64), (3 * K * d.V + 6 * K) * sizeof(float), s, d.logits + (long)l * d.V,
                            (long)L * d.V, d.V, K, l, d.eos_id, d.length_penalty, d.beam_logp + (long)pin * B, d.beam_fin + (long)pin * B,
                            d.beam_len + (long)pin * B, d.beam_logp + (long)pout * B, d.beam_fin + (long)pout * B,
                            d.beam_len + (long)pout * B, d.tok, d.parent_rows, d.step_ids + (long)l * B, d.parent_ids + (long)l * B,

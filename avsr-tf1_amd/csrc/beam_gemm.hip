@@ -5,7 +5,7 @@
 // product and the attention layers two [640 x 512] x [512 x 256] ones.  The per-step `step_kernel` (16 x 16 output tiles, built for
 // the 64-row steps of training, where only latency matters) runs them as 2560 / 1280 workgroups that re-read their operands from
 // L2 -- 46 + 41 us of the 145 us step (profiles/r03_decode_rates_v3.txt).  Here the same products are 64 x 64 output tiles walked
-// through LDS in 64-deep K stages (register prefetch of the next stage under the current stage's MFMAs), with the operand ROWS
+// through LDS in 64-deep K stages (coalesced row pieces, register prefetch of the next stage under the current stage's MFMAs), with the operand ROWS
 // GATHERED while they are staged -- token embedding by `tok`, attention record and recurrent state by the parent hypothesis'
 // row -- and the cell's gate math, clip and state update in the epilogue:
 //   beam_gemm_kernel<LSTM>    z = [emb[tok[r]] | att[parent[r]] | h[parent[r]]] . W + b -> i, j, f, o -> c, h of row r
@@ -37,9 +37,18 @@ struct BGProb {
 };
 struct BGLaunch { int nprob, ntiles; BGProb p[BG_MAX_PROB]; };
 
+// Operand staging.  Both operands are K-contiguous in memory (gathered activation rows; weight rows [N][ldw]).  A wave-instruction
+// fetches 4 rows x 256 contiguous bytes (16 lanes x 16 bytes per row: 8 full 128-byte lines; one lane per ROW, the obvious mapping,
+// is 64 different lines per instruction and ran the 640 x 1024 x 896 cell product at 34 us against its 13 us of matrix-pipe time) and
+// writes them to LDS as they are, row-major [row][k] with a pitch of 68 floats: conflict-free ds_write_b128 and ds_read_b128.
+// MFMA operand fetch: v_mfma_f32_32x32x2 takes ONE k per lane half; which k the two halves supply is free as long as A and B agree,
+// so lane half h owns k in [32 h, 32 h + 32) of a stage -- its 32 operand values are 8 ds_read_b128 of one LDS row -- and instruction
+// i multiplies the pair (i, 32 + i).
+#define BG_P 68            // LDS row pitch in floats (272 bytes: 16-byte aligned, rows 4 banks apart)
+
 template <bool LSTM>
 __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
-  __shared__ __attribute__((aligned(16))) float lds[2][2][BG_T * BG_T];      // [buffer][A | B][k][row or column]: 64 KB
+  __shared__ __attribute__((aligned(16))) float lds[2][2][BG_T * BG_P];      // [buffer][A | B][row or column][k]: 68 KB
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < BG_MAX_PROB; ++i) if (i < L.nprob && (int)blockIdx.x >= L.p[i].tile0) pi = i;
@@ -48,41 +57,54 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
   const int tile = blockIdx.x - P.tile0, tx = tile % P.ntx, ty = tile / P.ntx;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // ---- operand rows of this thread: A row (gathered per source) and weight row, both K-contiguous ----
-  const int mrow = ty * BG_T + lane, ncol = tx * BG_T + lane;
-  const bool rok = mrow < P.R, cok = ncol < P.N;
-  __amdgpu_buffer_rsrc_t ars[BG_MAX_SRC];
-  int aoff[BG_MAX_SRC], kbase[BG_MAX_SRC + 1];
+  // ---- staging role of this thread: piece p = row / column (tid >> 4) + 16 p of the tile, k = 4 (tid & 15) of the stage ----
+  const int srow = tid >> 4, sk = 4 * (tid & 15);
+  int kbase[BG_MAX_SRC + 1];
   kbase[0] = 0;
+#pragma unroll
+  for (int s = 0; s < BG_MAX_SRC; ++s) kbase[s + 1] = kbase[s] + (s < P.nsrc ? P.src[s].K : 0);
+  const int Ktot = kbase[BG_MAX_SRC];
+  __amdgpu_buffer_rsrc_t ars[BG_MAX_SRC];
+  int aoff[BG_MAX_SRC][4];                       // byte offset of the gathered row of piece p in source s
 #pragma unroll
   for (int s = 0; s < BG_MAX_SRC; ++s) {
     const bool on = s < P.nsrc;
     ars[s] = make_rsrc(on ? P.src[s].a : P.wt);
-    long rb = mrow;
-    if (on && rok && P.src[s].gather) rb = P.src[s].gather[mrow];
-    aoff[s] = (on && rok) ? (int)(rb * P.src[s].sb * 4) : P_OOB;
-    kbase[s + 1] = kbase[s] + (on ? P.src[s].K : 0);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int mrow = ty * BG_T + srow + 16 * p;
+      const bool rok = on && mrow < P.R;
+      long rb = mrow;
+      if (rok && P.src[s].gather) rb = P.src[s].gather[mrow];
+      aoff[s][p] = rok ? (int)(rb * P.src[s].sb * 4) : P_OOB;
+    }
   }
-  const int Ktot = kbase[BG_MAX_SRC];
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(P.wt);
-  const int woff = cok ? (int)((long)ncol * P.ldw * 4) : P_OOB;
+  int woff[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ncol = tx * BG_T + srow + 16 * p;
+    woff[p] = ncol < P.N ? (int)((long)ncol * P.ldw * 4) : P_OOB;
+  }
   const int nstage = (Ktot + BG_T - 1) / BG_T;
 
   f32x4 ra[4], rb4[4];
   auto fetch = [&](int st) {
+    const int k = st * BG_T + sk;                  // the 16 lanes of a row may straddle two sources (sources are multiples of 16 wide)
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < BG_MAX_SRC; ++q) if (k >= kbase[q]) s = q;
+    const bool in = k < Ktot;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int k = st * BG_T + 16 * p + 4 * wave;          // wave-uniform: the source of a piece is found by scalar compares
-      int s = 0;
+      // one load per source with an out-of-range offset where it does not apply (unconditional loads keep exact vmcnt counting);
+      // the pieces of the sources a lane does not read return zero and are added
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 1; q < BG_MAX_SRC; ++q) if (k >= kbase[q]) s = q;
-      const bool in = k < Ktot;
-      int ao = P_OOB;
-      __amdgpu_buffer_rsrc_t rs = ars[0];
-#pragma unroll
-      for (int q = 0; q < BG_MAX_SRC; ++q) if (q == s) { rs = ars[q]; ao = (in && aoff[q] != P_OOB) ? aoff[q] + (k - kbase[q]) * 4 : P_OOB; }
-      ra[p] = ldb4(rs, ao);
-      rb4[p] = ldb4(wrs, (in && cok) ? woff + k * 4 : P_OOB);
+      for (int q = 0; q < BG_MAX_SRC; ++q)
+        v += ldb4(ars[q], (in && q == s && aoff[q][p] != P_OOB) ? aoff[q][p] + (k - kbase[q]) * 4 : P_OOB);
+      ra[p] = v;
+      rb4[p] = ldb4(wrs, (in && woff[p] != P_OOB) ? woff[p] + k * 4 : P_OOB);
     }
   };
   auto commit = [&](int buf) {
@@ -90,9 +112,8 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
     float* Bs = lds[buf][1];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int k = 16 * p + 4 * wave;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { As[(k + e) * BG_T + lane] = ra[p][e]; Bs[(k + e) * BG_T + lane] = rb4[p][e]; }
+      *reinterpret_cast<f32x4*>(&As[(srow + 16 * p) * BG_P + sk]) = ra[p];
+      *reinterpret_cast<f32x4*>(&Bs[(srow + 16 * p) * BG_P + sk]) = rb4[p];
     }
   };
 
@@ -103,14 +124,23 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
   commit(0);
   if (nstage > 1) fetch(1);
   __syncthreads();
+  const int hk = 32 * (lane >> 5);
   for (int st = 0; st < nstage; ++st) {
     const int buf = st & 1;
-    const float* As = lds[buf][0] + wm * 32 + (lane & 31);
-    const float* Bs = lds[buf][1] + wn * 32 + (lane & 31);
+    const float* Ar = lds[buf][0] + (wm * 32 + (lane & 31)) * BG_P + hk;
+    const float* Br = lds[buf][1] + (wn * 32 + (lane & 31)) * BG_P + hk;
 #pragma unroll
-    for (int kk = 0; kk < BG_T / 2; ++kk) {
-      const int k = 2 * kk + (lane >> 5);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * BG_T], Bs[k * BG_T], acc, 0, 0, 0);
+    for (int half = 0; half < 2; ++half) {
+      f32x4 a4[4], b4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a4[j] = *reinterpret_cast<const f32x4*>(Ar + 16 * half + 4 * j);
+        b4[j] = *reinterpret_cast<const f32x4*>(Br + 16 * half + 4 * j);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j][e], b4[j][e], acc, 0, 0, 0);
     }
     if (st + 1 < nstage) {
       commit(buf ^ 1);                                       // the stage fetched while the previous one was multiplied
@@ -132,7 +162,7 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
     }
   } else {
     // gate pre-activations of a unit sit in four adjacent columns: through LDS into (row, unit) order
-    constexpr int CS = BG_T + 4;                               // row stride of the staged tile (16-byte aligned rows)
+    constexpr int CS = BG_P;                                   // row stride of the staged tile (16-byte aligned rows)
     float* Cs = &lds[0][0][0];
     {
       const int col = wn * 32 + (lane & 31), rbase = wm * 32 + 4 * (lane >> 5);
