@@ -58,25 +58,47 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   // ---- staging role of this thread: piece p = row / column (tid >> 4) + 16 p of the tile, k = 4 (tid & 15) of the stage ----
+  // A stage never straddles two sources: every source occupies whole 64-deep stages of a VIRTUAL K axis (its tail, if its width is
+  // not a multiple of 64, reads zeros on both operands), so the source of a stage is wave-uniform -- one load per piece, its resource
+  // and row offset picked by scalar selects, and no arithmetic on a loaded value before the stage is committed to LDS: the loads of
+  // stage s + 2 stay in flight under the MFMAs of stage s + 1.  (Summing one load per source, zeros where it did not apply, made the
+  // compiler wait for every load right behind its issue: 36 us for the 640 x 1024 x 896 cell product.)
   const int srow = tid >> 4, sk = 4 * (tid & 15);
-  int kbase[BG_MAX_SRC + 1];
-  kbase[0] = 0;
-#pragma unroll
-  for (int s = 0; s < BG_MAX_SRC; ++s) kbase[s + 1] = kbase[s] + (s < P.nsrc ? P.src[s].K : 0);
-  const int Ktot = kbase[BG_MAX_SRC];
-  __amdgpu_buffer_rsrc_t ars[BG_MAX_SRC];
-  int aoff[BG_MAX_SRC][4];                       // byte offset of the gathered row of piece p in source s
+  int kreal[BG_MAX_SRC + 1], sbeg[BG_MAX_SRC + 1];          // first real k / first stage of every source
+  kreal[0] = 0; sbeg[0] = 0;
 #pragma unroll
   for (int s = 0; s < BG_MAX_SRC; ++s) {
-    const bool on = s < P.nsrc;
-    ars[s] = make_rsrc(on ? P.src[s].a : P.wt);
+    const int Ks = s < P.nsrc ? P.src[s].K : 0;
+    kreal[s + 1] = kreal[s] + Ks;
+    sbeg[s + 1] = sbeg[s] + (Ks + BG_T - 1) / BG_T;
+  }
+  const int nstage = sbeg[BG_MAX_SRC];
+  const float* abase[BG_MAX_SRC];
+  int aoff[BG_MAX_SRC][4];                       // byte offset of the gathered row of piece p in source s
+  {
+    int gi[BG_MAX_SRC][4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int mrow = ty * BG_T + srow + 16 * p;
-      const bool rok = on && mrow < P.R;
-      long rb = mrow;
-      if (rok && P.src[s].gather) rb = P.src[s].gather[mrow];
-      aoff[s][p] = rok ? (int)(rb * P.src[s].sb * 4) : P_OOB;
+    for (int s = 0; s < BG_MAX_SRC; ++s) {       // all gather indices in one round of loads (a branch per index serialised 12 round trips)
+      const bool on = s < P.nsrc;
+      const bool hasg = on && P.src[s].gather != nullptr;
+      const __amdgpu_buffer_rsrc_t grs = make_rsrc(hasg ? (const void*)P.src[s].gather : (const void*)P.wt);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int mrow = ty * BG_T + srow + 16 * p;
+        gi[s][p] = __builtin_bit_cast(int, ldb1(grs, (hasg && mrow < P.R) ? mrow * 4 : P_OOB));
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < BG_MAX_SRC; ++s) {
+      const bool on = s < P.nsrc;
+      const bool hasg = on && P.src[s].gather != nullptr;
+      abase[s] = on ? P.src[s].a : P.wt;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int mrow = ty * BG_T + srow + 16 * p;
+        const long rb = hasg ? (long)gi[s][p] : (long)mrow;
+        aoff[s][p] = (on && mrow < P.R) ? (int)(rb * P.src[s].sb * 4) : P_OOB;
+      }
     }
   }
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(P.wt);
@@ -86,25 +108,28 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
     const int ncol = tx * BG_T + srow + 16 * p;
     woff[p] = ncol < P.N ? (int)((long)ncol * P.ldw * 4) : P_OOB;
   }
-  const int nstage = (Ktot + BG_T - 1) / BG_T;
 
   f32x4 ra[4], rb4[4];
   auto fetch = [&](int st) {
-    const int k = st * BG_T + sk;                  // the 16 lanes of a row may straddle two sources (sources are multiples of 16 wide)
     int s = 0;
 #pragma unroll
-    for (int q = 1; q < BG_MAX_SRC; ++q) if (k >= kbase[q]) s = q;
-    const bool in = k < Ktot;
+    for (int q = 1; q < BG_MAX_SRC; ++q) if (st >= sbeg[q]) s = q;
+    s = __builtin_amdgcn_readfirstlane(s);                                        // uniform
+    const int kl = (st - sbeg[s]) * BG_T + sk;                                    // k inside the source
+    const int Ks = kreal[s + 1] - kreal[s];
+    const bool in = kl < Ks;
+    // (the resource is rebuilt from a pointer forced into SGPRs: selected as a value, the compiler treats it as divergent and wraps
+    // every load in a readfirstlane loop with a full wait behind it)
+    const float* ab = s == 0 ? abase[0] : (s == 1 ? abase[1] : abase[2]);
+    const unsigned long au = reinterpret_cast<unsigned long>(ab);
+    const unsigned long auu = ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(au >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)au);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const float*>(auu));
+    const int kw = (kreal[s] + kl) * 4;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      // one load per source with an out-of-range offset where it does not apply (unconditional loads keep exact vmcnt counting);
-      // the pieces of the sources a lane does not read return zero and are added
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < BG_MAX_SRC; ++q)
-        v += ldb4(ars[q], (in && q == s && aoff[q][p] != P_OOB) ? aoff[q][p] + (k - kbase[q]) * 4 : P_OOB);
-      ra[p] = v;
-      rb4[p] = ldb4(wrs, (in && woff[p] != P_OOB) ? woff[p] + k * 4 : P_OOB);
+      const int ao = s == 0 ? aoff[0][p] : (s == 1 ? aoff[1][p] : aoff[2][p]);
+      ra[p] = ldb4(rs, (in && ao != P_OOB) ? ao + kl * 4 : P_OOB);
+      rb4[p] = ldb4(wrs, (in && woff[p] != P_OOB) ? woff[p] + kw : P_OOB);
     }
   };
   auto commit = [&](int buf) {
@@ -129,18 +154,27 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
     const int buf = st & 1;
     const float* Ar = lds[buf][0] + (wm * 32 + (lane & 31)) * BG_P + hk;
     const float* Br = lds[buf][1] + (wn * 32 + (lane & 31)) * BG_P + hk;
+    // four quarters of 16 k (8 per lane half); the operand reads of quarter q + 1 are issued ahead of the MFMAs of quarter q
+    f32x4 a4[2][2], b4[2][2];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      f32x4 a4[4], b4[4];
+    for (int j = 0; j < 2; ++j) {
+      a4[0][j] = *reinterpret_cast<const f32x4*>(Ar + 4 * j);
+      b4[0][j] = *reinterpret_cast<const f32x4*>(Br + 4 * j);
+    }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        a4[j] = *reinterpret_cast<const f32x4*>(Ar + 16 * half + 4 * j);
-        b4[j] = *reinterpret_cast<const f32x4*>(Br + 16 * half + 4 * j);
+    for (int qt = 0; qt < 4; ++qt) {
+      if (qt + 1 < 4) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          a4[(qt + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Ar + 8 * (qt + 1) + 4 * j);
+          b4[(qt + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Br + 8 * (qt + 1) + 4 * j);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);          // (the compiler otherwise sinks the reads to just ahead of their first MFMA)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j][e], b4[j][e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qt & 1][j][e], b4[qt & 1][j][e], acc, 0, 0, 0);
     }
     if (st + 1 < nstage) {
       commit(buf ^ 1);                                       // the stage fetched while the previous one was multiplied

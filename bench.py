@@ -366,7 +366,7 @@ def main():
         pmc, pmc_file = {}, None
         try:
             if args.workload == "c4" and args.video_frontend == "resnet_cnn":
-                for cand in ("r03_c4_lipcnn_pmc_v2.json", "r03_c4_lipcnn_pmc_v1.json", "r02_c4_lipcnn_pmc_v5.json"):
+                for cand in ("r04_c4_lipcnn_pmc_v1.json", "r03_c4_lipcnn_pmc_v2.json", "r03_c4_lipcnn_pmc_v1.json", "r02_c4_lipcnn_pmc_v5.json"):
                     path = os.path.join(ROOT, "profiles", cand)
                     if os.path.exists(path):
                         pmc, pmc_file = json.load(open(path))["kernels"], "profiles/" + cand
@@ -375,6 +375,22 @@ def main():
             pmc, pmc_file = {}, None
         # `traffic` is NOT measured in this run: it is read from the committed PMC summary above (separate rocprofv3 --pmc passes)
         out["traffic_source"] = pmc_file
+        # ONE correction rule, calibrated on this GPU with known-bytes kernels in the engine's access forms (tools/pmc_calibrate.py ->
+        # profiles/r04_pmc_calibration.json): FETCH_SIZE counts L2-miss read REQUESTS at 64 B apiece, and a request that needs a whole
+        # 128-byte line is one request -- contiguous reads of every width (4 / 8 / 16 B per lane, global, buffer and LDS-DMA loads) are
+        # reported at exactly half their bytes, half-line reads exactly; WRITE_SIZE is exact; Infinity-Cache hits are counted.
+        # traffic = fetch_factor * FETCH_SIZE + write_factor * WRITE_SIZE (every kernel of this engine streams whole lines).
+        fetch_factor, write_factor, calib_file = 2.0, 1.0, None
+        try:
+            cpath = os.path.join(ROOT, "profiles", "r04_pmc_calibration.json")
+            ck = json.load(open(cpath))["kernels"]
+            fetch_factor = float(ck["calib_rd16b"]["factor_true_over_reported"])
+            write_factor = float(ck["calib_wr16"]["factor_true_over_reported"])
+            calib_file = "profiles/r04_pmc_calibration.json"
+        except Exception:
+            pass
+        out["traffic_correction"] = {"fetch_factor": fetch_factor, "write_factor": write_factor, "calibration": calib_file,
+                                     "rule": "traffic = fetch_factor * FETCH_SIZE + write_factor * WRITE_SIZE per dispatch"}
         # kernel-name prefixes of the PMC summary (template arguments vary with the configuration: the first match is taken)
         pmc_name = {"attn_fwd": ["avsr::attn_fwd_kernel"], "attn_bwd": ["avsr::attn_bwd_kernel"],
                     "dec_persist_fwd": ["avsr::dec_persist_kernel<"], "dec_persist_bwd": ["avsr::dec_persist_bwd_kernel<"],
@@ -387,7 +403,10 @@ def main():
             for prefix in pmc_name.get(kind, []):
                 for name in sorted(pmc):
                     if name.startswith(prefix):
-                        return pmc[name]["hbm_bytes_per_dispatch_corrected"]
+                        e = pmc[name]
+                        if "FETCH_SIZE_KiB" in e and "WRITE_SIZE_KiB" in e:
+                            return int(1024.0 * (fetch_factor * e["FETCH_SIZE_KiB"] + write_factor * e["WRITE_SIZE_KiB"]))
+                        return e["hbm_bytes_per_dispatch_corrected"]
             return None
 
         def roof(kind):
