@@ -188,15 +188,17 @@ __global__ __launch_bounds__(256) void logits_sample_kernel(const float* x, long
   }
 }
 
-// One BeamSearchDecoder step for one utterance (one wave per utterance): see avsr_hip.h mode 3 and oracle.beam_search_decode.
-// Candidate scores of all K*V continuations are computed by the whole wave; the top K are K rounds of a wave arg-max (value, then
-// LOWER index on ties = tf.nn.top_k's order).  (Round 2: one thread selected serially -- 165 us per step, the largest kernel of the
-// reference's default evaluation path.)  The per-beam log-sum-exp keeps its serial summation order (bit-identical candidates).
-__global__ __launch_bounds__(64) void beam_step_kernel(const float* logits, long logits_sb, int V, int K, int l, int eos, float w,
+// One BeamSearchDecoder step for one utterance (one 256-thread workgroup per utterance): see avsr_hip.h mode 3 and
+// oracle.beam_search_decode.  Everything the step reads comes in with ONE round of loads; the per-beam log-sum-exp is a wave
+// reduction (one wave per beam in turn); the top K of the K * V candidate scores are found by RANK: candidate i counts the candidates
+// that beat it (larger score, or equal score and lower index = tf.nn.top_k's order) with broadcast LDS reads, and the K candidates of
+// rank < K write themselves to slot `rank` -- no serial selection rounds.  (Round 2: one thread selected serially, 165 us per step;
+// round 3: K rounds of a wave arg-max with the parents' flags loaded inside every round, 22 us.)
+__global__ __launch_bounds__(256) void beam_step_kernel(const float* logits, long logits_sb, int V, int K, int l, int eos, float w,
                                  const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
                                  float* logp_out, int32_t* fin_out, int32_t* len_out, int32_t* tok, int32_t* parent_rows,
                                  int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished) {
-  extern __shared__ float sm[];          // scores [K*V] | totals [K*V] | lse [K] | length penalties [K][2] | logits [K*V] | fin [K] | len [K] | logp [K]
+  extern __shared__ float sm[];          // scores [K*V] | totals [K*V] | lse [K] | length penalties [K][2] | logits [K*V] | fin [K] | len [K] | logp [K] | alive
   float* score = sm;
   float* total = sm + K * V;
   float* lse_s = sm + 2 * K * V;
@@ -205,63 +207,55 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* logits, long
   int* fin_s = reinterpret_cast<int*>(lg_s + K * V);
   int* len_s = fin_s + K;
   float* logp_s = reinterpret_cast<float*>(len_s + K);
-  const int b = blockIdx.x, lane = threadIdx.x;
+  int* alive_s = reinterpret_cast<int*>(logp_s + K);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float FMIN = -3.4028234663852886e38f;
   const int n = K * V;
-  // everything the step reads from memory, in ONE round of loads (round 3 read the logits serially per beam and the parents' flags
-  // inside every selection round: ~10 dependent L2 round trips, most of the kernel's 22 us)
-  for (int i = lane; i < n; i += 64) {
+  for (int i = tid; i < n; i += 256) {
     const int k = i / V, v = i - k * V;
     lg_s[i] = logits[(long)(b * K + k) * logits_sb + v];
   }
-  for (int k = lane; k < K; k += 64) { fin_s[k] = fin_in[b * K + k]; len_s[k] = len_in[b * K + k]; logp_s[k] = logp_in[b * K + k]; }
+  if (tid < K) { fin_s[tid] = fin_in[b * K + tid]; len_s[tid] = len_in[b * K + tid]; logp_s[tid] = logp_in[b * K + tid]; }
+  if (tid == 0) alive_s[0] = 0;
   __syncthreads();
-  for (int k = lane; k < K; k += 64) {
-    const float* lg = lg_s + k * V;
-    float mx = lg[0];
-    for (int v = 1; v < V; ++v) mx = fmaxf(mx, lg[v]);
-    float s = 0.f;
-    for (int v = 0; v < V; ++v) s += expf(lg[v] - mx);
-    lse_s[k] = mx + logf(s);
-    // a beam's continuations have one of two lengths: the same powf(...) values as one call per candidate, 2 instead of V per beam
-    const int ln = len_s[k];
-    pen[2 * k] = powf((5.0f + (float)ln) / 6.0f, w);
-    pen[2 * k + 1] = powf((5.0f + (float)(ln + 1)) / 6.0f, w);
+  for (int k = wave; k < K; k += 4) {                 // log-sum-exp of beam k: wave reductions over its V logits
+    float mx = -INFINITY;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, lg_s[k * V + v]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int v = lane; v < V; v += 64) sum += expf(lg_s[k * V + v] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) {
+      lse_s[k] = mx + logf(sum);
+      // a beam's continuations have one of two lengths: the same powf(...) values as one call per candidate, 2 instead of V per beam
+      const int ln = len_s[k];
+      pen[2 * k] = powf((5.0f + (float)ln) / 6.0f, w);
+      pen[2 * k + 1] = powf((5.0f + (float)(ln + 1)) / 6.0f, w);
+    }
   }
   __syncthreads();
-  for (int i = lane; i < n; i += 64) {
+  for (int i = tid; i < n; i += 256) {
     const int k = i / V, v = i - k * V;
     const bool fin = fin_s[k] != 0;
-    const float lgv = lg_s[i];
-    const float sl = fin ? (v == eos ? 0.f : FMIN) : lgv - lse_s[k];
+    const float sl = fin ? (v == eos ? 0.f : FMIN) : lg_s[i] - lse_s[k];
     const float tot = logp_s[k] + sl;
     total[i] = tot;
     score[i] = tot / pen[2 * k + ((fin || v == eos) ? 0 : 1)];
   }
   __syncthreads();
   int alive = 0;
-  for (int j = 0; j < K; ++j) {
-    // this lane's best remaining candidate (NaN marks a selected one), then the wave's: larger score, lower index on ties
-    float bs = 0.f;
-    int best = 0x7fffffff;
-    for (int i = lane; i < n; i += 64) {
-      const float sc = score[i];
-      if (sc != sc) continue;
-      if (best == 0x7fffffff || sc > bs) { best = i; bs = sc; }
+  for (int i = tid; i < n; i += 256) {
+    const float si = score[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {                     // every lane reads the same word: LDS broadcast
+      const float sj = score[j];
+      rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float os = __shfl_xor(bs, o, 64);
-      const int ob = __shfl_xor(best, o, 64);
-      const bool take = ob != 0x7fffffff && (best == 0x7fffffff || os > bs || (os == bs && ob < best));
-      if (take) { bs = os; best = ob; }
-    }
-    if (lane == 0) {
-      score[best] = __builtin_nanf("");
-      const int word = best % V, parent = best / V, r = b * K + j, pr = b * K + parent;
+    if (rank < K) {
+      const int word = i % V, parent = i / V, r = b * K + rank, pr = b * K + parent;
       const bool pf = fin_s[parent] != 0;
       const int f = (pf || word == eos) ? 1 : 0;
-      logp_out[r] = total[best];
+      logp_out[r] = total[i];
       fin_out[r] = f;
       len_out[r] = len_s[parent] + (pf ? 0 : 1);
       tok[r] = word;
@@ -270,9 +264,10 @@ __global__ __launch_bounds__(64) void beam_step_kernel(const float* logits, long
       parent_ids[r] = parent;
       if (!f) ++alive;
     }
-    __syncthreads();
   }
-  if (lane == 0 && alive) atomicAdd(n_unfinished, alive);
+  if (alive) atomicAdd(alive_s, alive);
+  __syncthreads();
+  if (tid == 0 && alive_s[0]) atomicAdd(n_unfinished, alive_s[0]);
 }
 
 __global__ void beam_gather_tree_kernel(const int32_t* step_ids, const int32_t* parent_ids, const int32_t* beam_len, int32_t* out,
@@ -383,7 +378,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
   if (d.mode == 2 && (!d.embedding || !d.wout_t || !d.logits || !d.xs || !d.labels || !d.fed || !d.seed)) return AVSR_ERR_ARG;
   if (d.mode == 3 && (!d.embedding || !d.wout_t || !d.logits || !d.tok || !d.n_unfinished || d.beam_width <= 0 || B % d.beam_width ||
                       !d.beam_logp || !d.beam_fin || !d.beam_len || !d.step_ids || !d.parent_ids || !d.parent_rows)) return AVSR_ERR_ARG;
-  if (d.mode == 3 && (size_t)(3 * d.beam_width * d.V + 6 * d.beam_width) * sizeof(float) > 60000) return AVSR_ERR_UNSUPPORTED;
+  if (d.mode == 3 && (size_t)(3 * d.beam_width * d.V + 6 * d.beam_width + 4) * sizeof(float) > 60000) return AVSR_ERR_UNSUPPORTED;
   const bool feed = (d.mode == 1 || d.mode == 3);      // inputs come from the embedding of the previous prediction
   const bool gru = d.cell == 1;
   if (gru && (!d.wt2 || !d.rh_seq)) return AVSR_ERR_ARG;
@@ -591,7 +586,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
                            d.ids + l, (long)L, d.tok, d.steplen, d.n_unfinished, B, l, d.eos_id);
       } else if (d.mode == 3) {
         const int K = d.beam_width, pin = l & 1, pout = (l + 1) & 1;
-        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(64), (3 * K * d.V + 6 * K) * sizeof(float), s, d.logits + (long)l * d.V,
+        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(256), (3 * K * d.V + 6 * K + 4) * sizeof(float), s, d.logits + (long)l * d.V,
                            (long)L * d.V, d.V, K, l, d.eos_id, d.length_penalty, d.beam_logp + (long)pin * B, d.beam_fin + (long)pin * B,
                            d.beam_len + (long)pin * B, d.beam_logp + (long)pout * B, d.beam_fin + (long)pout * B,
                            d.beam_len + (long)pout * B, d.tok, d.parent_rows, d.step_ids + (long)l * B, d.parent_ids + (long)l * B,

@@ -47,7 +47,7 @@ struct BGLaunch { int nprob, ntiles; BGProb p[BG_MAX_PROB]; };
 #define BG_P 68            // LDS row pitch in floats (272 bytes: 16-byte aligned, rows 4 banks apart)
 
 template <bool LSTM>
-__global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
+__global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][BG_T * BG_P];      // [buffer][A | B][row or column][k]: 68 KB
   int pi = 0;
 #pragma unroll
@@ -56,8 +56,11 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
   const BGProb& P = L.p[pi];
   const int tile = blockIdx.x - P.tile0, tx = tile % P.ntx, ty = tile / P.ntx;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  // ---- staging role of this thread: piece p = row / column (tid >> 4) + 16 p of the tile, k = 4 (tid & 15) of the stage ----
+  // 8 waves, two per SIMD: wave = (k half of a stage, 32 x 32 quadrant).  The two waves of a SIMD work on the same quadrant's two k halves,
+  // so one's LDS / barrier / staging stalls are covered by the other's MFMAs (one wave per SIMD ran the cell product at 2.1 us per
+  // stage against 0.93 us of matrix-pipe time); the halves meet through LDS once, after the last stage.
+  const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  // ---- staging role of this thread: piece p = row / column (tid >> 4) + 32 p of the tile, k = 4 (tid & 15) of the stage ----
   // A stage never straddles two sources: every source occupies whole 64-deep stages of a VIRTUAL K axis (its tail, if its width is
   // not a multiple of 64, reads zeros on both operands), so the source of a stage is wave-uniform -- one load per piece, its resource
   // and row offset picked by scalar selects, and no arithmetic on a loaded value before the stage is committed to LDS: the loads of
@@ -74,17 +77,17 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
   }
   const int nstage = sbeg[BG_MAX_SRC];
   const float* abase[BG_MAX_SRC];
-  int aoff[BG_MAX_SRC][4];                       // byte offset of the gathered row of piece p in source s
+  int aoff[BG_MAX_SRC][2];                       // byte offset of the gathered row of piece p in source s
   {
-    int gi[BG_MAX_SRC][4];
+    int gi[BG_MAX_SRC][2];
 #pragma unroll
-    for (int s = 0; s < BG_MAX_SRC; ++s) {       // all gather indices in one round of loads (a branch per index serialised 12 round trips)
+    for (int s = 0; s < BG_MAX_SRC; ++s) {       // all gather indices in one round of loads (a branch per index serialised the round trips)
       const bool on = s < P.nsrc;
       const bool hasg = on && P.src[s].gather != nullptr;
       const __amdgpu_buffer_rsrc_t grs = make_rsrc(hasg ? (const void*)P.src[s].gather : (const void*)P.wt);
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int mrow = ty * BG_T + srow + 16 * p;
+      for (int p = 0; p < 2; ++p) {
+        const int mrow = ty * BG_T + srow + 32 * p;
         gi[s][p] = __builtin_bit_cast(int, ldb1(grs, (hasg && mrow < P.R) ? mrow * 4 : P_OOB));
       }
     }
@@ -94,22 +97,22 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
       const bool hasg = on && P.src[s].gather != nullptr;
       abase[s] = on ? P.src[s].a : P.wt;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int mrow = ty * BG_T + srow + 16 * p;
+      for (int p = 0; p < 2; ++p) {
+        const int mrow = ty * BG_T + srow + 32 * p;
         const long rb = hasg ? (long)gi[s][p] : (long)mrow;
         aoff[s][p] = (on && mrow < P.R) ? (int)(rb * P.src[s].sb * 4) : P_OOB;
       }
     }
   }
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(P.wt);
-  int woff[4];
+  int woff[2];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int ncol = tx * BG_T + srow + 16 * p;
+  for (int p = 0; p < 2; ++p) {
+    const int ncol = tx * BG_T + srow + 32 * p;
     woff[p] = ncol < P.N ? (int)((long)ncol * P.ldw * 4) : P_OOB;
   }
 
-  f32x4 ra[4], rb4[4];
+  f32x4 ra[2], rb4[2];
   auto fetch = [&](int st) {
     int s = 0;
 #pragma unroll
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const float*>(auu));
     const int kw = (kreal[s] + kl) * 4;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < 2; ++p) {
       const int ao = s == 0 ? aoff[0][p] : (s == 1 ? aoff[1][p] : aoff[2][p]);
       ra[p] = ldb4(rs, (in && ao != P_OOB) ? ao + kl * 4 : P_OOB);
       rb4[p] = ldb4(wrs, (in && woff[p] != P_OOB) ? woff[p] + kw : P_OOB);
@@ -136,9 +139,9 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
     float* As = lds[buf][0];
     float* Bs = lds[buf][1];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<f32x4*>(&As[(srow + 16 * p) * BG_P + sk]) = ra[p];
-      *reinterpret_cast<f32x4*>(&Bs[(srow + 16 * p) * BG_P + sk]) = rb4[p];
+    for (int p = 0; p < 2; ++p) {
+      *reinterpret_cast<f32x4*>(&As[(srow + 32 * p) * BG_P + sk]) = ra[p];
+      *reinterpret_cast<f32x4*>(&Bs[(srow + 32 * p) * BG_P + sk]) = rb4[p];
     }
   };
 
@@ -149,45 +152,49 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
   commit(0);
   if (nstage > 1) fetch(1);
   __syncthreads();
-  const int hk = 32 * (lane >> 5);
+  // lane half h of wave-half kh owns k in [32 kh + 16 h, + 16) of a stage: 4 ds_read_b128 per operand, instruction i multiplies the
+  // pair (i, 16 + i) of the wave's 32 k
+  const int hk = 32 * kh + 16 * (lane >> 5);
   for (int st = 0; st < nstage; ++st) {
     const int buf = st & 1;
     const float* Ar = lds[buf][0] + (wm * 32 + (lane & 31)) * BG_P + hk;
     const float* Br = lds[buf][1] + (wn * 32 + (lane & 31)) * BG_P + hk;
-    // four quarters of 16 k (8 per lane half); the operand reads of quarter q + 1 are issued ahead of the MFMAs of quarter q
-    f32x4 a4[2][2], b4[2][2];
+    f32x4 a4[4], b4[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      a4[0][j] = *reinterpret_cast<const f32x4*>(Ar + 4 * j);
-      b4[0][j] = *reinterpret_cast<const f32x4*>(Br + 4 * j);
+    for (int j = 0; j < 4; ++j) {
+      a4[j] = *reinterpret_cast<const f32x4*>(Ar + 4 * j);
+      b4[j] = *reinterpret_cast<const f32x4*>(Br + 4 * j);
     }
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      if (qt + 1 < 4) {
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          a4[(qt + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Ar + 8 * (qt + 1) + 4 * j);
-          b4[(qt + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Br + 8 * (qt + 1) + 4 * j);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);          // (the compiler otherwise sinks the reads to just ahead of their first MFMA)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[qt & 1][j][e], b4[qt & 1][j][e], acc, 0, 0, 0);
-    }
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j][e], b4[j][e], acc, 0, 0, 0);
     if (st + 1 < nstage) {
       commit(buf ^ 1);                                       // the stage fetched while the previous one was multiplied
       if (st + 2 < nstage) fetch(st + 2);
     }
     lds_barrier();
   }
+  // ---- the two k halves of a quadrant meet: waves 4-7 hand their accumulators to waves 0-3 through LDS ----
+  {
+    float* X = &lds[0][0][0] + ((wave & 3) * 64 + lane) * 17;             // 17-float stride: conflict-free scalar rows
+    if (kh == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) X[r] = acc[r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += X[r];
+    }
+    __syncthreads();
+  }
 
   // C layout of mfma 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   if constexpr (!LSTM) {
     const int col = tx * BG_T + wn * 32 + (lane & 31);
     const int rbase = ty * BG_T + wm * 32 + 4 * (lane >> 5);
-    if (col < P.N) {
+    if (kh == 0 && col < P.N) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -197,8 +204,8 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
   } else {
     // gate pre-activations of a unit sit in four adjacent columns: through LDS into (row, unit) order
     constexpr int CS = BG_P;                                   // row stride of the staged tile (16-byte aligned rows)
-    float* Cs = &lds[0][0][0];
-    {
+    float* Cs = &lds[1][0][0];
+    if (kh == 0) {
       const int col = wn * 32 + (lane & 31), rbase = wm * 32 + 4 * (lane >> 5);
 #pragma unroll
       for (int r = 0; r < 16; ++r) Cs[(rbase + (r & 3) + 8 * (r >> 2)) * CS + col] = acc[r];
@@ -206,8 +213,8 @@ __global__ __launch_bounds__(256) void beam_gemm_kernel(const BGLaunch L) {
     __syncthreads();
     const int H = P.N >> 2;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int item = tid + 256 * it, rl = item >> 4, ul = item & 15;
+    for (int it = 0; it < 2; ++it) {
+      const int item = tid + 512 * it, rl = item >> 4, ul = item & 15;
       const int row = ty * BG_T + rl, u = tx * 16 + ul;
       if (row >= P.R || u >= H) continue;
       f32x4 z = *reinterpret_cast<const f32x4*>(&Cs[rl * CS + 4 * ul]);
@@ -283,7 +290,7 @@ int beam_cell_launch(const avsr_attn_rnn& d, int l, hipStream_t s) {
   P.seq_out = d.cell_out + (long)(l + 1) * H; P.seq_sb = (long)(L + 1) * H;
   G.nprob = 1; G.ntiles = P.ntx * ((B + BG_T - 1) / BG_T);
   ProfScope ps(PROF_STEP_LSTM_FWD, s);
-  hipLaunchKernelGGL(beam_gemm_kernel<true>, dim3(G.ntiles), dim3(256), 0, s, G);
+  hipLaunchKernelGGL(beam_gemm_kernel<true>, dim3(G.ntiles), dim3(512), 0, s, G);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
@@ -318,7 +325,7 @@ int beam_attention_layer_launch(const avsr_attn_rnn& d, int l, hipStream_t s) {
   G.nprob = d.n_mech; G.ntiles = tiles;
   ProfScope ps(PROF_STEP_LINEAR, s);
   hipLaunchKernelGGL(beam_ctx_merge_kernel, dim3(B, d.n_mech), dim3(((dmax / 4 + 63) / 64) * 64), 0, s, C);
-  hipLaunchKernelGGL(beam_gemm_kernel<false>, dim3(tiles), dim3(256), 0, s, G);
+  hipLaunchKernelGGL(beam_gemm_kernel<false>, dim3(tiles), dim3(512), 0, s, G);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
