@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnLaunch L) {
 // softmax partials by one wave, context rows in row order then row groups in order), same outputs (raw scores, chunk max / sum,
 // un-normalised partial contexts by hypothesis row).  Luong / scaled Luong, H <= 256, chunk <= 64, D <= 1024, K <= 16.
 #define ATTN_BEAM_KMAX 16
+template <bool PF>
 __global__ __launch_bounds__(256) void attn_fwd_beam_kernel(const AttnLaunch L) {
   __shared__ float sc[ATTN_BEAM_KMAX][64];
   __shared__ __attribute__((aligned(16))) float qs[ATTN_BEAM_KMAX][256];
@@ -219,6 +220,21 @@ __global__ __launch_bounds__(256) void attn_fwd_beam_kernel(const AttnLaunch L) 
   const int H = M.H, D = M.D;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+  // ---- values of the first column block / row pass, requested FIRST: they travel under the whole key / score / softmax phase (the
+  //      two operand fetches of a step were two dependent bursts: 29 us for 75 MB at c4).  Hidden loads: the compiler would sink them
+  //      back to their first use. ----
+  const int cols = D >> 2;
+  const int vst = (int)M.values_st * 4;
+  f32x4 vr0[PF ? 16 : 1];
+  if constexpr (PF) {
+    const i32x4_ vrw = make_rsrc_words(M.values + (long)u * M.values_sb);
+    const int ccols0 = min(256, cols), G0 = 256 / ccols0, col0 = tid % ccols0, grp0 = tid / ccols0;
+#pragma unroll
+    for (int uu = 0; uu < 16; ++uu) {
+      const int r = grp0 + G0 * uu;
+      ldb4_hidden(vr0[uu], vrw, (grp0 < G0 && r < n) ? (t0 + r) * vst + col0 * 16 : P_OOB);
+    }
+  }
   // ---- keys of the chunk: 16 lanes per row, rows rg + 16*u4 ----
   const int s16 = tid & 15, rg = tid >> 4;
   {
@@ -274,9 +290,12 @@ __global__ __launch_bounds__(256) void attn_fwd_beam_kernel(const AttnLaunch L) 
   }
   __syncthreads();
   // ---- partial contexts: one float4 column per thread, G row groups; the chunk's values stay in registers for the K queries ----
-  const int cols = D >> 2;
   const __amdgpu_buffer_rsrc_t vrs = make_rsrc(M.values + (long)u * M.values_sb);
-  const int vst = (int)M.values_st * 4;
+  if constexpr (PF) {
+    vm_wait_all();
+#pragma unroll
+    for (int uu = 0; uu < 16; ++uu) vm_landed(vr0[uu]);
+  }
   for (int cb = 0; cb < cols; cb += 256) {
     const int ccols = min(256, cols - cb);
     const int G = 256 / ccols;                           // 64 columns (D = 256): four row groups of 16 rows
@@ -284,10 +303,15 @@ __global__ __launch_bounds__(256) void attn_fwd_beam_kernel(const AttnLaunch L) 
     const bool act = grp < G;
     for (int r0 = 0; r0 < n; r0 += 16 * G) {            // (G >= 4 at D <= 256: one trip)
       f32x4 vr[16];
+      if (PF && cb == 0 && r0 == 0) {                  // (uniform) the block requested at the top of the kernel
 #pragma unroll
-      for (int uu = 0; uu < 16; ++uu) {
-        const int r = r0 + grp + G * uu;
-        vr[uu] = ldb4(vrs, (act && r < n) ? (t0 + r) * vst + (cb + col) * 16 : P_OOB);
+        for (int uu = 0; uu < 16; ++uu) vr[uu] = vr0[PF ? uu : 0];
+      } else {
+#pragma unroll
+        for (int uu = 0; uu < 16; ++uu) {
+          const int r = r0 + grp + G * uu;
+          vr[uu] = ldb4(vrs, (act && r < n) ? (t0 + r) * vst + (cb + col) * 16 : P_OOB);
+        }
       }
       for (int k0 = 0; k0 < K; k0 += 8) {
         const int kn = min(8, K - k0);
@@ -533,7 +557,11 @@ extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stre
     nbeam += (L->B / (M.mem_div > 0 ? M.mem_div : 1)) * M.nchunk;
   }
   if (backward) hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *L);
-  else if (beam) hipLaunchKernelGGL(attn_fwd_beam_kernel, dim3(nbeam), dim3(256), 0, (hipStream_t)stream, *L);
+  else if (beam) {
+    static const int pf = getenv("AVSR_ATTN_BEAM_PREFETCH") ? atoi(getenv("AVSR_ATTN_BEAM_PREFETCH")) : 1;
+    if (pf) hipLaunchKernelGGL(attn_fwd_beam_kernel<true>, dim3(nbeam), dim3(256), 0, (hipStream_t)stream, *L);
+    else hipLaunchKernelGGL(attn_fwd_beam_kernel<false>, dim3(nbeam), dim3(256), 0, (hipStream_t)stream, *L);
+  }
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *L);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;

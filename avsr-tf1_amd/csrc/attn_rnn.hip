@@ -198,19 +198,20 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* logits, lon
                                  const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
                                  float* logp_out, int32_t* fin_out, int32_t* len_out, int32_t* tok, int32_t* parent_rows,
                                  int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished) {
-  extern __shared__ float sm[];          // scores [K*V] | totals [K*V] | lse [K] | length penalties [K][2] | logits [K*V] | fin [K] | len [K] | logp [K] | alive
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // scores [n4] | totals [K*V] | lse [K] | length penalties [K][2] | logits [K*V] | fin [K] | len [K] | logp [K] | alive
+  const int n = K * V, n4 = (n + 3) & ~3;               // scores are padded to whole float4s with -inf (never outrank anything)
   float* score = sm;
-  float* total = sm + K * V;
-  float* lse_s = sm + 2 * K * V;
+  float* total = sm + n4;
+  float* lse_s = total + n;
   float* pen = lse_s + K;
   float* lg_s = pen + 2 * K;
-  int* fin_s = reinterpret_cast<int*>(lg_s + K * V);
+  int* fin_s = reinterpret_cast<int*>(lg_s + n);
   int* len_s = fin_s + K;
   float* logp_s = reinterpret_cast<float*>(len_s + K);
   int* alive_s = reinterpret_cast<int*>(logp_s + K);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float FMIN = -3.4028234663852886e38f;
-  const int n = K * V;
+  if (tid < n4 - n) score[n + tid] = -INFINITY;
   for (int i = tid; i < n; i += 256) {
     const int k = i / V, v = i - k * V;
     lg_s[i] = logits[(long)(b * K + k) * logits_sb + v];
@@ -247,9 +248,18 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* logits, lon
   for (int i = tid; i < n; i += 256) {
     const float si = score[i];
     int rank = 0;
-    for (int j = 0; j < n; ++j) {                     // every lane reads the same word: LDS broadcast
-      const float sj = score[j];
-      rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+    for (int j = 0; j < n4; j += 16) {                // every lane reads the same words (LDS broadcast), 16 per round trip
+      f32x4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = (j + 4 * u < n4) ? *reinterpret_cast<const f32x4*>(score + j + 4 * u) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sj = q[u][e];
+          const int jj = j + 4 * u + e;
+          rank += (sj > si || (sj == si && jj < i)) ? 1 : 0;
+        }
     }
     if (rank < K) {
       const int word = i % V, parent = i / V, r = b * K + rank, pr = b * K + parent;
@@ -378,7 +388,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
   if (d.mode == 2 && (!d.embedding || !d.wout_t || !d.logits || !d.xs || !d.labels || !d.fed || !d.seed)) return AVSR_ERR_ARG;
   if (d.mode == 3 && (!d.embedding || !d.wout_t || !d.logits || !d.tok || !d.n_unfinished || d.beam_width <= 0 || B % d.beam_width ||
                       !d.beam_logp || !d.beam_fin || !d.beam_len || !d.step_ids || !d.parent_ids || !d.parent_rows)) return AVSR_ERR_ARG;
-  if (d.mode == 3 && (size_t)(3 * d.beam_width * d.V + 6 * d.beam_width + 4) * sizeof(float) > 60000) return AVSR_ERR_UNSUPPORTED;
+  if (d.mode == 3 && (size_t)(3 * d.beam_width * d.V + 6 * d.beam_width + 8) * sizeof(float) > 60000) return AVSR_ERR_UNSUPPORTED;
   const bool feed = (d.mode == 1 || d.mode == 3);      // inputs come from the embedding of the previous prediction
   const bool gru = d.cell == 1;
   if (gru && (!d.wt2 || !d.rh_seq)) return AVSR_ERR_ARG;
@@ -586,7 +596,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
                            d.ids + l, (long)L, d.tok, d.steplen, d.n_unfinished, B, l, d.eos_id);
       } else if (d.mode == 3) {
         const int K = d.beam_width, pin = l & 1, pout = (l + 1) & 1;
-        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(256), (3 * K * d.V + 6 * K + 4) * sizeof(float), s, d.logits + (long)l * d.V,
+        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(256), (3 * K * d.V + 6 * K + 8) * sizeof(float), s, d.logits + (long)l * d.V,
                            (long)L * d.V, d.V, K, l, d.eos_id, d.length_penalty, d.beam_logp + (long)pin * B, d.beam_fin + (long)pin * B,
                            d.beam_len + (long)pin * B, d.beam_logp + (long)pout * B, d.beam_fin + (long)pout * B,
                            d.beam_len + (long)pout * B, d.tok, d.parent_rows, d.step_ids + (long)l * B, d.parent_ids + (long)l * B,

@@ -131,8 +131,12 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int ao = s == 0 ? aoff[0][p] : (s == 1 ? aoff[1][p] : aoff[2][p]);
+#ifdef BG_NO_LOAD      // dissection build (tools/beam_gemm_dissect.sh): everything but the operand fetch
+      ra[p] = f32x4{(float)kl, 1.f, 2.f, (float)ao}; rb4[p] = f32x4{(float)kw, 1.f, 2.f, 3.f};
+#else
       ra[p] = ldb4(rs, (in && ao != P_OOB) ? ao + kl * 4 : P_OOB);
       rb4[p] = ldb4(wrs, (in && woff[p] != P_OOB) ? woff[p] + kw : P_OOB);
+#endif
     }
   };
   auto commit = [&](int buf) {
@@ -168,7 +172,13 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j][e], b4[j][e], acc, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) {
+#ifdef BG_NO_MFMA      // dissection build: everything but the matrix instructions
+        acc[(4 * j + e) & 15] += a4[j][e] * b4[j][e];
+#else
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j][e], b4[j][e], acc, 0, 0, 0);
+#endif
+      }
     if (st + 1 < nstage) {
       commit(buf ^ 1);                                       // the stage fetched while the previous one was multiplied
       if (st + 2 < nstage) fetch(st + 2);
