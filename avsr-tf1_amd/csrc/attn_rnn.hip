@@ -219,6 +219,10 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* logits, lon
   if (tid < K) { fin_s[tid] = fin_in[b * K + tid]; len_s[tid] = len_in[b * K + tid]; logp_s[tid] = logp_in[b * K + tid]; }
   if (tid == 0) alive_s[0] = 0;
   __syncthreads();
+#if defined(BS_STOP) && BS_STOP <= 1
+  if (tid == 0) n_unfinished[0] = (int)lg_s[0];
+  return;
+#endif
   for (int k = wave; k < K; k += 4) {                 // log-sum-exp of beam k: wave reductions over its V logits
     float mx = -INFINITY;
     for (int v = lane; v < V; v += 64) mx = fmaxf(mx, lg_s[k * V + v]);
@@ -235,6 +239,10 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* logits, lon
     }
   }
   __syncthreads();
+#if defined(BS_STOP) && BS_STOP <= 2
+  if (tid == 0) n_unfinished[0] = (int)lse_s[0];
+  return;
+#endif
   for (int i = tid; i < n; i += 256) {
     const int k = i / V, v = i - k * V;
     const bool fin = fin_s[k] != 0;
@@ -244,6 +252,10 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* logits, lon
     score[i] = tot / pen[2 * k + ((fin || v == eos) ? 0 : 1)];
   }
   __syncthreads();
+#if defined(BS_STOP) && BS_STOP <= 3
+  if (tid == 0) n_unfinished[0] = (int)score[0];
+  return;
+#endif
   int alive = 0;
   for (int i = tid; i < n; i += 256) {
     const float si = score[i];

@@ -24,7 +24,7 @@
 namespace avsr {
 
 #define BG_MAX_SRC 3
-#define BG_MAX_PROB 4
+#define BG_MAX_PROB 2
 #define BG_T 64            // tile rows = tile columns = K per stage
 
 struct BGSrc { const float* a; long sb; const int* gather; int K, pad; };
@@ -46,115 +46,93 @@ struct BGLaunch { int nprob, ntiles; BGProb p[BG_MAX_PROB]; };
 // i multiplies the pair (i, 32 + i).
 #define BG_P 68            // LDS row pitch in floats (272 bytes: 16-byte aligned, rows 4 banks apart)
 
+// Code-generation notes (each visible in the ISA, each cost a whole serialised memory round trip per stage until fixed;
+// tools/beam_gemm_dissect.sh):  (1) the problem descriptor is read through CONSTANT indices into the by-value kernel argument (PF below):
+// `L.p[pi]` with a run-time pi makes the compiler copy the argument into scratch memory and turn every field access into a scratch load;
+// (2) no local array is indexed by the stage's source -- such an array lives in scratch too; (3) no arithmetic on a loaded operand
+// before it is committed to LDS, else the compiler waits for the load right behind its issue.
 template <bool LSTM>
 __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][BG_T * BG_P];      // [buffer][A | B][row or column][k]: 68 KB
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < BG_MAX_PROB; ++i) if (i < L.nprob && (int)blockIdx.x >= L.p[i].tile0) pi = i;
-  pi = __builtin_amdgcn_readfirstlane(pi);
-  const BGProb& P = L.p[pi];
-  const int tile = blockIdx.x - P.tile0, tx = tile % P.ntx, ty = tile / P.ntx;
+  const bool p1 = L.nprob > 1 && (int)blockIdx.x >= L.p[1].tile0;            // uniform
+#define PF(f) (p1 ? L.p[1].f : L.p[0].f)
+  const int P_tile0 = PF(tile0), P_ntx = PF(ntx), P_nsrc = PF(nsrc), P_R = PF(R), P_N = PF(N);
+  const float* const P_wt = PF(wt);
+  const long P_ldw = PF(ldw);
+  const int tile = blockIdx.x - P_tile0, tx = tile % P_ntx, ty = tile / P_ntx;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // 8 waves, two per SIMD: wave = (k half of a stage, 32 x 32 quadrant).  The two waves of a SIMD work on the same quadrant's two k halves,
-  // so one's LDS / barrier / staging stalls are covered by the other's MFMAs (one wave per SIMD ran the cell product at 2.1 us per
-  // stage against 0.93 us of matrix-pipe time); the halves meet through LDS once, after the last stage.
+  // 8 waves, two per SIMD: wave = (k half of a stage, 32 x 32 quadrant); the halves meet through LDS once, after the last stage.
   const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
   // ---- staging role of this thread: piece p = row / column (tid >> 4) + 32 p of the tile, k = 4 (tid & 15) of the stage ----
   // A stage never straddles two sources: every source occupies whole 64-deep stages of a VIRTUAL K axis (its tail, if its width is
-  // not a multiple of 64, reads zeros on both operands), so the source of a stage is wave-uniform -- one load per piece, its resource
-  // and row offset picked by scalar selects, and no arithmetic on a loaded value before the stage is committed to LDS: the loads of
-  // stage s + 2 stay in flight under the MFMAs of stage s + 1.  (Summing one load per source, zeros where it did not apply, made the
-  // compiler wait for every load right behind its issue: 36 us for the 640 x 1024 x 896 cell product.)
+  // not a multiple of 64, reads zeros on both operands), so the source of a stage is wave-uniform: one load per piece, its resource
+  // and row offset picked by scalar selects; the loads of stage s + 2 stay in flight under the MFMAs of stage s + 1.
   const int srow = tid >> 4, sk = 4 * (tid & 15);
-  int kreal[BG_MAX_SRC + 1], sbeg[BG_MAX_SRC + 1];          // first real k / first stage of every source
-  kreal[0] = 0; sbeg[0] = 0;
-#pragma unroll
-  for (int s = 0; s < BG_MAX_SRC; ++s) {
-    const int Ks = s < P.nsrc ? P.src[s].K : 0;
-    kreal[s + 1] = kreal[s] + Ks;
-    sbeg[s + 1] = sbeg[s] + (Ks + BG_T - 1) / BG_T;
-  }
-  const int nstage = sbeg[BG_MAX_SRC];
-  const float* abase[BG_MAX_SRC];
-  int aoff[BG_MAX_SRC][2];                       // byte offset of the gathered row of piece p in source s
-  {
-    int gi[BG_MAX_SRC][2];
-#pragma unroll
-    for (int s = 0; s < BG_MAX_SRC; ++s) {       // all gather indices in one round of loads (a branch per index serialised the round trips)
-      const bool on = s < P.nsrc;
-      const bool hasg = on && P.src[s].gather != nullptr;
-      const __amdgpu_buffer_rsrc_t grs = make_rsrc(hasg ? (const void*)P.src[s].gather : (const void*)P.wt);
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int mrow = ty * BG_T + srow + 32 * p;
-        gi[s][p] = __builtin_bit_cast(int, ldb1(grs, (hasg && mrow < P.R) ? mrow * 4 : P_OOB));
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < BG_MAX_SRC; ++s) {
-      const bool on = s < P.nsrc;
-      const bool hasg = on && P.src[s].gather != nullptr;
-      abase[s] = on ? P.src[s].a : P.wt;
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int mrow = ty * BG_T + srow + 32 * p;
-        const long rb = hasg ? (long)gi[s][p] : (long)mrow;
-        aoff[s][p] = (on && mrow < P.R) ? (int)(rb * P.src[s].sb * 4) : P_OOB;
-      }
-    }
-  }
-  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(P.wt);
-  int woff[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int ncol = tx * BG_T + srow + 32 * p;
-    woff[p] = ncol < P.N ? (int)((long)ncol * P.ldw * 4) : P_OOB;
-  }
+  const int K0 = P_nsrc > 0 ? PF(src[0].K) : 0, K1 = P_nsrc > 1 ? PF(src[1].K) : 0, K2 = P_nsrc > 2 ? PF(src[2].K) : 0;
+  const int sb1 = (K0 + BG_T - 1) / BG_T, sb2 = sb1 + (K1 + BG_T - 1) / BG_T, nstage = sb2 + (K2 + BG_T - 1) / BG_T;
+  const float* const ab0 = P_nsrc > 0 ? PF(src[0].a) : P_wt;
+  const float* const ab1 = P_nsrc > 1 ? PF(src[1].a) : P_wt;
+  const float* const ab2 = P_nsrc > 2 ? PF(src[2].a) : P_wt;
+  const int* const ga0 = P_nsrc > 0 ? PF(src[0].gather) : nullptr;
+  const int* const ga1 = P_nsrc > 1 ? PF(src[1].gather) : nullptr;
+  const int* const ga2 = P_nsrc > 2 ? PF(src[2].gather) : nullptr;
+  const long rs0 = P_nsrc > 0 ? PF(src[0].sb) : 0, rs1 = P_nsrc > 1 ? PF(src[1].sb) : 0, rs2 = P_nsrc > 2 ? PF(src[2].sb) : 0;
+  const int mrow0 = ty * BG_T + srow, mrow1 = mrow0 + 32;
+  // gather indices of both pieces in the three sources: one round of unconditional loads (out of range = 0)
+#define GIDX(ga, mrow) __builtin_bit_cast(int, ldb1(make_rsrc((ga) ? (const void*)(ga) : (const void*)P_wt), ((ga) && (mrow) < P_R) ? (mrow) * 4 : P_OOB))
+  const int g00 = GIDX(ga0, mrow0), g01 = GIDX(ga0, mrow1), g10 = GIDX(ga1, mrow0), g11 = GIDX(ga1, mrow1), g20 = GIDX(ga2, mrow0), g21 = GIDX(ga2, mrow1);
+#undef GIDX
+#define ROFF(on, ga, g, mrow, rsb) (((on) && (mrow) < P_R) ? (int)(((ga) ? (long)(g) : (long)(mrow)) * (rsb) * 4) : P_OOB)
+  const int o00 = ROFF(P_nsrc > 0, ga0, g00, mrow0, rs0), o01 = ROFF(P_nsrc > 0, ga0, g01, mrow1, rs0);
+  const int o10 = ROFF(P_nsrc > 1, ga1, g10, mrow0, rs1), o11 = ROFF(P_nsrc > 1, ga1, g11, mrow1, rs1);
+  const int o20 = ROFF(P_nsrc > 2, ga2, g20, mrow0, rs2), o21 = ROFF(P_nsrc > 2, ga2, g21, mrow1, rs2);
+#undef ROFF
+  const __amdgpu_buffer_rsrc_t wrs = make_rsrc(P_wt);
+  const int n0 = tx * BG_T + srow, n1 = n0 + 32;
+  const int woff0 = n0 < P_N ? (int)((long)n0 * P_ldw * 4) : P_OOB, woff1 = n1 < P_N ? (int)((long)n1 * P_ldw * 4) : P_OOB;
 
-  f32x4 ra[2], rb4[2];
-  auto fetch = [&](int st) {
-    int s = 0;
-#pragma unroll
-    for (int q = 1; q < BG_MAX_SRC; ++q) if (st >= sbeg[q]) s = q;
-    s = __builtin_amdgcn_readfirstlane(s);                                        // uniform
-    const int kl = (st - sbeg[s]) * BG_T + sk;                                    // k inside the source
-    const int Ks = kreal[s + 1] - kreal[s];
-    const bool in = kl < Ks;
-    // (the resource is rebuilt from a pointer forced into SGPRs: selected as a value, the compiler treats it as divergent and wraps
-    // every load in a readfirstlane loop with a full wait behind it)
-    const float* ab = s == 0 ? abase[0] : (s == 1 ? abase[1] : abase[2]);
-    const unsigned long au = reinterpret_cast<unsigned long>(ab);
-    const unsigned long auu = ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(au >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)au);
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const float*>(auu));
-    const int kw = (kreal[s] + kl) * 4;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int ao = s == 0 ? aoff[0][p] : (s == 1 ? aoff[1][p] : aoff[2][p]);
+  f32x4 ra0, ra1, rb0, rb1;
+  // operand fetch of stage ST into ra0 / ra1 / rb0 / rb1
 #ifdef BG_NO_LOAD      // dissection build (tools/beam_gemm_dissect.sh): everything but the operand fetch
-      ra[p] = f32x4{(float)kl, 1.f, 2.f, (float)ao}; rb4[p] = f32x4{(float)kw, 1.f, 2.f, 3.f};
+#define BG_LOADS(rs, in, ao0, ao1, kl, kw)                                                                         \
+    ra0 = f32x4{(float)(kl), 1.f, 2.f, (float)(ao0)}; rb0 = f32x4{(float)(kw), 1.f, 2.f, 3.f};                    \
+    ra1 = f32x4{(float)(kl), 1.f, 2.f, (float)(ao1)}; rb1 = f32x4{(float)(kw), 1.f, 2.f, 3.f};
 #else
-      ra[p] = ldb4(rs, (in && ao != P_OOB) ? ao + kl * 4 : P_OOB);
-      rb4[p] = ldb4(wrs, (in && woff[p] != P_OOB) ? woff[p] + kw : P_OOB);
+#define BG_LOADS(rs, in, ao0, ao1, kl, kw)                                                                         \
+    ra0 = ldb4(rs, ((in) && (ao0) != P_OOB) ? (ao0) + (kl) * 4 : P_OOB);                                          \
+    rb0 = ldb4(wrs, ((in) && woff0 != P_OOB) ? woff0 + (kw) : P_OOB);                                             \
+    ra1 = ldb4(rs, ((in) && (ao1) != P_OOB) ? (ao1) + (kl) * 4 : P_OOB);                                          \
+    rb1 = ldb4(wrs, ((in) && woff1 != P_OOB) ? woff1 + (kw) : P_OOB);
 #endif
-    }
-  };
-  auto commit = [&](int buf) {
-    float* As = lds[buf][0];
-    float* Bs = lds[buf][1];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      *reinterpret_cast<f32x4*>(&As[(srow + 32 * p) * BG_P + sk]) = ra[p];
-      *reinterpret_cast<f32x4*>(&Bs[(srow + 32 * p) * BG_P + sk]) = rb4[p];
-    }
-  };
+#define BG_FETCH(ST) {                                                                                             \
+    const int st_ = (ST);                                                                                          \
+    const int s_ = __builtin_amdgcn_readfirstlane(st_ >= sb2 ? 2 : (st_ >= sb1 ? 1 : 0));                          \
+    const int st0_ = s_ == 0 ? 0 : (s_ == 1 ? sb1 : sb2);                                                          \
+    const int Ks_ = s_ == 0 ? K0 : (s_ == 1 ? K1 : K2);                                                            \
+    const int kr_ = s_ == 0 ? 0 : (s_ == 1 ? K0 : K0 + K1);                                                        \
+    const int kl_ = (st_ - st0_) * BG_T + sk;                                                                      \
+    const bool in_ = kl_ < Ks_;                                                                                    \
+    /* the resource is rebuilt from a pointer forced into SGPRs (a selected resource value is treated as divergent) */ \
+    const float* ab_ = s_ == 0 ? ab0 : (s_ == 1 ? ab1 : ab2);                                                      \
+    const unsigned long au_ = reinterpret_cast<unsigned long>(ab_);                                               \
+    const unsigned long auu_ = ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(au_ >> 32)) << 32) | \
+                               (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)au_);                     \
+    const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(reinterpret_cast<const float*>(auu_));                          \
+    const int kw_ = (kr_ + kl_) * 4;                                                                               \
+    const int ao0_ = s_ == 0 ? o00 : (s_ == 1 ? o10 : o20), ao1_ = s_ == 0 ? o01 : (s_ == 1 ? o11 : o21);         \
+    BG_LOADS(rs_, in_, ao0_, ao1_, kl_, kw_) }
+#define BG_COMMIT(BUF) {                                                                                           \
+    *reinterpret_cast<f32x4*>(&lds[BUF][0][srow * BG_P + sk]) = ra0;                                               \
+    *reinterpret_cast<f32x4*>(&lds[BUF][1][srow * BG_P + sk]) = rb0;                                               \
+    *reinterpret_cast<f32x4*>(&lds[BUF][0][(srow + 32) * BG_P + sk]) = ra1;                                        \
+    *reinterpret_cast<f32x4*>(&lds[BUF][1][(srow + 32) * BG_P + sk]) = rb1; }
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  fetch(0);
-  commit(0);
-  if (nstage > 1) fetch(1);
+  BG_FETCH(0)
+  BG_COMMIT(0)
+  if (nstage > 1) BG_FETCH(1)
   __syncthreads();
   // lane half h of wave-half kh owns k in [32 kh + 16 h, + 16) of a stage: 4 ds_read_b128 per operand, instruction i multiplies the
   // pair (i, 16 + i) of the wave's 32 k
@@ -180,11 +158,14 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
 #endif
       }
     if (st + 1 < nstage) {
-      commit(buf ^ 1);                                       // the stage fetched while the previous one was multiplied
-      if (st + 2 < nstage) fetch(st + 2);
+      if (buf) BG_COMMIT(0) else BG_COMMIT(1)                 // the stage fetched while the previous one was multiplied
+      if (st + 2 < nstage) BG_FETCH(st + 2)
     }
     lds_barrier();
   }
+#undef BG_FETCH
+#undef BG_COMMIT
+#undef BG_LOADS
   // ---- the two k halves of a quadrant meet: waves 4-7 hand their accumulators to waves 0-3 through LDS ----
   {
     float* X = &lds[0][0][0] + ((wave & 3) * 64 + lane) * 17;             // 17-float stride: conflict-free scalar rows
@@ -202,13 +183,15 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
 
   // C layout of mfma 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   if constexpr (!LSTM) {
+    float* const P_out = PF(out);
+    const long P_out_sb = PF(out_sb);
     const int col = tx * BG_T + wn * 32 + (lane & 31);
     const int rbase = ty * BG_T + wm * 32 + 4 * (lane >> 5);
-    if (kh == 0 && col < P.N) {
+    if (kh == 0 && col < P_N) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + (r & 3) + 8 * (r >> 2);
-        if (row < P.R) P.out[(long)row * P.out_sb + col] = acc[r];
+        if (row < P_R) P_out[(long)row * P_out_sb + col] = acc[r];
       }
     }
   } else {
@@ -221,25 +204,29 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
       for (int r = 0; r < 16; ++r) Cs[(rbase + (r & 3) + 8 * (r >> 2)) * CS + col] = acc[r];
     }
     __syncthreads();
-    const int H = P.N >> 2;
+    const float* const P_bias = PF(bias); const float* const P_c_in = PF(c_in); const int* const P_parent = PF(parent);
+    float* const P_c_out = PF(c_out); float* const P_h_out = PF(h_out); float* const P_seq_out = PF(seq_out);
+    const long P_seq_sb = PF(seq_sb);
+    const int H = P_N >> 2;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int item = tid + 512 * it, rl = item >> 4, ul = item & 15;
       const int row = ty * BG_T + rl, u = tx * 16 + ul;
-      if (row >= P.R || u >= H) continue;
+      if (row >= P_R || u >= H) continue;
       f32x4 z = *reinterpret_cast<const f32x4*>(&Cs[rl * CS + 4 * ul]);
-      if (P.bias) z += ld4(P.bias + 4 * u);
-      const long pr = P.parent ? P.parent[row] : row;         // the previous state lives in the parent hypothesis' row
-      const float cprev = P.c_in[pr * H + u];
+      if (P_bias) z += ld4(P_bias + 4 * u);
+      const long pr = P_parent ? P_parent[row] : row;         // the previous state lives in the parent hypothesis' row
+      const float cprev = P_c_in[pr * H + u];
       const float gi = p_sigmoid(z[0]), gj = p_tanh(z[1]), gf = p_sigmoid(z[2] + 1.0f), go = p_sigmoid(z[3]);   // cells.py:14-18
       float c = gf * cprev + gi * gj;
       c = fminf(1.0f, fmaxf(-1.0f, c));                        // cell_clip = 1.0
       const float h = go * p_tanh(c);
-      P.c_out[(long)row * H + u] = c;
-      P.h_out[(long)row * H + u] = h;
-      if (P.seq_out) P.seq_out[(long)row * P.seq_sb + u] = h;
+      P_c_out[(long)row * H + u] = c;
+      P_h_out[(long)row * H + u] = h;
+      if (P_seq_out) P_seq_out[(long)row * P_seq_sb + u] = h;
     }
   }
+#undef PF
 }
 
 // ctx[r] = sum_j w_j pctx[j][r] with the softmax-merge weights of SRC_SOFTMAX (step.hip): M = max_j pm_j, w_j = exp(pm_j - M) / sum_j exp(pm_j - M) pl_j
