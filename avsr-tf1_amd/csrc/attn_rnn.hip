@@ -189,29 +189,32 @@ __global__ __launch_bounds__(256) void logits_sample_kernel(const float* x, long
 }
 
 // One BeamSearchDecoder step for one utterance (one 256-thread workgroup per utterance): see avsr_hip.h mode 3 and
-// oracle.beam_search_decode.  Everything the step reads comes in with ONE round of loads; the per-beam log-sum-exp is a wave
-// reduction (one wave per beam in turn); the top K of the K * V candidate scores are found by RANK: candidate i counts the candidates
-// that beat it (larger score, or equal score and lower index = tf.nn.top_k's order) with broadcast LDS reads, and the K candidates of
-// rank < K write themselves to slot `rank` -- no serial selection rounds.  (Round 2: one thread selected serially, 165 us per step;
-// round 3: K rounds of a wave arg-max with the parents' flags loaded inside every round, 22 us.)
+// oracle.beam_search_decode.  Everything the step reads comes in with ONE round of loads; the per-beam log-sum-exp is a wave reduction,
+// its logf / the 2 K length penalties (powf) run one per lane side by side; every thread keeps its (at most two) candidates
+// -- score as a sortable 32-bit key, accumulated log-probability -- in REGISTERS, and the top K are K rounds of
+// {wave arg-max of a 64-bit (score key, ~index) word, four wave winners through LDS}: larger score first, LOWER index on ties
+// (= tf.nn.top_k's order; -inf scores stay selectable, in index order).
+// History, measured at c4 (B * K = 640 rows, V = 31; tools/beam_gemm_dissect.sh): round 2 one thread selecting serially 165 us;
+// round 3 one wave, candidates in LDS, parents' flags loaded inside every round 22 us; rank by counting (every candidate against
+// every other, broadcast LDS reads) 28 us -- 310 x 310 comparisons are more instructions than ten reductions.
 __global__ __launch_bounds__(256) void beam_step_kernel(const float* logits, long logits_sb, int V, int K, int l, int eos, float w,
                                  const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
                                  float* logp_out, int32_t* fin_out, int32_t* len_out, int32_t* tok, int32_t* parent_rows,
                                  int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // scores [n4] | totals [K*V] | lse [K] | length penalties [K][2] | logits [K*V] | fin [K] | len [K] | logp [K] | alive
-  const int n = K * V, n4 = (n + 3) & ~3;               // scores are padded to whole float4s with -inf (never outrank anything)
-  float* score = sm;
-  float* total = sm + n4;
-  float* lse_s = total + n;
-  float* pen = lse_s + K;
-  float* lg_s = pen + 2 * K;
-  int* fin_s = reinterpret_cast<int*>(lg_s + n);
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // logits [K*V] | lse [K] | max [K] | sum [K] | penalties [K][2] | fin [K] | len [K] | logp [K] | alive | winners [2][4] x 64 bit
+  const int n = K * V;
+  float* lg_s = sm;
+  float* lse_s = lg_s + n;
+  float* mx_s = lse_s + K;
+  float* sum_s = mx_s + K;
+  float* pen = sum_s + K;
+  int* fin_s = reinterpret_cast<int*>(pen + 2 * K);
   int* len_s = fin_s + K;
   float* logp_s = reinterpret_cast<float*>(len_s + K);
   int* alive_s = reinterpret_cast<int*>(logp_s + K);
+  unsigned long long* win = reinterpret_cast<unsigned long long*>(sm + ((n + 8 * K + 1 + 1) & ~1));      // 8-byte aligned
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float FMIN = -3.4028234663852886e38f;
-  if (tid < n4 - n) score[n + tid] = -INFINITY;
   for (int i = tid; i < n; i += 256) {
     const int k = i / V, v = i - k * V;
     lg_s[i] = logits[(long)(b * K + k) * logits_sb + v];
@@ -223,61 +226,79 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* logits, lon
   if (tid == 0) n_unfinished[0] = (int)lg_s[0];
   return;
 #endif
-  for (int k = wave; k < K; k += 4) {                 // log-sum-exp of beam k: wave reductions over its V logits
+  for (int k = wave; k < K; k += 4) {                 // max and exp-sum of beam k: wave reductions over its V logits
     float mx = -INFINITY;
     for (int v = lane; v < V; v += 64) mx = fmaxf(mx, lg_s[k * V + v]);
     mx = wave_max(mx);
     float sum = 0.f;
     for (int v = lane; v < V; v += 64) sum += expf(lg_s[k * V + v] - mx);
     sum = wave_sum(sum);
-    if (lane == 0) {
-      lse_s[k] = mx + logf(sum);
-      // a beam's continuations have one of two lengths: the same powf(...) values as one call per candidate, 2 instead of V per beam
-      const int ln = len_s[k];
-      pen[2 * k] = powf((5.0f + (float)ln) / 6.0f, w);
-      pen[2 * k + 1] = powf((5.0f + (float)(ln + 1)) / 6.0f, w);
-    }
+    if (lane == 0) { mx_s[k] = mx; sum_s[k] = sum; }
   }
+  __syncthreads();
+  // one logf / powf per lane: K log-sum-exps on wave 0, the 2 K length penalties ((5 + len) / 6) ^ w of the two possible lengths of a
+  // beam's continuations on waves 1-3 (the same powf values as one call per candidate)
+  if (tid < K) lse_s[tid] = mx_s[tid] + logf(sum_s[tid]);
+  for (int j = tid - 64; j >= 0 && j < 2 * K; j += 192) pen[j] = powf((5.0f + (float)(len_s[j >> 1] + (j & 1))) / 6.0f, w);
   __syncthreads();
 #if defined(BS_STOP) && BS_STOP <= 2
   if (tid == 0) n_unfinished[0] = (int)lse_s[0];
   return;
 #endif
-  for (int i = tid; i < n; i += 256) {
-    const int k = i / V, v = i - k * V;
-    const bool fin = fin_s[k] != 0;
-    const float sl = fin ? (v == eos ? 0.f : FMIN) : lg_s[i] - lse_s[k];
-    const float tot = logp_s[k] + sl;
-    total[i] = tot;
-    score[i] = tot / pen[2 * k + ((fin || v == eos) ? 0 : 1)];
+  // ---- this thread's candidates i = tid + 256 c: key (0 = none / taken) and accumulated log-probability, in registers ----
+  constexpr int NC = 4;                               // K * V <= 1024
+  unsigned key[NC];
+  float tot[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int i = tid + 256 * c;
+    key[c] = 0u; tot[c] = 0.f;
+    if (i < n) {
+      const int k = i / V, v = i - k * V;
+      const bool fin = fin_s[k] != 0;
+      const float sl = fin ? (v == eos ? 0.f : FMIN) : lg_s[i] - lse_s[k];
+      const float t = logp_s[k] + sl;
+      const float sc = t / pen[2 * k + ((fin || v == eos) ? 0 : 1)];
+      const unsigned u = __builtin_bit_cast(unsigned, sc);
+      key[c] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);        // monotone in the score; -inf -> 0x007fffff (> 0 = none)
+      tot[c] = t;
+    }
   }
-  __syncthreads();
 #if defined(BS_STOP) && BS_STOP <= 3
-  if (tid == 0) n_unfinished[0] = (int)score[0];
+  if (tid == 0) n_unfinished[0] = (int)key[0];
   return;
 #endif
   int alive = 0;
-  for (int i = tid; i < n; i += 256) {
-    const float si = score[i];
-    int rank = 0;
-    for (int j = 0; j < n4; j += 16) {                // every lane reads the same words (LDS broadcast), 16 per round trip
-      f32x4 q[4];
+  for (int j = 0; j < K; ++j) {
+    // this thread's best remaining candidate as one 64-bit word: (score key, ~index) -- larger is better, lower index wins ties
+    unsigned long long best = 0ull;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) q[u] = (j + 4 * u < n4) ? *reinterpret_cast<const f32x4*>(score + j + 4 * u) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float sj = q[u][e];
-          const int jj = j + 4 * u + e;
-          rank += (sj > si || (sj == si && jj < i)) ? 1 : 0;
-        }
+    for (int c = 0; c < NC; ++c) {
+      const unsigned long long cand = key[c] ? (((unsigned long long)key[c] << 32) | (unsigned)(0xffffffffu - (unsigned)(tid + 256 * c))) : 0ull;
+      best = cand > best ? cand : best;
     }
-    if (rank < K) {
-      const int word = i % V, parent = i / V, r = b * K + rank, pr = b * K + parent;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned hi = (unsigned)__shfl_xor((int)(best >> 32), o, 64), lo = (unsigned)__shfl_xor((int)(unsigned)best, o, 64);
+      const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+      best = other > best ? other : best;
+    }
+    unsigned long long* slot = win + (j & 1) * 4;
+    if (lane == 0) slot[wave] = best;
+    __syncthreads();
+    unsigned long long g = slot[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) g = slot[q] > g ? slot[q] : g;
+    const int idx = (int)(0xffffffffu - (unsigned)g);
+    if ((idx & 255) == tid) {                           // the owner writes hypothesis j and retires the candidate
+      const int c = idx >> 8;
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) if (q == c) { t = tot[q]; key[q] = 0u; }
+      const int word = idx % V, parent = idx / V, r = b * K + j, pr = b * K + parent;
       const bool pf = fin_s[parent] != 0;
       const int f = (pf || word == eos) ? 1 : 0;
-      logp_out[r] = total[i];
+      logp_out[r] = t;
       fin_out[r] = f;
       len_out[r] = len_s[parent] + (pf ? 0 : 1);
       tok[r] = word;
@@ -400,7 +421,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
   if (d.mode == 2 && (!d.embedding || !d.wout_t || !d.logits || !d.xs || !d.labels || !d.fed || !d.seed)) return AVSR_ERR_ARG;
   if (d.mode == 3 && (!d.embedding || !d.wout_t || !d.logits || !d.tok || !d.n_unfinished || d.beam_width <= 0 || B % d.beam_width ||
                       !d.beam_logp || !d.beam_fin || !d.beam_len || !d.step_ids || !d.parent_ids || !d.parent_rows)) return AVSR_ERR_ARG;
-  if (d.mode == 3 && (size_t)(3 * d.beam_width * d.V + 6 * d.beam_width + 8) * sizeof(float) > 60000) return AVSR_ERR_UNSUPPORTED;
+  if (d.mode == 3 && (d.beam_width * d.V > 1024 || d.beam_width > 64)) return AVSR_ERR_UNSUPPORTED;
   const bool feed = (d.mode == 1 || d.mode == 3);      // inputs come from the embedding of the previous prediction
   const bool gru = d.cell == 1;
   if (gru && (!d.wt2 || !d.rh_seq)) return AVSR_ERR_ARG;
@@ -608,7 +629,7 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
                            d.ids + l, (long)L, d.tok, d.steplen, d.n_unfinished, B, l, d.eos_id);
       } else if (d.mode == 3) {
         const int K = d.beam_width, pin = l & 1, pout = (l + 1) & 1;
-        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(256), (3 * K * d.V + 6 * K + 8) * sizeof(float), s, d.logits + (long)l * d.V,
+        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(256), (K * d.V + 8 * K + 24) * sizeof(float), s, d.logits + (long)l * d.V,
                            (long)L * d.V, d.V, K, l, d.eos_id, d.length_penalty, d.beam_logp + (long)pin * B, d.beam_fin + (long)pin * B,
                            d.beam_len + (long)pin * B, d.beam_logp + (long)pout * B, d.beam_fin + (long)pout * B,
                            d.beam_len + (long)pout * B, d.tok, d.parent_rows, d.step_ids + (long)l * B, d.parent_ids + (long)l * B,
