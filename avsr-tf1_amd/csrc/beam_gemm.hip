@@ -5,7 +5,7 @@
 // product and the attention layers two [640 x 512] x [512 x 256] ones.  The per-step `step_kernel` (16 x 16 output tiles, built for
 // the 64-row steps of training, where only latency matters) runs them as 2560 / 1280 workgroups that re-read their operands from
 // L2 -- 46 + 41 us of the 145 us step (profiles/r03_decode_rates_v3.txt).  Here the same products are 64 x 64 output tiles walked
-// through LDS in 64-deep K stages (coalesced row pieces, register prefetch of the next stage under the current stage's MFMAs), with the operand ROWS
+// through LDS in 128-deep K stages (coalesced row pieces, register prefetch of the next stage under the current stage's MFMAs), with the operand ROWS
 // GATHERED while they are staged -- token embedding by `tok`, attention record and recurrent state by the parent hypothesis'
 // row -- and the cell's gate math, clip and state update in the epilogue:
 //   beam_gemm_kernel<LSTM>    z = [emb[tok[r]] | att[parent[r]] | h[parent[r]]] . W + b -> i, j, f, o -> c, h of row r
@@ -25,7 +25,8 @@ namespace avsr {
 
 #define BG_MAX_SRC 3
 #define BG_MAX_PROB 2
-#define BG_T 64            // tile rows = tile columns = K per stage
+#define BG_T 64            // tile rows = tile columns
+#define BG_K 128           // K per stage
 
 struct BGSrc { const float* a; long sb; const int* gather; int K, pad; };
 struct BGProb {
@@ -44,7 +45,7 @@ struct BGLaunch { int nprob, ntiles; BGProb p[BG_MAX_PROB]; };
 // MFMA operand fetch: v_mfma_f32_32x32x2 takes ONE k per lane half; which k the two halves supply is free as long as A and B agree,
 // so lane half h owns k in [32 h, 32 h + 32) of a stage -- its 32 operand values are 8 ds_read_b128 of one LDS row -- and instruction
 // i multiplies the pair (i, 32 + i).
-#define BG_P 68            // LDS row pitch in floats (272 bytes: 16-byte aligned, rows 4 banks apart)
+#define BG_P (BG_K + 4)    // LDS row pitch in floats (16-byte aligned rows, 4 banks apart)
 
 // Code-generation notes (each visible in the ISA, each cost a whole serialised memory round trip per stage until fixed;
 // tools/beam_gemm_dissect.sh):  (1) the problem descriptor is read through CONSTANT indices into the by-value kernel argument (PF below):
@@ -53,7 +54,7 @@ struct BGLaunch { int nprob, ntiles; BGProb p[BG_MAX_PROB]; };
 // before it is committed to LDS, else the compiler waits for the load right behind its issue.
 template <bool LSTM>
 __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
-  __shared__ __attribute__((aligned(16))) float lds[2][2][BG_T * BG_P];      // [buffer][A | B][row or column][k]: 68 KB
+  __shared__ __attribute__((aligned(16))) float lds[2][2][BG_T * BG_P];      // [buffer][A | B][row or column][k]: 132 KB
   const bool p1 = L.nprob > 1 && (int)blockIdx.x >= L.p[1].tile0;            // uniform
 #define PF(f) (p1 ? L.p[1].f : L.p[0].f)
   const int P_tile0 = PF(tile0), P_ntx = PF(ntx), P_nsrc = PF(nsrc), P_R = PF(R), P_N = PF(N);
@@ -64,12 +65,12 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
   // 8 waves, two per SIMD: wave = (k half of a stage, 32 x 32 quadrant); the halves meet through LDS once, after the last stage.
   const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
   // ---- staging role of this thread: piece p = row / column (tid >> 4) + 32 p of the tile, k = 4 (tid & 15) of the stage ----
-  // A stage never straddles two sources: every source occupies whole 64-deep stages of a VIRTUAL K axis (its tail, if its width is
+  // A stage never straddles two sources: every source occupies whole 128-deep stages of a VIRTUAL K axis (its tail, if its width is
   // not a multiple of 64, reads zeros on both operands), so the source of a stage is wave-uniform: one load per piece, its resource
   // and row offset picked by scalar selects; the loads of stage s + 2 stay in flight under the MFMAs of stage s + 1.
-  const int srow = tid >> 4, sk = 4 * (tid & 15);
+  const int srow = tid >> 5, sk = 4 * (tid & 31);
   const int K0 = P_nsrc > 0 ? PF(src[0].K) : 0, K1 = P_nsrc > 1 ? PF(src[1].K) : 0, K2 = P_nsrc > 2 ? PF(src[2].K) : 0;
-  const int sb1 = (K0 + BG_T - 1) / BG_T, sb2 = sb1 + (K1 + BG_T - 1) / BG_T, nstage = sb2 + (K2 + BG_T - 1) / BG_T;
+  const int sb1 = (K0 + BG_K - 1) / BG_K, sb2 = sb1 + (K1 + BG_K - 1) / BG_K, nstage = sb2 + (K2 + BG_K - 1) / BG_K;
   const float* const ab0 = P_nsrc > 0 ? PF(src[0].a) : P_wt;
   const float* const ab1 = P_nsrc > 1 ? PF(src[1].a) : P_wt;
   const float* const ab2 = P_nsrc > 2 ? PF(src[2].a) : P_wt;
@@ -77,32 +78,31 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
   const int* const ga1 = P_nsrc > 1 ? PF(src[1].gather) : nullptr;
   const int* const ga2 = P_nsrc > 2 ? PF(src[2].gather) : nullptr;
   const long rs0 = P_nsrc > 0 ? PF(src[0].sb) : 0, rs1 = P_nsrc > 1 ? PF(src[1].sb) : 0, rs2 = P_nsrc > 2 ? PF(src[2].sb) : 0;
-  const int mrow0 = ty * BG_T + srow, mrow1 = mrow0 + 32;
+  const int mrow0 = ty * BG_T + srow, mrow1 = mrow0 + 16, mrow2 = mrow0 + 32, mrow3 = mrow0 + 48;
   // gather indices of both pieces in the three sources: one round of unconditional loads (out of range = 0)
 #define GIDX(ga, mrow) __builtin_bit_cast(int, ldb1(make_rsrc((ga) ? (const void*)(ga) : (const void*)P_wt), ((ga) && (mrow) < P_R) ? (mrow) * 4 : P_OOB))
-  const int g00 = GIDX(ga0, mrow0), g01 = GIDX(ga0, mrow1), g10 = GIDX(ga1, mrow0), g11 = GIDX(ga1, mrow1), g20 = GIDX(ga2, mrow0), g21 = GIDX(ga2, mrow1);
+  const int g00 = GIDX(ga0, mrow0), g01 = GIDX(ga0, mrow1), g02 = GIDX(ga0, mrow2), g03 = GIDX(ga0, mrow3);
+  const int g10 = GIDX(ga1, mrow0), g11 = GIDX(ga1, mrow1), g12 = GIDX(ga1, mrow2), g13 = GIDX(ga1, mrow3);
+  const int g20 = GIDX(ga2, mrow0), g21 = GIDX(ga2, mrow1), g22 = GIDX(ga2, mrow2), g23 = GIDX(ga2, mrow3);
 #undef GIDX
 #define ROFF(on, ga, g, mrow, rsb) (((on) && (mrow) < P_R) ? (int)(((ga) ? (long)(g) : (long)(mrow)) * (rsb) * 4) : P_OOB)
-  const int o00 = ROFF(P_nsrc > 0, ga0, g00, mrow0, rs0), o01 = ROFF(P_nsrc > 0, ga0, g01, mrow1, rs0);
-  const int o10 = ROFF(P_nsrc > 1, ga1, g10, mrow0, rs1), o11 = ROFF(P_nsrc > 1, ga1, g11, mrow1, rs1);
-  const int o20 = ROFF(P_nsrc > 2, ga2, g20, mrow0, rs2), o21 = ROFF(P_nsrc > 2, ga2, g21, mrow1, rs2);
+  const int o00 = ROFF(P_nsrc > 0, ga0, g00, mrow0, rs0), o01 = ROFF(P_nsrc > 0, ga0, g01, mrow1, rs0), o02 = ROFF(P_nsrc > 0, ga0, g02, mrow2, rs0), o03 = ROFF(P_nsrc > 0, ga0, g03, mrow3, rs0);
+  const int o10 = ROFF(P_nsrc > 1, ga1, g10, mrow0, rs1), o11 = ROFF(P_nsrc > 1, ga1, g11, mrow1, rs1), o12 = ROFF(P_nsrc > 1, ga1, g12, mrow2, rs1), o13 = ROFF(P_nsrc > 1, ga1, g13, mrow3, rs1);
+  const int o20 = ROFF(P_nsrc > 2, ga2, g20, mrow0, rs2), o21 = ROFF(P_nsrc > 2, ga2, g21, mrow1, rs2), o22 = ROFF(P_nsrc > 2, ga2, g22, mrow2, rs2), o23 = ROFF(P_nsrc > 2, ga2, g23, mrow3, rs2);
 #undef ROFF
   const __amdgpu_buffer_rsrc_t wrs = make_rsrc(P_wt);
-  const int n0 = tx * BG_T + srow, n1 = n0 + 32;
+  const int n0 = tx * BG_T + srow, n1 = n0 + 16, n2 = n0 + 32, n3 = n0 + 48;
   const int woff0 = n0 < P_N ? (int)((long)n0 * P_ldw * 4) : P_OOB, woff1 = n1 < P_N ? (int)((long)n1 * P_ldw * 4) : P_OOB;
+  const int woff2 = n2 < P_N ? (int)((long)n2 * P_ldw * 4) : P_OOB, woff3 = n3 < P_N ? (int)((long)n3 * P_ldw * 4) : P_OOB;
 
-  f32x4 ra0, ra1, rb0, rb1;
+  f32x4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
   // operand fetch of stage ST into ra0 / ra1 / rb0 / rb1
 #ifdef BG_NO_LOAD      // dissection build (tools/beam_gemm_dissect.sh): everything but the operand fetch
-#define BG_LOADS(rs, in, ao0, ao1, kl, kw)                                                                         \
-    ra0 = f32x4{(float)(kl), 1.f, 2.f, (float)(ao0)}; rb0 = f32x4{(float)(kw), 1.f, 2.f, 3.f};                    \
-    ra1 = f32x4{(float)(kl), 1.f, 2.f, (float)(ao1)}; rb1 = f32x4{(float)(kw), 1.f, 2.f, 3.f};
+#define BG_LOAD1(ra, rb, rs, in, ao, wo, kl, kw) ra = f32x4{(float)(kl), 1.f, 2.f, (float)(ao)}; rb = f32x4{(float)(kw), 1.f, 2.f, (float)(wo)};
 #else
-#define BG_LOADS(rs, in, ao0, ao1, kl, kw)                                                                         \
-    ra0 = ldb4(rs, ((in) && (ao0) != P_OOB) ? (ao0) + (kl) * 4 : P_OOB);                                          \
-    rb0 = ldb4(wrs, ((in) && woff0 != P_OOB) ? woff0 + (kw) : P_OOB);                                             \
-    ra1 = ldb4(rs, ((in) && (ao1) != P_OOB) ? (ao1) + (kl) * 4 : P_OOB);                                          \
-    rb1 = ldb4(wrs, ((in) && woff1 != P_OOB) ? woff1 + (kw) : P_OOB);
+#define BG_LOAD1(ra, rb, rs, in, ao, wo, kl, kw)                                                                  \
+    ra = ldb4(rs, ((in) && (ao) != P_OOB) ? (ao) + (kl) * 4 : P_OOB);                                             \
+    rb = ldb4(wrs, ((in) && (wo) != P_OOB) ? (wo) + (kw) : P_OOB);
 #endif
 #define BG_FETCH(ST) {                                                                                             \
     const int st_ = (ST);                                                                                          \
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
     const int st0_ = s_ == 0 ? 0 : (s_ == 1 ? sb1 : sb2);                                                          \
     const int Ks_ = s_ == 0 ? K0 : (s_ == 1 ? K1 : K2);                                                            \
     const int kr_ = s_ == 0 ? 0 : (s_ == 1 ? K0 : K0 + K1);                                                        \
-    const int kl_ = (st_ - st0_) * BG_T + sk;                                                                      \
+    const int kl_ = (st_ - st0_) * BG_K + sk;                                                                      \
     const bool in_ = kl_ < Ks_;                                                                                    \
     /* the resource is rebuilt from a pointer forced into SGPRs (a selected resource value is treated as divergent) */ \
     const float* ab_ = s_ == 0 ? ab0 : (s_ == 1 ? ab1 : ab2);                                                      \
@@ -120,12 +120,18 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
     const __amdgpu_buffer_rsrc_t rs_ = make_rsrc(reinterpret_cast<const float*>(auu_));                          \
     const int kw_ = (kr_ + kl_) * 4;                                                                               \
     const int ao0_ = s_ == 0 ? o00 : (s_ == 1 ? o10 : o20), ao1_ = s_ == 0 ? o01 : (s_ == 1 ? o11 : o21);         \
-    BG_LOADS(rs_, in_, ao0_, ao1_, kl_, kw_) }
+    const int ao2_ = s_ == 0 ? o02 : (s_ == 1 ? o12 : o22), ao3_ = s_ == 0 ? o03 : (s_ == 1 ? o13 : o23);         \
+    BG_LOAD1(ra0, rb0, rs_, in_, ao0_, woff0, kl_, kw_) BG_LOAD1(ra1, rb1, rs_, in_, ao1_, woff1, kl_, kw_)        \
+    BG_LOAD1(ra2, rb2, rs_, in_, ao2_, woff2, kl_, kw_) BG_LOAD1(ra3, rb3, rs_, in_, ao3_, woff3, kl_, kw_) }
 #define BG_COMMIT(BUF) {                                                                                           \
     *reinterpret_cast<f32x4*>(&lds[BUF][0][srow * BG_P + sk]) = ra0;                                               \
     *reinterpret_cast<f32x4*>(&lds[BUF][1][srow * BG_P + sk]) = rb0;                                               \
-    *reinterpret_cast<f32x4*>(&lds[BUF][0][(srow + 32) * BG_P + sk]) = ra1;                                        \
-    *reinterpret_cast<f32x4*>(&lds[BUF][1][(srow + 32) * BG_P + sk]) = rb1; }
+    *reinterpret_cast<f32x4*>(&lds[BUF][0][(srow + 16) * BG_P + sk]) = ra1;                                        \
+    *reinterpret_cast<f32x4*>(&lds[BUF][1][(srow + 16) * BG_P + sk]) = rb1;                                        \
+    *reinterpret_cast<f32x4*>(&lds[BUF][0][(srow + 32) * BG_P + sk]) = ra2;                                        \
+    *reinterpret_cast<f32x4*>(&lds[BUF][1][(srow + 32) * BG_P + sk]) = rb2;                                        \
+    *reinterpret_cast<f32x4*>(&lds[BUF][0][(srow + 48) * BG_P + sk]) = ra3;                                        \
+    *reinterpret_cast<f32x4*>(&lds[BUF][1][(srow + 48) * BG_P + sk]) = rb3; }
 
   f32x16 acc;
 #pragma unroll
@@ -134,21 +140,21 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
   BG_COMMIT(0)
   if (nstage > 1) BG_FETCH(1)
   __syncthreads();
-  // lane half h of wave-half kh owns k in [32 kh + 16 h, + 16) of a stage: 4 ds_read_b128 per operand, instruction i multiplies the
-  // pair (i, 16 + i) of the wave's 32 k
-  const int hk = 32 * kh + 16 * (lane >> 5);
+  // lane half h of wave-half kh owns k in [64 kh + 32 h, + 32) of a stage: 8 ds_read_b128 per operand, instruction i multiplies the
+  // pair (i, 32 + i) of the wave's 64 k
+  const int hk = 64 * kh + 32 * (lane >> 5);
   for (int st = 0; st < nstage; ++st) {
     const int buf = st & 1;
     const float* Ar = lds[buf][0] + (wm * 32 + (lane & 31)) * BG_P + hk;
     const float* Br = lds[buf][1] + (wn * 32 + (lane & 31)) * BG_P + hk;
-    f32x4 a4[4], b4[4];
+    f32x4 a4[8], b4[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 8; ++j) {
       a4[j] = *reinterpret_cast<const f32x4*>(Ar + 4 * j);
       b4[j] = *reinterpret_cast<const f32x4*>(Br + 4 * j);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 8; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #ifdef BG_NO_MFMA      // dissection build: everything but the matrix instructions
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
   }
 #undef BG_FETCH
 #undef BG_COMMIT
-#undef BG_LOADS
+#undef BG_LOAD1
   // ---- the two k halves of a quadrant meet: waves 4-7 hand their accumulators to waves 0-3 through LDS ----
   {
     float* X = &lds[0][0][0] + ((wave & 3) * 64 + lane) * 17;             // 17-float stride: conflict-free scalar rows

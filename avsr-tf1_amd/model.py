@@ -324,6 +324,7 @@ class Seq2SeqModel:
         D["ids"] = torch.zeros(B, Ldec, dtype=torch.int32, device=dev)
         D["tok"] = torch.zeros(B, dtype=torch.int32, device=dev)
         D["nunf"] = torch.zeros(1, dtype=torch.int32, device=dev)
+        D["nunf_prev"] = torch.zeros(1, dtype=torch.int32, device=dev)
         D["steplen"] = torch.zeros(B, dtype=torch.int32, device=dev)
         ws["B"], ws["L"] = B, L
         self._ws_cache[key] = ws
@@ -1571,13 +1572,19 @@ class Seq2SeqModel:
         d.beam_width, d.length_penalty, d.mem_shared = K, float(w), 1
         d.beam_logp, d.beam_fin, d.beam_len = ops.fptr(logp), ops.fptr(fin), ops.fptr(ln)
         d.step_ids, d.parent_ids, d.parent_rows = ops.fptr(sid), ops.fptr(pid), ops.fptr(prow)
-        l = 0
+        # steps are launched in chunks of check_every; the "every beam finished" flag of a chunk is read while the NEXT chunk is already
+        # queued (the read would otherwise leave the GPU idle for a host round trip per chunk).  A chunk past the end is harmless:
+        # with every beam finished a step reproduces its input state, and T below comes from the per-step counters.
+        fr = self._flag_reader()
+        l, pending = 0, False
         while l < L:
             l1 = min(L, l + check_every)
             ops.attn_rnn_fwd(d, l, l1)
-            l = l1
-            if int(D["nunf"][l - 1].item()) == 0:
+            if pending and fr.value() == 0:
+                l = l1
                 break
+            fr.request(D["nunf"][l1 - 1:l1])
+            pending, l = True, l1
         # dynamic_decode stops right after the first step at which every beam is finished
         hist = D["nunf"][:l].cpu().numpy()
         done = np.nonzero(hist == 0)[0]
@@ -1588,6 +1595,11 @@ class Seq2SeqModel:
         if return_all:
             return out
         return out[:, :, 0].contiguous()
+
+    def _flag_reader(self):
+        if getattr(self, "_fr", None) is None:
+            self._fr = _FlagReader(self.dev)
+        return self._fr
 
     def _greedy_decode(self, batch: Batch, max_steps: Optional[int] = None, check_every: int = 8):
         """Eval graph with GreedyEmbeddingHelper (decoder_unimodal.py:176-217): int32 ids [B, T_out], zeros after EOS."""
@@ -1611,13 +1623,19 @@ class Seq2SeqModel:
         d.wout_t = ops.fptr(self.derived, self.Tr["dec/out/kernel"].off)
         d.bout = ops.fptr(self.params, self.P["dec/out/bias"].off)
         d.logits, d.ids, d.tok, d.n_unfinished = ops.fptr(D["logits"]), ops.fptr(D["ids"]), ops.fptr(D["tok"]), ops.fptr(D["nunf"])
-        l = 0
+        # chunks of check_every steps; a chunk's "unfinished" count is read after the next chunk has been queued (no idle GPU while the
+        # host waits).  Steps past the end change nothing: finished rows are frozen (impute_finished) and t_out is the longest row.
+        fr = self._flag_reader()
+        l, pending = 0, False
         while l < L:
             l1 = min(L, l + check_every)
             ops.attn_rnn_fwd(d, l, l1)
-            l = l1
-            if int(D["nunf"].item()) == 0:      # all utterances emitted EOS
+            if pending and fr.value() == 0:      # all utterances had emitted EOS by the end of the previous chunk
+                l = l1
                 break
+            ops.copy_(D["nunf_prev"], D["nunf"])                         # this chunk's count (the next call resets the counter)
+            fr.request(D["nunf_prev"])
+            pending, l = True, l1
         t_out = min(int(D["steplen"].max().item()), l)   # dynamic_decode stops once every utterance has finished
         self._last_greedy = (ws, t_out)
         self._last_align = None
@@ -1648,6 +1666,30 @@ class Seq2SeqModel:
             out["encoder"] = alphas(E["blk"], E["len"])[0]
         self._last_align = out
         return out
+
+
+class _FlagReader:
+    """Reads a device int32 word for the host WITHOUT draining the main stream: the word is copied to page-locked memory on a side
+    stream behind an event, so a decode loop can queue its next chunk of steps before it looks at the previous chunk's "all finished"
+    counter (a plain .item() waits for everything queued so far, the next chunk included)."""
+
+    def __init__(self, device):
+        self.side = torch.cuda.Stream(device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.done = torch.cuda.Event()
+
+    def request(self, word):
+        """Queue the read of `word` (a 1-element int32 device tensor) as of everything queued on the current stream so far."""
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            self.host.copy_(word, non_blocking=True)
+            self.done.record()
+
+    def value(self):
+        self.done.synchronize()
+        return int(self.host[0])
 
 
 def desc_steplen(desc):
