@@ -574,22 +574,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int tau = reverse ? len_b - 1 - t : t;
         const long bt = (long)b * T + tau;
         f32x4 z = bias4 + zpre;
-#pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
-          const int cc = eu * 4 + gi;
+        // the four gates of a unit are four consecutive floats of every partial: 16-byte LDS reads (one per partial instead of four;
+        // the scalar form also put the 8 rows of a wave on the same banks), each element summed in the same order as before
+        {
+          const int c0 = eu * 4;
           if constexpr (Q4) {
-            float s4 = 0.f;
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
             if (UW == 16) {
 #pragma unroll
-              for (int w = 0; w < 4; ++w) s4 += red4[(w * 8 + er) * 64 + cc];
+              for (int w = 0; w < 4; ++w) s4 += *reinterpret_cast<const f32x4*>(&red4[(w * 8 + er) * 64 + c0]);
             } else {
 #pragma unroll
-              for (int w = 0; w < 8; ++w) s4 += red4[(w * 8 + er) * 32 + cc];          // (wave, k-half) pairs in order
-              s4 += (red[0][cc >> 4][er][cc & 15] + red[1][cc >> 4][er][cc & 15]) + (red[2][cc >> 4][er][cc & 15] + red[3][cc >> 4][er][cc & 15]);
+              for (int w = 0; w < 8; ++w) s4 += *reinterpret_cast<const f32x4*>(&red4[(w * 8 + er) * 32 + c0]);          // (wave, k-half) pairs in order
+              const int ct4 = c0 >> 4, cl = c0 & 15;
+              s4 += (*reinterpret_cast<const f32x4*>(&red[0][ct4][er][cl]) + *reinterpret_cast<const f32x4*>(&red[1][ct4][er][cl])) +
+                    (*reinterpret_cast<const f32x4*>(&red[2][ct4][er][cl]) + *reinterpret_cast<const f32x4*>(&red[3][ct4][er][cl]));
             }
-            z[gi] += s4;
-          } else
-          z[gi] += (red[0][cc >> 4][er][cc & 15] + red[1][cc >> 4][er][cc & 15]) + (red[2][cc >> 4][er][cc & 15] + red[3][cc >> 4][er][cc & 15]);
+            z += s4;
+          } else {
+            const int ct4 = c0 >> 4, cl = c0 & 15;
+            z += (*reinterpret_cast<const f32x4*>(&red[0][ct4][er][cl]) + *reinterpret_cast<const f32x4*>(&red[1][ct4][er][cl])) +
+                 (*reinterpret_cast<const f32x4*>(&red[2][ct4][er][cl]) + *reinterpret_cast<const f32x4*>(&red[3][ct4][er][cl]));
+          }
         }
         f32x4 g4;
         g4[0] = p_sigmoid(z[0]); g4[1] = p_tanh(z[1]); g4[2] = p_sigmoid(z[2] + 1.0f); g4[3] = p_sigmoid(z[3]);
