@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnLaunch L) {
 // softmax partials by one wave, context rows in row order then row groups in order), same outputs (raw scores, chunk max / sum,
 // un-normalised partial contexts by hypothesis row).  Luong / scaled Luong, H <= 256, chunk <= 64, D <= 1024, K <= 16.
 #define ATTN_BEAM_KMAX 16
-template <bool PF>
+template <int PF>      // PF: value rows of the first block requested ahead of the key phase (0, 8 or 16 of its 16)
 __global__ __launch_bounds__(256) void attn_fwd_beam_kernel(const AttnLaunch L) {
   __shared__ float sc[ATTN_BEAM_KMAX][64];
   __shared__ __attribute__((aligned(16))) float qs[ATTN_BEAM_KMAX][256];
@@ -225,12 +225,12 @@ __global__ __launch_bounds__(256) void attn_fwd_beam_kernel(const AttnLaunch L) 
   //      back to their first use. ----
   const int cols = D >> 2;
   const int vst = (int)M.values_st * 4;
-  f32x4 vr0[PF ? 16 : 1];
-  if constexpr (PF) {
+  f32x4 vr0[PF ? PF : 1];
+  if constexpr (PF > 0) {
     const i32x4_ vrw = make_rsrc_words(M.values + (long)u * M.values_sb);
     const int ccols0 = min(256, cols), G0 = 256 / ccols0, col0 = tid % ccols0, grp0 = tid / ccols0;
 #pragma unroll
-    for (int uu = 0; uu < 16; ++uu) {
+    for (int uu = 0; uu < PF; ++uu) {
       const int r = grp0 + G0 * uu;
       ldb4_hidden(vr0[uu], vrw, (grp0 < G0 && r < n) ? (t0 + r) * vst + col0 * 16 : P_OOB);
     }
@@ -291,10 +291,10 @@ __global__ __launch_bounds__(256) void attn_fwd_beam_kernel(const AttnLaunch L) 
   __syncthreads();
   // ---- partial contexts: one float4 column per thread, G row groups; the chunk's values stay in registers for the K queries ----
   const __amdgpu_buffer_rsrc_t vrs = make_rsrc(M.values + (long)u * M.values_sb);
-  if constexpr (PF) {
+  if constexpr (PF > 0) {
     vm_wait_all();
 #pragma unroll
-    for (int uu = 0; uu < 16; ++uu) vm_landed(vr0[uu]);
+    for (int uu = 0; uu < PF; ++uu) vm_landed(vr0[uu]);
   }
   for (int cb = 0; cb < cols; cb += 256) {
     const int ccols = min(256, cols - cb);
@@ -303,15 +303,12 @@ __global__ __launch_bounds__(256) void attn_fwd_beam_kernel(const AttnLaunch L) 
     const bool act = grp < G;
     for (int r0 = 0; r0 < n; r0 += 16 * G) {            // (G >= 4 at D <= 256: one trip)
       f32x4 vr[16];
-      if (PF && cb == 0 && r0 == 0) {                  // (uniform) the block requested at the top of the kernel
+      const bool first = PF > 0 && cb == 0 && r0 == 0;   // (uniform) the block whose first PF rows were requested at the top of the kernel
 #pragma unroll
-        for (int uu = 0; uu < 16; ++uu) vr[uu] = vr0[PF ? uu : 0];
-      } else {
-#pragma unroll
-        for (int uu = 0; uu < 16; ++uu) {
-          const int r = r0 + grp + G * uu;
-          vr[uu] = ldb4(vrs, (act && r < n) ? (t0 + r) * vst + (cb + col) * 16 : P_OOB);
-        }
+      for (int uu = 0; uu < 16; ++uu) {
+        const int r = r0 + grp + G * uu;
+        if (uu < PF) vr[uu] = first ? vr0[uu < PF ? uu : 0] : ldb4(vrs, (act && r < n) ? (t0 + r) * vst + (cb + col) * 16 : P_OOB);
+        else vr[uu] = ldb4(vrs, (act && r < n) ? (t0 + r) * vst + (cb + col) * 16 : P_OOB);
       }
       for (int k0 = 0; k0 < K; k0 += 8) {
         const int kn = min(8, K - k0);
@@ -559,8 +556,9 @@ extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stre
   if (backward) hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *L);
   else if (beam) {
     static const int pf = getenv("AVSR_ATTN_BEAM_PREFETCH") ? atoi(getenv("AVSR_ATTN_BEAM_PREFETCH")) : 0;   // measured: 46.6 vs 29.5 us (200 VGPRs, one workgroup fewer per CU): off
-    if (pf) hipLaunchKernelGGL(attn_fwd_beam_kernel<true>, dim3(nbeam), dim3(256), 0, (hipStream_t)stream, *L);
-    else hipLaunchKernelGGL(attn_fwd_beam_kernel<false>, dim3(nbeam), dim3(256), 0, (hipStream_t)stream, *L);
+    if (pf >= 16) hipLaunchKernelGGL(attn_fwd_beam_kernel<16>, dim3(nbeam), dim3(256), 0, (hipStream_t)stream, *L);
+    else if (pf >= 8) hipLaunchKernelGGL(attn_fwd_beam_kernel<8>, dim3(nbeam), dim3(256), 0, (hipStream_t)stream, *L);
+    else hipLaunchKernelGGL(attn_fwd_beam_kernel<0>, dim3(nbeam), dim3(256), 0, (hipStream_t)stream, *L);
   }
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *L);
   AVSR_CHECK_LAUNCH();

@@ -133,6 +133,29 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
     *reinterpret_cast<f32x4*>(&lds[BUF][0][(srow + 48) * BG_P + sk]) = ra3;                                        \
     *reinterpret_cast<f32x4*>(&lds[BUF][1][(srow + 48) * BG_P + sk]) = rb3; }
 
+  // LSTM epilogue operands (parent row -> previous cell state; bias) requested now: two dependent round trips that would otherwise
+  // sit behind the last stage
+  float e_c[2] = {0.f, 0.f};
+  f32x4 e_b[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  if constexpr (LSTM) {
+    const float* const P_bias = PF(bias); const float* const P_c_in = PF(c_in); const int* const P_parent = PF(parent);
+    const int H = P_N >> 2;
+    const __amdgpu_buffer_rsrc_t prs = make_rsrc(P_parent ? (const void*)P_parent : (const void*)P_wt), crs = make_rsrc(P_c_in), brs = make_rsrc(P_bias ? P_bias : P_wt);
+    int pr[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = tid + 512 * it, row = ty * BG_T + (item >> 4);
+      pr[it] = __builtin_bit_cast(int, ldb1(prs, (P_parent && row < P_R) ? row * 4 : P_OOB));
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = tid + 512 * it, row = ty * BG_T + (item >> 4), u = tx * 16 + (item & 15);
+      const bool ok = row < P_R && u < H;
+      const long prow = P_parent ? (long)pr[it] : (long)row;
+      e_c[it] = ldb1(crs, ok ? (int)((prow * H + u) * 4) : P_OOB);
+      e_b[it] = ldb4(brs, (ok && P_bias) ? u * 16 : P_OOB);
+    }
+  }
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -210,7 +233,6 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
       for (int r = 0; r < 16; ++r) Cs[(rbase + (r & 3) + 8 * (r >> 2)) * CS + col] = acc[r];
     }
     __syncthreads();
-    const float* const P_bias = PF(bias); const float* const P_c_in = PF(c_in); const int* const P_parent = PF(parent);
     float* const P_c_out = PF(c_out); float* const P_h_out = PF(h_out); float* const P_seq_out = PF(seq_out);
     const long P_seq_sb = PF(seq_sb);
     const int H = P_N >> 2;
@@ -220,9 +242,8 @@ __global__ __launch_bounds__(512) void beam_gemm_kernel(const BGLaunch L) {
       const int row = ty * BG_T + rl, u = tx * 16 + ul;
       if (row >= P_R || u >= H) continue;
       f32x4 z = *reinterpret_cast<const f32x4*>(&Cs[rl * CS + 4 * ul]);
-      if (P_bias) z += ld4(P_bias + 4 * u);
-      const long pr = P_parent ? P_parent[row] : row;         // the previous state lives in the parent hypothesis' row
-      const float cprev = P_c_in[pr * H + u];
+      z += e_b[it];
+      const float cprev = e_c[it];                           // the previous state lives in the parent hypothesis' row (fetched in the prologue)
       const float gi = p_sigmoid(z[0]), gj = p_tanh(z[1]), gf = p_sigmoid(z[2] + 1.0f), go = p_sigmoid(z[3]);   // cells.py:14-18
       float c = gf * cprev + gi * gj;
       c = fminf(1.0f, fmaxf(-1.0f, c));                        // cell_clip = 1.0
