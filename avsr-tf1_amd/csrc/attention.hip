@@ -351,6 +351,131 @@ __global__ __launch_bounds__(256) void attn_fwd_beam_kernel(const AttnLaunch L) 
   }
 }
 
+// The same step on the matrix pipe (default under beam search; avsr_attn_rnn_set_beam_kernel(1)).  attn_fwd_beam_kernel above is
+// instruction-bound, not memory-bound: per workgroup 2 x 164 k scalar FMAs plus 160 cross-lane reduction steps per thread -- 29.5 us per
+// decode step at c4 whether or not its two operand fetches overlap (measured).  Both products are small
+// GEMMs with the K <= 16 hypotheses as one MFMA row tile:
+//   scores   S[q][r] = sum_h Q[q][h] K[r][h]      [16 x 256] x [256 x 64]   wave w takes frames 16 w .. 16 w + 15: 64 x v_mfma_f32_16x16x4_f32
+//   contexts C[q][d] = sum_r p[q][r] V[r][d]      [16 x 64]  x [64 x D]     wave w takes the 16-wide column tiles w, w + 4, ...: 16 each
+// (k permutation: lane group g = lane >> 4 owns k in [64 g, 64 g + 64) of the score product -- its key row piece is 16 contiguous
+// 16-byte loads -- and rows [16 g, 16 g + 16) of the context product; instruction i takes element i of every group's range.)
+// Same outputs as attn_fwd_beam_kernel (raw scores, chunk max / sum, un-normalised partial contexts by hypothesis row); the summation
+// order differs (an MFMA is an fp32 fma chain over its k), i.e. results agree to rounding, not bit for bit: tests/test_gpu_beam.py checks
+// this path against the oracle and the other two against each other.
+__global__ __launch_bounds__(256) void attn_fwd_beam_mfma_kernel(const AttnLaunch L) {
+  __shared__ __attribute__((aligned(16))) float sc[16][68];               // scaled scores, then probabilities [q][r]
+  __shared__ __attribute__((aligned(16))) float qs[16][260];              // queries [q][h], zero rows / columns beyond K / H
+  int blk = blockIdx.x, mi = 0;
+  for (int i = 0; i < L.nmech; ++i) {
+    const int nb = (L.B / L.m[i].mem_div) * L.m[i].nchunk;
+    if (blk < nb) { mi = i; break; }
+    blk -= nb;
+  }
+  const AttnMechDev& M = L.m[mi];
+  const int K = M.mem_div, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int c = blk % M.nchunk, u = blk / M.nchunk;
+  const int len = min(M.len ? M.len[u] : M.T, M.T);
+  const int t0 = c * M.chunk;
+  const int n = max(0, min(M.chunk, len - t0));
+  const int H = M.H, D = M.D;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // ---- key row piece of this lane: frame 16 wave + i16, k in [64 g, 64 g + 64) ----
+  f32x4 kr[16];
+  {
+    const __amdgpu_buffer_rsrc_t krs = make_rsrc(M.keys + (long)u * M.T * H);
+    const int r = 16 * wave + i16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = 64 * g + 4 * j;
+      kr[j] = ldb4(krs, (r < n && k < H) ? ((t0 + r) * H + k) * 4 : P_OOB);
+    }
+  }
+  for (int e = tid * 4; e < 16 * 256; e += 1024) {
+    const int q = e >> 8, k = e & 255;
+    st4(&qs[q][k], (q < K && k < H) ? ld4(M.query + (long)(u * K + q) * M.query_sb + k) : zero4);
+  }
+  __syncthreads();
+  {
+    f32x4 acc = zero4;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const f32x4 qa = *reinterpret_cast<const f32x4*>(&qs[i16][64 * g + 4 * j]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[e], kr[j][e], acc, 0, 0, 0);
+    }
+    // C layout: lane holds S[q = 4 g + reg][frame = 16 wave + i16]
+    const float gsc = (M.type == ATT_SCALED_LUONG) ? M.g[0] : 1.f;
+    const int r = 16 * wave + i16;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int q = 4 * g + reg;
+      if (q < K && r < n) M.scores[(long)(u * K + q) * M.scores_sb + t0 + r] = acc[reg];
+      sc[q][r] = acc[reg] * gsc;
+    }
+  }
+  // value operands of this wave's first four column tiles: requested before the softmax phase (the key registers are dead)
+  const __amdgpu_buffer_rsrc_t vrs = make_rsrc(M.values + (long)u * M.values_sb);
+  const int vst = (int)M.values_st * 4;
+  const int ntile = D >> 4;
+  float vv[4][16];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int dt = wave + 4 * tt;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = 16 * g + i;
+      vv[tt][i] = ldb1(vrs, (dt < ntile && r < n) ? (t0 + r) * vst + (16 * dt + i16) * 4 : P_OOB);
+    }
+  }
+  __syncthreads();
+  // ---- chunk max / exp / sum per hypothesis: one wave per query, one lane per frame (rows q >= K: zero probabilities) ----
+  for (int q = wave; q < 16; q += 4) {
+    const float v = (lane < n && q < K) ? sc[q][lane] : -INFINITY;
+    const float mx = wave_max(v);
+    const float pr = (lane < n && q < K) ? expf(v - mx) : 0.f;
+    const float lsum = wave_sum(pr);
+    sc[q][lane] = pr;
+    if (lane == 0 && q < K) {
+      const int b = u * K + q;
+      M.pm[(long)c * L.B + b] = (n > 0) ? mx : -INFINITY;
+      M.pl[(long)c * L.B + b] = lsum;
+    }
+  }
+  __syncthreads();
+  // ---- partial contexts: column tiles wave, wave + 4, ... ----
+  for (int tb = 0; tb < ntile; tb += 16) {
+    if (tb > 0) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const int dt = tb + wave + 4 * tt;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int r = 16 * g + i;
+          vv[tt][i] = ldb1(vrs, (dt < ntile && r < n) ? (t0 + r) * vst + (16 * dt + i16) * 4 : P_OOB);
+        }
+      }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int dt = tb + wave + 4 * tt;
+      if (dt >= ntile) continue;                       // (wave-uniform)
+      f32x4 acc = zero4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 pa = *reinterpret_cast<const f32x4*>(&sc[i16][16 * g + 4 * j]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[e], vv[tt][4 * j + e], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int q = 4 * g + reg;
+        if (q < K) M.pctx[((long)c * L.B + (u * K + q)) * D + 16 * dt + i16] = acc[reg];
+      }
+    }
+  }
+}
+
 // Per-step backward.  Inputs: d ctx [B,D] (gradient of this step's context), the forward context,
 // the saved raw scores and softmax partial statistics of this step.  Outputs: d score [B,T] (wrt the
 // softmax input) and per-chunk partial gradients of the query.
@@ -531,8 +656,8 @@ __global__ void bahdanau_dkeys_kernel(const float* keys, const float* pq, long p
 
 }  // namespace avsr
 
+namespace avsr { extern int g_beam_dense; bool beam_dense_on(); }
 static int g_beam_on = -1;
-namespace avsr { extern int g_beam_dense; }
 extern "C" int avsr_attn_rnn_set_beam_kernel(int32_t on) { g_beam_on = on ? 1 : 0; avsr::g_beam_dense = on == 1 ? 1 : 0; return AVSR_OK; }
 
 extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stream) {
@@ -543,7 +668,7 @@ extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stre
   if (nblk <= 0) return AVSR_ERR_ARG;
   ProfScope ps(backward ? PROF_ATTN_BWD : PROF_ATTN_FWD, (hipStream_t)stream);
   // beam search over shared memories: one workgroup per (utterance, chunk) runs the K hypotheses (attn_fwd_beam_kernel)
-  bool beam = !backward;
+  bool beam = !backward, mfma_ok = true;
   int nbeam = 0;
   if (g_beam_on < 0) { const char* e = getenv("AVSR_ATTN_BEAM"); g_beam_on = e ? (atoi(e) != 0) : 1; }
   const int beam_on = g_beam_on;
@@ -552,8 +677,10 @@ extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stre
     beam = beam_on && M.mem_div > 1 && M.mem_div <= ATTN_BEAM_KMAX && L->B % M.mem_div == 0 && M.type <= ATT_SCALED_LUONG && M.H <= 256 && M.H % 4 == 0 &&
            M.chunk <= 64 && M.D % 4 == 0 && M.D <= 1024 && (long)M.T * M.H * 4 < (1L << 31) && (long)M.T * M.values_st * 4 < (1L << 31);
     nbeam += (L->B / (M.mem_div > 0 ? M.mem_div : 1)) * M.nchunk;
+    mfma_ok = mfma_ok && M.D % 16 == 0;
   }
   if (backward) hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *L);
+  else if (beam && mfma_ok && avsr::beam_dense_on()) hipLaunchKernelGGL(attn_fwd_beam_mfma_kernel, dim3(nbeam), dim3(256), 0, (hipStream_t)stream, *L);
   else if (beam) {
     static const int pf = getenv("AVSR_ATTN_BEAM_PREFETCH") ? atoi(getenv("AVSR_ATTN_BEAM_PREFETCH")) : 0;   // measured: 46.6 vs 29.5 us (200 VGPRs, one workgroup fewer per CU): off
     if (pf >= 16) hipLaunchKernelGGL(attn_fwd_beam_kernel<16>, dim3(nbeam), dim3(256), 0, (hipStream_t)stream, *L);

@@ -351,8 +351,9 @@ int avsr_attn_rnn_fused_eligible(const avsr_attn_rnn* d);
 int avsr_attn_rnn_set_fused(int32_t on);
 /* Beam search (mode 3): which kernels run the B * K-row steps.  1 (default; AVSR_ATTN_BEAM / AVSR_BEAM_DENSE in the environment set
  * the initial values) = all beam-shaped kernels: the per-step attention as one workgroup per (utterance, chunk) serving all K
- * hypotheses over the shared memories (attn_fwd_beam_kernel), and the LSTM cell / attention layers as 64 x 64-tiled products with
- * row-gathered operands (csrc/beam_gemm.hip); 2 = the attention kernel only, dense steps through the small-tile step kernel;
+ * hypotheses over the shared memories, scores and contexts on the matrix pipe with the hypotheses as one MFMA row tile
+ * (attn_fwd_beam_mfma_kernel), and the LSTM cell / attention layers as 64 x 64-tiled products with row-gathered operands
+ * (csrc/beam_gemm.hip); 2 = the scalar K-hypotheses attention kernel (attn_fwd_beam_kernel) only, dense steps through the small-tile step kernel;
  * 0 = the general kernels everywhere.  0 and 2 give bit-identical scores, statistics and contexts; 1 differs from them by the
  * summation order of the dense products (tests/test_gpu_beam.py checks all three against the oracle). */
 int avsr_attn_rnn_set_beam_kernel(int32_t on);
