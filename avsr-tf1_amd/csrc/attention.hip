@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void attn_fwd_beam_kernel(const AttnLaunch L) 
 // decode step at c4 whether or not its two operand fetches overlap (measured).  Both products are small
 // GEMMs with the K <= 16 hypotheses as one MFMA row tile:
 //   scores   S[q][r] = sum_h Q[q][h] K[r][h]      [16 x 256] x [256 x 64]   wave w takes frames 16 w .. 16 w + 15: 64 x v_mfma_f32_16x16x4_f32
-//   contexts C[q][d] = sum_r p[q][r] V[r][d]      [16 x 64]  x [64 x D]     wave w takes the 16-wide column tiles w, w + 4, ...: 16 each
+//   contexts C[q][d] = sum_r p[q][r] V[r][d]      [16 x 64]  x [64 x D]     wave w takes the 64-column blocks w, w + 4, ...: 64 each
 // (k permutation: lane group g = lane >> 4 owns k in [64 g, 64 g + 64) of the score product -- its key row piece is 16 contiguous
 // 16-byte loads -- and rows [16 g, 16 g + 16) of the context product; instruction i takes element i of every group's range.)
 // Same outputs as attn_fwd_beam_kernel (raw scores, chunk max / sum, un-normalised partial contexts by hypothesis row); the summation
@@ -391,11 +391,26 @@ __global__ __launch_bounds__(256) void attn_fwd_beam_mfma_kernel(const AttnLaunc
       kr[j] = ldb4(krs, (r < n && k < H) ? ((t0 + r) * H + k) * 4 : P_OOB);
     }
   }
-  for (int e = tid * 4; e < 16 * 256; e += 1024) {
-    const int q = e >> 8, k = e & 255;
-    st4(&qs[q][k], (q < K && k < H) ? ld4(M.query + (long)(u * K + q) * M.query_sb + k) : zero4);
+  // queries, then the value operands of this wave's first 64-column block: all three operand fetches of the step are in flight together
+  // (in-order counters: the query wait below leaves the younger value loads outstanding; barriers here are LDS-only, __syncthreads()
+  // would drain them).  A lane fetches 16 bytes = 4 consecutive d of its 16 rows; instruction e of a row takes component e, so the
+  // column set of MFMA e is {64 blk + 4 i16 + e}: a permutation of the block's columns that costs nothing (the result of (reg, e = 0..3)
+  // is 4 consecutive d, one 16-byte store) and makes every load 256 contiguous bytes per row.
+  f32x4 qv[4];
+  {
+    const __amdgpu_buffer_rsrc_t qrs = make_rsrc(M.query + (long)u * K * M.query_sb);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid * 4 + 1024 * it, q = e >> 8, k = e & 255;
+      qv[it] = ldb4(qrs, (q < K && k < H) ? (int)(((long)q * M.query_sb + k) * 4) : P_OOB);
+    }
   }
-  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e = tid * 4 + 1024 * it;
+    st4(&qs[e >> 8][e & 255], qv[it]);
+  }
+  lds_barrier();
   {
     f32x4 acc = zero4;
 #pragma unroll
@@ -414,21 +429,21 @@ __global__ __launch_bounds__(256) void attn_fwd_beam_mfma_kernel(const AttnLaunc
       sc[q][r] = acc[reg] * gsc;
     }
   }
-  // value operands of this wave's first four column tiles: requested before the softmax phase (the key registers are dead)
+  // value operands of this wave's first 64-column block, requested before the softmax phase (the key registers are dead).  A lane
+  // fetches 16 bytes = 4 consecutive d of its 16 rows; instruction e of a row takes component e, so the column set of MFMA e is
+  // {64 blk + 4 i16 + e}: a permutation of the block's columns that costs nothing (the result of (reg, e = 0..3) is 4 consecutive d,
+  // one 16-byte store) and makes every load 256 contiguous bytes per row.  (Requested at the very top instead -- hidden loads, keys,
+  // queries and values in one burst -- the kernel needs 159 registers and loses a workgroup per CU: 27.0 us against 23 us.)
   const __amdgpu_buffer_rsrc_t vrs = make_rsrc(M.values + (long)u * M.values_sb);
   const int vst = (int)M.values_st * 4;
-  const int ntile = D >> 4;
-  float vv[4][16];
+  const int nblk = (D + 63) >> 6;
+  f32x4 vq[16];
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt) {
-    const int dt = wave + 4 * tt;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = 16 * g + i;
-      vv[tt][i] = ldb1(vrs, (dt < ntile && r < n) ? (t0 + r) * vst + (16 * dt + i16) * 4 : P_OOB);
-    }
+  for (int i = 0; i < 16; ++i) {
+    const int r = 16 * g + i, d = 64 * wave + 4 * i16;
+    vq[i] = ldb4(vrs, (wave < nblk && r < n && d < D) ? (t0 + r) * vst + d * 4 : P_OOB);
   }
-  __syncthreads();
+  lds_barrier();
   // ---- chunk max / exp / sum per hypothesis: one wave per query, one lane per frame (rows q >= K: zero probabilities) ----
   for (int q = wave; q < 16; q += 4) {
     const float v = (lane < n && q < K) ? sc[q][lane] : -INFINITY;
@@ -442,36 +457,30 @@ __global__ __launch_bounds__(256) void attn_fwd_beam_mfma_kernel(const AttnLaunc
       M.pl[(long)c * L.B + b] = lsum;
     }
   }
-  __syncthreads();
-  // ---- partial contexts: column tiles wave, wave + 4, ... ----
-  for (int tb = 0; tb < ntile; tb += 16) {
-    if (tb > 0) {
+  lds_barrier();
+  // ---- partial contexts: 64-column blocks wave, wave + 4, ... ----
+  for (int blk = wave; blk < nblk; blk += 4) {
+    if (blk != wave) {
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const int dt = tb + wave + 4 * tt;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int r = 16 * g + i;
-          vv[tt][i] = ldb1(vrs, (dt < ntile && r < n) ? (t0 + r) * vst + (16 * dt + i16) * 4 : P_OOB);
-        }
+      for (int i = 0; i < 16; ++i) {
+        const int r = 16 * g + i, d = 64 * blk + 4 * i16;
+        vq[i] = ldb4(vrs, (r < n && d < D) ? (t0 + r) * vst + d * 4 : P_OOB);
       }
     }
+    f32x4 acc[4] = {zero4, zero4, zero4, zero4};
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const int dt = tb + wave + 4 * tt;
-      if (dt >= ntile) continue;                       // (wave-uniform)
-      f32x4 acc = zero4;
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 pa = *reinterpret_cast<const f32x4*>(&sc[i16][16 * g + 4 * j]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 pa = *reinterpret_cast<const f32x4*>(&sc[i16][16 * g + 4 * j]);
+      for (int ee = 0; ee < 4; ++ee)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[e], vv[tt][4 * j + e], acc, 0, 0, 0);
-      }
+        for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[ee], vq[4 * j + ee][e], acc[e], 0, 0, 0);
+    }
+    const int d = 64 * blk + 4 * i16;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int q = 4 * g + reg;
-        if (q < K) M.pctx[((long)c * L.B + (u * K + q)) * D + 16 * dt + i16] = acc[reg];
-      }
+    for (int reg = 0; reg < 4; ++reg) {
+      const int q = 4 * g + reg;
+      if (q < K && d < D) st4(M.pctx + ((long)c * L.B + (u * K + q)) * D + d, f32x4{acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]});
     }
   }
 }
@@ -677,7 +686,7 @@ extern "C" int avsr_attn_launch_raw(const void* launch, int backward, void* stre
     beam = beam_on && M.mem_div > 1 && M.mem_div <= ATTN_BEAM_KMAX && L->B % M.mem_div == 0 && M.type <= ATT_SCALED_LUONG && M.H <= 256 && M.H % 4 == 0 &&
            M.chunk <= 64 && M.D % 4 == 0 && M.D <= 1024 && (long)M.T * M.H * 4 < (1L << 31) && (long)M.T * M.values_st * 4 < (1L << 31);
     nbeam += (L->B / (M.mem_div > 0 ? M.mem_div : 1)) * M.nchunk;
-    mfma_ok = mfma_ok && M.D % 16 == 0;
+    mfma_ok = mfma_ok && M.D % 4 == 0;
   }
   if (backward) hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *L);
   else if (beam && mfma_ok && avsr::beam_dense_on()) hipLaunchKernelGGL(attn_fwd_beam_mfma_kernel, dim3(nbeam), dim3(256), 0, (hipStream_t)stream, *L);
