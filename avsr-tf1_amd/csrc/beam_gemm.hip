@@ -262,28 +262,40 @@ struct BCLaunch { int nmech, R; BCMech m[AVSR_MAX_MECH]; };
 
 __global__ __launch_bounds__(256) void beam_ctx_merge_kernel(const BCLaunch L) {
   const BCMech& M = L.m[blockIdx.y];
-  const int r = blockIdx.x, c4 = threadIdx.x;
-  if (4 * c4 >= M.D) return;
-  float w[STEP_MAX_SLAB];
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per hypothesis row, four rows per workgroup
+  if (r >= L.R) return;
+  // statistics and partial contexts through unconditional buffer loads (out of range = 0): all slabs of a row in flight together
+  const __amdgpu_buffer_rsrc_t pm_rs = make_rsrc(M.pm), pl_rs = make_rsrc(M.pl), pc_rs = make_rsrc(M.pctx);
+  float w[STEP_MAX_SLAB], plv[STEP_MAX_SLAB];
+#pragma unroll
+  for (int j = 0; j < STEP_MAX_SLAB; ++j) {
+    const int o = j < M.nslab ? (j * L.R + r) * 4 : P_OOB;
+    w[j] = ldb1(pm_rs, o);
+    plv[j] = ldb1(pl_rs, o);
+  }
   float mx = -INFINITY;
 #pragma unroll
   for (int j = 0; j < STEP_MAX_SLAB; ++j) {
-    w[j] = j < M.nslab ? M.pm[(long)j * L.R + r] : -INFINITY;
+    w[j] = j < M.nslab ? w[j] : -INFINITY;
     mx = fmaxf(mx, w[j]);
   }
   float ls = 0.f;
 #pragma unroll
   for (int j = 0; j < STEP_MAX_SLAB; ++j) {
     const float e = (w[j] == -INFINITY) ? 0.f : expf(w[j] - mx);
-    ls += e * (j < M.nslab ? M.pl[(long)j * L.R + r] : 0.f);
+    ls += e * plv[j];                                   // plv is 0 for slabs that do not exist
     w[j] = e;
   }
   const float inv = ls > 0.f ? 1.0f / ls : 0.f;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int c4 = threadIdx.x & 63; 4 * c4 < M.D; c4 += 64) {
+    f32x4 sv[STEP_MAX_SLAB];
 #pragma unroll
-  for (int j = 0; j < STEP_MAX_SLAB; ++j)
-    if (j < M.nslab) acc += (w[j] * inv) * ld4(M.pctx + ((long)j * L.R + r) * M.D + 4 * c4);
-  st4(M.ctx + (long)r * M.ctx_sb + 4 * c4, acc);
+    for (int j = 0; j < STEP_MAX_SLAB; ++j) sv[j] = ldb4(pc_rs, j < M.nslab ? (int)((((long)j * L.R + r) * M.D + 4 * c4) * 4) : P_OOB);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < STEP_MAX_SLAB; ++j) acc += (w[j] * inv) * sv[j];
+    st4(M.ctx + (long)r * M.ctx_sb + 4 * c4, acc);
+  }
 }
 
 // ---- host side (called from avsr_attn_rnn_fwd, mode 3) --------------------------------------------------------------------------
@@ -331,7 +343,7 @@ int beam_attention_layer_launch(const avsr_attn_rnn& d, int l, hipStream_t s) {
   for (int m = 0; m < d.n_mech; ++m) {
     const avsr_attn_mech& M = d.mech[m];
     const int nc = (M.T + M.chunk - 1) / M.chunk;
-    if (M.D % 16 || nc > STEP_MAX_SLAB || M.D > 1024 || !M.ctx || (long)B * L * M.D * 4 >= (1L << 31) || (long)H * (H + M.D) * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
+    if (M.D % 16 || nc > STEP_MAX_SLAB || M.D > 1024 || !M.ctx || (long)nc * B * M.D * 4 >= (1L << 31) || (long)B * L * M.D * 4 >= (1L << 31) || (long)H * (H + M.D) * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
     BCMech& X = C.m[m];
     X.pm = M.pstat + (long)(2 * l) * nc * B; X.pl = M.pstat + (long)(2 * l + 1) * nc * B; X.pctx = M.pctx;
     X.ctx = M.ctx + (long)l * M.D; X.ctx_sb = (long)L * M.D; X.D = M.D; X.nslab = nc;
@@ -348,7 +360,7 @@ int beam_attention_layer_launch(const avsr_attn_rnn& d, int l, hipStream_t s) {
   }
   G.nprob = d.n_mech; G.ntiles = tiles;
   ProfScope ps(PROF_STEP_LINEAR, s);
-  hipLaunchKernelGGL(beam_ctx_merge_kernel, dim3(B, d.n_mech), dim3(((dmax / 4 + 63) / 64) * 64), 0, s, C);
+  hipLaunchKernelGGL(beam_ctx_merge_kernel, dim3((B + 3) / 4, d.n_mech), dim3(256), 0, s, C);
   hipLaunchKernelGGL(beam_gemm_kernel<false>, dim3(tiles), dim3(512), 0, s, G);
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
