@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libavsr_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "step.hip", "rnn.hip", "rnn_persist.hip", "rnn_persist_pair.hip", "rnn_persist_bwd.hip", "rnn_persist_bwd2.hip", "attention.hip", "attn_rnn.hip", "beam_gemm.hip", "dec_persist.hip", "dec_persist_bwd.hip", "elementwise.hip", "conv.hip", "conv_direct.hip", "conv_mfma.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "step.hip", "rnn.hip", "rnn_persist.hip", "rnn_persist_bwd.hip", "attention.hip", "attn_rnn.hip", "beam_gemm.hip", "dec_persist.hip", "dec_persist_bwd.hip", "elementwise.hip", "conv.hip", "conv_direct.hip", "conv_mfma.hip"]
 
 
 def _hipcc():
@@ -26,10 +26,16 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# Two alternative layouts of the persistent encoder kernels that were built, verified and measured slower (split BPTT,
+# pair-layout forward; AVSR_PERSISTENT_RNN bits 2 and 3).  Not part of the default library: AVSR_BUILD_EXPERIMENTAL=1 adds them.
+EXPERIMENTAL = ["experimental/rnn_persist_pair.hip", "experimental/rnn_persist_bwd2.hip"]
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    experimental = os.environ.get("AVSR_BUILD_EXPERIMENTAL") == "1"
+    srcs = [os.path.join(CSRC, s) for s in SOURCES + (EXPERIMENTAL if experimental else []) if os.path.exists(os.path.join(CSRC, s))]
     objs = []
     procs = []
     for s in srcs:
@@ -37,6 +43,8 @@ def build(force=False, verbose=False):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
                "-Wno-pass-failed", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", s, "-o", o]
         cmd[1:1] = os.environ.get("AVSR_HIPCC_FLAGS", "").split()     # e.g. -DPERSIST_TIMING for the probes
+        if experimental:
+            cmd[1:1] = ["-DAVSR_EXPERIMENTAL"]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(o)
     for cmd, p in procs:

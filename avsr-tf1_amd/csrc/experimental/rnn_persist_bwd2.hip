@@ -27,8 +27,8 @@
 
 namespace avsr {
 
-float* g_persist_scratch = nullptr;      // float scratch for the dx operands (caller-owned, avsr_rnn_set_persistent_scratch)
-int64_t g_persist_scratch_floats = 0;
+extern float* g_persist_scratch;         // float scratch for the dx operands (caller-owned, avsr_rnn_set_persistent_scratch; rnn_persist_bwd.hip)
+extern int64_t g_persist_scratch_floats;
 
 struct STask {
   int kind;                               // 0 CELL, 1 HELP
@@ -250,10 +250,6 @@ static_assert(sizeof(SLaunch) <= 3072, "launch descriptor must fit the kernel-ar
 
 }  // namespace avsr
 
-extern "C" int avsr_rnn_set_persistent_scratch(float* scratch, int64_t floats) {
-  avsr::g_persist_scratch = scratch; avsr::g_persist_scratch_floats = scratch ? floats : 0;
-  return AVSR_OK;
-}
 
 #define UNSUP2(code) do { if (getenv("AVSR_PERSIST_DEBUG")) fprintf(stderr, "[avsr] split persistent BPTT not used: reason %d (rnn_persist_bwd2.hip)\n", code); return AVSR_ERR_UNSUPPORTED; } while (0)
 

@@ -67,9 +67,12 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
   if (!st || n <= 0 || n > AVSR_MAX_STACKS) return AVSR_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   {
-    int rc = run_persistent(avsr_rnn_fwd_persistent_pair, st, n, stream);    // one launch for the whole sequence when it fits:
-    if (rc != AVSR_ERR_UNSUPPORTED) return rc;                                // 16-row groups on XCD pairs first (mode bit 3),
-    rc = run_persistent(avsr_rnn_fwd_persistent, st, n, stream);             // then 8-row groups per XCD / the agent-scope form
+    int rc = AVSR_ERR_UNSUPPORTED;                                            // one launch for the whole sequence when it fits:
+#ifdef AVSR_EXPERIMENTAL                                                      // (csrc/experimental/: built with AVSR_BUILD_EXPERIMENTAL=1)
+    rc = run_persistent(avsr_rnn_fwd_persistent_pair, st, n, stream);        // 16-row groups on XCD pairs first (mode bit 3),
+    if (rc != AVSR_ERR_UNSUPPORTED) return rc;
+#endif
+    rc = run_persistent(avsr_rnn_fwd_persistent, st, n, stream);             // 8-row groups per XCD / the agent-scope form
     if (rc != AVSR_ERR_UNSUPPORTED) return rc;
   }
   int nsteps = 0, ntask_max = 0;
@@ -222,8 +225,11 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
   }
   if (ntask_max > STEP_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
   {
-    int rc = run_persistent(avsr_rnn_bwd_persistent_split, st, n, stream);   // one launch for the whole BPTT when it fits:
-    if (rc != AVSR_ERR_UNSUPPORTED) return rc;                                // split form first, then the fused form
+    int rc = AVSR_ERR_UNSUPPORTED;                                            // one launch for the whole BPTT when it fits:
+#ifdef AVSR_EXPERIMENTAL
+    rc = run_persistent(avsr_rnn_bwd_persistent_split, st, n, stream);       // split form first (mode bit 2), then the fused form
+    if (rc != AVSR_ERR_UNSUPPORTED) return rc;
+#endif
     rc = run_persistent(avsr_rnn_bwd_persistent, st, n, stream);
     if (rc != AVSR_ERR_UNSUPPORTED) return rc;
   }

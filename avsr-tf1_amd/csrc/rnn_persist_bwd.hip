@@ -23,7 +23,14 @@
 #include "persist.h"
 
 #define B_MAX_TASKS 12
-namespace avsr { extern float* g_persist_scratch; extern int64_t g_persist_scratch_floats; }
+namespace avsr {
+float* g_persist_scratch = nullptr;      // float scratch of the K-split kernel: partial d h slabs, the helpers' dx records (caller-owned)
+int64_t g_persist_scratch_floats = 0;
+}
+extern "C" int avsr_rnn_set_persistent_scratch(float* scratch, int64_t floats) {
+  avsr::g_persist_scratch = scratch; avsr::g_persist_scratch_floats = scratch ? floats : 0;
+  return AVSR_OK;
+}
 #define B_CH 8            // 16-wide K chunks per wave per operand part (4H / 16 / 8 waves, H <= 256)
 
 namespace avsr {
