@@ -59,6 +59,20 @@ def test_random_configuration(seed):
     _check(_sample(rng), rng, seed)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AVSR_FUZZ_VOCAB_N", "12"))))
+def test_random_configuration_other_vocabularies(seed):
+    """The same walk with the vocabularies the reference ships besides characters (viseme V = 15, phoneme V = 41; avsr/misc/*_list) and
+    the largest the fused decode takes (V = 64): logits split, sampler, sequence loss, one-hot table and (V > 32) the 64-symbol rows of
+    the fused kernel under random model options.  (A separate generator picks the vocabulary: the configurations of the seeds above
+    stay what they were.)"""
+    rng = np.random.default_rng(1000 + seed)
+    ocfg = _sample(rng)
+    V = int(np.random.default_rng(7000 + seed).choice([15, 41, 41, 64]))
+    ocfg = dataclasses.replace(ocfg, vocab_size=V, eos_id=V - 2, go_id=V - 1)
+    ocfg.validate()
+    _check(ocfg, rng, 7000 + seed)
+
+
 def _unpadded(ocfg, rng):
     """The same configuration at widths the kernels do not take natively (the engine pads them to multiples of 4 inside;
     ModelConfig.engine()): odd / 4k+2 unit, feature, embedding and Dense sizes, sometimes one-hot decoder inputs.  Dropout off: its
