@@ -197,10 +197,16 @@ __global__ __launch_bounds__(256) void logits_sample_kernel(const float* x, long
 // History, measured at c4 (B * K = 640 rows, V = 31; tools/beam_gemm_dissect.sh): round 2 one thread selecting serially 165 us;
 // round 3 one wave, candidates in LDS, parents' flags loaded inside every round 22 us; rank by counting (every candidate against
 // every other, broadcast LDS reads) 28 us -- 310 x 310 comparisons are more instructions than ten reductions.
-__global__ __launch_bounds__(256) void beam_step_kernel(const float* logits, long logits_sb, int V, int K, int l, int eos, float w,
+// NCT > 0: the output layer runs here too (seq2seq.py:339 the decoder's Dense(vocab) under BeamSearchDecoder): the utterance's K rows of
+// the attention output [K x O] times Wout^T [O x V] as NCT 16-column tiles of v_mfma_f32_16x16x4_f32, wave w taking the O / 4 inputs
+// [w O / 4, (w + 1) O / 4), the four partial tiles summed through LDS -- one launch and one read-back of the logits less per step
+// (the separate projection was a 7 us launch of 640 x 31 outputs).  Needs K <= 16, V <= 16 NCT, O % 256 == 0.  NCT == 0: logits given.
+template <int NCT>
+__global__ __launch_bounds__(256) void beam_step_kernel(float* logits, long logits_sb, int V, int K, int l, int eos, float w,
                                  const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
                                  float* logp_out, int32_t* fin_out, int32_t* len_out, int32_t* tok, int32_t* parent_rows,
-                                 int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished) {
+                                 int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished,
+                                 const float* xa, long xsb, int O, const float* wout_t, const float* bout) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // logits [K*V] | lse [K] | max [K] | sum [K] | penalties [K][2] | fin [K] | len [K] | logp [K] | alive | winners [2][4] x 64 bit
   const int n = K * V;
   float* lg_s = sm;
@@ -215,12 +221,61 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* logits, lon
   unsigned long long* win = reinterpret_cast<unsigned long long*>(sm + ((n + 8 * K + 1 + 1) & ~1));      // 8-byte aligned
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float FMIN = -3.4028234663852886e38f;
-  for (int i = tid; i < n; i += 256) {
-    const int k = i / V, v = i - k * V;
-    lg_s[i] = logits[(long)(b * K + k) * logits_sb + v];
-  }
   if (tid < K) { fin_s[tid] = fin_in[b * K + tid]; len_s[tid] = len_in[b * K + tid]; logp_s[tid] = logp_in[b * K + tid]; }
   if (tid == 0) alive_s[0] = 0;
+  if constexpr (NCT > 0) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    float* part = reinterpret_cast<float*>(win + 8);               // [4 waves][16 rows][16 NCT columns]
+    const int i16 = lane & 15, g = lane >> 4, kw = O >> 2;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const float* xr = xa + (long)(b * K + (i16 < K ? i16 : 0)) * xsb + wave * kw + 4 * g;
+    const float* wr[NCT];
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+      const int v = c * 16 + i16;
+      wr[c] = wout_t + (long)(v < V ? v : 0) * O + wave * kw + 4 * g;
+      acc[c] = zero;
+    }
+    const bool arow = i16 < K;
+#pragma unroll 1
+    for (int kk = 0; kk < kw; kk += 64) {                         // lane (i16, g) holds inputs kk + 16 u + 4 g .. + 3 of row / column i16
+      f32x4 a[4], bv[4][NCT];                                     // (all loads of four 16-input groups in flight, then their products)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = *reinterpret_cast<const f32x4*>(xr + kk + 16 * u);
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) bv[u][c] = *reinterpret_cast<const f32x4*>(wr[c] + kk + 16 * u);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!arow) a[u] = zero;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) if (c * 16 + i16 >= V) bv[u][c] = zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], bv[u][c][e], acc[c], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(wave * 16 + 4 * g + r) * (16 * NCT) + c * 16 + i16] = acc[c][r];
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const int k = i / V, v = i - k * V, o = k * (16 * NCT) + v;
+      const float sv = ((part[o] + part[256 * NCT + o]) + (part[512 * NCT + o] + part[768 * NCT + o])) + bout[v];
+      lg_s[i] = sv;
+      logits[(long)(b * K + k) * logits_sb + v] = sv;
+    }
+  } else {
+    for (int i = tid; i < n; i += 256) {
+      const int k = i / V, v = i - k * V;
+      lg_s[i] = logits[(long)(b * K + k) * logits_sb + v];
+    }
+  }
   __syncthreads();
 #if defined(BS_STOP) && BS_STOP <= 1
   if (tid == 0) n_unfinished[0] = (int)lg_s[0];
@@ -615,25 +670,33 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
         AVSR_CHECK_LAUNCH();
         continue;
       }
-      SL.ntask = 1;
-      StepTask& tk = SL.task[0];
-      tk = StepTask{};
-      StepSrc& x = tk.src[tk.nsrc++];
-      x.a = xa; x.sb = xsb;
-      x.K = O; x.w = d.wout_t; x.ldw = O; x.kind = SRC_PLAIN;
-      tk.B = B; tk.N = d.V; tk.mode = EP_LINEAR; tk.t = l; tk.T = L; tk.len = (d.mode == 3) ? nullptr : d.steplen; tk.bias = d.bout;
-      tk.p0 = d.logits + (long)l * d.V; tk.s0 = (long)L * d.V;
-      if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+      // beam search on the dense path: the output layer inside the beam step (beam_step_kernel<NCT>)
+      const int bs_nct = (beam_dense && d.beam_width <= 16 && d.V <= 64 && O % 256 == 0 && xsb % 4 == 0 &&
+                          (((uintptr_t)xa | (uintptr_t)d.wout_t) & 15) == 0) ? (d.V <= 32 ? 2 : 4) : 0;
+      if (!bs_nct) {
+        SL.ntask = 1;
+        StepTask& tk = SL.task[0];
+        tk = StepTask{};
+        StepSrc& x = tk.src[tk.nsrc++];
+        x.a = xa; x.sb = xsb;
+        x.K = O; x.w = d.wout_t; x.ldw = O; x.kind = SRC_PLAIN;
+        tk.B = B; tk.N = d.V; tk.mode = EP_LINEAR; tk.t = l; tk.T = L; tk.len = (d.mode == 3) ? nullptr : d.steplen; tk.bias = d.bout;
+        tk.p0 = d.logits + (long)l * d.V; tk.s0 = (long)L * d.V;
+        if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+      }
       if (d.mode == 1) {
         hipLaunchKernelGGL(greedy_sample_kernel, dim3(1), dim3(256), 0, s, d.logits + (long)l * d.V, (long)L * d.V, d.V,
                            d.ids + l, (long)L, d.tok, d.steplen, d.n_unfinished, B, l, d.eos_id);
       } else if (d.mode == 3) {
         const int K = d.beam_width, pin = l & 1, pout = (l + 1) & 1;
-        hipLaunchKernelGGL(beam_step_kernel, dim3(B / K), dim3(256), (K * d.V + 8 * K + 24) * sizeof(float), s, d.logits + (long)l * d.V,
-                           (long)L * d.V, d.V, K, l, d.eos_id, d.length_penalty, d.beam_logp + (long)pin * B, d.beam_fin + (long)pin * B,
-                           d.beam_len + (long)pin * B, d.beam_logp + (long)pout * B, d.beam_fin + (long)pout * B,
-                           d.beam_len + (long)pout * B, d.tok, d.parent_rows, d.step_ids + (long)l * B, d.parent_ids + (long)l * B,
-                           d.n_unfinished + l);
+#define BS_GO(NCT_)                                                                                                                       \
+  hipLaunchKernelGGL(beam_step_kernel<NCT_>, dim3(B / K), dim3(256), (K * d.V + 8 * K + 24 + 1024 * NCT_) * sizeof(float), s,               \
+                     d.logits + (long)l * d.V, (long)L * d.V, d.V, K, l, d.eos_id, d.length_penalty, d.beam_logp + (long)pin * B,           \
+                     d.beam_fin + (long)pin * B, d.beam_len + (long)pin * B, d.beam_logp + (long)pout * B, d.beam_fin + (long)pout * B,    \
+                     d.beam_len + (long)pout * B, d.tok, d.parent_rows, d.step_ids + (long)l * B, d.parent_ids + (long)l * B,              \
+                     d.n_unfinished + l, xa, xsb, O, d.wout_t, d.bout)
+        if (bs_nct == 2) BS_GO(2); else if (bs_nct == 4) BS_GO(4); else BS_GO(0);
+#undef BS_GO
       } else {
         hipLaunchKernelGGL(sched_sample_kernel, dim3(B), dim3(128), sizeof(float) * d.V, s, d.logits + (long)l * d.V, (long)L * d.V, d.V, d.labels,
                            d.fed, d.xs, d.embedding, B, L, E, l, d.seed, d.sampling_prob, drop ? d.keep_in : 1.0f, cid4, E + A);

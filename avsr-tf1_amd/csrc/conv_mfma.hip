@@ -1551,9 +1551,11 @@ static int wg_pick_frames(int N, int Fmax, int slots) {
 
 // final reduction of the pixel-pair weight gradient (below): part [nblk][12*Ci*16 (+16)] with rows (ti, tj', ci), columns (pp, co):
 // dw[ti][tj][ci][co] = sum_blk part[(ti*4 + tj)*Ci + ci][co] + part[(ti*4 + tj + 1)*Ci + ci][8 + co];  dbias[co] = sum_blk bias[co] + bias[8 + co]
-__global__ __launch_bounds__(256) void wgrad_pair_final_kernel(const float* __restrict__ part, int nblk, int slab, int Ci, float* __restrict__ dw,
-                                                              float* __restrict__ dbias, float beta) {
-  __shared__ double red[8][33];
+__global__ __launch_bounds__(1024) void wgrad_pair_final_kernel(const float* __restrict__ part, int nblk, int slab, int Ci, float* __restrict__ dw,
+                                                               float* __restrict__ dbias, float beta) {
+  // 32 outputs per workgroup, 32 slices of the slab list each (one thread per (slice, output): 512 slabs = 16 dependent fp64 adds per
+  // thread with four slabs' loads in flight; 8 slices of 64 slabs took 22 us per launch, three launches per step)
+  __shared__ double red[32][33];
   const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int nw = 9 * Ci * 8, f = blockIdx.x * 32 + fl;              // outputs: 9*Ci*8 kernel entries, then 8 bias entries
   int o0 = -1, o1 = -1;
@@ -1566,14 +1568,26 @@ __global__ __launch_bounds__(256) void wgrad_pair_final_kernel(const float* __re
     o1 = o0 + 8;
   }
   double s = 0.0;
-  if (o0 >= 0)
-    for (int i = g; i < nblk; i += 8) s += (double)part[(long)i * slab + o0] + (double)part[(long)i * slab + o1];
+  if (o0 >= 0) {
+    int i = g;
+    for (; i + 96 < nblk; i += 128) {
+      const float a0 = part[(long)i * slab + o0], b0 = part[(long)i * slab + o1];
+      const float a1 = part[(long)(i + 32) * slab + o0], b1 = part[(long)(i + 32) * slab + o1];
+      const float a2 = part[(long)(i + 64) * slab + o0], b2 = part[(long)(i + 64) * slab + o1];
+      const float a3 = part[(long)(i + 96) * slab + o0], b3 = part[(long)(i + 96) * slab + o1];
+      s += (double)a0 + (double)b0;
+      s += (double)a1 + (double)b1;
+      s += (double)a2 + (double)b2;
+      s += (double)a3 + (double)b3;
+    }
+    for (; i < nblk; i += 32) s += (double)part[(long)i * slab + o0] + (double)part[(long)i * slab + o1];
+  }
   red[g][fl] = s;
   __syncthreads();
   if (g == 0 && o0 >= 0) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][fl];
+    for (int k = 0; k < 32; ++k) t += red[k][fl];
     float* const o = f < nw ? dw + f : dbias + (f - nw);
     *o = beta != 0.f ? (float)t + beta * *o : (float)t;
   }
@@ -1635,7 +1649,7 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
         if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
       }
       const int nout = 9 * Ci * 8 + 8;
-      hipLaunchKernelGGL(wgrad_pair_final_kernel, dim3((nout + 31) / 32), dim3(256), 0, s, scratch, grid, A.slab, Ci, dw, dbias, beta);
+      hipLaunchKernelGGL(wgrad_pair_final_kernel, dim3((nout + 31) / 32), dim3(1024), 0, s, scratch, grid, A.slab, Ci, dw, dbias, beta);
       if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
       return AVSR_OK;
     }

@@ -234,3 +234,31 @@ def test_beam_width_10_at_benchmark_widths_and_lengths(case, over):
     O, ocfg, mcfg, W, batch = make(case, B=2, Ta=500, Tv=75, L=40, ragged=True, **over)
     frac = _beam_check(O, ocfg, mcfg, _trained(O, ocfg, W, batch), batch, 10, 40, case, check_every=8, min_strict=0.5)
     print("strictly compared fraction of (utterance, step) pairs:", frac)
+
+
+@pytest.mark.parametrize("K", [10, 16])
+@pytest.mark.parametrize("unit", ["viseme", "character", "phoneme"])
+def test_output_layer_inside_the_beam_step(unit, K):
+    """At 256 units the dense beam path runs the decoder's Dense(vocab) inside beam_step_kernel<NCT> (csrc/attn_rnn.hip: two 16-column
+    MFMA tiles for V <= 32, four for V <= 64; O = 512 attention outputs split over the four waves).  Oracle parity step by step, and
+    the logits it leaves behind against those of the separate projection launch (setting 2: general step kernels), to rounding."""
+    from avsr_tf1_amd import ops
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    over = dict(video_units=(256,), audio_units=(256, 256), decoder_units=(256,), embedding_size=128, video_feat=128, audio_feat=80,
+                **VOCABS[unit])
+    O, ocfg, mcfg, W, batch = make("c4_bimodal_uni", B=3, Ta=60, Tv=20, L=12, ragged=True, **over)
+    W2 = _trained(O, ocfg, W, batch)
+    frac = _beam_check(O, ocfg, mcfg, W2, batch, K, 12, (unit, K), check_every=4, min_strict=0.5)
+    print("strictly compared fraction of (utterance, step) pairs:", frac)
+    db = Batch.from_numpy(batch)
+    first = []
+    try:
+        for setting in (1, 2):
+            ops.attn_rnn_set_beam_kernel(setting)
+            m = Seq2SeqModel(mcfg, weights=W2)
+            m.beam_search_decode(db, beam_width=K, max_steps=12, check_every=4, return_all=True)
+            torch.cuda.synchronize()
+            first.append(m._beam_ws[1]["dec"]["logits"][:, 0].cpu().numpy().copy())     # step 0: identical inputs on both paths
+    finally:
+        ops.attn_rnn_set_beam_kernel(1)
+    assert np.isfinite(first[0]).all() and np.abs(first[0] - first[1]).max() < 1e-4 * max(1.0, np.abs(first[1]).max())
