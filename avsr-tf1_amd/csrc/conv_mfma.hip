@@ -116,6 +116,9 @@ struct CGArgs {
 template <int MAXCH, bool CH4, int EP>
 __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef CONV_DEBUG
+  const long t_k0 = __builtin_readcyclecounter();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
   const int Cs = A.Cs, CsL = A.CsL, Cd = A.Cd, C4 = CsL >> 2;
@@ -131,9 +134,18 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   const int rows_all = A.F * opf, rows_pad = ((rows_all + 15) >> 4) << 4;
   int* const rowtab = reinterpret_cast<int*>(lds + A.F * fstride);
   int* const dsttab = rowtab + rows_pad;
+  // The tap list, copied to LDS: the weight-fragment set-up below indexes it per LANE (a chunk's four k-quads can lie in different taps),
+  // and a lane-dependent index into the kernel argument became, per chunk, a global load of the entry followed by a wait for EVERYTHING
+  // outstanding -- 18 serialised memory round trips, 22 k cycles (9 us) of every 18-chunk launch (profiles/r04_conv_deep_dissection.txt).
+  int* const taptab = dsttab + rows_pad;               // [CG_MAXTAP][4]: da, db, w[0] | w[1] << 16, w[2] | w[3] << 16
+  const int tapword = reinterpret_cast<const int*>(A.tap)[tid & (CG_MAXTAP * 4 - 1)];      // (in flight under the zeroing loop)
 
   // zero the LDS once: halos (and the padded 4th channel of a 3-channel source) stay zero, frames overwrite the interior
   for (int idx = tid; idx < A.F * fstride; idx += 256) lds[idx] = 0.f;
+  if (tid < CG_MAXTAP * 4) taptab[tid] = tapword;
+#ifdef CONV_DEBUG
+  const long t_s1 = __builtin_readcyclecounter();
+#endif
   // tile tables (rows beyond the staged frames read the window of row 0 and are never written out)
   for (int m = tid; m < rows_pad; m += 256) {
     int ro = 0, dt = 4;
@@ -149,6 +161,10 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
     dsttab[m] = dt;
   }
 
+  __syncthreads();                                      // (tap table visible)
+#ifdef CONV_DEBUG
+  const long t_s2 = __builtin_readcyclecounter();
+#endif
   // weight fragments of this wave's column tile (A operand: row i of the fragment = column nt*16 + i of the product) + per-chunk LDS
   // offsets of this lane's k-quad
   const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(A.w);
@@ -163,10 +179,10 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
       const int kq = 4 * c + q;
       const bool in = c < nch && kq < KQ;
       const int t = in ? kq / C4 : 0, cs4 = in ? kq - t * C4 : 0;
-      koff[c] = in ? (A.tap[t].da * PW + A.tap[t].db) * CsL + cs4 * 4 : 0;
-      int widx = -1;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) widx = (k == sp) ? (int)A.tap[t].w[k] : widx;
+      const i32x4_ tp = *reinterpret_cast<const i32x4_*>(taptab + 4 * t);
+      koff[c] = in ? (tp[0] * PW + tp[1]) * CsL + cs4 * 4 : 0;
+      const int wpair = (sp & 2) ? tp[3] : tp[2];
+      const int widx = (int)(short)((sp & 1) ? (wpair >> 16) : (wpair & 0xffff));
       // unconditional buffer loads (out-of-range offset = 0): all fragments of the wave are in flight together
       f32x4 wv;
 #pragma unroll
@@ -178,6 +194,9 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
       wreg[c] = wv;
     }
   }
+#ifdef CONV_DEBUG
+  const long t_s3 = __builtin_readcyclecounter();
+#endif
   // result columns of this lane: cD0 .. cD0 + 3 = four consecutive channels of sub-position spD
   const int cD0 = nt * 16 + q * 4;
   const bool colok = cD0 < NC;
@@ -221,8 +240,19 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   const int per3 = A.SH * A.SW * Cs;                                // floats per frame (3-channel path)
   // (hidden loads, see persist.h: left to the compiler the whole prefetch is waited for BEFORE the tile loop it should overlap)
   const i32x4_ src_rs = make_rsrc_words(A.src);                     // (source maps stay below 2 GB: checked by the host)
+  // Frames of this workgroup: an EVEN share [n_begin, n_end) of the N frames, walked in passes of FP <= F frames.  (Passes of F frames dealt
+  // round-robin left the busiest workgroup with ceil(passes / grid) * F frames: 4800 frames of a 9x9 map, F = 4, 512 workgroups = 12 frames
+  // against 9.4 on average -- the kernel ends with its slowest workgroup: profiles/r04_conv_deep_dissection.txt, max vs mean cycles.)
+  // (F = 1, the 36x36 maps: single frames dealt round-robin as before -- the same maximum, and neighbouring workgroups stream
+  // neighbouring frames: measured 3-4 % faster there than 512 separate ranges)
+  const int fs_per = A.N / (int)gridDim.x, fs_extra = A.N - fs_per * (int)gridDim.x;
+  const int fs_cnt = fs_per + ((int)blockIdx.x < fs_extra ? 1 : 0), fs_np = (fs_cnt + A.F - 1) / A.F;
+  const bool fs_rr = A.F == 1;
+  const int FP = fs_rr ? 1 : (fs_np > 0 ? (fs_cnt + fs_np - 1) / fs_np : A.F);
+  const int n_begin = fs_rr ? (int)blockIdx.x : (int)blockIdx.x * fs_per + min((int)blockIdx.x, fs_extra);
+  const int n_end = fs_rr ? A.N : n_begin + fs_cnt, n_step = fs_rr ? (int)gridDim.x : FP;
   auto fetch = [&](int n0) {
-    const int fcur = min(A.F, A.N - n0);
+    const int fcur = min(FP, n_end - n0);
     if (c4) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -241,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
     }
   };
   auto commit = [&](int n0) {
-    const int fcur = min(A.F, A.N - n0);
+    const int fcur = min(FP, n_end - n0);
     vm_wait_all();
 #pragma unroll
     for (int u = 0; u < PF; ++u) vm_landed(pre[u]);
@@ -273,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
       for (int e = tot4 * 4 + tid; e < tot; e += 256) put(e, sp[e]);
     }
   };
-  int n0 = blockIdx.x * A.F;
+  int n0 = n_begin;
 #ifdef CONV_DEBUG
   long t_pro = 0, t_b1 = 0, t_commit = 0, t_b2 = 0, t_comp = 0, t_mark = __builtin_readcyclecounter();
   const long t_start = t_mark;
@@ -281,17 +311,17 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
 #else
 #define CG_STAMP(acc)
 #endif
-  if (n0 < A.N) fetch(n0);
+  if (n0 < n_end) fetch(n0);
   CG_STAMP(t_pro)
-  for (; n0 < A.N; n0 += gridDim.x * A.F) {
-    const int fcur = min(A.F, A.N - n0);
+  for (; n0 < n_end; n0 += n_step) {
+    const int fcur = min(FP, n_end - n0);
     __syncthreads();                                    // previous pass has finished reading the LDS (first pass: tables written)
     CG_STAMP(t_b1)
     commit(n0);
     CG_STAMP(t_commit)
     __syncthreads();
     CG_STAMP(t_b2)
-    if (n0 + gridDim.x * A.F < A.N) fetch(n0 + gridDim.x * A.F);      // in flight during the MFMAs below
+    if (n0 + n_step < n_end) fetch(n0 + n_step);      // in flight during the MFMAs below
     // ---- implicit GEMM over the staged frames ----
     const int Mtot = fcur * opf, mtiles = (Mtot + 15) >> 4;
     const unsigned pass_o = (unsigned)((long)n0 * pixf * Cd * 4);     // (destination maps stay below 2 GB: checked by the host)
@@ -475,6 +505,8 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
     float* o = A.stats + (long)gridDim.x * 2 * Cd + ((long)blockIdx.x * 4 + wave) * 8;
     o[0] = (float)t_pro; o[1] = (float)t_b1; o[2] = (float)t_commit; o[3] = (float)t_b2; o[4] = (float)t_comp;
     o[5] = (float)(__builtin_readcyclecounter() - t_start);
+    o[6] = (float)(t_start - t_k0);                      // set-up: LDS zeroing, tile tables, weight fragments
+    if (A.dbg & 16) { o[0] = (float)(t_s1 - t_k0); o[1] = (float)(t_s2 - t_s1); o[2] = (float)(t_s3 - t_s2); o[3] = (float)(t_start - t_s3); }   // set-up split
   }
 #endif
   if (A.stats) {
@@ -535,7 +567,10 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
   const int opf = A.OA * A.OB, pixf = A.DH * A.DW;
   const int rows_all = A.F * opf, rows_pad = ((rows_all + 63) >> 6) << 6;
   int* const rowtab = reinterpret_cast<int*>(lds + A.F * fstride);
+  int* const taptab = rowtab + rows_pad;               // the tap list in LDS (see conv_gen_kernel): indexed per lane below
+  const int tapword = reinterpret_cast<const int*>(A.tap)[tid & (CG_MAXTAP * 4 - 1)];      // (in flight under the zeroing loop)
   for (int idx = tid; idx < A.F * fstride; idx += 256) lds[idx] = 0.f;
+  if (tid < CG_MAXTAP * 4) taptab[tid] = tapword;
   // window of position m: LDS offset of its centre pixel (floats), and -- 8-channel sources -- the swizzle phase of that pixel's column
   for (int m = tid; m < rows_pad; m += 256) {
     int ro = ((PW + 1) * CsL) | (1 << 24);             // rows beyond the staged frames: the window of position 0 (never written out)
@@ -545,6 +580,7 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
     }
     rowtab[m] = ro;
   }
+  __syncthreads();                                      // (tap table visible)
   // weights: lane (block bb, i) holds W[channel 4h + i][k = 16a + bb]; k = 4*(tap*C4T + quad) + e
   float wA[2][NA];
   {
@@ -555,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
       const int k = 16 * a + bb, kq = k >> 2, e = k & 3;
       const bool in = kq < NQ;
       const int t = in ? kq / C4T : 0, cs = (kq - t * C4T) * 4 + e;
-      const int widx = in ? (int)A.tap[t].w[0] : -1;
+      const int widx = in ? (int)(short)(taptab[4 * t + 2] & 0xffff) : -1;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int co = 4 * h + i;
@@ -604,8 +640,19 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
   const int per3 = A.SH * A.SW * Cs;                                // floats per frame (3-channel path)
   // (hidden loads, see persist.h: left to the compiler the whole prefetch is waited for BEFORE the tile loop it should overlap)
   const i32x4_ src_rs = make_rsrc_words(A.src);                     // (source maps stay below 2 GB: checked by the host)
+  // Frames of this workgroup: an EVEN share [n_begin, n_end) of the N frames, walked in passes of FP <= F frames.  (Passes of F frames dealt
+  // round-robin left the busiest workgroup with ceil(passes / grid) * F frames: 4800 frames of a 9x9 map, F = 4, 512 workgroups = 12 frames
+  // against 9.4 on average -- the kernel ends with its slowest workgroup: profiles/r04_conv_deep_dissection.txt, max vs mean cycles.)
+  // (F = 1, the 36x36 maps: single frames dealt round-robin as before -- the same maximum, and neighbouring workgroups stream
+  // neighbouring frames: measured 3-4 % faster there than 512 separate ranges)
+  const int fs_per = A.N / (int)gridDim.x, fs_extra = A.N - fs_per * (int)gridDim.x;
+  const int fs_cnt = fs_per + ((int)blockIdx.x < fs_extra ? 1 : 0), fs_np = (fs_cnt + A.F - 1) / A.F;
+  const bool fs_rr = A.F == 1;
+  const int FP = fs_rr ? 1 : (fs_np > 0 ? (fs_cnt + fs_np - 1) / fs_np : A.F);
+  const int n_begin = fs_rr ? (int)blockIdx.x : (int)blockIdx.x * fs_per + min((int)blockIdx.x, fs_extra);
+  const int n_end = fs_rr ? A.N : n_begin + fs_cnt, n_step = fs_rr ? (int)gridDim.x : FP;
   auto fetch = [&](int n0) {
-    const int fcur = min(A.F, A.N - n0);
+    const int fcur = min(FP, n_end - n0);
     if (c4) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -624,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
     }
   };
   auto commit = [&](int n0) {
-    const int fcur = min(A.F, A.N - n0);
+    const int fcur = min(FP, n_end - n0);
     vm_wait_all();
 #pragma unroll
     for (int u = 0; u < PF; ++u) vm_landed(pre[u]);
@@ -659,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
       for (int e = tot4 * 4 + tid; e < tot; e += 256) put(e, sp[e]);
     }
   };
-  int n0 = blockIdx.x * A.F;
+  int n0 = n_begin;
 #ifdef CONV_DEBUG
   long t_pro = 0, t_b1 = 0, t_commit = 0, t_b2 = 0, t_comp = 0, t_mark = __builtin_readcyclecounter();
   const long t_start = t_mark;
@@ -667,17 +714,17 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
 #else
 #define CG_STAMP(acc)
 #endif
-  if (n0 < A.N) fetch(n0);
+  if (n0 < n_end) fetch(n0);
   CG_STAMP(t_pro)
-  for (; n0 < A.N; n0 += gridDim.x * A.F) {
-    const int fcur = min(A.F, A.N - n0);
+  for (; n0 < n_end; n0 += n_step) {
+    const int fcur = min(FP, n_end - n0);
     __syncthreads();                                    // previous pass has finished reading the LDS (first pass: tables written)
     CG_STAMP(t_b1)
     commit(n0);
     CG_STAMP(t_commit)
     __syncthreads();
     CG_STAMP(t_b2)
-    if (n0 + gridDim.x * A.F < A.N) fetch(n0 + gridDim.x * A.F);      // in flight during the MFMAs below
+    if (n0 + n_step < n_end) fetch(n0 + n_step);      // in flight during the MFMAs below
     // ---- the staged frames' positions, 64 per wave tile ----
     const int Mtot = fcur * opf, mtiles = (Mtot + 63) >> 6;
     const unsigned pass_o = (unsigned)((long)n0 * pixf * Cd * 4);     // (destination maps stay below 2 GB: checked by the host)
@@ -829,8 +876,19 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   const int ppf = CH4 ? (A.H + st_rpp - 1) / st_rpp : 0;
   const unsigned m_ppf = fmagic_dev(ppf > 0 ? ppf : 1);
   const int per3 = A.H * A.W * Ci;
+  // Frames of this workgroup: an EVEN share [n_begin, n_end) of the N frames, walked in passes of FP <= F frames.  (Passes of F frames dealt
+  // round-robin left the busiest workgroup with ceil(passes / grid) * F frames: 4800 frames of a 9x9 map, F = 4, 512 workgroups = 12 frames
+  // against 9.4 on average -- the kernel ends with its slowest workgroup: profiles/r04_conv_deep_dissection.txt, max vs mean cycles.)
+  // (F = 1, the 36x36 maps: single frames dealt round-robin as before -- the same maximum, and neighbouring workgroups stream
+  // neighbouring frames: measured 3-4 % faster there than 512 separate ranges)
+  const int fs_per = A.N / (int)gridDim.x, fs_extra = A.N - fs_per * (int)gridDim.x;
+  const int fs_cnt = fs_per + ((int)blockIdx.x < fs_extra ? 1 : 0), fs_np = (fs_cnt + A.F - 1) / A.F;
+  const bool fs_rr = A.F == 1;
+  const int FP = fs_rr ? 1 : (fs_np > 0 ? (fs_cnt + fs_np - 1) / fs_np : A.F);
+  const int n_begin = fs_rr ? (int)blockIdx.x : (int)blockIdx.x * fs_per + min((int)blockIdx.x, fs_extra);
+  const int n_end = fs_rr ? A.N : n_begin + fs_cnt, n_step = fs_rr ? (int)gridDim.x : FP;
   auto fetch = [&](int n0) {
-    const int fcur = min(A.F, A.N - n0);
+    const int fcur = min(FP, n_end - n0);
     if (CH4) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -845,7 +903,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
     }
   };
   auto commit = [&](int n0) {
-    const int fcur = min(A.F, A.N - n0);
+    const int fcur = min(FP, n_end - n0);
     if (CH4) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -882,7 +940,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   const __amdgpu_buffer_rsrc_t dy_rs = make_rsrc(A.dy);
   const int cpf = (opf + 15) >> 4;                       // chunks per frame
   const unsigned m_cpf = fmagic_dev(cpf);
-  int n0 = blockIdx.x * A.F;
+  int n0 = n_begin;
 #ifdef CONV_DEBUG
   long w_b1 = 0, w_commit = 0, w_b2 = 0, w_comp = 0, w_mark = __builtin_readcyclecounter();
   const long w_start = w_mark;
@@ -890,9 +948,9 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
 #else
 #define WG_STAMP(acc)
 #endif
-  if (n0 < A.N) fetch(n0);
-  for (; n0 < A.N; n0 += gridDim.x * A.F) {
-    const int fcur = min(A.F, A.N - n0);
+  if (n0 < n_end) fetch(n0);
+  for (; n0 < n_end; n0 += n_step) {
+    const int fcur = min(FP, n_end - n0);
     __syncthreads();
     WG_STAMP(w_b1)
     commit(n0);
@@ -914,7 +972,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
     if (kc0 < kch) load_b(kc0, bn);
     __syncthreads();
     WG_STAMP(w_b2)
-    if (n0 + gridDim.x * A.F < A.N) fetch(n0 + gridDim.x * A.F);      // next pass's frames: in flight during the MFMAs
+    if (n0 + n_step < n_end) fetch(n0 + n_step);      // next pass's frames: in flight during the MFMAs
     for (int kc = kc0; kc < kch; kc += KCS) {
       float av[MT][4], bv[NTC][4];
 #pragma unroll
@@ -1057,16 +1115,16 @@ static int cg_launch_q4(CGArgs& A, hipStream_t s, int kind, double flops, bool d
   A.m_opf = fmagic(A.OA * A.OB); A.m_ob = fmagic(A.OB);
   const int opf = A.OA * A.OB;
   const size_t frame_b = sizeof(float) * (size_t)(A.SH + 2) * (A.SW + 2) * A.CsL;
-  auto lds_bytes = [&](int F) { return F * frame_b + 4 * ((((size_t)F * opf + 63) / 64) * 64); };
+  auto lds_bytes = [&](int F) { return F * frame_b + 4 * ((((size_t)F * opf + 63) / 64) * 64) + sizeof(CGTap) * CG_MAXTAP; };
   // frames per pass: (rounds of the busiest workgroup) x (64-position tiles of a pass per wave), as cg_launch
   double best = -1.0;
   int bestF = 0;
   for (int F = (Fcap < 16 ? Fcap : 16); F >= 1; --F) {
     if (lds_bytes(F) > 64 * 1024 || (long)F * frame_b / 4 >= (1 << 14) * 4 || (long)F * opf >= (1 << 24)) continue;
-    const long units = (A.N + F - 1) / F, full = units / 512, rem = units - full * 512;
-    const double rounds = (double)full + (rem ? 0.5 + 0.5 * (double)rem / 512 : 0.0);
-    const long tiles = ((long)F * opf + 63) / 64, per_wave = (tiles + 3) / 4;
-    const double cost = rounds * (double)(per_wave * 8 + 4);
+    const long units = (A.N + F - 1) / F, grid = units < 512 ? units : 512;
+    const long cnt = (A.N + grid - 1) / grid, np = (cnt + F - 1) / F, fp = (cnt + np - 1) / np;
+    const long tiles = (fp * opf + 63) / 64, per_wave = (tiles + 3) / 4;
+    const double cost = (double)np * (double)(per_wave * 8 + 4);
     if (best < 0.0 || cost < 0.97 * best) { best = cost; bestF = F; }
   }
   if (!bestF) return AVSR_ERR_UNSUPPORTED;
@@ -1109,7 +1167,7 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
   if (cg_q4_ok(A, A.ntap) && A.nsp == 1 && A.lin && cg_q4_taps_ok(A)) return cg_launch_q4(A, s, kind, flops, dry);
   const int KQ = A.ntap * (A.CsL / 4), nch = (KQ + 3) / 4;
   const int NT = (A.nsp * A.Cd + 15) / 16;
-  if (!(NT == 1 || NT == 2 || NT == 4) || nch > 18) return AVSR_ERR_UNSUPPORTED;
+  if (!(NT == 1 || NT == 2 || NT == 4) || nch > 20) return AVSR_ERR_UNSUPPORTED;
   if (A.Cs % 4 && nch > 5) return AVSR_ERR_UNSUPPORTED;
   // a pass (F frames) must fit the prefetch registers of a staging thread
   int Fcap = 16;
@@ -1132,21 +1190,21 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
   const size_t frame_b = sizeof(float) * (size_t)(A.SH + 2) * (A.SW + 2) * A.CsL;
   auto lds_bytes = [&](int F) {
     const size_t rows_pad = (((size_t)F * opf + 15) / 16) * 16;
-    return F * frame_b + 4 * rows_pad * 2;
+    return F * frame_b + 4 * rows_pad * 2 + sizeof(CGTap) * CG_MAXTAP;
   };
-  // Frames per pass: the kernel's time is (passes of the busiest workgroup) x (row tiles of a pass per wave); both are ceilings, and
-  // on the small maps their product swings by 30 % with F (4800 frames of 5x5 positions on 512 workgroups: F = 4 -> 3 rounds x 7
-  // tiles, F = 5 -> 2 rounds x 8 tiles).  Take the feasible F with the smallest product (ties: the larger F, fewer barriers).
+  // Frames per pass (upper bound F; a workgroup splits its even share of the frames into equal passes of FP <= F): the kernel's time is
+  // (passes of a workgroup) x (row tiles of a pass per wave + the pass's fixed part).  Take the feasible F with the smallest product
+  // (ties: the larger F, fewer barriers).
   auto pick = [&](size_t budget, int slots) {
     double best = -1.0;
     int bestF = 0;
     for (int F = (Fcap < 16 ? Fcap : 16); F >= 1; --F) {
       if (lds_bytes(F) > budget || (long)F * opf >= 65536) continue;
-      const long units = (A.N + F - 1) / F, full = units / slots, rem = units - full * slots;
-      // a partial last round runs on a half-empty chip: cheaper than a full one (measured on the 9x9 layers), not free
-      const double rounds = (double)full + (rem ? 0.5 + 0.5 * (double)rem / slots : 0.0);
-      const long tiles = ((long)F * opf + 15) / 16, per_wave = (tiles + mstep - 1) / mstep;
-      const double cost = rounds * (double)(per_wave * 8 + 16);     // (+ a pass's fixed part: staging, barriers, pipeline fill ~ two tiles)
+      // every workgroup walks an even share of the frames in passes of at most F (the kernel's FP)
+      const long units = (A.N + F - 1) / F, grid = units < slots ? units : slots;
+      const long cnt = (A.N + grid - 1) / grid, np = (cnt + F - 1) / F, fp = (cnt + np - 1) / np;
+      const long tiles = (fp * opf + 15) / 16, per_wave = (tiles + mstep - 1) / mstep;
+      const double cost = (double)np * (double)(per_wave * 8 + 16);     // (+ a pass's fixed part: staging, barriers, pipeline fill ~ two tiles)
       if (best < 0.0 || cost < 0.97 * best) { best = cost; bestF = F; }
     }
     return bestF;
@@ -1179,6 +1237,7 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
   else if (nch <= 6) { CG_GO(6, true) }
   else if (nch <= 9) { CG_GO(9, true) }
   else if (nch <= 18) { CG_GO(18, true) }
+  else if (nch <= 20) { CG_GO(20, true) }
   else return AVSR_ERR_UNSUPPORTED;                     // K > 288 (64-channel sources) stays on im2col + GEMM
 #undef CG_GO
 #undef CG_ONE
@@ -1369,9 +1428,10 @@ static bool cd_ok(const avsr_conv_desc* c) {
 // run the tap list in groups that fit the K chunks a wave holds; bias / beta on the first group, residual / statistics on the last
 static int cg_run(CGArgs A, const CGTap* taps, int ntaps, hipStream_t s, int kind, double flops_per_tap, bool dry, int* grid_out) {
   const int C4 = A.CsL / 4;
-  int G = (18 * 4) / C4;
-  if (G < 1) return AVSR_ERR_UNSUPPORTED;
+  int G = (20 * 4) / C4;                                 // (64-channel sources: 5 + 4 taps on the 20- and 18-chunk instantiations; 4 + 4 + 1
+  if (G < 1) return AVSR_ERR_UNSUPPORTED;                //  before, and the one-tap launch cost as much set-up and staging as the others)
   if (G > CG_MAXTAP) G = CG_MAXTAP;
+  { const int ng = (ntaps + G - 1) / G; G = (ntaps + ng - 1) / ng; }     // even groups
   const float* res = A.res; float* stats = A.stats; const float* bias = A.bias; const float beta = A.beta;
   const float* acc = A.acc; const float* bnb_x = A.bnb_x;
   int grid = 0;
@@ -1535,15 +1595,16 @@ static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const fl
   return AVSR_OK;
 }
 
-// frames per pass of the weight-gradient kernel: its time is (passes of the busiest workgroup) x (frames of a pass) -- chunks never span
+// frames per pass of the weight-gradient kernel (upper bound; even shares in equal passes as above): its time is (passes) x (frames of a pass) -- chunks never span
 // frames --, so among the feasible F the one with the smallest rounds * F wins (4800 frames on 512 workgroups: F = 4 -> 3 x 4, F = 2 or 5
 // -> 10); ties: the larger F
 static int wg_pick_frames(int N, int Fmax, int slots) {
   double best = -1.0;
   int bestF = Fmax;
   for (int F = Fmax; F >= 1; --F) {
-    const long units = (N + F - 1) / F, rounds = (units + slots - 1) / slots;    // (whole rounds: measured better here than a discounted tail)
-    const double cost = (double)rounds * (8.0 * F + 1.0);
+    const long units = (N + F - 1) / F, grid = units < slots ? units : slots;
+    const long cnt = (N + grid - 1) / grid, np = (cnt + F - 1) / F, fp = (cnt + np - 1) / np;      // (the kernel's even shares)
+    const double cost = (double)np * (8.0 * fp + 1.0);
     if (best < 0.0 || cost < best) { best = cost; bestF = F; }
   }
   return bestF;
