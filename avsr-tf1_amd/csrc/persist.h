@@ -82,6 +82,13 @@ __device__ __forceinline__ f32x4 ldb4(__amdgpu_buffer_rsrc_t r, int byte_off) {
 // (SIInsertWaitcnts "flush in preheader"), which serialises a register prefetch with the very loop it is meant to overlap; a hidden
 // load leaves the wait to the caller (vm_wait_all() before the first use of the destination).  The compiler's own waits stay safe:
 // vmcnt counts in order, so extra older operations can only make one of its waits longer, never shorter.
+// Limits (round 4, measured the hard way on a ring of prefetched operands in the weight-gradient kernel): the register allocator believes a
+// hidden load's destination holds its value from the asm statement on.  If it ever COPIES that value before the caller's wait -- a phi
+// copy at a loop's back edge, a move between register classes under pressure -- it copies the stale content, and when it then reuses the
+// old register (e.g. for an address) the landing load overwrites it: wrong operands, or a memory fault.  Use hidden loads only where the
+// destination is consumed by straight-line code behind one vm_wait_all() + vm_landed() (the convolution's frame prefetch: issued at the
+// bottom of a pass, committed at the top of the next, the same registers in every pass), never for values rotated through a ring across
+// iterations; tests/test_gpu_conv.py and the full-size property check in tests/test_gpu_bench.py run the users of this after every build.
 typedef int i32x4_ __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ i32x4_ make_rsrc_words(const void* p) {
   const unsigned long a = reinterpret_cast<unsigned long>(p);
