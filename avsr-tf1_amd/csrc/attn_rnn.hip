@@ -489,26 +489,27 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
   const size_t bh = sizeof(float) * B * H;
 
   if (l_begin == 0) {
-    // initial state -> ping-pong parity 0, cell_out slot 0 = h0, attention slot 0 = 0
-    if (d.h0) { if (avsr::dev_copy(hbuf(d, 0), d.h0, bh, s) != hipSuccess) return AVSR_ERR_HIP; }
-    else if (avsr::dev_zero(hbuf(d, 0), bh, s) != hipSuccess) return AVSR_ERR_HIP;
-    if (d.c0) { if (avsr::dev_copy(cbuf(d, 0), d.c0, bh, s) != hipSuccess) return AVSR_ERR_HIP; }
-    else if (avsr::dev_zero(cbuf(d, 0), bh, s) != hipSuccess) return AVSR_ERR_HIP;
-    if (avsr::dev_copy_2d(layer_out(d, 0), sizeof(float) * (L + 1) * H, hbuf(d, 0), sizeof(float) * H, sizeof(float) * H, B, s) != hipSuccess) return AVSR_ERR_HIP;
+    // initial state -> ping-pong parity 0, cell_out slot 0 = h0, attention slot 0 = 0: one launch (every operation reads the caller's
+    // h0 / c0 or writes zeros: none reads another's result)
+    avsr::DevBatch db(s);
+    const size_t hrow = sizeof(float) * H, orow = sizeof(float) * (L + 1) * H;
+    if (d.h0) { db.copy(hbuf(d, 0), d.h0, bh); db.copy_2d(layer_out(d, 0), orow, d.h0, hrow, hrow, B); }
+    else { db.zero(hbuf(d, 0), bh); db.zero_2d(layer_out(d, 0), orow, hrow, B); }
+    if (d.c0) db.copy(cbuf(d, 0), d.c0, bh);
+    else db.zero(cbuf(d, 0), bh);
     for (int j = 0; j < d.n_extra; ++j) {            // layers above start from the zero state (decoder_unimodal.py:151-157)
       const avsr_dec_layer& X = d.extra[j];
-      if (avsr::dev_zero(X.state, 4 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
-      if (avsr::dev_zero_2d(X.out, sizeof(float) * (L + 1) * H, sizeof(float) * H, B, s) != hipSuccess) return AVSR_ERR_HIP;
-      if (drop && X.hs_seq && avsr::dev_zero_2d(X.hs_seq, sizeof(float) * (L + 1) * H, sizeof(float) * H, B, s) != hipSuccess)
-        return AVSR_ERR_HIP;
+      db.zero(X.state, 4 * bh);
+      db.zero_2d(X.out, orow, hrow, B);
+      if (drop && X.hs_seq) db.zero_2d(X.hs_seq, orow, hrow, B);
     }
-    if (A > 0 && avsr::dev_zero_2d(d.att, sizeof(float) * (L + 1) * A, sizeof(float) * A, B, s) != hipSuccess)
-      return AVSR_ERR_HIP;
+    if (A > 0) db.zero_2d(d.att, sizeof(float) * (L + 1) * A, sizeof(float) * A, B);
     if (drop) {
-      if (avsr::dev_copy_2d(d.hs_seq, sizeof(float) * (L + 1) * H, hbuf(d, 0), sizeof(float) * H, sizeof(float) * H, B, s) != hipSuccess) return AVSR_ERR_HIP;
-      if (A > 0 && avsr::dev_zero_2d(d.attd, sizeof(float) * (L + 1) * A, sizeof(float) * A, B, s) != hipSuccess)
-        return AVSR_ERR_HIP;
+      if (d.h0) db.copy_2d(d.hs_seq, orow, d.h0, hrow, hrow, B);
+      else db.zero_2d(d.hs_seq, orow, hrow, B);
+      if (A > 0) db.zero_2d(d.attd, sizeof(float) * (L + 1) * A, sizeof(float) * A, B);
     }
+    if (db.flush() != hipSuccess) return AVSR_ERR_HIP;
   }
 
   static thread_local StepLaunch SL;
@@ -705,8 +706,10 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
     }
   }
   if (l_end == L) {
-    if (d.h_final && avsr::dev_copy(d.h_final, hbuf(d, L & 1), bh, s) != hipSuccess) return AVSR_ERR_HIP;
-    if (!gru && d.c_final && avsr::dev_copy(d.c_final, cbuf(d, L & 1), bh, s) != hipSuccess) return AVSR_ERR_HIP;
+    avsr::DevBatch db(s);
+    if (d.h_final) db.copy(d.h_final, hbuf(d, L & 1), bh);
+    if (!gru && d.c_final) db.copy(d.c_final, cbuf(d, L & 1), bh);
+    if (db.flush() != hipSuccess) return AVSR_ERR_HIP;
   }
   return AVSR_OK;
 }
@@ -741,15 +744,20 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
   if (use_dq && !d.dq) return AVSR_ERR_ARG;
   const size_t bh = sizeof(float) * B * H;
   const int NX = d.n_extra;
-  for (int j = 0; j < NX; ++j) {
-    if (!d.extra[j].w || !d.extra[j].dgates || !d.extra[j].dstate) return AVSR_ERR_ARG;
-    if (avsr::dev_zero(d.extra[j].dstate, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
-  }
   if (NX > 0 && (d.dh_final || d.dc_final)) return AVSR_ERR_UNSUPPORTED;     // final-state gradients: single-cell blocks only
-  if (avsr::dev_zero(d.dstate, 12 * bh, s) != hipSuccess) return AVSR_ERR_HIP;
-  if (!gru && d.dc_final && avsr::dev_copy(dcbuf(d, L & 1), d.dc_final, bh, s) != hipSuccess) return AVSR_ERR_HIP;
-  if (d.dh_final && avsr::dev_copy(gru ? g_carry(L & 1) : dhcarry(d, L & 1), d.dh_final, bh, s) != hipSuccess)
-    return AVSR_ERR_HIP;
+  {
+    avsr::DevBatch db(s);                            // the zeroed rolling state of every layer: one launch
+    for (int j = 0; j < NX; ++j) {
+      if (!d.extra[j].w || !d.extra[j].dgates || !d.extra[j].dstate) return AVSR_ERR_ARG;
+      db.zero(d.extra[j].dstate, 12 * bh);
+    }
+    db.zero(d.dstate, 12 * bh);
+    if (db.flush() != hipSuccess) return AVSR_ERR_HIP;
+    // ... then the final-state gradients into their slots of it (a second launch: they overwrite part of what the first zeroes)
+    if (!gru && d.dc_final) db.copy(dcbuf(d, L & 1), d.dc_final, bh);
+    if (d.dh_final) db.copy(gru ? g_carry(L & 1) : dhcarry(d, L & 1), d.dh_final, bh);
+    if (db.flush() != hipSuccess) return AVSR_ERR_HIP;
+  }
 
   static thread_local StepLaunch SL;
   static thread_local AttnLaunch AL;

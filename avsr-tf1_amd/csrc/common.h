@@ -117,4 +117,52 @@ static inline hipError_t dev_copy_2d(void* d, size_t dpitch, const void* src, si
   return hipGetLastError();
 }
 
+
+// Several independent fills / copies in ONE launch (the set-up of a decoder block was six 4-5 us launches in a row on the step's critical
+// chain).  The operations of a batch must not depend on each other; 2-D forms take byte pitches like dev_copy_2d.
+#define DEV_BATCH_MAX 12
+struct DevOp { uint32_t* d; const uint32_t* s; long dpitch, spitch, width, rows; };      // s == NULL: fill with zeros; all in words
+struct DevBatchArgs { int n; int blk0[DEV_BATCH_MAX + 1]; DevOp op[DEV_BATCH_MAX]; };
+__global__ static void k_dev_batch(const DevBatchArgs A) {
+  int j = 0;
+#pragma unroll 1
+  for (int k = 1; k < A.n; ++k) if ((int)blockIdx.x >= A.blk0[k]) j = k;
+  j = __builtin_amdgcn_readfirstlane(j);
+  uint32_t* const d = A.op[j].d; const uint32_t* const s = A.op[j].s;
+  const long dp = A.op[j].dpitch, sp = A.op[j].spitch, w = A.op[j].width, total = w * A.op[j].rows;
+  const long nb = A.blk0[j + 1] - A.blk0[j];
+  for (long i = (long)((int)blockIdx.x - A.blk0[j]) * blockDim.x + threadIdx.x; i < total; i += nb * blockDim.x) {
+    const long r = i / w, c = i - r * w;
+    d[r * dp + c] = s ? s[r * sp + c] : 0u;
+  }
+}
+struct DevBatch {
+  DevBatchArgs a;
+  hipStream_t st;
+  bool bad;
+  explicit DevBatch(hipStream_t s) : st(s), bad(false) { a.n = 0; a.blk0[0] = 0; }
+  hipError_t flush() {
+    if (bad) return hipErrorInvalidValue;
+    if (!a.n) return hipSuccess;
+    hipLaunchKernelGGL(k_dev_batch, dim3(a.blk0[a.n]), dim3(256), 0, st, a);
+    a.n = 0; a.blk0[0] = 0;
+    return hipGetLastError();
+  }
+  void add(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t rows) {
+    if (!width || !rows) return;
+    if (dpitch % 4 || spitch % 4 || width % 4 || !d) { bad = true; return; }
+    if (a.n == DEV_BATCH_MAX && flush() != hipSuccess) { bad = true; return; }
+    DevOp& o = a.op[a.n];
+    o.d = (uint32_t*)d; o.s = (const uint32_t*)s; o.dpitch = (long)(dpitch / 4); o.spitch = (long)(spitch / 4); o.width = (long)(width / 4); o.rows = (long)rows;
+    int nb = k_blocks(o.width * o.rows);
+    if (nb > 256) nb = 256;
+    a.blk0[a.n + 1] = a.blk0[a.n] + nb;
+    ++a.n;
+  }
+  void zero(void* p, size_t bytes) { add(p, bytes, nullptr, 0, bytes, 1); }
+  void copy(void* d, const void* s, size_t bytes) { if (!s) bad = true; else add(d, bytes, s, bytes, bytes, 1); }
+  void zero_2d(void* p, size_t pitch, size_t width, size_t rows) { add(p, pitch, nullptr, 0, width, rows); }
+  void copy_2d(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t rows) { if (!s) bad = true; else add(d, dpitch, s, spitch, width, rows); }
+};
+
 }  // namespace avsr
