@@ -35,7 +35,8 @@ class GemmDesc(C.Structure):
                 ("stride_a", C.c_int64), ("stride_b", C.c_int64), ("stride_c", C.c_int64),
                 ("alpha_dev", C.c_void_p),
                 ("splitk", C.c_int32), ("pad_", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64)]
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
+                ("colsum", C.c_void_p), ("colsum_beta", C.c_float), ("pad2_", C.c_int32)]
 
 
 class RnnLayer(C.Structure):

@@ -47,6 +47,7 @@ struct GemmArgs {
   float* ws;            // split-K partials [splitk][M][N]
   long sA, sB, sC;      // batch strides (floats)
   int batch;
+  float* cs_out; float cs_beta; float* cs_ws;     // column sums of B (bias gradient): output, its beta, split-K partials [splitk][N]
 };
 
 // Operand loader.  One thread fetches two 16-byte pieces of each operand per K tile into registers; the LDS image is
@@ -169,8 +170,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
   lb.load(kbeg, kend, rb[0]);
   la.load(kbeg + BK, kend, ra[1]);
   lb.load(kbeg + BK, kend, rb[1]);
+  // column sums of B (g.cs_out; B stored [K][N] only): a thread's pieces of every K tile are the same four columns, summed as the tiles
+  // are committed to LDS (out-of-range pieces are zeros); the first row tile's workgroups own the sums
+  const bool do_cs = !BKC && g.cs_out != nullptr && by == 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   store_tile<AKC>(lds[0][0], ra[0]);
   store_tile<BKC>(lds[0][1], rb[0]);
+  if (do_cs) csum += rb[0][0] + rb[0][1];
   __syncthreads();
 
   auto ktile = [&](int k0, int buf, f32x4 (&ra_next)[2], f32x4 (&rb_next)[2], f32x4 (&ra_free)[2], f32x4 (&rb_free)[2]) {
@@ -193,6 +199,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     }
     store_tile<AKC>(lds[buf ^ 1][0], ra_next);
     store_tile<BKC>(lds[buf ^ 1][1], rb_next);
+    if (do_cs) csum += rb_next[0] + rb_next[1];
     // LDS-only barrier: __syncthreads() also drains vmcnt, i.e. it would wait for the tiles still in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
@@ -201,6 +208,22 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int bx, const
     if (k0 + BK < kend) ktile(k0 + BK, 1, ra[0], rb[0], ra[1], rb[1]);
   }
 
+  if (!BKC && g.cs_out != nullptr) {                  // (uniform per workgroup; the LDS tiles are free: every K tile ends with a barrier)
+    float* red = &lds[0][0][0];                       // [8 k rows of the staging layout][128 columns]
+    if (do_cs) st4(red + (tid >> 5) * BN + 4 * (tid & 31), csum);
+    __syncthreads();
+    if (do_cs && tid < BN) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v += red[r * BN + tid];
+      const int col = n0 + tid;
+      if (col < g.N) {
+        if (g.splitk > 1) g.cs_ws[(long)z * g.N + col] = v;
+        else g.cs_out[col] = g.cs_beta != 0.f ? v + g.cs_beta * g.cs_out[col] : v;
+      }
+    }
+    __syncthreads();
+  }
   // epilogue: C/D layout of mfma 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   // Per 32x32 tile: the 16 destination addresses of the lane first (the two-level row address by an exact multiply-high division for
   // row counts below 2^16), then -- beta != 0 -- its 16 old values with all loads in flight together, then the 16 stores.  (The
@@ -296,6 +319,21 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_group_kernel(const GemmGroup 
 
 __device__ __forceinline__ void splitk_reduce_body(const GemmArgs& g, const long first, const long stride) {
   const long total = (long)g.batch * g.M * g.N;
+  if (g.cs_out) {                                     // the column sums' split-K partials (batch == 1)
+    for (long col = first; col < g.N; col += stride) {
+      float v = 0.f;
+      int zz = 0;
+      for (; zz + 8 <= g.splitk; zz += 8) {             // eight slices in flight (one at a time was a chain of ~48 memory round trips)
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = g.cs_ws[(long)(zz + u) * g.N + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += w[u];
+      }
+      for (; zz < g.splitk; ++zz) v += g.cs_ws[(long)zz * g.N + col];
+      g.cs_out[col] = g.cs_beta != 0.f ? v + g.cs_beta * g.cs_out[col] : v;
+    }
+  }
   // four consecutive columns per thread with 16-byte loads, eight slices in flight (the K = 32000 weight gradients are reduced from
   // ~48 one-megabyte slabs each: scalar loads, four in flight, ran at 1.5 TB/s).  Every element keeps its summation order.
   const bool vec = (g.N & 3) == 0 && ((uintptr_t)g.ws & 15) == 0 && ((uintptr_t)g.C & 15) == 0 && (g.ldc & 3) == 0 && (g.sC & 3) == 0 &&
@@ -390,6 +428,14 @@ static int gemm_prepare(const avsr_gemm_desc* d, avsr::GemmArgs& g, dim3* grid, 
   splitk = (g.K + kper - 1) / kper;
   if (splitk < 1) splitk = 1;
   g.splitk = splitk; g.kper = kper; g.ws = d->workspace;
+  g.cs_out = d->colsum; g.cs_beta = d->colsum_beta; g.cs_ws = nullptr;
+  if (g.cs_out) {
+    if (g.tb || g.batch != 1) return AVSR_ERR_UNSUPPORTED;
+    if (splitk > 1) {
+      if (d->workspace_floats < (long)splitk * g.M * g.N + (long)splitk * g.N) return AVSR_ERR_ARG;
+      g.cs_ws = d->workspace + (long)splitk * g.M * g.N;
+    }
+  }
   const bool va = vec_ok(&d->A, g.ta == 0, g.M, g.K);
   const bool vb = vec_ok(&d->B, g.tb != 0, g.N, g.K);
   *grid = dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch * splitk);

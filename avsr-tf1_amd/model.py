@@ -904,12 +904,14 @@ class Seq2SeqModel:
                         a_x = E["layers"][(d, l - 1)]["xt_seq"].mat(0)
                     else:
                         a_x = E["layers"][(d, l - 1)]["out"].mat(0, E["layers"][(d, l - 1)]["col"])
+                    nct = (G * u + 127) // 128
+                    gt = (((i + 127) // 128) + ((u + 127) // 128)) * nct if not self.gru else None     # tiles of the launch below
                     with ops.gemm_group():       # the row blocks of one layer's kernel gradient(s): independent, one launch
-                        self._gemm_tn(a_x, dg, Gk.mat(G * u), i, G * u, B * T)
+                        self._gemm_tn(a_x, dg, Gk.mat(G * u), i, G * u, B * T, group_tiles=gt)
                         sh = 1 if d == "bw" else -1
                         a_h = Ld["hs_seq"].mat(sh) if (drop or (cfg.residual(s) and l > 0)) else Ld["out"].mat(sh, Ld["col"])
-                        self._gemm_tn(a_h, dg, Gk.mat(G * u, row0=i), u, G * u, B * T)
-                        ops.colsum(dg, B * T, G * u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
+                        # (the bias gradient = column sums of d gates rides in this launch: the tiles of dg pass through it anyway)
+                        self._gemm_tn(a_h, dg, Gk.mat(G * u, row0=i), u, G * u, B * T, colsum=(self.grads, self.Gr[bname].off), group_tiles=gt)
                         if self.gru:                 # candidate kernel: inputs [x ; r*h]
                             Gc = self.Gr[f"{s}/enc/{d}/l{cfg.shared_layer(s, l)}/cand_kernel"]
                             dpc = ops.mat(Ld["dpc"], u)
@@ -964,12 +966,18 @@ class Seq2SeqModel:
             self.gemm_ws = torch.empty(48 << 20, device=self.dev)
         ops.set_gemm_workspace(self.gemm_ws)
 
-    def _gemm_tn(self, A, Bm, Cm, M, N, K, beta=1.0):
-        """C (+)= A^T B with K = number of (b,t) rows: split-K so the small M x N output still fills the chip."""
+    def _gemm_tn(self, A, Bm, Cm, M, N, K, beta=1.0, colsum=None, group_tiles=None):
+        """C (+)= A^T B with K = number of (b,t) rows: split-K so the small M x N output still fills the chip.
+        colsum=(tensor, offset): the column sums of B (the layer's bias gradient) are accumulated there by the same launch.
+        group_tiles: 128 x 128 output tiles of ALL the GEMMs this one shares a grouped launch with (itself included): the K split is
+        then chosen for the launch, not the GEMM -- two 256 x 1024 x 32000 gradients split 48 ways each are 1536 workgroups = two uneven
+        rounds of the chip's 768 slots (361 us measured); split 24 ways they are one round (294 us)."""
         sk = _splitk(M, N, K)
-        while sk > 1 and sk * M * N > self.gemm_ws.numel():
+        if group_tiles and K >= 16384:
+            sk = max(2, min(768 // int(group_tiles), K // 256))
+        while sk > 1 and sk * (M * N + (N if colsum is not None else 0)) > self.gemm_ws.numel():
             sk //= 2
-        ops.gemm(A, Bm, Cm, M, N, K, trans_a=1, beta=beta, splitk=sk, workspace=self.gemm_ws)
+        ops.gemm(A, Bm, Cm, M, N, K, trans_a=1, beta=beta, splitk=sk, workspace=self.gemm_ws, colsum=colsum, colsum_beta=1.0)
 
     # ------------------------------------------------------------------------------------------------
     # attention-wrapped LSTM block (decoder, AV-Align top layer)

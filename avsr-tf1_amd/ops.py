@@ -87,9 +87,10 @@ _GROUP_ON = _os.environ.get("AVSR_GEMM_GROUP", "1") != "0"
 
 
 def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None,
-         batch=1, strides=(0, 0, 0), splitk=None, workspace=None, alpha_dev=None):
+         batch=1, strides=(0, 0, 0), splitk=None, workspace=None, alpha_dev=None, colsum=None, colsum_beta=0.0):
     """C = alpha*op(A)*op(B) + beta*C + bias.  A, B, Cm are `Mat` views (see `mat`).
-    splitk=None picks the factor (auto_splitk) when a workspace is available, else 1."""
+    splitk=None picks the factor (auto_splitk) when a workspace is available, else 1.
+    colsum=(tensor, offset): also tensor[offset + n] = colsum_beta * tensor[offset + n] + sum_k B[k, n] (trans_b False, batch 1)."""
     d = GemmDesc()
     d.A, d.B, d.C = A, B, Cm
     d.bias = fptr(bias)
@@ -99,15 +100,20 @@ def gemm(A, B, Cm, M, N, K, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, b
     d.batch = int(batch)
     d.stride_a, d.stride_b, d.stride_c = [int(s) for s in strides]
     d.alpha_dev = fptr(alpha_dev)
+    cs_extra = 0
+    if colsum is not None:
+        assert not trans_b and batch == 1
+        d.colsum, d.colsum_beta = fptr(colsum[0], colsum[1]), float(colsum_beta)
+        cs_extra = N
     if splitk is None:
         workspace = workspace if workspace is not None else _gemm_ws
         splitk = auto_splitk(M, N, K, batch) if workspace is not None else 1
-        while splitk > 1 and batch * splitk * M * N > workspace.numel():
+        while splitk > 1 and batch * splitk * (M * N + cs_extra) > workspace.numel():
             splitk //= 2
     d.splitk = int(splitk)
     grp = _gemm_group
     if splitk > 1:
-        need = batch * splitk * M * N
+        need = batch * splitk * (M * N + cs_extra)
         assert workspace is not None and workspace.numel() >= need, "split-K workspace too small"
         if grp is not None:
             # concurrent entries need disjoint slabs: carve consecutive regions; when the workspace is used up the collected

@@ -76,6 +76,12 @@ typedef struct avsr_gemm_desc {
   int32_t pad_;
   float* workspace;
   int64_t workspace_floats;
+  /* optional: colsum[n] = colsum_beta * colsum[n] + sum_k op(B)[k][n], taken from the B tiles while they pass through the kernel (the bias
+   * gradient of a layer whose weight gradient this GEMM is: seq2seq.py:222 -- the same d gates, one pass less over them).  trans_b == 0
+   * and batch == 1 only; with split-K the workspace must hold splitk * N more floats. */
+  float* colsum;
+  float colsum_beta;
+  int32_t pad2_;
 } avsr_gemm_desc;
 
 int avsr_gemm(const avsr_gemm_desc* d, void* stream);

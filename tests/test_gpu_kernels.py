@@ -59,6 +59,42 @@ def test_gemm_splitk_and_two_level_rows():
     assert np.abs(y.cpu().numpy() - yr).max() < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K,splitk,ta", [(256, 1024, 3000, None, 1), (80, 1024, 777, 4, 1), (40, 136, 50, 1, 1), (300, 260, 1000, 6, 0),
+                                             (20, 48, 111, 8, 1)])
+def test_gemm_with_column_sums_of_b(M, N, K, splitk, ta):
+    """avsr_gemm_desc.colsum: the bias gradient (column sums of d gates) taken from the B tiles of the weight-gradient GEMM, with and
+    without split-K, several row tiles (only the first owns the sums), ragged N and K, accumulating onto the destination; alone and
+    as an entry of a grouped launch."""
+    from avsr_tf1_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    c0 = rng.standard_normal(N).astype(np.float32)
+    ref = (A.T if ta else A).astype(np.float64) @ B.astype(np.float64)
+    cref = B.astype(np.float64).sum(0) + c0
+    a, b = dev(A), dev(B)
+    ws = torch.empty(1 << 22, device="cuda")
+    for grouped in (False, True):
+        c = torch.zeros(M, N, device="cuda")
+        buf = torch.zeros(7 + N, device="cuda")
+        buf[7:] = dev(c0)
+        if grouped:
+            other = torch.zeros(M, N, device="cuda")
+            with ops.gemm_group():
+                ops.gemm(ops.mat(a, A.shape[1]), ops.mat(b, N), ops.mat(other, N), M, N, K, trans_a=ta, splitk=splitk, workspace=ws)
+                ops.gemm(ops.mat(a, A.shape[1]), ops.mat(b, N), ops.mat(c, N), M, N, K, trans_a=ta, splitk=splitk, workspace=ws,
+                         colsum=(buf, 7), colsum_beta=1.0)
+        else:
+            ops.gemm(ops.mat(a, A.shape[1]), ops.mat(b, N), ops.mat(c, N), M, N, K, trans_a=ta, splitk=splitk, workspace=ws,
+                     colsum=(buf, 7), colsum_beta=1.0)
+        torch.cuda.synchronize()
+        assert np.abs(c.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+        assert np.abs(buf[7:].cpu().numpy() - cref).max() < 1e-4 * max(1.0, np.abs(cref).max()), grouped
+        assert (buf[:7] == 0).all()
+        if grouped:
+            assert np.abs(other.cpu().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
 def test_gemm_batched():
     from avsr_tf1_amd import ops
     rng = np.random.default_rng(9)
