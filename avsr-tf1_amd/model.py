@@ -126,6 +126,7 @@ class Seq2SeqModel:
         self.grads_and_loss = z(max(nt, 4) + 4 + max(ns, 4))
         self.grads = self.grads_and_loss[:max(nt, 4)]
         self.stats = z(ns)
+        self._redo_pass, self._stats_sink = False, None
         self.n_stats, self._stats_mirror_off = ns, max(nt, 4) + 4
         self.dp_world = 1                         # set by DataParallelTrainer
         self.n_train = nt
@@ -820,8 +821,29 @@ class Seq2SeqModel:
         return r.t[r.off:r.off + r.n]
 
     def _sp(self, name):
+        """The non-trainable buffer `name` (batch-norm moving statistics) as the kernels update it.  While a flagged pass is being REDONE
+        (redoing()) the updates go to a scratch copy: every batch norm sits upstream of the persistent kernels, so the flagged pass
+        has already applied this step's (valid) update, and a second one would move the averages twice in one step."""
         r = self.S[name]
+        if self._redo_pass:
+            if self._stats_sink is None:
+                self._stats_sink = torch.empty_like(self.stats)
+            ops.copy_(self._stats_sink[r.off:r.off + r.n], r.t[r.off:r.off + r.n])      # (the kernels read the old value to blend it)
+            return self._stats_sink[r.off:r.off + r.n]
         return r.t[r.off:r.off + r.n]
+
+    def redoing(self):
+        """Context of a pass that repeats one whose persistent kernels flagged (trainer / decode redo paths): see _sp."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            self._redo_pass = True
+            try:
+                yield
+            finally:
+                self._redo_pass = False
+        return ctx()
 
     def _final_state_fwd(self, ws, s):
         """uni: last layer's (c, h) (decoder_unimodal.py:144-145); bi: Dense on concat fw|bw (encoder.py:133-138)."""

@@ -316,7 +316,8 @@ class DataParallelTrainer:
             if self._pending is not None:
                 self._pending.wait()
                 self._pending = None
-            self._fwd_bwd_collective(st) if self.collective else self._fwd_bwd(st)
+            with self._redoing():
+                self._fwd_bwd_collective(st) if self.collective else self._fwd_bwd(st)
         if self.collective:
             if self.drain_around_collectives:          # the gradient all-reduce is a large eager kernel between two graph launches
                 self._drain()
@@ -341,10 +342,17 @@ class DataParallelTrainer:
             if self._pending is not None:                # the bucket reduced an invalid pass: finish it, then redo everything
                 self._pending.wait()
                 self._pending = None
-            self._fwd_bwd_collective(batch) if self.collective else self._fwd_bwd(batch)
+            with self._redoing():
+                self._fwd_bwd_collective(batch) if self.collective else self._fwd_bwd(batch)
         if self.collective:
             self._reduce_grads()
             self._reduce_loss()
+
+    def _redoing(self):
+        """The pass being repeated has already moved the batch-norm averages once (model.redoing): the repeat must not move them again."""
+        import contextlib
+        ctx = getattr(self.model, "redoing", None)
+        return ctx() if ctx else contextlib.nullcontext()
 
     def _drop_graphs(self):
         unpin = getattr(self.model, "unpin_workspace", None)

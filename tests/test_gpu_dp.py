@@ -256,3 +256,35 @@ def test_avsr_train_two_ranks_equals_one_rank_on_the_whole_data(tmp_path, monkey
     for k, v in ref.items():
         assert np.array_equal(r0[k], r1[k]), k                       # replicas stay bit-identical
         assert np.abs(r0[k] - v).max() < 2e-5 + 2e-3 * np.abs(v).max(), (k, np.abs(r0[k] - v).max(), np.abs(v).max())
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_a_redone_pass_moves_the_batch_norm_averages_once(use_graph, monkeypatch):
+    """A pass whose persistent kernels flagged is repeated by the trainer (parallel.py).  Every batch norm sits upstream of those kernels,
+    so the flagged pass has already blended this step's statistics into the moving averages; the repeat must not blend them again
+    (found as a 1-in-6 failure of the two-rank contention test above: moving_mean off by (1 - 0.99^5) / (1 - 0.99^4)).  Forced here:
+    check_persistent reports a flag on the second step (without switching anything off), so the repeat is the same computation and the
+    result must equal the undisturbed run bit for bit."""
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    from avsr_tf1_amd.parallel import DataParallelTrainer
+    monkeypatch.setenv("AVSR_PERSISTENT_RNN", "0")
+    O, mcfg, W, full = _setup(False)
+    batch = Batch.from_numpy(full)
+    outs = []
+    for force in (False, True):
+        model = Seq2SeqModel(mcfg, weights=W)
+        trainer = DataParallelTrainer(model, None, use_graph=use_graph)
+        calls = {"n": 0}
+        if force:
+            def flagged(disable=True, force=False, _c=calls):
+                _c["n"] += 1
+                return _c["n"] == 2
+            monkeypatch.setattr(model, "check_persistent", flagged)
+        for _ in range(STEPS):
+            trainer.train_step(batch)
+        torch.cuda.synchronize()
+        if force:
+            assert calls["n"] >= 2
+        outs.append(model.export_tf_weights("params"))
+    for k, v in outs[0].items():
+        assert np.array_equal(outs[1][k], v), k
