@@ -199,6 +199,15 @@ class LipCNN:
         for t, dst in self.alias.items():
             self.gmaps[t] = self.gmaps[dst]
         self.dcol = torch.empty(max_col, device=dev)              # d col of the layer being differentiated (transient)
+        # Weight-gradient slabs: every MFMA convolution gets its own region, so that the twelve final reductions of a backward pass can
+        # run as ONE launch at its end (ops.slab_defer_begin / _end) instead of one 5 us launch behind every convolution.
+        self.wg_off, off = {}, 0
+        for op in self.ops:
+            if op[0] == "conv" and op[1] in self.mfma:
+                _, name, _src, _dst, k, _s, cin, cout = op
+                self.wg_off[name] = off
+                off += 512 * max(k * k * cin * cout + cout, 12 * cin * 16 + 16)
+        self.wg_scratch = torch.empty(max(off, 4), device=dev)
 
     # parameters live in the model's flat buffers
     def _p(self, n):
@@ -316,96 +325,100 @@ class LipCNN:
         self._copy(dfeat, gout)
         written.add("out")
         self.bnb_rows, self.acc_src = {}, {}
-        for op in reversed(self.ops):
-            kind = op[0]
-            if kind == "flatten":
-                _, name, src, dst, kh, kw, cin, cout = op
-                K = kh * kw * cin
-                dpre = self.pre_act                                           # overwritten in place: d(pre-activation)
-                ops.relu_bwd(self.maps[dst], self.gmaps[dst], dpre, N * cout)
-                m._gemm_tn(ops.mat(self.maps[src], K), ops.mat(dpre, cout), self._g(name + "/kernel").mat(cout), K, cout, N)
-                ops.colsum(ops.mat(dpre, cout), N, cout, m.grads, m.scratch, beta=1.0, out_offset=self._g(name + "/bias").off)
-                g, beta = target(src)
-                ops.gemm(ops.mat(dpre, cout), self._p(name + "/kernel").mat(cout), ops.mat(g, K), N, K, cout, trans_b=1, beta=beta)
-            elif kind == "add":
-                _, name, a, b, dst = op
-                for t in (a, b):
-                    if t in self.alias:                                        # same buffer as the add's output gradient
-                        written.add(t)
-                        continue
-                    if t in self.acc_ok and t not in written and t in self.lazy:
-                        # first of two contributions, the second being a fused data gradient: it reads this one in place
-                        written.add(t)
-                        self.acc_src[t] = self.gmaps[dst]
-                        continue
-                    g, beta = target(t)
-                    if beta:
-                        ops.add(g, self.gmaps[dst], g, g.numel())
-                    else:
-                        self._copy(self.gmaps[dst], g)
-            elif kind == "bnrelu":
-                _, name, src, dst, c = op
-                h, w, _ = self.shapes[src]
-                mean, invstd = self.bn[name][:2]
-                g, beta = target(src)
-                gg, gb = self._g(name + "/gamma"), self._g(name + "/beta")
-                if name in self.bnb_rows:            # stage 1 ran in the producing data gradient's epilogue: gmaps[dst] holds dz
-                    ops.bn_bwd_finalize(self.bnb_stat[name], self.bnb_rows.pop(name), c, N * h * w, mean, invstd, self._pv(name + "/gamma"),
-                                        gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c], self.bnb_k[name], grad_beta=0.0)
-                    ops.bn_bwd_apply(self.gmaps[dst], self.maps[src], self.bnb_k[name], g, N * h * w, c, beta=beta)
-                    continue
-                ops.batchnorm_bwd(self.maps[src], self.gmaps[dst], self._pv(name + "/gamma"), self._pv(name + "/beta"), mean, invstd, g,
-                                  gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c], N * h * w, c, 1, m.scratch, dx_beta=beta)
-            else:
-                _, name, src, dst, k, s, cin, cout = op
-                h, w, _ = self.shapes[src]
-                ho, pt = same_pad(h, k, s)
-                wo, pl = same_pad(w, k, s)
-                rows, K = N * ho * wo, k * k * cin
-                dy = ops.mat(self.gmaps[dst], cout)
-                gk, kw_, gb = self._g(name + "/kernel"), self._p(name + "/kernel"), self._g(name + "/bias")
-                if name in self.mfma:
-                    x, bn = self._src(src)
-                    d = ops.conv_desc(*self.mfma[name], bn=bn)
-                    ops.conv_bwd_weight(d, x, self.gmaps[dst], gk.t[gk.off:], gb.t[gb.off:], m.scratch)
-                    fused_bn = self.bnb_conv.get(name)
-                    if src != "in" and fused_bn is not None and src in self.lazy:
-                        g, beta = target(src)
-                        pre, sc, sh = self.lazy[src]
-                        self.bnb_rows[fused_bn] = ops.conv_bwd_data_bn(d, self.gmaps[dst], kw_.t[kw_.off:], g, beta=beta,
-                                                                       acc=self.acc_src.pop(src, None), bn_x=self.maps[pre], bn=(sc, sh),
-                                                                       stats=self.bnb_stat[fused_bn])
-                    elif src != "in":
-                        def data_grad(d=d, src=src, dst=dst, kw_=kw_):
-                            g, beta = target(src)
-                            ops.conv_bwd_data(d, self.gmaps[dst], kw_.t[kw_.off:], g, beta=beta)
-                        if k == 1 and s == 2 and src not in written:          # reaches only the even pixels: must accumulate
-                            deferred.append((src, data_grad))
+        ops.slab_defer_begin()
+        try:
+            for op in reversed(self.ops):
+                kind = op[0]
+                if kind == "flatten":
+                    _, name, src, dst, kh, kw, cin, cout = op
+                    K = kh * kw * cin
+                    dpre = self.pre_act                                           # overwritten in place: d(pre-activation)
+                    ops.relu_bwd(self.maps[dst], self.gmaps[dst], dpre, N * cout)
+                    m._gemm_tn(ops.mat(self.maps[src], K), ops.mat(dpre, cout), self._g(name + "/kernel").mat(cout), K, cout, N)
+                    ops.colsum(ops.mat(dpre, cout), N, cout, m.grads, m.scratch, beta=1.0, out_offset=self._g(name + "/bias").off)
+                    g, beta = target(src)
+                    ops.gemm(ops.mat(dpre, cout), self._p(name + "/kernel").mat(cout), ops.mat(g, K), N, K, cout, trans_b=1, beta=beta)
+                elif kind == "add":
+                    _, name, a, b, dst = op
+                    for t in (a, b):
+                        if t in self.alias:                                        # same buffer as the add's output gradient
+                            written.add(t)
+                            continue
+                        if t in self.acc_ok and t not in written and t in self.lazy:
+                            # first of two contributions, the second being a fused data gradient: it reads this one in place
+                            written.add(t)
+                            self.acc_src[t] = self.gmaps[dst]
+                            continue
+                        g, beta = target(t)
+                        if beta:
+                            ops.add(g, self.gmaps[dst], g, g.numel())
                         else:
-                            data_grad()
-                elif name in self.direct:
-                    ops.conv3x3_bwd_weight(self.maps[src], self.gmaps[dst], gk.t[gk.off:], N, h, w, cin, cout, s, pt, pl, ho, wo, m.scratch)
-                    ops.colsum(dy, rows, cout, m.grads, m.scratch, beta=1.0, out_offset=gb.off)
-                    if src != "in":
-                        g, beta = target(src)
-                        if s == 1:       # the same kernel on dy with the kernel flipped and transposed
-                            ops.conv3x3(self.gmaps[dst], kw_.t[kw_.off:], None, g, N, ho, wo, cout, cin, 1, 1, 1, h, w, flip=1, beta=beta)
-                        else:
-                            ops.conv3x3_bwd_data_s2(self.gmaps[dst], kw_.t[kw_.off:], g, N, h, w, cin, cout, pt, pl, ho, wo, beta=beta)
+                            self._copy(self.gmaps[dst], g)
+                elif kind == "bnrelu":
+                    _, name, src, dst, c = op
+                    h, w, _ = self.shapes[src]
+                    mean, invstd = self.bn[name][:2]
+                    g, beta = target(src)
+                    gg, gb = self._g(name + "/gamma"), self._g(name + "/beta")
+                    if name in self.bnb_rows:            # stage 1 ran in the producing data gradient's epilogue: gmaps[dst] holds dz
+                        ops.bn_bwd_finalize(self.bnb_stat[name], self.bnb_rows.pop(name), c, N * h * w, mean, invstd, self._pv(name + "/gamma"),
+                                            gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c], self.bnb_k[name], grad_beta=0.0)
+                        ops.bn_bwd_apply(self.gmaps[dst], self.maps[src], self.bnb_k[name], g, N * h * w, c, beta=beta)
+                        continue
+                    ops.batchnorm_bwd(self.maps[src], self.gmaps[dst], self._pv(name + "/gamma"), self._pv(name + "/beta"), mean, invstd, g,
+                                      gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c], N * h * w, c, 1, m.scratch, dx_beta=beta)
                 else:
-                    m._gemm_tn(ops.mat(self.col[name], K), dy, gk.mat(cout), K, cout, rows)
-                    ops.colsum(dy, rows, cout, m.grads, m.scratch, beta=1.0, out_offset=gb.off)
-                    if src != "in":                                                # pixels are data: no gradient needed
-                        dcol = self.dcol[:rows * K]
-                        ops.gemm(dy, kw_.mat(cout), ops.mat(dcol, K), rows, K, cout, trans_b=1)
-                        g, beta = target(src)
-                        ops.col2im(dcol, g, N, h, w, cin, k, k, s, pt, pl, ho, wo, beta=beta)
-            for item in list(deferred):
-                if item[0] in written:
-                    deferred.remove(item)
-                    item[1]()
-        # A deferred 1x1/2 data gradient waits for another contribution to its map.  In resnet_cnn every such map is also read by the
-        # block's first batch norm, whose backward writes it -- and that backward is what the map's PRODUCER then consumes.  A layout
-        # in which the strided shortcut were the map's only reader would reach this point with the producer's backward already run on
-        # an unwritten gradient map: refuse it instead of flushing too late.
+                    _, name, src, dst, k, s, cin, cout = op
+                    h, w, _ = self.shapes[src]
+                    ho, pt = same_pad(h, k, s)
+                    wo, pl = same_pad(w, k, s)
+                    rows, K = N * ho * wo, k * k * cin
+                    dy = ops.mat(self.gmaps[dst], cout)
+                    gk, kw_, gb = self._g(name + "/kernel"), self._p(name + "/kernel"), self._g(name + "/bias")
+                    if name in self.mfma:
+                        x, bn = self._src(src)
+                        d = ops.conv_desc(*self.mfma[name], bn=bn)
+                        ops.conv_bwd_weight(d, x, self.gmaps[dst], gk.t[gk.off:], gb.t[gb.off:], self.wg_scratch[self.wg_off[name]:])
+                        fused_bn = self.bnb_conv.get(name)
+                        if src != "in" and fused_bn is not None and src in self.lazy:
+                            g, beta = target(src)
+                            pre, sc, sh = self.lazy[src]
+                            self.bnb_rows[fused_bn] = ops.conv_bwd_data_bn(d, self.gmaps[dst], kw_.t[kw_.off:], g, beta=beta,
+                                                                           acc=self.acc_src.pop(src, None), bn_x=self.maps[pre], bn=(sc, sh),
+                                                                           stats=self.bnb_stat[fused_bn])
+                        elif src != "in":
+                            def data_grad(d=d, src=src, dst=dst, kw_=kw_):
+                                g, beta = target(src)
+                                ops.conv_bwd_data(d, self.gmaps[dst], kw_.t[kw_.off:], g, beta=beta)
+                            if k == 1 and s == 2 and src not in written:          # reaches only the even pixels: must accumulate
+                                deferred.append((src, data_grad))
+                            else:
+                                data_grad()
+                    elif name in self.direct:
+                        ops.conv3x3_bwd_weight(self.maps[src], self.gmaps[dst], gk.t[gk.off:], N, h, w, cin, cout, s, pt, pl, ho, wo, m.scratch)
+                        ops.colsum(dy, rows, cout, m.grads, m.scratch, beta=1.0, out_offset=gb.off)
+                        if src != "in":
+                            g, beta = target(src)
+                            if s == 1:       # the same kernel on dy with the kernel flipped and transposed
+                                ops.conv3x3(self.gmaps[dst], kw_.t[kw_.off:], None, g, N, ho, wo, cout, cin, 1, 1, 1, h, w, flip=1, beta=beta)
+                            else:
+                                ops.conv3x3_bwd_data_s2(self.gmaps[dst], kw_.t[kw_.off:], g, N, h, w, cin, cout, pt, pl, ho, wo, beta=beta)
+                    else:
+                        m._gemm_tn(ops.mat(self.col[name], K), dy, gk.mat(cout), K, cout, rows)
+                        ops.colsum(dy, rows, cout, m.grads, m.scratch, beta=1.0, out_offset=gb.off)
+                        if src != "in":                                                # pixels are data: no gradient needed
+                            dcol = self.dcol[:rows * K]
+                            ops.gemm(dy, kw_.mat(cout), ops.mat(dcol, K), rows, K, cout, trans_b=1)
+                            g, beta = target(src)
+                            ops.col2im(dcol, g, N, h, w, cin, k, k, s, pt, pl, ho, wo, beta=beta)
+                for item in list(deferred):
+                    if item[0] in written:
+                        deferred.remove(item)
+                        item[1]()
+            # A deferred 1x1/2 data gradient waits for another contribution to its map.  In resnet_cnn every such map is also read by the
+            # block's first batch norm, whose backward writes it -- and that backward is what the map's PRODUCER then consumes.  A layout
+            # in which the strided shortcut were the map's only reader would reach this point with the producer's backward already run on
+            # an unwritten gradient map: refuse it instead of flushing too late.
+        finally:
+            ops.slab_defer_end()
         assert not deferred, "LipCNN.backward: a map read only by a strided 1x1 shortcut (%s) is not supported" % [d[0] for d in deferred]

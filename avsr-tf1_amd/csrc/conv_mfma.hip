@@ -1066,6 +1066,11 @@ static int g_conv_mfma = 1;
 
 }  // namespace avsr
 
+namespace avsr {
+bool slab_defer_push(const float* part, long ld, int nblk, int F, float* out, float* out2, int split, int kind, int Ci, float alpha, float beta,
+                     hipStream_t s);
+bool slab_deferring();
+}
 int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, float alpha, float beta, void* stream);
 
 using namespace avsr;
@@ -1410,6 +1415,7 @@ int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int
 #undef WG_GO
     if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
   }
+  if (avsr::slab_defer_push(scratch, nout, grid, nout, dw, nullptr, 0x7fffffff, 0, 0, 1.0f, beta, S_(stream))) return AVSR_OK;
   return avsr_colsum_final_launch(scratch, grid, dw, nout, 1.0f, beta, stream);
 }
 
@@ -1710,6 +1716,7 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
         if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
       }
       const int nout = 9 * Ci * 8 + 8;
+      if (avsr::slab_defer_push(scratch, A.slab, grid, nout, dw, dbias, 0, 1, Ci, 1.0f, beta, s)) return AVSR_OK;
       hipLaunchKernelGGL(wgrad_pair_final_kernel, dim3((nout + 31) / 32), dim3(1024), 0, s, scratch, grid, A.slab, Ci, dw, dbias, beta);
       if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
       return AVSR_OK;
@@ -1787,12 +1794,16 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
     }
     int rc;
     if (A.want_bias) {                                     // weight and bias gradients of the slab in one reduction launch
-      rc = avsr_colsum_final_launch_split(scratch, A.slab, grid, dw + (long)t0 * Ci * Co, dbias, wF, A.slab, 1.0f, beta, stream);
+      if (avsr::slab_defer_push(scratch, A.slab, grid, A.slab, dw + (long)t0 * Ci * Co, dbias, wF, 0, 0, 1.0f, beta, s)) rc = AVSR_OK;
+      else rc = avsr_colsum_final_launch_split(scratch, A.slab, grid, dw + (long)t0 * Ci * Co, dbias, wF, A.slab, 1.0f, beta, stream);
       bias_done = true;
     } else {
-      rc = avsr_colsum_final_launch_ld(scratch, A.slab, grid, dw + (long)t0 * Ci * Co, wF, 1.0f, beta, stream);
+      if (avsr::slab_defer_push(scratch, A.slab, grid, wF, dw + (long)t0 * Ci * Co, nullptr, 0x7fffffff, 0, 0, 1.0f, beta, s)) rc = AVSR_OK;
+      else rc = avsr_colsum_final_launch_ld(scratch, A.slab, grid, dw + (long)t0 * Ci * Co, wF, 1.0f, beta, stream);
     }
     if (rc != AVSR_OK) return rc;
+    // (deferred reductions: the next tap group of this call must not overwrite the slabs just recorded)
+    if (avsr::slab_deferring()) { scratch += (long)grid * A.slab; scratch_floats -= (long)grid * A.slab; A.part = scratch; }
   }
   return AVSR_OK;
 }

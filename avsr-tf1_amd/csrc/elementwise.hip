@@ -594,6 +594,108 @@ int avsr_colsum_final_launch_split(const float* part, long ld, int nblk, float* 
   return AVSR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deferred slab reductions.  Every weight-gradient launch of the lip CNN leaves per-workgroup partial slabs that a tiny kernel then sums
+// (5 us of launch latency for ~1 MB, twelve times per step, each in line behind its convolution).  Nothing reads a weight gradient
+// before the optimiser, so between avsr_slab_defer_begin() and avsr_slab_defer_end() those reductions are only RECORDED (the caller
+// gives every convolution its own scratch region) and run as ONE launch at the end.  Same arithmetic per job as the kernels they replace.
+#define SLABJ_MAX 32
+struct SlabJob { const float* part; long ld; int nblk, F; float* out; float* out2; int split, kind, Ci, blk0; float alpha, beta; };
+struct SlabLaunch { int n; SlabJob job[SLABJ_MAX]; };
+__global__ __launch_bounds__(1024) void slab_final_multi_kernel(const SlabLaunch L) {
+  __shared__ double red[32][33];
+  int j = 0;
+#pragma unroll 1
+  for (int k = 1; k < L.n; ++k) if ((int)blockIdx.x >= L.job[k].blk0) j = k;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const float* const part = L.job[j].part;
+  const long ld = L.job[j].ld;
+  const int nblk = L.job[j].nblk, F = L.job[j].F, Ci = L.job[j].Ci, kind = L.job[j].kind;
+  const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int f = ((int)blockIdx.x - L.job[j].blk0) * 32 + fl;
+  long o0 = -1, o1 = -1;
+  const int nw = 9 * Ci * 8;                          // (kind 1: kernel entries of the pixel-pair slab, then 8 bias entries)
+  if (kind == 0) { if (f < F) o0 = f; }
+  else if (f < nw) {
+    const int co = f & 7, ci = (f >> 3) % Ci, t = (f >> 3) / Ci, ti = t / 3, tj = t - ti * 3;
+    o0 = ((ti * 4 + tj) * Ci + ci) * 16 + co;
+    o1 = ((ti * 4 + tj + 1) * Ci + ci) * 16 + 8 + co;
+  } else if (f < nw + 8 && L.job[j].out2) { o0 = 12 * Ci * 16 + (f - nw); o1 = o0 + 8; }
+  double s = 0.0;
+  if (o0 >= 0) {
+    int i = g;
+    if (kind == 0) {
+      for (; i + 96 < nblk; i += 128) {
+        const float a0 = part[(long)i * ld + o0], a1 = part[(long)(i + 32) * ld + o0];
+        const float a2 = part[(long)(i + 64) * ld + o0], a3 = part[(long)(i + 96) * ld + o0];
+        s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      }
+      for (; i < nblk; i += 32) s += (double)part[(long)i * ld + o0];
+    } else {
+      for (; i + 96 < nblk; i += 128) {
+        const float a0 = part[(long)i * ld + o0], b0 = part[(long)i * ld + o1];
+        const float a1 = part[(long)(i + 32) * ld + o0], b1 = part[(long)(i + 32) * ld + o1];
+        const float a2 = part[(long)(i + 64) * ld + o0], b2 = part[(long)(i + 64) * ld + o1];
+        const float a3 = part[(long)(i + 96) * ld + o0], b3 = part[(long)(i + 96) * ld + o1];
+        s += (double)a0 + (double)b0;
+        s += (double)a1 + (double)b1;
+        s += (double)a2 + (double)b2;
+        s += (double)a3 + (double)b3;
+      }
+      for (; i < nblk; i += 32) s += (double)part[(long)i * ld + o0] + (double)part[(long)i * ld + o1];
+    }
+  }
+  red[g][fl] = s;
+  __syncthreads();
+  if (g == 0 && o0 >= 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += red[k][fl];
+    const float beta = L.job[j].beta;
+    float* o;
+    float v;
+    if (kind == 0) { v = L.job[j].alpha * (float)t; o = f < L.job[j].split ? L.job[j].out + f : L.job[j].out2 + (f - L.job[j].split); }
+    else { v = (float)t; o = f < nw ? L.job[j].out + f : L.job[j].out2 + (f - nw); }
+    *o = beta != 0.f ? v + beta * *o : v;
+  }
+}
+
+namespace avsr {
+static thread_local bool g_slab_defer = false;
+static thread_local SlabLaunch g_slab_jobs;
+// record a reduction instead of launching it; false: not deferring (the caller launches as before)
+bool slab_defer_push(const float* part, long ld, int nblk, int F, float* out, float* out2, int split, int kind, int Ci, float alpha, float beta,
+                     hipStream_t s);
+bool slab_deferring() { return g_slab_defer; }
+static int slab_flush(hipStream_t s) {
+  SlabLaunch& L = g_slab_jobs;
+  if (!L.n) return AVSR_OK;
+  int blocks = 0;
+  for (int j = 0; j < L.n; ++j) { L.job[j].blk0 = blocks; blocks += ((L.job[j].kind ? 9 * L.job[j].Ci * 8 + 8 : L.job[j].F) + 31) / 32; }
+  hipLaunchKernelGGL(slab_final_multi_kernel, dim3(blocks), dim3(1024), 0, s, L);
+  L.n = 0;
+  return hipGetLastError() == hipSuccess ? AVSR_OK : AVSR_ERR_HIP;
+}
+bool slab_defer_push(const float* part, long ld, int nblk, int F, float* out, float* out2, int split, int kind, int Ci, float alpha, float beta,
+                     hipStream_t s) {
+  if (!g_slab_defer) return false;
+  if (g_slab_jobs.n == SLABJ_MAX && slab_flush(s) != AVSR_OK) return false;
+  SlabJob& J = g_slab_jobs.job[g_slab_jobs.n++];
+  J = SlabJob{part, ld, nblk, F, out, out2, split, kind, Ci, 0, alpha, beta};
+  return true;
+}
+}  // namespace avsr
+
+extern "C" int avsr_slab_defer_begin(void) {
+  avsr::g_slab_jobs.n = 0;                            // (a collection left open by an aborted pass is dropped)
+  avsr::g_slab_defer = true;
+  return AVSR_OK;
+}
+extern "C" int avsr_slab_defer_end(void* stream) {
+  avsr::g_slab_defer = false;
+  return avsr::slab_flush(S_(stream));
+}
+
 // partial rows `ld` floats apart (F <= ld): several column ranges of one slab are reduced to different destinations
 int avsr_colsum_final_launch_ld(const float* part, long ld, int nblk, float* out, int F, float alpha, float beta, void* stream) {
   hipLaunchKernelGGL(colsum_final_kernel, dim3((F + 31) / 32), dim3(1024), 0, S_(stream), part, ld, nblk, out, F, alpha, beta);

@@ -565,6 +565,16 @@ def conv_bwd_weight(d, x, dy, dw, dbias, scratch, beta=1.0):
           "avsr_conv_bwd_weight")
 
 
+def slab_defer_begin():
+    """From here to slab_defer_end() the conv_bwd_weight calls of this thread record their final slab reductions instead of launching
+    them: one launch at the end (every call needs its own scratch region)."""
+    check(_L().avsr_slab_defer_begin(), "avsr_slab_defer_begin")
+
+
+def slab_defer_end():
+    check(_L().avsr_slab_defer_end(_s()), "avsr_slab_defer_end")
+
+
 def bn_finalize(part, nparts, Cn, count, eps, momentum, mean, invstd, mov_mean, mov_var, gamma=None, beta=None, scale=None, shift=None):
     check(_L().avsr_bn_finalize(fptr(part), int(nparts), int(Cn), int(count), float(eps), float(momentum), fptr(mean), fptr(invstd),
                                 fptr(mov_mean), fptr(mov_var), fptr(gamma), fptr(beta), fptr(scale), fptr(shift), _s()), "avsr_bn_finalize")

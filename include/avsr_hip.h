@@ -589,6 +589,12 @@ typedef struct avsr_colsum_job {
   float alpha, beta;
 } avsr_colsum_job;
 int avsr_colsum_multi(const avsr_colsum_job* jobs, int32_t n, float* scratch, int64_t scratch_floats, void* stream);
+/* Deferred weight-gradient reductions of the lip CNN (video.py:57-88 layers; seq2seq.py:222 tf.gradients of their kernels / biases):
+ * between _begin and _end every avsr_conv_bwd_weight on this thread only RECORDS the final sum over its per-workgroup partial slabs;
+ * _end runs all of them as one launch.  The caller passes each convolution its OWN scratch region (the slabs must survive until _end:
+ * at most 512 * max(k*k*Ci*Co + Co, 12*Ci*16 + 16) floats per call) and must not read dw / dbias in between. */
+int avsr_slab_defer_begin(void);
+int avsr_slab_defer_end(void* stream);
 /* AU regression loss (avsr/encoder.py:173-189); z = pre-sigmoid Dense(2) outputs [B][T][2]. */
 int avsr_au_loss(const float* z, const float* aus, const int32_t* len, float* row_loss, float* dz, int32_t B, int32_t T,
                  float weight, void* stream);
