@@ -873,9 +873,10 @@ class Seq2SeqModel:
             return
         if cfg.encoder_type == "unidirectional":
             Lt = E["layers"][("fw", top)]
-            if not self.gru:
+            if not self.gru and dc.data_ptr() != Lt["dcf"].data_ptr():
                 ops.copy_(Lt["dcf"], dc)
-            ops.copy_(Lt["dhf"], dh)
+            if dh.data_ptr() != Lt["dhf"].data_ptr():
+                ops.copy_(Lt["dhf"], dh)
             return
         for nm, key, dkey, g in ((("proj", "hf", "dhf", dh),) if self.gru else (("proj_c", "cf", "dcf", dc), ("proj_h", "hf", "dhf", dh))):
             Pm, Gm = self.P[f"{s}/enc/{nm}"], self.Gr[f"{s}/enc/{nm}"]
@@ -1320,18 +1321,22 @@ class Seq2SeqModel:
             return
         SP, GSP = self.P["dec/state_proj"], self.Gr["dec/state_proj"]
         present = [(si, s) for si, s in enumerate(("video", "audio")) if s in ws["enc"]]
+        tgt = {}
+        for si, s in present:                     # plain unidirectional encoders of the decoder's width: the products land where the encoder
+            E = ws["enc"][s]                      # BPTT reads its final-state gradient (no copy launches behind them)
+            direct = (not E["attentive"]) and cfg.encoder_type == "unidirectional" and E["units"][-1] == H
+            Lt = E["layers"][("fw", len(E["units"]) - 1)] if direct else None
+            tgt[s] = (Lt["dcf"] if (direct and not self.gru) else E["dc_dec"], Lt["dhf"] if direct else E["dh_dec"])
         with ops.gemm_group():                    # d (c, h) of every stream: independent
             for si, s in present:
-                E = ws["enc"][s]
-                for key, g, dst in (("c_fin", D["dc0"], "dc_dec"), ("h_fin", D["dh0"], "dh_dec")):
-                    ops.gemm(ops.mat(g, H), SP.mat(H, row0=si * H), ops.mat(E[dst], H), B, H, H, trans_b=1)
+                for key, g, dst in (("c_fin", D["dc0"], tgt[s][0]), ("h_fin", D["dh0"], tgt[s][1])):
+                    ops.gemm(ops.mat(g, H), SP.mat(H, row0=si * H), ops.mat(dst, H), B, H, H, trans_b=1)
         for key, g in (("c_fin", D["dc0"]), ("h_fin", D["dh0"])):      # the c and the h term of a stream accumulate into the same rows
             with ops.gemm_group():
                 for si, s in present:
                     ops.gemm(ops.mat(ws["enc"][s][key], H), ops.mat(g, H), GSP.mat(H, row0=si * H), H, H, B, trans_a=1, beta=1.0)
         for si, s in present:
-            E = ws["enc"][s]
-            self._final_state_bwd(ws, s, E["dc_dec"], E["dh_dec"])
+            self._final_state_bwd(ws, s, tgt[s][0], tgt[s][1])
 
     def _out_vec(self, D):
         """what the output Dense consumes: attention (Luong family) or the cell output (Bahdanau family)."""
