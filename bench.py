@@ -366,7 +366,7 @@ def main():
         pmc, pmc_file = {}, None
         try:
             if args.workload == "c4" and args.video_frontend == "resnet_cnn":
-                for cand in ("r04_c4_lipcnn_pmc_v4.json", "r04_c4_lipcnn_pmc_v3.json", "r04_c4_lipcnn_pmc_v1.json", "r03_c4_lipcnn_pmc_v2.json", "r03_c4_lipcnn_pmc_v1.json", "r02_c4_lipcnn_pmc_v5.json"):
+                for cand in ("r04_c4_lipcnn_pmc_v5.json", "r04_c4_lipcnn_pmc_v4.json", "r04_c4_lipcnn_pmc_v3.json", "r04_c4_lipcnn_pmc_v1.json", "r03_c4_lipcnn_pmc_v2.json", "r03_c4_lipcnn_pmc_v1.json", "r02_c4_lipcnn_pmc_v5.json"):
                     path = os.path.join(ROOT, "profiles", cand)
                     if os.path.exists(path):
                         pmc, pmc_file = json.load(open(path))["kernels"], "profiles/" + cand
