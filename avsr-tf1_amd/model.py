@@ -998,6 +998,8 @@ class Seq2SeqModel:
         sk = _splitk(M, N, K)
         if group_tiles and K >= 16384:
             sk = max(2, min(768 // int(group_tiles), K // 256))
+        elif group_tiles and K >= 1024:             # (the decoder block's B * L rows: at least four 16-deep K tiles per slice)
+            sk = max(1, min(768 // int(group_tiles), K // 64))
         while sk > 1 and sk * (M * N + (N if colsum is not None else 0)) > self.gemm_ws.numel():
             sk //= 2
         ops.gemm(A, Bm, Cm, M, N, K, trans_a=1, beta=beta, splitk=sk, workspace=self.gemm_ws, colsum=colsum, colsum_beta=1.0)
@@ -1207,11 +1209,13 @@ class Seq2SeqModel:
             self._gemm_tn((X["hs_seq"] if drop else X["out"]).mat(-1), dgx, self.Gr[kx].mat(4 * H, row0=H), H, 4 * H, rows)
             ops.colsum(dgx, rows, 4 * H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bx].off)
             below = X["out"]
+        nct = (G * H + 127) // 128
+        gt = (((E + 127) // 128) + ((A + 127) // 128 if A else 0) + ((H + 127) // 128)) * nct if not self.gru else None
         with ops.gemm_group():                   # the row blocks of the cell kernel's gradient and d inputs: independent
-            self._gemm_tn(xin_mat, dg, Gk.mat(G * H), E, G * H, rows)
+            self._gemm_tn(xin_mat, dg, Gk.mat(G * H), E, G * H, rows, group_tiles=gt)
             if A:
-                self._gemm_tn(a_att, dg, Gk.mat(G * H, row0=E), A, G * H, rows)
-            self._gemm_tn(a_h, dg, Gk.mat(G * H, row0=E + A), H, G * H, rows)
+                self._gemm_tn(a_att, dg, Gk.mat(G * H, row0=E), A, G * H, rows, group_tiles=gt)
+            self._gemm_tn(a_h, dg, Gk.mat(G * H, row0=E + A), H, G * H, rows, group_tiles=gt)
             ops.colsum(dg, rows, G * H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
             if dxin_mat is not None and not self.gru:
                 ops.gemm(dg, self.P[kname].mat(G * H), dxin_mat, rows, E, G * H, trans_b=1, beta=dxin_beta)
