@@ -26,16 +26,27 @@ def main():
     calls = []
     real = ops.gemm
 
+    launches = collections.OrderedDict()      # (grouped launch id or call index, operand class) -> [workgroups, GEMMs]
+
     def spy(A, B, Cm, M, N, K, trans_a=False, trans_b=False, alpha=1.0, beta=0.0, bias=None, batch=1, strides=(0, 0, 0), splitk=None,
-            workspace=None, alpha_dev=None):
+            workspace=None, alpha_dev=None, **kw):
         calls.append((int(M), int(N), int(K), int(bool(trans_a)), int(bool(trans_b)), int(batch), float(beta), splitk,
                       (A, B, Cm, bias, strides, workspace, alpha_dev, alpha)))
-        return real(A, B, Cm, M, N, K, trans_a, trans_b, alpha, beta, bias, batch, strides, splitk, workspace, alpha_dev)
+        sk = splitk if splitk else (ops.auto_splitk(M, N, K, batch) if (workspace is not None or ops._gemm_ws is not None) else 1)
+        wgs = ((M + 127) // 128) * ((N + 127) // 128) * batch * max(1, int(sk))
+        gid = id(ops._gemm_group) if ops._gemm_group is not None else -len(calls)
+        e = launches.setdefault((gid, len([k for k in launches if k[0] == gid and False]), int(bool(trans_a)), int(bool(trans_b))), [0, 0, []])
+        e[0] += wgs; e[1] += 1; e[2].append("%dx%dx%d/%d" % (M, N, K, sk))
+        return real(A, B, Cm, M, N, K, trans_a, trans_b, alpha, beta, bias, batch, strides, splitk, workspace, alpha_dev, **kw)
 
     ops.gemm = spy
     m.train_step(batch)
     torch.cuda.synchronize()
     ops.gemm = real
+    if "launches" in sys.argv:                 # workgroups per launch (768 slots = 3 per CU): rounds of the chip a launch takes
+        for (gid, _z, ta, tb), (wgs, n, names) in launches.items():
+            print("ta=%d tb=%d  GEMMs %d  workgroups %5d = %.2f rounds   %s" % (ta, tb, n, wgs, wgs / 768.0, " ".join(names)))
+        return
     groups = collections.OrderedDict()
     for c in calls:
         groups.setdefault(c[:6], []).append(c)
