@@ -207,7 +207,13 @@ class LipCNN:
                 _, name, _src, _dst, k, _s, cin, cout = op
                 self.wg_off[name] = off
                 off += 512 * max(k * k * cin * cout + cout, 12 * cin * 16 + 16)
-        self.wg_scratch = torch.empty(max(off, 4), device=dev)
+        # ONE buffer per model, shared by the LipCNN of every workspace shape (the region sizes do not depend on N; the slabs are live
+        # only inside one backward pass, and passes -- eager or replayed graphs -- are serialised on the engine's stream): a buffer
+        # per shape was ~180 MB x (8 cached + 8 pinned) shapes
+        shared = getattr(model, "_cnn_wg_scratch", None)
+        if shared is None or shared.numel() < max(off, 4):
+            shared = model._cnn_wg_scratch = torch.empty(max(off, 4), device=dev)
+        self.wg_scratch = shared
 
     # parameters live in the model's flat buffers
     def _p(self, n):

@@ -221,6 +221,18 @@ __global__ __launch_bounds__(256) void beam_step_kernel(float* logits, long logi
   unsigned long long* win = reinterpret_cast<unsigned long long*>(sm + ((n + 8 * K + 1 + 1) & ~1));      // 8-byte aligned
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float FMIN = -3.4028234663852886e38f;
+  // Steps queued past the end of the search (the host reads the "all finished" counter a chunk late): dynamic_decode has stopped, so
+  // the step hands its input state through unchanged.  Without this a beam that finished at the last real step would be re-scored with
+  // len + 1 and the beams re-ordered -- harmless for gather_tree (it reads step_ids / parent_ids [:T] and the maximum length) but not for
+  // a caller reading the per-beam state afterwards.  n_unfinished[-1] is the previous step's count, complete when this launch starts.
+  if (l > 0 && n_unfinished[-1] == 0) {
+    if (tid < K) {
+      const int r = b * K + tid;
+      logp_out[r] = logp_in[r]; fin_out[r] = fin_in[r]; len_out[r] = len_in[r];
+      tok[r] = eos; parent_rows[r] = r; step_ids[r] = eos; parent_ids[r] = tid;
+    }
+    return;
+  }
   if (tid < K) { fin_s[tid] = fin_in[b * K + tid]; len_s[tid] = len_in[b * K + tid]; logp_s[tid] = logp_in[b * K + tid]; }
   if (tid == 0) alive_s[0] = 0;
   if constexpr (NCT > 0) {

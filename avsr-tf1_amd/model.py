@@ -331,6 +331,15 @@ class Seq2SeqModel:
         self._ws_cache[key] = ws
         return ws
 
+    def prepare_workspace(self, batch):
+        """Allocate (or fetch) every buffer a train step on a batch of this shape needs, without launching anything.  The data-parallel
+        trainer calls it ahead of a shape's first pass so that an out-of-memory surfaces before any collective of the step."""
+        B, L = batch.labels.shape
+        Ta = batch.audio.shape[1] if batch.audio is not None else 0
+        Tv = batch.video.shape[1] if batch.video is not None else 0
+        self._ensure_gemm_ws()
+        return self._get_ws(B, Ta, Tv, L, False)
+
     def pin_workspace(self, ws):
         """A captured graph holds raw pointers into this workspace: exempt it from the LRU eviction of _get_ws until unpinned."""
         for k, v in self._ws_cache.items():
@@ -1549,6 +1558,10 @@ class Seq2SeqModel:
         int32 [B, T_out]; positions after the first EOS hold EOS (gather_tree).  length_penalty_weight defaults to the
         reference's 0.6 (unimodal / av_align) or 0.5 (bimodal)."""
         cfg, K = self.cfg, int(beam_width)
+        if K < 1 or K > 64 or K * cfg.vocab_size > 1024:
+            # beam_step_kernel keeps the K * V candidates of an utterance in registers, four per thread of one workgroup
+            raise ValueError("beam search: beam_width must be in 1..64 with beam_width * vocabulary <= 1024 (got %d x %d); "
+                             "the reference's default width 10 fits every shipped unit list" % (K, cfg.vocab_size))
         B = (batch.audio if batch.audio is not None else batch.video if batch.video is not None else batch.labels).shape[0]
         L = cfg.max_label_length if max_steps is None else max_steps
         w = length_penalty_weight if length_penalty_weight is not None else (0.5 if cfg.architecture == "bimodal" else 0.6)
@@ -1613,7 +1626,8 @@ class Seq2SeqModel:
         d.step_ids, d.parent_ids, d.parent_rows = ops.fptr(sid), ops.fptr(pid), ops.fptr(prow)
         # steps are launched in chunks of check_every; the "every beam finished" flag of a chunk is read while the NEXT chunk is already
         # queued (the read would otherwise leave the GPU idle for a host round trip per chunk).  A chunk past the end is harmless:
-        # with every beam finished a step reproduces its input state, and T below comes from the per-step counters.
+        # a beam step whose predecessor left no unfinished beam hands its input state through unchanged (beam_step_kernel), and T
+        # below comes from the per-step counters.
         fr = self._flag_reader()
         l, pending = 0, False
         while l < L:

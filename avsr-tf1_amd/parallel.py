@@ -264,21 +264,31 @@ class DataParallelTrainer:
             # one eager step allocates every workspace, then capture.  The eager step issues EXACTLY the collectives of every other
             # path (bucket, remainder, loss): ranks may reach the capture step of a shape at different times (their shard sizes, hence
             # their shape keys and sighting counts, can differ), and a rank capturing must pair up with one that replays or runs eagerly.
+            # A new shape's buffers are allocated BEFORE the pass (model.prepare_workspace): an out-of-memory there happens ahead of every
+            # collective of the step, so the rank can drop its graphs and run the ordinary eager pass -- the same collective sequence,
+            # the same do_check -- while the other ranks capture or replay.  Allocations later in the pass are only retried on a single
+            # rank: under collectives the aborted pass may already have started the bucket all-reduce, and a retry would pair a second
+            # set of reductions with the other ranks' one.
+            prep = getattr(m, "prepare_workspace", None)
             try:
-                self._eager_pass(st, do_check)
+                if prep is not None:
+                    prep(st)
             except torch.cuda.OutOfMemoryError:
-                # too many captured shapes alive (each pins a workspace and a private graph pool): drop them all and stay eager
-                self._drop_graphs()
-                self._static.clear()
-                self.use_graph = False
-                self.mode = "eager (out of memory while allocating a shape's workspace; captured graphs dropped)"
-                torch.cuda.empty_cache()
-                if self._pending is not None:
-                    self._pending.wait()
-                    self._pending = None
-                self._eager_pass(batch, False)
+                self._oom_to_eager()
+                self._eager_pass(batch, do_check)
                 m.apply_update()
                 return m.loss, m.gnorm
+            if self.collective:
+                self._eager_pass(st, do_check)
+            else:
+                try:
+                    self._eager_pass(st, do_check)
+                except torch.cuda.OutOfMemoryError:
+                    self._oom_to_eager()
+                    with self._redoing():      # the aborted pass may have reached the batch norms: the retry must not move their averages again
+                        self._eager_pass(batch, do_check)
+                    m.apply_update()
+                    return m.loss, m.gnorm
             m.apply_update()
             torch.cuda.synchronize()
             try:
@@ -353,6 +363,14 @@ class DataParallelTrainer:
         import contextlib
         ctx = getattr(self.model, "redoing", None)
         return ctx() if ctx else contextlib.nullcontext()
+
+    def _oom_to_eager(self):
+        """Too many captured shapes alive (each pins a workspace and a private graph pool): drop them all and stay eager."""
+        self._drop_graphs()
+        self._static.clear()
+        self.use_graph = False
+        self.mode = "eager (out of memory while allocating a shape's workspace; captured graphs dropped)"
+        torch.cuda.empty_cache()
 
     def _drop_graphs(self):
         unpin = getattr(self.model, "unpin_workspace", None)

@@ -213,3 +213,89 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path, fused):
     for k in W:                                                 # sync-BN: moving statistics are those of the GLOBAL batch
         if "moving_" in k:
             assert np.array_equal(r0[k], r1[k]) and np.abs(r0[k] - b["params"][k]).max() < 1e-6, k
+
+
+# ---- out-of-memory while a rank prepares a new shape's capture: the collective schedule must stay shared ----------------
+class _TinyModel:
+    """Minimal stand-in: gradient = batch mean of the labels, one parameter; records every pass."""
+
+    def __init__(self, oom_on_prepare):
+        self.grads_and_loss = torch.zeros(8, dtype=torch.float64)
+        self.grads, self.loss = self.grads_and_loss[:4], self.grads_and_loss[4:5]
+        self.gnorm, self.denom = torch.zeros(1, dtype=torch.float64), torch.zeros(1)
+        self.param = torch.zeros(4, dtype=torch.float64)
+        self.oom_on_prepare, self.prepared, self.passes, self.flag_checks = oom_on_prepare, 0, 0, 0
+
+    def prepare_workspace(self, batch):
+        self.prepared += 1
+        if self.oom_on_prepare and self.prepared == 1:
+            raise torch.cuda.OutOfMemoryError("simulated")
+
+    def forward_train(self, batch, compute_denom=True):
+        self.passes += 1
+        self._x = batch.labels.to(torch.float64).sum()
+
+    def backward(self):
+        self.grads.fill_(float(self._x))
+        self.loss.fill_(float(self._x))
+
+    def apply_update(self):
+        self.param -= 0.1 * self.grads
+        self.gnorm.copy_(self.grads.norm().reshape(1))
+
+    def check_persistent(self, disable=True, force=False):
+        self.flag_checks += 1
+        return False
+
+
+class _FakeGraph:
+    def __init__(self, fn):           # (a capture records, it does not execute)
+        self.fn = fn
+
+    def replay(self):
+        self.fn()
+
+
+def _oom_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the capture path's GPU plumbing, replaced for the CPU run: the test is about WHICH collectives each rank issues
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.empty_cache = lambda: None
+    DataParallelTrainer._drain = staticmethod(lambda: None)
+    DataParallelTrainer._copy_into = staticmethod(lambda dst, src: dst.copy_(src))
+    model = _TinyModel(oom_on_prepare=(rank == 1))
+    trainer = DataParallelTrainer(model, dist, use_graph=True, check_every_step=True)
+    trainer._capture = lambda fn: _FakeGraph(fn)
+    ncoll, real = [0], dist.all_reduce
+
+    def counting(*a, **k):
+        ncoll[0] += 1
+        return real(*a, **k)
+    dist.all_reduce = counting
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt)
+    for step in range(4):
+        b = Batch(z(2, 3, 4), z(2, dt=torch.int32), None, None, None, torch.full((2, 5), rank + step + 1, dtype=torch.int32),
+                  torch.full((2,), 5, dtype=torch.int32))
+        trainer.train_step(b)
+    dist.all_reduce = real
+    np.savez(os.path.join(out_dir, "oom%d.npz" % rank), param=model.param.numpy(), ncoll=ncoll[0], passes=model.passes,
+             graph=int(trainer.use_graph), checks=model.flag_checks)
+    dist.destroy_process_group()
+
+
+def test_out_of_memory_on_one_rank_keeps_the_collective_schedule(tmp_path):
+    """Rank 1 runs out of memory while allocating the shape it is about to capture; rank 0 captures and replays.  Both must issue the
+    same collectives every step (a hang or a mismatched reduction otherwise) and end with identical parameters."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_oom_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "oom0.npz"), np.load(tmp_path / "oom1.npz")
+    assert int(r0["graph"]) == 1 and int(r1["graph"]) == 0            # rank 1 dropped to eager launches, rank 0 replays its graph
+    assert int(r0["ncoll"]) == int(r1["ncoll"])
+    assert int(r1["passes"]) == 4 and int(r0["passes"]) == 4
+    assert np.array_equal(r0["param"], r1["param"])
+    # 4 steps, gradient of step s = sum over ranks of 10 * (rank + s + 1)
+    want = -0.1 * sum(10.0 * ((0 + s + 1) + (1 + s + 1)) for s in range(4))
+    assert np.allclose(r0["param"], want)
