@@ -99,6 +99,7 @@ class LipCNN:
         dev = model.dev
         z = lambda *s: torch.zeros(*s, device=dev)
         self.maps, self.gmaps, self.col, self.bn, self.direct, self.mfma = {}, {}, {}, {}, set(), {}
+        self._sync_bufs = {}
         max_col = 4
         for op in self.ops:
             kind = op[0]
@@ -215,6 +216,13 @@ class LipCNN:
             shared = model._cnn_wg_scratch = torch.empty(max(off, 4), device=dev)
         self.wg_scratch = shared
 
+    def _sync_buf(self, name, c):
+        """fp64 [sum | sum of squares | rows] + a second [2c] for this rank's own sums: what one batch norm all-reduces (sync_cnn_bn)."""
+        b = self._sync_bufs.get(name)
+        if b is None:
+            b = self._sync_bufs[name] = torch.zeros(4 * c + 2, dtype=torch.float64, device=self.m.dev)
+        return b
+
     # parameters live in the model's flat buffers
     def _p(self, n):
         return self.m.P[self.pre + n]
@@ -279,13 +287,28 @@ class LipCNN:
                 mean, invstd, scale, shift = self.bn[name]
                 # seq2seq.py:241-250: the UPDATE_OPS (moving averages) only run with the train op under batch_normalisation=True
                 upd = not training or m.cfg.batch_normalisation
-                if training and self.stat_rows.get(src):
+                sync = getattr(m, "cnn_bn_sync", None) if training else None
+                if sync is not None and not self.stat_rows.get(src):
+                    raise NotImplementedError("sync_cnn_bn: batch norm %s takes its statistics outside the fused convolution epilogues" % name)
+                if training and self.stat_rows.get(src) and sync is not None:
+                    # data parallel, opt-in: statistics of the GLOBAL batch.  This rank's fp64 sums + its row count -> one small all-reduce
+                    # -> the same finalisation from the global sums (moving averages included: identical on every rank)
+                    buf = self._sync_buf(name, c)
+                    ops.bn_partials_f64(self.stat_buf[src], self.stat_rows[src], c, buf)
+                    buf[2 * c:2 * c + 1].fill_(float(N * h * w))
+                    sync(buf[:2 * c + 1])
+                    ops.bn_finalize_f64(buf, c, self.BN_EPS, self.BN_MOMENTUM, mean, invstd,
+                                        m._sp(self.pre + name + "/moving_mean") if upd else None,
+                                        m._sp(self.pre + name + "/moving_variance") if upd else None,
+                                        self._pv(name + "/gamma"), self._pv(name + "/beta"), scale, shift)
+                elif training and self.stat_rows.get(src):
                     # statistics came with the producing convolution's epilogue: finalise (fp64 merge); no statistic passes, and no
                     # normalisation pass either when every reader applies scale / shift in its loader
                     ops.bn_finalize(self.stat_buf[src], self.stat_rows[src], c, N * h * w, self.BN_EPS, self.BN_MOMENTUM, mean, invstd,
                                     m._sp(self.pre + name + "/moving_mean") if upd else None,
                                     m._sp(self.pre + name + "/moving_variance") if upd else None,
                                     self._pv(name + "/gamma"), self._pv(name + "/beta"), scale, shift)
+                if training and self.stat_rows.get(src):
                     if name in self.lazy_ok:
                         self.lazy[dst] = (src, scale, shift)
                     else:
@@ -366,6 +389,21 @@ class LipCNN:
                     mean, invstd = self.bn[name][:2]
                     g, beta = target(src)
                     gg, gb = self._g(name + "/gamma"), self._g(name + "/beta")
+                    sync = getattr(m, "cnn_bn_sync", None)
+                    if sync is not None and name not in self.bnb_rows:
+                        raise NotImplementedError("sync_cnn_bn: batch norm %s is differentiated outside the fused data gradients" % name)
+                    if name in self.bnb_rows and sync is not None:
+                        # global means of dz and dz * xhat for the input gradient; d gamma / d beta keep this rank's share
+                        buf = self._sync_buf(name, c)
+                        loc = buf[2 * c + 1:4 * c + 1]
+                        ops.bn_partials_f64(self.bnb_stat[name], self.bnb_rows.pop(name), c, loc)
+                        buf[:2 * c].copy_(loc)
+                        buf[2 * c:2 * c + 1].fill_(float(N * h * w))
+                        sync(buf[:2 * c + 1])
+                        ops.bn_bwd_finalize_f64(loc, buf, c, mean, invstd, self._pv(name + "/gamma"), gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c],
+                                                self.bnb_k[name], grad_beta=0.0)
+                        ops.bn_bwd_apply(self.gmaps[dst], self.maps[src], self.bnb_k[name], g, N * h * w, c, beta=beta)
+                        continue
                     if name in self.bnb_rows:            # stage 1 ran in the producing data gradient's epilogue: gmaps[dst] holds dz
                         ops.bn_bwd_finalize(self.bnb_stat[name], self.bnb_rows.pop(name), c, N * h * w, mean, invstd, self._pv(name + "/gamma"),
                                             gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c], self.bnb_k[name], grad_beta=0.0)

@@ -1907,6 +1907,84 @@ extern "C" int avsr_bn_bwd_apply(const float* dz, const float* x, const float* k
   return AVSR_OK;
 }
 
+// ---- batch-norm statistics across data-parallel ranks (opt-in: DataParallelTrainer(sync_cnn_bn=True)) --------------------------------
+// The partial sums a convolution epilogue wrote are merged into fp64 per-channel sums, the host all-reduces that small buffer (with the
+// rank's row count behind it), and the finalisation reads the GLOBAL sums: mean / variance / moving averages / loader affine of the
+// whole batch on every rank (video.py:4-14 over the global batch).  Same arithmetic as bn_finalize_kernel / bn_bwd_finalize_kernel.
+__global__ __launch_bounds__(1024) void bn_partials_f64_kernel(const float* part, int nparts, int C, double* out) {
+  __shared__ double red[2][64][17];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+  double s = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int p = rg; p < nparts; p += 64) { s += (double)part[(long)p * 2 * C + c]; s2 += (double)part[(long)p * 2 * C + C + c]; }
+  red[0][rg][cl] = s; red[1][rg][cl] = s2;
+  __syncthreads();
+  if (threadIdx.x >= 16 || c >= C) return;
+  s = 0.0; s2 = 0.0;
+  for (int r = 0; r < 64; ++r) { s += red[0][r][cl]; s2 += red[1][r][cl]; }
+  out[c] = s; out[C + c] = s2;
+}
+extern "C" int avsr_bn_partials_f64(const float* part, int32_t nparts, int32_t C, double* out64, void* stream) {
+  if (!part || nparts <= 0 || C <= 0 || !out64) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(bn_partials_f64_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), part, nparts, C, out64);
+  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+  return AVSR_OK;
+}
+// sums [2C + 1]: sum | sum of squares | rows per channel (all ranks)
+__global__ void bn_finalize_f64_kernel(const double* sums, int C, float eps, float momentum, float* mean, float* invstd, float* mov_mean,
+                                       float* mov_var, const float* gamma, const float* beta, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double count = sums[2 * C], m = sums[c] / count;
+  double var = sums[C + c] / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = rsqrtf((float)var + eps);
+  mean[c] = (float)m;
+  invstd[c] = is;
+  if (scale) {
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)m * sc;
+  }
+  if (mov_mean) {
+    const float unbiased = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+    mov_mean[c] = momentum * mov_mean[c] + (1.f - momentum) * (float)m;
+    mov_var[c] = momentum * mov_var[c] + (1.f - momentum) * unbiased;
+  }
+}
+extern "C" int avsr_bn_finalize_f64(const double* sums, int32_t C, float eps, float momentum, float* mean, float* invstd, float* mov_mean,
+                                    float* mov_var, const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
+  if (!sums || C <= 0 || !mean || !invstd || (scale && (!gamma || !beta || !shift))) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_f64_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), sums, C, eps, momentum, mean, invstd, mov_mean, mov_var,
+                     gamma, beta, scale, shift);
+  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+  return AVSR_OK;
+}
+// local [2C]: this rank's (sum dz | sum dz*x); global [2C + 1]: the all-reduced sums and the global row count.  d gamma / d beta take the
+// LOCAL sums (the gradient all-reduce adds the ranks' shares), the coefficient vectors of dx = k1*dz + k2*x + k3 the GLOBAL means.
+__global__ void bn_bwd_finalize_f64_kernel(const double* local, const double* global, int C, const float* mean, const float* invstd,
+                                           const float* gamma, float* dgamma, float* dbeta, float grad_beta, float* k) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = mean[c], is = invstd[c], g = gamma[c], count = global[2 * C];
+  const double sl = local[c], sxh_l = is * (local[C + c] - m * sl);
+  if (dbeta) dbeta[c] = (grad_beta != 0.f ? grad_beta * dbeta[c] : 0.f) + (float)sl;
+  if (dgamma) dgamma[c] = (grad_beta != 0.f ? grad_beta * dgamma[c] : 0.f) + (float)sxh_l;
+  const double s = global[c], sxh = is * (global[C + c] - m * s);
+  const double a = s / count, b = sxh / count;
+  k[c] = (float)(g * is);
+  k[C + c] = (float)(-g * is * is * b);
+  k[2 * C + c] = (float)(-g * is * a + g * is * is * b * m);
+}
+extern "C" int avsr_bn_bwd_finalize_f64(const double* local, const double* global, int32_t C, const float* mean, const float* invstd,
+                                        const float* gamma, float* dgamma, float* dbeta, float grad_beta, float* k, void* stream) {
+  if (!local || !global || C <= 0 || !mean || !invstd || !gamma || !k) return AVSR_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_finalize_f64_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), local, global, C, mean, invstd, gamma, dgamma, dbeta,
+                     grad_beta, k);
+  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+  return AVSR_OK;
+}
+
 extern "C" int avsr_conv_bwd_weight(const avsr_conv_desc* c, const float* x, const float* dy, float* dw, float* dbias, float beta, float* scratch,
                                     int64_t scratch_floats, void* stream) {
   if (!cd_ok(c) || !x || !dy || !dw || !scratch) return AVSR_ERR_ARG;

@@ -745,7 +745,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   }
 #ifdef DP_TIMING
   if (tid0 == 0 && j == 0 && g == 0)
-    for (int k = 0; k < 24; ++k) L.err[16 + k] = (int)(tm[k] / (L.l_end - L.l_begin));
+    for (int k = 0; k < 24; ++k) L.err[(MODE == 0 ? 176 : 16) + k] = (int)(tm[k] / (L.l_end - L.l_begin));   // attentive layer: its own words
 #endif
   // ---- state back to the ping-pong buffers (the next call / the caller's h_final, c_final copies read them) ----
   {

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_bwd_kernel(const DBLaunch L
   }
 #ifdef DP_TIMING
   if (tid0 == 0 && j == 0 && g == 0)
-    for (int k = 0; k < 12; ++k) L.err[16 + k] = (int)(tm[k] / Ls);
+    for (int k = 0; k < 12; ++k) L.err[(R == 16 ? 200 : 16) + k] = (int)(tm[k] / Ls);      // 16-row groups = the AV-Align attentive layer: its own words
 #endif
   {
     const int tid = tid0;

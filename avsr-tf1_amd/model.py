@@ -729,7 +729,24 @@ class Seq2SeqModel:
             assert x.shape == (B, T, F) and x.is_contiguous() and x.dtype == torch.float32
             E["x"], E["len"] = x, len_t
             if cfg.batch_normalisation:
-                if training and self.bn_sync is not None and s in self.bn_sync["streams"]:
+                sync = getattr(self, "cnn_bn_sync", None) if (training and "cnn" in E) else None
+                if sync is not None:
+                    # data parallel with sync_cnn_bn: the CNN-fed stream's input batch norm takes the statistics of the GLOBAL batch too --
+                    # its input only exists inside the step, so its fp64 moments get their own small all-reduce here
+                    if "sync64" not in E:
+                        E["sync64"] = torch.zeros(2 * F + 1, dtype=torch.float64, device=self.dev)
+                        E["sync_mean"], E["sync_sq"], E["sync_rows"] = (torch.zeros(F, device=self.dev), torch.zeros(F, device=self.dev),
+                                                                       torch.zeros(1, device=self.dev))
+                    buf = E["sync64"]
+                    ops.batchnorm_sync_moments(x, B * T, F, buf[:2 * F], self.scratch)
+                    buf[2 * F:2 * F + 1].fill_(float(B * T))
+                    sync(buf)
+                    ops.dp_sync_unpack(buf, None, [(0, F, E["sync_mean"], E["sync_sq"], E["sync_rows"])])
+                    ops.batchnorm_sync_apply(x, E["xn"], B * T, F, self._pp(f"{s}/bn/gamma"), self._pp(f"{s}/bn/beta"),
+                                             self._sp(f"{s}/bn/moving_mean"), self._sp(f"{s}/bn/moving_variance"),
+                                             E["sync_mean"], E["sync_sq"], E["sync_rows"], E["invstd"])
+                    E["mean"] = E["sync_mean"]
+                elif training and self.bn_sync is not None and s in self.bn_sync["streams"]:
                     # statistics of the GLOBAL batch: mean / centred squares were all-reduced by the trainer (bn_sync_*)
                     o = self.bn_sync["off"][s]
                     ops.batchnorm_sync_apply(x, E["xn"], B * T, F, self._pp(f"{s}/bn/gamma"), self._pp(f"{s}/bn/beta"),
@@ -986,7 +1003,24 @@ class Seq2SeqModel:
                            out_offset=self.Gr[f"{s}/bn/gamma"].off)
                 ops.colsum(ops.mat(E["dxn"], F), B * T, F, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[f"{s}/bn/beta"].off)
             if "cnn" in E:                       # gradient wrt the visual features, then through the CNN
-                if cfg.batch_normalisation:
+                sync = getattr(self, "cnn_bn_sync", None)
+                if cfg.batch_normalisation and sync is not None:
+                    # sync_cnn_bn: dx = gamma*invstd*(dy - mean(dy) - xhat*mean(dy*xhat)) with the means over the GLOBAL batch.  This rank's
+                    # sums are what the two column-sum launches above left in the gradient buffer (d beta | d gamma, accumulated from
+                    # zero); their all-reduced copy gives the three coefficient vectors of dx = k1*dy + k2*x + k3 (a handful of [F]-sized
+                    # torch ops: this mode launches eagerly)
+                    ops.colsum_batch_flush(self.scratch)      # (the column sums of a half-pass are collected: run the ones queued so far)
+                    ob, og = self.Gr[f"{s}/bn/beta"].off, self.Gr[f"{s}/bn/gamma"].off
+                    red = torch.cat([self.grads[ob:ob + F], self.grads[og:og + F], torch.full((1,), float(B * T), device=self.dev)]).to(torch.float64)
+                    sync(red)
+                    n = red[2 * F]
+                    g64, is64, m64 = (self.params[self.P[f"{s}/bn/gamma"].off:self.P[f"{s}/bn/gamma"].off + F].to(torch.float64),
+                                      E["invstd"].to(torch.float64), E["mean"].to(torch.float64))
+                    a, b = red[:F] / n, red[F:2 * F] / n
+                    E["bn_k"] = torch.cat([g64 * is64, -g64 * is64 * is64 * b, -g64 * is64 * a + g64 * is64 * is64 * b * m64]).to(torch.float32).contiguous()
+                    ops.bn_bwd_apply(E["dxn"], E["x"], E["bn_k"], E["dfeat"], B * T, F)
+                    E["cnn"].backward(E["dfeat"])
+                elif cfg.batch_normalisation:
                     ops.batchnorm_bwd(E["x"], E["dxn"], self._pp(f"{s}/bn/gamma"), self._pp(f"{s}/bn/beta"), E["mean"], E["invstd"],
                                       E["dfeat"], None, None, B * T, F, 0, self.scratch)
                     E["cnn"].backward(E["dfeat"])

@@ -551,6 +551,20 @@ def bn_bwd_finalize(part, nparts, Cn, count, mean, invstd, gamma, dgamma, dbeta,
                                     float(grad_beta), fptr(k), _s()), "avsr_bn_bwd_finalize")
 
 
+def bn_partials_f64(part, nparts, Cn, out64):
+    check(_L().avsr_bn_partials_f64(fptr(part), int(nparts), int(Cn), out64.data_ptr(), _s()), "avsr_bn_partials_f64")
+
+
+def bn_finalize_f64(sums64, Cn, eps, momentum, mean, invstd, mov_mean, mov_var, gamma=None, beta=None, scale=None, shift=None):
+    check(_L().avsr_bn_finalize_f64(sums64.data_ptr(), int(Cn), float(eps), float(momentum), fptr(mean), fptr(invstd), fptr(mov_mean), fptr(mov_var),
+                                    fptr(gamma), fptr(beta), fptr(scale), fptr(shift), _s()), "avsr_bn_finalize_f64")
+
+
+def bn_bwd_finalize_f64(local64, global64, Cn, mean, invstd, gamma, dgamma, dbeta, k, grad_beta=1.0):
+    check(_L().avsr_bn_bwd_finalize_f64(local64.data_ptr(), global64.data_ptr(), int(Cn), fptr(mean), fptr(invstd), fptr(gamma), fptr(dgamma),
+                                        fptr(dbeta), float(grad_beta), fptr(k), _s()), "avsr_bn_bwd_finalize_f64")
+
+
 def bn_eval_affine(gamma, beta, mov_mean, mov_var, eps, scale, shift, Cn):
     check(_L().avsr_bn_eval_affine(fptr(gamma), fptr(beta), fptr(mov_mean), fptr(mov_var), float(eps), fptr(scale), fptr(shift), int(Cn), _s()),
           "avsr_bn_eval_affine")

@@ -29,7 +29,7 @@ class DataParallelTrainer:
     MAX_GRAPHS = 24          # captured shapes kept (bucketed training visits many): least recently used is dropped with its buffers
 
     def __init__(self, model, dist=None, use_graph=True, sync_bn=True, force_collectives=False, check_every_step=True, graph_after=1,
-                 max_graphs=None):
+                 max_graphs=None, sync_cnn_bn=None):
         self.model, self.dist = model, dist
         if max_graphs is not None:               # bucketed training on large batches: every captured shape pins a workspace and a graph pool
             self.MAX_GRAPHS = max(1, int(max_graphs))
@@ -77,6 +77,19 @@ class DataParallelTrainer:
             model.seed_offset = dist.get_rank() << 24      # decorrelate the ranks' dropout / sampling masks
         model.au_scale = 1.0 / self.world          # stand-in models without dp_norm: the AU term is averaged over ranks
         self.sync_bn = bool(sync_bn and self.collective and getattr(model, "bn_sync_enable", None) and model.bn_sync_enable())
+        # Opt-in (sync_cnn_bn=True or AVSR_DP_SYNC_CNN_BN=1): the batch norms INSIDE the lip CNN and the input batch norm of the CNN-fed
+        # stream normalise with the statistics of the GLOBAL batch (video.py:4-14 on one device sees the whole batch): two ranks then
+        # reproduce one engine on the whole batch from lip crops.  Their statistics are sequentially dependent (layer k's moments are
+        # taken over layer k-1's normalised output), so each of the 8 batch norms needs its own small all-reduce in the forward pass and
+        # one in the backward pass -- 16 collectives INSIDE the step, which therefore launches eagerly (no captured graph).  Default
+        # off: per-rank statistics, replicas bit-identical, the deviation stated in the bench JSON.
+        if sync_cnn_bn is None:
+            sync_cnn_bn = os.environ.get("AVSR_DP_SYNC_CNN_BN") == "1"
+        self.sync_cnn_bn = bool(sync_cnn_bn and self.collective and getattr(model, "use_cnn", False))
+        if self.sync_cnn_bn:
+            model.cnn_bn_sync = lambda t: dist.all_reduce(t)
+            self.use_graph = False
+            self.mode = "eager (sync_cnn_bn: 16 small collectives inside the step)"
 
     # -- helpers ----------------------------------------------------------------------------------
     @staticmethod

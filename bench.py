@@ -173,6 +173,35 @@ def cpu_baseline(wl, stoch, sample_B=4, warmups=3, steps=10, video_frontend="fea
                       % (ncores, sample_B, TA, TV, LDEC, video_frontend, len(times), warmups)}
 
 
+def cpu_baseline_full(wl, stoch, budget_s=45.0):
+    """Second CPU figure, SURVEY 8(d) to the letter: the WHOLE workload batch (B utterances, not a 4-utterance sample), torch threads =
+    the host's physical cores, oneDNN enabled -- on the `features` video input (pre-computed 128-d lip features; the oneDNN heap
+    corruption on this image was in the convolution backward of the lip CNN only).  One warm-up step, then as many timed steps as fit
+    the budget (at least one): a B = 64 step takes tens of seconds, so this leg reports one to three steps and says so."""
+    from oracle import avsr_oracle as O
+    ncores = _physical_cores() or (os.cpu_count() or 1)
+    torch.set_num_threads(ncores)
+    torch.backends.mkldnn.enabled = True
+    ocfg = O.OracleConfig(video_processing="features", **wl["cfg"], **stoch)
+    P = O.init_params(ocfg, seed=2001)
+    Bf = wl["B"]
+    b = O.synthetic_batch(ocfg, B=Bf, T_a=TA, T_v=TV, L=LDEC)
+    t_start = time.perf_counter()
+    O.train_step(P, None, ocfg, b, dtype=torch.float32)
+    times = []
+    while len(times) < 3 and (not times or time.perf_counter() - t_start + times[-1] < budget_s):
+        t0 = time.perf_counter()
+        O.train_step(P, None, ocfg, b, dtype=torch.float32)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    return {"value": round(Bf / dt, 3), "unit": "utterances/sec", "cores": ncores, "kind": "port", "onednn": True,
+            "host_cpu": _cpu_model(), "host_physical_cores": _physical_cores(), "host_logical_cpus": os.cpu_count(),
+            "timed_steps": len(times), "warmup_steps": 1, "step_seconds_median": round(dt, 3),
+            "sample": "oracle/avsr_oracle.py train_step (torch-CPU fp32, autograd BPTT, oneDNN on, %d threads = physical cores), the whole "
+                      "batch of %d utterances at full T_a=%d T_v=%d L=%d, video input: 128-d lip features (no lip CNN), median of %d step(s) "
+                      "after 1 warm-up; TF-1.13.1 reference cannot run here" % (ncores, Bf, TA, TV, LDEC, len(times))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,7 +214,7 @@ def main():
     ap.add_argument("--video-frontend", default="resnet_cnn", choices=["features", "resnet_cnn"],
                     help="resnet_cnn (default): 36x36x3 lip crops through the CNN front-end, north_star's input; features: 128-d lip features")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--section", default=None, choices=[None, "aux_frontend", "cpu_baseline"], help="internal: run one auxiliary section in a child process and print its JSON")
+    ap.add_argument("--section", default=None, choices=[None, "aux_frontend", "cpu_baseline", "cpu_baseline_full"], help="internal: run one auxiliary section in a child process and print its JSON")
     ap.add_argument("--strong", action="store_true", help="N > 1: global batch fixed at the workload's B (B/N utterances per GPU) instead of B per GPU")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -232,6 +261,9 @@ def main():
     if args.section == "cpu_baseline":
         os.write(json_fd, (json.dumps(cpu_baseline(wl, stoch, video_frontend=args.video_frontend)) + "\n").encode())
         return
+    if args.section == "cpu_baseline_full":
+        os.write(json_fd, (json.dumps(cpu_baseline_full(wl, stoch)) + "\n").encode())
+        return
     if args.section == "aux_frontend":
         cfg2 = ModelConfig(audio_feat=FA, video_feat=FV, video_processing=args.video_frontend, **wl["cfg"], **stoch)
         m2 = Seq2SeqModel(cfg2, seed=2001)
@@ -270,18 +302,29 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # an event behind every step: per-step GPU times of this rank (read after the timed region; an event record costs no host wait)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         trainer.train_step(batch)
+        marks[i + 1].record()
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    rank_stats = [dt_local, min(step_ms), float(np.median(step_ms)), max(step_ms)]
+    per_rank = [rank_stats]
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        allr = [torch.zeros(4, device="cuda", dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allr, torch.tensor(rank_stats, device="cuda", dtype=torch.float64))
+        per_rank = [[float(v) for v in a.cpu()] for a in allr]
     loss = float(model.loss.item())
     trace("timed steps done")
     persist_err = bool(ops.rnn_persistent_error())      # sticky flag of the persistent encoder kernels (a bounded device-side wait expired)
@@ -304,6 +347,11 @@ def main():
                                      "(tests/test_gpu_dp.py::test_two_ranks_with_the_lip_cnn)") if world > 1 else None,
                    "parity": "vs CPU restatement of TF-1.13.1 semantics; TF parity unpinned"},
         "final_loss": round(loss, 5),
+        # per rank: wall seconds of the timed loop before the closing barrier, and min / median / max GPU milliseconds per step (event
+        # pairs; includes the collectives).  A slow rank or a slow step shows here: the first thing to read in a multi-GPU run.
+        "rank_timing": {"seconds_before_barrier": [round(r[0], 4) for r in per_rank],
+                        "step_ms_min_median_max": [[round(r[1], 3), round(r[2], 3), round(r[3], 3)] for r in per_rank],
+                        "slowest_over_fastest_rank": round(max(r[0] for r in per_rank) / max(1e-9, min(r[0] for r in per_rank)), 4)},
     }
 
     force_strong = force_dist and os.environ.get("AVSR_BENCH_FORCE_STRONG") == "1"      # test hook: this section with one rank
@@ -545,6 +593,18 @@ def main():
                 {"value": None, "error": "child exit %d: %s" % (p.returncode, p.stderr.strip().splitlines()[-1][:200] if p.stderr.strip() else "")}
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        # second leg (its own child: thread count and oneDNN are process-wide): the whole batch on every physical core, features input
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--section", "cpu_baseline_full", "--workload", args.workload] + \
+                  (["--no-dropout"] if args.no_dropout else [])
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            full = json.loads(lines[-1]) if (p.returncode == 0 and lines) else \
+                {"value": None, "error": "child exit %d: %s" % (p.returncode, p.stderr.strip().splitlines()[-1][:200] if p.stderr.strip() else "")}
+        except Exception as e:
+            full = {"value": None, "error": repr(e)}
+        if isinstance(out.get("cpu_baseline"), dict):
+            out["cpu_baseline"]["whole_batch_all_cores"] = full
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

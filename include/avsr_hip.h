@@ -497,6 +497,16 @@ int avsr_bn_bwd_finalize(const float* part, int32_t nparts, int32_t C, int64_t c
 int avsr_bn_bwd_apply(const float* dz, const float* x, const float* k, float* dx, int64_t rows, int32_t C, float beta, void* stream);
 int avsr_bn_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, float eps, float momentum, float* mean, float* invstd,
                      float* mov_mean, float* mov_var, const float* gamma, const float* beta, float* scale, float* shift, void* stream);
+/* The same two finalisations from GLOBAL statistics under data parallelism (video.py:4-14 `tf.layers.batch_normalization` over the whole
+ * batch; opt-in, DataParallelTrainer(sync_cnn_bn=True)): avsr_bn_partials_f64 merges a convolution's partial rows into fp64 sums
+ * out64 [2*C]; the caller all-reduces [sums | rows per channel] over the ranks; avsr_bn_finalize_f64 reads sums [2*C + 1] (count last);
+ * avsr_bn_bwd_finalize_f64 takes this rank's sums `local` [2*C] for d gamma / d beta (the gradient all-reduce adds the ranks' shares)
+ * and the all-reduced `global` [2*C + 1] for the coefficient vectors k [3*C]. */
+int avsr_bn_partials_f64(const float* part, int32_t nparts, int32_t C, double* out64, void* stream);
+int avsr_bn_finalize_f64(const double* sums, int32_t C, float eps, float momentum, float* mean, float* invstd, float* mov_mean,
+                         float* mov_var, const float* gamma, const float* beta, float* scale, float* shift, void* stream);
+int avsr_bn_bwd_finalize_f64(const double* local, const double* global, int32_t C, const float* mean, const float* invstd,
+                             const float* gamma, float* dgamma, float* dbeta, float grad_beta, float* k, void* stream);
 /* scale = gamma * rsqrt(moving_variance + eps), shift = beta - moving_mean * scale: the evaluation graph's batch norm as the
  * loader-applied affine of avsr_conv_desc (no normalised map is written in evaluation either). */
 int avsr_bn_eval_affine(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, float eps, float* scale,

@@ -1169,9 +1169,16 @@ def gather_tree(step_ids: np.ndarray, parent_ids: np.ndarray, max_len: np.ndarra
 @torch.no_grad()
 def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Batch, beam_width: int = 10,
                        length_penalty_weight: Optional[float] = None, max_steps: Optional[int] = None, dtype=torch.float64,
-                       return_all: bool = False, return_trace: bool = False):
+                       return_all: bool = False, return_trace: bool = False, follow=None):
     """Returns predicted ids of beam 0, int32 [B, T_out] (`outputs.predicted_ids[:, :, 0]`, decoder_unimodal.py:269).
-    length_penalty_weight defaults to the reference's 0.6 (unimodal / av_align) or 0.5 (bimodal)."""
+    length_penalty_weight defaults to the reference's 0.6 (unimodal / av_align) or 0.5 (bimodal).
+
+    follow = (step_ids [T, B, K], parent_ids [T, B, K]) of ANOTHER implementation's search (test aid, tests/test_gpu_beam.py): at every
+    step the oracle scores all K * V candidates from the current state, records how far the followed implementation's j-th selection
+    lies from the oracle's own j-th best score (`follow_dev` [T, B]: 0 when they are the same candidates in the same order, within an
+    fp32 implementation's rounding when it ordered a near-tie the other way, large when it picked a wrong candidate), whether the
+    selections were identical (`follow_same` [T, B]) and whether they were K distinct candidates, and then CONTINUES FROM THE FOLLOWED
+    SELECTION -- so every step of the other search is checked, not only those before its first near-tie."""
     P = to_torch(P_np, dtype)
     m = _Model(P, cfg, batch, False, dtype)
     B, K, V, eos = m.B, beam_width, cfg.vocab_size, cfg.eos_id
@@ -1191,6 +1198,7 @@ def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Ba
     step_ids, parent_ids = [], []
     min_gap = torch.full((B,), float("inf"), dtype=dtype)
     step_gaps = []
+    f_dev, f_same, f_distinct, f_short = [], [], [], False
     for t in range(max_steps):
         out, state, att, _ = m.step(_embedding(P, cfg)[tok], state, att, t)
         step_lp = torch.log_softmax(m.logits(out), dim=-1).reshape(B, K, V)
@@ -1213,6 +1221,20 @@ def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Ba
         gap = torch.where((top[:, :-1] == top[:, 1:]) | torch.isnan(gap), torch.full_like(gap, float("inf")), gap)
         min_gap = torch.minimum(min_gap, gap.min(dim=1).values)
         step_gaps.append(gap.min(dim=1).values.numpy())
+        if follow is not None:
+            if t >= follow[0].shape[0]:                      # the followed search stopped earlier than this one would
+                f_short = True
+                break
+            eng = torch.as_tensor(follow[1][t].astype(np.int64)) * V + torch.as_tensor(follow[0][t].astype(np.int64))      # [B, K]
+            s_eng, s_ref = torch.gather(scores, 1, eng), torch.gather(scores, 1, order)
+            both_inf = torch.isinf(s_eng) & torch.isinf(s_ref) & (s_eng == s_ref)
+            dev = torch.where(both_inf, torch.zeros_like(s_ref), (s_eng - s_ref).abs() / torch.clamp(s_ref.abs(), min=1.0))
+            dev = torch.where(torch.isnan(dev), torch.full_like(dev, float("inf")), dev)
+            f_dev.append(dev.max(dim=1).values.numpy())
+            f_same.append((eng == order).all(dim=1).numpy())
+            srt = torch.sort(eng, dim=1).values
+            f_distinct.append(((srt[:, 1:] != srt[:, :-1]).all(dim=1) if K > 1 else torch.ones(B, dtype=torch.bool)).numpy())
+            order = eng
         word = order % V
         parent = order // V
         logp = torch.gather(total.reshape(B, K * V), 1, order)
@@ -1231,7 +1253,10 @@ def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Ba
     beams = gather_tree(sid, pid, lengths.max(dim=1).values.numpy(), eos)               # [T, B, K]
     ids = np.ascontiguousarray(beams.transpose(1, 0, 2))                                 # [B, T, K]
     if return_trace:        # per-step selections before gather_tree ([T, B, K]) and per-step near-tie gaps ([T, B]): see tests/test_gpu_beam.py
-        return ids, logp.numpy(), lengths.numpy(), dict(step_ids=sid, parent_ids=pid, gaps=np.stack(step_gaps))
+        tr = dict(step_ids=sid, parent_ids=pid, gaps=np.stack(step_gaps)[:sid.shape[0]])
+        if follow is not None:
+            tr.update(follow_dev=np.stack(f_dev), follow_same=np.stack(f_same), follow_distinct=np.stack(f_distinct), follow_short=f_short)
+        return ids, logp.numpy(), lengths.numpy(), tr
     if return_all:
         return ids, logp.numpy(), lengths.numpy(), min_gap.numpy()
     return ids[:, :, 0]

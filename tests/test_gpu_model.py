@@ -531,7 +531,10 @@ FULL_LENGTH = [
 @pytest.mark.parametrize("case,over", FULL_LENGTH)
 def test_full_length_train_step_and_greedy(case, over):
     from avsr_tf1_amd.model import Batch, Seq2SeqModel
-    O, ocfg, mcfg, W, batch = make(case, B=8 if os.environ.get("AVSR_LONG_TESTS") else 2, Ta=500, Tv=75, L=40, ragged=True, **over)
+    # the benchmark configuration (c4) runs 8 utterances -- one whole 8-row group of the persistent kernels -- in the default suite
+    # (round 5; about two minutes of fp64 oracle time), the other two configurations 2 (8 with AVSR_LONG_TESTS=1)
+    nb = 8 if (os.environ.get("AVSR_LONG_TESTS") or case == "c4_bimodal_uni") else 2
+    O, ocfg, mcfg, W, batch = make(case, B=nb, Ta=500, Tv=75, L=40, ragged=True, **over)
     ref = O.train_step(W, None, ocfg, batch)
     model = Seq2SeqModel(mcfg, weights=W)
     db = Batch.from_numpy(batch)

@@ -245,3 +245,36 @@ def test_beam_search_with_a_beam_that_never_prunes_finds_the_exhaustive_optimum(
         score, seq = best[0]
         want = seq + [eos] * (ids.shape[1] - len(seq))
         assert list(ids[b, :, 0]) == want[:ids.shape[1]], (b, list(ids[b, :, 0]), want, score)
+
+
+def test_beam_search_follow_mode_checks_every_step_of_another_search():
+    """`follow` (the test aid tests/test_gpu_beam.py uses on the engine's selections): following the oracle's own search reports zero
+    deviation and identical selections at every step and reproduces its result; a search that swaps two beams of a step (what fp32
+    rounding does at a near-tie) deviates by exactly their score gap and is followed onto ITS branch; a search that picks a
+    candidate from outside the top K deviates by far more than any rounding."""
+    V, eos, go = 7, 5, 6
+    cfg = O.OracleConfig(architecture="bimodal", audio_units=(8,), video_units=(8,), decoder_units=(8,), embedding_size=4, vocab_size=V,
+                         eos_id=eos, go_id=go, audio_feat=4, video_feat=4)
+    cfg.validate()
+    W = O.init_params(cfg, seed=7)
+    rng = np.random.default_rng(3)
+    W["dec/out/kernel"] = (rng.standard_normal(W["dec/out/kernel"].shape) * 2).astype(np.float32)
+    batch = O.synthetic_batch(cfg, B=3, T_a=6, T_v=4, L=3, ragged=True)
+    K, steps = 4, 6
+    ids, lp, ln, tr = O.beam_search_decode(W, cfg, batch, beam_width=K, max_steps=steps, return_trace=True)
+    ids2, lp2, ln2, tr2 = O.beam_search_decode(W, cfg, batch, beam_width=K, max_steps=steps, return_trace=True,
+                                               follow=(tr["step_ids"], tr["parent_ids"]))
+    assert (ids2 == ids).all() and np.array_equal(lp2, lp) and (ln2 == ln).all()
+    assert tr2["follow_same"].all() and tr2["follow_distinct"].all() and not tr2["follow_short"] and tr2["follow_dev"].max() == 0.0
+    # swap beams 1 and 2 of utterance 0 at step 1: deviation = their score gap, and the continuation follows the swapped order
+    sid, pid = tr["step_ids"].copy(), tr["parent_ids"].copy()
+    sid[1, 0, [1, 2]], pid[1, 0, [1, 2]] = sid[1, 0, [2, 1]], pid[1, 0, [2, 1]]
+    _i, _l, _n, tr3 = O.beam_search_decode(W, cfg, batch, beam_width=K, max_steps=2, return_trace=True, follow=(sid[:2], pid[:2]))
+    assert not tr3["follow_same"][1, 0] and tr3["follow_same"][1, 1:].all() and tr3["follow_same"][0].all()
+    assert 0.0 < tr3["follow_dev"][1, 0] < 10.0 and tr3["follow_distinct"].all()
+    assert (tr3["step_ids"][1, 0] == sid[1, 0]).all() and (tr3["parent_ids"][1, 0] == pid[1, 0]).all()
+    # a duplicate candidate is flagged
+    sid4, pid4 = tr["step_ids"].copy(), tr["parent_ids"].copy()
+    sid4[0, 2, 1], pid4[0, 2, 1] = sid4[0, 2, 0], pid4[0, 2, 0]
+    _i, _l, _n, tr4 = O.beam_search_decode(W, cfg, batch, beam_width=K, max_steps=1, return_trace=True, follow=(sid4[:1], pid4[:1]))
+    assert not tr4["follow_distinct"][0, 2] and tr4["follow_distinct"][0, :2].all()
