@@ -48,8 +48,8 @@ namespace avsr {
 // pq = cell_out . W_q for the group (one more hand-off per step), the scores are v . tanh(keys + pq + b), and -- output_attention
 // being False for this family -- the logits come from the cell output (split-K shares published with the cell phase).
 // V64: vocabularies of 33..64 symbols (`phoneme`: V = 41, io_utils.py:354-370): the (row, symbol) phases of the output layer use all 512
-// threads as 8 rows x 64 symbols (one wave per row) instead of 256 threads as 8 x 32, the output-kernel rows in LDS are 64 wide
-// (the resident values start 2 KB later), and the logit shares are [.][64].
+// threads as 8 rows x 64 symbols (one wave per row) instead of 256 threads as 8 x 32, the output-kernel rows in LDS are round4(V) wide
+// and the quarter's scores share the input-row buffer (round 5: no more LDS than the 32-symbol layout), the logit shares are [.][64].
 template <int KR0, int KR1, int MODE, int R, bool BAH = false, bool V64 = false>
 __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   static_assert(R == 8 || (R == 16 && MODE == 0), "16-row groups: attentive layer only");
@@ -63,13 +63,19 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   constexpr int RED_F = 256 * R;                // floats of the reduction buffer [8 waves][2 tiles][R][16]
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const red = lds;                       // [8][2][R][16] cell / [2][2][256] context partials / [8][R][16] attention layer / [8][32] exp
+  // V64: the quarter's scaled scores (written and read in P2 only) share the input-row buffer (read in P1, rewritten in P4: dead in
+  // between, every phase boundary is a workgroup barrier), and the output-kernel rows are as wide as the vocabulary needs (round4(V),
+  // not 64): 64 floats LESS ahead of the values than the 32-symbol layout at V = 41, so a phoneme model takes this kernel wherever a
+  // character model does -- also at the benchmark shape, whose memories fill LDS to the last 2 KB (round 4 declined it there).
+  constexpr int SPO = V64 ? 0 : 256;            // floats of the scores' own region
+  const int WOS = V64 ? ((L.V + 3) & ~3) : 32;  // row stride of the output-kernel rows in LDS
   float* const s_p = lds + RED_F;               // [2][128] scaled scores of this quarter (P2) ...
-  float* const s_x = lds + RED_F + 256;         // [8][128] input rows of the next step (MODE >= 1: R = 8)
-  float* const s_att = lds + RED_F + 1280;      // [R][16]  this workgroup's attention columns
-  int* const s_int = reinterpret_cast<int*>(lds + RED_F + 1280 + 16 * R + 32);   // [0..R) tokens, [R..2R) step lengths, [2R] slot, [2R+1] unfinished, [2R+8..+12) zero pad
-  constexpr int ZPAD = RED_F + 1280 + 16 * R + 32 + 2 * R + 8;                     // 4 zero floats: where operand slots of another source "read" LDS
-  float* const s_wo = lds + RED_F + 1280 + 16 * R + 32 + 2 * R + 16;             // [16][VW] this workgroup's rows of the output kernel
-  float* const vals = lds + (R == 8 ? DP_MISC + (V64 ? 512 : 0) : DP_MISC16);      // resident value rows of this workgroup's share
+  float* const s_x = lds + RED_F + SPO;         // [8][128] input rows of the next step (MODE >= 1: R = 8)
+  float* const s_att = lds + RED_F + SPO + 1024;      // [R][16]  this workgroup's attention columns
+  int* const s_int = reinterpret_cast<int*>(lds + RED_F + SPO + 1024 + 16 * R + 32);   // [0..R) tokens, [R..2R) step lengths, [2R] slot, [2R+1] unfinished, [2R+8..+12) zero pad
+  constexpr int ZPAD = RED_F + SPO + 1024 + 16 * R + 32 + 2 * R + 8;                     // 4 zero floats: where operand slots of another source "read" LDS
+  float* const s_wo = lds + RED_F + SPO + 1024 + 16 * R + 32 + 2 * R + 16;             // [16][WOS] this workgroup's rows of the output kernel
+  float* const vals = lds + (R == 8 ? DP_MISC + (V64 ? 16 * WOS - 512 - 256 : 0) : DP_MISC16);      // resident value rows of this workgroup's share
   static_assert(2048 + 1280 + 128 + 32 + 16 + 16 + 512 == DP_MISC, "8-row layout");
   static_assert(4096 + 1280 + 256 + 32 + 32 + 16 + 512 <= DP_MISC16, "16-row layout");
 
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
   const int ag0 = (wave * na) / DP_WV, naw = ((wave + 1) * na) / DP_WV - ag0;
   const int hg0 = (wave * nh) / DP_WV, nhw = ((wave + 1) * nh) / DP_WV - hg0;
   unsigned uk1[DP_CPW];                         // byte offset of the slot's chunk inside its global source row
-  const int uxa = nxw > 0 ? 2304 + (xg0 << 4) : -1;   // LDS float index of the input-row chunk
+  const int uxa = nxw > 0 ? RED_F + SPO + (xg0 << 4) : -1;   // LDS float index of the input-row chunk (s_x; MODE >= 1: R = 8)
   const int AW = L.AW, awsh = L.awsh, an0 = j * AW;
   const bool has_att = an0 < A;
   const int ma = has_att ? an0 / H : 0;
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         if (!BAH) { if (L.oa && has_att && k < AW) wv = L.wout_t[(long)v * A + an0 + k]; }
         else if (k < UW && unit0 + k < H) wv = L.wout_t[(long)v * H + unit0 + k];
       }
-      s_wo[e] = wv;
+      if (v < WOS) s_wo[k * WOS + v] = wv;
     }
     // (3b) Bahdanau: this workgroup's columns [unit0, unit0 + UW) of the query layer, K split over the waves like the attention layer's
     //      cell-output slots
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         const int pr = (tid >> VSH) & 7, pv = tid & (VW - 1);
         if (tid < 8 * VW && pv < V) {
           float sacc = 0.f;
-          for (int k = 0; k < UW; ++k) sacc += s_att[pr * 16 + k] * s_wo[k * VW + pv];
+          for (int k = 0; k < UW; ++k) sacc += s_att[pr * 16 + k] * s_wo[k * WOS + pv];
           L.plog[((((long)(l & 1) * 8 + g) * DP_NW + j) * DP_R + pr) * VW + pv] = sacc;
         }
       }
@@ -634,7 +640,7 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
       lds_barrier();
       if (!BAH && mode >= 1 && L.oa && has_att && tid < 8 * VW && pv < V) {
         float s = 0.f;
-        for (int k = 0; k < AW; ++k) s += s_att[pr * 16 + k] * s_wo[k * VW + pv];
+        for (int k = 0; k < AW; ++k) s += s_att[pr * 16 + k] * s_wo[k * WOS + pv];
         L.plog[((((long)(l & 1) * 8 + g) * DP_NW + j) * DP_R + pr) * VW + pv] = s;
       }
       DTICK(7)
@@ -688,8 +694,8 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
             if (id == L.eos_id) s_int[R + r] = l + 1; else unfin = true;
           }
           if (j == 0 && b < B) L.ids[(long)b * Ls + l] = id;
-          if (l == L.l_end - 1) {
-            const int cnt = __popcll(__ballot(unfin));
+          {
+            const int cnt = __popcll(__ballot(unfin));      // rows of this group still decoding after step l
             if (tid == 0) s_int[2 * R + 1] = cnt;
           }
         } else if (l + 1 < Ls && b < B) {
@@ -740,6 +746,11 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         }
       }
       lds_barrier();
+      // greedy decode: every utterance of this group has emitted EOS -- dynamic_decode(impute_finished=True) emits zeros from here on and
+      // the ids buffer is zeroed by the caller, so the group stops.  Every workgroup of the group holds the same tokens and step
+      // lengths, hence takes this exit at the same step: nobody is left waiting for a hand-off.  (The host can therefore queue all
+      // maximum_iterations steps as ONE launch instead of chunks with a host check in between.)
+      if (mode == 1 && s_int[2 * R + 1] == 0) break;
     }
     DTICK(10)
   }
@@ -833,8 +844,8 @@ int dp_plan(const avsr_attn_rnn& d, DPLaunch& L, int* variant, size_t* lds_bytes
     X.lds_off = lds_off; lds_off += X.ch * M.D;
     X.ppm = ws; ws += 4L * B; X.ppl = ws; ws += 4L * B; X.ppctx = ws; ws += 4L * B * M.D;
   }
-  const bool v64 = d.mode >= 1 && d.V > 32;                                        // 64-wide output-kernel rows: 2 KB more ahead of the values
-  const size_t bytes = sizeof(float) * ((size_t)(L.R == 16 ? DP_MISC16 : DP_MISC + (v64 ? 512 : 0)) + lds_off);
+  const bool v64 = d.mode >= 1 && d.V > 32;                                        // output-kernel rows round4(V) wide, scores in the input-row buffer
+  const size_t bytes = sizeof(float) * ((size_t)(L.R == 16 ? DP_MISC16 : DP_MISC + (v64 ? 16 * ((d.V + 3) & ~3) - 512 - 256 : 0)) + lds_off);
   if (bytes > DP_LDS_BYTES) return AVSR_ERR_UNSUPPORTED;
   *lds_bytes = bytes;
   // register-resident key capacity (32 frames per pass): variant 0 = one mechanism up to 128 frames per quarter;

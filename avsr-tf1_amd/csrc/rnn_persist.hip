@@ -428,11 +428,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int in_W = tk.in_W, in_coff = tk.in_coff;
 
   // wave 0: wait until own progress >= need_own and lower progress >= need_low (bounded)
-  // first: a poll value fetched earlier (the caller issued the load ahead of work that does not depend on the hand-off)
-  auto wait_progress = [&](int need_own, int need_low, int first = -1) {
+  auto wait_progress = [&](int need_own, int need_low) {
     if (wave != 0) return;
     const int need = lane < 32 ? need_own : need_low;
-    if (__all(first >= need)) return;
     for (int spins = 0; spins < (1 << 21); ++spins) {
       const int v = poll_ptr ? __hip_atomic_load(poll_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
       if (__all(v >= need)) return;
@@ -476,28 +474,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     asm volatile("" : "+v"(zpre));
     // dependencies: step t-1 of this layer (all column tiles of my rows); the layer below one step ahead
     // (PT: the pair (t+1, t+2) is requested during the odd step t, so the layer below must then be three steps on)
-#ifdef RNN_XPRE
-    // The input part of this step (PT: of the pair of steps starting here) needs nothing of the hand-off: its operands were fetched a step
-    // ago.  Wave 0 requests the progress words, every wave runs its input-part MFMAs under that round trip, then the words are looked at.
-    int poll0 = -1;
-    if (wave == 0) poll0 = poll_ptr ? __hip_atomic_load(poll_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
-    if (!hoisted && (!PT || !(t & 1))) {
-      f32x4 ax[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int c = 0; c < P_XC; ++c)
-        if (c < nxw) {
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              ax[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xcur[c][e], Q4 ? wq[Q4 ? 8 + 2 * c + nt : 0][e] : wa[c][nt][e], ax[nt], 0, 0, 0);
-        }
-      accx[0] = ax[0]; accx[1] = ax[1];
-    }
-    wait_progress(t, PT ? ((t & 1) ? (t + 3 < T ? t + 3 : T) : 0) : (t + 2 < T ? t + 2 : T), poll0);
-#else
     wait_progress(t, PT ? ((t & 1) ? (t + 3 < T ? t + 3 : T) : 0) : (t + 2 < T ? t + 2 : T));
-#endif
     lds_barrier();
     TICK(0)
     const bool avalid = aok && t < len_a && (!PT || sub == (t & 1));
@@ -522,13 +499,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!hoisted) {
-#ifdef RNN_XPRE
-      acc[0] = accx[0]; acc[1] = accx[1];
-      if (false) {
-#else
       // input part first: its operands arrived a step ago, so these MFMAs run under the loads just issued
       if (!PT || !(t & 1)) {
-#endif
 #pragma unroll
         for (int c = 0; c < P_XC; ++c)
           if (c < nxw) {

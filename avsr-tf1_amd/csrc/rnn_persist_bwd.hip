@@ -332,10 +332,19 @@ __device__ __forceinline__ float ldb1_sc1(__amdgpu_buffer_rsrc_t r, int byte_off
   return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 16));
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void rnn_persist_bwdk_kernel(const BLaunch L) {
-  __shared__ __attribute__((aligned(16))) float red[8][16][16];
-  __shared__ __attribute__((aligned(16))) float dgs[16][68];
-  __shared__ __attribute__((aligned(16))) float stg[8][16][36];
+// NW: waves per workgroup.  8 = 512 threads owning 16 units (two workgroups per CU).  16 (round 5) = 1024 threads owning 32 units, one
+// workgroup per CU: a cell then has HALF as many producers -- half the partial-slab bytes through the XCD's L2 per step and half the
+// partial loads per consumer -- with the same matrix work and registers per wave (one 16-column tile of the partial d h with K = 128
+// instead of two with K = 64).  tools/handoff_probe.hip: the bare exchange of this kernel's pattern costs 1.73 us per step with 16
+// producers of 512 threads and 1.22 us with 8 of 1024.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void rnn_persist_bwdk_kernel(const BLaunch L) {
+  constexpr int UW = 2 * NW, UWSH = NW == 8 ? 4 : 5;       // units per workgroup
+  constexpr int TPW = 16 / NW;                              // 16-column tiles of the partial d h per wave (H <= 256)
+  constexpr int KC = UW / 4;                                // 16-deep chunks of the workgroup's own gate columns
+  __shared__ __attribute__((aligned(16))) float red[NW][16][16];
+  __shared__ __attribute__((aligned(16))) float dgs[16][UW * 4 + 4];
+  __shared__ __attribute__((aligned(16))) float stg[NW][16][TPW * 16 + 4];
   __shared__ int s_slot;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int xcc = __builtin_amdgcn_readfirstlane(xcc_id());
@@ -353,13 +362,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int ct = slot - tk.slot_begin;
   const int H = tk.H, T = tk.T, reverse = tk.reverse, nct = tk.nct;
   const bool helper = tk.kind == 1;
-  const int unit0 = ct * 16, row0 = L.b0 + g * 16;
+  const int unit0 = ct * UW, row0 = L.b0 + g * 16;
   const int i = lane & 15, q = lane >> 4;
 
-  // ---- ownership of (row, unit) by threads 0..255 for all steps ----
-  const int er = (tid & 255) >> 4, eu = tid & 15;
+  // ---- ownership of (row, unit) by threads 0 .. 16 * UW - 1 for all steps ----
+  const int er = (tid & (16 * UW - 1)) >> UWSH, eu = tid & (UW - 1);
   const int b = row0 + er, u = unit0 + eu;
-  const bool eok = tid < 256 && b < tk.B && u < H;
+  const bool eok = tid < 16 * UW && b < tk.B && u < H;
   const int len_b = eok ? (tk.len ? tk.len[b] : T) : 0;
   const int rec_b = b * T * H + u;
   const bool drop_on = tk.seed != nullptr;
@@ -407,10 +416,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // ================= HELP: dx(t) = input mask . (d gates of the layer above at step t) . Wx^T, by units, K over the 8 waves.
     // No recurrence: it follows the cell above as closely as that cell publishes, off every step-to-step chain. =================
     const int K_up = 4 * tk.H_up, ncu = K_up >> 4;
-    const int b0 = (wave * ncu) / 8, nB = ((wave + 1) * ncu) / 8 - b0;
+    const int kw = wave & 7, tl = wave >> 3;               // K eighth / 16-unit tile of this wave
+    const int b0 = (kw * ncu) / 8, nB = ((kw + 1) * ncu) / 8 - b0;
     f32x4 wB[B_CH];
     {
-      const int uu = unit0 + i;
+      const int uu = unit0 + tl * 16 + i;
 #pragma unroll
       for (int c = 0; c < B_CH; ++c)
         wB[c] = (c < nB && uu < H) ? ld4(tk.w_up + (long)uu * tk.ldw_up + (b0 + c) * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const long bt = (long)b * T + tau;
         float z = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) z += red[w][er][eu];
+        for (int w = 0; w < 8; ++w) z += red[(eu >> 4) * 8 + w][er][eu & 15];
         const float v = z * p_drop(drop_on, seedv, r_in, (uint32_t)(bt * in_W + in_coff + u), k_in);
         if (publish_remote) st_sc1(dx_p + bt * H + u, v);
         else dx_p[bt * H + u] = v;
@@ -455,12 +465,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   // ================= CELL =================
   // my 64 rows of Wh^T for two 16-unit column tiles per wave (product by K), resident for the whole sequence
-  f32x4 wR[2][4];
+  f32x4 wR[TPW][KC];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int n = (wave * 2 + nt) * 16 + i;
+  for (int nt = 0; nt < TPW; ++nt) {
+    const int n = (wave * TPW + nt) * 16 + i;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < KC; ++c)
       wR[nt][c] = (n < H && unit0 * 4 + c * 16 + 4 * q < 4 * H) ? ld4(tk.w_own + (long)n * tk.ldw_own + unit0 * 4 + c * 16 + 4 * q)
                                                               : f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -530,7 +540,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     KTICK(1)
 #endif
     // ---- LSTM cell backward (same arithmetic as EP_LSTM_BWD in step.hip; dx already carries the layer above's input mask) ----
-    if (tid < 256) {
+    if (tid < 16 * UW) {
       f32x4 dg = {0.f, 0.f, 0.f, 0.f};
       const bool valid = eok && t < len_b;
       int tau = t;
@@ -562,31 +572,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     KTICK(2)
     // ---- my K slice of the recurrent product: [16 x 64] d gates . 64 rows of Wh^T -> partial d h of ALL units, two tiles per wave ----
     {
-      f32x4 A[4];
+      f32x4 A[KC];
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) A[cc] = *reinterpret_cast<const f32x4*>(&dgs[i][cc * 16 + 4 * q]);
+      for (int cc = 0; cc < KC; ++cc) A[cc] = *reinterpret_cast<const f32x4*>(&dgs[i][cc * 16 + 4 * q]);
       float* const dst = part_p + ((long)((t & 1) * nct + ct) * tk.B) * H;
       {
         // the two column tiles' accumulator chains alternate (one after the other they are 2 x 16 DEPENDENT MFMAs: 40 cycles each
         // instead of 32)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        if constexpr (TPW == 2) {
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
+          for (int cc = 0; cc < KC; ++cc)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cc][e], wR[0][cc][e], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cc][e], wR[1][cc][e], acc1, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0x7F6);           // MFMAs keep this order (everything else may move across)
-          }
+            for (int e = 0; e < 4; ++e) {
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cc][e], wR[0][cc][e], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cc][e], wR[TPW - 1][cc][e], acc1, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0x7F6);           // MFMAs keep this order (everything else may move across)
+            }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { stg[wave][q * 4 + r][i] = acc0[r]; stg[wave][q * 4 + r][16 + i] = acc1[r]; }
+          for (int r = 0; r < 4; ++r) { stg[wave][q * 4 + r][i] = acc0[r]; stg[wave][q * 4 + r][(TPW - 1) * 16 + i] = acc1[r]; }
+        } else {
+          // one column tile per wave, K = 128: the chunk pairs' chains alternate (same reason)
+#pragma unroll
+          for (int cc = 0; cc < KC; cc += 2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cc][e], wR[0][cc][e], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[cc + 1][e], wR[0][cc + 1][e], acc1, 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0x7F6);
+            }
+          acc0 += acc1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stg[wave][q * 4 + r][i] = acc0[r];
+        }
       }
-      // the wave's [16 x 32] tile leaves as whole 128-byte rows, 16 bytes per lane (narrow stores retire one by one ahead of the drain)
+      // the wave's [16 x 32] ([16 x 16]) tile leaves as whole 128-byte (64-byte) rows, 16 bytes per lane (narrow stores retire one by one
+      // ahead of the drain)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int idx = lane + 64 * j, rr = idx >> 3, c4 = idx & 7;
+      for (int j = 0; j < TPW; ++j) {
+        const int idx = lane + 64 * j, rr = idx / (4 * TPW), c4 = idx % (4 * TPW);
         const f32x4 v = *reinterpret_cast<const f32x4*>(&stg[wave][rr][c4 * 4]);
-        const int n = wave * 32 + c4 * 4, rb = row0 + rr;
+        const int n = wave * (16 * TPW) + c4 * 4, rb = row0 + rr;
         if (n < H && rb < tk.B) st4(dst + (long)rb * H + n, v);
       }
     }
@@ -633,19 +659,29 @@ static_assert(sizeof(BLaunch) <= 4000, "launch descriptor must fit the kernel-ar
 #include <cstdlib>
 // AVSR_PERSIST_DEBUG=1 prints which precondition sent a call back to the per-step launches
 #define UNSUP(code) do { if (getenv("AVSR_PERSIST_DEBUG")) fprintf(stderr, "[avsr] persistent BPTT not used: reason %d (rnn_persist_bwd.hip)\n", code); return AVSR_ERR_UNSUPPORTED; } while (0)
-static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry, bool ksplit);
+static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry, bool ksplit, bool wide);
 
 int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry) {
-  // the K-split kernel first (16-unit cells everywhere, 32 workgroups per XCD); configurations it declines take the kernel above
+  // the K-split kernel first: 16-unit workgroups of 512 threads; configurations it declines take the kernel above.  AVSR_RNN_BWD_WIDE=1
+  // selects the 32-unit / 1024-thread form where every layer allows and the tasks fit: built in round 5 on the strength of
+  // tools/handoff_probe.hip (the bare exchange 1.73 -> 1.22 us per step), same results (232 parity tests), and measured SLOWER in the
+  // real kernel -- c4 4.28 -> 4.77 us per sequential step, c2 4.52 -> 4.67, c5 4.62 -> 4.79 (profiles/r05_experiments.txt): with one
+  // 16-wave workgroup per CU every in-step barrier waits for sixteen waves and nothing else runs on the CU meanwhile.  Off by default.
   static const int ksplit = getenv("AVSR_RNN_BWD_KSPLIT") ? atoi(getenv("AVSR_RNN_BWD_KSPLIT")) : 1;
-  if (ksplit) {
-    const int rc = bwd_persistent(st, n, stream, dry, true);
+  static const int wide = getenv("AVSR_RNN_BWD_WIDE") ? atoi(getenv("AVSR_RNN_BWD_WIDE")) : 0;
+  if (ksplit && wide) {
+    const int rc = bwd_persistent(st, n, stream, dry, true, true);
     if (rc != AVSR_ERR_UNSUPPORTED) return rc;
   }
-  return bwd_persistent(st, n, stream, dry, false);
+  if (ksplit) {
+    const int rc = bwd_persistent(st, n, stream, dry, true, false);
+    if (rc != AVSR_ERR_UNSUPPORTED) return rc;
+  }
+  return bwd_persistent(st, n, stream, dry, false, false);
 }
 
-static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry, bool ksplit) {
+static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry, bool ksplit, bool wide) {
+  const int UWH = wide ? 32 : 16;                    // units per workgroup of the K-split kernel
   using namespace avsr;
   int32_t* sync = g_sync; const int64_t sync_ints = g_sync_ints;
   if (!sync || !(g_persist_mode & 2)) return AVSR_ERR_UNSUPPORTED;
@@ -678,8 +714,9 @@ static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int
       if (top) { tk.dh_final = S.dh_final; tk.dc_final = S.dc_final; }
       tk.B = S.B; tk.T = S.T; tk.H = H; tk.reverse = S.reverse;
       flops += 2.0 * S.B * S.T * (4.0 * H + (top ? 0.0 : 4.0 * S.layer[l + 1].units)) * H;
+      if (wide && H % 32) UNSUP(14);
       tk.ntile = (!ksplit && top && H % 32 == 0) ? 2 : 1;
-      tk.nct = H / (16 * tk.ntile);
+      tk.nct = ksplit ? H / UWH : H / (16 * tk.ntile);
       if (tk.nct > 32) UNSUP(8);
       if (ksplit) {
         if (tk.nct > 16 || (long)2 * tk.nct * S.B * H * 4 >= (1L << 30)) UNSUP(11);
@@ -704,7 +741,7 @@ static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int
         hk.kind = 1;
         hk.w_up = Up.w; hk.ldw_up = 4 * Up.units; hk.H_up = Up.units; hk.up_dgates = Up.dgates;
         hk.len = S.len; hk.B = S.B; hk.T = S.T; hk.H = H; hk.reverse = S.reverse;
-        hk.ntile = 1; hk.nct = H / 16;
+        hk.ntile = 1; hk.nct = H / UWH;
         const long need = (long)S.B * S.T * H;
         if (part_used + need > g_persist_scratch_floats) UNSUP(13);
         hk.dx = g_persist_scratch + part_used; part_used += need;
@@ -727,9 +764,10 @@ static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int
   static const int solo_on = getenv("AVSR_RNN_BWD_SOLO") ? atoi(getenv("AVSR_RNN_BWD_SOLO")) : 1;
   int total_cost = 0;
   for (int i = 0; i < L.ntask; ++i) total_cost += cost[i];
-  const bool solo = ksplit && solo_on && B > 64 && total_cost <= 64;      // one XCD per 16-row group, 128 rows per launch
+  const int cap = ksplit ? (wide ? 32 : 64) : 28;                         // workgroup slots of an XCD (1024 threads: one per CU)
+  const bool solo = ksplit && solo_on && B > 64 && total_cost <= cap;     // one XCD per 16-row group, 128 rows per launch
   if (solo) { for (int i = 0; i < L.ntask; ++i) half[i] = 0; ngroups = 8; }
-  else if (!assign_halves(cost, upper, L.ntask, ksplit ? 64 : 28, half, ksplit ? ecost : nullptr)) UNSUP(9);
+  else if (!assign_halves(cost, upper, L.ntask, cap, half, ksplit ? ecost : nullptr)) UNSUP(9);
   long words = P_HDR + 8;
   int slots[2] = {0, 0};
   // slots are claimed in arrival order and the dispatcher fills every CU once before it doubles up: cells take the first slots (a CU
@@ -764,7 +802,8 @@ static int bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int
     if (avsr::dev_zero(sync + P_HDR, sizeof(int32_t) * (words - P_HDR), s) != hipSuccess) return AVSR_ERR_HIP;
     {
       ProfScope ps(PROF_RNN_PERSIST_BWD, s, flops * rows / B);
-      if (ksplit) hipLaunchKernelGGL(rnn_persist_bwdk_kernel, dim3(8 * wpx), dim3(512), 0, s, L);
+      if (ksplit && wide) hipLaunchKernelGGL(rnn_persist_bwdk_kernel<16>, dim3(8 * wpx), dim3(1024), 0, s, L);
+      else if (ksplit) hipLaunchKernelGGL(rnn_persist_bwdk_kernel<8>, dim3(8 * wpx), dim3(512), 0, s, L);
       else hipLaunchKernelGGL(rnn_persist_bwd_kernel, dim3(8 * wpx), dim3(512), 0, s, L);
     }
     AVSR_CHECK_LAUNCH();

