@@ -138,7 +138,9 @@ def test_batchnorm_forward_backward(rows, F, relu):
     # pixel-pair rows (8 destination channels, even width) next to the odd width that cannot pair; stride-2 data gradients with all four
     # parity classes in one launch on even and odd maps (partial 2x2 cells), 8 and 16 channels
     (3, 7, 8, 8, 3, 1, False, False), (3, 10, 8, 8, 3, 1, False, True), (5, 9, 16, 32, 3, 2, False, False), (4, 11, 8, 16, 3, 2, False, False),
-    (3, 18, 16, 32, 3, 2, False, False), (70, 6, 8, 16, 3, 2, False, False)])
+    (3, 18, 16, 32, 3, 2, False, False), (70, 6, 8, 16, 3, 2, False, False),
+    # projection shortcuts on odd maps, many frames (several pixel tiles per workgroup), 4 -> 4 and 64 -> 64 channels
+    (5, 11, 8, 16, 1, 2, False, False), (300, 18, 16, 32, 1, 2, False, False), (33, 5, 64, 64, 1, 2, False, False), (9, 7, 4, 4, 1, 2, False, False)])
 def test_conv_desc_forward_and_gradients(N, H, Ci, Co, k, s, bn, res):
     from avsr_tf1_amd import ops
     rng = np.random.default_rng(H * 100 + Ci * 10 + Co + s + k)
@@ -172,6 +174,16 @@ def test_conv_desc_forward_and_gradients(N, H, Ci, Co, k, s, bn, res):
     part = stats[:n * 2 * Co].view(n, 2, Co).double().sum(0).cpu().numpy()
     assert np.abs(part[0] - yr.sum((0, 1, 2))).max() <= 1e-4 * max(1.0, np.abs(yr).sum((0, 1, 2)).max())
     assert np.abs(part[1] - (yr ** 2).sum((0, 1, 2))).max() <= 1e-4 * (yr ** 2).sum((0, 1, 2)).max()
+    if k == 1 and s == 2 and not res:
+        # the projection shortcuts of the network run without statistics and, in one layout, without a bias gradient
+        y2 = torch.full((N, Ho, Wo, Co), -3.0, device="cuda")
+        ops.conv_fwd(d, xd, wd, bd, y2, None, None, None)
+        torch.cuda.synchronize()
+        assert _close(y2.cpu().numpy(), yr)
+        dw2 = torch.full((k, k, Ci, Co), 0.5, device="cuda")
+        ops.conv_bwd_weight(d, xd, dyd, dw2, None, torch.empty(1 << 22, device="cuda"))     # (without the bias gradient)
+        torch.cuda.synchronize()
+        assert _close(dw2.cpu().numpy() - 0.5, w.grad.numpy(), 5e-5)
     dw = torch.full((k, k, Ci, Co), 0.5, device="cuda")
     db = torch.full((Co,), -0.25, device="cuda")
     scratch = torch.empty(1 << 22, device="cuda")

@@ -34,10 +34,11 @@ def _shard(O, b, lo, hi):
                       for k in ("audio", "audio_len", "video", "video_len", "aus", "labels", "labels_len")})
 
 
-def _worker(rank, world, port, out_dir, use_graph, overlap, odd, persistent=False):
+def _worker(rank, world, port, out_dir, use_graph, overlap, odd, persistent=False, drain="1", steps=STEPS):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["AVSR_DP_DRAIN"] = drain
     # persistent=False: two processes on ONE GPU do not both claim the chip.  persistent=True: they do -- each rank's shard (<= 8
     # utterances) is one row group, i.e. BOTH ranks' persistent encoder / fused decoder kernels want the workgroup slots of XCD 0 at
     # the same time.  The dispatcher may run them side by side, one after the other, or interleave them so that a bounded wait
@@ -54,10 +55,11 @@ def _worker(rank, world, port, out_dir, use_graph, overlap, odd, persistent=Fals
     model = Seq2SeqModel(mcfg, weights=W)
     trainer = DataParallelTrainer(model, dist, use_graph=use_graph)
     batch = Batch.from_numpy(_shard(O, full, cut[rank], cut[rank + 1]))
-    for _ in range(STEPS):
+    for _ in range(steps):
         trainer.train_step(batch)
     torch.cuda.synchronize()
     assert (trainer._bucket is not None) == bool(overlap)
+    assert trainer.drain_around_collectives == (drain != "0")
     from avsr_tf1_amd import ops
     assert not ops.rnn_persistent_error()            # every flagged pass was redone and the flag cleared (check_every_step)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mode=np.array(trainer.mode), sync_bn=np.array(trainer.sync_bn),
@@ -117,6 +119,35 @@ def test_two_ranks_equal_one_engine_on_the_whole_batch(tmp_path, use_graph, over
     for k, v in ref.items():
         assert np.array_equal(r0[k], r1[k]), k                       # replicas stay bit-identical
         assert np.abs(r0[k] - v).max() < 5e-6 + 1e-4 * np.abs(v).max() * 0.01, (k, np.abs(r0[k] - v).max())
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_ranks_without_the_stream_drains_around_the_collectives(tmp_path, overlap, monkeypatch):
+    """AVSR_DP_DRAIN=0: graph replays and the collectives queued back to back, no host wait in between (the default drains the stream on
+    both sides of every collective -- two host round trips per step -- as belt and braces after the round-1 memset / memcpy-node finding,
+    DESIGN.md section 5).  Twelve queued steps with graphs (and the overlapped decoder bucket) must leave both replicas bit-identical
+    and equal to one engine on the whole batch.  Transport here is gloo (device-to-host copy, host reduction, copy back between the
+    graph launches -- the very pattern that misbehaved with memcpy nodes INSIDE the graphs); RCCL's kernels cannot be run with two
+    ranks on a one-GPU box, so the default stays 1 until a multi-GPU run has been seen."""
+    import torch.multiprocessing as mp
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path), True, overlap, False, False, "0", 12), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert str(r0["mode"]).startswith("hipgraph")
+    monkeypatch.setenv("AVSR_PERSISTENT_RNN", "0")
+    O, mcfg, W, full = _setup(False)
+    model = Seq2SeqModel(mcfg, weights=W)
+    batch = Batch.from_numpy(full)
+    for _ in range(12):
+        model.train_step(batch)
+    torch.cuda.synchronize()
+    ref = model.export_tf_weights("params")
+    for k, v in ref.items():
+        assert np.array_equal(r0[k], r1[k]), k
+        assert np.abs(r0[k] - v).max() < 2e-5 + 3e-4 * np.abs(v).max(), (k, np.abs(r0[k] - v).max())
 
 
 # ------------------------------------------------------------------------------------------------
