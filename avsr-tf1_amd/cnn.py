@@ -15,6 +15,8 @@ gradient kernel also produces the bias gradient.  Shapes those kernels do not co
 transposed GEMM + avsr_col2im, weight gradient = split-K TN GEMM), with BN through avsr_batchnorm_fwd_ex / avsr_batchnorm_bwd.
 This file only owns buffers and the op order; all arithmetic is in csrc/conv_mfma.hip, conv_direct.hip, conv.hip, gemm.hip,
 elementwise.hip."""
+import os
+
 import torch
 
 from . import ops
@@ -191,6 +193,20 @@ class LipCNN:
             self.bnb_stat[name], self.bnb_k[name] = z(512 * 2 * c), z(3 * c)
             if len(readers) == 2 and readers[1][0] == "add":
                 self.acc_ok.add(dst)
+        # Batch-norm backward folded into the weight gradient of the convolution that PRODUCED the batch norm's input (round 5): when that
+        # convolution has no data gradient (its source is the crops) the gradient of its output has exactly one reader -- its weight
+        # gradient -- which evaluates dx = k1*dz + k2*x + k3 while it fetches the operand (avsr_conv_bwd_weight_bn): the stand-alone
+        # avsr_bn_bwd_apply pass over three 199 MB maps of layer 0 disappears.
+        self.fold_wg = {}                                        # bn name -> producing conv name
+        for op in self.ops:
+            if op[0] != "bnrelu" or op[1] not in self.bnb:
+                continue
+            prod = by_dst.get(op[2])
+            if os.environ.get("AVSR_CNN_FOLD", "1") != "0" and prod is not None and prod[2] == "in" and prod[1] in self.mfma and \
+                    self.consumers.get(op[2], 0) == 1 and \
+                    ops.conv_bwd_weight_bn_supported(ops.conv_desc(*self.mfma[prod[1]])):
+                self.fold_wg[op[1]] = prod[1]
+        self.fold_src = {}
         for name, (h, w, c) in self.shapes.items():
             if name == "in":
                 continue
@@ -353,7 +369,7 @@ class LipCNN:
         gout = self.gmaps["out"].view(N, -1)
         self._copy(dfeat, gout)
         written.add("out")
-        self.bnb_rows, self.acc_src = {}, {}
+        self.bnb_rows, self.acc_src, self.fold_src = {}, {}, {}
         ops.slab_defer_begin()
         try:
             for op in reversed(self.ops):
@@ -402,12 +418,19 @@ class LipCNN:
                         sync(buf[:2 * c + 1])
                         ops.bn_bwd_finalize_f64(loc, buf, c, mean, invstd, self._pv(name + "/gamma"), gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c],
                                                 self.bnb_k[name], grad_beta=0.0)
-                        ops.bn_bwd_apply(self.gmaps[dst], self.maps[src], self.bnb_k[name], g, N * h * w, c, beta=beta)
+                        if name in self.fold_wg and beta == 0.0:
+                            self.fold_src[src] = (self.gmaps[dst], self.maps[src], self.bnb_k[name])
+                        else:
+                            ops.bn_bwd_apply(self.gmaps[dst], self.maps[src], self.bnb_k[name], g, N * h * w, c, beta=beta)
                         continue
                     if name in self.bnb_rows:            # stage 1 ran in the producing data gradient's epilogue: gmaps[dst] holds dz
                         ops.bn_bwd_finalize(self.bnb_stat[name], self.bnb_rows.pop(name), c, N * h * w, mean, invstd, self._pv(name + "/gamma"),
                                             gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c], self.bnb_k[name], grad_beta=0.0)
-                        ops.bn_bwd_apply(self.gmaps[dst], self.maps[src], self.bnb_k[name], g, N * h * w, c, beta=beta)
+                        if name in self.fold_wg and beta == 0.0:
+                            # the one reader of this gradient -- the producing convolution's weight gradient -- evaluates it in its loader
+                            self.fold_src[src] = (self.gmaps[dst], self.maps[src], self.bnb_k[name])
+                        else:
+                            ops.bn_bwd_apply(self.gmaps[dst], self.maps[src], self.bnb_k[name], g, N * h * w, c, beta=beta)
                         continue
                     ops.batchnorm_bwd(self.maps[src], self.gmaps[dst], self._pv(name + "/gamma"), self._pv(name + "/beta"), mean, invstd, g,
                                       gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c], N * h * w, c, 1, m.scratch, dx_beta=beta)
@@ -422,7 +445,11 @@ class LipCNN:
                     if name in self.mfma:
                         x, bn = self._src(src)
                         d = ops.conv_desc(*self.mfma[name], bn=bn)
-                        ops.conv_bwd_weight(d, x, self.gmaps[dst], gk.t[gk.off:], gb.t[gb.off:], self.wg_scratch[self.wg_off[name]:])
+                        fold = self.fold_src.pop(dst, None)
+                        if fold is not None:
+                            ops.conv_bwd_weight_bn(d, x, fold[0], fold[1], fold[2], gk.t[gk.off:], gb.t[gb.off:], self.wg_scratch[self.wg_off[name]:])
+                        else:
+                            ops.conv_bwd_weight(d, x, self.gmaps[dst], gk.t[gk.off:], gb.t[gb.off:], self.wg_scratch[self.wg_off[name]:])
                         fused_bn = self.bnb_conv.get(name)
                         if src != "in" and fused_bn is not None and src in self.lazy:
                             g, beta = target(src)

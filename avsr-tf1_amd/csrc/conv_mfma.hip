@@ -547,6 +547,11 @@ struct WGArgs {
   int slab, want_bias;                    // floats per workgroup partial: nt*Ci*Co (+ Co column sums of dy = the bias gradient)
   const float* bn_sc; const float* bn_sh; // BN-ReLU applied to x while staging (see CGArgs)
   int dbg;                                // CONV_DEBUG builds: bit 3 = per-wave cycle stamps behind the partial slabs
+  // FOLD (round 5): dy is not stored -- it is the batch-norm backward's output gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) =
+  // k1[c]*dz + k2[c]*y + k3[c] of the convolution's OWN output y (avsr_bn_bwd_finalize's coefficient vectors fk [3*fC]), evaluated while
+  // the operand is fetched: `dy` points at dz, fy at y (same layout).  For a convolution whose only gradient consumer is this kernel
+  // (layer 0: its input are the lip crops) the stand-alone avsr_bn_bwd_apply pass over three maps disappears.
+  const float* fy; const float* fk; int fC;
 };
 
 // 8 destination channels, stride 1, linear destination (the 36x36 layers: layer 0 and residual block 0, forward and data gradient): the
@@ -825,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
 // RS (row split): the four waves own DIFFERENT row tiles (wave w: rows [w*MT*16, (w+1)*MT*16)) and each walks every chunk, instead of
 // all waves sharing MT row tiles and splitting the chunks: a deep layer whose (tap, channel) rows exceed one wave's accumulators then
 // takes ONE launch -- its input staged once -- instead of one per tap group, and no cross-wave reduction at the end.
-template <int MT, int NTC, bool CH4, bool RS = false>
+template <int MT, int NTC, bool CH4, bool RS = false, bool FOLD = false>
 __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kernel(const WGArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -938,6 +943,17 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   // depth = output positions; a chunk = 16 positions of ONE frame (the last chunk of a frame is partial), lane quad q takes
   // positions 4q .. 4q+3 of the chunk; chunks are dealt to the waves round-robin.
   const __amdgpu_buffer_rsrc_t dy_rs = make_rsrc(A.dy);
+  const __amdgpu_buffer_rsrc_t fy_rs = make_rsrc(FOLD ? A.fy : A.dy);
+  float fk1[NTC], fk2[NTC], fk3[NTC];                    // FOLD: coefficients of this lane's column(s)
+#pragma unroll
+  for (int nt = 0; nt < NTC; ++nt) {
+    fk1[nt] = 1.f; fk2[nt] = 0.f; fk3[nt] = 0.f;
+    if (FOLD) {
+      const int col = nt * 16 + i, ch = col % A.fC;
+      const bool okc = col < Co;
+      fk1[nt] = okc ? A.fk[ch] : 0.f; fk2[nt] = okc ? A.fk[A.fC + ch] : 0.f; fk3[nt] = okc ? A.fk[2 * A.fC + ch] : 0.f;
+    }
+  }
   const int cpf = (opf + 15) >> 4;                       // chunks per frame
   const unsigned m_cpf = fmagic_dev(cpf);
   int n0 = n_begin;
@@ -957,7 +973,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
     WG_STAMP(w_commit)
     const int kch = fcur * cpf;
     const unsigned dyo = (unsigned)((long)n0 * opf * Co * 4);     // [fcur][opf][Co]
-    float bn[NTC][4];
+    float bn[NTC][4], byn[FOLD ? NTC : 1][4];
     auto load_b = [&](int kc, float (&b)[NTC][4]) {
       // unconditional buffer loads (positions beyond the frame / columns beyond Co: out-of-range offset = 0)
       const int f = fdiv(kc, m_cpf), r0 = (kc - f * cpf) * 16 + q * 4;
@@ -965,7 +981,11 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) b[nt][e] = ldb1(dy_rs, (r0 + e < opf && nt * 16 + i < Co) ? (int)(o + (unsigned)((e * Co + nt * 16) * 4)) : P_OOB);
+        for (int nt = 0; nt < NTC; ++nt) {
+          const int off = (r0 + e < opf && nt * 16 + i < Co) ? (int)(o + (unsigned)((e * Co + nt * 16) * 4)) : P_OOB;
+          b[nt][e] = ldb1(dy_rs, off);
+          if (FOLD) byn[nt][e] = ldb1(fy_rs, off);
+        }
     };
     constexpr int KC0 = RS ? 0 : -1, KCS = RS ? 1 : 4;                // first chunk / chunk step of a wave
     const int kc0 = KC0 < 0 ? wave : KC0;
@@ -975,14 +995,18 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
     if (n0 + n_step < n_end) fetch(n0 + n_step);      // next pass's frames: in flight during the MFMAs
     for (int kc = kc0; kc < kch; kc += KCS) {
       float av[MT][4], bv[NTC][4];
+      const int f = fdiv(kc, m_cpf), r0 = (kc - f * cpf) * 16 + q * 4;
 #pragma unroll
       for (int nt = 0; nt < NTC; ++nt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[nt][e] = bn[nt][e];
+        for (int e = 0; e < 4; ++e) {
+          bv[nt][e] = bn[nt][e];
+          // (positions beyond the frame must stay zero: the constant term would otherwise enter the sums)
+          if (FOLD) bv[nt][e] = (r0 + e < opf) ? fmaf(fk1[nt], bn[nt][e], fmaf(fk2[nt], byn[nt][e], fk3[nt])) : 0.f;
+        }
 #pragma unroll
       for (int nt = 0; nt < NTC; ++nt) bsum[nt] += (bv[nt][0] + bv[nt][1]) + (bv[nt][2] + bv[nt][3]);
       if (kc + KCS < kch) load_b(kc + KCS, bn);
-      const int f = fdiv(kc, m_cpf), r0 = (kc - f * cpf) * 16 + q * 4;
       int ho = fdiv(min(r0, opf - 1), A.m_wo), wo = min(r0, opf - 1) - ho * A.Wo;
       const float* xf = xs + f * xstride + (PW + 1) * CsP;
 #pragma unroll
@@ -1661,8 +1685,10 @@ __global__ __launch_bounds__(1024) void wgrad_pair_final_kernel(const float* __r
 }
 
 static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const float* dy, float* dw, float* dbias, float beta, float* scratch,
-                                long scratch_floats, void* stream, bool dry) {
+                                long scratch_floats, void* stream, bool dry, const float* fold_y = nullptr, const float* fold_k = nullptr) {
   const int Ci = c->Ci, Co = c->Co, H = c->H, W = c->W, Ho = c->Ho, Wo = c->Wo, N = c->N, k = c->k;
+  const bool fold = fold_k != nullptr;                   // dy = k1*dz + k2*y + k3 evaluated in the operand fetch: the pixel-pair form of a
+                                                         // 3-channel-input layer only (layer 0), anything else declines
   // Pixel-pair form for 8 destination channels (the 36x36 layers, the most expensive weight gradients): with 8 columns half of
   // every 16-column MFMA tile multiplies padding.  dy is read as [N, Ho, Wo/2, 16] (the same bytes): a column is (pixel parity pp,
   // channel), the depth index a PAIR of horizontally adjacent output pixels; the rows run over the union of the two pixels' windows
@@ -1673,6 +1699,8 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
     A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo / 2; A.Co = 16;
     A.S = 1; A.SW = 2; A.pt = c->pad_t; A.pl = c->pad_l; A.kw = 4; A.bn_sc = c->bn_scale; A.bn_sh = c->bn_shift;
     A.t0 = 0; A.nt = 12; A.want_bias = dbias ? 1 : 0;
+    A.fy = fold_y; A.fk = fold_k; A.fC = 8;
+    if (fold && Ci % 4 == 0) return AVSR_ERR_UNSUPPORTED;
 #ifdef CONV_DEBUG
     { const char* e = getenv("AVSR_CONV_DBG"); A.dbg = e ? atoi(e) : 0; }
 #endif
@@ -1711,7 +1739,8 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
       hipStream_t s = S_(stream);
       {
         ProfScope ps(PROF_CONV_BWD_WEIGHT, s, 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
-        if (Ci % 4) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, false>), dim3(grid), dim3(256), lds, s, A);
+        if (fold) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, false, false, true>), dim3(grid), dim3(256), lds, s, A);
+        else if (Ci % 4) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, false>), dim3(grid), dim3(256), lds, s, A);
         else hipLaunchKernelGGL((conv_wgrad_kernel<6, 1, true>), dim3(grid), dim3(256), lds, s, A);
         if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
       }
@@ -1722,6 +1751,7 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
       return AVSR_OK;
     }
   }
+  if (fold) return AVSR_ERR_UNSUPPORTED;
   WGArgs A = {};
   A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo; A.Co = Co;
   A.S = c->stride; A.pt = c->pad_t; A.pl = c->pad_l; A.kw = k; A.bn_sc = c->bn_scale; A.bn_sh = c->bn_shift;
@@ -1983,6 +2013,20 @@ extern "C" int avsr_bn_bwd_finalize_f64(const double* local, const double* globa
                      grad_beta, k);
   if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
   return AVSR_OK;
+}
+
+// Weight (+ bias) gradient with the batch-norm backward of the convolution's own output folded into the operand fetch: dy = k[0..C)*dz +
+// k[C..2C)*y + k[2C..3C) (avsr_bn_bwd_finalize's vectors) -- see WGArgs.  AVSR_ERR_UNSUPPORTED unless avsr_conv_bwd_weight_bn_supported.
+extern "C" int avsr_conv_bwd_weight_bn(const avsr_conv_desc* c, const float* x, const float* dz, const float* y, const float* k, float* dw,
+                                       float* dbias, float beta, float* scratch, int64_t scratch_floats, void* stream) {
+  if (!cd_ok(c) || !x || !dz || !y || !k || !dw || !scratch) return AVSR_ERR_ARG;
+  if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
+  return conv_bwd_weight_impl(c, x, dz, dw, dbias, beta, scratch, scratch_floats, stream, false, y, k);
+}
+extern "C" int avsr_conv_bwd_weight_bn_supported(const avsr_conv_desc* c) {
+  if (!g_conv_mfma || !cd_ok(c)) return 0;
+  static float dummy;
+  return conv_bwd_weight_impl(c, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, 1L << 40, nullptr, true, &dummy, &dummy) == AVSR_OK;
 }
 
 extern "C" int avsr_conv_bwd_weight(const avsr_conv_desc* c, const float* x, const float* dy, float* dw, float* dbias, float beta, float* scratch,

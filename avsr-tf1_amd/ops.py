@@ -579,6 +579,16 @@ def conv_bwd_weight(d, x, dy, dw, dbias, scratch, beta=1.0):
           "avsr_conv_bwd_weight")
 
 
+def conv_bwd_weight_bn(d, x, dz, y, k, dw, dbias, scratch, beta=1.0):
+    """Weight gradient with dy = k1*dz + k2*y + k3 (the batch-norm backward of the convolution's own output) evaluated in the operand fetch."""
+    check(_L().avsr_conv_bwd_weight_bn(C.byref(d), fptr(x), fptr(dz), fptr(y), fptr(k), fptr(dw), fptr(dbias), float(beta), fptr(scratch),
+                                       scratch.numel(), _s()), "avsr_conv_bwd_weight_bn")
+
+
+def conv_bwd_weight_bn_supported(d):
+    return bool(_L().avsr_conv_bwd_weight_bn_supported(C.byref(d)))
+
+
 def slab_defer_begin():
     """From here to slab_defer_end() the conv_bwd_weight calls of this thread record their final slab reductions instead of launching
     them: one launch at the end (every call needs its own scratch region)."""
