@@ -177,7 +177,7 @@ def load():
         "avsr_conv_bwd_weight": [C.POINTER(ConvDesc), vp, vp, vp, vp, f32, vp, i64, vp],
         "avsr_conv_bwd_data_bn": [C.POINTER(ConvDesc), vp, vp, vp, f32, vp, vp, vp, vp, vp, C.POINTER(i32), vp],
         "avsr_conv_bwd_data_bn_supported": [C.POINTER(ConvDesc)],
-        "avsr_conv_bwd_weight_bn": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, f32, vp, i64, vp],
+        "avsr_conv_bwd_weight_bn": [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, f32, vp, i64, vp],
         "avsr_conv_bwd_weight_bn_supported": [C.POINTER(ConvDesc)],
         "avsr_bn_bwd_finalize": [vp, i32, i32, i64, vp, vp, vp, vp, vp, f32, vp, vp],
         "avsr_bn_bwd_apply": [vp, vp, vp, vp, i64, i32, f32, vp],

@@ -202,9 +202,10 @@ class LipCNN:
             if op[0] != "bnrelu" or op[1] not in self.bnb:
                 continue
             prod = by_dst.get(op[2])
-            if os.environ.get("AVSR_CNN_FOLD", "1") != "0" and prod is not None and prod[2] == "in" and prod[1] in self.mfma and \
-                    self.consumers.get(op[2], 0) == 1 and \
-                    ops.conv_bwd_weight_bn_supported(ops.conv_desc(*self.mfma[prod[1]])):
+            lvl = int(os.environ.get("AVSR_CNN_FOLD", "2"))      # 0 off, 1 layers without a data gradient only, 2 every single-reader case
+            if lvl and prod is not None and prod[1] in self.mfma and self.consumers.get(op[2], 0) == 1 and \
+                    (prod[2] == "in" or lvl >= 2) and ops.conv_bwd_weight_bn_supported(ops.conv_desc(*self.mfma[prod[1]])):
+                # (a producer WITH a data gradient: the weight gradient -- issued first -- also writes the evaluated gradient for it)
                 self.fold_wg[op[1]] = prod[1]
         self.fold_src = {}
         for name, (h, w, c) in self.shapes.items():
@@ -419,7 +420,7 @@ class LipCNN:
                         ops.bn_bwd_finalize_f64(loc, buf, c, mean, invstd, self._pv(name + "/gamma"), gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c],
                                                 self.bnb_k[name], grad_beta=0.0)
                         if name in self.fold_wg and beta == 0.0:
-                            self.fold_src[src] = (self.gmaps[dst], self.maps[src], self.bnb_k[name])
+                            self.fold_src[src] = (self.gmaps[dst], self.maps[src], self.bnb_k[name], g)
                         else:
                             ops.bn_bwd_apply(self.gmaps[dst], self.maps[src], self.bnb_k[name], g, N * h * w, c, beta=beta)
                         continue
@@ -427,8 +428,9 @@ class LipCNN:
                         ops.bn_bwd_finalize(self.bnb_stat[name], self.bnb_rows.pop(name), c, N * h * w, mean, invstd, self._pv(name + "/gamma"),
                                             gg.t[gg.off:gg.off + c], gb.t[gb.off:gb.off + c], self.bnb_k[name], grad_beta=0.0)
                         if name in self.fold_wg and beta == 0.0:
-                            # the one reader of this gradient -- the producing convolution's weight gradient -- evaluates it in its loader
-                            self.fold_src[src] = (self.gmaps[dst], self.maps[src], self.bnb_k[name])
+                            # the first reader of this gradient -- the producing convolution's weight gradient -- evaluates it in its loader
+                            # (and stores it for the data gradient, if the layer has one)
+                            self.fold_src[src] = (self.gmaps[dst], self.maps[src], self.bnb_k[name], g)
                         else:
                             ops.bn_bwd_apply(self.gmaps[dst], self.maps[src], self.bnb_k[name], g, N * h * w, c, beta=beta)
                         continue
@@ -447,7 +449,8 @@ class LipCNN:
                         d = ops.conv_desc(*self.mfma[name], bn=bn)
                         fold = self.fold_src.pop(dst, None)
                         if fold is not None:
-                            ops.conv_bwd_weight_bn(d, x, fold[0], fold[1], fold[2], gk.t[gk.off:], gb.t[gb.off:], self.wg_scratch[self.wg_off[name]:])
+                            ops.conv_bwd_weight_bn(d, x, fold[0], fold[1], fold[2], gk.t[gk.off:], gb.t[gb.off:], self.wg_scratch[self.wg_off[name]:],
+                                                   dx_out=fold[3] if src != "in" else None)
                         else:
                             ops.conv_bwd_weight(d, x, self.gmaps[dst], gk.t[gk.off:], gb.t[gb.off:], self.wg_scratch[self.wg_off[name]:])
                         fused_bn = self.bnb_conv.get(name)

@@ -551,7 +551,9 @@ struct WGArgs {
   // k1[c]*dz + k2[c]*y + k3[c] of the convolution's OWN output y (avsr_bn_bwd_finalize's coefficient vectors fk [3*fC]), evaluated while
   // the operand is fetched: `dy` points at dz, fy at y (same layout).  For a convolution whose only gradient consumer is this kernel
   // (layer 0: its input are the lip crops) the stand-alone avsr_bn_bwd_apply pass over three maps disappears.
-  const float* fy; const float* fk; int fC;
+  // fdx != NULL: the evaluated gradient is also WRITTEN there (same layout) for the layer's data gradient, which runs after this kernel:
+  // every element is fetched by exactly one lane, so the stand-alone pass is replaced by one store per operand.
+  const float* fy; const float* fk; int fC; float* fdx;
 };
 
 // 8 destination channels, stride 1, linear destination (the 36x36 layers: layer 0 and residual block 0, forward and data gradient): the
@@ -830,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
 // RS (row split): the four waves own DIFFERENT row tiles (wave w: rows [w*MT*16, (w+1)*MT*16)) and each walks every chunk, instead of
 // all waves sharing MT row tiles and splitting the chunks: a deep layer whose (tap, channel) rows exceed one wave's accumulators then
 // takes ONE launch -- its input staged once -- instead of one per tap group, and no cross-wave reduction at the end.
-template <int MT, int NTC, bool CH4, bool RS = false, bool FOLD = false>
+template <int MT, int NTC, bool CH4, bool RS = false, int FOLD = 0>
 __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kernel(const WGArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -944,6 +946,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   // positions 4q .. 4q+3 of the chunk; chunks are dealt to the waves round-robin.
   const __amdgpu_buffer_rsrc_t dy_rs = make_rsrc(A.dy);
   const __amdgpu_buffer_rsrc_t fy_rs = make_rsrc(FOLD ? A.fy : A.dy);
+  const __amdgpu_buffer_rsrc_t fdx_rs = make_rsrc(FOLD == 2 ? A.fdx : A.part);
   float fk1[NTC], fk2[NTC], fk3[NTC];                    // FOLD: coefficients of this lane's column(s)
 #pragma unroll
   for (int nt = 0; nt < NTC; ++nt) {
@@ -1003,6 +1006,9 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
           bv[nt][e] = bn[nt][e];
           // (positions beyond the frame must stay zero: the constant term would otherwise enter the sums)
           if (FOLD) bv[nt][e] = (r0 + e < opf) ? fmaf(fk1[nt], bn[nt][e], fmaf(fk2[nt], byn[nt][e], fk3[nt])) : 0.f;
+          if (FOLD == 2 && (!RS || wave == 0))
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bv[nt][e]), fdx_rs,
+                                                  (r0 + e < opf && nt * 16 + i < Co) ? (int)(dyo + (unsigned)(((f * opf + r0 + e) * Co + nt * 16 + i) * 4)) : P_OOB, 0, 0);
         }
 #pragma unroll
       for (int nt = 0; nt < NTC; ++nt) bsum[nt] += (bv[nt][0] + bv[nt][1]) + (bv[nt][2] + bv[nt][3]);
@@ -1685,10 +1691,11 @@ __global__ __launch_bounds__(1024) void wgrad_pair_final_kernel(const float* __r
 }
 
 static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const float* dy, float* dw, float* dbias, float beta, float* scratch,
-                                long scratch_floats, void* stream, bool dry, const float* fold_y = nullptr, const float* fold_k = nullptr) {
+                                long scratch_floats, void* stream, bool dry, const float* fold_y = nullptr, const float* fold_k = nullptr,
+                                float* fold_dx = nullptr) {
   const int Ci = c->Ci, Co = c->Co, H = c->H, W = c->W, Ho = c->Ho, Wo = c->Wo, N = c->N, k = c->k;
-  const bool fold = fold_k != nullptr;                   // dy = k1*dz + k2*y + k3 evaluated in the operand fetch: the pixel-pair form of a
-                                                         // 3-channel-input layer only (layer 0), anything else declines
+  const bool fold = fold_k != nullptr;                   // dy = k1*dz + k2*y + k3 evaluated in the operand fetch (single-launch forms only);
+                                                         // fold_dx: also written out for the data gradient that follows
   // Pixel-pair form for 8 destination channels (the 36x36 layers, the most expensive weight gradients): with 8 columns half of
   // every 16-column MFMA tile multiplies padding.  dy is read as [N, Ho, Wo/2, 16] (the same bytes): a column is (pixel parity pp,
   // channel), the depth index a PAIR of horizontally adjacent output pixels; the rows run over the union of the two pixels' windows
@@ -1699,8 +1706,7 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
     A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo / 2; A.Co = 16;
     A.S = 1; A.SW = 2; A.pt = c->pad_t; A.pl = c->pad_l; A.kw = 4; A.bn_sc = c->bn_scale; A.bn_sh = c->bn_shift;
     A.t0 = 0; A.nt = 12; A.want_bias = dbias ? 1 : 0;
-    A.fy = fold_y; A.fk = fold_k; A.fC = 8;
-    if (fold && Ci % 4 == 0) return AVSR_ERR_UNSUPPORTED;
+    A.fy = fold_y; A.fk = fold_k; A.fC = 8; A.fdx = fold_dx;
 #ifdef CONV_DEBUG
     { const char* e = getenv("AVSR_CONV_DBG"); A.dbg = e ? atoi(e) : 0; }
 #endif
@@ -1739,7 +1745,10 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
       hipStream_t s = S_(stream);
       {
         ProfScope ps(PROF_CONV_BWD_WEIGHT, s, 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
-        if (fold) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, false, false, true>), dim3(grid), dim3(256), lds, s, A);
+        if (fold && Ci % 4 && fold_dx) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, false, false, 2>), dim3(grid), dim3(256), lds, s, A);
+        else if (fold && Ci % 4) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, false, false, 1>), dim3(grid), dim3(256), lds, s, A);
+        else if (fold && fold_dx) hipLaunchKernelGGL((conv_wgrad_kernel<6, 1, true, false, 2>), dim3(grid), dim3(256), lds, s, A);
+        else if (fold) hipLaunchKernelGGL((conv_wgrad_kernel<6, 1, true, false, 1>), dim3(grid), dim3(256), lds, s, A);
         else if (Ci % 4) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, false>), dim3(grid), dim3(256), lds, s, A);
         else hipLaunchKernelGGL((conv_wgrad_kernel<6, 1, true>), dim3(grid), dim3(256), lds, s, A);
         if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
@@ -1751,10 +1760,10 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
       return AVSR_OK;
     }
   }
-  if (fold) return AVSR_ERR_UNSUPPORTED;
   WGArgs A = {};
   A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo; A.Co = Co;
   A.S = c->stride; A.pt = c->pad_t; A.pl = c->pad_l; A.kw = k; A.bn_sc = c->bn_scale; A.bn_sh = c->bn_shift;
+  A.fy = fold_y; A.fk = fold_k; A.fC = Co; A.fdx = fold_dx;
   const int NTC = (Co + 15) / 16;
   if (NTC == 3) return AVSR_ERR_UNSUPPORTED;
   const int mt_max = NTC == 4 ? 9 : 18;
@@ -1796,6 +1805,12 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
   const int Mall = k * k * A.CiL;
   const bool rs = rs_on && NTC == 4 && Ci % 4 == 0 && G < k * k && Mall <= 4 * 9 * 16;   // (32-column layers fit one launch already: no gain measured)
   if (rs) G = k * k;
+  if (fold) {
+    // one launch only (a second tap group would evaluate -- and write -- the gradient again), and only the forms instantiated below
+    const int MT1 = rs ? ((k * k * A.CiL + 3) / 4 + 15) / 16 : (k * k * A.CiL + 15) / 16;
+    const bool okf = G >= k * k && Ci % 4 == 0 && (rs ? MT1 <= 5 : (NTC == 1 ? MT1 <= 5 : (NTC == 2 && MT1 <= 9)));
+    if (!okf) return AVSR_ERR_UNSUPPORTED;
+  }
   for (int t0 = 0; t0 < k * k; t0 += G) {
     A.t0 = t0; A.nt = k * k - t0 < G ? k * k - t0 : G;
     A.want_bias = bias_done ? 0 : 1;
@@ -1812,7 +1827,14 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
     {
       ProfScope ps(PROF_CONV_BWD_WEIGHT, s, 2.0 * N * Ho * Wo * (double)A.nt * Ci * Co);
 #define WG_GO(M_, N_, C_) hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_, C_>), dim3(grid), dim3(256), lds, s, A)
-      if (rs) {
+      if (fold) {
+#define WG_FOLD(M_, N_, R_) { if (fold_dx) hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_, true, R_, 2>), dim3(grid), dim3(256), lds, s, A); \
+                              else hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_, true, R_, 1>), dim3(grid), dim3(256), lds, s, A); }
+        if (rs) WG_FOLD(5, 4, true)
+        else if (NTC == 1) WG_FOLD(5, 1, false)
+        else WG_FOLD(9, 2, false)
+#undef WG_FOLD
+      } else if (rs) {
         if (MT <= 5) hipLaunchKernelGGL((conv_wgrad_kernel<5, 4, true, true>), dim3(grid), dim3(256), lds, s, A);
         else hipLaunchKernelGGL((conv_wgrad_kernel<9, 4, true, true>), dim3(grid), dim3(256), lds, s, A);
       } else if (Ci % 4) WG_GO(3, 1, false);
@@ -2016,12 +2038,13 @@ extern "C" int avsr_bn_bwd_finalize_f64(const double* local, const double* globa
 }
 
 // Weight (+ bias) gradient with the batch-norm backward of the convolution's own output folded into the operand fetch: dy = k[0..C)*dz +
-// k[C..2C)*y + k[2C..3C) (avsr_bn_bwd_finalize's vectors) -- see WGArgs.  AVSR_ERR_UNSUPPORTED unless avsr_conv_bwd_weight_bn_supported.
-extern "C" int avsr_conv_bwd_weight_bn(const avsr_conv_desc* c, const float* x, const float* dz, const float* y, const float* k, float* dw,
-                                       float* dbias, float beta, float* scratch, int64_t scratch_floats, void* stream) {
+// k[C..2C)*y + k[2C..3C) (avsr_bn_bwd_finalize's vectors) -- see WGArgs; dx_out (may be NULL): the evaluated gradient is also stored there
+// for the layer's data gradient.  AVSR_ERR_UNSUPPORTED unless avsr_conv_bwd_weight_bn_supported.
+extern "C" int avsr_conv_bwd_weight_bn(const avsr_conv_desc* c, const float* x, const float* dz, const float* y, const float* k, float* dx_out,
+                                       float* dw, float* dbias, float beta, float* scratch, int64_t scratch_floats, void* stream) {
   if (!cd_ok(c) || !x || !dz || !y || !k || !dw || !scratch) return AVSR_ERR_ARG;
   if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
-  return conv_bwd_weight_impl(c, x, dz, dw, dbias, beta, scratch, scratch_floats, stream, false, y, k);
+  return conv_bwd_weight_impl(c, x, dz, dw, dbias, beta, scratch, scratch_floats, stream, false, y, k, dx_out);
 }
 extern "C" int avsr_conv_bwd_weight_bn_supported(const avsr_conv_desc* c) {
   if (!g_conv_mfma || !cd_ok(c)) return 0;

@@ -20,6 +20,8 @@
 #include "avsr_hip.h"
 #include "prof.h"
 #include "persist.h"
+#include <cstring>
+#include <cstdlib>
 
 #define P_MAX_TASKS 8
 #define P_MAXC 8
@@ -36,7 +38,7 @@ struct PTask {
   float* xt_w; long xt_sb, xt_st;           // this layer's output as ITS consumer sees it (dropout only)
   float* h_final; float* c_final;
   int* done; const int* done_lower;         // arrival counters [nrt][T]
-  int B, T, H, in, hoisted, reverse, nct, nct_lower, wg_begin, nrt, uw, part;
+  int B, T, H, in, hoisted, reverse, nct, nct_lower, wg_begin, nrt, uw, part, prio;
   const int32_t* seed; float k_st, k_out, k_in; uint32_t r_st, r_out, r_in; int in_W, in_coff;
 };
 // b0: first batch row of this launch.  npart = 2 (XCD-local kernel only): the launch holds TWO independent stacks (the directions of
@@ -323,7 +325,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // ~20 % ahead).  Three workgroups share each SIMD's matrix pipe: the pace-setters take it first.  Round 3: 2.42 -> 2.37 ms at c4; a
   // distinct priority per cell (0..3) did nothing.  (`v_mfma_f32_4x4x1_16B_f32` for the 8-row products -- no padding rows -- was
   // sized and dropped: K = 1 per instruction needs one weight register per k, 128 per wave against 64 with 16x16x4.)
-  if (!tk.hoisted) __builtin_amdgcn_s_setprio(2);
+  if (tk.prio == 3) __builtin_amdgcn_s_setprio(3);
+  else if (tk.prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (tk.prio == 1) __builtin_amdgcn_s_setprio(1);
   const int ct = slot - tk.wg_begin;
   const int UW = tk.uw, uw_shift = UW == 16 ? 4 : 3;
   const int row0 = L.b0 + g * R, col0 = ct * UW * 4, unit0 = ct * UW;
@@ -693,6 +697,13 @@ static int build_tasks(const avsr_rnn_stack* st, int n, bool local, int32_t* syn
       tk.B = S.B; tk.T = S.T; tk.H = H; tk.in = in; tk.hoisted = Ly.hoisted; tk.reverse = S.reverse;
       g_fwd_flops += 2.0 * S.B * S.T * ((Ly.hoisted ? 0 : in) + H) * 4.0 * H;
       tk.uw = (local && Ly.hoisted && H % 16 == 0) ? 16 : 8;
+      {
+        // wave priority of the task's workgroups: the cells with an input product set the pace (default 2, recurrent-only layer 0: 0);
+        // AVSR_RNN_PRIO="p0,p1,..." (by task index) overrides for experiments
+        tk.prio = Ly.hoisted ? 0 : 2;
+        static const char* pe = getenv("AVSR_RNN_PRIO");
+        if (pe) { const char* q = pe; for (int k = 0; k < L.ntask - 1 && q; ++k) { q = strchr(q, ','); if (q) ++q; } if (q && *q >= '0' && *q <= '3') tk.prio = *q - '0'; }
+      }
       tk.nct = H / tk.uw; tk.nrt = nrt; tk.wg_begin = wg; tk.part = parts ? i : 0;
       if (tk.nct > 32) return AVSR_ERR_UNSUPPORTED;
       wg += local ? tk.nct : nrt * tk.nct;

@@ -579,10 +579,11 @@ def conv_bwd_weight(d, x, dy, dw, dbias, scratch, beta=1.0):
           "avsr_conv_bwd_weight")
 
 
-def conv_bwd_weight_bn(d, x, dz, y, k, dw, dbias, scratch, beta=1.0):
-    """Weight gradient with dy = k1*dz + k2*y + k3 (the batch-norm backward of the convolution's own output) evaluated in the operand fetch."""
-    check(_L().avsr_conv_bwd_weight_bn(C.byref(d), fptr(x), fptr(dz), fptr(y), fptr(k), fptr(dw), fptr(dbias), float(beta), fptr(scratch),
-                                       scratch.numel(), _s()), "avsr_conv_bwd_weight_bn")
+def conv_bwd_weight_bn(d, x, dz, y, k, dw, dbias, scratch, beta=1.0, dx_out=None):
+    """Weight gradient with dy = k1*dz + k2*y + k3 (the batch-norm backward of the convolution's own output) evaluated in the operand fetch;
+    dx_out: also stored there for the layer's data gradient."""
+    check(_L().avsr_conv_bwd_weight_bn(C.byref(d), fptr(x), fptr(dz), fptr(y), fptr(k), fptr(dx_out), fptr(dw), fptr(dbias), float(beta),
+                                       fptr(scratch), scratch.numel(), _s()), "avsr_conv_bwd_weight_bn")
 
 
 def conv_bwd_weight_bn_supported(d):

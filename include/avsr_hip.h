@@ -494,11 +494,12 @@ int avsr_conv_bwd_data_bn(const avsr_conv_desc* c, const float* dy, const float*
 int avsr_conv_bwd_data_bn_supported(const avsr_conv_desc* c);
 /* Weight (+ bias) gradient of a convolution whose OUTPUT y feeds a batch norm (video.py:4-14), with that batch norm's backward folded into
  * the operand fetch: the gradient of y, gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) = k[0..C)*dz + k[C..2C)*y + k[2C..3C)
- * (avsr_bn_bwd_finalize's coefficient vectors), is never stored.  For a layer with no data gradient (layer 0 of resnet_cnn: its input
- * are the lip crops) the avsr_bn_bwd_apply pass over three maps disappears.  avsr_conv_bwd_weight_bn_supported: 0 = use
- * avsr_bn_bwd_apply + avsr_conv_bwd_weight. */
-int avsr_conv_bwd_weight_bn(const avsr_conv_desc* c, const float* x, const float* dz, const float* y, const float* k, float* dw,
-                            float* dbias, float beta, float* scratch, int64_t scratch_floats, void* stream);
+ * (avsr_bn_bwd_finalize's coefficient vectors), is evaluated where the kernel fetches it.  dx_out == NULL (a layer with no data gradient:
+ * layer 0 of resnet_cnn, whose input are the lip crops): it is never stored; dx_out != NULL: every element is also written there by the
+ * one lane that fetched it, for the layer's data gradient (issued after this call) -- either way the avsr_bn_bwd_apply pass over three
+ * maps disappears.  avsr_conv_bwd_weight_bn_supported (single-launch forms only): 0 = use avsr_bn_bwd_apply + avsr_conv_bwd_weight. */
+int avsr_conv_bwd_weight_bn(const avsr_conv_desc* c, const float* x, const float* dz, const float* y, const float* k, float* dx_out,
+                            float* dw, float* dbias, float beta, float* scratch, int64_t scratch_floats, void* stream);
 int avsr_conv_bwd_weight_bn_supported(const avsr_conv_desc* c);
 int avsr_bn_bwd_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, const float* mean, const float* invstd,
                          const float* gamma, float* dgamma, float* dbeta, float grad_beta, float* k, void* stream);

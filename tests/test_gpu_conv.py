@@ -259,33 +259,41 @@ def test_data_gradient_with_fused_batchnorm_backward(N, H, Ci, Co, s, acc):
     assert not np.any(dz.cpu().numpy()[yn <= 0])
 
 
-@pytest.mark.parametrize("N,H,Ci,Co", [(5, 12, 3, 8), (3, 36, 3, 8), (70, 10, 3, 8)])
-def test_weight_gradient_with_the_batchnorm_backward_in_its_operand_fetch(N, H, Ci, Co):
+@pytest.mark.parametrize("N,H,Ci,Co,st", [(5, 12, 3, 8, 1), (3, 36, 3, 8, 1), (70, 10, 3, 8, 1), (3, 36, 8, 8, 1), (7, 10, 8, 8, 1), (4, 36, 8, 16, 2),
+                                           (5, 18, 16, 32, 2), (6, 9, 32, 64, 2), (9, 11, 8, 16, 2)])
+def test_weight_gradient_with_the_batchnorm_backward_in_its_operand_fetch(N, H, Ci, Co, st):
     """avsr_conv_bwd_weight_bn (round 5): the gradient of the convolution's output, dx = k1*dz + k2*y + k3 (avsr_bn_bwd_finalize's
-    vectors), evaluated while the weight-gradient kernel fetches its operand, against avsr_bn_bwd_apply + avsr_conv_bwd_weight on the
-    materialised dx -- weight AND bias gradient, including maps whose last 16-position chunk of a frame is partial."""
+    vectors), evaluated while the weight-gradient kernel fetches its operand -- and, for layers with a data gradient, stored by the lane
+    that fetched it -- against avsr_bn_bwd_apply + avsr_conv_bwd_weight on the materialised dx: weight AND bias gradient AND the stored
+    map, including maps whose last 16-position chunk of a frame is partial, every kernel form the lip CNN's layers take (pixel-pair
+    8-channel, one / two / four column tiles, the row-split form), and the BN-ReLU loader on the input side."""
     from avsr_tf1_amd import ops
-    rng = np.random.default_rng(N + H)
+    rng = np.random.default_rng(N + H + Ci)
     dev = lambda a: torch.tensor(a, dtype=torch.float32).cuda().contiguous()
+    Ho, pt, _ = _same(H, 3, st)
     x = dev(rng.standard_normal((N, H, H, Ci)))
-    y = dev(rng.standard_normal((N, H, H, Co)))
-    dz = dev(rng.standard_normal((N, H, H, Co)))
+    y = dev(rng.standard_normal((N, Ho, Ho, Co)))
+    dz = dev(rng.standard_normal((N, Ho, Ho, Co)))
     k = dev(np.concatenate([rng.uniform(0.5, 1.5, Co), rng.standard_normal(Co) * 0.3, rng.standard_normal(Co) * 0.2]))
-    d = ops.conv_desc(N, H, H, Ci, Co, 3, 1, 1, 1, H, H)
+    bnv = (dev(rng.uniform(0.5, 1.5, Ci)), dev(rng.standard_normal(Ci) * 0.3)) if Ci % 4 == 0 else None
+    d = ops.conv_desc(N, H, H, Ci, Co, 3, st, pt, pt, Ho, Ho, bn=bnv)
     assert ops.conv_bwd_weight_bn_supported(d)
     dx = torch.zeros_like(y)
-    ops.bn_bwd_apply(dz, y, k, dx, N * H * H, Co)
-    scratch = torch.empty(1 << 22, device="cuda")
+    ops.bn_bwd_apply(dz, y, k, dx, N * Ho * Ho, Co)
+    scratch = torch.empty(1 << 23, device="cuda")
     dw0, db0 = torch.full((3, 3, Ci, Co), 0.5, device="cuda"), torch.full((Co,), -0.25, device="cuda")
     ops.conv_bwd_weight(d, x, dx, dw0, db0, scratch)
-    dw1, db1 = torch.full((3, 3, Ci, Co), 0.5, device="cuda"), torch.full((Co,), -0.25, device="cuda")
-    ops.conv_bwd_weight_bn(d, x, dz, y, k, dw1, db1, torch.empty(1 << 22, device="cuda"))
-    torch.cuda.synchronize()
-    assert _close(dw1.cpu().numpy(), dw0.cpu().numpy(), 2e-5) and _close(db1.cpu().numpy(), db0.cpu().numpy(), 2e-5)
+    for store in ((False, True) if Ci % 4 == 0 else (False,)):
+        dw1, db1 = torch.full((3, 3, Ci, Co), 0.5, device="cuda"), torch.full((Co,), -0.25, device="cuda")
+        out = torch.full_like(y, 9.0) if store else None
+        ops.conv_bwd_weight_bn(d, x, dz, y, k, dw1, db1, torch.empty(1 << 23, device="cuda"), dx_out=out)
+        torch.cuda.synchronize()
+        assert _close(dw1.cpu().numpy(), dw0.cpu().numpy(), 2e-5) and _close(db1.cpu().numpy(), db0.cpu().numpy(), 2e-5)
+        if store:
+            assert _close(out.cpu().numpy(), dx.cpu().numpy(), 1e-6)
     # against fp64 autograd
-    xt, w64 = x.double().cpu(), torch.zeros(3, 3, Ci, Co, dtype=torch.float64, requires_grad=True)
+    xin = torch.relu(x.double().cpu() * bnv[0].double().cpu() + bnv[1].double().cpu()) if bnv else x.double().cpu()
+    w64 = torch.zeros(3, 3, Ci, Co, dtype=torch.float64, requires_grad=True)
     b64 = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
-    (_ref_conv(xt, w64, b64, 1) * dx.double().cpu()).sum().backward()
+    (_ref_conv(xin, w64, b64, st) * dx.double().cpu()).sum().backward()
     assert _close(dw1.cpu().numpy() - 0.5, w64.grad.numpy(), 5e-5) and _close(db1.cpu().numpy() + 0.25, b64.grad.numpy(), 5e-5)
-    # a 4-channel-multiple input declines (its gradient has a second reader: the data gradient)
-    assert not ops.conv_bwd_weight_bn_supported(ops.conv_desc(N, H, H, 8, 8, 3, 1, 1, 1, H, H))
