@@ -617,6 +617,15 @@ int avsr_dec_persist_bwd(const avsr_attn_rnn* dp, void* stream) {
   if (g_dec_fused == 2) return AVSR_ERR_UNSUPPORTED;
   int rc = dp_plan(d, F, &variant, &lds);
   if (rc) return rc;
+  {
+    // this kernel's OWN LDS size (MISC + the resident values): the forward's figure differs for 33..64-symbol vocabularies, whose layout
+    // ahead of the values is smaller since round 5 -- launched with the forward's size, the last 256 bytes of the values lay outside the
+    // allocation (caught by tests/test_gpu_beam.py: the memory-kernel gradient of a phoneme model)
+    long vals = 0;
+    for (int m = 0; m < d.n_mech; ++m) vals += (long)F.m[m].ch * d.mech[m].D;
+    lds = sizeof(float) * (size_t)((F.R == 16 ? DP_MISC16 : DP_MISC) + vals);
+    if (lds > DP_LDS_BYTES) return AVSR_ERR_UNSUPPORTED;
+  }
   if (F.bah && (!d.mech[0].wq || !d.mech[0].dpq || !d.mech[0].pq || !d.mech[0].v)) return AVSR_ERR_ARG;
   if (!d.w || !d.dgates || !d.dstate || !d.datt) return AVSR_ERR_ARG;
   if (avsr_dec_persist_fwd_ws_floats(d.B, d.n_mech, 256) + avsr_dec_persist_bwd_ws_floats(d.B, d.n_mech) > d.fused_ws_floats) return AVSR_ERR_UNSUPPORTED;

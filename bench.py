@@ -344,7 +344,9 @@ def main():
                                      "all-reduce); the batch norms inside the lip CNN (and the input batch norm of the CNN-fed stream) NORMALISE with PER-RANK "
                                      "statistics -- a documented deviation from one engine on the whole batch; their moving averages are averaged "
                                      "over the ranks in the gradient all-reduce's tail, so replicas stay bit-identical "
-                                     "(tests/test_gpu_dp.py::test_two_ranks_with_the_lip_cnn)") if world > 1 else None,
+                                     "(tests/test_gpu_dp.py::test_two_ranks_with_the_lip_cnn).  Opt-in global statistics for those batch norms: "
+                                     "AVSR_DP_SYNC_CNN_BN=1 (16 small collectives inside the step, eager launches; "
+                                     "tests/test_gpu_dp.py::test_two_ranks_with_synchronised_cnn_batch_norms_equal_one_engine)") if world > 1 else None,
                    "parity": "vs CPU restatement of TF-1.13.1 semantics; TF parity unpinned"},
         "final_loss": round(loss, 5),
         # per rank: wall seconds of the timed loop before the closing barrier, and min / median / max GPU milliseconds per step (event
@@ -414,7 +416,7 @@ def main():
         pmc, pmc_file = {}, None
         try:
             if args.workload == "c4" and args.video_frontend == "resnet_cnn":
-                for cand in ("r04_c4_lipcnn_pmc_v5.json", "r04_c4_lipcnn_pmc_v4.json", "r04_c4_lipcnn_pmc_v3.json", "r04_c4_lipcnn_pmc_v1.json", "r03_c4_lipcnn_pmc_v2.json", "r03_c4_lipcnn_pmc_v1.json", "r02_c4_lipcnn_pmc_v5.json"):
+                for cand in ("r05_c4_lipcnn_pmc_v2.json", "r05_c4_lipcnn_pmc_v1.json", "r04_c4_lipcnn_pmc_v5.json", "r04_c4_lipcnn_pmc_v4.json", "r04_c4_lipcnn_pmc_v3.json", "r04_c4_lipcnn_pmc_v1.json", "r03_c4_lipcnn_pmc_v2.json", "r03_c4_lipcnn_pmc_v1.json", "r02_c4_lipcnn_pmc_v5.json"):
                     path = os.path.join(ROOT, "profiles", cand)
                     if os.path.exists(path):
                         pmc, pmc_file = json.load(open(path))["kernels"], "profiles/" + cand
@@ -542,7 +544,8 @@ def main():
             torch.cuda.synchronize()
             dtd = (time.perf_counter() - t0) / 3
             out["greedy_decode"] = {"value": round(B / dtd, 2), "unit": "utterances/sec", "ms_per_batch": round(1e3 * dtd, 3),
-                                    "steps": LDEC, "launch": "eager (host-driven early-exit check every 8 steps)"}
+                                    "steps": LDEC, "launch": "one launch of all steps where the fused persistent decode kernel takes the block (per-group in-kernel exit once every "
+                                              "utterance has emitted EOS); chunks of 8 steps with a host check otherwise"}
         except Exception as e:
             out["greedy_decode"] = {"value": None, "error": repr(e)}
         try:   # the reference's DEFAULT evaluation algorithm: beam search, width 10 (avsr/avsr.py:58-59)
