@@ -202,6 +202,51 @@ def cpu_baseline_full(wl, stoch, budget_s=45.0):
                       "after 1 warm-up; TF-1.13.1 reference cannot run here" % (ncores, Bf, TA, TV, LDEC, len(times))}
 
 
+def measure_traffic(args):
+    """HBM traffic per dispatch MEASURED IN THIS RUN: two separate `rocprofv3 --pmc <counter> --kernel-trace` passes (FETCH_SIZE, then
+    WRITE_SIZE; MI355X_MICROARCH.md: one counter set per pass, kernel trace only) of a short eager run of the same workload in child
+    processes, averaged per kernel name.  Returns ({kernel name: {"FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "dispatches"}}, description) or
+    (None, reason).  Skipped when rocprofv3 is missing, when this process is itself being profiled, or with AVSR_BENCH_TRAFFIC=0."""
+    import glob
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if os.environ.get("AVSR_BENCH_TRAFFIC", "1") == "0":
+        return None, "AVSR_BENCH_TRAFFIC=0"
+    if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ):
+        return None, "this process is being profiled"
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, "rocprofv3 not found"
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline", "--no-profile",
+            "--workload", args.workload, "--video-frontend", args.video_frontend] + (["--no-dropout"] if args.no_dropout else []) + \
+           (["--batch", str(args.batch)] if args.batch else [])
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp", AVSR_BENCH_TRAFFIC="0")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="avsr_pmc_", dir="/tmp")
+        try:
+            p = subprocess.run([rp, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--"] + base, cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=400)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if p.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed (exit %d)" % (counter, p.returncode)
+            cur = sqlite3.connect(dbs[0]).cursor()
+            for name, n, val in cur.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? "
+                                            "group by kernel_name", (counter,)):
+                k = re.sub(r"\(.*$", "", name).replace("void ", "")
+                out.setdefault(k, {})["dispatches"] = n
+                out[k][counter + "_KiB"] = round(float(val), 1)
+        except Exception as e:
+            return None, "rocprofv3 --pmc %s: %r" % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out, ("measured in this run: rocprofv3 --pmc FETCH_SIZE --kernel-trace and rocprofv3 --pmc WRITE_SIZE --kernel-trace (separate passes) "
+                 "of `bench.py --steps 2 --warmup 1 --no-graph` on the same workload, averages per dispatch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,7 +468,13 @@ def main():
                         break
         except Exception:
             pmc, pmc_file = {}, None
-        # `traffic` is NOT measured in this run: it is read from the committed PMC summary above (separate rocprofv3 --pmc passes)
+        # `traffic`: measured in THIS run where rocprofv3 is available (two --pmc passes of a short eager run, child processes: round 5);
+        # the committed PMC summary above is the fallback, and the JSON says which one it was
+        live, why = measure_traffic(args) if world == 1 else (None, "multi-GPU run")
+        if live:
+            pmc, pmc_file = live, why
+        else:
+            pmc_file = "%s (not measured in this run: %s)" % (pmc_file, why)
         out["traffic_source"] = pmc_file
         # ONE correction rule, calibrated on this GPU with known-bytes kernels in the engine's access forms (tools/pmc_calibrate.py ->
         # profiles/r04_pmc_calibration.json): FETCH_SIZE counts L2-miss read REQUESTS at 64 B apiece, and a request that needs a whole

@@ -52,7 +52,7 @@ CASES = {
     # in the input-row buffer
     "phoneme_c4_full_memories": (dict(architecture="bimodal", video_units=(256,), audio_units=(256,), decoder_units=(256,), embedding_size=128,
                                       video_feat=128, audio_feat=80, use_dropout=True, sampling_probability=0.1, vocab_size=41, eos_id=39,
-                                      go_id=40), 4, 500, 75, 6),
+                                      go_id=40), 2, 500, 75, 5),
     "vocab64_unimodal": (dict(architecture="unimodal", video_units=None, audio_units=(48,), decoder_units=(48,), embedding_size=32,
                               attention_type=(("luong",), ("luong",)), sampling_probability=0.3, vocab_size=64, eos_id=62, go_id=63), 9, 70, 0, 9),
     "viseme_bimodal_sampling": (dict(architecture="bimodal", video_units=(32,), audio_units=(32, 32), use_dropout=True,
