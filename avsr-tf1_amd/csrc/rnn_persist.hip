@@ -306,11 +306,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   __shared__ __attribute__((aligned(16))) float red[4][4][R][16];
   __shared__ __attribute__((aligned(16))) float red4[Q4 ? 2048 : 4];   // [4 waves][2 k-halves][8 rows][32 cols] / wide: [4][8][64]
   __shared__ int s_slot;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gx = __builtin_amdgcn_readfirstlane(xcc_id());
-  if (tid == 0) s_slot = __hip_atomic_fetch_add(L.claim + gx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) s_slot = __hip_atomic_fetch_add(L.claim + gx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const int slot = __builtin_amdgcn_readfirstlane(s_slot);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int part = L.npart == 2 ? gx >> 2 : 0;      // which stack this XCD works for
   const int g = L.npart == 2 ? gx & 3 : gx;         // row group of that stack
   if (g >= L.ngroups || slot >= (L.npart == 2 ? L.pwg[part] : L.wpx)) return;
