@@ -348,12 +348,13 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         float hnext = h_state;
         if (valid) {
           f32x4 z = bias4 + zpre;
-#pragma unroll
-          for (int gi = 0; gi < 4; ++gi) {
-            const int cc = eu * 4 + gi;
-            const int o = ((cc >> 4) * R + er) * 16 + (cc & 15);
+          {
+            // the four gates of a unit are four consecutive columns of one 16-column tile: one 16-byte LDS read per wave partial instead
+            // of four 4-byte ones (same per-element summation order)
+            const int c0 = eu * 4;
+            const float* ro = red + ((c0 >> 4) * R + er) * 16 + (c0 & 15);
             constexpr int WS = 32 * R;               // floats per wave
-            z[gi] += ((red[o] + red[WS + o]) + (red[2 * WS + o] + red[3 * WS + o])) + ((red[4 * WS + o] + red[5 * WS + o]) + (red[6 * WS + o] + red[7 * WS + o]));
+            z += ((ld4(ro) + ld4(ro + WS)) + (ld4(ro + 2 * WS) + ld4(ro + 3 * WS))) + ((ld4(ro + 4 * WS) + ld4(ro + 5 * WS)) + (ld4(ro + 6 * WS) + ld4(ro + 7 * WS)));
           }
           f32x4 g4;
           g4[0] = p_sigmoid(z[0]); g4[1] = p_tanh(z[1]); g4[2] = p_sigmoid(z[2] + 1.0f); g4[3] = p_sigmoid(z[3]);
@@ -536,8 +537,16 @@ __global__ __launch_bounds__(DP_NT) void dec_persist_kernel(const DPLaunch L) {
         const int m = tid >> 6, c4 = tid & 63;
         if (m < L.n_mech && 4 * c4 < L.m[m].D) {
           const int w0 = m ? nw0 : 0, w1 = (m || L.n_mech < 2) ? DP_WV : nw0;
-          f32x4 sacc = ld4(red + w0 * 256 + 4 * c4);
-          for (int w = w0 + 1; w < w1; ++w) sacc += ld4(red + w * 256 + 4 * c4);
+          // all eight waves' partial rows in flight at once, summed in the same order over [w0, w1) (a loop with run-time bounds made
+          // this eight dependent LDS round trips: ~1000 ticks of the phase, profiles/r05_phase_ticks_before.txt "P2 rest")
+          f32x4 pv8[DP_WV];
+#pragma unroll
+          for (int w = 0; w < DP_WV; ++w) pv8[w] = ld4(red + w * 256 + 4 * c4);
+          f32x4 sacc = zero4;
+          bool first = true;
+#pragma unroll
+          for (int w = 0; w < DP_WV; ++w)
+            if (w >= w0 && w < w1) { sacc = first ? pv8[w] : sacc + pv8[w]; first = false; }
           st4(L.m[m].ppctx + ((long)cq * B + b_att) * L.m[m].D + 4 * c4, sacc);
         }
       }
