@@ -159,7 +159,9 @@ class Seq2SeqModel:
         for name, off, r, c in self._tjobs:
             self.Tr[name] = Ref(self.derived, off, (c, r))
         self._ws_cache = OrderedDict()
-        self.max_cached_shapes = 8
+        # workspaces kept (least recently used dropped): bucketed training cycles through more (B, T_a, T_v, L) shapes than 8 -- a miss
+        # allocates and zero-fills several GB (c4 with the lip CNN: ~6.5 GB per shape), a tenth of a step's time
+        self.max_cached_shapes = int(os.environ.get("AVSR_WS_CACHE", "12"))
         self._ws_pinned = set()                  # keys whose buffers a captured hipGraph points into: never evicted (parallel.py)
         self._dropping = False
         self.au_scale = 1.0

@@ -259,12 +259,27 @@ class DataParallelTrainer:
         do_check = self.check_every_step or not self._checked
         self._checked = True
         eager_now = not self.use_graph
-        if self.use_graph and self.graph_after > 1 and key not in self._graphs:
-            n = self._seen.pop(key, 0) + 1
-            self._seen[key] = n
-            while len(self._seen) > 4096:
-                self._seen.popitem(last=False)
+        # sightings per shape (halved every 1024 steps so that a new phase of a curriculum can displace the old one's shapes)
+        n = self._seen.pop(key, 0) + 1
+        self._seen[key] = n
+        while len(self._seen) > 4096:
+            self._seen.popitem(last=False)
+        self._steps_seen = getattr(self, "_steps_seen", 0) + 1
+        if self._steps_seen % 1024 == 0:
+            for k in list(self._seen):
+                self._seen[k] = (self._seen[k] + 1) // 2
+        if self.use_graph and key not in self._graphs:
             eager_now = n < self.graph_after
+            if not eager_now and self.graph_after > 1 and len(self._graphs) >= self.MAX_GRAPHS:
+                # Cache full.  Capturing costs two extra passes of host launches, an instantiation and a pinned workspace: with more
+                # recurring shapes than slots, least-recently-used replacement recaptures for ever (measured: AVSR.train on utterances of
+                # 450-500 frames ran at 0.6-0.8x its eager rate).  A new shape displaces the LEAST OFTEN seen captured shape, and only
+                # once it has been seen clearly more often; otherwise it keeps launching eagerly.
+                victim = min(self._graphs, key=lambda k: self._seen.get(k, 0))
+                if n <= self._seen.get(victim, 0) + self.graph_after:
+                    eager_now = True
+                else:
+                    self._drop_graph(victim)
         if eager_now:
             self._eager_pass(batch, do_check)
             m.apply_update()
@@ -384,6 +399,13 @@ class DataParallelTrainer:
         self.use_graph = False
         self.mode = "eager (out of memory while allocating a shape's workspace; captured graphs dropped)"
         torch.cuda.empty_cache()
+
+    def _drop_graph(self, key):
+        _ga, _gb, wskey = self._graphs.pop(key)
+        self._static.pop(key, None)
+        unpin = getattr(self.model, "unpin_workspace", None)
+        if unpin and wskey is not None:
+            unpin(wskey)
 
     def _drop_graphs(self):
         unpin = getattr(self.model, "unpin_workspace", None)
