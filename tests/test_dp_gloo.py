@@ -299,3 +299,31 @@ def test_out_of_memory_on_one_rank_keeps_the_collective_schedule(tmp_path):
     # 4 steps, gradient of step s = sum over ranks of 10 * (rank + s + 1)
     want = -0.1 * sum(10.0 * ((0 + s + 1) + (1 + s + 1)) for s in range(4))
     assert np.allclose(r0["param"], want)
+
+
+def test_graph_cache_admission_does_not_thrash(monkeypatch):
+    """More recurring batch shapes than graph slots (bucketed training on ragged data): least-recently-used replacement would recapture
+    on almost every step.  The trainer admits a new shape to a FULL cache only once it has been seen clearly more often than the least
+    often seen captured shape; everything else launches eagerly.  Round-robin over 5 shapes with 2 slots: the captures stop."""
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(DataParallelTrainer, "_drain", staticmethod(lambda: None))
+    monkeypatch.setattr(DataParallelTrainer, "_copy_into", staticmethod(lambda dst, src: dst.copy_(src)))
+    model = _TinyModel(oom_on_prepare=False)
+    trainer = DataParallelTrainer(model, None, use_graph=True, check_every_step=False, graph_after=2, max_graphs=2)
+    captures = [0]
+
+    def cap(fn):
+        captures[0] += 1
+        return _FakeGraph(fn)
+    trainer._capture = cap
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt)
+    mk = lambda T: Batch(z(2, T, 4), z(2, dt=torch.int32), None, None, None, torch.ones(2, 5, dtype=torch.int32), torch.full((2,), 5, dtype=torch.int32))
+    for step in range(100):
+        trainer.train_step(mk(3 + step % 5))
+    assert len(trainer._graphs) == 2
+    assert captures[0] == 4, captures[0]                # two shapes x (forward+backward graph, update graph): captured once, never again
+    assert model.passes == 100                           # every step ran exactly one pass (a capture step's pass is its eager one)
+    # a shape that becomes dominant is admitted: it displaces the least often seen captured shape
+    for step in range(40):
+        trainer.train_step(mk(9))
+    assert trainer._key(mk(9)) in trainer._graphs and captures[0] == 6
