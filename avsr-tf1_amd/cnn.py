@@ -408,7 +408,17 @@ class LipCNN:
                     gg, gb = self._g(name + "/gamma"), self._g(name + "/beta")
                     sync = getattr(m, "cnn_bn_sync", None)
                     if sync is not None and name not in self.bnb_rows:
-                        raise NotImplementedError("sync_cnn_bn: batch norm %s is differentiated outside the fused data gradients" % name)
+                        # the output gradient was assembled by several launches (the four-class 3x3/2 data gradient of a wide layer): stage 1
+                        # -- ReLU mask + partial sums -- as a pass of its own, then the same global finalisation as the fused layers
+                        if c % 4 or c > 1024:
+                            raise NotImplementedError("sync_cnn_bn: batch norm %s (%d channels)" % (name, c))
+                        if name not in self.bnb_stat:
+                            self.bnb_stat[name] = torch.zeros(512 * 2 * c, device=m.dev)
+                            self.bnb_k[name] = torch.zeros(3 * c, device=m.dev)
+                        lz = self.lazy.get(dst)
+                        self.bnb_rows[name] = ops.bn_bwd_stage1(self.gmaps[dst], self.maps[src], self.gmaps[dst], N * h * w, c, self.bnb_stat[name],
+                                                                scale=lz[1] if lz else None, shift=lz[2] if lz else None,
+                                                                y=None if lz else self.maps[dst])
                     if name in self.bnb_rows and sync is not None:
                         # global means of dz and dz * xhat for the input gradient; d gamma / d beta keep this rank's share
                         buf = self._sync_buf(name, c)

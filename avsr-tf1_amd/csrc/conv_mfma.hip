@@ -1959,6 +1959,60 @@ extern "C" int avsr_bn_bwd_apply(const float* dz, const float* x, const float* k
   return AVSR_OK;
 }
 
+// Batch-norm backward, stage 1 on its own (the form avsr_conv_bwd_data_bn fuses into a single-launch data gradient's epilogue), for a
+// batch norm whose output gradient was assembled by several launches (the per-class 3x3/2 data gradient of a wide layer):
+//   dz = dy * [relu(scale*x + shift) > 0]   (or [y > 0] when the batch-norm output map was written),  part [nparts][2C] = (sum dz | sum dz*x)
+// dz may alias dy.  C % 4 == 0, C <= 1024; *nparts <= 512 blocks, each over a contiguous run of rows.
+__global__ __launch_bounds__(256) void bn_bwd_stage1_kernel(const float* dy, const float* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ y, float* dz, long rows,
+                                                            int C, long rows_per_block, float* __restrict__ part) {
+  __shared__ float red[256][9];
+  const int C4 = C / 4, RL = 256 / C4, q = threadIdx.x % C4, rl = threadIdx.x / C4;
+  const long r0 = blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, sx = s;
+  f32x4 sc = s, sh = s;
+  if (scale && rl < RL) { sc = ld4(scale + 4 * q); sh = ld4(shift + 4 * q); }
+  if (rl < RL)
+    for (long r = r0 + rl; r < r1; r += RL) {
+      const long o = r * C + 4 * q;
+      const f32x4 g = ld4(dy + o), xv = ld4(x + o);
+      f32x4 v;
+      if (scale) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(xv[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+      } else {
+        const f32x4 yv = ld4(y + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = yv[e] > 0.f ? g[e] : 0.f;
+      }
+      st4(dz + o, v);
+      s += v; sx += v * xv;
+    }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s[e]; red[threadIdx.x][4 + e] = sx[e]; }
+  __syncthreads();
+  if (threadIdx.x >= C4) return;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < RL; ++r)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += red[r * C4 + q][e];
+  float* p = part + (long)blockIdx.x * 2 * C;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { p[4 * q + e] = a[e]; p[C + 4 * q + e] = a[4 + e]; }
+}
+extern "C" int avsr_bn_bwd_stage1(const float* dy, const float* x, const float* scale, const float* shift, const float* y, float* dz, int64_t rows,
+                                  int32_t C, float* part, int32_t* nparts, void* stream) {
+  if (!dy || !x || !dz || !part || !nparts || rows <= 0 || C <= 0 || C % 4 || C > 1024 || (!scale && !y) || (scale && !shift)) return AVSR_ERR_ARG;
+  const int RL = 256 / (C / 4);
+  long per = (rows + 511) / 512;
+  if (per < 8L * RL) per = 8L * RL;                          // at least eight passes of a block's row lanes
+  const int blocks = (int)((rows + per - 1) / per);
+  *nparts = blocks;
+  hipLaunchKernelGGL(bn_bwd_stage1_kernel, dim3(blocks), dim3(256), 0, S_(stream), dy, x, scale, shift, y, dz, (long)rows, C, per, part);
+  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
+  return AVSR_OK;
+}
+
 // ---- batch-norm statistics across data-parallel ranks (opt-in: DataParallelTrainer(sync_cnn_bn=True)) --------------------------------
 // The partial sums a convolution epilogue wrote are merged into fp64 per-channel sums, the host all-reduces that small buffer (with the
 // rank's row count behind it), and the finalisation reads the GLOBAL sums: mean / variance / moving averages / loader affine of the

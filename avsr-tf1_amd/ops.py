@@ -574,6 +574,14 @@ def bn_bwd_apply(dz, x, k, dx, rows, Cn, beta=0.0):
     check(_L().avsr_bn_bwd_apply(fptr(dz), fptr(x), fptr(k), fptr(dx), int(rows), int(Cn), float(beta), _s()), "avsr_bn_bwd_apply")
 
 
+def bn_bwd_stage1(dy, x, dz, rows, Cn, part, scale=None, shift=None, y=None):
+    """dz = dy * [relu(scale*x + shift) > 0] (or [y > 0]) and its partial sums [nparts][2*Cn]; returns nparts."""
+    n = C.c_int32(0)
+    check(_L().avsr_bn_bwd_stage1(fptr(dy), fptr(x), fptr(scale), fptr(shift), fptr(y), fptr(dz), int(rows), int(Cn), fptr(part), C.byref(n), _s()),
+          "avsr_bn_bwd_stage1")
+    return int(n.value)
+
+
 def conv_bwd_weight(d, x, dy, dw, dbias, scratch, beta=1.0):
     check(_L().avsr_conv_bwd_weight(C.byref(d), fptr(x), fptr(dy), fptr(dw), fptr(dbias), float(beta), fptr(scratch), scratch.numel(), _s()),
           "avsr_conv_bwd_weight")

@@ -504,6 +504,12 @@ int avsr_conv_bwd_weight_bn_supported(const avsr_conv_desc* c);
 int avsr_bn_bwd_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, const float* mean, const float* invstd,
                          const float* gamma, float* dgamma, float* dbeta, float grad_beta, float* k, void* stream);
 int avsr_bn_bwd_apply(const float* dz, const float* x, const float* k, float* dx, int64_t rows, int32_t C, float beta, void* stream);
+/* Stage 1 of the batch-norm backward as a pass of its own, for a batch norm whose output gradient several launches assembled (no single
+ * epilogue to fuse it into): dz = dy * [scale*x + shift > 0] (scale == NULL: [y > 0]), part [*nparts <= 512][2*C] = (sum dz | sum dz*x) --
+ * the layout avsr_bn_bwd_finalize / avsr_bn_partials_f64 read.  dz may alias dy; C % 4 == 0, C <= 1024.  Used by sync_cnn_bn for the
+ * layers avsr_conv_bwd_data_bn does not cover (video.py:4-14 differentiated over the global batch). */
+int avsr_bn_bwd_stage1(const float* dy, const float* x, const float* scale, const float* shift, const float* y, float* dz, int64_t rows,
+                       int32_t C, float* part, int32_t* nparts, void* stream);
 int avsr_bn_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, float eps, float momentum, float* mean, float* invstd,
                      float* mov_mean, float* mov_var, const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 /* The same two finalisations from GLOBAL statistics under data parallelism (video.py:4-14 `tf.layers.batch_normalization` over the whole

@@ -259,6 +259,48 @@ def test_data_gradient_with_fused_batchnorm_backward(N, H, Ci, Co, s, acc):
     assert not np.any(dz.cpu().numpy()[yn <= 0])
 
 
+@pytest.mark.parametrize("rows,Cn,lazy,alias", [(81 * 7, 32, True, True), (1, 4, True, False), (4099, 8, False, True), (300 * 25, 64, True, False),
+                                                (513 * 9, 12, False, False), (37, 1024, True, True)])
+def test_batchnorm_backward_stage_one_as_its_own_pass(rows, Cn, lazy, alias):
+    """avsr_bn_bwd_stage1 (the ReLU mask + the partial sums a single-launch data gradient emits from its epilogue, as a pass of its own) +
+    avsr_bn_bwd_finalize + avsr_bn_bwd_apply against torch autograd (fp64) through x -> batch_norm -> relu (avsr/video.py:4-14)."""
+    from avsr_tf1_amd import ops
+    rng = np.random.default_rng(rows + Cn)
+    eps = 1e-5
+    t64 = lambda a, g=True: torch.tensor(a, dtype=torch.float64, requires_grad=g)
+    x = t64(rng.standard_normal((rows, Cn)) * 1.5 + 0.2)
+    gamma, beta = t64(rng.uniform(0.5, 1.5, Cn)), t64(rng.standard_normal(Cn) * 0.3)
+    mean = x.mean(0)
+    var = ((x - mean) ** 2).mean(0)
+    invstd = torch.rsqrt(var + eps)
+    dev = lambda t: t.detach().to(torch.float32).cuda().contiguous()
+    f32 = lambda t: t.detach().numpy().astype(np.float32)
+    sc32, sh32, y32 = f32(gamma * invstd), f32(beta - mean * gamma * invstd), f32(torch.relu((x - mean) * invstd * gamma + beta))
+    # the mask the kernel takes, exactly: the sign of fma(x, scale, shift) in fp32 is the sign of the exact value, which fp64 holds
+    mask = (f32(x).astype(np.float64) * sc32 + sh32 > 0) if lazy else (y32 > 0)
+    y = ((x - mean) * invstd * gamma + beta) * torch.tensor(mask.astype(np.float64))
+    dy = torch.tensor(rng.standard_normal((rows, Cn)), dtype=torch.float64)
+    (y * dy).sum().backward()
+    xd, dyd = dev(x), dev(dy)
+    expect_dz = np.where(mask, f32(dy), np.float32(0.0))
+    dz = dyd if alias else torch.full((rows, Cn), 3.0, device="cuda")
+    part = torch.full((512 * 2 * Cn,), 7.0, device="cuda")
+    if lazy:
+        n = ops.bn_bwd_stage1(dyd, xd, dz, rows, Cn, part, scale=torch.tensor(sc32).cuda(), shift=torch.tensor(sh32).cuda())
+    else:
+        n = ops.bn_bwd_stage1(dyd, xd, dz, rows, Cn, part, y=torch.tensor(y32).cuda())
+    assert 0 < n <= 512
+    k3 = torch.zeros(3 * Cn, device="cuda")
+    dg, db = torch.full((Cn,), 9.0, device="cuda"), torch.full((Cn,), 9.0, device="cuda")
+    ops.bn_bwd_finalize(part, n, Cn, rows, dev(mean), dev(invstd), dev(gamma), dg, db, k3, grad_beta=0.0)
+    dx = torch.zeros((rows, Cn), device="cuda")
+    ops.bn_bwd_apply(dz, xd, k3, dx, rows, Cn)
+    torch.cuda.synchronize()
+    assert np.array_equal(dz.cpu().numpy(), expect_dz)
+    assert _close(dg.cpu().numpy(), gamma.grad.numpy(), 2e-4) and _close(db.cpu().numpy(), beta.grad.numpy(), 2e-4)
+    assert _close(dx.cpu().numpy(), x.grad.numpy(), 2e-4)
+
+
 @pytest.mark.parametrize("N,H,Ci,Co,st", [(5, 12, 3, 8, 1), (3, 36, 3, 8, 1), (70, 10, 3, 8, 1), (3, 36, 8, 8, 1), (7, 10, 8, 8, 1), (4, 36, 8, 16, 2),
                                            (5, 18, 16, 32, 2), (6, 9, 32, 64, 2), (9, 11, 8, 16, 2)])
 def test_weight_gradient_with_the_batchnorm_backward_in_its_operand_fetch(N, H, Ci, Co, st):

@@ -163,11 +163,16 @@ CASE_CNN = dict(architecture="bimodal", encoder_type="unidirectional", video_uni
                 cnn_filters=(8, 8, 16, 16), cnn_dense_units=16, video_feat=16)
 
 
-def _setup_cnn(duplicate):
+# the reference's own filter widths (avsr/avsr.py:33): the 32 -> 64 stride-2 layer's data gradient is four launches, so its batch norm takes
+# the stand-alone stage 1 (avsr_bn_bwd_stage1) under sync_cnn_bn -- the path the full-size benchmark shape runs
+CASE_CNN_WIDE = dict(CASE_CNN, cnn_filters=(8, 16, 32, 64))
+
+
+def _setup_cnn(duplicate, case=None):
     import dataclasses
     from avsr_tf1_amd.config import ModelConfig
     from oracle import avsr_oracle as O
-    ocfg = O.OracleConfig(**CASE_CNN)
+    ocfg = O.OracleConfig(**(case or CASE_CNN))
     mcfg = ModelConfig(**{f.name: getattr(ocfg, f.name) for f in dataclasses.fields(ModelConfig) if hasattr(ocfg, f.name)})
     W = O.init_params(ocfg, seed=7)
     if duplicate:
@@ -336,9 +341,16 @@ def _worker_cnn_sync(rank, world, port, out_dir, sync=True):
     from avsr_tf1_amd.parallel import DataParallelTrainer
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    O, mcfg, W, full = _setup_cnn(False)
+    O, mcfg, W, full = _setup_cnn(False, CASE_CNN_WIDE)
     model = Seq2SeqModel(mcfg, weights=W)
     trainer = DataParallelTrainer(model, dist, use_graph=True, sync_cnn_bn=sync)
+    from avsr_tf1_amd import ops
+    calls, stage1 = [0], ops.bn_bwd_stage1
+
+    def counted(*a, **k):
+        calls[0] += 1
+        return stage1(*a, **k)
+    ops.bn_bwd_stage1 = counted
     cut = [0, 1, 4]                                   # unequal shards: 1 and 3 utterances
     batch = Batch.from_numpy(_shard(O, full, cut[rank], cut[rank + 1]))
     losses = []
@@ -347,7 +359,7 @@ def _worker_cnn_sync(rank, world, port, out_dir, sync=True):
         losses.append(float(loss.item()))
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, "%srank%d.npz" % ("" if sync else "nosync_", rank)), mode=np.array(trainer.mode), step_losses=np.array(losses),
-             **model.export_tf_weights("params"))
+             stage1_calls=np.array(calls[0]), **model.export_tf_weights("params"))
     dist.destroy_process_group()
 
 
@@ -360,12 +372,13 @@ def test_two_ranks_with_synchronised_cnn_batch_norms_equal_one_engine(tmp_path, 
     mp.spawn(_worker_cnn_sync, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     assert "sync_cnn_bn" in str(r0["mode"])
-    names = [k for k in r0.files if k not in ("mode", "step_losses")]
+    assert int(r0["stage1_calls"]) == 3                             # the 32 -> 64 stride-2 layer's batch norm, once per step
+    names = [k for k in r0.files if k not in ("mode", "step_losses", "stage1_calls")]
     for k in names:
         assert np.array_equal(r0[k], r1[k]), k                       # replicas bit-identical, moving statistics included
     assert np.array_equal(r0["step_losses"], r1["step_losses"])
     monkeypatch.setenv("AVSR_PERSISTENT_RNN", "0")
-    O, mcfg, W, full = _setup_cnn(False)
+    O, mcfg, W, full = _setup_cnn(False, CASE_CNN_WIDE)
     model = Seq2SeqModel(mcfg, weights=W)
     batch = Batch.from_numpy(full)
     ref_losses = []
