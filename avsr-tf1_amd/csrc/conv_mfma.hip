@@ -960,6 +960,13 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   const int cpf = (opf + 15) >> 4;                       // chunks per frame
   const unsigned m_cpf = fmagic_dev(cpf);
   int n0 = n_begin;
+  // dissection builds (tools/wgrad_ablate.sh: -DWG_ABLATE=mask, compile-time so that the rest of the code is generated as shipped):
+  // 1 no dy loads, 2 no LDS operand reads, 4 no MFMAs, 16 no frame staging.  Results: profiles/r05_wgrad_ablation.txt
+#ifdef WG_ABLATE
+#define WG_ABL(b) (((WG_ABLATE) & (b)) != 0)
+#else
+#define WG_ABL(b) false
+#endif
 #ifdef CONV_DEBUG
   long w_b1 = 0, w_commit = 0, w_b2 = 0, w_comp = 0, w_mark = __builtin_readcyclecounter();
   const long w_start = w_mark;
@@ -972,7 +979,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
     const int fcur = min(FP, n_end - n0);
     __syncthreads();
     WG_STAMP(w_b1)
-    commit(n0);
+    if (!WG_ABL(16)) commit(n0);
     WG_STAMP(w_commit)
     const int kch = fcur * cpf;
     const unsigned dyo = (unsigned)((long)n0 * opf * Co * 4);     // [fcur][opf][Co]
@@ -986,8 +993,8 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
 #pragma unroll
         for (int nt = 0; nt < NTC; ++nt) {
           const int off = (r0 + e < opf && nt * 16 + i < Co) ? (int)(o + (unsigned)((e * Co + nt * 16) * 4)) : P_OOB;
-          b[nt][e] = ldb1(dy_rs, off);
-          if (FOLD) byn[nt][e] = ldb1(fy_rs, off);
+          b[nt][e] = ldb1(dy_rs, WG_ABL(1) ? P_OOB : off);
+          if (FOLD) byn[nt][e] = ldb1(fy_rs, WG_ABL(1) ? P_OOB : off);
         }
     };
     constexpr int KC0 = RS ? 0 : -1, KCS = RS ? 1 : 4;                // first chunk / chunk step of a wave
@@ -995,7 +1002,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
     if (kc0 < kch) load_b(kc0, bn);
     __syncthreads();
     WG_STAMP(w_b2)
-    if (n0 + n_step < n_end) fetch(n0 + n_step);      // next pass's frames: in flight during the MFMAs
+    if (n0 + n_step < n_end && !WG_ABL(16)) fetch(n0 + n_step);      // next pass's frames: in flight during the MFMAs
     for (int kc = kc0; kc < kch; kc += KCS) {
       float av[MT][4], bv[NTC][4];
       const int f = fdiv(kc, m_cpf), r0 = (kc - f * cpf) * 16 + q * 4;
@@ -1021,7 +1028,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
         // positions beyond the frame read a clamped (finite) LDS address: their dy operand is zero (out-of-range buffer load), so the
         // product vanishes without a select per operand
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt][e] = xb[roff[mt]];
+        for (int mt = 0; mt < MT; ++mt) av[mt][e] = WG_ABL(2) ? (float)roff[mt] : xb[roff[mt]];
         if (++wo == A.Wo) { wo = 0; ++ho; }
         if (ho >= A.Ho) { ho = A.Ho - 1; }                 // (only reached by out-of-range positions: masked above)
       }
@@ -1032,7 +1039,10 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NTC; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], bv[nt][e], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < NTC; ++nt) {
+            if (WG_ABL(4)) acc[mt][nt][0] += av[mt][e] * bv[nt][e];
+            else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], bv[nt][e], acc[mt][nt], 0, 0, 0);
+          }
       __builtin_amdgcn_sched_barrier(0);
     }
     WG_STAMP(w_comp)
