@@ -538,10 +538,15 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // weight gradient: part[blk][(t*Ci + ci)*Co + co] = sum over the block's frames and positions of x[pos(t)][ci] * dy[pos][co]
 #define WG_PAD 2          // floats of padding per LDS pixel in the weight-gradient kernel (bank spreading, see the kernel)
+// workgroups per CU the weight-gradient kernel is compiled for, by accumulator tiles per wave (its register budget): the stages of its
+// per-frame pipeline hide behind one another only ACROSS waves (profiles/r05_wgrad_ablation.txt), so the small forms take every wave
+// the registers and the LDS allow
+#define WG_WPC(tiles) ((tiles) > 16 ? 1 : ((tiles) <= 3 ? 4 : ((tiles) <= 6 ? 3 : 2)))
 struct WGArgs {
   const float* x; const float* dy; float* part;
   int N, H, W, Ci, CiL, Ho, Wo, Co, S, pt, pl, F;
   int SW;                                 // source step along W per output column (0 = S): 2 for the pixel-pair form, see conv_bwd_weight_impl
+  int pad;                                // floats of padding per LDS pixel (WG_PAD; 1 where three workgroups of a 36x36 frame share a CU)
   unsigned m_opf, m_wo, m_rq, m_per, m_w;
   int t0, nt, kw;                         // taps t0 .. t0+nt-1 of a kw x kw kernel: rows (t - t0, ci) of this launch's slab
   int slab, want_bias;                    // floats per workgroup partial: nt*Ci*Co (+ Co column sums of dy = the bias gradient)
@@ -833,7 +838,7 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
 // all waves sharing MT row tiles and splitting the chunks: a deep layer whose (tap, channel) rows exceed one wave's accumulators then
 // takes ONE launch -- its input staged once -- instead of one per tap group, and no cross-wave reduction at the end.
 template <int MT, int NTC, bool CH4, bool RS = false, int FOLD = 0>
-__global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kernel(const WGArgs A) {
+__global__ __launch_bounds__(256, WG_WPC(MT * NTC)) void conv_wgrad_kernel(const WGArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
@@ -842,7 +847,7 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   // with a stride of 8 / 16 / 32 / 64 floats the four position groups hit the same banks (4-5 LDS cycles per read, SQ_LDS_BANK_CONFLICT =
   // 53 % of the LDS-active cycles); + 2 floats spreads them (2 cycles per read, the minimum for 64 lanes on 32 banks).  Staging stores
   // become 8-byte pairs.
-  const int CsP = CiL + WG_PAD;
+  const int CsP = CiL + A.pad;
   const int PH = A.H + 2, PW = A.W + 2, xstride = PH * PW * CsP;
   const int opf = A.Ho * A.Wo;
   float* const xs = lds;                               // [F][PH][PW][CiL]   (the output gradient is read straight from memory:
@@ -871,7 +876,8 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
   const int st_rpp = (CH4 && st_rq > 0) ? (256 / st_rq > 0 ? 256 / st_rq : 1) : 1;
   const int st_row = CH4 ? (tid < st_rpp * st_rq ? fdiv(tid, A.m_rq) : -1) : -1;
   const int st_p4 = st_row >= 0 ? tid - st_row * st_rq : 0;
-  const int st_pad = (CH4 && st_row >= 0) ? (st_p4 / (Ci >> 2)) * WG_PAD : 0;     // padding floats ahead of this piece's pixel in its LDS row
+  const int st_pad = (CH4 && st_row >= 0) ? (st_p4 / (Ci >> 2)) * A.pad : 0;      // padding floats ahead of this piece's pixel in its LDS row
+  const bool st_odd = (A.pad & 1) != 0;                                           // odd pixel stride: 4-byte staging stores
   f32x4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = zero4;
   const bool bn_on = CH4 && A.bn_sc != nullptr;
   if (bn_on && st_row >= 0) { const int cb = (st_p4 * 4) % Ci; bsc = ld4(A.bn_sc + cb); bsh = ld4(A.bn_sh + cb); }
@@ -922,8 +928,11 @@ __global__ __launch_bounds__(256, (MT * NTC > 16 ? 1 : 2)) void conv_wgrad_kerne
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], bsc[e], bsh[e]), 0.f);
           }
           float* const dpx = xs + f * xstride + ((r + 1) * PW + 1) * CsP + st_pad + st_p4 * 4;
-          *reinterpret_cast<float2*>(dpx) = float2{v[0], v[1]};
-          *reinterpret_cast<float2*>(dpx + 2) = float2{v[2], v[3]};
+          if (st_odd) { dpx[0] = v[0]; dpx[1] = v[1]; dpx[2] = v[2]; dpx[3] = v[3]; }
+          else {
+            *reinterpret_cast<float2*>(dpx) = float2{v[0], v[1]};
+            *reinterpret_cast<float2*>(dpx + 2) = float2{v[2], v[3]};
+          }
         }
       }
     } else {
@@ -1414,7 +1423,7 @@ int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int
   WGArgs A = {};
   A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo; A.Co = Co;
   A.S = stride; A.pt = pad_t; A.pl = pad_l;
-  A.t0 = 0; A.nt = 9; A.kw = 3; A.slab = 9 * Ci * Co; A.want_bias = 0;
+  A.t0 = 0; A.nt = 9; A.kw = 3; A.slab = 9 * Ci * Co; A.want_bias = 0; A.pad = WG_PAD;
   const int MT = (9 * A.CiL + 15) / 16, NTC = (Co + 15) / 16;
   if (MT > 18 || NTC > 2 || MT * NTC > 36) return AVSR_ERR_UNSUPPORTED;
   A.F = cg_frames(H, W, A.CiL + WG_PAD, Ho * Wo);
@@ -1641,6 +1650,24 @@ static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const fl
   return AVSR_OK;
 }
 
+// Workgroups per CU and LDS pixel padding of a weight-gradient launch whose passes hold ONE frame: up to WG_WPC(tiles) workgroups where
+// the frames fit the CU's 160 KB side by side -- with + 1 float of padding instead of + 2 where that is what makes the next one fit
+// (36x36x8: 3 x 52 KB; the odd pixel stride costs 4-byte staging stores and measured nothing on the operand reads).  AVSR_WG_WPC caps it.
+static int wg_occupancy(int tiles, int H, int W, int CiL, int* pad) {
+  static int cap_env = -1;
+  if (cap_env < 0) { const char* e = getenv("AVSR_WG_WPC"); cap_env = e ? atoi(e) : 4; }
+  *pad = WG_PAD;
+  int cap = WG_WPC(tiles);
+  if (cap > cap_env) cap = cap_env;
+  auto frame = [&](int p) { return sizeof(float) * (size_t)(H + 2) * (W + 2) * (CiL + p); };
+  if (2 * frame(WG_PAD) <= 64 * 1024) return 2;                       // several frames per pass: as before
+  for (int w = cap; w > 2; --w) {
+    if (w * (frame(WG_PAD) + 512) <= 160 * 1024) return w;
+    if (w * (frame(1) + 512) <= 160 * 1024) { *pad = 1; return w; }
+  }
+  return 2;
+}
+
 // frames per pass of the weight-gradient kernel (upper bound; even shares in equal passes as above): its time is (passes) x (frames of a pass) -- chunks never span
 // frames --, so among the feasible F the one with the smallest rounds * F wins (4800 frames on 512 workgroups: F = 4 -> 3 x 4, F = 2 or 5
 // -> 10); ties: the larger F
@@ -1723,7 +1750,8 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
     A.slab = 12 * Ci * 16 + (A.want_bias ? 16 : 0);
     const int MT = (12 * A.CiL + 15) / 16;
     bool ok = (Ci % 4 == 0) ? MT <= 6 : (MT <= 3 && !c->bn_scale);
-    A.F = cg_frames(H, W, A.CiL + WG_PAD, Ho * A.Wo);
+    const int wpc_cap = wg_occupancy(MT, H, W, A.CiL, &A.pad);
+    A.F = cg_frames(H, W, A.CiL + A.pad, Ho * A.Wo);
     A.m_opf = fmagic(Ho * A.Wo); A.m_wo = fmagic(A.Wo); A.m_w = fmagic(W);
     if (Ci % 4 == 0) {
       const int rq = W * Ci / 4;
@@ -1739,13 +1767,13 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
       ok = ok && (A.F * H * W * Ci / 4 + 255) / 256 <= 4 && (long)A.F * H * W * Ci < 65536;
       A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci);
     }
-    if (ok) A.F = wg_pick_frames(N, A.F, 512);
-    size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + WG_PAD);
+    if (ok) A.F = wg_pick_frames(N, A.F, 256 * wpc_cap);
+    size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + A.pad);
     if (lds < sizeof(float) * 4 * 256) lds = sizeof(float) * 4 * 256;
     ok = ok && lds <= 64 * 1024 && (long)A.F * ((Ho * A.Wo + 15) / 16) < 65536 && (long)N * Ho * Wo * Co * 4 < (1L << 31);
     if (ok) {
-      int wpc = (int)((150 * 1024) / (lds + 512));
-      if (wpc > 2) wpc = 2;
+      int wpc = (int)((160 * 1024) / (lds + 512));
+      if (wpc > wpc_cap) wpc = wpc_cap;
       if (wpc < 1) wpc = 1;
       int grid = (N + A.F - 1) / A.F;
       if (grid > 256 * wpc) grid = 256 * wpc;
@@ -1779,7 +1807,11 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
   const int mt_max = NTC == 4 ? 9 : 18;
   int G = mt_max * 16 / A.CiL;                           // taps per launch
   if (G < 1) return AVSR_ERR_UNSUPPORTED;
-  A.F = cg_frames(H, W, A.CiL + WG_PAD, Ho * Wo);
+  // (tiles of the form the first launch takes: the tap groups of one call share the staging layout)
+  const int mt_first = ((k * k < G ? k * k : G) * A.CiL + 15) / 16;
+  const int tiles_first = (mt_first <= 5 ? 5 : (mt_first <= 9 ? 9 : 18)) * (NTC == 1 ? 1 : (NTC == 2 ? 2 : 4));
+  const int wpc_cap = (Ci % 4 == 0) ? wg_occupancy(tiles_first, H, W, A.CiL, &A.pad) : (A.pad = WG_PAD, 2);
+  A.F = cg_frames(H, W, A.CiL + A.pad, Ho * Wo);
   A.m_opf = fmagic(Ho * Wo); A.m_wo = fmagic(Wo); A.m_w = fmagic(W);
   if (Ci % 4 == 0) {
     const int rq = W * Ci / 4;
@@ -1794,18 +1826,18 @@ static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const f
     if ((A.F * H * W * Ci / 4 + 255) / 256 > 4 || (long)A.F * H * W * Ci >= 65536) return AVSR_ERR_UNSUPPORTED;
     A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci);
   }
-  while (A.F > 1 && sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + WG_PAD) > 64 * 1024) --A.F;
+  while (A.F > 1 && sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + A.pad) > 64 * 1024) --A.F;
   {
     const int nt0 = k * k < G ? k * k : G;
-    A.F = wg_pick_frames(N, A.F, (nt0 * Ci * Co + Co > 2048) ? 256 : 512);
+    A.F = wg_pick_frames(N, A.F, (nt0 * Ci * Co + Co > 2048) ? 256 : 256 * wpc_cap);
   }
   if ((long)A.F * ((Ho * Wo + 15) / 16) >= 65536 || (long)N * Ho * Wo * Co * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
   const size_t red = sizeof(float) * 4 * 256;
-  size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + WG_PAD);
+  size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + A.pad);
   if (lds < red) lds = red;
   if (lds > 64 * 1024) return AVSR_ERR_UNSUPPORTED;
-  int wpc = (int)((150 * 1024) / (lds + 512));
-  if (wpc > 2) wpc = 2;
+  int wpc = (int)((160 * 1024) / (lds + 512));
+  if (wpc > wpc_cap) wpc = wpc_cap;
   if (wpc < 1) wpc = 1;
   hipStream_t s = S_(stream);
   bool bias_done = dbias == nullptr;
