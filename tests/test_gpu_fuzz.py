@@ -202,3 +202,44 @@ def test_random_configuration_two_shards(seed):
     desc = repr(ocfg)
     assert float((g - gw).abs().max()) < 3e-5 * max(1.0, float(gw.abs().max())), (float((g - gw).abs().max()), desc)
     assert abs(float(models[0].loss.item() + models[1].loss.item()) - float(whole.loss.item())) < 2e-4, desc
+
+
+# ------------------------------------------------------------------------------------------------
+# Lip-CNN geometries the benchmark does not visit: other crop sizes (odd, non-square, one channel), other filter ladders (one block, five
+# blocks, 4-channel layers that fall off the pixel-pair / 4x4x1 forms), other dense widths -- every convolution form's shape dispatch
+# (frames per pass, tap groups, workgroups per CU, stride-2 parity classes) against the oracle's plain im2col arithmetic.
+CNN_HW = [(36, 36, 3), (24, 24, 3), (20, 28, 3), (12, 12, 3), (36, 36, 1), (17, 17, 3), (9, 13, 3), (30, 18, 3)]
+CNN_FILTERS = [(8, 16, 32, 64), (8, 8, 16, 16), (4, 8), (8,), (16, 32), (4, 4, 4, 8, 8), (12, 20), (8, 8)]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AVSR_FUZZ_CNN_N", "10"))))
+def test_random_lip_cnn_geometry(seed):
+    from test_gpu_model import make
+    from avsr_tf1_amd.model import Batch, Seq2SeqModel
+    rng = np.random.default_rng(9000 + seed)
+    hw = CNN_HW[int(rng.integers(len(CNN_HW)))]
+    filters = CNN_FILTERS[int(rng.integers(len(CNN_FILTERS)))]
+    while min(hw[0], hw[1]) < 2 ** (len(filters) - 1):          # every strided block must leave at least one pixel
+        filters = filters[:-1]
+    dense = int(rng.choice([8, 16, 32]))
+    case = "c4_bimodal_cnn" if rng.integers(2) else "c3_video_cnn_bi"
+    B, Tv = int(rng.integers(2, 5)), int(rng.integers(3, 7))
+    O, ocfg, mcfg, W, batch = make(case, B=B, Ta=4 * Tv, Tv=Tv, L=5, video_hw=hw, cnn_filters=filters, cnn_dense_units=dense, video_feat=dense,
+                                   use_dropout=bool(rng.integers(2)))
+    tag = (seed, case, hw, filters, dense, B, Tv)
+    ref = O.train_step(W, None, ocfg, batch)
+    model = Seq2SeqModel(mcfg, weights=W)
+    db = Batch.from_numpy(batch)
+    logits = model.forward_train(db)
+    model.backward()
+    model.apply_update()
+    torch.cuda.synchronize()
+    assert np.abs(logits.cpu().numpy() - ref["logits"]).max() < 1e-4, tag
+    assert abs(float(model.loss.item()) - ref["loss"]) < 1e-4, tag
+    assert abs(float(model.gnorm.item()) - ref["global_norm"]) < 1e-4 * max(1.0, ref["global_norm"]), tag
+    grads = model.export_tf_weights("grads")
+    for k, g in ref["grads"].items():
+        scale = max(1e-3, np.abs(g).max())
+        assert np.abs(grads[k] - g).max() < 2e-4 * scale + 1e-6, (tag, k)
+    ids_ref = O.greedy_decode(ref["params"], ocfg, batch, max_steps=6)
+    assert (model.greedy_decode(db, max_steps=6).cpu().numpy() == ids_ref).all(), tag
