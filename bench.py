@@ -141,18 +141,24 @@ def _physical_cores():
         return None
 
 
-def cpu_baseline(wl, stoch, sample_B=4, warmups=3, steps=10, video_frontend="features", budget_s=40.0):
-    """the CPU oracle (torch-CPU fp32 restatement, "port") on a bounded sample -- sample_B utterances at the FULL
-    T_a / T_v / T_dec of the workload -- 3 warm-up steps, then the MEDIAN of up to 10 timed steps (fewer only if the time budget
-    runs out; the count is reported).  'TF-1.13.1 CPU number unavailable' -- see BASELINE.md section 2."""
+def cpu_budget():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup's CPU quota (the GPU node shows 256 logical CPUs to a
+    container whose cpu.max is 16: a torch pool sized from the host's core count runs 10x slower there, profiles/r06_oracle_threads.txt)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _cpu_leg(wl, stoch, sample_B, video_frontend, warmups, steps, budget_s, onednn):
     from oracle import avsr_oracle as O
-    # the recurrent chain is thousands of tiny [B,H]x[H,4H] matmuls: past ~16 threads torch-CPU only adds
-    # synchronisation cost (256 hardware threads on the GPU node made a step take minutes), so cap it
-    ncores = min(16, os.cpu_count() or 1)
+    ncores = cpu_budget()
     torch.set_num_threads(ncores)
-    # torch-CPU's oneDNN convolution backward corrupted the heap on this image with the lip-CNN shapes (fp32, [300,3,36,36] frames):
-    # the native (non-oneDNN) kernels are used for the baseline
-    torch.backends.mkldnn.enabled = False
+    torch.backends.mkldnn.enabled = bool(onednn)
     ocfg = O.OracleConfig(video_processing=video_frontend, **wl["cfg"], **stoch)
     P = O.init_params(ocfg, seed=2001)
     b = O.synthetic_batch(ocfg, B=sample_B, T_a=TA, T_v=TV, L=LDEC)
@@ -160,46 +166,31 @@ def cpu_baseline(wl, stoch, sample_B=4, warmups=3, steps=10, video_frontend="fea
     for _ in range(warmups):
         O.train_step(P, None, ocfg, b, dtype=torch.float32)
     times = []
-    while len(times) < steps and (len(times) < 3 or time.perf_counter() - t_start < budget_s):
+    while len(times) < steps and (len(times) < 5 or time.perf_counter() - t_start < budget_s):
         t0 = time.perf_counter()
         O.train_step(P, None, ocfg, b, dtype=torch.float32)
         times.append(time.perf_counter() - t0)
     dt = float(np.median(times))
-    return {"value": round(sample_B / dt, 3), "unit": "utterances/sec", "cores": ncores, "kind": "port",
+    return {"value": round(sample_B / dt, 3), "unit": "utterances/sec", "cores": ncores, "kind": "port", "onednn": bool(onednn),
             "host_cpu": _cpu_model(), "host_physical_cores": _physical_cores(), "host_logical_cpus": os.cpu_count(),
+            "container_cpu_quota": ncores, "utterances": sample_B, "video_input": video_frontend,
             "timed_steps": len(times), "warmup_steps": warmups, "step_seconds_median": round(dt, 4),
-            "sample": "oracle/avsr_oracle.py train_step (torch-CPU fp32, autograd BPTT, %d threads), %d utterances at full T_a=%d T_v=%d L=%d "
-                      "(video input: %s), median of %d steps after %d warm-ups; TF-1.13.1 reference cannot run here"
-                      % (ncores, sample_B, TA, TV, LDEC, video_frontend, len(times), warmups)}
+            "sample": "oracle/avsr_oracle.py train_step (torch-CPU fp32, autograd BPTT, oneDNN %s, %d threads = the CPUs this container may use: "
+                      "affinity mask capped by the cgroup quota), B=%d utterances at full T_a=%d T_v=%d L=%d, video input: %s, median of %d timed steps "
+                      "after %d warm-ups; TF-1.13.1 reference cannot run here"
+                      % ("on" if onednn else "off", ncores, sample_B, TA, TV, LDEC, video_frontend, len(times), warmups)}
 
 
-def cpu_baseline_full(wl, stoch, budget_s=45.0):
-    """Second CPU figure, SURVEY 8(d) to the letter: the WHOLE workload batch (B utterances, not a 4-utterance sample), torch threads =
-    the host's physical cores, oneDNN enabled -- on the `features` video input (pre-computed 128-d lip features; the oneDNN heap
-    corruption on this image was in the convolution backward of the lip CNN only).  One warm-up step, then as many timed steps as fit
-    the budget (at least one): a B = 64 step takes tens of seconds, so this leg reports one to three steps and says so."""
-    from oracle import avsr_oracle as O
-    ncores = _physical_cores() or (os.cpu_count() or 1)
-    torch.set_num_threads(ncores)
-    torch.backends.mkldnn.enabled = True
-    ocfg = O.OracleConfig(video_processing="features", **wl["cfg"], **stoch)
-    P = O.init_params(ocfg, seed=2001)
-    Bf = wl["B"]
-    b = O.synthetic_batch(ocfg, B=Bf, T_a=TA, T_v=TV, L=LDEC)
-    t_start = time.perf_counter()
-    O.train_step(P, None, ocfg, b, dtype=torch.float32)
-    times = []
-    while len(times) < 3 and (not times or time.perf_counter() - t_start + times[-1] < budget_s):
-        t0 = time.perf_counter()
-        O.train_step(P, None, ocfg, b, dtype=torch.float32)
-        times.append(time.perf_counter() - t0)
-    dt = float(np.median(times))
-    return {"value": round(Bf / dt, 3), "unit": "utterances/sec", "cores": ncores, "kind": "port", "onednn": True,
-            "host_cpu": _cpu_model(), "host_physical_cores": _physical_cores(), "host_logical_cpus": os.cpu_count(),
-            "timed_steps": len(times), "warmup_steps": 1, "step_seconds_median": round(dt, 3),
-            "sample": "oracle/avsr_oracle.py train_step (torch-CPU fp32, autograd BPTT, oneDNN on, %d threads = physical cores), the whole "
-                      "batch of %d utterances at full T_a=%d T_v=%d L=%d, video input: 128-d lip features (no lip CNN), median of %d step(s) "
-                      "after 1 warm-up; TF-1.13.1 reference cannot run here" % (ncores, Bf, TA, TV, LDEC, len(times))}
+def cpu_baseline(wl, stoch, video_frontend="resnet_cnn", onednn=True):
+    """the CPU oracle (torch-CPU fp32 restatement, "port") on the SAME workload as the timed GPU step -- the workload's whole
+    batch (c4: 64 utterances) from the same input form (lip crops through the CNN front-end), every CPU the container may use, 3 warm-up
+    steps, then the median of >= 5 timed steps (more while a 60 s budget lasts).  'TF-1.13.1 CPU number unavailable' -- BASELINE.md section 2."""
+    return _cpu_leg(wl, stoch, wl["B"], video_frontend, warmups=3, steps=10, budget_s=60.0, onednn=onednn)
+
+
+def cpu_baseline_sample(wl, stoch, video_frontend="resnet_cnn"):
+    """The bounded sample of earlier rounds (4 utterances at full lengths), kept for continuity with BENCH_r01..r05."""
+    return _cpu_leg(wl, stoch, 4, video_frontend, warmups=3, steps=10, budget_s=20.0, onednn=False)
 
 
 def measure_traffic(args):
@@ -220,7 +211,7 @@ def measure_traffic(args):
     rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if rp is None:
         return None, "rocprofv3 not found"
-    base = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline", "--no-profile",
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline", "--no-profile", "--no-other-workloads",
             "--workload", args.workload, "--video-frontend", args.video_frontend] + (["--no-dropout"] if args.no_dropout else []) + \
            (["--batch", str(args.batch)] if args.batch else [])
     out = {}
@@ -247,6 +238,50 @@ def measure_traffic(args):
                  "of `bench.py --steps 2 --warmup 1 --no-graph` on the same workload, averages per dispatch")
 
 
+def collective_selftest(dist, world, rank, backend):
+    """Pre-flight for the first contact with N > 1 real devices: before anything is timed, every collective shape the step uses is
+    run on buffers with a known answer and checked EXACTLY (small integers: fp32 / fp64 sums are exact) -- the 13 MB fp32 gradient
+    all-reduce (SUM), the fp64 batch-norm moments vector (SUM), the fp64 MAX reduction and the all_gather of the timing block.  A
+    wrong sum aborts the run (a bench line over a broken transport would be worse than none).  Returns what goes into the JSON line:
+    the ranks the transport saw, the RCCL version, and the time of one 13 MB all-reduce after a warm-up."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    res = {"backend": "rccl" if backend == "nccl" else backend, "ranks": dist.get_world_size(), "rank0_device": torch.cuda.get_device_name(dev)}
+    try:
+        res["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+    except Exception:
+        res["rccl_version"] = None
+    tri = world * (world + 1) // 2
+    n = 13 * (1 << 20) // 4
+    pat = (torch.arange(n, device=dev, dtype=torch.int64) % 251).to(torch.float32)
+    for rep in range(2):                                           # first pass = transport set-up, second pass is the timed one
+        g = pat * float(rank + 1)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.all_reduce(g)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if not torch.equal(g, pat * float(tri)):
+            raise SystemExit("collective self-test FAILED: 13 MB fp32 all-reduce (SUM) over %d ranks returned a wrong sum on rank %d" % (world, rank))
+    res["allreduce_13MB_f32_us"] = round(1e6 * dt, 1)
+    m = (torch.arange(4096, device=dev, dtype=torch.float64) % 17) * float(rank + 1)
+    dist.all_reduce(m)
+    if not torch.equal(m, (torch.arange(4096, device=dev, dtype=torch.float64) % 17) * float(tri)):
+        raise SystemExit("collective self-test FAILED: fp64 moments all-reduce (SUM) on rank %d" % rank)
+    mx = torch.tensor([float(rank)], device=dev, dtype=torch.float64)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    if float(mx.item()) != float(world - 1):
+        raise SystemExit("collective self-test FAILED: fp64 all-reduce (MAX) on rank %d" % rank)
+    parts = [torch.zeros(4, device=dev, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(parts, torch.full((4,), float(rank), device=dev, dtype=torch.float64))
+    if [float(p[0].item()) for p in parts] != [float(r) for r in range(world)]:
+        raise SystemExit("collective self-test FAILED: all_gather on rank %d" % rank)
+    seen = sorted({int(p[0].item()) for p in parts})
+    res["ranks_seen"] = len(seen)
+    res["ok"] = True
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,9 +294,11 @@ def main():
     ap.add_argument("--video-frontend", default="resnet_cnn", choices=["features", "resnet_cnn"],
                     help="resnet_cnn (default): 36x36x3 lip crops through the CNN front-end, north_star's input; features: 128-d lip features")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--section", default=None, choices=[None, "aux_frontend", "cpu_baseline", "cpu_baseline_full"], help="internal: run one auxiliary section in a child process and print its JSON")
+    ap.add_argument("--section", default=None, choices=[None, "aux_frontend", "cpu_baseline", "cpu_baseline_noonednn", "cpu_baseline_sample"], help="internal: run one auxiliary section in a child process and print its JSON")
     ap.add_argument("--strong", action="store_true", help="N > 1: global batch fixed at the workload's B (B/N utterances per GPU) instead of B per GPU")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--brief", action="store_true", help="timed steps + the per-kernel event pass only (no counters, decode rates, other input form, CPU baseline)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the c2 / c3 / c5 lines appended to the default c4 run")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL does, through C stdio that is only
@@ -292,6 +329,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    selftest = collective_selftest(dist, world, rank, backend) if dist is not None else None
 
     trace = (lambda m: (torch.cuda.synchronize(), sys.stderr.write("[bench] %s\n" % m), sys.stderr.flush())) \
         if os.environ.get("AVSR_BENCH_TRACE") else (lambda m: None)
@@ -303,11 +341,12 @@ def main():
     wl = WORKLOADS[args.workload]
     B = args.batch or wl["B"]
     stoch = {} if args.no_dropout else dict(use_dropout=True, sampling_probability=0.1)   # avsr/avsr.py:51-56 defaults
-    if args.section == "cpu_baseline":
-        os.write(json_fd, (json.dumps(cpu_baseline(wl, stoch, video_frontend=args.video_frontend)) + "\n").encode())
+    if args.section in ("cpu_baseline", "cpu_baseline_noonednn"):
+        os.write(json_fd, (json.dumps(cpu_baseline(wl, stoch, video_frontend=args.video_frontend,
+                                                   onednn=args.section == "cpu_baseline")) + "\n").encode())
         return
-    if args.section == "cpu_baseline_full":
-        os.write(json_fd, (json.dumps(cpu_baseline_full(wl, stoch)) + "\n").encode())
+    if args.section == "cpu_baseline_sample":
+        os.write(json_fd, (json.dumps(cpu_baseline_sample(wl, stoch, video_frontend=args.video_frontend)) + "\n").encode())
         return
     if args.section == "aux_frontend":
         cfg2 = ModelConfig(audio_feat=FA, video_feat=FV, video_processing=args.video_frontend, **wl["cfg"], **stoch)
@@ -379,7 +418,7 @@ def main():
         "value": round(B * world * args.steps / dt, 2), "unit": "utterances/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "strong" if (args.strong and world > 1) else "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "persistent_wait_expired": persist_err,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic, device-resident (one batch replayed; no host-to-device copy in the timed region)", "persistent_wait_expired": persist_err,
         "config": {"workload": args.workload + ": " + wl["desc"], "utterances_per_gpu": B, "global_batch": B * world,
                    "T_a": TA, "F_a": FA, "T_v": TV, "F_v": FV, "T_dec": LDEC, "parallelism": "dp%d" % world,
                    "video_frontend": (cfg.video_processing if cfg.video_units is not None else None), "launch": trainer.mode, "dropout": bool(cfg.use_dropout), "dropout_keep": list(cfg.decoder_dropout) if cfg.use_dropout else None,
@@ -394,6 +433,7 @@ def main():
                                      "tests/test_gpu_dp.py::test_two_ranks_with_synchronised_cnn_batch_norms_equal_one_engine)") if world > 1 else None,
                    "parity": "vs CPU restatement of TF-1.13.1 semantics; TF parity unpinned"},
         "final_loss": round(loss, 5),
+        "rccl_ranks": (selftest["ranks_seen"] if selftest else None), "collective_selftest": selftest,
         # per rank: wall seconds of the timed loop before the closing barrier, and min / median / max GPU milliseconds per step (event
         # pairs; includes the collectives).  A slow rank or a slow step shows here: the first thing to read in a multi-GPU run.
         "rank_timing": {"seconds_before_barrier": [round(r[0], 4) for r in per_rank],
@@ -470,7 +510,7 @@ def main():
             pmc, pmc_file = {}, None
         # `traffic`: measured in THIS run where rocprofv3 is available (two --pmc passes of a short eager run, child processes: round 5);
         # the committed PMC summary above is the fallback, and the JSON says which one it was
-        live, why = measure_traffic(args) if world == 1 else (None, "multi-GPU run")
+        live, why = (None, "--brief") if args.brief else (measure_traffic(args) if world == 1 else (None, "multi-GPU run"))
         if live:
             pmc, pmc_file = live, why
         else:
@@ -582,7 +622,7 @@ def main():
 
         out["roofline"] = roof(dom)
         out["roofline_other"] = [roof(k) for k in kinds if k != dom and k != "step_dense"]
-    if rank == 0 and world == 1 and not args.no_profile:
+    if rank == 0 and world == 1 and not args.no_profile and not args.brief:
         # SURVEY 8(d) also asks for the greedy-decode rate: eval graph (no dropout, BN moving statistics), GreedyEmbeddingHelper,
         # T_dec steps per utterance (random weights never emit EOS, so every utterance runs all LDEC steps)
         trace("profile section done")
@@ -611,7 +651,7 @@ def main():
                                          "beam_width": 10, "steps": LDEC}
         except Exception as e:
             out["beam_search_decode"] = {"value": None, "error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_profile and cfg.video_units is not None:
+    if rank == 0 and world == 1 and not args.no_profile and not args.brief and cfg.video_units is not None:
         # The same workload with the OTHER video input: the headline feeds lip crops through the CNN front-end (north_star's
         # synthetic shape); `without_lip_cnn` is the step on pre-computed 128-d lip features, i.e. the replaced subsystems alone.
         # Runs in a child process: an auxiliary figure must not be able to take the headline line down with it.
@@ -634,31 +674,58 @@ def main():
                 {"value": None, "error": "child exit %d: %s" % (p.returncode, p.stderr.strip().splitlines()[-1][:200] if p.stderr.strip() else "")}
         except Exception as e:
             out[aux_key] = {"value": None, "error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # child process: the CPU oracle is test infrastructure and must not be able to take the headline line down with it
-        try:
-            import subprocess
-            cmd = [sys.executable, os.path.abspath(__file__), "--section", "cpu_baseline", "--video-frontend", args.video_frontend,
+    if rank == 0 and world == 1 and not args.brief and not args.no_other_workloads and args.workload == "c4" and not args.batch:
+        # The other BASELINE configs, driver-timed in the same command: the bench line of each (child process, --brief: the timed steps
+        # and the per-kernel event pass, nothing else), reduced to its step time, loss and dominant kernel.
+        import subprocess
+        out["other_workloads"] = {}
+        for w in ("c2", "c3", "c5"):
+            try:
+                cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", "10", "--warmup", "3", "--brief"] + \
+                      (["--no-graph"] if args.no_graph else []) + (["--no-dropout"] if args.no_dropout else [])
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+                if p.returncode != 0 or not lines:
+                    raise RuntimeError("child exit %d: %s" % (p.returncode, p.stderr.strip().splitlines()[-1][:200] if p.stderr.strip() else ""))
+                r = json.loads(lines[-1])
+                rf = r.get("roofline") or {}
+                out["other_workloads"][w] = {
+                    "workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                    "utterances_per_gpu": r["config"]["utterances_per_gpu"], "steps": r["steps"], "launch": r["config"]["launch"],
+                    "video_frontend": r["config"]["video_frontend"], "final_loss": r["final_loss"],
+                    "persistent_wait_expired": r["persistent_wait_expired"],
+                    "dominant_kernel": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us",
+                                                                "us_per_sequential_step", "us_per_audio_frame", "us_per_decode_step") if k in rf},
+                    "kernel_time_events_ms": {k: v["total_ms"] for k, v in (r.get("kernel_time_events") or {}).items()}}
+            except Exception as e:
+                out["other_workloads"][w] = {"value": None, "error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.brief:
+        # child processes: the CPU oracle is test infrastructure and must not be able to take the headline line down with it; thread
+        # count and oneDNN are process-wide, so every leg is its own child.  Main leg = the SAME workload as the timed GPU step (whole
+        # batch, same video input); oneDNN on, and once more without it if that child dies (an earlier image's oneDNN convolution
+        # backward corrupted the heap on the lip-CNN shapes) -- the JSON says which one ran.
+        import subprocess
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", "0"))
+
+        def leg(section, timeout):
+            cmd = [sys.executable, os.path.abspath(__file__), "--section", section, "--video-frontend", args.video_frontend,
                    "--workload", args.workload] + (["--no-dropout"] if args.no_dropout else [])
-            env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", "0"))
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-            lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-            out["cpu_baseline"] = json.loads(lines[-1]) if (p.returncode == 0 and lines) else \
-                {"value": None, "error": "child exit %d: %s" % (p.returncode, p.stderr.strip().splitlines()[-1][:200] if p.stderr.strip() else "")}
-        except Exception as e:
-            out["cpu_baseline"] = {"value": None, "error": repr(e)}
-        # second leg (its own child: thread count and oneDNN are process-wide): the whole batch on every physical core, features input
-        try:
-            cmd = [sys.executable, os.path.abspath(__file__), "--section", "cpu_baseline_full", "--workload", args.workload] + \
-                  (["--no-dropout"] if args.no_dropout else [])
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-            lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-            full = json.loads(lines[-1]) if (p.returncode == 0 and lines) else \
-                {"value": None, "error": "child exit %d: %s" % (p.returncode, p.stderr.strip().splitlines()[-1][:200] if p.stderr.strip() else "")}
-        except Exception as e:
-            full = {"value": None, "error": repr(e)}
-        if isinstance(out.get("cpu_baseline"), dict):
-            out["cpu_baseline"]["whole_batch_all_cores"] = full
+            try:
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+                lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+                if p.returncode == 0 and lines:
+                    return json.loads(lines[-1])
+                return {"value": None, "error": "child exit %d: %s" % (p.returncode, p.stderr.strip().splitlines()[-1][:200] if p.stderr.strip() else "")}
+            except Exception as e:
+                return {"value": None, "error": repr(e)}
+
+        main_leg = leg("cpu_baseline", 900)
+        if main_leg.get("value") is None:
+            first_error = main_leg.get("error")
+            main_leg = leg("cpu_baseline_noonednn", 900)
+            main_leg["onednn_attempt_error"] = first_error
+        out["cpu_baseline"] = main_leg
+        out["cpu_baseline"]["four_utterance_sample"] = leg("cpu_baseline_sample", 300)
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

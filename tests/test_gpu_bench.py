@@ -31,6 +31,10 @@ def test_bench_json_contract_and_forced_collectives():
     assert plain["n_gpus"] == 1 and plain["steps"] == 20 and plain["value"] > 0 and plain["config"]["launch"] == "hipgraph"
     forced = _bench({"AVSR_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
     assert forced["config"]["launch"] == "hipgraph"                # graphs are replayed around the collectives
+    st = forced["collective_selftest"]                             # RCCL pre-flight (known-answer all-reduces before anything is timed)
+    assert st["ok"] and st["backend"] == "rccl" and st["ranks"] == 1 and forced["rccl_ranks"] == 1 and st["allreduce_13MB_f32_us"] > 0
+    assert plain["collective_selftest"] is None and plain["rccl_ranks"] is None
+    assert plain["data"].startswith("synthetic, device-resident")
     # the strong-scaling section `--gpus N > 1` adds (global batch fixed: here 64 / 8 utterances on the one rank)
     strong = _bench({"AVSR_BENCH_FORCE_DIST": "1", "AVSR_BENCH_FORCE_STRONG": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29535"})
     assert strong["strong_scaling"]["value"] > 0 and strong["strong_scaling"]["utterances_per_gpu"] == 8 and strong["scaling"] == "weak"
@@ -41,31 +45,39 @@ def test_bench_json_contract_and_forced_collectives():
     assert abs(forced["final_loss"] - plain["final_loss"]) < 1e-4 * max(1.0, abs(plain["final_loss"]))
 
 
-def test_bench_two_ranks_over_gloo_with_persistent_kernels_contending():
-    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), except that the transport
-    is gloo and both ranks sit on the box's one GPU: weak-scaling headline + the strong-scaling section, hipGraph replays around the
-    collectives, and -- what a one-rank run can never show -- the persistent encoder / decoder kernels of TWO processes contending for
-    the same XCDs.  Whatever the dispatcher does (both grids resident, one after the other, or a bounded wait expiring -> flag
-    MAX-reduced over the ranks -> both redo through the per-step launches), the run must finish with one JSON line, finite equal
-    losses on the replicas' shared step count, and report the flag truthfully."""
+def _ranks_over_gloo(world, batch, steps):
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, AVSR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "8",
-           "--video-frontend", "features", "--no-cpu-baseline", "--no-profile"]
+    env = dict(os.environ, AVSR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(steps), "--warmup", "2",
+           "--batch", str(batch), "--video-frontend", "features", "--no-cpu-baseline", "--no-profile"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 16 and out["value"] > 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_ranks_over_gloo_with_persistent_kernels_contending(world):
+    """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one process per rank; N = 2 and the driver's
+    N = 8), except that the transport is gloo and all ranks sit on the box's one GPU: weak-scaling headline + the strong-scaling
+    section, the collective self-test, hipGraph replays around the collectives, and -- what a one-rank run can never show -- the
+    persistent encoder / decoder kernels of SEVERAL processes contending for the same XCDs.  Whatever the dispatcher does (grids
+    resident together, one after the other, or a bounded wait expiring -> flag MAX-reduced over the ranks -> all redo through the
+    per-step launches), the run must finish with one JSON line, finite equal losses on the replicas' shared step count, and report
+    the flag truthfully."""
+    out = _ranks_over_gloo(world, 8, 6 if world == 2 else 3)
+    assert out["n_gpus"] == world and out["scaling"] == "weak" and out["config"]["global_batch"] == 8 * world and out["value"] > 0
     assert out["config"]["collectives_per_step"] == 2
+    assert out["collective_selftest"]["ok"] and out["rccl_ranks"] == world and out["collective_selftest"]["backend"] == "gloo"
+    assert len(out["rank_timing"]["seconds_before_barrier"]) == world
     assert out["final_loss"] == out["final_loss"] and abs(out["final_loss"]) < 100.0            # finite
     ss = out["strong_scaling"]
-    assert ss.get("value") and ss["utterances_per_gpu"] == 32 and ss["global_batch"] == 64, ss
+    assert ss.get("value") and ss["utterances_per_gpu"] == 64 // world and ss["global_batch"] == 64, ss
     assert isinstance(out["persistent_wait_expired"], bool) and isinstance(ss["persistent_wait_expired"], bool)   # reported either way
 
 
