@@ -26,16 +26,10 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-# Two alternative layouts of the persistent encoder kernels that were built, verified and measured slower (split BPTT,
-# pair-layout forward; AVSR_PERSISTENT_RNN bits 2 and 3).  Not part of the default library: AVSR_BUILD_EXPERIMENTAL=1 adds them.
-EXPERIMENTAL = ["experimental/rnn_persist_pair.hip", "experimental/rnn_persist_bwd2.hip"]
-
-
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    experimental = os.environ.get("AVSR_BUILD_EXPERIMENTAL") == "1"
-    srcs = [os.path.join(CSRC, s) for s in SOURCES + (EXPERIMENTAL if experimental else []) if os.path.exists(os.path.join(CSRC, s))]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
     objs = []
     procs = []
     for s in srcs:
@@ -43,8 +37,6 @@ def build(force=False, verbose=False):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
                "-Wno-pass-failed", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", s, "-o", o]
         cmd[1:1] = os.environ.get("AVSR_HIPCC_FLAGS", "").split()     # e.g. -DPERSIST_TIMING for the probes
-        if experimental:
-            cmd[1:1] = ["-DAVSR_EXPERIMENTAL"]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(o)
     for cmd, p in procs:

@@ -224,7 +224,11 @@ class LipCNN:
             if op[0] == "conv" and op[1] in self.mfma:
                 _, name, _src, _dst, k, _s, cin, cout = op
                 self.wg_off[name] = off
-                off += 1024 * max(k * k * cin * cout + cout, 12 * cin * 16 + 16)     # (up to four workgroups per CU leave a slab each)
+                # the kernel's own rule (conv_bwd_weight_impl): slabs above 2048 floats come from at most 256 workgroups (one per CU:
+                # there the partial slabs, not the staging, are the traffic), smaller ones from up to four workgroups per CU
+                # (a launch covers the whole kernel or a group of its taps: whichever of the two caps needs more floats)
+                slab = max(k * k * cin * cout + cout, 12 * cin * 16 + 16)
+                off += max(256 * slab, 1024 * min(slab, 2048))
         # ONE buffer per model, shared by the LipCNN of every workspace shape (the region sizes do not depend on N; the slabs are live
         # only inside one backward pass, and passes -- eager or replayed graphs -- are serialised on the engine's stream): a buffer
         # per shape was ~180 MB x (8 cached + 8 pinned) shapes

@@ -895,6 +895,15 @@ extern "C" int avsr_attn_rnn_fused_eligible(const avsr_attn_rnn* d) {
   return dp_plan(*d, L, &variant, &lds) == AVSR_OK ? 1 : 0;
 }
 
+// the SAME run-time conditions avsr_dec_persist_fwd declines on, on top of the plan: a caller that sizes its host checks by the answer
+// (greedy decode runs all steps as ONE call when it is 1) must not be told "fused" and then get one launch per step and phase
+extern "C" int avsr_attn_rnn_fused_fwd_active(const avsr_attn_rnn* d) {
+  using namespace avsr;
+  if (g_dec_fused == 3 || g_dec_fused == 0 || !g_sync) return 0;
+  if ((long)(P_HDR + 8 + 8 * 4 * 32) > g_sync_ints) return 0;
+  return avsr_attn_rnn_fused_eligible(d);
+}
+
 // Steps [l_begin, l_end) of the decoder as one persistent launch per 64-row slice.  The caller (avsr_attn_rnn_fwd) has
 // initialised the state / slot-0 records exactly as for the per-step path and copies h_final / c_final afterwards.
 int avsr_dec_persist_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32_t l_end, void* stream) {

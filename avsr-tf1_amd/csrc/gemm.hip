@@ -407,6 +407,28 @@ static bool vec_ok(const avsr_mat* m, bool contig_is_k, int MN, int K) {
 
 }  // namespace avsr
 
+// AVSR_GEMM_LOG=1: every launch is bracketed by events, waited for, and printed to stderr with its shapes (tools/gemm_step_log.py);
+// a debugging aid -- it serialises the stream -- never set in a timed run
+#include <cstdio>
+#include <cstdlib>
+static bool gemm_log_on() { static int v = -1; if (v < 0) { const char* e = getenv("AVSR_GEMM_LOG"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
+struct GemmLog {
+  hipEvent_t e0, e1; hipStream_t s; bool on;
+  explicit GemmLog(hipStream_t st) : s(st), on(gemm_log_on()) { if (on) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); } }
+  void done(const avsr::GemmArgs* g, int n, const char* what) {
+    if (!on) return;
+    hipEventRecord(e1, s); hipEventSynchronize(e1);
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    double fl = 0.0;
+    for (int i = 0; i < n; ++i) fl += 2.0 * g[i].M * g[i].N * g[i].K * g[i].batch;
+    fprintf(stderr, "[gemm] %s %8.1f us %6.1f TF :", what, ms * 1e3, fl / (ms * 1e-3) * 1e-12);
+    for (int i = 0; i < n; ++i) fprintf(stderr, " (M=%d N=%d K=%d ta=%d tb=%d splitk=%d batch=%d beta=%g%s)", g[i].M, g[i].N, g[i].K, g[i].ta, g[i].tb,
+                                         g[i].splitk, g[i].batch, g[i].beta, g[i].cs_out ? " colsum" : "");
+    fprintf(stderr, "\n");
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+};
+
 // descriptor -> kernel arguments; *cls = operand-layout class (akc, bkc, vec a, vec b as bits 3..0); AVSR_OK or an error code
 static int gemm_prepare(const avsr_gemm_desc* d, avsr::GemmArgs& g, dim3* grid, int* cls) {
   using namespace avsr;
@@ -486,6 +508,7 @@ extern "C" int avsr_gemm_batch(const avsr_gemm_desc* descs, int32_t n, void* str
       done[j] = true;
     }
     G.blk_off[G.n] = blocks; G.red_off[G.n] = rblocks;
+    GemmLog gl(s);
     ProfScope ps(PROF_GEMM, s, flops);
 #define GG(AK, BK_, VA, VB) hipLaunchKernelGGL((gemm_f32_group_kernel<AK, BK_, VA, VB>), dim3(blocks), dim3(256), 0, s, G)
     switch (cls[i]) {
@@ -504,6 +527,7 @@ extern "C" int avsr_gemm_batch(const avsr_gemm_desc* descs, int32_t n, void* str
       hipLaunchKernelGGL(gemm_splitk_reduce_group_kernel, dim3(rblocks), dim3(256), 0, s, G);
       AVSR_CHECK_LAUNCH();
     }
+    gl.done(G.g, G.n, "group ");
   }
   return AVSR_OK;
 }
@@ -516,6 +540,7 @@ extern "C" int avsr_gemm(const avsr_gemm_desc* d, void* stream) {
   const int rc = gemm_prepare(d, g, &grid, &cls);
   if (rc != AVSR_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
+  GemmLog gl(s);
   ProfScope ps(PROF_GEMM, s, 2.0 * g.M * g.N * g.K * g.batch);
 #define GO(AK, BK_, VA, VB) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, VA, VB>), grid, dim3(256), 0, s, g)
   switch (cls) {
@@ -537,5 +562,6 @@ extern "C" int avsr_gemm(const avsr_gemm_desc* d, void* stream) {
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g);
     AVSR_CHECK_LAUNCH();
   }
+  gl.done(&g, 1, "single");
   return AVSR_OK;
 }

@@ -11,9 +11,7 @@
 
 extern "C" int avsr_step_launch_raw(const void* launch, void* stream);
 int avsr_rnn_fwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
-int avsr_rnn_fwd_persistent_pair(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
 int avsr_rnn_bwd_persistent(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
-int avsr_rnn_bwd_persistent_split(const avsr_rnn_stack* st, int32_t n, void* stream, int dry);
 
 // Persistent execution: all stacks in one launch when they fit together, else one launch per stack when every
 // stack fits on its own (checked first: nothing runs unless everything can), else AVSR_ERR_UNSUPPORTED.
@@ -68,10 +66,6 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   {
     int rc = AVSR_ERR_UNSUPPORTED;                                            // one launch for the whole sequence when it fits:
-#ifdef AVSR_EXPERIMENTAL                                                      // (csrc/experimental/: built with AVSR_BUILD_EXPERIMENTAL=1)
-    rc = run_persistent(avsr_rnn_fwd_persistent_pair, st, n, stream);        // 16-row groups on XCD pairs first (mode bit 3),
-    if (rc != AVSR_ERR_UNSUPPORTED) return rc;
-#endif
     rc = run_persistent(avsr_rnn_fwd_persistent, st, n, stream);             // 8-row groups per XCD / the agent-scope form
     if (rc != AVSR_ERR_UNSUPPORTED) return rc;
   }
@@ -226,10 +220,6 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
   if (ntask_max > STEP_MAX_TASKS) return AVSR_ERR_UNSUPPORTED;
   {
     int rc = AVSR_ERR_UNSUPPORTED;                                            // one launch for the whole BPTT when it fits:
-#ifdef AVSR_EXPERIMENTAL
-    rc = run_persistent(avsr_rnn_bwd_persistent_split, st, n, stream);       // split form first (mode bit 2), then the fused form
-    if (rc != AVSR_ERR_UNSUPPORTED) return rc;
-#endif
     rc = run_persistent(avsr_rnn_bwd_persistent, st, n, stream);
     if (rc != AVSR_ERR_UNSUPPORTED) return rc;
   }

@@ -1706,6 +1706,7 @@ class Seq2SeqModel:
         D["steplen"].fill_(L)
         D["tok"].fill_(cfg.go_id)
         D["ids"].zero_()
+        D["logits"].zero_()          # a group of the fused kernel that exits early leaves its later steps unwritten: zeros, not a previous batch's logits
         d = self._block_desc(ws, D, D["steplen"], 1, D["h0"], D["c0"], with_bwd=False)
         d.output_attention = int(cfg.output_attention())
         d.embedding = ops.fptr(*self._emb())
@@ -1716,7 +1717,7 @@ class Seq2SeqModel:
         # host waits).  Steps past the end change nothing: finished rows are frozen (impute_finished) and t_out is the longest row.
         # The fused persistent decode kernel stops by itself, group by group, once every utterance of a group has emitted EOS
         # (dec_persist.hip): all maximum_iterations steps are then ONE launch and the host never looks at the device in between.
-        if self.fused_decode and ops.attn_rnn_fused_eligible(d):
+        if self.fused_decode and ops.attn_rnn_fused_fwd_active(d):
             check_every = L
         fr = self._flag_reader()
         l, pending = 0, False

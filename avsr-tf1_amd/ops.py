@@ -453,6 +453,11 @@ def attn_rnn_fused_eligible(desc):
     return bool(_L().avsr_attn_rnn_fused_eligible(C.byref(desc)))
 
 
+def attn_rnn_fused_fwd_active(desc):
+    """Will avsr_attn_rnn_fwd run the fused forward kernel NOW (eligible + switched on + sync scratch registered)?"""
+    return bool(_L().avsr_attn_rnn_fused_fwd_active(C.byref(desc)))
+
+
 def attn_rnn_set_fused(on):
     check(_L().avsr_attn_rnn_set_fused(int(on)), "avsr_attn_rnn_set_fused")   # 0 off, 1 / True both, 2 forward only, 3 backward only
 

@@ -259,22 +259,26 @@ class DataParallelTrainer:
         do_check = self.check_every_step or not self._checked
         self._checked = True
         eager_now = not self.use_graph
-        # sightings per shape (halved every 1024 steps so that a new phase of a curriculum can displace the old one's shapes)
-        n = self._seen.pop(key, 0) + 1
-        self._seen[key] = n
-        while len(self._seen) > 4096:
-            self._seen.popitem(last=False)
-        self._steps_seen = getattr(self, "_steps_seen", 0) + 1
-        if self._steps_seen % 1024 == 0:
-            for k in list(self._seen):
-                self._seen[k] = (self._seen[k] + 1) // 2
+        n = 0
+        if self.use_graph:
+            # sightings per shape (halved every 1024 steps so that a new phase of a curriculum can displace the old one's shapes);
+            # no bookkeeping once the trainer launches eagerly for good (sync_cnn_bn, AVSR_DP_GRAPH=0, a failed capture)
+            n = self._seen.pop(key, 0) + 1
+            self._seen[key] = n
+            while len(self._seen) > 4096:
+                self._seen.popitem(last=False)
+            self._steps_seen = getattr(self, "_steps_seen", 0) + 1
+            if self._steps_seen % 1024 == 0:
+                for k in list(self._seen):
+                    self._seen[k] = (self._seen[k] + 1) // 2
         if self.use_graph and key not in self._graphs:
             eager_now = n < self.graph_after
-            if not eager_now and self.graph_after > 1 and len(self._graphs) >= self.MAX_GRAPHS:
+            if not eager_now and len(self._graphs) >= self.MAX_GRAPHS:
                 # Cache full.  Capturing costs two extra passes of host launches, an instantiation and a pinned workspace: with more
                 # recurring shapes than slots, least-recently-used replacement recaptures for ever (measured: AVSR.train on utterances of
                 # 450-500 frames ran at 0.6-0.8x its eager rate).  A new shape displaces the LEAST OFTEN seen captured shape, and only
-                # once it has been seen clearly more often; otherwise it keeps launching eagerly.
+                # once it has been seen clearly more often (graph_after = 1, capture at first sight, included: a shape seen once does
+                # not displace one that has been replayed); otherwise it keeps launching eagerly.
                 victim = min(self._graphs, key=lambda k: self._seen.get(k, 0))
                 if n <= self._seen.get(victim, 0) + self.graph_after:
                     eager_now = True
@@ -297,6 +301,9 @@ class DataParallelTrainer:
             # the same do_check -- while the other ranks capture or replay.  Allocations later in the pass are only retried on a single
             # rank: under collectives the aborted pass may already have started the bucket all-reduce, and a retry would pair a second
             # set of reductions with the other ranks' one.
+            # (Under collectives an out-of-memory anywhere else in the step -- the lazily allocated synchronisation buffers in front of
+            # the step's first all-reduce, an allocation later in the pass -- is FATAL for the job: the failing rank raises while the
+            # others block in a collective; the launcher's timeout ends them.  A rank cannot leave a collective schedule on its own.)
             prep = getattr(m, "prepare_workspace", None)
             try:
                 if prep is not None:

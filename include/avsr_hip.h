@@ -349,8 +349,13 @@ typedef struct avsr_attn_rnn {
   int64_t fused_ws_floats;
 } avsr_attn_rnn;
 int64_t avsr_attn_rnn_fused_ws_floats(int32_t B, int32_t n_mech, int32_t Dmax);
-/* 1 if avsr_attn_rnn_fwd(d, ...) would run the fused persistent decode kernel for this descriptor, else 0. */
+/* 1 if the fused persistent decode kernels are built for this descriptor (the block is inside their plan), else 0. */
 int avsr_attn_rnn_fused_eligible(const avsr_attn_rnn* d);
+/* 1 if avsr_attn_rnn_fwd(d, ...) WILL run the fused forward kernel right now: eligible, forward fusion switched on
+ * (avsr_attn_rnn_set_fused 1 or 2) and the persistent sync scratch registered and large enough.  Greedy decode
+ * (avsr/decoder_unimodal.py:176-217) issues all maximum_iterations steps as one call only then; otherwise it keeps its
+ * host check every few steps. */
+int avsr_attn_rnn_fused_fwd_active(const avsr_attn_rnn* d);
 /* avsr_attn_rnn_bwd runs the same block's BPTT loop as one launch of the fused persistent backward kernel (csrc/dec_persist_bwd.hip)
  * under the same conditions.  Process-wide switch: 0 per-step launches, 1 (default) fused forward and backward, 2 forward only,
  * 3 backward only; the path also needs avsr_rnn_set_persistent's sync scratch. */

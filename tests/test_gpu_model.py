@@ -328,7 +328,7 @@ def test_baseline_widths_c3_cnn_and_c5_b128(case, over, shape):
     assert (model.greedy_decode(db, max_steps=6).cpu().numpy() == ids_ref).all()
 
 
-@pytest.mark.parametrize("mode", ["0", "3"])         # (bits 2 / 3 select the csrc/experimental/ kernels: AVSR_BUILD_EXPERIMENTAL=1 builds only)
+@pytest.mark.parametrize("mode", ["0", "3"])         # per-step launches / the persistent kernels
 @pytest.mark.parametrize("case,over", FULL_WIDTH)
 def test_full_width_train_step(case, over, mode, monkeypatch):
     from avsr_tf1_amd import ops
