@@ -501,11 +501,17 @@ def main():
         pmc, pmc_file = {}, None
         try:
             if args.workload == "c4" and args.video_frontend == "resnet_cnn":
-                for cand in ("r05_c4_lipcnn_pmc_v2.json", "r05_c4_lipcnn_pmc_v1.json", "r04_c4_lipcnn_pmc_v5.json", "r04_c4_lipcnn_pmc_v4.json", "r04_c4_lipcnn_pmc_v3.json", "r04_c4_lipcnn_pmc_v1.json", "r03_c4_lipcnn_pmc_v2.json", "r03_c4_lipcnn_pmc_v1.json", "r02_c4_lipcnn_pmc_v5.json"):
-                    path = os.path.join(ROOT, "profiles", cand)
-                    if os.path.exists(path):
-                        pmc, pmc_file = json.load(open(path))["kernels"], "profiles/" + cand
-                        break
+                # the newest committed counter summary of this workload (profiles/rNN_c4_lipcnn_pmc_vK.json: highest round, then version)
+                import glob
+                import re
+                cands = []
+                for path in glob.glob(os.path.join(ROOT, "profiles", "r*_c4_lipcnn_pmc_v*.json")):
+                    mm = re.search(r"r(\d+)_c4_lipcnn_pmc_v(\d+)\.json$", path)
+                    if mm:
+                        cands.append((int(mm.group(1)), int(mm.group(2)), path))
+                if cands:
+                    path = max(cands)[2]
+                    pmc, pmc_file = json.load(open(path))["kernels"], "profiles/" + os.path.basename(path)
         except Exception:
             pmc, pmc_file = {}, None
         # `traffic`: measured in THIS run where rocprofv3 is available (two --pmc passes of a short eager run, child processes: round 5);
@@ -565,6 +571,9 @@ def main():
                 return {"kernel": kind, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK, 4), "traffic": traffic(kind), "algorithmic_bytes_per_decode_step": int(byts),
                         "rows_per_launch": rows, "decode_steps_per_launch": LDEC, "us_per_decode_step": round(per_step_us, 3), "avg_launch_us": us,
+                        "figure": "speed-equivalent, not a bandwidth measurement: the algorithmic bytes a per-step attention kernel would stream, "
+                                  "divided by the measured time per decode step; the keys / values are register- and LDS-resident here, so the "
+                                  "HBM counters (`traffic`) read a few percent of the algorithmic bytes",
                         "note": "whole decode step (cell + scores/softmax/context + attention layer + output layer + sample) fused; keys/values resident on chip"
                         if kind == "dec_persist_fwd" else
                         "whole BPTT step (attention-layer transpose + attention backward + cell backward) fused; the per-step attention backward "
@@ -674,7 +683,7 @@ def main():
                 {"value": None, "error": "child exit %d: %s" % (p.returncode, p.stderr.strip().splitlines()[-1][:200] if p.stderr.strip() else "")}
         except Exception as e:
             out[aux_key] = {"value": None, "error": repr(e)}
-    if rank == 0 and world == 1 and not args.brief and not args.no_other_workloads and args.workload == "c4" and not args.batch:
+    if rank == 0 and world == 1 and not args.brief and not args.no_profile and not args.no_other_workloads and args.workload == "c4" and not args.batch:
         # The other BASELINE configs, driver-timed in the same command: the bench line of each (child process, --brief: the timed steps
         # and the per-kernel event pass, nothing else), reduced to its step time, loss and dominant kernel.
         import subprocess
@@ -729,7 +738,15 @@ def main():
     if rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
-        dist.destroy_process_group()
+        # every rank leaves together: rank 0 alone runs the per-kernel event pass above, and a communicator torn down under a rank that
+        # is still working has hung the launcher on some stacks -- one closing barrier, then the teardown (errors there cannot change the
+        # line that has already been printed)
+        try:
+            dist.barrier()
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+        except Exception as e:      # noqa: BLE001
+            sys.stderr.write("[bench] process-group teardown: %r\n" % (e,))
 
 
 if __name__ == "__main__":

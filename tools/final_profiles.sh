@@ -3,7 +3,7 @@
 #   bench lines of c4 (headline) / c2 / c3 / c5, rocprofv3 kernel statistics of an eager c4 step, FETCH_SIZE / WRITE_SIZE / MFMA-busy
 #   counter passes (each --pmc pass on its own, with --kernel-trace only).   usage: tools/final_profiles.sh <tag, e.g. r04 v2>
 cd "$(dirname "$0")/.." || exit 1
-R=${1:-r05}; V=${2:-v1}; O=gpurun_out; export TMPDIR=/tmp
+R=${1:-r06}; V=${2:-v1}; O=gpurun_out; export TMPDIR=/tmp
 mkdir -p $O/ck
 python bench.py > $O/${R}_bench_default_${V}.json 2> $O/${R}_bench_default_${V}.err
 for w in c2 c3 c5; do timeout 400 python bench.py --workload $w --no-cpu-baseline --steps 10 > $O/${R}_bench_${w}_${V}.json 2>/dev/null; done
