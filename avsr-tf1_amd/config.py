@@ -179,13 +179,11 @@ class ModelConfig:
             raise Exception('Unsupported optimiser, try Adam')                            # seq2seq.py:218
         for st in self.streams():                 # the wrapper flags only where the reference applies them (see `wrapped`)
             u = self.units(st)
-            if self.highway(st) and (self.cell_type != "lstm" or self.encoder_weight_sharing):
-                raise NotImplementedError("highway_encoder: LSTM cells without weight sharing only")
+            if self.highway(st) and self.encoder_weight_sharing:
+                raise NotImplementedError("highway_encoder with encoder_weight_sharing")
             if self.highway(st) or self.residual(st):
                 if len(set(u)) != 1:
                     raise ValueError("residual_encoder needs equal layer widths")
-                if self.cell_type != "lstm":
-                    raise NotImplementedError("residual_encoder: LSTM cells only")
             if self.encoder_weight_sharing and self.wrapped(st):
                 if len(u) > 2 and (len(set(u[1:])) != 1 or u[0] != u[1]):
                     raise ValueError("encoder_weight_sharing needs equal layer sizes: layers >= 2 reuse layer 1's kernel")

@@ -80,7 +80,6 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
       if (Ly.units % 4 || Ly.in_dim % 4 || !Ly.wt || !Ly.gates || !Ly.cs || !Ly.state) return AVSR_ERR_ARG;
       if (Ly.hoisted && l != 0) return AVSR_ERR_ARG;
       if (Ly.residual && (l == 0 || Ly.in_dim != Ly.units || !S.layer[l - 1].out)) return AVSR_ERR_ARG;
-      if (Ly.residual && S.cell != 0) return AVSR_ERR_UNSUPPORTED;
       // zero initial state: h parity 0, c parity 0
       if (avsr::dev_zero(hbuf(Ly, S.B, 0), sizeof(float) * S.B * Ly.units, s) != hipSuccess) return AVSR_ERR_HIP;
       if (avsr::dev_zero(cbuf(Ly, S.B, 0), sizeof(float) * S.B * Ly.units, s) != hipSuccess) return AVSR_ERR_HIP;
@@ -112,7 +111,7 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
             if (l == 0) return AVSR_ERR_UNSUPPORTED;
             const avsr_rnn_layer& Lo = S.layer[l - 1];
             StepSrc& x = tk.src[tk.nsrc++];
-            x.a = S.seed ? xbuf(Lo, S.B, (t + 1) & 1) : hbuf(Lo, S.B, (t + 1) & 1); x.sb = Lo.units; x.K = in; x.w = wt; x.ldw = in + H; x.kind = SRC_PLAIN;
+            x.a = (S.seed || Lo.residual) ? xbuf(Lo, S.B, (t + 1) & 1) : hbuf(Lo, S.B, (t + 1) & 1); x.sb = Lo.units; x.K = in; x.w = wt; x.ldw = in + H; x.kind = SRC_PLAIN;
           }
           StepSrc& h = tk.src[tk.nsrc++];
           h.a = phase == 0 ? hbuf(Ly, S.B, t & 1) : hbuf(Ly, S.B, 2) /* r*h */; h.sb = H; h.K = H; h.w = wt + in; h.ldw = in + H; h.kind = SRC_PLAIN;
@@ -127,12 +126,19 @@ extern "C" int avsr_rnn_fwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
             tk.p2 = Ly.out ? Ly.out + Ly.ld_out + Ly.out_col : nullptr;
             tk.s0 = (long)(S.T + 2) * Ly.ld_out; tk.s1 = Ly.ld_out;
             tk.p6 = hbuf(Ly, S.B, (t + 1) & 1);
+            if (Ly.residual) {   // + raw input = the lower layer's output record (slot 1 = time 0), as for the LSTM below
+              const avsr_rnn_layer& Lo = S.layer[l - 1];
+              tk.p8 = Lo.out + Lo.ld_out + Lo.out_col; tk.pad0 = (int)((long)(S.T + 2) * Lo.ld_out); tk.pad1 = (int)Lo.ld_out;
+            }
             if (S.seed) {
               set_cell_dropout(tk, S, l);
               tk.s4 = (long)(S.T + 2) * H; tk.s5 = H;
               if (Ly.hs_seq) tk.p9 = Ly.hs_seq + H;
               if (l + 1 < S.n_layers) tk.p10 = xbuf(Ly, S.B, (t + 1) & 1);
               if (Ly.xt_seq) tk.p11 = Ly.xt_seq + H;
+            } else if (Ly.residual) {
+              if (l + 1 < S.n_layers) tk.p10 = xbuf(Ly, S.B, (t + 1) & 1);   // no masks: the plain residual sum, for the layer above
+              if (Ly.hs_seq) { tk.p9 = Ly.hs_seq + H; tk.s4 = (long)(S.T + 2) * H; tk.s5 = H; }   // h itself: `out` holds h + x
             }
           }
           continue;
@@ -242,8 +248,10 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
         if (gru) {
           if (!Ly.w2 || !Ly.dgates2) return AVSR_ERR_ARG;
           // h(t-1) as the cell consumed it: the state-dropped sequence under dropout, else the output sequence
-          const float* hseq = S.seed ? Ly.hs_seq : Ly.out + Ly.out_col;
-          const long hld = S.seed ? H : Ly.ld_out;
+          const bool own_h = S.seed || Ly.residual;        // (a residual layer's output record holds h + x)
+          if (own_h && !Ly.hs_seq) return AVSR_ERR_ARG;
+          const float* hseq = own_h ? Ly.hs_seq : Ly.out + Ly.out_col;
+          const long hld = own_h ? H : Ly.ld_out;
           tk.B = S.B; tk.N = H; tk.t = t; tk.T = S.T; tk.reverse = S.reverse; tk.len = S.len;
           tk.p0 = Ly.gates;
           tk.p2 = const_cast<float*>(hseq) + (S.reverse ? 2 * hld : 0); tk.s2 = (long)(S.T + 2) * hld; tk.s3 = hld;
@@ -264,7 +272,10 @@ extern "C" int avsr_rnn_bwd(const avsr_rnn_stack* st, int32_t n, void* stream) {
             if (Ly.dout) {
               tk.p8 = const_cast<float*>(Ly.dout) + Ly.ld_dout + Ly.dout_col;
               tk.s0 = (long)(S.T + 2) * Ly.ld_dout; tk.s1 = Ly.ld_dout;
+            } else if (l + 1 < nl && S.layer[l + 1].residual) {
+              tk.p8 = dresbuf(S.layer[l + 1], S.B, t & 1); tk.s0 = H; tk.s1 = 0;   // d(output) through the upper layer's residual sum
             }
+            if (Ly.residual) tk.p10 = dresbuf(Ly, S.B, t & 1);
             if (S.seed) {
               set_cell_dropout(tk, S, l);
               if (l + 1 >= nl) tk.k_in = 1.0f;

@@ -353,7 +353,10 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
         const float h = uu * hprev + (1.f - uu) * cand;
         tk.p0[bt * H + nn] = cand;
         const uint32_t oidx = (uint32_t)(bt * H + nn);
-        const float ho = h * drop_scale(tk.seed, tk.r_out, oidx, tk.k_out);
+        float ho = h * drop_scale(tk.seed, tk.r_out, oidx, tk.k_out);
+        // ResidualWrapper (cells.py:91-92): emitted output = (dropped) cell output + the layer's raw input (the lower layer's output
+        // record: p8 base, pad0 batch stride, pad1 time stride), as in the LSTM epilogue
+        if (tk.p8) ho += tk.p8[(long)bb * tk.pad0 + (long)ta * tk.pad1 + nn];
         const float hs = h * drop_scale(tk.seed, tk.r_st, oidx, tk.k_st);
         if (tk.p2) tk.p2[(long)bb * tk.s0 + (long)ta * tk.s1 + nn] = ho;
         tk.p6[bh] = hs;
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(TN * KP * 64) void step_kernel(const StepLaunch L) 
         const uint32_t oidx = (uint32_t)(bt * H + nn);
         float dout = zB * drop_scale(tk.seed, tk.r_in, (uint32_t)(bt * tk.in_W + tk.in_coff + nn), tk.k_in);
         if (tk.p8) dout += tk.p8[(long)bb * tk.s0 + (long)ta * tk.s1 + nn];
+        if (tk.p10) tk.p10[bh] = dout;          // ResidualWrapper: the same gradient also reaches the lower layer's output
         const float dh = dout * drop_scale(tk.seed, tk.r_out, oidx, tk.k_out) + (z + carry) * drop_scale(tk.seed, tk.r_st, oidx, tk.k_st);
         const float uu = tk.p0[(bt * H + nn) * 2 + 1], cand = tk.p1[bt * H + nn];
         const float hprev = tk.p2[(long)bb * tk.s2 + (long)ta * tk.s3 + nn];

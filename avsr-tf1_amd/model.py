@@ -494,7 +494,7 @@ class Seq2SeqModel:
         Ld = E["layers"][(d, l)]
         u = E["units"][l]
         st = RnnStack()
-        st.B, st.T, st.reverse, st.n_layers, st.cell = B, E["T"], int(d == "bw"), 1, 0
+        st.B, st.T, st.reverse, st.n_layers, st.cell = B, E["T"], int(d == "bw"), 1, int(self.gru)
         st.len = ops.fptr(len_t)
         drop = self._sdrop(s)
         if drop:
@@ -506,6 +506,11 @@ class Seq2SeqModel:
         Ly.units, Ly.in_dim, Ly.hoisted = u, (E["F0"] if l == 0 else u), 1
         Ly.wt, Ly.w = ops.fptr(self.derived, self.Tr[name].off), ops.fptr(self.params, self.P[name].off)
         Ly.bias = ops.fptr(self.params, self.P[bname].off)
+        if self.gru:                             # candidate kernel; its hoisted input part sits in the c~ record (`cs`)
+            cn = f"{s}/enc/{d}/l{l}/cand_kernel"
+            Ly.wt2, Ly.w2 = ops.fptr(self.derived, self.Tr[cn].off), ops.fptr(self.params, self.P[cn].off)
+            Ly.bias2 = ops.fptr(self.params, self.P[f"{s}/enc/{d}/l{l}/cand_bias"].off)
+            Ly.rh_seq, Ly.dgates2 = ops.fptr(Ld["rh"]), ops.fptr(Ld["dpc"])
         Ly.gates, Ly.cs = ops.fptr(Ld["gates"]), ops.fptr(Ld["cs"])
         if l == 0:
             Ly.out, Ly.ld_out, Ly.out_col = ops.fptr(Ld["out"].t), Ld["out"].D, Ld["col"]
@@ -521,7 +526,7 @@ class Seq2SeqModel:
             else:
                 Ly.dout, Ly.ld_dout, Ly.dout_col = ops.fptr(Ld["dhout"].t), u, 0
             if l == E["nplain"] - 1 and not E["attentive"]:
-                st.dh_final, st.dc_final = ops.fptr(Ld["dhf"]), ops.fptr(Ld["dcf"])
+                st.dh_final, st.dc_final = ops.fptr(Ld["dhf"]), (None if self.gru else ops.fptr(Ld["dcf"]))
         return st
 
     def _highway_x(self, E, d, l):
@@ -548,8 +553,10 @@ class Seq2SeqModel:
                     if self._sdrop(s):           # DropoutWrapper input mask of this cell
                         xin = ops.mat(E["xd"][d] if l == 0 else Ld["xd"], in_w)
                         ops.dropout_rows(x, xin, B * T, in_w, self.seed, encoder_cell_id(s, d, l) * 4, self._keeps(s)[0], in_w)
-                    Wk = self.P[self._kn(f"{s}/enc/{d}/l{l}")[0]]
-                    ops.gemm(xin, Wk.mat(4 * u), ops.mat(Ld["gates"], 4 * u), B * T, 4 * u, in_w)
+                    Wk, G = self.P[self._kn(f"{s}/enc/{d}/l{l}")[0]], self.G
+                    ops.gemm(xin, Wk.mat(G * u), ops.mat(Ld["gates"], G * u), B * T, G * u, in_w)
+                    if self.gru:                 # candidate kernel's input part, hoisted into the c~ record
+                        ops.gemm(xin, self.P[f"{s}/enc/{d}/l{l}/cand_kernel"].mat(u), ops.mat(Ld["cs"], u), B * T, u, in_w)
                     stacks.append(self._rnn_stack_single(ws, s, d, l, B, E["len"]))
             self._run_stacks(stacks, ops.rnn_fwd)
             if l == 0:
@@ -602,26 +609,34 @@ class Seq2SeqModel:
                 for d in cfg.directions():
                     Ld = E["layers"][(d, l)]
                     kname, bname = self._kn(f"{s}/enc/{d}/l{l}")
-                    Gk, dg = self.Gr[kname], ops.mat(Ld["dgates"], 4 * u)
+                    G = self.G
+                    Gk, dg = self.Gr[kname], ops.mat(Ld["dgates"], G * u)
                     in_w = F0 if l == 0 else u
                     if l == 0:
                         a_x = ops.mat(E["xd"][d] if drop else E["xin0"], F0)
                     else:
                         a_x = ops.mat(Ld["xd"], u) if drop else self._highway_x(E, d, l)
-                    self._gemm_tn(a_x, dg, Gk.mat(4 * u), in_w, 4 * u, B * T)
+                    self._gemm_tn(a_x, dg, Gk.mat(G * u), in_w, G * u, B * T)
                     sh = 1 if d == "bw" else -1
                     hrec = Ld["hs_seq"].mat(sh) if drop else (Ld["out"].mat(sh, Ld["col"]) if l == 0 else Ld["hout"].mat(sh))
-                    self._gemm_tn(hrec, dg, Gk.mat(4 * u, row0=in_w), u, 4 * u, B * T)
-                    ops.colsum(dg, B * T, 4 * u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
+                    self._gemm_tn(hrec, dg, Gk.mat(G * u, row0=in_w), u, G * u, B * T)
+                    ops.colsum(dg, B * T, G * u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bname].off)
+                    if self.gru:                 # candidate kernel: inputs [x ; r*h]
+                        cpre = f"{s}/enc/{d}/l{l}"
+                        Gc, dpc = self.Gr[cpre + "/cand_kernel"], ops.mat(Ld["dpc"], u)
+                        self._gemm_tn(a_x, dpc, Gc.mat(u), in_w, u, B * T)
+                        self._gemm_tn(ops.mat(Ld["rh"], u), dpc, Gc.mat(u, row0=in_w), u, u, B * T)
+                        ops.colsum(dpc, B * T, u, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[cpre + "/cand_bias"].off)
                     if l > 0:                    # gradient of the cell's (masked) input -> the layer below's emitted output
                         Lo = E["layers"][(d, l - 1)]
                         dy_below = Lo["dy"].mat(0, Lo["col"])
+                        tgt, beta = (ops.mat(Ld["dxtmp"], u), 0.0) if drop else (dy_below, 1.0)
+                        ops.gemm(dg, self.P[kname].mat(G * u), tgt, B * T, u, G * u, trans_b=1, beta=beta)
+                        if self.gru:
+                            ops.gemm(ops.mat(Ld["dpc"], u), self.P[f"{s}/enc/{d}/l{l}/cand_kernel"].mat(u), tgt, B * T, u, u, trans_b=1, beta=1.0)
                         if drop:
-                            ops.gemm(dg, self.P[kname].mat(4 * u), ops.mat(Ld["dxtmp"], u), B * T, u, 4 * u, trans_b=1)
                             ops.dropout_rows(ops.mat(Ld["dxtmp"], u), dy_below, B * T, u, self.seed, encoder_cell_id(s, d, l) * 4,
                                              self._keeps(s)[0], u, accumulate=True)
-                        else:
-                            ops.gemm(dg, self.P[kname].mat(4 * u), dy_below, B * T, u, 4 * u, trans_b=1, beta=1.0)
 
     # ---- sync batch-norm of the encoder inputs across data-parallel ranks (SURVEY 8(e) collective (3)) ----
     def bn_sync_enable(self):

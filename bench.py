@@ -610,11 +610,26 @@ def main():
                 try:
                     cnn = model._cur[0]["enc"]["video"]["cnn"]
                     hb = mb = bind = 0.0
+                    folded = set(getattr(cnn, "fold_wg", {}).values())      # convolutions whose weight gradient evaluates the BN backward
+                    src_of = {op[1]: op[2] for op in cnn.ops if op[0] == "conv"}
                     for name, (n_, h_, w_, ci, co, k_, s_, _pt, _pl, ho, wo) in cnn.mfma.items():
                         if kind == "conv_bwd_data" and ci % 4:
                             continue                                       # no gradient flows into the crops
                         xb, yb = 4.0 * n_ * h_ * w_ * ci, 4.0 * n_ * ho * wo * co
-                        byt = xb + yb * (2 if (kind == "conv_fwd" and name in getattr(cnn, "fuse_add", {})) else 1)
+                        # compulsory bytes = every operand map of the launch once: source + destination, plus the maps the fused forms read
+                        # where they lie -- the residual a forward adds; the pre-BN map of a data gradient with the fused batch-norm
+                        # backward and the earlier contribution it accumulates onto; the y (and the dx it writes) of a weight gradient
+                        # that evaluates the batch-norm backward in its loader
+                        byt = xb + yb
+                        if kind == "conv_fwd" and name in getattr(cnn, "fuse_add", {}):
+                            byt += yb
+                        if kind == "conv_bwd_data":
+                            if name in getattr(cnn, "bnb_conv", {}):
+                                byt += xb
+                            if src_of.get(name) in getattr(cnn, "acc_ok", ()):
+                                byt += xb
+                        if kind == "conv_bwd_weight" and name in folded:
+                            byt += yb + (yb if src_of.get(name) != "in" else 0.0)
                         t_h, t_m = byt / (HBM_PEAK * 1e3), 2.0 * n_ * ho * wo * k_ * k_ * ci * co / (MFMA_PEAK * 1e6)     # us
                         hb += t_h; mb += t_m; bind += max(t_h, t_m)
                     r.update({"hbm_bound_us": round(hb, 1), "mfma_bound_us": round(mb, 1), "binding_bound_us": round(bind, 1),

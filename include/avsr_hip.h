@@ -128,7 +128,7 @@ typedef struct avsr_rnn_layer {
   const float* dout;
   int64_t ld_dout;
   int32_t dout_col;
-  int32_t residual;             /* ResidualWrapper around this layer's cell (cells.py:91-92; layers > 0, LSTM, units == in_dim):
+  int32_t residual;             /* ResidualWrapper around this layer's cell (cells.py:91-92; layers > 0, LSTM or GRU, units == in_dim):
                                  * emitted output = cell output + layer input.  Runs through the per-step launches; `state`
                                  * must hold 6*B*units and `dstate` 14*B*units floats, and hs_seq must be given (it then records
                                  * the recurrent h even without dropout: `out` holds h + input). */

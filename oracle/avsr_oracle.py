@@ -176,8 +176,6 @@ class OracleConfig:
             if self.highway(st) or self.residual(st):
                 if len(set(u)) != 1:
                     raise ValueError("residual_encoder needs equal layer widths")
-                if self.cell_type != "lstm":
-                    raise NotImplementedError("residual_encoder / highway_encoder: LSTM cells only")
                 if self.highway(st) and self.encoder_weight_sharing:
                     raise NotImplementedError("highway_encoder with encoder_weight_sharing")
             if self.encoder_weight_sharing and self.wrapped(st):

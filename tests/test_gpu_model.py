@@ -89,6 +89,11 @@ CASES = {
                           residual_encoder=True),
     "residual_bimodal_uni": dict(architecture="bimodal", encoder_type="unidirectional", video_units=(32, 32), audio_units=(32, 32, 32),
                                  decoder_units=(32,), residual_encoder=True),
+    # ResidualWrapper around GRU cells (cells.py:89-92 wraps whatever _build_single_cell returned)
+    "residual_gru_uni3": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32, 32),
+                              cell_type="gru", residual_encoder=True),
+    "residual_gru_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32, 32, 32), audio_units=(32, 32),
+                                  cell_type="gru", residual_encoder=True, attention_type=(("scaled_luong",), ("bahdanau",))),
     # inert on bidirectional stacks (encoder.py:92-108) -- unequal widths are therefore fine -- and on the AV-Align audio stack (:225-233)
     "residual_bimodal_bi_inert": dict(architecture="bimodal", encoder_type="bidirectional", video_units=(16, 16), audio_units=(16, 32, 16),
                                       decoder_units=(32,), residual_encoder=True),
@@ -118,6 +123,11 @@ CASES = {
                              highway_encoder=True, residual_encoder=True),
     "highway_av_align_audio3": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32, 32), audio_units=(16, 32, 32),
                                     highway_encoder=True),       # video stack highway, the 3-layer audio stack plain
+    # HighwayWrapper around GRU cells (layer by layer, both input projections of every layer hoisted)
+    "highway_gru_uni3": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32, 32),
+                             cell_type="gru", highway_encoder=True),
+    "highway_gru_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32, 32), audio_units=(32, 32),
+                                 cell_type="gru", highway_encoder=True, regress_aus=True),
     "no_bn_no_clip": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32,),
                           batch_normalisation=False, clip_gradients=False, recurrent_l2=None, warmup_steps=0),
 }
@@ -247,6 +257,10 @@ STOCH = [
     ("opt_momentum", dict(use_dropout=True)),
     ("instnorm_bimodal", dict(use_dropout=True, sampling_probability=0.2)),
     ("residual_bimodal_uni", dict(use_dropout=True, audio_dropout=(0.8, 0.9, 0.7))),
+    ("residual_gru_uni3", dict(use_dropout=True, sampling_probability=0.2)),
+    ("highway_gru_uni3", dict(use_dropout=True, sampling_probability=0.2)),
+    ("highway_gru_av_align", dict(use_dropout=True, video_dropout=(0.8, 0.9, 0.7))),
+    ("residual_gru_av_align", dict(use_dropout=True, video_dropout=(0.8, 0.9, 0.7))),
 ]
 
 
