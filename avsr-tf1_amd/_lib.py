@@ -143,8 +143,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
-    if _build.needs_build():
+    # AVSR_LIB: load another build of the library (A/B timing of kernel variants: tools/build_variant.py); never set in product use
+    path = os.environ.get("AVSR_LIB") or _build.LIB
+    if path == _build.LIB and _build.needs_build():
         try:
             _build.build()
         except Exception as e:  # no hipcc on the box: fall through to a prebuilt .so if present

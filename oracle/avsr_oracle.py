@@ -293,6 +293,19 @@ def _same_pad(n, k, s):
     return total // 2, total - total // 2
 
 
+# Test diagnostic: the smallest |ReLU input| the last cnn_forward saw.  The gradient is discontinuous at a ReLU input of exactly zero; an
+# fp32 implementation and this fp64 restatement can land on different sides of it when an input lies within fp32 rounding (~1e-6) of
+# zero -- forward values agree to 1e-7, one element's gradient contribution is there or not (found by the 4 000-seed fuzz run of round 6,
+# profiles/r06_fuzz_large.txt).  Tests that compare CNN gradients read it (train_step's "relu_margin") to tell a kink from a bug.
+RELU_MARGIN = [float("inf")]
+
+
+def _note_relu(z: Tensor) -> Tensor:
+    if z.numel():
+        RELU_MARGIN[0] = min(RELU_MARGIN[0], float(z.detach().abs().min()))
+    return z
+
+
 def cnn_forward(P, cfg: OracleConfig, frames: Tensor, training: bool, updates: Optional[dict]) -> Tensor:
     """video.resnet_cnn on [N, H, W, C] frames -> [N, cnn_dense_units] (video.py:143-195, cnn_layers :224-233).
     Every frame goes through, zero padding frames included (the reference reshapes [B*T, H, W, C] without a mask)."""
@@ -309,13 +322,13 @@ def cnn_forward(P, cfg: OracleConfig, frames: Tensor, training: bool, updates: O
         elif kind == "bnrelu":
             x = maps[a["src"]].permute(0, 2, 3, 1)                 # channels last for the statistics
             y = batch_norm(x, P, pre, training, updates, eps=1e-5, momentum=0.98, fused=True)   # rank 4: the fused kernel
-            maps[a["dst"]] = torch.relu(y).permute(0, 3, 1, 2)
+            maps[a["dst"]] = torch.relu(_note_relu(y)).permute(0, 3, 1, 2)
         elif kind == "add":
             maps[a["dst"]] = maps[a["a"]] + maps[a["b"]]
         elif kind == "flatten":
             x = maps[a["src"]]
             w = P[pre + "/kernel"].permute(3, 2, 0, 1)
-            maps[a["dst"]] = torch.relu(F.conv2d(x, w, P[pre + "/bias"])).reshape(x.shape[0], -1)
+            maps[a["dst"]] = torch.relu(_note_relu(F.conv2d(x, w, P[pre + "/bias"]))).reshape(x.shape[0], -1)
     return maps["out"]
 
 
@@ -1026,7 +1039,9 @@ def train_step(P_np: Dict[str, np.ndarray], opt: Optional[dict], cfg: OracleConf
     """One full train step: fwd, BPTT, global-norm clip, Adam, BN moving stats.
     Returns dict(loss, seq_loss, global_norm, grads, params, opt, logits)."""
     P = to_torch(P_np, dtype, requires_grad=True)
+    RELU_MARGIN[0] = float("inf")
     logits, m = forward_train(P, cfg, batch, dtype, seed=(opt["step"] if opt else 0))
+    relu_margin = RELU_MARGIN[0]
     loss, seq = loss_fn(P, cfg, batch, logits, m)
     names = trainable_names(P)
     grads = torch.autograd.grad(loss, [P[k] for k in names], allow_unused=True)
@@ -1066,7 +1081,7 @@ def train_step(P_np: Dict[str, np.ndarray], opt: Optional[dict], cfg: OracleConf
     au_term = float((cfg.au_loss_weight * m.aux_loss).detach()) if (cfg.regress_aus and m.aux_loss is not None) else 0.0
     return {"loss": float(loss.detach()), "seq_loss": float(seq.detach()), "au_term": au_term, "global_norm": float(gnorm.detach()),
             "grads": {k: g.detach().numpy() for k, g in grads.items()}, "params": newP, "opt": new_opt,
-            "logits": logits.detach().numpy(), "fed_tokens": m.fed_tokens}
+            "logits": logits.detach().numpy(), "fed_tokens": m.fed_tokens, "relu_margin": relu_margin}
 
 
 @torch.no_grad()
