@@ -416,12 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // progress words: 32 per (task, group); wave 0 polls own (lanes 0-31) and lower (lanes 32-63) in one load
   int* const my_flag = tk.done + gx * 32 + ct;    // progress words are per (task, XCD)
   const int* poll_ptr = nullptr;
-#ifdef POLL_ALL
-  constexpr bool poll_all = true;                  // experiment: every wave polls for itself, no barrier between the poll and the operand loads
-#else
-  constexpr bool poll_all = false;
-#endif
-  if (wave == 0 || poll_all) {
+  if (wave == 0) {
     if (lane < 32) { if (lane < tk.nct) poll_ptr = tk.done + gx * 32 + lane; }
     else if (has_low && lane - 32 < tk.nct_lower) poll_ptr = tk.done_lower + gx * 32 + (lane - 32);
   }
@@ -438,21 +433,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   // wave 0: wait until own progress >= need_own and lower progress >= need_low (bounded)
   auto wait_progress = [&](int need_own, int need_low) {
-    if (wave != 0 && !poll_all) return;
+    if (wave != 0) return;
     const int need = lane < 32 ? need_own : need_low;
-#ifdef POLL_PIPE
-    // two polls in flight, half a round trip apart: the progress words are sampled twice per L2 round trip instead of once
-    int v0 = poll_ptr ? __hip_atomic_load(poll_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
-    for (int spins = 0; spins < (1 << 20); ++spins) {
-      __builtin_amdgcn_s_sleep(POLL_PIPE);
-      const int v1 = poll_ptr ? __hip_atomic_load(poll_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
-      if (__all(v0 >= need)) return;
-      __builtin_amdgcn_s_sleep(POLL_PIPE);
-      v0 = poll_ptr ? __hip_atomic_load(poll_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
-      if (__all(v1 >= need)) return;
-      if ((spins & 511) == 511 && __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    }
-#else
     for (int spins = 0; spins < (1 << 21); ++spins) {
       const int v = poll_ptr ? __hip_atomic_load(poll_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
       if (__all(v >= need)) return;
@@ -461,7 +443,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #endif
       if ((spins & 1023) == 1023 && __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     }
-#endif
     if (lane == 0) __hip_atomic_store(L.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
@@ -498,7 +479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // dependencies: step t-1 of this layer (all column tiles of my rows); the layer below one step ahead
     // (PT: the pair (t+1, t+2) is requested during the odd step t, so the layer below must then be three steps on)
     wait_progress(t, PT ? ((t & 1) ? (t + 3 < T ? t + 3 : T) : 0) : (t + 2 < T ? t + 2 : T));
-    if (!poll_all) lds_barrier();
+    lds_barrier();
     TICK(0)
     const bool avalid = aok && t < len_a && (!PT || sub == (t & 1));
     const int ho_ = hrow + (reverse ? len_a - 1 - t : t) * h_st;
