@@ -572,6 +572,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     lds_barrier();
     TICK(2)
+    // The gate epilogue is a dependent chain (LDS partials -> 5 exp / rcp pairs -> stores) on ONE or two waves, and it is on every
+    // step's critical path, while the SIMD's other waves (two more workgroups per CU) poll or multiply: top priority for its duration
+    // (round 6: 1.97 -> 1.94 ms per launch, profiles/r06_experiments.txt call B; storing the gate / cell RECORDS behind the publish
+    // instead -- they have no reader inside the launch -- made it 2.08 ms: the late stores sit in front of the next step's operand loads)
+    __builtin_amdgcn_s_setprio(3);
     if (eok) {
       const bool valid = t < len_b;
       if (valid) {
@@ -623,6 +628,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
     }
     TICK(3)
+    if (tk.prio == 3) __builtin_amdgcn_s_setprio(3);      // back to the task's static priority
+    else if (tk.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (tk.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
     // publish: stores drained into the XCD's L2, then this workgroup's progress word
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
