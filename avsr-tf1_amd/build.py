@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libavsr_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "step.hip", "rnn.hip", "rnn_persist.hip", "rnn_persist_bwd.hip", "attention.hip", "attn_rnn.hip", "beam_gemm.hip", "dec_persist.hip", "dec_persist_bwd.hip", "elementwise.hip", "conv.hip", "conv_direct.hip", "conv_mfma.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "step.hip", "rnn.hip", "rnn_persist.hip", "rnn_persist_bwd.hip", "attention.hip", "attn_rnn.hip", "beam_gemm.hip", "dec_persist.hip", "dec_persist_bwd.hip", "elementwise.hip", "conv.hip", "conv_direct.hip", "conv_mfma.hip", "conv_wgrad.hip", "conv_bn.hip"]
 
 
 def _hipcc():

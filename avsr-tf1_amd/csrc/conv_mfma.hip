@@ -15,93 +15,9 @@
 // gradient staged the same way; per-workgroup partial sums are reduced by avsr_colsum_final_launch.
 // The epilogue of the data-path kernel can emit per-channel sum / sum-of-squares partials of what it wrote (batch-norm
 // statistics of the producing convolution: removes two full passes over the map per batch norm).
-#include "common.h"
-#include "persist.h"
-#include "prof.h"
-#include "avsr_hip.h"
+#include "conv_mfma.h"
 
 namespace avsr {
-
-// exact n / d for n < 2^16, 0 < d < 2^16: one 32x32 -> high-32 multiply instead of the ~40-instruction integer division
-// (d = 1 has no 32-bit magic: encoded as 0)
-__device__ __forceinline__ int fdiv(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
-static inline unsigned fmagic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) / (unsigned)d) + 1ull); }
-__device__ __forceinline__ unsigned fmagic_dev(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) / (unsigned)d) + 1ull); }
-
-// Stage `nf4` 16-byte pieces global -> LDS with all of a thread's loads of a batch in flight before the first LDS store
-// (one load, one store per loop trip left every trip exposed to the full memory latency: 40 trips per 36x36x8 frame).
-template <class SrcOff, class DstOff>
-__device__ __forceinline__ void stage4(const float* __restrict__ src, float* __restrict__ lds, int nf4, int tid, SrcOff so, DstOff dof) {
-  for (int base = 0; base < nf4; base += 256 * 16) {
-    f32x4 v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * 256 + tid;
-      v[u] = idx < nf4 ? ld4(src + so(idx)) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int idx = base + u * 256 + tid;
-      if (idx < nf4) st4(lds + dof(idx), v[u]);
-    }
-  }
-}
-
-// Row-structured staging of one [rows][rq pieces] block (16-byte pieces) into a pitched LDS image: a thread keeps its piece
-// column and walks rows by pointer increments; up to 16 loads in flight before the first LDS store.
-__device__ __forceinline__ void stage_rows(const float* __restrict__ src, float* __restrict__ dst, int rows, int rq, int dst_pitch, int tid,
-                                           int my_row, int my_p4, int rpp) {
-  if (my_row < 0) return;
-  const float* sp = src + ((long)my_row * rq + my_p4) * 4;
-  float* dp = dst + my_row * dst_pitch + my_p4 * 4;
-  const int sstep = rpp * rq * 4, dstep = rpp * dst_pitch;
-  int r = my_row;
-  while (r < rows) {
-    f32x4 v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = (r + u * rpp < rows) ? ld4(sp + u * sstep) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < 16; ++u) if (r + u * rpp < rows) st4(dp + u * dstep, v[u]);
-    r += 16 * rpp; sp += 16 * sstep; dp += 16 * dstep;
-  }
-}
-
-#define CG_MAXTAP 16
-// One (wide) tap of the product's depth: source offset (da, db) from the row's base position; w[sp] = index of the kernel tap this
-// source pixel meets for sub-position sp of the row, or -1 (zero weights).
-struct CGTap { int da, db; short w[4]; };
-static inline CGTap cgtap1(int da, int db, int widx) { CGTap t; t.da = da; t.db = db; t.w[0] = (short)widx; t.w[1] = t.w[2] = t.w[3] = -1; return t; }
-struct CGArgs {
-  const float* src; const float* w; const float* bias; float* dst; float* stats;
-  const float* acc;                      // beta != 0: the map beta multiplies (NULL = dst itself); same shape / indexing as dst
-  const float* res;                      // optional residual input, same shape / indexing as dst
-  const float* bn_sc; const float* bn_sh; // non-NULL: the source is relu(src * bn_sc[c] + bn_sh[c]) applied while staging (BN-ReLU of the
-                                          // consumer's loader: the normalised map is never written); halo / padding stays zero
-  const float* res_sc; const float* res_sh; // same for the residual input (per destination channel)
-  // Batch-norm backward, stage 1, fused into a data-gradient epilogue (bnb_x != NULL): dst is the gradient of y = relu(x*sc + sh) for the
-  // pre-normalisation map x (same shape / indexing as dst).  The epilogue writes dz = dst * [x*sc + sh > 0] instead and emits, in the
-  // statistics slots, the per-channel partial sums of dz and of dz*x -- what the separate two-map statistics pass of the batch-norm
-  // backward computed (d beta = sum dz, d gamma = invstd * (sum dz*x - mean * sum dz)).
-  const float* bnb_x; const float* bnb_sc; const float* bnb_sh;
-  int N, SH, SW, Cs, CsL;
-  int DH, DW, Cd;
-  int OA, OB, S, OS, oh0, ow0;
-  // Sub-position columns: a row of the product is a SUPER position (a, b) of nsp destination pixels, its columns are (sp, channel).
-  //   nsp = 1: one pixel per row (SB = S, OSA = OSB = OS).
-  //   nsp = 2 (8-channel stride-1 layers): two horizontally adjacent pixels share one row over the union of their windows (3 x 4
-  //            taps): the 16 columns of a tile are all used (8 channels alone leave half of every MFMA multiplying padding).
-  //   nsp = 4 (stride-2 data gradient): the four parity classes of a 2x2 destination cell in ONE launch: dy staged once, whole
-  //            destination rows written instead of every other pixel per launch.
-  // source base of row (a, b): (a*S, b*SB); destination pixel of (a, b, sp): (a*OSA + oh0 + sp_dh[sp], b*OSB + ow0 + sp_dw[sp]).
-  int nsp, SB, OSA, OSB, lin;
-  signed char sp_dh[4], sp_dw[4];
-  int ntap, wmode, F;
-  int dbg;                                // CONV_DEBUG builds only: bit 0 no stores, bit 1 no LDS operand reads, bit 2 no MFMAs
-  float beta;
-  unsigned m_opf, m_ob, m_rq, m_per, m_sw;   // division magics: positions per frame, OB, pieces per source row / per frame (Cs % 4 == 0),
-                                          // or channels / floats per frame / SW (otherwise)
-  CGTap tap[CG_MAXTAP];
-};
 
 // The product is computed TRANSPOSED: the weight fragments are the MFMA's A operand (rows = 16 destination columns), the staged
 // activations its B operand (columns = 16 positions), so a lane of the result holds FOUR CONSECUTIVE CHANNELS of ONE position
@@ -535,32 +451,6 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// weight gradient: part[blk][(t*Ci + ci)*Co + co] = sum over the block's frames and positions of x[pos(t)][ci] * dy[pos][co]
-#define WG_PAD 2          // floats of padding per LDS pixel in the weight-gradient kernel (bank spreading, see the kernel)
-// workgroups per CU the weight-gradient kernel is compiled for, by accumulator tiles per wave (its register budget): the stages of its
-// per-frame pipeline hide behind one another only ACROSS waves (profiles/r05_wgrad_ablation.txt), so the small forms take every wave
-// the registers and the LDS allow
-#define WG_WPC(tiles) ((tiles) > 16 ? 1 : ((tiles) <= 3 ? 4 : ((tiles) <= 6 ? 3 : 2)))
-struct WGArgs {
-  const float* x; const float* dy; float* part;
-  int N, H, W, Ci, CiL, Ho, Wo, Co, S, pt, pl, F;
-  int SW;                                 // source step along W per output column (0 = S): 2 for the pixel-pair form, see conv_bwd_weight_impl
-  int pad;                                // floats of padding per LDS pixel (WG_PAD; 1 where three workgroups of a 36x36 frame share a CU)
-  unsigned m_opf, m_wo, m_rq, m_per, m_w;
-  int t0, nt, kw;                         // taps t0 .. t0+nt-1 of a kw x kw kernel: rows (t - t0, ci) of this launch's slab
-  int slab, want_bias;                    // floats per workgroup partial: nt*Ci*Co (+ Co column sums of dy = the bias gradient)
-  const float* bn_sc; const float* bn_sh; // BN-ReLU applied to x while staging (see CGArgs)
-  int dbg;                                // CONV_DEBUG builds: bit 3 = per-wave cycle stamps behind the partial slabs
-  // FOLD (round 5): dy is not stored -- it is the batch-norm backward's output gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) =
-  // k1[c]*dz + k2[c]*y + k3[c] of the convolution's OWN output y (avsr_bn_bwd_finalize's coefficient vectors fk [3*fC]), evaluated while
-  // the operand is fetched: `dy` points at dz, fy at y (same layout).  For a convolution whose only gradient consumer is this kernel
-  // (layer 0: its input are the lip crops) the stand-alone avsr_bn_bwd_apply pass over three maps disappears.
-  // fdx != NULL: the evaluated gradient is also WRITTEN there (same layout) for the layer's data gradient, which runs after this kernel:
-  // every element is fetched by exactly one lane, so the stand-alone pass is replaced by one store per operand.
-  const float* fy; const float* fk; int fC; float* fdx;
-};
-
 // 8 destination channels, stride 1, linear destination (the 36x36 layers: layer 0 and residual block 0, forward and data gradient): the
 // product on v_mfma_f32_4x4x1_16B_f32 with cbsz = 4.  All 16 blocks of an instruction share the A block `abid` = 4 destination channels
 // at ONE k (a weight VGPR holds 4 channels x 16 k: the whole 3x3x8x8 kernel is ten registers), the B operand is one staged activation
@@ -833,312 +723,14 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
   }
 }
 
-// MT: row tiles (16 rows of (tap, ci)) held per wave; NTC: column tiles; CH4: 4-channel-multiple input (row-structured staging)
-// RS (row split): the four waves own DIFFERENT row tiles (wave w: rows [w*MT*16, (w+1)*MT*16)) and each walks every chunk, instead of
-// all waves sharing MT row tiles and splitting the chunks: a deep layer whose (tap, channel) rows exceed one wave's accumulators then
-// takes ONE launch -- its input staged once -- instead of one per tap group, and no cross-wave reduction at the end.
-template <int MT, int NTC, bool CH4, bool RS = false, int FOLD = 0>
-__global__ __launch_bounds__(256, WG_WPC(MT * NTC)) void conv_wgrad_kernel(const WGArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i = lane & 15, q = lane >> 4;
-  const int Ci = A.Ci, CiL = A.CiL, Co = A.Co;
-  // LDS pixel stride = channels + 2 floats: the A operand is read 4 bytes at a time by lanes (row = (tap, channel), q = position group);
-  // with a stride of 8 / 16 / 32 / 64 floats the four position groups hit the same banks (4-5 LDS cycles per read, SQ_LDS_BANK_CONFLICT =
-  // 53 % of the LDS-active cycles); + 2 floats spreads them (2 cycles per read, the minimum for 64 lanes on 32 banks).  Staging stores
-  // become 8-byte pairs.
-  const int CsP = CiL + A.pad;
-  const int PH = A.H + 2, PW = A.W + 2, xstride = PH * PW * CsP;
-  const int opf = A.Ho * A.Wo;
-  float* const xs = lds;                               // [F][PH][PW][CiL]   (the output gradient is read straight from memory:
-                                                       //  every value is used once per row tile, 16 lanes = 64 contiguous bytes)
-  const int Mrows = A.nt * CiL;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  for (int idx = tid; idx < A.F * xstride; idx += 256) xs[idx] = 0.f;
-
-  // row (t, ci) of this lane in every row tile -> LDS offset of its tap / channel (rows beyond 9*CiL read offset 0: their
-  // accumulators are never written out)
-  int roff[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int row = (RS ? wave * MT * 16 : 0) + mt * 16 + i;
-    const bool ok = row < Mrows;
-    const int tl = ok ? row / CiL : 0, ci = ok ? row - tl * CiL : 0, t = A.t0 + tl, ti = t / A.kw, tj = t - ti * A.kw;
-    roff[mt] = ok ? ((ti - A.pt) * PW + (tj - A.pl)) * CsP + ci : 0;
-  }
-  f32x4 acc[MT][NTC];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NTC; ++nt) acc[mt][nt] = zero4;
-  const int rowf = A.W * Ci;
-  const int st_rq = rowf >> 2;
-  const int st_rpp = (CH4 && st_rq > 0) ? (256 / st_rq > 0 ? 256 / st_rq : 1) : 1;
-  const int st_row = CH4 ? (tid < st_rpp * st_rq ? fdiv(tid, A.m_rq) : -1) : -1;
-  const int st_p4 = st_row >= 0 ? tid - st_row * st_rq : 0;
-  const int st_pad = (CH4 && st_row >= 0) ? (st_p4 / (Ci >> 2)) * A.pad : 0;      // padding floats ahead of this piece's pixel in its LDS row
-  const bool st_odd = (A.pad & 1) != 0;                                           // odd pixel stride: 4-byte staging stores
-  f32x4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = zero4;
-  const bool bn_on = CH4 && A.bn_sc != nullptr;
-  if (bn_on && st_row >= 0) { const int cb = (st_p4 * 4) % Ci; bsc = ld4(A.bn_sc + cb); bsh = ld4(A.bn_sh + cb); }
-  float bsum[NTC];
-#pragma unroll
-  for (int nt = 0; nt < NTC; ++nt) bsum[nt] = 0.f;
-  constexpr int PF = CH4 ? 12 : 4;
-  f32x4 pre[PF];
-  const int ppf = CH4 ? (A.H + st_rpp - 1) / st_rpp : 0;
-  const unsigned m_ppf = fmagic_dev(ppf > 0 ? ppf : 1);
-  const int per3 = A.H * A.W * Ci;
-  // Frames of this workgroup: an EVEN share [n_begin, n_end) of the N frames, walked in passes of FP <= F frames.  (Passes of F frames dealt
-  // round-robin left the busiest workgroup with ceil(passes / grid) * F frames: 4800 frames of a 9x9 map, F = 4, 512 workgroups = 12 frames
-  // against 9.4 on average -- the kernel ends with its slowest workgroup: profiles/r04_conv_deep_dissection.txt, max vs mean cycles.)
-  // (F = 1, the 36x36 maps: single frames dealt round-robin as before -- the same maximum, and neighbouring workgroups stream
-  // neighbouring frames: measured 3-4 % faster there than 512 separate ranges)
-  const int fs_per = A.N / (int)gridDim.x, fs_extra = A.N - fs_per * (int)gridDim.x;
-  const int fs_cnt = fs_per + ((int)blockIdx.x < fs_extra ? 1 : 0), fs_np = (fs_cnt + A.F - 1) / A.F;
-  const bool fs_rr = A.F == 1;
-  const int FP = fs_rr ? 1 : (fs_np > 0 ? (fs_cnt + fs_np - 1) / fs_np : A.F);
-  const int n_begin = fs_rr ? (int)blockIdx.x : (int)blockIdx.x * fs_per + min((int)blockIdx.x, fs_extra);
-  const int n_end = fs_rr ? A.N : n_begin + fs_cnt, n_step = fs_rr ? (int)gridDim.x : FP;
-  auto fetch = [&](int n0) {
-    const int fcur = min(FP, n_end - n0);
-    if (CH4) {
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int f = fdiv(u, m_ppf), k = u - f * ppf, r = st_row + k * st_rpp;
-        pre[u] = (st_row >= 0 && f < fcur && r < A.H) ? ld4(A.x + ((long)(n0 + f) * A.H + r) * rowf + st_p4 * 4) : zero4;
-      }
-    } else {
-      const float* sp = A.x + (long)n0 * per3;
-      const int tot4 = (fcur * per3) >> 2;
-#pragma unroll
-      for (int u = 0; u < PF; ++u) { const int idx = u * 256 + tid; pre[u] = idx < tot4 ? ld4(sp + idx * 4) : zero4; }
-    }
-  };
-  auto commit = [&](int n0) {
-    const int fcur = min(FP, n_end - n0);
-    if (CH4) {
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int f = fdiv(u, m_ppf), k = u - f * ppf, r = st_row + k * st_rpp;
-        if (st_row >= 0 && f < fcur && r < A.H) {
-          f32x4 v = pre[u];
-          if (bn_on) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], bsc[e], bsh[e]), 0.f);
-          }
-          float* const dpx = xs + f * xstride + ((r + 1) * PW + 1) * CsP + st_pad + st_p4 * 4;
-          if (st_odd) { dpx[0] = v[0]; dpx[1] = v[1]; dpx[2] = v[2]; dpx[3] = v[3]; }
-          else {
-            *reinterpret_cast<float2*>(dpx) = float2{v[0], v[1]};
-            *reinterpret_cast<float2*>(dpx + 2) = float2{v[2], v[3]};
-          }
-        }
-      }
-    } else {
-      const int tot = fcur * per3, tot4 = tot >> 2;
-      auto put = [&](int e, float v) {
-        const int f = fdiv(e, A.m_per), r = e - f * per3, px = fdiv(r, A.m_rq), c = r - px * Ci, h = fdiv(px, A.m_w), pw = px - h * A.W;
-        xs[f * xstride + ((h + 1) * PW + pw + 1) * CsP + c] = v;
-      };
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int idx = u * 256 + tid;
-        if (idx < tot4) { put(idx * 4, pre[u][0]); put(idx * 4 + 1, pre[u][1]); put(idx * 4 + 2, pre[u][2]); put(idx * 4 + 3, pre[u][3]); }
-      }
-      const float* sp = A.x + (long)n0 * per3;
-      for (int e = tot4 * 4 + tid; e < tot; e += 256) put(e, sp[e]);
-    }
-  };
-
-  // depth = output positions; a chunk = 16 positions of ONE frame (the last chunk of a frame is partial), lane quad q takes
-  // positions 4q .. 4q+3 of the chunk; chunks are dealt to the waves round-robin.
-  const __amdgpu_buffer_rsrc_t dy_rs = make_rsrc(A.dy);
-  const __amdgpu_buffer_rsrc_t fy_rs = make_rsrc(FOLD ? A.fy : A.dy);
-  const __amdgpu_buffer_rsrc_t fdx_rs = make_rsrc(FOLD == 2 ? A.fdx : A.part);
-  float fk1[NTC], fk2[NTC], fk3[NTC];                    // FOLD: coefficients of this lane's column(s)
-#pragma unroll
-  for (int nt = 0; nt < NTC; ++nt) {
-    fk1[nt] = 1.f; fk2[nt] = 0.f; fk3[nt] = 0.f;
-    if (FOLD) {
-      const int col = nt * 16 + i, ch = col % A.fC;
-      const bool okc = col < Co;
-      fk1[nt] = okc ? A.fk[ch] : 0.f; fk2[nt] = okc ? A.fk[A.fC + ch] : 0.f; fk3[nt] = okc ? A.fk[2 * A.fC + ch] : 0.f;
-    }
-  }
-  const int cpf = (opf + 15) >> 4;                       // chunks per frame
-  const unsigned m_cpf = fmagic_dev(cpf);
-  int n0 = n_begin;
-  // dissection builds (tools/wgrad_ablate.sh: -DWG_ABLATE=mask, compile-time so that the rest of the code is generated as shipped):
-  // 1 no dy loads, 2 no LDS operand reads, 4 no MFMAs, 16 no frame staging.  Results: profiles/r05_wgrad_ablation.txt
-#ifdef WG_ABLATE
-#define WG_ABL(b) (((WG_ABLATE) & (b)) != 0)
-#else
-#define WG_ABL(b) false
-#endif
-#ifdef CONV_DEBUG
-  long w_b1 = 0, w_commit = 0, w_b2 = 0, w_comp = 0, w_mark = __builtin_readcyclecounter();
-  const long w_start = w_mark;
-#define WG_STAMP(acc) { const long t_now = __builtin_readcyclecounter(); acc += t_now - w_mark; w_mark = t_now; }
-#else
-#define WG_STAMP(acc)
-#endif
-  if (n0 < n_end) fetch(n0);
-  for (; n0 < n_end; n0 += n_step) {
-    const int fcur = min(FP, n_end - n0);
-    __syncthreads();
-    WG_STAMP(w_b1)
-    if (!WG_ABL(16)) commit(n0);
-    WG_STAMP(w_commit)
-    const int kch = fcur * cpf;
-    const unsigned dyo = (unsigned)((long)n0 * opf * Co * 4);     // [fcur][opf][Co]
-    float bn[NTC][4], byn[FOLD ? NTC : 1][4];
-    auto load_b = [&](int kc, float (&b)[NTC][4]) {
-      // unconditional buffer loads (positions beyond the frame / columns beyond Co: out-of-range offset = 0)
-      const int f = fdiv(kc, m_cpf), r0 = (kc - f * cpf) * 16 + q * 4;
-      const unsigned o = dyo + (unsigned)(((f * opf + r0) * Co + i) * 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) {
-          const int off = (r0 + e < opf && nt * 16 + i < Co) ? (int)(o + (unsigned)((e * Co + nt * 16) * 4)) : P_OOB;
-          b[nt][e] = ldb1(dy_rs, WG_ABL(1) ? P_OOB : off);
-          if (FOLD) byn[nt][e] = ldb1(fy_rs, WG_ABL(1) ? P_OOB : off);
-        }
-    };
-    constexpr int KC0 = RS ? 0 : -1, KCS = RS ? 1 : 4;                // first chunk / chunk step of a wave
-    const int kc0 = KC0 < 0 ? wave : KC0;
-    if (kc0 < kch) load_b(kc0, bn);
-    __syncthreads();
-    WG_STAMP(w_b2)
-    if (n0 + n_step < n_end && !WG_ABL(16)) fetch(n0 + n_step);      // next pass's frames: in flight during the MFMAs
-    for (int kc = kc0; kc < kch; kc += KCS) {
-      float av[MT][4], bv[NTC][4];
-      const int f = fdiv(kc, m_cpf), r0 = (kc - f * cpf) * 16 + q * 4;
-#pragma unroll
-      for (int nt = 0; nt < NTC; ++nt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          bv[nt][e] = bn[nt][e];
-          // (positions beyond the frame must stay zero: the constant term would otherwise enter the sums)
-          if (FOLD) bv[nt][e] = (r0 + e < opf) ? fmaf(fk1[nt], bn[nt][e], fmaf(fk2[nt], byn[nt][e], fk3[nt])) : 0.f;
-          if (FOLD == 2 && (!RS || wave == 0))
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bv[nt][e]), fdx_rs,
-                                                  (r0 + e < opf && nt * 16 + i < Co) ? (int)(dyo + (unsigned)(((f * opf + r0 + e) * Co + nt * 16 + i) * 4)) : P_OOB, 0, 0);
-        }
-#pragma unroll
-      for (int nt = 0; nt < NTC; ++nt) bsum[nt] += (bv[nt][0] + bv[nt][1]) + (bv[nt][2] + bv[nt][3]);
-      if (kc + KCS < kch) load_b(kc + KCS, bn);
-      int ho = fdiv(min(r0, opf - 1), A.m_wo), wo = min(r0, opf - 1) - ho * A.Wo;
-      const float* xf = xs + f * xstride + (PW + 1) * CsP;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float* xb = xf + (ho * A.S * PW + wo * (A.SW ? A.SW : A.S)) * CsP;
-        // positions beyond the frame read a clamped (finite) LDS address: their dy operand is zero (out-of-range buffer load), so the
-        // product vanishes without a select per operand
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt][e] = WG_ABL(2) ? (float)roff[mt] : xb[roff[mt]];
-        if (++wo == A.Wo) { wo = 0; ++ho; }
-        if (ho >= A.Ho) { ho = A.Ho - 1; }                 // (only reached by out-of-range positions: masked above)
-      }
-      // all LDS reads of the chunk first, then its MFMAs (left alone the compiler waits for each read just ahead of its first use)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NTC; ++nt) {
-            if (WG_ABL(4)) acc[mt][nt][0] += av[mt][e] * bv[nt][e];
-            else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], bv[nt][e], acc[mt][nt], 0, 0, 0);
-          }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    WG_STAMP(w_comp)
-  }
-#ifdef CONV_DEBUG
-  if ((A.dbg & 8) && lane == 0) {
-    float* o = A.part + (long)gridDim.x * A.slab + ((long)blockIdx.x * 4 + wave) * 8;
-    o[0] = (float)w_b1; o[1] = (float)w_commit; o[2] = (float)w_b2; o[3] = (float)w_comp; o[4] = (float)(__builtin_readcyclecounter() - w_start);
-  }
-#endif
-  // cross-wave reduction (waves hold different depth slices of the same tiles), tile by tile through a 4 KB staging area, then
-  // one partial per workgroup
-  float* red = lds;                                     // [4][16][16]
-  const int rr = tid >> 4, cc = tid & 15;
-  if (RS) {                                             // every wave writes its own rows: C[4q + r][i] of tile (mt, nt)
-    __syncthreads();                                    // (the staging area is free: the bias sums below reuse it)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wave * MT * 16 + mt * 16 + q * 4 + r;
-        if (row < Mrows) {
-          const int t = row / CiL, ci = row - t * CiL;
-          if (ci < Ci) {
-#pragma unroll
-            for (int nt = 0; nt < NTC; ++nt)
-              if (nt * 16 + i < Co) A.part[(long)blockIdx.x * A.slab + ((long)t * Ci + ci) * Co + nt * 16 + i] = acc[mt][nt][r];
-          }
-        }
-      }
-  } else
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NTC; ++nt) {
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[(wave * 16 + q * 4 + r) * 16 + i] = acc[mt][nt][r];
-      __syncthreads();
-      const int row = mt * 16 + rr, co = nt * 16 + cc;
-      if (row < Mrows && co < Co) {
-        const int t = row / CiL, ci = row - t * CiL;
-        if (ci < Ci) A.part[(long)blockIdx.x * A.slab + ((long)t * Ci + ci) * Co + co] = (red[rr * 16 + cc] + red[(16 + rr) * 16 + cc]) + (red[(32 + rr) * 16 + cc] + red[(48 + rr) * 16 + cc]);
-      }
-    }
-  if (A.want_bias) {                                    // column sums of dy: lanes (q, wave) hold disjoint positions of column nt*16 + i
-    __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < NTC; ++nt) red[((wave * 4 + q) * NTC + nt) * 16 + i] = (RS && wave) ? 0.f : bsum[nt];   // (RS: every wave saw every chunk)
-    __syncthreads();
-    if (tid < NTC * 16) {
-      const int nt = tid >> 4, ci = tid & 15;
-      float s = 0.f;
-      for (int g = 0; g < 16; ++g) s += red[(g * NTC + nt) * 16 + ci];
-      if (nt * 16 + ci < Co) A.part[(long)blockIdx.x * A.slab + (long)A.nt * Ci * Co + nt * 16 + ci] = s;
-    }
-  }
-}
-
-static int g_conv_mfma = 1;
+int g_conv_mfma = 1;
 
 }  // namespace avsr
 
-namespace avsr {
-bool slab_defer_push(const float* part, long ld, int nblk, int F, float* out, float* out2, int split, int kind, int Ci, float alpha, float beta,
-                     hipStream_t s);
-bool slab_deferring();
-}
-int avsr_colsum_final_launch(const float* part, int nblk, float* out, int F, float alpha, float beta, void* stream);
-
 using namespace avsr;
-#define S_(x) ((hipStream_t)(x))
 
 extern "C" int avsr_conv_set_mfma(int32_t on) { g_conv_mfma = on ? 1 : 0; return AVSR_OK; }
 
-static int cg_frames(int sh, int sw, int csl, int opf, int extra_floats_per_frame = 0) {
-  const long per = (long)(sh + 2) * (sw + 2) * csl + extra_floats_per_frame;
-  int F = (int)((63 * 1024 / 4) / per);                 // <= 63 KB of frames (+ tables <= 64 KB): two workgroups per CU
-  if (F < 1) F = 1;
-  int want = (1024 + opf - 1) / opf;                    // enough positions per pass to keep the four waves in row tiles
-  if (want < 1) want = 1;
-  if (F > want) F = want;
-  if (F > 16) F = 16;
-  return F;
-}
-
-// 8 destination channels, stride 1, 3x3 taps, whole map: the 4x4x1-MFMA kernel (conv_q4_kernel) instead of the pixel-pair form
 static int g_conv_q4 = -1;
 static bool cg_q4_ok(const CGArgs& A, int ntaps) {
   if (g_conv_q4 < 0) { const char* e = getenv("AVSR_CONV_Q4"); g_conv_q4 = e ? (atoi(e) != 0) : 1; }
@@ -1322,68 +914,6 @@ int avsr_conv3x3_mfma(const float* x, const float* w, const float* bias, float* 
   return AVSR_OK;
 }
 
-// finalise batch-norm statistics from the per-workgroup partial sums the convolution epilogue wrote: part [nparts][2*C] (sum | sum of
-// squares), count = rows per channel.  fp64 merge; the moving averages take the Bessel-corrected variance (fused rank-4 path).
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* part, int nparts, int C, double count, float eps, float momentum,
-                                                          float* mean, float* invstd, float* mov_mean, float* mov_var, const float* gamma,
-                                                          const float* beta, float* scale, float* shift) {
-  // one workgroup per 16 channels: 16 lanes read 16 consecutive channels of a partial row (64 B segments), 64 row groups stride the rows
-  // (1024 threads: the 512 partial rows are eight loads per thread -- the kernel is a latency chain, not a bandwidth one)
-  __shared__ double red[2][64][17];
-  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
-  double s = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int p = rg; p < nparts; p += 64) { s += (double)part[(long)p * 2 * C + c]; s2 += (double)part[(long)p * 2 * C + C + c]; }
-  red[0][rg][cl] = s; red[1][rg][cl] = s2;
-  __syncthreads();
-  if (threadIdx.x >= 16 || c >= C) return;
-  s = 0.0; s2 = 0.0;
-  for (int r = 0; r < 64; ++r) { s += red[0][r][cl]; s2 += red[1][r][cl]; }
-  const double m = s / count;
-  double var = s2 / count - m * m;
-  if (var < 0.0) var = 0.0;
-  const float is = rsqrtf((float)var + eps);
-  mean[c] = (float)m;
-  invstd[c] = is;
-  if (scale) {                                          // y = x * scale + shift  ==  (x - mean) * invstd * gamma + beta
-    const float sc = gamma[c] * is;
-    scale[c] = sc;
-    shift[c] = beta[c] - (float)m * sc;
-  }
-  if (mov_mean) {
-    const float unbiased = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
-    mov_mean[c] = momentum * mov_mean[c] + (1.f - momentum) * (float)m;
-    mov_var[c] = momentum * mov_var[c] + (1.f - momentum) * unbiased;
-  }
-}
-
-// evaluation graph (training=False, video.py:8-12): scale / shift of the loader-applied batch norm from the MOVING statistics
-__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, float eps, float* scale,
-                                      float* shift, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float sc = gamma[c] * rsqrtf(mov_var[c] + eps);
-  scale[c] = sc;
-  shift[c] = beta[c] - mov_mean[c] * sc;
-}
-extern "C" int avsr_bn_eval_affine(const float* gamma, const float* beta, const float* mov_mean, const float* mov_var, float eps, float* scale,
-                                   float* shift, int32_t C, void* stream) {
-  if (!gamma || !beta || !mov_mean || !mov_var || !scale || !shift || C <= 0) return AVSR_ERR_ARG;
-  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), gamma, beta, mov_mean, mov_var, eps, scale, shift, C);
-  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
-  return AVSR_OK;
-}
-
-extern "C" int avsr_bn_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, float eps, float momentum, float* mean,
-                                float* invstd, float* mov_mean, float* mov_var, const float* gamma, const float* beta, float* scale,
-                                float* shift, void* stream) {
-  if (!part || nparts <= 0 || C <= 0 || count <= 0 || !mean || !invstd || (scale && (!gamma || !beta || !shift))) return AVSR_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), part, nparts, C, (double)count, eps, momentum, mean, invstd,
-                     mov_mean, mov_var, gamma, beta, scale, shift);
-  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
-  return AVSR_OK;
-}
-
 // stride-2 data gradient: dx [N,H,W,Ci] (+)= from dy [N,Ho,Wo,Co]; one launch per parity class of the input pixels
 int avsr_conv3x3_bwd_data_s2_mfma(const float* dy, const float* w, float* dx, int N, int H, int W, int Ci, int Co, int pad_t, int pad_l, int Ho,
                                   int Wo, float beta, void* stream) {
@@ -1415,70 +945,10 @@ int avsr_conv3x3_bwd_data_s2_mfma(const float* dy, const float* w, float* dx, in
   return AVSR_OK;
 }
 
-// weight gradient: dw[3,3,Ci,Co] = beta*dw + sum x (x) dy; scratch >= 256 * 9*Ci*Co floats
-int avsr_conv3x3_bwd_weight_mfma(const float* x, const float* dy, float* dw, int N, int H, int W, int Ci, int Co, int stride, int pad_t,
-                                 int pad_l, int Ho, int Wo, float beta, float* scratch, long scratch_floats, void* stream) {
-  if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
-  if (Co % 4 || (Ci % 4 && Ci >= 4) || pad_t > 1 || pad_l > 1) return AVSR_ERR_UNSUPPORTED;
-  WGArgs A = {};
-  A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo; A.Co = Co;
-  A.S = stride; A.pt = pad_t; A.pl = pad_l;
-  A.t0 = 0; A.nt = 9; A.kw = 3; A.slab = 9 * Ci * Co; A.want_bias = 0; A.pad = WG_PAD;
-  const int MT = (9 * A.CiL + 15) / 16, NTC = (Co + 15) / 16;
-  if (MT > 18 || NTC > 2 || MT * NTC > 36) return AVSR_ERR_UNSUPPORTED;
-  A.F = cg_frames(H, W, A.CiL + WG_PAD, Ho * Wo);
-  const int nout = 9 * Ci * Co;
-  A.m_opf = fmagic(Ho * Wo); A.m_wo = fmagic(Wo); A.m_w = fmagic(W);
-  if (Ci % 4 == 0) {
-    const int rq = W * Ci / 4;
-    if (rq > 256 || rq < 1) return AVSR_ERR_UNSUPPORTED;
-    const int rpp = 256 / rq;
-    while (A.F > 1 && A.F * ((H + rpp - 1) / rpp) > 12) --A.F;
-    if (A.F * ((H + rpp - 1) / rpp) > 12) return AVSR_ERR_UNSUPPORTED;
-    A.m_rq = fmagic(rq); A.m_per = fmagic(H * rq);
-  } else {
-    while (A.F > 1 && (A.F * H * W * Ci / 4 + 255) / 256 > 4) --A.F;
-    if ((A.F * H * W * Ci / 4 + 255) / 256 > 4 || (long)A.F * H * W * Ci >= 65536) return AVSR_ERR_UNSUPPORTED;
-    A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci);
-  }
-  if ((long)A.F * ((Ho * Wo + 15) / 16) >= 65536 || (long)N * Ho * Wo * Co * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
-  const size_t red = sizeof(float) * 4 * 256;
-  size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + WG_PAD);
-  if (lds < red) lds = red;
-  if (lds > 64 * 1024) return AVSR_ERR_UNSUPPORTED;
-  int wpc = (int)((150 * 1024) / (lds + 512));
-  if (wpc > 2) wpc = 2;
-  if (wpc < 1) wpc = 1;
-  if (nout > 2048) wpc = 1;                              // large kernels: the partial slabs, not the staging, are the traffic
-  int grid = (N + A.F - 1) / A.F;
-  if (grid > 256 * wpc) grid = 256 * wpc;
-  if ((long)grid * nout > scratch_floats) grid = (int)(scratch_floats / nout);
-  if (grid < 1) return AVSR_ERR_ARG;
-  hipStream_t s = S_(stream);
-  {
-    ProfScope ps(PROF_CONV_BWD_WEIGHT, s, 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
-#define WG_GO(M_, N_, C_) hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_, C_>), dim3(grid), dim3(256), lds, s, A)
-    if (Ci % 4) { if (MT <= 3 && NTC == 1) WG_GO(3, 1, false); else return AVSR_ERR_UNSUPPORTED; }
-    else if (NTC == 1) { if (MT <= 5) WG_GO(5, 1, true); else if (MT <= 9) WG_GO(9, 1, true); else WG_GO(18, 1, true); }
-    else { if (MT <= 5) WG_GO(5, 2, true); else if (MT <= 9) WG_GO(9, 2, true); else WG_GO(18, 2, true); }
-#undef WG_GO
-    if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
-  }
-  if (avsr::slab_defer_push(scratch, nout, grid, nout, dw, nullptr, 0x7fffffff, 0, 0, 1.0f, beta, S_(stream))) return AVSR_OK;
-  return avsr_colsum_final_launch(scratch, grid, dw, nout, 1.0f, beta, stream);
-}
 
 // =====================================================================================================================
 // Descriptor API (include/avsr_hip.h: avsr_conv_desc): k = 1 or 3, stride 1 or 2, 3..64 channels; BN-ReLU of the input applied by the
 // loader; kernels deeper than one wave's register budget run as several launches over tap groups (the later ones accumulate).
-int avsr_colsum_final_launch_ld(const float* part, long ld, int nblk, float* out, int F, float alpha, float beta, void* stream);
-int avsr_colsum_final_launch_split(const float* part, long ld, int nblk, float* out, float* out2, int split, int F, float alpha, float beta,
-                                   void* stream);
-
-static bool cd_ok(const avsr_conv_desc* c) {
-  return c && c->N > 0 && (c->k == 1 || c->k == 3) && (c->stride == 1 || c->stride == 2) && c->Co % 4 == 0 && (c->Ci % 4 == 0 || c->Ci < 4) &&
-         c->Ci > 0 && c->Co > 0 && c->Co <= 64 && c->pad_t >= 0 && c->pad_t <= 1 && c->pad_l >= 0 && c->pad_l <= 1 && (c->k == 3 || (c->pad_t == 0 && c->pad_l == 0));
-}
 
 // run the tap list in groups that fit the K chunks a wave holds; bias / beta on the first group, residual / statistics on the last
 static int cg_run(CGArgs A, const CGTap* taps, int ntaps, hipStream_t s, int kind, double flops_per_tap, bool dry, int* grid_out) {
@@ -1532,7 +1002,7 @@ static int cg_pair_taps(CGArgs& A, const CGTap* taps, int ntaps, CGTap* wide) {
   return nw;
 }
 
-static int conv_fwd_impl(const avsr_conv_desc* c, const float* x, const float* w, const float* bias, const float* res, const float* res_sc,
+int conv_fwd_impl(const avsr_conv_desc* c, const float* x, const float* w, const float* bias, const float* res, const float* res_sc,
                          const float* res_sh, float* y, float* stats, int32_t* nparts, void* stream, bool dry) {
   CGArgs A = {};
   A.src = x; A.w = w; A.bias = bias; A.dst = y; A.stats = stats; A.res = res; A.bn_sc = c->bn_scale; A.bn_sh = c->bn_shift;
@@ -1556,9 +1026,9 @@ static int conv_fwd_impl(const avsr_conv_desc* c, const float* x, const float* w
 
 // acc (may be NULL): dx = beta*acc + ... instead of beta*dx.  bnb_x != NULL: batch-norm backward stage 1 in the epilogue (see CGArgs):
 // needs ONE launch group that writes every destination pixel once; stats [>= grid][2*Ci] receives the partial sums, *nparts the grid.
-static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const float* w, float* dx, float beta, void* stream, bool dry,
-                              const float* acc = nullptr, const float* bnb_x = nullptr, const float* bnb_sc = nullptr,
-                              const float* bnb_sh = nullptr, float* stats = nullptr, int32_t* nparts = nullptr) {
+int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const float* w, float* dx, float beta, void* stream, bool dry,
+                              const float* acc, const float* bnb_x, const float* bnb_sc,
+                              const float* bnb_sh, float* stats, int32_t* nparts) {
   if (c->Ci % 4) return AVSR_ERR_UNSUPPORTED;
   const int k = c->k;
   auto fuse = [&](CGArgs& A) { A.acc = acc; A.bnb_x = bnb_x; A.bnb_sc = bnb_sc; A.bnb_sh = bnb_sh; A.stats = stats; };
@@ -1650,258 +1120,6 @@ static int conv_bwd_data_impl(const avsr_conv_desc* c, const float* dy, const fl
   return AVSR_OK;
 }
 
-// Workgroups per CU and LDS pixel padding of a weight-gradient launch whose passes hold ONE frame: up to WG_WPC(tiles) workgroups where
-// the frames fit the CU's 160 KB side by side -- with + 1 float of padding instead of + 2 where that is what makes the next one fit
-// (36x36x8: 3 x 52 KB; the odd pixel stride costs 4-byte staging stores and measured nothing on the operand reads).  AVSR_WG_WPC caps it.
-static int wg_occupancy(int tiles, int H, int W, int CiL, int* pad) {
-  static int cap_env = -1;
-  if (cap_env < 0) { const char* e = getenv("AVSR_WG_WPC"); cap_env = e ? atoi(e) : 4; }
-  *pad = WG_PAD;
-  int cap = WG_WPC(tiles);
-  if (cap > cap_env) cap = cap_env;
-  auto frame = [&](int p) { return sizeof(float) * (size_t)(H + 2) * (W + 2) * (CiL + p); };
-  if (2 * frame(WG_PAD) <= 64 * 1024) return 2;                       // several frames per pass: as before
-  for (int w = cap; w > 2; --w) {
-    if (w * (frame(WG_PAD) + 512) <= 160 * 1024) return w;
-    if (w * (frame(1) + 512) <= 160 * 1024) { *pad = 1; return w; }
-  }
-  return 2;
-}
-
-// frames per pass of the weight-gradient kernel (upper bound; even shares in equal passes as above): its time is (passes) x (frames of a pass) -- chunks never span
-// frames --, so among the feasible F the one with the smallest rounds * F wins (4800 frames on 512 workgroups: F = 4 -> 3 x 4, F = 2 or 5
-// -> 10); ties: the larger F
-static int wg_pick_frames(int N, int Fmax, int slots) {
-  double best = -1.0;
-  int bestF = Fmax;
-  for (int F = Fmax; F >= 1; --F) {
-    const long units = (N + F - 1) / F, grid = units < slots ? units : slots;
-    const long cnt = (N + grid - 1) / grid, np = (cnt + F - 1) / F, fp = (cnt + np - 1) / np;      // (the kernel's even shares)
-    const double cost = (double)np * (8.0 * fp + 1.0);
-    if (best < 0.0 || cost < best) { best = cost; bestF = F; }
-  }
-  return bestF;
-}
-
-// final reduction of the pixel-pair weight gradient (below): part [nblk][12*Ci*16 (+16)] with rows (ti, tj', ci), columns (pp, co):
-// dw[ti][tj][ci][co] = sum_blk part[(ti*4 + tj)*Ci + ci][co] + part[(ti*4 + tj + 1)*Ci + ci][8 + co];  dbias[co] = sum_blk bias[co] + bias[8 + co]
-__global__ __launch_bounds__(1024) void wgrad_pair_final_kernel(const float* __restrict__ part, int nblk, int slab, int Ci, float* __restrict__ dw,
-                                                               float* __restrict__ dbias, float beta) {
-  // 32 outputs per workgroup, 32 slices of the slab list each (one thread per (slice, output): 512 slabs = 16 dependent fp64 adds per
-  // thread with four slabs' loads in flight; 8 slices of 64 slabs took 22 us per launch, three launches per step)
-  __shared__ double red[32][33];
-  const int fl = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int nw = 9 * Ci * 8, f = blockIdx.x * 32 + fl;              // outputs: 9*Ci*8 kernel entries, then 8 bias entries
-  int o0 = -1, o1 = -1;
-  if (f < nw) {
-    const int co = f & 7, ci = (f >> 3) % Ci, t = (f >> 3) / Ci, ti = t / 3, tj = t - ti * 3;
-    o0 = ((ti * 4 + tj) * Ci + ci) * 16 + co;
-    o1 = ((ti * 4 + tj + 1) * Ci + ci) * 16 + 8 + co;
-  } else if (f < nw + 8 && dbias) {
-    o0 = 12 * Ci * 16 + (f - nw);
-    o1 = o0 + 8;
-  }
-  double s = 0.0;
-  if (o0 >= 0) {
-    int i = g;
-    for (; i + 96 < nblk; i += 128) {
-      const float a0 = part[(long)i * slab + o0], b0 = part[(long)i * slab + o1];
-      const float a1 = part[(long)(i + 32) * slab + o0], b1 = part[(long)(i + 32) * slab + o1];
-      const float a2 = part[(long)(i + 64) * slab + o0], b2 = part[(long)(i + 64) * slab + o1];
-      const float a3 = part[(long)(i + 96) * slab + o0], b3 = part[(long)(i + 96) * slab + o1];
-      s += (double)a0 + (double)b0;
-      s += (double)a1 + (double)b1;
-      s += (double)a2 + (double)b2;
-      s += (double)a3 + (double)b3;
-    }
-    for (; i < nblk; i += 32) s += (double)part[(long)i * slab + o0] + (double)part[(long)i * slab + o1];
-  }
-  red[g][fl] = s;
-  __syncthreads();
-  if (g == 0 && o0 >= 0) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) t += red[k][fl];
-    float* const o = f < nw ? dw + f : dbias + (f - nw);
-    *o = beta != 0.f ? (float)t + beta * *o : (float)t;
-  }
-}
-
-static int conv_bwd_weight_impl(const avsr_conv_desc* c, const float* x, const float* dy, float* dw, float* dbias, float beta, float* scratch,
-                                long scratch_floats, void* stream, bool dry, const float* fold_y = nullptr, const float* fold_k = nullptr,
-                                float* fold_dx = nullptr) {
-  const int Ci = c->Ci, Co = c->Co, H = c->H, W = c->W, Ho = c->Ho, Wo = c->Wo, N = c->N, k = c->k;
-  const bool fold = fold_k != nullptr;                   // dy = k1*dz + k2*y + k3 evaluated in the operand fetch (single-launch forms only);
-                                                         // fold_dx: also written out for the data gradient that follows
-  // Pixel-pair form for 8 destination channels (the 36x36 layers, the most expensive weight gradients): with 8 columns half of
-  // every 16-column MFMA tile multiplies padding.  dy is read as [N, Ho, Wo/2, 16] (the same bytes): a column is (pixel parity pp,
-  // channel), the depth index a PAIR of horizontally adjacent output pixels; the rows run over the union of the two pixels' windows
-  // (3 x 4 taps, source step 2 along W): C[(ti, tj', ci)][(pp, co)] is the gradient of tap (ti, tj' - pp) where that is a tap at all.
-  // 6 row tiles per pair instead of 2 x 5 per two positions; the reduction kernel above adds the two parities' valid entries.
-  if (Co == 8 && c->stride == 1 && k == 3 && (Wo & 1) == 0 && Wo == W && Ho == H && !getenv("AVSR_WGRAD_NOPAIR")) {
-    WGArgs A = {};
-    A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo / 2; A.Co = 16;
-    A.S = 1; A.SW = 2; A.pt = c->pad_t; A.pl = c->pad_l; A.kw = 4; A.bn_sc = c->bn_scale; A.bn_sh = c->bn_shift;
-    A.t0 = 0; A.nt = 12; A.want_bias = dbias ? 1 : 0;
-    A.fy = fold_y; A.fk = fold_k; A.fC = 8; A.fdx = fold_dx;
-#ifdef CONV_DEBUG
-    { const char* e = getenv("AVSR_CONV_DBG"); A.dbg = e ? atoi(e) : 0; }
-#endif
-    A.slab = 12 * Ci * 16 + (A.want_bias ? 16 : 0);
-    const int MT = (12 * A.CiL + 15) / 16;
-    bool ok = (Ci % 4 == 0) ? MT <= 6 : (MT <= 3 && !c->bn_scale);
-    const int wpc_cap = wg_occupancy(MT, H, W, A.CiL, &A.pad);
-    A.F = cg_frames(H, W, A.CiL + A.pad, Ho * A.Wo);
-    A.m_opf = fmagic(Ho * A.Wo); A.m_wo = fmagic(A.Wo); A.m_w = fmagic(W);
-    if (Ci % 4 == 0) {
-      const int rq = W * Ci / 4;
-      ok = ok && rq <= 256 && rq >= 1;
-      if (ok) {
-        const int rpp = 256 / rq;
-        while (A.F > 1 && A.F * ((H + rpp - 1) / rpp) > 12) --A.F;
-        ok = A.F * ((H + rpp - 1) / rpp) <= 12;
-        A.m_rq = fmagic(rq); A.m_per = fmagic(H * rq);
-      }
-    } else {
-      while (A.F > 1 && (A.F * H * W * Ci / 4 + 255) / 256 > 4) --A.F;
-      ok = ok && (A.F * H * W * Ci / 4 + 255) / 256 <= 4 && (long)A.F * H * W * Ci < 65536;
-      A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci);
-    }
-    if (ok) A.F = wg_pick_frames(N, A.F, 256 * wpc_cap);
-    size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + A.pad);
-    if (lds < sizeof(float) * 4 * 256) lds = sizeof(float) * 4 * 256;
-    ok = ok && lds <= 64 * 1024 && (long)A.F * ((Ho * A.Wo + 15) / 16) < 65536 && (long)N * Ho * Wo * Co * 4 < (1L << 31);
-    if (ok) {
-      int wpc = (int)((160 * 1024) / (lds + 512));
-      if (wpc > wpc_cap) wpc = wpc_cap;
-      if (wpc < 1) wpc = 1;
-      int grid = (N + A.F - 1) / A.F;
-      if (grid > 256 * wpc) grid = 256 * wpc;
-      if ((long)grid * A.slab > scratch_floats) grid = (int)(scratch_floats / A.slab);
-      if (grid < 1) return AVSR_ERR_ARG;
-      if (dry) return AVSR_OK;
-      hipStream_t s = S_(stream);
-      {
-        ProfScope ps(PROF_CONV_BWD_WEIGHT, s, 2.0 * N * Ho * Wo * 9.0 * Ci * Co);
-        if (fold && Ci % 4 && fold_dx) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, false, false, 2>), dim3(grid), dim3(256), lds, s, A);
-        else if (fold && Ci % 4) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, false, false, 1>), dim3(grid), dim3(256), lds, s, A);
-        else if (fold && fold_dx) hipLaunchKernelGGL((conv_wgrad_kernel<6, 1, true, false, 2>), dim3(grid), dim3(256), lds, s, A);
-        else if (fold) hipLaunchKernelGGL((conv_wgrad_kernel<6, 1, true, false, 1>), dim3(grid), dim3(256), lds, s, A);
-        else if (Ci % 4) hipLaunchKernelGGL((conv_wgrad_kernel<3, 1, false>), dim3(grid), dim3(256), lds, s, A);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<6, 1, true>), dim3(grid), dim3(256), lds, s, A);
-        if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
-      }
-      const int nout = 9 * Ci * 8 + 8;
-      if (avsr::slab_defer_push(scratch, A.slab, grid, nout, dw, dbias, 0, 1, Ci, 1.0f, beta, s)) return AVSR_OK;
-      hipLaunchKernelGGL(wgrad_pair_final_kernel, dim3((nout + 31) / 32), dim3(1024), 0, s, scratch, grid, A.slab, Ci, dw, dbias, beta);
-      if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
-      return AVSR_OK;
-    }
-  }
-  WGArgs A = {};
-  A.x = x; A.dy = dy; A.part = scratch; A.N = N; A.H = H; A.W = W; A.Ci = Ci; A.CiL = (Ci + 3) & ~3; A.Ho = Ho; A.Wo = Wo; A.Co = Co;
-  A.S = c->stride; A.pt = c->pad_t; A.pl = c->pad_l; A.kw = k; A.bn_sc = c->bn_scale; A.bn_sh = c->bn_shift;
-  A.fy = fold_y; A.fk = fold_k; A.fC = Co; A.fdx = fold_dx;
-  const int NTC = (Co + 15) / 16;
-  if (NTC == 3) return AVSR_ERR_UNSUPPORTED;
-  const int mt_max = NTC == 4 ? 9 : 18;
-  int G = mt_max * 16 / A.CiL;                           // taps per launch
-  if (G < 1) return AVSR_ERR_UNSUPPORTED;
-  // (tiles of the form the first launch takes: the tap groups of one call share the staging layout)
-  const int mt_first = ((k * k < G ? k * k : G) * A.CiL + 15) / 16;
-  const int tiles_first = (mt_first <= 5 ? 5 : (mt_first <= 9 ? 9 : 18)) * (NTC == 1 ? 1 : (NTC == 2 ? 2 : 4));
-  const int wpc_cap = (Ci % 4 == 0) ? wg_occupancy(tiles_first, H, W, A.CiL, &A.pad) : (A.pad = WG_PAD, 2);
-  A.F = cg_frames(H, W, A.CiL + A.pad, Ho * Wo);
-  A.m_opf = fmagic(Ho * Wo); A.m_wo = fmagic(Wo); A.m_w = fmagic(W);
-  if (Ci % 4 == 0) {
-    const int rq = W * Ci / 4;
-    if (rq > 256 || rq < 1) return AVSR_ERR_UNSUPPORTED;
-    const int rpp = 256 / rq;
-    while (A.F > 1 && A.F * ((H + rpp - 1) / rpp) > 12) --A.F;
-    if (A.F * ((H + rpp - 1) / rpp) > 12) return AVSR_ERR_UNSUPPORTED;
-    A.m_rq = fmagic(rq); A.m_per = fmagic(H * rq);
-  } else {
-    if (c->bn_scale) return AVSR_ERR_UNSUPPORTED;
-    while (A.F > 1 && (A.F * H * W * Ci / 4 + 255) / 256 > 4) --A.F;
-    if ((A.F * H * W * Ci / 4 + 255) / 256 > 4 || (long)A.F * H * W * Ci >= 65536) return AVSR_ERR_UNSUPPORTED;
-    A.m_rq = fmagic(Ci); A.m_per = fmagic(H * W * Ci);
-  }
-  while (A.F > 1 && sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + A.pad) > 64 * 1024) --A.F;
-  {
-    const int nt0 = k * k < G ? k * k : G;
-    A.F = wg_pick_frames(N, A.F, (nt0 * Ci * Co + Co > 2048) ? 256 : 256 * wpc_cap);
-  }
-  if ((long)A.F * ((Ho * Wo + 15) / 16) >= 65536 || (long)N * Ho * Wo * Co * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;
-  const size_t red = sizeof(float) * 4 * 256;
-  size_t lds = sizeof(float) * (size_t)A.F * (size_t)(H + 2) * (W + 2) * (A.CiL + A.pad);
-  if (lds < red) lds = red;
-  if (lds > 64 * 1024) return AVSR_ERR_UNSUPPORTED;
-  int wpc = (int)((160 * 1024) / (lds + 512));
-  if (wpc > wpc_cap) wpc = wpc_cap;
-  if (wpc < 1) wpc = 1;
-  hipStream_t s = S_(stream);
-  bool bias_done = dbias == nullptr;
-  // deep layers (64 destination channels, more (tap, channel) rows than one wave's accumulators hold): the row-split form, one launch
-  static int rs_on = -1;
-  if (rs_on < 0) { const char* e = getenv("AVSR_WGRAD_RS"); rs_on = e ? (atoi(e) != 0) : 1; }
-  const int Mall = k * k * A.CiL;
-  const bool rs = rs_on && NTC == 4 && Ci % 4 == 0 && G < k * k && Mall <= 4 * 9 * 16;   // (32-column layers fit one launch already: no gain measured)
-  if (rs) G = k * k;
-  if (fold) {
-    // one launch only (a second tap group would evaluate -- and write -- the gradient again), and only the forms instantiated below
-    const int MT1 = rs ? ((k * k * A.CiL + 3) / 4 + 15) / 16 : (k * k * A.CiL + 15) / 16;
-    const bool okf = G >= k * k && Ci % 4 == 0 && (rs ? MT1 <= 5 : (NTC == 1 ? MT1 <= 5 : (NTC == 2 && MT1 <= 9)));
-    if (!okf) return AVSR_ERR_UNSUPPORTED;
-  }
-  for (int t0 = 0; t0 < k * k; t0 += G) {
-    A.t0 = t0; A.nt = k * k - t0 < G ? k * k - t0 : G;
-    A.want_bias = bias_done ? 0 : 1;
-    const int wF = A.nt * Ci * Co;
-    A.slab = wF + (A.want_bias ? Co : 0);
-    const int MT = rs ? ((A.nt * A.CiL + 3) / 4 + 15) / 16 : (A.nt * A.CiL + 15) / 16;      // (rs: row tiles per WAVE)
-    if (Ci % 4 && (MT > 3 || NTC != 1)) return AVSR_ERR_UNSUPPORTED;
-    int grid = (N + A.F - 1) / A.F;
-    const int cap = 256 * (A.slab > 2048 ? 1 : wpc);      // large kernels: the partial slabs, not the staging, are the traffic
-    if (grid > cap) grid = cap;
-    if ((long)grid * A.slab > scratch_floats) grid = (int)(scratch_floats / A.slab);
-    if (grid < 1) return AVSR_ERR_ARG;
-    if (dry) continue;
-    {
-      ProfScope ps(PROF_CONV_BWD_WEIGHT, s, 2.0 * N * Ho * Wo * (double)A.nt * Ci * Co);
-#define WG_GO(M_, N_, C_) hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_, C_>), dim3(grid), dim3(256), lds, s, A)
-      if (fold) {
-#define WG_FOLD(M_, N_, R_) { if (fold_dx) hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_, true, R_, 2>), dim3(grid), dim3(256), lds, s, A); \
-                              else hipLaunchKernelGGL((conv_wgrad_kernel<M_, N_, true, R_, 1>), dim3(grid), dim3(256), lds, s, A); }
-        if (rs) WG_FOLD(5, 4, true)
-        else if (NTC == 1) WG_FOLD(5, 1, false)
-        else WG_FOLD(9, 2, false)
-#undef WG_FOLD
-      } else if (rs) {
-        if (MT <= 5) hipLaunchKernelGGL((conv_wgrad_kernel<5, 4, true, true>), dim3(grid), dim3(256), lds, s, A);
-        else hipLaunchKernelGGL((conv_wgrad_kernel<9, 4, true, true>), dim3(grid), dim3(256), lds, s, A);
-      } else if (Ci % 4) WG_GO(3, 1, false);
-      else if (NTC == 1) { if (MT <= 5) WG_GO(5, 1, true); else if (MT <= 9) WG_GO(9, 1, true); else WG_GO(18, 1, true); }
-      else if (NTC == 2) { if (MT <= 5) WG_GO(5, 2, true); else if (MT <= 9) WG_GO(9, 2, true); else WG_GO(18, 2, true); }
-      else { if (MT <= 5) WG_GO(5, 4, true); else WG_GO(9, 4, true); }
-#undef WG_GO
-      if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
-    }
-    int rc;
-    if (A.want_bias) {                                     // weight and bias gradients of the slab in one reduction launch
-      if (avsr::slab_defer_push(scratch, A.slab, grid, A.slab, dw + (long)t0 * Ci * Co, dbias, wF, 0, 0, 1.0f, beta, s)) rc = AVSR_OK;
-      else rc = avsr_colsum_final_launch_split(scratch, A.slab, grid, dw + (long)t0 * Ci * Co, dbias, wF, A.slab, 1.0f, beta, stream);
-      bias_done = true;
-    } else {
-      if (avsr::slab_defer_push(scratch, A.slab, grid, wF, dw + (long)t0 * Ci * Co, nullptr, 0x7fffffff, 0, 0, 1.0f, beta, s)) rc = AVSR_OK;
-      else rc = avsr_colsum_final_launch_ld(scratch, A.slab, grid, dw + (long)t0 * Ci * Co, wF, 1.0f, beta, stream);
-    }
-    if (rc != AVSR_OK) return rc;
-    // (deferred reductions: the next tap group of this call must not overwrite the slabs just recorded)
-    if (avsr::slab_deferring()) { scratch += (long)grid * A.slab; scratch_floats -= (long)grid * A.slab; A.part = scratch; }
-  }
-  return AVSR_OK;
-}
-
 extern "C" int avsr_conv_supported(const avsr_conv_desc* c) {
   if (!g_conv_mfma || !cd_ok(c)) return 0;
   if (conv_fwd_impl(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true) != AVSR_OK) return 0;
@@ -1937,220 +1155,4 @@ extern "C" int avsr_conv_bwd_data_bn_supported(const avsr_conv_desc* c) {
   static float dummy;
   int32_t n = 0;
   return conv_bwd_data_impl(c, nullptr, nullptr, nullptr, 1.f, nullptr, true, &dummy, &dummy, &dummy, &dummy, &dummy, &n) == AVSR_OK;
-}
-
-// Batch-norm backward, stage 2 (after avsr_conv_bwd_data_bn wrote dz and the partial sums [nparts][2*C] = (sum dz | sum dz*x)):
-//   d beta (+)= sum dz;  d gamma (+)= invstd * (sum dz*x - mean * sum dz);
-//   k[0..C) = gamma*invstd, k[C..2C) = -gamma*invstd^2 * b, k[2C..3C) = -gamma*invstd*a + gamma*invstd^2 * b * mean
-// with a = sum dz / count, b = invstd * (sum dz*x - mean * sum dz) / count, so that dx = k1*dz + k2*x + k3 (avsr_bn_bwd_apply) is
-// gamma*invstd * (dz - a - xhat*b).  fp64 merge of the partials.
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* part, int nparts, int C, double count, const float* mean,
-                                                              const float* invstd, const float* gamma, float* dgamma, float* dbeta,
-                                                              float grad_beta, float* k) {
-  __shared__ double red[2][64][17];
-  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
-  double s = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int p = rg; p < nparts; p += 64) { s += (double)part[(long)p * 2 * C + c]; s2 += (double)part[(long)p * 2 * C + C + c]; }
-  red[0][rg][cl] = s; red[1][rg][cl] = s2;
-  __syncthreads();
-  if (threadIdx.x >= 16 || c >= C) return;
-  s = 0.0; s2 = 0.0;
-  for (int r = 0; r < 64; ++r) { s += red[0][r][cl]; s2 += red[1][r][cl]; }
-  const double m = mean[c], is = invstd[c], g = gamma[c];
-  const double sxh = is * (s2 - m * s);                  // sum dz * xhat
-  if (dbeta) dbeta[c] = (grad_beta != 0.f ? grad_beta * dbeta[c] : 0.f) + (float)s;
-  if (dgamma) dgamma[c] = (grad_beta != 0.f ? grad_beta * dgamma[c] : 0.f) + (float)sxh;
-  const double a = s / count, b = sxh / count;
-  k[c] = (float)(g * is);
-  k[C + c] = (float)(-g * is * is * b);
-  k[2 * C + c] = (float)(-g * is * a + g * is * is * b * m);
-}
-
-extern "C" int avsr_bn_bwd_finalize(const float* part, int32_t nparts, int32_t C, int64_t count, const float* mean, const float* invstd,
-                                    const float* gamma, float* dgamma, float* dbeta, float grad_beta, float* k, void* stream) {
-  if (!part || nparts <= 0 || C <= 0 || count <= 0 || !mean || !invstd || !gamma || !k) return AVSR_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), part, nparts, C, (double)count, mean, invstd, gamma,
-                     dgamma, dbeta, grad_beta, k);
-  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
-  return AVSR_OK;
-}
-
-// dx = beta*dx + k1[c]*dz + k2[c]*x + k3[c] over [rows][C] maps, C % 4 == 0 (16-byte accesses, one channel quad per lane)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ k,
-                                                           float* __restrict__ dx, long n4, int C4, int C, float beta) {
-  const long stride = (long)gridDim.x * 256;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += stride) {
-    const int c = (int)(idx % C4) * 4;
-    const f32x4 k1 = ld4(k + c), k2 = ld4(k + C + c), k3 = ld4(k + 2 * C + c);
-    const f32x4 a = ld4(dz + idx * 4), b = ld4(x + idx * 4);
-    f32x4 v = k1 * a + k2 * b + k3;
-    if (beta != 0.f) v += beta * ld4(dx + idx * 4);
-    st4(dx + idx * 4, v);
-  }
-}
-
-extern "C" int avsr_bn_bwd_apply(const float* dz, const float* x, const float* k, float* dx, int64_t rows, int32_t C, float beta, void* stream) {
-  if (!dz || !x || !k || !dx || rows <= 0 || C <= 0 || C % 4) return AVSR_ERR_ARG;
-  const long n4 = rows * (C / 4);
-  long blocks = (n4 + 256 * 8 - 1) / (256 * 8);
-  if (blocks > 2048) blocks = 2048;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)blocks), dim3(256), 0, S_(stream), dz, x, k, dx, n4, C / 4, C, beta);
-  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
-  return AVSR_OK;
-}
-
-// Batch-norm backward, stage 1 on its own (the form avsr_conv_bwd_data_bn fuses into a single-launch data gradient's epilogue), for a
-// batch norm whose output gradient was assembled by several launches (the per-class 3x3/2 data gradient of a wide layer):
-//   dz = dy * [relu(scale*x + shift) > 0]   (or [y > 0] when the batch-norm output map was written),  part [nparts][2C] = (sum dz | sum dz*x)
-// dz may alias dy.  C % 4 == 0, C <= 1024; *nparts <= 512 blocks, each over a contiguous run of rows.
-__global__ __launch_bounds__(256) void bn_bwd_stage1_kernel(const float* dy, const float* __restrict__ x, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, const float* __restrict__ y, float* dz, long rows,
-                                                            int C, long rows_per_block, float* __restrict__ part) {
-  __shared__ float red[256][9];
-  const int C4 = C / 4, RL = 256 / C4, q = threadIdx.x % C4, rl = threadIdx.x / C4;
-  const long r0 = blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f}, sx = s;
-  f32x4 sc = s, sh = s;
-  if (scale && rl < RL) { sc = ld4(scale + 4 * q); sh = ld4(shift + 4 * q); }
-  if (rl < RL)
-    for (long r = r0 + rl; r < r1; r += RL) {
-      const long o = r * C + 4 * q;
-      const f32x4 g = ld4(dy + o), xv = ld4(x + o);
-      f32x4 v;
-      if (scale) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaf(xv[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
-      } else {
-        const f32x4 yv = ld4(y + o);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = yv[e] > 0.f ? g[e] : 0.f;
-      }
-      st4(dz + o, v);
-      s += v; sx += v * xv;
-    }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { red[threadIdx.x][e] = s[e]; red[threadIdx.x][4 + e] = sx[e]; }
-  __syncthreads();
-  if (threadIdx.x >= C4) return;
-  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int r = 0; r < RL; ++r)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] += red[r * C4 + q][e];
-  float* p = part + (long)blockIdx.x * 2 * C;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { p[4 * q + e] = a[e]; p[C + 4 * q + e] = a[4 + e]; }
-}
-extern "C" int avsr_bn_bwd_stage1(const float* dy, const float* x, const float* scale, const float* shift, const float* y, float* dz, int64_t rows,
-                                  int32_t C, float* part, int32_t* nparts, void* stream) {
-  if (!dy || !x || !dz || !part || !nparts || rows <= 0 || C <= 0 || C % 4 || C > 1024 || (!scale && !y) || (scale && !shift)) return AVSR_ERR_ARG;
-  const int RL = 256 / (C / 4);
-  long per = (rows + 511) / 512;
-  if (per < 8L * RL) per = 8L * RL;                          // at least eight passes of a block's row lanes
-  const int blocks = (int)((rows + per - 1) / per);
-  *nparts = blocks;
-  hipLaunchKernelGGL(bn_bwd_stage1_kernel, dim3(blocks), dim3(256), 0, S_(stream), dy, x, scale, shift, y, dz, (long)rows, C, per, part);
-  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
-  return AVSR_OK;
-}
-
-// ---- batch-norm statistics across data-parallel ranks (opt-in: DataParallelTrainer(sync_cnn_bn=True)) --------------------------------
-// The partial sums a convolution epilogue wrote are merged into fp64 per-channel sums, the host all-reduces that small buffer (with the
-// rank's row count behind it), and the finalisation reads the GLOBAL sums: mean / variance / moving averages / loader affine of the
-// whole batch on every rank (video.py:4-14 over the global batch).  Same arithmetic as bn_finalize_kernel / bn_bwd_finalize_kernel.
-__global__ __launch_bounds__(1024) void bn_partials_f64_kernel(const float* part, int nparts, int C, double* out) {
-  __shared__ double red[2][64][17];
-  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
-  double s = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int p = rg; p < nparts; p += 64) { s += (double)part[(long)p * 2 * C + c]; s2 += (double)part[(long)p * 2 * C + C + c]; }
-  red[0][rg][cl] = s; red[1][rg][cl] = s2;
-  __syncthreads();
-  if (threadIdx.x >= 16 || c >= C) return;
-  s = 0.0; s2 = 0.0;
-  for (int r = 0; r < 64; ++r) { s += red[0][r][cl]; s2 += red[1][r][cl]; }
-  out[c] = s; out[C + c] = s2;
-}
-extern "C" int avsr_bn_partials_f64(const float* part, int32_t nparts, int32_t C, double* out64, void* stream) {
-  if (!part || nparts <= 0 || C <= 0 || !out64) return AVSR_ERR_ARG;
-  hipLaunchKernelGGL(bn_partials_f64_kernel, dim3((C + 15) / 16), dim3(1024), 0, S_(stream), part, nparts, C, out64);
-  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
-  return AVSR_OK;
-}
-// sums [2C + 1]: sum | sum of squares | rows per channel (all ranks)
-__global__ void bn_finalize_f64_kernel(const double* sums, int C, float eps, float momentum, float* mean, float* invstd, float* mov_mean,
-                                       float* mov_var, const float* gamma, const float* beta, float* scale, float* shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double count = sums[2 * C], m = sums[c] / count;
-  double var = sums[C + c] / count - m * m;
-  if (var < 0.0) var = 0.0;
-  const float is = rsqrtf((float)var + eps);
-  mean[c] = (float)m;
-  invstd[c] = is;
-  if (scale) {
-    const float sc = gamma[c] * is;
-    scale[c] = sc;
-    shift[c] = beta[c] - (float)m * sc;
-  }
-  if (mov_mean) {
-    const float unbiased = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
-    mov_mean[c] = momentum * mov_mean[c] + (1.f - momentum) * (float)m;
-    mov_var[c] = momentum * mov_var[c] + (1.f - momentum) * unbiased;
-  }
-}
-extern "C" int avsr_bn_finalize_f64(const double* sums, int32_t C, float eps, float momentum, float* mean, float* invstd, float* mov_mean,
-                                    float* mov_var, const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
-  if (!sums || C <= 0 || !mean || !invstd || (scale && (!gamma || !beta || !shift))) return AVSR_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_f64_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), sums, C, eps, momentum, mean, invstd, mov_mean, mov_var,
-                     gamma, beta, scale, shift);
-  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
-  return AVSR_OK;
-}
-// local [2C]: this rank's (sum dz | sum dz*x); global [2C + 1]: the all-reduced sums and the global row count.  d gamma / d beta take the
-// LOCAL sums (the gradient all-reduce adds the ranks' shares), the coefficient vectors of dx = k1*dz + k2*x + k3 the GLOBAL means.
-__global__ void bn_bwd_finalize_f64_kernel(const double* local, const double* global, int C, const float* mean, const float* invstd,
-                                           const float* gamma, float* dgamma, float* dbeta, float grad_beta, float* k) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double m = mean[c], is = invstd[c], g = gamma[c], count = global[2 * C];
-  const double sl = local[c], sxh_l = is * (local[C + c] - m * sl);
-  if (dbeta) dbeta[c] = (grad_beta != 0.f ? grad_beta * dbeta[c] : 0.f) + (float)sl;
-  if (dgamma) dgamma[c] = (grad_beta != 0.f ? grad_beta * dgamma[c] : 0.f) + (float)sxh_l;
-  const double s = global[c], sxh = is * (global[C + c] - m * s);
-  const double a = s / count, b = sxh / count;
-  k[c] = (float)(g * is);
-  k[C + c] = (float)(-g * is * is * b);
-  k[2 * C + c] = (float)(-g * is * a + g * is * is * b * m);
-}
-extern "C" int avsr_bn_bwd_finalize_f64(const double* local, const double* global, int32_t C, const float* mean, const float* invstd,
-                                        const float* gamma, float* dgamma, float* dbeta, float grad_beta, float* k, void* stream) {
-  if (!local || !global || C <= 0 || !mean || !invstd || !gamma || !k) return AVSR_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_f64_kernel, dim3((C + 63) / 64), dim3(64), 0, S_(stream), local, global, C, mean, invstd, gamma, dgamma, dbeta,
-                     grad_beta, k);
-  if (hipGetLastError() != hipSuccess) return AVSR_ERR_HIP;
-  return AVSR_OK;
-}
-
-// Weight (+ bias) gradient with the batch-norm backward of the convolution's own output folded into the operand fetch: dy = k[0..C)*dz +
-// k[C..2C)*y + k[2C..3C) (avsr_bn_bwd_finalize's vectors) -- see WGArgs; dx_out (may be NULL): the evaluated gradient is also stored there
-// for the layer's data gradient.  AVSR_ERR_UNSUPPORTED unless avsr_conv_bwd_weight_bn_supported.
-extern "C" int avsr_conv_bwd_weight_bn(const avsr_conv_desc* c, const float* x, const float* dz, const float* y, const float* k, float* dx_out,
-                                       float* dw, float* dbias, float beta, float* scratch, int64_t scratch_floats, void* stream) {
-  if (!cd_ok(c) || !x || !dz || !y || !k || !dw || !scratch) return AVSR_ERR_ARG;
-  if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
-  return conv_bwd_weight_impl(c, x, dz, dw, dbias, beta, scratch, scratch_floats, stream, false, y, k, dx_out);
-}
-extern "C" int avsr_conv_bwd_weight_bn_supported(const avsr_conv_desc* c) {
-  if (!g_conv_mfma || !cd_ok(c)) return 0;
-  static float dummy;
-  return conv_bwd_weight_impl(c, nullptr, nullptr, nullptr, nullptr, 1.f, nullptr, 1L << 40, nullptr, true, &dummy, &dummy) == AVSR_OK;
-}
-
-extern "C" int avsr_conv_bwd_weight(const avsr_conv_desc* c, const float* x, const float* dy, float* dw, float* dbias, float beta, float* scratch,
-                                    int64_t scratch_floats, void* stream) {
-  if (!cd_ok(c) || !x || !dy || !dw || !scratch) return AVSR_ERR_ARG;
-  if (!g_conv_mfma) return AVSR_ERR_UNSUPPORTED;
-  return conv_bwd_weight_impl(c, x, dy, dw, dbias, beta, scratch, scratch_floats, stream, false);
 }

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Weight-gradient ablation on the GPU box: csrc/conv_mfma.hip rebuilt with -DWG_ABLATE=<mask> (there only), the kernel timed per layer.
+# Weight-gradient ablation on the GPU box: csrc/conv_wgrad.hip (the weight-gradient kernel; conv_mfma.hip before the round-6 split) rebuilt with -DWG_ABLATE=<mask> (there only), the kernel timed per layer.
 # usage: tools/wgrad_ablate.sh H,Ci,Co ...
 cd "$(dirname "$0")/.." || exit 1
 ROOT=$(pwd); C=$ROOT/avsr-tf1_amd/csrc
 run() {
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result -Wno-pass-failed $1 -I $ROOT/include -I $C -c $C/conv_mfma.hip -o $C/conv_mfma.o || exit 1
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-result -Wno-pass-failed $1 -I $ROOT/include -I $C -c $C/conv_wgrad.hip -o $C/conv_wgrad.o || exit 1
   hipcc --offload-arch=gfx950 -shared -fPIC -o $C/libavsr_hip.so $C/*.o || exit 1
   shift
   python tools/wgrad_ablate.py "$@" 2>&1 | grep -v amdgpu.ids
