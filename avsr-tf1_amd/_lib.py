@@ -73,7 +73,8 @@ class AttnMech(C.Structure):
 class DecLayer(C.Structure):
     _fields_ = [("wt", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("gates", C.c_void_p), ("cs", C.c_void_p),
                 ("out", C.c_void_p), ("state", C.c_void_p), ("hs_seq", C.c_void_p), ("xin_seq", C.c_void_p),
-                ("dgates", C.c_void_p), ("dstate", C.c_void_p), ("cell_id", C.c_int32), ("pad_", C.c_int32)]
+                ("dgates", C.c_void_p), ("dstate", C.c_void_p), ("cell_id", C.c_int32), ("pad_", C.c_int32),
+                ("wt2", C.c_void_p), ("w2", C.c_void_p), ("bias2", C.c_void_p), ("rh_seq", C.c_void_p), ("dgates2", C.c_void_p)]
 
 
 MAX_DEC_EXTRA = 3

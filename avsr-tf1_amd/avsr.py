@@ -8,7 +8,7 @@ try_restore_latest_checkpoint)` / `evaluate(checkpoint_path, epoch)` behaviour a
 
 `video_processing='resnet_cnn'` runs the lip crops through the HIP lip-CNN front-end (cnn.py; avsr/video.py:143-195).
 Built besides the defaults: `input_dense_layers`, `instance_normalisation`, `residual_encoder`, `highway_encoder`, `encoder_weight_sharing`, multi-layer
-decoders (equal widths, LSTM), `enable_attention=False`, `loss_fun` / `label_smoothing`, `lr_decay=('cosine_restarts', N)`, the Nadam /
+decoders (equal widths), `enable_attention=False`, `loss_fun` / `label_smoothing`, `lr_decay=('cosine_restarts', N)`, the Nadam /
 AdamW / Momentum optimisers, `write_attention_alignment` (greedy decoding), one-hot decoder inputs (`embedding_size <= 0`).  Feature / unit /
 embedding sizes may be anything (the engine pads to multiples of 4 inside, config.py `engine()`; checkpoints keep the reference's shapes).
 Not built (raise explicitly): `precision='float16'`, the `2dconv_cnn` / `3dconv_cnn` front-ends, `'wav'` audio

@@ -198,8 +198,6 @@ class ModelConfig:
             raise ValueError("input_dense_layers must be positive")
         if len(set(self.decoder_units)) != 1 or len(self.decoder_units) > 4:
             raise NotImplementedError("multi-layer decoders: up to 4 layers of equal width")
-        if len(self.decoder_units) > 1 and self.cell_type != "lstm":
-            raise NotImplementedError("multi-layer decoders: LSTM cells only")
         if not self.streams() and self.architecture != "lm":
             raise Exception("labels are None")                                         # seq2seq.py:94
         dims = [self.decoder_units[0]]

@@ -416,6 +416,11 @@ static inline float* xdgroll(const avsr_attn_rnn& d, int j, int p) { return d.ex
 static inline float* xdcbuf(const avsr_attn_rnn& d, int j, int p) { return d.extra[j].dstate + (long)(8 + p) * d.B * d.H; }
 static inline float* xdhcarry(const avsr_attn_rnn& d, int j, int p) { return d.extra[j].dstate + (long)(10 + p) * d.B * d.H; }
 // output record of decoder layer j (0 = the attention-fed cell): [B][L+1][H], slot l+1 = step l
+// GRU extra layers: the same dstate layout as the block's own GRU cell (d gates rolling [2][B][2H] | d cand [2][B][H] | carry [2][B][H] | 2 tmp)
+static inline float* xg_dgg(const avsr_attn_rnn& d, int j, int p) { return d.extra[j].dstate + (long)p * d.B * 2 * d.H; }
+static inline float* xg_dpc(const avsr_attn_rnn& d, int j, int p) { return d.extra[j].dstate + (long)(4 + p) * d.B * d.H; }
+static inline float* xg_carry(const avsr_attn_rnn& d, int j, int p) { return d.extra[j].dstate + (long)(6 + p) * d.B * d.H; }
+static inline float* xg_tmp(const avsr_attn_rnn& d, int j, int w) { return d.extra[j].dstate + (long)(8 + w) * d.B * d.H; }
 static inline float* layer_out(const avsr_attn_rnn& d, int j) { return j == 0 ? (d.n_extra > 0 ? d.out0 : d.cell_out) : d.extra[j - 1].out; }
 static inline int nchunk(const avsr_attn_mech& m) { return (m.T + m.chunk - 1) / m.chunk; }
 static inline bool is_bahdanau(const avsr_attn_mech& m) { return m.type >= ATT_BAHDANAU; }
@@ -427,11 +432,11 @@ static int validate(const avsr_attn_rnn* d) {
   if (d->n_mech > 0 && !d->att) return AVSR_ERR_ARG;
   if (d->n_extra < 0 || d->n_extra > AVSR_MAX_DEC_EXTRA) return AVSR_ERR_ARG;
   if (d->n_extra > 0) {
-    if (d->cell == 1) return AVSR_ERR_UNSUPPORTED;                      // multi-layer decoder cells: LSTM only
     if (!d->out0 || d->extra[d->n_extra - 1].out != d->cell_out) return AVSR_ERR_ARG;
     for (int j = 0; j < d->n_extra; ++j) {
       const avsr_dec_layer& X = d->extra[j];
       if (!X.wt || !X.gates || !X.cs || !X.out || !X.state) return AVSR_ERR_ARG;
+      if (d->cell == 1 && (!X.wt2 || !X.rh_seq)) return AVSR_ERR_ARG;  // GRU layers: candidate kernel and the r*h record
     }
   }
   for (int m = 0; m < d->n_mech; ++m) {
@@ -593,20 +598,32 @@ extern "C" int avsr_attn_rnn_fwd(const avsr_attn_rnn* dp, int32_t l_begin, int32
       if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
     }
     // ---- K1b: the layers above (MultiRNNCell): layer j consumes layer j-1's output of this step -----------------------
-    for (int j = 0; j < d.n_extra; ++j) {
+    for (int j = 0; j < d.n_extra; ++j)
+     for (int phase = 0; phase < (gru ? 2 : 1); ++phase) {
       const avsr_dec_layer& X = d.extra[j];
       SL.ntask = 1;
       StepTask& tk = SL.task[0];
       tk = StepTask{};
+      const float* xwt = (gru && phase == 1) ? X.wt2 : X.wt;
       StepSrc& x = tk.src[tk.nsrc++];
-      x.a = (drop ? X.xin_seq : layer_out(d, j)) + (long)(l + 1) * H; x.sb = (long)(L + 1) * H; x.K = H; x.w = X.wt; x.ldw = 2 * H;
+      x.a = (drop ? X.xin_seq : layer_out(d, j)) + (long)(l + 1) * H; x.sb = (long)(L + 1) * H; x.K = H; x.w = xwt; x.ldw = 2 * H;
       x.kind = SRC_OWNROW;
       StepSrc& h = tk.src[tk.nsrc++];
-      h.a = xhbuf(d, j, l & 1); h.sb = H; h.K = H; h.w = X.wt + H; h.ldw = 2 * H; h.kind = SRC_PLAIN;
+      h.a = (gru && phase == 1) ? xhbuf(d, j, 2) /* r*h of this step, own row */ : xhbuf(d, j, l & 1);
+      h.sb = H; h.K = H; h.w = xwt + H; h.ldw = 2 * H; h.kind = (gru && phase == 1) ? SRC_OWNROW : SRC_PLAIN;
       if (d.mode == 3) tk.gather2 = d.parent_rows;
       tk.B = B; tk.t = l; tk.T = L; tk.reverse = 0; tk.len = d.steplen;
-      tk.N = 4 * H; tk.mode = EP_LSTM_FWD; tk.bias = X.bias; tk.p0 = X.gates; tk.p1 = X.cs;
-      tk.p3 = xcbuf(d, j, l & 1); tk.p4 = xhbuf(d, j, l & 1); tk.p5 = xcbuf(d, j, (l + 1) & 1); tk.p6 = xhbuf(d, j, (l + 1) & 1);
+      tk.p4 = xhbuf(d, j, l & 1);
+      if (gru && phase == 0) {                       // gates of a GRU layer above the attention-fed one (same epilogues as the block's cell)
+        tk.N = 2 * H; tk.mode = EP_GRU_GATES; tk.bias = X.bias;
+        tk.p0 = X.gates; tk.p1 = xhbuf(d, j, 2); tk.p2 = X.rh_seq;
+        if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+        continue;
+      }
+      if (gru) { tk.N = H; tk.mode = EP_GRU_CAND; tk.bias = X.bias2; tk.p0 = X.cs; tk.p1 = X.gates; }
+      else { tk.N = 4 * H; tk.mode = EP_LSTM_FWD; tk.bias = X.bias; tk.p0 = X.gates; tk.p1 = X.cs;
+             tk.p3 = xcbuf(d, j, l & 1); tk.p5 = xcbuf(d, j, (l + 1) & 1); }
+      tk.p6 = xhbuf(d, j, (l + 1) & 1);
       tk.p2 = X.out + H; tk.s0 = (long)(L + 1) * H; tk.s1 = H;
       if (drop) {
         const uint32_t c4 = (uint32_t)X.cell_id * 4;
@@ -855,6 +872,8 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
       StepSrc& a = tk.src[tk.nsrc++];
       if (j == 0) {
         a.a = gru ? g_dgg((l + 1) & 1) : dgroll(d, (l + 1) & 1); a.sb = G * H; a.K = G * H; a.w = d.w + (long)(E + A) * G * H; a.ldw = G * H;
+      } else if (gru) {
+        a.a = xg_dgg(d, j - 1, (l + 1) & 1); a.sb = 2 * H; a.K = 2 * H; a.w = d.extra[j - 1].w + (long)H * 2 * H; a.ldw = 2 * H;
       } else {
         a.a = xdgroll(d, j - 1, (l + 1) & 1); a.sb = 4 * H; a.K = 4 * H; a.w = d.extra[j - 1].w + (long)H * 4 * H; a.ldw = 4 * H;
       }
@@ -869,16 +888,28 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
             q.a = M.dpq + (long)l * H; q.sb = (long)L * H; q.K = H; q.w = M.wq; q.ldw = H; q.kind = SRC_PLAIN;
           }
         }
+      } else if (gru) {   // GRU layer above: through its gate kernel and its candidate kernel (both phases of it ran a moment ago)
+        StepSrc& x = tk.src[tk.nsrc++];
+        x.a = xg_dgg(d, j, l & 1); x.sb = 2 * H; x.K = 2 * H; x.w = d.extra[j].w; x.ldw = 2 * H; x.kind = SRC_PLAIN;
+        StepSrc& x2 = tk.src[tk.nsrc++];
+        x2.a = xg_dpc(d, j, l & 1); x2.sb = H; x2.K = H; x2.w = d.extra[j].w2; x2.ldw = H; x2.kind = SRC_PLAIN;
       } else {   // d(output of layer j) = dG_{j+1}(l) . Wx_{j+1}^T  (dG of the layer above, computed a moment ago)
         StepSrc& x = tk.src[tk.nsrc++];
         x.a = xdgroll(d, j, l & 1); x.sb = 4 * H; x.K = 4 * H; x.w = d.extra[j].w; x.ldw = 4 * H; x.kind = SRC_PLAIN;
       }
       tk.B = B; tk.N = H; tk.t = l; tk.T = L; tk.reverse = 0; tk.len = d.steplen;
-      if (gru) {
+      if (gru && j == 0) {
         tk.mode = EP_GRU_BWD_CAND;
         tk.p0 = d.gates; tk.p1 = d.cs;
-        tk.p2 = drop ? d.hs_seq : d.cell_out; tk.s2 = (long)(L + 1) * H; tk.s3 = H;     // slot l = h consumed by step l
+        tk.p2 = drop ? d.hs_seq : layer_out(d, 0); tk.s2 = (long)(L + 1) * H; tk.s3 = H;     // slot l = h consumed by step l
         tk.p4 = g_carry((l + 1) & 1); tk.p5 = g_dpc(l & 1); tk.p3 = d.dgates2; tk.p6 = g_tmp(0); tk.p7 = g_tmp(1);
+      } else if (gru) {
+        const avsr_dec_layer& X = d.extra[j - 1];
+        tk.mode = EP_GRU_BWD_CAND;
+        tk.p0 = X.gates; tk.p1 = X.cs;
+        tk.p2 = drop ? X.hs_seq : X.out; tk.s2 = (long)(L + 1) * H; tk.s3 = H;
+        tk.p4 = xg_carry(d, j - 1, (l + 1) & 1); tk.p5 = xg_dpc(d, j - 1, l & 1); tk.p3 = X.dgates2;
+        tk.p6 = xg_tmp(d, j - 1, 0); tk.p7 = xg_tmp(d, j - 1, 1);
       } else if (j == 0) {
         tk.mode = EP_LSTM_BWD;
         tk.bias = d.c0;
@@ -910,17 +941,26 @@ extern "C" int avsr_attn_rnn_bwd(const avsr_attn_rnn* dp, void* stream) {
         if (!top) { tk.k_in = d.keep_in; tk.r_in = (uint32_t)d.extra[j].cell_id * 4; tk.in_W = H; tk.in_coff = 0; }
       }
       if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
-    }
-    if (gru) {   // second phase: through r*h and the gate pre-activations
-      SL.ntask = 1;
-      StepTask& tk = SL.task[0];
-      tk = StepTask{};
-      StepSrc& a = tk.src[tk.nsrc++];
-      a.a = g_dpc(l & 1); a.sb = H; a.K = H; a.w = d.w2 + (long)(E + A) * H; a.ldw = H; a.kind = SRC_PLAIN;
-      tk.B = B; tk.N = H; tk.mode = EP_GRU_BWD_GATES; tk.t = l; tk.T = L; tk.reverse = 0; tk.len = d.steplen;
-      tk.p0 = d.gates; tk.p2 = drop ? d.hs_seq : d.cell_out; tk.s2 = (long)(L + 1) * H; tk.s3 = H;
-      tk.p6 = g_tmp(0); tk.p7 = g_tmp(1); tk.p5 = g_carry(l & 1); tk.p3 = d.dgates; tk.p1 = g_dgg(l & 1);
-      if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+      if (gru) {   // second phase of THIS layer: through r*h and the gate pre-activations (the layer below reads both results)
+        SL.ntask = 1;
+        StepTask& tg = SL.task[0];
+        tg = StepTask{};
+        StepSrc& ag = tg.src[tg.nsrc++];
+        tg.B = B; tg.N = H; tg.mode = EP_GRU_BWD_GATES; tg.t = l; tg.T = L; tg.reverse = 0; tg.len = d.steplen;
+        tg.s2 = (long)(L + 1) * H; tg.s3 = H;
+        if (j == 0) {
+          ag.a = g_dpc(l & 1); ag.sb = H; ag.K = H; ag.w = d.w2 + (long)(E + A) * H; ag.ldw = H; ag.kind = SRC_PLAIN;
+          tg.p0 = d.gates; tg.p2 = drop ? d.hs_seq : layer_out(d, 0);
+          tg.p6 = g_tmp(0); tg.p7 = g_tmp(1); tg.p5 = g_carry(l & 1); tg.p3 = d.dgates; tg.p1 = g_dgg(l & 1);
+        } else {
+          const avsr_dec_layer& X = d.extra[j - 1];
+          if (!X.w2 || !X.dgates2) return AVSR_ERR_ARG;
+          ag.a = xg_dpc(d, j - 1, l & 1); ag.sb = H; ag.K = H; ag.w = X.w2 + (long)H * H; ag.ldw = H; ag.kind = SRC_PLAIN;
+          tg.p0 = X.gates; tg.p2 = drop ? X.hs_seq : X.out;
+          tg.p6 = xg_tmp(d, j - 1, 0); tg.p7 = xg_tmp(d, j - 1, 1); tg.p5 = xg_carry(d, j - 1, l & 1); tg.p3 = X.dgates; tg.p1 = xg_dgg(d, j - 1, l & 1);
+        }
+        if ((rc = avsr_step_launch_raw(&SL, stream))) return rc;
+      }
     }
   }
   // gradient wrt the initial state

@@ -2,7 +2,7 @@
 #include <string.h>
 #include "avsr_hip.h"
 
-extern "C" int avsr_abi_version(void) { return 1; }
+extern "C" int avsr_abi_version(void) { return 2; }
 
 extern "C" int64_t avsr_sizeof(const char* name) {
   if (!name) return -1;

@@ -338,6 +338,8 @@ class Seq2SeqModel(EncoderMixin, DecoderMixin):
                          dgates=z(B, L, H, 4), dstate=z(12 * B * H), out=(blk["cell_out"] if j == n_extra else SeqBuf(B, L, H, 1, 0, dev)))
                 if cfg.use_dropout:
                     X["hs_seq"], X["xin_seq"] = SeqBuf(B, L, H, 1, 0, dev), SeqBuf(B, L, H, 1, 0, dev)
+                if self.gru:                      # r*h record and d(candidate pre-activation) record of a GRU layer
+                    X["rh"], X["dpc"] = z(B, L, H), z(B, L, H)
                 blk["extra"].append(X)
         for (stream, att_type), pre in zip(mems, att_prefixes):
             T = Ta if stream == "audio" else Tv

@@ -101,6 +101,11 @@ class DecoderMixin:
             Xd.wt, Xd.w, Xd.bias = ops.fptr(self.derived, self.Tr[kn].off), ops.fptr(self.params, self.P[kn].off), ops.fptr(self.params, self.P[bn].off)
             Xd.gates, Xd.cs, Xd.out, Xd.state = ops.fptr(X["gates"]), ops.fptr(X["cs"]), ops.fptr(X["out"].t), ops.fptr(X["state"])
             Xd.cell_id = X["cell_id"]
+            if self.gru:
+                cn = X["prefix"] + "/cand_kernel"
+                Xd.wt2, Xd.w2 = ops.fptr(self.derived, self.Tr[cn].off), ops.fptr(self.params, self.P[cn].off)
+                Xd.bias2 = ops.fptr(self.params, self.P[X["prefix"] + "/cand_bias"].off)
+                Xd.rh_seq, Xd.dgates2 = ops.fptr(X["rh"]), ops.fptr(X["dpc"])
             if self._bdrop(blk) and mode != 1:
                 Xd.hs_seq, Xd.xin_seq = ops.fptr(X["hs_seq"].t), ops.fptr(X["xin_seq"].t)
             if with_bwd:
@@ -214,10 +219,16 @@ class DecoderMixin:
         below = out0
         for X in blk["extra"]:                                    # MultiRNNCell layers above: kernel rows [0:H] input, [H:2H] previous h
             kx, bx = self._kn(X["prefix"])
-            dgx = ops.mat(X["dgates"], 4 * H)
-            self._gemm_tn((X["xin_seq"] if drop else below).mat(0), dgx, self.Gr[kx].mat(4 * H), H, 4 * H, rows)
-            self._gemm_tn((X["hs_seq"] if drop else X["out"]).mat(-1), dgx, self.Gr[kx].mat(4 * H, row0=H), H, 4 * H, rows)
-            ops.colsum(dgx, rows, 4 * H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bx].off)
+            dgx = ops.mat(X["dgates"], G * H)
+            x_in = (X["xin_seq"] if drop else below).mat(0)
+            self._gemm_tn(x_in, dgx, self.Gr[kx].mat(G * H), H, G * H, rows)
+            self._gemm_tn((X["hs_seq"] if drop else X["out"]).mat(-1), dgx, self.Gr[kx].mat(G * H, row0=H), H, G * H, rows)
+            ops.colsum(dgx, rows, G * H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[bx].off)
+            if self.gru:                                          # candidate kernel of the layer: rows [0:H] input, [H:2H] r*h
+                Gcx, dpcx = self.Gr[X["prefix"] + "/cand_kernel"], ops.mat(X["dpc"], H)
+                self._gemm_tn(x_in, dpcx, Gcx.mat(H), H, H, rows)
+                self._gemm_tn(ops.mat(X["rh"], H), dpcx, Gcx.mat(H, row0=H), H, H, rows)
+                ops.colsum(dpcx, rows, H, self.grads, self.scratch, beta=1.0, out_offset=self.Gr[X["prefix"] + "/cand_bias"].off)
             below = X["out"]
         nct = (G * H + 127) // 128
         gt = (((E + 127) // 128) + ((A + 127) // 128 if A else 0) + ((H + 127) // 128)) * nct if not self.gru else None

@@ -238,13 +238,16 @@ typedef struct avsr_attn_mech {
 } avsr_attn_mech;
 
 /* One extra decoder layer above the attention-fed cell: the wrapped cell is a MultiRNNCell (cells.py:96-100,
- * decoder_unimodal.py:101-108 with len(decoder_units_per_layer) > 1).  LSTM only, width = H of the block.  Layer j consumes
+ * decoder_unimodal.py:101-108 with len(decoder_units_per_layer) > 1).  LSTM or GRU (the block's cell kind), width = H of the block.  Layer j consumes
  * the emitted output of layer j-1 of the same step; the TOP layer's output is what the attention mechanisms query and
  * what `cell_out` records, so the top layer's `out` must be the block's cell_out.  State starts at zero
  * (decoder_unimodal.py:151-157).  Buffers: wt [4H][2H] / w [2H][4H] (rows: input part, then recurrent part), bias [H][4],
  * gates [B][L][H][4], cs [B][L][H], out [B][L+1][H] (slot l+1 = step l, slot 0 = 0), state 4*B*H, dgates [B][L][H][4],
  * dstate 12*B*H; dropout only: hs_seq [B][L+1][H] state-dropped h, xin_seq [B][L+1][H] = the input as this layer consumed it
- * (slot l+1 = step l: lower layer's output mask x this layer's input mask). */
+ * (slot l+1 = step l: lower layer's output mask x this layer's input mask).
+ * GRU layers (round 6): wt [2H][2H] / w [2H][2H] = the gate kernel (columns unit-interleaved r, u), bias [H][2], gates [B][L][H][2],
+ * cs = the candidate record [B][L][H], dgates [B][L][H][2]; plus the candidate kernel wt2 [H][2H] / w2 [2H][H] (rows: input part, then
+ * the r*h part), bias2 [H], rh_seq [B][L][H] (r*h as the candidate consumed it) and dgates2 [B][L][H] (d candidate pre-activation). */
 typedef struct avsr_dec_layer {
   const float* wt;
   const float* w;
@@ -258,6 +261,11 @@ typedef struct avsr_dec_layer {
   float* dgates;
   float* dstate;
   int32_t cell_id, pad_;
+  const float* wt2;             /* GRU only (NULL for LSTM layers) */
+  const float* w2;
+  const float* bias2;
+  float* rh_seq;
+  float* dgates2;
 } avsr_dec_layer;
 #define AVSR_MAX_DEC_EXTRA 3
 

@@ -183,8 +183,6 @@ class OracleConfig:
                     raise ValueError("encoder_weight_sharing needs equal layer sizes: layers >= 2 reuse layer 1's kernel")
         if len(set(self.decoder_units)) != 1:
             raise NotImplementedError("multi-layer decoders: equal layer widths only")
-        if len(self.decoder_units) > 1 and self.cell_type != "lstm":
-            raise NotImplementedError("multi-layer decoders: LSTM cells only")
 
 
 # ----------------------------------------------------------------------------------------

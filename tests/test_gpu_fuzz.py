@@ -33,8 +33,7 @@ def _sample(rng):
                   label_smoothing=float(rng.choice([0.0, 0.0, 0.1])), optimiser=rng.choice(["Adam", "Adam", "Nadam", "AdamW", "Momentum"]),
                   lr_decay_steps=int(rng.choice([0, 0, 7])), warmup_steps=int(rng.choice([0, 5, 750])),
                   clip_gradients=bool(rng.random() < 0.8), recurrent_l2=rng.choice([None, 1e-4]))
-        if cell == "gru":                        # GRU: the one option the engine still restricts to LSTM (multi-layer decoder cells) is switched off
-            kw.update(decoder_units=(u,))
+        if cell == "gru":                        # (the bimodal decoder needs LSTM state tuples, in the reference too)
             if arch == "bimodal":
                 kw["architecture"] = arch = "unimodal"
         if kw["video_units"] is None and arch == "unimodal" and rng.random() < 0.2:

@@ -84,6 +84,12 @@ CASES = {
     "dec2_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
                           decoder_units=(32, 32), attention_type=(("scaled_luong",), ("bahdanau",))),
     "dec2_lm": dict(architecture="lm", video_units=None, audio_units=None, decoder_units=(32, 32), warmup_steps=0),
+    # ... with GRU cells (round 6): every layer runs its gate and candidate phases, the layer below reads both gradients of the one above
+    "dec2_gru_unimodal": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32),
+                              decoder_units=(32, 32), cell_type="gru"),
+    "dec3_gru_av_align": dict(architecture="av_align", encoder_type="unidirectional", video_units=(32,), audio_units=(32, 32),
+                              decoder_units=(32, 32, 32), cell_type="gru", attention_type=(("scaled_luong",), ("normed_bahdanau",))),
+    "dec2_gru_lm": dict(architecture="lm", video_units=None, audio_units=None, decoder_units=(32, 32), cell_type="gru", warmup_steps=0),
     # residual_encoder (cells.py:91-92): ResidualWrapper on encoder layers > 0; those stacks run through the per-step launches
     "residual_uni3": dict(architecture="unimodal", encoder_type="unidirectional", video_units=None, audio_units=(32, 32, 32),
                           residual_encoder=True),
@@ -183,7 +189,7 @@ def test_train_step_parity(case):
         assert err < 2e-5, (k, err)     # one Adam step moves each weight by <= lr_t ~ 4e-5 at step 1 of warm-up
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if not c.startswith("lm_") and c != "dec2_lm"])
+@pytest.mark.parametrize("case", [c for c in CASES if not c.startswith("lm_") and c not in ("dec2_lm", "dec2_gru_lm")])
 def test_greedy_decode_parity(case):
     from avsr_tf1_amd.model import Batch, Seq2SeqModel
     O, ocfg, mcfg, W, batch = make(case)
@@ -249,6 +255,9 @@ STOCH = [
     ("dec3_bimodal_mixed", dict(use_dropout=True, decoder_dropout=(0.8, 0.9, 0.7))),
     ("dec2_av_align", dict(use_dropout=True, sampling_probability=0.2)),
     ("dec2_lm", dict(use_dropout=True, sampling_probability=0.1)),
+    ("dec2_gru_unimodal", dict(use_dropout=True, sampling_probability=0.3)),
+    ("dec3_gru_av_align", dict(use_dropout=True, decoder_dropout=(0.8, 0.9, 0.7))),
+    ("dec2_gru_lm", dict(use_dropout=True, sampling_probability=0.1)),
     ("residual_uni3", dict(use_dropout=True)),
     ("highway_uni3", dict(use_dropout=True, sampling_probability=0.2)),
     ("highway_bimodal_uni", dict(use_dropout=True, video_dropout=(0.8, 0.9, 0.7))),
@@ -372,7 +381,7 @@ def test_full_width_train_step(case, over, mode, monkeypatch):
 # ------------------------------------------------------------------------------------------------
 # beam search (the reference's default decoding_algorithm, avsr.py:58): engine vs the oracle restatement
 @pytest.mark.parametrize("case", ["c1_audio_uni_luong", "c2_audio_bi_bahdanau", "c4_bimodal_uni", "c5_av_align", "gru_audio_uni", "dec2_unimodal",
-                                  "dec3_bimodal_mixed"])
+                                  "dec3_bimodal_mixed", "dec2_gru_unimodal", "dec3_gru_av_align"])
 @pytest.mark.parametrize("K", [1, 4])
 def test_beam_search_parity(case, K):
     from avsr_tf1_amd.model import Batch, Seq2SeqModel
@@ -517,7 +526,7 @@ def test_greedy_attention_alignments(case):
         assert al["encoder"] is None
 
 
-@pytest.mark.parametrize("case", ["lm_lstm", "lm_gru", "dec2_lm"])
+@pytest.mark.parametrize("case", ["lm_lstm", "lm_gru", "dec2_lm", "dec2_gru_lm"])
 def test_lm_sequence_likelihoods(case):
     """The language model's evaluate graph: per-utterance average step loss of a teacher-forced pass (lm.py:390-401)."""
     from avsr_tf1_amd.model import Batch, Seq2SeqModel

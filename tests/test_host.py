@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_builds_loads_and_exports_every_header_symbol():
     from avsr_tf1_amd import _lib
     lib = _lib.load()                              # builds with hipcc (cross-compiles gfx950 without a GPU) if needed
-    assert lib.avsr_abi_version() == 1
+    assert lib.avsr_abi_version() == 2
     hdr = open(os.path.join(ROOT, "include", "avsr_hip.h")).read()
     declared = sorted(set(re.findall(r"^\s*(?:int|int64_t)\s+(avsr_\w+)\s*\(", hdr, flags=re.M)))
     assert len(declared) >= 20
@@ -213,8 +213,7 @@ def test_config_validation_errors_follow_the_reference():
         ModelConfig(encoder_weight_sharing=True, audio_units=(128, 256, 256)).validate()
     with pytest.raises(NotImplementedError):
         ModelConfig(decoder_units=(256, 128)).validate()                                   # multi-layer decoders: equal widths only
-    with pytest.raises(NotImplementedError):
-        ModelConfig(decoder_units=(256, 256), cell_type="gru").validate()
+    ModelConfig(decoder_units=(256, 256), cell_type="gru").validate()                      # GRU multi-layer decoders: built in round 6
     with pytest.raises(ValueError, match="no encoders"):
         ModelConfig(architecture="lm").validate()                                          # default audio_units is set
     for ok in (dict(architecture="lm", video_units=None, audio_units=None), dict(decoder_units=(256, 256, 256)),
