@@ -125,7 +125,7 @@ _STRUCTS = {"avsr_dec_layer": DecLayer, "avsr_mat": Mat, "avsr_gemm_desc": GemmD
 
 EXPORTS = ["avsr_abi_version", "avsr_sizeof", "avsr_gemm", "avsr_gemm_batch", "avsr_rnn_fwd", "avsr_rnn_bwd", "avsr_rnn_set_persistent", "avsr_rnn_set_persistent_mode", "avsr_rnn_set_persistent_scratch", "avsr_attn_rnn_fwd",
            "avsr_attn_rnn_fused_ws_floats", "avsr_attn_rnn_fused_eligible", "avsr_attn_rnn_fused_fwd_active", "avsr_attn_rnn_set_fused", "avsr_attn_rnn_set_beam_kernel", "avsr_conv_set_mfma", "avsr_conv_supported", "avsr_conv_fwd", "avsr_conv_bwd_data", "avsr_conv_bwd_weight", "avsr_bn_finalize", "avsr_batchnorm_apply", "avsr_conv_bwd_data_bn", "avsr_conv_bwd_data_bn_supported", "avsr_conv_bwd_weight_bn", "avsr_conv_bwd_weight_bn_supported", "avsr_bn_bwd_finalize", "avsr_bn_bwd_apply", "avsr_bn_bwd_stage1", "avsr_bn_eval_affine", "avsr_bn_partials_f64", "avsr_bn_finalize_f64", "avsr_bn_bwd_finalize_f64",
-           "avsr_attn_rnn_bwd", "avsr_beam_gather_tree", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_slab_defer_begin", "avsr_slab_defer_end", "avsr_colsum",
+           "avsr_attn_rnn_bwd", "avsr_beam_gather_tree", "avsr_beam_search_step", "avsr_attn_alpha_rows", "avsr_bahdanau_dkeys", "avsr_transpose", "avsr_slab_defer_begin", "avsr_slab_defer_end", "avsr_colsum",
            "avsr_batchnorm_fwd", "avsr_batchnorm_fwd_ex", "avsr_batchnorm_bwd", "avsr_batchnorm_xhat", "avsr_im2col", "avsr_col2im",
            "avsr_relu", "avsr_relu_bwd", "avsr_add", "avsr_selu", "avsr_selu_bwd", "avsr_conv3x3_supported", "avsr_conv3x3", "avsr_conv3x3_bwd_data_s2",
            "avsr_conv3x3_bwd_weight", "avsr_embed_labels", "avsr_embed_grad", "avsr_dropout_rows", "avsr_seq_loss",
@@ -193,6 +193,7 @@ def load():
         "avsr_batchnorm_apply": [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp],
         "avsr_attn_rnn_bwd": [C.POINTER(AttnRnn), vp],
         "avsr_beam_gather_tree": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+        "avsr_beam_search_step": [vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "avsr_attn_alpha_rows": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
         "avsr_bahdanau_dkeys": [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "avsr_transpose": [C.POINTER(TransposeJob), i32, vp],

@@ -989,3 +989,23 @@ extern "C" int avsr_beam_gather_tree(const int32_t* step_ids, const int32_t* par
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }
+
+extern "C" int avsr_beam_search_step(const float* logits, int32_t n_utt, int32_t beam_width, int32_t V, int32_t step, int32_t eos_id,
+                                     float length_penalty_weight, const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
+                                     float* logp_out, int32_t* fin_out, int32_t* len_out, int32_t* tok, int32_t* parent_rows,
+                                     int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished, void* stream) {
+  using namespace avsr;
+  if (!logits || !logp_in || !fin_in || !len_in || !logp_out || !fin_out || !len_out || !tok || !parent_rows || !step_ids || !parent_ids ||
+      !n_unfinished || n_utt <= 0 || beam_width <= 0 || V <= 0 || step < 0 || eos_id < 0 || eos_id >= V)
+    return AVSR_ERR_ARG;
+  if ((long)beam_width * V > 1024) return AVSR_ERR_UNSUPPORTED;      // the kernel keeps a thread's candidates in registers (4 x 256)
+  const int K = beam_width;
+  const long B = (long)n_utt * K;
+  // the same launch avsr_attn_rnn_fwd (mode 3) issues after its output layer: logits given (NCT = 0), state ping-pong by the caller
+  hipLaunchKernelGGL(beam_step_kernel<0>, dim3(n_utt), dim3(256), (K * V + 8 * K + 24) * sizeof(float), (hipStream_t)stream,
+                     const_cast<float*>(logits), (long)V, V, K, step, eos_id, length_penalty_weight, logp_in, fin_in, len_in, logp_out, fin_out,
+                     len_out, tok, parent_rows, step_ids + (long)step * B, parent_ids + (long)step * B, n_unfinished + step,
+                     (const float*)nullptr, 0L, 0, (const float*)nullptr, (const float*)nullptr);
+  AVSR_CHECK_LAUNCH();
+  return AVSR_OK;
+}

@@ -431,7 +431,7 @@ def main():
                                      "(tests/test_gpu_dp.py::test_two_ranks_with_the_lip_cnn).  Opt-in global statistics for those batch norms: "
                                      "AVSR_DP_SYNC_CNN_BN=1 (16 small collectives inside the step, eager launches; "
                                      "tests/test_gpu_dp.py::test_two_ranks_with_synchronised_cnn_batch_norms_equal_one_engine)") if world > 1 else None,
-                   "parity": "vs CPU restatement of TF-1.13.1 semantics; TF parity unpinned"},
+                   "parity": "vs CPU restatement of TF-1.13.1 semantics; TF parity unpinned (pinned to reference outputs: the beam-search step, CER/WER)"},
         "final_loss": round(loss, 5),
         "rccl_ranks": (selftest["ranks_seen"] if selftest else None), "collective_selftest": selftest,
         # per rank: wall seconds of the timed loop before the closing barrier, and min / median / max GPU milliseconds per step (event

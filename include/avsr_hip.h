@@ -383,6 +383,20 @@ int avsr_attn_rnn_bwd(const avsr_attn_rnn* d, void* stream);
 int avsr_beam_gather_tree(const int32_t* step_ids, const int32_t* parent_ids, const int32_t* beam_len, int32_t* out,
                           int32_t n_utt, int32_t beam_width, int32_t T, int32_t eos_id, void* stream);
 
+/* One BeamSearchDecoder step on GIVEN logits [n_utt * beam_width][V] -- the selection avsr_attn_rnn_fwd (mode 3) runs after its output
+ * layer, as an entry point of its own (contrib.seq2seq `_beam_search_step` as decoder_unimodal.py:248-271 / decoder_bimodal.py:358-381
+ * reach it through BeamSearchDecoder): log_softmax, finished beams continue with EOS at log-probability 0, scores =
+ * accumulated log-probability / ((5 + len) / 6)^w with an EOS continuation not counted in len, top beam_width of the beam_width * V
+ * continuations per utterance (best first, ties -> lower index).  State in / out: logp, fin, len [n_utt * beam_width] (start:
+ * logp = {0, -inf, ...} per utterance, fin = len = 0); tok / parent_rows [n_utt * beam_width] = the kept symbols and the global rows of their
+ * parents; step_ids / parent_ids [L][n_utt * beam_width] and n_unfinished [L] (zeroed by the caller) are written at index `step`
+ * (a step after one that left n_unfinished == 0 hands the state through unchanged).  beam_width * V <= 1024.
+ * tests/test_gpu_beam.py replays TensorFlow's own trace of the reference's sample search (avsr/visualise/00025.html) through it. */
+int avsr_beam_search_step(const float* logits, int32_t n_utt, int32_t beam_width, int32_t V, int32_t step, int32_t eos_id,
+                          float length_penalty_weight, const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
+                          float* logp_out, int32_t* fin_out, int32_t* len_out, int32_t* tok, int32_t* parent_rows,
+                          int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished, void* stream);
+
 /* Post-loop helpers of the attention backward (see csrc/attention.hip). */
 int avsr_attn_alpha_rows(float* scores, const float* dscores, const int32_t* len, const int32_t* steplen,
                          const float* g, float* rowdot, int32_t B, int32_t L, int32_t T, void* stream);

@@ -10,7 +10,11 @@ function); the *arithmetic* follows the published TF r1.13 algorithms
 `contrib.seq2seq.{LuongAttention,BahdanauAttention,AttentionWrapper,BasicDecoder,
 GreedyEmbeddingHelper,TrainingHelper,dynamic_decode,sequence_loss}`, `layers.batch_normalization`,
 `train.AdamOptimizer`, `clip_by_global_norm`) as summarised in SURVEY.md Appendix A.
-Nothing here has been checked against a running TensorFlow.
+Nothing here has been checked against a running TensorFlow.  Two pieces ARE pinned to outputs of the reference: the beam-search
+bookkeeping (`beam_candidates` / `beam_advance`: finished-beam masking, length penalty and its exponent, which length a step is
+scored with, top-k order, end of the search) replays TensorFlow's own BeamSearchDecoder output for the reference's sample utterance
+avsr/visualise/00025.html (tests/test_beam_trace.py; three printed decimals, 190 nodes), and CER / WER equal the reference's own
+avsr/utils.py functions executed here (tests/golden/reference_cer_wer.json).  Everything else stays unpinned.
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import
 this module.  The product (`avsr_tf1_amd`) never does.
@@ -1152,7 +1156,10 @@ def encoder_outputs(P_np, cfg: OracleConfig, batch: Batch, training: bool, dtype
 # beam search (contrib.seq2seq.BeamSearchDecoder as configured by decoder_unimodal.py:248-271 /
 # decoder_bimodal.py:358-381).  Restated from the published r1.13 algorithm (beam_search_decoder.py:
 # _beam_search_step, _get_scores / _length_penalty, _mask_probs, finalize -> gather_tree); SURVEY A12 rates
-# the recall of its details "low confidence" -- parity unpinned like everything else here.
+# the recall of its details "low confidence".  Since round 6 the per-step bookkeeping is PINNED: the reference tree holds one output
+# of TensorFlow's BeamSearchDecoder (avsr/visualise/00025.html: scores, ids, parents of 19 steps x 10 beams) and tests/test_beam_trace.py
+# replays it through beam_candidates / beam_advance below (and tests/test_gpu_beam.py through the HIP beam step); three other
+# readings of `_beam_search_step` are shown NOT to reproduce it.  gather_tree and the model around the step remain unpinned.
 # ----------------------------------------------------------------------------------------
 def gather_tree(step_ids: np.ndarray, parent_ids: np.ndarray, max_len: np.ndarray, end_token: int) -> np.ndarray:
     """step_ids / parent_ids [T, B, K] -> beams [T, B, K] (gather_tree op semantics)."""
@@ -1178,6 +1185,37 @@ def gather_tree(step_ids: np.ndarray, parent_ids: np.ndarray, max_len: np.ndarra
 
 
 @torch.no_grad()
+def beam_candidates(logp, finished, lengths, step_lp, w: float, eos: int):
+    """The scoring half of one contrib.seq2seq.BeamSearchDecoder step (`_beam_search_step`, called through decoder_unimodal.py:248-271 /
+    decoder_bimodal.py:358-381): accumulated log-probabilities `total` [B, K, V] and length-penalised `scores` [B, K * V] of all
+    continuations.  A finished beam continues with EOS only, at log-probability 0 (`_mask_probs`); an EOS continuation does not count
+    towards the length its score is normalised by, every other token does (`lengths_to_add`); penalty ((5 + len) / 6) ^ w.
+    PINNED against TensorFlow's own output: tests/test_beam_trace.py replays the reference's sample search avsr/visualise/00025.html
+    (190 nodes of `BeamSearchDecoderOutput.scores / predicted_ids / parent_ids`, written by avsr.py:472-487) through this function."""
+    V = step_lp.shape[-1]
+    fin_row = torch.full((V,), torch.finfo(torch.float32).min, dtype=step_lp.dtype)
+    fin_row[eos] = 0.0
+    step_lp = torch.where(finished[:, :, None], fin_row[None, None, :], step_lp)     # _mask_probs
+    total = logp[:, :, None] + step_lp
+    add = torch.ones(V, dtype=torch.int64)
+    add[eos] = 0
+    new_len = lengths[:, :, None] + add[None, None, :] * (~finished)[:, :, None].to(torch.int64)
+    penalty = ((5.0 + new_len.to(step_lp.dtype)) / 6.0) ** w
+    return total, (total / penalty).reshape(total.shape[0], -1)
+
+
+def beam_advance(total, finished, lengths, order, V: int, eos: int):
+    """The state half of the step: the beams selected by `order` [B, K] (indices into K * V) become the new hypotheses.  A beam that
+    was not finished BEFORE this step gets one position longer -- the step that emits EOS included, so a finished beam's score is
+    divided by a penalty one position larger from the step AFTER its EOS on (the one-time shift visible in the reference's trace)."""
+    B = total.shape[0]
+    word, parent = order % V, order // V
+    logp = torch.gather(total.reshape(B, -1), 1, order)
+    prev_fin = torch.gather(finished, 1, parent)
+    lengths = torch.gather(lengths, 1, parent) + (~prev_fin).to(torch.int64)
+    return logp, prev_fin | (word == eos), lengths
+
+
 def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Batch, beam_width: int = 10,
                        length_penalty_weight: Optional[float] = None, max_steps: Optional[int] = None, dtype=torch.float64,
                        return_all: bool = False, return_trace: bool = False, follow=None):
@@ -1205,7 +1243,6 @@ def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Ba
     logp[:, 0] = 0.0
     finished = torch.zeros(B, K, dtype=torch.bool)
     lengths = torch.zeros(B, K, dtype=torch.int64)
-    FMIN = torch.finfo(torch.float32).min
     step_ids, parent_ids = [], []
     min_gap = torch.full((B,), float("inf"), dtype=dtype)
     step_gaps = []
@@ -1213,15 +1250,7 @@ def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Ba
     for t in range(max_steps):
         out, state, att, _ = m.step(_embedding(P, cfg)[tok], state, att, t)
         step_lp = torch.log_softmax(m.logits(out), dim=-1).reshape(B, K, V)
-        fin_row = torch.full((V,), FMIN, dtype=dtype)
-        fin_row[eos] = 0.0
-        step_lp = torch.where(finished[:, :, None], fin_row[None, None, :], step_lp)     # _mask_probs
-        total = logp[:, :, None] + step_lp
-        add = torch.ones(V, dtype=torch.int64)
-        add[eos] = 0
-        new_len = lengths[:, :, None] + add[None, None, :] * (~finished)[:, :, None].to(torch.int64)
-        penalty = ((5.0 + new_len.to(dtype)) / 6.0) ** w
-        scores = (total / penalty).reshape(B, K * V)
+        total, scores = beam_candidates(logp, finished, lengths, step_lp, w, eos)
         # tf.nn.top_k: descending, ties -> lower index first
         order_all = torch.argsort(scores, dim=1, descending=True, stable=True)
         order = order_all[:, :K]
@@ -1248,10 +1277,7 @@ def beam_search_decode(P_np: Dict[str, np.ndarray], cfg: OracleConfig, batch: Ba
             order = eng
         word = order % V
         parent = order // V
-        logp = torch.gather(total.reshape(B, K * V), 1, order)
-        prev_fin = torch.gather(finished, 1, parent)
-        lengths = torch.gather(lengths, 1, parent) + (~prev_fin).to(torch.int64)
-        finished = prev_fin | (word == eos)
+        logp, finished, lengths = beam_advance(total, finished, lengths, order, V, eos)
         rows = (torch.arange(B)[:, None] * K + parent).reshape(-1)
         state = tuple(s[rows] for s in state)
         att = att[rows]

@@ -7,6 +7,10 @@
 2. reference_cer_wer.json -- outputs of the REAL reference functions avsr/utils.py:compute_wer / levenshtein,
    loaded by file path from /root/reference (importing the `avsr` package itself needs TensorFlow).  This is the
    one piece of the reference that can execute here; it pins our CER/WER implementation (avsr_tf1_amd/utils.py).
+3. reference_beam_trace_00025.json -- the search tree of the reference's sample beam-search visualisation
+   avsr/visualise/00025.html, i.e. `BeamSearchDecoderOutput.scores / predicted_ids / parent_ids` of one utterance as TensorFlow's own
+   BeamSearchDecoder produced them (written by avsr/avsr.py:472-487 through avsr/visualise/beam_search.py:create_html), flattened
+   to one list per decode step.  The only TensorFlow OUTPUT in the reference tree; it pins the beam bookkeeping (tests/test_beam_trace.py).
 """
 import importlib.util
 import json
@@ -104,6 +108,39 @@ def reference_cer():
     print("reference CER %.6f WER %.6f" % (cer, wer))
 
 
+def reference_beam_trace():
+    import re
+    path = "/root/reference/avsr/visualise/00025.html"
+    if not os.path.exists(path):
+        print("reference not present; keeping the committed reference_beam_trace_00025.json")
+        return
+    html = open(path).read()
+    tree = json.loads(re.search(r"var treeData = (\{.*\});\s*\n", html).group(1))
+    transcript = re.search(r'const transcript = "(.*)";', html).group(1)
+    levels = {}
+
+    def walk(node, parent):                        # node id = [decode step (1-based), beam]; the root is START
+        lv, beam = node["id"]
+        if lv > 0:
+            levels.setdefault(lv, {})[beam] = (node["name"], node["score"], parent)
+        for ch in node.get("children", []):
+            walk(ch, beam)
+
+    walk(tree, None)
+    K = len(levels[1])
+    steps = []
+    for lv in sorted(levels):
+        assert sorted(levels[lv]) == list(range(K)), "every step of a BeamSearchDecoder output has beam_width entries"
+        steps.append({"names": [levels[lv][i][0] for i in range(K)], "scores": [levels[lv][i][1] for i in range(K)],
+                      "parents": [levels[lv][i][2] for i in range(K)]})
+    with open(os.path.join(HERE, "reference_beam_trace_00025.json"), "w") as f:
+        json.dump({"source": "georgesterpu/avsr-tf1 avsr/visualise/00025.html: BeamSearchDecoderOutput (scores printed with 3 decimals, "
+                             "predicted_ids as characters, parent_ids) of one utterance, one entry per decode step",
+                   "transcript": transcript, "beam_width": K, "steps": steps}, f, indent=0)
+    print("reference beam trace: %d steps x %d beams" % (len(steps), K))
+
+
 if __name__ == "__main__":
     oracle_fixtures()
     reference_cer()
+    reference_beam_trace()

@@ -292,3 +292,65 @@ def test_output_layer_inside_the_beam_step(unit, K):
     finally:
         ops.attn_rnn_set_beam_kernel(1)
     assert np.isfinite(first[0]).all() and np.abs(first[0] - first[1]).max() < 1e-4 * max(1.0, np.abs(first[1]).max())
+
+
+def test_hip_beam_step_replays_the_reference_trace():
+    """TensorFlow's OWN BeamSearchDecoder output -- the reference's sample search avsr/visualise/00025.html (19 steps x 10 beams:
+    scores, predicted ids, parent ids; tests/golden/reference_beam_trace_00025.json) -- replayed through the HIP beam step
+    (avsr_beam_search_step = the selection kernel of avsr_attn_rnn_fwd mode 3): fed with logits whose log-softmax carries the trace's step
+    log-probabilities (tests/beam_trace.py), the kernel must keep TensorFlow's symbols and parents in TensorFlow's order at every step,
+    reach TensorFlow's printed scores to their third decimal, continue finished beams with EOS whatever their logits say, re-score them
+    once with the longer length, and report zero unfinished beams exactly at step 19.  This part of the path is pinned to TF, not to the
+    restatement (the same replay through the oracle: tests/test_beam_trace.py)."""
+    import beam_trace as bt
+    from avsr_tf1_amd import ops
+    tr = bt.load()
+    rec = bt.reconstruct(tr)
+    K, V, eos, T = tr["beam_width"], tr["V"], tr["eos"], len(tr["steps"])
+    U, L = 3, T + 2                                         # three copies of the utterance (one workgroup each), two steps past the end
+    dev = torch.device("cuda:0")
+    i32 = dict(dtype=torch.int32, device=dev)
+    logp = torch.full((2, U * K), -float("inf"), device=dev)
+    logp[0].view(U, K)[:, 0] = 0.0
+    fin, length = torch.zeros(2, U * K, **i32), torch.zeros(2, U * K, **i32)
+    tok, prow = torch.zeros(U * K, **i32), torch.zeros(U * K, **i32)
+    step_ids, parent_ids, nun = torch.zeros(L, U * K, **i32), torch.zeros(L, U * K, **i32), torch.zeros(L, **i32)
+    worst = 0.0
+    for t in range(L):
+        if t < T:
+            lg = np.tile(bt.logits_for_step(tr, rec, t)[None], (U, 1, 1))
+            lg += np.arange(U)[:, None, None] * 1.5        # log_softmax is shift-invariant: the copies must not differ
+        else:
+            lg = np.random.default_rng(t).normal(0.0, 3.0, (U, K, V))
+        logits = torch.as_tensor(lg.reshape(U * K, V), dtype=torch.float32).to(dev)
+        a, b = t & 1, (t + 1) & 1
+        ops.beam_search_step(logits, U, K, V, t, eos, bt.W, logp[a], fin[a], length[a], logp[b], fin[b], length[b], tok, prow,
+                             step_ids, parent_ids, nun)
+        torch.cuda.synchronize()
+        ids_t, par_t = step_ids[t].view(U, K).cpu().numpy(), parent_ids[t].view(U, K).cpu().numpy()
+        if t >= T:                                          # the search is over: state handed through, EOS recorded
+            assert (ids_t == eos).all() and (par_t == np.arange(K)[None]).all() and int(nun[t]) == 0
+            assert torch.equal(logp[b], logp[a]) and torch.equal(length[b], length[a]) and torch.equal(fin[b], fin[a])
+            continue
+        st = tr["steps"][t]
+        for u in range(U):
+            assert ids_t[u].tolist() == st["ids"] and par_t[u].tolist() == st["parents"], (t, u, ids_t[u], st["ids"], par_t[u], st["parents"])
+        assert (tok.view(U, K).cpu().numpy() == ids_t).all()
+        assert (prow.view(U, K).cpu().numpy() == par_t + K * np.arange(U)[:, None]).all()
+        # BeamSearchDecoderOutput.scores = accumulated log-probability / penalty(the length the continuation was scored with)
+        lp_t, len_t, fin_t = (x[b].view(U, K).cpu().numpy() for x in (logp, length, fin))
+        first_eos = np.array([[n == "EOS" and rec[t][k]["step_lp"] is not None for k, n in enumerate(st["names"])]] * U)
+        score = lp_t / bt.penalty(len_t - first_eos.astype(np.int64))
+        worst = max(worst, float(np.abs(score - np.asarray(st["score"])[None]).max()))
+        assert (len_t == np.asarray([c["length"] for c in rec[t]])[None]).all() and (fin_t == np.asarray([c["fin"] for c in rec[t]])[None]).all()
+        assert int(nun[t]) == U * sum(not c["fin"] for c in rec[t])
+    assert worst < 2.5e-3, worst                            # three printed decimals (see tests/test_beam_trace.py)
+    assert int(nun[T - 1]) == 0 and int(nun[T - 2]) > 0     # dynamic_decode stops after step 19, as TensorFlow's output did
+    out = torch.zeros(U, T, K, **i32)
+    final = (T + 2) & 1
+    ops.beam_gather_tree(step_ids, parent_ids, length[final], out, U, K, T, eos)
+    torch.cuda.synchronize()
+    names = {v: k for k, v in tr["vocab"].items()}
+    for u in range(U):
+        best = [names[int(i)] for i in out[u, :, 0].cpu()]
+        assert "".join(n for n in best if n != "EOS") == "and the next day" and best[16:] == ["EOS"] * 3
