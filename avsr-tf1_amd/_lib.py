@@ -193,7 +193,7 @@ def load():
         "avsr_batchnorm_apply": [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp],
         "avsr_attn_rnn_bwd": [C.POINTER(AttnRnn), vp],
         "avsr_beam_gather_tree": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
-        "avsr_beam_search_step": [vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "avsr_beam_search_step": [vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, vp],
         "avsr_attn_alpha_rows": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
         "avsr_bahdanau_dkeys": [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "avsr_transpose": [C.POINTER(TransposeJob), i32, vp],

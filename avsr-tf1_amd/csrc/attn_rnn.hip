@@ -990,10 +990,11 @@ extern "C" int avsr_beam_gather_tree(const int32_t* step_ids, const int32_t* par
   return AVSR_OK;
 }
 
-extern "C" int avsr_beam_search_step(const float* logits, int32_t n_utt, int32_t beam_width, int32_t V, int32_t step, int32_t eos_id,
+extern "C" int avsr_beam_search_step(float* logits, int32_t n_utt, int32_t beam_width, int32_t V, int32_t step, int32_t eos_id,
                                      float length_penalty_weight, const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
                                      float* logp_out, int32_t* fin_out, int32_t* len_out, int32_t* tok, int32_t* parent_rows,
-                                     int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished, void* stream) {
+                                     int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished, const float* x, int64_t x_stride,
+                                     int32_t O, const float* wout_t, const float* bout, void* stream) {
   using namespace avsr;
   if (!logits || !logp_in || !fin_in || !len_in || !logp_out || !fin_out || !len_out || !tok || !parent_rows || !step_ids || !parent_ids ||
       !n_unfinished || n_utt <= 0 || beam_width <= 0 || V <= 0 || step < 0 || eos_id < 0 || eos_id >= V)
@@ -1001,11 +1002,20 @@ extern "C" int avsr_beam_search_step(const float* logits, int32_t n_utt, int32_t
   if ((long)beam_width * V > 1024) return AVSR_ERR_UNSUPPORTED;      // the kernel keeps a thread's candidates in registers (4 x 256)
   const int K = beam_width;
   const long B = (long)n_utt * K;
-  // the same launch avsr_attn_rnn_fwd (mode 3) issues after its output layer: logits given (NCT = 0), state ping-pong by the caller
-  hipLaunchKernelGGL(beam_step_kernel<0>, dim3(n_utt), dim3(256), (K * V + 8 * K + 24) * sizeof(float), (hipStream_t)stream,
-                     const_cast<float*>(logits), (long)V, V, K, step, eos_id, length_penalty_weight, logp_in, fin_in, len_in, logp_out, fin_out,
-                     len_out, tok, parent_rows, step_ids + (long)step * B, parent_ids + (long)step * B, n_unfinished + step,
-                     (const float*)nullptr, 0L, 0, (const float*)nullptr, (const float*)nullptr);
+  hipStream_t s = (hipStream_t)stream;
+  // the same launches avsr_attn_rnn_fwd (mode 3) issues: logits given (NCT = 0), or the output layer inside the step (x != NULL; its conditions below)
+  int nct = 0;
+  if (x) {
+    if (!wout_t || !bout || O <= 0) return AVSR_ERR_ARG;
+    if (K > 16 || V > 64 || O % 256 != 0 || x_stride % 4 != 0 || (((uintptr_t)x | (uintptr_t)wout_t) & 15) != 0) return AVSR_ERR_UNSUPPORTED;
+    nct = V <= 32 ? 2 : 4;
+  }
+#define BS_GO(NCT_)                                                                                                                       \
+  hipLaunchKernelGGL(beam_step_kernel<NCT_>, dim3(n_utt), dim3(256), (K * V + 8 * K + 24 + 1024 * NCT_) * sizeof(float), s, logits, (long)V, V, K,  \
+                     step, eos_id, length_penalty_weight, logp_in, fin_in, len_in, logp_out, fin_out, len_out, tok, parent_rows,                     \
+                     step_ids + (long)step * B, parent_ids + (long)step * B, n_unfinished + step, x, (long)x_stride, O, wout_t, bout)
+  if (nct == 2) BS_GO(2); else if (nct == 4) BS_GO(4); else BS_GO(0);
+#undef BS_GO
   AVSR_CHECK_LAUNCH();
   return AVSR_OK;
 }

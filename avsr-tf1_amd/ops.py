@@ -163,11 +163,12 @@ def attn_rnn_bwd(desc):
 
 
 def beam_search_step(logits, n_utt, beam_width, V, step, eos_id, length_penalty_weight, logp_in, fin_in, len_in, logp_out, fin_out, len_out,
-                     tok, parent_rows, step_ids, parent_ids, n_unfinished):
-    """One BeamSearchDecoder step on given logits (decoder_unimodal.py:248-271); see include/avsr_hip.h."""
+                     tok, parent_rows, step_ids, parent_ids, n_unfinished, x=None, x_stride=0, O=0, wout_t=None, bout=None):
+    """One BeamSearchDecoder step on given logits, or (x given) with the output layer inside (decoder_unimodal.py:248-271); see include/avsr_hip.h."""
     check(_L().avsr_beam_search_step(fptr(logits), n_utt, beam_width, V, step, eos_id, float(length_penalty_weight), fptr(logp_in), fptr(fin_in),
                                      fptr(len_in), fptr(logp_out), fptr(fin_out), fptr(len_out), fptr(tok), fptr(parent_rows), fptr(step_ids),
-                                     fptr(parent_ids), fptr(n_unfinished), _s()), "avsr_beam_search_step")
+                                     fptr(parent_ids), fptr(n_unfinished), fptr(x), x_stride, O, fptr(wout_t), fptr(bout), _s()),
+          "avsr_beam_search_step")
 
 
 def beam_gather_tree(step_ids, parent_ids, beam_len, out, n_utt, beam_width, T, eos_id):

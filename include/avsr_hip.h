@@ -391,11 +391,15 @@ int avsr_beam_gather_tree(const int32_t* step_ids, const int32_t* parent_ids, co
  * logp = {0, -inf, ...} per utterance, fin = len = 0); tok / parent_rows [n_utt * beam_width] = the kept symbols and the global rows of their
  * parents; step_ids / parent_ids [L][n_utt * beam_width] and n_unfinished [L] (zeroed by the caller) are written at index `step`
  * (a step after one that left n_unfinished == 0 hands the state through unchanged).  beam_width * V <= 1024.
+ * x != NULL: the decoder's output layer runs inside the step as it does in the default evaluation path (seq2seq.py:339 Dense(vocab)):
+ * logits [row][v] = x[row * x_stride + .] (O inputs) . wout_t[v][.] + bout[v] are COMPUTED (and written to `logits`) before the selection;
+ * needs beam_width <= 16, V <= 64, O % 256 == 0, 16-byte aligned x / wout_t, else AVSR_ERR_UNSUPPORTED.  x == NULL: `logits` is the input.
  * tests/test_gpu_beam.py replays TensorFlow's own trace of the reference's sample search (avsr/visualise/00025.html) through it. */
-int avsr_beam_search_step(const float* logits, int32_t n_utt, int32_t beam_width, int32_t V, int32_t step, int32_t eos_id,
+int avsr_beam_search_step(float* logits, int32_t n_utt, int32_t beam_width, int32_t V, int32_t step, int32_t eos_id,
                           float length_penalty_weight, const float* logp_in, const int32_t* fin_in, const int32_t* len_in,
                           float* logp_out, int32_t* fin_out, int32_t* len_out, int32_t* tok, int32_t* parent_rows,
-                          int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished, void* stream);
+                          int32_t* step_ids, int32_t* parent_ids, int32_t* n_unfinished, const float* x, int64_t x_stride,
+                          int32_t O, const float* wout_t, const float* bout, void* stream);
 
 /* Post-loop helpers of the attention backward (see csrc/attention.hip). */
 int avsr_attn_alpha_rows(float* scores, const float* dscores, const int32_t* len, const int32_t* steplen,

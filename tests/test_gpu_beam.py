@@ -294,14 +294,17 @@ def test_output_layer_inside_the_beam_step(unit, K):
     assert np.isfinite(first[0]).all() and np.abs(first[0] - first[1]).max() < 1e-4 * max(1.0, np.abs(first[1]).max())
 
 
-def test_hip_beam_step_replays_the_reference_trace():
+@pytest.mark.parametrize("output_layer_inside", [False, True])
+def test_hip_beam_step_replays_the_reference_trace(output_layer_inside):
     """TensorFlow's OWN BeamSearchDecoder output -- the reference's sample search avsr/visualise/00025.html (19 steps x 10 beams:
     scores, predicted ids, parent ids; tests/golden/reference_beam_trace_00025.json) -- replayed through the HIP beam step
     (avsr_beam_search_step = the selection kernel of avsr_attn_rnn_fwd mode 3): fed with logits whose log-softmax carries the trace's step
     log-probabilities (tests/beam_trace.py), the kernel must keep TensorFlow's symbols and parents in TensorFlow's order at every step,
     reach TensorFlow's printed scores to their third decimal, continue finished beams with EOS whatever their logits say, re-score them
     once with the longer length, and report zero unfinished beams exactly at step 19.  This part of the path is pinned to TF, not to the
-    restatement (the same replay through the oracle: tests/test_beam_trace.py)."""
+    restatement (the same replay through the oracle: tests/test_beam_trace.py).
+    output_layer_inside: the form the default evaluation path launches (beam_step_kernel<2>: logits = x . Wout^T + b computed by the step's
+    own MFMA tiles) -- the table goes in as the output kernel's first K input columns, the rows' inputs are unit vectors."""
     import beam_trace as bt
     from avsr_tf1_amd import ops
     tr = bt.load()
@@ -324,8 +327,23 @@ def test_hip_beam_step_replays_the_reference_trace():
             lg = np.random.default_rng(t).normal(0.0, 3.0, (U, K, V))
         logits = torch.as_tensor(lg.reshape(U * K, V), dtype=torch.float32).to(dev)
         a, b = t & 1, (t + 1) & 1
+        extra = {}
+        if output_layer_inside:
+            O = 256
+            bias = np.random.default_rng(100 + t).normal(0.0, 1.0, V)
+            wout_t = np.zeros((V, O), np.float32)
+            wout_t[:, :K] = (lg[0] - bias[None]).T          # copy 0's table; the copies' shifts ride on input column K
+            wout_t[:, K] = 1.0
+            x = np.zeros((U * K, O), np.float32)
+            x[np.arange(U * K), np.arange(U * K) % K] = 1.0
+            x[:, K] = 1.5 * (np.arange(U * K) // K)
+            extra = dict(x=torch.as_tensor(x).to(dev), x_stride=O, O=O, wout_t=torch.as_tensor(wout_t).to(dev),
+                         bout=torch.as_tensor(bias, dtype=torch.float32).to(dev))
+            want, logits = logits, torch.full_like(logits, float("nan"))
         ops.beam_search_step(logits, U, K, V, t, eos, bt.W, logp[a], fin[a], length[a], logp[b], fin[b], length[b], tok, prow,
-                             step_ids, parent_ids, nun)
+                             step_ids, parent_ids, nun, **extra)
+        if output_layer_inside and t < T:
+            assert float((logits - want).abs().max()) < 1e-5          # the step wrote the logits it computed
         torch.cuda.synchronize()
         ids_t, par_t = step_ids[t].view(U, K).cpu().numpy(), parent_ids[t].view(U, K).cpu().numpy()
         if t >= T:                                          # the search is over: state handed through, EOS recorded
