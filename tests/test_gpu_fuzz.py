@@ -123,8 +123,9 @@ def _check(ocfg, rng, seed):
     for k, g in r1["grads"].items():
         scale = max(1e-3, np.abs(g).max())
         # (+3e-6 absolute: some gradients are mathematically zero -- e.g. a batch-norm beta in front of an instance norm -- and then
-        # consist of rounding noise only)
-        assert np.abs(grads[k] - g).max() < 2e-4 * scale + 3e-6, (k, desc)
+        # consist of rounding noise only: where the fp64 oracle itself reports < 1e-9 the engine's fp32 sum of cancelling terms gets
+        # 1e-5; seed 4094 of the 9 000-seed run had 3.3e-6 on such a `video/bn/beta`, profiles/r06_fuzz_final.txt)
+        assert np.abs(grads[k] - g).max() < 2e-4 * scale + (1e-5 if np.abs(g).max() < 1e-9 else 3e-6), (k, desc)
     loss2, _ = model.train_step(db)
     torch.cuda.synchronize()
     assert abs(float(loss2.item()) - r2["loss"]) < 3e-4, desc
