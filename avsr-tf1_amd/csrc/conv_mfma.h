@@ -70,6 +70,7 @@ struct CGArgs {
   // backward computed (d beta = sum dz, d gamma = invstd * (sum dz*x - mean * sum dz)).
   const float* bnb_x; const float* bnb_sc; const float* bnb_sh;
   int N, SH, SW, Cs, CsL;
+  int CsP;                                // floats per staged pixel in LDS (>= CsL: bank spreading, set by cg_launch; conv_gen_kernel only)
   int DH, DW, Cd;
   int OA, OB, S, OS, oh0, ow0;
   // Sub-position columns: a row of the product is a SUPER position (a, b) of nsp destination pixels, its columns are (sp, channel).

@@ -37,8 +37,8 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, q = lane >> 4;
-  const int Cs = A.Cs, CsL = A.CsL, Cd = A.Cd, C4 = CsL >> 2;
-  const int PH = A.SH + 2, PW = A.SW + 2, fstride = PH * PW * CsL;
+  const int Cs = A.Cs, CsL = A.CsL, CsP = A.CsP, Cd = A.Cd, C4 = CsL >> 2;
+  const int PH = A.SH + 2, PW = A.SW + 2, fstride = PH * PW * CsP;
   const int KQ = A.ntap * C4, nch = (KQ + 3) >> 2;
   const int NC = A.nsp * Cd;                          // columns of the product: (sub-position, channel)
   const int NT = (NC + 15) >> 4;                      // 1, 2 or 4 column tiles; a wave keeps ONE
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
     int ro = 0, dt = 4;
     if (m < rows_all) {
       const int f = fdiv(m, A.m_opf), r = m - f * opf, a = fdiv(r, A.m_ob), b = r - a * A.OB;
-      ro = f * fstride + ((a * A.S + 1) * PW + (b * A.SB + 1)) * CsL;
+      ro = f * fstride + ((a * A.S + 1) * PW + (b * A.SB + 1)) * CsP;
       const int ph = a * A.OSA + A.oh0, pw = b * A.OSB + A.ow0;
       // low bits (offsets are multiples of 16 bytes): 1 = no pixel below this one (odd map heights), 2 = none to its right, 4 = no pixel at all
       dt = lin ? (m * NC) << 2
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
       const bool in = c < nch && kq < KQ;
       const int t = in ? kq / C4 : 0, cs4 = in ? kq - t * C4 : 0;
       const i32x4_ tp = *reinterpret_cast<const i32x4_*>(taptab + 4 * t);
-      koff[c] = in ? (tp[0] * PW + tp[1]) * CsL + cs4 * 4 : 0;
+      koff[c] = in ? (tp[0] * PW + tp[1]) * CsP + cs4 * 4 : 0;
       const int wpair = (sp & 2) ? tp[3] : tp[2];
       const int widx = (int)(short)((sp & 1) ? (wpair >> 16) : (wpair & 0xffff));
       // unconditional buffer loads (out-of-range offset = 0): all fragments of the wave are in flight together
@@ -140,6 +140,9 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
   const int st_rpp = st_rq > 0 ? (256 / st_rq > 0 ? 256 / st_rq : 1) : 1;
   const int st_row = (st_rq > 0 && st_rq <= 256) ? (tid < st_rpp * st_rq ? fdiv(tid, A.m_rq) : -1) : -1;
   const int st_p4 = st_row >= 0 ? tid - st_row * st_rq : 0;
+  // LDS offset of the piece inside its row: pixels are CsP floats apart (CsP == Cs: the row is contiguous, the offset is st_p4 * 4)
+  const int st_px = (CH4 && CsP != Cs) ? (st_p4 * 4) / Cs : 0;
+  const int st_lo = (CH4 && CsP != Cs) ? st_px * CsP + (st_p4 * 4 - st_px * Cs) : st_p4 * 4;
   f32x4 bsc = {1.f, 1.f, 1.f, 1.f}, bsh = zero4;
   const bool bn_on = CH4 && A.bn_sc != nullptr;
   if (bn_on && st_row >= 0) { const int cb = (st_p4 * 4) % Cs; bsc = ld4(A.bn_sc + cb); bsh = ld4(A.bn_sh + cb); }
@@ -201,14 +204,14 @@ __global__ __launch_bounds__(256, 2) void conv_gen_kernel(const CGArgs A) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(v[e], bsc[e], bsh[e]), 0.f);
           }
-          st4(lds + f * fstride + ((r + 1) * PW + 1) * CsL + st_p4 * 4, v);
+          st4(lds + f * fstride + ((r + 1) * PW + 1) * CsP + st_lo, v);
         }
       }
     } else {
       const int tot = fcur * per3, tot4 = tot >> 2;
       auto put = [&](int e, float v) {
         const int f = fdiv(e, A.m_per), r = e - f * per3, px = fdiv(r, A.m_rq), c = r - px * Cs, h = fdiv(px, A.m_sw), pw = px - h * A.SW;
-        lds[f * fstride + ((h + 1) * PW + pw + 1) * CsL + c] = v;
+        lds[f * fstride + ((h + 1) * PW + pw + 1) * CsP + c] = v;
       };
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
@@ -724,6 +727,7 @@ __global__ __launch_bounds__(256, 2) void conv_q4_kernel(const CGArgs A) {
 }
 
 int g_conv_mfma = 1;
+static const int g_conv_pad = [] { const char* e = getenv("AVSR_CONV_PAD"); return e ? atoi(e) : 1; }();   // A/B switch of the padded LDS pixel stride
 
 }  // namespace avsr
 
@@ -833,7 +837,17 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
   if ((long)A.N * A.SH * A.SW * A.Cs * 4 >= (1L << 31)) return AVSR_ERR_UNSUPPORTED;   // ... and of the staging loads
   A.m_opf = fmagic(A.OA * A.OB); A.m_ob = fmagic(A.OB);
   const int opf = A.OA * A.OB, mstep = 4 / NT;
-  const size_t frame_b = sizeof(float) * (size_t)(A.SH + 2) * (A.SW + 2) * A.CsL;
+  // Floats per staged pixel.  The tile loop reads its B operand with one 16-byte LDS load per lane: lane (i, q) takes channel quad
+  // (4c + q) of position mt*16 + i, and a ds_read_b128 is served in four groups of 16 lanes, each conflict-free only if its lanes hit 16
+  // different 16-byte slots (MI355X_MICROARCH.md, LDS table).  Positions of a row are SB * CsP floats apart: with CsP = 32 (64) that is
+  // 8 (16) slots -- 4 (8) lanes per slot, and SQ_LDS_BANK_CONFLICT counted 68-84 % of the LDS-active cycles of the 16- / 32- / 64-channel
+  // launches (profiles/r06_c4_lds_pmc_v1.txt).  A stride of 2 (mod 4) slots per position spreads every group over all 16 slots.
+  A.CsP = A.CsL;
+  if (A.Cs % 4 == 0 && g_conv_pad) {
+    for (int p = 0; p < 4; ++p)
+      if ((A.SB * (A.CsL / 4 + p)) % 4 == 2) { A.CsP = A.CsL + 4 * p; break; }
+  }
+  size_t frame_b = sizeof(float) * (size_t)(A.SH + 2) * (A.SW + 2) * A.CsP;
   auto lds_bytes = [&](int F) {
     const size_t rows_pad = (((size_t)F * opf + 15) / 16) * 16;
     return F * frame_b + 4 * rows_pad * 2 + sizeof(CGTap) * CG_MAXTAP;
@@ -856,6 +870,11 @@ static int cg_launch(CGArgs& A, hipStream_t s, int kind, double flops, bool dry 
     return bestF;
   };
   A.F = pick(64 * 1024, 512);                            // two 256-thread workgroups per CU
+  if (!A.F && A.CsP != A.CsL) {                          // the padded frame does not fit (36 x 36 maps): unpadded
+    A.CsP = A.CsL;
+    frame_b = sizeof(float) * (size_t)(A.SH + 2) * (A.SW + 2) * A.CsP;
+    A.F = pick(64 * 1024, 512);
+  }
   if (!A.F) return AVSR_ERR_UNSUPPORTED;
   size_t lds = lds_bytes(A.F);
   if (lds < sizeof(float) * 4 * 4 * 2 * 4) lds = sizeof(float) * 4 * 4 * 2 * 4;      // the statistics reduction's staging area
