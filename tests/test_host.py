@@ -33,6 +33,23 @@ def test_library_builds_loads_and_exports_every_header_symbol():
     assert sorted(_lib.EXPORTS) == declared
 
 
+def test_beam_search_step_rejects_bad_arguments_before_any_launch():
+    """avsr_beam_search_step (include/avsr_hip.h): argument errors are decided on the host -- no GPU needed, nothing is dereferenced."""
+    from avsr_tf1_amd import _lib
+    lib = _lib.load()
+    p = 64                                          # any non-NULL address: the checks below return before a launch could read it
+
+    def call(logits=p, n_utt=2, K=10, V=31, step=0, eos=29, x=None, x_stride=0, O=0, wout=None, bout=None, state=p):
+        return lib.avsr_beam_search_step(logits, n_utt, K, V, step, eos, 0.6, state, p, p, p, p, p, p, p, p, p, p, x, x_stride, O, wout, bout, None)
+
+    assert call(logits=None) == -1 and call(state=None) == -1          # AVSR_ERR_ARG
+    assert call(n_utt=0) == -1 and call(K=0) == -1 and call(step=-1) == -1 and call(eos=31) == -1
+    assert call(K=40, V=31) == -3                                       # AVSR_ERR_UNSUPPORTED: beam_width * V > 1024
+    assert call(x=p, x_stride=256, O=256) == -1                         # output layer inside the step: kernel and bias are required
+    assert call(x=p, x_stride=256, O=200, wout=p, bout=p) == -3         # ... and O % 256 == 0
+    assert call(x=p, x_stride=256, O=256, wout=p, bout=p, K=20, V=31) == -3    # ... beam_width <= 16
+
+
 def test_io_helper_builds_loads_and_exports_every_header_symbol():
     """include/avsr_io.h / libavsr_io.so: the native record indexer + batch filler of the input pipeline (plain C99)."""
     import subprocess
