@@ -131,3 +131,19 @@ def _cand_eos_counted(logp, fin, length, step_lp, w, eos):
     total = logp[:, :, None] + torch.where(fin[:, :, None], fin_row[None, None, :], step_lp)
     new_len = length[:, :, None] + (~fin)[:, :, None].to(torch.int64).expand(-1, -1, V)
     return total, (total / ((5.0 + new_len.to(step_lp.dtype)) / 6.0) ** w).reshape(1, -1)
+
+
+def test_committed_fixture_is_what_the_generator_extracts_from_the_reference(tmp_path, monkeypatch):
+    """Where the reference tree is present (this container, not the GPU box): tests/golden/make_golden.py re-extracts the trace from
+    avsr/visualise/00025.html and the result must be the committed fixture, byte for byte."""
+    import importlib.util
+    import os
+    if not os.path.exists("/root/reference/avsr/visualise/00025.html"):
+        pytest.skip("reference tree not present")
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    monkeypatch.setattr(mg, "HERE", str(tmp_path))
+    mg.reference_beam_trace()
+    assert open(tmp_path / "reference_beam_trace_00025.json").read() == open(os.path.join(here, "golden", "reference_beam_trace_00025.json")).read()
