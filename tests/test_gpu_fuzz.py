@@ -152,11 +152,20 @@ def _check(ocfg, rng, seed):
     assert out.shape == ref.shape, desc
     assert (out[:, :, 0] == ref[:, :, 0]).all(), desc                         # the returned (best) hypothesis
     if (out != ref).any():
-        # lower beams may swap when two hypotheses score within fp32 noise of each other (random weights give near-uniform
-        # distributions): every utterance that differs must have such a near-tie among its kept beams in the fp64 oracle
-        for b in np.unique(np.nonzero(out != ref)[0]):
-            gaps = np.abs(np.diff(np.sort(score[b])))
-            assert gaps.min() < 5e-3, (desc, score[b])
+        # lower beams may follow another branch where two candidates score within fp32 noise of each other (random weights give
+        # near-uniform distributions).  The fp64 oracle then FOLLOWS the engine's search (tests/test_gpu_beam.py::_follow_check): at every
+        # step the engine's j-th selection must score within 2e-5 of the oracle's j-th best from the same state, the selections must be
+        # distinct, and the kept beams must be what the oracle arrives at along that branch.  (Until round 6 this compared the FINAL
+        # scores' gaps with 5e-3 -- a tie at an early step can end far wider than that: seed 187 of the large-size run.)
+        X = m2._beam_ws[2]
+        Bq, T = out.shape[0], out.shape[1]
+        sid = X["sid"].cpu().numpy().reshape(-1, Bq, K)[:T]
+        pid = X["pid"].cpu().numpy().reshape(-1, Bq, K)[:T]
+        ref2, _lp, _ln, tr = O.beam_search_decode(W2, ocfg, batch, beam_width=K, max_steps=7, return_trace=True, follow=(sid, pid))
+        assert not tr["follow_short"] and tr["step_ids"].shape[0] == T, desc
+        assert tr["follow_distinct"].all(), desc
+        assert float(tr["follow_dev"].max()) < 2e-5, (desc, float(tr["follow_dev"].max()), np.argwhere(tr["follow_dev"] >= 2e-5)[:4])
+        assert (out == ref2).all(), desc
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("AVSR_FUZZ_DP_N", "32"))))
